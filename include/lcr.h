@@ -1,0 +1,227 @@
+/*
+ * lcr.h — C ABI of liblcr: the MI355X-native replacement for longcallR's per-region
+ * pileup -> candidate/genotype -> read x SNP fragment matrix -> haplotype phasing hot path.
+ *
+ * The reference (huangnengCSU/longcallR v1.12.0, Rust) has no FFI seam; the seam is cut at the
+ * five call sites of the per-region closure src/thread.rs:77-222.  Each entry point below names
+ * the reference method it replaces.  BAM/FASTA decode, the CLI and the VCF/BAM writers stay on
+ * the host: the ABI takes *decoded, already filtered* reads (filters of src/util.rs:652-668 /
+ * src/fragment.rs:32-49 are the caller's job), grouped by region.
+ *
+ * Batched form: the reference runs one rayon task per region (src/thread.rs:77).  A GPU launch
+ * per region would be launch-bound, so every entry point takes a *batch* of regions; results are
+ * per region and independent of batch composition.
+ *
+ * Conventions: plain pointers + sizes, no C++/torch types.  All functions return 0 (LCR_OK) or a
+ * negative LCR_E_* code and never abort/throw across the boundary (the reference panics instead).
+ * A ctx is single-threaded; create one per host worker thread (mirrors one rayon worker).  Output
+ * pointers handed back by lcr_get_* point into ctx-owned pinned host buffers that stay valid until
+ * the next call of the same getter on that ctx or lcr_ctx_destroy.
+ */
+#ifndef LCR_H
+#define LCR_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCR_OK 0
+#define LCR_E_ARG (-1)     /* bad argument / inconsistent sizes                                   */
+#define LCR_E_CIGAR (-2)   /* unknown CIGAR op (reference: panic, util.rs:944, fragment.rs:192)    */
+#define LCR_E_DEVICE (-3)  /* HIP runtime error (message via lcr_last_error)                       */
+#define LCR_E_STATE (-4)   /* call order violated (e.g. lcr_candidates before lcr_pileup)          */
+#define LCR_E_NOMEM (-5)
+
+#define LCR_PLATFORM_HIFI 0 /* main.rs:35-38 Platform::Hifi */
+#define LCR_PLATFORM_ONT 1  /* Platform::Ont  */
+
+#define LCR_MEM_HOST 0   /* pointers in lcr_reads / lcr_regions are host memory (copied H2D)       */
+#define LCR_MEM_DEVICE 1 /* pointers are device (HBM) memory, used in place                         */
+
+typedef struct lcr_ctx lcr_ctx;
+
+/* ---- inputs ------------------------------------------------------------------------------- */
+
+/* Decoded reads, SoA, borrowed for the duration of the call.  Reads are grouped by region
+ * (lcr_regions.read_begin) and inside a region keep BAM order (sorted by pos).  A read that a
+ * caller fetches for two regions appears twice.
+ * flags: bit0 = reverse strand; bits1-2 = `ts` aux tag: 0 absent, 1 '+', 2 '-' (util.rs:674-680). */
+typedef struct {
+  int32_t mem;              /* LCR_MEM_HOST or LCR_MEM_DEVICE                                       */
+  int32_t n_reads;
+  int64_t n_bases;          /* total bytes in bases/quals                                          */
+  int64_t n_cigar;          /* total u32 in cigar                                                  */
+  const int32_t* pos;       /* 0-based leftmost reference position (record.pos())                  */
+  const int32_t* seq_len;   /* l_seq                                                               */
+  const int32_t* lead_clip; /* cigar.leading_softclips()  (looks past a hard clip)                 */
+  const int32_t* trail_clip;/* cigar.trailing_softclips()                                          */
+  const uint8_t* flags;
+  const uint64_t* seq_off;  /* offset of read's first base in bases/quals                          */
+  const uint64_t* cig_off;  /* offset of read's first op in cigar                                  */
+  const uint32_t* n_cig;
+  const uint8_t* bases;     /* decoded upper-case ASCII, as htslib yields (=ACMGRSVTWYHKDBN)       */
+  const uint8_t* quals;     /* raw phred                                                           */
+  const uint32_t* cigar;    /* BAM encoding len<<4|op, ops MIDNSHP=X (P and B are LCR_E_CIGAR)     */
+} lcr_reads;
+
+/* A batch of regions.  Region i covers 0-based reference columns [start0[i], start0[i]+len[i])
+ * (= util.rs:639-642: vec_size = end-start, first column = start-1) and owns reads
+ * [read_begin[i], read_begin[i+1]).  ref holds the reference bytes of every window back to back
+ * (case preserved, util.rs:646-648); window i starts at ref + col_off[i]. */
+typedef struct {
+  int32_t mem;
+  int32_t n_regions;
+  const int64_t* start0;    /* n_regions                                                            */
+  const int32_t* len;       /* n_regions                                                            */
+  const int64_t* col_off;   /* n_regions+1 prefix sums of len                                       */
+  const int32_t* read_begin;/* n_regions+1                                                          */
+  const uint8_t* ref;       /* col_off[n_regions] bytes                                             */
+} lcr_regions;
+
+/* Thresholds; the code values of main.rs:272-396 are the spec (see lcr_params_preset). */
+typedef struct {
+  int32_t platform;         /* LCR_PLATFORM_*                                                      */
+  uint32_t min_baseq;       /* main.rs min_baseq (10)                                              */
+  uint32_t dist_to_end;     /* distance_to_read_end                                                */
+  uint32_t polya_len;       /* polya_tail_length (<= 16)                                           */
+  uint32_t min_depth, max_depth;
+  uint32_t min_qual;        /* min_variant_qual                                                    */
+  uint32_t dense_win, min_dense_cnt;
+  uint32_t low_cnt_cut;     /* low_allele_cnt_cutoff                                               */
+  uint32_t min_linkers;
+  uint32_t max_enum_snps;
+  uint32_t ld_weight_threshold; /* thread.rs:166 passes 1                                           */
+  int32_t use_strand_bias;
+  float min_af;             /* min_allele_freq                                                     */
+  float min_af_intron;      /* min_allele_freq_include_intron                                      */
+  float low_frac_cut;       /* low_allele_frac_cutoff                                              */
+  float min_phase_score;
+  double read_assign_cutoff;/* min_read_assignment_diff                                            */
+  uint64_t seed;            /* replaces rand::thread_rng() (phase.rs:444,611,674,1198)             */
+} lcr_params;
+
+/* preset: 0 hifi-isoseq, 1 hifi-masseq, 2 ont-cdna, 3 ont-drna (main.rs:272-396). */
+int lcr_params_preset(int preset, lcr_params* out);
+
+/* ---- outputs ------------------------------------------------------------------------------ */
+
+/* Pileup columns (replaces Vec<BaseFreq>, util.rs:100-127) as u32 planes of n_cols each.
+ * plane[k] = planes + k*n_cols.  Reverse-strand counts are cnt - fwd.  The never-read fields of
+ * BaseFreq (forward_cnt, backward_cnt, distance_to_end, i) are not produced. */
+enum {
+  LCR_PL_A = 0, LCR_PL_C, LCR_PL_G, LCR_PL_T, /* a,c,g,t                                            */
+  LCR_PL_N,                                    /* n  (intron)                                        */
+  LCR_PL_D,                                    /* d  (deletion)                                      */
+  LCR_PL_NI,                                   /* ni (insertion after this column)                   */
+  LCR_PL_FWD_A, LCR_PL_FWD_C, LCR_PL_FWD_G, LCR_PL_FWD_T, /* base_strands.x[0]                      */
+  LCR_PL_TS_FWD, LCR_PL_TS_REV,               /* transcript_strands[0], [1]                         */
+  LCR_NPLANES
+};
+typedef struct {
+  int64_t n_cols;
+  const uint32_t* planes;   /* LCR_NPLANES * n_cols                                                 */
+} lcr_columns;
+
+/* One candidate site (replaces CandidateSNP, snp.rs:39-90).  Array sorted by (region, pos). */
+enum {
+  LCR_F_RNA_EDIT = 1, LCR_F_DENSE = 2, LCR_F_HET = 4, LCR_F_FOR_PHASING = 8, LCR_F_HOM = 16,
+  LCR_F_SINGLE = 32, LCR_F_NON_SELECTED = 64, LCR_F_CAND_SOMATIC = 128
+};
+typedef struct {
+  int64_t pos;              /* 0-based                                                              */
+  int32_t region;
+  uint8_t ref_base, allele1, allele2, n_alt; /* ASCII; n_alt = alternate_alleles.num               */
+  uint32_t cnt1, cnt2, depth;
+  float af1, af2;           /* allele_freqs (f32, candidate.rs:97-98)                               */
+  int32_t variant_type;     /* 0 homref 1 het 2 homvar 3 triallelic                                 */
+  int32_t genotype;         /* eta: -1 homvar, 0 het, 1 homref                                      */
+  int32_t haplotype;        /* delta: +1/-1, 0 unassigned                                           */
+  uint32_t flags;           /* LCR_F_*                                                              */
+  uint32_t phase_set;
+  double loglik[3];         /* log10 L: [0] homvar [1] het [2] homref (candidate.rs:267-282)        */
+  double gt_prob[3];        /* genotype_probability                                                 */
+  double qual;              /* variant_quality                                                      */
+  double gq;                /* genotype_quality                                                     */
+  double phase_score;
+} lcr_candidate;
+typedef struct {
+  int32_t n_cand;
+  int32_t n_regions;
+  const lcr_candidate* cand;
+  const int32_t* region_off; /* n_regions+1: candidates of region i are [off[i], off[i+1])          */
+} lcr_candidate_list;
+
+/* Read x SNP fragment matrix (replaces Vec<Fragment>, snp.rs:197-239) in CSR.  Row k = k-th
+ * fragment pushed by get_fragments (fragment.rs:293-307), i.e. every read of the region that starts
+ * at or before the region's last candidate, empty rows included.
+ * val: bits0-4 q (clamped to 30), bit5 = 1 if p=+1 (ref) / 0 if p=-1 (alt), bits6-7 base code ACGT,
+ * col: index into lcr_candidate_list.cand (global, batch-wide). */
+typedef struct {
+  int32_t n_rows;
+  int64_t nnz;
+  int32_t n_regions;
+  const int32_t* row_region_off; /* n_regions+1                                                     */
+  const int64_t* row_ptr;        /* n_rows+1                                                        */
+  const int32_t* row_read;       /* n_rows: index into lcr_reads                                    */
+  const int32_t* col;            /* nnz                                                             */
+  const uint8_t* val;            /* nnz                                                             */
+  const uint8_t* row_for_phasing;/* n_rows                                                          */
+  const uint32_t* row_links;     /* n_rows: num_hete_links                                          */
+} lcr_fragmat;
+
+/* Phasing result: candidates updated in place (haplotype, genotype, variant_type, phase_score,
+ * phase_set, flags) plus per row sigma / assignment / phase set. */
+typedef struct {
+  int32_t n_rows;
+  int32_t n_regions;
+  const int8_t* haplotag;    /* sigma in {-1,0,1}                                                   */
+  const uint8_t* assignment; /* 0 unassigned, 1 hap1, 2 hap2 (snpfrags.rs:548-625)                   */
+  const uint32_t* phase_set; /* read -> PS (snpfrags.rs:628-733), 0 = none                           */
+  const double* objective;   /* n_regions: best cal_overall_probability (phase.rs:257-276)           */
+} lcr_phase_result;
+
+/* ---- entry points ---------------------------------------------------------------------------- */
+
+int lcr_ctx_create(int device, lcr_ctx** out);
+void lcr_ctx_destroy(lcr_ctx*);
+const char* lcr_last_error(const lcr_ctx*);
+/* Launch on an existing hipStream_t (e.g. torch's current stream); NULL = ctx-owned stream. */
+int lcr_ctx_set_stream(lcr_ctx*, void* hip_stream);
+int lcr_ctx_sync(lcr_ctx*);
+
+/* Bind a batch (reads + regions).  LCR_MEM_HOST inputs are copied to HBM here; LCR_MEM_DEVICE
+ * inputs are used in place and must outlive the calls below.  Validates CIGAR ops. */
+int lcr_load_batch(lcr_ctx*, const lcr_reads*, const lcr_regions*);
+
+/* replaces Profile::fill_data_into_freq_vec (util.rs:621-949); thread.rs:93-103 */
+int lcr_pileup(lcr_ctx*, const lcr_params*);
+int lcr_get_columns(lcr_ctx*, lcr_columns* out);
+
+/* replaces SNPFrag::get_candidate_snps (candidate.rs:54-528); thread.rs:118-133 */
+int lcr_candidates(lcr_ctx*, const lcr_params*);
+int lcr_get_candidates(lcr_ctx*, lcr_candidate_list* out);
+
+/* replaces SNPFrag::get_fragments (fragment.rs:10-309); thread.rs:136-143 */
+int lcr_fragments(lcr_ctx*, const lcr_params*);
+int lcr_get_fragmat(lcr_ctx*, lcr_fragmat* out);
+
+/* replaces init_haplotypes/init_assignment + SNPFrag::phase (phase.rs:1087-1296) and the
+ * post-phase sequence thread.rs:162-201 (assign_reads_haplotype, assign_snp_haplotype_genotype,
+ * eval_rna_edit_var_phase, eval_low_frac_var_phase, assign_phase_set). */
+int lcr_phase(lcr_ctx*, const lcr_params*);
+int lcr_get_phase_result(lcr_ctx*, lcr_phase_result* out);
+
+/* Timing: HIP-event time (ms) of the last launch of each kernel on the ctx's stream. */
+enum { LCR_K_SPANS = 0, LCR_K_PILEUP, LCR_K_CAND_FILTER, LCR_K_CAND_HIST, LCR_K_CAND_GT,
+       LCR_K_FRAG_COUNT, LCR_K_FRAG_FILL, LCR_K_PHASE, LCR_NKERNELS };
+int lcr_enable_timing(lcr_ctx*, int on);
+int lcr_kernel_ms(lcr_ctx*, int kernel, float* ms);
+/* Algorithmic byte count of the last lcr_pileup launch (2B + 4C + 32R + 4*LCR_NPLANES*L + L). */
+int lcr_pileup_bytes(lcr_ctx*, int64_t* bytes);
+
+const char* lcr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,196 @@
+"""Minimal host-side BGZF/BAM decoder -> ReadBatch (SoA) for liblcr.
+
+Host plumbing only: the reference uses rust-htslib for this
+(src/util.rs:636-691, src/fragment.rs:19-59).  Implements exactly what the hot path needs:
+record decode, the read filter of util.rs:652-668, `leading/trailing_softclips`, the `de:f` and
+`ts:A` aux tags, htslib's region-overlap rule for `fetch`, and the coverage-island region
+discovery of util.rs:236-332.
+"""
+import struct
+import zlib
+
+import numpy as np
+
+from ._abi import ReadBatch
+
+_NT16 = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
+_CONSUMES_REF = np.array([1, 0, 1, 1, 0, 0, 0, 1, 1], dtype=bool)  # MIDNSHP=X
+
+
+def bgzf_decompress(path):
+    raw = open(path, "rb").read()
+    out, off = [], 0
+    while off < len(raw):
+        if raw[off:off + 4] != b"\x1f\x8b\x08\x04":
+            raise ValueError("not a BGZF block at offset %d" % off)
+        xlen = struct.unpack_from("<H", raw, off + 10)[0]
+        p, bsize = off + 12, None
+        while p < off + 12 + xlen:
+            si1, si2, slen = raw[p], raw[p + 1], struct.unpack_from("<H", raw, p + 2)[0]
+            if si1 == 66 and si2 == 67:
+                bsize = struct.unpack_from("<H", raw, p + 4)[0]
+            p += 4 + slen
+        if bsize is None:
+            raise ValueError("BGZF block without BC field")
+        cdata = raw[off + 12 + xlen: off + bsize + 1 - 8]
+        out.append(zlib.decompress(cdata, -15))
+        off += bsize + 1
+    return b"".join(out)
+
+
+def _aux_scan(buf, p, end):
+    """Return (de or None, ts code 0/1/2) from the aux block buf[p:end]."""
+    de, ts = None, 0
+    while p + 3 <= end:
+        tag, typ = buf[p:p + 2], chr(buf[p + 2])
+        p += 3
+        if typ in "AcC":
+            if tag == b"ts" and typ == "A":
+                ts = 1 if buf[p:p + 1] == b"+" else (2 if buf[p:p + 1] == b"-" else 0)
+            p += 1
+        elif typ in "sS":
+            p += 2
+        elif typ in "iI":
+            p += 4
+        elif typ == "f":
+            if tag == b"de":
+                de = struct.unpack_from("<f", buf, p)[0]
+            p += 4
+        elif typ in "ZH":
+            while buf[p] != 0:
+                p += 1
+            p += 1
+        elif typ == "B":
+            sub, cnt = chr(buf[p]), struct.unpack_from("<I", buf, p + 1)[0]
+            p += 5 + cnt * {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[sub]
+        else:
+            raise ValueError("bad aux type %r" % typ)
+    return de, ts
+
+
+def read_bam(path):
+    """Decode a BAM file. Returns (refs [(name, length)], records list of dicts) in file order."""
+    buf = bgzf_decompress(path)
+    if buf[:4] != b"BAM\x01":
+        raise ValueError("not a BAM file")
+    l_text = struct.unpack_from("<i", buf, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", buf, p)[0]
+    p += 4
+    refs = []
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", buf, p)[0]
+        name = buf[p + 4:p + 4 + l_name - 1].decode()
+        l_ref = struct.unpack_from("<i", buf, p + 4 + l_name)[0]
+        refs.append((name, l_ref))
+        p += 8 + l_name
+    recs = []
+    while p < len(buf):
+        (bs, ref_id, pos, l_rn, mapq, _bin, n_cig, flag, l_seq, _nr, _np, _tl) = struct.unpack_from(
+            "<iiiBBHHHiiii", buf, p)
+        q = p + 36
+        name = buf[q:q + l_rn - 1].decode()
+        q += l_rn
+        cigar = np.frombuffer(buf, dtype="<u4", count=n_cig, offset=q).copy()
+        q += 4 * n_cig
+        packed = np.frombuffer(buf, dtype=np.uint8, count=(l_seq + 1) // 2, offset=q)
+        seq = np.empty(2 * packed.size, dtype=np.uint8)
+        seq[0::2] = _NT16[packed >> 4]
+        seq[1::2] = _NT16[packed & 15]
+        seq = seq[:l_seq].copy()
+        q += (l_seq + 1) // 2
+        qual = np.frombuffer(buf, dtype=np.uint8, count=l_seq, offset=q).copy()
+        q += l_seq
+        de, ts = _aux_scan(buf, q, p + 4 + bs)
+        ops, lens = cigar & 15, cigar >> 4
+        ref_len = int(lens[_CONSUMES_REF[np.minimum(ops, 8)] & (ops <= 8)].sum())
+        lead = trail = 0
+        if n_cig:
+            if ops[0] == 4:
+                lead = int(lens[0])
+            elif ops[0] == 5 and n_cig > 1 and ops[1] == 4:
+                lead = int(lens[1])
+            if ops[-1] == 4:
+                trail = int(lens[-1])
+            elif ops[-1] == 5 and n_cig > 1 and ops[-2] == 4:
+                trail = int(lens[-2])
+        recs.append(dict(name=name, ref_id=ref_id, pos=pos, mapq=mapq, flag=flag, l_seq=l_seq,
+                         cigar=cigar, seq=seq, qual=qual, de=de, ts=ts, ref_len=ref_len,
+                         lead=lead, trail=trail))
+        p += 4 + bs
+    return refs, recs
+
+
+def passes_filter(r, min_mapq=20, min_read_length=500, divergence=0.5):
+    """util.rs:652-668 / fragment.rs:32-49."""
+    if r["mapq"] < min_mapq or r["l_seq"] < min_read_length:
+        return False
+    if r["flag"] & 0x4 or r["flag"] & 0x100 or r["flag"] & 0x800:
+        return False
+    if r["de"] is not None and r["de"] >= divergence:
+        return False
+    return True
+
+
+def discover_regions(recs, ref_id, ref_len):
+    """util.rs:236-332 (no truncation): coverage islands as (start0, len, max_cov).
+
+    The reference emits 1-based [start, end) = [first0+1, last0+2); we return the 0-based column
+    window [first0, last0] = (start0=first0, len=last0-first0+1) and drop single-column islands
+    (`region_end > region_start`).
+    """
+    diff = np.zeros(ref_len + 1, dtype=np.int64)
+    for r in recs:
+        if r["ref_id"] != ref_id:
+            continue
+        s, e = r["pos"], r["pos"] + (r["ref_len"] if r["ref_len"] > 0 else 1)
+        diff[s] += 1
+        diff[min(e, ref_len)] -= 1
+    depth = np.cumsum(diff[:-1])
+    cov = depth > 0
+    edges = np.flatnonzero(np.diff(np.concatenate(([0], cov.view(np.int8), [0]))))
+    out = []
+    for s, e in zip(edges[0::2], edges[1::2]):  # [s, e) covered
+        if e - 1 > s:
+            out.append((int(s), int(e - s), int(depth[s:e].max())))
+    return out
+
+
+def build_batch(recs, regions, ref_windows):
+    """Group filtered records by region with htslib's fetch rule.
+
+    regions: list of (start0, len); the reference calls fetch((chr, start, end)) with the 1-based
+    numbers used as a 0-based half-open interval (util.rs:637), i.e. [start0+1, start0+len+1).
+    ref_windows: list of uint8 arrays, one per region (len bytes each).
+    """
+    cols = {f: [] for f in ["pos", "seq_len", "lead_clip", "trail_clip", "flags", "n_cig"]}
+    bases, quals, cigars, names = [], [], [], []
+    seq_off, cig_off, read_begin = [], [], [0]
+    so = co = 0
+    for (start0, length) in regions:
+        beg, end = start0 + 1, start0 + length + 1
+        for r in recs:
+            rend = r["pos"] + (r["ref_len"] if r["ref_len"] > 0 else 1)
+            if not (r["pos"] < end and rend > beg):
+                continue
+            cols["pos"].append(r["pos"])
+            cols["seq_len"].append(r["l_seq"])
+            cols["lead_clip"].append(r["lead"])
+            cols["trail_clip"].append(r["trail"])
+            cols["flags"].append((1 if r["flag"] & 0x10 else 0) | (r["ts"] << 1))
+            cols["n_cig"].append(len(r["cigar"]))
+            seq_off.append(so)
+            cig_off.append(co)
+            bases.append(r["seq"])
+            quals.append(r["qual"])
+            cigars.append(r["cigar"])
+            names.append(r["name"])
+            so += r["l_seq"]
+            co += len(r["cigar"])
+        read_begin.append(len(seq_off))
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+    return ReadBatch(
+        seq_off=np.array(seq_off, dtype=np.uint64), cig_off=np.array(cig_off, dtype=np.uint64),
+        bases=cat(bases, np.uint8), quals=cat(quals, np.uint8), cigar=cat(cigars, np.uint32),
+        start0=[s for s, _ in regions], len=[l for _, l in regions], read_begin=read_begin,
+        ref=cat(list(ref_windows), np.uint8), names=names, **cols)

@@ -1,0 +1,98 @@
+/*
+ * oracle/orc_common.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * Shared declarations of the CPU oracle: a structure-faithful restatement, written from the Rust
+ * text, of longcallR v1.12.0's per-region hot path (pileup -> candidates -> fragments -> phasing).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * library (longcallr_amd/csrc) never includes, links or calls anything under oracle/.
+ *
+ * PARITY UNPINNED BY THE REFERENCE: the reference has no tests, golden vectors or expected
+ * outputs, cargo/rustc are absent (no oracle/_ref can be built), and demo/chr20.fa is missing.
+ * The oracle is pinned by (i) hand-derived known-answer tests (tests/test_oracle_kat.py) and
+ * (ii) an independent NumPy restatement (oracle/oracle_np.py) written separately from the same
+ * Rust source, compared on demo.bam and synthetic inputs.
+ */
+#ifndef ORC_COMMON_H
+#define ORC_COMMON_H
+#include <stdint.h>
+#include "../include/lcr.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Injected counter-based RNG replacing rand::thread_rng() (phase.rs:444,611,674,1198;
+ * snpfrags.rs:256,349).  u01(seed, ctr) is a pure function so that a GPU can evaluate draw #ctr
+ * without replaying the stream; the oracle simply draws ctr = 0,1,2,... in the reference's call
+ * order. */
+static inline uint64_t orc_mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static inline double orc_u01(uint64_t seed, uint64_t ctr) {
+  uint64_t z = orc_mix64(seed + (ctr + 1) * 0x9E3779B97F4A7C15ULL);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+static inline uint64_t orc_region_seed(uint64_t seed, int64_t start0) {
+  return orc_mix64(seed + 0xD1B54A32D192ED03ULL * (uint64_t)(start0 + 1));
+}
+
+/* decision arithmetic of the optimiser (see DESIGN.md "Decision arithmetic") */
+#define ORC_MODE_F64 0   /* reference-order f64 running sums (faithful to phase.rs)            */
+#define ORC_MODE_EXACT 1 /* exact fixed-point sums, scale 2^40 (the GPU parity contract)      */
+
+typedef struct orc_region orc_region;
+
+orc_region* orc_region_create(const lcr_reads* reads, int32_t read_begin, int32_t read_end,
+                              int64_t start0, int32_t len, const uint8_t* ref_window,
+                              const lcr_params* params);
+void orc_region_destroy(orc_region*);
+
+void orc_pileup(orc_region*);     /* util.rs:621-949                                            */
+void orc_candidates(orc_region*); /* candidate.rs:54-528                                        */
+void orc_fragments(orc_region*);  /* fragment.rs:10-309                                         */
+void orc_phase(orc_region*, int mode); /* thread.rs:162-166 + phase.rs:1087-1296               */
+void orc_post_phase(orc_region*); /* thread.rs:168-201 (snpfrags.rs:191-733)                    */
+
+/* getters (flat copies, same formats as include/lcr.h) */
+void orc_get_planes(const orc_region*, uint32_t* out /* LCR_NPLANES*len */);
+/* per-column clamped quality list of one allele (BaseQual, util.rs:71-77), read order */
+int32_t orc_get_baseq(const orc_region*, int32_t col, int allele /*0..3*/, uint8_t* out, int32_t cap);
+int32_t orc_n_cand(const orc_region*);
+void orc_get_cands(const orc_region*, lcr_candidate* out);
+/* hist-based evaluation of the genotype-likelihood block for candidate i (the order-free form the
+ * GPU uses): loglik[3], gt_prob[3], qual, gq */
+void orc_cand_gt_hist(const orc_region*, int32_t col, double* out8);
+int32_t orc_n_rows(const orc_region*);
+int64_t orc_nnz(const orc_region*);
+void orc_get_fragmat(const orc_region*, int64_t* row_ptr, int32_t* row_read, int32_t* col,
+                     uint8_t* val, uint8_t* row_for_phasing, uint32_t* row_links);
+/* LD blocks (candidate.rs:615-747): returns number of blocks; block b's members are
+ * members[off[b]..off[b+1]) in petgraph DFS order */
+int32_t orc_get_ld_blocks(const orc_region*, int32_t* off, int32_t* members, int32_t cap);
+void orc_get_phase(const orc_region*, int8_t* haplotag, uint8_t* assignment, uint32_t* phase_set,
+                   double* objective);
+/* counters: [0] cross_optimize calls, [1] total iterations, [2] f64-vs-exact decision
+ * disagreements seen (rounding-noise ties), [3] monotonicity assert violations */
+void orc_get_stats(const orc_region*, int64_t* out4);
+/* VCF body text of this region (vcf.rs:27-306 + thread.rs:266-303); returns length */
+int64_t orc_vcf_text(orc_region*, const char* chrom, char* buf, int64_t cap);
+
+/* scalar functions exposed for known-answer tests */
+float orc_strand_odds_ratio(int ref_fw, int ref_rv, int alt_fw, int alt_rv); /* candidate.rs:24-35 */
+double orc_binomial_two_tailed(uint64_t successes, uint64_t trials);       /* candidate.rs:37-47 */
+void orc_two_major_alleles(const uint32_t cnt[4], uint8_t ref_base, uint8_t* a1, uint32_t* c1,
+                           uint8_t* a2, uint32_t* c2);                       /* util.rs:162-176   */
+double orc_aki(int sigma, int delta, int eta, int p, double err);            /* phase.rs:32-49    */
+double orc_cal_sigma_delta_eta_log(int sigma_k, int n, const int* delta, const int* eta,
+                                   const int* ps, const double* probs);      /* phase.rs:77-96    */
+double orc_cal_delta_eta_sigma_log(int delta_i, int eta_i, int n, const int* sigma, const int* ps,
+                                   const double* probs);                     /* phase.rs:128-176  */
+double orc_cal_phase_score_log(int delta_i, int eta_i, int n, const int* sigma, const int* ps,
+                               const double* probs);                         /* phase.rs:238-255  */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
