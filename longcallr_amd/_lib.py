@@ -1,0 +1,55 @@
+"""ctypes loader of liblcr.so (the HIP product library).  Fails loudly: there is no CPU fallback."""
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "liblcr.so")
+
+# every symbol include/lcr.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "lcr_params_preset", "lcr_ctx_create", "lcr_ctx_destroy", "lcr_last_error", "lcr_ctx_set_stream",
+    "lcr_ctx_sync", "lcr_load_batch", "lcr_pileup", "lcr_get_columns", "lcr_candidates",
+    "lcr_get_candidates", "lcr_fragments", "lcr_get_fragmat", "lcr_phase", "lcr_get_phase_result",
+    "lcr_enable_timing", "lcr_kernel_ms", "lcr_pileup_bytes", "lcr_version",
+]
+
+_lib = None
+
+
+class LcrError(RuntimeError):
+    pass
+
+
+def load():
+    """Load liblcr.so.  Raises if the HIP extension has not been built (python -m longcallr_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise LcrError("liblcr.so is missing: build it with `python -m longcallr_amd.build` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    l = C.CDLL(SO_PATH)
+    vp, i32 = C.c_void_p, C.c_int
+    l.lcr_version.restype = C.c_char_p
+    l.lcr_last_error.restype = C.c_char_p
+    l.lcr_last_error.argtypes = [vp]
+    l.lcr_params_preset.argtypes = [i32, C.POINTER(_abi.LcrParams)]
+    l.lcr_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    l.lcr_ctx_destroy.argtypes = [vp]
+    l.lcr_ctx_destroy.restype = None
+    l.lcr_ctx_set_stream.argtypes = [vp, vp]
+    l.lcr_ctx_sync.argtypes = [vp]
+    l.lcr_load_batch.argtypes = [vp, C.POINTER(_abi.LcrReads), C.POINTER(_abi.LcrRegions)]
+    for f in ("lcr_pileup", "lcr_candidates", "lcr_fragments", "lcr_phase"):
+        getattr(l, f).argtypes = [vp, C.POINTER(_abi.LcrParams)]
+    l.lcr_get_columns.argtypes = [vp, C.POINTER(_abi.LcrColumns)]
+    l.lcr_get_candidates.argtypes = [vp, C.POINTER(_abi.LcrCandidateList)]
+    l.lcr_get_fragmat.argtypes = [vp, C.POINTER(_abi.LcrFragmat)]
+    l.lcr_get_phase_result.argtypes = [vp, C.POINTER(_abi.LcrPhaseResult)]
+    l.lcr_enable_timing.argtypes = [vp, i32]
+    l.lcr_kernel_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
+    l.lcr_pileup_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
+    _lib = l
+    return l

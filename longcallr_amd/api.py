@@ -1,0 +1,125 @@
+"""Host-side mirror of the reference's per-region call sequence (src/thread.rs:93-201) on top of
+the C ABI.  Names follow the reference methods they replace:
+
+    Engine.fill_data_into_freq_vec  -> Profile::fill_data_into_freq_vec   (util.rs:621)
+    Engine.get_candidate_snps       -> SNPFrag::get_candidate_snps        (candidate.rs:54)
+    Engine.get_fragments            -> SNPFrag::get_fragments             (fragment.rs:10)
+    Engine.phase                    -> SNPFrag::phase + post-phase steps  (phase.rs:1087, snpfrags.rs)
+
+All compute happens in liblcr.so (HIP); this module only marshals numpy / device pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi, _lib
+from ._lib import LcrError
+
+
+def _view(ptr, dtype, n):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (np.dtype(dtype).itemsize * n)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+class Engine:
+    def __init__(self, device=0, params=None, timing=False):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.lcr_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise LcrError("lcr_ctx_create(device=%d) failed with %d: no usable HIP device; "
+                           "liblcr has no CPU fallback" % (device, rc))
+        self.h = h
+        self.params = params if params is not None else _abi.make_params()
+        self._keep = None
+        if timing:
+            self.lib.lcr_enable_timing(self.h, 1)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lcr_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise LcrError("%s failed (%d): %s" % (what, rc, self.lib.lcr_last_error(self.h).decode()))
+
+    def set_stream(self, hip_stream_ptr):
+        self._chk(self.lib.lcr_ctx_set_stream(self.h, C.c_void_p(hip_stream_ptr)), "lcr_ctx_set_stream")
+
+    def sync(self):
+        self._chk(self.lib.lcr_ctx_sync(self.h), "lcr_ctx_sync")
+
+    # ---- batch binding -------------------------------------------------------------------------
+    def load_batch(self, batch):
+        """batch: _abi.ReadBatch (host numpy) or a (LcrReads, LcrRegions, keepalive) device triple."""
+        if isinstance(batch, _abi.ReadBatch):
+            reads, regions = batch.c_reads(), batch.c_regions()
+            self._keep = (batch, reads, regions)
+        else:
+            reads, regions, keep = batch
+            self._keep = (keep, reads, regions)
+        self._chk(self.lib.lcr_load_batch(self.h, C.byref(reads), C.byref(regions)), "lcr_load_batch")
+        return self
+
+    # ---- stages ----------------------------------------------------------------------------------
+    def fill_data_into_freq_vec(self):
+        self._chk(self.lib.lcr_pileup(self.h, C.byref(self.params)), "lcr_pileup")
+        return self
+
+    def get_candidate_snps(self):
+        self._chk(self.lib.lcr_candidates(self.h, C.byref(self.params)), "lcr_candidates")
+        return self
+
+    def get_fragments(self):
+        self._chk(self.lib.lcr_fragments(self.h, C.byref(self.params)), "lcr_fragments")
+        return self
+
+    def phase(self):
+        self._chk(self.lib.lcr_phase(self.h, C.byref(self.params)), "lcr_phase")
+        return self
+
+    def run_all(self):
+        return self.fill_data_into_freq_vec().get_candidate_snps().get_fragments().phase()
+
+    # ---- results ---------------------------------------------------------------------------------
+    def columns(self):
+        o = _abi.LcrColumns()
+        self._chk(self.lib.lcr_get_columns(self.h, C.byref(o)), "lcr_get_columns")
+        return _view(o.planes, np.uint32, _abi.NPLANES * o.n_cols).reshape(_abi.NPLANES, o.n_cols)
+
+    def candidates(self):
+        o = _abi.LcrCandidateList()
+        self._chk(self.lib.lcr_get_candidates(self.h, C.byref(o)), "lcr_get_candidates")
+        return (_view(o.cand, _abi.CAND_DTYPE, o.n_cand), _view(o.region_off, np.int32, o.n_regions + 1))
+
+    def fragmat(self):
+        o = _abi.LcrFragmat()
+        self._chk(self.lib.lcr_get_fragmat(self.h, C.byref(o)), "lcr_get_fragmat")
+        return dict(
+            row_region_off=_view(o.row_region_off, np.int32, o.n_regions + 1),
+            row_ptr=_view(o.row_ptr, np.int64, o.n_rows + 1), row_read=_view(o.row_read, np.int32, o.n_rows),
+            col=_view(o.col, np.int32, o.nnz), val=_view(o.val, np.uint8, o.nnz),
+            row_for_phasing=_view(o.row_for_phasing, np.uint8, o.n_rows),
+            row_links=_view(o.row_links, np.uint32, o.n_rows))
+
+    def phase_result(self):
+        o = _abi.LcrPhaseResult()
+        self._chk(self.lib.lcr_get_phase_result(self.h, C.byref(o)), "lcr_get_phase_result")
+        return dict(haplotag=_view(o.haplotag, np.int8, o.n_rows), assignment=_view(o.assignment, np.uint8, o.n_rows),
+                    phase_set=_view(o.phase_set, np.uint32, o.n_rows),
+                    objective=_view(o.objective, np.float64, o.n_regions))
+
+    def kernel_ms(self, k):
+        ms = C.c_float()
+        self._chk(self.lib.lcr_kernel_ms(self.h, k, C.byref(ms)), "lcr_kernel_ms")
+        return float(ms.value)
+
+    def pileup_bytes(self):
+        b = C.c_int64()
+        self._chk(self.lib.lcr_pileup_bytes(self.h, C.byref(b)), "lcr_pileup_bytes")
+        return int(b.value)

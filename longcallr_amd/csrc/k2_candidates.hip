@@ -1,0 +1,497 @@
+// k2_candidates.hip — K2: candidate selection + genotype likelihood (gfx950).
+//
+// Replaces SNPFrag::get_candidate_snps (reference src/candidate.rs:54-463).  Every filter of the
+// reference loop is a plain `continue`, so their order does not change the candidate set; we run
+// them in two passes:
+//   pass 1 (k2_filter, one thread per column, count planes only): depth window, two major alleles,
+//           reference validity, low-fraction / low-count, deletion, intron-fraction, strand bias
+//           (candidate.rs:90-234 except :174-194).  > 99 % of columns stop here.
+//   pass 2 (k2_hist + k2_gt, survivors only): per-allele quality histogram hist[4][31] rebuilt from
+//           the reads (same trim / poly-A mask as K1), base-quality filter (candidate.rs:174-194),
+//           log10-likelihoods as an exact integer histogram x 31-entry f64 LUT (order-free form of
+//           candidate.rs:267-282), posterior / QUAL / GQ (candidate.rs:287-335), classification
+//           (candidate.rs:337-460).
+// The sequential dense-cluster sweep (candidate.rs:465-526) is a host epilogue in lcr_api.hip.
+#include "lcr_dev.h"
+
+struct BinomTable { uint32_t reject[31]; };  // bit k of reject[n]: binomial_two_tailed(k, n, .5) < 0.05
+
+// ---- generic 3-phase exclusive scan over int32 ------------------------------------------------
+#define SCAN_ITEMS 4
+#define SCAN_TILE (LCR_BLOCK * SCAN_ITEMS)
+
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ long long wave_incl_scan_ll(long long v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    long long t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(LCR_BLOCK) scan_phase1(const int32_t* __restrict__ in, OutT* __restrict__ out, int32_t n,
+                                                         long long* __restrict__ block_sum) {
+  __shared__ long long wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)tid * SCAN_ITEMS;
+  long long v[SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (base + k < n) ? (long long)in[base + k] : 0; s += v[k]; }
+  long long incl = wave_incl_scan_ll(s, lane);
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  long long add = 0;
+  for (int i = 0; i < w; i++) add += wsum[i];
+  long long run = incl - s + add;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { if (base + k < n) out[base + k] = (OutT)run; run += v[k]; }
+  if (tid == LCR_BLOCK - 1) block_sum[blockIdx.x] = incl + add;
+}
+__global__ void __launch_bounds__(1024) scan_phase2(long long* __restrict__ block_sum, int32_t n_blocks, long long* total) {
+  __shared__ long long wsum[16];
+  __shared__ long long carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n_blocks; base += 1024) {
+    long long v = (base + tid < n_blocks) ? block_sum[base + tid] : 0;
+    long long incl = wave_incl_scan_ll(v, lane);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    long long add = carry_s;
+    for (int i = 0; i < w; i++) add += wsum[i];
+    if (base + tid < n_blocks) block_sum[base + tid] = incl - v + add;
+    __syncthreads();
+    if (tid == 1023) carry_s = incl + add;
+    __syncthreads();
+  }
+  if (tid == 0 && total) *total = carry_s;
+}
+template <typename OutT>
+__global__ void __launch_bounds__(LCR_BLOCK) scan_phase3(OutT* __restrict__ out, int32_t n, const long long* __restrict__ block_sum,
+                                                         int write_last) {
+  const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+  const long long add = block_sum[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) out[base + k] += (OutT)add;
+  (void)write_last;
+}
+__global__ void write_total_i32(const long long* total, int32_t* dst) { *dst = (int32_t)*total; }
+__global__ void write_total_i64(const long long* total, int64_t* dst) { *dst = (int64_t)*total; }
+
+static DevBuf g_scan_tmp;  // block sums + total (per process; ctx is single-threaded per device)
+
+void launch_scan_i32(const int32_t* in, int32_t* out_excl, int32_t n, int32_t* total, hipStream_t s) {
+  const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  (void)g_scan_tmp.reserve(((size_t)nb + 2) * sizeof(long long));
+  long long* bs = g_scan_tmp.as<long long>();
+  if (n > 0) {
+    hipLaunchKernelGGL(scan_phase1<int32_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, in, out_excl, n, bs);
+    hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(1024), 0, s, bs, nb, bs + nb);
+    hipLaunchKernelGGL(scan_phase3<int32_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, out_excl, n, bs, 0);
+    if (total) hipLaunchKernelGGL(write_total_i32, dim3(1), dim3(1), 0, s, bs + nb, total);
+  } else if (total) {
+    (void)hipMemsetAsync(total, 0, sizeof(int32_t), s);
+  }
+}
+// out_excl has n+1 entries; the last receives the total
+void launch_scan_i32_to_i64(const int32_t* in, int64_t* out_excl, int32_t n, hipStream_t s) {
+  const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  (void)g_scan_tmp.reserve(((size_t)nb + 2) * sizeof(long long));
+  long long* bs = g_scan_tmp.as<long long>();
+  if (n > 0) {
+    hipLaunchKernelGGL(scan_phase1<int64_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, in, out_excl, n, bs);
+    hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(1024), 0, s, bs, nb, bs + nb);
+    hipLaunchKernelGGL(scan_phase3<int64_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, out_excl, n, bs, 0);
+    hipLaunchKernelGGL(write_total_i64, dim3(1), dim3(1), 0, s, bs + nb, out_excl + n);
+  } else {
+    (void)hipMemsetAsync(out_excl, 0, sizeof(int64_t), s);
+  }
+}
+
+// ---- pass 1 ------------------------------------------------------------------------------------
+// candidate.rs:24-35 in f32 (no contraction: built with -ffp-contract=off)
+__device__ __forceinline__ float strand_odds_ratio(int ref_fw, int ref_rv, int alt_fw, int alt_rv) {
+  float x00 = (float)(ref_fw + 1), x01 = (float)(ref_rv + 1), x10 = (float)(alt_fw + 1), x11 = (float)(alt_rv + 1);
+  float sym = (x00 * x11) / (x01 * x10) + (x01 * x10) / (x00 * x11);
+  float ref_ratio = fminf(x00, x01) / fmaxf(x00, x01);
+  float alt_ratio = fminf(x10, x11) / fmaxf(x10, x11);
+  return logf(sym) + logf(ref_ratio) - logf(alt_ratio);
+}
+__global__ void k2_sor_threshold(float* out) { *out = strand_odds_ratio(5, 5, 9, 1); }  // candidate.rs:49-51
+
+struct ColEval {
+  bool pass;
+  uint8_t ref_base, allele1, allele2, n_alt;
+  uint32_t cnt1, cnt2, depth;
+  float af1, af2;
+};
+
+// BaseFreq::get_two_major_alleles (util.rs:162-176): stable sort by count, descending
+__device__ __forceinline__ void two_major(const uint32_t cnt[4], uint8_t ref_base, uint8_t* a1, uint32_t* c1, uint8_t* a2,
+                                          uint32_t* c2) {
+  const uint8_t ch[4] = {'A', 'C', 'G', 'T'};
+  int order[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) rank += (cnt[j] > cnt[i]) || (cnt[j] == cnt[i] && j < i);
+    order[rank] = i;
+  }
+  int second = 1;
+  if (ch[order[0]] != ref_base && ch[order[1]] != ref_base) {
+    if (cnt[order[2]] == cnt[order[1]] && ch[order[2]] == ref_base) second = 2;
+    else if (cnt[order[3]] == cnt[order[1]] && ch[order[3]] == ref_base) second = 3;
+  }
+  *a1 = ch[order[0]]; *c1 = cnt[order[0]]; *a2 = ch[order[second]]; *c2 = cnt[order[second]];
+}
+
+__device__ __forceinline__ ColEval eval_column(const uint32_t* __restrict__ planes, int64_t n_cols, int64_t o, uint8_t ref_base,
+                                               const DevParams& prm, const BinomTable& bt) {
+  ColEval ev;
+  ev.pass = false;
+  uint32_t cnt[4], fwd[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { cnt[k] = planes[(int64_t)(LCR_PL_A + k) * n_cols + o]; }
+  const uint32_t total = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+  ev.depth = total;
+  if (total < prm.min_depth || total > prm.max_depth) return ev;  // candidate.rs:90-94
+  // a reference byte other than upper-case ACGT never reaches a candidate (candidate.rs:132,243-265)
+  if (!(ref_base == 'A' || ref_base == 'C' || ref_base == 'G' || ref_base == 'T')) return ev;
+  two_major(cnt, ref_base, &ev.allele1, &ev.cnt1, &ev.allele2, &ev.cnt2);
+  ev.af1 = (float)ev.cnt1 / (float)total;
+  ev.af2 = (float)ev.cnt2 / (float)total;
+  ev.ref_base = ref_base;
+  uint8_t alt0; uint32_t altc0; float altf0;
+  if (ev.allele1 == ref_base) { ev.n_alt = 1; alt0 = ev.allele2; altc0 = ev.cnt2; altf0 = ev.af2; }
+  else if (ev.allele2 == ref_base) { ev.n_alt = 1; alt0 = ev.allele1; altc0 = ev.cnt1; altf0 = ev.af1; }
+  else { ev.n_alt = 2; alt0 = ev.allele1; altc0 = ev.cnt1; altf0 = ev.af1; }
+  if (ev.n_alt == 1) {  // candidate.rs:142-155
+    if (total < 200 && altf0 < prm.low_frac_cut) return ev;
+    if (total >= 200 && altc0 < prm.low_cnt_cut) return ev;
+  }
+  const uint32_t d = planes[(int64_t)LCR_PL_D * n_cols + o], n = planes[(int64_t)LCR_PL_N * n_cols + o];
+  if (d >= altc0) return ev;  // candidate.rs:165
+  if ((float)(ev.cnt1 + ev.cnt2) / (float)(total + d + n) < prm.min_af_intron) return ev;  // candidate.rs:170
+  if (prm.use_strand_bias) {  // candidate.rs:199-234
+#pragma unroll
+    for (int k = 0; k < 4; k++) fwd[k] = planes[(int64_t)(LCR_PL_FWD_A + k) * n_cols + o];
+    const int ri = base_code(ref_base), a0 = base_code(alt0);
+    const int ref_fw = (int)fwd[ri], ref_rv = (int)(cnt[ri] - fwd[ri]);
+    const int alt_fw = (int)fwd[a0], alt_rv = (int)(cnt[a0] - fwd[a0]);
+    float sor = strand_odds_ratio(ref_fw, ref_rv, alt_fw, alt_rv);
+    if (ev.n_alt == 2) {
+      const int a1i = base_code(ev.allele2);
+      sor = fmaxf(sor, strand_odds_ratio(ref_fw, ref_rv, (int)fwd[a1i], (int)(cnt[a1i] - fwd[a1i])));
+    }
+    if (sor > prm.sor_threshold) return ev;
+    if (ev.n_alt == 1) {
+      if (alt_fw + alt_rv <= 30 && ((bt.reject[alt_fw + alt_rv] >> alt_fw) & 1u)) return ev;
+      if (alt_fw * alt_rv == 0) return ev;
+    }
+  }
+  ev.pass = true;
+  return ev;
+}
+
+__global__ void __launch_bounds__(LCR_BLOCK)
+k2_filter(BatchView b, DevParams prm, BinomTable bt, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0,
+          int64_t n_cols, const uint32_t* __restrict__ planes, uint8_t* __restrict__ flags, int32_t* __restrict__ tile_count) {
+  __shared__ int cnt_s;
+  const int g = tile_region[blockIdx.x], tc0 = tile_col0[blockIdx.x];
+  const int tlen = min(LCR_TILE, b.len[g] - tc0);
+  const int64_t gcol0 = b.col_off[g] + tc0;
+  if (threadIdx.x == 0) cnt_s = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int col = threadIdx.x; col < tlen; col += LCR_BLOCK) {
+    ColEval ev = eval_column(planes, n_cols, gcol0 + col, b.ref[gcol0 + col], prm, bt);
+    flags[gcol0 + col] = ev.pass ? 1 : 0;
+    mine += ev.pass ? 1 : 0;
+  }
+  if (mine) atomicAdd(&cnt_s, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = cnt_s;
+}
+
+static BinomTable make_binom_table() {
+  // exact sums of C(n,k)/2^n restate statrs 0.16 Binomial(0.5, n).cdf for the n <= 30 the reference
+  // allows (candidate.rs:37-47, 223-229)
+  BinomTable t;
+  for (int n = 0; n <= 30; n++) {
+    t.reject[n] = 0;
+    double cdf[32];
+    double c = 1.0, s = 0.0, p2 = 1.0;
+    for (int i = 0; i < n; i++) p2 *= 2.0;
+    for (int k = 0; k <= n; k++) { s += c; cdf[k] = (k >= n) ? 1.0 : s / p2; c = c * (double)(n - k) / (double)(k + 1); }
+    for (int k = 0; k <= n; k++) {
+      double p;
+      if (k == 0) p = 2.0 * cdf[0];
+      else if (k == n) p = 2.0 * (1.0 - (n - 1 >= n ? 1.0 : cdf[n - 1]));
+      else { double lo = cdf[k], hi = 1.0 - cdf[k - 1]; p = 2.0 * (lo < hi ? lo : hi); }
+      if (p < 0.05) t.reject[n] |= (1u << k);
+    }
+  }
+  return t;
+}
+
+void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
+                      int32_t n_tiles, int64_t n_cols, const uint32_t* planes, uint8_t* flags, int32_t* tile_count,
+                      hipStream_t s) {
+  static const BinomTable bt = make_binom_table();
+  if (n_tiles == 0) return;
+  hipLaunchKernelGGL(k2_filter, dim3(n_tiles), dim3(LCR_BLOCK), 0, s, b, p, bt, tile_region, tile_col0, n_cols, planes,
+                     flags, tile_count);
+}
+
+// ordered compaction of pass-1 survivors (tile order = (region, column) order)
+__global__ void __launch_bounds__(LCR_BLOCK)
+k2_compact(BatchView b, DevParams prm, BinomTable bt, const int32_t* __restrict__ tile_region,
+           const int32_t* __restrict__ tile_col0, int64_t n_cols, const uint32_t* __restrict__ planes,
+           const uint8_t* __restrict__ flags, const int32_t* __restrict__ tile_off, Survivor* __restrict__ out) {
+  __shared__ int wsum[4];
+  const int g = tile_region[blockIdx.x], tc0 = tile_col0[blockIdx.x];
+  const int tlen = min(LCR_TILE, b.len[g] - tc0);
+  const int64_t gcol0 = b.col_off[g] + tc0;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int base = tile_off[blockIdx.x];
+  // thread t owns columns [4t, 4t+4) so that ranks follow column order
+  int f[4], c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { int col = tid * 4 + k; f[k] = (col < tlen) ? flags[gcol0 + col] : 0; c += f[k]; }
+  int incl = wave_incl_scan_i(c, lane);
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int add = 0;
+  for (int i = 0; i < w; i++) add += wsum[i];
+  int rank = base + incl - c + add;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (!f[k]) continue;
+    const int col = tid * 4 + k;
+    ColEval ev = eval_column(planes, n_cols, gcol0 + col, b.ref[gcol0 + col], prm, bt);
+    Survivor sv;
+    sv.gcol = gcol0 + col; sv.region = g; sv.col = tc0 + col;
+    sv.ref_base = ev.ref_base; sv.allele1 = ev.allele1; sv.allele2 = ev.allele2; sv.n_alt = ev.n_alt;
+    sv.cnt1 = ev.cnt1; sv.cnt2 = ev.cnt2; sv.depth = ev.depth; sv.af1 = ev.af1; sv.af2 = ev.af2;
+    sv.ts_fwd = planes[(int64_t)LCR_PL_TS_FWD * n_cols + gcol0 + col];
+    sv.ts_rev = planes[(int64_t)LCR_PL_TS_REV * n_cols + gcol0 + col];
+    out[rank++] = sv;
+  }
+}
+
+
+// ---- pass 2a: per-survivor quality histograms --------------------------------------------------
+// One thread per read walks its CIGAR once with a cursor over the region's survivors (sorted by
+// column), exactly like the reference's fragment walk, and adds (allele, clamped q) of every *kept*
+// base (same trim / poly-A mask as K1) to hist[s][allele][q].
+__global__ void __launch_bounds__(LCR_BLOCK)
+k2_hist(BatchView b, DevParams prm, const Survivor* __restrict__ sv, const int32_t* __restrict__ sv_region_off,
+        uint32_t* __restrict__ hist) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= b.n_reads) return;
+  const int g = region_of_read(b.read_begin, b.n_regions, r);
+  int s_lo = sv_region_off[g];
+  const int s_hi = sv_region_off[g + 1];
+  if (s_lo >= s_hi) return;
+  const int vec = b.len[g];
+  int p = (int)((int64_t)b.pos[r] - b.start0[g]);  // pos_in_freq_vec
+  {  // first survivor with col >= max(p, 0)
+    int lo = s_lo, hi = s_hi, key = max(p, 0);
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (sv[mid].col >= key) hi = mid; else lo = mid + 1; }
+    s_lo = lo;
+  }
+  if (s_lo >= s_hi) return;
+  const uint32_t ncig = b.n_cig[r];
+  const uint32_t* __restrict__ cg = b.cigar + b.cig_off[r];
+  const uint8_t* __restrict__ seq = b.bases + b.seq_off[r];
+  const uint8_t* __restrict__ qual = b.quals + b.seq_off[r];
+  const int seq_len = b.seq_len[r], lead = b.lead[r], reb = seq_len - b.trail[r];
+  int q = lead > 0 ? lead : 0;
+  int cur = s_lo;
+  int scol = sv[cur].col;
+  for (uint32_t i = 0; i < ncig && cur < s_hi; i++) {
+    const int op = cg[i] & 15, len = (int)(cg[i] >> 4);
+    if (op == 0 || op == 7 || op == 8) {
+      while (cur < s_hi && scol < p + len) {
+        if (scol >= p && scol < vec) {
+          const int c = q + (scol - p);
+          const uint8_t base = seq[c];
+          bool masked = false;
+          if (in_end_zone(c, lead, reb, prm.dist_to_end))
+            masked = prm.ont ? true : polya_masked(seq, seq_len, c, prm.polya_len, sv[cur].ref_base);
+          const int bi = base_code(base);
+          if (!masked && bi >= 0) {
+            const uint8_t bq = qual[c] < 30 ? qual[c] : 30;  // MAX_BASE_QUALITY (util.rs:711-715)
+            atomicAdd(&hist[((int64_t)cur * 4 + bi) * 31 + bq], 1u);
+          }
+        }
+        cur++;
+        if (cur < s_hi) scol = sv[cur].col;
+      }
+      p += len; q += len;
+    } else if (op == 1) {
+      q += len;
+    } else if (op == 2 || op == 3) {
+      while (cur < s_hi && scol < p + len) { cur++; if (cur < s_hi) scol = sv[cur].col; }
+      p += len;
+    }
+  }
+}
+
+void launch_k2_hist(const BatchView& b, const DevParams& p, const Survivor* sv, const int32_t* sv_region_off,
+                    uint32_t* hist, hipStream_t s) {
+  if (b.n_reads == 0) return;
+  hipLaunchKernelGGL(k2_hist, dim3((b.n_reads + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, b, p, sv,
+                     sv_region_off, hist);
+}
+
+// ---- pass 2b: genotype likelihood + classification --------------------------------------------
+struct GtConst {
+  double le[31], l1e[31];   // log10(e_q), log10(1-e_q) with e_q = 0.1^(q/10)  (candidate.rs:268)
+  double log10_2;
+  double log_prior[3];      // log10 of (theta/2, theta, 1-1.5 theta)
+};
+static GtConst g_gtc;
+static bool g_gtc_init = false;
+
+__global__ void __launch_bounds__(LCR_BLOCK)
+k2_gt(DevParams prm, GtConst gc, const Survivor* __restrict__ sv, int32_t n_sv, const uint32_t* __restrict__ hist,
+      const int64_t* __restrict__ start0, lcr_candidate* __restrict__ out, uint8_t* __restrict__ keep) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_sv) return;
+  const Survivor v = sv[s];
+  const uint32_t* h = hist + (int64_t)s * 124;
+  keep[s] = 0;
+  const int ri = base_code(v.ref_base);
+  // base-quality filter (candidate.rs:174-194): first non-reference major allele needs >= 2 quals >= min_baseq
+  {
+    int ai = -1; uint32_t ac = 0;
+    if (v.allele1 != v.ref_base) { ai = base_code(v.allele1); ac = v.cnt1; }
+    else if (v.allele2 != v.ref_base) { ai = base_code(v.allele2); ac = v.cnt2; }
+    if (ai >= 0) {
+      uint32_t pass = 0;
+      for (uint32_t q = prm.min_baseq; q <= 30; q++) pass += h[ai * 31 + q];
+      if (ac > 0 && pass < 2) return;
+    }
+  }
+  // log10 likelihoods: integer histogram x LUT, q ascending; zero counts are skipped so that
+  // q = 0 (log10(1-1) = -inf) never produces 0 * -inf
+  double l0 = 0.0, l2 = 0.0;
+  uint32_t num_reads = 0;
+  for (int q = 0; q <= 30; q++) {
+    const uint32_t hm = h[ri * 31 + q];
+    uint32_t hx = 0;
+#pragma unroll
+    for (int bq = 0; bq < 4; bq++) if (bq != ri) hx += h[bq * 31 + q];
+    num_reads += hm + hx;
+    if (hm) { l0 += (double)hm * gc.le[q]; l2 += (double)hm * gc.l1e[q]; }
+    if (hx) { l0 += (double)hx * gc.l1e[q]; l2 += (double)hx * gc.le[q]; }
+  }
+  double loglik[3] = {l0, 0.0, l2};
+  loglik[1] -= (double)num_reads * gc.log10_2;
+  // posterior / QUAL / GQ (candidate.rs:287-335)
+  double logprob[3] = {loglik[0] + gc.log_prior[0], loglik[1] + gc.log_prior[1], loglik[2] + gc.log_prior[2]};
+  const double mlp = fmax(fmax(logprob[0], logprob[1]), logprob[2]);
+  double vp[3] = {pow(10.0, logprob[0] - mlp), pow(10.0, logprob[1] - mlp), pow(10.0, logprob[2] - mlp)};
+  const double svp = vp[0] + vp[1] + vp[2];
+  vp[2] = vp[2] / svp;
+  const double variant_quality = -10.0 * log10(fmax(10e-301, vp[2]));
+  const double ml = fmax(fmax(loglik[0], loglik[1]), loglik[2]);
+  double gl[3] = {pow(10.0, loglik[0] - ml), pow(10.0, loglik[1] - ml), pow(10.0, loglik[2] - ml)};
+  const double sgl = gl[0] + gl[1] + gl[2];
+  double gp[3] = {gl[0] / sgl, gl[1] / sgl, gl[2] / sgl};
+  double ph[3] = {-10.0 * log10(gp[0]), -10.0 * log10(gp[1]), -10.0 * log10(gp[2])};
+  for (int i = 1; i < 3; i++) {  // insertion sort, is_less = (a < b)  (Rust sort_by on 3 elements)
+    double x = ph[i];
+    int j = i;
+    while (j > 0 && x < ph[j - 1]) { ph[j] = ph[j - 1]; j--; }
+    ph[j] = x;
+  }
+  const double genotype_quality = ph[1] - ph[0];
+
+  lcr_candidate c;
+  c.pos = start0[v.region] + v.col;  // 0-based reference position (candidate.rs:74,339)
+  c.region = v.region;
+  c.ref_base = v.ref_base; c.allele1 = v.allele1; c.allele2 = v.allele2; c.n_alt = v.n_alt;
+  c.cnt1 = v.cnt1; c.cnt2 = v.cnt2; c.depth = v.depth; c.af1 = v.af1; c.af2 = v.af2;
+  c.haplotype = 0; c.phase_set = 0; c.phase_score = 0.0;
+  for (int k = 0; k < 3; k++) { c.loglik[k] = loglik[k]; c.gt_prob[k] = gp[k]; }
+  c.qual = variant_quality; c.gq = genotype_quality;
+  if (gp[0] > gp[1] && gp[0] > gp[2]) { c.variant_type = 2; c.genotype = -1; }
+  else if (gp[1] > gp[0] && gp[1] > gp[2]) { c.variant_type = 1; c.genotype = 0; }
+  else { c.variant_type = 0; c.genotype = 1; }
+  c.flags = 0;
+  if (variant_quality < (double)prm.min_qual) return;  // candidate.rs:374
+  // classification (candidate.rs:379-460)
+  uint8_t ref_allele_base, alt0; float altf0, altf1 = 0.0f;
+  if (v.allele1 == v.ref_base) { ref_allele_base = v.allele1; alt0 = v.allele2; altf0 = v.af2; }
+  else if (v.allele2 == v.ref_base) { ref_allele_base = v.allele2; alt0 = v.allele1; altf0 = v.af1; }
+  else { ref_allele_base = v.ref_base; alt0 = v.allele1; altf0 = v.af1; altf1 = v.af2; }
+  const int fwd_t = (int)v.ts_fwd, rev_t = (int)v.ts_rev;
+  bool kept = false;
+  if (ref_allele_base == 'A' && alt0 == 'G' && (fwd_t > rev_t * 2 || (fwd_t == 0 && rev_t == 0)) && c.variant_type != 2) {
+    c.flags = LCR_F_RNA_EDIT; kept = true;
+  } else if (ref_allele_base == 'T' && alt0 == 'C' && (rev_t > fwd_t * 2 || (fwd_t == 0 && rev_t == 0)) && c.variant_type != 2) {
+    c.flags = LCR_F_RNA_EDIT; kept = true;
+  } else if (v.n_alt == 1 && altf0 < prm.min_af) {
+    c.flags = LCR_F_CAND_SOMATIC; kept = true;
+  } else if (c.variant_type == 2) {
+    if (v.n_alt == 2 && altf0 >= prm.min_af && altf1 >= prm.min_af) { c.variant_type = 3; c.genotype = -1; }
+    c.flags = LCR_F_HOM | LCR_F_FOR_PHASING; kept = true;
+  } else if (c.variant_type == 1) {
+    if (v.n_alt == 2) { c.variant_type = 3; c.genotype = -1; c.flags = LCR_F_HOM | LCR_F_FOR_PHASING; }
+    else c.flags = LCR_F_HET | LCR_F_FOR_PHASING;
+    kept = true;
+  }
+  if (!kept) return;  // variant_type 0 (candidate.rs:457-460)
+  out[s] = c;
+  keep[s] = 1;
+}
+
+void launch_k2_gt(const DevParams& p, const Survivor* sv, int32_t n_sv, const uint32_t* hist, const int64_t* start0,
+                  lcr_candidate* out, uint8_t* keep, hipStream_t s) {
+  if (!g_gtc_init) {
+    for (int q = 0; q <= 30; q++) {
+      double e = pow(0.1, (double)q / 10.0);
+      g_gtc.le[q] = log10(e);
+      g_gtc.l1e[q] = log10(1.0 - e);
+    }
+    g_gtc.log10_2 = log10(2.0);
+    const double theta = 0.001;
+    g_gtc.log_prior[0] = log10(theta / 2.0); g_gtc.log_prior[1] = log10(theta); g_gtc.log_prior[2] = log10(1.0 - 1.5 * theta);
+    g_gtc_init = true;
+  }
+  if (n_sv == 0) return;
+  hipLaunchKernelGGL(k2_gt, dim3((n_sv + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, p, g_gtc, sv, n_sv, hist, start0, out, keep);
+}
+
+void launch_k2_compact(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
+                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const uint8_t* flags,
+                       const int32_t* tile_off, Survivor* out, hipStream_t s) {
+  static const BinomTable bt = make_binom_table();
+  if (n_tiles == 0) return;
+  hipLaunchKernelGGL(k2_compact, dim3(n_tiles), dim3(LCR_BLOCK), 0, s, b, p, bt, tile_region, tile_col0, n_cols,
+                     planes, flags, tile_off, out);
+}
+
+float lcr_device_sor_threshold(hipStream_t s) {
+  float* d = nullptr;
+  float h = 0.f;
+  if (hipMalloc(&d, sizeof(float)) != hipSuccess) return 0.f;
+  hipLaunchKernelGGL(k2_sor_threshold, dim3(1), dim3(1), 0, s, d);
+  (void)hipMemcpyAsync(&h, d, sizeof(float), hipMemcpyDeviceToHost, s);
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(d);
+  return h;
+}

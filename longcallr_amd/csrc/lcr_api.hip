@@ -1,0 +1,489 @@
+// lcr_api.hip — C ABI (include/lcr.h) over the HIP kernels: context, batch binding, stage drivers
+// and the small sequential host epilogues (dense-cluster sweep, candidate.rs:465-526).
+// There is NO CPU fallback: every stage launches HIP kernels and fails with LCR_E_DEVICE otherwise.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "lcr_dev.h"
+#include "lcr_phase_host.h"
+
+struct lcr_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // bound batch
+  bool loaded = false;
+  BatchView bv{};
+  int64_t n_cols = 0, n_bases = 0, n_cigar = 0;
+  int32_t n_tiles = 0;
+  std::vector<int64_t> h_start0, h_col_off;
+  std::vector<int32_t> h_len, h_read_begin, h_region_first_tile;
+  DevBuf in_[16];  // device copies of host inputs (LCR_MEM_HOST)
+  DevBuf ref_end, max_span, errflag, tile_region, tile_col0;
+
+  // K1
+  bool have_planes = false;
+  DevBuf planes;
+  DevParams dp{};
+  HostBuf h_planes;
+
+  // K2
+  bool have_cand = false;
+  DevBuf flags, tile_count, tile_off, total, survivors, sv_region_off, hist, cand_tmp, keep;
+  std::vector<lcr_candidate> h_cand;
+  std::vector<int32_t> h_cand_off;
+  DevBuf d_cand, d_cand_off;
+
+  // K3
+  bool have_frag = false;
+  uint32_t min_linkers = 1;
+  int32_t n_rows = 0;
+  int64_t nnz = 0;
+  std::vector<int32_t> h_row_region_off;
+  DevBuf region_rows, row_region_off, row_cnt, row_links, row_ptr, col, val;
+  HostBuf h_row_ptr, h_row_read, h_col, h_val, h_row_fp, h_row_links;
+
+  // K4 + post-phase
+  bool have_phase = false;
+  PhaseHost phase;
+
+  // timing
+  bool timing = false;
+  hipEvent_t ev[LCR_NKERNELS][2] = {};
+  bool ev_valid[LCR_NKERNELS] = {};
+  int64_t pileup_bytes = 0;
+};
+
+namespace {
+
+struct Timer {  // records HIP events on the ctx stream around one kernel
+  lcr_ctx* c; int k;
+  Timer(lcr_ctx* c_, int k_) : c(c_), k(k_) { if (c->timing) { (void)hipEventRecord(c->ev[k][0], c->stream); } }
+  ~Timer() { if (c->timing) { (void)hipEventRecord(c->ev[k][1], c->stream); c->ev_valid[k] = true; } }
+};
+
+DevParams to_dev(const lcr_params* p, float sor_thr) {
+  DevParams d{};
+  d.ont = p->platform == LCR_PLATFORM_ONT;
+  d.dist_to_end = (int32_t)p->dist_to_end;
+  d.polya_len = (int32_t)p->polya_len;
+  d.min_baseq = p->min_baseq; d.min_depth = p->min_depth; d.max_depth = p->max_depth; d.min_qual = p->min_qual;
+  d.low_cnt_cut = p->low_cnt_cut; d.min_linkers = p->min_linkers; d.use_strand_bias = p->use_strand_bias;
+  d.min_af = p->min_af; d.min_af_intron = p->min_af_intron; d.low_frac_cut = p->low_frac_cut;
+  d.sor_threshold = sor_thr;
+  return d;
+}
+
+template <class T>
+int upload(lcr_ctx* c, DevBuf& buf, const T* src, size_t n, const T** dst, int mem) {
+  if (mem == LCR_MEM_DEVICE) { *dst = src; return LCR_OK; }
+  HIPCHK(c, buf.reserve(std::max<size_t>(n, 1) * sizeof(T)));
+  if (n) HIPCHK(c, hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  *dst = buf.as<T>();
+  return LCR_OK;
+}
+
+// candidate.rs:465-526 on one region's candidates [lo, hi) (position order)
+void dense_filter(std::vector<lcr_candidate>& cand, int lo, int hi, uint32_t dense_win, uint32_t min_dense_cnt) {
+  std::vector<int> concat;
+  for (int i = lo; i < hi; i++)
+    if (cand[i].flags & (LCR_F_HOM | LCR_F_HET)) concat.push_back(i);  // homo_snps U het_snps, sorted by index
+  const size_t n = concat.size();
+  auto mark = [&](size_t i, size_t j) {
+    for (size_t tk = i; tk < j; tk++) { cand[concat[tk]].flags |= LCR_F_DENSE; cand[concat[tk]].flags &= ~(uint32_t)LCR_F_FOR_PHASING; }
+  };
+  for (size_t i = 0; i < n; i++) {
+    const int64_t start_pos = cand[concat[i]].pos;
+    for (size_t j = i; j < n; j++) {
+      const int64_t diff = cand[concat[j]].pos - start_pos;
+      if (diff > (int64_t)dense_win) { if ((uint32_t)(j - i) >= min_dense_cnt) mark(i, j); break; }
+      if (j == n - 1 && (uint32_t)(j - i + 1) >= min_dense_cnt) mark(i, j);
+    }
+  }
+  for (size_t i = 0; i < n; i++) {
+    const int64_t start_pos = cand[concat[i]].pos;
+    for (size_t j = i; j < n; j++) {
+      const int64_t diff = cand[concat[j]].pos - start_pos;
+      if (diff >= 5) { if ((uint32_t)(j - i) >= 3) mark(i, j); break; }
+      if (j == n - 1 && (uint32_t)(j - i + 1) >= 3) mark(i, j);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lcr_version(void) { return "liblcr 0.1 (gfx950)"; }
+
+int lcr_params_preset(int preset, lcr_params* o) {
+  if (!o || preset < 0 || preset > 3) return LCR_E_ARG;
+  memset(o, 0, sizeof *o);
+  const bool ont = preset >= 2;  // main.rs:272-396
+  o->platform = ont ? LCR_PLATFORM_ONT : LCR_PLATFORM_HIFI;
+  o->min_baseq = 10; o->dist_to_end = ont ? 20 : 40; o->polya_len = 5;
+  o->min_depth = ont ? 10 : 6; o->max_depth = 50000; o->min_qual = 2;
+  o->dense_win = 100; o->min_dense_cnt = 5; o->low_cnt_cut = 10; o->min_linkers = 1; o->max_enum_snps = 10;
+  o->ld_weight_threshold = 1;
+  o->use_strand_bias = (preset == 0 || preset == 2) ? 1 : 0;
+  o->min_af = ont ? 0.20f : 0.15f; o->min_af_intron = 0.0f; o->low_frac_cut = 0.05f;
+  o->min_phase_score = ont ? 13.0f : 11.0f;
+  o->read_assign_cutoff = 0.0; o->seed = 2025;
+  return LCR_OK;
+}
+
+int lcr_ctx_create(int device, lcr_ctx** out) {
+  if (!out) return LCR_E_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return LCR_E_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return LCR_E_DEVICE;
+  lcr_ctx* c = new lcr_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LCR_E_DEVICE; }
+  c->own_stream = true;
+  for (int k = 0; k < LCR_NKERNELS; k++)
+    for (int j = 0; j < 2; j++)
+      if (hipEventCreate(&c->ev[k][j]) != hipSuccess) { delete c; return LCR_E_DEVICE; }
+  *out = c;
+  return LCR_OK;
+}
+
+void lcr_ctx_destroy(lcr_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& b : c->in_) b.release();
+  DevBuf* bufs[] = {&c->ref_end, &c->max_span, &c->errflag, &c->tile_region, &c->tile_col0, &c->planes, &c->flags,
+                    &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
+                    &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
+                    &c->row_links, &c->row_ptr, &c->col, &c->val};
+  for (auto* b : bufs) b->release();
+  HostBuf* hb[] = {&c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
+  for (auto* b : hb) b->release();
+  c->phase.release();
+  for (int k = 0; k < LCR_NKERNELS; k++) for (int j = 0; j < 2; j++) if (c->ev[k][j]) (void)hipEventDestroy(c->ev[k][j]);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* lcr_last_error(const lcr_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int lcr_ctx_set_stream(lcr_ctx* c, void* s) {
+  if (!c) return LCR_E_ARG;
+  (void)hipSetDevice(c->device);
+  if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
+  else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  return LCR_OK;
+}
+
+int lcr_ctx_sync(lcr_ctx* c) {
+  if (!c) return LCR_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LCR_OK;
+}
+
+int lcr_enable_timing(lcr_ctx* c, int on) { if (!c) return LCR_E_ARG; c->timing = on != 0; return LCR_OK; }
+
+int lcr_kernel_ms(lcr_ctx* c, int k, float* ms) {
+  if (!c || !ms || k < 0 || k >= LCR_NKERNELS) return LCR_E_ARG;
+  if (!c->ev_valid[k]) return LCR_E_STATE;
+  HIPCHK(c, hipEventSynchronize(c->ev[k][1]));
+  HIPCHK(c, hipEventElapsedTime(ms, c->ev[k][0], c->ev[k][1]));
+  return LCR_OK;
+}
+
+int lcr_pileup_bytes(lcr_ctx* c, int64_t* bytes) {
+  if (!c || !bytes) return LCR_E_ARG;
+  *bytes = c->pileup_bytes;
+  return LCR_OK;
+}
+
+int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
+  if (!c || !rd || !rg) return LCR_E_ARG;
+  if (rd->n_reads < 0 || rg->n_regions < 0 || rd->mem != rg->mem) { c->err = "bad batch header"; return LCR_E_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  c->loaded = c->have_planes = c->have_cand = c->have_frag = c->have_phase = false;
+  const int nr = rd->n_reads, ng = rg->n_regions, mem = rd->mem;
+  // host copies of the small per-region arrays
+  c->h_start0.assign(ng, 0); c->h_len.assign(ng, 0); c->h_col_off.assign(ng + 1, 0); c->h_read_begin.assign(ng + 1, 0);
+  if (mem == LCR_MEM_HOST) {
+    if (ng) { memcpy(c->h_start0.data(), rg->start0, ng * sizeof(int64_t)); memcpy(c->h_len.data(), rg->len, ng * sizeof(int32_t)); }
+    memcpy(c->h_col_off.data(), rg->col_off, (ng + 1) * sizeof(int64_t));
+    memcpy(c->h_read_begin.data(), rg->read_begin, (ng + 1) * sizeof(int32_t));
+  } else {
+    if (ng) {
+      HIPCHK(c, hipMemcpy(c->h_start0.data(), rg->start0, ng * sizeof(int64_t), hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(c->h_len.data(), rg->len, ng * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    HIPCHK(c, hipMemcpy(c->h_col_off.data(), rg->col_off, (ng + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(c->h_read_begin.data(), rg->read_begin, (ng + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  if (c->h_read_begin[ng] != nr || c->h_col_off[0] != 0) { c->err = "read_begin/col_off inconsistent"; return LCR_E_ARG; }
+  for (int g = 0; g < ng; g++)
+    if (c->h_len[g] < 0 || c->h_col_off[g + 1] - c->h_col_off[g] != c->h_len[g] || c->h_read_begin[g + 1] < c->h_read_begin[g]) {
+      c->err = "region table inconsistent"; return LCR_E_ARG;
+    }
+  c->n_cols = c->h_col_off[ng];
+  c->n_bases = rd->n_bases; c->n_cigar = rd->n_cigar;
+
+  BatchView& b = c->bv;
+  b.n_reads = nr; b.n_regions = ng;
+  int rc;
+#define UP(i, field, T, n) if ((rc = upload<T>(c, c->in_[i], (const T*)rd->field, (size_t)(n), (const T**)&b.field, mem))) return rc
+  UP(0, pos, int32_t, nr); UP(1, seq_len, int32_t, nr);
+  if ((rc = upload<int32_t>(c, c->in_[2], rd->lead_clip, nr, &b.lead, mem))) return rc;
+  if ((rc = upload<int32_t>(c, c->in_[3], rd->trail_clip, nr, &b.trail, mem))) return rc;
+  UP(4, flags, uint8_t, nr); UP(5, seq_off, uint64_t, nr); UP(6, cig_off, uint64_t, nr); UP(7, n_cig, uint32_t, nr);
+  UP(8, bases, uint8_t, rd->n_bases); UP(9, quals, uint8_t, rd->n_bases); UP(10, cigar, uint32_t, rd->n_cigar);
+#undef UP
+  if ((rc = upload<int64_t>(c, c->in_[11], rg->start0, ng, &b.start0, mem))) return rc;
+  if ((rc = upload<int32_t>(c, c->in_[12], rg->len, ng, &b.len, mem))) return rc;
+  if ((rc = upload<int64_t>(c, c->in_[13], rg->col_off, ng + 1, &b.col_off, mem))) return rc;
+  if ((rc = upload<int32_t>(c, c->in_[14], rg->read_begin, ng + 1, &b.read_begin, mem))) return rc;
+  if ((rc = upload<uint8_t>(c, c->in_[15], rg->ref, c->n_cols, &b.ref, mem))) return rc;
+
+  // tile table: tiles never cross a region
+  std::vector<int32_t> treg, tcol;
+  c->h_region_first_tile.assign(ng + 1, 0);
+  for (int g = 0; g < ng; g++) {
+    c->h_region_first_tile[g] = (int32_t)treg.size();
+    for (int32_t c0 = 0; c0 < c->h_len[g]; c0 += LCR_TILE) { treg.push_back(g); tcol.push_back(c0); }
+  }
+  c->h_region_first_tile[ng] = (int32_t)treg.size();
+  c->n_tiles = (int32_t)treg.size();
+  HIPCHK(c, c->tile_region.reserve(std::max<size_t>(treg.size(), 1) * 4));
+  HIPCHK(c, c->tile_col0.reserve(std::max<size_t>(tcol.size(), 1) * 4));
+  if (c->n_tiles) {
+    HIPCHK(c, hipMemcpyAsync(c->tile_region.p, treg.data(), treg.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->tile_col0.p, tcol.data(), tcol.size() * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, c->ref_end.reserve(std::max(nr, 1) * 4));
+  HIPCHK(c, c->max_span.reserve(std::max(ng, 1) * 4));
+  HIPCHK(c, c->errflag.reserve(4));
+  b.ref_end = c->ref_end.as<int32_t>(); b.region_max_span = c->max_span.as<int32_t>(); b.error_flag = c->errflag.as<int32_t>();
+  HIPCHK(c, hipMemsetAsync(b.region_max_span, 0, std::max(ng, 1) * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(b.error_flag, 0, 4, c->stream));
+  { Timer t(c, LCR_K_SPANS); launch_k0_spans(b, c->stream); }
+  int32_t bad = 0;
+  HIPCHK(c, hipMemcpyAsync(&bad, b.error_flag, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // also keeps treg/tcol alive until copied
+  HIPCHK(c, hipGetLastError());
+  if (bad) { c->err = "unknown CIGAR operation (reference panics: util.rs:944)"; return LCR_E_CIGAR; }
+  c->loaded = true;
+  return LCR_OK;
+}
+
+int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
+  if (!c || !p) return LCR_E_ARG;
+  if (!c->loaded) { c->err = "lcr_pileup before lcr_load_batch"; return LCR_E_STATE; }
+  if (p->polya_len == 0 || p->polya_len > 16) { c->err = "polya_len must be in 1..16"; return LCR_E_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  static float sor_thr = -1.f;
+  if (sor_thr < 0.f) sor_thr = lcr_device_sor_threshold(c->stream);
+  c->dp = to_dev(p, sor_thr);
+  HIPCHK(c, c->planes.reserve(std::max<size_t>((size_t)c->n_cols * LCR_NPLANES, 1) * 4));
+  { Timer t(c, LCR_K_PILEUP);
+    launch_k1_pileup(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), c->n_tiles, c->n_cols,
+                     c->planes.as<uint32_t>(), c->stream); }
+  HIPCHK(c, hipGetLastError());
+  // algorithmic bytes of this launch: bases once, CIGAR once, 32 B read header,
+  // 13 u32 planes written + 1 reference byte read per column
+  c->pileup_bytes = c->n_bases + 4 * c->n_cigar + 32 * (int64_t)c->bv.n_reads + (4 * LCR_NPLANES + 1) * c->n_cols;
+  c->have_planes = true;
+  c->have_cand = c->have_frag = c->have_phase = false;
+  return LCR_OK;
+}
+
+int lcr_get_columns(lcr_ctx* c, lcr_columns* out) {
+  if (!c || !out) return LCR_E_ARG;
+  if (!c->have_planes) { c->err = "lcr_get_columns before lcr_pileup"; return LCR_E_STATE; }
+  const size_t bytes = (size_t)c->n_cols * LCR_NPLANES * 4;
+  HIPCHK(c, c->h_planes.reserve(std::max<size_t>(bytes, 1)));
+  if (bytes) HIPCHK(c, hipMemcpyAsync(c->h_planes.p, c->planes.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  out->n_cols = c->n_cols;
+  out->planes = c->h_planes.as<uint32_t>();
+  return LCR_OK;
+}
+
+int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
+  if (!c || !p) return LCR_E_ARG;
+  if (!c->have_planes) { c->err = "lcr_candidates before lcr_pileup"; return LCR_E_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  c->dp = to_dev(p, c->dp.sor_threshold);
+  const int ng = c->bv.n_regions, nt = c->n_tiles;
+  HIPCHK(c, c->flags.reserve(std::max<size_t>(c->n_cols, 1)));
+  HIPCHK(c, c->tile_count.reserve(std::max(nt, 1) * 4));
+  HIPCHK(c, c->tile_off.reserve((std::max(nt, 1) + 1) * 4));
+  HIPCHK(c, c->total.reserve(16));
+  { Timer t(c, LCR_K_CAND_FILTER);
+    launch_k2_filter(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
+                     c->planes.as<uint32_t>(), c->flags.as<uint8_t>(), c->tile_count.as<int32_t>(), c->stream);
+    launch_scan_i32(c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(), nt, c->total.as<int32_t>(), c->stream); }
+  std::vector<int32_t> h_tile_off(nt + 1, 0);
+  int32_t n_sv = 0;
+  if (nt) HIPCHK(c, hipMemcpyAsync(h_tile_off.data(), c->tile_off.p, (size_t)nt * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&n_sv, c->total.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  h_tile_off[nt] = n_sv;
+  std::vector<int32_t> sv_off(ng + 1);
+  for (int g = 0; g <= ng; g++) sv_off[g] = h_tile_off[c->h_region_first_tile[g]];
+  HIPCHK(c, c->sv_region_off.reserve((ng + 1) * 4));
+  HIPCHK(c, hipMemcpyAsync(c->sv_region_off.p, sv_off.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, c->survivors.reserve(std::max(n_sv, 1) * sizeof(Survivor)));
+  HIPCHK(c, c->hist.reserve(std::max<size_t>(n_sv, 1) * 124 * 4));
+  HIPCHK(c, c->cand_tmp.reserve(std::max<size_t>(n_sv, 1) * sizeof(lcr_candidate)));
+  HIPCHK(c, c->keep.reserve(std::max(n_sv, 1)));
+  c->h_cand.clear();
+  c->h_cand_off.assign(ng + 1, 0);
+  if (n_sv) {
+    HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (size_t)n_sv * 124 * 4, c->stream));
+    { Timer t(c, LCR_K_CAND_HIST);
+      launch_k2_compact(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
+                        c->planes.as<uint32_t>(), c->flags.as<uint8_t>(), c->tile_off.as<int32_t>(),
+                        c->survivors.as<Survivor>(), c->stream);
+      launch_k2_hist(c->bv, c->dp, c->survivors.as<Survivor>(), c->sv_region_off.as<int32_t>(), c->hist.as<uint32_t>(),
+                     c->stream); }
+    { Timer t(c, LCR_K_CAND_GT);
+      launch_k2_gt(c->dp, c->survivors.as<Survivor>(), n_sv, c->hist.as<uint32_t>(), c->bv.start0,
+                   c->cand_tmp.as<lcr_candidate>(), c->keep.as<uint8_t>(), c->stream); }
+    std::vector<lcr_candidate> tmp(n_sv);
+    std::vector<uint8_t> keep(n_sv);
+    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->cand_tmp.p, (size_t)n_sv * sizeof(lcr_candidate), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(keep.data(), c->keep.p, n_sv, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    for (int g = 0; g < ng; g++) {
+      c->h_cand_off[g] = (int32_t)c->h_cand.size();
+      for (int s = sv_off[g]; s < sv_off[g + 1]; s++) if (keep[s]) c->h_cand.push_back(tmp[s]);
+      dense_filter(c->h_cand, c->h_cand_off[g], (int)c->h_cand.size(), p->dense_win, p->min_dense_cnt);
+    }
+    c->h_cand_off[ng] = (int32_t)c->h_cand.size();
+  }
+  const size_t nc = c->h_cand.size();
+  HIPCHK(c, c->d_cand.reserve(std::max<size_t>(nc, 1) * sizeof(lcr_candidate)));
+  HIPCHK(c, c->d_cand_off.reserve((ng + 1) * 4));
+  if (nc) HIPCHK(c, hipMemcpyAsync(c->d_cand.p, c->h_cand.data(), nc * sizeof(lcr_candidate), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_cand_off.p, c->h_cand_off.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_cand = true;
+  c->have_frag = c->have_phase = false;
+  return LCR_OK;
+}
+
+int lcr_get_candidates(lcr_ctx* c, lcr_candidate_list* out) {
+  if (!c || !out) return LCR_E_ARG;
+  if (!c->have_cand) { c->err = "lcr_get_candidates before lcr_candidates"; return LCR_E_STATE; }
+  out->n_cand = (int32_t)c->h_cand.size();
+  out->n_regions = c->bv.n_regions;
+  out->cand = c->h_cand.data();
+  out->region_off = c->h_cand_off.data();
+  return LCR_OK;
+}
+
+int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
+  if (!c || !p) return LCR_E_ARG;
+  if (!c->have_cand) { c->err = "lcr_fragments before lcr_candidates"; return LCR_E_STATE; }
+  if (p->min_linkers == 0) { c->err = "min_linkers must be > 0 (fragment.rs:252)"; return LCR_E_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const int ng = c->bv.n_regions;
+  c->min_linkers = p->min_linkers;
+  HIPCHK(c, c->region_rows.reserve(std::max(ng, 1) * 4));
+  launch_k3_rows(c->bv, c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->region_rows.as<int32_t>(), c->stream);
+  std::vector<int32_t> rr(ng, 0);
+  if (ng) HIPCHK(c, hipMemcpyAsync(rr.data(), c->region_rows.p, ng * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  c->h_row_region_off.assign(ng + 1, 0);
+  for (int g = 0; g < ng; g++) c->h_row_region_off[g + 1] = c->h_row_region_off[g] + rr[g];
+  c->n_rows = c->h_row_region_off[ng];
+  const int nrow = c->n_rows;
+  HIPCHK(c, c->row_region_off.reserve((ng + 1) * 4));
+  HIPCHK(c, hipMemcpyAsync(c->row_region_off.p, c->h_row_region_off.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, c->row_cnt.reserve(std::max(nrow, 1) * 4));
+  HIPCHK(c, c->row_links.reserve(std::max(nrow, 1) * 4));
+  HIPCHK(c, c->row_ptr.reserve((std::max(nrow, 1) + 1) * 8));
+  { Timer t(c, LCR_K_FRAG_COUNT);
+    launch_k3_count(c->bv, c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nrow,
+                    c->row_cnt.as<int32_t>(), c->row_links.as<uint32_t>(), c->stream);
+    launch_scan_i32_to_i64(c->row_cnt.as<int32_t>(), c->row_ptr.as<int64_t>(), nrow, c->stream); }
+  int64_t nnz = 0;
+  HIPCHK(c, hipMemcpyAsync(&nnz, c->row_ptr.as<int64_t>() + nrow, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  c->nnz = nnz;
+  HIPCHK(c, c->col.reserve(std::max<int64_t>(nnz, 1) * 4));
+  HIPCHK(c, c->val.reserve(std::max<int64_t>(nnz, 1)));
+  { Timer t(c, LCR_K_FRAG_FILL);
+    launch_k3_fill(c->bv, c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nrow,
+                   c->row_ptr.as<int64_t>(), c->col.as<int32_t>(), c->val.as<uint8_t>(), c->stream); }
+  HIPCHK(c, hipGetLastError());
+  c->have_frag = true;
+  c->have_phase = false;
+  return LCR_OK;
+}
+
+int lcr_get_fragmat(lcr_ctx* c, lcr_fragmat* out) {
+  if (!c || !out) return LCR_E_ARG;
+  if (!c->have_frag) { c->err = "lcr_get_fragmat before lcr_fragments"; return LCR_E_STATE; }
+  const int nrow = c->n_rows, ng = c->bv.n_regions;
+  const int64_t nnz = c->nnz;
+  HIPCHK(c, c->h_row_ptr.reserve((nrow + 1) * 8));
+  HIPCHK(c, c->h_row_read.reserve(std::max(nrow, 1) * 4));
+  HIPCHK(c, c->h_col.reserve(std::max<int64_t>(nnz, 1) * 4));
+  HIPCHK(c, c->h_val.reserve(std::max<int64_t>(nnz, 1)));
+  HIPCHK(c, c->h_row_fp.reserve(std::max(nrow, 1)));
+  HIPCHK(c, c->h_row_links.reserve(std::max(nrow, 1) * 4));
+  HIPCHK(c, hipMemcpyAsync(c->h_row_ptr.p, c->row_ptr.p, (size_t)(nrow + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+  if (nrow) HIPCHK(c, hipMemcpyAsync(c->h_row_links.p, c->row_links.p, (size_t)nrow * 4, hipMemcpyDeviceToHost, c->stream));
+  if (nnz) {
+    HIPCHK(c, hipMemcpyAsync(c->h_col.p, c->col.p, (size_t)nnz * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_val.p, c->val.p, (size_t)nnz, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int32_t* rread = c->h_row_read.as<int32_t>();
+  uint8_t* fp = c->h_row_fp.as<uint8_t>();
+  const uint32_t* links = c->h_row_links.as<uint32_t>();
+  for (int g = 0; g < ng; g++)
+    for (int r = c->h_row_region_off[g]; r < c->h_row_region_off[g + 1]; r++) rread[r] = c->h_read_begin[g] + (r - c->h_row_region_off[g]);
+  for (int r = 0; r < nrow; r++) fp[r] = links[r] >= c->min_linkers ? 1 : 0;
+  out->n_rows = nrow; out->nnz = nnz; out->n_regions = ng;
+  out->row_region_off = c->h_row_region_off.data();
+  out->row_ptr = c->h_row_ptr.as<int64_t>(); out->row_read = rread; out->col = c->h_col.as<int32_t>();
+  out->val = c->h_val.as<uint8_t>(); out->row_for_phasing = fp; out->row_links = links;
+  return LCR_OK;
+}
+
+int lcr_phase(lcr_ctx* c, const lcr_params* p) {
+  if (!c || !p) return LCR_E_ARG;
+  if (!c->have_frag) { c->err = "lcr_phase before lcr_fragments"; return LCR_E_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  PhaseInputs in;
+  in.n_regions = c->bv.n_regions; in.n_rows = c->n_rows; in.nnz = c->nnz;
+  in.row_region_off = c->h_row_region_off.data(); in.cand_region_off = c->h_cand_off.data();
+  in.region_start0 = c->h_start0.data();
+  in.d_row_ptr = c->row_ptr.as<int64_t>(); in.d_col = c->col.as<int32_t>(); in.d_val = c->val.as<uint8_t>();
+  in.d_row_links = c->row_links.as<uint32_t>();
+  in.cand = &c->h_cand;
+  Timer t(c, LCR_K_PHASE);
+  int rc = c->phase.run(in, *p, c->stream, &c->err);
+  if (rc) return rc;
+  c->have_phase = true;
+  return LCR_OK;
+}
+
+int lcr_get_phase_result(lcr_ctx* c, lcr_phase_result* out) {
+  if (!c || !out) return LCR_E_ARG;
+  if (!c->have_phase) { c->err = "lcr_get_phase_result before lcr_phase"; return LCR_E_STATE; }
+  out->n_rows = c->n_rows; out->n_regions = c->bv.n_regions;
+  out->haplotag = c->phase.haplotag.data(); out->assignment = c->phase.assignment.data();
+  out->phase_set = c->phase.phase_set.data(); out->objective = c->phase.objective.data();
+  return LCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+// lcr_dev.h — shared host/device declarations of liblcr (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lcr.h"
+
+#define LCR_TILE 1024      // pileup columns per workgroup tile
+#define LCR_BLOCK 256      // threads per workgroup (4 wave64)
+#define LCR_WAVE 64
+
+// Device view of a bound batch (all pointers in HBM).
+struct BatchView {
+  int32_t n_reads, n_regions;
+  const int32_t* pos;
+  const int32_t* seq_len;
+  const int32_t* lead;
+  const int32_t* trail;
+  const uint8_t* flags;
+  const uint64_t* seq_off;
+  const uint64_t* cig_off;
+  const uint32_t* n_cig;
+  const uint8_t* bases;
+  const uint8_t* quals;
+  const uint32_t* cigar;
+  const int64_t* start0;
+  const int32_t* len;
+  const int64_t* col_off;
+  const int32_t* read_begin;
+  const uint8_t* ref;
+  // derived by k0_spans
+  int32_t* ref_end;          // n_reads: pos + reference span
+  int32_t* region_max_span;  // n_regions
+  int32_t* error_flag;       // != 0 -> unknown CIGAR op seen
+};
+
+struct DevParams {
+  int32_t ont;
+  int32_t dist_to_end, polya_len;
+  uint32_t min_baseq, min_depth, max_depth, min_qual, low_cnt_cut, min_linkers;
+  int32_t use_strand_bias;
+  float min_af, min_af_intron, low_frac_cut;
+  float sor_threshold;
+};
+
+// pass-1 survivor of the candidate filters (one per column that reaches the likelihood block)
+struct Survivor {
+  int64_t gcol;      // global column index (col_off[region] + column)
+  int32_t region;
+  int32_t col;       // column inside region
+  uint8_t ref_base, allele1, allele2, n_alt;
+  uint32_t cnt1, cnt2, depth;
+  uint32_t ts_fwd, ts_rev;
+  float af1, af2;
+};
+
+#define HIPCHK(ctx, expr)                                                              \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+      return LCR_E_DEVICE;                                                             \
+    }                                                                                  \
+  } while (0)
+
+// growable device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+struct HostBuf {  // pinned
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---- phasing LUT (fixed point, scale 2^40; DESIGN.md "Decision arithmetic") ----
+struct PhaseLutDev {
+  int64_t fe[31], f1e[31];           // log10(eps), log10(1-eps), eps = 10^(-q/10) (q=0 -> q=1)
+  int64_t f_homref, f_homvar, f_het0, f_log2;
+};
+
+// ---- kernel launchers (defined in the .hip files) ----
+void launch_k0_spans(const BatchView& b, hipStream_t s);
+void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
+                      int32_t n_tiles, int64_t n_cols, uint32_t* planes, hipStream_t s);
+void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
+                      int32_t n_tiles, int64_t n_cols, const uint32_t* planes, uint8_t* flags, int32_t* tile_count,
+                      hipStream_t s);
+void launch_scan_i32(const int32_t* in, int32_t* out_excl, int32_t n, int32_t* total, hipStream_t s);
+void launch_k2_compact(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
+                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const uint8_t* flags,
+                       const int32_t* tile_off, Survivor* out, hipStream_t s);
+float lcr_device_sor_threshold(hipStream_t s);
+void launch_k2_hist(const BatchView& b, const DevParams& p, const Survivor* sv, const int32_t* sv_region_off,
+                    uint32_t* hist /* n_sv * 4 * 31 */, hipStream_t s);
+void launch_k2_gt(const DevParams& p, const Survivor* sv, int32_t n_sv, const uint32_t* hist, const int64_t* start0,
+                  lcr_candidate* out, uint8_t* keep, hipStream_t s);
+void launch_k3_count(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off,
+                     const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, uint32_t* row_links,
+                     hipStream_t s);
+void launch_k3_fill(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off,
+                    const int32_t* row_region_off, int32_t n_rows, const int64_t* row_ptr, int32_t* col, uint8_t* val,
+                    hipStream_t s);
+void launch_k3_rows(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off, int32_t* region_rows,
+                    hipStream_t s);
+void launch_scan_i32_to_i64(const int32_t* in, int64_t* out_excl, int32_t n, hipStream_t s);
+
+// device helpers shared by kernels -------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int base_code(uint8_t b) {
+  // A,C,G,T (either case, as util.rs:822-889 matches 'A'|'a' ...) -> 0..3, else -1
+  switch (b) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return -1;
+  }
+}
+__device__ __forceinline__ int iabs_(int x) { return x < 0 ? -x : x; }
+
+// util.rs:745-751: |curr_pos - leading_softclips| < D or |curr_pos - (seq_len - trailing)| < D
+__device__ __forceinline__ bool in_end_zone(int c, int lead, int reb, int D) {
+  return iabs_(c - lead) < D || iabs_(c - reb) < D;
+}
+
+// util.rs:754-789 restated as a single scan: the base at read position c facing reference byte R is
+// masked iff a window of L identical bases X in {A,C,G,T}, X != R, starts at some t in [c-L, c+1]
+// and lies inside the read.  Window [t, t+L-1] is all-X iff the L-1 adjacent equalities hold.
+__device__ __forceinline__ bool polya_masked(const uint8_t* __restrict__ seq, int seq_len, int c, int L, uint8_t R) {
+  int lo = c - L;            // first byte that can belong to a window
+  int hi = c + L;            // last byte that can belong to a window (window t=c+1 ends at c+L)
+  if (lo < 0) lo = 0;
+  if (hi > seq_len - 1) hi = seq_len - 1;
+  if (hi - lo + 1 < L) return false;
+  int run = 1;               // length of the run of equal bytes ending at i
+  uint8_t prev = seq[lo];
+  bool masked = false;
+  for (int i = lo + 1; i <= hi; i++) {
+    uint8_t cur = seq[i];
+    run = (cur == prev) ? run + 1 : 1;
+    prev = cur;
+    if (run >= L) {
+      // window [i-L+1, i] is homopolymer of `cur`; its start t = i-L+1 must be in [c-L, c+1]
+      int t = i - L + 1;
+      if (t >= c - L && t <= c + 1 && cur != R && (cur == 'A' || cur == 'C' || cur == 'G' || cur == 'T')) masked = true;
+    }
+  }
+  return masked;
+}
+
+// region index of read r (binary search in read_begin)
+__device__ __forceinline__ int region_of_read(const int32_t* __restrict__ read_begin, int n_regions, int r) {
+  int lo = 0, hi = n_regions;  // find last g with read_begin[g] <= r
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (read_begin[mid] <= r) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+#endif
