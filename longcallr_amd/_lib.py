@@ -30,6 +30,13 @@ def load():
     if not os.path.exists(SO_PATH):
         raise LcrError("liblcr.so is missing: build it with `python -m longcallr_amd.build` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7; importing torch first
+    # makes liblcr.so (NEEDED libamdhip64.so.7) bind to that already-loaded runtime instead of a second
+    # copy from /opt/rocm, which could not see the GPU ("No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing only; liblcr works without it
+        pass
     l = C.CDLL(SO_PATH)
     vp, i32 = C.c_void_p, C.c_int
     l.lcr_version.restype = C.c_char_p

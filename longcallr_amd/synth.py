@@ -1,0 +1,234 @@
+"""Synthetic long-read RNA-seq batches: the inputs of the parity tests and of bench.py.
+
+Emits `_abi.ReadBatch` (decoded-read SoA) directly — no BAM round trip.  One gene = one coverage
+island = one region; "depth" is mean aligned-base depth over the whole window, so the number of
+aligned bases is depth x window.  Truth haplotypes exist (every read carries a haplotype label and
+het SNPs follow it), so phasing results can be sanity-checked, but parity tests only compare the GPU
+against the oracle.  q >= 1 always (q = 0 makes the reference's optimiser NaN-panic, phase.rs:307).
+
+Profiles:
+  ont-cdna  (C3): both strands, sub 3 % / ins 1 % / del 1.5 %, quals {3,7,12,18,25,35}
+  masseq    (C4): forward strand only, error 0.3 %, quals {40,27,22,17,10,3}
+  ont-drna  (C5): forward transcript strand, error 6 %, one dense island
+"""
+import numpy as np
+
+from ._abi import ReadBatch
+
+PROFILES = {
+    "ont-cdna": dict(sub=0.03, ins=0.01, dele=0.015, both_strands=True,
+                     quals=([3, 7, 12, 18, 25, 35], [0.01, 0.04, 0.10, 0.25, 0.35, 0.25]),
+                     mean_len=900, sigma_len=0.5, het_per_exonic_bp=1 / 1250.0, hom_frac=0.1, edit_frac=0.15),
+    "masseq": dict(sub=0.002, ins=0.0005, dele=0.0005, both_strands=False,
+                   quals=([40, 27, 22, 17, 10, 3], [0.92, 0.03, 0.02, 0.015, 0.01, 0.005]),
+                   mean_len=1200, sigma_len=0.4, het_per_exonic_bp=1 / 1500.0, hom_frac=0.1, edit_frac=0.1),
+    "ont-drna": dict(sub=0.04, ins=0.008, dele=0.012, both_strands=False,
+                     quals=([3, 7, 12, 18, 25, 35], [0.03, 0.07, 0.15, 0.30, 0.30, 0.15]),
+                     mean_len=1500, sigma_len=0.4, het_per_exonic_bp=1 / 400.0, hom_frac=0.05, edit_frac=0.1),
+}
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = {0: 3, 1: 2, 2: 1, 3: 0}
+OP_M, OP_I, OP_D, OP_N, OP_S = 0, 1, 2, 3, 4
+
+
+def _gene(rng, prof, gene_len, depth, gene_start, exon_frac=0.25):
+    """One gene: returns per-read arrays + concatenated bases/quals/cigar (gene-local offsets)."""
+    # ---- exon structure: 8-14 exons of 300-800 bp, scaled to ~exon_frac of the gene
+    n_ex = int(rng.integers(8, 15))
+    ex_len = rng.integers(300, 801, size=n_ex)
+    scale = exon_frac * gene_len / ex_len.sum()
+    ex_len = np.maximum((ex_len * min(scale, 1.0)).astype(np.int64), 60)
+    T = int(ex_len.sum())
+    intr_total = gene_len - T
+    w = rng.random(n_ex - 1) + 0.2
+    in_len = np.maximum((w / w.sum() * intr_total).astype(np.int64), 20)
+    ex_start = np.zeros(n_ex, dtype=np.int64)
+    for k in range(1, n_ex):
+        ex_start[k] = ex_start[k - 1] + ex_len[k - 1] + in_len[k - 1]
+    span = int(ex_start[-1] + ex_len[-1])
+    tx2g = np.concatenate([np.arange(s, s + l) for s, l in zip(ex_start, ex_len)])  # exonic -> gene coords
+    ref = _ACGT[rng.integers(0, 4, size=span + 64)]
+    plus_gene = bool(rng.integers(0, 2)) if prof["both_strands"] else True
+    # ---- variants at exonic positions
+    n_het = max(1, int(rng.poisson(T * prof["het_per_exonic_bp"])))
+    n_hom = int(round(n_het * prof["hom_frac"]))
+    n_edit = int(round(n_het * prof["edit_frac"]))
+    vpos = rng.choice(T, size=min(T, n_het + n_hom + n_edit), replace=False)
+    het_t, hom_t, edit_t = vpos[:n_het], vpos[n_het:n_het + n_hom], vpos[n_het + n_hom:]
+    refi = np.searchsorted(_ACGT, ref[:span])  # 0..3
+    alt_of = (refi + rng.integers(1, 4, size=span)) % 4
+    if edit_t.size:  # A>G on + genes, T>C on - genes (candidate.rs:382-407)
+        g = tx2g[edit_t]
+        ref[g] = ord("A") if plus_gene else ord("T")
+        refi[g] = 0 if plus_gene else 3
+        alt_of[g] = 2 if plus_gene else 1
+    edit_af = rng.uniform(0.1, 0.6, size=edit_t.size)
+    # ---- reads
+    n_reads = max(4, int(depth * span / prof["mean_len"]))
+    rlen = np.exp(rng.normal(np.log(prof["mean_len"]), prof["sigma_len"], size=n_reads)).astype(np.int64)
+    rlen = np.clip(rlen, 520, max(T - 1, 521))
+    rlen = np.minimum(rlen, T)
+    tstart = (rng.random(n_reads) * (T - rlen + 1)).astype(np.int64)
+    order = np.argsort(tx2g[tstart], kind="stable")
+    tstart, rlen = tstart[order], rlen[order]
+    hap = rng.integers(0, 2, size=n_reads)
+    rev = (rng.integers(0, 2, size=n_reads) if prof["both_strands"] else np.zeros(n_reads, dtype=np.int64))
+    ts_plus = np.full(n_reads, plus_gene)
+    # flat per-template-base arrays
+    N = int(rlen.sum())
+    rid = np.repeat(np.arange(n_reads), rlen)
+    roff = np.arange(N) - np.repeat(np.cumsum(rlen) - rlen, rlen)
+    tpos = np.repeat(tstart, rlen) + roff
+    gpos = tx2g[tpos]
+    b = refi[gpos].copy()
+    is_het = np.zeros(T, dtype=bool); is_het[het_t] = True
+    is_hom = np.zeros(T, dtype=bool); is_hom[hom_t] = True
+    m = is_het[tpos] & (hap[rid] == 1)
+    b[m] = alt_of[gpos[m]]
+    m = is_hom[tpos]
+    b[m] = alt_of[gpos[m]]
+    if edit_t.size:
+        af_t = np.zeros(T); af_t[edit_t] = edit_af
+        m = rng.random(N) < af_t[tpos]
+        b[m] = alt_of[gpos[m]]
+    u = rng.random(N)
+    sub = u < prof["sub"]
+    b[sub] = (b[sub] + rng.integers(1, 4, size=int(sub.sum()))) % 4
+    dele = (u >= prof["sub"]) & (u < prof["sub"] + prof["dele"]) & (roff > 2) & (roff < np.repeat(rlen, rlen) - 3)
+    ins = (u >= prof["sub"] + prof["dele"]) & (u < prof["sub"] + prof["dele"] + prof["ins"]) & (roff > 2) & (
+        roff < np.repeat(rlen, rlen) - 3)
+    # ---- token stream: per template base [N-junction?] then (M | D) then [I]
+    junction = np.zeros(N, dtype=np.int64)
+    nz = roff > 0
+    gap = np.zeros(N, dtype=np.int64)
+    gap[1:] = gpos[1:] - gpos[:-1] - 1
+    junction[nz] = gap[nz]
+    has_j = junction > 0
+    n_tok = 1 + has_j.astype(np.int64) + ins.astype(np.int64)
+    tok_base = np.cumsum(n_tok) - n_tok
+    total = int(n_tok.sum())
+    t_op = np.empty(total, dtype=np.int64); t_len = np.ones(total, dtype=np.int64); t_rid = np.empty(total, dtype=np.int64)
+    p_main = tok_base + has_j
+    t_op[p_main] = np.where(dele, OP_D, OP_M); t_rid[p_main] = rid
+    pj = tok_base[has_j]
+    t_op[pj] = OP_N; t_len[pj] = junction[has_j]; t_rid[pj] = rid[has_j]
+    pi = p_main[ins] + 1
+    t_op[pi] = OP_I; t_rid[pi] = rid[ins]
+    newrun = np.ones(total, dtype=bool)
+    newrun[1:] = (t_op[1:] != t_op[:-1]) | (t_rid[1:] != t_rid[:-1]) | (t_op[1:] == OP_N)
+    starts = np.flatnonzero(newrun)
+    run_op, run_rid = t_op[starts], t_rid[starts]
+    run_len = np.add.reduceat(t_len, starts)
+    # ---- read sequences: kept template bases + inserted bases, in token order
+    emits = (t_op == OP_M) | (t_op == OP_I)
+    seq_tok = np.full(total, -1, dtype=np.int64)
+    seq_tok[p_main] = b
+    seq_tok[pi] = rng.integers(0, 4, size=pi.size)
+    seq_codes = seq_tok[emits]
+    seq_rid = t_rid[emits]
+    # ---- poly-A tails on 60 % of reads: 70 % soft-clipped, 30 % aligned past the 3' end
+    tail = np.where(rng.random(n_reads) < 0.6, rng.integers(15, 41, size=n_reads), 0)
+    soft = rng.random(n_reads) < 0.7
+    tail_right = ts_plus  # + transcript: poly-A at the right end; - transcript: poly-T at the left end
+    read_end_t = tstart + rlen - 1
+    read_beg_t = tstart
+    for r in np.flatnonzero(tail > 0):  # aligned tails need room: right of the last exon base / left of the first
+        if not soft[r]:
+            if tail_right[r] and read_end_t[r] != T - 1:
+                soft[r] = True
+            if (not tail_right[r]) and (read_beg_t[r] != 0 or gene_start < 64):
+                soft[r] = True
+    seq_cnt = np.bincount(seq_rid, minlength=n_reads)
+    cig_cnt = np.bincount(run_rid, minlength=n_reads)
+    seq_start = np.cumsum(seq_cnt) - seq_cnt
+    cig_start = np.cumsum(cig_cnt) - cig_cnt
+    pos = gpos[np.cumsum(rlen) - rlen].copy()
+    out_seq, out_cig = [], []
+    tail_base = 0 if plus_gene else 3  # A or T
+    final_pos = pos.copy()
+    lead = np.zeros(n_reads, dtype=np.int64); trail = np.zeros(n_reads, dtype=np.int64)
+    for r in range(n_reads):
+        s = seq_codes[seq_start[r]:seq_start[r] + seq_cnt[r]]
+        ops = (run_len[cig_start[r]:cig_start[r] + cig_cnt[r]] << 4) | run_op[cig_start[r]:cig_start[r] + cig_cnt[r]]
+        if tail[r]:
+            tb = np.full(tail[r], tail_base, dtype=np.int64)
+            if tail_right[r]:
+                s = np.concatenate([s, tb])
+                if soft[r]:
+                    ops = np.concatenate([ops, [(tail[r] << 4) | OP_S]]); trail[r] = tail[r]
+                else:
+                    ops = ops.copy(); ops[-1] += tail[r] << 4
+            else:
+                s = np.concatenate([tb, s])
+                if soft[r]:
+                    ops = np.concatenate([[(tail[r] << 4) | OP_S], ops]); lead[r] = tail[r]
+                else:
+                    ops = ops.copy(); ops[0] += tail[r] << 4; final_pos[r] -= tail[r]
+        out_seq.append(s)
+        out_cig.append(ops)
+    seq_len = np.array([len(s) for s in out_seq], dtype=np.int64)
+    n_cig = np.array([len(c) for c in out_cig], dtype=np.int64)
+    bases = _ACGT[np.concatenate(out_seq)]
+    qv, qp = prof["quals"]
+    quals = np.asarray(qv, dtype=np.uint8)[rng.choice(len(qv), size=bases.size, p=qp)]
+    cigar = np.concatenate(out_cig).astype(np.uint32)
+    # reads must stay sorted by pos inside the region
+    o2 = np.argsort(final_pos, kind="stable")
+    def regroup(flat, cnt):
+        st = np.cumsum(cnt) - cnt
+        return np.concatenate([flat[st[r]:st[r] + cnt[r]] for r in o2]) if len(o2) else flat
+    bases, quals = regroup(bases, seq_len), regroup(quals, seq_len)
+    cigar = regroup(cigar, n_cig)
+    final_pos, seq_len, n_cig, lead, trail, rev = final_pos[o2], seq_len[o2], n_cig[o2], lead[o2], trail[o2], rev[o2]
+    ts_code = np.where(ts_plus, 1, 2)
+    # transcript-strand tag relative to the read strand: minimap2 `ts` is the transcript strand of the
+    # read itself; (read +, ts +) and (read -, ts -) both mean transcript + (util.rs:803-819)
+    ts_tag = np.where(rev == 0, ts_code, 3 - ts_code)
+    flags = (rev.astype(np.uint8)) | (ts_tag.astype(np.uint8) << 1)
+    return dict(pos=final_pos + gene_start, seq_len=seq_len, lead_clip=lead, trail_clip=trail, flags=flags,
+                n_cig=n_cig, bases=bases, quals=quals, cigar=cigar, ref=ref, span=span)
+
+
+def make_batch(profile="ont-cdna", n_genes=4, gene_len=25000, depth=40.0, seed=1, gap=1000, min_q1=True):
+    """n_genes regions of ~gene_len columns at mean aligned depth `depth`."""
+    rng = np.random.default_rng(seed)
+    prof = PROFILES[profile]
+    parts, regions_start, regions_len, refs, read_begin = [], [], [], [], [0]
+    cursor = 100000
+    for _ in range(n_genes):
+        g = _gene(rng, prof, gene_len, depth, cursor)
+        # region window = coverage island [min pos, max end)
+        ops, lens = g["cigar"] & 15, (g["cigar"] >> 4).astype(np.int64)
+        consume = np.isin(ops, [0, 2, 3, 7, 8])
+        cig_read = np.repeat(np.arange(len(g["n_cig"])), g["n_cig"])
+        ref_len = np.bincount(cig_read, weights=np.where(consume, lens, 0), minlength=len(g["n_cig"])).astype(np.int64)
+        lo, hi = int(g["pos"].min()), int((g["pos"] + ref_len).max())
+        pad_l = cursor - lo  # aligned poly-T tails may start left of the gene
+        ref = g["ref"]
+        if pad_l > 0:
+            ref = np.concatenate([_ACGT[rng.integers(0, 4, size=pad_l)], ref])
+        elif pad_l < 0:
+            ref = ref[-pad_l:]
+        need = hi - lo
+        if ref.size < need:
+            ref = np.concatenate([ref, _ACGT[rng.integers(0, 4, size=need - ref.size)]])
+        refs.append(ref[:need])
+        regions_start.append(lo); regions_len.append(need)
+        parts.append(g)
+        read_begin.append(read_begin[-1] + len(g["pos"]))
+        cursor = hi + gap
+    cat = lambda k, dt: np.concatenate([p[k] for p in parts]).astype(dt)
+    seq_len, n_cig = cat("seq_len", np.int64), cat("n_cig", np.int64)
+    quals = cat("quals", np.uint8)
+    if min_q1:
+        quals = np.maximum(quals, 1)
+    return ReadBatch(pos=cat("pos", np.int32), seq_len=seq_len.astype(np.int32), lead_clip=cat("lead_clip", np.int32),
+                     trail_clip=cat("trail_clip", np.int32), flags=cat("flags", np.uint8),
+                     seq_off=(np.cumsum(seq_len) - seq_len).astype(np.uint64),
+                     cig_off=(np.cumsum(n_cig) - n_cig).astype(np.uint64), n_cig=n_cig.astype(np.uint32),
+                     bases=cat("bases", np.uint8), quals=quals, cigar=cat("cigar", np.uint32),
+                     start0=regions_start, len=regions_len, read_begin=read_begin, ref=np.concatenate(refs))
+
+
+def preset_for(profile):
+    return {"ont-cdna": "ont-cdna", "masseq": "hifi-masseq", "ont-drna": "ont-drna"}[profile]

@@ -802,7 +802,8 @@ struct orc_region {
     }
   }
 
-  /* phase.rs:257-276 (F64) / histogram x LUT canonical form (EXACT) */
+  /* phase.rs:257-276 (F64) / exact fixed-point sum, compared as int64 and reported / 2^40 (EXACT) */
+  mutable int64_t last_obj_fx = 0;
   double cal_overall_probability(int mode) const {
     if (mode == ORC_MODE_F64) {
       double logp = 0.0;
@@ -815,19 +816,17 @@ struct orc_region {
       }
       return logp;
     }
-    int64_t cm[31] = {0}, ce[31] = {0};
+    int64_t sum = 0;
     for (size_t k = 0; k < frags.size(); k++) {
       if (!frags[k].for_phasing || frags[k].haplotag == 0) continue;
       for (const FragElem& fe : frags[k].list) {
         if (!fe.phase_site) continue;
         const Cand& c = cands[fe.snp_idx];
-        int x = (c.genotype == 0) ? frags[k].haplotag * c.haplotype : c.genotype;
-        if (fe.p == x) cm[fe.baseq]++; else ce[fe.baseq]++;
+        sum += fx_aki(frags[k].haplotag, c.haplotype, c.genotype, fe.p, fe.baseq);
       }
     }
-    double obj = 0.0;
-    for (int q = 0; q <= 30; q++) { obj += (double)cm[q] * plut().l1e[q]; obj += (double)ce[q] * plut().le[q]; }
-    return obj;
+    last_obj_fx = sum;
+    return (double)sum / FX_SCALE;
   }
 
   /* ---------- P12: cross_optimize (phase.rs:810-976) ---------- */
@@ -1028,6 +1027,12 @@ struct orc_region {
     for (auto& c : cands) c.haplotype = rnd() < 0.5 ? 1 : -1; /* init_haplotypes, phase.rs:443-448 */
     init_assignment();
     double largest_prob = -std::numeric_limits<double>::infinity();
+    int64_t largest_fx = std::numeric_limits<int64_t>::min();
+    auto better = [&](double prob) {  /* `prob > largest_prob` (phase.rs:1117,1129,...); EXACT compares the int64 sums */
+      const bool b = mode == ORC_MODE_F64 ? prob > largest_prob : last_obj_fx > largest_fx;
+      if (b) { largest_prob = prob; largest_fx = last_obj_fx; }
+      return b;
+    };
     Best best;
     std::set<int> conserved;
     GraphMap ld_graph = divide_snps_into_blocks();
@@ -1043,7 +1048,7 @@ struct orc_region {
         init_assignment();
         init_genotype();
         const double prob = cross_optimize(mode, conserved, false, true);
-        if (prob > largest_prob) { largest_prob = prob; save_best(best); }
+        if (better(prob)) save_best(best);
       }
       load_best(best);
     } else {
@@ -1051,10 +1056,10 @@ struct orc_region {
       init_genotype();
       init_assignment();
       double prob = cross_optimize(mode, conserved, true, false);
-      if (prob > largest_prob) { largest_prob = prob; save_best(best); }
+      if (better(prob)) save_best(best);
       load_best(best);
       prob = cross_optimize_by_block(mode);
-      if (prob > largest_prob) { largest_prob = prob; save_best(best); }
+      if (better(prob)) save_best(best);
       load_best(best);
       for (size_t tidx = 0; tidx <= S / 4; tidx++) {
         const bool flip = tidx % 2 == 1;
@@ -1064,14 +1069,14 @@ struct orc_region {
           else if (rg >= 0.9) c.haplotype = flip ? -1 : 1;
         }
         prob = cross_optimize(mode, conserved, false, false);
-        if (prob > largest_prob) { largest_prob = prob; save_best(best); }
+        if (better(prob)) save_best(best);
         load_best(best);
         for (auto& f : frags) {
           if (!f.for_phasing || f.haplotag == 0) continue;
           if (rnd() < 0.1) f.haplotag *= -1;
         }
         prob = cross_optimize(mode, conserved, false, false);
-        if (prob > largest_prob) { largest_prob = prob; save_best(best); }
+        if (better(prob)) save_best(best);
         load_best(best);
       }
       load_best(best);
