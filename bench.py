@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py — one "step" = one pass of the hot path (bind batch -> pileup -> candidates/GT ->
+fragment matrix -> phasing) over one synthetic batch already resident in HBM.
+
+Workload (config.workload): BASELINE.json configs[2], "synthetic 10 Mb ONT-cDNA, 40x" (C3) per GPU —
+the largest single-GPU configuration; demo.bam (configs[0]/[1]) is ~5 MB of traffic and is a parity
+fixture, not a bench line.  Weak scaling: every rank gets its own C3-sized region set; regions never
+span ranks, the only collective is the final gather of candidate records to rank 0 (RCCL).
+
+Prints ONE JSON line on rank 0 (see the driver contract): value = candidate sites (pileup columns
+evaluated) per second, whole job, over the full step time; roofline = the pileup kernel's
+algorithmic bytes / its HIP-event time; cpu_baseline = the CPU oracle (a C++ restatement of the
+reference, NOT the Rust binary) timed on a bounded sample of the same workload, rank 0 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def tile_batch(base, copies, gap=1000):
+    """Replicate a ReadBatch `copies` times at shifted coordinates (synthetic-data generation speed)."""
+    from longcallr_amd import _abi
+    if copies == 1:
+        return base
+    span = int(base.start0[-1] + base.len[-1] - base.start0[0]) + gap
+    rep = lambda a: np.concatenate([a] * copies)
+    shift_r = np.repeat(np.arange(copies, dtype=np.int64) * span, base.n_reads)
+    shift_g = np.repeat(np.arange(copies, dtype=np.int64) * span, base.n_regions)
+    nb, nc = int(base.bases.size), int(base.cigar.size)
+    rb = np.concatenate([base.read_begin[:-1] + k * base.n_reads for k in range(copies)] + [[copies * base.n_reads]])
+    return _abi.ReadBatch(
+        pos=(rep(base.pos).astype(np.int64) + shift_r), seq_len=rep(base.seq_len), lead_clip=rep(base.lead_clip),
+        trail_clip=rep(base.trail_clip), flags=rep(base.flags),
+        seq_off=rep(base.seq_off) + np.repeat(np.arange(copies, dtype=np.uint64) * np.uint64(nb), base.n_reads),
+        cig_off=rep(base.cig_off) + np.repeat(np.arange(copies, dtype=np.uint64) * np.uint64(nc), base.n_reads),
+        n_cig=rep(base.n_cig), bases=rep(base.bases), quals=rep(base.quals), cigar=rep(base.cigar),
+        start0=rep(base.start0) + shift_g, len=rep(base.len), read_begin=rb, ref=rep(base.ref))
+
+
+def to_device(batch, torch, dev):
+    from longcallr_amd import _abi
+    t = {}
+    for f in batch.FIELDS + ["start0", "len", "col_off", "read_begin", "ref"]:
+        a = getattr(batch, f)
+        if a.dtype == np.uint64:
+            a = a.view(np.int64)
+        elif a.dtype == np.uint32:
+            a = a.view(np.int32)
+        t[f] = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    reads, regions = batch.c_reads(), batch.c_regions()
+    reads.mem = regions.mem = _abi.LCR_MEM_DEVICE
+    for f in batch.FIELDS:
+        setattr(reads, f, C.c_void_p(t[f].data_ptr()))
+    for f in ["start0", "len", "col_off", "read_begin", "ref"]:
+        setattr(regions, f, C.c_void_p(t[f].data_ptr()))
+    return reads, regions, t
+
+
+def cpu_baseline(batch, params, budget_s=15.0):
+    """Oracle (kind 'port': C++ restatement of the reference's scalar loops, 1 thread) on the first
+    regions of the same batch until ~budget_s of CPU time has been spent."""
+    from oracle import orc
+    orc.build()
+    cols = reads = 0
+    t0 = time.perf_counter()
+    g = 0
+    while g < batch.n_regions and (time.perf_counter() - t0 < budget_s or g < 2):
+        R = orc.Region(batch, g, params)
+        R.run_all(orc.MODE_F64)  # reference-order f64 arithmetic with libm per observation
+        cols += int(batch.len[g])
+        reads += int(batch.read_begin[g + 1] - batch.read_begin[g])
+        g += 1
+    dt = time.perf_counter() - t0
+    return dict(value=cols / dt, unit="candidate_sites/s", cores=1, kind="port",
+                sample="first %d of %d regions of the rank-0 batch (%d columns, %d reads), full hot path, %.1f s"
+                       % (g, batch.n_regions, cols, reads, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--profile", default="ont-cdna")
+    ap.add_argument("--genes", type=int, default=400)
+    ap.add_argument("--unique-genes", type=int, default=50)
+    ap.add_argument("--gene-len", type=int, default=25000)
+    ap.add_argument("--depth", type=float, default=40.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    a = ap.parse_args()
+
+    import torch
+    from longcallr_amd import _abi, api, synth, shard
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP GPU (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    copies = max(1, a.genes // a.unique_genes)
+    base = synth.make_batch(a.profile, n_genes=a.unique_genes, gene_len=a.gene_len, depth=a.depth, seed=1000 + rank)
+    batch = tile_batch(base, copies)
+    params = _abi.make_params(synth.preset_for(a.profile), seed=2025)
+    reads, regions, keep = to_device(batch, torch, dev)
+    torch.cuda.synchronize()
+
+    E = api.Engine(local, params, timing=True)
+    E.set_stream(torch.cuda.current_stream().cuda_stream)  # torch.cuda.synchronize() then covers liblcr
+
+    def step():
+        E.load_batch((reads, regions, keep))
+        E.fill_data_into_freq_vec()
+        t_pile = E.kernel_ms(_abi.K_PILEUP)
+        E.get_candidate_snps().get_fragments().phase()
+        if dist is not None:
+            shard.gather_records(E.candidates()[0], dist, device=dev)
+        return t_pile
+
+    for _ in range(a.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pile_ms = []
+    for _ in range(a.steps):
+        pile_ms.append(step())
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # stage breakdown (untimed extra pass, HIP events on the ctx stream)
+    E.load_batch((reads, regions, keep))
+    ts = time.perf_counter(); E.fill_data_into_freq_vec().get_candidate_snps(); E.sync(); t_call = time.perf_counter() - ts
+    ts = time.perf_counter(); E.get_fragments().phase(); E.sync(); t_phase = time.perf_counter() - ts
+    fm = E.fragmat()
+    n_phased = int(fm["row_for_phasing"].sum())
+    cands = E.candidates()[0]
+    kms = {n: E.kernel_ms(k) for n, k in (("k0_spans", _abi.K_SPANS), ("k1_pileup", _abi.K_PILEUP),
+                                          ("k2_filter", _abi.K_CAND_FILTER), ("k2_hist", _abi.K_CAND_HIST),
+                                          ("k2_gt", _abi.K_CAND_GT), ("k3_count", _abi.K_FRAG_COUNT),
+                                          ("k3_fill", _abi.K_FRAG_FILL))}
+
+    if rank == 0:
+        cols = int(batch.col_off[-1])
+        pbytes = E.pileup_bytes()
+        avg_ms = float(np.mean(pile_ms))
+        achieved = pbytes / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "candidate_sites_per_sec", "value": cols * world * a.steps / dt, "unit": "sites/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 in, u32 counts, f64 likelihoods, i64 fixed-point phase scores", "data": "synthetic",
+            "config": {"workload": "C3: synthetic ONT-cDNA, %d regions x %d bp, %.0fx mean aligned depth per GPU "
+                                   "(%d unique genes tiled x%d), preset %s; step = bind+pileup+candidates+fragments+phase"
+                                   % (batch.n_regions, a.gene_len, a.depth, a.unique_genes, copies, synth.preset_for(a.profile)),
+                       "columns_per_gpu": cols, "aligned_bases_per_gpu": int(batch.bases.size), "reads_per_gpu": batch.n_reads,
+                       "candidates_per_gpu": int(cands.size), "fragment_nnz_per_gpu": int(fm["col"].size),
+                       "parallelism": "regions sharded over %d GPU(s), gather to rank 0" % world},
+            "roofline": {"bound": "hbm", "kernel": "k1_pileup", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None, "algorithmic_bytes": pbytes, "avg_ms": avg_ms},
+            "stages": {"pileup_plus_candidates_s": t_call, "fragments_plus_phase_s": t_phase,
+                       "sites_per_sec_pileup_gt": cols / t_call, "phased_reads_per_sec": n_phased / t_phase,
+                       "kernel_ms": kms},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batch, params, a.cpu_budget)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
