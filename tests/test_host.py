@@ -1,0 +1,93 @@
+"""Host logic: BAM decode, region discovery, synthetic generator invariants, LPT sharding, and the
+N > 1 gather path on gloo (world_size 2, CPU)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from longcallr_amd import _abi, bamio, shard, synth
+
+
+def test_demo_bam_decode():
+    refs, recs = bamio.read_bam(os.path.join(helpers.GOLDEN, "demo.bam"))
+    assert len(recs) == 1713 and refs[recs[0]["ref_id"]] == ("chr20", 64444167)
+    keep = [r for r in recs if bamio.passes_filter(r)]
+    assert len(keep) == 1697
+    assert all(r["ts"] == 1 and r["de"] is not None and not (r["flag"] & 16) for r in keep)
+    regs = bamio.discover_regions(keep, keep[0]["ref_id"], 64444167)
+    assert regs == [(16729960, 13256, 1649)]
+    b = helpers.demo_batch()
+    ops, lens = b.cigar & 15, b.cigar >> 4
+    assert int(lens[np.isin(ops, [0, 7, 8])].sum()) == 2162368  # aligned bases
+    assert int(b.seq_len.sum()) == b.bases.size == b.quals.size
+
+
+@pytest.mark.parametrize("profile", ["ont-cdna", "masseq", "ont-drna"])
+def test_synthetic_batches_are_well_formed(profile):
+    b = synth.make_batch(profile, n_genes=3, gene_len=7000, depth=20, seed=9)
+    assert b.quals.min() >= 1 and set(np.unique(b.bases)) <= set(b"ACGT")
+    cig_read = np.repeat(np.arange(b.n_reads), b.n_cig)
+    ops, lens = b.cigar & 15, (b.cigar >> 4).astype(np.int64)
+    qlen = np.bincount(cig_read, weights=np.where(np.isin(ops, [0, 1, 4, 7, 8]), lens, 0), minlength=b.n_reads)
+    assert np.array_equal(qlen.astype(np.int64), b.seq_len.astype(np.int64))
+    rlen = np.bincount(cig_read, weights=np.where(np.isin(ops, [0, 2, 3, 7, 8]), lens, 0), minlength=b.n_reads)
+    for g in range(b.n_regions):
+        s = slice(int(b.read_begin[g]), int(b.read_begin[g + 1]))
+        assert np.all(np.diff(b.pos[s]) >= 0)
+        assert b.pos[s].min() >= b.start0[g] and (b.pos[s] + rlen[s]).max() <= b.start0[g] + b.len[g]
+    depth = lens[np.isin(ops, [0, 7, 8])].sum() / b.col_off[-1]
+    assert 0.6 * 20 < depth < 1.6 * 20
+
+
+def test_lpt_assignment_is_balanced_and_deterministic():
+    costs = [9, 7, 6, 5, 5, 4, 3, 1]
+    own = shard.assign_regions(costs, 3)
+    assert sorted(sum(own, [])) == list(range(8)) and own == shard.assign_regions(costs, 3)
+    loads = [sum(costs[i] for i in o) for o in own]
+    assert max(loads) - min(loads) <= max(costs)
+    assert shard.assign_regions([], 2) == [[], []]
+
+
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rec = np.zeros(3 + 2 * rank, dtype=_abi.CAND_DTYPE)
+    rec["pos"] = np.arange(rec.size) + 100 * rank
+    rec["region"] = rank
+    rec["qual"] = 1.5 + rank
+    out = shard.gather_records(rec, dist)
+    if rank == 0:
+        q.put((out["pos"].tolist(), out["region"].tolist(), out["qual"].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_records_gloo_world2():
+    """The only collective of the path: variable-length gather of result records to rank 0."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    pos, region, qual = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert pos == [0, 1, 2, 100, 101, 102, 103, 104] and region == [0] * 3 + [1] * 5
+    assert qual == [1.5] * 3 + [2.5] * 5
+
+
+def test_vcf_formatter_matches_oracle_text(orc):
+    """longcallr_amd.vcf (product formatter) on oracle candidates == the oracle's own text."""
+    from longcallr_amd import vcf
+    p = _abi.make_params("hifi-masseq")
+    R = orc.Region(helpers.demo_batch(), 0, p).run_all(orc.MODE_EXACT)
+    assert vcf.format_records(R.cands(), "chr20", p.min_phase_score) == R.vcf_text("chr20")
+    b = synth.make_batch("ont-drna", n_genes=1, gene_len=12000, depth=30, seed=2)
+    p = _abi.make_params("ont-drna")
+    R = orc.Region(b, 0, p).run_all(orc.MODE_EXACT)
+    assert vcf.format_records(R.cands(), "c", p.min_phase_score) == R.vcf_text("c")
