@@ -1,46 +1,120 @@
-// k1_pileup.hip — K0 (read spans) and K1 (pileup tally) for gfx950.
+// k1_pileup.hip — K0 (CIGAR binning) and K1 (pileup tally) for gfx950.
 //
 // K1 replaces Profile::fill_data_into_freq_vec (reference src/util.rs:621-949).
 //
-// Design: column-tile gather.  One workgroup owns LCR_TILE consecutive pileup
-// columns of one region and keeps every counter of those columns in LDS; each wave64 takes reads
-// that overlap the tile, scans their CIGAR 64 ops at a time (wave prefix sums give every op's
-// reference/query start) and
-//   * turns D / N runs and whole M blocks into +1/-1 *difference-array* updates (2 LDS atomics per
-//     op instead of one per base; prefix-scanned once at the end of the tile),
-//   * streams the aligned read bases against the tile's reference bytes held in LDS: a base that
-//     equals the reference byte and is not near a read end needs no further work (its count is
-//     "depth - mismatches"); only mismatching, masked (poly-A / homopolymer / ONT end-trim) and
-//     non-ACGT bases — a few % of the stream — touch per-column counters.
-// All arithmetic is u32 adds => results are bit-exact regardless of order.  HBM traffic is the
-// read bases once (each base belongs to exactly one tile), the CIGAR words of overlapping reads,
-// and one coalesced write of the 13 count planes.
+// Design: column-tile gather fed by a work list.
+//   K0  one wave64 per read scans the CIGAR 64 ops at a time (wave prefix sums give every op's
+//       reference / query start) and
+//         * turns every intron (N) run into a +1/-1 pair in a global difference array (prefix-
+//           scanned once per batch): introns dominate coverage (mean intron depth 1190 vs allele
+//           depth 163 on demo.bam) but need no per-tile work at all,
+//         * emits one work item (read, first op of the 64-op chunk, column / read offset there)
+//           for every pileup tile that the chunk touches with an M / D / I op; items are counting-
+//           sorted by tile (count pass -> scan -> fill pass).
+//   K1  one workgroup (16 wave64) owns LCR_TILE consecutive columns of one region and keeps every
+//       counter of those columns in LDS.  Each wave pulls 64 items at a time (coalesced), prefetches
+//       their read headers lane-parallel, then for each item re-scans the 64-op chunk and
+//         * turns D runs and whole M blocks into +1/-1 difference-array updates in LDS (2 atomics
+//           per op instead of one per base; prefix-scanned at the end of the tile),
+//         * streams the aligned read bases against the tile's reference bytes held in LDS: a base
+//           equal to the reference byte and not near a read end needs no further work (its count is
+//           "depth - mismatches"); only mismatching, masked (poly-A / homopolymer / ONT end-trim)
+//           and non-ACGT bases — a few % of the stream — touch per-column counters.
+// All arithmetic is u32 adds => results are bit-exact regardless of order.  HBM traffic: the read
+// bases once (each base belongs to exactly one tile), CIGAR words (K0 twice + once per item), the
+// work items, and one coalesced write of the 13 count planes.  Base qualities are NOT read here:
+// they are only needed at the < 1 % of columns that survive the count filters (k2_hist).
+#include <climits>
+
 #include "lcr_dev.h"
 
-// ---------------------------------------------------------------------------------------------
-// K0: per read reference span + per region max span; validates CIGAR ops.
-__global__ void __launch_bounds__(LCR_BLOCK) k0_spans(BatchView b) {
-  int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= b.n_reads) return;
-  const uint32_t* cg = b.cigar + b.cig_off[r];
-  const uint32_t n = b.n_cig[r];
-  int32_t span = 0;
-  bool bad = false;
-  for (uint32_t i = 0; i < n; i++) {
-    uint32_t op = cg[i] & 15u, len = cg[i] >> 4;
-    // M,=,X,D,N consume reference; I,S,H do not; anything else is the reference's panic branch
-    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += (int32_t)len;
-    else if (!(op == 1 || op == 4 || op == 5)) bad = true;
+#define K1_THREADS 512
+#define K1_CPT (LCR_TILE / K1_THREADS)  // columns per thread in the tile epilogue
+#define K1_STAGE 2048  // bytes of read bases staged per wave and pass
+#define K1_WAVES (K1_THREADS / 64)
+
+// wave64 inclusive add-scan with DPP row shifts / row broadcasts (6 VALU ops, no LDS round trips).
+// update_dpp(old = 0, ..., bound_ctrl = false): lanes without a source keep 0, the identity.
+__device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+__device__ __forceinline__ int wave_incl_max(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(v, d, 64);
+    if (lane >= d) v = max(v, t);
   }
-  b.ref_end[r] = b.pos[r] + span;
-  if (bad) atomicExch(b.error_flag, 1);
-  int g = region_of_read(b.read_begin, b.n_regions, r);
-  atomicMax(&b.region_max_span[g], span);
+  return v;
 }
 
-void launch_k0_spans(const BatchView& b, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------
+// K0: one wave per read.  pass 0: validate ops, intron difference array, items per tile.
+//                          pass 1: write the items (slot = atomic counter per tile).
+__global__ void __launch_bounds__(LCR_BLOCK)
+k0_bin(BatchView b, int pass, int32_t* __restrict__ tile_count, const int32_t* __restrict__ tile_off,
+       int32_t* __restrict__ tile_fill, WorkItem* __restrict__ items, uint32_t* __restrict__ ndiff) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (LCR_BLOCK / 64) + (threadIdx.x >> 6);
+  if (r >= b.n_reads) return;
+  const int g = region_of_read(b.read_begin, b.n_regions, r);
+  const int vec = b.len[g];
+  const int64_t gbase = b.col_off[g] + g;  // one spare slot per region so that end markers never leak
+  const int ftile = b.region_first_tile[g];
+  const uint32_t ncig = b.n_cig[r];
+  const uint32_t* __restrict__ cg = b.cigar + b.cig_off[r];
+  const int lead = b.lead[r];
+  int ref_cur = (int)((int64_t)b.pos[r] - b.start0[g]);
+  int q_cur = lead > 0 ? lead : 0;
+  for (uint32_t c0 = 0; c0 < ncig; c0 += 64) {
+    if (ref_cur > vec && pass == 1) break;  // nothing at or right of column vec contributes
+    const bool act = c0 + lane < ncig;
+    const uint32_t word = act ? cg[c0 + lane] : 0u;
+    const int op = word & 15, len = (int)(word >> 4);
+    const bool is_m = act && (op == 0 || op == 7 || op == 8);
+    const bool is_d = act && op == 2, is_n = act && op == 3, is_i = act && op == 1;
+    if (pass == 0 && act && !(is_m || is_d || is_n || is_i || op == 4 || op == 5)) atomicExch(b.error_flag, 1);
+    const int dr = (is_m || is_d || is_n) ? len : 0;
+    const int dq = (is_m || is_i) ? len : 0;
+    const int ir = wave_incl_scan(dr, lane), iq = wave_incl_scan(dq, lane);
+    const int rs = ref_cur + ir - dr;
+    const int a = max(rs, 0), e = min(rs + len, vec);
+    if (pass == 0 && is_n && e > a) {  // util.rs:930-942
+      atomicAdd(&ndiff[gbase + a], 1u);
+      atomicAdd(&ndiff[gbase + e], 0xFFFFFFFFu);
+    }
+    int tlo = 0, thi = -1;
+    if ((is_m || is_d) && len > 0 && e > a) { tlo = a / LCR_TILE; thi = (e - 1) / LCR_TILE; }
+    else if (is_i && len > 0 && rs >= 1 && rs < vec) { tlo = thi = (rs - 1) / LCR_TILE; }  // util.rs:918-929
+    int prevmax = wave_incl_max(thi, lane);
+    prevmax = __shfl_up(prevmax, 1, 64);
+    if (lane == 0) prevmax = -1;
+    const int first = max(tlo, prevmax + 1);
+    for (int t = first; t <= thi; t++) {  // tiles this lane is the first in the chunk to touch
+      if (pass == 0) atomicAdd(&tile_count[ftile + t], 1);
+      else {
+        const int slot = atomicAdd(&tile_fill[ftile + t], 1);
+        WorkItem it;
+        it.read = (uint32_t)r; it.c0 = c0; it.ref_cur = ref_cur; it.q_cur = q_cur;
+        items[tile_off[ftile + t] + slot] = it;
+      }
+    }
+    ref_cur += __shfl(ir, 63, 64);
+    q_cur += __shfl(iq, 63, 64);
+  }
+}
+
+void launch_k0_bin(const BatchView& b, int pass, int32_t* tile_count, const int32_t* tile_off, int32_t* tile_fill,
+                   WorkItem* items, uint32_t* ndiff, hipStream_t s) {
   if (b.n_reads == 0) return;
-  hipLaunchKernelGGL(k0_spans, dim3((b.n_reads + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, b);
+  const int per = LCR_BLOCK / 64;
+  hipLaunchKernelGGL(k0_bin, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, pass, tile_count, tile_off,
+                     tile_fill, items, ndiff);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -50,7 +124,6 @@ enum {
   P_DIFF_DEPTH_R,      //                   ... of reverse reads
   P_DIFF_TS0,          // difference array: transcript_strands[0]
   P_DIFF_TS1,          //                   transcript_strands[1]
-  P_DIFF_N,            // intron runs
   P_DIFF_D,            // deletion runs
   P_NI,                // insertions (plain counter)
   P_MM_F,              // 4 planes: mismatching base counts A,C,G,T of forward reads
@@ -59,17 +132,8 @@ enum {
 };
 #define TSTRIDE (LCR_TILE + 1)
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int t = __shfl_up(v, d, 64);
-    if (lane >= d) v += t;
-  }
-  return v;
-}
-
-// inclusive block scan (256 threads) of one int per thread; returns inclusive value
-__device__ __forceinline__ int block_incl_scan(int v, int* wsum /* 4 ints of LDS */) {
+// inclusive scan of one int per thread over the whole block
+__device__ __forceinline__ int block_incl_scan(int v, int* wsum /* K1_WAVES ints of LDS */) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int s = wave_incl_scan(v, lane);
   if (lane == 63) wsum[w] = s;
@@ -80,23 +144,37 @@ __device__ __forceinline__ int block_incl_scan(int v, int* wsum /* 4 ints of LDS
   return s + add;
 }
 
-__global__ void __launch_bounds__(LCR_BLOCK)
+__global__ void __launch_bounds__(K1_THREADS)
 k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0,
-          int64_t n_cols, uint32_t* __restrict__ planes) {
+          int64_t n_cols, const int32_t* __restrict__ tile_off, const WorkItem* __restrict__ items,
+          const int32_t* __restrict__ nscan, uint32_t* __restrict__ planes) {
   __shared__ uint32_t pl[P_NPL * TSTRIDE];
-  __shared__ uint8_t refl[LCR_TILE];
-  __shared__ int wsum[4];
+  __shared__ __attribute__((aligned(16))) uint8_t refl[LCR_TILE];
+  __shared__ int wsum[K1_WAVES];
+  __shared__ uint4 stage_all[K1_WAVES][K1_STAGE / 16];  // per-wave staging buffer of read bases
+  __shared__ int lookup_all[K1_WAVES][128];             // per-wave op-start histograms (byte 0 / byte 3)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = tile_region[blockIdx.x];
   const int tc0 = tile_col0[blockIdx.x];               // first column of the tile inside the region
   const int vec = b.len[g];
   const int tlen = min(LCR_TILE, vec - tc0);
-  const int64_t start0 = b.start0[g];
   const int64_t gcol0 = b.col_off[g] + tc0;            // global column of tile column 0
 
-  for (int i = tid; i < P_NPL * TSTRIDE; i += LCR_BLOCK) pl[i] = 0;
-  for (int i = tid; i < LCR_TILE; i += LCR_BLOCK) {
+  const int i0 = tile_off[blockIdx.x], i1 = tile_off[blockIdx.x + 1];
+  if (i0 == i1 && prm.dbg != 4) {
+    // no M / D / I op touches this tile (pure intron or uncovered): every plane is 0 except the
+    // intron plane, which comes from the global scan.  Most tiles of a spliced data set are like this.
+    for (int col = tid; col < tlen; col += K1_THREADS) {
+      const int64_t o = gcol0 + col;
+#pragma unroll
+      for (int k = 0; k < LCR_NPLANES; k++) planes[(int64_t)k * n_cols + o] = 0u;
+      planes[(int64_t)LCR_PL_N * n_cols + o] = (uint32_t)nscan[o + g + 1];
+    }
+    return;
+  }
+  for (int i = tid; i < P_NPL * TSTRIDE; i += K1_THREADS) pl[i] = 0;
+  for (int i = tid; i < LCR_TILE; i += K1_THREADS) {
     uint8_t R = i < tlen ? b.ref[gcol0 + i] : 0;
     // only upper-case ACGT can equal a read base (htslib decodes to upper case); anything else is
     // stored as 0xFF so that every base at such a column takes the explicit-count path
@@ -104,48 +182,41 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   }
   __syncthreads();
 
-  // reads of region g that can overlap tile columns [tc0, tc0+tlen): pos < t1 and ref_end > t0
-  const int rb = b.read_begin[g], re = b.read_begin[g + 1];
-  const int64_t t0 = start0 + tc0, t1 = t0 + tlen;     // absolute reference interval of the tile
-  const int64_t lo_pos = t0 - (int64_t)b.region_max_span[g];
-  int r_lo, r_hi;
-  {
-    int lo = rb, hi = re;  // first read with pos >= lo_pos
-    while (lo < hi) { int mid = (lo + hi) >> 1; if ((int64_t)b.pos[mid] >= lo_pos) hi = mid; else lo = mid + 1; }
-    r_lo = lo;
-    lo = rb; hi = re;      // first read with pos > t1 (a read starting at t1 with a leading insertion
-                           // still adds `ni` to the tile's last column)
-    while (lo < hi) { int mid = (lo + hi) >> 1; if ((int64_t)b.pos[mid] > t1) hi = mid; else lo = mid + 1; }
-    r_hi = lo;
-  }
-
   const int D = prm.dist_to_end, L = prm.polya_len;
 
-  for (int r = r_lo + wave; r < r_hi; r += LCR_BLOCK / 64) {
-    const int rend = b.ref_end[r];
-    if ((int64_t)rend < t0) continue;
-    const int rpos = b.pos[r];
-    const uint32_t ncig = b.n_cig[r];
-    const uint32_t* __restrict__ cg = b.cigar + b.cig_off[r];
-    const uint8_t* __restrict__ seq = b.bases + b.seq_off[r];
-    const int seq_len = b.seq_len[r];
-    const int lead = b.lead[r];
-    const int reb = seq_len - b.trail[r];
-    const uint8_t fl = b.flags[r];
-    const int strand = fl & 1;
-    const int ts = (fl >> 1) & 3;
-    // transcript_strands index (util.rs:803-819): (+,+)->0 (+,-)->1 (-,+)->1 (-,-)->0, none -> -1
-    const int tsidx = ts == 0 ? -1 : ((strand == 0) == (ts == 1) ? 0 : 1);
-    uint32_t* depth_pl = pl + (strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
-    uint32_t* ts_pl = pl + (tsidx == 1 ? P_DIFF_TS1 : P_DIFF_TS0) * TSTRIDE;
-    uint32_t* mm_pl = pl + (strand ? P_MM_R : P_MM_F) * TSTRIDE;
+  // items are dealt round-robin to the 16 waves (item i -> wave i % 16) so that a tile with a few
+  // hundred items keeps every wave busy; each wave fetches 64 of its items at a time, lane-parallel
+  for (int ibase = i0; ibase < i1 && prm.dbg != 3; ibase += K1_WAVES * 64) {
+    const int avail = min(i1 - ibase, K1_WAVES * 64) - wave;             // items from ibase+wave on
+    const int n_here = avail > 0 ? (avail + K1_WAVES - 1) / K1_WAVES : 0;  // ... taking every 16th
+    // lane-parallel fetch of up to 64 items and of their read headers
+    WorkItem my; my.read = 0; my.c0 = 0; my.ref_cur = 0; my.q_cur = 0;
+    if (lane < n_here) my = items[ibase + wave + K1_WAVES * lane];
+    const uint32_t rr = my.read;
+    const uint32_t h_ncig = b.n_cig[rr];
+    const unsigned long long h_cig = b.cig_off[rr], h_seq = b.seq_off[rr];
+    const int h_len = b.seq_len[rr], h_lead = b.lead[rr], h_trail = b.trail[rr];
+    const int h_fl = b.flags[rr];
+    for (int k = 0; k < n_here && prm.dbg != 2; k++) {
+      const uint32_t c0 = __shfl(my.c0, k, 64);
+      const uint32_t ncig = __shfl(h_ncig, k, 64);
+      const uint32_t* __restrict__ cg = b.cigar + __shfl(h_cig, k, 64);
+      const uint8_t* __restrict__ seq = b.bases + __shfl(h_seq, k, 64);
+      const int seq_len = __shfl(h_len, k, 64);
+      const int lead = __shfl(h_lead, k, 64);
+      const int reb = seq_len - __shfl(h_trail, k, 64);
+      const int fl = __shfl(h_fl, k, 64);
+      const int ref_cur = __shfl(my.ref_cur, k, 64) - tc0;  // tile-relative column at op c0
+      const int q_cur = __shfl(my.q_cur, k, 64);
+      const int strand = fl & 1;
+      const int ts = (fl >> 1) & 3;
+      // transcript_strands index (util.rs:803-819): (+,+)->0 (+,-)->1 (-,+)->1 (-,-)->0, none -> -1
+      const int tsidx = ts == 0 ? -1 : ((strand == 0) == (ts == 1) ? 0 : 1);
+      uint32_t* depth_pl = pl + (strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
+      uint32_t* ts_pl = pl + (tsidx == 1 ? P_DIFF_TS1 : P_DIFF_TS0) * TSTRIDE;
+      uint32_t* mm_pl = pl + (strand ? P_MM_R : P_MM_F) * TSTRIDE;
 
-    int ref_cur = rpos - (int)(start0 + tc0);  // tile-relative column of the next reference base
-    int q_cur = lead > 0 ? lead : 0;           // util.rs:686-690
-    for (uint32_t c0 = 0; c0 < ncig; c0 += 64) {
-      if (ref_cur > tlen) break;               // nothing further right contributes (an insertion that
-                                               // starts exactly at column tlen still counts on tlen-1)
-      uint32_t word = (c0 + lane < ncig) ? cg[c0 + lane] : 0u;
+      const uint32_t word = (c0 + lane < ncig) ? cg[c0 + lane] : 0u;
       const int op = word & 15, len = (int)(word >> 4);
       const bool is_m = (op == 0 || op == 7 || op == 8) && len > 0;
       const bool is_dn = (op == 2 || op == 3) && len > 0;
@@ -154,15 +225,12 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
       const int ir = wave_incl_scan(dr, lane), iq = wave_incl_scan(dq, lane);
       const int rs = ref_cur + ir - dr;        // tile-relative column where this op starts
       const int qs = q_cur + iq - dq;          // read offset where this op starts
-      ref_cur += __shfl(ir, 63, 64);
-      q_cur += __shfl(iq, 63, 64);
 
       // clip the op's column range to the tile
-      int a = max(rs, 0), e = min(rs + len, tlen);
-      if (is_dn && e > a) {  // util.rs:905-917 (D) / 930-942 (N): +1 per reference position
-        uint32_t* dp = pl + (op == 3 ? P_DIFF_N : P_DIFF_D) * TSTRIDE;
-        atomicAdd(&dp[a], 1u);
-        atomicAdd(&dp[e], 0xFFFFFFFFu);
+      const int a = max(rs, 0), e = min(rs + len, tlen);
+      if (op == 2 && len > 0 && e > a) {  // util.rs:905-917: +1 per deleted reference position
+        atomicAdd(&pl[P_DIFF_D * TSTRIDE + a], 1u);
+        atomicAdd(&pl[P_DIFF_D * TSTRIDE + e], 0xFFFFFFFFu);
       }
       if (op == 1 && len > 0) {  // util.rs:918-929: counted on the previous column, 1 <= p < vec
         const int p = rs + tc0;  // pos_in_freq_vec
@@ -174,53 +242,128 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
         atomicAdd(&depth_pl[e], 0xFFFFFFFFu);
         if (tsidx >= 0) { atomicAdd(&ts_pl[a], 1u); atomicAdd(&ts_pl[e], 0xFFFFFFFFu); }
       }
-      // stream the bases of every M block that intersects the tile
-      unsigned long long mmask = __ballot(m_hit);
-      while (mmask) {
-        const int j = __ffsll((long long)mmask) - 1;
-        mmask &= mmask - 1;
-        const int ja = __shfl(a, j, 64), je = __shfl(e, j, 64);
-        const int jq = __shfl(qs, j, 64) - __shfl(rs, j, 64);  // read offset = column + jq
-        for (int col = ja + lane; col < je; col += 64) {
-          const int c = col + jq;
-          const uint8_t base = seq[c];
-          const uint8_t R = refl[col];
-          const bool zone = in_end_zone(c, lead, reb, D);
-          if (base == R && !zone) continue;  // fast path: plain reference match
-          bool masked = false;
-          if (zone) masked = prm.ont ? true : polya_masked(seq, seq_len, c, L, b.ref[gcol0 + col]);
-          if (masked) {  // contributes nothing (util.rs:801): undo the range update at this column
-            atomicAdd(&depth_pl[col], 0xFFFFFFFFu);
-            atomicAdd(&depth_pl[col + 1], 1u);
-            if (tsidx >= 0) { atomicAdd(&ts_pl[col], 0xFFFFFFFFu); atomicAdd(&ts_pl[col + 1], 1u); }
-          } else if (base != R) {
-            const int bi = base_code(base);
-            if (bi >= 0) atomicAdd(&mm_pl[bi * TSTRIDE + col], 1u);
-            else {  // "Invalid nucleotide base" (util.rs:890-892): no allele count, ts still counted
-              atomicAdd(&depth_pl[col], 0xFFFFFFFFu);
-              atomicAdd(&depth_pl[col + 1], 1u);
+      // stream the bases of every M block that intersects the tile.  The read range covered by
+      // the chunk inside this tile is contiguous in the read: stage it in LDS with 16-byte
+      // coalesced loads (1 KiB per wave instruction keeps enough bytes in flight for HBM), then
+      // compare per block from LDS.
+      const unsigned long long mmask0 = __ballot(m_hit);
+      if (mmask0 != 0ull && prm.dbg != 1) {
+        const int jlo = __ffsll((long long)mmask0) - 1, jhi = 63 - __clzll((long long)mmask0);
+        const int q_lo = __shfl(qs + (a - rs), jlo, 64), q_hi = __shfl(qs + (e - rs), jhi, 64);  // [q_lo, q_hi)
+        const long long seq_abs = (long long)__shfl(h_seq, k, 64);
+        for (long long w0 = (seq_abs + q_lo) & ~15ll; w0 < seq_abs + q_hi; w0 += K1_STAGE) {
+          const long long w1 = min(w0 + (long long)K1_STAGE, seq_abs + (long long)q_hi);
+          const int n16 = (int)((w1 - w0 + 15) >> 4);
+          for (int i = lane; i < n16; i += 64) {
+            const long long off = w0 + 16ll * i;
+            uint4 v;
+            if (off + 16 <= b.n_bases) v = *reinterpret_cast<const uint4*>(b.bases + off);
+            else {  // last partial 16 bytes of the whole base array
+              uint32_t t[4] = {0, 0, 0, 0};
+              for (int x = 0; x < 16; x++)
+                if (off + x < b.n_bases) t[x >> 2] |= (uint32_t)b.bases[off + x] << (8 * (x & 3));
+              v = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            stage_all[wave][i] = v;
+          }
+          __builtin_amdgcn_wave_barrier();
+          // Flattened walk: lane handles one staged dword = 4 consecutive read offsets.  The op that
+          // contains read offset c is the last op j of the chunk with qs_j <= c.  qs is non-decreasing
+          // over the lanes, so "number of ops with qs <= c" for all 64 dwords at once is a histogram
+          // of op start dwords (one LDS atomic per op) followed by a DPP prefix scan.
+          const int sbase = (int)(seq_abs - w0);                 // stage index of read offset c is c + sbase
+          const int n_dw = (int)((w1 - w0 + 3) >> 2);
+          const uint32_t* stage32 = reinterpret_cast<const uint32_t*>(stage_all[wave]);
+          const uint32_t* rl32 = reinterpret_cast<const uint32_t*>(refl);
+          int* hist = lookup_all[wave];
+          const int jqm = is_m ? (rs - qs) : INT_MIN;            // column = read offset + jqm for M ops
+          const int k0 = (qs + sbase + 3) >> 2;                  // first dword whose byte 0 is at/after qs
+          const int k3 = (qs + sbase) >> 2;                      // first dword whose byte 3 is at/after qs
+          for (int d0 = 0; d0 < n_dw; d0 += 64) {                // uniform trip count: shuffles stay convergent
+            const int d = d0 + lane;
+            const int cb = 4 * d - sbase;                        // read offset of byte 0 of this dword
+            const uint32_t basew = d < n_dw ? stage32[d] : 0u;
+            hist[lane] = 0; hist[64 + lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            const int base0 = __popcll(__ballot(k0 <= d0)), base3 = __popcll(__ballot(k3 <= d0));
+            if (k0 > d0 && k0 < d0 + 64) atomicAdd(&hist[k0 - d0], 1);
+            if (k3 > d0 && k3 < d0 + 64) atomicAdd(&hist[64 + k3 - d0], 1);
+            __builtin_amdgcn_wave_barrier();
+            const int lo0 = base0 + wave_incl_scan(hist[lane], lane) - 1;       // last op with qs <= cb
+            const int lo3 = base3 + wave_incl_scan(hist[64 + lane], lane) - 1;  // last op with qs <= cb + 3
+            const int dj0 = __shfl(jqm, max(lo0, 0), 64);
+            // which bytes need individual attention?
+            uint32_t slow = 0;  // bit i: byte i
+            if (d < n_dw && cb + 3 >= q_lo && cb < q_hi) {
+              const bool inside = cb >= q_lo && cb + 3 < q_hi;
+              if (inside && lo0 == lo3 && dj0 != INT_MIN) {      // 4 bytes of one M block
+                const int col = cb + dj0;
+                const uint32_t w_lo = rl32[col >> 2], w_hi = rl32[min((col >> 2) + 1, LCR_TILE / 4 - 1)];
+                const uint32_t x = __builtin_amdgcn_alignbyte(w_hi, w_lo, (uint32_t)(col & 3)) ^ basew;
+                const bool nearend = (cb < lead + D && cb + 3 > lead - D) || (cb < reb + D && cb + 3 > reb - D);
+                slow = nearend ? 15u : (((x & 0xffu) ? 1u : 0u) | ((x & 0xff00u) ? 2u : 0u) | ((x & 0xff0000u) ? 4u : 0u) |
+                                        ((x & 0xff000000u) ? 8u : 0u));
+              } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) if (cb + i >= q_lo && cb + i < q_hi) slow |= 1u << i;
+              }
+            }
+            const bool cross = __ballot(slow != 0 && lo0 != lo3) != 0ull;  // some dword spans two ops
+            if (prm.dbg == 5) slow = 0;
+            while (__ballot(slow != 0) != 0ull) {                           // uniform loop
+              const bool has = slow != 0;
+              const int i = has ? __ffs(slow) - 1 : 0;
+              slow &= slow - 1;
+              const int c = cb + i;
+              int lo = lo0;
+              if (cross) {                                                  // uniform branch
+                lo = 0;
+#pragma unroll
+                for (int st = 32; st >= 1; st >>= 1) { const int qt = __shfl(qs, lo + st, 64); if (qt <= c) lo += st; }
+              }
+              const int dj = __shfl(jqm, max(lo, 0), 64);                   // executed by all lanes
+              if (!has || dj == INT_MIN) continue;
+              const int col = c + dj;
+              const uint32_t base = (basew >> (8 * i)) & 0xffu;
+              const uint32_t R = refl[col];
+              const bool zone = in_end_zone(c, lead, reb, D);
+              if (base == R && !zone) continue;                            // plain reference match
+              bool masked = false;
+              if (zone) masked = prm.ont ? true : polya_masked(seq, seq_len, c, L, b.ref[gcol0 + col]);
+              // branch-free classification: 0..3 = mismatching A,C,G,T; otherwise undo depth (masked or non-ACGT)
+              const uint32_t h = (base >> 1) & 3u;
+              const uint32_t bi = h ^ (h >> 1);                             // A,C,G,T -> 0,1,2,3 (either case)
+              const bool acgt = ((base & 0xC0u) == 0x40u) && ((0x0010008Au >> (base & 31u)) & 1u);
+              if (!masked && acgt) {
+                if (base != R) atomicAdd(&mm_pl[bi * TSTRIDE + col], 1u);
+              } else {  // masked: contributes nothing (util.rs:801); non-ACGT: no allele count (util.rs:890-892)
+                atomicAdd(&depth_pl[col], 0xFFFFFFFFu);
+                atomicAdd(&depth_pl[col + 1], 1u);
+                if (masked && tsidx >= 0) { atomicAdd(&ts_pl[col], 0xFFFFFFFFu); atomicAdd(&ts_pl[col + 1], 1u); }
+              }
             }
           }
+          __builtin_amdgcn_wave_barrier();
         }
       }
     }
   }
   __syncthreads();
 
-  // prefix-scan the six difference arrays, 4 consecutive columns per thread
+  // prefix-scan the five difference arrays, K1_CPT consecutive columns per thread
   for (int p = P_DIFF_DEPTH_F; p <= P_DIFF_D; p++) {
     uint32_t* d = pl + p * TSTRIDE;
-    const int i0 = tid * 4;
-    int v0 = (int)d[i0], v1 = v0 + (int)d[i0 + 1], v2 = v1 + (int)d[i0 + 2], v3 = v2 + (int)d[i0 + 3];
-    int incl = block_incl_scan(v3, wsum);
-    int excl = incl - v3;
-    d[i0] = (uint32_t)(excl + v0); d[i0 + 1] = (uint32_t)(excl + v1);
-    d[i0 + 2] = (uint32_t)(excl + v2); d[i0 + 3] = (uint32_t)(excl + v3);
+    int v[K1_CPT], run = 0;
+#pragma unroll
+    for (int x = 0; x < K1_CPT; x++) { run += (int)d[tid * K1_CPT + x]; v[x] = run; }
+    const int excl = block_incl_scan(run, wsum) - run;
+#pragma unroll
+    for (int x = 0; x < K1_CPT; x++) d[tid * K1_CPT + x] = (uint32_t)(excl + v[x]);
     __syncthreads();
   }
 
-  // assemble the ABI planes and write them out (coalesced, one column per thread per pass)
-  for (int col = tid; col < tlen; col += LCR_BLOCK) {
+  // assemble the ABI planes and write them out (coalesced: consecutive threads, consecutive columns)
+  for (int col = tid; col < tlen; col += K1_THREADS) {
     const uint8_t R = refl[col];
     const int ri = R == 'A' ? 0 : R == 'C' ? 1 : R == 'G' ? 2 : R == 'T' ? 3 : -1;
     uint32_t f[4], rv[4];
@@ -241,7 +384,8 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
       planes[(int64_t)(LCR_PL_A + k) * n_cols + o] = f[k] + rv[k];
       planes[(int64_t)(LCR_PL_FWD_A + k) * n_cols + o] = f[k];
     }
-    planes[(int64_t)LCR_PL_N * n_cols + o] = pl[P_DIFF_N * TSTRIDE + col];
+    // intron plane: exclusive scan of the global difference array (one spare slot per region)
+    planes[(int64_t)LCR_PL_N * n_cols + o] = (uint32_t)nscan[o + g + 1];
     planes[(int64_t)LCR_PL_D * n_cols + o] = pl[P_DIFF_D * TSTRIDE + col];
     planes[(int64_t)LCR_PL_NI * n_cols + o] = pl[P_NI * TSTRIDE + col];
     planes[(int64_t)LCR_PL_TS_FWD * n_cols + o] = pl[P_DIFF_TS0 * TSTRIDE + col];
@@ -250,7 +394,9 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
 }
 
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
-                      int32_t n_tiles, int64_t n_cols, uint32_t* planes, hipStream_t s) {
+                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_off, const WorkItem* items,
+                      const int32_t* nscan, uint32_t* planes, hipStream_t s) {
   if (n_tiles == 0) return;
-  hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(LCR_BLOCK), 0, s, b, p, tile_region, tile_col0, n_cols, planes);
+  hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_off,
+                     items, nscan, planes);
 }

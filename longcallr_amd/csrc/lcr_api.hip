@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 #include "lcr_dev.h"
 #include "lcr_phase_host.h"
@@ -22,7 +23,8 @@ struct lcr_ctx {
   std::vector<int64_t> h_start0, h_col_off;
   std::vector<int32_t> h_len, h_read_begin, h_region_first_tile;
   DevBuf in_[16];  // device copies of host inputs (LCR_MEM_HOST)
-  DevBuf ref_end, max_span, errflag, tile_region, tile_col0;
+  DevBuf errflag, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_off, k0_tile_fill, k0_items, ndiff, nscan;
+  int64_t n_items = 0;
 
   // K1
   bool have_planes = false;
@@ -156,7 +158,8 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto& b : c->in_) b.release();
-  DevBuf* bufs[] = {&c->ref_end, &c->max_span, &c->errflag, &c->tile_region, &c->tile_col0, &c->planes, &c->flags,
+  DevBuf* bufs[] = {&c->errflag, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, &c->k0_tile_off,
+                    &c->k0_tile_fill, &c->k0_items, &c->ndiff, &c->nscan, &c->planes, &c->flags,
                     &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
                     &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
                     &c->row_links, &c->row_ptr, &c->col, &c->val};
@@ -231,7 +234,7 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   c->n_bases = rd->n_bases; c->n_cigar = rd->n_cigar;
 
   BatchView& b = c->bv;
-  b.n_reads = nr; b.n_regions = ng;
+  b.n_reads = nr; b.n_regions = ng; b.n_bases = rd->n_bases;
   int rc;
 #define UP(i, field, T, n) if ((rc = upload<T>(c, c->in_[i], (const T*)rd->field, (size_t)(n), (const T**)&b.field, mem))) return rc
   UP(0, pos, int32_t, nr); UP(1, seq_len, int32_t, nr);
@@ -261,13 +264,32 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
     HIPCHK(c, hipMemcpyAsync(c->tile_region.p, treg.data(), treg.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->tile_col0.p, tcol.data(), tcol.size() * 4, hipMemcpyHostToDevice, c->stream));
   }
-  HIPCHK(c, c->ref_end.reserve(std::max(nr, 1) * 4));
-  HIPCHK(c, c->max_span.reserve(std::max(ng, 1) * 4));
+  HIPCHK(c, c->first_tile.reserve((ng + 1) * 4));
+  HIPCHK(c, hipMemcpyAsync(c->first_tile.p, c->h_region_first_tile.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, c->errflag.reserve(4));
-  b.ref_end = c->ref_end.as<int32_t>(); b.region_max_span = c->max_span.as<int32_t>(); b.error_flag = c->errflag.as<int32_t>();
-  HIPCHK(c, hipMemsetAsync(b.region_max_span, 0, std::max(ng, 1) * 4, c->stream));
+  b.region_first_tile = c->first_tile.as<int32_t>(); b.error_flag = c->errflag.as<int32_t>();
   HIPCHK(c, hipMemsetAsync(b.error_flag, 0, 4, c->stream));
-  { Timer t(c, LCR_K_SPANS); launch_k0_spans(b, c->stream); }
+  // K0: bin 64-op CIGAR chunks into per-tile work items (count -> scan -> fill) and build the intron plane
+  const int nt = c->n_tiles;
+  const size_t nd = (size_t)c->n_cols + ng + 1;
+  HIPCHK(c, c->k0_tile_count.reserve((nt + 1) * 4));
+  HIPCHK(c, c->k0_tile_off.reserve((nt + 2) * 4));
+  HIPCHK(c, c->k0_tile_fill.reserve((nt + 1) * 4));
+  HIPCHK(c, c->ndiff.reserve(nd * 4));
+  HIPCHK(c, c->nscan.reserve(nd * 4));
+  HIPCHK(c, hipMemsetAsync(c->k0_tile_count.p, 0, (nt + 1) * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->k0_tile_fill.p, 0, (nt + 1) * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->ndiff.p, 0, nd * 4, c->stream));
+  int32_t n_items = 0;
+  { Timer t(c, LCR_K_SPANS);
+    launch_k0_bin(b, 0, c->k0_tile_count.as<int32_t>(), nullptr, nullptr, nullptr, c->ndiff.as<uint32_t>(), c->stream);
+    launch_scan_i32(c->k0_tile_count.as<int32_t>(), c->k0_tile_off.as<int32_t>(), nt, c->k0_tile_off.as<int32_t>() + nt, c->stream);
+    HIPCHK(c, hipMemcpyAsync(&n_items, c->k0_tile_off.as<int32_t>() + nt, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, c->k0_items.reserve(std::max<size_t>(n_items, 1) * sizeof(WorkItem)));
+    launch_k0_bin(b, 1, nullptr, c->k0_tile_off.as<int32_t>(), c->k0_tile_fill.as<int32_t>(), c->k0_items.as<WorkItem>(), nullptr, c->stream);
+    launch_scan_i32((const int32_t*)c->ndiff.p, c->nscan.as<int32_t>(), (int32_t)nd, nullptr, c->stream); }
+  c->n_items = n_items;
   int32_t bad = 0;
   HIPCHK(c, hipMemcpyAsync(&bad, b.error_flag, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));  // also keeps treg/tcol alive until copied
@@ -285,9 +307,11 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   static float sor_thr = -1.f;
   if (sor_thr < 0.f) sor_thr = lcr_device_sor_threshold(c->stream);
   c->dp = to_dev(p, sor_thr);
+  { const char* e = getenv("LCR_K1_DBG"); c->dp.dbg = e ? atoi(e) : 0; }
   HIPCHK(c, c->planes.reserve(std::max<size_t>((size_t)c->n_cols * LCR_NPLANES, 1) * 4));
   { Timer t(c, LCR_K_PILEUP);
     launch_k1_pileup(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), c->n_tiles, c->n_cols,
+                     c->k0_tile_off.as<int32_t>(), c->k0_items.as<WorkItem>(), c->nscan.as<int32_t>(),
                      c->planes.as<uint32_t>(), c->stream); }
   HIPCHK(c, hipGetLastError());
   // algorithmic bytes of this launch: bases once, CIGAR once, 32 B read header,

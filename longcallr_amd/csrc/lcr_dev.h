@@ -15,6 +15,7 @@
 // Device view of a bound batch (all pointers in HBM).
 struct BatchView {
   int32_t n_reads, n_regions;
+  int64_t n_bases;           // bytes in bases / quals
   const int32_t* pos;
   const int32_t* seq_len;
   const int32_t* lead;
@@ -31,12 +32,17 @@ struct BatchView {
   const int64_t* col_off;
   const int32_t* read_begin;
   const uint8_t* ref;
-  // derived by k0_spans
-  int32_t* ref_end;          // n_reads: pos + reference span
-  int32_t* region_max_span;  // n_regions
-  int32_t* error_flag;       // != 0 -> unknown CIGAR op seen
+  // derived by K0 (lcr_load_batch)
+  const int32_t* region_first_tile;  // n_regions+1: first pileup tile of each region
+  int32_t* error_flag;               // != 0 -> unknown CIGAR op seen
 };
 
+// One unit of pileup work: CIGAR ops [c0, c0+64) of read `read` touch the tile with at least one
+// M / D / I op.  ref_cur / q_cur are the region-relative column and the read offset at op c0.
+struct WorkItem {
+  uint32_t read, c0;
+  int32_t ref_cur, q_cur;
+};
 struct DevParams {
   int32_t ont;
   int32_t dist_to_end, polya_len;
@@ -44,6 +50,7 @@ struct DevParams {
   int32_t use_strand_bias;
   float min_af, min_af_intron, low_frac_cut;
   float sor_threshold;
+  int32_t dbg;  // ablation switches for profiling (LCR_K1_DBG), 0 in production
 };
 
 // pass-1 survivor of the candidate filters (one per column that reaches the likelihood block)
@@ -107,9 +114,12 @@ struct PhaseLutDev {
 };
 
 // ---- kernel launchers (defined in the .hip files) ----
-void launch_k0_spans(const BatchView& b, hipStream_t s);
+// K0: pass 0 counts work items per tile (+ intron difference array, CIGAR validation); pass 1 fills them
+void launch_k0_bin(const BatchView& b, int pass, int32_t* tile_count, const int32_t* tile_off, int32_t* tile_fill,
+                   WorkItem* items, uint32_t* ndiff, hipStream_t s);
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
-                      int32_t n_tiles, int64_t n_cols, uint32_t* planes, hipStream_t s);
+                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_off, const WorkItem* items,
+                      const int32_t* nscan, uint32_t* planes, hipStream_t s);
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, uint8_t* flags, int32_t* tile_count,
                       hipStream_t s);
