@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
         if verbose and out:
             print(out.decode(), file=sys.stderr)
     if force or procs or _stale(SO, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", SO] + objs
         subprocess.check_call(cmd)
     return SO
 

@@ -24,10 +24,16 @@
 // reference's call order implies, so restarts can run in parallel.
 #include <algorithm>
 #include <array>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <map>
 #include <set>
+#include <atomic>
+#include <functional>
+#include <thread>
 
 #include "lcr_phase_host.h"
 
@@ -540,6 +546,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
 #define PCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e_); return LCR_E_DEVICE; } } while (0)
   const int ng = in.n_regions, nrow = in.n_rows;
   const int64_t nnz = in.nnz;
+  const bool prof = getenv("LCR_PHASE_PROF") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) { if (!prof) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[phase] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
   std::vector<lcr_candidate>& cand = *in.cand;
   haplotag.assign(nrow, 0); assignment.assign(nrow, 0); phase_set.assign(nrow, 0); objective.assign(ng, 0.0);
   // host copy of the fragment matrix (needed by the LD-block pass and the post-phase epilogue)
@@ -554,20 +563,22 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   }
   if (nrow) PCHK(hipMemcpyAsync(links.data(), in.d_row_links, (size_t)nrow * 4, hipMemcpyDeviceToHost, stream));
   PCHK(hipStreamSynchronize(stream));
+  lap("d2h fragment matrix");
 
   std::vector<RegionHost> R(ng);
   std::vector<std::vector<std::vector<std::pair<int, uint8_t>>>> prows(ng);  // phase matrix rows per region
-  std::vector<RegionDev> rdev;
-  std::vector<int> slot_of(ng, -1);
-  std::vector<int32_t> h_prow_ptr, h_pcol, h_ccol_ptr, h_crow;
-  std::vector<uint8_t> h_pval, h_cval, h_fp, h_cons;
-  std::vector<int8_t> h_vt, h_delta0;
-  int32_t sig_total = 0, snp_total = 0, max_state = 0;
-  std::vector<int32_t> enum_slots, chain_slots;
   std::vector<std::vector<std::vector<int>>> ld_blocks(ng);
+  struct RegionBuild {  // per-region pieces, built in parallel, concatenated below
+    std::vector<int32_t> prow_ptr, pcol, ccol_ptr, crow;
+    std::vector<uint8_t> pval, cval, fp, cons;
+    std::vector<int8_t> vt, delta0;
+  };
+  std::vector<RegionBuild> RB(ng);
+  (void)hlut();
 
-  for (int g = 0; g < ng; g++) {
+  auto prep = [&](int g) {
     RegionHost& rh = R[g];
+    RegionBuild& rb = RB[g];
     rh.g = g; rh.c0 = in.cand_region_off[g]; rh.S = in.cand_region_off[g + 1] - rh.c0;
     rh.r0 = in.row_region_off[g]; rh.nrow = in.row_region_off[g + 1] - rh.r0;
     rh.row_ptr = row_ptr.data(); rh.col = col.data(); rh.val = val.data(); rh.links = links.data();
@@ -575,7 +586,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     rh.seed = region_seed(prm.seed, in.region_start0[g]);
     rh.min_linkers = prm.min_linkers;
     rh.e0 = nrow ? row_ptr[rh.r0] : 0;
-    if (rh.S == 0) continue;
+    if (rh.S == 0) return;
     const int64_t e1 = row_ptr[rh.r0 + rh.nrow];
     rh.phase_site.assign((size_t)(e1 - rh.e0), 0);
     rh.tag.assign(rh.nrow, 0); rh.asg.assign(rh.nrow, 0); rh.fp.assign(rh.nrow, 0);
@@ -597,103 +608,130 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
           if (rh.phase_site[e - rh.e0]) pr.back().push_back({rh.lc(e), (uint8_t)(val[e] & 63)});
       }
     }
-    // device slice of this region
+    int32_t acc = 0;
+    std::vector<int32_t> ccnt(rh.S + 1, 0);
+    for (auto& row : pr) {
+      rb.prow_ptr.push_back(acc);
+      for (auto& pe : row) { rb.pcol.push_back(pe.first); rb.pval.push_back(pe.second); ccnt[pe.first + 1]++; acc++; }
+    }
+    rb.prow_ptr.push_back(acc);
+    for (int i = 0; i < rh.S; i++) ccnt[i + 1] += ccnt[i];
+    rb.ccol_ptr.assign(ccnt.begin(), ccnt.end());
+    rb.crow.resize(acc); rb.cval.resize(acc);
+    std::vector<int32_t> fill(ccnt.begin(), ccnt.end() - 1);
+    for (size_t k = 0; k < pr.size(); k++)
+      for (auto& pe : pr[k]) { rb.crow[fill[pe.first]] = (int32_t)k; rb.cval[fill[pe.first]] = pe.second; fill[pe.first]++; }
+    rb.fp.resize(rh.S); rb.vt.resize(rh.S); rb.cons.assign(rh.S, 0); rb.delta0.assign(rh.S, 1);
+    for (int i = 0; i < rh.S; i++) { rb.fp[i] = rh.fphase(i) ? 1 : 0; rb.vt[i] = (int8_t)rh.cand[i].variant_type; }
+    // thread.rs:162-163: init_haplotypes + init_assignment consume S + F draws; both are overwritten
+    if ((uint32_t)rh.S <= prm.max_enum_snps) return;
+    // ---- divide_snps_into_blocks (candidate.rs:615-747) + init_haplotypes_LD2 (phase.rs:609-671), host
+    const int F = (int)rh.fp_rows.size();
+    std::map<std::pair<int, int>, std::array<int, 4>> pairs;  // (i<j) -> counts [ref/alt i][ref/alt j]
+    auto one_ref = [&](int i) {  // exactly one of the two major alleles is the reference (candidate.rs:637-660)
+      const lcr_candidate& c = rh.cand[i];
+      return (c.allele1 == c.ref_base) != (c.allele2 == c.ref_base);
+    };
+    for (auto& row : pr)
+      for (size_t x = 0; x < row.size(); x++)
+        for (size_t y = x + 1; y < row.size(); y++) {
+          int i = row[x].first, j = row[y].first;
+          int pi = (row[x].second & 32) ? 0 : 1, pj = (row[y].second & 32) ? 0 : 1;
+          if (i > j) { std::swap(i, j); std::swap(pi, pj); }
+          pairs[{i, j}][pi * 2 + pj]++;
+        }
+    std::map<std::pair<int, int>, int> ld_weight;  // perfect-LD pairs (score == 0) -> weight
+    std::vector<std::pair<int, int>> pass;
+    for (auto& kv : pairs) {
+      const int i = kv.first.first, j = kv.first.second;
+      if (!one_ref(i) || !one_ref(j)) continue;
+      const lcr_candidate &si = rh.cand[i], &sj = rh.cand[j];
+      if (si.af1 == 0.0f || si.af2 == 0.0f || sj.af1 == 0.0f || sj.af2 == 0.0f) continue;
+      const auto& c = kv.second;  // snp.rs:158-188
+      const int cis = c[0] + c[3], trans = c[1] + c[2];
+      const int c1 = std::min(cis, trans), c2 = std::max(cis, trans);
+      const int weight = cis > trans ? c2 : -c2;
+      if (c2 > 0 && c1 == 0) { pass.push_back({i, j}); ld_weight[{i, j}] = weight; }
+    }
+    PGraph lg;
+    for (auto& pq : pass) lg.add_edge(pq.first, pq.second);  // std::map order == (i asc, j asc) loop order
+    // edges with |weight| < ld_weight_threshold are removed (candidate.rs:703-711); petgraph swap_removes
+    for (auto& kv : ld_weight)
+      if ((uint32_t)std::abs(kv.second) < prm.ld_weight_threshold) {
+        lg.edges.erase(PGraph::key(kv.first.first, kv.first.second));
+        auto rm = [&](int x, int y) { auto& v = lg.adj[x]; auto f = std::find(v.begin(), v.end(), y); if (f != v.end()) { *f = v.back(); v.pop_back(); } };
+        rm(kv.first.first, kv.first.second); rm(kv.first.second, kv.first.first);
+      }
+    ld_blocks[g] = lg.components();
+    // init_haplotypes_LD2: S random draws (ctr S+F ..), then BFS propagation inside each block
+    const uint64_t c_ld = (uint64_t)rh.S + (uint64_t)F;
+    int8_t* d0 = rb.delta0.data();
+    uint8_t* cons = rb.cons.data();
+    for (int i = 0; i < rh.S; i++) d0[i] = u01(rh.seed, c_ld + i) < 0.5 ? 1 : -1;
+    const int thr = (int)prm.ld_weight_threshold;
+    for (auto& block : ld_blocks[g]) {
+      if (block.size() < 2) continue;
+      std::set<int> disc; std::vector<int> queue, visited;
+      size_t qh = 0;
+      disc.insert(block[0]); queue.push_back(block[0]);
+      d0[block[0]] = 1;
+      visited.push_back(block[0]);
+      while (qh < queue.size()) {  // petgraph Bfs: pop front, push unseen neighbours
+        const int nx = queue[qh++];
+        for (int y : lg.adj.at(nx)) if (disc.insert(y).second) queue.push_back(y);
+        for (int vis : visited) {
+          if (vis == nx) continue;
+          auto f = ld_weight.find({std::min(vis, nx), std::max(vis, nx)});
+          if (f == ld_weight.end()) continue;  // pair absent, not valid, or not perfect LD
+          if (f->second >= thr) { d0[nx] = d0[vis]; break; }
+          if (f->second <= -thr) { d0[nx] = (int8_t)(-d0[vis]); break; }
+        }
+        visited.push_back(nx);
+      }
+      for (int i : block) cons[i] = 1;
+    }
+  };
+  int nthreads = (int)std::thread::hardware_concurrency();
+  if (const char* e = getenv("LCR_HOST_THREADS")) nthreads = atoi(e);
+  nthreads = std::max(1, std::min(std::min(nthreads, 32), ng));
+  auto for_regions = [&](const std::function<void(int)>& fn) {
+    if (nthreads <= 1) { for (int g = 0; g < ng; g++) fn(g); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; t++)
+      pool.emplace_back([&]() { for (int g = next.fetch_add(1); g < ng; g = next.fetch_add(1)) fn(g); });
+    for (auto& th : pool) th.join();
+  };
+  for_regions(prep);
+
+  // ---- concatenate the per-region slices (serial, memcpy-sized)
+  std::vector<RegionDev> rdev;
+  std::vector<int> slot_of(ng, -1);
+  std::vector<int32_t> h_prow_ptr, h_pcol, h_ccol_ptr, h_crow;
+  std::vector<uint8_t> h_pval, h_cval, h_fp, h_cons;
+  std::vector<int8_t> h_vt, h_delta0;
+  int32_t sig_total = 0, snp_total = 0, max_state = 0;
+  std::vector<int32_t> enum_slots, chain_slots;
+  auto app = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
+  for (int g = 0; g < ng; g++) {
+    RegionHost& rh = R[g];
+    if (rh.S == 0) continue;
+    RegionBuild& rb = RB[g];
     RegionDev rd{};
     rd.R = (int32_t)rh.fp_rows.size(); rd.S = rh.S;
     rd.rp_off = (int32_t)h_prow_ptr.size(); rd.cp_off = (int32_t)h_ccol_ptr.size(); rd.e_off = (int64_t)h_pcol.size();
     rd.sig_off = sig_total; rd.snp_off = snp_total; rd.seed = rh.seed;
     sig_total += rd.R; snp_total += rd.S;
     max_state = std::max(max_state, rd.R + 2 * rd.S);
-    int32_t acc = 0;
-    std::vector<int32_t> ccnt(rh.S + 1, 0);
-    for (auto& row : pr) {
-      h_prow_ptr.push_back(acc);
-      for (auto& pe : row) { h_pcol.push_back(pe.first); h_pval.push_back(pe.second); ccnt[pe.first + 1]++; acc++; }
-    }
-    h_prow_ptr.push_back(acc);
-    for (int i = 0; i < rh.S; i++) ccnt[i + 1] += ccnt[i];
-    for (int i = 0; i <= rh.S; i++) h_ccol_ptr.push_back(ccnt[i]);
-    const size_t cbase = h_crow.size();
-    h_crow.resize(cbase + acc); h_cval.resize(cbase + acc);
-    std::vector<int32_t> fill(ccnt.begin(), ccnt.end() - 1);
-    for (size_t k = 0; k < pr.size(); k++)
-      for (auto& pe : pr[k]) { h_crow[cbase + fill[pe.first]] = (int32_t)k; h_cval[cbase + fill[pe.first]] = pe.second; fill[pe.first]++; }
-    for (int i = 0; i < rh.S; i++) { h_fp.push_back(rh.fphase(i) ? 1 : 0); h_vt.push_back((int8_t)rh.cand[i].variant_type); }
-    h_cons.resize(h_fp.size(), 0);
-    h_delta0.resize(h_fp.size(), 1);
+    app(h_prow_ptr, rb.prow_ptr); app(h_pcol, rb.pcol); app(h_pval, rb.pval);
+    app(h_ccol_ptr, rb.ccol_ptr); app(h_crow, rb.crow); app(h_cval, rb.cval);
+    app(h_fp, rb.fp); app(h_vt, rb.vt); app(h_cons, rb.cons); app(h_delta0, rb.delta0);
     slot_of[g] = (int)rdev.size();
-    // thread.rs:162-163: init_haplotypes + init_assignment consume S + F draws; both are overwritten
-    if ((uint32_t)rh.S <= prm.max_enum_snps) enum_slots.push_back(slot_of[g]);
-    else {
-      chain_slots.push_back(slot_of[g]);
-      // ---- divide_snps_into_blocks (candidate.rs:615-747) + init_haplotypes_LD2 (phase.rs:609-671), host
-      std::map<std::pair<int, int>, std::array<int, 4>> pairs;  // (i<j) -> counts [ref/alt i][ref/alt j]
-      auto one_ref = [&](int i) {  // exactly one of the two major alleles is the reference (candidate.rs:637-660)
-        const lcr_candidate& s = rh.cand[i];
-        return (s.allele1 == s.ref_base) != (s.allele2 == s.ref_base);
-      };
-      for (auto& row : pr)
-        for (size_t a = 0; a < row.size(); a++)
-          for (size_t b = a + 1; b < row.size(); b++) {
-            int i = row[a].first, j = row[b].first;
-            int pi = (row[a].second & 32) ? 0 : 1, pj = (row[b].second & 32) ? 0 : 1;
-            if (i > j) { std::swap(i, j); std::swap(pi, pj); }
-            pairs[{i, j}][pi * 2 + pj]++;
-          }
-      std::map<std::pair<int, int>, int> ld_weight;  // perfect-LD pairs (score == 0) -> weight
-      std::vector<std::pair<int, int>> pass;
-      for (auto& kv : pairs) {
-        const int i = kv.first.first, j = kv.first.second;
-        if (!one_ref(i) || !one_ref(j)) continue;
-        const lcr_candidate &si = rh.cand[i], &sj = rh.cand[j];
-        if (si.af1 == 0.0f || si.af2 == 0.0f || sj.af1 == 0.0f || sj.af2 == 0.0f) continue;
-        const auto& c = kv.second;  // snp.rs:158-188
-        const int cis = c[0] + c[3], trans = c[1] + c[2];
-        const int c1 = std::min(cis, trans), c2 = std::max(cis, trans);
-        const int weight = cis > trans ? c2 : -c2;
-        if (c2 > 0 && c1 == 0) { pass.push_back({i, j}); ld_weight[{i, j}] = weight; }
-      }
-      PGraph lg;
-      for (auto& pq : pass) lg.add_edge(pq.first, pq.second);  // std::map order == (i asc, j asc) loop order
-      // edges with |weight| < ld_weight_threshold are removed (candidate.rs:703-711); petgraph swap_removes
-      for (auto& kv : ld_weight)
-        if ((uint32_t)std::abs(kv.second) < prm.ld_weight_threshold) {
-          lg.edges.erase(PGraph::key(kv.first.first, kv.first.second));
-          auto rm = [&](int a, int b) { auto& v = lg.adj[a]; auto f = std::find(v.begin(), v.end(), b); if (f != v.end()) { *f = v.back(); v.pop_back(); } };
-          rm(kv.first.first, kv.first.second); rm(kv.first.second, kv.first.first);
-        }
-      ld_blocks[g] = lg.components();
-      // init_haplotypes_LD2: S random draws (ctr S+F ..), then BFS propagation inside each block
-      const uint64_t c_ld = (uint64_t)rh.S + (uint64_t)rd.R;
-      int8_t* d0 = h_delta0.data() + rd.snp_off;
-      uint8_t* cons = h_cons.data() + rd.snp_off;
-      for (int i = 0; i < rh.S; i++) d0[i] = u01(rh.seed, c_ld + i) < 0.5 ? 1 : -1;
-      const int thr = (int)prm.ld_weight_threshold;
-      for (auto& block : ld_blocks[g]) {
-        if (block.size() < 2) continue;
-        std::set<int> disc; std::vector<int> queue, visited;
-        size_t qh = 0;
-        disc.insert(block[0]); queue.push_back(block[0]);
-        d0[block[0]] = 1;
-        visited.push_back(block[0]);
-        while (qh < queue.size()) {  // petgraph Bfs: pop front, push unseen neighbours
-          const int nx = queue[qh++];
-          for (int y : lg.adj.at(nx)) if (disc.insert(y).second) queue.push_back(y);
-          for (int vis : visited) {
-            if (vis == nx) continue;
-            auto f = ld_weight.find({std::min(vis, nx), std::max(vis, nx)});
-            if (f == ld_weight.end()) continue;  // pair absent, not valid, or not perfect LD
-            if (f->second >= thr) { d0[nx] = d0[vis]; break; }
-            if (f->second <= -thr) { d0[nx] = (int8_t)(-d0[vis]); break; }
-          }
-          visited.push_back(nx);
-        }
-        for (int i : block) cons[i] = 1;
-      }
-    }
+    if ((uint32_t)rh.S <= prm.max_enum_snps) enum_slots.push_back(slot_of[g]); else chain_slots.push_back(slot_of[g]);
     rdev.push_back(rd);
+    RegionBuild().prow_ptr.swap(rb.prow_ptr);
   }
-
+  lap("host region prep + LD");
   const HostLut& L = hlut();
   if (!rdev.empty()) {
     // ---- upload the phase matrices
@@ -738,6 +776,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     P.scratch = b_scr.as<int8_t>(); P.scratch_stride = stride;
     P.lut = L.dev;
 
+    PCHK(hipStreamSynchronize(stream));
+    lap("upload phase matrices");
     // ---- enumeration regions: all restarts in one launch, then re-run the winners
     if (!enum_slots.empty()) {
       std::vector<int32_t> job_slot; std::vector<uint32_t> job_e; std::vector<size_t> first_job;
@@ -773,6 +813,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       PCHK(hipGetLastError());
       PCHK(hipStreamSynchronize(stream));  // win_slot / win_e are pageable host vectors
     }
+    lap("enum kernels");
     // ---- chain regions
     std::vector<int8_t> st_host;
     auto pull_state = [&]() -> hipError_t {
@@ -852,6 +893,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     }
     PCHK(pull_state());
     PCHK(hipGetLastError());
+    lap("chain kernels + block pass");
     // ---- scatter device results into the host region views
     for (int g = 0; g < ng; g++) {
       if (slot_of[g] < 0) continue;
@@ -869,10 +911,13 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     }
   }
 
-  // ---- post-phase epilogue, thread.rs:168-201
-  for (int g = 0; g < ng; g++) {
+  lap("scatter");
+  // ---- post-phase epilogue, thread.rs:168-201.  Regions are independent (the reference runs them as
+  // rayon tasks, thread.rs:77): a small host thread pool walks them; results do not depend on the
+  // thread count (per-region RNG stream, disjoint output rows).
+  auto epilogue = [&](int g) {
     RegionHost& rh = R[g];
-    if (rh.S == 0) continue;
+    if (rh.S == 0) return;
     rh.assign_reads_haplotype(prm.read_assign_cutoff);
     rh.assign_snp_haplotype_genotype();
     rh.assign_reads_haplotype(prm.read_assign_cutoff);
@@ -884,7 +929,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     rh.assign_snp_haplotype_genotype();
     rh.assign_phase_set(prm.min_phase_score, phase_set.data());
     for (int r = 0; r < rh.nrow; r++) { haplotag[rh.r0 + r] = rh.tag[r]; assignment[rh.r0 + r] = rh.asg[r]; }
-  }
+  };
+  for_regions(epilogue);
+  lap("post-phase epilogue");
   return LCR_OK;
 #undef PCHK
 }
