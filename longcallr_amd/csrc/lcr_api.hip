@@ -31,6 +31,7 @@ struct lcr_ctx {
   DevBuf planes;
   DevParams dp{};
   HostBuf h_planes;
+  DevBuf hpmask;
 
   // K2
   bool have_cand = false;
@@ -161,7 +162,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   DevBuf* bufs[] = {&c->errflag, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, &c->k0_tile_off,
                     &c->k0_tile_fill, &c->k0_items, &c->ndiff, &c->nscan, &c->planes, &c->flags,
                     &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
-                    &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
+                    &c->keep, &c->hpmask, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
                     &c->row_links, &c->row_ptr, &c->col, &c->val};
   for (auto* b : bufs) b->release();
   HostBuf* hb[] = {&c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
@@ -294,7 +295,8 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   HIPCHK(c, hipMemcpyAsync(&bad, b.error_flag, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));  // also keeps treg/tcol alive until copied
   HIPCHK(c, hipGetLastError());
-  if (bad) { c->err = "unknown CIGAR operation (reference panics: util.rs:944)"; return LCR_E_CIGAR; }
+  if (bad == 1) { c->err = "unknown CIGAR operation (reference panics: util.rs:944)"; return LCR_E_CIGAR; }
+  if (bad) { c->err = "CIGAR inconsistent with l_seq / soft clips"; return LCR_E_CIGAR; }
   c->loaded = true;
   return LCR_OK;
 }
@@ -309,10 +311,12 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   c->dp = to_dev(p, sor_thr);
   { const char* e = getenv("LCR_K1_DBG"); c->dp.dbg = e ? atoi(e) : 0; }
   HIPCHK(c, c->planes.reserve(std::max<size_t>((size_t)c->n_cols * LCR_NPLANES, 1) * 4));
+  if (!c->dp.ont) HIPCHK(c, c->hpmask.reserve(std::max<size_t>((size_t)c->bv.n_reads * 2 * p->dist_to_end, 16)));
   { Timer t(c, LCR_K_PILEUP);
+    if (!c->dp.ont) launch_k1_hpmask(c->bv, c->dp.dist_to_end, c->dp.polya_len, c->hpmask.as<uint8_t>(), c->stream);
     launch_k1_pileup(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), c->n_tiles, c->n_cols,
                      c->k0_tile_off.as<int32_t>(), c->k0_items.as<WorkItem>(), c->nscan.as<int32_t>(),
-                     c->planes.as<uint32_t>(), c->stream); }
+                     c->hpmask.as<uint8_t>(), c->planes.as<uint32_t>(), c->stream); }
   HIPCHK(c, hipGetLastError());
   // algorithmic bytes of this launch: bases once, CIGAR once, 32 B read header,
   // 13 u32 planes written + 1 reference byte read per column

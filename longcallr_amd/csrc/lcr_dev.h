@@ -119,7 +119,8 @@ void launch_k0_bin(const BatchView& b, int pass, int32_t* tile_count, const int3
                    WorkItem* items, uint32_t* ndiff, hipStream_t s);
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const int32_t* tile_off, const WorkItem* items,
-                      const int32_t* nscan, uint32_t* planes, hipStream_t s);
+                      const int32_t* nscan, const uint8_t* hp, uint32_t* planes, hipStream_t s);
+void launch_k1_hpmask(const BatchView& b, int D, int L, uint8_t* hp, hipStream_t s);
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, uint8_t* flags, int32_t* tile_count,
                       hipStream_t s);
