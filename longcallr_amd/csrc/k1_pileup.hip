@@ -54,6 +54,17 @@ __device__ __forceinline__ int wave_incl_max(int v, int lane) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// read -> region map (one block per region writes its read range)
+__global__ void __launch_bounds__(LCR_BLOCK) k0_read_region(const int32_t* __restrict__ read_begin, int32_t* __restrict__ out) {
+  const int g = blockIdx.x;
+  for (int r = read_begin[g] + threadIdx.x; r < read_begin[g + 1]; r += blockDim.x) out[r] = g;
+}
+void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s) {
+  if (b.n_regions == 0) return;
+  hipLaunchKernelGGL(k0_read_region, dim3(b.n_regions), dim3(LCR_BLOCK), 0, s, b.read_begin, read_region);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K0: one wave per read.  pass 0: validate ops, intron difference array, items per tile.
 //                          pass 1: write the items (slot = atomic counter per tile).
 __global__ void __launch_bounds__(LCR_BLOCK)
@@ -62,7 +73,7 @@ k0_bin(BatchView b, int pass, int32_t* __restrict__ tile_count, const int32_t* _
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * (LCR_BLOCK / 64) + (threadIdx.x >> 6);
   if (r >= b.n_reads) return;
-  const int g = region_of_read(b.read_begin, b.n_regions, r);
+  const int g = region_of_read(b, r);
   const int vec = b.len[g];
   const int64_t gbase = b.col_off[g] + g;  // one spare slot per region so that end markers never leak
   const int ftile = b.region_first_tile[g];

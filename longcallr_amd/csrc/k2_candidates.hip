@@ -300,7 +300,7 @@ k2_hist(BatchView b, DevParams prm, const Survivor* __restrict__ sv, const int32
         uint32_t* __restrict__ hist) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= b.n_reads) return;
-  const int g = region_of_read(b.read_begin, b.n_regions, r);
+  const int g = region_of_read(b, r);
   int s_lo = sv_region_off[g];
   const int s_hi = sv_region_off[g + 1];
   if (s_lo >= s_hi) return;

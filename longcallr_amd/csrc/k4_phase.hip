@@ -524,16 +524,17 @@ struct RegionHost {
     }
   }
 
-  // exact objective of the current state over the phase matrix
-  long long objective_fx(const std::vector<std::vector<std::pair<int, uint8_t>>>& prow) const {
+  // exact objective of the current state over the phase matrix (flat CSR of the phasing rows)
+  long long objective_fx(const std::vector<int32_t>& prow_ptr, const std::vector<int32_t>& pcol,
+                         const std::vector<uint8_t>& pval) const {
     long long s = 0;
     const PhaseLutDev& L = hlut().dev;
     for (size_t k = 0; k < fp_rows.size(); k++) {
       const int sg = tag[fp_rows[k]];
-      for (auto& pe : prow[k]) {
-        const int p = (pe.second & 32) ? 1 : -1;
-        const int x = cand[pe.first].genotype == 0 ? sg * cand[pe.first].haplotype : cand[pe.first].genotype;
-        s += p == x ? L.f1e[pe.second & 31] : L.fe[pe.second & 31];
+      for (int e = prow_ptr[k]; e < prow_ptr[k + 1]; e++) {
+        const int p = (pval[e] & 32) ? 1 : -1;
+        const int x = cand[pcol[e]].genotype == 0 ? sg * cand[pcol[e]].haplotype : cand[pcol[e]].genotype;
+        s += p == x ? L.f1e[pval[e] & 31] : L.fe[pval[e] & 31];
       }
     }
     return s;
@@ -566,7 +567,6 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   lap("d2h fragment matrix");
 
   std::vector<RegionHost> R(ng);
-  std::vector<std::vector<std::vector<std::pair<int, uint8_t>>>> prows(ng);  // phase matrix rows per region
   std::vector<std::vector<std::vector<int>>> ld_blocks(ng);
   struct RegionBuild {  // per-region pieces, built in parallel, concatenated below
     std::vector<int32_t> prow_ptr, pcol, ccol_ptr, crow;
@@ -593,7 +593,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     rh.cover.assign(rh.S, {});
     rh.orig_flags.resize(rh.S);
     for (int i = 0; i < rh.S; i++) rh.orig_flags[i] = rh.cand[i].flags;
-    auto& pr = prows[g];
+    // phase matrix of the region: flat CSR over the phasing rows (entries at phase sites only) + CSC mirror
+    std::vector<int32_t> ccnt(rh.S + 1, 0);
+    rb.prow_ptr.push_back(0);
     for (int r = 0; r < rh.nrow; r++) {
       for (int64_t e = rh.eb(r); e < rh.ee(r); e++) {
         const int i = rh.lc(e);
@@ -603,24 +605,22 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       if (links[rh.r0 + r] >= prm.min_linkers) {          // fragment.rs:253-255
         rh.fp[r] = 1;
         rh.fp_rows.push_back(r);
-        pr.emplace_back();
         for (int64_t e = rh.eb(r); e < rh.ee(r); e++)
-          if (rh.phase_site[e - rh.e0]) pr.back().push_back({rh.lc(e), (uint8_t)(val[e] & 63)});
+          if (rh.phase_site[e - rh.e0]) { rb.pcol.push_back(rh.lc(e)); rb.pval.push_back((uint8_t)(val[e] & 63)); ccnt[rh.lc(e) + 1]++; }
+        rb.prow_ptr.push_back((int32_t)rb.pcol.size());
       }
     }
-    int32_t acc = 0;
-    std::vector<int32_t> ccnt(rh.S + 1, 0);
-    for (auto& row : pr) {
-      rb.prow_ptr.push_back(acc);
-      for (auto& pe : row) { rb.pcol.push_back(pe.first); rb.pval.push_back(pe.second); ccnt[pe.first + 1]++; acc++; }
-    }
-    rb.prow_ptr.push_back(acc);
+    const int32_t acc = (int32_t)rb.pcol.size();
+    const size_t n_prow = rh.fp_rows.size();
     for (int i = 0; i < rh.S; i++) ccnt[i + 1] += ccnt[i];
     rb.ccol_ptr.assign(ccnt.begin(), ccnt.end());
     rb.crow.resize(acc); rb.cval.resize(acc);
     std::vector<int32_t> fill(ccnt.begin(), ccnt.end() - 1);
-    for (size_t k = 0; k < pr.size(); k++)
-      for (auto& pe : pr[k]) { rb.crow[fill[pe.first]] = (int32_t)k; rb.cval[fill[pe.first]] = pe.second; fill[pe.first]++; }
+    for (size_t k = 0; k < n_prow; k++)
+      for (int e = rb.prow_ptr[k]; e < rb.prow_ptr[k + 1]; e++) {
+        const int i = rb.pcol[e];
+        rb.crow[fill[i]] = (int32_t)k; rb.cval[fill[i]] = rb.pval[e]; fill[i]++;
+      }
     rb.fp.resize(rh.S); rb.vt.resize(rh.S); rb.cons.assign(rh.S, 0); rb.delta0.assign(rh.S, 1);
     for (int i = 0; i < rh.S; i++) { rb.fp[i] = rh.fphase(i) ? 1 : 0; rb.vt[i] = (int8_t)rh.cand[i].variant_type; }
     // thread.rs:162-163: init_haplotypes + init_assignment consume S + F draws; both are overwritten
@@ -632,11 +632,11 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       const lcr_candidate& c = rh.cand[i];
       return (c.allele1 == c.ref_base) != (c.allele2 == c.ref_base);
     };
-    for (auto& row : pr)
-      for (size_t x = 0; x < row.size(); x++)
-        for (size_t y = x + 1; y < row.size(); y++) {
-          int i = row[x].first, j = row[y].first;
-          int pi = (row[x].second & 32) ? 0 : 1, pj = (row[y].second & 32) ? 0 : 1;
+    for (size_t k = 0; k < n_prow; k++)
+      for (int x = rb.prow_ptr[k]; x < rb.prow_ptr[k + 1]; x++)
+        for (int y = x + 1; y < rb.prow_ptr[k + 1]; y++) {
+          int i = rb.pcol[x], j = rb.pcol[y];
+          int pi = (rb.pval[x] & 32) ? 0 : 1, pj = (rb.pval[y] & 32) ? 0 : 1;
           if (i > j) { std::swap(i, j); std::swap(pi, pj); }
           pairs[{i, j}][pi * 2 + pj]++;
         }
@@ -729,7 +729,6 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     slot_of[g] = (int)rdev.size();
     if ((uint32_t)rh.S <= prm.max_enum_snps) enum_slots.push_back(slot_of[g]); else chain_slots.push_back(slot_of[g]);
     rdev.push_back(rd);
-    RegionBuild().prow_ptr.swap(rb.prow_ptr);
   }
   lap("host region prep + LD");
   const HostLut& L = hlut();
@@ -833,8 +832,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       PCHK(hipGetLastError());
       PCHK(pull_state());
       // LD-block flip pass on the host (phase.rs:1298-1394): a sum-of-ratios f64 decision per block
-      for (int g = 0; g < ng; g++) {
-        if (slot_of[g] < 0 || (uint32_t)R[g].S <= prm.max_enum_snps) continue;
+      auto block_pass = [&](int g) {
+        if (slot_of[g] < 0 || (uint32_t)R[g].S <= prm.max_enum_snps) return;
         RegionHost& rh = R[g];
         const RegionDev& rd = rdev[slot_of[g]];
         int8_t* sg = st_host.data() + st_sig + rd.sig_off; int8_t* dl = st_host.data() + st_del + rd.snp_off;
@@ -877,7 +876,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
         for (int i = 0; i < rh.S; i++) old_hap[i] = (int8_t)rh.cand[i].haplotype;
         for (auto& kv : new_hap) rh.cand[kv.first].haplotype = kv.second;
         for (auto& kv : new_tag) rh.tag[kv.first] = (int8_t)kv.second;
-        const long long obj2 = rh.objective_fx(prows[g]);
+        const long long obj2 = rh.objective_fx(RB[g].prow_ptr, RB[g].pcol, RB[g].pval);
         if (obj2 > *ob) {  // `prob > largest_prob` (phase.rs:1140-1144): keep the flipped state
           *ob = obj2;
           for (size_t k = 0; k < rh.fp_rows.size(); k++) sg[k] = rh.tag[rh.fp_rows[k]];
@@ -886,7 +885,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
           rh.tag = old_tag;
           for (int i = 0; i < rh.S; i++) rh.cand[i].haplotype = old_hap[i];
         }
-      }
+      };
+      for_regions(block_pass);
       PCHK(hipMemcpyAsync(b_st.p, st_host.data(), st_host.size(), hipMemcpyHostToDevice, stream));
       hipLaunchKernelGGL(k4_chain_b, dim3(nc), dim3(LCR_BLOCK), 0, stream, P, b_slots.as<int32_t>(), nc);
       PCHK(hipGetLastError());

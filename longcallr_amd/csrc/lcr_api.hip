@@ -23,7 +23,7 @@ struct lcr_ctx {
   std::vector<int64_t> h_start0, h_col_off;
   std::vector<int32_t> h_len, h_read_begin, h_region_first_tile;
   DevBuf in_[16];  // device copies of host inputs (LCR_MEM_HOST)
-  DevBuf errflag, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_off, k0_tile_fill, k0_items, ndiff, nscan;
+  DevBuf read_region, errflag, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_off, k0_tile_fill, k0_items, ndiff, nscan;
   int64_t n_items = 0;
 
   // K1
@@ -159,7 +159,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto& b : c->in_) b.release();
-  DevBuf* bufs[] = {&c->errflag, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, &c->k0_tile_off,
+  DevBuf* bufs[] = {&c->read_region, &c->errflag, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, &c->k0_tile_off,
                     &c->k0_tile_fill, &c->k0_items, &c->ndiff, &c->nscan, &c->planes, &c->flags,
                     &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
                     &c->keep, &c->hpmask, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
@@ -268,6 +268,9 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   HIPCHK(c, c->first_tile.reserve((ng + 1) * 4));
   HIPCHK(c, hipMemcpyAsync(c->first_tile.p, c->h_region_first_tile.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, c->errflag.reserve(4));
+  HIPCHK(c, c->read_region.reserve(std::max(nr, 1) * 4));
+  b.read_region = c->read_region.as<int32_t>();
+  launch_k0_read_region(b, c->read_region.as<int32_t>(), c->stream);
   b.region_first_tile = c->first_tile.as<int32_t>(); b.error_flag = c->errflag.as<int32_t>();
   HIPCHK(c, hipMemsetAsync(b.error_flag, 0, 4, c->stream));
   // K0: bin 64-op CIGAR chunks into per-tile work items (count -> scan -> fill) and build the intron plane

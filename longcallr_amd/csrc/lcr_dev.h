@@ -34,6 +34,7 @@ struct BatchView {
   const uint8_t* ref;
   // derived by K0 (lcr_load_batch)
   const int32_t* region_first_tile;  // n_regions+1: first pileup tile of each region
+  const int32_t* read_region;        // n_reads: region index of each read
   int32_t* error_flag;               // != 0 -> unknown CIGAR op seen
 };
 
@@ -120,6 +121,7 @@ void launch_k0_bin(const BatchView& b, int pass, int32_t* tile_count, const int3
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const int32_t* tile_off, const WorkItem* items,
                       const int32_t* nscan, const uint8_t* hp, uint32_t* planes, hipStream_t s);
+void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s);
 void launch_k1_hpmask(const BatchView& b, int D, int L, uint8_t* hp, hipStream_t s);
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, uint8_t* flags, int32_t* tile_count,
@@ -187,13 +189,7 @@ __device__ __forceinline__ bool polya_masked(const uint8_t* __restrict__ seq, in
   return masked;
 }
 
-// region index of read r (binary search in read_begin)
-__device__ __forceinline__ int region_of_read(const int32_t* __restrict__ read_begin, int n_regions, int r) {
-  int lo = 0, hi = n_regions;  // find last g with read_begin[g] <= r
-  while (hi - lo > 1) {
-    int mid = (lo + hi) >> 1;
-    if (read_begin[mid] <= r) lo = mid; else hi = mid;
-  }
-  return lo;
-}
+// region index of read r: precomputed by k0_read_region (a binary search over read_begin would cost
+// ~log2(n_regions) dependent global loads per read in every read-parallel kernel)
+#define region_of_read(b_, r_) ((b_).read_region[(r_)])
 #endif
