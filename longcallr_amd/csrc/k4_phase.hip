@@ -481,46 +481,46 @@ struct RegionHost {
   std::vector<uint32_t> orig_flags;
 
   // snpfrags.rs:628-733
+  // snpfrags.rs:628-733.  The reference builds a petgraph GraphMap whose nodes are the PASS het SNPs
+  // (added in index order), adds an edge per read and allele-consistent SNP pair, and walks
+  // kosaraju_scc: components come out in descending order of their first-inserted (= smallest-index)
+  // node, a component's phase set is pos+1 of that node, and a read takes the phase set of the first
+  // component in that order that owns one of its edges.  Union-find gives exactly that.
   void assign_phase_set(float min_phase_score, uint32_t* row_ps /* global rows */) {
-    PGraph g;
-    std::map<std::pair<int, int>, std::vector<int>> efr;
+    std::vector<int> parent(S, -1);  // -1: not a node
     for (int i = 0; i < S; i++) {
       const lcr_candidate& s = cand[i];
       if (s.genotype != 0 || s.variant_type != 1) continue;
       if (s.flags & (LCR_F_DENSE | LCR_F_RNA_EDIT)) continue;
       if (s.phase_score < (double)min_phase_score) continue;
-      g.add_node(i);
+      parent[i] = i;
     }
-    std::vector<int> ns;
+    auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    auto unite = [&](int x, int y) { x = find(x); y = find(y); if (x != y) { if (x < y) parent[y] = x; else parent[x] = y; } };  // root = min index
+    int ns[64], np[64];
+    auto row_nodes = [&](int r) {
+      int n = 0;
+      for (int64_t e = eb(r); e < ee(r) && n < 64; e++)
+        if (parent[lc(e)] >= 0) { ns[n] = lc(e); np[n] = (val[e] & 32) ? 1 : -1; n++; }
+      return n;
+    };
     for (int r = 0; r < nrow; r++) {
       if (!fp[r] || asg[r] == 0) continue;
-      ns.clear();
-      for (int64_t e = eb(r); e < ee(r); e++) if (g.has_node(lc(e))) ns.push_back(lc(e));
-      if (ns.size() == 1) { g.add_edge(ns[0], ns[0]); efr[PGraph::key(ns[0], ns[0])].push_back(r); }
-      if (ns.size() >= 2)
-        for (size_t a = 0; a < ns.size(); a++)
-          for (size_t b = 0; b < ns.size(); b++) {
-            if (a == b) continue;
-            int pa = 0, pb = 0;
-            for (int64_t e = eb(r); e < ee(r); e++) {
-              if (lc(e) == ns[a]) pa = (val[e] & 32) ? 1 : -1;
-              else if (lc(e) == ns[b]) pb = (val[e] & 32) ? 1 : -1;
-            }
-            if (cand[ns[a]].haplotype * cand[ns[b]].haplotype != pa * pb) continue;
-            g.add_edge(ns[a], ns[b]);
-            efr[PGraph::key(ns[a], ns[b])].push_back(r);
-          }
+      const int n = row_nodes(r);
+      for (int x = 0; x < n; x++)
+        for (int y = x + 1; y < n; y++)
+          if (cand[ns[x]].haplotype * cand[ns[y]].haplotype == np[x] * np[y]) unite(ns[x], ns[y]);
     }
-    std::set<int> assigned;
-    for (const auto& comp : g.components()) {
-      uint32_t pid = 0;
-      for (int node : comp) {
-        if (pid == 0) pid = (uint32_t)(cand[node].pos + 1);
-        cand[node].phase_set = pid;
-        for (int nb : g.adj.at(node))
-          for (int r : efr[PGraph::key(node, nb)])
-            if (assigned.insert(r).second) row_ps[r0 + r] = pid;
-      }
+    for (int i = 0; i < S; i++) if (parent[i] >= 0) cand[i].phase_set = (uint32_t)(cand[find(i)].pos + 1);
+    for (int r = 0; r < nrow; r++) {
+      if (!fp[r] || asg[r] == 0) continue;
+      const int n = row_nodes(r);
+      int best = -1;  // largest component root among the components that own an edge of this read
+      if (n == 1) best = find(ns[0]);  // self loop (snpfrags.rs:659-665)
+      for (int x = 0; x < n; x++)
+        for (int y = x + 1; y < n; y++)
+          if (cand[ns[x]].haplotype * cand[ns[y]].haplotype == np[x] * np[y]) best = std::max(best, find(ns[x]));
+      if (best >= 0) row_ps[r0 + r] = (uint32_t)(cand[best].pos + 1);
     }
   }
 
@@ -691,17 +691,13 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       for (int i : block) cons[i] = 1;
     }
   };
-  int nthreads = (int)std::thread::hardware_concurrency();
-  if (const char* e = getenv("LCR_HOST_THREADS")) nthreads = atoi(e);
-  nthreads = std::max(1, std::min(std::min(nthreads, 32), ng));
-  auto for_regions = [&](const std::function<void(int)>& fn) {
-    if (nthreads <= 1) { for (int g = 0; g < ng; g++) fn(g); return; }
-    std::atomic<int> next{0};
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nthreads; t++)
-      pool.emplace_back([&]() { for (int g = next.fetch_add(1); g < ng; g = next.fetch_add(1)) fn(g); });
-    for (auto& th : pool) th.join();
-  };
+  if (!pool) {
+    int nthreads = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("LCR_HOST_THREADS")) nthreads = atoi(e);
+    nthreads = std::max(1, std::min(nthreads, 48));
+    pool = new HostPool(nthreads > 1 ? nthreads : 0);
+  }
+  auto for_regions = [&](const std::function<void(int)>& fn) { pool->parallel_for(ng, fn); };
   for_regions(prep);
 
   // ---- concatenate the per-region slices (serial, memcpy-sized)

@@ -1,5 +1,11 @@
 // lcr_phase_host.h — host driver of the phasing stage (K4 kernels + sequential control).
 #pragma once
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
 #include "lcr_dev.h"
 
 struct PhaseInputs {
@@ -15,12 +21,60 @@ struct PhaseInputs {
   std::vector<lcr_candidate>* cand = nullptr;  // host candidates, updated in place
 };
 
+// Persistent host worker pool: regions are independent units of host-side work (the reference runs
+// them as rayon tasks, thread.rs:77); parallel_for hands out region indices through an atomic counter.
+class HostPool {
+ public:
+  explicit HostPool(int n) {
+    for (int i = 0; i < n; i++) workers_.emplace_back([this]() { loop(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  int size() const { return (int)workers_.size(); }
+  void parallel_for(int n, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    if (workers_.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    { std::lock_guard<std::mutex> l(m_); fn_ = &fn; n_ = n; next_.store(0); pending_ = (int)workers_.size(); gen_++; }
+    cv_.notify_all();
+    std::unique_lock<std::mutex> l(m_);
+    done_.wait(l, [this]() { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+ private:
+  void loop() {
+    unsigned long seen = 0;
+    for (;;) {
+      const std::function<void(int)>* fn;
+      int n;
+      { std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&]() { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        fn = fn_; n = n_; }
+      for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*fn)(i);
+      { std::lock_guard<std::mutex> l(m_); if (--pending_ == 0) done_.notify_all(); }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int n_ = 0, pending_ = 0;
+  unsigned long gen_ = 0;
+  bool stop_ = false;
+  std::atomic<int> next_{0};
+};
+
 struct PhaseHost {
   std::vector<int8_t> haplotag;
   std::vector<uint8_t> assignment;
   std::vector<uint32_t> phase_set;
   std::vector<double> objective;
   DevBuf d_state[12];
+  HostPool* pool = nullptr;
   int run(const PhaseInputs& in, const lcr_params& p, hipStream_t s, std::string* err);
-  void release() { for (auto& b : d_state) b.release(); }
+  void release() { for (auto& b : d_state) b.release(); delete pool; pool = nullptr; }
 };
