@@ -174,6 +174,15 @@ def main():
         pbytes = E.pileup_bytes()
         avg_ms = float(np.mean(pile_ms))
         achieved = pbytes / (avg_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per K1 launch from the committed PMC passes (same workload only)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "k1_traffic.json")))
+            w = tj["workload"]
+            if (w["profile"], w["genes"], w["unique_genes"], w["gene_len"], w["depth"]) == (
+                    a.profile, a.genes, a.unique_genes, a.gene_len, a.depth):
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "candidate_sites_per_sec", "value": cols * world * a.steps / dt, "unit": "sites/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -186,7 +195,7 @@ def main():
                        "candidates_per_gpu": int(cands.size), "fragment_nnz_per_gpu": int(fm["col"].size),
                        "parallelism": "regions sharded over %d GPU(s), gather to rank 0" % world},
             "roofline": {"bound": "hbm", "kernel": "k1_pileup", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None, "algorithmic_bytes": pbytes, "avg_ms": avg_ms},
+                         "frac": achieved / 8000.0, "traffic": traffic, "algorithmic_bytes": pbytes, "avg_ms": avg_ms},
             "stages": {"pileup_plus_candidates_s": t_call, "fragments_plus_phase_s": t_phase,
                        "sites_per_sec_pileup_gt": cols / t_call, "phased_reads_per_sec": n_phased / t_phase,
                        "api_ms": api_ms, "kernel_ms": kms},
