@@ -190,10 +190,11 @@ int lcr_ctx_set_stream(lcr_ctx*, void* hip_stream);
 int lcr_ctx_sync(lcr_ctx*);
 
 /* Bind a batch (reads + regions).  LCR_MEM_HOST inputs are copied to HBM here; LCR_MEM_DEVICE
- * inputs are used in place and must outlive the calls below.  Validates CIGAR ops. */
+ * inputs are used in place and must outlive the calls below. */
 int lcr_load_batch(lcr_ctx*, const lcr_reads*, const lcr_regions*);
 
-/* replaces Profile::fill_data_into_freq_vec (util.rs:621-949); thread.rs:93-103 */
+/* replaces Profile::fill_data_into_freq_vec (util.rs:621-949); thread.rs:93-103.
+ * Returns LCR_E_CIGAR for an unknown CIGAR op or a CIGAR inconsistent with l_seq / soft clips. */
 int lcr_pileup(lcr_ctx*, const lcr_params*);
 int lcr_get_columns(lcr_ctx*, lcr_columns* out);
 
@@ -212,12 +213,15 @@ int lcr_phase(lcr_ctx*, const lcr_params*);
 int lcr_get_phase_result(lcr_ctx*, lcr_phase_result* out);
 
 /* Timing: HIP-event time (ms) of the last launch of each kernel on the ctx's stream. */
-enum { LCR_K_SPANS = 0, LCR_K_PILEUP, LCR_K_CAND_FILTER, LCR_K_CAND_HIST, LCR_K_CAND_GT,
+enum { LCR_K_SPANS = 0 /* K0: CIGAR decode + binning */, LCR_K_PILEUP, LCR_K_CAND_FILTER, LCR_K_CAND_HIST, LCR_K_CAND_GT,
        LCR_K_FRAG_COUNT, LCR_K_FRAG_FILL, LCR_K_PHASE, LCR_NKERNELS };
 int lcr_enable_timing(lcr_ctx*, int on);
 int lcr_kernel_ms(lcr_ctx*, int kernel, float* ms);
-/* Algorithmic byte count of the last lcr_pileup launch (2B + 4C + 32R + 4*LCR_NPLANES*L + L). */
+/* Bytes the pileup tally kernel (K1) of the last lcr_pileup has to move: read bases once (B) + 8-byte
+ * records + (1 + 4 + 4*LCR_NPLANES)*L; and the implementation-independent figure of the whole pileup
+ * stage (K0 + K1): B + 4C + 37R + (4*LCR_NPLANES + 1)*L.  See DESIGN.md. */
 int lcr_pileup_bytes(lcr_ctx*, int64_t* bytes);
+int lcr_pileup_stage_bytes(lcr_ctx*, int64_t* bytes);
 
 const char* lcr_version(void);
 

@@ -12,7 +12,7 @@ SYMBOLS = [
     "lcr_params_preset", "lcr_ctx_create", "lcr_ctx_destroy", "lcr_last_error", "lcr_ctx_set_stream",
     "lcr_ctx_sync", "lcr_load_batch", "lcr_pileup", "lcr_get_columns", "lcr_candidates",
     "lcr_get_candidates", "lcr_fragments", "lcr_get_fragmat", "lcr_phase", "lcr_get_phase_result",
-    "lcr_enable_timing", "lcr_kernel_ms", "lcr_pileup_bytes", "lcr_version",
+    "lcr_enable_timing", "lcr_kernel_ms", "lcr_pileup_bytes", "lcr_pileup_stage_bytes", "lcr_version",
 ]
 
 _lib = None
@@ -58,5 +58,6 @@ def load():
     l.lcr_enable_timing.argtypes = [vp, i32]
     l.lcr_kernel_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     l.lcr_pileup_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
+    l.lcr_pileup_stage_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
     _lib = l
     return l

@@ -123,3 +123,8 @@ class Engine:
         b = C.c_int64()
         self._chk(self.lib.lcr_pileup_bytes(self.h, C.byref(b)), "lcr_pileup_bytes")
         return int(b.value)
+
+    def pileup_stage_bytes(self):
+        b = C.c_int64()
+        self._chk(self.lib.lcr_pileup_stage_bytes(self.h, C.byref(b)), "lcr_pileup_stage_bytes")
+        return int(b.value)

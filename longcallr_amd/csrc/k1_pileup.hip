@@ -1,55 +1,52 @@
-// k1_pileup.hip — K0 (CIGAR binning) and K1 (pileup tally) for gfx950.
+// k1_pileup.hip — K0 (CIGAR decode + binning), K1 (pileup tally), K1z (poly-A mask fix) for gfx950.
 //
-// K1 replaces Profile::fill_data_into_freq_vec (reference src/util.rs:621-949).
+// Together they replace Profile::fill_data_into_freq_vec (reference src/util.rs:621-949).
 //
-// Design: column-tile gather fed by a work list.
-//   K0  one wave64 per read scans the CIGAR 64 ops at a time (wave prefix sums give every op's
-//       reference / query start) and
-//         * turns every intron (N) run into a +1/-1 pair in a global difference array (prefix-
-//           scanned once per batch): introns dominate coverage (mean intron depth 1190 vs allele
-//           depth 163 on demo.bam) but need no per-tile work at all,
-//         * emits one work item (read, first op of the 64-op chunk, column / read offset there)
-//           for every pileup tile that the chunk touches with an M / D / I op; items are counting-
-//           sorted by tile (count pass -> scan -> fill pass).
-//   K1  one workgroup (16 wave64) owns LCR_TILE consecutive columns of one region and keeps every
-//       counter of those columns in LDS.  Each wave pulls 64 items at a time (coalesced), prefetches
-//       their read headers lane-parallel, then for each item re-scans the 64-op chunk and
-//         * turns D runs and whole M blocks into +1/-1 difference-array updates in LDS (2 atomics
-//           per op instead of one per base; prefix-scanned at the end of the tile),
-//         * streams the aligned read bases against the tile's reference bytes held in LDS: a base
-//           equal to the reference byte and not near a read end needs no further work (its count is
-//           "depth - mismatches"); only mismatching, masked (poly-A / homopolymer / ONT end-trim)
-//           and non-ACGT bases — a few % of the stream — touch per-column counters.
-// All arithmetic is u32 adds => results are bit-exact regardless of order.  HBM traffic: the read
-// bases once (each base belongs to exactly one tile), CIGAR words (K0 twice + once per item), the
-// work items, and one coalesced write of the 13 count planes.  Base qualities are NOT read here:
-// they are only needed at the < 1 % of columns that survive the count filters (k2_hist).
+// Design.  The reference walks every read base by base.  Here:
+//   K0  one wave64 per read scans the CIGAR 64 ops at a time (DPP prefix sums give every op's
+//       reference / query start) and emits, per pileup tile (LCR_TILE columns of one region), compact
+//       8-byte records:  M-segment (tile column, length, byte offset of its first read base, strand,
+//       transcript-strand class), D-run (column, length), I-point (column).  ONT end trimming
+//       (util.rs:745-751) is applied here by clipping M blocks to the untrimmed read interval.
+//       Intron (N) runs never reach a tile: they become +1/-1 pairs in a global difference array that
+//       is prefix-scanned once (introns dominate RNA-seq coverage).  Records are counting-sorted by
+//       tile (count pass -> scan -> fill pass; slots are allocated per run of equal tiles with one
+//       atomic per run).
+//   K1  one workgroup owns one tile and keeps all its counters in LDS.  It never sees a CIGAR:
+//       threads take one record each (coalesced 8-byte loads); whole M-segments and D-runs are
+//       difference-array range updates (2 LDS atomics per record, prefix-scanned at the end); then
+//       the segments' read bases are cut into 16-byte aligned pieces, one piece per thread, loaded
+//       with one 16-byte global load each (512 independent loads in flight per workgroup) and XORed
+//       against the tile's reference bytes in LDS: a piece that equals the reference is finished
+//       (counts are "depth - mismatches"); only mismatching / non-ACGT bytes touch per-column counters.
+//   K1z (HiFi presets only) re-visits the <= 2*dist_to_end read offsets next to each read end,
+//       evaluates the poly-A / homopolymer window rule (util.rs:754-789) and subtracts the rare masked
+//       bases from the finished planes with global atomics.
+// All arithmetic is u32 adds => bit-exact regardless of order.  Base qualities are NOT read here: they
+// are only needed at the < 1 % of columns that survive the count filters (k2_hist).
 #include <climits>
 
 #include "lcr_dev.h"
 
 #define K1_THREADS 512
-#define K1_CPT (LCR_TILE / K1_THREADS)  // columns per thread in the tile epilogue
-#define K1_STAGE 1024  // bytes of read bases staged per wave and pass (LDS budget: 2 workgroups per CU)
 #define K1_WAVES (K1_THREADS / 64)
+#define K1_CPT (LCR_TILE / K1_THREADS)  // columns per thread in the tile epilogue
+
+// record layout (64 bit): [0,40) byte offset of the first read base | [40,50) tile column |
+// [50,60) length-1 | [60] reverse strand | [61,63) transcript-strand class (0 none, 1 -> [0], 2 -> [1])
+#define REC_OFF_MASK 0xFFFFFFFFFFull
+#define REC_KIND_D 0xFFFFFFFFFFull  // offset field of a D-run record
+#define REC_KIND_I 0xFFFFFFFFFEull  // offset field of an I-point record
 
 // wave64 inclusive add-scan with DPP row shifts / row broadcasts (6 VALU ops, no LDS round trips).
 // update_dpp(old = 0, ..., bound_ctrl = false): lanes without a source keep 0, the identity.
-__device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/) {
+__device__ __forceinline__ int wave_incl_scan(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
   v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
-  return v;
-}
-__device__ __forceinline__ int wave_incl_max(int v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int t = __shfl_up(v, d, 64);
-    if (lane >= d) v = max(v, t);
-  }
   return v;
 }
 
@@ -65,11 +62,11 @@ void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// K0: one wave per read.  pass 0: validate ops, intron difference array, items per tile.
-//                          pass 1: write the items (slot = atomic counter per tile).
+// K0: one wave per read.  pass 0: validate ops, intron difference array, records per tile.
+//                          pass 1: write the records.
 __global__ void __launch_bounds__(LCR_BLOCK)
-k0_bin(BatchView b, int pass, int32_t* __restrict__ tile_count, const int32_t* __restrict__ tile_off,
-       int32_t* __restrict__ tile_fill, WorkItem* __restrict__ items, uint32_t* __restrict__ ndiff) {
+k0_bin(BatchView b, int pass, int ont, int D, int32_t* __restrict__ tile_count, const int32_t* __restrict__ tile_off,
+       int32_t* __restrict__ tile_fill, unsigned long long* __restrict__ recs, uint32_t* __restrict__ ndiff) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * (LCR_BLOCK / 64) + (threadIdx.x >> 6);
   if (r >= b.n_reads) return;
@@ -80,6 +77,15 @@ k0_bin(BatchView b, int pass, int32_t* __restrict__ tile_count, const int32_t* _
   const uint32_t ncig = b.n_cig[r];
   const uint32_t* __restrict__ cg = b.cigar + b.cig_off[r];
   const int lead = b.lead[r];
+  const int seq_len = b.seq_len[r];
+  const int reb = seq_len - b.trail[r];
+  const unsigned long long seq_off = b.seq_off[r];
+  const int fl = b.flags[r];
+  const int strand = fl & 1, ts = (fl >> 1) & 3;
+  // transcript_strands index (util.rs:803-819): (+,+)->0 (+,-)->1 (-,+)->1 (-,-)->0, none -> -1
+  const unsigned long long tscls = ts == 0 ? 0ull : ((strand == 0) == (ts == 1) ? 1ull : 2ull);
+  const unsigned long long hi_bits = ((unsigned long long)strand << 60) | (tscls << 61);
+  const unsigned long long below = (1ull << lane) - 1ull;
   int ref_cur = (int)((int64_t)b.pos[r] - b.start0[g]);
   int q_cur = lead > 0 ? lead : 0;
   for (uint32_t c0 = 0; c0 < ncig; c0 += 64) {
@@ -92,78 +98,77 @@ k0_bin(BatchView b, int pass, int32_t* __restrict__ tile_count, const int32_t* _
     if (pass == 0 && act && !(is_m || is_d || is_n || is_i || op == 4 || op == 5)) atomicExch(b.error_flag, 1);
     const int dr = (is_m || is_d || is_n) ? len : 0;
     const int dq = (is_m || is_i) ? len : 0;
-    const int ir = wave_incl_scan(dr, lane), iq = wave_incl_scan(dq, lane);
-    const int rs = ref_cur + ir - dr;
-    const int a = max(rs, 0), e = min(rs + len, vec);
+    const int ir = wave_incl_scan(dr), iq = wave_incl_scan(dq);
+    const int rs = ref_cur + ir - dr;   // region-relative column where this op starts
+    const int qs = q_cur + iq - dq;     // read offset where this op starts
+    int a = max(rs, 0), e = min(rs + len, vec);
     if (pass == 0 && is_n && e > a) {  // util.rs:930-942
       atomicAdd(&ndiff[gbase + a], 1u);
       atomicAdd(&ndiff[gbase + e], 0xFFFFFFFFu);
     }
-    int tlo = 0, thi = -1;
-    if ((is_m || is_d) && len > 0 && e > a) { tlo = a / LCR_TILE; thi = (e - 1) / LCR_TILE; }
-    else if (is_i && len > 0 && rs >= 1 && rs < vec) { tlo = thi = (rs - 1) / LCR_TILE; }  // util.rs:918-929
-    int prevmax = wave_incl_max(thi, lane);
-    prevmax = __shfl_up(prevmax, 1, 64);
-    if (lane == 0) prevmax = -1;
-    const int first = max(tlo, prevmax + 1);
-    for (int t = first; t <= thi; t++) {  // tiles this lane is the first in the chunk to touch
-      if (pass == 0) atomicAdd(&tile_count[ftile + t], 1);
-      else {
-        const int slot = atomicAdd(&tile_fill[ftile + t], 1);
-        WorkItem it;
-        it.read = (uint32_t)r; it.c0 = c0; it.ref_cur = ref_cur; it.q_cur = q_cur;
-        items[tile_off[ftile + t] + slot] = it;
+    if (ont && is_m) {  // ONT end trim (util.rs:745-751): keep read offsets lead + D <= c <= reb - D
+      a = max(a, rs + (lead + D - qs));
+      e = min(e, rs + (reb - D + 1 - qs));
+    }
+    // column range [a, e) this op contributes records for (I: the single column rs-1, 1 <= rs < vec)
+    bool has = (is_m || is_d) && len > 0 && e > a;
+    if (is_i && len > 0 && rs >= 1 && rs < vec) { has = true; a = rs - 1; e = rs; }
+    int t_cur = has ? a / LCR_TILE : INT_MAX;       // tile of the next record of this lane
+    const int t_last = has ? (e - 1) / LCR_TILE : -1;
+    // rounds: every lane emits its record for tile t_cur, then moves to its next tile (ops rarely span
+    // more than two tiles).  Ops are ordered by position, so within a round the emitting lanes' tiles
+    // are non-decreasing: runs of equal tiles are contiguous, each run's first lane allocates the
+    // slots of the whole run with ONE atomic, and all runs of the round issue their atomics together.
+    for (;;) {
+      const bool emit = has && t_cur <= t_last;
+      const unsigned long long em = __ballot(emit);
+      if (em == 0ull) break;
+      const unsigned long long em_below = em & below;
+      const int prev_lane = em_below ? 63 - __clzll((long long)em_below) : 0;
+      const int prev_tile = __shfl(t_cur, prev_lane, 64);
+      const bool leader = emit && (em_below == 0ull || prev_tile != t_cur);
+      const unsigned long long lm = __ballot(leader);
+      // my run: from its leader (highest leader bit at or below me) to just before the next leader
+      const unsigned long long lm_le = lm & (below | (1ull << lane));
+      const int my_leader = lm_le ? 63 - __clzll((long long)lm_le) : 0;
+      int base = 0;
+      if (leader) {
+        const unsigned long long above = lane == 63 ? 0ull : (~0ull << (lane + 1));
+        const unsigned long long nxt = lm & above;
+        const unsigned long long run = nxt ? (em & above & ((1ull << (__ffsll((long long)nxt) - 1)) - 1ull)) : (em & above);
+        const int cnt = 1 + __popcll(run);
+        if (pass == 0) atomicAdd(&tile_count[ftile + t_cur], cnt);
+        else base = atomicAdd(&tile_fill[ftile + t_cur], cnt);
       }
+      if (pass == 1) {
+        base = __shfl(base, my_leader, 64);
+        if (emit) {
+          const unsigned long long leader_below = my_leader == 0 ? 0ull : ((1ull << my_leader) - 1ull);
+          const int slot = tile_off[ftile + t_cur] + base + __popcll(em_below & ~leader_below);
+          const int c_lo = max(a, t_cur * LCR_TILE), c_hi = min(e, (t_cur + 1) * LCR_TILE);  // columns in this tile
+          unsigned long long rec = ((unsigned long long)(c_lo - t_cur * LCR_TILE) << 40) |
+                                   ((unsigned long long)(c_hi - c_lo - 1) << 50);
+          if (is_m) rec |= ((seq_off + (unsigned long long)(qs + (c_lo - rs))) & REC_OFF_MASK) | hi_bits;
+          else rec |= is_d ? REC_KIND_D : REC_KIND_I;
+          recs[slot] = rec;
+        }
+      }
+      if (emit) t_cur++;
     }
     ref_cur += __shfl(ir, 63, 64);
     q_cur += __shfl(iq, 63, 64);
   }
-  // aligned read offsets must lie in [lead, seq_len - trail): the end-zone tests of K1 rely on it
+  // aligned read offsets must lie in [lead, seq_len - trail): the end-zone logic relies on it
   // (true for every valid BAM record: l_seq = sum of M/I/S/=/X lengths)
-  if (pass == 0 && lane == 0 && ncig > 0 && q_cur != b.seq_len[r] - b.trail[r]) atomicExch(b.error_flag, 2);
+  if (pass == 0 && lane == 0 && ncig > 0 && q_cur != reb) atomicExch(b.error_flag, 2);
 }
 
-void launch_k0_bin(const BatchView& b, int pass, int32_t* tile_count, const int32_t* tile_off, int32_t* tile_fill,
-                   WorkItem* items, uint32_t* ndiff, hipStream_t s) {
+void launch_k0_bin(const BatchView& b, int pass, int ont, int D, int32_t* tile_count, const int32_t* tile_off,
+                   int32_t* tile_fill, unsigned long long* recs, uint32_t* ndiff, hipStream_t s) {
   if (b.n_reads == 0) return;
   const int per = LCR_BLOCK / 64;
-  hipLaunchKernelGGL(k0_bin, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, pass, tile_count, tile_off,
-                     tile_fill, items, ndiff);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1a (HiFi only): for every read offset c within dist_to_end of a read end, the set of bases X for
-// which a window of L identical X starts in [c-L, c+1] (util.rs:754-789).  The base at c is masked
-// iff that set contains a base other than the column's reference base.  One thread per (read, slot):
-// slot s < D -> c = lead + s;  slot D + s -> c = reb - D + 1 + s  (s < D-1).
-__global__ void __launch_bounds__(LCR_BLOCK) k1_hpmask(BatchView b, int D, int L, uint8_t* __restrict__ hp) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int per = 2 * D;
-  const int r = (int)(gid / per), s = (int)(gid % per);
-  if (r >= b.n_reads) return;
-  const int seq_len = b.seq_len[r], lead = b.lead[r], reb = seq_len - b.trail[r];
-  const int c = s < D ? lead + s : reb - D + 1 + (s - D);
-  uint8_t m = 0;
-  if (c >= 0 && c < seq_len && !(s == per - 1)) {
-    const uint8_t* __restrict__ seq = b.bases + b.seq_off[r];
-    int lo = max(c - L, 0), hi = min(c + L, seq_len - 1);
-    if (hi - lo + 1 >= L) {
-      int run = 1;
-      uint8_t prev = seq[lo];
-      for (int i = lo + 1; i <= hi; i++) {
-        const uint8_t cur = seq[i];
-        run = (cur == prev) ? run + 1 : 1;
-        prev = cur;
-        if (run >= L) m |= cur == 'A' ? 1 : cur == 'C' ? 2 : cur == 'G' ? 4 : cur == 'T' ? 8 : 0;
-      }
-    }
-  }
-  hp[gid] = m;
-}
-void launch_k1_hpmask(const BatchView& b, int D, int L, uint8_t* hp, hipStream_t s) {
-  const long long n = (long long)b.n_reads * 2 * D;
-  if (n == 0) return;
-  hipLaunchKernelGGL(k1_hpmask, dim3((unsigned)((n + LCR_BLOCK - 1) / LCR_BLOCK)), dim3(LCR_BLOCK), 0, s, b, D, L, hp);
+  hipLaunchKernelGGL(k0_bin, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, pass, ont, D, tile_count,
+                     tile_off, tile_fill, recs, ndiff);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -180,11 +185,12 @@ enum {
   P_NPL = P_MM_R + 4
 };
 #define TSTRIDE (LCR_TILE + 1)
+#define REF_PAD 16  // reference bytes are stored at refl[REF_PAD + column] so that piece starts may be "negative"
 
 // inclusive scan of one int per thread over the whole block
 __device__ __forceinline__ int block_incl_scan(int v, int* wsum /* K1_WAVES ints of LDS */) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int s = wave_incl_scan(v, lane);
+  int s = wave_incl_scan(v);
   if (lane == 63) wsum[w] = s;
   __syncthreads();
   int add = 0;
@@ -195,24 +201,23 @@ __device__ __forceinline__ int block_incl_scan(int v, int* wsum /* K1_WAVES ints
 
 __global__ void __launch_bounds__(K1_THREADS)
 k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0,
-          int64_t n_cols, const int32_t* __restrict__ tile_off, const WorkItem* __restrict__ items,
-          const int32_t* __restrict__ nscan, const uint8_t* __restrict__ hp, uint32_t* __restrict__ planes) {
+          int64_t n_cols, const int32_t* __restrict__ tile_off, const unsigned long long* __restrict__ recs,
+          const int32_t* __restrict__ nscan, uint32_t* __restrict__ planes) {
   __shared__ uint32_t pl[P_NPL * TSTRIDE];
-  __shared__ __attribute__((aligned(16))) uint8_t refl[LCR_TILE];
+  __shared__ __attribute__((aligned(16))) uint8_t refl[REF_PAD + LCR_TILE + 32];
+  __shared__ unsigned long long rec_s[K1_THREADS];
+  __shared__ int pstart[K1_THREADS + 1];
   __shared__ int wsum[K1_WAVES];
-  __shared__ uint4 stage_all[K1_WAVES][K1_STAGE / 16];  // per-wave staging buffer of read bases
-  __shared__ __attribute__((aligned(16))) int lookup_all[K1_WAVES][256];  // per-wave histogram of op start bytes
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int g = tile_region[blockIdx.x];
   const int tc0 = tile_col0[blockIdx.x];               // first column of the tile inside the region
   const int vec = b.len[g];
   const int tlen = min(LCR_TILE, vec - tc0);
   const int64_t gcol0 = b.col_off[g] + tc0;            // global column of tile column 0
-
   const int i0 = tile_off[blockIdx.x], i1 = tile_off[blockIdx.x + 1];
-  if (i0 == i1 && prm.dbg != 4) {
-    // no M / D / I op touches this tile (pure intron or uncovered): every plane is 0 except the
+  if (i0 == i1) {
+    // no M / D / I record touches this tile (pure intron or uncovered): every plane is 0 except the
     // intron plane, which comes from the global scan.  Most tiles of a spliced data set are like this.
     for (int col = tid; col < tlen; col += K1_THREADS) {
       const int64_t o = gcol0 + col;
@@ -223,203 +228,99 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
     return;
   }
   for (int i = tid; i < P_NPL * TSTRIDE; i += K1_THREADS) pl[i] = 0;
-  for (int i = tid; i < LCR_TILE; i += K1_THREADS) {
-    uint8_t R = i < tlen ? b.ref[gcol0 + i] : 0;
+  for (int i = tid; i < REF_PAD + LCR_TILE + 32; i += K1_THREADS) {
+    const int col = i - REF_PAD;
+    uint8_t R = (col >= 0 && col < tlen) ? b.ref[gcol0 + col] : 0;
     // only upper-case ACGT can equal a read base (htslib decodes to upper case); anything else is
     // stored as 0xFF so that every base at such a column takes the explicit-count path
     refl[i] = (R == 'A' || R == 'C' || R == 'G' || R == 'T') ? R : 0xFF;
   }
   __syncthreads();
+  const uint32_t* rl32 = reinterpret_cast<const uint32_t*>(refl);
 
-  const int D = prm.dist_to_end;
-
-  // items are dealt round-robin to the waves (item i -> wave i % K1_WAVES) so that a tile with a few
-  // hundred items keeps every wave busy; each wave fetches 64 of its items at a time, lane-parallel.
-  // The per-item work is software-pipelined: the CIGAR words of item k+2 and the read bases of item
-  // k+1 are in flight while item k is processed (each item otherwise pays two dependent HBM round trips).
-  struct ItemPrep {
-    int op, len, rs, qs, a, e;   // this lane's op of the 64-op chunk
-    bool is_m;
-    int lead, reb, strand, tsidx, q_lo, q_hi, jlo, jhi, n16;
-    uint32_t rd_idx;
-    unsigned long long mmask0;
-    long long seq_abs, w0;
-    uint4 pre;                   // lane's 16-byte piece of the first staging window
-  };
-  uint8_t* const stage_b = reinterpret_cast<uint8_t*>(stage_all[wave]);
-  auto load16 = [&](long long off) -> uint4 {
-    if (off + 16 <= b.n_bases) return *reinterpret_cast<const uint4*>(b.bases + off);
-    uint32_t t[4] = {0, 0, 0, 0};  // last partial 16 bytes of the whole base array
-    for (int x = 0; x < 16; x++)
-      if (off + x < b.n_bases) t[x >> 2] |= (uint32_t)b.bases[off + x] << (8 * (x & 3));
-    return make_uint4(t[0], t[1], t[2], t[3]);
-  };
-  for (int ibase = i0; ibase < i1 && prm.dbg != 3; ibase += K1_WAVES * 64) {
-    const int avail = min(i1 - ibase, K1_WAVES * 64) - wave;                 // items from ibase+wave on
-    const int n_here = avail > 0 ? (avail + K1_WAVES - 1) / K1_WAVES : 0;    // ... taking every K1_WAVES-th
-    // lane-parallel fetch of up to 64 items and of their read headers
-    WorkItem my; my.read = 0; my.c0 = 0; my.ref_cur = 0; my.q_cur = 0;
-    if (lane < n_here) my = items[ibase + wave + K1_WAVES * lane];
-    const uint32_t rr = my.read;
-    const uint32_t h_ncig = b.n_cig[rr];
-    const unsigned long long h_cig = b.cig_off[rr], h_seq = b.seq_off[rr];
-    const int h_len = b.seq_len[rr], h_lead = b.lead[rr], h_trail = b.trail[rr];
-    const int h_fl = b.flags[rr];
-
-    auto load_word = [&](int k) -> uint32_t {
-      const uint32_t c0 = __shfl(my.c0, k, 64);
-      const uint32_t ncig = __shfl(h_ncig, k, 64);
-      const uint32_t* __restrict__ cg = b.cigar + __shfl(h_cig, k, 64);
-      return (c0 + lane < ncig) ? cg[c0 + lane] : 0u;
-    };
-    auto prep = [&](int k, uint32_t word, ItemPrep& st) {
-      const int seq_len = __shfl(h_len, k, 64);
-      st.lead = __shfl(h_lead, k, 64);
-      st.reb = seq_len - __shfl(h_trail, k, 64);
-      st.rd_idx = __shfl(rr, k, 64);
-      const int fl = __shfl(h_fl, k, 64);
-      const int ref_cur = __shfl(my.ref_cur, k, 64) - tc0;  // tile-relative column at op c0
-      const int q_cur = __shfl(my.q_cur, k, 64);
-      st.strand = fl & 1;
-      const int ts = (fl >> 1) & 3;
-      // transcript_strands index (util.rs:803-819): (+,+)->0 (+,-)->1 (-,+)->1 (-,-)->0, none -> -1
-      st.tsidx = ts == 0 ? -1 : ((st.strand == 0) == (ts == 1) ? 0 : 1);
-      st.op = word & 15; st.len = (int)(word >> 4);
-      st.is_m = (st.op == 0 || st.op == 7 || st.op == 8) && st.len > 0;
-      const bool is_dn = (st.op == 2 || st.op == 3) && st.len > 0;
-      const int dr = (st.is_m || is_dn) ? st.len : 0;
-      const int dq = (st.is_m || st.op == 1) ? st.len : 0;
-      const int ir = wave_incl_scan(dr, lane), iq = wave_incl_scan(dq, lane);
-      st.rs = ref_cur + ir - dr;        // tile-relative column where this op starts
-      st.qs = q_cur + iq - dq;          // read offset where this op starts
-      // clip the op's column range to the tile; ONT: also to the read offsets that survive the end
-      // trim (util.rs:745-751), i.e. lead + D <= c <= reb - D, so trimmed bases are never touched
-      st.a = max(st.rs, 0); st.e = min(st.rs + st.len, tlen);
-      if (prm.ont && st.is_m) {
-        st.a = max(st.a, st.rs + (st.lead + D - st.qs));
-        st.e = min(st.e, st.rs + (st.reb - D + 1 - st.qs));
-      }
-      st.mmask0 = prm.dbg == 1 ? 0ull : __ballot(st.is_m && st.e > st.a);
-      st.n16 = 0;
-      if (st.mmask0 != 0ull) {
-        st.jlo = __ffsll((long long)st.mmask0) - 1; st.jhi = 63 - __clzll((long long)st.mmask0);
-        st.q_lo = __shfl(st.qs + (st.a - st.rs), st.jlo, 64);   // read range [q_lo, q_hi) compared in this tile
-        st.q_hi = __shfl(st.qs + (st.e - st.rs), st.jhi, 64);
-        st.seq_abs = (long long)__shfl(h_seq, k, 64);
-        st.w0 = (st.seq_abs + st.q_lo) & ~15ll;
-        const long long w1 = min(st.w0 + (long long)K1_STAGE, st.seq_abs + (long long)st.q_hi);
-        st.n16 = (int)((w1 - st.w0 + 15) >> 4);               // <= 64: one piece per lane
-        if (lane < st.n16) st.pre = load16(st.w0 + 16ll * lane);
-      }
-    };
-
-    ItemPrep cur, nxt;
-    uint32_t word_nn = 0;
-    if (n_here > 0 && prm.dbg != 2) { prep(0, load_word(0), nxt); if (n_here > 1) word_nn = load_word(1); }
-    for (int k = 0; k < n_here && prm.dbg != 2; k++) {
-      cur = nxt;
-      if (k + 1 < n_here) prep(k + 1, word_nn, nxt);
-      if (k + 2 < n_here) word_nn = load_word(k + 2);
-      const ItemPrep& st = cur;
-      uint32_t* depth_pl = pl + (st.strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
-      uint32_t* ts_pl = pl + (st.tsidx == 1 ? P_DIFF_TS1 : P_DIFF_TS0) * TSTRIDE;
-      uint32_t* mm_pl = pl + (st.strand ? P_MM_R : P_MM_F) * TSTRIDE;
-      const int tsidx = st.tsidx, lead = st.lead, reb = st.reb;
-      const int rs = st.rs, qs = st.qs, a = st.a, e = st.e, len = st.len, op = st.op;
-      if (op == 2 && len > 0 && e > a) {  // util.rs:905-917: +1 per deleted reference position
-        atomicAdd(&pl[P_DIFF_D * TSTRIDE + a], 1u);
-        atomicAdd(&pl[P_DIFF_D * TSTRIDE + e], 0xFFFFFFFFu);
-      }
-      if (op == 1 && len > 0) {  // util.rs:918-929: counted on the previous column, 1 <= p < vec
-        const int p = rs + tc0;  // pos_in_freq_vec
-        if (p >= 1 && p < vec && rs - 1 >= 0 && rs - 1 < tlen) atomicAdd(&pl[P_NI * TSTRIDE + rs - 1], 1u);
-      }
-      if (st.is_m && e > a) {  // whole block as a range update; per-base corrections follow below
-        atomicAdd(&depth_pl[a], 1u);
-        atomicAdd(&depth_pl[e], 0xFFFFFFFFu);
-        if (tsidx >= 0) { atomicAdd(&ts_pl[a], 1u); atomicAdd(&ts_pl[e], 0xFFFFFFFFu); }
-      }
-      if (st.mmask0 == 0ull) continue;
-      // Compare the read bases of the chunk inside this tile with the reference.  The read range
-      // [q_lo, q_hi) is contiguous in the read: it is staged in LDS by 16-byte coalesced loads
-      // (first window prefetched above), then walked 4 bytes per lane.
-      const int q_lo = st.q_lo, q_hi = st.q_hi;
-      const long long seq_abs = st.seq_abs;
-      const int jqm = st.is_m ? (rs - qs) : INT_MIN;       // column = read offset + jqm for M ops
-      int* hist = lookup_all[wave];                          // 256 ints: ops starting at each staged byte
-      const uint32_t* stage32 = reinterpret_cast<const uint32_t*>(stage_b);
-      for (long long w0 = st.w0; w0 < seq_abs + q_hi; w0 += K1_STAGE) {
-        const long long w1 = min(w0 + (long long)K1_STAGE, seq_abs + (long long)q_hi);
-        const int n16 = (int)((w1 - w0 + 15) >> 4);
-        if (w0 == st.w0) { if (lane < n16) stage_all[wave][lane] = st.pre; }
-        else { if (lane < n16) stage_all[wave][lane] = load16(w0 + 16ll * lane); }
-        __builtin_amdgcn_wave_barrier();
-        const int sbase = (int)(seq_abs - w0);               // stage index of read offset c is c + sbase
-        const int n_dw = (int)((w1 - w0 + 3) >> 2);
-        const int kb = qs + sbase;                           // staged byte index where this op starts
-        for (int d0 = 0; d0 < n_dw; d0 += 64) {              // uniform trip count: shuffles stay convergent
-          const int d = d0 + lane;
-          const int cb = 4 * d - sbase;                      // read offset of byte 0 of this dword
-          const uint32_t basew = d < n_dw ? stage32[d] : 0u;
-          // "last op with qs <= c" for all 256 staged bytes of this pass: histogram of op start bytes
-          // (one LDS atomic per op) + prefix sum (4 local adds + one DPP scan)
-          reinterpret_cast<int4*>(hist)[lane] = make_int4(0, 0, 0, 0);
-          __builtin_amdgcn_wave_barrier();
-          const int kk = kb - 4 * d0;
-          const int nbefore = __popcll(__ballot(kk <= 0));   // ops that start at or before byte 0 of the pass
-          if (kk > 0 && kk < 256) atomicAdd(&hist[kk], 1);
-          __builtin_amdgcn_wave_barrier();
-          const int4 h4 = reinterpret_cast<const int4*>(hist)[lane];
-          const int s0 = h4.x, s1 = s0 + h4.y, s2 = s1 + h4.z, s3 = s2 + h4.w;
-          const int excl = wave_incl_scan(s3, lane) - s3 + nbefore - 1;
-          const int lo[4] = {excl + s0, excl + s1, excl + s2, excl + s3};
-          // per byte: column offset of its op (INT_MIN: not an M op), reference byte, verdict
-          uint32_t slow = 0;  // bit i: byte i needs individual attention (mismatch or near a read end)
-          int dj[4];
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            dj[i] = __shfl(jqm, max(lo[i], 0), 64);          // executed by all lanes
-            const int c = cb + i;
-            const bool live = d < n_dw && c >= q_lo && c < q_hi && dj[i] != INT_MIN;
-            const int col = live ? c + dj[i] : 0;
-            const uint32_t R = refl[col];
-            const uint32_t base = (basew >> (8 * i)) & 0xffu;
-            const bool zone = !prm.ont && (c - lead < D || reb - c < D);  // lead <= c < reb (checked by K0)
-            if (live && (base != R || zone)) slow |= 1u << i;
-          }
-          if (prm.dbg == 5) slow = 0;
-          while (__ballot(slow != 0) != 0ull) {              // uniform loop
-            if (slow == 0) continue;
-            const int i = __ffs(slow) - 1;
-            slow &= slow - 1;
-            const int c = cb + i;
-            const int col = c + (i == 0 ? dj[0] : i == 1 ? dj[1] : i == 2 ? dj[2] : dj[3]);
-            const uint32_t base = (basew >> (8 * i)) & 0xffu;
-            const uint32_t R = refl[col];
-            const bool zone = !prm.ont && (c - lead < D || reb - c < D);
-            bool masked = false;
-            if (zone) {  // util.rs:754-789 via the precomputed window masks
-              const uint32_t hm = hp[(long long)st.rd_idx * (2 * D) + (c - lead < D ? c - lead : D + (c - (reb - D + 1)))];
-              const uint8_t Rraw = b.ref[gcol0 + col];
-              const uint32_t rbit = Rraw == 'A' ? 1u : Rraw == 'C' ? 2u : Rraw == 'G' ? 4u : Rraw == 'T' ? 8u : 0u;
-              masked = (hm & ~rbit) != 0;
-            }
-            // branch-free classification: 0..3 = mismatching A,C,G,T; otherwise undo depth (masked or non-ACGT)
-            const uint32_t h = (base >> 1) & 3u;
-            const uint32_t bi = h ^ (h >> 1);                // A,C,G,T -> 0,1,2,3 (either case)
-            const bool acgt = ((base & 0xC0u) == 0x40u) && ((0x0010008Au >> (base & 31u)) & 1u);
-            if (!masked && acgt) {
-              if (base != R) atomicAdd(&mm_pl[bi * TSTRIDE + col], 1u);
-            } else {  // masked: contributes nothing (util.rs:801); non-ACGT: no allele count (util.rs:890-892)
-              atomicAdd(&depth_pl[col], 0xFFFFFFFFu);
-              atomicAdd(&depth_pl[col + 1], 1u);
-              if (masked && tsidx >= 0) { atomicAdd(&ts_pl[col], 0xFFFFFFFFu); atomicAdd(&ts_pl[col + 1], 1u); }
-            }
-          }
+  for (int rbase = i0; rbase < i1 && prm.dbg != 3; rbase += K1_THREADS) {
+    // ---- phase 1: one record per thread
+    const bool hasrec = rbase + tid < i1;
+    const unsigned long long rec = hasrec ? recs[rbase + tid] : 0ull;
+    const unsigned long long off = rec & REC_OFF_MASK;
+    const int col0 = (int)((rec >> 40) & 1023u), len = (int)((rec >> 50) & 1023u) + 1;
+    int npieces = 0;
+    if (hasrec) {
+      if (off == REC_KIND_D) {          // util.rs:905-917: +1 per deleted reference position
+        atomicAdd(&pl[P_DIFF_D * TSTRIDE + col0], 1u);
+        atomicAdd(&pl[P_DIFF_D * TSTRIDE + col0 + len], 0xFFFFFFFFu);
+      } else if (off == REC_KIND_I) {   // util.rs:918-929
+        atomicAdd(&pl[P_NI * TSTRIDE + col0], 1u);
+      } else {                          // M-segment: range update now, per-base corrections in phase 2
+        const int strand = (int)((rec >> 60) & 1u), tscls = (int)((rec >> 61) & 3u);
+        uint32_t* dp = pl + (strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
+        atomicAdd(&dp[col0], 1u);
+        atomicAdd(&dp[col0 + len], 0xFFFFFFFFu);
+        if (tscls) {
+          uint32_t* tp = pl + (tscls == 2 ? P_DIFF_TS1 : P_DIFF_TS0) * TSTRIDE;
+          atomicAdd(&tp[col0], 1u);
+          atomicAdd(&tp[col0 + len], 0xFFFFFFFFu);
         }
-        __builtin_amdgcn_wave_barrier();
+        npieces = (int)(((off & 15ull) + (unsigned long long)len + 15ull) >> 4);
       }
     }
+    rec_s[tid] = rec;
+    const int incl = block_incl_scan(prm.dbg == 1 ? 0 : npieces, wsum);
+    pstart[tid + 1] = incl;
+    if (tid == 0) pstart[0] = 0;
+    __syncthreads();
+    const int P = pstart[K1_THREADS];
+    // ---- phase 2: one 16-byte aligned piece of read bases per thread
+    for (int p = tid; p < P; p += K1_THREADS) {
+      int lo = 0;  // last record with pstart <= p
+#pragma unroll
+      for (int st = K1_THREADS / 2; st >= 1; st >>= 1) if (pstart[lo + st] <= p) lo += st;
+      const unsigned long long rc = rec_s[lo];
+      const long long soff = (long long)(rc & REC_OFF_MASK);
+      const int scol = (int)((rc >> 40) & 1023u), slen = (int)((rc >> 50) & 1023u) + 1;
+      const int strand = (int)((rc >> 60) & 1u);
+      const long long A = (soff & ~15ll) + 16ll * (p - pstart[lo]);      // byte address of the piece
+      const int k_lo = (int)max(0ll, soff - A), k_hi = (int)min(16ll, soff + slen - A);  // valid bytes
+      const int colA = scol + (int)(A - soff);                            // column of byte 0 (may be < 0)
+      uint4 v;
+      if (A + 16 <= b.n_bases) v = *reinterpret_cast<const uint4*>(b.bases + A);
+      else {  // last partial 16 bytes of the whole base array
+        uint32_t t[4] = {0, 0, 0, 0};
+        for (int x = 0; x < 16; x++)
+          if (A + x < b.n_bases) t[x >> 2] |= (uint32_t)b.bases[A + x] << (8 * (x & 3));
+        v = make_uint4(t[0], t[1], t[2], t[3]);
+      }
+      // 16 reference bytes starting at column colA (unaligned in LDS): 5 dwords + byte alignment
+      const int ci = colA + REF_PAD, di = ci >> 2;
+      const uint32_t sh = (uint32_t)(ci & 3);
+      const uint32_t r0 = rl32[di], r1 = rl32[di + 1], r2 = rl32[di + 2], r3 = rl32[di + 3], r4 = rl32[di + 4];
+      const uint32_t x0 = v.x ^ __builtin_amdgcn_alignbyte(r1, r0, sh), x1 = v.y ^ __builtin_amdgcn_alignbyte(r2, r1, sh);
+      const uint32_t x2 = v.z ^ __builtin_amdgcn_alignbyte(r3, r2, sh), x3 = v.w ^ __builtin_amdgcn_alignbyte(r4, r3, sh);
+      // 16-bit mask of mismatching bytes among the valid ones
+      auto nz4 = [](uint32_t x) -> uint32_t {
+        return ((x & 0xffu) ? 1u : 0u) | ((x & 0xff00u) ? 2u : 0u) | ((x & 0xff0000u) ? 4u : 0u) | ((x & 0xff000000u) ? 8u : 0u);
+      };
+      uint32_t mm = nz4(x0) | (nz4(x1) << 4) | (nz4(x2) << 8) | (nz4(x3) << 12);
+      mm &= ((1u << k_hi) - 1u) & ~((1u << k_lo) - 1u);
+      if (prm.dbg == 5) mm = 0;
+      uint32_t* dp = pl + (strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
+      uint32_t* mp = pl + (strand ? P_MM_R : P_MM_F) * TSTRIDE;
+      while (mm) {  // rare: a few % of the bases
+        const int kx = __ffs(mm) - 1;
+        mm &= mm - 1;
+        const uint32_t w = kx < 4 ? v.x : kx < 8 ? v.y : kx < 12 ? v.z : v.w;
+        const uint32_t base = (w >> (8 * (kx & 3))) & 0xffu;
+        const int col = colA + kx;
+        // branch-free classification: A,C,G,T (either case) -> 0..3; anything else is "Invalid nucleotide
+        // base" (util.rs:890-892): no allele count (depth - 1), transcript strand still counted
+        const uint32_t h = (base >> 1) & 3u;
+        const uint32_t bi = h ^ (h >> 1);
+        const bool acgt = ((base & 0xC0u) == 0x40u) && ((0x0010008Au >> (base & 31u)) & 1u);
+        if (acgt) atomicAdd(&mp[bi * TSTRIDE + col], 1u);
+        else { atomicAdd(&dp[col], 0xFFFFFFFFu); atomicAdd(&dp[col + 1], 1u); }
+      }
+    }
+    __syncthreads();
   }
   __syncthreads();
 
@@ -437,7 +338,7 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
 
   // assemble the ABI planes and write them out (coalesced: consecutive threads, consecutive columns)
   for (int col = tid; col < tlen; col += K1_THREADS) {
-    const uint8_t R = refl[col];
+    const uint8_t R = refl[REF_PAD + col];
     const int ri = R == 'A' ? 0 : R == 'C' ? 1 : R == 'G' ? 2 : R == 'T' ? 3 : -1;
     uint32_t f[4], rv[4];
     uint32_t sf = 0, sr = 0;
@@ -467,9 +368,79 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
 }
 
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
-                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_off, const WorkItem* items,
-                      const int32_t* nscan, const uint8_t* hp, uint32_t* planes, hipStream_t s) {
+                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_off, const unsigned long long* recs,
+                      const int32_t* nscan, uint32_t* planes, hipStream_t s) {
   if (n_tiles == 0) return;
   hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_off,
-                     items, nscan, hp, planes);
+                     recs, nscan, planes);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1z (HiFi presets): poly-A / homopolymer mask (util.rs:754-789).  One thread per (read, slot): slot
+// s < D -> read offset c = lead + s; slot D + s -> c = reb - D + 1 + s (s < D-1): exactly the offsets
+// with c - lead < D or reb - c < D.  The base at c is masked iff a window of L identical bases X in
+// {A,C,G,T}, X != the column's reference byte, starts in [c-L, c+1] inside the read.  Masked bases were
+// counted by K1 like any other base; they are rare, so they are subtracted with global atomics.
+__global__ void __launch_bounds__(LCR_BLOCK)
+k1_zonefix(BatchView b, int D, int L, int64_t n_cols, uint32_t* __restrict__ planes) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = 2 * D;
+  const int r = (int)(gid / per), s = (int)(gid % per);
+  if (r >= b.n_reads || s == per - 1) return;
+  const int seq_len = b.seq_len[r], lead = b.lead[r], reb = seq_len - b.trail[r];
+  const int c = s < D ? lead + s : reb - D + 1 + (s - D);
+  if (c < lead || c >= reb) return;                    // not an aligned read offset
+  if (s >= D && c - lead < D) return;                  // both zones overlap: offset already covered by slot c-lead
+  const uint8_t* __restrict__ seq = b.bases + b.seq_off[r];
+  uint32_t m = 0;  // bit X: a homopolymer window of X starts in [c-L, c+1]
+  {
+    const int lo = max(c - L, 0), hi = min(c + L, seq_len - 1);
+    if (hi - lo + 1 < L) return;
+    int run = 1;
+    uint8_t prev = seq[lo];
+    for (int i = lo + 1; i <= hi; i++) {
+      const uint8_t cur = seq[i];
+      run = (cur == prev) ? run + 1 : 1;
+      prev = cur;
+      if (run >= L) m |= cur == 'A' ? 1u : cur == 'C' ? 2u : cur == 'G' ? 4u : cur == 'T' ? 8u : 0u;
+    }
+  }
+  if (m == 0) return;
+  // column of read offset c: walk the CIGAR (HiFi reads have a handful of ops)
+  const int g = region_of_read(b, r);
+  const int vec = b.len[g];
+  const uint32_t* __restrict__ cg = b.cigar + b.cig_off[r];
+  const uint32_t ncig = b.n_cig[r];
+  int p = (int)((int64_t)b.pos[r] - b.start0[g]), q = lead > 0 ? lead : 0, col = -1;
+  bool found = false;
+  for (uint32_t i = 0; i < ncig && !found; i++) {
+    const int op = cg[i] & 15, len = (int)(cg[i] >> 4);
+    if (op == 0 || op == 7 || op == 8) {
+      if (c < q + len) { col = p + (c - q); found = true; }
+      p += len; q += len;
+    } else if (op == 1) {
+      if (c < q + len) found = true;  // inside an insertion: no column
+      q += len;
+    } else if (op == 2 || op == 3) p += len;
+  }
+  if (col < 0 || col >= vec) return;
+  const int64_t o = b.col_off[g] + col;
+  const uint8_t R = b.ref[o];
+  const uint32_t rbit = R == 'A' ? 1u : R == 'C' ? 2u : R == 'G' ? 4u : R == 'T' ? 8u : 0u;
+  if ((m & ~rbit) == 0) return;
+  // masked: the base contributes nothing (util.rs:801)
+  const int fl = b.flags[r];
+  const int strand = fl & 1, ts = (fl >> 1) & 3;
+  const int bi = base_code(seq[c]);
+  if (bi >= 0) {
+    atomicSub(&planes[(int64_t)(LCR_PL_A + bi) * n_cols + o], 1u);
+    if (strand == 0) atomicSub(&planes[(int64_t)(LCR_PL_FWD_A + bi) * n_cols + o], 1u);
+  }
+  if (ts != 0) atomicSub(&planes[(int64_t)(((strand == 0) == (ts == 1)) ? LCR_PL_TS_FWD : LCR_PL_TS_REV) * n_cols + o], 1u);
+}
+
+void launch_k1_zonefix(const BatchView& b, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s) {
+  const long long n = (long long)b.n_reads * 2 * D;
+  if (n == 0) return;
+  hipLaunchKernelGGL(k1_zonefix, dim3((unsigned)((n + LCR_BLOCK - 1) / LCR_BLOCK)), dim3(LCR_BLOCK), 0, s, b, D, L, n_cols, planes);
 }

@@ -31,7 +31,6 @@ struct lcr_ctx {
   DevBuf planes;
   DevParams dp{};
   HostBuf h_planes;
-  DevBuf hpmask;
 
   // K2
   bool have_cand = false;
@@ -57,7 +56,7 @@ struct lcr_ctx {
   bool timing = false;
   hipEvent_t ev[LCR_NKERNELS][2] = {};
   bool ev_valid[LCR_NKERNELS] = {};
-  int64_t pileup_bytes = 0;
+  int64_t pileup_bytes = 0, stage_bytes = 0;
 };
 
 namespace {
@@ -162,7 +161,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   DevBuf* bufs[] = {&c->read_region, &c->errflag, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, &c->k0_tile_off,
                     &c->k0_tile_fill, &c->k0_items, &c->ndiff, &c->nscan, &c->planes, &c->flags,
                     &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
-                    &c->keep, &c->hpmask, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
+                    &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
                     &c->row_links, &c->row_ptr, &c->col, &c->val};
   for (auto* b : bufs) b->release();
   HostBuf* hb[] = {&c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
@@ -203,6 +202,12 @@ int lcr_kernel_ms(lcr_ctx* c, int k, float* ms) {
 int lcr_pileup_bytes(lcr_ctx* c, int64_t* bytes) {
   if (!c || !bytes) return LCR_E_ARG;
   *bytes = c->pileup_bytes;
+  return LCR_OK;
+}
+
+int lcr_pileup_stage_bytes(lcr_ctx* c, int64_t* bytes) {
+  if (!c || !bytes) return LCR_E_ARG;
+  *bytes = c->stage_bytes;
   return LCR_OK;
 }
 
@@ -273,33 +278,8 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   launch_k0_read_region(b, c->read_region.as<int32_t>(), c->stream);
   b.region_first_tile = c->first_tile.as<int32_t>(); b.error_flag = c->errflag.as<int32_t>();
   HIPCHK(c, hipMemsetAsync(b.error_flag, 0, 4, c->stream));
-  // K0: bin 64-op CIGAR chunks into per-tile work items (count -> scan -> fill) and build the intron plane
-  const int nt = c->n_tiles;
-  const size_t nd = (size_t)c->n_cols + ng + 1;
-  HIPCHK(c, c->k0_tile_count.reserve((nt + 1) * 4));
-  HIPCHK(c, c->k0_tile_off.reserve((nt + 2) * 4));
-  HIPCHK(c, c->k0_tile_fill.reserve((nt + 1) * 4));
-  HIPCHK(c, c->ndiff.reserve(nd * 4));
-  HIPCHK(c, c->nscan.reserve(nd * 4));
-  HIPCHK(c, hipMemsetAsync(c->k0_tile_count.p, 0, (nt + 1) * 4, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->k0_tile_fill.p, 0, (nt + 1) * 4, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->ndiff.p, 0, nd * 4, c->stream));
-  int32_t n_items = 0;
-  { Timer t(c, LCR_K_SPANS);
-    launch_k0_bin(b, 0, c->k0_tile_count.as<int32_t>(), nullptr, nullptr, nullptr, c->ndiff.as<uint32_t>(), c->stream);
-    launch_scan_i32(c->k0_tile_count.as<int32_t>(), c->k0_tile_off.as<int32_t>(), nt, c->k0_tile_off.as<int32_t>() + nt, c->stream);
-    HIPCHK(c, hipMemcpyAsync(&n_items, c->k0_tile_off.as<int32_t>() + nt, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, c->k0_items.reserve(std::max<size_t>(n_items, 1) * sizeof(WorkItem)));
-    launch_k0_bin(b, 1, nullptr, c->k0_tile_off.as<int32_t>(), c->k0_tile_fill.as<int32_t>(), c->k0_items.as<WorkItem>(), nullptr, c->stream);
-    launch_scan_i32((const int32_t*)c->ndiff.p, c->nscan.as<int32_t>(), (int32_t)nd, nullptr, c->stream); }
-  c->n_items = n_items;
-  int32_t bad = 0;
-  HIPCHK(c, hipMemcpyAsync(&bad, b.error_flag, 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // also keeps treg/tcol alive until copied
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // keeps treg/tcol alive until copied
   HIPCHK(c, hipGetLastError());
-  if (bad == 1) { c->err = "unknown CIGAR operation (reference panics: util.rs:944)"; return LCR_E_CIGAR; }
-  if (bad) { c->err = "CIGAR inconsistent with l_seq / soft clips"; return LCR_E_CIGAR; }
   c->loaded = true;
   return LCR_OK;
 }
@@ -314,16 +294,46 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   c->dp = to_dev(p, sor_thr);
   { const char* e = getenv("LCR_K1_DBG"); c->dp.dbg = e ? atoi(e) : 0; }
   HIPCHK(c, c->planes.reserve(std::max<size_t>((size_t)c->n_cols * LCR_NPLANES, 1) * 4));
-  if (!c->dp.ont) HIPCHK(c, c->hpmask.reserve(std::max<size_t>((size_t)c->bv.n_reads * 2 * p->dist_to_end, 16)));
+  BatchView& b = c->bv;
+  const int ng = b.n_regions, nt = c->n_tiles;
+  // ---- K0: decode every CIGAR once into per-tile records (count -> scan -> fill) + intron plane
+  const size_t nd = (size_t)c->n_cols + ng + 1;
+  HIPCHK(c, c->k0_tile_count.reserve((nt + 1) * 4));
+  HIPCHK(c, c->k0_tile_off.reserve((nt + 2) * 4));
+  HIPCHK(c, c->k0_tile_fill.reserve((nt + 1) * 4));
+  HIPCHK(c, c->ndiff.reserve(nd * 4));
+  HIPCHK(c, c->nscan.reserve(nd * 4));
+  HIPCHK(c, hipMemsetAsync(b.error_flag, 0, 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->k0_tile_count.p, 0, (nt + 1) * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->k0_tile_fill.p, 0, (nt + 1) * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->ndiff.p, 0, nd * 4, c->stream));
+  int32_t n_recs = 0, bad = 0;
+  { Timer t(c, LCR_K_SPANS);
+    launch_k0_bin(b, 0, c->dp.ont, c->dp.dist_to_end, c->k0_tile_count.as<int32_t>(), nullptr, nullptr, nullptr,
+                  c->ndiff.as<uint32_t>(), c->stream);
+    launch_scan_i32(c->k0_tile_count.as<int32_t>(), c->k0_tile_off.as<int32_t>(), nt, c->k0_tile_off.as<int32_t>() + nt, c->stream);
+    HIPCHK(c, hipMemcpyAsync(&n_recs, c->k0_tile_off.as<int32_t>() + nt, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&bad, b.error_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (bad == 1) { c->err = "unknown CIGAR operation (reference panics: util.rs:944)"; return LCR_E_CIGAR; }
+    if (bad) { c->err = "CIGAR inconsistent with l_seq / soft clips"; return LCR_E_CIGAR; }
+    HIPCHK(c, c->k0_items.reserve(std::max<size_t>(n_recs, 1) * 8));
+    launch_k0_bin(b, 1, c->dp.ont, c->dp.dist_to_end, nullptr, c->k0_tile_off.as<int32_t>(), c->k0_tile_fill.as<int32_t>(),
+                  c->k0_items.as<unsigned long long>(), nullptr, c->stream);
+    launch_scan_i32((const int32_t*)c->ndiff.p, c->nscan.as<int32_t>(), (int32_t)nd, nullptr, c->stream); }
+  c->n_items = n_recs;
+  // ---- K1: per-tile tally from the records; K1z: poly-A / homopolymer mask of the HiFi presets
   { Timer t(c, LCR_K_PILEUP);
-    if (!c->dp.ont) launch_k1_hpmask(c->bv, c->dp.dist_to_end, c->dp.polya_len, c->hpmask.as<uint8_t>(), c->stream);
-    launch_k1_pileup(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), c->n_tiles, c->n_cols,
-                     c->k0_tile_off.as<int32_t>(), c->k0_items.as<WorkItem>(), c->nscan.as<int32_t>(),
-                     c->hpmask.as<uint8_t>(), c->planes.as<uint32_t>(), c->stream); }
+    launch_k1_pileup(b, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
+                     c->k0_tile_off.as<int32_t>(), c->k0_items.as<unsigned long long>(), c->nscan.as<int32_t>(),
+                     c->planes.as<uint32_t>(), c->stream);
+    if (!c->dp.ont && c->dp.dist_to_end > 0)
+      launch_k1_zonefix(b, c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->stream); }
   HIPCHK(c, hipGetLastError());
-  // algorithmic bytes of this launch: bases once, CIGAR once, 32 B read header,
-  // 13 u32 planes written + 1 reference byte read per column
-  c->pileup_bytes = c->n_bases + 4 * c->n_cigar + 32 * (int64_t)c->bv.n_reads + (4 * LCR_NPLANES + 1) * c->n_cols;
+  // bytes K1 itself has to move: read bases once + 8-byte records + reference byte and
+  // intron-scan word per column, 13 u32 planes written per column
+  c->pileup_bytes = c->n_bases + 8 * (int64_t)n_recs + (4 * LCR_NPLANES + 1 + 4) * c->n_cols;
+  c->stage_bytes = c->n_bases + 4 * c->n_cigar + 37 * (int64_t)b.n_reads + (4 * LCR_NPLANES + 1) * c->n_cols;
   c->have_planes = true;
   c->have_cand = c->have_frag = c->have_phase = false;
   return LCR_OK;

@@ -38,12 +38,6 @@ struct BatchView {
   int32_t* error_flag;               // != 0 -> unknown CIGAR op seen
 };
 
-// One unit of pileup work: CIGAR ops [c0, c0+64) of read `read` touch the tile with at least one
-// M / D / I op.  ref_cur / q_cur are the region-relative column and the read offset at op c0.
-struct WorkItem {
-  uint32_t read, c0;
-  int32_t ref_cur, q_cur;
-};
 struct DevParams {
   int32_t ont;
   int32_t dist_to_end, polya_len;
@@ -115,14 +109,14 @@ struct PhaseLutDev {
 };
 
 // ---- kernel launchers (defined in the .hip files) ----
-// K0: pass 0 counts work items per tile (+ intron difference array, CIGAR validation); pass 1 fills them
-void launch_k0_bin(const BatchView& b, int pass, int32_t* tile_count, const int32_t* tile_off, int32_t* tile_fill,
-                   WorkItem* items, uint32_t* ndiff, hipStream_t s);
-void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
-                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_off, const WorkItem* items,
-                      const int32_t* nscan, const uint8_t* hp, uint32_t* planes, hipStream_t s);
+// K0: pass 0 counts records per tile (+ intron difference array, CIGAR validation); pass 1 writes them
 void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s);
-void launch_k1_hpmask(const BatchView& b, int D, int L, uint8_t* hp, hipStream_t s);
+void launch_k0_bin(const BatchView& b, int pass, int ont, int D, int32_t* tile_count, const int32_t* tile_off,
+                   int32_t* tile_fill, unsigned long long* recs, uint32_t* ndiff, hipStream_t s);
+void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
+                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_off, const unsigned long long* recs,
+                      const int32_t* nscan, uint32_t* planes, hipStream_t s);
+void launch_k1_zonefix(const BatchView& b, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s);
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, uint8_t* flags, int32_t* tile_count,
                       hipStream_t s);

@@ -29,7 +29,7 @@ def demo_batch():
 CIG = {c: i for i, c in enumerate("MIDNSHP=X")}
 
 
-def mk_batch(reads, regions):
+def mk_batch(reads, regions):  # noqa: C901
     """reads: list of dict(pos, seq(str), qual(list|int), cigar(str like '5M2I3M'), rev=0, ts=0,
     region=idx).  regions: list of (start0, ref_str).  Reads must be listed grouped by region."""
     import re

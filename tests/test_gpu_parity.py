@@ -208,8 +208,11 @@ def test_empty_batch_and_errors(engine_cls):
     with pytest.raises(LcrError):  # call order
         engine_cls(0, p).fill_data_into_freq_vec()
     bad = helpers.mk_batch([dict(pos=10, seq="ACGT" * 5, cigar="10M2P10M")], [(0, "A" * 64)])
-    with pytest.raises(LcrError, match="CIGAR"):
-        engine_cls(0, p).load_batch(bad)
+    with pytest.raises(LcrError, match="CIGAR"):  # unknown op: the reference panics (util.rs:944)
+        engine_cls(0, p).load_batch(bad).fill_data_into_freq_vec()
+    bad2 = helpers.mk_batch([dict(pos=10, seq="ACGT" * 5, cigar="10M")], [(0, "A" * 64)])  # l_seq 20 != 10
+    with pytest.raises(LcrError, match="inconsistent"):
+        engine_cls(0, p).load_batch(bad2).fill_data_into_freq_vec()
 
 
 def test_device_resident_inputs_and_idempotence(engine_cls):
