@@ -60,6 +60,7 @@ struct RegionDev {
   int32_t sig_off;       // offset into per-row state arrays
   int32_t snp_off;       // offset into per-SNP arrays
   uint64_t seed;
+  long long f_total;     // sum of fe[q] over all phase entries (the sigma/delta independent part of the objective)
 };
 
 struct PhaseDev {
@@ -67,17 +68,12 @@ struct PhaseDev {
   const int32_t* prow_ptr; const int32_t* pcol; const uint8_t* pval;
   const int32_t* ccol_ptr; const int32_t* crow; const uint8_t* cval;
   const uint8_t* snp_fp; const int8_t* snp_vt; const uint8_t* snp_cons;
+  const long long* snp_const;  // per SNP: F = sum fe, W = sum w, Cref = sum (p==+1 ? f1e : fe), Cvar = sum (p==-1 ? f1e : fe)
   int8_t* st_sigma; int8_t* st_delta; int8_t* st_eta; long long* st_obj;  // per region best / result state
   int8_t* scratch; int32_t scratch_stride;                                // per block working state
+  int32_t lds_state;                                                      // 1: working state lives in dynamic LDS
   PhaseLutDev lut;
 };
-
-__device__ __forceinline__ long long fx_term(const PhaseLutDev& lut, int sigma, int delta, int eta, uint8_t v) {
-  const int p = (v & 32) ? 1 : -1;
-  const int x = eta == 0 ? sigma * delta : eta;   // aki, phase.rs:32-49
-  const int q = v & 31;
-  return p == x ? lut.f1e[q] : lut.fe[q];
-}
 
 __device__ __forceinline__ long long wave_sum_ll(long long v) {
 #pragma unroll
@@ -85,9 +81,12 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
   return v;
 }
 
-// one cross_optimize (phase.rs:810-976); returns the exact objective (phase.rs:257-276) to all threads
+// one cross_optimize (phase.rs:810-976); returns the exact objective (phase.rs:257-276) to all threads.
+// Every emission term is fe[q] + hit * w[q] with w[q] = f1e[q] - fe[q] > 0 and hit = [p == x]
+// (aki, phase.rs:32-49), so per row / column only the data dependent sum of w over the hits is
+// accumulated; the sigma/delta independent parts are per-SNP constants (PhaseDev::snp_const).
 __device__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, int8_t* sg, int8_t* dl, int8_t* et,
-                                    bool keep_conserved, bool with_genotype, long long* red) {
+                                    bool keep_conserved, bool with_genotype, long long* red, const long long* wl) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int32_t* rp = P.prow_ptr + rd.rp_off;
   const int32_t* pc = P.pcol + rd.e_off;
@@ -97,21 +96,22 @@ __device__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, int8
   const uint8_t* cv = P.cval + rd.e_off;
   const uint8_t* fp = P.snp_fp + rd.snp_off;
   const uint8_t* cons = P.snp_cons + rd.snp_off;
+  const long long* sc = P.snp_const + 4ll * rd.snp_off;
   bool hg_inc = true, h_inc = true;
   int iters = 0;
   while (hg_inc | h_inc) {
-    // ---- sigma step (phase.rs:824-862): flip every row whose flipped likelihood is strictly larger
+    // ---- sigma step (phase.rs:824-862): A - B = sum over het sites of (+w if p == sigma*delta else -w);
+    //      flip every row with A < B (sites with eta != 0 contribute equally to both)
     int any = 0;
     for (int row = tid; row < rd.R; row += blockDim.x) {
       const int s = sg[row];
-      long long A = 0, B = 0;
+      long long diff = 0;
       for (int e = rp[row]; e < rp[row + 1]; e++) {
         const int i = pc[e];
         const uint8_t v = pv[e];
-        A += fx_term(P.lut, s, dl[i], et[i], v);
-        B += fx_term(P.lut, -s, dl[i], et[i], v);
+        if (et[i] == 0) { const long long w = wl[v & 31]; diff += (((v & 32) ? 1 : -1) == s * dl[i]) ? w : -w; }
       }
-      if (A < B) { sg[row] = (int8_t)(-s); any = 1; }
+      if (diff < 0) { sg[row] = (int8_t)(-s); any = 1; }
     }
     any = __syncthreads_or(any);
     if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
@@ -123,19 +123,16 @@ __device__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, int8
       const int c0 = cp[i], c1 = cp[i + 1];
       if (c1 == c0) continue;
       const int d = dl[i], h = et[i];
-      long long N0 = 0, N1 = 0, N2 = 0, N3 = 0;
+      long long M = 0;  // sum of w over the entries with p == sigma * d
       for (int e = c0 + lane; e < c1; e += 64) {
-        const int s = sg[cr[e]];
         const uint8_t v = cv[e];
-        N0 += fx_term(P.lut, s, d, 0, v);
-        N1 += fx_term(P.lut, s, -d, 0, v);
-        N2 += fx_term(P.lut, s, d, 1, v);
-        N3 += fx_term(P.lut, s, d, -1, v);
+        if (((v & 32) ? 1 : -1) == sg[cr[e]] * d) M += wl[v & 31];
       }
-      N0 = wave_sum_ll(N0); N1 = wave_sum_ll(N1); N2 = wave_sum_ll(N2); N3 = wave_sum_ll(N3);
+      M = wave_sum_ll(M);
       if (lane == 0) {
         const long long het = P.lut.f_het0 - (long long)(c1 - c0) * P.lut.f_log2;  // phase.rs:136-144
-        long long N[4] = {N0 + het, N1 + het, N2 + P.lut.f_homref, N3 + P.lut.f_homvar};
+        const long long F = sc[4 * i], W = sc[4 * i + 1];
+        long long N[4] = {F + M + het, F + W - M + het, sc[4 * i + 2] + P.lut.f_homref, sc[4 * i + 3] + P.lut.f_homvar};
         int ch;
         if (with_genotype) { ch = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch]) ch = t; }   // phase.rs:908-921
         else if (h == 0) ch = N[1] > N[0] ? 1 : 0;                                                // phase.rs:923-930
@@ -150,20 +147,31 @@ __device__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, int8
     if (!any) hg_inc = false; else { hg_inc = true; h_inc = true; }
     if (++iters > 20) break;  // phase.rs:967-972
   }
-  // ---- objective (phase.rs:257-276)
+  // ---- objective (phase.rs:257-276) = f_total + sum of w over the hits
   long long acc = 0;
   for (int row = tid; row < rd.R; row += blockDim.x) {
     const int s = sg[row];
-    for (int e = rp[row]; e < rp[row + 1]; e++) acc += fx_term(P.lut, s, dl[pc[e]], et[pc[e]], pv[e]);
+    for (int e = rp[row]; e < rp[row + 1]; e++) {
+      const int i = pc[e];
+      const uint8_t v = pv[e];
+      const int x = et[i] == 0 ? s * dl[i] : et[i];
+      if (((v & 32) ? 1 : -1) == x) acc += wl[v & 31];
+    }
   }
   acc = wave_sum_ll(acc);
   __syncthreads();
   if (lane == 0) red[wave] = acc;
   __syncthreads();
-  long long total = 0;
+  long long total = rd.f_total;
   for (int w = 0; w < nw; w++) total += red[w];
   __syncthreads();
   return total;
+}
+
+// w[q] = f1e[q] - fe[q] into LDS (dynamic indexing of a kernel-argument table would go through memory)
+__device__ __forceinline__ void load_w(const PhaseDev& P, long long* wl) {
+  if (threadIdx.x < 32) wl[threadIdx.x] = threadIdx.x < 31 ? P.lut.f1e[threadIdx.x] - P.lut.fe[threadIdx.x] : 0;
+  __syncthreads();
 }
 
 __device__ __forceinline__ int8_t init_genotype(int8_t vt) { return vt == 0 ? 1 : (vt == 1 ? 0 : -1); }  // phase.rs:682-691
@@ -173,7 +181,10 @@ __global__ void __launch_bounds__(LCR_BLOCK)
 k4_enum(PhaseDev P, const int32_t* __restrict__ job_slot, const uint32_t* __restrict__ job_e, int32_t n_jobs,
         long long* __restrict__ job_obj, int materialize) {
   __shared__ long long red[LCR_BLOCK / 64];
-  int8_t* base = P.scratch + (size_t)blockIdx.x * P.scratch_stride;
+  __shared__ long long wl[32];
+  load_w(P, wl);
+  extern __shared__ __attribute__((aligned(16))) int8_t dyn_state[];  // working sigma|delta|eta when it fits in LDS
+  int8_t* base = P.lds_state ? dyn_state : P.scratch + (size_t)blockIdx.x * P.scratch_stride;
   for (int job = blockIdx.x; job < n_jobs; job += gridDim.x) {
     const RegionDev rd = P.reg[job_slot[job]];
     const uint32_t e = job_e[job];
@@ -185,7 +196,7 @@ k4_enum(PhaseDev P, const int32_t* __restrict__ job_slot, const uint32_t* __rest
     const uint64_t ctr0 = (uint64_t)rd.S + (uint64_t)rd.R + (uint64_t)e * (uint64_t)rd.R;
     for (int row = threadIdx.x; row < rd.R; row += blockDim.x) sg[row] = u01(rd.seed, ctr0 + row) < 0.5 ? -1 : 1;
     __syncthreads();
-    const long long obj = cross_optimize(P, rd, sg, dl, et, false, true, red);
+    const long long obj = cross_optimize(P, rd, sg, dl, et, false, true, red, wl);
     if (threadIdx.x == 0) job_obj[job] = obj;
     if (materialize) {
       for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { P.st_delta[rd.snp_off + i] = dl[i]; P.st_eta[rd.snp_off + i] = et[i]; }
@@ -199,7 +210,9 @@ k4_enum(PhaseDev P, const int32_t* __restrict__ job_slot, const uint32_t* __rest
 // chain, part A (phase.rs:1124-1132): delta from init_haplotypes_LD2 (host), random sigma, keep_conserved
 __global__ void __launch_bounds__(LCR_BLOCK) k4_chain_a(PhaseDev P, const int32_t* __restrict__ slots, int32_t n) {
   __shared__ long long red[LCR_BLOCK / 64];
+  __shared__ long long wl[32];
   if ((int)blockIdx.x >= n) return;
+  load_w(P, wl);
   const int slot = slots[blockIdx.x];
   const RegionDev rd = P.reg[slot];
   int8_t* sg = P.st_sigma + rd.sig_off; int8_t* dl = P.st_delta + rd.snp_off; int8_t* et = P.st_eta + rd.snp_off;
@@ -208,18 +221,22 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_chain_a(PhaseDev P, const int32_
   const uint64_t ctr0 = 2 * (uint64_t)rd.S + (uint64_t)rd.R;  // after S+F (thread.rs) and S (init_haplotypes_LD2)
   for (int row = threadIdx.x; row < rd.R; row += blockDim.x) sg[row] = u01(rd.seed, ctr0 + row) < 0.5 ? -1 : 1;
   __syncthreads();
-  const long long obj = cross_optimize(P, rd, sg, dl, et, true, false, red);
+  const long long obj = cross_optimize(P, rd, sg, dl, et, true, false, red, wl);
   if (threadIdx.x == 0) P.st_obj[slot] = obj;
 }
 
 // chain, part B (phase.rs:1197-1233): perturbation rounds with best-state tracking
 __global__ void __launch_bounds__(LCR_BLOCK) k4_chain_b(PhaseDev P, const int32_t* __restrict__ slots, int32_t n) {
   __shared__ long long red[LCR_BLOCK / 64];
+  __shared__ long long wl[32];
   if ((int)blockIdx.x >= n) return;
+  load_w(P, wl);
   const int slot = slots[blockIdx.x];
   const RegionDev rd = P.reg[slot];
   int8_t* bsg = P.st_sigma + rd.sig_off; int8_t* bdl = P.st_delta + rd.snp_off; int8_t* bet = P.st_eta + rd.snp_off;
-  int8_t* sg = P.scratch + (size_t)blockIdx.x * P.scratch_stride; int8_t* dl = sg + rd.R; int8_t* et = dl + rd.S;
+  extern __shared__ __attribute__((aligned(16))) int8_t dyn_state[];
+  int8_t* sg = P.lds_state ? dyn_state : P.scratch + (size_t)blockIdx.x * P.scratch_stride;
+  int8_t* dl = sg + rd.R; int8_t* et = dl + rd.S;
   long long best = P.st_obj[slot];
   auto load_best = [&]() {
     for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { dl[i] = bdl[i]; et[i] = bet[i]; }
@@ -245,13 +262,13 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_chain_b(PhaseDev P, const int32_
       else if (rg >= 0.9) dl[i] = flip ? -1 : 1;
     }
     __syncthreads();
-    long long obj = cross_optimize(P, rd, sg, dl, et, false, false, red);
+    long long obj = cross_optimize(P, rd, sg, dl, et, false, false, red, wl);
     save_if_better(obj);
     load_best();
     for (int row = threadIdx.x; row < rd.R; row += blockDim.x)  // phase.rs:1217-1224
       if (u01(rd.seed, ctr_t + rd.S + row) < 0.1) sg[row] = (int8_t)(-sg[row]);
     __syncthreads();
-    obj = cross_optimize(P, rd, sg, dl, et, false, false, red);
+    obj = cross_optimize(P, rd, sg, dl, et, false, false, red, wl);
     save_if_better(obj);
     load_best();
   }
@@ -331,19 +348,30 @@ inline double lg(int sigma, int delta, int eta, uint8_t v) {  // log10(aki(...))
   const int p = (v & 32) ? 1 : -1, x = eta == 0 ? sigma * delta : eta;
   return p == x ? hlut().l1e[v & 31] : hlut().le[v & 31];
 }
-// phase.rs:128-176
-double delta_eta_sigma_log(int delta_i, int eta_i, const std::vector<Obs>& o) {
-  double q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
-  const double p_het = o.empty() ? hlut().log_theta : hlut().log_theta - (double)(uint32_t)o.size() * hlut().log2;
-  for (const Obs& x : o) q1 += lg(x.sigma, delta_i, eta_i, x.v);
-  q1 += eta_i == 0 ? p_het : (eta_i == 1 ? hlut().p_homref : hlut().p_homvar);
-  for (const Obs& x : o) {
-    q2 += lg(x.sigma, delta_i, -1, x.v); q3 += lg(x.sigma, delta_i, 0, x.v);
-    q4 += lg(x.sigma, delta_i, 1, x.v); q5 += lg(x.sigma, -delta_i, 0, x.v);
+// phase.rs:128-176.  The five log sums of one call are running sums over the same observation order;
+// the sum for eta != 0 does not depend on delta, and log_q1 repeats one of the other four, so the four
+// distinct sums are computed once (identical addition sequences => identical doubles) and each of
+// the reference's calls is assembled from them.
+struct ColScores {
+  double het_d = 0, het_nd = 0, homref = 0, homvar = 0;  // sum log10 aki for (delta,0), (-delta,0), (.,+1), (.,-1)
+  double p_het = 0;
+  ColScores(int delta_i, const std::vector<Obs>& o) {
+    p_het = o.empty() ? hlut().log_theta : hlut().log_theta - (double)(uint32_t)o.size() * hlut().log2;
+    for (const Obs& x : o) {
+      het_d += lg(x.sigma, delta_i, 0, x.v); het_nd += lg(x.sigma, -delta_i, 0, x.v);
+      homref += lg(x.sigma, delta_i, 1, x.v); homvar += lg(x.sigma, delta_i, -1, x.v);
+    }
   }
-  q2 += hlut().p_homvar; q3 += p_het; q4 += hlut().p_homref; q5 += p_het;
-  return 1.0 - q1 / (q2 + q3 + q4 + q5);
-}
+  // cal_delta_eta_sigma_log(sign * delta_i, eta_i, ...), sign = +1 / -1
+  double score(int sign, int eta_i) const {
+    const double hd = sign > 0 ? het_d : het_nd, hn = sign > 0 ? het_nd : het_d;
+    double q1 = eta_i == 0 ? hd : (eta_i == 1 ? homref : homvar);
+    q1 += eta_i == 0 ? p_het : (eta_i == 1 ? hlut().p_homref : hlut().p_homvar);
+    const double q2 = homvar + hlut().p_homvar, q3 = hd + p_het, q4 = homref + hlut().p_homref, q5 = hn + p_het;
+    return 1.0 - q1 / (q2 + q3 + q4 + q5);
+  }
+};
+double delta_eta_sigma_log(int delta_i, int eta_i, const std::vector<Obs>& o) { return ColScores(delta_i, o).score(1, eta_i); }
 // phase.rs:238-255
 double phase_score_log(int delta_i, int eta_i, const std::vector<Obs>& o) {
   double q1 = 0, q2 = 0, q3 = 0;
@@ -432,8 +460,8 @@ struct RegionHost {
       int hap1, hap2;
       gather(ti, false, snp.variant_type == 1, o, hap1, hap2);
       if (o.empty()) { snp.flags |= LCR_F_NON_SELECTED; continue; }
-      const double q1 = delta_eta_sigma_log(delta_i, 0, o), q2 = delta_eta_sigma_log(-delta_i, 0, o);
-      const double q3 = delta_eta_sigma_log(delta_i, 1, o), q4 = delta_eta_sigma_log(delta_i, -1, o);
+      const ColScores cs(delta_i, o);
+      const double q1 = cs.score(1, 0), q2 = cs.score(-1, 0), q3 = cs.score(1, 1), q4 = cs.score(1, -1);
       const double mx = std::fmax(q1, std::fmax(q2, std::fmax(q3, q4)));
       if (q1 == mx) { snp.haplotype = delta_i; snp.genotype = 0; snp.variant_type = 1; }
       else if (q2 == mx) { snp.haplotype = -delta_i; snp.genotype = 0; snp.variant_type = 1; }
@@ -572,6 +600,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     std::vector<int32_t> prow_ptr, pcol, ccol_ptr, crow;
     std::vector<uint8_t> pval, cval, fp, cons;
     std::vector<int8_t> vt, delta0;
+    std::vector<long long> snp_const;  // 4 per SNP: F, W, Cref, Cvar
+    long long f_total = 0;
   };
   std::vector<RegionBuild> RB(ng);
   (void)hlut();
@@ -622,6 +652,15 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
         rb.crow[fill[i]] = (int32_t)k; rb.cval[fill[i]] = rb.pval[e]; fill[i]++;
       }
     rb.fp.resize(rh.S); rb.vt.resize(rh.S); rb.cons.assign(rh.S, 0); rb.delta0.assign(rh.S, 1);
+    rb.snp_const.assign(4 * (size_t)rh.S, 0);
+    for (int e = 0; e < acc; e++) {
+      const PhaseLutDev& LD = hlut().dev;
+      const int q = rb.pval[e] & 31, i = rb.pcol[e];
+      const bool pref = (rb.pval[e] & 32) != 0;
+      rb.snp_const[4 * i] += LD.fe[q]; rb.snp_const[4 * i + 1] += LD.f1e[q] - LD.fe[q];
+      rb.snp_const[4 * i + 2] += pref ? LD.f1e[q] : LD.fe[q]; rb.snp_const[4 * i + 3] += pref ? LD.fe[q] : LD.f1e[q];
+      rb.f_total += LD.fe[q];
+    }
     for (int i = 0; i < rh.S; i++) { rb.fp[i] = rh.fphase(i) ? 1 : 0; rb.vt[i] = (int8_t)rh.cand[i].variant_type; }
     // thread.rs:162-163: init_haplotypes + init_assignment consume S + F draws; both are overwritten
     if ((uint32_t)rh.S <= prm.max_enum_snps) return;
@@ -706,6 +745,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   std::vector<int32_t> h_prow_ptr, h_pcol, h_ccol_ptr, h_crow;
   std::vector<uint8_t> h_pval, h_cval, h_fp, h_cons;
   std::vector<int8_t> h_vt, h_delta0;
+  std::vector<long long> h_snp_const;
   int32_t sig_total = 0, snp_total = 0, max_state = 0;
   std::vector<int32_t> enum_slots, chain_slots;
   auto app = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
@@ -716,12 +756,12 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     RegionDev rd{};
     rd.R = (int32_t)rh.fp_rows.size(); rd.S = rh.S;
     rd.rp_off = (int32_t)h_prow_ptr.size(); rd.cp_off = (int32_t)h_ccol_ptr.size(); rd.e_off = (int64_t)h_pcol.size();
-    rd.sig_off = sig_total; rd.snp_off = snp_total; rd.seed = rh.seed;
+    rd.sig_off = sig_total; rd.snp_off = snp_total; rd.seed = rh.seed; rd.f_total = rb.f_total;
     sig_total += rd.R; snp_total += rd.S;
     max_state = std::max(max_state, rd.R + 2 * rd.S);
     app(h_prow_ptr, rb.prow_ptr); app(h_pcol, rb.pcol); app(h_pval, rb.pval);
     app(h_ccol_ptr, rb.ccol_ptr); app(h_crow, rb.crow); app(h_cval, rb.cval);
-    app(h_fp, rb.fp); app(h_vt, rb.vt); app(h_cons, rb.cons); app(h_delta0, rb.delta0);
+    app(h_fp, rb.fp); app(h_vt, rb.vt); app(h_cons, rb.cons); app(h_delta0, rb.delta0); app(h_snp_const, rb.snp_const);
     slot_of[g] = (int)rdev.size();
     if ((uint32_t)rh.S <= prm.max_enum_snps) enum_slots.push_back(slot_of[g]); else chain_slots.push_back(slot_of[g]);
     rdev.push_back(rd);
@@ -737,7 +777,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     };
     DevBuf &b_reg = d_state[0], &b_prp = d_state[1], &b_pc = d_state[2], &b_pv = d_state[3], &b_cp = d_state[4],
            &b_cr = d_state[5], &b_cv = d_state[6], &b_snp = d_state[7], &b_st = d_state[8], &b_scr = d_state[9],
-           &b_job = d_state[10], &b_obj = d_state[11];
+           &b_job = d_state[10], &b_obj = d_state[11], &b_sc = d_state[12];
     PCHK(up(b_reg, rdev.data(), rdev.size() * sizeof(RegionDev)));
     PCHK(up(b_prp, h_prow_ptr.data(), h_prow_ptr.size() * 4));
     PCHK(up(b_pc, h_pcol.data(), h_pcol.size() * 4));
@@ -751,6 +791,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     memcpy(snp_pack.data() + snp_total, h_vt.data(), snp_total);
     memcpy(snp_pack.data() + 2 * (size_t)snp_total, h_cons.data(), snp_total);
     PCHK(up(b_snp, snp_pack.data(), snp_pack.size()));
+    PCHK(up(b_sc, h_snp_const.data(), h_snp_const.size() * sizeof(long long)));
     // state: sigma[sig_total] | delta[snp_total] | eta[snp_total] | obj[n_slots] (8-byte aligned)
     const size_t st_sig = 0, st_del = ((size_t)sig_total + 15) & ~(size_t)15, st_eta = st_del + (((size_t)snp_total + 15) & ~(size_t)15);
     const size_t st_obj = st_eta + (((size_t)snp_total + 15) & ~(size_t)15);
@@ -765,10 +806,13 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     P.reg = b_reg.as<RegionDev>();
     P.prow_ptr = b_prp.as<int32_t>(); P.pcol = b_pc.as<int32_t>(); P.pval = b_pv.as<uint8_t>();
     P.ccol_ptr = b_cp.as<int32_t>(); P.crow = b_cr.as<int32_t>(); P.cval = b_cv.as<uint8_t>();
+    P.snp_const = b_sc.as<long long>();
     P.snp_fp = b_snp.as<uint8_t>(); P.snp_vt = b_snp.as<int8_t>() + snp_total; P.snp_cons = b_snp.as<uint8_t>() + 2 * (size_t)snp_total;
     P.st_sigma = b_st.as<int8_t>() + st_sig; P.st_delta = b_st.as<int8_t>() + st_del; P.st_eta = b_st.as<int8_t>() + st_eta;
     P.st_obj = (long long*)(b_st.as<int8_t>() + st_obj);
     P.scratch = b_scr.as<int8_t>(); P.scratch_stride = stride;
+    const size_t dyn_bytes = stride <= 48 * 1024 ? (size_t)stride : 0;  // working state in LDS when it fits
+    P.lds_state = dyn_bytes ? 1 : 0;
     P.lut = L.dev;
 
     PCHK(hipStreamSynchronize(stream));
@@ -788,7 +832,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       int32_t* d_js = b_job.as<int32_t>(); uint32_t* d_je = (uint32_t*)(b_job.as<int32_t>() + nj);
       PCHK(hipMemcpyAsync(d_js, job_slot.data(), (size_t)nj * 4, hipMemcpyHostToDevice, stream));
       PCHK(hipMemcpyAsync(d_je, job_e.data(), (size_t)nj * 4, hipMemcpyHostToDevice, stream));
-      hipLaunchKernelGGL(k4_enum, dim3(std::min(nj, n_blocks_max)), dim3(LCR_BLOCK), 0, stream, P, d_js, d_je, nj,
+      hipLaunchKernelGGL(k4_enum, dim3(std::min(nj, n_blocks_max)), dim3(LCR_BLOCK), dyn_bytes, stream, P, d_js, d_je, nj,
                          b_obj.as<long long>(), 0);
       std::vector<long long> obj(nj);
       PCHK(hipMemcpyAsync(obj.data(), b_obj.p, (size_t)nj * 8, hipMemcpyDeviceToHost, stream));
@@ -803,7 +847,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       const int nw = (int)win_slot.size();
       PCHK(hipMemcpyAsync(d_js, win_slot.data(), (size_t)nw * 4, hipMemcpyHostToDevice, stream));
       PCHK(hipMemcpyAsync(d_js + nw, win_e.data(), (size_t)nw * 4, hipMemcpyHostToDevice, stream));
-      hipLaunchKernelGGL(k4_enum, dim3(std::min(nw, n_blocks_max)), dim3(LCR_BLOCK), 0, stream, P, d_js, (uint32_t*)(d_js + nw), nw,
+      hipLaunchKernelGGL(k4_enum, dim3(std::min(nw, n_blocks_max)), dim3(LCR_BLOCK), dyn_bytes, stream, P, d_js, (uint32_t*)(d_js + nw), nw,
                          b_obj.as<long long>(), 1);
       PCHK(hipGetLastError());
       PCHK(hipStreamSynchronize(stream));  // win_slot / win_e are pageable host vectors
@@ -884,7 +928,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       };
       for_regions(block_pass);
       PCHK(hipMemcpyAsync(b_st.p, st_host.data(), st_host.size(), hipMemcpyHostToDevice, stream));
-      hipLaunchKernelGGL(k4_chain_b, dim3(nc), dim3(LCR_BLOCK), 0, stream, P, b_slots.as<int32_t>(), nc);
+      hipLaunchKernelGGL(k4_chain_b, dim3(nc), dim3(LCR_BLOCK), dyn_bytes, stream, P, b_slots.as<int32_t>(), nc);
       PCHK(hipGetLastError());
     }
     PCHK(pull_state());

@@ -73,7 +73,7 @@ struct PhaseHost {
   std::vector<uint8_t> assignment;
   std::vector<uint32_t> phase_set;
   std::vector<double> objective;
-  DevBuf d_state[12];
+  DevBuf d_state[13];
   HostPool* pool = nullptr;
   int run(const PhaseInputs& in, const lcr_params& p, hipStream_t s, std::string* err);
   void release() { for (auto& b : d_state) b.release(); delete pool; pool = nullptr; }
