@@ -24,6 +24,7 @@
 //       bases from the finished planes with global atomics.
 // All arithmetic is u32 adds => bit-exact regardless of order.  Base qualities are NOT read here: they
 // are only needed at the < 1 % of columns that survive the count filters (k2_hist).
+#include <algorithm>
 #include <climits>
 
 #include "lcr_dev.h"
@@ -62,113 +63,150 @@ void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// K0: one wave per read.  pass 0: validate ops, intron difference array, records per tile.
-//                          pass 1: write the records.
-__global__ void __launch_bounds__(LCR_BLOCK)
-k0_bin(BatchView b, int pass, int ont, int D, int32_t* __restrict__ tile_count, const int32_t* __restrict__ tile_off,
-       int32_t* __restrict__ tile_fill, unsigned long long* __restrict__ recs, uint32_t* __restrict__ ndiff) {
-  const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * (LCR_BLOCK / 64) + (threadIdx.x >> 6);
+// per-read header pack (once per batch): everything K0 needs about a read in one 64-byte line
+__global__ void __launch_bounds__(LCR_BLOCK) k0_pack(BatchView b, ReadBin* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= b.n_reads) return;
   const int g = region_of_read(b, r);
-  const int vec = b.len[g];
-  const int64_t gbase = b.col_off[g] + g;  // one spare slot per region so that end markers never leak
-  const int ftile = b.region_first_tile[g];
-  const uint32_t ncig = b.n_cig[r];
-  const uint32_t* __restrict__ cg = b.cigar + b.cig_off[r];
-  const int lead = b.lead[r];
-  const int seq_len = b.seq_len[r];
-  const int reb = seq_len - b.trail[r];
-  const unsigned long long seq_off = b.seq_off[r];
-  const int fl = b.flags[r];
-  const int strand = fl & 1, ts = (fl >> 1) & 3;
-  // transcript_strands index (util.rs:803-819): (+,+)->0 (+,-)->1 (-,+)->1 (-,-)->0, none -> -1
-  const unsigned long long tscls = ts == 0 ? 0ull : ((strand == 0) == (ts == 1) ? 1ull : 2ull);
-  const unsigned long long hi_bits = ((unsigned long long)strand << 60) | (tscls << 61);
-  const unsigned long long below = (1ull << lane) - 1ull;
-  int ref_cur = (int)((int64_t)b.pos[r] - b.start0[g]);
-  int q_cur = lead > 0 ? lead : 0;
-  for (uint32_t c0 = 0; c0 < ncig; c0 += 64) {
-    if (ref_cur > vec && pass == 1) break;  // nothing at or right of column vec contributes
-    const bool act = c0 + lane < ncig;
-    const uint32_t word = act ? cg[c0 + lane] : 0u;
-    const int op = word & 15, len = (int)(word >> 4);
-    const bool is_m = act && (op == 0 || op == 7 || op == 8);
-    const bool is_d = act && op == 2, is_n = act && op == 3, is_i = act && op == 1;
-    if (pass == 0 && act && !(is_m || is_d || is_n || is_i || op == 4 || op == 5)) atomicExch(b.error_flag, 1);
-    const int dr = (is_m || is_d || is_n) ? len : 0;
-    const int dq = (is_m || is_i) ? len : 0;
-    const int ir = wave_incl_scan(dr), iq = wave_incl_scan(dq);
-    const int rs = ref_cur + ir - dr;   // region-relative column where this op starts
-    const int qs = q_cur + iq - dq;     // read offset where this op starts
-    int a = max(rs, 0), e = min(rs + len, vec);
-    if (pass == 0 && is_n && e > a) {  // util.rs:930-942
-      atomicAdd(&ndiff[gbase + a], 1u);
-      atomicAdd(&ndiff[gbase + e], 0xFFFFFFFFu);
-    }
-    if (ont && is_m) {  // ONT end trim (util.rs:745-751): keep read offsets lead + D <= c <= reb - D
-      a = max(a, rs + (lead + D - qs));
-      e = min(e, rs + (reb - D + 1 - qs));
-    }
-    // column range [a, e) this op contributes records for (I: the single column rs-1, 1 <= rs < vec)
-    bool has = (is_m || is_d) && len > 0 && e > a;
-    if (is_i && len > 0 && rs >= 1 && rs < vec) { has = true; a = rs - 1; e = rs; }
-    int t_cur = has ? a / LCR_TILE : INT_MAX;       // tile of the next record of this lane
-    const int t_last = has ? (e - 1) / LCR_TILE : -1;
-    // rounds: every lane emits its record for tile t_cur, then moves to its next tile (ops rarely span
-    // more than two tiles).  Ops are ordered by position, so within a round the emitting lanes' tiles
-    // are non-decreasing: runs of equal tiles are contiguous, each run's first lane allocates the
-    // slots of the whole run with ONE atomic, and all runs of the round issue their atomics together.
-    for (;;) {
-      const bool emit = has && t_cur <= t_last;
-      const unsigned long long em = __ballot(emit);
-      if (em == 0ull) break;
-      const unsigned long long em_below = em & below;
-      const int prev_lane = em_below ? 63 - __clzll((long long)em_below) : 0;
-      const int prev_tile = __shfl(t_cur, prev_lane, 64);
-      const bool leader = emit && (em_below == 0ull || prev_tile != t_cur);
-      const unsigned long long lm = __ballot(leader);
-      // my run: from its leader (highest leader bit at or below me) to just before the next leader
-      const unsigned long long lm_le = lm & (below | (1ull << lane));
-      const int my_leader = lm_le ? 63 - __clzll((long long)lm_le) : 0;
-      int base = 0;
-      if (leader) {
-        const unsigned long long above = lane == 63 ? 0ull : (~0ull << (lane + 1));
-        const unsigned long long nxt = lm & above;
-        const unsigned long long run = nxt ? (em & above & ((1ull << (__ffsll((long long)nxt) - 1)) - 1ull)) : (em & above);
-        const int cnt = 1 + __popcll(run);
-        if (pass == 0) atomicAdd(&tile_count[ftile + t_cur], cnt);
-        else base = atomicAdd(&tile_fill[ftile + t_cur], cnt);
-      }
-      if (pass == 1) {
-        base = __shfl(base, my_leader, 64);
-        if (emit) {
-          const unsigned long long leader_below = my_leader == 0 ? 0ull : ((1ull << my_leader) - 1ull);
-          const int slot = tile_off[ftile + t_cur] + base + __popcll(em_below & ~leader_below);
-          const int c_lo = max(a, t_cur * LCR_TILE), c_hi = min(e, (t_cur + 1) * LCR_TILE);  // columns in this tile
-          unsigned long long rec = ((unsigned long long)(c_lo - t_cur * LCR_TILE) << 40) |
-                                   ((unsigned long long)(c_hi - c_lo - 1) << 50);
-          if (is_m) rec |= ((seq_off + (unsigned long long)(qs + (c_lo - rs))) & REC_OFF_MASK) | hi_bits;
-          else rec |= is_d ? REC_KIND_D : REC_KIND_I;
-          recs[slot] = rec;
-        }
-      }
-      if (emit) t_cur++;
-    }
-    ref_cur += __shfl(ir, 63, 64);
-    q_cur += __shfl(iq, 63, 64);
-  }
-  // aligned read offsets must lie in [lead, seq_len - trail): the end-zone logic relies on it
-  // (true for every valid BAM record: l_seq = sum of M/I/S/=/X lengths)
-  if (pass == 0 && lane == 0 && ncig > 0 && q_cur != reb) atomicExch(b.error_flag, 2);
+  ReadBin h;
+  h.rel_pos = (int32_t)((int64_t)b.pos[r] - b.start0[g]);
+  h.vec = b.len[g]; h.ftile = b.region_first_tile[g]; h.n_cig = (int32_t)b.n_cig[r];
+  h.gbase = b.col_off[g] + g;
+  h.seq_off = b.seq_off[r]; h.cig_off = b.cig_off[r];
+  h.lead = b.lead[r]; h.reb = b.seq_len[r] - b.trail[r];
+  h.flags = b.flags[r]; h.pad_ = 0; h.pad2_ = 0;
+  out[r] = h;
+}
+void launch_k0_pack(const BatchView& b, ReadBin* out, hipStream_t s) {
+  if (b.n_reads == 0) return;
+  hipLaunchKernelGGL(k0_pack, dim3((b.n_reads + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, b, out);
 }
 
-void launch_k0_bin(const BatchView& b, int pass, int ont, int D, int32_t* tile_count, const int32_t* tile_off,
-                   int32_t* tile_fill, unsigned long long* recs, uint32_t* ndiff, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------
+// K0: persistent waves, one read per wave and step.  pass 0: validate ops, intron difference array,
+// records per tile.  pass 1: write the records.  The header of the next read and the first CIGAR words
+// of the next read / next chunk are requested before the current chunk is processed, so the dependent
+// HBM round trips (header -> CIGAR -> slot atomics) of consecutive reads overlap.
+__global__ void __launch_bounds__(LCR_BLOCK)
+k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int pass, int ont, int D, int32_t* __restrict__ tile_count,
+       const int32_t* __restrict__ tile_off, int32_t* __restrict__ tile_fill, unsigned long long* __restrict__ recs,
+       uint32_t* __restrict__ ndiff) {
+  const int lane = threadIdx.x & 63;
+  const int n_waves = gridDim.x * (LCR_BLOCK / 64);
+  int r = blockIdx.x * (LCR_BLOCK / 64) + (threadIdx.x >> 6);
+  if (r >= b.n_reads) return;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  r = __builtin_amdgcn_readfirstlane(r);  // wave-uniform: header loads become scalar loads
+  ReadBin h = rbin[r];
+  uint32_t word = (uint32_t)lane < (uint32_t)h.n_cig ? b.cigar[h.cig_off + lane] : 0u;
+  for (; r < b.n_reads; r += n_waves) {
+    const int r_next = r + n_waves;
+    ReadBin hn = h;
+    if (r_next < b.n_reads) hn = rbin[r_next];          // prefetch the next read's header
+    const int vec = h.vec;
+    const int64_t gbase = h.gbase;
+    const int ftile = h.ftile;
+    const uint32_t ncig = (uint32_t)h.n_cig;
+    const uint32_t* __restrict__ cg = b.cigar + h.cig_off;
+    const int lead = h.lead, reb = h.reb;
+    const unsigned long long seq_off = h.seq_off;
+    const int strand = h.flags & 1, ts = (h.flags >> 1) & 3;
+    // transcript_strands index (util.rs:803-819): (+,+)->0 (+,-)->1 (-,+)->1 (-,-)->0, none -> -1
+    const unsigned long long tscls = ts == 0 ? 0ull : ((strand == 0) == (ts == 1) ? 1ull : 2ull);
+    const unsigned long long hi_bits = ((unsigned long long)strand << 60) | (tscls << 61);
+    int ref_cur = h.rel_pos;
+    int q_cur = lead > 0 ? lead : 0;
+    uint32_t word_n = 0;                                 // first CIGAR words of the next read
+    bool have_wn = false;
+    for (uint32_t c0 = 0; c0 < ncig; c0 += 64) {
+      if (ref_cur > vec && pass == 1) break;  // nothing at or right of column vec contributes
+      const bool act = c0 + lane < ncig;
+      const uint32_t w = word;
+      if (c0 + 64 < ncig) word = c0 + 64 + lane < ncig ? cg[c0 + 64 + lane] : 0u;      // prefetch the next chunk
+      else if (r_next < b.n_reads) { word_n = (uint32_t)lane < (uint32_t)hn.n_cig ? b.cigar[hn.cig_off + lane] : 0u; have_wn = true; }
+      const int op = w & 15, len = (int)(w >> 4);
+      const bool is_m = act && (op == 0 || op == 7 || op == 8);
+      const bool is_d = act && op == 2, is_n = act && op == 3, is_i = act && op == 1;
+      if (pass == 0 && act && !(is_m || is_d || is_n || is_i || op == 4 || op == 5)) atomicExch(b.error_flag, 1);
+      const int dr = (is_m || is_d || is_n) ? len : 0;
+      const int dq = (is_m || is_i) ? len : 0;
+      const int ir = wave_incl_scan(dr), iq = wave_incl_scan(dq);
+      const int rs = ref_cur + ir - dr;   // region-relative column where this op starts
+      const int qs = q_cur + iq - dq;     // read offset where this op starts
+      int a = max(rs, 0), e = min(rs + len, vec);
+      if (pass == 0 && is_n && e > a) {  // util.rs:930-942
+        atomicAdd(&ndiff[gbase + a], 1u);
+        atomicAdd(&ndiff[gbase + e], 0xFFFFFFFFu);
+      }
+      if (ont && is_m) {  // ONT end trim (util.rs:745-751): keep read offsets lead + D <= c <= reb - D
+        a = max(a, rs + (lead + D - qs));
+        e = min(e, rs + (reb - D + 1 - qs));
+      }
+      // column range [a, e) this op contributes records for (I: the single column rs-1, 1 <= rs < vec)
+      bool has = (is_m || is_d) && len > 0 && e > a;
+      if (is_i && len > 0 && rs >= 1 && rs < vec) { has = true; a = rs - 1; e = rs; }
+      int t_cur = has ? a / LCR_TILE : INT_MAX;       // tile of the next record of this lane
+      const int t_last = has ? (e - 1) / LCR_TILE : -1;
+      // rounds: every lane emits its record for tile t_cur, then moves to its next tile (ops rarely span
+      // more than two tiles).  Ops are ordered by position, so within a round the emitting lanes' tiles
+      // are non-decreasing: runs of equal tiles are contiguous, each run's first lane allocates the
+      // slots of the whole run with ONE atomic, and all runs of the round issue their atomics together.
+      for (;;) {
+        const bool emit = has && t_cur <= t_last;
+        const unsigned long long em = __ballot(emit);
+        if (em == 0ull) break;
+        const unsigned long long em_below = em & below;
+        const int prev_lane = em_below ? 63 - __clzll((long long)em_below) : 0;
+        const int prev_tile = __shfl(t_cur, prev_lane, 64);
+        const bool leader = emit && (em_below == 0ull || prev_tile != t_cur);
+        const unsigned long long lm = __ballot(leader);
+        // my run: from its leader (highest leader bit at or below me) to just before the next leader
+        const unsigned long long lm_le = lm & (below | (1ull << lane));
+        const int my_leader = lm_le ? 63 - __clzll((long long)lm_le) : 0;
+        int base = 0;
+        if (leader) {
+          const unsigned long long above = lane == 63 ? 0ull : (~0ull << (lane + 1));
+          const unsigned long long nxt = lm & above;
+          const unsigned long long run = nxt ? (em & above & ((1ull << (__ffsll((long long)nxt) - 1)) - 1ull)) : (em & above);
+          const int cnt = 1 + __popcll(run);
+          if (pass == 0) atomicAdd(&tile_count[ftile + t_cur], cnt);
+          else base = atomicAdd(&tile_fill[ftile + t_cur], cnt);
+        }
+        if (pass == 1) {
+          base = __shfl(base, my_leader, 64);
+          if (emit) {
+            const unsigned long long leader_below = my_leader == 0 ? 0ull : ((1ull << my_leader) - 1ull);
+            const int slot = tile_off[ftile + t_cur] + base + __popcll(em_below & ~leader_below);
+            const int c_lo = max(a, t_cur * LCR_TILE), c_hi = min(e, (t_cur + 1) * LCR_TILE);  // columns in this tile
+            unsigned long long rec = ((unsigned long long)(c_lo - t_cur * LCR_TILE) << 40) |
+                                     ((unsigned long long)(c_hi - c_lo - 1) << 50);
+            if (is_m) rec |= ((seq_off + (unsigned long long)(qs + (c_lo - rs))) & REC_OFF_MASK) | hi_bits;
+            else rec |= is_d ? REC_KIND_D : REC_KIND_I;
+            recs[slot] = rec;
+          }
+        }
+        if (emit) t_cur++;
+      }
+      ref_cur += __shfl(ir, 63, 64);
+      q_cur += __shfl(iq, 63, 64);
+      if (c0 + 64 >= ncig && pass == 0 && lane == 0 && q_cur != reb) atomicExch(b.error_flag, 2);
+    }
+    // (the loop above may leave early in pass 1; the next read's first words are then fetched here)
+    if (r_next < b.n_reads) {
+      if (!have_wn) word_n = (uint32_t)lane < (uint32_t)hn.n_cig ? b.cigar[hn.cig_off + lane] : 0u;
+      word = word_n;
+    }
+    h = hn;
+  }
+}
+
+void launch_k0_bin(const BatchView& b, const ReadBin* rb, int pass, int ont, int D, int32_t* tile_count,
+                   const int32_t* tile_off, int32_t* tile_fill, unsigned long long* recs, uint32_t* ndiff, hipStream_t s) {
   if (b.n_reads == 0) return;
   const int per = LCR_BLOCK / 64;
-  hipLaunchKernelGGL(k0_bin, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, pass, ont, D, tile_count,
-                     tile_off, tile_fill, recs, ndiff);
+  const int blocks = std::min((b.n_reads + per - 1) / per, 256 * 8);  // persistent: 8 workgroups per CU
+  hipLaunchKernelGGL(k0_bin, dim3(blocks), dim3(LCR_BLOCK), 0, s, b, rb, pass, ont, D, tile_count, tile_off, tile_fill,
+                     recs, ndiff);
 }
 
 // ---------------------------------------------------------------------------------------------

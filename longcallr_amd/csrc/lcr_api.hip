@@ -23,7 +23,7 @@ struct lcr_ctx {
   std::vector<int64_t> h_start0, h_col_off;
   std::vector<int32_t> h_len, h_read_begin, h_region_first_tile;
   DevBuf in_[16];  // device copies of host inputs (LCR_MEM_HOST)
-  DevBuf read_region, errflag, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_off, k0_tile_fill, k0_items, ndiff, nscan;
+  DevBuf read_region, read_bin, errflag, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_off, k0_tile_fill, k0_items, ndiff, nscan;
   int64_t n_items = 0;
 
   // K1
@@ -158,7 +158,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto& b : c->in_) b.release();
-  DevBuf* bufs[] = {&c->read_region, &c->errflag, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, &c->k0_tile_off,
+  DevBuf* bufs[] = {&c->read_region, &c->read_bin, &c->errflag, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, &c->k0_tile_off,
                     &c->k0_tile_fill, &c->k0_items, &c->ndiff, &c->nscan, &c->planes, &c->flags,
                     &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
                     &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
@@ -278,6 +278,8 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   launch_k0_read_region(b, c->read_region.as<int32_t>(), c->stream);
   b.region_first_tile = c->first_tile.as<int32_t>(); b.error_flag = c->errflag.as<int32_t>();
   HIPCHK(c, hipMemsetAsync(b.error_flag, 0, 4, c->stream));
+  HIPCHK(c, c->read_bin.reserve(std::max<size_t>(nr, 1) * sizeof(ReadBin)));
+  launch_k0_pack(b, c->read_bin.as<ReadBin>(), c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));  // keeps treg/tcol alive until copied
   HIPCHK(c, hipGetLastError());
   c->loaded = true;
@@ -309,7 +311,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, hipMemsetAsync(c->ndiff.p, 0, nd * 4, c->stream));
   int32_t n_recs = 0, bad = 0;
   { Timer t(c, LCR_K_SPANS);
-    launch_k0_bin(b, 0, c->dp.ont, c->dp.dist_to_end, c->k0_tile_count.as<int32_t>(), nullptr, nullptr, nullptr,
+    launch_k0_bin(b, c->read_bin.as<ReadBin>(), 0, c->dp.ont, c->dp.dist_to_end, c->k0_tile_count.as<int32_t>(), nullptr, nullptr, nullptr,
                   c->ndiff.as<uint32_t>(), c->stream);
     launch_scan_i32(c->k0_tile_count.as<int32_t>(), c->k0_tile_off.as<int32_t>(), nt, c->k0_tile_off.as<int32_t>() + nt, c->stream);
     HIPCHK(c, hipMemcpyAsync(&n_recs, c->k0_tile_off.as<int32_t>() + nt, 4, hipMemcpyDeviceToHost, c->stream));
@@ -318,7 +320,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
     if (bad == 1) { c->err = "unknown CIGAR operation (reference panics: util.rs:944)"; return LCR_E_CIGAR; }
     if (bad) { c->err = "CIGAR inconsistent with l_seq / soft clips"; return LCR_E_CIGAR; }
     HIPCHK(c, c->k0_items.reserve(std::max<size_t>(n_recs, 1) * 8));
-    launch_k0_bin(b, 1, c->dp.ont, c->dp.dist_to_end, nullptr, c->k0_tile_off.as<int32_t>(), c->k0_tile_fill.as<int32_t>(),
+    launch_k0_bin(b, c->read_bin.as<ReadBin>(), 1, c->dp.ont, c->dp.dist_to_end, nullptr, c->k0_tile_off.as<int32_t>(), c->k0_tile_fill.as<int32_t>(),
                   c->k0_items.as<unsigned long long>(), nullptr, c->stream);
     launch_scan_i32((const int32_t*)c->ndiff.p, c->nscan.as<int32_t>(), (int32_t)nd, nullptr, c->stream); }
   c->n_items = n_recs;

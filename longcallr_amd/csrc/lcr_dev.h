@@ -38,6 +38,20 @@ struct BatchView {
   int32_t* error_flag;               // != 0 -> unknown CIGAR op seen
 };
 
+// Per-read header packed once per batch (k0_pack) so that K0 needs a single 64-byte load per read.
+struct ReadBin {
+  int32_t rel_pos;     // pos - start0[region]
+  int32_t vec;         // region length in columns
+  int32_t ftile;       // first tile of the region
+  int32_t n_cig;
+  int64_t gbase;       // col_off[region] + region (slot base in the intron difference array)
+  uint64_t seq_off, cig_off;
+  int32_t lead, reb;   // leading soft clip, seq_len - trailing soft clip
+  int32_t flags, pad_;
+  int64_t pad2_;
+};
+static_assert(sizeof(ReadBin) == 64, "ReadBin must be 64 bytes");
+
 struct DevParams {
   int32_t ont;
   int32_t dist_to_end, polya_len;
@@ -111,7 +125,8 @@ struct PhaseLutDev {
 // ---- kernel launchers (defined in the .hip files) ----
 // K0: pass 0 counts records per tile (+ intron difference array, CIGAR validation); pass 1 writes them
 void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s);
-void launch_k0_bin(const BatchView& b, int pass, int ont, int D, int32_t* tile_count, const int32_t* tile_off,
+void launch_k0_pack(const BatchView& b, ReadBin* out, hipStream_t s);
+void launch_k0_bin(const BatchView& b, const ReadBin* rb, int pass, int ont, int D, int32_t* tile_count, const int32_t* tile_off,
                    int32_t* tile_fill, unsigned long long* recs, uint32_t* ndiff, hipStream_t s);
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const int32_t* tile_off, const unsigned long long* recs,
