@@ -32,6 +32,7 @@
 #define K1_THREADS 512
 #define K1_WAVES (K1_THREADS / 64)
 #define K1_CPT (LCR_TILE / K1_THREADS)  // columns per thread in the tile epilogue
+#define K1_RPB 2                        // records per thread and batch
 
 // record layout (64 bit): [0,40) byte offset of the first read base | [40,50) tile column |
 // [50,60) length-1 | [60] reverse strand | [61,63) transcript-strand class (0 none, 1 -> [0], 2 -> [1])
@@ -243,8 +244,8 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
           const int32_t* __restrict__ nscan, uint32_t* __restrict__ planes) {
   __shared__ uint32_t pl[P_NPL * TSTRIDE];
   __shared__ __attribute__((aligned(16))) uint8_t refl[REF_PAD + LCR_TILE + 32];
-  __shared__ unsigned long long rec_s[K1_THREADS];
-  __shared__ int pstart[K1_THREADS + 1];
+  __shared__ unsigned long long rec_s[K1_RPB * K1_THREADS];
+  __shared__ int pstart[K1_RPB * K1_THREADS + 1];
   __shared__ int wsum[K1_WAVES];
 
   const int tid = threadIdx.x;
@@ -276,79 +277,95 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   __syncthreads();
   const uint32_t* rl32 = reinterpret_cast<const uint32_t*>(refl);
 
-  for (int rbase = i0; rbase < i1 && prm.dbg != 3; rbase += K1_THREADS) {
-    // ---- phase 1: one record per thread
-    const bool hasrec = rbase + tid < i1;
-    const unsigned long long rec = hasrec ? recs[rbase + tid] : 0ull;
-    const unsigned long long off = rec & REC_OFF_MASK;
-    const int col0 = (int)((rec >> 40) & 1023u), len = (int)((rec >> 50) & 1023u) + 1;
-    int npieces = 0;
-    if (hasrec) {
-      if (off == REC_KIND_D) {          // util.rs:905-917: +1 per deleted reference position
-        atomicAdd(&pl[P_DIFF_D * TSTRIDE + col0], 1u);
-        atomicAdd(&pl[P_DIFF_D * TSTRIDE + col0 + len], 0xFFFFFFFFu);
-      } else if (off == REC_KIND_I) {   // util.rs:918-929
-        atomicAdd(&pl[P_NI * TSTRIDE + col0], 1u);
-      } else {                          // M-segment: range update now, per-base corrections in phase 2
-        const int strand = (int)((rec >> 60) & 1u), tscls = (int)((rec >> 61) & 3u);
-        uint32_t* dp = pl + (strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
-        atomicAdd(&dp[col0], 1u);
-        atomicAdd(&dp[col0 + len], 0xFFFFFFFFu);
-        if (tscls) {
-          uint32_t* tp = pl + (tscls == 2 ? P_DIFF_TS1 : P_DIFF_TS0) * TSTRIDE;
-          atomicAdd(&tp[col0], 1u);
-          atomicAdd(&tp[col0 + len], 0xFFFFFFFFu);
+  // record batches of K1_RPB * K1_THREADS records: fewer block-wide barriers per record
+  for (int rbase = i0; rbase < i1 && prm.dbg != 3; rbase += K1_RPB * K1_THREADS) {
+    // ---- phase 1: K1_RPB records per thread (thread t owns batch slots K1_RPB*t .. K1_RPB*t + K1_RPB-1)
+    int npc[K1_RPB], nsum = 0;
+#pragma unroll
+    for (int x = 0; x < K1_RPB; x++) {
+      const int slot = tid * K1_RPB + x;
+      const bool hasrec = rbase + slot < i1;
+      const unsigned long long rec = hasrec ? recs[rbase + slot] : 0ull;
+      const unsigned long long off = rec & REC_OFF_MASK;
+      const int col0 = (int)((rec >> 40) & 1023u), len = (int)((rec >> 50) & 1023u) + 1;
+      int npieces = 0;
+      if (hasrec) {
+        if (off == REC_KIND_D) {          // util.rs:905-917: +1 per deleted reference position
+          atomicAdd(&pl[P_DIFF_D * TSTRIDE + col0], 1u);
+          atomicAdd(&pl[P_DIFF_D * TSTRIDE + col0 + len], 0xFFFFFFFFu);
+        } else if (off == REC_KIND_I) {   // util.rs:918-929
+          atomicAdd(&pl[P_NI * TSTRIDE + col0], 1u);
+        } else {                          // M-segment: range update now, per-base corrections in phase 2
+          const int strand = (int)((rec >> 60) & 1u), tscls = (int)((rec >> 61) & 3u);
+          uint32_t* dp = pl + (strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
+          atomicAdd(&dp[col0], 1u);
+          atomicAdd(&dp[col0 + len], 0xFFFFFFFFu);
+          if (tscls) {
+            uint32_t* tp = pl + (tscls == 2 ? P_DIFF_TS1 : P_DIFF_TS0) * TSTRIDE;
+            atomicAdd(&tp[col0], 1u);
+            atomicAdd(&tp[col0 + len], 0xFFFFFFFFu);
+          }
+          npieces = (int)(((off & 15ull) + (unsigned long long)len + 15ull) >> 4);
         }
-        npieces = (int)(((off & 15ull) + (unsigned long long)len + 15ull) >> 4);
       }
+      rec_s[slot] = rec;
+      npc[x] = prm.dbg == 1 ? 0 : npieces;
+      nsum += npc[x];
     }
-    rec_s[tid] = rec;
-    const int incl = block_incl_scan(prm.dbg == 1 ? 0 : npieces, wsum);
-    pstart[tid + 1] = incl;
+    int run = block_incl_scan(nsum, wsum) - nsum;   // exclusive prefix of this thread's first record
     if (tid == 0) pstart[0] = 0;
+#pragma unroll
+    for (int x = 0; x < K1_RPB; x++) { run += npc[x]; pstart[tid * K1_RPB + x + 1] = run; }
     __syncthreads();
-    const int P = pstart[K1_THREADS];
-    // ---- phase 2: one 16-byte aligned piece of read bases per thread
-    for (int p = tid; p < P; p += K1_THREADS) {
+    const int P = pstart[K1_RPB * K1_THREADS];
+    // ---- phase 2: one 16-byte aligned piece of read bases per thread, four pieces in flight per thread
+    struct Piece { uint4 v; int colA, k_lo, k_hi, strand; bool ok; };
+    auto fetch = [&](int p) -> Piece {
+      Piece q;
+      q.ok = p < P;
+      if (!q.ok) { q.v = make_uint4(0, 0, 0, 0); q.colA = 0; q.k_lo = q.k_hi = 0; q.strand = 0; return q; }
       int lo = 0;  // last record with pstart <= p
 #pragma unroll
-      for (int st = K1_THREADS / 2; st >= 1; st >>= 1) if (pstart[lo + st] <= p) lo += st;
+      for (int st = K1_RPB * K1_THREADS / 2; st >= 1; st >>= 1) if (pstart[lo + st] <= p) lo += st;
       const unsigned long long rc = rec_s[lo];
       const long long soff = (long long)(rc & REC_OFF_MASK);
       const int scol = (int)((rc >> 40) & 1023u), slen = (int)((rc >> 50) & 1023u) + 1;
-      const int strand = (int)((rc >> 60) & 1u);
+      q.strand = (int)((rc >> 60) & 1u);
       const long long A = (soff & ~15ll) + 16ll * (p - pstart[lo]);      // byte address of the piece
-      const int k_lo = (int)max(0ll, soff - A), k_hi = (int)min(16ll, soff + slen - A);  // valid bytes
-      const int colA = scol + (int)(A - soff);                            // column of byte 0 (may be < 0)
-      uint4 v;
-      if (A + 16 <= b.n_bases) v = *reinterpret_cast<const uint4*>(b.bases + A);
+      q.k_lo = (int)max(0ll, soff - A); q.k_hi = (int)min(16ll, soff + slen - A);   // valid bytes
+      q.colA = scol + (int)(A - soff);                                    // column of byte 0 (may be < 0)
+      if (A + 16 <= b.n_bases) q.v = *reinterpret_cast<const uint4*>(b.bases + A);
       else {  // last partial 16 bytes of the whole base array
         uint32_t t[4] = {0, 0, 0, 0};
         for (int x = 0; x < 16; x++)
           if (A + x < b.n_bases) t[x >> 2] |= (uint32_t)b.bases[A + x] << (8 * (x & 3));
-        v = make_uint4(t[0], t[1], t[2], t[3]);
+        q.v = make_uint4(t[0], t[1], t[2], t[3]);
       }
+      return q;
+    };
+    auto tally = [&](const Piece& q) {
+      if (!q.ok) return;
       // 16 reference bytes starting at column colA (unaligned in LDS): 5 dwords + byte alignment
-      const int ci = colA + REF_PAD, di = ci >> 2;
+      const int ci = q.colA + REF_PAD, di = ci >> 2;
       const uint32_t sh = (uint32_t)(ci & 3);
       const uint32_t r0 = rl32[di], r1 = rl32[di + 1], r2 = rl32[di + 2], r3 = rl32[di + 3], r4 = rl32[di + 4];
-      const uint32_t x0 = v.x ^ __builtin_amdgcn_alignbyte(r1, r0, sh), x1 = v.y ^ __builtin_amdgcn_alignbyte(r2, r1, sh);
-      const uint32_t x2 = v.z ^ __builtin_amdgcn_alignbyte(r3, r2, sh), x3 = v.w ^ __builtin_amdgcn_alignbyte(r4, r3, sh);
+      const uint32_t x0 = q.v.x ^ __builtin_amdgcn_alignbyte(r1, r0, sh), x1 = q.v.y ^ __builtin_amdgcn_alignbyte(r2, r1, sh);
+      const uint32_t x2 = q.v.z ^ __builtin_amdgcn_alignbyte(r3, r2, sh), x3 = q.v.w ^ __builtin_amdgcn_alignbyte(r4, r3, sh);
       // 16-bit mask of mismatching bytes among the valid ones
       auto nz4 = [](uint32_t x) -> uint32_t {
         return ((x & 0xffu) ? 1u : 0u) | ((x & 0xff00u) ? 2u : 0u) | ((x & 0xff0000u) ? 4u : 0u) | ((x & 0xff000000u) ? 8u : 0u);
       };
       uint32_t mm = nz4(x0) | (nz4(x1) << 4) | (nz4(x2) << 8) | (nz4(x3) << 12);
-      mm &= ((1u << k_hi) - 1u) & ~((1u << k_lo) - 1u);
+      mm &= ((1u << q.k_hi) - 1u) & ~((1u << q.k_lo) - 1u);
       if (prm.dbg == 5) mm = 0;
-      uint32_t* dp = pl + (strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
-      uint32_t* mp = pl + (strand ? P_MM_R : P_MM_F) * TSTRIDE;
+      uint32_t* dp = pl + (q.strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
+      uint32_t* mp = pl + (q.strand ? P_MM_R : P_MM_F) * TSTRIDE;
       while (mm) {  // rare: a few % of the bases
         const int kx = __ffs(mm) - 1;
         mm &= mm - 1;
-        const uint32_t w = kx < 4 ? v.x : kx < 8 ? v.y : kx < 12 ? v.z : v.w;
+        const uint32_t w = kx < 4 ? q.v.x : kx < 8 ? q.v.y : kx < 12 ? q.v.z : q.v.w;
         const uint32_t base = (w >> (8 * (kx & 3))) & 0xffu;
-        const int col = colA + kx;
+        const int col = q.colA + kx;
         // branch-free classification: A,C,G,T (either case) -> 0..3; anything else is "Invalid nucleotide
         // base" (util.rs:890-892): no allele count (depth - 1), transcript strand still counted
         const uint32_t h = (base >> 1) & 3u;
@@ -357,6 +374,13 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
         if (acgt) atomicAdd(&mp[bi * TSTRIDE + col], 1u);
         else { atomicAdd(&dp[col], 0xFFFFFFFFu); atomicAdd(&dp[col + 1], 1u); }
       }
+    };
+    for (int p = tid; p < P; p += 4 * K1_THREADS) {
+      const Piece q0 = fetch(p), q1 = fetch(p + K1_THREADS), q2 = fetch(p + 2 * K1_THREADS), q3 = fetch(p + 3 * K1_THREADS);
+      tally(q0);
+      tally(q1);
+      tally(q2);
+      tally(q3);
     }
     __syncthreads();
   }
@@ -421,17 +445,37 @@ void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* til
 // counted by K1 like any other base; they are rare, so they are subtracted with global atomics.
 __global__ void __launch_bounds__(LCR_BLOCK)
 k1_zonefix(BatchView b, int D, int L, int64_t n_cols, uint32_t* __restrict__ planes) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // one workgroup handles LCR_BLOCK / per reads: 32-bit index math only
   const int per = 2 * D;
-  const int r = (int)(gid / per), s = (int)(gid % per);
-  if (r >= b.n_reads || s == per - 1) return;
+  const int rpb = LCR_BLOCK / per;                       // reads per block (>= 1: dist_to_end <= 128)
+  const int lr = (int)threadIdx.x / per, s = (int)threadIdx.x - lr * per;
+  const int r = (int)blockIdx.x * rpb + lr;
+  if (lr >= rpb || r >= b.n_reads || s >= per - 1) return;
   const int seq_len = b.seq_len[r], lead = b.lead[r], reb = seq_len - b.trail[r];
   const int c = s < D ? lead + s : reb - D + 1 + (s - D);
   if (c < lead || c >= reb) return;                    // not an aligned read offset
   if (s >= D && c - lead < D) return;                  // both zones overlap: offset already covered by slot c-lead
   const uint8_t* __restrict__ seq = b.bases + b.seq_off[r];
   uint32_t m = 0;  // bit X: a homopolymer window of X starts in [c-L, c+1]
-  {
+  const long long gabs = (long long)b.seq_off[r] + c - L;   // absolute byte offset of read offset c-L
+  if (L <= 6 && c - L >= 0 && c + L <= seq_len - 1 && (gabs & ~3ll) + 16 <= b.n_bases) {
+    // fast path: the 2L+1 <= 13 window bytes lie inside 4 aligned dwords; one round trip, no loop of byte loads
+    const uint32_t* wp = reinterpret_cast<const uint32_t*>(b.bases + (gabs & ~3ll));
+    const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], sh = (uint32_t)(gabs & 3ll);
+    const uint32_t d[4] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+                           __builtin_amdgcn_alignbyte(w3, w2, sh), w3 >> (8 * sh)};
+    int run = 1;
+    uint32_t prev = d[0] & 0xffu;
+#pragma unroll
+    for (int i = 1; i < 13; i++) {
+      if (i <= 2 * L) {
+        const uint32_t cur = (d[i >> 2] >> (8 * (i & 3))) & 0xffu;
+        run = (cur == prev) ? run + 1 : 1;
+        prev = cur;
+        if (run >= L) m |= cur == 'A' ? 1u : cur == 'C' ? 2u : cur == 'G' ? 4u : cur == 'T' ? 8u : 0u;
+      }
+    }
+  } else {
     const int lo = max(c - L, 0), hi = min(c + L, seq_len - 1);
     if (hi - lo + 1 < L) return;
     int run = 1;
@@ -478,7 +522,7 @@ k1_zonefix(BatchView b, int D, int L, int64_t n_cols, uint32_t* __restrict__ pla
 }
 
 void launch_k1_zonefix(const BatchView& b, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s) {
-  const long long n = (long long)b.n_reads * 2 * D;
-  if (n == 0) return;
-  hipLaunchKernelGGL(k1_zonefix, dim3((unsigned)((n + LCR_BLOCK - 1) / LCR_BLOCK)), dim3(LCR_BLOCK), 0, s, b, D, L, n_cols, planes);
+  if (b.n_reads == 0 || D <= 0) return;
+  const int rpb = LCR_BLOCK / (2 * D);
+  hipLaunchKernelGGL(k1_zonefix, dim3((unsigned)((b.n_reads + rpb - 1) / rpb)), dim3(LCR_BLOCK), 0, s, b, D, L, n_cols, planes);
 }

@@ -290,6 +290,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   if (!c || !p) return LCR_E_ARG;
   if (!c->loaded) { c->err = "lcr_pileup before lcr_load_batch"; return LCR_E_STATE; }
   if (p->polya_len == 0 || p->polya_len > 16) { c->err = "polya_len must be in 1..16"; return LCR_E_ARG; }
+  if (p->dist_to_end > 128) { c->err = "dist_to_end must be <= 128"; return LCR_E_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   static float sor_thr = -1.f;
   if (sor_thr < 0.f) sor_thr = lcr_device_sor_threshold(c->stream);
