@@ -258,11 +258,23 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   if (i0 == i1) {
     // no M / D / I record touches this tile (pure intron or uncovered): every plane is 0 except the
     // intron plane, which comes from the global scan.  Most tiles of a spliced data set are like this.
-    for (int col = tid; col < tlen; col += K1_THREADS) {
+    // 16-byte stores: 4 consecutive columns per thread and plane (dword-aligned addresses)
+    for (int col = tid * 4; col < tlen; col += K1_THREADS * 4) {
       const int64_t o = gcol0 + col;
+      if (col + 4 <= tlen) {
 #pragma unroll
-      for (int k = 0; k < LCR_NPLANES; k++) planes[(int64_t)k * n_cols + o] = 0u;
-      planes[(int64_t)LCR_PL_N * n_cols + o] = (uint32_t)nscan[o + g + 1];
+        for (int k = 0; k < LCR_NPLANES; k++)
+          if (k != LCR_PL_N) *reinterpret_cast<uint4*>(planes + (int64_t)k * n_cols + o) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(planes + (int64_t)LCR_PL_N * n_cols + o) =
+            make_uint4((uint32_t)nscan[o + g + 1], (uint32_t)nscan[o + g + 2], (uint32_t)nscan[o + g + 3], (uint32_t)nscan[o + g + 4]);
+      } else {
+        for (int c2 = col; c2 < tlen; c2++) {
+          const int64_t o2 = gcol0 + c2;
+#pragma unroll
+          for (int k = 0; k < LCR_NPLANES; k++) planes[(int64_t)k * n_cols + o2] = 0u;
+          planes[(int64_t)LCR_PL_N * n_cols + o2] = (uint32_t)nscan[o2 + g + 1];
+        }
+      }
     }
     return;
   }
