@@ -212,6 +212,21 @@ int lcr_get_fragmat(lcr_ctx*, lcr_fragmat* out);
 int lcr_phase(lcr_ctx*, const lcr_params*);
 int lcr_get_phase_result(lcr_ctx*, lcr_phase_result* out);
 
+/* Region discovery: replaces find_isolated_regions_with_depth (util.rs:236-332, truncation
+ * off) for one contig.  ref_start / ref_end are record.reference_start() / reference_end() of the reads that
+ * pass the filters of util.rs:264-279 (mem = LCR_MEM_HOST or LCR_MEM_DEVICE).  Region i covers 0-based columns
+ * [start0[i], start0[i] + len[i]) — the reference's 1-based [start, end) = [start0+1, start0+len+1).  As in the
+ * reference, cursors and max_coverage are reset only when a region is emitted (`region_end > region_start`,
+ * util.rs:297-310): a single-column island stays pending and starts the region that ends with the next island. */
+typedef struct {
+  int32_t n_regions;
+  const int64_t* start0;
+  const int32_t* len;
+  const uint32_t* max_cov;
+} lcr_region_list;
+int lcr_discover_regions(lcr_ctx*, int32_t mem, int32_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                         int64_t contig_len, lcr_region_list* out);
+
 /* Timing: HIP-event time (ms) of the last launch of each kernel on the ctx's stream. */
 enum { LCR_K_SPANS = 0 /* K0: CIGAR decode + binning */, LCR_K_PILEUP, LCR_K_CAND_FILTER, LCR_K_CAND_HIST, LCR_K_CAND_GT,
        LCR_K_FRAG_COUNT, LCR_K_FRAG_FILL, LCR_K_PHASE, LCR_NKERNELS };

@@ -78,6 +78,10 @@ class LcrFragmat(C.Structure):
     ]
 
 
+class LcrRegionList(C.Structure):
+    _fields_ = [("n_regions", C.c_int32), ("start0", C.c_void_p), ("len", C.c_void_p), ("max_cov", C.c_void_p)]
+
+
 class LcrPhaseResult(C.Structure):
     _fields_ = [("n_rows", C.c_int32), ("n_regions", C.c_int32), ("haplotag", C.c_void_p),
                 ("assignment", C.c_void_p), ("phase_set", C.c_void_p), ("objective", C.c_void_p)]

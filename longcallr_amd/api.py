@@ -66,6 +66,16 @@ class Engine:
         self._chk(self.lib.lcr_load_batch(self.h, C.byref(reads), C.byref(regions)), "lcr_load_batch")
         return self
 
+    def discover_regions(self, ref_start, ref_end, contig_len):
+        """find_isolated_regions_with_depth (util.rs:236-332) for one contig -> [(start0, len, max_cov)]."""
+        rs = np.ascontiguousarray(ref_start, dtype=np.int32)
+        re_ = np.ascontiguousarray(ref_end, dtype=np.int32)
+        o = _abi.LcrRegionList()
+        self._chk(self.lib.lcr_discover_regions(self.h, _abi.LCR_MEM_HOST, int(rs.size), rs.ctypes.data, re_.ctypes.data,
+                                                int(contig_len), C.byref(o)), "lcr_discover_regions")
+        return list(zip(_view(o.start0, np.int64, o.n_regions).tolist(), _view(o.len, np.int32, o.n_regions).tolist(),
+                        _view(o.max_cov, np.uint32, o.n_regions).tolist()))
+
     # ---- stages ----------------------------------------------------------------------------------
     def fill_data_into_freq_vec(self):
         self._chk(self.lib.lcr_pileup(self.h, C.byref(self.params)), "lcr_pileup")

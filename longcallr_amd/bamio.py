@@ -133,11 +133,13 @@ def passes_filter(r, min_mapq=20, min_read_length=500, divergence=0.5):
 
 
 def discover_regions(recs, ref_id, ref_len):
-    """util.rs:236-332 (no truncation): coverage islands as (start0, len, max_cov).
+    """util.rs:236-332 (no truncation) on the host: coverage islands as (start0, len, max_cov).
 
     The reference emits 1-based [start, end) = [first0+1, last0+2); we return the 0-based column
-    window [first0, last0] = (start0=first0, len=last0-first0+1) and drop single-column islands
-    (`region_end > region_start`).
+    window (start0=first0, len=last0-first0+1).  As in the reference, a single-column island is not
+    emitted on its own: it stays pending and starts the region that ends with the next island
+    (cursors and max_coverage are only reset when a region is emitted).  `lcr_discover_regions` is the
+    GPU version of the same function.
     """
     diff = np.zeros(ref_len + 1, dtype=np.int64)
     for r in recs:
@@ -149,10 +151,14 @@ def discover_regions(recs, ref_id, ref_len):
     depth = np.cumsum(diff[:-1])
     cov = depth > 0
     edges = np.flatnonzero(np.diff(np.concatenate(([0], cov.view(np.int8), [0]))))
-    out = []
-    for s, e in zip(edges[0::2], edges[1::2]):  # [s, e) covered
-        if e - 1 > s:
-            out.append((int(s), int(e - s), int(depth[s:e].max())))
+    out, pend, running = [], -1, 0
+    for s, e in zip(edges[0::2], edges[1::2]):  # island [s, e)
+        running = max(running, int(depth[s:e].max()))
+        if pend < 0:
+            pend = int(s)
+        if e - 1 > pend:
+            out.append((pend, int(e - pend), running))
+            pend, running = -1, 0
     return out
 
 

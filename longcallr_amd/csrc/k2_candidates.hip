@@ -88,12 +88,11 @@ __global__ void __launch_bounds__(LCR_BLOCK) scan_phase3(OutT* __restrict__ out,
 __global__ void write_total_i32(const long long* total, int32_t* dst) { *dst = (int32_t)*total; }
 __global__ void write_total_i64(const long long* total, int64_t* dst) { *dst = (int64_t)*total; }
 
-static DevBuf g_scan_tmp;  // block sums + total (per process; ctx is single-threaded per device)
-
-void launch_scan_i32(const int32_t* in, int32_t* out_excl, int32_t n, int32_t* total, hipStream_t s) {
+// `tmp` is a caller-owned (per ctx) scratch buffer for the block sums: a ctx is single-threaded, two ctxs never share it
+void launch_scan_i32(DevBuf& tmp, const int32_t* in, int32_t* out_excl, int32_t n, int32_t* total, hipStream_t s) {
   const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-  (void)g_scan_tmp.reserve(((size_t)nb + 2) * sizeof(long long));
-  long long* bs = g_scan_tmp.as<long long>();
+  (void)tmp.reserve(((size_t)nb + 2) * sizeof(long long));
+  long long* bs = tmp.as<long long>();
   if (n > 0) {
     hipLaunchKernelGGL(scan_phase1<int32_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, in, out_excl, n, bs);
     hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(1024), 0, s, bs, nb, bs + nb);
@@ -104,10 +103,10 @@ void launch_scan_i32(const int32_t* in, int32_t* out_excl, int32_t n, int32_t* t
   }
 }
 // out_excl has n+1 entries; the last receives the total
-void launch_scan_i32_to_i64(const int32_t* in, int64_t* out_excl, int32_t n, hipStream_t s) {
+void launch_scan_i32_to_i64(DevBuf& tmp, const int32_t* in, int64_t* out_excl, int32_t n, hipStream_t s) {
   const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-  (void)g_scan_tmp.reserve(((size_t)nb + 2) * sizeof(long long));
-  long long* bs = g_scan_tmp.as<long long>();
+  (void)tmp.reserve(((size_t)nb + 2) * sizeof(long long));
+  long long* bs = tmp.as<long long>();
   if (n > 0) {
     hipLaunchKernelGGL(scan_phase1<int64_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, in, out_excl, n, bs);
     hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(1024), 0, s, bs, nb, bs + nb);
@@ -362,8 +361,18 @@ struct GtConst {
   double log10_2;
   double log_prior[3];      // log10 of (theta/2, theta, 1-1.5 theta)
 };
-static GtConst g_gtc;
-static bool g_gtc_init = false;
+static GtConst make_gt_const() {
+  GtConst c;
+  for (int q = 0; q <= 30; q++) {
+    double e = pow(0.1, (double)q / 10.0);
+    c.le[q] = log10(e);
+    c.l1e[q] = log10(1.0 - e);
+  }
+  c.log10_2 = log10(2.0);
+  const double theta = 0.001;
+  c.log_prior[0] = log10(theta / 2.0); c.log_prior[1] = log10(theta); c.log_prior[2] = log10(1.0 - 1.5 * theta);
+  return c;
+}
 
 __global__ void __launch_bounds__(LCR_BLOCK)
 k2_gt(DevParams prm, GtConst gc, const Survivor* __restrict__ sv, int32_t n_sv, const uint32_t* __restrict__ hist,
@@ -461,17 +470,7 @@ k2_gt(DevParams prm, GtConst gc, const Survivor* __restrict__ sv, int32_t n_sv, 
 
 void launch_k2_gt(const DevParams& p, const Survivor* sv, int32_t n_sv, const uint32_t* hist, const int64_t* start0,
                   lcr_candidate* out, uint8_t* keep, hipStream_t s) {
-  if (!g_gtc_init) {
-    for (int q = 0; q <= 30; q++) {
-      double e = pow(0.1, (double)q / 10.0);
-      g_gtc.le[q] = log10(e);
-      g_gtc.l1e[q] = log10(1.0 - e);
-    }
-    g_gtc.log10_2 = log10(2.0);
-    const double theta = 0.001;
-    g_gtc.log_prior[0] = log10(theta / 2.0); g_gtc.log_prior[1] = log10(theta); g_gtc.log_prior[2] = log10(1.0 - 1.5 * theta);
-    g_gtc_init = true;
-  }
+  static const GtConst g_gtc = make_gt_const();  // host libm values: the device only adds/multiplies them
   if (n_sv == 0) return;
   hipLaunchKernelGGL(k2_gt, dim3((n_sv + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, p, g_gtc, sv, n_sv, hist, start0, out, keep);
 }

@@ -23,13 +23,14 @@ struct lcr_ctx {
   std::vector<int64_t> h_start0, h_col_off;
   std::vector<int32_t> h_len, h_read_begin, h_region_first_tile;
   DevBuf in_[16];  // device copies of host inputs (LCR_MEM_HOST)
-  DevBuf read_region, read_bin, errflag, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_off, k0_tile_fill, k0_items, ndiff, nscan;
+  DevBuf scan_tmp, read_region, read_bin, errflag, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_off, k0_tile_fill, k0_items, ndiff, nscan;
   int64_t n_items = 0;
 
   // K1
   bool have_planes = false;
   DevBuf planes;
   DevParams dp{};
+  float sor_thr = -1.f;
   HostBuf h_planes;
 
   // K2
@@ -51,6 +52,12 @@ struct lcr_ctx {
   // K4 + post-phase
   bool have_phase = false;
   PhaseHost phase;
+
+  // region discovery (N3)
+  DevBuf rd_start, rd_end, rd_diff, rd_ex, rd_cnt, rd_off, rd_s, rd_e, rd_max;
+  std::vector<int64_t> rl_start0;
+  std::vector<int32_t> rl_len;
+  std::vector<uint32_t> rl_max;
 
   // timing
   bool timing = false;
@@ -158,7 +165,8 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto& b : c->in_) b.release();
-  DevBuf* bufs[] = {&c->read_region, &c->read_bin, &c->errflag, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, &c->k0_tile_off,
+  DevBuf* bufs[] = {&c->rd_start, &c->rd_end, &c->rd_diff, &c->rd_ex, &c->rd_cnt, &c->rd_off, &c->rd_s, &c->rd_e, &c->rd_max,
+                    &c->scan_tmp, &c->read_region, &c->read_bin, &c->errflag, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, &c->k0_tile_off,
                     &c->k0_tile_fill, &c->k0_items, &c->ndiff, &c->nscan, &c->planes, &c->flags,
                     &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
                     &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
@@ -292,9 +300,8 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   if (p->polya_len == 0 || p->polya_len > 16) { c->err = "polya_len must be in 1..16"; return LCR_E_ARG; }
   if (p->dist_to_end > 128) { c->err = "dist_to_end must be <= 128"; return LCR_E_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
-  static float sor_thr = -1.f;
-  if (sor_thr < 0.f) sor_thr = lcr_device_sor_threshold(c->stream);
-  c->dp = to_dev(p, sor_thr);
+  if (c->sor_thr < 0.f) c->sor_thr = lcr_device_sor_threshold(c->stream);  // candidate.rs:49-51, evaluated by the device's logf
+  c->dp = to_dev(p, c->sor_thr);
   { const char* e = getenv("LCR_K1_DBG"); c->dp.dbg = e ? atoi(e) : 0; }
   HIPCHK(c, c->planes.reserve(std::max<size_t>((size_t)c->n_cols * LCR_NPLANES, 1) * 4));
   BatchView& b = c->bv;
@@ -314,7 +321,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   { Timer t(c, LCR_K_SPANS);
     launch_k0_bin(b, c->read_bin.as<ReadBin>(), 0, c->dp.ont, c->dp.dist_to_end, c->k0_tile_count.as<int32_t>(), nullptr, nullptr, nullptr,
                   c->ndiff.as<uint32_t>(), c->stream);
-    launch_scan_i32(c->k0_tile_count.as<int32_t>(), c->k0_tile_off.as<int32_t>(), nt, c->k0_tile_off.as<int32_t>() + nt, c->stream);
+    launch_scan_i32(c->scan_tmp, c->k0_tile_count.as<int32_t>(), c->k0_tile_off.as<int32_t>(), nt, c->k0_tile_off.as<int32_t>() + nt, c->stream);
     HIPCHK(c, hipMemcpyAsync(&n_recs, c->k0_tile_off.as<int32_t>() + nt, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&bad, b.error_flag, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -323,7 +330,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
     HIPCHK(c, c->k0_items.reserve(std::max<size_t>(n_recs, 1) * 8));
     launch_k0_bin(b, c->read_bin.as<ReadBin>(), 1, c->dp.ont, c->dp.dist_to_end, nullptr, c->k0_tile_off.as<int32_t>(), c->k0_tile_fill.as<int32_t>(),
                   c->k0_items.as<unsigned long long>(), nullptr, c->stream);
-    launch_scan_i32((const int32_t*)c->ndiff.p, c->nscan.as<int32_t>(), (int32_t)nd, nullptr, c->stream); }
+    launch_scan_i32(c->scan_tmp, (const int32_t*)c->ndiff.p, c->nscan.as<int32_t>(), (int32_t)nd, nullptr, c->stream); }
   c->n_items = n_recs;
   // ---- K1: per-tile tally from the records; K1z: poly-A / homopolymer mask of the HiFi presets
   { Timer t(c, LCR_K_PILEUP);
@@ -367,7 +374,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   { Timer t(c, LCR_K_CAND_FILTER);
     launch_k2_filter(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
                      c->planes.as<uint32_t>(), c->flags.as<uint8_t>(), c->tile_count.as<int32_t>(), c->stream);
-    launch_scan_i32(c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(), nt, c->total.as<int32_t>(), c->stream); }
+    launch_scan_i32(c->scan_tmp, c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(), nt, c->total.as<int32_t>(), c->stream); }
   std::vector<int32_t> h_tile_off(nt + 1, 0);
   int32_t n_sv = 0;
   if (nt) HIPCHK(c, hipMemcpyAsync(h_tile_off.data(), c->tile_off.p, (size_t)nt * 4, hipMemcpyDeviceToHost, c->stream));
@@ -455,7 +462,7 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   { Timer t(c, LCR_K_FRAG_COUNT);
     launch_k3_count(c->bv, c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nrow,
                     c->row_cnt.as<int32_t>(), c->row_links.as<uint32_t>(), c->stream);
-    launch_scan_i32_to_i64(c->row_cnt.as<int32_t>(), c->row_ptr.as<int64_t>(), nrow, c->stream); }
+    launch_scan_i32_to_i64(c->scan_tmp, c->row_cnt.as<int32_t>(), c->row_ptr.as<int64_t>(), nrow, c->stream); }
   int64_t nnz = 0;
   HIPCHK(c, hipMemcpyAsync(&nnz, c->row_ptr.as<int64_t>() + nrow, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -518,6 +525,62 @@ int lcr_phase(lcr_ctx* c, const lcr_params* p) {
   int rc = c->phase.run(in, *p, c->stream, &c->err);
   if (rc) return rc;
   c->have_phase = true;
+  return LCR_OK;
+}
+
+int lcr_discover_regions(lcr_ctx* c, int32_t mem, int32_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                         int64_t contig_len, lcr_region_list* out) {
+  if (!c || !out || n_reads < 0 || contig_len < 0 || contig_len > 0x7FFFFFF0ll) return LCR_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->rl_start0.clear(); c->rl_len.clear(); c->rl_max.clear();
+  out->n_regions = 0; out->start0 = nullptr; out->len = nullptr; out->max_cov = nullptr;
+  if (n_reads == 0 || contig_len == 0) return LCR_OK;
+  const int32_t *d_s = ref_start, *d_e = ref_end;
+  if (mem == LCR_MEM_HOST) {
+    HIPCHK(c, c->rd_start.reserve((size_t)n_reads * 4)); HIPCHK(c, c->rd_end.reserve((size_t)n_reads * 4));
+    HIPCHK(c, hipMemcpyAsync(c->rd_start.p, ref_start, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rd_end.p, ref_end, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
+    d_s = c->rd_start.as<int32_t>(); d_e = c->rd_end.as<int32_t>();
+  }
+  const size_t nd = (size_t)contig_len + 2;
+  HIPCHK(c, c->rd_diff.reserve(nd * 4)); HIPCHK(c, c->rd_ex.reserve((nd + 1) * 4));
+  HIPCHK(c, hipMemsetAsync(c->rd_diff.p, 0, nd * 4, c->stream));
+  launch_k5_span_diff(d_s, d_e, n_reads, contig_len, c->rd_diff.as<uint32_t>(), c->stream);
+  launch_scan_i32(c->scan_tmp, (const int32_t*)c->rd_diff.p, c->rd_ex.as<int32_t>(), (int32_t)nd, nullptr, c->stream);
+  const int32_t nb = (int32_t)((contig_len + 1023) / 1024);
+  HIPCHK(c, c->rd_cnt.reserve(((size_t)nb + 1) * 4)); HIPCHK(c, c->rd_off.reserve(((size_t)nb + 2) * 4));
+  launch_k5_bounds(false, c->rd_ex.as<int32_t>(), contig_len, nb, c->rd_cnt.as<int32_t>(), nullptr, nullptr, nullptr, c->stream);
+  launch_scan_i32(c->scan_tmp, c->rd_cnt.as<int32_t>(), c->rd_off.as<int32_t>(), nb, c->rd_off.as<int32_t>() + nb, c->stream);
+  int32_t n_isl = 0;
+  HIPCHK(c, hipMemcpyAsync(&n_isl, c->rd_off.as<int32_t>() + nb, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  if (n_isl == 0) return LCR_OK;
+  HIPCHK(c, c->rd_s.reserve((size_t)n_isl * 4)); HIPCHK(c, c->rd_e.reserve((size_t)n_isl * 4)); HIPCHK(c, c->rd_max.reserve((size_t)n_isl * 4));
+  launch_k5_bounds(true, c->rd_ex.as<int32_t>(), contig_len, nb, nullptr, c->rd_off.as<int32_t>(), c->rd_s.as<int32_t>(), c->rd_e.as<int32_t>(), c->stream);
+  launch_k5_island_max(c->rd_ex.as<int32_t>(), c->rd_s.as<int32_t>(), c->rd_e.as<int32_t>(), n_isl, c->rd_max.as<uint32_t>(), c->stream);
+  std::vector<int32_t> hs(n_isl), he(n_isl);
+  std::vector<uint32_t> hm(n_isl);
+  HIPCHK(c, hipMemcpyAsync(hs.data(), c->rd_s.p, (size_t)n_isl * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(he.data(), c->rd_e.p, (size_t)n_isl * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(hm.data(), c->rd_max.p, (size_t)n_isl * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  // util.rs:287-330: cursors and max_coverage are reset only when a region is emitted, and a region is
+  // emitted only if region_end > region_start: a single-column island stays pending and becomes the
+  // start of the region that ends with the next island (the gap between them included).
+  uint32_t running = 0;
+  int64_t pend = -1;
+  for (int i = 0; i < n_isl; i++) {
+    running = std::max(running, hm[i]);
+    if (pend < 0) pend = hs[i];
+    if ((int64_t)he[i] > pend) {
+      c->rl_start0.push_back(pend); c->rl_len.push_back((int32_t)(he[i] - pend + 1)); c->rl_max.push_back(running);
+      pend = -1; running = 0;
+    }
+  }
+  out->n_regions = (int32_t)c->rl_start0.size();
+  out->start0 = c->rl_start0.data(); out->len = c->rl_len.data(); out->max_cov = c->rl_max.data();
   return LCR_OK;
 }
 

@@ -135,7 +135,7 @@ void launch_k1_zonefix(const BatchView& b, int D, int L, int64_t n_cols, uint32_
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, uint8_t* flags, int32_t* tile_count,
                       hipStream_t s);
-void launch_scan_i32(const int32_t* in, int32_t* out_excl, int32_t n, int32_t* total, hipStream_t s);
+void launch_scan_i32(DevBuf& tmp, const int32_t* in, int32_t* out_excl, int32_t n, int32_t* total, hipStream_t s);
 void launch_k2_compact(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                        int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const uint8_t* flags,
                        const int32_t* tile_off, Survivor* out, hipStream_t s);
@@ -152,7 +152,12 @@ void launch_k3_fill(const BatchView& b, const lcr_candidate* cand, const int32_t
                     hipStream_t s);
 void launch_k3_rows(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off, int32_t* region_rows,
                     hipStream_t s);
-void launch_scan_i32_to_i64(const int32_t* in, int64_t* out_excl, int32_t n, hipStream_t s);
+void launch_scan_i32_to_i64(DevBuf& tmp, const int32_t* in, int64_t* out_excl, int32_t n, hipStream_t s);
+
+void launch_k5_span_diff(const int32_t* ref_start, const int32_t* ref_end, int32_t n, int64_t contig_len, uint32_t* diff, hipStream_t s);
+void launch_k5_bounds(bool write, const int32_t* ex, int64_t contig_len, int32_t n_blocks, int32_t* blk_cnt, const int32_t* blk_off,
+                      int32_t* starts, int32_t* ends, hipStream_t s);
+void launch_k5_island_max(const int32_t* ex, const int32_t* starts, const int32_t* ends, int32_t n_islands, uint32_t* maxcov, hipStream_t s);
 
 // device helpers shared by kernels -------------------------------------------------------------
 #ifdef __HIPCC__

@@ -254,3 +254,36 @@ def cal_delta_eta_sigma_log(delta_i, eta_i, sigma, ps, probs):
 def cal_phase_score_log(delta_i, eta_i, sigma, ps, probs):
     l = lambda d: sum(math.log10(aki(s, d, eta_i, p, pr)) for s, p, pr in zip(sigma, ps, probs))
     return 1.0 - l(delta_i) / (l(1) + l(-1))
+
+
+def discover_regions(spans, ref_len):
+    """find_isolated_regions_with_depth (util.rs:236-332, truncation off), restated loop for loop:
+    spans = [(reference_start, reference_end)] of the filtered reads of one contig.
+    Returns [(start0, len, max_cov)] with start0 = Region.start - 1, len = Region.end - Region.start.
+
+    Quirk kept (util.rs:297-310): the cursors are reset only when a region is emitted, and a region is
+    emitted only if region_end > region_start, so a single-column island is not dropped: it stays
+    pending and becomes the start of a region that runs through the next island (gap included)."""
+    depth = [0] * ref_len
+    for s, e in spans:
+        for i in range(max(s, 0), min(e, ref_len)):
+            depth[i] += 1
+    out = []
+    region_start = region_end = -1
+    max_coverage = 0
+    for i in range(ref_len):
+        if depth[i] > max_coverage:
+            max_coverage = depth[i]
+        if depth[i] == 0:
+            if region_end > region_start:
+                out.append((region_start, region_end - region_start + 1, max_coverage))
+                region_start = region_end = -1
+                max_coverage = 0
+        else:
+            if region_start == -1:
+                region_start = region_end = i
+            else:
+                region_end = i
+    if region_end > region_start:
+        out.append((region_start, region_end - region_start + 1, max_coverage))
+    return out

@@ -263,3 +263,23 @@ def test_full_size_properties(engine_cls):
     c1 = E.candidates()[0].tobytes()
     E.load_batch(b).run_all()
     assert np.array_equal(E.columns(), pl) and E.candidates()[0].tobytes() == c1
+
+
+def test_region_discovery_gpu(engine_cls):
+    """lcr_discover_regions vs the loop-for-loop restatement of util.rs:236-332."""
+    import os
+    from longcallr_amd import bamio
+    from oracle import oracle_np
+    E = engine_cls(0, _abi.make_params())
+    spans = [(5, 6), (10, 20), (12, 18), (30, 31), (40, 41), (50, 60), (70, 71), (1023, 1025), (2047, 2049), (3000, 3001)]
+    assert E.discover_regions([s for s, _ in spans], [e for _, e in spans], 4096) == oracle_np.discover_regions(spans, 4096)
+    assert E.discover_regions([], [], 1000) == [] and E.discover_regions([0], [10], 10) == [(0, 10, 1)]
+    rng = np.random.default_rng(3)
+    st = np.sort(rng.integers(0, 200000, size=3000)); ln = rng.integers(1, 400, size=3000)
+    spans = list(zip(st.tolist(), (st + ln).tolist()))
+    assert E.discover_regions(st, st + ln, 200100) == oracle_np.discover_regions(spans, 200100)
+    # demo.bam (whole chr20 depth vector: 64 M positions)
+    refs, recs = bamio.read_bam(os.path.join(helpers.GOLDEN, "demo.bam"))
+    keep = [r for r in recs if bamio.passes_filter(r)]
+    rs = np.array([r["pos"] for r in keep]); re_ = rs + np.array([max(r["ref_len"], 1) for r in keep])
+    assert E.discover_regions(rs, re_, 64444167) == bamio.discover_regions(keep, keep[0]["ref_id"], 64444167) == [(16729960, 13256, 1649)]

@@ -91,3 +91,15 @@ def test_vcf_formatter_matches_oracle_text(orc):
     p = _abi.make_params("ont-drna")
     R = orc.Region(b, 0, p).run_all(orc.MODE_EXACT)
     assert vcf.format_records(R.cands(), "c", p.min_phase_score) == R.vcf_text("c")
+
+
+def test_region_discovery_quirks():
+    """util.rs:287-330 restated (oracle_np) vs the host version: single-column islands stay pending."""
+    from oracle import oracle_np
+    spans = [(5, 6), (10, 20), (12, 18), (30, 31), (40, 41), (50, 60), (70, 71)]
+    want = oracle_np.discover_regions(spans, 80)
+    # island [5,5] is pending -> region 5..19 (gap 6..9 included), max 2; [30,30] pending, [40,40] -> region 30..40;
+    # [50,59] alone; trailing single column [70,70] never emitted
+    assert want == [(5, 15, 2), (30, 11, 1), (50, 10, 1)]
+    recs = [dict(ref_id=0, pos=s, ref_len=e - s) for s, e in spans]
+    assert bamio.discover_regions(recs, 0, 80) == want
