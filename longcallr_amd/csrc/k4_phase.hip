@@ -581,17 +581,24 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   std::vector<lcr_candidate>& cand = *in.cand;
   haplotag.assign(nrow, 0); assignment.assign(nrow, 0); phase_set.assign(nrow, 0); objective.assign(ng, 0.0);
   // host copy of the fragment matrix (needed by the LD-block pass and the post-phase epilogue)
-  std::vector<int64_t> row_ptr(nrow + 1, 0);
-  std::vector<int32_t> col(std::max<int64_t>(nnz, 1));
-  std::vector<uint8_t> val(std::max<int64_t>(nnz, 1));
-  std::vector<uint32_t> links(std::max(nrow, 1));
-  PCHK(hipMemcpyAsync(row_ptr.data(), in.d_row_ptr, (size_t)(nrow + 1) * 8, hipMemcpyDeviceToHost, stream));
+  // (pinned staging buffers: the pageable path of hipMemcpyAsync costs an extra host copy)
+  PCHK(h_pin[0].reserve((size_t)(nrow + 1) * 8)); PCHK(h_pin[1].reserve(std::max<size_t>(nnz, 1) * 4));
+  PCHK(h_pin[2].reserve(std::max<size_t>(nnz, 1))); PCHK(h_pin[3].reserve(std::max<size_t>(nrow, 1) * 4));
+  int64_t* const row_ptr_p = h_pin[0].as<int64_t>();
+  int32_t* const col_p = h_pin[1].as<int32_t>();
+  uint8_t* const val_p = h_pin[2].as<uint8_t>();
+  uint32_t* const links_p = h_pin[3].as<uint32_t>();
+  PCHK(hipMemcpyAsync(row_ptr_p, in.d_row_ptr, (size_t)(nrow + 1) * 8, hipMemcpyDeviceToHost, stream));
   if (nnz) {
-    PCHK(hipMemcpyAsync(col.data(), in.d_col, (size_t)nnz * 4, hipMemcpyDeviceToHost, stream));
-    PCHK(hipMemcpyAsync(val.data(), in.d_val, (size_t)nnz, hipMemcpyDeviceToHost, stream));
+    PCHK(hipMemcpyAsync(col_p, in.d_col, (size_t)nnz * 4, hipMemcpyDeviceToHost, stream));
+    PCHK(hipMemcpyAsync(val_p, in.d_val, (size_t)nnz, hipMemcpyDeviceToHost, stream));
   }
-  if (nrow) PCHK(hipMemcpyAsync(links.data(), in.d_row_links, (size_t)nrow * 4, hipMemcpyDeviceToHost, stream));
+  if (nrow) PCHK(hipMemcpyAsync(links_p, in.d_row_links, (size_t)nrow * 4, hipMemcpyDeviceToHost, stream));
   PCHK(hipStreamSynchronize(stream));
+  struct Arr64 { int64_t* p; int64_t& operator[](size_t i) const { return p[i]; } int64_t* data() const { return p; } } row_ptr{row_ptr_p};
+  struct Arr32 { int32_t* p; int32_t& operator[](size_t i) const { return p[i]; } int32_t* data() const { return p; } } col{col_p};
+  struct Arr8 { uint8_t* p; uint8_t& operator[](size_t i) const { return p[i]; } uint8_t* data() const { return p; } } val{val_p};
+  struct ArrU { uint32_t* p; uint32_t& operator[](size_t i) const { return p[i]; } uint32_t* data() const { return p; } } links{links_p};
   lap("d2h fragment matrix");
 
   std::vector<RegionHost> R(ng);
@@ -854,9 +861,10 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     }
     lap("enum kernels");
     // ---- chain regions
-    std::vector<int8_t> st_host;
+    const size_t st_bytes = st_obj + rdev.size() * 8;
+    PCHK(h_pin[4].reserve(st_bytes + 16));
+    struct StHost { int8_t* p; size_t n; int8_t* data() const { return p; } size_t size() const { return n; } } st_host{h_pin[4].as<int8_t>(), st_bytes};
     auto pull_state = [&]() -> hipError_t {
-      st_host.resize(st_obj + rdev.size() * 8);
       hipError_t e = hipMemcpyAsync(st_host.data(), b_st.p, st_host.size(), hipMemcpyDeviceToHost, stream);
       if (e != hipSuccess) return e;
       return hipStreamSynchronize(stream);

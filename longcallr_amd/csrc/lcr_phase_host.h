@@ -74,7 +74,8 @@ struct PhaseHost {
   std::vector<uint32_t> phase_set;
   std::vector<double> objective;
   DevBuf d_state[13];
+  HostBuf h_pin[5];   // pinned staging: row_ptr, col, val, links, packed state
   HostPool* pool = nullptr;
   int run(const PhaseInputs& in, const lcr_params& p, hipStream_t s, std::string* err);
-  void release() { for (auto& b : d_state) b.release(); delete pool; pool = nullptr; }
+  void release() { for (auto& b : d_state) b.release(); for (auto& b : h_pin) b.release(); delete pool; pool = nullptr; }
 };
