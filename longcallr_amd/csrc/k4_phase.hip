@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <climits>
 #include <map>
 #include <set>
 #include <atomic>
@@ -50,7 +51,7 @@ __host__ __device__ inline double u01(uint64_t seed, uint64_t ctr) {
   uint64_t z = mix64(seed + (ctr + 1) * 0x9E3779B97F4A7C15ULL);
   return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
-inline uint64_t region_seed(uint64_t seed, int64_t start0) { return mix64(seed + 0xD1B54A32D192ED03ULL * (uint64_t)(start0 + 1)); }
+__host__ __device__ inline uint64_t region_seed(uint64_t seed, int64_t start0) { return mix64(seed + 0xD1B54A32D192ED03ULL * (uint64_t)(start0 + 1)); }
 
 struct RegionDev {
   int32_t R, S;          // phasing rows, candidates
@@ -72,6 +73,7 @@ struct PhaseDev {
   int8_t* st_sigma; int8_t* st_delta; int8_t* st_eta; long long* st_obj;  // per region best / result state
   int8_t* scratch; int32_t scratch_stride;                                // per block working state
   int32_t lds_state;                                                      // 1: working state lives in dynamic LDS
+  int32_t dbg;                                                            // LCR_K4_DBG: timing experiments only
   PhaseLutDev lut;
 };
 
@@ -176,35 +178,491 @@ __device__ __forceinline__ void load_w(const PhaseDev& P, long long* wl) {
 
 __device__ __forceinline__ int8_t init_genotype(int8_t vt) { return vt == 0 ? 1 : (vt == 1 ? 0 : -1); }  // phase.rs:682-691
 
-// enumeration restarts (phase.rs:1097-1122).  job -> (region slot, enumeration index e)
+// ---------------------------------------------------------------------------------------------
+// Enumeration restarts, register-resident form.  A region's phase matrix is a few KB (rows x <= 31
+// SNPs) while its 2^S restarts each sweep it ~7 times: one workgroup stages the matrix in LDS once,
+// every wave64 copies "its lane's share" of the entries into VGPRs, and then runs complete restarts
+// with the matrix in registers, delta / eta in wave-uniform bit masks and sigma as a bit vector in LDS.
+// Only wave-level synchronisation inside a restart.  Same decisions as cross_optimize() above.
+//   sigma step : lane <-> a run of whole rows in CSR order (~E/64 entries); two VGPRs per entry hold the
+//                23-bit + signed 24-bit limbs of w[q] with the metadata in the bits v_mad_i32_i24 ignores
+//   delta step : lane <-> a contiguous chunk of the CSC entries; per-SNP sums M[i] by LDS atomics
+//                (integer, order-free), then lane i takes SNP i's four-way decision
+//   objective  : sum over SNPs of the chosen branch's data term, which the last delta step already
+//                holds (sigma does not change after it) -- no extra pass over the matrix.
+// ---------------------------------------------------------------------------------------------
+struct EnumTile { int32_t slot; uint32_t e0, ne; };   // restarts e0 .. e0+ne-1 of one region
+constexpr int ENUM_WAVES = 4;
+constexpr uint32_t ENUM_TILE_JOBS = 32;
+constexpr uint32_t ENUM_LDS_BYTES = 48 * 1024;
+
+// LDS image: wl2[32] {lo23, hi24 (signed)} | csr[E] {lo | meta << 24, hi | row_in_lane << 24} | csc[E] | rp[R+1] u16 |
+//            first_row[65] u16 | per wave: sigma bits (u64 words, +1 pad) and M[32]
+//   csr meta : bits 0-4 SNP, 5 allele (1: p == +1), 6 last entry of its row, 7 valid
+//   csc      : bits 0-15 row, 16-20 SNP, 21 allele, 22-26 q, 31 valid
+struct EnumLayout { uint32_t csr, csc, rp, first_row, state, stride, total; };
+__host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E) {
+  EnumLayout L;
+  uint32_t o = 256;
+  L.csr = o; o += 8 * E;
+  L.csc = o; o += 4 * E;
+  L.rp = o; o += 2 * (R + 1);
+  L.first_row = o; o += 2 * 65;
+  o = (o + 15) & ~15u;
+  L.state = o;
+  L.stride = 8 * ((R + 63) / 64 + 1) + 8 * 32;
+  L.total = o + ENUM_WAVES * L.stride;
+  return L;
+}
+// lane l owns the rows whose first entry index lies in [l*c, (l+1)*c), c = ceil(E / 64)
+__host__ __device__ inline uint32_t enum_chunk(uint32_t E) { return E ? (E + 63) / 64 : 1; }
+
+#define LCR_DPP_LL(v, ctrl, rmask) \
+  (((long long)__builtin_amdgcn_update_dpp(0, (int)((v) >> 32), ctrl, rmask, 0xf, false) << 32) | \
+   (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xf, false))
+// wave64 sum of int64 through DPP row shifts / broadcasts; every lane gets the total
+__device__ __forceinline__ long long wave_sum_ll_dpp(long long v) {
+  v += LCR_DPP_LL(v, 0x111, 0xf);
+  v += LCR_DPP_LL(v, 0x112, 0xf);
+  v += LCR_DPP_LL(v, 0x114, 0xf);
+  v += LCR_DPP_LL(v, 0x118, 0xf);
+  v += LCR_DPP_LL(v, 0x142, 0xa);
+  v += LCR_DPP_LL(v, 0x143, 0xc);
+  const int lo = __builtin_amdgcn_readlane((int)v, 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+  return ((long long)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// tiles of restarts of regions whose per-lane share is <= CK entries (host decides); win_e != nullptr:
+// re-run restart win_e[slot] of each tile's region and store its state.
+template <int CK>
+__global__ void __launch_bounds__(64 * ENUM_WAVES)
+k4_enum_reg(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __restrict__ job_base,
+            long long* __restrict__ job_obj, const uint32_t* __restrict__ win_e) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const EnumTile t = tiles[blockIdx.x];
+  const RegionDev rd = P.reg[t.slot];
+  const int R = rd.R, S = rd.S;
+  const uint32_t E = (uint32_t)P.prow_ptr[rd.rp_off + R];
+  const EnumLayout L = enum_layout(R, E);
+  uint2* wl2 = (uint2*)lds;
+  uint2* csr = (uint2*)(lds + L.csr);
+  uint32_t* csc = (uint32_t*)(lds + L.csc);
+  uint16_t* rp = (uint16_t*)(lds + L.rp); uint16_t* first_row = (uint16_t*)(lds + L.first_row);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t c = enum_chunk(E);
+  // ---- stage the region (once per workgroup)
+  if (tid < 32) {
+    const long long w = tid < 31 ? P.lut.f1e[tid] - P.lut.fe[tid] : 0;
+    wl2[tid] = make_uint2((uint32_t)w & 0x7fffffu, (uint32_t)(w >> 23) & 0xffffffu);   // w = hi * 2^23 + lo, hi signed (w < 0 for q <= 3)
+  }
+  const int32_t* g_rp = P.prow_ptr + rd.rp_off;
+  for (int r = tid; r <= R; r += nt) rp[r] = (uint16_t)g_rp[r];
+  __shared__ int32_t cps[33];
+  if (tid <= S && tid < 33) cps[tid] = P.ccol_ptr[rd.cp_off + tid];
+  __syncthreads();
+  for (int l = tid; l <= 64; l += nt) {   // first row whose start offset is >= l * c
+    const uint32_t target = (uint32_t)l * c;
+    int lo = 0, hi = R;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (rp[mid] < target) lo = mid + 1; else hi = mid; }
+    first_row[l] = (uint16_t)lo;
+  }
+  for (int e = tid; e < (int)E; e += nt) {
+    const uint32_t cv = P.cval[rd.e_off + e];
+    int col = 0;
+    for (int i = 0; i < S; i++) col += (int)((uint32_t)e >= (uint32_t)cps[i + 1]);
+    csc[e] = (uint32_t)P.crow[rd.e_off + e] | ((uint32_t)col << 16) | ((cv & 32u) << 16) | ((cv & 31u) << 22) | 0x80000000u;
+  }
+  __syncthreads();
+  for (int r = tid; r < R; r += nt) {
+    const int e0 = rp[r], e1 = rp[r + 1];
+    if (e0 == e1) continue;
+    const uint32_t owner = (uint32_t)e0 / c;
+    const uint32_t roff = (uint32_t)r - first_row[owner];
+    for (int e = e0; e < e1; e++) {
+      const uint32_t v = P.pval[rd.e_off + e];
+      const uint32_t meta = (uint32_t)P.pcol[rd.e_off + e] | (v & 32u) | (e + 1 == e1 ? 64u : 0u) | 128u;
+      const uint2 w = wl2[v & 31u];
+      csr[e] = make_uint2(w.x | (meta << 24), w.y | (roff << 24));
+    }
+  }
+  __syncthreads();
+  // ---- per wave: my share of the matrix into registers
+  const int lane = tid & 63, wave = tid >> 6;
+  unsigned long long* sgb = (unsigned long long*)(lds + L.state + wave * L.stride);   // bit = 1: sigma == -1
+  unsigned long long* Macc = sgb + (R + 63) / 64 + 1;
+  const int r_a = first_row[lane];
+  uint32_t re0[CK], re1[CK], ce[CK];
+  {
+    const int s0 = rp[r_a], s1 = rp[first_row[lane + 1]];
+    const int c0 = min((int)E, lane * (int)c), c1 = min((int)E, (lane + 1) * (int)c);
+#pragma unroll
+    for (int x = 0; x < CK; x++) {
+      const uint2 v = s0 + x < s1 ? csr[s0 + x] : make_uint2(0, 0);
+      re0[x] = v.x; re1[x] = v.y;
+      ce[x] = c0 + x < c1 ? csc[c0 + x] : 0;
+    }
+  }
+  // wave-uniform trip counts of the two unrolled entry loops
+  int n_sig, n_del;
+  {
+    int n = rp[first_row[lane + 1]] - rp[r_a];
+    for (int d = 32; d >= 1; d >>= 1) n = max(n, __shfl_xor(n, d, 64));
+    n_sig = __builtin_amdgcn_readfirstlane(n);
+    n_del = (int)min(c, E);
+  }
+  const uint32_t smask = S >= 32 ? 0xffffffffu : ((1u << S) - 1u);
+  // lane i < S owns SNP i
+  long long cF = 0, cW = 0, cRef = 0, cVar = 0, het = 0;
+  bool live = false; int eta_init = 0;
+  if (lane < S) {
+    const long long* sc = P.snp_const + 4ll * (rd.snp_off + lane);
+    cF = sc[0]; cW = sc[1]; cRef = sc[2] + P.lut.f_homref; cVar = sc[3] + P.lut.f_homvar;
+    const int n = P.ccol_ptr[rd.cp_off + lane + 1] - P.ccol_ptr[rd.cp_off + lane];
+    het = P.lut.f_het0 - (long long)n * P.lut.f_log2;                     // phase.rs:136-144
+    live = P.snp_fp[rd.snp_off + lane] != 0 && n > 0;
+    eta_init = init_genotype(P.snp_vt[rd.snp_off + lane]);
+  }
+  const uint32_t e0_init = (uint32_t)__ballot(lane < S && eta_init == 0), ep_init = (uint32_t)__ballot(lane < S && eta_init == 1);
+  const int nk = (R + 63) / 64;
+  const int wsh = r_a & 63;
+  const uint32_t ne = (P.dbg & 1) ? 0u : (win_e ? 1u : t.ne);
+  for (uint32_t kk = wave; kk < ne; kk += ENUM_WAVES) {
+    const uint32_t e = win_e ? win_e[t.slot] : t.e0 + kk;
+    uint32_t dneg = e & smask;            // bit i: delta_i == -1 (doubling order of phase.rs:1099-1106)
+    uint32_t eta0 = e0_init, etap = ep_init;   // eta_i == 0 / eta_i == +1
+    // init_assignment (phase.rs:673-680): u01() < 0.5  <=>  top bit of the draw clear  -> sigma = -1
+    const uint64_t ctr0 = (uint64_t)S + (uint64_t)R + (uint64_t)e * (uint64_t)R;
+    for (int k = 0; k <= nk; k++) {
+      const int row = lane + 64 * k;
+      const bool neg = row < R && (mix64(rd.seed + (ctr0 + row + 1) * 0x9E3779B97F4A7C15ULL) >> 63) == 0;
+      const unsigned long long b = __ballot(neg);
+      if (lane == 0) sgb[k] = b;
+    }
+    if (lane < 32) Macc[lane] = 0;
+    wave_lds_sync();
+    bool hg_inc = true, h_inc = true;
+    int iters = 0;
+    long long obj_i = 0;
+    if (P.dbg & 4) hg_inc = h_inc = false;
+    while (hg_inc | h_inc) {
+      // ---- sigma step (phase.rs:824-862)
+      if (!(P.dbg & 32)) {
+        const unsigned long long w0 = sgb[r_a >> 6], w1 = sgb[(r_a >> 6) + 1];
+        const unsigned long long win = wsh ? (w0 >> wsh) | (w1 << (64 - wsh)) : w0;
+        int alo = 0, ahi = 0;
+        unsigned long long fm = 0;
+#pragma unroll
+        for (int x = 0; x < CK; x++) {
+          if (x >= n_sig) break;
+          // opaque to the optimiser: otherwise every field extraction below is hoisted out of the restart
+          // loop into its own VGPR (x CK entries) and the kernel drops to one wave per SIMD
+          asm volatile("" : "+v"(re0[x]), "+v"(re1[x]));
+          const uint32_t v0 = re0[x], v1 = re1[x];
+          const uint32_t m = v0 >> 24, i = m & 31u, roff = v1 >> 24;
+          const uint32_t sneg = (uint32_t)(win >> roff);
+          const uint32_t use = (m >> 7) & (eta0 >> i) & 1u;                 // het sites only
+          const uint32_t hit = ((m >> 5) ^ sneg ^ (dneg >> i)) & use;       // p == sigma * delta
+          const uint32_t mis = hit ^ use;
+          alo += __mul24((int)hit, (int)v0) - __mul24((int)mis, (int)v0);   // A - B of phase.rs:824-862
+          ahi += __mul24((int)hit, (int)v1) - __mul24((int)mis, (int)v1);
+          const bool end = (m >> 6) & 1u;
+          // sign of ahi * 2^23 + alo: fold alo's carry into ahi, the remainder is in [0, 2^23)
+          if (end && ahi + (alo >> 23) < 0) fm |= 1ull << roff;
+          alo = end ? 0 : alo; ahi = end ? 0 : ahi;
+        }
+        const bool any = __ballot(fm != 0) != 0;
+        if (fm) {
+          atomicXor(&sgb[r_a >> 6], fm << wsh);
+          if (wsh && (fm >> (64 - wsh))) atomicXor(&sgb[(r_a >> 6) + 1], fm >> (64 - wsh));
+        }
+        wave_lds_sync();
+        if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
+      }
+      // ---- delta / eta step (phase.rs:872-959): a lane's chunk is CSC-ordered (SNP index non-decreasing)
+      if (!(P.dbg & 16)) {
+        constexpr int HB = 8;   // look-ups of one batch in flight, then its run-length flush
+        int cur = -1; int alo = 0, ahi = 0;
+#pragma unroll
+        for (int h = 0; h < CK; h += HB) {
+          if (h >= n_del) break;
+          uint32_t sw[HB]; uint2 wq[HB];
+#pragma unroll
+          for (int x = 0; x < HB; x++) {
+            asm volatile("" : "+v"(ce[h + x]));
+            const uint32_t row = ce[h + x] & 0xffffu;
+            sw[x] = ((const uint32_t*)sgb)[row >> 5];
+            wq[x] = wl2[(ce[h + x] >> 22) & 31u];
+          }
+#pragma unroll
+          for (int x = 0; x < HB; x++) {
+            const uint32_t v = ce[h + x];
+            const int i = (v >> 16) & 31;
+            const uint32_t hit = ((v >> 21) ^ (sw[x] >> (v & 31u)) ^ (dneg >> i)) & (v >> 31);
+            if ((v >> 31) && i != cur) {
+              if (alo | ahi) atomicAdd(&Macc[cur], (unsigned long long)(((long long)ahi << 23) + alo));
+              cur = i; alo = 0; ahi = 0;
+            }
+            alo += __mul24((int)hit, (int)wq[x].x);
+            ahi += __mul24((int)hit, (int)wq[x].y);   // sign-extends the 24-bit hi limb
+          }
+        }
+        if (alo | ahi) atomicAdd(&Macc[cur], (unsigned long long)(((long long)ahi << 23) + alo));
+      }
+      wave_lds_sync();
+      bool changed = false;
+      int d_new = (dneg >> lane) & 1u, h_new = ((eta0 >> lane) & 1u) ? 0 : (((etap >> lane) & 1u) ? 1 : -1);
+      if (live) {
+        const long long M = (long long)Macc[lane];
+        Macc[lane] = 0;
+        const long long N0 = cF + M + het, N1 = cF + cW - M + het;
+        int ch = 0; long long nb = N0;                       // first maximum (phase.rs:908-921)
+        if (N1 > nb) { ch = 1; nb = N1; }
+        if (cRef > nb) { ch = 2; nb = cRef; }
+        if (cVar > nb) { ch = 3; nb = cVar; }
+        const long long ncur = h_new == 0 ? N0 : (h_new == 1 ? cRef : cVar);
+        changed = nb > ncur;
+        if (ch == 1) d_new ^= 1;
+        h_new = ch <= 1 ? 0 : (ch == 2 ? 1 : -1);
+        obj_i = ch <= 1 ? nb - het : (ch == 2 ? cRef - P.lut.f_homref : cVar - P.lut.f_homvar);
+      }
+      dneg = (uint32_t)__ballot(lane < S && d_new);
+      eta0 = (uint32_t)__ballot(lane < S && h_new == 0);
+      etap = (uint32_t)__ballot(lane < S && h_new == 1);
+      const bool any2 = __ballot(changed) != 0;
+      wave_lds_sync();
+      if (!any2) hg_inc = false; else { hg_inc = true; h_inc = true; }
+      if (++iters > 20) break;  // phase.rs:967-972
+      if (P.dbg & 2) break;
+    }
+    // objective (phase.rs:257-276) = sum over phase entries of fe + hit * w = sum_i (F_i + hits_i) over live SNPs
+    const long long total = wave_sum_ll_dpp(obj_i);
+    if (win_e) {
+      if (lane < S) {
+        P.st_delta[rd.snp_off + lane] = (int8_t)(((dneg >> lane) & 1u) ? -1 : 1);
+        P.st_eta[rd.snp_off + lane] = (int8_t)(((eta0 >> lane) & 1u) ? 0 : (((etap >> lane) & 1u) ? 1 : -1));
+      }
+      for (int k = 0; k < nk; k++) {
+        const int row = lane + 64 * k;
+        if (row < R) P.st_sigma[rd.sig_off + row] = (int8_t)(((sgb[k] >> lane) & 1ull) ? -1 : 1);
+      }
+      if (lane == 0) P.st_obj[t.slot] = total;
+    } else if (lane == 0) job_obj[job_base[t.slot] + e] = total;
+    wave_lds_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k4_stage: phase matrices on the device, one workgroup per region, straight from K3's fragment CSR.
+// For every region: the rows with >= min_linkers linked SNPs (fragment.rs:253-255) restricted to the
+// phase sites (for_phasing candidates, fragment.rs:144-146) as CSR + CSC mirror, the per-SNP constants
+// of cross_optimize and the region descriptor.  Slices sit at offsets derived from K3's own offsets
+// (rows: r0 + g, SNPs: c0 + g, entries: row_ptr[r0]) so no cross-region scan is needed.  The CSC fill
+// order inside a column is whatever the atomics give: every consumer only sums over a column.
+// ---------------------------------------------------------------------------------------------
+struct StageIn {
+  const int64_t* row_ptr; const int32_t* col; const uint8_t* val; const uint32_t* links;
+  const lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off; const int64_t* start0;
+  uint32_t min_linkers, max_enum_snps; uint64_t seed;
+};
+struct StageStat { int32_t R, E, max_n, max_rows; };   // max_*: per-lane share of k4_enum_reg's row partition
+struct StageOut {
+  RegionDev* reg; StageStat* stat;
+  int32_t* prow_ptr; int32_t* pcol; uint8_t* pval; int32_t* ccol_ptr; int32_t* crow; uint8_t* cval;
+  uint8_t* snp_fp; int8_t* snp_vt; uint8_t* snp_cons; long long* snp_const; int32_t* cursor;
+};
+
+// exclusive scan of two ints over a 256-thread workgroup; returns the totals through ta / tb
+__device__ __forceinline__ void block_scan2(int a, int b, int& ea, int& eb, int& ta, int& tb, int (*sm)[8]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int ia = a, ib = b;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int ua = __shfl_up(ia, d, 64), ub = __shfl_up(ib, d, 64);
+    if (lane >= d) { ia += ua; ib += ub; }
+  }
+  __syncthreads();
+  if (lane == 63) { sm[0][wave] = ia; sm[1][wave] = ib; }
+  __syncthreads();
+  int oa = 0, ob = 0; ta = 0; tb = 0;
+  for (int w = 0; w < 4; w++) { if (w < wave) { oa += sm[0][w]; ob += sm[1][w]; } ta += sm[0][w]; tb += sm[1][w]; }
+  ea = oa + ia - a; eb = ob + ib - b;
+}
+
+__global__ void __launch_bounds__(LCR_BLOCK) k4_stage(StageIn in, StageOut out, PhaseLutDev lut) {
+  static_assert(LCR_BLOCK == 256, "k4_stage assumes 4 waves");
+  __shared__ int sm[2][8];
+  __shared__ int s_max[2];
+  __shared__ long long s_ft[4];
+  __shared__ long long s_fe[32], s_f1e[32];
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = in.row_region_off[g], nrow = in.row_region_off[g + 1] - r0;
+  const int c0 = in.cand_off[g], S = in.cand_off[g + 1] - c0;
+  const int64_t e_base = in.row_ptr[r0];
+  RegionDev rd{};
+  rd.S = S; rd.rp_off = r0 + g; rd.cp_off = c0 + g; rd.e_off = e_base; rd.sig_off = r0; rd.snp_off = c0;
+  rd.seed = region_seed(in.seed, in.start0[g]);
+  if (S == 0) {
+    if (tid == 0) { out.reg[g] = rd; out.stat[g] = StageStat{0, 0, 0, 0}; out.prow_ptr[rd.rp_off] = 0; out.ccol_ptr[rd.cp_off] = 0; }
+    return;
+  }
+  if (tid < 32) { s_fe[tid] = tid < 31 ? lut.fe[tid] : 0; s_f1e[tid] = tid < 31 ? lut.f1e[tid] : 0; }
+  if (tid < 2) s_max[tid] = 0;
+  for (int i = tid; i < S; i += LCR_BLOCK) {
+    const lcr_candidate& c = in.cand[c0 + i];
+    out.snp_fp[c0 + i] = (c.flags & LCR_F_FOR_PHASING) ? 1 : 0;
+    out.snp_vt[c0 + i] = (int8_t)c.variant_type;
+    out.snp_cons[c0 + i] = 0;
+    out.cursor[c0 + i] = 0;
+  }
+  __syncthreads();
+  int32_t* prp = out.prow_ptr + rd.rp_off;
+  int32_t* pcp = out.ccol_ptr + rd.cp_off;
+  // ---- pass 1: phasing rows and their phase-site entries (CSR), column counts
+  int R = 0, E = 0;
+  for (int base = 0; base < nrow; base += LCR_BLOCK) {
+    const int r = base + tid;
+    int isp = 0, cnt = 0;
+    int64_t eb = 0, ee = 0;
+    if (r < nrow) {
+      isp = in.links[r0 + r] >= in.min_linkers ? 1 : 0;
+      if (isp) {
+        eb = in.row_ptr[r0 + r]; ee = in.row_ptr[r0 + r + 1];
+        for (int64_t e = eb; e < ee; e++) cnt += out.snp_fp[in.col[e]];
+      }
+    }
+    int k, eo, tk, te;
+    block_scan2(isp, cnt, k, eo, tk, te, sm);
+    if (isp) {
+      k += R; eo += E;
+      prp[k] = eo;
+      for (int64_t e = eb; e < ee; e++) {
+        const int ci = in.col[e];
+        if (!out.snp_fp[ci]) continue;
+        out.pcol[e_base + eo] = ci - c0; out.pval[e_base + eo] = in.val[e] & 63;
+        atomicAdd(&out.cursor[ci], 1);
+        eo++;
+      }
+    }
+    R += tk; E += te;
+  }
+  if (tid == 0) prp[R] = E;
+  __syncthreads();
+  // ---- column offsets
+  {
+    int carry = 0;
+    for (int base = 0; base < S; base += LCR_BLOCK) {
+      const int i = base + tid;
+      const int v = i < S ? out.cursor[c0 + i] : 0;
+      int ex, dummy, tot, tdummy;
+      block_scan2(v, 0, ex, dummy, tot, tdummy, sm);
+      if (i < S) { pcp[i] = carry + ex; out.cursor[c0 + i] = carry + ex; }
+      carry += tot;
+    }
+    if (tid == 0) pcp[S] = carry;
+  }
+  __syncthreads();
+  // ---- pass 2: CSC mirror (phasing-row index, value)
+  {
+    int Rk = 0;
+    for (int base = 0; base < nrow; base += LCR_BLOCK) {
+      const int r = base + tid;
+      const int isp = (r < nrow && in.links[r0 + r] >= in.min_linkers) ? 1 : 0;
+      int k, dummy, tk, tdummy;
+      block_scan2(isp, 0, k, dummy, tk, tdummy, sm);
+      if (isp) {
+        k += Rk;
+        for (int64_t e = in.row_ptr[r0 + r]; e < in.row_ptr[r0 + r + 1]; e++) {
+          const int ci = in.col[e];
+          if (!out.snp_fp[ci]) continue;
+          const int pos = atomicAdd(&out.cursor[ci], 1);
+          out.crow[e_base + pos] = k; out.cval[e_base + pos] = in.val[e] & 63;
+        }
+      }
+      Rk += tk;
+    }
+  }
+  __syncthreads();
+  // ---- per-SNP constants: F = sum fe, W = sum w, Cref = sum (p==+1 ? f1e : fe), Cvar = sum (p==-1 ? f1e : fe)
+  long long ft = 0;
+  for (int i = wave; i < S; i += LCR_BLOCK / 64) {
+    long long F = 0, W = 0, Cr = 0, Cv = 0;
+    for (int e = pcp[i] + lane; e < pcp[i + 1]; e += 64) {
+      const uint8_t v = out.cval[e_base + e];
+      const long long fe = s_fe[v & 31], f1 = s_f1e[v & 31];
+      F += fe; W += f1 - fe;
+      Cr += (v & 32) ? f1 : fe; Cv += (v & 32) ? fe : f1;
+    }
+    F = wave_sum_ll_dpp(F); W = wave_sum_ll_dpp(W); Cr = wave_sum_ll_dpp(Cr); Cv = wave_sum_ll_dpp(Cv);
+    if (lane == 0) { long long* sc = out.snp_const + 4ll * (c0 + i); sc[0] = F; sc[1] = W; sc[2] = Cr; sc[3] = Cv; }
+    ft += F;
+  }
+  if (lane == 0) s_ft[wave] = ft;
+  // ---- per-lane share of k4_enum_reg's row partition (enumeration regions only)
+  if (S <= (int)in.max_enum_snps && tid < 64) {
+    const uint32_t c = enum_chunk((uint32_t)E);
+    auto lower = [&](uint32_t target) { int lo = 0, hi = R; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)prp[mid] < target) lo = mid + 1; else hi = mid; } return lo; };
+    const int f0 = lower((uint32_t)tid * c), f1 = lower((uint32_t)(tid + 1) * c);
+    atomicMax(&s_max[0], prp[f1] - prp[f0]);
+    atomicMax(&s_max[1], f1 - f0);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    rd.R = R; rd.f_total = s_ft[0] + s_ft[1] + s_ft[2] + s_ft[3];
+    out.reg[g] = rd;
+    out.stat[g] = StageStat{R, E, max(s_max[0], (int)enum_chunk((uint32_t)E)), s_max[1]};
+  }
+}
+
+// the same tiles for regions whose matrix does not fit the LDS budget: one restart at a time per workgroup
 __global__ void __launch_bounds__(LCR_BLOCK)
-k4_enum(PhaseDev P, const int32_t* __restrict__ job_slot, const uint32_t* __restrict__ job_e, int32_t n_jobs,
-        long long* __restrict__ job_obj, int materialize) {
+k4_enum_big(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __restrict__ job_base,
+            long long* __restrict__ job_obj, const uint32_t* __restrict__ win_e) {
   __shared__ long long red[LCR_BLOCK / 64];
   __shared__ long long wl[32];
+  const EnumTile t = tiles[blockIdx.x];
+  const RegionDev rd = P.reg[t.slot];
   load_w(P, wl);
-  extern __shared__ __attribute__((aligned(16))) int8_t dyn_state[];  // working sigma|delta|eta when it fits in LDS
-  int8_t* base = P.lds_state ? dyn_state : P.scratch + (size_t)blockIdx.x * P.scratch_stride;
-  for (int job = blockIdx.x; job < n_jobs; job += gridDim.x) {
-    const RegionDev rd = P.reg[job_slot[job]];
-    const uint32_t e = job_e[job];
-    int8_t* sg = base; int8_t* dl = base + rd.R; int8_t* et = dl + rd.S;
-    const int8_t* vt = P.snp_vt + rd.snp_off;
-    // hap[e][i] = -1 iff bit i of e (the doubling order of phase.rs:1099-1106)
+  int8_t* base = P.scratch + (size_t)blockIdx.x * P.scratch_stride;
+  int8_t* sg = base; int8_t* dl = base + rd.R; int8_t* et = dl + rd.S;
+  const int8_t* vt = P.snp_vt + rd.snp_off;
+  const uint32_t ne = win_e ? 1u : t.ne;
+  for (uint32_t k = 0; k < ne; k++) {
+    const uint32_t e = win_e ? win_e[t.slot] : t.e0 + k;
     for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { dl[i] = ((e >> i) & 1u) ? -1 : 1; et[i] = init_genotype(vt[i]); }
-    // init_assignment (phase.rs:673-680): draws continue after thread.rs:162-163's S + F draws
     const uint64_t ctr0 = (uint64_t)rd.S + (uint64_t)rd.R + (uint64_t)e * (uint64_t)rd.R;
     for (int row = threadIdx.x; row < rd.R; row += blockDim.x) sg[row] = u01(rd.seed, ctr0 + row) < 0.5 ? -1 : 1;
     __syncthreads();
     const long long obj = cross_optimize(P, rd, sg, dl, et, false, true, red, wl);
-    if (threadIdx.x == 0) job_obj[job] = obj;
-    if (materialize) {
+    if (win_e) {
       for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { P.st_delta[rd.snp_off + i] = dl[i]; P.st_eta[rd.snp_off + i] = et[i]; }
       for (int row = threadIdx.x; row < rd.R; row += blockDim.x) P.st_sigma[rd.sig_off + row] = sg[row];
-      if (threadIdx.x == 0) P.st_obj[job_slot[job]] = obj;
-    }
+      if (threadIdx.x == 0) P.st_obj[t.slot] = obj;
+    } else if (threadIdx.x == 0) job_obj[job_base[t.slot] + e] = obj;
     __syncthreads();
   }
+}
+
+// winner of each enumeration region: first maximum over e (`prob > largest_prob`, phase.rs:1113-1119)
+__global__ void __launch_bounds__(64) k4_enum_pick(const int32_t* __restrict__ slots, int32_t n, const RegionDev* __restrict__ reg,
+                                                    const int64_t* __restrict__ job_base, const long long* __restrict__ job_obj,
+                                                    uint32_t* __restrict__ win_e) {
+  const int k = blockIdx.x;
+  if (k >= n) return;
+  const int slot = slots[k];
+  const uint32_t nj = 1u << reg[slot].S;
+  const long long* o = job_obj + job_base[slot];
+  long long best = LLONG_MIN; uint32_t be = 0xffffffffu;
+  for (uint32_t e = threadIdx.x; e < nj; e += 64) { const long long v = o[e]; if (v > best) { best = v; be = e; } }
+  for (int d = 32; d >= 1; d >>= 1) {
+    const long long ob = __shfl_xor(best, d, 64); const uint32_t oe = __shfl_xor(be, d, 64);
+    if (ob > best || (ob == best && oe < be)) { best = ob; be = oe; }
+  }
+  if (threadIdx.x == 0) win_e[slot] = be;
 }
 
 // chain, part A (phase.rs:1124-1132): delta from init_haplotypes_LD2 (host), random sigma, keep_conserved
@@ -573,46 +1031,181 @@ struct RegionHost {
 
 int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t stream, std::string* err) {
 #define PCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e_); return LCR_E_DEVICE; } } while (0)
+  // Two queues: `stream` stages the phase matrices on the device and runs the enumeration regions;
+  // `side` brings the fragment matrix to the host (LD blocks, block-flip pass and the post-phase
+  // epilogue need it) and runs the few chain regions.  Host work overlaps the enumeration kernels.
   const int ng = in.n_regions, nrow = in.n_rows;
   const int64_t nnz = in.nnz;
+  const int ncand = in.cand_region_off[ng];
   const bool prof = getenv("LCR_PHASE_PROF") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) { if (!prof) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[phase] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
   std::vector<lcr_candidate>& cand = *in.cand;
   haplotag.assign(nrow, 0); assignment.assign(nrow, 0); phase_set.assign(nrow, 0); objective.assign(ng, 0.0);
-  // host copy of the fragment matrix (needed by the LD-block pass and the post-phase epilogue)
-  // (pinned staging buffers: the pageable path of hipMemcpyAsync costs an extra host copy)
-  PCHK(h_pin[0].reserve((size_t)(nrow + 1) * 8)); PCHK(h_pin[1].reserve(std::max<size_t>(nnz, 1) * 4));
-  PCHK(h_pin[2].reserve(std::max<size_t>(nnz, 1))); PCHK(h_pin[3].reserve(std::max<size_t>(nrow, 1) * 4));
+  if (!side) {
+    PCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    PCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+    PCHK(hipEventCreateWithFlags(&ev_csr, hipEventDisableTiming));
+  }
+  const HostLut& L = hlut();
+
+  // ---- device buffers
+  DevBuf &b_reg = d_state[0], &b_prp = d_state[1], &b_pc = d_state[2], &b_pv = d_state[3], &b_cp = d_state[4],
+         &b_cr = d_state[5], &b_cv = d_state[6], &b_snp = d_state[7], &b_st = d_state[8], &b_scr = d_state[9],
+         &b_job = d_state[10], &b_obj = d_state[11], &b_sc = d_state[12], &b_stat = d_state[13], &b_cur = d_state[14],
+         &b_stc = d_state[15], &b_slots = d_state[16];
+  const size_t nnz1 = (size_t)std::max<int64_t>(nnz, 1), nc1 = (size_t)std::max(ncand, 1), nr1 = (size_t)std::max(nrow, 1);
+  PCHK(b_reg.reserve((size_t)std::max(ng, 1) * sizeof(RegionDev)));
+  PCHK(b_stat.reserve((size_t)std::max(ng, 1) * sizeof(StageStat)));
+  PCHK(b_prp.reserve((nr1 + ng + 1) * 4)); PCHK(b_pc.reserve(nnz1 * 4)); PCHK(b_pv.reserve(nnz1));
+  PCHK(b_cp.reserve((nc1 + ng + 1) * 4)); PCHK(b_cr.reserve(nnz1 * 4)); PCHK(b_cv.reserve(nnz1));
+  PCHK(b_snp.reserve(nc1 * 3 + 16)); PCHK(b_sc.reserve(nc1 * 4 * sizeof(long long))); PCHK(b_cur.reserve(nc1 * 4));
+  // state: sigma[n_rows] | delta[n_cand] | eta[n_cand] | obj[n_regions] (8-byte aligned); one copy per queue
+  const size_t st_sig = 0, st_del = (nr1 + 15) & ~(size_t)15, st_eta = st_del + ((nc1 + 15) & ~(size_t)15);
+  const size_t st_obj = st_eta + ((nc1 + 15) & ~(size_t)15);
+  const size_t st_bytes = st_obj + (size_t)std::max(ng, 1) * 8;
+  PCHK(b_st.reserve(st_bytes + 16)); PCHK(b_stc.reserve(st_bytes + 16));
+  PCHK(h_pin[0].reserve((nr1 + 1) * 8)); PCHK(h_pin[1].reserve(nnz1 * 4));
+  PCHK(h_pin[2].reserve(nnz1)); PCHK(h_pin[3].reserve(nr1 * 4));
+  PCHK(h_pin[4].reserve(st_bytes + 16)); PCHK(h_pin[5].reserve((size_t)std::max(ng, 1) * sizeof(StageStat)));
+  PCHK(h_pin[6].reserve(st_bytes + 16));
+
+  PhaseDev P{};
+  P.reg = b_reg.as<RegionDev>();
+  P.prow_ptr = b_prp.as<int32_t>(); P.pcol = b_pc.as<int32_t>(); P.pval = b_pv.as<uint8_t>();
+  P.ccol_ptr = b_cp.as<int32_t>(); P.crow = b_cr.as<int32_t>(); P.cval = b_cv.as<uint8_t>();
+  P.snp_const = b_sc.as<long long>();
+  P.snp_fp = b_snp.as<uint8_t>(); P.snp_vt = b_snp.as<int8_t>() + nc1; P.snp_cons = b_snp.as<uint8_t>() + 2 * nc1;
+  P.st_sigma = b_st.as<int8_t>() + st_sig; P.st_delta = b_st.as<int8_t>() + st_del; P.st_eta = b_st.as<int8_t>() + st_eta;
+  P.st_obj = (long long*)(b_st.as<int8_t>() + st_obj);
+  P.lut = L.dev;
+  if (const char* e = getenv("LCR_K4_DBG")) P.dbg = atoi(e);
+
+  // ---- queue `side`: fragment matrix to the host (pinned)
   int64_t* const row_ptr_p = h_pin[0].as<int64_t>();
   int32_t* const col_p = h_pin[1].as<int32_t>();
   uint8_t* const val_p = h_pin[2].as<uint8_t>();
   uint32_t* const links_p = h_pin[3].as<uint32_t>();
-  PCHK(hipMemcpyAsync(row_ptr_p, in.d_row_ptr, (size_t)(nrow + 1) * 8, hipMemcpyDeviceToHost, stream));
+  PCHK(hipEventRecord(ev_in, stream));
+  PCHK(hipStreamWaitEvent(side, ev_in, 0));
+  PCHK(hipMemcpyAsync(row_ptr_p, in.d_row_ptr, (size_t)(nrow + 1) * 8, hipMemcpyDeviceToHost, side));
   if (nnz) {
-    PCHK(hipMemcpyAsync(col_p, in.d_col, (size_t)nnz * 4, hipMemcpyDeviceToHost, stream));
-    PCHK(hipMemcpyAsync(val_p, in.d_val, (size_t)nnz, hipMemcpyDeviceToHost, stream));
+    PCHK(hipMemcpyAsync(col_p, in.d_col, (size_t)nnz * 4, hipMemcpyDeviceToHost, side));
+    PCHK(hipMemcpyAsync(val_p, in.d_val, (size_t)nnz, hipMemcpyDeviceToHost, side));
   }
-  if (nrow) PCHK(hipMemcpyAsync(links_p, in.d_row_links, (size_t)nrow * 4, hipMemcpyDeviceToHost, stream));
-  PCHK(hipStreamSynchronize(stream));
+  if (nrow) PCHK(hipMemcpyAsync(links_p, in.d_row_links, (size_t)nrow * 4, hipMemcpyDeviceToHost, side));
+  PCHK(hipEventRecord(ev_csr, side));
+
+  // ---- queue `stream`: stage the phase matrices, fetch the per-region sizes
+  StageStat* const stat = h_pin[5].as<StageStat>();
+  if (ng) {
+    StageIn si{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, in.d_cand, in.d_cand_off, in.d_row_region_off, in.d_start0,
+               prm.min_linkers, prm.max_enum_snps, prm.seed};
+    StageOut so{b_reg.as<RegionDev>(), b_stat.as<StageStat>(), b_prp.as<int32_t>(), b_pc.as<int32_t>(), b_pv.as<uint8_t>(),
+                b_cp.as<int32_t>(), b_cr.as<int32_t>(), b_cv.as<uint8_t>(), b_snp.as<uint8_t>(), b_snp.as<int8_t>() + nc1,
+                b_snp.as<uint8_t>() + 2 * nc1, b_sc.as<long long>(), b_cur.as<int32_t>()};
+    hipLaunchKernelGGL(k4_stage, dim3(ng), dim3(LCR_BLOCK), 0, stream, si, so, L.dev);
+    PCHK(hipGetLastError());
+    PCHK(hipMemcpyAsync(stat, b_stat.p, (size_t)ng * sizeof(StageStat), hipMemcpyDeviceToHost, stream));
+    PCHK(hipMemsetAsync(b_st.p, 0, st_bytes, stream));
+    PCHK(hipStreamSynchronize(stream));
+  }
+  lap("stage + sizes");
+
+  // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
+  std::vector<int32_t> enum_slots, chain_slots;
+  int32_t max_state = 0;
+  for (int g = 0; g < ng; g++) {
+    const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
+    if (S == 0) continue;
+    if ((uint32_t)S <= prm.max_enum_snps) enum_slots.push_back(g); else chain_slots.push_back(g);
+    max_state = std::max(max_state, stat[g].R + 2 * S);
+  }
+  const int32_t stride = (max_state + 63) & ~63;
+  P.scratch_stride = stride;
+  const size_t dyn_bytes = stride <= 48 * 1024 ? (size_t)stride : 0;  // chain working state in LDS when it fits
+  P.lds_state = dyn_bytes ? 1 : 0;
+  std::vector<uint8_t> packed;   // pageable upload source; must outlive the copy (synchronised below)
+  size_t n_big_blocks = 0;
+  if (!enum_slots.empty()) {
+    const bool force_big = getenv("LCR_ENUM_FORCE_BIG") != nullptr;  // test hook: exercise the fallback kernel
+    // class 0..2: register-resident kernel with <= 8 / 16 / 32 entries per lane; class 3: global-memory kernel
+    constexpr int NCLS = 4;
+    std::vector<EnumTile> tiles[NCLS], wtiles[NCLS];
+    std::vector<int64_t> job_base(ng, 0);
+    int64_t nj = 0;
+    uint32_t lds_need[NCLS] = {0, 0, 0, 0};
+    for (int g : enum_slots) {
+      const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
+      const StageStat& st = stat[g];
+      const EnumLayout EL = enum_layout(st.R, st.E);
+      int cls = 3;
+      if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_BYTES && st.max_rows <= 64)
+        cls = st.max_n <= 8 ? 0 : (st.max_n <= 16 ? 1 : (st.max_n <= 32 ? 2 : 3));
+      if (cls < 3) lds_need[cls] = std::max(lds_need[cls], EL.total);
+      job_base[g] = nj;
+      const uint32_t n = 1u << S;
+      const uint32_t per = cls == 3 ? 1u : ENUM_TILE_JOBS;
+      for (uint32_t e0 = 0; e0 < n; e0 += per) tiles[cls].push_back({g, e0, std::min(per, n - e0)});
+      wtiles[cls].push_back({g, 0, 1});
+      nj += n;
+    }
+    // one upload: tiles | winner tiles | job_base | slots ; then job objectives and winners
+    size_t n_t[NCLS], n_w[NCLS], n_tiles = 0;
+    for (int k = 0; k < NCLS; k++) { n_t[k] = tiles[k].size(); n_w[k] = wtiles[k].size(); n_tiles += n_t[k] + n_w[k]; }
+    const size_t ns = enum_slots.size();
+    const size_t off_jb_al = (n_tiles * sizeof(EnumTile) + 7) & ~(size_t)7;  // sizeof(EnumTile) == 12
+    packed.resize(off_jb_al + (size_t)ng * 8 + ns * 4);
+    size_t t_off[NCLS], w_off[NCLS], cursor = 0;
+    EnumTile* pt = (EnumTile*)packed.data();
+    for (int k = 0; k < NCLS; k++) { t_off[k] = cursor; memcpy(pt + cursor, tiles[k].data(), n_t[k] * sizeof(EnumTile)); cursor += n_t[k]; }
+    for (int k = 0; k < NCLS; k++) { w_off[k] = cursor; memcpy(pt + cursor, wtiles[k].data(), n_w[k] * sizeof(EnumTile)); cursor += n_w[k]; }
+    memcpy(packed.data() + off_jb_al, job_base.data(), (size_t)ng * 8);
+    memcpy(packed.data() + off_jb_al + (size_t)ng * 8, enum_slots.data(), ns * 4);
+    PCHK(b_job.reserve(packed.size() + 64));
+    PCHK(b_obj.reserve((size_t)nj * 8 + (size_t)ng * 4 + 64));
+    PCHK(hipMemcpyAsync(b_job.p, packed.data(), packed.size(), hipMemcpyHostToDevice, stream));
+    const EnumTile* d_t = b_job.as<EnumTile>();
+    const int64_t* d_jb = (const int64_t*)(b_job.as<uint8_t>() + off_jb_al);
+    const int32_t* d_sl = (const int32_t*)(b_job.as<uint8_t>() + off_jb_al + (size_t)ng * 8);
+    long long* d_obj = b_obj.as<long long>();
+    uint32_t* d_win = (uint32_t*)(d_obj + nj);
+    n_big_blocks = std::max(n_t[3], n_w[3]);
+    PCHK(b_scr.reserve((size_t)stride * (n_big_blocks + chain_slots.size()) + 64));   // chain regions use the tail
+    P.scratch = b_scr.as<int8_t>();
+    auto launch = [&](const size_t* cnt, const size_t* off, const uint32_t* win) {
+      const dim3 blk(64 * ENUM_WAVES);
+      if (cnt[0]) hipLaunchKernelGGL(k4_enum_reg<8>, dim3((unsigned)cnt[0]), blk, lds_need[0], stream, P, d_t + off[0], d_jb, d_obj, win);
+      if (cnt[1]) hipLaunchKernelGGL(k4_enum_reg<16>, dim3((unsigned)cnt[1]), blk, lds_need[1], stream, P, d_t + off[1], d_jb, d_obj, win);
+      if (cnt[2]) hipLaunchKernelGGL(k4_enum_reg<32>, dim3((unsigned)cnt[2]), blk, lds_need[2], stream, P, d_t + off[2], d_jb, d_obj, win);
+      if (cnt[3]) hipLaunchKernelGGL(k4_enum_big, dim3((unsigned)cnt[3]), dim3(LCR_BLOCK), 0, stream, P, d_t + off[3], d_jb, d_obj, win);
+    };
+    launch(n_t, t_off, nullptr);
+    hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)ns), dim3(64), 0, stream, d_sl, (int32_t)ns, P.reg, d_jb, d_obj, d_win);
+    launch(n_w, w_off, d_win);
+    PCHK(hipGetLastError());
+  }
+  int8_t* const st1 = h_pin[4].as<int8_t>();   // enumeration results
+  int8_t* const st2 = h_pin[6].as<int8_t>();   // chain results
+  if (ng) PCHK(hipMemcpyAsync(st1, b_st.p, st_bytes, hipMemcpyDeviceToHost, stream));
+  lap("enum launch");
+
+  // ---- host views of the regions (epilogue structures; LD blocks of the chain regions)
+  PCHK(hipEventSynchronize(ev_csr));
+  lap("wait fragment matrix");
   struct Arr64 { int64_t* p; int64_t& operator[](size_t i) const { return p[i]; } int64_t* data() const { return p; } } row_ptr{row_ptr_p};
   struct Arr32 { int32_t* p; int32_t& operator[](size_t i) const { return p[i]; } int32_t* data() const { return p; } } col{col_p};
   struct Arr8 { uint8_t* p; uint8_t& operator[](size_t i) const { return p[i]; } uint8_t* data() const { return p; } } val{val_p};
   struct ArrU { uint32_t* p; uint32_t& operator[](size_t i) const { return p[i]; } uint32_t* data() const { return p; } } links{links_p};
-  lap("d2h fragment matrix");
-
   std::vector<RegionHost> R(ng);
   std::vector<std::vector<std::vector<int>>> ld_blocks(ng);
-  struct RegionBuild {  // per-region pieces, built in parallel, concatenated below
-    std::vector<int32_t> prow_ptr, pcol, ccol_ptr, crow;
-    std::vector<uint8_t> pval, cval, fp, cons;
-    std::vector<int8_t> vt, delta0;
-    std::vector<long long> snp_const;  // 4 per SNP: F, W, Cref, Cvar
-    long long f_total = 0;
+  struct RegionBuild {  // chain regions only: host copy of the phase matrix rows for the block-flip objective
+    std::vector<int32_t> prow_ptr, pcol;
+    std::vector<uint8_t> pval;
   };
   std::vector<RegionBuild> RB(ng);
-  (void)hlut();
-
+  std::vector<int8_t> h_delta0(nc1, 1);
+  std::vector<uint8_t> h_cons(nc1, 0);
   auto prep = [&](int g) {
     RegionHost& rh = R[g];
     RegionBuild& rb = RB[g];
@@ -624,15 +1217,14 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     rh.min_linkers = prm.min_linkers;
     rh.e0 = nrow ? row_ptr[rh.r0] : 0;
     if (rh.S == 0) return;
+    const bool chain = (uint32_t)rh.S > prm.max_enum_snps;
     const int64_t e1 = row_ptr[rh.r0 + rh.nrow];
     rh.phase_site.assign((size_t)(e1 - rh.e0), 0);
     rh.tag.assign(rh.nrow, 0); rh.asg.assign(rh.nrow, 0); rh.fp.assign(rh.nrow, 0);
     rh.cover.assign(rh.S, {});
     rh.orig_flags.resize(rh.S);
     for (int i = 0; i < rh.S; i++) rh.orig_flags[i] = rh.cand[i].flags;
-    // phase matrix of the region: flat CSR over the phasing rows (entries at phase sites only) + CSC mirror
-    std::vector<int32_t> ccnt(rh.S + 1, 0);
-    rb.prow_ptr.push_back(0);
+    if (chain) rb.prow_ptr.push_back(0);
     for (int r = 0; r < rh.nrow; r++) {
       for (int64_t e = rh.eb(r); e < rh.ee(r); e++) {
         const int i = rh.lc(e);
@@ -642,35 +1234,16 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       if (links[rh.r0 + r] >= prm.min_linkers) {          // fragment.rs:253-255
         rh.fp[r] = 1;
         rh.fp_rows.push_back(r);
-        for (int64_t e = rh.eb(r); e < rh.ee(r); e++)
-          if (rh.phase_site[e - rh.e0]) { rb.pcol.push_back(rh.lc(e)); rb.pval.push_back((uint8_t)(val[e] & 63)); ccnt[rh.lc(e) + 1]++; }
-        rb.prow_ptr.push_back((int32_t)rb.pcol.size());
+        if (chain) {
+          for (int64_t e = rh.eb(r); e < rh.ee(r); e++)
+            if (rh.phase_site[e - rh.e0]) { rb.pcol.push_back(rh.lc(e)); rb.pval.push_back((uint8_t)(val[e] & 63)); }
+          rb.prow_ptr.push_back((int32_t)rb.pcol.size());
+        }
       }
     }
-    const int32_t acc = (int32_t)rb.pcol.size();
-    const size_t n_prow = rh.fp_rows.size();
-    for (int i = 0; i < rh.S; i++) ccnt[i + 1] += ccnt[i];
-    rb.ccol_ptr.assign(ccnt.begin(), ccnt.end());
-    rb.crow.resize(acc); rb.cval.resize(acc);
-    std::vector<int32_t> fill(ccnt.begin(), ccnt.end() - 1);
-    for (size_t k = 0; k < n_prow; k++)
-      for (int e = rb.prow_ptr[k]; e < rb.prow_ptr[k + 1]; e++) {
-        const int i = rb.pcol[e];
-        rb.crow[fill[i]] = (int32_t)k; rb.cval[fill[i]] = rb.pval[e]; fill[i]++;
-      }
-    rb.fp.resize(rh.S); rb.vt.resize(rh.S); rb.cons.assign(rh.S, 0); rb.delta0.assign(rh.S, 1);
-    rb.snp_const.assign(4 * (size_t)rh.S, 0);
-    for (int e = 0; e < acc; e++) {
-      const PhaseLutDev& LD = hlut().dev;
-      const int q = rb.pval[e] & 31, i = rb.pcol[e];
-      const bool pref = (rb.pval[e] & 32) != 0;
-      rb.snp_const[4 * i] += LD.fe[q]; rb.snp_const[4 * i + 1] += LD.f1e[q] - LD.fe[q];
-      rb.snp_const[4 * i + 2] += pref ? LD.f1e[q] : LD.fe[q]; rb.snp_const[4 * i + 3] += pref ? LD.fe[q] : LD.f1e[q];
-      rb.f_total += LD.fe[q];
-    }
-    for (int i = 0; i < rh.S; i++) { rb.fp[i] = rh.fphase(i) ? 1 : 0; rb.vt[i] = (int8_t)rh.cand[i].variant_type; }
     // thread.rs:162-163: init_haplotypes + init_assignment consume S + F draws; both are overwritten
-    if ((uint32_t)rh.S <= prm.max_enum_snps) return;
+    if (!chain) return;
+    const size_t n_prow = rh.fp_rows.size();
     // ---- divide_snps_into_blocks (candidate.rs:615-747) + init_haplotypes_LD2 (phase.rs:609-671), host
     const int F = (int)rh.fp_rows.size();
     std::map<std::pair<int, int>, std::array<int, 4>> pairs;  // (i<j) -> counts [ref/alt i][ref/alt j]
@@ -711,8 +1284,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     ld_blocks[g] = lg.components();
     // init_haplotypes_LD2: S random draws (ctr S+F ..), then BFS propagation inside each block
     const uint64_t c_ld = (uint64_t)rh.S + (uint64_t)F;
-    int8_t* d0 = rb.delta0.data();
-    uint8_t* cons = rb.cons.data();
+    int8_t* d0 = h_delta0.data() + rh.c0;
+    uint8_t* cons = h_cons.data() + rh.c0;
     for (int i = 0; i < rh.S; i++) d0[i] = u01(rh.seed, c_ld + i) < 0.5 ? 1 : -1;
     const int thr = (int)prm.ld_weight_threshold;
     for (auto& block : ld_blocks[g]) {
@@ -745,148 +1318,34 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   }
   auto for_regions = [&](const std::function<void(int)>& fn) { pool->parallel_for(ng, fn); };
   for_regions(prep);
-
-  // ---- concatenate the per-region slices (serial, memcpy-sized)
-  std::vector<RegionDev> rdev;
-  std::vector<int> slot_of(ng, -1);
-  std::vector<int32_t> h_prow_ptr, h_pcol, h_ccol_ptr, h_crow;
-  std::vector<uint8_t> h_pval, h_cval, h_fp, h_cons;
-  std::vector<int8_t> h_vt, h_delta0;
-  std::vector<long long> h_snp_const;
-  int32_t sig_total = 0, snp_total = 0, max_state = 0;
-  std::vector<int32_t> enum_slots, chain_slots;
-  auto app = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
-  for (int g = 0; g < ng; g++) {
-    RegionHost& rh = R[g];
-    if (rh.S == 0) continue;
-    RegionBuild& rb = RB[g];
-    RegionDev rd{};
-    rd.R = (int32_t)rh.fp_rows.size(); rd.S = rh.S;
-    rd.rp_off = (int32_t)h_prow_ptr.size(); rd.cp_off = (int32_t)h_ccol_ptr.size(); rd.e_off = (int64_t)h_pcol.size();
-    rd.sig_off = sig_total; rd.snp_off = snp_total; rd.seed = rh.seed; rd.f_total = rb.f_total;
-    sig_total += rd.R; snp_total += rd.S;
-    max_state = std::max(max_state, rd.R + 2 * rd.S);
-    app(h_prow_ptr, rb.prow_ptr); app(h_pcol, rb.pcol); app(h_pval, rb.pval);
-    app(h_ccol_ptr, rb.ccol_ptr); app(h_crow, rb.crow); app(h_cval, rb.cval);
-    app(h_fp, rb.fp); app(h_vt, rb.vt); app(h_cons, rb.cons); app(h_delta0, rb.delta0); app(h_snp_const, rb.snp_const);
-    slot_of[g] = (int)rdev.size();
-    if ((uint32_t)rh.S <= prm.max_enum_snps) enum_slots.push_back(slot_of[g]); else chain_slots.push_back(slot_of[g]);
-    rdev.push_back(rd);
-  }
   lap("host region prep + LD");
-  const HostLut& L = hlut();
-  if (!rdev.empty()) {
-    // ---- upload the phase matrices
-    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
-      hipError_t e = b.reserve(std::max<size_t>(bytes, 16));
-      if (e != hipSuccess) return e;
-      return bytes ? hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, stream) : hipSuccess;
-    };
-    DevBuf &b_reg = d_state[0], &b_prp = d_state[1], &b_pc = d_state[2], &b_pv = d_state[3], &b_cp = d_state[4],
-           &b_cr = d_state[5], &b_cv = d_state[6], &b_snp = d_state[7], &b_st = d_state[8], &b_scr = d_state[9],
-           &b_job = d_state[10], &b_obj = d_state[11], &b_sc = d_state[12];
-    PCHK(up(b_reg, rdev.data(), rdev.size() * sizeof(RegionDev)));
-    PCHK(up(b_prp, h_prow_ptr.data(), h_prow_ptr.size() * 4));
-    PCHK(up(b_pc, h_pcol.data(), h_pcol.size() * 4));
-    PCHK(up(b_pv, h_pval.data(), h_pval.size()));
-    PCHK(up(b_cp, h_ccol_ptr.data(), h_ccol_ptr.size() * 4));
-    PCHK(up(b_cr, h_crow.data(), h_crow.size() * 4));
-    PCHK(up(b_cv, h_cval.data(), h_cval.size()));
-    // per-SNP arrays: fp | vt | cons, each snp_total bytes
-    std::vector<uint8_t> snp_pack((size_t)snp_total * 3 + 16);
-    memcpy(snp_pack.data(), h_fp.data(), snp_total);
-    memcpy(snp_pack.data() + snp_total, h_vt.data(), snp_total);
-    memcpy(snp_pack.data() + 2 * (size_t)snp_total, h_cons.data(), snp_total);
-    PCHK(up(b_snp, snp_pack.data(), snp_pack.size()));
-    PCHK(up(b_sc, h_snp_const.data(), h_snp_const.size() * sizeof(long long)));
-    // state: sigma[sig_total] | delta[snp_total] | eta[snp_total] | obj[n_slots] (8-byte aligned)
-    const size_t st_sig = 0, st_del = ((size_t)sig_total + 15) & ~(size_t)15, st_eta = st_del + (((size_t)snp_total + 15) & ~(size_t)15);
-    const size_t st_obj = st_eta + (((size_t)snp_total + 15) & ~(size_t)15);
-    PCHK(b_st.reserve(st_obj + rdev.size() * 8 + 16));
-    PCHK(hipMemsetAsync(b_st.p, 0, st_obj + rdev.size() * 8, stream));
-    PCHK(hipMemcpyAsync(b_st.as<int8_t>() + st_del, h_delta0.data(), snp_total, hipMemcpyHostToDevice, stream));
-    const int32_t stride = (max_state + 63) & ~63;
-    const int n_blocks_max = 2048;
-    PCHK(b_scr.reserve((size_t)stride * n_blocks_max + 64));
 
-    PhaseDev P{};
-    P.reg = b_reg.as<RegionDev>();
-    P.prow_ptr = b_prp.as<int32_t>(); P.pcol = b_pc.as<int32_t>(); P.pval = b_pv.as<uint8_t>();
-    P.ccol_ptr = b_cp.as<int32_t>(); P.crow = b_cr.as<int32_t>(); P.cval = b_cv.as<uint8_t>();
-    P.snp_const = b_sc.as<long long>();
-    P.snp_fp = b_snp.as<uint8_t>(); P.snp_vt = b_snp.as<int8_t>() + snp_total; P.snp_cons = b_snp.as<uint8_t>() + 2 * (size_t)snp_total;
-    P.st_sigma = b_st.as<int8_t>() + st_sig; P.st_delta = b_st.as<int8_t>() + st_del; P.st_eta = b_st.as<int8_t>() + st_eta;
-    P.st_obj = (long long*)(b_st.as<int8_t>() + st_obj);
-    P.scratch = b_scr.as<int8_t>(); P.scratch_stride = stride;
-    const size_t dyn_bytes = stride <= 48 * 1024 ? (size_t)stride : 0;  // working state in LDS when it fits
-    P.lds_state = dyn_bytes ? 1 : 0;
-    P.lut = L.dev;
-
-    PCHK(hipStreamSynchronize(stream));
-    lap("upload phase matrices");
-    // ---- enumeration regions: all restarts in one launch, then re-run the winners
-    if (!enum_slots.empty()) {
-      std::vector<int32_t> job_slot; std::vector<uint32_t> job_e; std::vector<size_t> first_job;
-      for (int s : enum_slots) {
-        first_job.push_back(job_slot.size());
-        const uint32_t n = 1u << rdev[s].S;
-        for (uint32_t e = 0; e < n; e++) { job_slot.push_back(s); job_e.push_back(e); }
-      }
-      first_job.push_back(job_slot.size());
-      const int nj = (int)job_slot.size();
-      PCHK(b_job.reserve((size_t)nj * 8 + 64));
-      PCHK(b_obj.reserve((size_t)nj * 8 + 64));
-      int32_t* d_js = b_job.as<int32_t>(); uint32_t* d_je = (uint32_t*)(b_job.as<int32_t>() + nj);
-      PCHK(hipMemcpyAsync(d_js, job_slot.data(), (size_t)nj * 4, hipMemcpyHostToDevice, stream));
-      PCHK(hipMemcpyAsync(d_je, job_e.data(), (size_t)nj * 4, hipMemcpyHostToDevice, stream));
-      hipLaunchKernelGGL(k4_enum, dim3(std::min(nj, n_blocks_max)), dim3(LCR_BLOCK), dyn_bytes, stream, P, d_js, d_je, nj,
-                         b_obj.as<long long>(), 0);
-      std::vector<long long> obj(nj);
-      PCHK(hipMemcpyAsync(obj.data(), b_obj.p, (size_t)nj * 8, hipMemcpyDeviceToHost, stream));
-      PCHK(hipStreamSynchronize(stream));
-      PCHK(hipGetLastError());
-      std::vector<int32_t> win_slot; std::vector<uint32_t> win_e;
-      for (size_t k = 0; k < enum_slots.size(); k++) {
-        size_t best = first_job[k];
-        for (size_t j = first_job[k] + 1; j < first_job[k + 1]; j++) if (obj[j] > obj[best]) best = j;  // first maximum
-        win_slot.push_back(enum_slots[k]); win_e.push_back(job_e[best]);
-      }
-      const int nw = (int)win_slot.size();
-      PCHK(hipMemcpyAsync(d_js, win_slot.data(), (size_t)nw * 4, hipMemcpyHostToDevice, stream));
-      PCHK(hipMemcpyAsync(d_js + nw, win_e.data(), (size_t)nw * 4, hipMemcpyHostToDevice, stream));
-      hipLaunchKernelGGL(k4_enum, dim3(std::min(nw, n_blocks_max)), dim3(LCR_BLOCK), dyn_bytes, stream, P, d_js, (uint32_t*)(d_js + nw), nw,
-                         b_obj.as<long long>(), 1);
-      PCHK(hipGetLastError());
-      PCHK(hipStreamSynchronize(stream));  // win_slot / win_e are pageable host vectors
-    }
-    lap("enum kernels");
-    // ---- chain regions
-    const size_t st_bytes = st_obj + rdev.size() * 8;
-    PCHK(h_pin[4].reserve(st_bytes + 16));
-    struct StHost { int8_t* p; size_t n; int8_t* data() const { return p; } size_t size() const { return n; } } st_host{h_pin[4].as<int8_t>(), st_bytes};
-    auto pull_state = [&]() -> hipError_t {
-      hipError_t e = hipMemcpyAsync(st_host.data(), b_st.p, st_host.size(), hipMemcpyDeviceToHost, stream);
-      if (e != hipSuccess) return e;
-      return hipStreamSynchronize(stream);
-    };
-    if (!chain_slots.empty()) {
-      const int nc = (int)chain_slots.size();
-      if ((size_t)stride * nc + 64 > b_scr.cap) PCHK(b_scr.reserve((size_t)stride * nc + 64));
-      P.scratch = b_scr.as<int8_t>();
-      DevBuf& b_slots = b_job;
-      PCHK(b_slots.reserve((size_t)nc * 4 + 64));
-      PCHK(hipMemcpyAsync(b_slots.p, chain_slots.data(), (size_t)nc * 4, hipMemcpyHostToDevice, stream));
-      hipLaunchKernelGGL(k4_chain_a, dim3(nc), dim3(LCR_BLOCK), 0, stream, P, b_slots.as<int32_t>(), nc);
-      PCHK(hipGetLastError());
-      PCHK(pull_state());
-      // LD-block flip pass on the host (phase.rs:1298-1394): a sum-of-ratios f64 decision per block
+  // ---- chain regions on queue `side` (their own copy of the state arrays)
+  if (!chain_slots.empty()) {
+    PhaseDev Pc = P;
+    Pc.st_sigma = b_stc.as<int8_t>() + st_sig; Pc.st_delta = b_stc.as<int8_t>() + st_del; Pc.st_eta = b_stc.as<int8_t>() + st_eta;
+    Pc.st_obj = (long long*)(b_stc.as<int8_t>() + st_obj);
+    const int nc = (int)chain_slots.size();
+    PCHK(b_scr.reserve((size_t)stride * (n_big_blocks + nc) + 64));   // no-op when the enumeration branch sized it
+    Pc.scratch = b_scr.as<int8_t>() + (size_t)stride * n_big_blocks;
+    PCHK(b_slots.reserve((size_t)nc * 4 + 64));
+    PCHK(hipMemsetAsync(b_stc.p, 0, st_bytes, side));
+    PCHK(hipMemcpyAsync(b_stc.as<int8_t>() + st_del, h_delta0.data(), (size_t)ncand, hipMemcpyHostToDevice, side));
+    PCHK(hipMemcpyAsync(b_snp.as<uint8_t>() + 2 * nc1, h_cons.data(), (size_t)ncand, hipMemcpyHostToDevice, side));
+    PCHK(hipMemcpyAsync(b_slots.p, chain_slots.data(), (size_t)nc * 4, hipMemcpyHostToDevice, side));
+    hipLaunchKernelGGL(k4_chain_a, dim3(nc), dim3(LCR_BLOCK), 0, side, Pc, b_slots.as<int32_t>(), nc);
+    PCHK(hipGetLastError());
+    PCHK(hipMemcpyAsync(st2, b_stc.p, st_bytes, hipMemcpyDeviceToHost, side));
+    PCHK(hipStreamSynchronize(side));
+    // LD-block flip pass on the host (phase.rs:1298-1394): a sum-of-ratios f64 decision per block
+    struct StHost { int8_t* p; int8_t* data() const { return p; } } st_host{st2};
       auto block_pass = [&](int g) {
-        if (slot_of[g] < 0 || (uint32_t)R[g].S <= prm.max_enum_snps) return;
+        if (R[g].S == 0 || (uint32_t)R[g].S <= prm.max_enum_snps) return;
         RegionHost& rh = R[g];
-        const RegionDev& rd = rdev[slot_of[g]];
+        struct { int32_t sig_off, snp_off; } rd{R[g].r0, R[g].c0};
         int8_t* sg = st_host.data() + st_sig + rd.sig_off; int8_t* dl = st_host.data() + st_del + rd.snp_off;
         int8_t* et = st_host.data() + st_eta + rd.snp_off;
-        long long* ob = (long long*)(st_host.data() + st_obj) + slot_of[g];
+        long long* ob = (long long*)(st_host.data() + st_obj) + g;
         for (size_t k = 0; k < rh.fp_rows.size(); k++) rh.tag[rh.fp_rows[k]] = sg[k];
         for (int i = 0; i < rh.S; i++) { rh.cand[i].haplotype = dl[i]; rh.cand[i].genotype = et[i]; }
         std::map<int, int> new_hap, new_tag;
@@ -935,37 +1394,38 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
         }
       };
       for_regions(block_pass);
-      PCHK(hipMemcpyAsync(b_st.p, st_host.data(), st_host.size(), hipMemcpyHostToDevice, stream));
-      hipLaunchKernelGGL(k4_chain_b, dim3(nc), dim3(LCR_BLOCK), dyn_bytes, stream, P, b_slots.as<int32_t>(), nc);
-      PCHK(hipGetLastError());
-    }
-    PCHK(pull_state());
+    PCHK(hipMemcpyAsync(b_stc.p, st2, st_bytes, hipMemcpyHostToDevice, side));
+    hipLaunchKernelGGL(k4_chain_b, dim3(nc), dim3(LCR_BLOCK), dyn_bytes, side, Pc, b_slots.as<int32_t>(), nc);
     PCHK(hipGetLastError());
-    lap("chain kernels + block pass");
-    // ---- scatter device results into the host region views
-    for (int g = 0; g < ng; g++) {
-      if (slot_of[g] < 0) continue;
-      RegionHost& rh = R[g];
-      const RegionDev& rd = rdev[slot_of[g]];
-      const int8_t* sg = st_host.data() + st_sig + rd.sig_off; const int8_t* dl = st_host.data() + st_del + rd.snp_off;
-      const int8_t* et = st_host.data() + st_eta + rd.snp_off;
-      const long long ob = *((const long long*)(st_host.data() + st_obj) + slot_of[g]);
-      std::fill(rh.tag.begin(), rh.tag.end(), 0);
-      for (size_t k = 0; k < rh.fp_rows.size(); k++) rh.tag[rh.fp_rows[k]] = sg[k];
-      for (int i = 0; i < rh.S; i++) { rh.cand[i].haplotype = dl[i]; rh.cand[i].genotype = et[i]; }
-      objective[g] = (double)ob / FX_SCALE;
-      const uint64_t S = rh.S, F = rd.R;
-      rh.ctr = (uint32_t)rh.S <= prm.max_enum_snps ? S + F + ((uint64_t)1 << S) * F : 2 * (S + F) + (S / 4 + 1) * (S + F);
-    }
+    PCHK(hipMemcpyAsync(st2, b_stc.p, st_bytes, hipMemcpyDeviceToHost, side));
+    PCHK(hipStreamSynchronize(side));
   }
-
-  lap("scatter");
+  lap("chain kernels + block pass");
+  PCHK(hipStreamSynchronize(stream));
+  PCHK(hipGetLastError());
+  lap("wait enum");
+  // ---- scatter device results into the host region views
+  auto scatter = [&](int g) {
+    RegionHost& rh = R[g];
+    if (rh.S == 0) return;
+    const bool chain = (uint32_t)rh.S > prm.max_enum_snps;
+    const int8_t* st = chain ? st2 : st1;
+    const int8_t* sg = st + st_sig + rh.r0; const int8_t* dl = st + st_del + rh.c0; const int8_t* et = st + st_eta + rh.c0;
+    const long long ob = *((const long long*)(st + st_obj) + g);
+    std::fill(rh.tag.begin(), rh.tag.end(), 0);
+    for (size_t k = 0; k < rh.fp_rows.size(); k++) rh.tag[rh.fp_rows[k]] = sg[k];
+    for (int i = 0; i < rh.S; i++) { rh.cand[i].haplotype = dl[i]; rh.cand[i].genotype = et[i]; }
+    objective[g] = (double)ob / FX_SCALE;
+    const uint64_t S = rh.S, F = rh.fp_rows.size();
+    rh.ctr = !chain ? S + F + ((uint64_t)1 << S) * F : 2 * (S + F) + (S / 4 + 1) * (S + F);
+  };
   // ---- post-phase epilogue, thread.rs:168-201.  Regions are independent (the reference runs them as
   // rayon tasks, thread.rs:77): a small host thread pool walks them; results do not depend on the
   // thread count (per-region RNG stream, disjoint output rows).
   auto epilogue = [&](int g) {
     RegionHost& rh = R[g];
     if (rh.S == 0) return;
+    scatter(g);
     rh.assign_reads_haplotype(prm.read_assign_cutoff);
     rh.assign_snp_haplotype_genotype();
     rh.assign_reads_haplotype(prm.read_assign_cutoff);
@@ -979,7 +1439,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     for (int r = 0; r < rh.nrow; r++) { haplotag[rh.r0 + r] = rh.tag[r]; assignment[rh.r0 + r] = rh.asg[r]; }
   };
   for_regions(epilogue);
-  lap("post-phase epilogue");
+  lap("scatter + post-phase epilogue");
   return LCR_OK;
 #undef PCHK
 }

@@ -521,6 +521,8 @@ int lcr_phase(lcr_ctx* c, const lcr_params* p) {
   in.d_row_ptr = c->row_ptr.as<int64_t>(); in.d_col = c->col.as<int32_t>(); in.d_val = c->val.as<uint8_t>();
   in.d_row_links = c->row_links.as<uint32_t>();
   in.cand = &c->h_cand;
+  in.d_cand = c->d_cand.as<lcr_candidate>(); in.d_cand_off = c->d_cand_off.as<int32_t>();
+  in.d_row_region_off = c->row_region_off.as<int32_t>(); in.d_start0 = c->bv.start0;
   Timer t(c, LCR_K_PHASE);
   int rc = c->phase.run(in, *p, c->stream, &c->err);
   if (rc) return rc;

@@ -19,6 +19,10 @@ struct PhaseInputs {
   const uint8_t* d_val = nullptr;
   const uint32_t* d_row_links = nullptr;
   std::vector<lcr_candidate>* cand = nullptr;  // host candidates, updated in place
+  const lcr_candidate* d_cand = nullptr;     // device copy of the same candidates (as K3 saw them)
+  const int32_t* d_cand_off = nullptr;       // device, n_regions+1
+  const int32_t* d_row_region_off = nullptr; // device, n_regions+1
+  const int64_t* d_start0 = nullptr;         // device, region start columns
 };
 
 // Persistent host worker pool: regions are independent units of host-side work (the reference runs
@@ -73,9 +77,18 @@ struct PhaseHost {
   std::vector<uint8_t> assignment;
   std::vector<uint32_t> phase_set;
   std::vector<double> objective;
-  DevBuf d_state[13];
-  HostBuf h_pin[5];   // pinned staging: row_ptr, col, val, links, packed state
+  DevBuf d_state[17];
+  HostBuf h_pin[7];   // pinned staging: row_ptr, col, val, links, enum state, region sizes, chain state
+  hipStream_t side = nullptr;   // second queue: fragment matrix download + chain regions
+  hipEvent_t ev_in = nullptr, ev_csr = nullptr;
   HostPool* pool = nullptr;
   int run(const PhaseInputs& in, const lcr_params& p, hipStream_t s, std::string* err);
-  void release() { for (auto& b : d_state) b.release(); for (auto& b : h_pin) b.release(); delete pool; pool = nullptr; }
+  void release() {
+    for (auto& b : d_state) b.release();
+    for (auto& b : h_pin) b.release();
+    if (side) { (void)hipStreamDestroy(side); side = nullptr; }
+    if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
+    if (ev_csr) { (void)hipEventDestroy(ev_csr); ev_csr = nullptr; }
+    delete pool; pool = nullptr;
+  }
 };

@@ -916,6 +916,7 @@ struct orc_region {
       num_iters++;
       if (num_iters > 20) break; /* phase.rs:968-972 */
     }
+    if (getenv("ORC_DEBUG_ITERS")) fprintf(stderr, "[orc] cross_optimize iters %d\n", num_iters);
     return cal_overall_probability(mode);
   }
 
