@@ -193,7 +193,7 @@ __device__ __forceinline__ int8_t init_genotype(int8_t vt) { return vt == 0 ? 1 
 // ---------------------------------------------------------------------------------------------
 struct EnumTile { int32_t slot; uint32_t e0, ne; };   // restarts e0 .. e0+ne-1 of one region
 constexpr int ENUM_WAVES = 4;
-constexpr uint32_t ENUM_TILE_JOBS = 32;
+constexpr uint32_t ENUM_TILE_JOBS = 16;
 constexpr uint32_t ENUM_LDS_BYTES = 48 * 1024;
 
 // LDS image: wl2[32] {lo23, hi24 (signed)} | csr[E] {lo | meta << 24, hi | row_in_lane << 24} | csc[E] | rp[R+1] u16 |
@@ -296,12 +296,14 @@ k4_enum_reg(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __res
   unsigned long long* sgb = (unsigned long long*)(lds + L.state + wave * L.stride);   // bit = 1: sigma == -1
   unsigned long long* Macc = sgb + (R + 63) / 64 + 1;
   const int r_a = first_row[lane];
-  uint32_t re0[CK], re1[CK], ce[CK];
-  {
-    const int s0 = rp[r_a], s1 = rp[first_row[lane + 1]];
-    const int c0 = min((int)E, lane * (int)c), c1 = min((int)E, (lane + 1) * (int)c);
+  // CK > 0: the lane's entries live in VGPRs; CK == 0: any share size, entries are re-read from LDS
+  constexpr int NREG = CK > 0 ? CK : 1;
+  uint32_t re0[NREG], re1[NREG], ce[NREG];
+  const int s0 = rp[r_a], s1 = rp[first_row[lane + 1]];
+  const int c0 = min((int)E, lane * (int)c), c1 = min((int)E, (lane + 1) * (int)c);
+  if (CK > 0) {
 #pragma unroll
-    for (int x = 0; x < CK; x++) {
+    for (int x = 0; x < NREG; x++) {
       const uint2 v = s0 + x < s1 ? csr[s0 + x] : make_uint2(0, 0);
       re0[x] = v.x; re1[x] = v.y;
       ce[x] = c0 + x < c1 ? csc[c0 + x] : 0;
@@ -356,13 +358,7 @@ k4_enum_reg(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __res
         const unsigned long long win = wsh ? (w0 >> wsh) | (w1 << (64 - wsh)) : w0;
         int alo = 0, ahi = 0;
         unsigned long long fm = 0;
-#pragma unroll
-        for (int x = 0; x < CK; x++) {
-          if (x >= n_sig) break;
-          // opaque to the optimiser: otherwise every field extraction below is hoisted out of the restart
-          // loop into its own VGPR (x CK entries) and the kernel drops to one wave per SIMD
-          asm volatile("" : "+v"(re0[x]), "+v"(re1[x]));
-          const uint32_t v0 = re0[x], v1 = re1[x];
+        auto sig_one = [&](uint32_t v0, uint32_t v1) {
           const uint32_t m = v0 >> 24, i = m & 31u, roff = v1 >> 24;
           const uint32_t sneg = (uint32_t)(win >> roff);
           const uint32_t use = (m >> 7) & (eta0 >> i) & 1u;                 // het sites only
@@ -374,6 +370,24 @@ k4_enum_reg(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __res
           // sign of ahi * 2^23 + alo: fold alo's carry into ahi, the remainder is in [0, 2^23)
           if (end && ahi + (alo >> 23) < 0) fm |= 1ull << roff;
           alo = end ? 0 : alo; ahi = end ? 0 : ahi;
+        };
+        if (CK > 0) {
+#pragma unroll
+          for (int x = 0; x < NREG; x++) {
+            if (x >= n_sig) break;
+            // opaque to the optimiser: otherwise every field extraction is hoisted out of the restart loop
+            // into its own VGPR (x CK entries) and the kernel drops to one wave per SIMD
+            asm volatile("" : "+v"(re0[x]), "+v"(re1[x]));
+            sig_one(re0[x], re1[x]);
+          }
+        } else {
+          for (int x0 = 0; x0 < n_sig; x0 += 4) {
+            uint2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = s0 + x0 + u < s1 ? csr[s0 + x0 + u] : make_uint2(0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) sig_one(v[u].x, v[u].y);
+          }
         }
         const bool any = __ballot(fm != 0) != 0;
         if (fm) {
@@ -387,20 +401,17 @@ k4_enum_reg(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __res
       if (!(P.dbg & 16)) {
         constexpr int HB = 8;   // look-ups of one batch in flight, then its run-length flush
         int cur = -1; int alo = 0, ahi = 0;
-#pragma unroll
-        for (int h = 0; h < CK; h += HB) {
-          if (h >= n_del) break;
+        auto del_batch = [&](const uint32_t* v8) {
           uint32_t sw[HB]; uint2 wq[HB];
 #pragma unroll
           for (int x = 0; x < HB; x++) {
-            asm volatile("" : "+v"(ce[h + x]));
-            const uint32_t row = ce[h + x] & 0xffffu;
+            const uint32_t row = v8[x] & 0xffffu;
             sw[x] = ((const uint32_t*)sgb)[row >> 5];
-            wq[x] = wl2[(ce[h + x] >> 22) & 31u];
+            wq[x] = wl2[(v8[x] >> 22) & 31u];
           }
 #pragma unroll
           for (int x = 0; x < HB; x++) {
-            const uint32_t v = ce[h + x];
+            const uint32_t v = v8[x];
             const int i = (v >> 16) & 31;
             const uint32_t hit = ((v >> 21) ^ (sw[x] >> (v & 31u)) ^ (dneg >> i)) & (v >> 31);
             if ((v >> 31) && i != cur) {
@@ -409,6 +420,23 @@ k4_enum_reg(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __res
             }
             alo += __mul24((int)hit, (int)wq[x].x);
             ahi += __mul24((int)hit, (int)wq[x].y);   // sign-extends the 24-bit hi limb
+          }
+        };
+        if (CK > 0) {
+#pragma unroll
+          for (int h = 0; h < NREG; h += HB) {
+            if (h >= n_del) break;
+            uint32_t v8[HB];
+#pragma unroll
+            for (int x = 0; x < HB; x++) { asm volatile("" : "+v"(ce[h + x < NREG ? h + x : 0])); v8[x] = ce[h + x < NREG ? h + x : 0]; }
+            del_batch(v8);
+          }
+        } else {
+          for (int h = 0; h < n_del; h += HB) {
+            uint32_t v8[HB];
+#pragma unroll
+            for (int x = 0; x < HB; x++) v8[x] = c0 + h + x < c1 ? csc[c0 + h + x] : 0;
+            del_batch(v8);
           }
         }
         if (alo | ahi) atomicAdd(&Macc[cur], (unsigned long long)(((long long)ahi << 23) + alo));
@@ -1128,24 +1156,28 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   std::vector<uint8_t> packed;   // pageable upload source; must outlive the copy (synchronised below)
   size_t n_big_blocks = 0;
   if (!enum_slots.empty()) {
-    const bool force_big = getenv("LCR_ENUM_FORCE_BIG") != nullptr;  // test hook: exercise the fallback kernel
-    // class 0..2: register-resident kernel with <= 8 / 16 / 32 entries per lane; class 3: global-memory kernel
-    constexpr int NCLS = 4;
+    const bool force_big = getenv("LCR_ENUM_FORCE_BIG") != nullptr;        // test hooks: exercise the fallback kernels
+    const bool force_stream = getenv("LCR_ENUM_FORCE_STREAM") != nullptr;
+    // class 2: register-resident kernel (<= 32 entries per lane; smaller instantiations were measured: separate
+    // launches each pay their own tail, one CK=32 launch with early exits is faster); class 3: same kernel
+    // streaming its entries from LDS (any share size); class 4: global-memory kernel (matrix larger than the
+    // LDS budget); classes 0 / 1 unused
+    constexpr int NCLS = 5;
     std::vector<EnumTile> tiles[NCLS], wtiles[NCLS];
     std::vector<int64_t> job_base(ng, 0);
     int64_t nj = 0;
-    uint32_t lds_need[NCLS] = {0, 0, 0, 0};
+    uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0};
     for (int g : enum_slots) {
       const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
       const StageStat& st = stat[g];
       const EnumLayout EL = enum_layout(st.R, st.E);
-      int cls = 3;
+      int cls = 4;
       if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_BYTES && st.max_rows <= 64)
-        cls = st.max_n <= 8 ? 0 : (st.max_n <= 16 ? 1 : (st.max_n <= 32 ? 2 : 3));
-      if (cls < 3) lds_need[cls] = std::max(lds_need[cls], EL.total);
+        cls = force_stream ? 3 : (st.max_n <= 32 ? 2 : 3);   // (the 8 / 16 instantiations: one launch has one tail)
+      if (cls < 4) lds_need[cls] = std::max(lds_need[cls], EL.total);
       job_base[g] = nj;
       const uint32_t n = 1u << S;
-      const uint32_t per = cls == 3 ? 1u : ENUM_TILE_JOBS;
+      const uint32_t per = cls == 4 ? 1u : (cls == 3 ? 2u * ENUM_WAVES : ENUM_TILE_JOBS);
       for (uint32_t e0 = 0; e0 < n; e0 += per) tiles[cls].push_back({g, e0, std::min(per, n - e0)});
       wtiles[cls].push_back({g, 0, 1});
       nj += n;
@@ -1170,15 +1202,14 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     const int32_t* d_sl = (const int32_t*)(b_job.as<uint8_t>() + off_jb_al + (size_t)ng * 8);
     long long* d_obj = b_obj.as<long long>();
     uint32_t* d_win = (uint32_t*)(d_obj + nj);
-    n_big_blocks = std::max(n_t[3], n_w[3]);
+    n_big_blocks = std::max(n_t[4], n_w[4]);
     PCHK(b_scr.reserve((size_t)stride * (n_big_blocks + chain_slots.size()) + 64));   // chain regions use the tail
     P.scratch = b_scr.as<int8_t>();
     auto launch = [&](const size_t* cnt, const size_t* off, const uint32_t* win) {
       const dim3 blk(64 * ENUM_WAVES);
-      if (cnt[0]) hipLaunchKernelGGL(k4_enum_reg<8>, dim3((unsigned)cnt[0]), blk, lds_need[0], stream, P, d_t + off[0], d_jb, d_obj, win);
-      if (cnt[1]) hipLaunchKernelGGL(k4_enum_reg<16>, dim3((unsigned)cnt[1]), blk, lds_need[1], stream, P, d_t + off[1], d_jb, d_obj, win);
       if (cnt[2]) hipLaunchKernelGGL(k4_enum_reg<32>, dim3((unsigned)cnt[2]), blk, lds_need[2], stream, P, d_t + off[2], d_jb, d_obj, win);
-      if (cnt[3]) hipLaunchKernelGGL(k4_enum_big, dim3((unsigned)cnt[3]), dim3(LCR_BLOCK), 0, stream, P, d_t + off[3], d_jb, d_obj, win);
+      if (cnt[3]) hipLaunchKernelGGL(k4_enum_reg<0>, dim3((unsigned)cnt[3]), blk, lds_need[3], stream, P, d_t + off[3], d_jb, d_obj, win);
+      if (cnt[4]) hipLaunchKernelGGL(k4_enum_big, dim3((unsigned)cnt[4]), dim3(LCR_BLOCK), 0, stream, P, d_t + off[4], d_jb, d_obj, win);
     };
     launch(n_t, t_off, nullptr);
     hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)ns), dim3(64), 0, stream, d_sl, (int32_t)ns, P.reg, d_jb, d_obj, d_win);
