@@ -40,18 +40,6 @@
 #define REC_KIND_D 0xFFFFFFFFFFull  // offset field of a D-run record
 #define REC_KIND_I 0xFFFFFFFFFEull  // offset field of an I-point record
 
-// wave64 inclusive add-scan with DPP row shifts / row broadcasts (6 VALU ops, no LDS round trips).
-// update_dpp(old = 0, ..., bound_ctrl = false): lanes without a source keep 0, the identity.
-__device__ __forceinline__ int wave_incl_scan(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
-  return v;
-}
-
 // ---------------------------------------------------------------------------------------------
 // read -> region map (one block per region writes its read range)
 __global__ void __launch_bounds__(LCR_BLOCK) k0_read_region(const int32_t* __restrict__ read_begin, int32_t* __restrict__ out) {
@@ -192,6 +180,7 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int pass, int ont, int D, 
       q_cur += __shfl(iq, 63, 64);
       if (c0 + 64 >= ncig && pass == 0 && lane == 0 && q_cur != reb) atomicExch(b.error_flag, 2);
     }
+    if (pass == 0 && lane == 0) b.read_rend[r] = ref_cur;   // pass 0 never leaves the chunk loop early
     // (the loop above may leave early in pass 1; the next read's first words are then fetched here)
     if (r_next < b.n_reads) {
       if (!have_wn) word_n = (uint32_t)lane < (uint32_t)hn.n_cig ? b.cigar[hn.cig_off + lane] : 0u;

@@ -291,68 +291,40 @@ k2_compact(BatchView b, DevParams prm, BinomTable bt, const int32_t* __restrict_
 
 
 // ---- pass 2a: per-survivor quality histograms --------------------------------------------------
-// One thread per read walks its CIGAR once with a cursor over the region's survivors (sorted by
-// column), exactly like the reference's fragment walk, and adds (allele, clamped q) of every *kept*
-// base (same trim / poly-A mask as K1) to hist[s][allele][q].
+// Sixteen lanes per read (row16_walk_sites, lcr_dev.h): the region's survivors (sorted by column) that
+// fall inside the read's reference span are located against the CIGAR spread over the lanes, and
+// (allele, clamped q) of every *kept* base (same trim / poly-A mask as K1) is added to
+// hist[s][allele][q].  Reads that cover no survivor never load their CIGAR.
 __global__ void __launch_bounds__(LCR_BLOCK)
-k2_hist(BatchView b, DevParams prm, const Survivor* __restrict__ sv, const int32_t* __restrict__ sv_region_off,
-        uint32_t* __restrict__ hist) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= b.n_reads) return;
-  const int g = region_of_read(b, r);
-  int s_lo = sv_region_off[g];
-  const int s_hi = sv_region_off[g + 1];
-  if (s_lo >= s_hi) return;
-  const int vec = b.len[g];
-  int p = (int)((int64_t)b.pos[r] - b.start0[g]);  // pos_in_freq_vec
-  {  // first survivor with col >= max(p, 0)
-    int lo = s_lo, hi = s_hi, key = max(p, 0);
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (sv[mid].col >= key) hi = mid; else lo = mid + 1; }
-    s_lo = lo;
-  }
-  if (s_lo >= s_hi) return;
-  const uint32_t ncig = b.n_cig[r];
-  const uint32_t* __restrict__ cg = b.cigar + b.cig_off[r];
-  const uint8_t* __restrict__ seq = b.bases + b.seq_off[r];
-  const uint8_t* __restrict__ qual = b.quals + b.seq_off[r];
-  const int seq_len = b.seq_len[r], lead = b.lead[r], reb = seq_len - b.trail[r];
-  int q = lead > 0 ? lead : 0;
-  int cur = s_lo;
-  int scol = sv[cur].col;
-  for (uint32_t i = 0; i < ncig && cur < s_hi; i++) {
-    const int op = cg[i] & 15, len = (int)(cg[i] >> 4);
-    if (op == 0 || op == 7 || op == 8) {
-      while (cur < s_hi && scol < p + len) {
-        if (scol >= p && scol < vec) {
-          const int c = q + (scol - p);
-          const uint8_t base = seq[c];
-          bool masked = false;
-          if (in_end_zone(c, lead, reb, prm.dist_to_end))
-            masked = prm.ont ? true : polya_masked(seq, seq_len, c, prm.polya_len, sv[cur].ref_base);
-          const int bi = base_code(base);
-          if (!masked && bi >= 0) {
-            const uint8_t bq = qual[c] < 30 ? qual[c] : 30;  // MAX_BASE_QUALITY (util.rs:711-715)
-            atomicAdd(&hist[((int64_t)cur * 4 + bi) * 31 + bq], 1u);
-          }
-        }
-        cur++;
-        if (cur < s_hi) scol = sv[cur].col;
-      }
-      p += len; q += len;
-    } else if (op == 1) {
-      q += len;
-    } else if (op == 2 || op == 3) {
-      while (cur < s_hi && scol < p + len) { cur++; if (cur < s_hi) scol = sv[cur].col; }
-      p += len;
-    }
-  }
+k2_hist(BatchView b, DevParams prm, const ReadBin* __restrict__ rbin, const Survivor* __restrict__ sv,
+        const int32_t* __restrict__ sv_region_off, uint32_t* __restrict__ hist) {
+  const int r = (blockIdx.x * LCR_BLOCK + threadIdx.x) >> 4;
+  const bool live = r < b.n_reads;
+  const int rr = live ? r : 0;
+  const int g = region_of_read(b, rr);
+  const int s_lo = sv_region_off[g], s_hi = sv_region_off[g + 1];
+  const ReadBin h = rbin[rr];
+  const uint8_t* __restrict__ seq = b.bases + h.seq_off;
+  const uint8_t* __restrict__ qual = b.quals + h.seq_off;
+  row16_walk_sites(b, live && s_lo < s_hi, h, b.read_rend[rr], s_lo, s_hi,
+    [&](int i) { return sv[i].col; },
+    [&](int cur, int c, bool hit) {   // lane <-> survivor
+      if (!hit) return;
+      const uint8_t base = seq[c];
+      const uint8_t bq = qual[c] < 30 ? qual[c] : 30;  // MAX_BASE_QUALITY (util.rs:711-715)
+      bool masked = false;
+      if (in_end_zone(c, h.lead, h.reb, prm.dist_to_end))
+        masked = prm.ont ? true : polya_masked(seq, b.seq_len[rr], c, prm.polya_len, sv[cur].ref_base);
+      const int bi = base_code(base);
+      if (!masked && bi >= 0) atomicAdd(&hist[((int64_t)cur * 4 + bi) * 31 + bq], 1u);
+    });
 }
 
-void launch_k2_hist(const BatchView& b, const DevParams& p, const Survivor* sv, const int32_t* sv_region_off,
-                    uint32_t* hist, hipStream_t s) {
+void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin, const Survivor* sv,
+                    const int32_t* sv_region_off, uint32_t* hist, hipStream_t s) {
   if (b.n_reads == 0) return;
-  hipLaunchKernelGGL(k2_hist, dim3((b.n_reads + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, b, p, sv,
-                     sv_region_off, hist);
+  const int per = LCR_BLOCK / 16;
+  hipLaunchKernelGGL(k2_hist, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, p, rbin, sv, sv_region_off, hist);
 }
 
 // ---- pass 2b: genotype likelihood + classification --------------------------------------------

@@ -1,7 +1,7 @@
 // k3_fragments.hip — K3: read x SNP fragment matrix in CSR (gfx950).
 //
-// Replaces SNPFrag::get_fragments (reference src/fragment.rs:10-309): per read one CIGAR walk with
-// a cursor over the region's candidates (sorted by position).  Two passes (count -> scan -> fill)
+// Replaces SNPFrag::get_fragments (reference src/fragment.rs:10-309): per read one CIGAR walk against
+// the region's candidates (sorted by position), sixteen lanes per read.  Two passes (count -> scan -> fill)
 // give a canonical CSR: row = k-th read of the region that starts at or before the last candidate
 // (fragment.rs:51-54, empty rows included), columns ascending.  Entry = (candidate index, u8 value
 // q5 | p-bit | base code).  Entries with p = 0 or at dense candidates are dropped (fragment.rs:148).
@@ -26,84 +26,72 @@ void launch_k3_rows(const BatchView& b, const lcr_candidate* cand, const int32_t
   hipLaunchKernelGGL(k3_rows, dim3((b.n_regions + 255) / 256), dim3(256), 0, s, b, cand, cand_region_off, region_rows);
 }
 
+// Sixteen lanes per row (row16_walk_sites, lcr_dev.h): the region's candidates inside the read's reference
+// span are located against the CIGAR spread over the lanes; a row without such candidates never loads
+// its CIGAR.  No trimming here: the reference's fragment walk takes every aligned base.
 template <bool FILL>
 __global__ void __launch_bounds__(LCR_BLOCK)
-k3_walk(BatchView b, const lcr_candidate* __restrict__ cand, const int32_t* __restrict__ cand_region_off,
-        const int32_t* __restrict__ row_region_off, int32_t n_rows, int32_t* __restrict__ row_cnt,
-        uint32_t* __restrict__ row_links, const int64_t* __restrict__ row_ptr, int32_t* __restrict__ col,
-        uint8_t* __restrict__ val) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= n_rows) return;
-  int g;
-  {  // last region with row_region_off[g] <= row
-    int lo = 0, hi = b.n_regions;
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (row_region_off[mid] <= row) lo = mid; else hi = mid; }
-    g = lo;
-  }
-  const int r = b.read_begin[g] + (row - row_region_off[g]);
+k3_walk(BatchView b, const ReadBin* __restrict__ rbin, const lcr_candidate* __restrict__ cand,
+        const int32_t* __restrict__ cand_region_off, const int32_t* __restrict__ row_region_off, int32_t n_rows,
+        int32_t* __restrict__ row_cnt, uint32_t* __restrict__ row_links, const int64_t* __restrict__ row_ptr,
+        int32_t* __restrict__ col, uint8_t* __restrict__ val) {
+  // rows are the first region_rows[g] reads of each region: index by read (one load for the region)
+  const int r_ = (blockIdx.x * LCR_BLOCK + threadIdx.x) >> 4;
+  const int r = r_ < b.n_reads ? r_ : 0;
+  const int g = region_of_read(b, r);
+  const int k = r - b.read_begin[g];
+  const int row0 = row_region_off[g];
+  const bool live = r_ < b.n_reads && k < row_region_off[g + 1] - row0;
+  const int row = live ? row0 + k : 0;
+  const int l16 = threadIdx.x & 15;
   const int c_lo = cand_region_off[g], c_hi = cand_region_off[g + 1];
-  const int64_t pos = b.pos[r];
-  int idx;
-  {  // fragment.rs:63-80: first candidate with pos >= read pos
-    int lo = c_lo, hi = c_hi;
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (cand[mid].pos >= pos) hi = mid; else lo = mid + 1; }
-    idx = lo;
-  }
-  const uint32_t ncig = b.n_cig[r];
-  const uint32_t* __restrict__ cg = b.cigar + b.cig_off[r];
-  const uint8_t* __restrict__ seq = b.bases + b.seq_off[r];
-  const uint8_t* __restrict__ qual = b.quals + b.seq_off[r];
-  int64_t pr = pos;
-  int64_t q = b.lead[r];
+  const ReadBin h = rbin[r];
+  const int64_t start0 = b.start0[g];
+  const uint8_t* __restrict__ seq = b.bases + h.seq_off;
+  const uint8_t* __restrict__ qual = b.quals + h.seq_off;
   int cnt = 0;
   uint32_t links = 0;
   int64_t w = FILL ? row_ptr[row] : 0;
-  for (uint32_t i = 0; i < ncig && idx < c_hi; i++) {
-    const int op = cg[i] & 15;
-    const int64_t len = (int64_t)(cg[i] >> 4);
-    if (op == 0 || op == 7 || op == 8) {
-      while (idx < c_hi && cand[idx].pos < pr + len) {
+  const int rbase = threadIdx.x & 48;
+  row16_walk_sites(b, live, h, b.read_rend[r], c_lo, c_hi,
+    [&](int i) { return (int)(cand[i].pos - start0); },
+    [&](int idx, int qq, bool hit) {   // lane <-> candidate; entries keep the candidates' order
+      int p = 0; uint8_t base = 0; bool fphase = false;
+      if (hit) {
         const lcr_candidate& c = cand[idx];
-        const int64_t qq = q + (c.pos - pr);
-        const uint8_t base = seq[qq];
-        int p = 0;
+        base = seq[qq];
         if (base == c.ref_base) p = 1;                                                // fragment.rs:134-135
         else if (base == c.allele1 || base == c.allele2) p = -1;                      // fragment.rs:136-140
-        if (p != 0 && !(c.flags & LCR_F_DENSE)) {                                     // fragment.rs:148-152
-          if (FILL) {
-            const uint8_t bq = qual[qq] < 30 ? qual[qq] : 30;                          // fragment.rs:127-131
-            col[w] = idx;
-            val[w] = (uint8_t)(bq | (p == 1 ? 32 : 0) | (base_code(base) << 6));
-            w++;
-          }
-          cnt++;
-          if (c.flags & LCR_F_FOR_PHASING) links++;                                   // fragment.rs:144-146,242-250
-        }
-        idx++;
+        if (c.flags & LCR_F_DENSE) p = 0;                                             // fragment.rs:148-152
+        fphase = (c.flags & LCR_F_FOR_PHASING) != 0;                                  // fragment.rs:144-146,242-250
       }
-      pr += len; q += len;
-    } else if (op == 1) {
-      q += len;
-    } else if (op == 2 || op == 3) {
-      while (idx < c_hi && cand[idx].pos < pr + len) idx++;                           // fragment.rs:166-189
-      pr += len;
-    }
-  }
-  if (!FILL) { row_cnt[row] = cnt; row_links[row] = links; }
+      const unsigned int em = (unsigned int)(__ballot(p != 0) >> rbase) & 0xffffu;
+      const unsigned int ph = (unsigned int)(__ballot(p != 0 && fphase) >> rbase) & 0xffffu;
+      if (FILL && p != 0) {
+        const int64_t at = w + __popc(em & ((1u << l16) - 1u));
+        const uint8_t bq = qual[qq] < 30 ? qual[qq] : 30;                              // fragment.rs:127-131
+        col[at] = idx;
+        val[at] = (uint8_t)(bq | (p == 1 ? 32 : 0) | (base_code(base) << 6));
+      }
+      w += __popc(em); cnt += __popc(em); links += __popc(ph);
+    });
+  if (!FILL && live && l16 == 0) { row_cnt[row] = cnt; row_links[row] = links; }
 }
 
-void launch_k3_count(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off,
+void launch_k3_count(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
                      const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, uint32_t* row_links,
                      hipStream_t s) {
   if (n_rows == 0) return;
-  hipLaunchKernelGGL(k3_walk<false>, dim3((n_rows + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, b, cand,
+  const int per = LCR_BLOCK / 16;
+  hipLaunchKernelGGL(k3_walk<false>, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, rbin, cand,
                      cand_region_off, row_region_off, n_rows, row_cnt, row_links, (const int64_t*)nullptr,
                      (int32_t*)nullptr, (uint8_t*)nullptr);
 }
-void launch_k3_fill(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off,
+void launch_k3_fill(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
                     const int32_t* row_region_off, int32_t n_rows, const int64_t* row_ptr, int32_t* col, uint8_t* val,
                     hipStream_t s) {
   if (n_rows == 0) return;
-  hipLaunchKernelGGL(k3_walk<true>, dim3((n_rows + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, b, cand,
+  const int per = LCR_BLOCK / 16;
+  hipLaunchKernelGGL(k3_walk<true>, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, rbin, cand,
                      cand_region_off, row_region_off, n_rows, (int32_t*)nullptr, (uint32_t*)nullptr, row_ptr, col, val);
 }

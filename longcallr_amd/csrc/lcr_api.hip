@@ -23,7 +23,7 @@ struct lcr_ctx {
   std::vector<int64_t> h_start0, h_col_off;
   std::vector<int32_t> h_len, h_read_begin, h_region_first_tile;
   DevBuf in_[16];  // device copies of host inputs (LCR_MEM_HOST)
-  DevBuf scan_tmp, read_region, read_bin, errflag, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_off, k0_tile_fill, k0_items, ndiff, nscan;
+  DevBuf scan_tmp, read_region, read_bin, read_rend, errflag, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_off, k0_tile_fill, k0_items, ndiff, nscan;
   int64_t n_items = 0;
 
   // K1
@@ -166,7 +166,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto& b : c->in_) b.release();
   DevBuf* bufs[] = {&c->rd_start, &c->rd_end, &c->rd_diff, &c->rd_ex, &c->rd_cnt, &c->rd_off, &c->rd_s, &c->rd_e, &c->rd_max,
-                    &c->scan_tmp, &c->read_region, &c->read_bin, &c->errflag, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, &c->k0_tile_off,
+                    &c->scan_tmp, &c->read_region, &c->read_bin, &c->read_rend, &c->errflag, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, &c->k0_tile_off,
                     &c->k0_tile_fill, &c->k0_items, &c->ndiff, &c->nscan, &c->planes, &c->flags,
                     &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
                     &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
@@ -281,6 +281,8 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   HIPCHK(c, c->first_tile.reserve((ng + 1) * 4));
   HIPCHK(c, hipMemcpyAsync(c->first_tile.p, c->h_region_first_tile.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, c->errflag.reserve(4));
+  HIPCHK(c, c->read_rend.reserve(std::max<size_t>(nr, 1) * 4));
+  b.read_rend = c->read_rend.as<int32_t>();
   HIPCHK(c, c->read_region.reserve(std::max(nr, 1) * 4));
   b.read_region = c->read_region.as<int32_t>();
   launch_k0_read_region(b, c->read_region.as<int32_t>(), c->stream);
@@ -398,7 +400,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
       launch_k2_compact(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
                         c->planes.as<uint32_t>(), c->flags.as<uint8_t>(), c->tile_off.as<int32_t>(),
                         c->survivors.as<Survivor>(), c->stream);
-      launch_k2_hist(c->bv, c->dp, c->survivors.as<Survivor>(), c->sv_region_off.as<int32_t>(), c->hist.as<uint32_t>(),
+      launch_k2_hist(c->bv, c->dp, c->read_bin.as<ReadBin>(), c->survivors.as<Survivor>(), c->sv_region_off.as<int32_t>(), c->hist.as<uint32_t>(),
                      c->stream); }
     { Timer t(c, LCR_K_CAND_GT);
       launch_k2_gt(c->dp, c->survivors.as<Survivor>(), n_sv, c->hist.as<uint32_t>(), c->bv.start0,
@@ -460,7 +462,7 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->row_links.reserve(std::max(nrow, 1) * 4));
   HIPCHK(c, c->row_ptr.reserve((std::max(nrow, 1) + 1) * 8));
   { Timer t(c, LCR_K_FRAG_COUNT);
-    launch_k3_count(c->bv, c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nrow,
+    launch_k3_count(c->bv, c->read_bin.as<ReadBin>(), c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nrow,
                     c->row_cnt.as<int32_t>(), c->row_links.as<uint32_t>(), c->stream);
     launch_scan_i32_to_i64(c->scan_tmp, c->row_cnt.as<int32_t>(), c->row_ptr.as<int64_t>(), nrow, c->stream); }
   int64_t nnz = 0;
@@ -471,7 +473,7 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->col.reserve(std::max<int64_t>(nnz, 1) * 4));
   HIPCHK(c, c->val.reserve(std::max<int64_t>(nnz, 1)));
   { Timer t(c, LCR_K_FRAG_FILL);
-    launch_k3_fill(c->bv, c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nrow,
+    launch_k3_fill(c->bv, c->read_bin.as<ReadBin>(), c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nrow,
                    c->row_ptr.as<int64_t>(), c->col.as<int32_t>(), c->val.as<uint8_t>(), c->stream); }
   HIPCHK(c, hipGetLastError());
   c->have_frag = true;

@@ -1,6 +1,7 @@
 // lcr_dev.h — shared host/device declarations of liblcr (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <climits>
 #include <stdint.h>
 
 #include <string>
@@ -36,6 +37,7 @@ struct BatchView {
   const int32_t* region_first_tile;  // n_regions+1: first pileup tile of each region
   const int32_t* read_region;        // n_reads: region index of each read
   int32_t* error_flag;               // != 0 -> unknown CIGAR op seen
+  int32_t* read_rend;                // n_reads: region-relative column one past the read's last reference base (K0 pass 0)
 };
 
 // Per-read header packed once per batch (k0_pack) so that K0 needs a single 64-byte load per read.
@@ -140,14 +142,14 @@ void launch_k2_compact(const BatchView& b, const DevParams& p, const int32_t* ti
                        int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const uint8_t* flags,
                        const int32_t* tile_off, Survivor* out, hipStream_t s);
 float lcr_device_sor_threshold(hipStream_t s);
-void launch_k2_hist(const BatchView& b, const DevParams& p, const Survivor* sv, const int32_t* sv_region_off,
+void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin, const Survivor* sv, const int32_t* sv_region_off,
                     uint32_t* hist /* n_sv * 4 * 31 */, hipStream_t s);
 void launch_k2_gt(const DevParams& p, const Survivor* sv, int32_t n_sv, const uint32_t* hist, const int64_t* start0,
                   lcr_candidate* out, uint8_t* keep, hipStream_t s);
-void launch_k3_count(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off,
+void launch_k3_count(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
                      const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, uint32_t* row_links,
                      hipStream_t s);
-void launch_k3_fill(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off,
+void launch_k3_fill(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
                     const int32_t* row_region_off, int32_t n_rows, const int64_t* row_ptr, int32_t* col, uint8_t* val,
                     hipStream_t s);
 void launch_k3_rows(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off, int32_t* region_rows,
@@ -201,6 +203,106 @@ __device__ __forceinline__ bool polya_masked(const uint8_t* __restrict__ seq, in
     }
   }
   return masked;
+}
+
+
+// wave64 inclusive add-scan with DPP row shifts / row broadcasts (6 VALU ops, no LDS round trips).
+// update_dpp(old = 0, ..., bound_ctrl = false): lanes without a source keep 0, the identity.
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+// inclusive add-scan inside each 16-lane DPP row (four reads share a wave in the site walkers)
+__device__ __forceinline__ int row16_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  return v;
+}
+
+// Sixteen lanes (one DPP row) locate, for one read, the bases that face a sorted list of sites
+// (region-relative columns site_col(i), i in [s_lo, s_hi), ascending).  This is the cursor walk of
+// util.rs:700-944 / fragment.rs:60-240 turned inside out so that no load depends on a previous site:
+//   1. the sites inside the read's reference span [max(rel_pos,0), rend) are found with one probe of
+//      sixteen site columns per step (lanes <-> sites);
+//   2. the CIGAR is read 64 ops at a time (four words per lane, one round trip), reference / read start
+//      offsets of the ops come from two row scans per 16 ops (lanes <-> ops), and every covered site
+//      records the read offset of its base in "its" lane (site j of the batch -> lane j);
+//   3. sink(i, c, hit) is then called ONCE per batch of <= 16 sites with all sixteen lanes active:
+//      lane j gets site i = first + j and c = read offset of the base an M/=/X op puts on that site
+//      (hit = false: no such base).  The sink does its loads / atomics for up to 16 sites in parallel
+//      and may use row ballots to keep the sites' order.
+// A read that covers no site returns before touching its CIGAR.  Four reads share a wave64.
+// `live` = this row has a read; rows without one pass live = false (their lanes still call).
+template <class ColFn, class Sink>
+__device__ __forceinline__ void row16_walk_sites(const BatchView& b, bool live, const ReadBin& h, int rend, int s_lo, int s_hi,
+                                                 ColFn site_col, Sink sink) {
+  const int lane = threadIdx.x & 63, l16 = lane & 15, rbase = lane & 48;
+  // ---- 1. first site with column >= key, first site with column >= rend
+  int cur = s_hi, s_end = s_hi;
+  if (live) {
+    const int key = h.rel_pos > 0 ? h.rel_pos : 0;
+    bool found_cur = false;
+    for (int base = s_lo; base < s_hi; base += 16) {
+      const int i = base + l16;
+      const int colv = i < s_hi ? site_col(i) : INT_MAX;
+      const unsigned int ge_key = (unsigned int)(__ballot(colv >= key) >> rbase) & 0xffffu;
+      const unsigned int ge_end = (unsigned int)(__ballot(colv >= rend) >> rbase) & 0xffffu;
+      if (!found_cur && ge_key) { cur = base + __ffs((int)ge_key) - 1; found_cur = true; }
+      if (ge_end) { s_end = base + __ffs((int)ge_end) - 1; break; }
+    }
+    if (!found_cur) cur = s_end;
+  }
+  if (cur >= s_end) return;   // (row-uniform)
+  const uint32_t ncig = (uint32_t)h.n_cig;
+  const uint32_t* __restrict__ cg = b.cigar + h.cig_off;
+  for (int first = cur; first < s_end; first += 16) {   // batches of 16 covered sites (one batch almost always)
+    const int n = min(16, s_end - first);
+    const int my_cc = l16 < n ? site_col(first + l16) : INT_MAX;
+    const int last_cc = __shfl(my_cc, rbase + n - 1, 64);
+    int myc = -1;
+    int ref_cur = h.rel_pos;
+    int q_cur = h.lead > 0 ? h.lead : 0;
+    int j = 0;                                           // next site of the batch (row-uniform)
+    int cc = __shfl(my_cc, rbase, 64);
+    for (uint32_t c0 = 0; c0 < ncig && j < n; c0 += 64) {
+      uint32_t w4[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) w4[k] = c0 + 16 * k + l16 < ncig ? cg[c0 + 16 * k + l16] : 0u;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t w = w4[k];
+        const int op = w & 15, len = (int)(w >> 4);
+        const bool is_m = op == 0 || op == 7 || op == 8;     // (a padding word is a 0-length M: covers nothing)
+        const int dr = (is_m || op == 2 || op == 3) ? len : 0;
+        const int dq = (is_m || op == 1) ? len : 0;
+        const int ir = row16_incl_scan(dr), iq = row16_incl_scan(dq);
+        const int rs = ref_cur + ir - dr, qs = q_cur + iq - dq;
+        const int chunk_end = ref_cur + __shfl(ir, rbase + 15, 64);
+        while (j < n && cc < chunk_end) {
+          const unsigned int m = (unsigned int)(__ballot(is_m && cc >= rs && cc < rs + len) >> rbase) & 0xffffu;
+          if (m) {
+            const int L = rbase + __ffs((int)m) - 1;
+            const int c = __shfl(qs, L, 64) + (cc - __shfl(rs, L, 64));
+            if (l16 == j) myc = c;
+          }
+          j++;
+          cc = __shfl(my_cc, rbase + (j < n ? j : 0), 64);
+        }
+        ref_cur = chunk_end;
+        q_cur += __shfl(iq, rbase + 15, 64);
+      }
+      if (ref_cur > last_cc) break;
+    }
+    sink(first + l16, myc, myc >= 0);
+  }
 }
 
 // region index of read r: precomputed by k0_read_region (a binary search over read_begin would cost
