@@ -1055,7 +1055,21 @@ struct RegionHost {
   }
 };
 
+struct RegionBuild {  // chain regions only: host copy of the phase matrix rows for the block-flip objective
+  std::vector<int32_t> prow_ptr, pcol;
+  std::vector<uint8_t> pval;
+};
+struct PhaseWork {
+  std::vector<RegionHost> R;
+  std::vector<std::vector<std::vector<int>>> ld_blocks;
+  std::vector<RegionBuild> RB;
+  std::vector<int8_t> h_delta0;
+  std::vector<uint8_t> h_cons;
+};
+
 }  // namespace
+
+void PhaseHost::free_work() { delete static_cast<PhaseWork*>(work); work = nullptr; }
 
 int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t stream, std::string* err) {
 #define PCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e_); return LCR_E_DEVICE; } } while (0)
@@ -1228,15 +1242,16 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   struct Arr32 { int32_t* p; int32_t& operator[](size_t i) const { return p[i]; } int32_t* data() const { return p; } } col{col_p};
   struct Arr8 { uint8_t* p; uint8_t& operator[](size_t i) const { return p[i]; } uint8_t* data() const { return p; } } val{val_p};
   struct ArrU { uint32_t* p; uint32_t& operator[](size_t i) const { return p[i]; } uint32_t* data() const { return p; } } links{links_p};
-  std::vector<RegionHost> R(ng);
-  std::vector<std::vector<std::vector<int>>> ld_blocks(ng);
-  struct RegionBuild {  // chain regions only: host copy of the phase matrix rows for the block-flip objective
-    std::vector<int32_t> prow_ptr, pcol;
-    std::vector<uint8_t> pval;
-  };
-  std::vector<RegionBuild> RB(ng);
-  std::vector<int8_t> h_delta0(nc1, 1);
-  std::vector<uint8_t> h_cons(nc1, 0);
+  // per-region host state lives across calls (PhaseWork): a batch has hundreds of regions with a dozen
+  // vectors each, and re-allocating / freeing them every call cost more than the work done with them
+  if (!work) work = new PhaseWork();
+  PhaseWork& W = *static_cast<PhaseWork*>(work);
+  if ((int)W.R.size() < ng) { W.R.resize(ng); W.ld_blocks.resize(ng); W.RB.resize(ng); }
+  std::vector<RegionHost>& R = W.R;
+  std::vector<std::vector<std::vector<int>>>& ld_blocks = W.ld_blocks;
+  std::vector<RegionBuild>& RB = W.RB;
+  std::vector<int8_t>& h_delta0 = W.h_delta0; h_delta0.assign(nc1, 1);
+  std::vector<uint8_t>& h_cons = W.h_cons; h_cons.assign(nc1, 0);
   auto prep = [&](int g) {
     RegionHost& rh = R[g];
     RegionBuild& rb = RB[g];
@@ -1252,7 +1267,10 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     const int64_t e1 = row_ptr[rh.r0 + rh.nrow];
     rh.phase_site.assign((size_t)(e1 - rh.e0), 0);
     rh.tag.assign(rh.nrow, 0); rh.asg.assign(rh.nrow, 0); rh.fp.assign(rh.nrow, 0);
-    rh.cover.assign(rh.S, {});
+    if ((int)rh.cover.size() < rh.S) rh.cover.resize(rh.S);
+    for (int i = 0; i < rh.S; i++) rh.cover[i].clear();
+    rh.fp_rows.clear();
+    rb.prow_ptr.clear(); rb.pcol.clear(); rb.pval.clear();
     rh.orig_flags.resize(rh.S);
     for (int i = 0; i < rh.S; i++) rh.orig_flags[i] = rh.cand[i].flags;
     if (chain) rb.prow_ptr.push_back(0);
@@ -1342,7 +1360,10 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     }
   };
   if (!pool) {
-    int nthreads = (int)std::thread::hardware_concurrency();
+    // one ctx per GPU: share the host's hardware threads between the GPUs of the node
+    int ndev = 1;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
+    int nthreads = (int)std::thread::hardware_concurrency() / ndev;
     if (const char* e = getenv("LCR_HOST_THREADS")) nthreads = atoi(e);
     nthreads = std::max(1, std::min(nthreads, 48));
     pool = new HostPool(nthreads > 1 ? nthreads : 0);
@@ -1469,6 +1490,12 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     rh.assign_phase_set(prm.min_phase_score, phase_set.data());
     for (int r = 0; r < rh.nrow; r++) { haplotag[rh.r0 + r] = rh.tag[r]; assignment[rh.r0 + r] = rh.asg[r]; }
   };
+  if (prof) {   // per-region cost of the epilogue (serial sum / max), to tell work from pool overhead
+    std::vector<double> tr(ng, 0.0);
+    for_regions([&](int g) { auto t0 = std::chrono::steady_clock::now(); epilogue(g); tr[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); });
+    double sum = 0, mx = 0; for (double v : tr) { sum += v; mx = std::max(mx, v); }
+    fprintf(stderr, "[phase] epilogue per-region: sum %.3f ms, max %.3f ms over %d regions, %d threads\n", sum, mx, ng, pool->size());
+  } else
   for_regions(epilogue);
   lap("scatter + post-phase epilogue");
   return LCR_OK;

@@ -82,6 +82,8 @@ struct PhaseHost {
   hipStream_t side = nullptr;   // second queue: fragment matrix download + chain regions
   hipEvent_t ev_in = nullptr, ev_csr = nullptr;
   HostPool* pool = nullptr;
+  void* work = nullptr;   // PhaseWork (k4_phase.hip): per-region host state reused across calls
+  void free_work();
   int run(const PhaseInputs& in, const lcr_params& p, hipStream_t s, std::string* err);
   void release() {
     for (auto& b : d_state) b.release();
@@ -90,5 +92,6 @@ struct PhaseHost {
     if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
     if (ev_csr) { (void)hipEventDestroy(ev_csr); ev_csr = nullptr; }
     delete pool; pool = nullptr;
+    free_work();
   }
 };
