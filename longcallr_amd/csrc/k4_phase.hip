@@ -497,7 +497,7 @@ struct StageIn {
   const lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off; const int64_t* start0;
   uint32_t min_linkers, max_enum_snps; uint64_t seed;
 };
-struct StageStat { int32_t R, E, max_n, max_rows; };   // max_*: per-lane share of k4_enum_reg's row partition
+struct StageStat { int32_t R, E, max_n, max_rows, E_all, pad_; };   // max_*: per-lane share of k4_enum_reg's row partition; E_all: all entries
 struct StageOut {
   RegionDev* reg; StageStat* stat;
   int32_t* prow_ptr; int32_t* pcol; uint8_t* pval; int32_t* ccol_ptr; int32_t* crow; uint8_t* cval;
@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_stage(StageIn in, StageOut out, 
   rd.S = S; rd.rp_off = r0 + g; rd.cp_off = c0 + g; rd.e_off = e_base; rd.sig_off = r0; rd.snp_off = c0;
   rd.seed = region_seed(in.seed, in.start0[g]);
   if (S == 0) {
-    if (tid == 0) { out.reg[g] = rd; out.stat[g] = StageStat{0, 0, 0, 0}; out.prow_ptr[rd.rp_off] = 0; out.ccol_ptr[rd.cp_off] = 0; }
+    if (tid == 0) { out.reg[g] = rd; out.stat[g] = StageStat{0, 0, 0, 0, 0, 0}; out.prow_ptr[rd.rp_off] = 0; out.ccol_ptr[rd.cp_off] = 0; }
     return;
   }
   if (tid < 32) { s_fe[tid] = tid < 31 ? lut.fe[tid] : 0; s_f1e[tid] = tid < 31 ? lut.f1e[tid] : 0; }
@@ -642,7 +642,7 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_stage(StageIn in, StageOut out, 
   if (tid == 0) {
     rd.R = R; rd.f_total = s_ft[0] + s_ft[1] + s_ft[2] + s_ft[3];
     out.reg[g] = rd;
-    out.stat[g] = StageStat{R, E, max(s_max[0], (int)enum_chunk((uint32_t)E)), s_max[1]};
+    out.stat[g] = StageStat{R, E, max(s_max[0], (int)enum_chunk((uint32_t)E)), s_max[1], (int)(in.row_ptr[r0 + nrow] - e_base), 0};
   }
 }
 
@@ -759,6 +759,386 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_chain_b(PhaseDev P, const int32_
     load_best();
   }
   if (threadIdx.x == 0) P.st_obj[slot] = best;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k4_post: the post-phase sequence of thread.rs:168-201 on the device, one workgroup per region:
+//   assign_reads_haplotype + assign_het_var_haplotype (x2), eval_rna_edit_var_phase,
+//   eval_low_frac_var_phase, assign_reads_haplotype + assign_het_var_haplotype, assign_phase_set
+//   (snpfrags.rs:191-733).
+// These are f64 sum-of-ratio decisions: every log10(eps) / log10(1-eps) term comes from the table of
+// libm values the host path uses (kernel argument), sums run in the reference's observation order (a
+// read's entries in column order, a SNP's reads in row order) and -ffp-contract=off keeps a*b+c
+// unfused, so the decisions are the host path's bit for bit; only phase_score's final log10 is the
+// device libm.  The region's fragment rows are staged in LDS with a row-ordered column index (stable
+// counting sort by one wave); a batch with a region too large for that takes the host epilogue.
+// ---------------------------------------------------------------------------------------------
+struct PostLut { double le[31], l1e[31]; double p_homref, p_homvar, log_theta, log2; };
+struct PostIn {
+  const int64_t* row_ptr; const int32_t* col; const uint8_t* val; const uint32_t* links;
+  lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off; const int64_t* start0;
+  const int8_t* st_sigma; const int8_t* st_delta; const int8_t* st_eta;
+  int8_t* haplotag; uint8_t* assignment; uint32_t* phase_set;
+  uint32_t min_linkers, max_enum_snps; uint64_t seed; double cutoff; float min_phase_score;
+};
+constexpr int POST_MAX_ROWS = 8192, POST_MAX_ENTRIES = 8192, POST_MAX_SNPS = 512;
+struct PostLayout { uint32_t sps, rpa, rpb, sflags, soflags, parent, rptr, ecol, erow, cent, ccptr, eval, tag, asg, fp, lok, shap, sgt, svt, rcode, total; };
+__host__ __device__ inline PostLayout post_layout(uint32_t nrow, uint32_t E, uint32_t S) {
+  PostLayout L;
+  uint32_t o = 64 * 8;                       // le[32] | l1e[32]
+  L.sps = o; o += 8 * S;                     // phase_score
+  L.rpa = o; o += 8 * S; L.rpb = o; o += 8 * S;   // rescue: the two candidate phase scores
+  L.sflags = o; o += 4 * S; L.soflags = o; o += 4 * S; L.parent = o; o += 4 * S;
+  L.rptr = o; o += 2 * (nrow + 2);
+  L.ecol = o; o += 2 * E; L.erow = o; o += 2 * E; L.cent = o; o += 2 * E;
+  L.ccptr = o; o += 2 * (S + 2);
+  L.eval = o; o += E;
+  L.tag = o; o += nrow; L.asg = o; o += nrow; L.fp = o; o += nrow; L.lok = o; o += nrow;
+  L.shap = o; o += S; L.sgt = o; o += S; L.svt = o; o += S; L.rcode = o; o += S;
+  L.total = (o + 15) & ~15u;
+  return L;
+}
+
+__global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* __restrict__ slots, int32_t n_slots, PostLut lut) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  __shared__ int sm[2][8];
+  __shared__ int s_flag;
+  __shared__ double stage[LCR_BLOCK / 64][4][64];
+  if ((int)blockIdx.x >= n_slots) return;
+  const int g = slots[blockIdx.x], tid = threadIdx.x, lane = tid & 63;
+  const int r0 = in.row_region_off[g], nrow = in.row_region_off[g + 1] - r0;
+  const int c0 = in.cand_off[g], S = in.cand_off[g + 1] - c0;
+  if (S == 0) return;
+  const int64_t e_base = in.row_ptr[r0];
+  const int E = (int)(in.row_ptr[r0 + nrow] - e_base);
+  const PostLayout L = post_layout(nrow, E, S);
+  double* le = (double*)lds; double* l1e = le + 32;
+  double* sps = (double*)(lds + L.sps); double* rpa = (double*)(lds + L.rpa); double* rpb = (double*)(lds + L.rpb);
+  uint32_t* sflags = (uint32_t*)(lds + L.sflags); uint32_t* soflags = (uint32_t*)(lds + L.soflags);
+  int32_t* parent = (int32_t*)(lds + L.parent);
+  uint16_t* rptr = (uint16_t*)(lds + L.rptr); uint16_t* ecol = (uint16_t*)(lds + L.ecol);
+  uint16_t* erow = (uint16_t*)(lds + L.erow); uint16_t* cent = (uint16_t*)(lds + L.cent);
+  uint16_t* ccptr = (uint16_t*)(lds + L.ccptr);
+  uint8_t* ev = lds + L.eval;
+  int8_t* tag = (int8_t*)(lds + L.tag); uint8_t* asg = lds + L.asg; uint8_t* fp = lds + L.fp; uint8_t* lok = lds + L.lok;
+  int8_t* shap = (int8_t*)(lds + L.shap); int8_t* sgt = (int8_t*)(lds + L.sgt); int8_t* svt = (int8_t*)(lds + L.svt);
+  uint8_t* rcode = lds + L.rcode;
+  lcr_candidate* cand = in.cand + c0;
+
+  // ---- stage: LUT, SNP state, rows (phasing-row index by scan), entries, row-ordered column index
+  if (tid < 31) { le[tid] = lut.le[tid]; l1e[tid] = lut.l1e[tid]; }
+  for (int i = tid; i < S; i += LCR_BLOCK) {
+    sflags[i] = soflags[i] = cand[i].flags;
+    shap[i] = in.st_delta[c0 + i]; sgt[i] = in.st_eta[c0 + i]; svt[i] = (int8_t)cand[i].variant_type;
+    sps[i] = cand[i].phase_score;
+    parent[i] = 0;   // column counts, then fill cursors
+  }
+  int F = 0;
+  for (int base = 0; base < nrow; base += LCR_BLOCK) {
+    const int r = base + tid;
+    const int isp = (r < nrow && in.links[r0 + r] >= in.min_linkers) ? 1 : 0;
+    int k, d0, tk, d1;
+    block_scan2(isp, 0, k, d0, tk, d1, sm);
+    if (r < nrow) {
+      rptr[r] = (uint16_t)(in.row_ptr[r0 + r] - e_base);
+      lok[r] = (uint8_t)isp; fp[r] = (uint8_t)isp; asg[r] = 0;
+      tag[r] = isp ? in.st_sigma[r0 + F + k] : (int8_t)0;
+    }
+    F += tk;
+  }
+  if (tid == 0) rptr[nrow] = (uint16_t)E;
+  __syncthreads();
+  for (int r = tid; r < nrow; r += LCR_BLOCK)
+    for (int e = rptr[r]; e < rptr[r + 1]; e++) {
+      const int ci = in.col[e_base + e] - c0;
+      ecol[e] = (uint16_t)ci; erow[e] = (uint16_t)r; ev[e] = in.val[e_base + e];
+      atomicAdd(&parent[ci], 1);
+    }
+  __syncthreads();
+  {
+    int carry = 0;
+    for (int base = 0; base < S; base += LCR_BLOCK) {
+      const int i = base + tid;
+      const int v = i < S ? parent[i] : 0;
+      int ex, d0, tot, d1;
+      block_scan2(v, 0, ex, d0, tot, d1, sm);
+      if (i < S) { ccptr[i] = (uint16_t)(carry + ex); parent[i] = carry + ex; }
+      carry += tot;
+    }
+    if (tid == 0) ccptr[S] = (uint16_t)carry;
+  }
+  __syncthreads();
+  if (tid < 64) {   // stable fill: entries in (row, column) order, 64 at a time; equal columns keep their order
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = 0; base < E; base += 64) {
+      const int e = base + lane;
+      const bool valid = e < E;
+      const int c = valid ? (int)ecol[e] : -1;
+      unsigned long long rem = __ballot(valid);
+      while (rem) {
+        const int cc = __shfl(c, __ffsll((long long)rem) - 1, 64);
+        const unsigned long long m = __ballot(c == cc);
+        const int at = parent[cc];
+        if (c == cc) cent[at + __popcll(m & below)] = (uint16_t)e;
+        wave_lds_sync();
+        if (lane == 0) parent[cc] = at + __popcll(m);
+        rem &= ~m;
+      }
+      wave_lds_sync();
+    }
+  }
+  __syncthreads();
+
+  auto lg = [&](int sigma, int delta, int eta, uint8_t v) -> double {   // log10(aki(...)), phase.rs:32-49
+    const int pp = (v & 32) ? 1 : -1, x = eta == 0 ? sigma * delta : eta;
+    return pp == x ? l1e[v & 31] : le[v & 31];
+  };
+  // Ordered sums over the observations of SNP column ti, one wave per column: 64 column entries at a time
+  // are loaded and filtered by the lanes (lane <-> entry), each lane stages its NACC terms (or +0.0, the
+  // exact identity here: the sums start at +0.0 and every term is a finite log) in LDS, and all lanes then
+  // add the 64 staged terms in entry order (broadcast reads; the result is wave-uniform).  The additions are
+  // the host's, in the host's order; only the loads and the filter run in parallel.
+  const int wave = tid >> 6;
+  double* stg = &stage[wave][0][0];
+  auto col_sums = [&](int ti, bool skip_unassigned, auto term, double* acc, int nacc, int& hap1, int& hap2, int& nobs) {
+    hap1 = hap2 = nobs = 0;
+    for (int a = 0; a < nacc; a++) acc[a] = 0.0;
+    const int kb = ccptr[ti], ke = ccptr[ti + 1];
+    for (int k0 = kb; k0 < ke; k0 += 64) {
+      const int k = k0 + lane;
+      bool keep = false; int r = 0, e = 0;
+      if (k < ke) { e = cent[k]; r = erow[e]; keep = fp[r] && lok[r] && !(skip_unassigned && asg[r] == 0); }
+      double t[4] = {0.0, 0.0, 0.0, 0.0};
+      if (keep) term((int)tag[r], ev[e], t);
+      for (int a = 0; a < nacc; a++) stg[a * 64 + lane] = t[a];
+      const unsigned long long km = __ballot(keep);
+      hap1 += __popcll(__ballot(keep && asg[r] == 1)); hap2 += __popcll(__ballot(keep && asg[r] == 2));
+      nobs += __popcll(km);
+      wave_lds_sync();
+      const int nk = min(64, ke - k0);
+      for (int j = 0; j < nk; j++)
+        for (int a = 0; a < nacc; a++) acc[a] += stg[a * 64 + j];
+      wave_lds_sync();
+    }
+  };
+  // phase.rs:238-255 over the kept observations of column ti (wave-uniform result)
+  auto psl = [&](int ti, int delta_i, int eta_i, bool skip_unassigned) -> double {
+    double q[3]; int h1, h2, nb;
+    col_sums(ti, skip_unassigned, [&](int sg, uint8_t v, double* t) {
+      t[0] = lg(sg, delta_i, eta_i, v); t[1] = lg(sg, 1, eta_i, v); t[2] = lg(sg, -1, eta_i, v);
+    }, q, 3, h1, h2, nb);
+    return 1.0 - q[0] / (q[1] + q[2]);
+  };
+  // snpfrags.rs:548-625
+  auto reads_hap = [&]() {
+    for (int r = tid; r < nrow; r += LCR_BLOCK) {
+      if (!fp[r]) continue;
+      const int sigma_k = tag[r];
+      double q1 = 0, q2 = 0, q3 = 0, n1 = 0;
+      int n = 0;
+      for (int e = rptr[r]; e < rptr[r + 1]; e++) {
+        const int i = ecol[e];
+        if (!(sflags[i] & LCR_F_FOR_PHASING) || shap[i] == 0 || sgt[i] != 0) continue;
+        q1 += lg(sigma_k, shap[i], 0, ev[e]);
+        n1 += lg(-sigma_k, shap[i], 0, ev[e]);
+        n++;
+      }
+      if (sigma_k == 0 || n == 0) { asg[r] = 0; tag[r] = 0; continue; }
+      for (int e = rptr[r]; e < rptr[r + 1]; e++) {
+        const int i = ecol[e];
+        if (!(sflags[i] & LCR_F_FOR_PHASING) || shap[i] == 0 || sgt[i] != 0) continue;
+        q2 += lg(1, shap[i], 0, ev[e]); q3 += lg(-1, shap[i], 0, ev[e]);
+      }
+      const double q = 1.0 - q1 / (q2 + q3), qn = 1.0 - n1 / (q2 + q3);
+      if (fabs(q - qn) >= in.cutoff) {
+        if (q >= qn) asg[r] = sigma_k == 1 ? 1 : 2;
+        else if (sigma_k == 1) { asg[r] = 2; tag[r] = -1; }
+        else { asg[r] = 1; tag[r] = 1; }
+      } else { asg[r] = 0; tag[r] = 0; }
+    }
+    __syncthreads();
+  };
+  // snpfrags.rs:378-546, one wave per SNP (all lanes hold the same values; lane 0 writes)
+  auto snp_hap = [&]() {
+    for (int ti = wave; ti < S; ti += LCR_BLOCK / 64) {
+      if (!(sflags[ti] & LCR_F_FOR_PHASING)) { if (lane == 0) sflags[ti] |= LCR_F_NON_SELECTED; continue; }
+      if (ccptr[ti] == ccptr[ti + 1]) { if (lane == 0) sflags[ti] |= LCR_F_SINGLE; continue; }
+      const int delta_i = shap[ti];
+      const bool het_skip = svt[ti] == 1;
+      int hap1, hap2, nobs;
+      double sum[4];   // het_d, het_nd, homref, homvar
+      col_sums(ti, het_skip, [&](int sg, uint8_t v, double* t) {
+        t[0] = lg(sg, delta_i, 0, v); t[1] = lg(sg, -delta_i, 0, v); t[2] = lg(sg, delta_i, 1, v); t[3] = lg(sg, delta_i, -1, v);
+      }, sum, 4, hap1, hap2, nobs);
+      if (nobs == 0) { if (lane == 0) sflags[ti] |= LCR_F_NON_SELECTED; continue; }
+      const double het_d = sum[0], het_nd = sum[1], homref = sum[2], homvar = sum[3];
+      const double p_het = lut.log_theta - (double)(uint32_t)nobs * lut.log2;
+      auto score = [&](int sign, int eta_i) -> double {   // cal_delta_eta_sigma_log, phase.rs:128-176
+        const double hd = sign > 0 ? het_d : het_nd, hn = sign > 0 ? het_nd : het_d;
+        double q1 = eta_i == 0 ? hd : (eta_i == 1 ? homref : homvar);
+        q1 += eta_i == 0 ? p_het : (eta_i == 1 ? lut.p_homref : lut.p_homvar);
+        const double q2 = homvar + lut.p_homvar, q3 = hd + p_het, q4 = homref + lut.p_homref, q5 = hn + p_het;
+        return 1.0 - q1 / (q2 + q3 + q4 + q5);
+      };
+      const double q1 = score(1, 0), q2 = score(-1, 0), q3 = score(1, 1), q4 = score(1, -1);
+      const double mx = fmax(q1, fmax(q2, fmax(q3, q4)));
+      int nh = delta_i, ng_ = 0, nv = svt[ti];
+      if (q1 == mx) { nh = delta_i; ng_ = 0; nv = 1; }
+      else if (q2 == mx) { nh = -delta_i; ng_ = 0; nv = 1; }
+      else if (q3 == mx) { nh = delta_i; ng_ = 1; nv = 0; }
+      else if (q4 == mx) { nh = delta_i; ng_ = -1; if (nv != 2 && nv != 3) nv = 2; }
+      else continue;  // NaN scores: the reference panics here
+      double ps = sps[ti];
+      uint32_t fl = sflags[ti];
+      if (ng_ != 0) fl |= LCR_F_NON_SELECTED;
+      else if (hap1 >= 1 && hap2 >= 1) ps = -10.0 * log10(1.0 - psl(ti, nh, ng_, het_skip));
+      else ps = 0.19940219;
+      if (lane == 0) { shap[ti] = (int8_t)nh; sgt[ti] = (int8_t)ng_; svt[ti] = (int8_t)nv; sflags[ti] = fl; sps[ti] = ps; }
+    }
+    __syncthreads();
+  };
+  // snpfrags.rs:191-376.  The list is walked in index order and a successful rescue changes fp / tag of
+  // its reads (and draws random numbers), which later list members see: all pending members are
+  // evaluated in parallel (a wave each) against the current state, thread 0 commits them in order up to
+  // and including the first success, and the members after it are evaluated again.
+  unsigned long long ctr = 0;   // thread 0: draws so far (thread.rs call order, see PhaseHost::run)
+  {
+    const unsigned long long Su = (unsigned long long)S, Fu = (unsigned long long)F;
+    ctr = (uint32_t)S <= in.max_enum_snps ? Su + Fu + (1ull << S) * Fu : 2 * (Su + Fu) + (Su / 4 + 1) * (Su + Fu);
+  }
+  auto rescue = [&](uint32_t list_flag, float min_ps, bool low_frac, uint64_t rseed) {
+    int start = 0;
+    for (;;) {
+      for (int ti = start + wave; ti < S; ti += LCR_BLOCK / 64) {
+        uint8_t code = 0;
+        if (soflags[ti] & list_flag) {
+          if (ccptr[ti] == ccptr[ti + 1]) code = 1;
+          else if (svt[ti] != 1) code = 2;
+          else {
+            double q[3]; int hap1, hap2, nobs;   // gather(need_assigned) + phase_score_log(+1, 0)
+            col_sums(ti, true, [&](int sg, uint8_t v, double* t) { t[0] = lg(sg, 1, 0, v); t[1] = lg(sg, 1, 0, v); t[2] = lg(sg, -1, 0, v); },
+                     q, 3, hap1, hap2, nobs);
+            if (nobs == 0 || hap1 < 2 || hap2 < 2) code = 3;
+            else {
+              const double pa = -10.0 * log10(1.0 - (1.0 - q[0] / (q[1] + q[2])));
+              const double pb = -10.0 * log10(1.0 - psl(ti, -1, 0, true));
+              if (lane == 0) { rpa[ti] = pa; rpb[ti] = pb; }
+              code = fmax(pa, pb) >= (double)min_ps ? 4 : 5;
+            }
+          }
+        }
+        if (lane == 0) rcode[ti] = code;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int ti = start;
+        for (; ti < S; ti++) {
+          const uint8_t code = rcode[ti];
+          if (code == 0) continue;
+          if (code == 1 || code == 3) { sflags[ti] |= LCR_F_SINGLE; continue; }
+          if (code == 2) { sflags[ti] |= LCR_F_NON_SELECTED; continue; }
+          sflags[ti] &= ~(uint32_t)LCR_F_SINGLE;
+          if (code == 5) {
+            sflags[ti] |= LCR_F_NON_SELECTED;
+            if (low_frac) { sflags[ti] |= LCR_F_CAND_SOMATIC; sflags[ti] &= ~(uint32_t)LCR_F_FOR_PHASING; }
+            else sflags[ti] |= LCR_F_RNA_EDIT;
+            continue;
+          }
+          sflags[ti] &= ~(uint32_t)(LCR_F_NON_SELECTED | LCR_F_RNA_EDIT);
+          if (low_frac) sflags[ti] &= ~(uint32_t)LCR_F_CAND_SOMATIC;
+          sflags[ti] |= LCR_F_FOR_PHASING;
+          for (int k = ccptr[ti]; k < ccptr[ti + 1]; k++) {
+            const int r = erow[cent[k]];
+            fp[r] = 1;
+            if (tag[r] == 0 || asg[r] == 0) tag[r] = u01(rseed, ctr++) < 0.5 ? -1 : 1;
+          }
+          shap[ti] = rpa[ti] >= rpb[ti] ? 1 : -1;
+          sgt[ti] = 0; svt[ti] = 1; sps[ti] = fmax(rpa[ti], rpb[ti]);
+          ti++;
+          break;
+        }
+        s_flag = ti;
+      }
+      __syncthreads();
+      start = s_flag;
+      __syncthreads();
+      if (start >= S) break;
+    }
+  };
+
+  // snpfrags.rs:628-733: connected components of the PASS het SNPs (edges = allele-consistent SNP pairs of
+  // a read); component label = smallest SNP index (see RegionHost::assign_phase_set), by min-label
+  // propagation over the reads + pointer jumping until no edge joins two labels
+  auto phase_set = [&]() {
+    for (int i = tid; i < S; i += LCR_BLOCK) {
+      const bool node = sgt[i] == 0 && svt[i] == 1 && !(sflags[i] & (LCR_F_DENSE | LCR_F_RNA_EDIT)) &&
+                        !(sps[i] < (double)in.min_phase_score);
+      parent[i] = node ? i : -1;
+    }
+    __syncthreads();
+    // pairs (x < y) among the first 64 PASS-het entries of a row whose alleles agree with the haplotypes
+    auto for_pairs = [&](int r, auto fn) -> int {
+      int nx = 0;
+      for (int e1 = rptr[r]; e1 < rptr[r + 1] && nx < 64; e1++) {
+        const int x = ecol[e1];
+        if (parent[x] < 0) continue;
+        int ny = nx + 1;
+        for (int e2 = e1 + 1; e2 < rptr[r + 1] && ny < 64; e2++) {
+          const int y = ecol[e2];
+          if (parent[y] < 0) continue;
+          if (shap[x] * shap[y] == (((ev[e1] ^ ev[e2]) & 32) ? -1 : 1)) fn(x, y);
+          ny++;
+        }
+        nx++;
+      }
+      return nx;
+    };
+    for (;;) {
+      if (tid == 0) s_flag = 0;
+      __syncthreads();
+      for (int r = tid; r < nrow; r += LCR_BLOCK) {
+        if (!fp[r] || asg[r] == 0) continue;
+        for_pairs(r, [&](int x, int y) {
+          const int lx = parent[x], ly = parent[y];
+          if (lx != ly) { const int m = min(lx, ly); atomicMin(&parent[x], m); atomicMin(&parent[y], m); s_flag = 1; }
+        });
+      }
+      __syncthreads();
+      for (int i = tid; i < S; i += LCR_BLOCK) if (parent[i] >= 0) { int l = parent[i]; while (parent[l] != l) l = parent[l]; atomicMin(&parent[i], l); }
+      __syncthreads();
+      if (!s_flag) break;
+      __syncthreads();
+    }
+    for (int i = tid; i < S; i += LCR_BLOCK) if (parent[i] >= 0) cand[i].phase_set = (uint32_t)(cand[parent[i]].pos + 1);
+    for (int r = tid; r < nrow; r += LCR_BLOCK) {
+      uint32_t ps = 0;
+      if (fp[r] && asg[r] != 0) {
+        int best = -1, first = -1;  // largest component root among the components that own an edge of this read
+        const int n = for_pairs(r, [&](int x, int y) { (void)y; best = max(best, parent[x]); });
+        if (n == 1) {               // self loop (snpfrags.rs:659-665)
+          for (int e = rptr[r]; e < rptr[r + 1]; e++) if (parent[ecol[e]] >= 0) { first = ecol[e]; break; }
+          best = parent[first];
+        }
+        if (best >= 0) ps = (uint32_t)(cand[best].pos + 1);
+      }
+      in.phase_set[r0 + r] = ps;
+    }
+    __syncthreads();
+  };
+
+  const uint64_t rseed = region_seed(in.seed, in.start0[g]);
+  reads_hap(); snp_hap();
+  reads_hap(); snp_hap();
+  const float relaxed = in.min_phase_score - 3.0f;
+  rescue(LCR_F_RNA_EDIT, relaxed, false, rseed);
+  rescue(LCR_F_CAND_SOMATIC, relaxed, true, rseed);
+  reads_hap(); snp_hap();
+  phase_set();
+  for (int i = tid; i < S; i += LCR_BLOCK) {
+    cand[i].haplotype = shap[i]; cand[i].genotype = sgt[i]; cand[i].variant_type = svt[i];
+    cand[i].flags = sflags[i]; cand[i].phase_score = sps[i];
+  }
+  for (int r = tid; r < nrow; r += LCR_BLOCK) { in.haplotag[r0 + r] = tag[r]; in.assignment[r0 + r] = asg[r]; }
 }
 
 // ================================= host side ====================================================
@@ -1083,7 +1463,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) { if (!prof) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[phase] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
   std::vector<lcr_candidate>& cand = *in.cand;
-  haplotag.assign(nrow, 0); assignment.assign(nrow, 0); phase_set.assign(nrow, 0); objective.assign(ng, 0.0);
+  objective.assign(ng, 0.0);
   if (!side) {
     PCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     PCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
@@ -1095,7 +1475,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   DevBuf &b_reg = d_state[0], &b_prp = d_state[1], &b_pc = d_state[2], &b_pv = d_state[3], &b_cp = d_state[4],
          &b_cr = d_state[5], &b_cv = d_state[6], &b_snp = d_state[7], &b_st = d_state[8], &b_scr = d_state[9],
          &b_job = d_state[10], &b_obj = d_state[11], &b_sc = d_state[12], &b_stat = d_state[13], &b_cur = d_state[14],
-         &b_stc = d_state[15], &b_slots = d_state[16];
+         &b_stc = d_state[15], &b_slots = d_state[16], &b_htag = d_state[17], &b_asg = d_state[18], &b_ps = d_state[19];
   const size_t nnz1 = (size_t)std::max<int64_t>(nnz, 1), nc1 = (size_t)std::max(ncand, 1), nr1 = (size_t)std::max(nrow, 1);
   PCHK(b_reg.reserve((size_t)std::max(ng, 1) * sizeof(RegionDev)));
   PCHK(b_stat.reserve((size_t)std::max(ng, 1) * sizeof(StageStat)));
@@ -1111,6 +1491,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   PCHK(h_pin[2].reserve(nnz1)); PCHK(h_pin[3].reserve(nr1 * 4));
   PCHK(h_pin[4].reserve(st_bytes + 16)); PCHK(h_pin[5].reserve((size_t)std::max(ng, 1) * sizeof(StageStat)));
   PCHK(h_pin[6].reserve(st_bytes + 16));
+  PCHK(b_htag.reserve(nr1)); PCHK(b_asg.reserve(nr1)); PCHK(b_ps.reserve(nr1 * 4));
+  PCHK(h_pin[7].reserve(nr1)); PCHK(h_pin[8].reserve(nr1)); PCHK(h_pin[9].reserve(nr1 * 4));
 
   PhaseDev P{};
   P.reg = b_reg.as<RegionDev>();
@@ -1157,12 +1539,30 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
   std::vector<int32_t> enum_slots, chain_slots;
   int32_t max_state = 0;
+  // post-phase epilogue on the device (k4_post) unless a region does not fit its LDS image
+  bool dev_post = getenv("LCR_POST_HOST") == nullptr;
+  uint32_t post_lds = 0;
   for (int g = 0; g < ng; g++) {
     const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
     if (S == 0) continue;
     if ((uint32_t)S <= prm.max_enum_snps) enum_slots.push_back(g); else chain_slots.push_back(g);
     max_state = std::max(max_state, stat[g].R + 2 * S);
+    const int nr_g = in.row_region_off[g + 1] - in.row_region_off[g];
+    const uint32_t need = post_layout(nr_g, stat[g].E_all, S).total;
+    if (nr_g > POST_MAX_ROWS || stat[g].E_all > POST_MAX_ENTRIES || S > POST_MAX_SNPS || need > 64 * 1024) dev_post = false;
+    post_lds = std::max(post_lds, need);
   }
+  PostLut plut;
+  for (int q = 0; q < 31; q++) { plut.le[q] = L.le[q]; plut.l1e[q] = L.l1e[q]; }
+  plut.p_homref = L.p_homref; plut.p_homvar = L.p_homvar; plut.log_theta = L.log_theta; plut.log2 = L.log2;
+  PostIn pin{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, const_cast<lcr_candidate*>(in.d_cand), in.d_cand_off,
+             in.d_row_region_off, in.d_start0, P.st_sigma, P.st_delta, P.st_eta, b_htag.as<int8_t>(), b_asg.as<uint8_t>(),
+             b_ps.as<uint32_t>(), prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score};
+  if (dev_post && nrow) {
+    PCHK(hipMemsetAsync(b_htag.p, 0, (size_t)nrow, stream)); PCHK(hipMemsetAsync(b_asg.p, 0, (size_t)nrow, stream));
+    PCHK(hipMemsetAsync(b_ps.p, 0, (size_t)nrow * 4, stream));
+  }
+  if (!dev_post) { haplotag.assign(nrow, 0); assignment.assign(nrow, 0); phase_set.assign(nrow, 0); }
   const int32_t stride = (max_state + 63) & ~63;
   P.scratch_stride = stride;
   const size_t dyn_bytes = stride <= 48 * 1024 ? (size_t)stride : 0;  // chain working state in LDS when it fits
@@ -1228,11 +1628,12 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     launch(n_t, t_off, nullptr);
     hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)ns), dim3(64), 0, stream, d_sl, (int32_t)ns, P.reg, d_jb, d_obj, d_win);
     launch(n_w, w_off, d_win);
+    if (dev_post) hipLaunchKernelGGL(k4_post, dim3((unsigned)ns), dim3(LCR_BLOCK), post_lds, stream, pin, d_sl, (int32_t)ns, plut);
     PCHK(hipGetLastError());
   }
   int8_t* const st1 = h_pin[4].as<int8_t>();   // enumeration results
   int8_t* const st2 = h_pin[6].as<int8_t>();   // chain results
-  if (ng) PCHK(hipMemcpyAsync(st1, b_st.p, st_bytes, hipMemcpyDeviceToHost, stream));
+  if (ng && !dev_post) PCHK(hipMemcpyAsync(st1, b_st.p, st_bytes, hipMemcpyDeviceToHost, stream));
   lap("enum launch");
 
   // ---- host views of the regions (epilogue structures; LD blocks of the chain regions)
@@ -1369,7 +1770,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     pool = new HostPool(nthreads > 1 ? nthreads : 0);
   }
   auto for_regions = [&](const std::function<void(int)>& fn) { pool->parallel_for(ng, fn); };
-  for_regions(prep);
+  if (dev_post) pool->parallel_for((int)chain_slots.size(), [&](int k) { prep(chain_slots[k]); });
+  else for_regions(prep);
   lap("host region prep + LD");
 
   // ---- chain regions on queue `side` (their own copy of the state arrays)
@@ -1445,14 +1847,44 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
           for (int i = 0; i < rh.S; i++) rh.cand[i].haplotype = old_hap[i];
         }
       };
-      for_regions(block_pass);
+      pool->parallel_for(nc, [&](int k) { block_pass(chain_slots[k]); });
     PCHK(hipMemcpyAsync(b_stc.p, st2, st_bytes, hipMemcpyHostToDevice, side));
     hipLaunchKernelGGL(k4_chain_b, dim3(nc), dim3(LCR_BLOCK), dyn_bytes, side, Pc, b_slots.as<int32_t>(), nc);
-    PCHK(hipGetLastError());
-    PCHK(hipMemcpyAsync(st2, b_stc.p, st_bytes, hipMemcpyDeviceToHost, side));
+    if (dev_post) {
+      PostIn pinc = pin;
+      pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta;
+      hipLaunchKernelGGL(k4_post, dim3(nc), dim3(LCR_BLOCK), post_lds, side, pinc, b_slots.as<int32_t>(), nc, plut);
+      PCHK(hipGetLastError());
+      PCHK(hipMemcpyAsync(st2 + st_obj, b_stc.as<int8_t>() + st_obj, (size_t)ng * 8, hipMemcpyDeviceToHost, side));
+    } else {
+      PCHK(hipGetLastError());
+      PCHK(hipMemcpyAsync(st2, b_stc.p, st_bytes, hipMemcpyDeviceToHost, side));
+    }
     PCHK(hipStreamSynchronize(side));
   }
   lap("chain kernels + block pass");
+  if (dev_post) {
+    // results: per-row haplotag / assignment / phase set, the candidates (updated in place on the device), objectives
+    int8_t* const h_tag = h_pin[7].as<int8_t>(); uint8_t* const h_asg = h_pin[8].as<uint8_t>(); uint32_t* const h_ps = h_pin[9].as<uint32_t>();
+    if (nrow) {
+      PCHK(hipMemcpyAsync(h_tag, b_htag.p, (size_t)nrow, hipMemcpyDeviceToHost, stream));
+      PCHK(hipMemcpyAsync(h_asg, b_asg.p, (size_t)nrow, hipMemcpyDeviceToHost, stream));
+      PCHK(hipMemcpyAsync(h_ps, b_ps.p, (size_t)nrow * 4, hipMemcpyDeviceToHost, stream));
+    }
+    if (ncand) PCHK(hipMemcpyAsync(cand.data(), in.d_cand, (size_t)ncand * sizeof(lcr_candidate), hipMemcpyDeviceToHost, stream));
+    if (ng) PCHK(hipMemcpyAsync(st1 + st_obj, b_st.as<int8_t>() + st_obj, (size_t)ng * 8, hipMemcpyDeviceToHost, stream));
+    PCHK(hipStreamSynchronize(stream));
+    PCHK(hipGetLastError());
+    for (int g = 0; g < ng; g++) {
+      const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
+      if (S == 0) continue;
+      const int8_t* st = (uint32_t)S > prm.max_enum_snps ? st2 : st1;
+      objective[g] = (double)(*((const long long*)(st + st_obj) + g)) / FX_SCALE;
+    }
+    r_haplotag = h_tag; r_assignment = h_asg; r_phase_set = h_ps;
+    lap("device epilogue + results");
+    return LCR_OK;
+  }
   PCHK(hipStreamSynchronize(stream));
   PCHK(hipGetLastError());
   lap("wait enum");
@@ -1498,6 +1930,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   } else
   for_regions(epilogue);
   lap("scatter + post-phase epilogue");
+  r_haplotag = haplotag.data(); r_assignment = assignment.data(); r_phase_set = phase_set.data();
   return LCR_OK;
 #undef PCHK
 }

@@ -592,8 +592,8 @@ int lcr_get_phase_result(lcr_ctx* c, lcr_phase_result* out) {
   if (!c || !out) return LCR_E_ARG;
   if (!c->have_phase) { c->err = "lcr_get_phase_result before lcr_phase"; return LCR_E_STATE; }
   out->n_rows = c->n_rows; out->n_regions = c->bv.n_regions;
-  out->haplotag = c->phase.haplotag.data(); out->assignment = c->phase.assignment.data();
-  out->phase_set = c->phase.phase_set.data(); out->objective = c->phase.objective.data();
+  out->haplotag = c->phase.r_haplotag; out->assignment = c->phase.r_assignment;
+  out->phase_set = c->phase.r_phase_set; out->objective = c->phase.objective.data();
   return LCR_OK;
 }
 

@@ -77,8 +77,11 @@ struct PhaseHost {
   std::vector<uint8_t> assignment;
   std::vector<uint32_t> phase_set;
   std::vector<double> objective;
-  DevBuf d_state[17];
-  HostBuf h_pin[7];   // pinned staging: row_ptr, col, val, links, enum state, region sizes, chain state
+  const int8_t* r_haplotag = nullptr;      // results of the last run (host vectors above or pinned buffers)
+  const uint8_t* r_assignment = nullptr;
+  const uint32_t* r_phase_set = nullptr;
+  DevBuf d_state[20];
+  HostBuf h_pin[10];   // pinned staging: row_ptr, col, val, links, enum state, region sizes, chain state
   hipStream_t side = nullptr;   // second queue: fragment matrix download + chain regions
   hipEvent_t ev_in = nullptr, ev_csr = nullptr;
   HostPool* pool = nullptr;
