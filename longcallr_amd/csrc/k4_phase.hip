@@ -780,15 +780,17 @@ struct PostIn {
   const int8_t* st_sigma; const int8_t* st_delta; const int8_t* st_eta;
   int8_t* haplotag; uint8_t* assignment; uint32_t* phase_set;
   uint32_t min_linkers, max_enum_snps; uint64_t seed; double cutoff; float min_phase_score;
+  long long* dbg_clk;   // LCR_PHASE_PROF: 100 MHz timestamps of workgroup 0's steps (nullptr otherwise)
 };
 constexpr int POST_MAX_ROWS = 8192, POST_MAX_ENTRIES = 8192, POST_MAX_SNPS = 512;
-struct PostLayout { uint32_t sps, rpa, rpb, sflags, soflags, parent, rptr, ecol, erow, cent, ccptr, eval, tag, asg, fp, lok, shap, sgt, svt, rcode, total; };
+struct PostLayout { uint32_t sps, rpa, rpb, sflags, soflags, parent, qcnt, rptr, ecol, erow, cent, ccptr, eval, tag, asg, fp, lok, shap, sgt, svt, rcode, total; };
 __host__ __device__ inline PostLayout post_layout(uint32_t nrow, uint32_t E, uint32_t S) {
   PostLayout L;
   uint32_t o = 64 * 8;                       // le[32] | l1e[32]
   L.sps = o; o += 8 * S;                     // phase_score
   L.rpa = o; o += 8 * S; L.rpb = o; o += 8 * S;   // rescue: the two candidate phase scores
   L.sflags = o; o += 4 * S; L.soflags = o; o += 4 * S; L.parent = o; o += 4 * S;
+  L.qcnt = o; o += 4 * 4 * S;                 // per (row quarter, SNP): entry count, then fill cursor
   L.rptr = o; o += 2 * (nrow + 2);
   L.ecol = o; o += 2 * E; L.erow = o; o += 2 * E; L.cent = o; o += 2 * E;
   L.ccptr = o; o += 2 * (S + 2);
@@ -803,7 +805,7 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   __shared__ int sm[2][8];
   __shared__ int s_flag;
-  __shared__ double stage[LCR_BLOCK / 64][4][64];
+  __shared__ double stage[LCR_BLOCK / 64][4 * 65];
   if ((int)blockIdx.x >= n_slots) return;
   const int g = slots[blockIdx.x], tid = threadIdx.x, lane = tid & 63;
   const int r0 = in.row_region_off[g], nrow = in.row_region_off[g + 1] - r0;
@@ -825,6 +827,9 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
   uint8_t* rcode = lds + L.rcode;
   lcr_candidate* cand = in.cand + c0;
 
+  int n_mark = 0;
+  auto mark = [&]() { if (in.dbg_clk && blockIdx.x == 0 && tid == 0) in.dbg_clk[n_mark] = (long long)wall_clock64(); n_mark++; };
+  mark();
   // ---- stage: LUT, SNP state, rows (phasing-row index by scan), entries, row-ordered column index
   if (tid < 31) { le[tid] = lut.le[tid]; l1e[tid] = lut.l1e[tid]; }
   for (int i = tid; i < S; i += LCR_BLOCK) {
@@ -848,61 +853,78 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
   }
   if (tid == 0) rptr[nrow] = (uint16_t)E;
   __syncthreads();
+  mark();
+  // row-ordered column index: wave q fills the entries of the q-th quarter of the rows (stable inside a
+  // quarter: 64 entries at a time in (row, column) order, equal columns keep their order), the quarters'
+  // slots inside a column follow each other
+  int32_t* qcnt = (int32_t*)(lds + L.qcnt);
+  const int rq = (nrow + 3) / 4;   // rows per quarter
+  for (int i = tid; i < 4 * S; i += LCR_BLOCK) qcnt[i] = 0;
+  __syncthreads();
   for (int r = tid; r < nrow; r += LCR_BLOCK)
     for (int e = rptr[r]; e < rptr[r + 1]; e++) {
       const int ci = in.col[e_base + e] - c0;
       ecol[e] = (uint16_t)ci; erow[e] = (uint16_t)r; ev[e] = in.val[e_base + e];
-      atomicAdd(&parent[ci], 1);
+      atomicAdd(&qcnt[(r / rq) * S + ci], 1);
     }
   __syncthreads();
   {
     int carry = 0;
     for (int base = 0; base < S; base += LCR_BLOCK) {
       const int i = base + tid;
-      const int v = i < S ? parent[i] : 0;
+      const int v = i < S ? qcnt[i] + qcnt[S + i] + qcnt[2 * S + i] + qcnt[3 * S + i] : 0;
       int ex, d0, tot, d1;
       block_scan2(v, 0, ex, d0, tot, d1, sm);
-      if (i < S) { ccptr[i] = (uint16_t)(carry + ex); parent[i] = carry + ex; }
+      if (i < S) {
+        int at = carry + ex;
+        ccptr[i] = (uint16_t)at;
+        for (int q = 0; q < 4; q++) { const int n = qcnt[q * S + i]; qcnt[q * S + i] = at; at += n; }
+      }
       carry += tot;
     }
     if (tid == 0) ccptr[S] = (uint16_t)carry;
   }
   __syncthreads();
-  if (tid < 64) {   // stable fill: entries in (row, column) order, 64 at a time; equal columns keep their order
+  {
+    const int q = tid >> 6;
+    int32_t* cur = qcnt + q * S;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int base = 0; base < E; base += 64) {
+    const int e_lo = rptr[min(q * rq, nrow)], e_hi = rptr[min((q + 1) * rq, nrow)];
+    for (int base = e_lo; base < e_hi; base += 64) {
       const int e = base + lane;
-      const bool valid = e < E;
+      const bool valid = e < e_hi;
       const int c = valid ? (int)ecol[e] : -1;
       unsigned long long rem = __ballot(valid);
       while (rem) {
         const int cc = __shfl(c, __ffsll((long long)rem) - 1, 64);
         const unsigned long long m = __ballot(c == cc);
-        const int at = parent[cc];
+        const int at = cur[cc];
         if (c == cc) cent[at + __popcll(m & below)] = (uint16_t)e;
         wave_lds_sync();
-        if (lane == 0) parent[cc] = at + __popcll(m);
+        if (lane == 0) cur[cc] = at + __popcll(m);
         rem &= ~m;
       }
       wave_lds_sync();
     }
   }
   __syncthreads();
+  mark();
 
   auto lg = [&](int sigma, int delta, int eta, uint8_t v) -> double {   // log10(aki(...)), phase.rs:32-49
     const int pp = (v & 32) ? 1 : -1, x = eta == 0 ? sigma * delta : eta;
     return pp == x ? l1e[v & 31] : le[v & 31];
   };
   // Ordered sums over the observations of SNP column ti, one wave per column: 64 column entries at a time
-  // are loaded and filtered by the lanes (lane <-> entry), each lane stages its NACC terms (or +0.0, the
-  // exact identity here: the sums start at +0.0 and every term is a finite log) in LDS, and all lanes then
-  // add the 64 staged terms in entry order (broadcast reads; the result is wave-uniform).  The additions are
-  // the host's, in the host's order; only the loads and the filter run in parallel.
+  // are loaded and filtered by the lanes (lane <-> entry) and each lane stages its NACC terms (or +0.0, the
+  // exact identity here: the sums start at +0.0 and every term is a finite log) in LDS; then lane a adds the
+  // 64 staged terms of accumulator a in entry order.  The additions are the host's, in the host's order;
+  // only the loads and the filter run in parallel.  Results are returned wave-uniform.
   const int wave = tid >> 6;
-  double* stg = &stage[wave][0][0];
+  constexpr int SSTR = 65;   // stage row stride in doubles (lanes a = 0..3 read different banks)
+  double* stg = &stage[wave][0];
   auto col_sums = [&](int ti, bool skip_unassigned, auto term, double* acc, int nacc, int& hap1, int& hap2, int& nobs) {
     hap1 = hap2 = nobs = 0;
-    for (int a = 0; a < nacc; a++) acc[a] = 0.0;
+    double mine = 0.0;   // lane a < nacc: running sum of accumulator a
     const int kb = ccptr[ti], ke = ccptr[ti + 1];
     for (int k0 = kb; k0 < ke; k0 += 64) {
       const int k = k0 + lane;
@@ -910,16 +932,28 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
       if (k < ke) { e = cent[k]; r = erow[e]; keep = fp[r] && lok[r] && !(skip_unassigned && asg[r] == 0); }
       double t[4] = {0.0, 0.0, 0.0, 0.0};
       if (keep) term((int)tag[r], ev[e], t);
-      for (int a = 0; a < nacc; a++) stg[a * 64 + lane] = t[a];
+      for (int a = 0; a < nacc; a++) stg[a * SSTR + lane] = t[a];
       const unsigned long long km = __ballot(keep);
       hap1 += __popcll(__ballot(keep && asg[r] == 1)); hap2 += __popcll(__ballot(keep && asg[r] == 2));
       nobs += __popcll(km);
       wave_lds_sync();
       const int nk = min(64, ke - k0);
-      for (int j = 0; j < nk; j++)
-        for (int a = 0; a < nacc; a++) acc[a] += stg[a * 64 + j];
+      if (lane < nacc) {
+        const double* src = stg + lane * SSTR;
+        int j = 0;
+        for (; j + 8 <= nk; j += 8) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) v[u] = src[j + u];
+#pragma unroll
+          for (int u = 0; u < 8; u++) mine += v[u];
+        }
+        for (; j < nk; j++) mine += src[j];
+      }
       wave_lds_sync();
     }
+    for (int a = 0; a < nacc; a++)
+      acc[a] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), a), __builtin_amdgcn_readlane(__double2loint(mine), a));
   };
   // phase.rs:238-255 over the kept observations of column ti (wave-uniform result)
   auto psl = [&](int ti, int delta_i, int eta_i, bool skip_unassigned) -> double {
@@ -991,7 +1025,14 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
       double ps = sps[ti];
       uint32_t fl = sflags[ti];
       if (ng_ != 0) fl |= LCR_F_NON_SELECTED;
-      else if (hap1 >= 1 && hap2 >= 1) ps = -10.0 * log10(1.0 - psl(ti, nh, ng_, het_skip));
+      else if (hap1 >= 1 && hap2 >= 1) {
+        // phase_score_log(nh, 0): q2 / q3 = sums of lg(sigma, +1 / -1, 0, v), q1 = the one of nh -- the very
+        // addition sequences of het_d / het_nd above (same observations, same order) when delta_i = +-1
+        if (delta_i == 1 || delta_i == -1) {
+          const double s2 = delta_i == 1 ? het_d : het_nd, s3 = delta_i == 1 ? het_nd : het_d;
+          ps = -10.0 * log10(1.0 - (1.0 - (nh == 1 ? s2 : s3) / (s2 + s3)));
+        } else ps = -10.0 * log10(1.0 - psl(ti, nh, ng_, het_skip));
+      }
       else ps = 0.19940219;
       if (lane == 0) { shap[ti] = (int8_t)nh; sgt[ti] = (int8_t)ng_; svt[ti] = (int8_t)nv; sflags[ti] = fl; sps[ti] = ps; }
     }
@@ -1015,13 +1056,13 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
           if (ccptr[ti] == ccptr[ti + 1]) code = 1;
           else if (svt[ti] != 1) code = 2;
           else {
-            double q[3]; int hap1, hap2, nobs;   // gather(need_assigned) + phase_score_log(+1, 0)
-            col_sums(ti, true, [&](int sg, uint8_t v, double* t) { t[0] = lg(sg, 1, 0, v); t[1] = lg(sg, 1, 0, v); t[2] = lg(sg, -1, 0, v); },
-                     q, 3, hap1, hap2, nobs);
+            double q[2]; int hap1, hap2, nobs;   // gather(need_assigned); phase_score_log(+-1, 0) share q2 / q3
+            col_sums(ti, true, [&](int sg, uint8_t v, double* t) { t[0] = lg(sg, 1, 0, v); t[1] = lg(sg, -1, 0, v); },
+                     q, 2, hap1, hap2, nobs);
             if (nobs == 0 || hap1 < 2 || hap2 < 2) code = 3;
             else {
-              const double pa = -10.0 * log10(1.0 - (1.0 - q[0] / (q[1] + q[2])));
-              const double pb = -10.0 * log10(1.0 - psl(ti, -1, 0, true));
+              const double pa = -10.0 * log10(1.0 - (1.0 - q[0] / (q[0] + q[1])));
+              const double pb = -10.0 * log10(1.0 - (1.0 - q[1] / (q[0] + q[1])));
               if (lane == 0) { rpa[ti] = pa; rpb[ti] = pb; }
               code = fmax(pa, pb) >= (double)min_ps ? 4 : 5;
             }
@@ -1127,18 +1168,21 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
   };
 
   const uint64_t rseed = region_seed(in.seed, in.start0[g]);
-  reads_hap(); snp_hap();
-  reads_hap(); snp_hap();
+  reads_hap(); mark(); snp_hap(); mark();
+  reads_hap(); snp_hap(); mark();
   const float relaxed = in.min_phase_score - 3.0f;
   rescue(LCR_F_RNA_EDIT, relaxed, false, rseed);
   rescue(LCR_F_CAND_SOMATIC, relaxed, true, rseed);
-  reads_hap(); snp_hap();
+  mark();
+  reads_hap(); snp_hap(); mark();
   phase_set();
+  mark();
   for (int i = tid; i < S; i += LCR_BLOCK) {
     cand[i].haplotype = shap[i]; cand[i].genotype = sgt[i]; cand[i].variant_type = svt[i];
     cand[i].flags = sflags[i]; cand[i].phase_score = sps[i];
   }
   for (int r = tid; r < nrow; r += LCR_BLOCK) { in.haplotag[r0 + r] = tag[r]; in.assignment[r0 + r] = asg[r]; }
+  mark();
 }
 
 // ================================= host side ====================================================
@@ -1557,7 +1601,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   plut.p_homref = L.p_homref; plut.p_homvar = L.p_homvar; plut.log_theta = L.log_theta; plut.log2 = L.log2;
   PostIn pin{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, const_cast<lcr_candidate*>(in.d_cand), in.d_cand_off,
              in.d_row_region_off, in.d_start0, P.st_sigma, P.st_delta, P.st_eta, b_htag.as<int8_t>(), b_asg.as<uint8_t>(),
-             b_ps.as<uint32_t>(), prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score};
+             b_ps.as<uint32_t>(), prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr};
+  if (prof) { PCHK(d_state[20].reserve(32 * 8)); pin.dbg_clk = d_state[20].as<long long>(); }
   if (dev_post && nrow) {
     PCHK(hipMemsetAsync(b_htag.p, 0, (size_t)nrow, stream)); PCHK(hipMemsetAsync(b_asg.p, 0, (size_t)nrow, stream));
     PCHK(hipMemsetAsync(b_ps.p, 0, (size_t)nrow * 4, stream));
@@ -1882,6 +1927,13 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       objective[g] = (double)(*((const long long*)(st + st_obj) + g)) / FX_SCALE;
     }
     r_haplotag = h_tag; r_assignment = h_asg; r_phase_set = h_ps;
+    if (prof && pin.dbg_clk) {   // steps of k4_post, first workgroup of the last launch on either queue
+      long long clk[16];
+      PCHK(hipMemcpy(clk, pin.dbg_clk, sizeof(clk), hipMemcpyDeviceToHost));
+      static const char* nm[] = {"stage rows", "stage entries + column index", "reads_hap", "snp_hap", "reads_hap + snp_hap", "rescue x2",
+                                 "reads_hap + snp_hap", "phase_set", "write back"};
+      for (int k = 0; k < 9; k++) fprintf(stderr, "[phase]   k4_post %-30s %7.1f us\n", nm[k], (double)(clk[k + 1] - clk[k]) / 100.0);
+    }
     lap("device epilogue + results");
     return LCR_OK;
   }

@@ -80,7 +80,7 @@ struct PhaseHost {
   const int8_t* r_haplotag = nullptr;      // results of the last run (host vectors above or pinned buffers)
   const uint8_t* r_assignment = nullptr;
   const uint32_t* r_phase_set = nullptr;
-  DevBuf d_state[20];
+  DevBuf d_state[21];
   HostBuf h_pin[10];   // pinned staging: row_ptr, col, val, links, enum state, region sizes, chain state
   hipStream_t side = nullptr;   // second queue: fragment matrix download + chain regions
   hipEvent_t ev_in = nullptr, ev_csr = nullptr;
