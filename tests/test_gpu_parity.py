@@ -134,6 +134,16 @@ def test_chain_path_many_snps(engine_cls, orc):
     assert max(np.bincount(c["region"])) > 10
 
 
+@pytest.mark.parametrize("hook", ["LCR_ENUM_FORCE_STREAM", "LCR_ENUM_FORCE_BIG", "LCR_POST_HOST"])
+def test_fallback_device_paths(engine_cls, orc, monkeypatch, hook):
+    """The size-dependent fallbacks of the phase stage give the same results as the default kernels:
+    enumeration restarts with LDS-streamed entries / from global memory, post-phase epilogue on the host."""
+    monkeypatch.setenv(hook, "1")
+    b = synth.make_batch("ont-drna", n_genes=3, gene_len=20000, depth=45, seed=14)
+    full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=14))
+    full_check(engine_cls, orc, helpers.demo_batch(), _abi.make_params("hifi-masseq"), "chr20")
+
+
 def test_strand_bias_and_isoseq_preset(engine_cls, orc):
     b = synth.make_batch("ont-cdna", n_genes=3, gene_len=8000, depth=50, seed=31)
     full_check(engine_cls, orc, b, _abi.make_params("hifi-isoseq", seed=1))
