@@ -72,14 +72,19 @@ void launch_k0_pack(const BatchView& b, ReadBin* out, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K0: persistent waves, one read per wave and step.  pass 0: validate ops, intron difference array,
-// records per tile.  pass 1: write the records.  The header of the next read and the first CIGAR words
-// of the next read / next chunk are requested before the current chunk is processed, so the dependent
-// HBM round trips (header -> CIGAR -> slot atomics) of consecutive reads overlap.
+// K0: persistent waves, one read per wave and step, ONE pass: validate ops, intron difference array,
+// reference end of the read, per-tile records.  Records of a tile live in geometrically growing
+// levels (64, 128, 256, ... slots) of one pool: a tile's k-th level is allocated -- one atomic on the
+// pool top -- by the lane that draws the level's first slot, so no counting pass is needed and the
+// waste is bounded by 2x.  The header of the next read and the first CIGAR words of the next read /
+// next chunk are requested before the current chunk is processed, so the dependent HBM round trips
+// (header -> CIGAR -> slot atomics) of consecutive reads overlap.
+__device__ __forceinline__ int rec_level(int slot) { return 31 - __clz((slot >> 6) + 1); }       // level of a tile-relative slot
+__device__ __forceinline__ int rec_level_first(int level) { return ((1 << level) - 1) << 6; }    // its first slot
 __global__ void __launch_bounds__(LCR_BLOCK)
-k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int pass, int ont, int D, int32_t* __restrict__ tile_count,
-       const int32_t* __restrict__ tile_off, int32_t* __restrict__ tile_fill, unsigned long long* __restrict__ recs,
-       uint32_t* __restrict__ ndiff) {
+k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* __restrict__ tile_fill,
+       int32_t* __restrict__ tile_lvl, unsigned int* __restrict__ pool_top, unsigned int pool_cap,
+       unsigned long long* __restrict__ recs, uint32_t* __restrict__ ndiff) {
   const int lane = threadIdx.x & 63;
   const int n_waves = gridDim.x * (LCR_BLOCK / 64);
   int r = blockIdx.x * (LCR_BLOCK / 64) + (threadIdx.x >> 6);
@@ -88,7 +93,7 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int pass, int ont, int D, 
   r = __builtin_amdgcn_readfirstlane(r);  // wave-uniform: header loads become scalar loads
   ReadBin h = rbin[r];
   uint32_t word = (uint32_t)lane < (uint32_t)h.n_cig ? b.cigar[h.cig_off + lane] : 0u;
-  for (; r < b.n_reads; r += n_waves) {
+  for (; r < b.n_reads; r += n_waves) {   // (strided: contiguous ranges per wave balance worse and were slower)
     const int r_next = r + n_waves;
     ReadBin hn = h;
     if (r_next < b.n_reads) hn = rbin[r_next];          // prefetch the next read's header
@@ -108,7 +113,6 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int pass, int ont, int D, 
     uint32_t word_n = 0;                                 // first CIGAR words of the next read
     bool have_wn = false;
     for (uint32_t c0 = 0; c0 < ncig; c0 += 64) {
-      if (ref_cur > vec && pass == 1) break;  // nothing at or right of column vec contributes
       const bool act = c0 + lane < ncig;
       const uint32_t w = word;
       if (c0 + 64 < ncig) word = c0 + 64 + lane < ncig ? cg[c0 + 64 + lane] : 0u;      // prefetch the next chunk
@@ -116,14 +120,14 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int pass, int ont, int D, 
       const int op = w & 15, len = (int)(w >> 4);
       const bool is_m = act && (op == 0 || op == 7 || op == 8);
       const bool is_d = act && op == 2, is_n = act && op == 3, is_i = act && op == 1;
-      if (pass == 0 && act && !(is_m || is_d || is_n || is_i || op == 4 || op == 5)) atomicExch(b.error_flag, 1);
+      if (act && !(is_m || is_d || is_n || is_i || op == 4 || op == 5)) atomicExch(b.error_flag, 1);
       const int dr = (is_m || is_d || is_n) ? len : 0;
       const int dq = (is_m || is_i) ? len : 0;
       const int ir = wave_incl_scan(dr), iq = wave_incl_scan(dq);
       const int rs = ref_cur + ir - dr;   // region-relative column where this op starts
       const int qs = q_cur + iq - dq;     // read offset where this op starts
       int a = max(rs, 0), e = min(rs + len, vec);
-      if (pass == 0 && is_n && e > a) {  // util.rs:930-942
+      if (is_n && e > a) {  // util.rs:930-942
         atomicAdd(&ndiff[gbase + a], 1u);
         atomicAdd(&ndiff[gbase + e], 0xFFFFFFFFu);
       }
@@ -158,30 +162,40 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int pass, int ont, int D, 
           const unsigned long long nxt = lm & above;
           const unsigned long long run = nxt ? (em & above & ((1ull << (__ffsll((long long)nxt) - 1)) - 1ull)) : (em & above);
           const int cnt = 1 + __popcll(run);
-          if (pass == 0) atomicAdd(&tile_count[ftile + t_cur], cnt);
-          else base = atomicAdd(&tile_fill[ftile + t_cur], cnt);
+          base = atomicAdd(&tile_fill[ftile + t_cur], cnt);
         }
-        if (pass == 1) {
-          base = __shfl(base, my_leader, 64);
-          if (emit) {
-            const unsigned long long leader_below = my_leader == 0 ? 0ull : ((1ull << my_leader) - 1ull);
-            const int slot = tile_off[ftile + t_cur] + base + __popcll(em_below & ~leader_below);
-            const int c_lo = max(a, t_cur * LCR_TILE), c_hi = min(e, (t_cur + 1) * LCR_TILE);  // columns in this tile
-            unsigned long long rec = ((unsigned long long)(c_lo - t_cur * LCR_TILE) << 40) |
-                                     ((unsigned long long)(c_hi - c_lo - 1) << 50);
-            if (is_m) rec |= ((seq_off + (unsigned long long)(qs + (c_lo - rs))) & REC_OFF_MASK) | hi_bits;
-            else rec |= is_d ? REC_KIND_D : REC_KIND_I;
-            recs[slot] = rec;
+        base = __shfl(base, my_leader, 64);
+        int slot = 0, lvl = 0;
+        if (emit) {
+          const unsigned long long leader_below = my_leader == 0 ? 0ull : ((1ull << my_leader) - 1ull);
+          slot = base + __popcll(em_below & ~leader_below);   // tile-relative
+          lvl = rec_level(slot);
+          if (slot == rec_level_first(lvl)) {                 // first slot of a level: allocate the level
+            const unsigned int at = atomicAdd(pool_top, 64u << lvl);
+            if (at + (64u << lvl) > pool_cap) atomicExch(b.error_flag, 3);
+            __hip_atomic_store(&tile_lvl[(ftile + t_cur) * LCR_REC_LEVELS + lvl], (int)at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (relaxed: only the value itself is communicated; acquire / release would invalidate L1 every round)
           }
+        }
+        if (emit) {   // (every allocation of this wave is issued above: the wait below is on other waves only)
+          int at, spins = 0;   // (bounded: a broken invariant must surface as an error, not as a hung device)
+          while ((at = __hip_atomic_load(&tile_lvl[(ftile + t_cur) * LCR_REC_LEVELS + lvl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 24)) { atomicExch(b.error_flag, 4); at = (int)pool_cap; break; }
+          }
+          const int c_lo = max(a, t_cur * LCR_TILE), c_hi = min(e, (t_cur + 1) * LCR_TILE);  // columns in this tile
+          unsigned long long rec = ((unsigned long long)(c_lo - t_cur * LCR_TILE) << 40) |
+                                   ((unsigned long long)(c_hi - c_lo - 1) << 50);
+          if (is_m) rec |= ((seq_off + (unsigned long long)(qs + (c_lo - rs))) & REC_OFF_MASK) | hi_bits;
+          else rec |= is_d ? REC_KIND_D : REC_KIND_I;
+          if ((unsigned int)at + (unsigned int)(slot - rec_level_first(lvl)) < pool_cap) recs[(unsigned int)at + (unsigned int)(slot - rec_level_first(lvl))] = rec;
         }
         if (emit) t_cur++;
       }
       ref_cur += __shfl(ir, 63, 64);
       q_cur += __shfl(iq, 63, 64);
-      if (c0 + 64 >= ncig && pass == 0 && lane == 0 && q_cur != reb) atomicExch(b.error_flag, 2);
+      if (c0 + 64 >= ncig && lane == 0 && q_cur != reb) atomicExch(b.error_flag, 2);
     }
-    if (pass == 0 && lane == 0) b.read_rend[r] = ref_cur;   // pass 0 never leaves the chunk loop early
-    // (the loop above may leave early in pass 1; the next read's first words are then fetched here)
+    if (lane == 0) b.read_rend[r] = ref_cur;
     if (r_next < b.n_reads) {
       if (!have_wn) word_n = (uint32_t)lane < (uint32_t)hn.n_cig ? b.cigar[hn.cig_off + lane] : 0u;
       word = word_n;
@@ -190,13 +204,12 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int pass, int ont, int D, 
   }
 }
 
-void launch_k0_bin(const BatchView& b, const ReadBin* rb, int pass, int ont, int D, int32_t* tile_count,
-                   const int32_t* tile_off, int32_t* tile_fill, unsigned long long* recs, uint32_t* ndiff, hipStream_t s) {
+void launch_k0_bin(const BatchView& b, const ReadBin* rb, int ont, int D, int32_t* tile_fill, int32_t* tile_lvl,
+                   unsigned int* pool_top, unsigned int pool_cap, unsigned long long* recs, uint32_t* ndiff, hipStream_t s) {
   if (b.n_reads == 0) return;
   const int per = LCR_BLOCK / 64;
-  const int blocks = std::min((b.n_reads + per - 1) / per, 256 * 8);  // persistent: 8 workgroups per CU
-  hipLaunchKernelGGL(k0_bin, dim3(blocks), dim3(LCR_BLOCK), 0, s, b, rb, pass, ont, D, tile_count, tile_off, tile_fill,
-                     recs, ndiff);
+  const int blocks = std::min((b.n_reads + per - 1) / per, 256 * 8);  // persistent and co-resident: 8 workgroups per CU
+  hipLaunchKernelGGL(k0_bin, dim3(blocks), dim3(LCR_BLOCK), 0, s, b, rb, ont, D, tile_fill, tile_lvl, pool_top, pool_cap, recs, ndiff);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -229,7 +242,8 @@ __device__ __forceinline__ int block_incl_scan(int v, int* wsum /* K1_WAVES ints
 
 __global__ void __launch_bounds__(K1_THREADS)
 k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0,
-          int64_t n_cols, const int32_t* __restrict__ tile_off, const unsigned long long* __restrict__ recs,
+          int64_t n_cols, const int32_t* __restrict__ tile_fill, const int32_t* __restrict__ tile_lvl,
+          const unsigned long long* __restrict__ recs,
           const int32_t* __restrict__ nscan, uint32_t* __restrict__ planes) {
   __shared__ uint32_t pl[P_NPL * TSTRIDE];
   __shared__ __attribute__((aligned(16))) uint8_t refl[REF_PAD + LCR_TILE + 32];
@@ -243,7 +257,7 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   const int vec = b.len[g];
   const int tlen = min(LCR_TILE, vec - tc0);
   const int64_t gcol0 = b.col_off[g] + tc0;            // global column of tile column 0
-  const int i0 = tile_off[blockIdx.x], i1 = tile_off[blockIdx.x + 1];
+  const int i0 = 0, i1 = tile_fill[blockIdx.x];   // records of this tile: slots 0 .. i1-1 of its levels (K0)
   if (i0 == i1) {
     // no M / D / I record touches this tile (pure intron or uncovered): every plane is 0 except the
     // intron plane, which comes from the global scan.  Most tiles of a spliced data set are like this.
@@ -267,6 +281,8 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
     }
     return;
   }
+  __shared__ int lvl_at[LCR_REC_LEVELS];
+  if (tid < LCR_REC_LEVELS) lvl_at[tid] = tile_lvl[blockIdx.x * LCR_REC_LEVELS + tid];
   for (int i = tid; i < P_NPL * TSTRIDE; i += K1_THREADS) pl[i] = 0;
   for (int i = tid; i < REF_PAD + LCR_TILE + 32; i += K1_THREADS) {
     const int col = i - REF_PAD;
@@ -286,7 +302,8 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
     for (int x = 0; x < K1_RPB; x++) {
       const int slot = tid * K1_RPB + x;
       const bool hasrec = rbase + slot < i1;
-      const unsigned long long rec = hasrec ? recs[rbase + slot] : 0ull;
+      const int lv = rec_level(rbase + slot);
+      const unsigned long long rec = hasrec ? recs[(unsigned int)lvl_at[lv] + (unsigned int)(rbase + slot - rec_level_first(lv))] : 0ull;
       const unsigned long long off = rec & REC_OFF_MASK;
       const int col0 = (int)((rec >> 40) & 1023u), len = (int)((rec >> 50) & 1023u) + 1;
       int npieces = 0;
@@ -431,10 +448,10 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
 }
 
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
-                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_off, const unsigned long long* recs,
+                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_fill, const int32_t* tile_lvl, const unsigned long long* recs,
                       const int32_t* nscan, uint32_t* planes, hipStream_t s) {
   if (n_tiles == 0) return;
-  hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_off,
+  hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_fill, tile_lvl,
                      recs, nscan, planes);
 }
 

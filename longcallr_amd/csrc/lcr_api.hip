@@ -308,40 +308,51 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->planes.reserve(std::max<size_t>((size_t)c->n_cols * LCR_NPLANES, 1) * 4));
   BatchView& b = c->bv;
   const int ng = b.n_regions, nt = c->n_tiles;
-  // ---- K0: decode every CIGAR once into per-tile records (count -> scan -> fill) + intron plane
+  // ---- K0: decode every CIGAR once into per-tile records (single pass, geometric levels) + intron plane
   const size_t nd = (size_t)c->n_cols + ng + 1;
-  HIPCHK(c, c->k0_tile_count.reserve((nt + 1) * 4));
+  // records <= M/D/I ops + their tile crossings (M: <= bases / tile + ops); a tile's levels hold < 2 x fill + 64
+  // slots.  Long D runs can exceed the estimate: K0 then flags an overflow (writes are bounds-checked) and the
+  // stage is repeated with a larger pool.
+  size_t pool_cap64 = 2 * ((size_t)c->n_cigar + (size_t)b.n_reads + (size_t)c->n_bases / LCR_TILE) + 64 * (size_t)nt + 64;
   HIPCHK(c, c->k0_tile_off.reserve((nt + 2) * 4));
-  HIPCHK(c, c->k0_tile_fill.reserve((nt + 1) * 4));
+  HIPCHK(c, c->k0_tile_fill.reserve((nt + 1) * 4 + 16));    // [nt + 1]: pool top
+  HIPCHK(c, c->k0_tile_count.reserve(std::max<size_t>((size_t)nt * LCR_REC_LEVELS, 1) * 4));   // level table
   HIPCHK(c, c->ndiff.reserve(nd * 4));
   HIPCHK(c, c->nscan.reserve(nd * 4));
-  HIPCHK(c, hipMemsetAsync(b.error_flag, 0, 4, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->k0_tile_count.p, 0, (nt + 1) * 4, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->k0_tile_fill.p, 0, (nt + 1) * 4, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->ndiff.p, 0, nd * 4, c->stream));
   int32_t n_recs = 0, bad = 0;
-  { Timer t(c, LCR_K_SPANS);
-    launch_k0_bin(b, c->read_bin.as<ReadBin>(), 0, c->dp.ont, c->dp.dist_to_end, c->k0_tile_count.as<int32_t>(), nullptr, nullptr, nullptr,
-                  c->ndiff.as<uint32_t>(), c->stream);
-    launch_scan_i32(c->scan_tmp, c->k0_tile_count.as<int32_t>(), c->k0_tile_off.as<int32_t>(), nt, c->k0_tile_off.as<int32_t>() + nt, c->stream);
+  for (;;) {
+    if (pool_cap64 > 0xFFFFFFF0ull) { c->err = "batch too large for the 32-bit record pool: split it"; return LCR_E_ARG; }
+    const unsigned int pool_cap = (unsigned int)pool_cap64;
+    HIPCHK(c, c->k0_items.reserve((size_t)pool_cap * 8));
+    HIPCHK(c, hipMemsetAsync(b.error_flag, 0, 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->k0_tile_fill.p, 0, (nt + 1) * 4 + 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->k0_tile_count.p, 0xFF, std::max<size_t>((size_t)nt * LCR_REC_LEVELS, 1) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->ndiff.p, 0, nd * 4, c->stream));
+    { Timer t(c, LCR_K_SPANS);
+      launch_k0_bin(b, c->read_bin.as<ReadBin>(), c->dp.ont, c->dp.dist_to_end, c->k0_tile_fill.as<int32_t>(), c->k0_tile_count.as<int32_t>(),
+                    (unsigned int*)(c->k0_tile_fill.as<int32_t>() + nt + 1), pool_cap, c->k0_items.as<unsigned long long>(),
+                    c->ndiff.as<uint32_t>(), c->stream);
+      launch_scan_i32(c->scan_tmp, (const int32_t*)c->ndiff.p, c->nscan.as<int32_t>(), (int32_t)nd, nullptr, c->stream); }
+    // ---- K1: per-tile tally from the records; K1z: poly-A / homopolymer mask of the HiFi presets
+    { Timer t(c, LCR_K_PILEUP);
+      launch_k1_pileup(b, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
+                       c->k0_tile_fill.as<int32_t>(), c->k0_tile_count.as<int32_t>(), c->k0_items.as<unsigned long long>(),
+                       c->nscan.as<int32_t>(), c->planes.as<uint32_t>(), c->stream);
+      if (!c->dp.ont && c->dp.dist_to_end > 0)
+        launch_k1_zonefix(b, c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->stream); }
+    // record count (byte accounting) and CIGAR validation result
+    launch_scan_i32(c->scan_tmp, c->k0_tile_fill.as<int32_t>(), c->k0_tile_off.as<int32_t>(), nt, c->k0_tile_off.as<int32_t>() + nt, c->stream);
     HIPCHK(c, hipMemcpyAsync(&n_recs, c->k0_tile_off.as<int32_t>() + nt, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&bad, b.error_flag, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
     if (bad == 1) { c->err = "unknown CIGAR operation (reference panics: util.rs:944)"; return LCR_E_CIGAR; }
-    if (bad) { c->err = "CIGAR inconsistent with l_seq / soft clips"; return LCR_E_CIGAR; }
-    HIPCHK(c, c->k0_items.reserve(std::max<size_t>(n_recs, 1) * 8));
-    launch_k0_bin(b, c->read_bin.as<ReadBin>(), 1, c->dp.ont, c->dp.dist_to_end, nullptr, c->k0_tile_off.as<int32_t>(), c->k0_tile_fill.as<int32_t>(),
-                  c->k0_items.as<unsigned long long>(), nullptr, c->stream);
-    launch_scan_i32(c->scan_tmp, (const int32_t*)c->ndiff.p, c->nscan.as<int32_t>(), (int32_t)nd, nullptr, c->stream); }
+    if (bad == 2) { c->err = "CIGAR inconsistent with l_seq / soft clips"; return LCR_E_CIGAR; }
+    if (bad == 4) { c->err = "K0 record level wait timed out (internal error)"; return LCR_E_DEVICE; }
+    if (bad == 0) break;
+    pool_cap64 = pool_cap64 * 2 + 4 * (size_t)std::max(n_recs, 0);   // overflow: the true record count is known now
+  }
   c->n_items = n_recs;
-  // ---- K1: per-tile tally from the records; K1z: poly-A / homopolymer mask of the HiFi presets
-  { Timer t(c, LCR_K_PILEUP);
-    launch_k1_pileup(b, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
-                     c->k0_tile_off.as<int32_t>(), c->k0_items.as<unsigned long long>(), c->nscan.as<int32_t>(),
-                     c->planes.as<uint32_t>(), c->stream);
-    if (!c->dp.ont && c->dp.dist_to_end > 0)
-      launch_k1_zonefix(b, c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->stream); }
-  HIPCHK(c, hipGetLastError());
   // bytes K1 itself has to move: read bases once + 8-byte records + reference byte and
   // intron-scan word per column, 13 u32 planes written per column
   c->pileup_bytes = c->n_bases + 8 * (int64_t)n_recs + (4 * LCR_NPLANES + 1 + 4) * c->n_cols;

@@ -10,6 +10,7 @@
 #include "../../include/lcr.h"
 
 #define LCR_TILE 1024      // pileup columns per workgroup tile
+#define LCR_REC_LEVELS 20   // record levels per tile: 64, 128, 256, ... slots (K0 allocates, K1 reads)
 #define LCR_BLOCK 256      // threads per workgroup (4 wave64)
 #define LCR_WAVE 64
 
@@ -128,11 +129,11 @@ struct PhaseLutDev {
 // K0: pass 0 counts records per tile (+ intron difference array, CIGAR validation); pass 1 writes them
 void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s);
 void launch_k0_pack(const BatchView& b, ReadBin* out, hipStream_t s);
-void launch_k0_bin(const BatchView& b, const ReadBin* rb, int pass, int ont, int D, int32_t* tile_count, const int32_t* tile_off,
-                   int32_t* tile_fill, unsigned long long* recs, uint32_t* ndiff, hipStream_t s);
+void launch_k0_bin(const BatchView& b, const ReadBin* rb, int ont, int D, int32_t* tile_fill, int32_t* tile_lvl,
+                   unsigned int* pool_top, unsigned int pool_cap, unsigned long long* recs, uint32_t* ndiff, hipStream_t s);
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
-                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_off, const unsigned long long* recs,
-                      const int32_t* nscan, uint32_t* planes, hipStream_t s);
+                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_fill, const int32_t* tile_lvl,
+                      const unsigned long long* recs, const int32_t* nscan, uint32_t* planes, hipStream_t s);
 void launch_k1_zonefix(const BatchView& b, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s);
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, uint8_t* flags, int32_t* tile_count,
