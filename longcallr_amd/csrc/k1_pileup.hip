@@ -257,6 +257,7 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   const int vec = b.len[g];
   const int tlen = min(LCR_TILE, vec - tc0);
   const int64_t gcol0 = b.col_off[g] + tc0;            // global column of tile column 0
+  if (*b.error_flag != 0) return;   // K0 failed (bad CIGAR or record pool overflow): the stage is rejected or repeated
   const int i0 = 0, i1 = tile_fill[blockIdx.x];   // records of this tile: slots 0 .. i1-1 of its levels (K0)
   if (i0 == i1) {
     // no M / D / I record touches this tile (pure intron or uncovered): every plane is 0 except the

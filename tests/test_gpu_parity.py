@@ -208,6 +208,27 @@ def test_edge_cases(engine_cls, orc):
     full_check(engine_cls, orc, b, p)
 
 
+def test_long_deletions_grow_the_record_pool(engine_cls, orc):
+    """K0 sizes its record pool from ops + reads + bases / tile; deletion runs that cross dozens of tiles
+    exceed that estimate: the stage must notice the overflow, repeat with a larger pool and still agree
+    with the oracle (planes, and the rest of the pipeline on the same batch)."""
+    L = 60 * 1024
+    rng = np.random.default_rng(3)
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    reads = []
+    for k in range(300):
+        p0 = int(rng.integers(0, 200))
+        dlen = 50 * 1024 + int(rng.integers(0, 2000))
+        tail = p0 + 300 + dlen
+        s = list(ref[p0:p0 + 300] + ref[tail:tail + 300])
+        if k % 2:
+            s[150] = "T" if s[150] != "T" else "G"
+        reads.append(dict(pos=5000 + p0, seq="".join(s), qual=30, cigar="300M%dD300M" % dlen, rev=k % 2, ts=1 + k % 2, region=0))
+    reads.sort(key=lambda r: r["pos"])
+    b = helpers.mk_batch(reads, [(5000, ref)])
+    full_check(engine_cls, orc, b, _abi.make_params("hifi-masseq", min_depth=3))
+
+
 def test_empty_batch_and_errors(engine_cls):
     from longcallr_amd.api import LcrError
     p = _abi.make_params()
