@@ -73,6 +73,7 @@ struct PhaseDev {
   int8_t* st_sigma; int8_t* st_delta; int8_t* st_eta; long long* st_obj;  // per region best / result state
   int8_t* scratch; int32_t scratch_stride;                                // per block working state
   int32_t lds_state;                                                      // 1: working state lives in dynamic LDS
+  int32_t lds_mat;                                                        // bytes of dynamic LDS behind the state for a matrix copy
   int32_t dbg;                                                            // LCR_K4_DBG: timing experiments only
   PhaseLutDev lut;
 };
@@ -87,17 +88,40 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 // Every emission term is fe[q] + hit * w[q] with w[q] = f1e[q] - fe[q] > 0 and hit = [p == x]
 // (aki, phase.rs:32-49), so per row / column only the data dependent sum of w over the hits is
 // accumulated; the sigma/delta independent parts are per-SNP constants (PhaseDev::snp_const).
-__device__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, int8_t* sg, int8_t* dl, int8_t* et,
+// a region's phase matrix: global memory, or a copy the calling kernel staged in LDS
+struct MatView { const int32_t* rp; const int32_t* pc; const uint8_t* pv; const int32_t* cp; const int32_t* cr; const uint8_t* cv;
+                 const uint8_t* fp; const uint8_t* cons; };
+__device__ __forceinline__ MatView global_view(const PhaseDev& P, const RegionDev& rd) {
+  return MatView{P.prow_ptr + rd.rp_off, P.pcol + rd.e_off, P.pval + rd.e_off, P.ccol_ptr + rd.cp_off, P.crow + rd.e_off,
+                 P.cval + rd.e_off, P.snp_fp + rd.snp_off, P.snp_cons + rd.snp_off};
+}
+__host__ __device__ inline uint32_t matview_bytes(uint32_t R, uint32_t S, uint32_t E) {
+  return 4 * (R + 1) + 4 * (S + 1) + 8 * E + 2 * ((E + 3) & ~3u) + 2 * ((S + 3) & ~3u);
+}
+// copy the region's matrix into LDS at `dst` (4-byte aligned); all threads of the workgroup call
+__device__ __forceinline__ MatView stage_view(const PhaseDev& P, const RegionDev& rd, uint8_t* dst, uint32_t E) {
+  const MatView g = global_view(P, rd);
+  int32_t* rp = (int32_t*)dst; int32_t* cp = rp + rd.R + 1; int32_t* pc = cp + rd.S + 1; int32_t* cr = pc + E;
+  uint8_t* pv = (uint8_t*)(cr + E); uint8_t* cv = pv + ((E + 3) & ~3u); uint8_t* fp = cv + ((E + 3) & ~3u); uint8_t* cons = fp + ((rd.S + 3) & ~3u);
+  for (int i = threadIdx.x; i <= rd.R; i += blockDim.x) rp[i] = g.rp[i];
+  for (int i = threadIdx.x; i <= rd.S; i += blockDim.x) cp[i] = g.cp[i];
+  for (int i = threadIdx.x; i < (int)E; i += blockDim.x) { pc[i] = g.pc[i]; cr[i] = g.cr[i]; pv[i] = g.pv[i]; cv[i] = g.cv[i]; }
+  for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { fp[i] = g.fp[i]; cons[i] = g.cons[i]; }
+  __syncthreads();
+  return MatView{rp, pc, pv, cp, cr, cv, fp, cons};
+}
+
+__device__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, const MatView& mv, int8_t* sg, int8_t* dl, int8_t* et,
                                     bool keep_conserved, bool with_genotype, long long* red, const long long* wl) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int32_t* rp = P.prow_ptr + rd.rp_off;
-  const int32_t* pc = P.pcol + rd.e_off;
-  const uint8_t* pv = P.pval + rd.e_off;
-  const int32_t* cp = P.ccol_ptr + rd.cp_off;
-  const int32_t* cr = P.crow + rd.e_off;
-  const uint8_t* cv = P.cval + rd.e_off;
-  const uint8_t* fp = P.snp_fp + rd.snp_off;
-  const uint8_t* cons = P.snp_cons + rd.snp_off;
+  const int32_t* rp = mv.rp;
+  const int32_t* pc = mv.pc;
+  const uint8_t* pv = mv.pv;
+  const int32_t* cp = mv.cp;
+  const int32_t* cr = mv.cr;
+  const uint8_t* cv = mv.cv;
+  const uint8_t* fp = mv.fp;
+  const uint8_t* cons = mv.cons;
   const long long* sc = P.snp_const + 4ll * rd.snp_off;
   bool hg_inc = true, h_inc = true;
   int iters = 0;
@@ -665,7 +689,7 @@ k4_enum_big(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __res
     const uint64_t ctr0 = (uint64_t)rd.S + (uint64_t)rd.R + (uint64_t)e * (uint64_t)rd.R;
     for (int row = threadIdx.x; row < rd.R; row += blockDim.x) sg[row] = u01(rd.seed, ctr0 + row) < 0.5 ? -1 : 1;
     __syncthreads();
-    const long long obj = cross_optimize(P, rd, sg, dl, et, false, true, red, wl);
+    const long long obj = cross_optimize(P, rd, global_view(P, rd), sg, dl, et, false, true, red, wl);
     if (win_e) {
       for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { P.st_delta[rd.snp_off + i] = dl[i]; P.st_eta[rd.snp_off + i] = et[i]; }
       for (int row = threadIdx.x; row < rd.R; row += blockDim.x) P.st_sigma[rd.sig_off + row] = sg[row];
@@ -694,8 +718,9 @@ __global__ void __launch_bounds__(64) k4_enum_pick(const int32_t* __restrict__ s
 }
 
 // chain, part A (phase.rs:1124-1132): delta from init_haplotypes_LD2 (host), random sigma, keep_conserved
-__global__ void __launch_bounds__(LCR_BLOCK) k4_chain_a(PhaseDev P, const int32_t* __restrict__ slots, int32_t n) {
-  __shared__ long long red[LCR_BLOCK / 64];
+constexpr int CHAIN_THREADS = 1024;   // a chain region is one workgroup: 16 waves shorten its sequential rounds
+__global__ void __launch_bounds__(CHAIN_THREADS) k4_chain_a(PhaseDev P, const int32_t* __restrict__ slots, int32_t n) {
+  __shared__ long long red[CHAIN_THREADS / 64];
   __shared__ long long wl[32];
   if ((int)blockIdx.x >= n) return;
   load_w(P, wl);
@@ -707,13 +732,13 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_chain_a(PhaseDev P, const int32_
   const uint64_t ctr0 = 2 * (uint64_t)rd.S + (uint64_t)rd.R;  // after S+F (thread.rs) and S (init_haplotypes_LD2)
   for (int row = threadIdx.x; row < rd.R; row += blockDim.x) sg[row] = u01(rd.seed, ctr0 + row) < 0.5 ? -1 : 1;
   __syncthreads();
-  const long long obj = cross_optimize(P, rd, sg, dl, et, true, false, red, wl);
+  const long long obj = cross_optimize(P, rd, global_view(P, rd), sg, dl, et, true, false, red, wl);
   if (threadIdx.x == 0) P.st_obj[slot] = obj;
 }
 
 // chain, part B (phase.rs:1197-1233): perturbation rounds with best-state tracking
-__global__ void __launch_bounds__(LCR_BLOCK) k4_chain_b(PhaseDev P, const int32_t* __restrict__ slots, int32_t n) {
-  __shared__ long long red[LCR_BLOCK / 64];
+__global__ void __launch_bounds__(CHAIN_THREADS) k4_chain_b(PhaseDev P, const int32_t* __restrict__ slots, int32_t n) {
+  __shared__ long long red[CHAIN_THREADS / 64];
   __shared__ long long wl[32];
   if ((int)blockIdx.x >= n) return;
   load_w(P, wl);
@@ -723,6 +748,10 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_chain_b(PhaseDev P, const int32_
   extern __shared__ __attribute__((aligned(16))) int8_t dyn_state[];
   int8_t* sg = P.lds_state ? dyn_state : P.scratch + (size_t)blockIdx.x * P.scratch_stride;
   int8_t* dl = sg + rd.R; int8_t* et = dl + rd.S;
+  // the perturbation rounds sweep the matrix dozens of times: keep it in LDS when it fits next to the state
+  const uint32_t E = (uint32_t)P.prow_ptr[rd.rp_off + rd.R];
+  const MatView mv = (P.lds_state && matview_bytes(rd.R, rd.S, E) <= (uint32_t)P.lds_mat)
+                         ? stage_view(P, rd, (uint8_t*)dyn_state + P.scratch_stride, E) : global_view(P, rd);
   long long best = P.st_obj[slot];
   auto load_best = [&]() {
     for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { dl[i] = bdl[i]; et[i] = bet[i]; }
@@ -748,13 +777,13 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_chain_b(PhaseDev P, const int32_
       else if (rg >= 0.9) dl[i] = flip ? -1 : 1;
     }
     __syncthreads();
-    long long obj = cross_optimize(P, rd, sg, dl, et, false, false, red, wl);
+    long long obj = cross_optimize(P, rd, mv, sg, dl, et, false, false, red, wl);
     save_if_better(obj);
     load_best();
     for (int row = threadIdx.x; row < rd.R; row += blockDim.x)  // phase.rs:1217-1224
       if (u01(rd.seed, ctr_t + rd.S + row) < 0.1) sg[row] = (int8_t)(-sg[row]);
     __syncthreads();
-    obj = cross_optimize(P, rd, sg, dl, et, false, false, red, wl);
+    obj = cross_optimize(P, rd, mv, sg, dl, et, false, false, red, wl);
     save_if_better(obj);
     load_best();
   }
@@ -1894,7 +1923,15 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       };
       pool->parallel_for(nc, [&](int k) { block_pass(chain_slots[k]); });
     PCHK(hipMemcpyAsync(b_stc.p, st2, st_bytes, hipMemcpyHostToDevice, side));
-    hipLaunchKernelGGL(k4_chain_b, dim3(nc), dim3(LCR_BLOCK), dyn_bytes, side, Pc, b_slots.as<int32_t>(), nc);
+    {   // room behind the working state for the largest chain matrix that fits 64 KB of LDS in total
+      uint32_t want = 0;
+      for (int g : chain_slots) {
+        const uint32_t m = matview_bytes(stat[g].R, in.cand_region_off[g + 1] - in.cand_region_off[g], stat[g].E);
+        if (dyn_bytes && dyn_bytes + m + 64 <= 64 * 1024) want = std::max(want, m);
+      }
+      Pc.lds_mat = (int32_t)want;
+    }
+    hipLaunchKernelGGL(k4_chain_b, dim3(nc), dim3(CHAIN_THREADS), dyn_bytes + (size_t)Pc.lds_mat, side, Pc, b_slots.as<int32_t>(), nc);
     if (dev_post) {
       PostIn pinc = pin;
       pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta;
