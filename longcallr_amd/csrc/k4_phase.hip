@@ -528,8 +528,9 @@ struct StageOut {
   uint8_t* snp_fp; int8_t* snp_vt; uint8_t* snp_cons; long long* snp_const; int32_t* cursor;
 };
 
-// exclusive scan of two ints over a 256-thread workgroup; returns the totals through ta / tb
-__device__ __forceinline__ void block_scan2(int a, int b, int& ea, int& eb, int& ta, int& tb, int (*sm)[8]) {
+// exclusive scan of two ints over a workgroup of NW waves; returns the totals through ta / tb
+template <int NW, int SMW>
+__device__ __forceinline__ void block_scan2n(int a, int b, int& ea, int& eb, int& ta, int& tb, int (*sm)[SMW]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int ia = a, ib = b;
 #pragma unroll
@@ -541,8 +542,11 @@ __device__ __forceinline__ void block_scan2(int a, int b, int& ea, int& eb, int&
   if (lane == 63) { sm[0][wave] = ia; sm[1][wave] = ib; }
   __syncthreads();
   int oa = 0, ob = 0; ta = 0; tb = 0;
-  for (int w = 0; w < 4; w++) { if (w < wave) { oa += sm[0][w]; ob += sm[1][w]; } ta += sm[0][w]; tb += sm[1][w]; }
+  for (int w = 0; w < NW; w++) { if (w < wave) { oa += sm[0][w]; ob += sm[1][w]; } ta += sm[0][w]; tb += sm[1][w]; }
   ea = oa + ia - a; eb = ob + ib - b;
+}
+__device__ __forceinline__ void block_scan2(int a, int b, int& ea, int& eb, int& ta, int& tb, int (*sm)[8]) {
+  block_scan2n<4, 8>(a, b, ea, eb, ta, tb, sm);
 }
 
 __global__ void __launch_bounds__(LCR_BLOCK) k4_stage(StageIn in, StageOut out, PhaseLutDev lut) {
@@ -819,7 +823,7 @@ __host__ __device__ inline PostLayout post_layout(uint32_t nrow, uint32_t E, uin
   L.sps = o; o += 8 * S;                     // phase_score
   L.rpa = o; o += 8 * S; L.rpb = o; o += 8 * S;   // rescue: the two candidate phase scores
   L.sflags = o; o += 4 * S; L.soflags = o; o += 4 * S; L.parent = o; o += 4 * S;
-  L.qcnt = o; o += 4 * 4 * S;                 // per (row quarter, SNP): entry count, then fill cursor
+  L.qcnt = o; o += 4 * 16 * S;                // per (row part, SNP): entry count, then fill cursor (<= 16 waves)
   L.rptr = o; o += 2 * (nrow + 2);
   L.ecol = o; o += 2 * E; L.erow = o; o += 2 * E; L.cent = o; o += 2 * E;
   L.ccptr = o; o += 2 * (S + 2);
@@ -830,11 +834,13 @@ __host__ __device__ inline PostLayout post_layout(uint32_t nrow, uint32_t E, uin
   return L;
 }
 
-__global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* __restrict__ slots, int32_t n_slots, PostLut lut) {
+template <int NT>
+__global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restrict__ slots, int32_t n_slots, PostLut lut) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  __shared__ int sm[2][8];
+  constexpr int NW = NT / 64;
+  __shared__ int sm[2][16];
   __shared__ int s_flag;
-  __shared__ double stage[LCR_BLOCK / 64][4 * 65];
+  __shared__ double stage[NW][4 * 65];
   if ((int)blockIdx.x >= n_slots) return;
   const int g = slots[blockIdx.x], tid = threadIdx.x, lane = tid & 63;
   const int r0 = in.row_region_off[g], nrow = in.row_region_off[g + 1] - r0;
@@ -861,18 +867,18 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
   mark();
   // ---- stage: LUT, SNP state, rows (phasing-row index by scan), entries, row-ordered column index
   if (tid < 31) { le[tid] = lut.le[tid]; l1e[tid] = lut.l1e[tid]; }
-  for (int i = tid; i < S; i += LCR_BLOCK) {
+  for (int i = tid; i < S; i += NT) {
     sflags[i] = soflags[i] = cand[i].flags;
     shap[i] = in.st_delta[c0 + i]; sgt[i] = in.st_eta[c0 + i]; svt[i] = (int8_t)cand[i].variant_type;
     sps[i] = cand[i].phase_score;
     parent[i] = 0;   // column counts, then fill cursors
   }
   int F = 0;
-  for (int base = 0; base < nrow; base += LCR_BLOCK) {
+  for (int base = 0; base < nrow; base += NT) {
     const int r = base + tid;
     const int isp = (r < nrow && in.links[r0 + r] >= in.min_linkers) ? 1 : 0;
     int k, d0, tk, d1;
-    block_scan2(isp, 0, k, d0, tk, d1, sm);
+    block_scan2n<NW, 16>(isp, 0, k, d0, tk, d1, sm);
     if (r < nrow) {
       rptr[r] = (uint16_t)(in.row_ptr[r0 + r] - e_base);
       lok[r] = (uint8_t)isp; fp[r] = (uint8_t)isp; asg[r] = 0;
@@ -887,10 +893,10 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
   // quarter: 64 entries at a time in (row, column) order, equal columns keep their order), the quarters'
   // slots inside a column follow each other
   int32_t* qcnt = (int32_t*)(lds + L.qcnt);
-  const int rq = (nrow + 3) / 4;   // rows per quarter
-  for (int i = tid; i < 4 * S; i += LCR_BLOCK) qcnt[i] = 0;
+  const int rq = (nrow + NW - 1) / NW;   // rows per part (one part per wave)
+  for (int i = tid; i < NW * S; i += NT) qcnt[i] = 0;
   __syncthreads();
-  for (int r = tid; r < nrow; r += LCR_BLOCK)
+  for (int r = tid; r < nrow; r += NT)
     for (int e = rptr[r]; e < rptr[r + 1]; e++) {
       const int ci = in.col[e_base + e] - c0;
       ecol[e] = (uint16_t)ci; erow[e] = (uint16_t)r; ev[e] = in.val[e_base + e];
@@ -899,15 +905,16 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
   __syncthreads();
   {
     int carry = 0;
-    for (int base = 0; base < S; base += LCR_BLOCK) {
+    for (int base = 0; base < S; base += NT) {
       const int i = base + tid;
-      const int v = i < S ? qcnt[i] + qcnt[S + i] + qcnt[2 * S + i] + qcnt[3 * S + i] : 0;
+      int v = 0;
+      if (i < S) for (int q = 0; q < NW; q++) v += qcnt[q * S + i];
       int ex, d0, tot, d1;
-      block_scan2(v, 0, ex, d0, tot, d1, sm);
+      block_scan2n<NW, 16>(v, 0, ex, d0, tot, d1, sm);
       if (i < S) {
         int at = carry + ex;
         ccptr[i] = (uint16_t)at;
-        for (int q = 0; q < 4; q++) { const int n = qcnt[q * S + i]; qcnt[q * S + i] = at; at += n; }
+        for (int q = 0; q < NW; q++) { const int n = qcnt[q * S + i]; qcnt[q * S + i] = at; at += n; }
       }
       carry += tot;
     }
@@ -994,7 +1001,7 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
   };
   // snpfrags.rs:548-625
   auto reads_hap = [&]() {
-    for (int r = tid; r < nrow; r += LCR_BLOCK) {
+    for (int r = tid; r < nrow; r += NT) {
       if (!fp[r]) continue;
       const int sigma_k = tag[r];
       double q1 = 0, q2 = 0, q3 = 0, n1 = 0;
@@ -1023,7 +1030,7 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
   };
   // snpfrags.rs:378-546, one wave per SNP (all lanes hold the same values; lane 0 writes)
   auto snp_hap = [&]() {
-    for (int ti = wave; ti < S; ti += LCR_BLOCK / 64) {
+    for (int ti = wave; ti < S; ti += NW) {
       if (!(sflags[ti] & LCR_F_FOR_PHASING)) { if (lane == 0) sflags[ti] |= LCR_F_NON_SELECTED; continue; }
       if (ccptr[ti] == ccptr[ti + 1]) { if (lane == 0) sflags[ti] |= LCR_F_SINGLE; continue; }
       const int delta_i = shap[ti];
@@ -1079,7 +1086,7 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
   auto rescue = [&](uint32_t list_flag, float min_ps, bool low_frac, uint64_t rseed) {
     int start = 0;
     for (;;) {
-      for (int ti = start + wave; ti < S; ti += LCR_BLOCK / 64) {
+      for (int ti = start + wave; ti < S; ti += NW) {
         uint8_t code = 0;
         if (soflags[ti] & list_flag) {
           if (ccptr[ti] == ccptr[ti + 1]) code = 1;
@@ -1140,7 +1147,7 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
   // a read); component label = smallest SNP index (see RegionHost::assign_phase_set), by min-label
   // propagation over the reads + pointer jumping until no edge joins two labels
   auto phase_set = [&]() {
-    for (int i = tid; i < S; i += LCR_BLOCK) {
+    for (int i = tid; i < S; i += NT) {
       const bool node = sgt[i] == 0 && svt[i] == 1 && !(sflags[i] & (LCR_F_DENSE | LCR_F_RNA_EDIT)) &&
                         !(sps[i] < (double)in.min_phase_score);
       parent[i] = node ? i : -1;
@@ -1166,7 +1173,7 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
     for (;;) {
       if (tid == 0) s_flag = 0;
       __syncthreads();
-      for (int r = tid; r < nrow; r += LCR_BLOCK) {
+      for (int r = tid; r < nrow; r += NT) {
         if (!fp[r] || asg[r] == 0) continue;
         for_pairs(r, [&](int x, int y) {
           const int lx = parent[x], ly = parent[y];
@@ -1174,13 +1181,13 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
         });
       }
       __syncthreads();
-      for (int i = tid; i < S; i += LCR_BLOCK) if (parent[i] >= 0) { int l = parent[i]; while (parent[l] != l) l = parent[l]; atomicMin(&parent[i], l); }
+      for (int i = tid; i < S; i += NT) if (parent[i] >= 0) { int l = parent[i]; while (parent[l] != l) l = parent[l]; atomicMin(&parent[i], l); }
       __syncthreads();
       if (!s_flag) break;
       __syncthreads();
     }
-    for (int i = tid; i < S; i += LCR_BLOCK) if (parent[i] >= 0) cand[i].phase_set = (uint32_t)(cand[parent[i]].pos + 1);
-    for (int r = tid; r < nrow; r += LCR_BLOCK) {
+    for (int i = tid; i < S; i += NT) if (parent[i] >= 0) cand[i].phase_set = (uint32_t)(cand[parent[i]].pos + 1);
+    for (int r = tid; r < nrow; r += NT) {
       uint32_t ps = 0;
       if (fp[r] && asg[r] != 0) {
         int best = -1, first = -1;  // largest component root among the components that own an edge of this read
@@ -1206,11 +1213,11 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_post(PostIn in, const int32_t* _
   reads_hap(); snp_hap(); mark();
   phase_set();
   mark();
-  for (int i = tid; i < S; i += LCR_BLOCK) {
+  for (int i = tid; i < S; i += NT) {
     cand[i].haplotype = shap[i]; cand[i].genotype = sgt[i]; cand[i].variant_type = svt[i];
     cand[i].flags = sflags[i]; cand[i].phase_score = sps[i];
   }
-  for (int r = tid; r < nrow; r += LCR_BLOCK) { in.haplotag[r0 + r] = tag[r]; in.assignment[r0 + r] = asg[r]; }
+  for (int r = tid; r < nrow; r += NT) { in.haplotag[r0 + r] = tag[r]; in.assignment[r0 + r] = asg[r]; }
   mark();
 }
 
@@ -1702,7 +1709,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     launch(n_t, t_off, nullptr);
     hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)ns), dim3(64), 0, stream, d_sl, (int32_t)ns, P.reg, d_jb, d_obj, d_win);
     launch(n_w, w_off, d_win);
-    if (dev_post) hipLaunchKernelGGL(k4_post, dim3((unsigned)ns), dim3(LCR_BLOCK), post_lds, stream, pin, d_sl, (int32_t)ns, plut);
+    if (dev_post) hipLaunchKernelGGL(k4_post<LCR_BLOCK>, dim3((unsigned)ns), dim3(LCR_BLOCK), post_lds, stream, pin, d_sl, (int32_t)ns, plut);
     PCHK(hipGetLastError());
   }
   int8_t* const st1 = h_pin[4].as<int8_t>();   // enumeration results
@@ -1935,7 +1942,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     if (dev_post) {
       PostIn pinc = pin;
       pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta;
-      hipLaunchKernelGGL(k4_post, dim3(nc), dim3(LCR_BLOCK), post_lds, side, pinc, b_slots.as<int32_t>(), nc, plut);
+      static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_post<CHAIN_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      PCHK(attr_);   // 33 KB of static stage buffers + up to 64 KB of region image
+      hipLaunchKernelGGL(k4_post<CHAIN_THREADS>, dim3(nc), dim3(CHAIN_THREADS), post_lds, side, pinc, b_slots.as<int32_t>(), nc, plut);
       PCHK(hipGetLastError());
       PCHK(hipMemcpyAsync(st2 + st_obj, b_stc.as<int8_t>() + st_obj, (size_t)ng * 8, hipMemcpyDeviceToHost, side));
     } else {
