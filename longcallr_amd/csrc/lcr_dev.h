@@ -9,7 +9,7 @@
 
 #include "../../include/lcr.h"
 
-#define LCR_TILE 1024      // pileup columns per workgroup tile
+#define LCR_TILE 512       // pileup columns per workgroup tile
 #define LCR_REC_LEVELS 20   // record levels per tile: 64, 128, 256, ... slots (K0 allocates, K1 reads)
 #define LCR_BLOCK 256      // threads per workgroup (4 wave64)
 #define LCR_WAVE 64
