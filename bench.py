@@ -199,7 +199,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k1_pileup", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "algorithmic_bytes": pbytes, "avg_ms": avg_ms,
                          "note": "k1_pileup (+ k1_zonefix on HiFi presets): read bases once + 8-byte records + 57 B/column",
-                         "pileup_stage": {"kernels": "k0_bin x2 + scans + k1_pileup", "ms": avg_ms + avg_k0_ms,
+                         "pileup_stage": {"kernels": "k0_bin + intron scan + k1_pileup", "ms": avg_ms + avg_k0_ms,
                                           "algorithmic_bytes": stage_bytes,
                                           "achieved": stage_bytes / ((avg_ms + avg_k0_ms) * 1e-3) / 1e9,
                                           "frac": stage_bytes / ((avg_ms + avg_k0_ms) * 1e-3) / 1e9 / 8000.0}},

@@ -93,6 +93,7 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* _
   r = __builtin_amdgcn_readfirstlane(r);  // wave-uniform: header loads become scalar loads
   ReadBin h = rbin[r];
   uint32_t word = (uint32_t)lane < (uint32_t)h.n_cig ? b.cigar[h.cig_off + lane] : 0u;
+  unsigned int n_items = 0;
   for (; r < b.n_reads; r += n_waves) {   // (strided: contiguous ranges per wave balance worse and were slower)
     const int r_next = r + n_waves;
     ReadBin hn = h;
@@ -138,6 +139,7 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* _
       // column range [a, e) this op contributes records for (I: the single column rs-1, 1 <= rs < vec)
       bool has = (is_m || is_d) && len > 0 && e > a;
       if (is_i && len > 0 && rs >= 1 && rs < vec) { has = true; a = rs - 1; e = rs; }
+      n_items += __popcll(__ballot(has));   // M / D / I items (tile independent), one atomic per wave at exit
       int t_cur = has ? a / LCR_TILE : INT_MAX;       // tile of the next record of this lane
       const int t_last = has ? (e - 1) / LCR_TILE : -1;
       // rounds: every lane emits its record for tile t_cur, then moves to its next tile (ops rarely span
@@ -202,6 +204,7 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* _
     }
     h = hn;
   }
+  if (lane == 0 && n_items) atomicAdd(pool_top + 1, n_items);
 }
 
 void launch_k0_bin(const BatchView& b, const ReadBin* rb, int ont, int D, int32_t* tile_fill, int32_t* tile_lvl,

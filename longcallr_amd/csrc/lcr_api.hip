@@ -319,7 +319,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->k0_tile_count.reserve(std::max<size_t>((size_t)nt * LCR_REC_LEVELS, 1) * 4));   // level table
   HIPCHK(c, c->ndiff.reserve(nd * 4));
   HIPCHK(c, c->nscan.reserve(nd * 4));
-  int32_t n_recs = 0, bad = 0;
+  int32_t n_recs = 0, bad = 0, n_ops = 0;
   for (;;) {
     if (pool_cap64 > 0xFFFFFFF0ull) { c->err = "batch too large for the 32-bit record pool: split it"; return LCR_E_ARG; }
     const unsigned int pool_cap = (unsigned int)pool_cap64;
@@ -344,6 +344,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
     launch_scan_i32(c->scan_tmp, c->k0_tile_fill.as<int32_t>(), c->k0_tile_off.as<int32_t>(), nt, c->k0_tile_off.as<int32_t>() + nt, c->stream);
     HIPCHK(c, hipMemcpyAsync(&n_recs, c->k0_tile_off.as<int32_t>() + nt, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&bad, b.error_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&n_ops, c->k0_tile_fill.as<int32_t>() + nt + 2, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     if (bad == 1) { c->err = "unknown CIGAR operation (reference panics: util.rs:944)"; return LCR_E_CIGAR; }
@@ -355,7 +356,8 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   c->n_items = n_recs;
   // bytes K1 itself has to move: read bases once + 8-byte records + reference byte and
   // intron-scan word per column, 13 u32 planes written per column
-  c->pileup_bytes = c->n_bases + 8 * (int64_t)n_recs + (4 * LCR_NPLANES + 1 + 4) * c->n_cols;
+  // (8 bytes per M / D / I item: the extra records of items that cross a tile boundary are overhead, not algorithm)
+  c->pileup_bytes = c->n_bases + 8 * (int64_t)n_ops + (4 * LCR_NPLANES + 1 + 4) * c->n_cols;
   c->stage_bytes = c->n_bases + 4 * c->n_cigar + 37 * (int64_t)b.n_reads + (4 * LCR_NPLANES + 1) * c->n_cols;
   c->have_planes = true;
   c->have_cand = c->have_frag = c->have_phase = false;
