@@ -111,8 +111,10 @@ __device__ __forceinline__ MatView stage_view(const PhaseDev& P, const RegionDev
   return MatView{rp, pc, pv, cp, cr, cv, fp, cons};
 }
 
+constexpr int CROSS_MACC = 2048;   // SNPs with a per-column accumulator in LDS (entry-balanced delta step)
 __device__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, const MatView& mv, int8_t* sg, int8_t* dl, int8_t* et,
-                                    bool keep_conserved, bool with_genotype, long long* red, const long long* wl) {
+                                    bool keep_conserved, bool with_genotype, long long* red, const long long* wl,
+                                    unsigned long long* macc = nullptr /* CROSS_MACC zeros in LDS, or nullptr */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int32_t* rp = mv.rp;
   const int32_t* pc = mv.pc;
@@ -143,30 +145,63 @@ __device__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, cons
     if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
     // ---- delta/eta step (phase.rs:872-959): per SNP the best of (d,0) (-d,0) (d,+1) (d,-1)
     any = 0;
-    for (int i = wave; i < rd.S; i += nw) {
-      if (!fp[i]) continue;
-      if (keep_conserved && cons[i]) continue;
-      const int c0 = cp[i], c1 = cp[i + 1];
-      if (c1 == c0) continue;
+    auto decide = [&](int i, long long M, int ncol) {
       const int d = dl[i], h = et[i];
-      long long M = 0;  // sum of w over the entries with p == sigma * d
-      for (int e = c0 + lane; e < c1; e += 64) {
-        const uint8_t v = cv[e];
-        if (((v & 32) ? 1 : -1) == sg[cr[e]] * d) M += wl[v & 31];
+      const long long het = P.lut.f_het0 - (long long)ncol * P.lut.f_log2;  // phase.rs:136-144
+      const long long F = sc[4 * i], W = sc[4 * i + 1];
+      long long N[4] = {F + M + het, F + W - M + het, sc[4 * i + 2] + P.lut.f_homref, sc[4 * i + 3] + P.lut.f_homvar};
+      int ch;
+      if (with_genotype) { ch = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch]) ch = t; }   // phase.rs:908-921
+      else if (h == 0) ch = N[1] > N[0] ? 1 : 0;                                                // phase.rs:923-930
+      else ch = N[3] > N[2] ? 3 : 2;                                                            // phase.rs:931-938
+      const int cur = h == 0 ? 0 : (h == 1 ? 2 : 3);
+      if (N[ch] > N[cur]) any = 1;
+      dl[i] = (int8_t)(ch == 1 ? -d : d);
+      et[i] = (int8_t)(ch <= 1 ? 0 : (ch == 2 ? 1 : -1));
+    };
+    if (macc && rd.S <= CROSS_MACC) {
+      // balanced over the CSC entries (not over the SNPs): thread t takes entries [t*c, (t+1)*c), walks them
+      // in column order and flushes its per-column sum of w over the hits into macc[] (LDS, integer, order-free)
+      const int E = cp[rd.S];
+      const int c = (E + (int)blockDim.x - 1) / (int)blockDim.x;
+      const int e0 = min(E, tid * c), e1 = min(E, e0 + c);
+      if (e0 < e1) {
+        int i; { int lo = 0, hi = rd.S; while (lo < hi) { const int mid = (lo + hi) >> 1; if (cp[mid + 1] <= e0) lo = mid + 1; else hi = mid; } i = lo; }
+        int d = dl[i]; int cend = cp[i + 1];
+        long long M = 0;
+        for (int e = e0; e < e1; e++) {
+          if (e >= cend) {
+            if (M) atomicAdd(&macc[i], (unsigned long long)M);
+            M = 0;
+            do { i++; cend = cp[i + 1]; } while (e >= cend);
+            d = dl[i];
+          }
+          const uint8_t v = cv[e];
+          if (((v & 32) ? 1 : -1) == sg[cr[e]] * d) M += wl[v & 31];
+        }
+        if (M) atomicAdd(&macc[i], (unsigned long long)M);
       }
-      M = wave_sum_ll(M);
-      if (lane == 0) {
-        const long long het = P.lut.f_het0 - (long long)(c1 - c0) * P.lut.f_log2;  // phase.rs:136-144
-        const long long F = sc[4 * i], W = sc[4 * i + 1];
-        long long N[4] = {F + M + het, F + W - M + het, sc[4 * i + 2] + P.lut.f_homref, sc[4 * i + 3] + P.lut.f_homvar};
-        int ch;
-        if (with_genotype) { ch = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch]) ch = t; }   // phase.rs:908-921
-        else if (h == 0) ch = N[1] > N[0] ? 1 : 0;                                                // phase.rs:923-930
-        else ch = N[3] > N[2] ? 3 : 2;                                                            // phase.rs:931-938
-        const int cur = h == 0 ? 0 : (h == 1 ? 2 : 3);
-        if (N[ch] > N[cur]) any = 1;
-        dl[i] = (int8_t)(ch == 1 ? -d : d);
-        et[i] = (int8_t)(ch <= 1 ? 0 : (ch == 2 ? 1 : -1));
+      __syncthreads();
+      for (int i = tid; i < rd.S; i += blockDim.x) {
+        const long long M = (long long)macc[i];
+        macc[i] = 0;
+        if (!fp[i] || (keep_conserved && cons[i]) || cp[i + 1] == cp[i]) continue;
+        decide(i, M, cp[i + 1] - cp[i]);
+      }
+    } else {
+      for (int i = wave; i < rd.S; i += nw) {
+        if (!fp[i]) continue;
+        if (keep_conserved && cons[i]) continue;
+        const int c0 = cp[i], c1 = cp[i + 1];
+        if (c1 == c0) continue;
+        const int d = dl[i];
+        long long M = 0;  // sum of w over the entries with p == sigma * d
+        for (int e = c0 + lane; e < c1; e += 64) {
+          const uint8_t v = cv[e];
+          if (((v & 32) ? 1 : -1) == sg[cr[e]] * d) M += wl[v & 31];
+        }
+        M = wave_sum_ll(M);
+        if (lane == 0) decide(i, M, c1 - c0);
       }
     }
     any = __syncthreads_or(any);
@@ -725,6 +760,8 @@ __global__ void __launch_bounds__(64) k4_enum_pick(const int32_t* __restrict__ s
 constexpr int CHAIN_THREADS = 1024;   // a chain region is one workgroup: 16 waves shorten its sequential rounds
 __global__ void __launch_bounds__(CHAIN_THREADS) k4_chain_a(PhaseDev P, const int32_t* __restrict__ slots, int32_t n) {
   __shared__ long long red[CHAIN_THREADS / 64];
+  __shared__ unsigned long long macc[CROSS_MACC];
+  for (int i = threadIdx.x; i < CROSS_MACC; i += blockDim.x) macc[i] = 0;
   __shared__ long long wl[32];
   if ((int)blockIdx.x >= n) return;
   load_w(P, wl);
@@ -736,13 +773,15 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k4_chain_a(PhaseDev P, const in
   const uint64_t ctr0 = 2 * (uint64_t)rd.S + (uint64_t)rd.R;  // after S+F (thread.rs) and S (init_haplotypes_LD2)
   for (int row = threadIdx.x; row < rd.R; row += blockDim.x) sg[row] = u01(rd.seed, ctr0 + row) < 0.5 ? -1 : 1;
   __syncthreads();
-  const long long obj = cross_optimize(P, rd, global_view(P, rd), sg, dl, et, true, false, red, wl);
+  const long long obj = cross_optimize(P, rd, global_view(P, rd), sg, dl, et, true, false, red, wl, macc);
   if (threadIdx.x == 0) P.st_obj[slot] = obj;
 }
 
 // chain, part B (phase.rs:1197-1233): perturbation rounds with best-state tracking
 __global__ void __launch_bounds__(CHAIN_THREADS) k4_chain_b(PhaseDev P, const int32_t* __restrict__ slots, int32_t n) {
   __shared__ long long red[CHAIN_THREADS / 64];
+  __shared__ unsigned long long macc[CROSS_MACC];
+  for (int i = threadIdx.x; i < CROSS_MACC; i += blockDim.x) macc[i] = 0;
   __shared__ long long wl[32];
   if ((int)blockIdx.x >= n) return;
   load_w(P, wl);
@@ -781,13 +820,13 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k4_chain_b(PhaseDev P, const in
       else if (rg >= 0.9) dl[i] = flip ? -1 : 1;
     }
     __syncthreads();
-    long long obj = cross_optimize(P, rd, mv, sg, dl, et, false, false, red, wl);
+    long long obj = cross_optimize(P, rd, mv, sg, dl, et, false, false, red, wl, macc);
     save_if_better(obj);
     load_best();
     for (int row = threadIdx.x; row < rd.R; row += blockDim.x)  // phase.rs:1217-1224
       if (u01(rd.seed, ctr_t + rd.S + row) < 0.1) sg[row] = (int8_t)(-sg[row]);
     __syncthreads();
-    obj = cross_optimize(P, rd, mv, sg, dl, et, false, false, red, wl);
+    obj = cross_optimize(P, rd, mv, sg, dl, et, false, false, red, wl, macc);
     save_if_better(obj);
     load_best();
   }
@@ -1949,6 +1988,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       }
       Pc.lds_mat = (int32_t)want;
     }
+    static const hipError_t attr_b_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_chain_b), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    PCHK(attr_b_);   // 17 KB static (column accumulators) + up to 64 KB of state and matrix copy
     hipLaunchKernelGGL(k4_chain_b, dim3(nc), dim3(CHAIN_THREADS), dyn_bytes + (size_t)Pc.lds_mat, side, Pc, b_slots.as<int32_t>(), nc);
     if (dev_post) {
       PostIn pinc = pin;
