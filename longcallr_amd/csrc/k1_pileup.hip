@@ -33,6 +33,7 @@
 #define K1_WAVES (K1_THREADS / 64)
 #define K1_CPT (LCR_TILE / K1_THREADS)  // columns per thread in the tile epilogue
 #define K1_RPB 2                        // records per thread and batch
+#define K1_PIF 4                        // 16-byte pieces in flight per thread (a batch of 1024 records has ~2500 pieces)
 
 // record layout (64 bit): [0,40) byte offset of the first read base | [40,50) tile column |
 // [50,60) length-1 | [60] reverse strand | [61,63) transcript-strand class (0 none, 1 -> [0], 2 -> [1])
@@ -397,12 +398,12 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
         else { atomicAdd(&dp[col], 0xFFFFFFFFu); atomicAdd(&dp[col + 1], 1u); }
       }
     };
-    for (int p = tid; p < P; p += 4 * K1_THREADS) {
-      const Piece q0 = fetch(p), q1 = fetch(p + K1_THREADS), q2 = fetch(p + 2 * K1_THREADS), q3 = fetch(p + 3 * K1_THREADS);
-      tally(q0);
-      tally(q1);
-      tally(q2);
-      tally(q3);
+    for (int p = tid; p < P; p += K1_PIF * K1_THREADS) {
+      Piece q[K1_PIF];
+#pragma unroll
+      for (int x = 0; x < K1_PIF; x++) q[x] = fetch(p + x * K1_THREADS);
+#pragma unroll
+      for (int x = 0; x < K1_PIF; x++) tally(q[x]);
     }
     __syncthreads();
   }

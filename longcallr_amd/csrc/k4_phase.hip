@@ -1988,14 +1988,14 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       }
       Pc.lds_mat = (int32_t)want;
     }
-    static const hipError_t attr_b_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_chain_b), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    PCHK(attr_b_);   // 17 KB static (column accumulators) + up to 64 KB of state and matrix copy
+    // 17 KB static (column accumulators) + up to 64 KB of state and matrix copy (per call: the attribute is per device)
+    PCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_chain_b), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     hipLaunchKernelGGL(k4_chain_b, dim3(nc), dim3(CHAIN_THREADS), dyn_bytes + (size_t)Pc.lds_mat, side, Pc, b_slots.as<int32_t>(), nc);
     if (dev_post) {
       PostIn pinc = pin;
       pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta;
-      static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_post<CHAIN_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      PCHK(attr_);   // 33 KB of static stage buffers + up to 64 KB of region image
+      // 33 KB of static stage buffers + up to 64 KB of region image (set per call: the attribute is per device)
+      PCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_post<CHAIN_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       hipLaunchKernelGGL(k4_post<CHAIN_THREADS>, dim3(nc), dim3(CHAIN_THREADS), post_lds, side, pinc, b_slots.as<int32_t>(), nc, plut);
       PCHK(hipGetLastError());
       PCHK(hipMemcpyAsync(st2 + st_obj, b_stc.as<int8_t>() + st_obj, (size_t)ng * 8, hipMemcpyDeviceToHost, side));

@@ -32,6 +32,7 @@ struct lcr_ctx {
   DevParams dp{};
   float sor_thr = -1.f;
   HostBuf h_planes;
+  HostBuf h_stage[4];   // pinned staging of lcr_candidates / lcr_fragments: survivor offsets, candidate records, keep flags, region rows
 
   // K2
   bool have_cand = false;
@@ -172,7 +173,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
                     &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
                     &c->row_links, &c->row_ptr, &c->col, &c->val};
   for (auto* b : bufs) b->release();
-  HostBuf* hb[] = {&c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
+  HostBuf* hb[] = {&c->h_stage[0], &c->h_stage[1], &c->h_stage[2], &c->h_stage[3], &c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
   for (auto* b : hb) b->release();
   c->phase.release();
   for (int k = 0; k < LCR_NKERNELS; k++) for (int j = 0; j < 2; j++) if (c->ev[k][j]) (void)hipEventDestroy(c->ev[k][j]);
@@ -390,17 +391,15 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
     launch_k2_filter(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
                      c->planes.as<uint32_t>(), c->flags.as<uint8_t>(), c->tile_count.as<int32_t>(), c->stream);
     launch_scan_i32(c->scan_tmp, c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(), nt, c->total.as<int32_t>(), c->stream); }
-  std::vector<int32_t> h_tile_off(nt + 1, 0);
-  int32_t n_sv = 0;
-  if (nt) HIPCHK(c, hipMemcpyAsync(h_tile_off.data(), c->tile_off.p, (size_t)nt * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(&n_sv, c->total.p, 4, hipMemcpyDeviceToHost, c->stream));
+  // survivors per region = tile offsets at the regions' first tiles (gathered on the device, pinned D2H)
+  HIPCHK(c, c->sv_region_off.reserve((ng + 1) * 4));
+  HIPCHK(c, c->h_stage[0].reserve((ng + 2) * 4));
+  launch_gather_i32(c->tile_off.as<int32_t>(), c->first_tile.as<int32_t>(), ng + 1, nt, c->total.as<int32_t>(), c->sv_region_off.as<int32_t>(), c->stream);
+  int32_t* const sv_off = c->h_stage[0].as<int32_t>();
+  HIPCHK(c, hipMemcpyAsync(sv_off, c->sv_region_off.p, (ng + 1) * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
-  h_tile_off[nt] = n_sv;
-  std::vector<int32_t> sv_off(ng + 1);
-  for (int g = 0; g <= ng; g++) sv_off[g] = h_tile_off[c->h_region_first_tile[g]];
-  HIPCHK(c, c->sv_region_off.reserve((ng + 1) * 4));
-  HIPCHK(c, hipMemcpyAsync(c->sv_region_off.p, sv_off.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  const int32_t n_sv = sv_off[ng];
   HIPCHK(c, c->survivors.reserve(std::max(n_sv, 1) * sizeof(Survivor)));
   HIPCHK(c, c->hist.reserve(std::max<size_t>(n_sv, 1) * 124 * 4));
   HIPCHK(c, c->cand_tmp.reserve(std::max<size_t>(n_sv, 1) * sizeof(lcr_candidate)));
@@ -418,10 +417,12 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
     { Timer t(c, LCR_K_CAND_GT);
       launch_k2_gt(c->dp, c->survivors.as<Survivor>(), n_sv, c->hist.as<uint32_t>(), c->bv.start0,
                    c->cand_tmp.as<lcr_candidate>(), c->keep.as<uint8_t>(), c->stream); }
-    std::vector<lcr_candidate> tmp(n_sv);
-    std::vector<uint8_t> keep(n_sv);
-    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->cand_tmp.p, (size_t)n_sv * sizeof(lcr_candidate), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(keep.data(), c->keep.p, n_sv, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, c->h_stage[1].reserve((size_t)n_sv * sizeof(lcr_candidate)));
+    HIPCHK(c, c->h_stage[2].reserve((size_t)n_sv));
+    const lcr_candidate* tmp = c->h_stage[1].as<lcr_candidate>();
+    const uint8_t* keep = c->h_stage[2].as<uint8_t>();
+    HIPCHK(c, hipMemcpyAsync(c->h_stage[1].p, c->cand_tmp.p, (size_t)n_sv * sizeof(lcr_candidate), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_stage[2].p, c->keep.p, n_sv, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     for (int g = 0; g < ng; g++) {
@@ -436,7 +437,14 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->d_cand_off.reserve((ng + 1) * 4));
   if (nc) HIPCHK(c, hipMemcpyAsync(c->d_cand.p, c->h_cand.data(), nc * sizeof(lcr_candidate), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_cand_off.p, c->h_cand_off.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  // rows of the fragment matrix per region (fragment.rs:51-54) depend on the candidates only: computed here so
+  // that lcr_fragments starts without a round trip
+  HIPCHK(c, c->region_rows.reserve(std::max(ng, 1) * 4));
+  HIPCHK(c, c->h_stage[3].reserve(std::max(ng, 1) * 4));
+  launch_k3_rows(c->bv, c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->region_rows.as<int32_t>(), c->stream);
+  if (ng) HIPCHK(c, hipMemcpyAsync(c->h_stage[3].p, c->region_rows.p, ng * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
   c->have_cand = true;
   c->have_frag = c->have_phase = false;
   return LCR_OK;
@@ -459,12 +467,7 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, hipSetDevice(c->device));
   const int ng = c->bv.n_regions;
   c->min_linkers = p->min_linkers;
-  HIPCHK(c, c->region_rows.reserve(std::max(ng, 1) * 4));
-  launch_k3_rows(c->bv, c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->region_rows.as<int32_t>(), c->stream);
-  std::vector<int32_t> rr(ng, 0);
-  if (ng) HIPCHK(c, hipMemcpyAsync(rr.data(), c->region_rows.p, ng * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipGetLastError());
+  const int32_t* rr = c->h_stage[3].as<int32_t>();   // rows per region, from lcr_candidates
   c->h_row_region_off.assign(ng + 1, 0);
   for (int g = 0; g < ng; g++) c->h_row_region_off[g + 1] = c->h_row_region_off[g] + rr[g];
   c->n_rows = c->h_row_region_off[ng];

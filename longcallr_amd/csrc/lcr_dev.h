@@ -138,6 +138,7 @@ void launch_k1_zonefix(const BatchView& b, int D, int L, int64_t n_cols, uint32_
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, uint8_t* flags, int32_t* tile_count,
                       hipStream_t s);
+void launch_gather_i32(const int32_t* src, const int32_t* idx, int32_t n, int32_t n_src, const int32_t* total, int32_t* out, hipStream_t s);
 void launch_scan_i32(DevBuf& tmp, const int32_t* in, int32_t* out_excl, int32_t n, int32_t* total, hipStream_t s);
 void launch_k2_compact(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                        int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const uint8_t* flags,
