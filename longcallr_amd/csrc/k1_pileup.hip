@@ -47,6 +47,15 @@ __global__ void __launch_bounds__(LCR_BLOCK) k0_read_region(const int32_t* __res
   const int g = blockIdx.x;
   for (int r = read_begin[g] + threadIdx.x; r < read_begin[g + 1]; r += blockDim.x) out[r] = g;
 }
+// tile table (one block per region): tile t of region g covers columns [(t - first) * LCR_TILE, ...)
+__global__ void __launch_bounds__(LCR_BLOCK) k0_tiles(const int32_t* __restrict__ first_tile, int32_t* __restrict__ tile_region,
+                                                       int32_t* __restrict__ tile_col0) {
+  const int g = blockIdx.x, t0 = first_tile[g], t1 = first_tile[g + 1];
+  for (int t = t0 + threadIdx.x; t < t1; t += blockDim.x) { tile_region[t] = g; tile_col0[t] = (t - t0) * LCR_TILE; }
+}
+void launch_k0_tiles(const int32_t* first_tile, int32_t n_regions, int32_t* tile_region, int32_t* tile_col0, hipStream_t s) {
+  if (n_regions > 0) hipLaunchKernelGGL(k0_tiles, dim3(n_regions), dim3(LCR_BLOCK), 0, s, first_tile, tile_region, tile_col0);
+}
 void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s) {
   if (b.n_regions == 0) return;
   hipLaunchKernelGGL(k0_read_region, dim3(b.n_regions), dim3(LCR_BLOCK), 0, s, b.read_begin, read_region);

@@ -232,13 +232,20 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
     if (ng) { memcpy(c->h_start0.data(), rg->start0, ng * sizeof(int64_t)); memcpy(c->h_len.data(), rg->len, ng * sizeof(int32_t)); }
     memcpy(c->h_col_off.data(), rg->col_off, (ng + 1) * sizeof(int64_t));
     memcpy(c->h_read_begin.data(), rg->read_begin, (ng + 1) * sizeof(int32_t));
-  } else {
+  } else {   // device-resident batch: the four small region arrays through one pinned buffer, one wait
+    const size_t o1 = (size_t)ng * 8, o2 = o1 + (size_t)(ng + 1) * 8, o3 = o2 + (size_t)ng * 4, tot = o3 + (size_t)(ng + 1) * 4;
+    HIPCHK(c, c->h_stage[0].reserve(tot + 16));
+    uint8_t* st = c->h_stage[0].as<uint8_t>();
     if (ng) {
-      HIPCHK(c, hipMemcpy(c->h_start0.data(), rg->start0, ng * sizeof(int64_t), hipMemcpyDeviceToHost));
-      HIPCHK(c, hipMemcpy(c->h_len.data(), rg->len, ng * sizeof(int32_t), hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpyAsync(st, rg->start0, ng * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(st + o2, rg->len, ng * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCHK(c, hipMemcpy(c->h_col_off.data(), rg->col_off, (ng + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(c->h_read_begin.data(), rg->read_begin, (ng + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpyAsync(st + o1, rg->col_off, (ng + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st + o3, rg->read_begin, (ng + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ng) { memcpy(c->h_start0.data(), st, ng * sizeof(int64_t)); memcpy(c->h_len.data(), st + o2, ng * sizeof(int32_t)); }
+    memcpy(c->h_col_off.data(), st + o1, (ng + 1) * sizeof(int64_t));
+    memcpy(c->h_read_begin.data(), st + o3, (ng + 1) * sizeof(int32_t));
   }
   if (c->h_read_begin[ng] != nr || c->h_col_off[0] != 0) { c->err = "read_begin/col_off inconsistent"; return LCR_E_ARG; }
   for (int g = 0; g < ng; g++)
@@ -264,23 +271,15 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   if ((rc = upload<int32_t>(c, c->in_[14], rg->read_begin, ng + 1, &b.read_begin, mem))) return rc;
   if ((rc = upload<uint8_t>(c, c->in_[15], rg->ref, c->n_cols, &b.ref, mem))) return rc;
 
-  // tile table: tiles never cross a region
-  std::vector<int32_t> treg, tcol;
+  // tile table: tiles never cross a region; first tile per region on the host, the table itself on the device
   c->h_region_first_tile.assign(ng + 1, 0);
-  for (int g = 0; g < ng; g++) {
-    c->h_region_first_tile[g] = (int32_t)treg.size();
-    for (int32_t c0 = 0; c0 < c->h_len[g]; c0 += LCR_TILE) { treg.push_back(g); tcol.push_back(c0); }
-  }
-  c->h_region_first_tile[ng] = (int32_t)treg.size();
-  c->n_tiles = (int32_t)treg.size();
-  HIPCHK(c, c->tile_region.reserve(std::max<size_t>(treg.size(), 1) * 4));
-  HIPCHK(c, c->tile_col0.reserve(std::max<size_t>(tcol.size(), 1) * 4));
-  if (c->n_tiles) {
-    HIPCHK(c, hipMemcpyAsync(c->tile_region.p, treg.data(), treg.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->tile_col0.p, tcol.data(), tcol.size() * 4, hipMemcpyHostToDevice, c->stream));
-  }
+  for (int g = 0; g < ng; g++) c->h_region_first_tile[g + 1] = c->h_region_first_tile[g] + (c->h_len[g] + LCR_TILE - 1) / LCR_TILE;
+  c->n_tiles = c->h_region_first_tile[ng];
+  HIPCHK(c, c->tile_region.reserve(std::max<size_t>(c->n_tiles, 1) * 4));
+  HIPCHK(c, c->tile_col0.reserve(std::max<size_t>(c->n_tiles, 1) * 4));
   HIPCHK(c, c->first_tile.reserve((ng + 1) * 4));
   HIPCHK(c, hipMemcpyAsync(c->first_tile.p, c->h_region_first_tile.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  launch_k0_tiles(c->first_tile.as<int32_t>(), ng, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), c->stream);
   HIPCHK(c, c->errflag.reserve(4));
   HIPCHK(c, c->read_rend.reserve(std::max<size_t>(nr, 1) * 4));
   b.read_rend = c->read_rend.as<int32_t>();
@@ -291,7 +290,7 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   HIPCHK(c, hipMemsetAsync(b.error_flag, 0, 4, c->stream));
   HIPCHK(c, c->read_bin.reserve(std::max<size_t>(nr, 1) * sizeof(ReadBin)));
   launch_k0_pack(b, c->read_bin.as<ReadBin>(), c->stream);
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // keeps treg/tcol alive until copied
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   c->loaded = true;
   return LCR_OK;

@@ -127,6 +127,7 @@ struct PhaseLutDev {
 
 // ---- kernel launchers (defined in the .hip files) ----
 // K0: pass 0 counts records per tile (+ intron difference array, CIGAR validation); pass 1 writes them
+void launch_k0_tiles(const int32_t* first_tile, int32_t n_regions, int32_t* tile_region, int32_t* tile_col0, hipStream_t s);
 void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s);
 void launch_k0_pack(const BatchView& b, ReadBin* out, hipStream_t s);
 void launch_k0_bin(const BatchView& b, const ReadBin* rb, int ont, int D, int32_t* tile_fill, int32_t* tile_lvl,
