@@ -584,11 +584,12 @@ __device__ __forceinline__ void block_scan2(int a, int b, int& ea, int& eb, int&
   block_scan2n<4, 8>(a, b, ea, eb, ta, tb, sm);
 }
 
-__global__ void __launch_bounds__(LCR_BLOCK) k4_stage(StageIn in, StageOut out, PhaseLutDev lut) {
-  static_assert(LCR_BLOCK == 256, "k4_stage assumes 4 waves");
-  __shared__ int sm[2][8];
+constexpr int STAGE_THREADS = 256;    // (1024 threads per region were measured: more barrier cost than latency saved)
+__global__ void __launch_bounds__(STAGE_THREADS) k4_stage(StageIn in, StageOut out, PhaseLutDev lut) {
+  constexpr int NW = STAGE_THREADS / 64;
+  __shared__ int sm[2][16];
   __shared__ int s_max[2];
-  __shared__ long long s_ft[4];
+  __shared__ long long s_ft[NW];
   __shared__ long long s_fe[32], s_f1e[32];
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = in.row_region_off[g], nrow = in.row_region_off[g + 1] - r0;
@@ -603,7 +604,7 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_stage(StageIn in, StageOut out, 
   }
   if (tid < 32) { s_fe[tid] = tid < 31 ? lut.fe[tid] : 0; s_f1e[tid] = tid < 31 ? lut.f1e[tid] : 0; }
   if (tid < 2) s_max[tid] = 0;
-  for (int i = tid; i < S; i += LCR_BLOCK) {
+  for (int i = tid; i < S; i += STAGE_THREADS) {
     const lcr_candidate& c = in.cand[c0 + i];
     out.snp_fp[c0 + i] = (c.flags & LCR_F_FOR_PHASING) ? 1 : 0;
     out.snp_vt[c0 + i] = (int8_t)c.variant_type;
@@ -615,7 +616,7 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_stage(StageIn in, StageOut out, 
   int32_t* pcp = out.ccol_ptr + rd.cp_off;
   // ---- pass 1: phasing rows and their phase-site entries (CSR), column counts
   int R = 0, E = 0;
-  for (int base = 0; base < nrow; base += LCR_BLOCK) {
+  for (int base = 0; base < nrow; base += STAGE_THREADS) {
     const int r = base + tid;
     int isp = 0, cnt = 0;
     int64_t eb = 0, ee = 0;
@@ -627,7 +628,7 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_stage(StageIn in, StageOut out, 
       }
     }
     int k, eo, tk, te;
-    block_scan2(isp, cnt, k, eo, tk, te, sm);
+    block_scan2n<NW, 16>(isp, cnt, k, eo, tk, te, sm);
     if (isp) {
       k += R; eo += E;
       prp[k] = eo;
@@ -646,11 +647,11 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_stage(StageIn in, StageOut out, 
   // ---- column offsets
   {
     int carry = 0;
-    for (int base = 0; base < S; base += LCR_BLOCK) {
+    for (int base = 0; base < S; base += STAGE_THREADS) {
       const int i = base + tid;
       const int v = i < S ? out.cursor[c0 + i] : 0;
       int ex, dummy, tot, tdummy;
-      block_scan2(v, 0, ex, dummy, tot, tdummy, sm);
+      block_scan2n<NW, 16>(v, 0, ex, dummy, tot, tdummy, sm);
       if (i < S) { pcp[i] = carry + ex; out.cursor[c0 + i] = carry + ex; }
       carry += tot;
     }
@@ -660,11 +661,11 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_stage(StageIn in, StageOut out, 
   // ---- pass 2: CSC mirror (phasing-row index, value)
   {
     int Rk = 0;
-    for (int base = 0; base < nrow; base += LCR_BLOCK) {
+    for (int base = 0; base < nrow; base += STAGE_THREADS) {
       const int r = base + tid;
       const int isp = (r < nrow && in.links[r0 + r] >= in.min_linkers) ? 1 : 0;
       int k, dummy, tk, tdummy;
-      block_scan2(isp, 0, k, dummy, tk, tdummy, sm);
+      block_scan2n<NW, 16>(isp, 0, k, dummy, tk, tdummy, sm);
       if (isp) {
         k += Rk;
         for (int64_t e = in.row_ptr[r0 + r]; e < in.row_ptr[r0 + r + 1]; e++) {
@@ -680,7 +681,7 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_stage(StageIn in, StageOut out, 
   __syncthreads();
   // ---- per-SNP constants: F = sum fe, W = sum w, Cref = sum (p==+1 ? f1e : fe), Cvar = sum (p==-1 ? f1e : fe)
   long long ft = 0;
-  for (int i = wave; i < S; i += LCR_BLOCK / 64) {
+  for (int i = wave; i < S; i += NW) {
     long long F = 0, W = 0, Cr = 0, Cv = 0;
     for (int e = pcp[i] + lane; e < pcp[i + 1]; e += 64) {
       const uint8_t v = out.cval[e_base + e];
@@ -703,7 +704,9 @@ __global__ void __launch_bounds__(LCR_BLOCK) k4_stage(StageIn in, StageOut out, 
   }
   __syncthreads();
   if (tid == 0) {
-    rd.R = R; rd.f_total = s_ft[0] + s_ft[1] + s_ft[2] + s_ft[3];
+    long long ftot = 0;
+    for (int w = 0; w < NW; w++) ftot += s_ft[w];
+    rd.R = R; rd.f_total = ftot;
     out.reg[g] = rd;
     out.stat[g] = StageStat{R, E, max(s_max[0], (int)enum_chunk((uint32_t)E)), s_max[1], (int)(in.row_ptr[r0 + nrow] - e_base), 0};
   }
@@ -1647,7 +1650,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     StageOut so{b_reg.as<RegionDev>(), b_stat.as<StageStat>(), b_prp.as<int32_t>(), b_pc.as<int32_t>(), b_pv.as<uint8_t>(),
                 b_cp.as<int32_t>(), b_cr.as<int32_t>(), b_cv.as<uint8_t>(), b_snp.as<uint8_t>(), b_snp.as<int8_t>() + nc1,
                 b_snp.as<uint8_t>() + 2 * nc1, b_sc.as<long long>(), b_cur.as<int32_t>()};
-    hipLaunchKernelGGL(k4_stage, dim3(ng), dim3(LCR_BLOCK), 0, stream, si, so, L.dev);
+    hipLaunchKernelGGL(k4_stage, dim3(ng), dim3(STAGE_THREADS), 0, stream, si, so, L.dev);
     PCHK(hipGetLastError());
     PCHK(hipMemcpyAsync(stat, b_stat.p, (size_t)ng * sizeof(StageStat), hipMemcpyDeviceToHost, stream));
     PCHK(hipMemsetAsync(b_st.p, 0, st_bytes, stream));
