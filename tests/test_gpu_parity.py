@@ -208,6 +208,44 @@ def test_edge_cases(engine_cls, orc):
     full_check(engine_cls, orc, b, p)
 
 
+def _low_fraction_batch(seed, frac=0.3):
+    """80 reads over 3 kb, four ordinary het SNPs (alt on haplotype A) and two sites whose alt allele sits on
+    a fraction of haplotype A's reads only (allele frequency 5-20 %: the low-fraction "somatic" list,
+    candidate.rs:410-417)."""
+    L = 3000
+    rng = np.random.default_rng(seed)
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    alt_of = {"A": "C", "C": "A", "G": "T", "T": "G"}   # never A>G / T>C: those are the RNA-edit class
+    reads = []
+    for k in range(80):
+        hap_a = k % 2 == 0
+        p0, n = int(rng.integers(0, 600)), int(rng.integers(1800, 2300))
+        s = list(ref[p0:p0 + n])
+        for x in (600, 1100, 1700, 2300):
+            if hap_a and p0 <= x < p0 + n:
+                s[x - p0] = alt_of[ref[x]]
+        for x in (900, 2000):
+            if hap_a and rng.random() < frac and p0 <= x < p0 + n:
+                s[x - p0] = alt_of[ref[x]]
+        reads.append(dict(pos=1000 + p0, seq="".join(s), qual=30, cigar="%dM" % len(s), rev=int(rng.integers(0, 2)), region=0))
+    reads.sort(key=lambda r: r["pos"])
+    return helpers.mk_batch(reads, [(1000, ref)])
+
+
+@pytest.mark.parametrize("min_phase_score,rescued", [(13.0, False), (4.0, True)])
+def test_low_fraction_rescue(engine_cls, orc, min_phase_score, rescued):
+    """eval_low_frac_var_phase (snpfrags.rs:283-376): both outcomes of the rescue of a low-fraction site, incl. the
+    random haplotags its unassigned reads receive (counter-based draws in the reference's call order)."""
+    b = _low_fraction_batch(seed=1)
+    c = full_check(engine_cls, orc, b, _abi.make_params("ont-cdna", seed=3, min_phase_score=min_phase_score))
+    som = c[(c["pos"] == 1000 + 900) | (c["pos"] == 1000 + 2000)]
+    assert len(som) >= 1
+    if rescued:
+        assert np.all((som["flags"] & _abi.F_FOR_PHASING) != 0) and np.all(som["phase_score"] > 1.0)
+    else:
+        assert np.all((som["flags"] & _abi.F_CAND_SOMATIC) != 0) and np.all((som["flags"] & _abi.F_FOR_PHASING) == 0)
+
+
 def test_long_deletions_grow_the_record_pool(engine_cls, orc):
     """K0 sizes its record pool from ops + reads + bases / tile; deletion runs that cross dozens of tiles
     exceed that estimate: the stage must notice the overflow, repeat with a larger pool and still agree
