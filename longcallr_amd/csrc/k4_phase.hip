@@ -1,25 +1,25 @@
-// k4_phase.hip — K4: haplotype phasing optimiser on gfx950 + its host control.
+// k4_phase.hip — K4: haplotype phasing on gfx950 (matrix staging, optimiser, post-phase) + its host control.
 //
-// Replaces SNPFrag::phase (reference src/phase.rs:1087-1296) with its kernels cross_optimize
+// Replaces SNPFrag::phase (reference src/phase.rs:1087-1296) with its kernel cross_optimize
 // (phase.rs:810-976) and the probability functions phase.rs:32-49,77-96,128-176,257-276, plus the
-// post-phase sequence of src/thread.rs:168-201 (snpfrags.rs:191-733) as a host epilogue.
+// post-phase sequence of src/thread.rs:168-201 (snpfrags.rs:191-733).
 //
-// Device side.  One workgroup runs one complete cross_optimize (alternating sigma / delta-eta
-// Jacobi steps until neither improves, <= 21 iterations) on one region's phase matrix:
-//   * sigma step: one thread per read row over the CSR slice,
-//   * delta/eta step: one wave64 per SNP column over the CSC mirror, wave-reduced,
-//   * objective: block reduction.
-// Decision arithmetic is exact: every emission term log10(eps_q) / log10(1-eps_q) comes from a
+// Kernels (in launch order; one queue stages + enumerates + post-processes, a second queue carries the
+// few chain regions, see PhaseHost::run):
+//   k4_stage      phase matrices (CSR + CSC, per-SNP constants) of every region from K3's fragment CSR
+//   k4_enum_reg   S <= max_enum_snps: all 2^S enumeration restarts (phase.rs:1097-1122), one wave64 per
+//                 restart with the matrix in registers; k4_enum_big = fallback on global memory
+//   k4_enum_pick  winner = first maximum (`prob > largest_prob`); it is re-run to materialise its state
+//   k4_chain_a/b  S > max_enum_snps: the sequential chain (phase.rs:1123-1233), one workgroup per region:
+//                 launch A = first cross_optimize; the host does the LD-block flip pass (sum-of-ratios f64
+//                 decision, phase.rs:1298-1394); launch B = all perturbation rounds with best-state tracking
+//   k4_post       post-phase assignment, rescue and phase sets (f64, reference observation order)
+// cross_optimize alternates sigma / delta-eta Jacobi steps until neither improves (<= 21 iterations).
+// Its decision arithmetic is exact: every emission term log10(eps_q) / log10(1-eps_q) comes from a
 // 31-entry table in fixed point (scale 2^40, int64), so sums are order-free and every comparison
 // the reference makes on f64 ratio scores (q < qn, argmax q1..q4, prob > largest_prob) becomes an
 // integer comparison of the log sums (the ratios 1 - A/D share a negative denominator D).  See
 // DESIGN.md "Decision arithmetic" for why this equals the reference except on rounding-noise ties.
-//   * S <= max_enum_snps: all 2^S enumeration restarts (phase.rs:1097-1122) run as independent
-//     workgroups in one launch; the winner (first maximum, as `prob > largest_prob`) is re-run to
-//     materialise its state.
-//   * S  > max_enum_snps: the sequential chain (phase.rs:1123-1233) runs inside one workgroup per
-//     region: launch A = first cross_optimize; host does the LD-block flip pass (sum-of-ratios f64
-//     decision, phase.rs:1298-1394); launch B = all perturbation rounds with best-state tracking.
 // rand::thread_rng() is replaced by a counter-based generator evaluated at the draw index the
 // reference's call order implies, so restarts can run in parallel.
 #include <algorithm>
@@ -74,7 +74,6 @@ struct PhaseDev {
   int8_t* scratch; int32_t scratch_stride;                                // per block working state
   int32_t lds_state;                                                      // 1: working state lives in dynamic LDS
   int32_t lds_mat;                                                        // bytes of dynamic LDS behind the state for a matrix copy
-  int32_t dbg;                                                            // LCR_K4_DBG: timing experiments only
   PhaseLutDev lut;
 };
 
@@ -391,7 +390,7 @@ k4_enum_reg(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __res
   const uint32_t e0_init = (uint32_t)__ballot(lane < S && eta_init == 0), ep_init = (uint32_t)__ballot(lane < S && eta_init == 1);
   const int nk = (R + 63) / 64;
   const int wsh = r_a & 63;
-  const uint32_t ne = (P.dbg & 1) ? 0u : (win_e ? 1u : t.ne);
+  const uint32_t ne = win_e ? 1u : t.ne;
   for (uint32_t kk = wave; kk < ne; kk += ENUM_WAVES) {
     const uint32_t e = win_e ? win_e[t.slot] : t.e0 + kk;
     uint32_t dneg = e & smask;            // bit i: delta_i == -1 (doubling order of phase.rs:1099-1106)
@@ -409,10 +408,9 @@ k4_enum_reg(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __res
     bool hg_inc = true, h_inc = true;
     int iters = 0;
     long long obj_i = 0;
-    if (P.dbg & 4) hg_inc = h_inc = false;
     while (hg_inc | h_inc) {
       // ---- sigma step (phase.rs:824-862)
-      if (!(P.dbg & 32)) {
+      {
         const unsigned long long w0 = sgb[r_a >> 6], w1 = sgb[(r_a >> 6) + 1];
         const unsigned long long win = wsh ? (w0 >> wsh) | (w1 << (64 - wsh)) : w0;
         int alo = 0, ahi = 0;
@@ -457,7 +455,7 @@ k4_enum_reg(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __res
         if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
       }
       // ---- delta / eta step (phase.rs:872-959): a lane's chunk is CSC-ordered (SNP index non-decreasing)
-      if (!(P.dbg & 16)) {
+      {
         constexpr int HB = 8;   // look-ups of one batch in flight, then its run-length flush
         int cur = -1; int alo = 0, ahi = 0;
         auto del_batch = [&](const uint32_t* v8) {
@@ -524,7 +522,6 @@ k4_enum_reg(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __res
       wave_lds_sync();
       if (!any2) hg_inc = false; else { hg_inc = true; h_inc = true; }
       if (++iters > 20) break;  // phase.rs:967-972
-      if (P.dbg & 2) break;
     }
     // objective (phase.rs:257-276) = sum over phase entries of fe + hit * w = sum_i (F_i + hits_i) over live SNPs
     const long long total = wave_sum_ll_dpp(obj_i);
@@ -1625,7 +1622,6 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   P.st_sigma = b_st.as<int8_t>() + st_sig; P.st_delta = b_st.as<int8_t>() + st_del; P.st_eta = b_st.as<int8_t>() + st_eta;
   P.st_obj = (long long*)(b_st.as<int8_t>() + st_obj);
   P.lut = L.dev;
-  if (const char* e = getenv("LCR_K4_DBG")) P.dbg = atoi(e);
 
   // ---- queue `side`: fragment matrix to the host (pinned)
   int64_t* const row_ptr_p = h_pin[0].as<int64_t>();
