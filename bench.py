@@ -190,9 +190,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 in, u32 counts, f64 likelihoods, i64 fixed-point phase scores", "data": "synthetic",
-            "config": {"workload": "C3: synthetic ONT-cDNA, %d regions x %d bp, %.0fx mean aligned depth per GPU "
+            "config": {"workload": "%s: synthetic %s reads, %d regions x %d bp, %.0fx mean aligned depth per GPU "
                                    "(%d unique genes tiled x%d), preset %s; step = bind+pileup+candidates+fragments+phase"
-                                   % (batch.n_regions, a.gene_len, a.depth, a.unique_genes, copies, synth.preset_for(a.profile)),
+                                   % ("C3" if a.profile == "ont-cdna" else "C3-shaped", a.profile, batch.n_regions, a.gene_len, a.depth,
+                                      a.unique_genes, copies, synth.preset_for(a.profile)),
                        "columns_per_gpu": cols, "aligned_bases_per_gpu": int(batch.bases.size), "reads_per_gpu": batch.n_reads,
                        "candidates_per_gpu": int(cands.size), "fragment_nnz_per_gpu": int(fm["col"].size),
                        "parallelism": "regions sharded over %d GPU(s), gather to rank 0" % world},
