@@ -484,10 +484,10 @@ k1_zonefix(BatchView b, int D, int L, int64_t n_cols, uint32_t* __restrict__ pla
   const int r = (int)blockIdx.x * rpb + lr;
   if (lr >= rpb || r >= b.n_reads || s >= per - 1) return;
   const int seq_len = b.seq_len[r], lead = b.lead[r], reb = seq_len - b.trail[r];
+  const uint8_t* __restrict__ seq = b.bases + b.seq_off[r];
   const int c = s < D ? lead + s : reb - D + 1 + (s - D);
   if (c < lead || c >= reb) return;                    // not an aligned read offset
   if (s >= D && c - lead < D) return;                  // both zones overlap: offset already covered by slot c-lead
-  const uint8_t* __restrict__ seq = b.bases + b.seq_off[r];
   uint32_t m = 0;  // bit X: a homopolymer window of X starts in [c-L, c+1]
   const long long gabs = (long long)b.seq_off[r] + c - L;   // absolute byte offset of read offset c-L
   if (L <= 6 && c - L >= 0 && c + L <= seq_len - 1 && (gabs & ~3ll) + 16 <= b.n_bases) {
@@ -525,17 +525,32 @@ k1_zonefix(BatchView b, int D, int L, int64_t n_cols, uint32_t* __restrict__ pla
   const int vec = b.len[g];
   const uint32_t* __restrict__ cg = b.cigar + b.cig_off[r];
   const uint32_t ncig = b.n_cig[r];
-  int p = (int)((int64_t)b.pos[r] - b.start0[g]), q = lead > 0 ? lead : 0, col = -1;
+  int col = -1;
   bool found = false;
-  for (uint32_t i = 0; i < ncig && !found; i++) {
-    const int op = cg[i] & 15, len = (int)(cg[i] >> 4);
-    if (op == 0 || op == 7 || op == 8) {
-      if (c < q + len) { col = p + (c - q); found = true; }
-      p += len; q += len;
-    } else if (op == 1) {
-      if (c < q + len) found = true;  // inside an insertion: no column
-      q += len;
-    } else if (op == 2 || op == 3) p += len;
+  if (s < D) {   // leading zone: the op is among the first few
+    int p = (int)((int64_t)b.pos[r] - b.start0[g]), q = lead > 0 ? lead : 0;
+    for (uint32_t i = 0; i < ncig && !found; i++) {
+      const int op = cg[i] & 15, len = (int)(cg[i] >> 4);
+      if (op == 0 || op == 7 || op == 8) {
+        if (c < q + len) { col = p + (c - q); found = true; }
+        p += len; q += len;
+      } else if (op == 1) {
+        if (c < q + len) found = true;  // inside an insertion: no column
+        q += len;
+      } else if (op == 2 || op == 3) p += len;
+    }
+  } else {       // trailing zone: walk back from the read's end (K0 recorded its reference end), the op is among the last few
+    int p = b.read_rend[r], q = reb;   // one past the last reference column / aligned read offset
+    for (int i = (int)ncig - 1; i >= 0 && !found; i--) {
+      const int op = cg[i] & 15, len = (int)(cg[i] >> 4);
+      if (op == 0 || op == 7 || op == 8) {
+        if (c >= q - len) { col = p - (q - c); found = true; }
+        p -= len; q -= len;
+      } else if (op == 1) {
+        if (c >= q - len) found = true;  // inside an insertion: no column
+        q -= len;
+      } else if (op == 2 || op == 3) p -= len;
+    }
   }
   if (col < 0 || col >= vec) return;
   const int64_t o = b.col_off[g] + col;
