@@ -33,6 +33,7 @@
 #define K1_WAVES (K1_THREADS / 64)
 #define K1_CPT (LCR_TILE / K1_THREADS)  // columns per thread in the tile epilogue
 #define K1_RPB 2                        // records per thread and batch
+#define K1_PMAP 4096                     // pieces per batch with a direct piece -> record map in LDS
 #define K1_PIF 4                        // 16-byte pieces in flight per thread (a batch of 1024 records has ~2500 pieces)
 
 // record layout (64 bit): [0,40) byte offset of the first read base | [40,50) tile column |
@@ -262,6 +263,7 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   __shared__ __attribute__((aligned(16))) uint8_t refl[REF_PAD + LCR_TILE + 32];
   __shared__ unsigned long long rec_s[K1_RPB * K1_THREADS];
   __shared__ int pstart[K1_RPB * K1_THREADS + 1];
+  __shared__ uint16_t pown[K1_PMAP];
   __shared__ int wsum[K1_WAVES];
 
   const int tid = threadIdx.x;
@@ -350,6 +352,16 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
     for (int x = 0; x < K1_RPB; x++) { run += npc[x]; pstart[tid * K1_RPB + x + 1] = run; }
     __syncthreads();
     const int P = pstart[K1_RPB * K1_THREADS];
+    // piece -> record map (short segments: a handful of pieces per record); larger batches search pstart[]
+    const bool mapped = P <= K1_PMAP;
+    if (mapped) {
+#pragma unroll
+      for (int x = 0; x < K1_RPB; x++) {
+        const int slot = tid * K1_RPB + x;
+        for (int q = pstart[slot]; q < pstart[slot + 1]; q++) pown[q] = (uint16_t)slot;
+      }
+      __syncthreads();
+    }
     // ---- phase 2: one 16-byte aligned piece of read bases per thread, four pieces in flight per thread
     struct Piece { uint4 v; int colA, k_lo, k_hi, strand; bool ok; };
     auto fetch = [&](int p) -> Piece {
@@ -357,8 +369,11 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
       q.ok = p < P;
       if (!q.ok) { q.v = make_uint4(0, 0, 0, 0); q.colA = 0; q.k_lo = q.k_hi = 0; q.strand = 0; return q; }
       int lo = 0;  // last record with pstart <= p
+      if (mapped) lo = pown[p];
+      else {
 #pragma unroll
-      for (int st = K1_RPB * K1_THREADS / 2; st >= 1; st >>= 1) if (pstart[lo + st] <= p) lo += st;
+        for (int st = K1_RPB * K1_THREADS / 2; st >= 1; st >>= 1) if (pstart[lo + st] <= p) lo += st;
+      }
       const unsigned long long rc = rec_s[lo];
       const long long soff = (long long)(rc & REC_OFF_MASK);
       const int scol = (int)((rc >> 40) & 1023u), slen = (int)((rc >> 50) & 1023u) + 1;
