@@ -114,7 +114,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     copies = max(1, a.genes // a.unique_genes)
-    base = synth.make_batch(a.profile, n_genes=a.unique_genes, gene_len=a.gene_len, depth=a.depth, seed=1000 + rank)
+    base = synth.make_batch(a.profile, n_genes=a.unique_genes, gene_len=a.gene_len, depth=a.depth, seed=1000)  # every rank owns an identically distributed (same seed) C3-sized region set: weak scaling with equal work
     batch = tile_batch(base, copies)
     params = _abi.make_params(synth.preset_for(a.profile), seed=2025)
     reads, regions, keep = to_device(batch, torch, dev)
