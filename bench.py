@@ -123,17 +123,29 @@ def main():
     E = api.Engine(local, params, timing=True)
     E.set_stream(torch.cuda.current_stream().cuda_stream)  # torch.cuda.synchronize() then covers liblcr
 
+    G = shard.RecordGather(dist, dev, _abi.CAND_DTYPE) if dist is not None else None
+    pending = [None]
+
     def step():
         E.load_batch((reads, regions, keep))
         E.fill_data_into_freq_vec()
         t_pile = (E.kernel_ms(_abi.K_PILEUP), E.kernel_ms(_abi.K_SPANS))  # HIP events on the ctx stream
         E.get_candidate_snps().get_fragments().phase()
-        if dist is not None:
-            shard.gather_records(E.candidates()[0], dist, device=dev)
+        if G is not None:   # the gather of this batch's records (HBM to rank 0's HBM) overlaps the next batch's kernels
+            h = G.start(E.candidates_device())
+            if pending[0] is not None:
+                G.finish(pending[0], parse=False)
+            pending[0] = h
         return t_pile
+
+    def drain():   # the last batch is also brought to rank 0's host and decoded
+        if G is not None and pending[0] is not None:
+            G.finish(pending[0], parse=True)
+            pending[0] = None
 
     for _ in range(a.warmup):
         step()
+    drain()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -141,6 +153,7 @@ def main():
     pile_ms = []
     for _ in range(a.steps):
         pile_ms.append(step())
+    drain()   # the last batch's records are on rank 0 before the clock stops
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

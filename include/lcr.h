@@ -201,6 +201,10 @@ int lcr_get_columns(lcr_ctx*, lcr_columns* out);
 /* replaces SNPFrag::get_candidate_snps (candidate.rs:54-528); thread.rs:118-133 */
 int lcr_candidates(lcr_ctx*, const lcr_params*);
 int lcr_get_candidates(lcr_ctx*, lcr_candidate_list* out);
+/* The same records in device memory (HBM), current after lcr_candidates and after lcr_phase: for consumers that stay
+ * on the device, e.g. the multi-GPU gather of result records (thread.rs:204-221 collects them per region). The pointer
+ * is valid until the next lcr_candidates / lcr_load_batch on this ctx. */
+int lcr_get_candidates_device(lcr_ctx*, const lcr_candidate** dev_cand, int32_t* n_cand);
 
 /* replaces SNPFrag::get_fragments (fragment.rs:10-309); thread.rs:136-143 */
 int lcr_fragments(lcr_ctx*, const lcr_params*);

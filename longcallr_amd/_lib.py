@@ -11,7 +11,7 @@ SO_PATH = os.path.join(_HERE, "liblcr.so")
 SYMBOLS = [
     "lcr_params_preset", "lcr_ctx_create", "lcr_ctx_destroy", "lcr_last_error", "lcr_ctx_set_stream",
     "lcr_ctx_sync", "lcr_load_batch", "lcr_pileup", "lcr_get_columns", "lcr_candidates",
-    "lcr_get_candidates", "lcr_fragments", "lcr_get_fragmat", "lcr_phase", "lcr_get_phase_result",
+    "lcr_get_candidates", "lcr_get_candidates_device", "lcr_fragments", "lcr_get_fragmat", "lcr_phase", "lcr_get_phase_result",
     "lcr_enable_timing", "lcr_kernel_ms", "lcr_pileup_bytes", "lcr_pileup_stage_bytes", "lcr_discover_regions", "lcr_version",
 ]
 
@@ -53,6 +53,7 @@ def load():
         getattr(l, f).argtypes = [vp, C.POINTER(_abi.LcrParams)]
     l.lcr_get_columns.argtypes = [vp, C.POINTER(_abi.LcrColumns)]
     l.lcr_get_candidates.argtypes = [vp, C.POINTER(_abi.LcrCandidateList)]
+    l.lcr_get_candidates_device.argtypes = [vp, C.POINTER(vp), C.POINTER(i32)]
     l.lcr_get_fragmat.argtypes = [vp, C.POINTER(_abi.LcrFragmat)]
     l.lcr_get_phase_result.argtypes = [vp, C.POINTER(_abi.LcrPhaseResult)]
     l.lcr_discover_regions.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.c_int64, C.POINTER(_abi.LcrRegionList)]

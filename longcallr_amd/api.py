@@ -107,6 +107,12 @@ class Engine:
         self._chk(self.lib.lcr_get_candidates(self.h, C.byref(o)), "lcr_get_candidates")
         return (_view(o.cand, _abi.CAND_DTYPE, o.n_cand), _view(o.region_off, np.int32, o.n_regions + 1))
 
+    def candidates_device(self):
+        """(device pointer, count) of the candidate records in HBM (current after get_candidate_snps / phase)."""
+        ptr, n = C.c_void_p(), C.c_int32()
+        self._chk(self.lib.lcr_get_candidates_device(self.h, C.byref(ptr), C.byref(n)), "lcr_get_candidates_device")
+        return int(ptr.value or 0), int(n.value)
+
     def fragmat(self):
         o = _abi.LcrFragmat()
         self._chk(self.lib.lcr_get_fragmat(self.h, C.byref(o)), "lcr_get_fragmat")

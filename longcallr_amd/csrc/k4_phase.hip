@@ -2110,6 +2110,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   for_regions(epilogue);
   lap("scatter + post-phase epilogue");
   r_haplotag = haplotag.data(); r_assignment = assignment.data(); r_phase_set = phase_set.data();
+  // keep the device copy of the candidates current (lcr_get_candidates_device)
+  if (ncand) { PCHK(hipMemcpyAsync(const_cast<lcr_candidate*>(in.d_cand), cand.data(), (size_t)ncand * sizeof(lcr_candidate), hipMemcpyHostToDevice, stream)); PCHK(hipStreamSynchronize(stream)); }
   return LCR_OK;
 #undef PCHK
 }

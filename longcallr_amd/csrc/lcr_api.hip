@@ -496,6 +496,14 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   return LCR_OK;
 }
 
+int lcr_get_candidates_device(lcr_ctx* c, const lcr_candidate** dev_cand, int32_t* n_cand) {
+  if (!c || !dev_cand || !n_cand) return LCR_E_ARG;
+  if (!c->have_cand) { c->err = "lcr_get_candidates_device before lcr_candidates"; return LCR_E_STATE; }
+  *dev_cand = c->d_cand.as<lcr_candidate>();
+  *n_cand = (int32_t)c->h_cand.size();
+  return LCR_OK;
+}
+
 int lcr_get_fragmat(lcr_ctx* c, lcr_fragmat* out) {
   if (!c || !out) return LCR_E_ARG;
   if (!c->have_frag) { c->err = "lcr_get_fragmat before lcr_fragments"; return LCR_E_STATE; }

@@ -81,6 +81,45 @@ def test_gather_records_gloo_world2():
     assert qual == [1.5] * 3 + [2.5] * 5
 
 
+def _stream_gather_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G = shard.RecordGather(dist, torch.device("cpu"), _abi.CAND_DTYPE)
+    got, prev = [], None
+    for batch in range(3):   # batch i's gather is finished only after batch i+1's has been started
+        rec = np.zeros(2 + rank + batch, dtype=_abi.CAND_DTYPE)
+        rec["pos"] = 1000 * batch + 100 * rank + np.arange(rec.size)
+        h = G.start(rec)
+        if prev is not None:
+            got.append(G.finish(prev))
+        prev = h
+    got.append(G.finish(prev))
+    if rank == 0:
+        q.put([g["pos"].tolist() for g in got])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_record_gather_stream_gloo_world2():
+    """RecordGather (bench.py's overlapped gather): fixed capacity agreed once, counts in the header."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_stream_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for batch, pos in enumerate(got):
+        want = [1000 * batch + k for k in range(2 + batch)] + [1000 * batch + 100 + k for k in range(3 + batch)]
+        assert pos == want
+
+
 def test_vcf_formatter_matches_oracle_text(orc):
     """longcallr_amd.vcf (product formatter) on oracle candidates == the oracle's own text."""
     from longcallr_amd import vcf
