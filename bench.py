@@ -113,8 +113,8 @@ def cpu_baseline(batch, params, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--profile", default="ont-cdna")
     ap.add_argument("--genes", type=int, default=400)
     ap.add_argument("--unique-genes", type=int, default=50)
