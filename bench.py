@@ -114,12 +114,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--profile", default="ont-cdna")
     ap.add_argument("--genes", type=int, default=400)
     ap.add_argument("--unique-genes", type=int, default=50)
     ap.add_argument("--gene-len", type=int, default=25000)
     ap.add_argument("--depth", type=float, default=40.0)
+    ap.add_argument("--prewarm", type=int, default=40,
+                    help="untimed passes during setup, before the W warm-up steps: allocations, thread pool, GPU clocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     a = ap.parse_args()
@@ -169,7 +171,7 @@ def main():
             G.finish(pending[0], parse=True)
             pending[0] = None
 
-    for _ in range(a.warmup):
+    for _ in range(a.prewarm + a.warmup):
         step()
     drain()
     if dist is not None:
