@@ -583,7 +583,111 @@ k1_zonefix(BatchView b, int D, int L, int64_t n_cols, uint32_t* __restrict__ pla
   if (ts != 0) atomicSub(&planes[(int64_t)(((strand == 0) == (ts == 1)) ? LCR_PL_TS_FWD : LCR_PL_TS_REV) * n_cols + o], 1u);
 }
 
-void launch_k1_zonefix(const BatchView& b, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s) {
+void launch_k1_zonefix_slots(const BatchView& b, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s);
+// K1z, one thread per read END (dist_to_end <= 63): the per-offset kernel above loads and scans an overlapping
+// 2L+1 byte window for each of the 2D offsets of a read; here a thread loads the <= D + 2L bytes its zone's
+// windows can touch once (16-byte loads into LDS), finds every homopolymer window [t, t+L-1] of X in {A,C,G,T}
+// in one pass and marks the offsets c in [t-1, t+L] it masks (the same rule: window start in [c-L, c+1]) in a
+// 64-bit mask per base; most read ends have none and stop there.  The marked offsets are then walked with a CIGAR
+// cursor (forwards in the leading zone, backwards from the read's reference end in the trailing zone).
+#define ZF_BYTES 112   // LDS bytes per thread: (63 + 2 * 16) zone bytes + 15 alignment slack, rounded to 16
+__global__ void __launch_bounds__(LCR_BLOCK)
+k1_zonefix_ends(BatchView b, const ReadBin* __restrict__ rbin, int D, int L, int64_t n_cols, uint32_t* __restrict__ planes) {
+  __shared__ __attribute__((aligned(16))) uint8_t zb[LCR_BLOCK * ZF_BYTES];
+  const int id = blockIdx.x * LCR_BLOCK + threadIdx.x;
+  const int r = id >> 1, end = id & 1;
+  if (r >= b.n_reads) return;
+  const int seq_len = b.seq_len[r], lead = b.lead[r], reb = seq_len - b.trail[r];
+  const int zlo = end == 0 ? lead : max(reb - D + 1, lead + D);
+  const int zhi = end == 0 ? min(lead + D, reb) - 1 : reb - 1;
+  if (zlo > zhi) return;
+  const int lo = max(zlo - L, 0), hi = min(zhi + L, seq_len - 1);
+  const long long g0 = (long long)b.seq_off[r] + lo, ga = g0 & ~15ll;
+  const int sh = (int)(g0 - ga);
+  uint8_t* mine = zb + threadIdx.x * ZF_BYTES;
+  for (int o = 0; o < sh + (hi - lo + 1); o += 16) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ga + o + 16 <= b.n_bases) v = *reinterpret_cast<const uint4*>(b.bases + ga + o);
+    else { uint32_t t[4] = {0, 0, 0, 0}; for (int x = 0; x < 16; x++) if (ga + o + x < b.n_bases) t[x >> 2] |= (uint32_t)b.bases[ga + o + x] << (8 * (x & 3)); v = make_uint4(t[0], t[1], t[2], t[3]); }
+    *reinterpret_cast<uint4*>(mine + o) = v;
+  }
+  const uint8_t* by = mine + sh - lo;   // by[i] = read byte i for lo <= i <= hi
+  unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};   // per base X: offsets c - zlo masked by a window of X
+  {
+    int run = 0; uint32_t prev = 0x100u;
+    for (int i = lo; i <= hi; i++) {
+      const uint32_t cur = by[i];
+      run = cur == prev ? run + 1 : 1;
+      prev = cur;
+      if (run >= L) {
+        const int x = cur == 'A' ? 0 : cur == 'C' ? 1 : cur == 'G' ? 2 : cur == 'T' ? 3 : -1;
+        if (x >= 0) {   // window start t = i - L + 1 masks c in [t-1, t+L] = [i-L, i+1]
+          const int c0 = max(i - L, zlo) - zlo, c1 = min(i + 1, zhi) - zlo;
+          if (c0 <= c1) {
+            const unsigned long long rng = (c1 >= 63 ? ~0ull : ((2ull << c1) - 1ull)) & ~((1ull << c0) - 1ull);
+            m[x] |= rng;
+          }
+        }
+      }
+    }
+  }
+  unsigned long long any = m[0] | m[1] | m[2] | m[3];
+  if (any == 0ull) return;
+  const int g = region_of_read(b, r);
+  const int vec = b.len[g];
+  const uint32_t* __restrict__ cg = b.cigar + b.cig_off[r];
+  const int ncig = (int)b.n_cig[r];
+  const int fl = b.flags[r];
+  const int strand = fl & 1, ts = (fl >> 1) & 3;
+  const int64_t cbase = b.col_off[g];
+  auto fix = [&](int c, int col) {   // base at read offset c sits on column col: undo its counts if a window of X != ref masks it
+    if (col < 0 || col >= vec) return;
+    const int64_t o = cbase + col;
+    const uint8_t R = b.ref[o];
+    const int k = c - zlo;
+    const uint32_t mm = (uint32_t)((m[0] >> k) & 1ull) | ((uint32_t)((m[1] >> k) & 1ull) << 1) | ((uint32_t)((m[2] >> k) & 1ull) << 2) |
+                        ((uint32_t)((m[3] >> k) & 1ull) << 3);
+    const uint32_t rbit = R == 'A' ? 1u : R == 'C' ? 2u : R == 'G' ? 4u : R == 'T' ? 8u : 0u;
+    if ((mm & ~rbit) == 0) return;
+    const int bi = base_code(by[c]);
+    if (bi >= 0) {
+      atomicSub(&planes[(int64_t)(LCR_PL_A + bi) * n_cols + o], 1u);
+      if (strand == 0) atomicSub(&planes[(int64_t)(LCR_PL_FWD_A + bi) * n_cols + o], 1u);
+    }
+    if (ts != 0) atomicSub(&planes[(int64_t)(((strand == 0) == (ts == 1)) ? LCR_PL_TS_FWD : LCR_PL_TS_REV) * n_cols + o], 1u);
+  };
+  if (end == 0) {   // forwards: ops in read order, every marked offset inside an M op gets its column
+    int p = (int)((int64_t)b.pos[r] - b.start0[g]), q = lead > 0 ? lead : 0;
+    for (int i = 0; i < ncig && q <= zhi; i++) {
+      const int op = cg[i] & 15, len = (int)(cg[i] >> 4);
+      if (op == 0 || op == 7 || op == 8) {
+        for (int c = max(q, zlo); c < q + len && c <= zhi; c++) if ((any >> (c - zlo)) & 1ull) fix(c, p + (c - q));
+        p += len; q += len;
+      } else if (op == 1) q += len;
+      else if (op == 2 || op == 3) p += len;
+    }
+  } else {          // backwards from the read's reference end (recorded by K0)
+    int p = b.read_rend[r], q = reb;
+    for (int i = ncig - 1; i >= 0 && q > zlo; i--) {
+      const int op = cg[i] & 15, len = (int)(cg[i] >> 4);
+      if (op == 0 || op == 7 || op == 8) {
+        for (int c = min(q - 1, zhi); c >= q - len && c >= zlo; c--) if ((any >> (c - zlo)) & 1ull) fix(c, p - (q - c));
+        p -= len; q -= len;
+      } else if (op == 1) q -= len;
+      else if (op == 2 || op == 3) p -= len;
+    }
+  }
+}
+
+void launch_k1_zonefix(const BatchView& b, const ReadBin* rbin, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s) {
+  if (b.n_reads > 0 && D > 0 && D <= 63 && L <= 16) {
+    const int n = 2 * b.n_reads;
+    hipLaunchKernelGGL(k1_zonefix_ends, dim3((unsigned)((n + LCR_BLOCK - 1) / LCR_BLOCK)), dim3(LCR_BLOCK), 0, s, b, rbin, D, L, n_cols, planes);
+    return;
+  }
+  launch_k1_zonefix_slots(b, D, L, n_cols, planes, s);
+}
+void launch_k1_zonefix_slots(const BatchView& b, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s) {
   if (b.n_reads == 0 || D <= 0) return;
   const int rpb = LCR_BLOCK / (2 * D);
   hipLaunchKernelGGL(k1_zonefix, dim3((unsigned)((b.n_reads + rpb - 1) / rpb)), dim3(LCR_BLOCK), 0, s, b, D, L, n_cols, planes);

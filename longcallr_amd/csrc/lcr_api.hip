@@ -339,7 +339,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
                        c->k0_tile_fill.as<int32_t>(), c->k0_tile_count.as<int32_t>(), c->k0_items.as<unsigned long long>(),
                        c->nscan.as<int32_t>(), c->planes.as<uint32_t>(), c->stream);
       if (!c->dp.ont && c->dp.dist_to_end > 0)
-        launch_k1_zonefix(b, c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->stream); }
+        launch_k1_zonefix(b, c->read_bin.as<ReadBin>(), c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->stream); }
     // record count (byte accounting) and CIGAR validation result
     launch_scan_i32(c->scan_tmp, c->k0_tile_fill.as<int32_t>(), c->k0_tile_off.as<int32_t>(), nt, c->k0_tile_off.as<int32_t>() + nt, c->stream);
     HIPCHK(c, hipMemcpyAsync(&n_recs, c->k0_tile_off.as<int32_t>() + nt, 4, hipMemcpyDeviceToHost, c->stream));
