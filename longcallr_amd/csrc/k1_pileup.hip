@@ -218,9 +218,131 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* _
   if (lane == 0 && n_items) atomicAdd(pool_top + 1, n_items);
 }
 
+// K0 for reads with few CIGAR ops (HiFi: ~8 per read): the same single pass with SIXTEEN lanes (one DPP row) per
+// read, four reads per wave64 -- a whole wave per read leaves 56 lanes idle there.  All ballots are taken over the
+// wave and restricted to the lane's row; the per-read state lives in every lane of the row.
+__global__ void __launch_bounds__(LCR_BLOCK)
+k0_bin16(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* __restrict__ tile_fill,
+         int32_t* __restrict__ tile_lvl, unsigned int* __restrict__ pool_top, unsigned int pool_cap,
+         unsigned long long* __restrict__ recs, uint32_t* __restrict__ ndiff) {
+  const int lane = threadIdx.x & 63, l16 = lane & 15, rbase = lane & 48;
+  const unsigned long long rowmask = 0xFFFFull << rbase;
+  const unsigned long long below = ((1ull << l16) - 1ull) << rbase;   // the lanes of my row below me
+  const unsigned long long self = 1ull << lane;
+  const int n_groups = gridDim.x * (LCR_BLOCK / 16);
+  const int n_steps = (b.n_reads + n_groups - 1) / n_groups;
+  unsigned int n_items = 0;
+  int r = (int)((blockIdx.x * LCR_BLOCK + threadIdx.x) >> 4);
+  for (int step = 0; step < n_steps; step++, r += n_groups) {
+    const bool live = r < b.n_reads;
+    // the 64-byte header: lane k of the row loads dword k, fields are broadcast inside the row
+    const uint32_t hw = live ? reinterpret_cast<const uint32_t*>(rbin + r)[l16] : 0u;
+    auto hf = [&](int kx) { return (uint32_t)__shfl((int)hw, rbase + kx, 64); };
+    const int rel_pos = (int)hf(0), vec = (int)hf(1), ftile = (int)hf(2);
+    const uint32_t ncig = live ? hf(3) : 0u;
+    const int64_t gbase = (int64_t)(((unsigned long long)hf(5) << 32) | hf(4));
+    const unsigned long long seq_off = ((unsigned long long)hf(7) << 32) | hf(6);
+    const unsigned long long cig_off = ((unsigned long long)hf(9) << 32) | hf(8);
+    const int lead = (int)hf(10), reb = (int)hf(11), flags = (int)hf(12);
+    const uint32_t* __restrict__ cg = b.cigar + cig_off;
+    const int strand = flags & 1, ts = (flags >> 1) & 3;
+    const unsigned long long tscls = ts == 0 ? 0ull : ((strand == 0) == (ts == 1) ? 1ull : 2ull);
+    const unsigned long long hi_bits = ((unsigned long long)strand << 60) | (tscls << 61);
+    int ref_cur = rel_pos;
+    int q_cur = lead > 0 ? lead : 0;
+    for (uint32_t c0 = 0; __any(c0 < ncig); c0 += 16) {
+      const bool act = c0 + l16 < ncig;
+      const uint32_t w = act ? cg[c0 + l16] : 0u;
+      const int op = w & 15, len = (int)(w >> 4);
+      const bool is_m = act && (op == 0 || op == 7 || op == 8);
+      const bool is_d = act && op == 2, is_n = act && op == 3, is_i = act && op == 1;
+      if (act && !(is_m || is_d || is_n || is_i || op == 4 || op == 5)) atomicExch(b.error_flag, 1);
+      const int dr = (is_m || is_d || is_n) ? len : 0;
+      const int dq = (is_m || is_i) ? len : 0;
+      const int ir = row16_incl_scan(dr), iq = row16_incl_scan(dq);
+      const int rs = ref_cur + ir - dr;   // region-relative column where this op starts
+      const int qs = q_cur + iq - dq;     // read offset where this op starts
+      int a = max(rs, 0), e = min(rs + len, vec);
+      if (is_n && e > a) {  // util.rs:930-942
+        atomicAdd(&ndiff[gbase + a], 1u);
+        atomicAdd(&ndiff[gbase + e], 0xFFFFFFFFu);
+      }
+      if (ont && is_m) {  // ONT end trim (util.rs:745-751)
+        a = max(a, rs + (lead + D - qs));
+        e = min(e, rs + (reb - D + 1 - qs));
+      }
+      bool has = (is_m || is_d) && len > 0 && e > a;
+      if (is_i && len > 0 && rs >= 1 && rs < vec) { has = true; a = rs - 1; e = rs; }
+      { const int nh = __popcll(__ballot(has)); if (lane == 0) n_items += (unsigned int)nh; }
+      int t_cur = has ? a / LCR_TILE : INT_MAX;
+      const int t_last = has ? (e - 1) / LCR_TILE : -1;
+      for (;;) {   // rounds, as in k0_bin, with every mask restricted to the lane's row
+        const bool emit = has && t_cur <= t_last;
+        const unsigned long long em = __ballot(emit);
+        if (em == 0ull) break;
+        const unsigned long long em_below = em & below;
+        const int prev_lane = em_below ? 63 - __clzll((long long)em_below) : 0;
+        const int prev_tile = __shfl(t_cur, prev_lane, 64);
+        const bool leader = emit && (em_below == 0ull || prev_tile != t_cur);
+        const unsigned long long lm = __ballot(leader);
+        const unsigned long long lm_le = lm & (below | self);
+        const int my_leader = lm_le ? 63 - __clzll((long long)lm_le) : 0;
+        int base = 0;
+        if (leader) {
+          const unsigned long long above = rowmask & ~(below | self);
+          const unsigned long long nxt = lm & above;
+          const unsigned long long run = nxt ? (em & above & ((1ull << (__ffsll((long long)nxt) - 1)) - 1ull)) : (em & above);
+          base = atomicAdd(&tile_fill[ftile + t_cur], 1 + __popcll(run));
+        }
+        base = __shfl(base, my_leader, 64);
+        int slot = 0, lvl = 0;
+        if (emit) {
+          const unsigned long long leader_below = ((1ull << (my_leader & 15)) - 1ull) << rbase;
+          slot = base + __popcll(em_below & ~leader_below);   // tile-relative
+          lvl = rec_level(slot);
+          if (slot == rec_level_first(lvl)) {
+            const unsigned int at = atomicAdd(pool_top, 64u << lvl);
+            if (at + (64u << lvl) > pool_cap) atomicExch(b.error_flag, 3);
+            __hip_atomic_store(&tile_lvl[(ftile + t_cur) * LCR_REC_LEVELS + lvl], (int)at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (emit) {
+          int at, spins = 0;
+          while ((at = __hip_atomic_load(&tile_lvl[(ftile + t_cur) * LCR_REC_LEVELS + lvl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 24)) { atomicExch(b.error_flag, 4); at = (int)pool_cap; break; }
+          }
+          const int c_lo = max(a, t_cur * LCR_TILE), c_hi = min(e, (t_cur + 1) * LCR_TILE);
+          unsigned long long rec = ((unsigned long long)(c_lo - t_cur * LCR_TILE) << 40) |
+                                   ((unsigned long long)(c_hi - c_lo - 1) << 50);
+          if (is_m) rec |= ((seq_off + (unsigned long long)(qs + (c_lo - rs))) & REC_OFF_MASK) | hi_bits;
+          else rec |= is_d ? REC_KIND_D : REC_KIND_I;
+          const unsigned int at_slot = (unsigned int)at + (unsigned int)(slot - rec_level_first(lvl));
+          if (at_slot < pool_cap) recs[at_slot] = rec;
+        }
+        if (emit) t_cur++;
+      }
+      ref_cur += __shfl(ir, rbase + 15, 64);
+      q_cur += __shfl(iq, rbase + 15, 64);
+      if (live && c0 < ncig && c0 + 16 >= ncig && l16 == 0 && q_cur != reb) atomicExch(b.error_flag, 2);
+    }
+    if (live && l16 == 0) b.read_rend[r] = ref_cur;
+  }
+  if (lane == 0 && n_items) atomicAdd(pool_top + 1, n_items);
+}
+
 void launch_k0_bin(const BatchView& b, const ReadBin* rb, int ont, int D, int32_t* tile_fill, int32_t* tile_lvl,
-                   unsigned int* pool_top, unsigned int pool_cap, unsigned long long* recs, uint32_t* ndiff, hipStream_t s) {
+                   unsigned int* pool_top, unsigned int pool_cap, unsigned long long* recs, uint32_t* ndiff, int64_t n_cigar,
+                   hipStream_t s) {
   if (b.n_reads == 0) return;
+  bool narrow = n_cigar <= 24 * (int64_t)b.n_reads;   // few ops per read (HiFi): sixteen lanes per read
+  if (const char* e = getenv("LCR_K0_LANES")) narrow = atoi(e) == 16;   // test hook: force either kernel
+  if (narrow) {
+    const int per = LCR_BLOCK / 16;
+    const int blocks = std::min((b.n_reads + per - 1) / per, 256 * 8);
+    hipLaunchKernelGGL(k0_bin16, dim3(blocks), dim3(LCR_BLOCK), 0, s, b, rb, ont, D, tile_fill, tile_lvl, pool_top, pool_cap, recs, ndiff);
+    return;
+  }
   const int per = LCR_BLOCK / 64;
   const int blocks = std::min((b.n_reads + per - 1) / per, 256 * 8);  // persistent and co-resident: 8 workgroups per CU
   hipLaunchKernelGGL(k0_bin, dim3(blocks), dim3(LCR_BLOCK), 0, s, b, rb, ont, D, tile_fill, tile_lvl, pool_top, pool_cap, recs, ndiff);

@@ -134,6 +134,16 @@ def test_chain_path_many_snps(engine_cls, orc):
     assert max(np.bincount(c["region"])) > 10
 
 
+@pytest.mark.parametrize("lanes", ["16", "64"])
+def test_k0_lane_widths(engine_cls, orc, monkeypatch, lanes):
+    """K0 with 16 lanes per read (few CIGAR ops, HiFi) and with a wave per read (ONT) give the same planes on
+    both kinds of reads (demo.bam: up to 118 ops per read, several 16-op chunks; ONT-like: ~56 ops)."""
+    monkeypatch.setenv("LCR_K0_LANES", lanes)
+    full_check(engine_cls, orc, helpers.demo_batch(), _abi.make_params("hifi-masseq"), "chr20")
+    b = synth.make_batch("ont-cdna", n_genes=3, gene_len=9000, depth=35, seed=12)
+    full_check(engine_cls, orc, b, _abi.make_params("ont-cdna", seed=12))
+
+
 @pytest.mark.parametrize("hook", ["LCR_ENUM_FORCE_STREAM", "LCR_ENUM_FORCE_BIG", "LCR_POST_HOST"])
 def test_fallback_device_paths(engine_cls, orc, monkeypatch, hook):
     """The size-dependent fallbacks of the phase stage give the same results as the default kernels:
