@@ -218,8 +218,9 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* _
   if (lane == 0 && n_items) atomicAdd(pool_top + 1, n_items);
 }
 
-// K0 for reads with few CIGAR ops (HiFi: ~8 per read): the same single pass with SIXTEEN lanes (one DPP row) per
-// read, four reads per wave64 -- a whole wave per read leaves 56 lanes idle there.  All ballots are taken over the
+// K0 for reads with up to a few dozen CIGAR ops: the same single pass with SIXTEEN lanes (one DPP row) per read,
+// four reads per wave64 -- a whole wave per read leaves most lanes idle on HiFi reads (~8 ops), and even at ~56 ops
+// (ONT) four shorter dependent chains per wave beat one long one.  All ballots are taken over the
 // wave and restricted to the lane's row; the per-read state lives in every lane of the row.
 __global__ void __launch_bounds__(LCR_BLOCK)
 k0_bin16(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* __restrict__ tile_fill,
@@ -335,7 +336,9 @@ void launch_k0_bin(const BatchView& b, const ReadBin* rb, int ont, int D, int32_
                    unsigned int* pool_top, unsigned int pool_cap, unsigned long long* recs, uint32_t* ndiff, int64_t n_cigar,
                    hipStream_t s) {
   if (b.n_reads == 0) return;
-  bool narrow = n_cigar <= 24 * (int64_t)b.n_reads;   // few ops per read (HiFi): sixteen lanes per read
+  // sixteen lanes per read up to a mean of 64 ops per read (measured: HiFi-like, 9 ops: 0.55 -> 0.44 ms; ONT-like,
+  // 56 ops: 0.83 -> 0.76 ms), a wave per read for longer CIGARs
+  bool narrow = n_cigar <= 64 * (int64_t)b.n_reads;
   if (const char* e = getenv("LCR_K0_LANES")) narrow = atoi(e) == 16;   // test hook: force either kernel
   if (narrow) {
     const int per = LCR_BLOCK / 16;
