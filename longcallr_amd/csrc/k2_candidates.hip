@@ -357,7 +357,7 @@ static GtConst make_gt_const() {
 
 __global__ void __launch_bounds__(LCR_BLOCK)
 k2_gt(DevParams prm, GtConst gc, const Survivor* __restrict__ sv, int32_t n_sv, const uint32_t* __restrict__ hist,
-      const int64_t* __restrict__ start0, lcr_candidate* __restrict__ out, uint8_t* __restrict__ keep) {
+      const int64_t* __restrict__ start0, lcr_candidate* __restrict__ out, int32_t* __restrict__ keep) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_sv) return;
   const Survivor v = sv[s];
@@ -450,7 +450,7 @@ k2_gt(DevParams prm, GtConst gc, const Survivor* __restrict__ sv, int32_t n_sv, 
 }
 
 void launch_k2_gt(const DevParams& p, const Survivor* sv, int32_t n_sv, const uint32_t* hist, const int64_t* start0,
-                  lcr_candidate* out, uint8_t* keep, hipStream_t s) {
+                  lcr_candidate* out, int32_t* keep, hipStream_t s) {
   static const GtConst g_gtc = make_gt_const();  // host libm values: the device only adds/multiplies them
   if (n_sv == 0) return;
   hipLaunchKernelGGL(k2_gt, dim3((n_sv + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, p, g_gtc, sv, n_sv, hist, start0, out, keep);
@@ -474,4 +474,60 @@ float lcr_device_sor_threshold(hipStream_t s) {
   (void)hipStreamSynchronize(s);
   (void)hipFree(d);
   return h;
+}
+
+// ---- pass 3: ordered compaction of the kept candidates and the dense-cluster sweep ---------------
+// kept survivor s -> candidate slot pos[s] (exclusive scan of keep); a region's candidates stay contiguous
+__global__ void __launch_bounds__(LCR_BLOCK)
+k2_scatter(const lcr_candidate* __restrict__ tmp, const int32_t* __restrict__ keep, const int32_t* __restrict__ pos, int32_t n_sv,
+           lcr_candidate* __restrict__ out) {
+  // 128-byte records: eight 16-byte words per record, one word per thread (coalesced both ways)
+  const int64_t id = (int64_t)blockIdx.x * LCR_BLOCK + threadIdx.x;
+  const int s = (int)(id >> 3), w = (int)(id & 7);
+  if (s >= n_sv || !keep[s]) return;
+  reinterpret_cast<uint4*>(out + pos[s])[w] = reinterpret_cast<const uint4*>(tmp + s)[w];
+}
+// candidate.rs:465-526, one thread per region over its candidates [lo, hi) in position order: windows of
+// >= min_dense_cnt het/hom candidates within dense_win bp, and of >= 3 within 5 bp (`tk in i..j` excludes j),
+// are marked dense and taken out of phasing.  idx = scratch list of the region's het/hom candidates.
+__global__ void __launch_bounds__(64)
+k2_dense(lcr_candidate* __restrict__ cand, const int32_t* __restrict__ cand_off, int32_t n_regions, int32_t* __restrict__ idx,
+         uint32_t dense_win, uint32_t min_dense_cnt) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_regions) return;
+  const int lo = cand_off[g], hi = cand_off[g + 1];
+  int32_t* concat = idx + lo;
+  int n = 0;
+  for (int i = lo; i < hi; i++) if (cand[i].flags & (LCR_F_HOM | LCR_F_HET)) concat[n++] = i;
+  auto mark = [&](int i, int j) {
+    for (int tk = i; tk < j; tk++) { cand[concat[tk]].flags |= LCR_F_DENSE; cand[concat[tk]].flags &= ~(uint32_t)LCR_F_FOR_PHASING; }
+  };
+  for (int i = 0; i < n; i++) {
+    const int64_t start_pos = cand[concat[i]].pos;
+    for (int j = i; j < n; j++) {
+      const int64_t diff = cand[concat[j]].pos - start_pos;
+      if (diff > (int64_t)dense_win) { if ((uint32_t)(j - i) >= min_dense_cnt) mark(i, j); break; }
+      if (j == n - 1 && (uint32_t)(j - i + 1) >= min_dense_cnt) mark(i, j);
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    const int64_t start_pos = cand[concat[i]].pos;
+    for (int j = i; j < n; j++) {
+      const int64_t diff = cand[concat[j]].pos - start_pos;
+      if (diff >= 5) { if ((uint32_t)(j - i) >= 3) mark(i, j); break; }
+      if (j == n - 1 && (uint32_t)(j - i + 1) >= 3) mark(i, j);
+    }
+  }
+}
+void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t* keep, int32_t n_sv, const int32_t* sv_region_off,
+                      int32_t n_regions, int32_t* pos /* n_sv + 1 */, int32_t* idx /* n_sv */, lcr_candidate* out,
+                      int32_t* cand_off /* n_regions + 1 */, uint32_t dense_win, uint32_t min_dense_cnt, hipStream_t s) {
+  // pos = exclusive scan of keep, pos[n_sv] = number of candidates; cand_off[g] = pos[sv_region_off[g]]
+  launch_scan_i32(scan_tmp, keep, pos, n_sv, pos + n_sv, s);
+  launch_gather_i32(pos, sv_region_off, n_regions + 1, n_sv, pos + n_sv, cand_off, s);
+  if (n_sv > 0) {
+    const int64_t nthreads = (int64_t)n_sv * 8;
+    hipLaunchKernelGGL(k2_scatter, dim3((unsigned)((nthreads + LCR_BLOCK - 1) / LCR_BLOCK)), dim3(LCR_BLOCK), 0, s, tmp, keep, pos, n_sv, out);
+  }
+  if (n_regions > 0) hipLaunchKernelGGL(k2_dense, dim3((n_regions + 63) / 64), dim3(64), 0, s, out, cand_off, n_regions, idx, dense_win, min_dense_cnt);
 }

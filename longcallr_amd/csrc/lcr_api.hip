@@ -96,33 +96,6 @@ int upload(lcr_ctx* c, DevBuf& buf, const T* src, size_t n, const T** dst, int m
   return LCR_OK;
 }
 
-// candidate.rs:465-526 on one region's candidates [lo, hi) (position order)
-void dense_filter(std::vector<lcr_candidate>& cand, int lo, int hi, uint32_t dense_win, uint32_t min_dense_cnt) {
-  std::vector<int> concat;
-  for (int i = lo; i < hi; i++)
-    if (cand[i].flags & (LCR_F_HOM | LCR_F_HET)) concat.push_back(i);  // homo_snps U het_snps, sorted by index
-  const size_t n = concat.size();
-  auto mark = [&](size_t i, size_t j) {
-    for (size_t tk = i; tk < j; tk++) { cand[concat[tk]].flags |= LCR_F_DENSE; cand[concat[tk]].flags &= ~(uint32_t)LCR_F_FOR_PHASING; }
-  };
-  for (size_t i = 0; i < n; i++) {
-    const int64_t start_pos = cand[concat[i]].pos;
-    for (size_t j = i; j < n; j++) {
-      const int64_t diff = cand[concat[j]].pos - start_pos;
-      if (diff > (int64_t)dense_win) { if ((uint32_t)(j - i) >= min_dense_cnt) mark(i, j); break; }
-      if (j == n - 1 && (uint32_t)(j - i + 1) >= min_dense_cnt) mark(i, j);
-    }
-  }
-  for (size_t i = 0; i < n; i++) {
-    const int64_t start_pos = cand[concat[i]].pos;
-    for (size_t j = i; j < n; j++) {
-      const int64_t diff = cand[concat[j]].pos - start_pos;
-      if (diff >= 5) { if ((uint32_t)(j - i) >= 3) mark(i, j); break; }
-      if (j == n - 1 && (uint32_t)(j - i + 1) >= 3) mark(i, j);
-    }
-  }
-}
-
 }  // namespace
 
 extern "C" {
@@ -402,7 +375,12 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->survivors.reserve(std::max(n_sv, 1) * sizeof(Survivor)));
   HIPCHK(c, c->hist.reserve(std::max<size_t>(n_sv, 1) * 124 * 4));
   HIPCHK(c, c->cand_tmp.reserve(std::max<size_t>(n_sv, 1) * sizeof(lcr_candidate)));
-  HIPCHK(c, c->keep.reserve(std::max(n_sv, 1)));
+  HIPCHK(c, c->keep.reserve(((size_t)std::max(n_sv, 1) * 3 + 2) * 4));   // keep | pos (+1) | het/hom index scratch
+  HIPCHK(c, c->d_cand.reserve(std::max<size_t>(n_sv, 1) * sizeof(lcr_candidate)));   // (capacity: every survivor kept)
+  HIPCHK(c, c->d_cand_off.reserve((ng + 1) * 4));
+  int32_t* const d_keep = c->keep.as<int32_t>();
+  int32_t* const d_pos = d_keep + std::max(n_sv, 1);
+  int32_t* const d_idx = d_pos + std::max(n_sv, 1) + 1;
   c->h_cand.clear();
   c->h_cand_off.assign(ng + 1, 0);
   if (n_sv) {
@@ -415,27 +393,16 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
                      c->stream); }
     { Timer t(c, LCR_K_CAND_GT);
       launch_k2_gt(c->dp, c->survivors.as<Survivor>(), n_sv, c->hist.as<uint32_t>(), c->bv.start0,
-                   c->cand_tmp.as<lcr_candidate>(), c->keep.as<uint8_t>(), c->stream); }
-    HIPCHK(c, c->h_stage[1].reserve((size_t)n_sv * sizeof(lcr_candidate)));
-    HIPCHK(c, c->h_stage[2].reserve((size_t)n_sv));
-    const lcr_candidate* tmp = c->h_stage[1].as<lcr_candidate>();
-    const uint8_t* keep = c->h_stage[2].as<uint8_t>();
-    HIPCHK(c, hipMemcpyAsync(c->h_stage[1].p, c->cand_tmp.p, (size_t)n_sv * sizeof(lcr_candidate), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_stage[2].p, c->keep.p, n_sv, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipGetLastError());
-    for (int g = 0; g < ng; g++) {
-      c->h_cand_off[g] = (int32_t)c->h_cand.size();
-      for (int s = sv_off[g]; s < sv_off[g + 1]; s++) if (keep[s]) c->h_cand.push_back(tmp[s]);
-      dense_filter(c->h_cand, c->h_cand_off[g], (int)c->h_cand.size(), p->dense_win, p->min_dense_cnt);
-    }
-    c->h_cand_off[ng] = (int32_t)c->h_cand.size();
+                   c->cand_tmp.as<lcr_candidate>(), d_keep, c->stream); }
   }
-  const size_t nc = c->h_cand.size();
-  HIPCHK(c, c->d_cand.reserve(std::max<size_t>(nc, 1) * sizeof(lcr_candidate)));
-  HIPCHK(c, c->d_cand_off.reserve((ng + 1) * 4));
-  if (nc) HIPCHK(c, hipMemcpyAsync(c->d_cand.p, c->h_cand.data(), nc * sizeof(lcr_candidate), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_cand_off.p, c->h_cand_off.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  // ordered compaction of the kept candidates + dense-cluster sweep (candidate.rs:465-526) on the device; the
+  // host copy (getters, chain-region host steps) arrives with the same round trip as the offsets
+  launch_k2_finish(c->scan_tmp, c->cand_tmp.as<lcr_candidate>(), d_keep, n_sv, c->sv_region_off.as<int32_t>(), ng, d_pos, d_idx,
+                   c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), p->dense_win, p->min_dense_cnt, c->stream);
+  HIPCHK(c, c->h_stage[1].reserve(std::max<size_t>(n_sv, 1) * sizeof(lcr_candidate)));
+  HIPCHK(c, c->h_stage[2].reserve((size_t)(ng + 1) * 4));
+  if (n_sv) HIPCHK(c, hipMemcpyAsync(c->h_stage[1].p, c->d_cand.p, (size_t)n_sv * sizeof(lcr_candidate), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_stage[2].p, c->d_cand_off.p, (size_t)(ng + 1) * 4, hipMemcpyDeviceToHost, c->stream));
   // rows of the fragment matrix per region (fragment.rs:51-54) depend on the candidates only: computed here so
   // that lcr_fragments starts without a round trip
   HIPCHK(c, c->region_rows.reserve(std::max(ng, 1) * 4));
@@ -444,6 +411,8 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   if (ng) HIPCHK(c, hipMemcpyAsync(c->h_stage[3].p, c->region_rows.p, ng * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
+  memcpy(c->h_cand_off.data(), c->h_stage[2].p, (size_t)(ng + 1) * 4);
+  c->h_cand.assign(c->h_stage[1].as<lcr_candidate>(), c->h_stage[1].as<lcr_candidate>() + c->h_cand_off[ng]);
   c->have_cand = true;
   c->have_frag = c->have_phase = false;
   return LCR_OK;

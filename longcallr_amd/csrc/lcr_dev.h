@@ -149,7 +149,10 @@ float lcr_device_sor_threshold(hipStream_t s);
 void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin, const Survivor* sv, const int32_t* sv_region_off,
                     uint32_t* hist /* n_sv * 4 * 31 */, hipStream_t s);
 void launch_k2_gt(const DevParams& p, const Survivor* sv, int32_t n_sv, const uint32_t* hist, const int64_t* start0,
-                  lcr_candidate* out, uint8_t* keep, hipStream_t s);
+                  lcr_candidate* out, int32_t* keep, hipStream_t s);
+void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t* keep, int32_t n_sv, const int32_t* sv_region_off,
+                      int32_t n_regions, int32_t* pos, int32_t* idx, lcr_candidate* out, int32_t* cand_off, uint32_t dense_win,
+                      uint32_t min_dense_cnt, hipStream_t s);
 void launch_k3_count(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
                      const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, uint32_t* row_links,
                      hipStream_t s);
