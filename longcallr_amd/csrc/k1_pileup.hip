@@ -436,15 +436,26 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   const uint32_t* rl32 = reinterpret_cast<const uint32_t*>(refl);
 
   // record batches of K1_RPB * K1_THREADS records: fewer block-wide barriers per record
+  // the records of the next batch are requested while the current batch is processed
+  auto load_rec = [&](int j) -> unsigned long long {
+    if (j >= i1) return 0ull;
+    const int lv = rec_level(j);
+    return recs[(unsigned int)lvl_at[lv] + (unsigned int)(j - rec_level_first(lv))];
+  };
+  unsigned long long rec_nx[K1_RPB];
+#pragma unroll
+  for (int x = 0; x < K1_RPB; x++) rec_nx[x] = load_rec(i0 + tid * K1_RPB + x);
   for (int rbase = i0; rbase < i1 && prm.dbg != 3; rbase += K1_RPB * K1_THREADS) {
     // ---- phase 1: K1_RPB records per thread (thread t owns batch slots K1_RPB*t .. K1_RPB*t + K1_RPB-1)
     int npc[K1_RPB], nsum = 0;
+    unsigned long long rec_cur[K1_RPB];
+#pragma unroll
+    for (int x = 0; x < K1_RPB; x++) { rec_cur[x] = rec_nx[x]; rec_nx[x] = load_rec(rbase + K1_RPB * K1_THREADS + tid * K1_RPB + x); }
 #pragma unroll
     for (int x = 0; x < K1_RPB; x++) {
       const int slot = tid * K1_RPB + x;
       const bool hasrec = rbase + slot < i1;
-      const int lv = rec_level(rbase + slot);
-      const unsigned long long rec = hasrec ? recs[(unsigned int)lvl_at[lv] + (unsigned int)(rbase + slot - rec_level_first(lv))] : 0ull;
+      const unsigned long long rec = rec_cur[x];
       const unsigned long long off = rec & REC_OFF_MASK;
       const int col0 = (int)((rec >> 40) & 1023u), len = (int)((rec >> 50) & 1023u) + 1;
       int npieces = 0;
