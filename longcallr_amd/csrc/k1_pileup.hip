@@ -83,160 +83,48 @@ void launch_k0_pack(const BatchView& b, ReadBin* out, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K0: persistent waves, one read per wave and step, ONE pass: validate ops, intron difference array,
-// reference end of the read, per-tile records.  Records of a tile live in geometrically growing
-// levels (64, 128, 256, ... slots) of one pool: a tile's k-th level is allocated -- one atomic on the
-// pool top -- by the lane that draws the level's first slot, so no counting pass is needed and the
-// waste is bounded by 2x.  The header of the next read and the first CIGAR words of the next read /
-// next chunk are requested before the current chunk is processed, so the dependent HBM round trips
-// (header -> CIGAR -> slot atomics) of consecutive reads overlap.
+// K0: persistent waves, ONE kernel: validate ops, intron difference array, reference end of the read,
+// per-tile records.  Records of a tile live in geometrically growing levels (64, 128, 256, ... slots) of one
+// pool: a tile's k-th level is allocated -- one atomic on the pool top -- by the lane whose slot reservation
+// holds the level's first slot, so the waste is bounded by 2x and no global counting pass is needed.
 __device__ __forceinline__ int rec_level(int slot) { return 31 - __clz((slot >> 6) + 1); }       // level of a tile-relative slot
 __device__ __forceinline__ int rec_level_first(int level) { return ((1 << level) - 1) << 6; }    // its first slot
+
+// Sixteen lanes (one DPP row) per read, four reads per wave64, WITHOUT a global round trip per record: per read (and per window of K0_WIN
+// tiles of its span) the CIGAR is walked twice.  Walk A counts the records each tile will get (LDS
+// counters of the read's row), then ONE atomic per (read, tile) reserves that many slots and the pool
+// levels those slots lie in are resolved (allocated when the reservation holds a level's first slot);
+// walk B draws the slots from the LDS counters and writes the records.  The dependent chain per read is
+// header -> CIGAR -> reservations -> level table, independent of the number of records.
+#define K0_WIN 64
+struct K0Row { int ctr[K0_WIN]; int l0[K0_WIN]; int p0[K0_WIN]; int p1[K0_WIN]; };
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __global__ void __launch_bounds__(LCR_BLOCK)
 k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* __restrict__ tile_fill,
-       int32_t* __restrict__ tile_lvl, unsigned int* __restrict__ pool_top, unsigned int pool_cap,
-       unsigned long long* __restrict__ recs, uint32_t* __restrict__ ndiff) {
-  const int lane = threadIdx.x & 63;
-  const int n_waves = gridDim.x * (LCR_BLOCK / 64);
-  int r = blockIdx.x * (LCR_BLOCK / 64) + (threadIdx.x >> 6);
-  if (r >= b.n_reads) return;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  r = __builtin_amdgcn_readfirstlane(r);  // wave-uniform: header loads become scalar loads
-  ReadBin h = rbin[r];
-  uint32_t word = (uint32_t)lane < (uint32_t)h.n_cig ? b.cigar[h.cig_off + lane] : 0u;
-  unsigned int n_items = 0;
-  for (; r < b.n_reads; r += n_waves) {   // (strided: contiguous ranges per wave balance worse and were slower)
-    const int r_next = r + n_waves;
-    ReadBin hn = h;
-    if (r_next < b.n_reads) hn = rbin[r_next];          // prefetch the next read's header
-    const int vec = h.vec;
-    const int64_t gbase = h.gbase;
-    const int ftile = h.ftile;
-    const uint32_t ncig = (uint32_t)h.n_cig;
-    const uint32_t* __restrict__ cg = b.cigar + h.cig_off;
-    const int lead = h.lead, reb = h.reb;
-    const unsigned long long seq_off = h.seq_off;
-    const int strand = h.flags & 1, ts = (h.flags >> 1) & 3;
-    // transcript_strands index (util.rs:803-819): (+,+)->0 (+,-)->1 (-,+)->1 (-,-)->0, none -> -1
-    const unsigned long long tscls = ts == 0 ? 0ull : ((strand == 0) == (ts == 1) ? 1ull : 2ull);
-    const unsigned long long hi_bits = ((unsigned long long)strand << 60) | (tscls << 61);
-    int ref_cur = h.rel_pos;
-    int q_cur = lead > 0 ? lead : 0;
-    uint32_t word_n = 0;                                 // first CIGAR words of the next read
-    bool have_wn = false;
-    for (uint32_t c0 = 0; c0 < ncig; c0 += 64) {
-      const bool act = c0 + lane < ncig;
-      const uint32_t w = word;
-      if (c0 + 64 < ncig) word = c0 + 64 + lane < ncig ? cg[c0 + 64 + lane] : 0u;      // prefetch the next chunk
-      else if (r_next < b.n_reads) { word_n = (uint32_t)lane < (uint32_t)hn.n_cig ? b.cigar[hn.cig_off + lane] : 0u; have_wn = true; }
-      const int op = w & 15, len = (int)(w >> 4);
-      const bool is_m = act && (op == 0 || op == 7 || op == 8);
-      const bool is_d = act && op == 2, is_n = act && op == 3, is_i = act && op == 1;
-      if (act && !(is_m || is_d || is_n || is_i || op == 4 || op == 5)) atomicExch(b.error_flag, 1);
-      const int dr = (is_m || is_d || is_n) ? len : 0;
-      const int dq = (is_m || is_i) ? len : 0;
-      const int ir = wave_incl_scan(dr), iq = wave_incl_scan(dq);
-      const int rs = ref_cur + ir - dr;   // region-relative column where this op starts
-      const int qs = q_cur + iq - dq;     // read offset where this op starts
-      int a = max(rs, 0), e = min(rs + len, vec);
-      if (is_n && e > a) {  // util.rs:930-942
-        atomicAdd(&ndiff[gbase + a], 1u);
-        atomicAdd(&ndiff[gbase + e], 0xFFFFFFFFu);
-      }
-      if (ont && is_m) {  // ONT end trim (util.rs:745-751): keep read offsets lead + D <= c <= reb - D
-        a = max(a, rs + (lead + D - qs));
-        e = min(e, rs + (reb - D + 1 - qs));
-      }
-      // column range [a, e) this op contributes records for (I: the single column rs-1, 1 <= rs < vec)
-      bool has = (is_m || is_d) && len > 0 && e > a;
-      if (is_i && len > 0 && rs >= 1 && rs < vec) { has = true; a = rs - 1; e = rs; }
-      n_items += __popcll(__ballot(has));   // M / D / I items (tile independent), one atomic per wave at exit
-      int t_cur = has ? a / LCR_TILE : INT_MAX;       // tile of the next record of this lane
-      const int t_last = has ? (e - 1) / LCR_TILE : -1;
-      // rounds: every lane emits its record for tile t_cur, then moves to its next tile (ops rarely span
-      // more than two tiles).  Ops are ordered by position, so within a round the emitting lanes' tiles
-      // are non-decreasing: runs of equal tiles are contiguous, each run's first lane allocates the
-      // slots of the whole run with ONE atomic, and all runs of the round issue their atomics together.
-      for (;;) {
-        const bool emit = has && t_cur <= t_last;
-        const unsigned long long em = __ballot(emit);
-        if (em == 0ull) break;
-        const unsigned long long em_below = em & below;
-        const int prev_lane = em_below ? 63 - __clzll((long long)em_below) : 0;
-        const int prev_tile = __shfl(t_cur, prev_lane, 64);
-        const bool leader = emit && (em_below == 0ull || prev_tile != t_cur);
-        const unsigned long long lm = __ballot(leader);
-        // my run: from its leader (highest leader bit at or below me) to just before the next leader
-        const unsigned long long lm_le = lm & (below | (1ull << lane));
-        const int my_leader = lm_le ? 63 - __clzll((long long)lm_le) : 0;
-        int base = 0;
-        if (leader) {
-          const unsigned long long above = lane == 63 ? 0ull : (~0ull << (lane + 1));
-          const unsigned long long nxt = lm & above;
-          const unsigned long long run = nxt ? (em & above & ((1ull << (__ffsll((long long)nxt) - 1)) - 1ull)) : (em & above);
-          const int cnt = 1 + __popcll(run);
-          base = atomicAdd(&tile_fill[ftile + t_cur], cnt);
-        }
-        base = __shfl(base, my_leader, 64);
-        int slot = 0, lvl = 0;
-        if (emit) {
-          const unsigned long long leader_below = my_leader == 0 ? 0ull : ((1ull << my_leader) - 1ull);
-          slot = base + __popcll(em_below & ~leader_below);   // tile-relative
-          lvl = rec_level(slot);
-          if (slot == rec_level_first(lvl)) {                 // first slot of a level: allocate the level
-            const unsigned int at = atomicAdd(pool_top, 64u << lvl);
-            if (at + (64u << lvl) > pool_cap) atomicExch(b.error_flag, 3);
-            __hip_atomic_store(&tile_lvl[(ftile + t_cur) * LCR_REC_LEVELS + lvl], (int)at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (relaxed: only the value itself is communicated; acquire / release would invalidate L1 every round)
-          }
-        }
-        if (emit) {   // (every allocation of this wave is issued above: the wait below is on other waves only)
-          int at, spins = 0;   // (bounded: a broken invariant must surface as an error, not as a hung device)
-          while ((at = __hip_atomic_load(&tile_lvl[(ftile + t_cur) * LCR_REC_LEVELS + lvl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 24)) { atomicExch(b.error_flag, 4); at = (int)pool_cap; break; }
-          }
-          const int c_lo = max(a, t_cur * LCR_TILE), c_hi = min(e, (t_cur + 1) * LCR_TILE);  // columns in this tile
-          unsigned long long rec = ((unsigned long long)(c_lo - t_cur * LCR_TILE) << 40) |
-                                   ((unsigned long long)(c_hi - c_lo - 1) << 50);
-          if (is_m) rec |= ((seq_off + (unsigned long long)(qs + (c_lo - rs))) & REC_OFF_MASK) | hi_bits;
-          else rec |= is_d ? REC_KIND_D : REC_KIND_I;
-          if ((unsigned int)at + (unsigned int)(slot - rec_level_first(lvl)) < pool_cap) recs[(unsigned int)at + (unsigned int)(slot - rec_level_first(lvl))] = rec;
-        }
-        if (emit) t_cur++;
-      }
-      ref_cur += __shfl(ir, 63, 64);
-      q_cur += __shfl(iq, 63, 64);
-      if (c0 + 64 >= ncig && lane == 0 && q_cur != reb) atomicExch(b.error_flag, 2);
-    }
-    if (lane == 0) b.read_rend[r] = ref_cur;
-    if (r_next < b.n_reads) {
-      if (!have_wn) word_n = (uint32_t)lane < (uint32_t)hn.n_cig ? b.cigar[hn.cig_off + lane] : 0u;
-      word = word_n;
-    }
-    h = hn;
-  }
-  if (lane == 0 && n_items) atomicAdd(pool_top + 1, n_items);
-}
-
-// K0 for reads with up to a few dozen CIGAR ops: the same single pass with SIXTEEN lanes (one DPP row) per read,
-// four reads per wave64 -- a whole wave per read leaves most lanes idle on HiFi reads (~8 ops), and even at ~56 ops
-// (ONT) four shorter dependent chains per wave beat one long one.  All ballots are taken over the
-// wave and restricted to the lane's row; the per-read state lives in every lane of the row.
-__global__ void __launch_bounds__(LCR_BLOCK)
-k0_bin16(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* __restrict__ tile_fill,
          int32_t* __restrict__ tile_lvl, unsigned int* __restrict__ pool_top, unsigned int pool_cap,
          unsigned long long* __restrict__ recs, uint32_t* __restrict__ ndiff) {
+  __shared__ K0Row rows[LCR_BLOCK / 16];
+  K0Row& R = rows[threadIdx.x >> 4];
   const int lane = threadIdx.x & 63, l16 = lane & 15, rbase = lane & 48;
   const unsigned long long rowmask = 0xFFFFull << rbase;
-  const unsigned long long below = ((1ull << l16) - 1ull) << rbase;   // the lanes of my row below me
-  const unsigned long long self = 1ull << lane;
   const int n_groups = gridDim.x * (LCR_BLOCK / 16);
   const int n_steps = (b.n_reads + n_groups - 1) / n_groups;
   unsigned int n_items = 0;
+  auto lvl_wait = [&](int tile, int lvl) {   // pool offset of a tile's level (bounded wait on its allocator)
+    int at, spins = 0;
+    while ((at = __hip_atomic_load(&tile_lvl[tile * LCR_REC_LEVELS + lvl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 24)) { atomicExch(b.error_flag, 4); at = (int)pool_cap; break; }
+    }
+    return at;
+  };
   int r = (int)((blockIdx.x * LCR_BLOCK + threadIdx.x) >> 4);
   for (int step = 0; step < n_steps; step++, r += n_groups) {
     const bool live = r < b.n_reads;
-    // the 64-byte header: lane k of the row loads dword k, fields are broadcast inside the row
     const uint32_t hw = live ? reinterpret_cast<const uint32_t*>(rbin + r)[l16] : 0u;
     auto hf = [&](int kx) { return (uint32_t)__shfl((int)hw, rbase + kx, 64); };
     const int rel_pos = (int)hf(0), vec = (int)hf(1), ftile = (int)hf(2);
@@ -249,105 +137,168 @@ k0_bin16(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t*
     const int strand = flags & 1, ts = (flags >> 1) & 3;
     const unsigned long long tscls = ts == 0 ? 0ull : ((strand == 0) == (ts == 1) ? 1ull : 2ull);
     const unsigned long long hi_bits = ((unsigned long long)strand << 60) | (tscls << 61);
-    int ref_cur = rel_pos;
-    int q_cur = lead > 0 ? lead : 0;
-    for (uint32_t c0 = 0; __any(c0 < ncig); c0 += 16) {
-      const bool act = c0 + l16 < ncig;
-      const uint32_t w = act ? cg[c0 + l16] : 0u;
+    const int t_first = max(rel_pos - 1, 0) / LCR_TILE;   // no record lies in an earlier tile (a leading I counts on column rel_pos - 1)
+    uint32_t wq0[4];                                   // the first 64 ops stay in registers for both walks
+#pragma unroll
+    for (int j = 0; j < 4; j++) wq0[j] = (uint32_t)(16 * j + l16) < ncig ? cg[16 * j + l16] : 0u;
+
+    // one op per lane: the columns [a, e) it contributes records for (util.rs:692-947)
+    struct Op { int a, e, rs, qs, ir, iq; bool m, d, i, has; };
+    auto decode = [&](uint32_t w, bool act, int ref_cur, int q_cur, bool first_walk) {
+      Op o;
       const int op = w & 15, len = (int)(w >> 4);
-      const bool is_m = act && (op == 0 || op == 7 || op == 8);
-      const bool is_d = act && op == 2, is_n = act && op == 3, is_i = act && op == 1;
-      if (act && !(is_m || is_d || is_n || is_i || op == 4 || op == 5)) atomicExch(b.error_flag, 1);
-      const int dr = (is_m || is_d || is_n) ? len : 0;
-      const int dq = (is_m || is_i) ? len : 0;
-      const int ir = row16_incl_scan(dr), iq = row16_incl_scan(dq);
-      const int rs = ref_cur + ir - dr;   // region-relative column where this op starts
-      const int qs = q_cur + iq - dq;     // read offset where this op starts
-      int a = max(rs, 0), e = min(rs + len, vec);
-      if (is_n && e > a) {  // util.rs:930-942
-        atomicAdd(&ndiff[gbase + a], 1u);
-        atomicAdd(&ndiff[gbase + e], 0xFFFFFFFFu);
+      o.m = act && (op == 0 || op == 7 || op == 8);
+      o.d = act && op == 2; o.i = act && op == 1;
+      const bool is_n = act && op == 3;
+      if (first_walk && act && !(o.m || o.d || is_n || o.i || op == 4 || op == 5)) atomicExch(b.error_flag, 1);
+      const int dr = (o.m || o.d || is_n) ? len : 0;
+      const int dq = (o.m || o.i) ? len : 0;
+      o.ir = row16_incl_scan(dr); o.iq = row16_incl_scan(dq);
+      o.rs = ref_cur + o.ir - dr;   // region-relative column where this op starts
+      o.qs = q_cur + o.iq - dq;     // read offset where this op starts
+      o.a = max(o.rs, 0); o.e = min(o.rs + len, vec);
+      if (first_walk && is_n && o.e > o.a) {  // util.rs:930-942
+        atomicAdd(&ndiff[gbase + o.a], 1u);
+        atomicAdd(&ndiff[gbase + o.e], 0xFFFFFFFFu);
       }
-      if (ont && is_m) {  // ONT end trim (util.rs:745-751)
-        a = max(a, rs + (lead + D - qs));
-        e = min(e, rs + (reb - D + 1 - qs));
+      if (ont && o.m) {  // ONT end trim (util.rs:745-751)
+        o.a = max(o.a, o.rs + (lead + D - o.qs));
+        o.e = min(o.e, o.rs + (reb - D + 1 - o.qs));
       }
-      bool has = (is_m || is_d) && len > 0 && e > a;
-      if (is_i && len > 0 && rs >= 1 && rs < vec) { has = true; a = rs - 1; e = rs; }
-      { const int nh = __popcll(__ballot(has)); if (lane == 0) n_items += (unsigned int)nh; }
-      int t_cur = has ? a / LCR_TILE : INT_MAX;
-      const int t_last = has ? (e - 1) / LCR_TILE : -1;
-      for (;;) {   // rounds, as in k0_bin, with every mask restricted to the lane's row
-        const bool emit = has && t_cur <= t_last;
-        const unsigned long long em = __ballot(emit);
-        if (em == 0ull) break;
-        const unsigned long long em_below = em & below;
-        const int prev_lane = em_below ? 63 - __clzll((long long)em_below) : 0;
-        const int prev_tile = __shfl(t_cur, prev_lane, 64);
-        const bool leader = emit && (em_below == 0ull || prev_tile != t_cur);
-        const unsigned long long lm = __ballot(leader);
-        const unsigned long long lm_le = lm & (below | self);
-        const int my_leader = lm_le ? 63 - __clzll((long long)lm_le) : 0;
-        int base = 0;
-        if (leader) {
-          const unsigned long long above = rowmask & ~(below | self);
-          const unsigned long long nxt = lm & above;
-          const unsigned long long run = nxt ? (em & above & ((1ull << (__ffsll((long long)nxt) - 1)) - 1ull)) : (em & above);
-          base = atomicAdd(&tile_fill[ftile + t_cur], 1 + __popcll(run));
-        }
-        base = __shfl(base, my_leader, 64);
-        int slot = 0, lvl = 0;
-        if (emit) {
-          const unsigned long long leader_below = ((1ull << (my_leader & 15)) - 1ull) << rbase;
-          slot = base + __popcll(em_below & ~leader_below);   // tile-relative
-          lvl = rec_level(slot);
-          if (slot == rec_level_first(lvl)) {
-            const unsigned int at = atomicAdd(pool_top, 64u << lvl);
-            if (at + (64u << lvl) > pool_cap) atomicExch(b.error_flag, 3);
-            __hip_atomic_store(&tile_lvl[(ftile + t_cur) * LCR_REC_LEVELS + lvl], (int)at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      o.has = (o.m || o.d) && len > 0 && o.e > o.a;
+      if (o.i && len > 0 && o.rs >= 1 && o.rs < vec) { o.has = true; o.a = o.rs - 1; o.e = o.rs; }
+      return o;
+    };
+
+    bool more = live;   // this row has a window left
+    for (int win = 0; __any(more); win++) {
+      const int tw0 = t_first + win * K0_WIN;
+      const uint32_t ncw = more ? ncig : 0u;
+#pragma unroll
+      for (int j = 0; j < 4; j++) R.ctr[l16 + 16 * j] = 0;
+      wave_lds_sync();
+        // ---- walk A: records per tile of the window
+      bool beyond = false;
+      {
+        int ref_cur = rel_pos, q_cur = lead > 0 ? lead : 0;
+        for (uint32_t g0 = 0; __any(g0 < ncw); g0 += 64) {
+          uint32_t wq[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            wq[j] = g0 == 0 ? wq0[j] : ((g0 + 16 * j + l16) < ncw ? cg[g0 + 16 * j + l16] : 0u);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint32_t c0 = g0 + 16 * j;
+            if (!__any(c0 < ncw)) break;
+            const Op o = decode(wq[j], c0 + l16 < ncw, ref_cur, q_cur, win == 0);
+            if (win == 0) { const int nh = __popcll(__ballot(o.has)); if (lane == 0) n_items += (unsigned int)nh; }
+            if (o.has) {
+              const int tl = (o.e - 1) / LCR_TILE;
+              if (tl >= tw0 + K0_WIN) beyond = true;
+              const int te = min(tl, tw0 + K0_WIN - 1);
+              for (int t = max(o.a / LCR_TILE, tw0); t <= te; t++) atomicAdd(&R.ctr[t - tw0], 1);
+            }
+            ref_cur += __shfl(o.ir, rbase + 15, 64);
+            q_cur += __shfl(o.iq, rbase + 15, 64);
+            if (win == 0 && c0 < ncw && c0 + 16 >= ncw && l16 == 0 && q_cur != reb) atomicExch(b.error_flag, 2);
           }
         }
-        if (emit) {
-          int at, spins = 0;
-          while ((at = __hip_atomic_load(&tile_lvl[(ftile + t_cur) * LCR_REC_LEVELS + lvl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 24)) { atomicExch(b.error_flag, 4); at = (int)pool_cap; break; }
-          }
-          const int c_lo = max(a, t_cur * LCR_TILE), c_hi = min(e, (t_cur + 1) * LCR_TILE);
-          unsigned long long rec = ((unsigned long long)(c_lo - t_cur * LCR_TILE) << 40) |
-                                   ((unsigned long long)(c_hi - c_lo - 1) << 50);
-          if (is_m) rec |= ((seq_off + (unsigned long long)(qs + (c_lo - rs))) & REC_OFF_MASK) | hi_bits;
-          else rec |= is_d ? REC_KIND_D : REC_KIND_I;
-          const unsigned int at_slot = (unsigned int)at + (unsigned int)(slot - rec_level_first(lvl));
-          if (at_slot < pool_cap) recs[at_slot] = rec;
-        }
-        if (emit) t_cur++;
+        if (win == 0 && live && l16 == 0) b.read_rend[r] = ref_cur;
       }
-      ref_cur += __shfl(ir, rbase + 15, 64);
-      q_cur += __shfl(iq, rbase + 15, 64);
-      if (live && c0 < ncig && c0 + 16 >= ncig && l16 == 0 && q_cur != reb) atomicExch(b.error_flag, 2);
+      wave_lds_sync();
+        // ---- reservations: lane k owns the window's tiles k, k+16, k+32, k+48
+      {
+        int cn[4], bs[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { cn[j] = R.ctr[l16 + 16 * j]; bs[j] = 0; }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (cn[j] > 0) bs[j] = atomicAdd(&tile_fill[ftile + tw0 + l16 + 16 * j], cn[j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++)     // every level whose first slot is mine is allocated here, before any wait
+          if (cn[j] > 0) {
+            const int tile = ftile + tw0 + l16 + 16 * j;
+            const int l_last = rec_level(bs[j] + cn[j] - 1);
+            for (int l = rec_level(bs[j]); l <= l_last; l++)
+              if (rec_level_first(l) >= bs[j]) {
+                const unsigned int at = atomicAdd(pool_top, 64u << l);
+                if (at + (64u << l) > pool_cap) atomicExch(b.error_flag, 3);
+                __hip_atomic_store(&tile_lvl[tile * LCR_REC_LEVELS + l], (int)at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (relaxed: only the value itself is communicated)
+              }
+          }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (cn[j] > 0) {
+            const int o = l16 + 16 * j, tile = ftile + tw0 + o;
+            const int l_first = rec_level(bs[j]);
+            R.ctr[o] = bs[j];
+            R.l0[o] = l_first;
+            R.p0[o] = lvl_wait(tile, l_first);
+            R.p1[o] = rec_level(bs[j] + cn[j] - 1) > l_first ? lvl_wait(tile, l_first + 1) : 0;
+          }
+      }
+      wave_lds_sync();
+        // ---- walk B: the records
+      {
+        int ref_cur = rel_pos, q_cur = lead > 0 ? lead : 0;
+        for (uint32_t g0 = 0; __any(g0 < ncw); g0 += 64) {
+          uint32_t wq[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            wq[j] = g0 == 0 ? wq0[j] : ((g0 + 16 * j + l16) < ncw ? cg[g0 + 16 * j + l16] : 0u);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint32_t c0 = g0 + 16 * j;
+            if (!__any(c0 < ncw)) break;
+            const Op o = decode(wq[j], c0 + l16 < ncw, ref_cur, q_cur, false);
+            if (o.has) {
+              const int te = min((o.e - 1) / LCR_TILE, tw0 + K0_WIN - 1);
+              for (int t = max(o.a / LCR_TILE, tw0); t <= te; t++) {
+                const int w_ = t - tw0;
+                const int slot = atomicAdd(&R.ctr[w_], 1);   // tile-relative
+                const int lvl = rec_level(slot), l0 = R.l0[w_];
+                const int at = lvl == l0 ? R.p0[w_] : lvl == l0 + 1 ? R.p1[w_] : lvl_wait(ftile + t, lvl);
+                const int c_lo = max(o.a, t * LCR_TILE), c_hi = min(o.e, (t + 1) * LCR_TILE);  // columns in this tile
+                unsigned long long rec = ((unsigned long long)(c_lo - t * LCR_TILE) << 40) |
+                                         ((unsigned long long)(c_hi - c_lo - 1) << 50);
+                if (o.m) rec |= ((seq_off + (unsigned long long)(o.qs + (c_lo - o.rs))) & REC_OFF_MASK) | hi_bits;
+                else rec |= o.d ? REC_KIND_D : REC_KIND_I;
+                const unsigned int at_slot = (unsigned int)at + (unsigned int)(slot - rec_level_first(lvl));
+                if (at_slot < pool_cap) recs[at_slot] = rec;
+              }
+            }
+            ref_cur += __shfl(o.ir, rbase + 15, 64);
+            q_cur += __shfl(o.iq, rbase + 15, 64);
+          }
+        }
+      }
+        more = more && (__ballot(beyond) & rowmask) != 0ull;
+      wave_lds_sync();
     }
-    if (live && l16 == 0) b.read_rend[r] = ref_cur;
   }
   if (lane == 0 && n_items) atomicAdd(pool_top + 1, n_items);
 }
 
-void launch_k0_bin(const BatchView& b, const ReadBin* rb, int ont, int D, int32_t* tile_fill, int32_t* tile_lvl,
-                   unsigned int* pool_top, unsigned int pool_cap, unsigned long long* recs, uint32_t* ndiff, int64_t n_cigar,
-                   hipStream_t s) {
-  if (b.n_reads == 0) return;
-  // sixteen lanes per read up to a mean of 64 ops per read (measured: HiFi-like, 9 ops: 0.55 -> 0.44 ms; ONT-like,
-  // 56 ops: 0.83 -> 0.76 ms), a wave per read for longer CIGARs
-  bool narrow = n_cigar <= 64 * (int64_t)b.n_reads;
-  if (const char* e = getenv("LCR_K0_LANES")) narrow = atoi(e) == 16;   // test hook: force either kernel
-  if (narrow) {
-    const int per = LCR_BLOCK / 16;
-    const int blocks = std::min((b.n_reads + per - 1) / per, 256 * 8);
-    hipLaunchKernelGGL(k0_bin16, dim3(blocks), dim3(LCR_BLOCK), 0, s, b, rb, ont, D, tile_fill, tile_lvl, pool_top, pool_cap, recs, ndiff);
-    return;
+// workgroups of K0 that are resident at once on the current device: the persistent kernel strides over the
+// reads, so a grid that does not fit would run a second, mostly idle generation
+static int k0_resident_blocks() {
+  static int cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cache[dev] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k0_bin, LCR_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    cache[dev] = per_cu * cus;
   }
-  const int per = LCR_BLOCK / 64;
-  const int blocks = std::min((b.n_reads + per - 1) / per, 256 * 8);  // persistent and co-resident: 8 workgroups per CU
+  return cache[dev];
+}
+
+void launch_k0_bin(const BatchView& b, const ReadBin* rb, int ont, int D, int32_t* tile_fill, int32_t* tile_lvl,
+                   unsigned int* pool_top, unsigned int pool_cap, unsigned long long* recs, uint32_t* ndiff, hipStream_t s) {
+  if (b.n_reads == 0) return;
+  const int per = LCR_BLOCK / 16;
+  const int blocks = std::min((b.n_reads + per - 1) / per, k0_resident_blocks());
   hipLaunchKernelGGL(k0_bin, dim3(blocks), dim3(LCR_BLOCK), 0, s, b, rb, ont, D, tile_fill, tile_lvl, pool_top, pool_cap, recs, ndiff);
 }
 

@@ -304,7 +304,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
     { Timer t(c, LCR_K_SPANS);
       launch_k0_bin(b, c->read_bin.as<ReadBin>(), c->dp.ont, c->dp.dist_to_end, c->k0_tile_fill.as<int32_t>(), c->k0_tile_count.as<int32_t>(),
                     (unsigned int*)(c->k0_tile_fill.as<int32_t>() + nt + 1), pool_cap, c->k0_items.as<unsigned long long>(),
-                    c->ndiff.as<uint32_t>(), c->n_cigar, c->stream);
+                    c->ndiff.as<uint32_t>(), c->stream);
       launch_scan_i32(c->scan_tmp, (const int32_t*)c->ndiff.p, c->nscan.as<int32_t>(), (int32_t)nd, nullptr, c->stream); }
     // ---- K1: per-tile tally from the records; K1z: poly-A / homopolymer mask of the HiFi presets
     { Timer t(c, LCR_K_PILEUP);

@@ -131,8 +131,7 @@ void launch_k0_tiles(const int32_t* first_tile, int32_t n_regions, int32_t* tile
 void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s);
 void launch_k0_pack(const BatchView& b, ReadBin* out, hipStream_t s);
 void launch_k0_bin(const BatchView& b, const ReadBin* rb, int ont, int D, int32_t* tile_fill, int32_t* tile_lvl,
-                   unsigned int* pool_top, unsigned int pool_cap, unsigned long long* recs, uint32_t* ndiff, int64_t n_cigar,
-                   hipStream_t s);
+                   unsigned int* pool_top, unsigned int pool_cap, unsigned long long* recs, uint32_t* ndiff, hipStream_t s);
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const int32_t* tile_fill, const int32_t* tile_lvl,
                       const unsigned long long* recs, const int32_t* nscan, uint32_t* planes, hipStream_t s);

@@ -134,14 +134,14 @@ def test_chain_path_many_snps(engine_cls, orc):
     assert max(np.bincount(c["region"])) > 10
 
 
-@pytest.mark.parametrize("lanes", ["16", "64"])
-def test_k0_lane_widths(engine_cls, orc, monkeypatch, lanes):
-    """K0 with 16 lanes per read (few CIGAR ops, HiFi) and with a wave per read (ONT) give the same planes on
-    both kinds of reads (demo.bam: up to 118 ops per read, several 16-op chunks; ONT-like: ~56 ops)."""
-    monkeypatch.setenv("LCR_K0_LANES", lanes)
+def test_k0_cigar_lengths(engine_cls, orc):
+    """K0 keeps a read's first 64 CIGAR ops in registers and reloads longer CIGARs in groups: HiFi reads
+    (~9 ops), ONT-like reads (~56 ops) and demo.bam (up to 118 ops, two groups) all give the oracle's planes."""
     full_check(engine_cls, orc, helpers.demo_batch(), _abi.make_params("hifi-masseq"), "chr20")
     b = synth.make_batch("ont-cdna", n_genes=3, gene_len=9000, depth=35, seed=12)
     full_check(engine_cls, orc, b, _abi.make_params("ont-cdna", seed=12))
+    b = synth.make_batch("masseq", n_genes=3, gene_len=9000, depth=35, seed=12)
+    full_check(engine_cls, orc, b, _abi.make_params("hifi-masseq", seed=12))
 
 
 @pytest.mark.parametrize("hook", ["LCR_ENUM_FORCE_STREAM", "LCR_ENUM_FORCE_BIG", "LCR_POST_HOST"])
@@ -275,6 +275,30 @@ def test_long_deletions_grow_the_record_pool(engine_cls, orc):
     reads.sort(key=lambda r: r["pos"])
     b = helpers.mk_batch(reads, [(5000, ref)])
     full_check(engine_cls, orc, b, _abi.make_params("hifi-masseq", min_depth=3))
+
+
+def test_dense_ops_span_several_pool_levels(engine_cls, orc):
+    """One read can put hundreds of records into a single tile (alternating 1-base ops): its slot
+    reservation then covers several pool levels at once, all of which it has to allocate, and reads whose
+    CIGARs are longer than the 64 ops K0 keeps in registers (here 300 - 550 ops) take the reload path."""
+    L = 4096
+    rng = np.random.default_rng(11)
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    reads = []
+    for k in range(40):
+        p0 = 100 + int(rng.integers(0, 600))
+        n = 150 + int(rng.integers(0, 120))
+        seq, cig, rp = [], [], p0
+        for i in range(n):
+            if i % 2 == 0:
+                seq.append(ref[rp]); rp += 1; cig.append("1M"); seq.append("ACGT"[(i // 2) % 4]); cig.append("1I")
+            else:
+                seq.append(ref[rp]); rp += 1; cig.append("1M"); rp += 1; cig.append("1D")
+        seq.append(ref[rp:rp + 40]); cig.append("40M")
+        reads.append(dict(pos=1000 + p0, seq="".join(seq), qual=25, cigar="".join(cig), rev=k % 2, ts=k % 3, region=0))
+    reads.sort(key=lambda r: r["pos"])
+    b = helpers.mk_batch(reads, [(1000, ref)])
+    full_check(engine_cls, orc, b, _abi.make_params("ont-cdna", min_depth=3))
 
 
 def test_empty_batch_and_errors(engine_cls):
