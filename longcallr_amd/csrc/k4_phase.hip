@@ -1652,111 +1652,15 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(hipGetLastError());
     PCHK(hipMemcpyAsync(stat, b_stat.p, (size_t)ng * sizeof(StageStat), hipMemcpyDeviceToHost, stream));
     PCHK(hipMemsetAsync(b_st.p, 0, st_bytes, stream));
-    PCHK(hipStreamSynchronize(stream));
   }
-  lap("stage + sizes");
-
-  // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
+  // enumeration (S <= max_enum_snps) and chain regions; the chain regions' host preparation (LD blocks) only
+  // needs the fragment matrix and runs while k4_stage is busy
   std::vector<int32_t> enum_slots, chain_slots;
-  int32_t max_state = 0;
-  // post-phase epilogue on the device (k4_post) unless a region does not fit its LDS image
-  bool dev_post = getenv("LCR_POST_HOST") == nullptr;
-  uint32_t post_lds = 0;
   for (int g = 0; g < ng; g++) {
     const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
     if (S == 0) continue;
     if ((uint32_t)S <= prm.max_enum_snps) enum_slots.push_back(g); else chain_slots.push_back(g);
-    max_state = std::max(max_state, stat[g].R + 2 * S);
-    const int nr_g = in.row_region_off[g + 1] - in.row_region_off[g];
-    const uint32_t need = post_layout(nr_g, stat[g].E_all, S).total;
-    if (nr_g > POST_MAX_ROWS || stat[g].E_all > POST_MAX_ENTRIES || S > POST_MAX_SNPS || need > 64 * 1024) dev_post = false;
-    post_lds = std::max(post_lds, need);
   }
-  PostLut plut;
-  for (int q = 0; q < 31; q++) { plut.le[q] = L.le[q]; plut.l1e[q] = L.l1e[q]; }
-  plut.p_homref = L.p_homref; plut.p_homvar = L.p_homvar; plut.log_theta = L.log_theta; plut.log2 = L.log2;
-  PostIn pin{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, const_cast<lcr_candidate*>(in.d_cand), in.d_cand_off,
-             in.d_row_region_off, in.d_start0, P.st_sigma, P.st_delta, P.st_eta, b_htag.as<int8_t>(), b_asg.as<uint8_t>(),
-             b_ps.as<uint32_t>(), prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr};
-  if (prof) { PCHK(d_state[20].reserve(32 * 8)); pin.dbg_clk = d_state[20].as<long long>(); }
-  if (dev_post && nrow) {
-    PCHK(hipMemsetAsync(b_htag.p, 0, (size_t)nrow, stream)); PCHK(hipMemsetAsync(b_asg.p, 0, (size_t)nrow, stream));
-    PCHK(hipMemsetAsync(b_ps.p, 0, (size_t)nrow * 4, stream));
-  }
-  if (!dev_post) { haplotag.assign(nrow, 0); assignment.assign(nrow, 0); phase_set.assign(nrow, 0); }
-  const int32_t stride = (max_state + 63) & ~63;
-  P.scratch_stride = stride;
-  const size_t dyn_bytes = stride <= 48 * 1024 ? (size_t)stride : 0;  // chain working state in LDS when it fits
-  P.lds_state = dyn_bytes ? 1 : 0;
-  std::vector<uint8_t> packed;   // pageable upload source; must outlive the copy (synchronised below)
-  size_t n_big_blocks = 0;
-  if (!enum_slots.empty()) {
-    const bool force_big = getenv("LCR_ENUM_FORCE_BIG") != nullptr;        // test hooks: exercise the fallback kernels
-    const bool force_stream = getenv("LCR_ENUM_FORCE_STREAM") != nullptr;
-    // class 2: register-resident kernel (<= 32 entries per lane; smaller instantiations were measured: separate
-    // launches each pay their own tail, one CK=32 launch with early exits is faster); class 3: same kernel
-    // streaming its entries from LDS (any share size); class 4: global-memory kernel (matrix larger than the
-    // LDS budget); classes 0 / 1 unused
-    constexpr int NCLS = 5;
-    std::vector<EnumTile> tiles[NCLS], wtiles[NCLS];
-    std::vector<int64_t> job_base(ng, 0);
-    int64_t nj = 0;
-    uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0};
-    for (int g : enum_slots) {
-      const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
-      const StageStat& st = stat[g];
-      const EnumLayout EL = enum_layout(st.R, st.E);
-      int cls = 4;
-      if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_BYTES && st.max_rows <= 64)
-        cls = force_stream ? 3 : (st.max_n <= 32 ? 2 : 3);   // (the 8 / 16 instantiations: one launch has one tail)
-      if (cls < 4) lds_need[cls] = std::max(lds_need[cls], EL.total);
-      job_base[g] = nj;
-      const uint32_t n = 1u << S;
-      const uint32_t per = cls == 4 ? 1u : (cls == 3 ? 2u * ENUM_WAVES : ENUM_TILE_JOBS);
-      for (uint32_t e0 = 0; e0 < n; e0 += per) tiles[cls].push_back({g, e0, std::min(per, n - e0)});
-      wtiles[cls].push_back({g, 0, 1});
-      nj += n;
-    }
-    // one upload: tiles | winner tiles | job_base | slots ; then job objectives and winners
-    size_t n_t[NCLS], n_w[NCLS], n_tiles = 0;
-    for (int k = 0; k < NCLS; k++) { n_t[k] = tiles[k].size(); n_w[k] = wtiles[k].size(); n_tiles += n_t[k] + n_w[k]; }
-    const size_t ns = enum_slots.size();
-    const size_t off_jb_al = (n_tiles * sizeof(EnumTile) + 7) & ~(size_t)7;  // sizeof(EnumTile) == 12
-    packed.resize(off_jb_al + (size_t)ng * 8 + ns * 4);
-    size_t t_off[NCLS], w_off[NCLS], cursor = 0;
-    EnumTile* pt = (EnumTile*)packed.data();
-    for (int k = 0; k < NCLS; k++) { t_off[k] = cursor; memcpy(pt + cursor, tiles[k].data(), n_t[k] * sizeof(EnumTile)); cursor += n_t[k]; }
-    for (int k = 0; k < NCLS; k++) { w_off[k] = cursor; memcpy(pt + cursor, wtiles[k].data(), n_w[k] * sizeof(EnumTile)); cursor += n_w[k]; }
-    memcpy(packed.data() + off_jb_al, job_base.data(), (size_t)ng * 8);
-    memcpy(packed.data() + off_jb_al + (size_t)ng * 8, enum_slots.data(), ns * 4);
-    PCHK(b_job.reserve(packed.size() + 64));
-    PCHK(b_obj.reserve((size_t)nj * 8 + (size_t)ng * 4 + 64));
-    PCHK(hipMemcpyAsync(b_job.p, packed.data(), packed.size(), hipMemcpyHostToDevice, stream));
-    const EnumTile* d_t = b_job.as<EnumTile>();
-    const int64_t* d_jb = (const int64_t*)(b_job.as<uint8_t>() + off_jb_al);
-    const int32_t* d_sl = (const int32_t*)(b_job.as<uint8_t>() + off_jb_al + (size_t)ng * 8);
-    long long* d_obj = b_obj.as<long long>();
-    uint32_t* d_win = (uint32_t*)(d_obj + nj);
-    n_big_blocks = std::max(n_t[4], n_w[4]);
-    PCHK(b_scr.reserve((size_t)stride * (n_big_blocks + chain_slots.size()) + 64));   // chain regions use the tail
-    P.scratch = b_scr.as<int8_t>();
-    auto launch = [&](const size_t* cnt, const size_t* off, const uint32_t* win) {
-      const dim3 blk(64 * ENUM_WAVES);
-      if (cnt[2]) hipLaunchKernelGGL(k4_enum_reg<32>, dim3((unsigned)cnt[2]), blk, lds_need[2], stream, P, d_t + off[2], d_jb, d_obj, win);
-      if (cnt[3]) hipLaunchKernelGGL(k4_enum_reg<0>, dim3((unsigned)cnt[3]), blk, lds_need[3], stream, P, d_t + off[3], d_jb, d_obj, win);
-      if (cnt[4]) hipLaunchKernelGGL(k4_enum_big, dim3((unsigned)cnt[4]), dim3(LCR_BLOCK), 0, stream, P, d_t + off[4], d_jb, d_obj, win);
-    };
-    launch(n_t, t_off, nullptr);
-    hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)ns), dim3(64), 0, stream, d_sl, (int32_t)ns, P.reg, d_jb, d_obj, d_win);
-    launch(n_w, w_off, d_win);
-    if (dev_post) hipLaunchKernelGGL(k4_post<LCR_BLOCK>, dim3((unsigned)ns), dim3(LCR_BLOCK), post_lds, stream, pin, d_sl, (int32_t)ns, plut);
-    PCHK(hipGetLastError());
-  }
-  int8_t* const st1 = h_pin[4].as<int8_t>();   // enumeration results
-  int8_t* const st2 = h_pin[6].as<int8_t>();   // chain results
-  if (ng && !dev_post) PCHK(hipMemcpyAsync(st1, b_st.p, st_bytes, hipMemcpyDeviceToHost, stream));
-  lap("enum launch");
-
   // ---- host views of the regions (epilogue structures; LD blocks of the chain regions)
   PCHK(hipEventSynchronize(ev_csr));
   lap("wait fragment matrix");
@@ -1917,11 +1821,112 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     pool = new HostPool(nthreads > 1 ? nthreads : 0);
   }
   auto for_regions = [&](const std::function<void(int)>& fn) { pool->parallel_for(ng, fn); };
-  if (dev_post) pool->parallel_for((int)chain_slots.size(), [&](int k) { prep(chain_slots[k]); });
-  else for_regions(prep);
-  if (prof) { long ssum = 0, rsum = 0; for (int g : chain_slots) { ssum += in.cand_region_off[g + 1] - in.cand_region_off[g]; rsum += stat[g].R; }
-    fprintf(stderr, "[phase]   %zu chain regions (sum S %ld, sum phasing rows %ld), %zu enumeration regions, %d host threads\n", chain_slots.size(), ssum, rsum, enum_slots.size(), pool->size()); }
+  pool->parallel_for((int)chain_slots.size(), [&](int k) { prep(chain_slots[k]); });
   lap("host region prep + LD");
+  if (ng) PCHK(hipStreamSynchronize(stream));
+  lap("stage + sizes");
+
+  // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
+  int32_t max_state = 0;
+  // post-phase epilogue on the device (k4_post) unless a region does not fit its LDS image
+  bool dev_post = getenv("LCR_POST_HOST") == nullptr;
+  uint32_t post_lds = 0;
+  for (int g = 0; g < ng; g++) {
+    const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
+    if (S == 0) continue;
+    max_state = std::max(max_state, stat[g].R + 2 * S);
+    const int nr_g = in.row_region_off[g + 1] - in.row_region_off[g];
+    const uint32_t need = post_layout(nr_g, stat[g].E_all, S).total;
+    if (nr_g > POST_MAX_ROWS || stat[g].E_all > POST_MAX_ENTRIES || S > POST_MAX_SNPS || need > 64 * 1024) dev_post = false;
+    post_lds = std::max(post_lds, need);
+  }
+  PostLut plut;
+  for (int q = 0; q < 31; q++) { plut.le[q] = L.le[q]; plut.l1e[q] = L.l1e[q]; }
+  plut.p_homref = L.p_homref; plut.p_homvar = L.p_homvar; plut.log_theta = L.log_theta; plut.log2 = L.log2;
+  PostIn pin{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, const_cast<lcr_candidate*>(in.d_cand), in.d_cand_off,
+             in.d_row_region_off, in.d_start0, P.st_sigma, P.st_delta, P.st_eta, b_htag.as<int8_t>(), b_asg.as<uint8_t>(),
+             b_ps.as<uint32_t>(), prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr};
+  if (prof) { PCHK(d_state[20].reserve(32 * 8)); pin.dbg_clk = d_state[20].as<long long>(); }
+  if (dev_post && nrow) {
+    PCHK(hipMemsetAsync(b_htag.p, 0, (size_t)nrow, stream)); PCHK(hipMemsetAsync(b_asg.p, 0, (size_t)nrow, stream));
+    PCHK(hipMemsetAsync(b_ps.p, 0, (size_t)nrow * 4, stream));
+  }
+  if (!dev_post) { haplotag.assign(nrow, 0); assignment.assign(nrow, 0); phase_set.assign(nrow, 0); }
+  if (!dev_post)   // host epilogue: every region needs its host view (the chain regions have theirs)
+    for_regions([&](int g) { if ((uint32_t)(in.cand_region_off[g + 1] - in.cand_region_off[g]) <= prm.max_enum_snps) prep(g); });
+  const int32_t stride = (max_state + 63) & ~63;
+  P.scratch_stride = stride;
+  const size_t dyn_bytes = stride <= 48 * 1024 ? (size_t)stride : 0;  // chain working state in LDS when it fits
+  P.lds_state = dyn_bytes ? 1 : 0;
+  std::vector<uint8_t> packed;   // pageable upload source; must outlive the copy (synchronised below)
+  size_t n_big_blocks = 0;
+  if (!enum_slots.empty()) {
+    const bool force_big = getenv("LCR_ENUM_FORCE_BIG") != nullptr;        // test hooks: exercise the fallback kernels
+    const bool force_stream = getenv("LCR_ENUM_FORCE_STREAM") != nullptr;
+    // class 2: register-resident kernel (<= 32 entries per lane; smaller instantiations were measured: separate
+    // launches each pay their own tail, one CK=32 launch with early exits is faster); class 3: same kernel
+    // streaming its entries from LDS (any share size); class 4: global-memory kernel (matrix larger than the
+    // LDS budget); classes 0 / 1 unused
+    constexpr int NCLS = 5;
+    std::vector<EnumTile> tiles[NCLS], wtiles[NCLS];
+    std::vector<int64_t> job_base(ng, 0);
+    int64_t nj = 0;
+    uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0};
+    for (int g : enum_slots) {
+      const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
+      const StageStat& st = stat[g];
+      const EnumLayout EL = enum_layout(st.R, st.E);
+      int cls = 4;
+      if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_BYTES && st.max_rows <= 64)
+        cls = force_stream ? 3 : (st.max_n <= 32 ? 2 : 3);   // (the 8 / 16 instantiations: one launch has one tail)
+      if (cls < 4) lds_need[cls] = std::max(lds_need[cls], EL.total);
+      job_base[g] = nj;
+      const uint32_t n = 1u << S;
+      const uint32_t per = cls == 4 ? 1u : (cls == 3 ? 2u * ENUM_WAVES : ENUM_TILE_JOBS);
+      for (uint32_t e0 = 0; e0 < n; e0 += per) tiles[cls].push_back({g, e0, std::min(per, n - e0)});
+      wtiles[cls].push_back({g, 0, 1});
+      nj += n;
+    }
+    // one upload: tiles | winner tiles | job_base | slots ; then job objectives and winners
+    size_t n_t[NCLS], n_w[NCLS], n_tiles = 0;
+    for (int k = 0; k < NCLS; k++) { n_t[k] = tiles[k].size(); n_w[k] = wtiles[k].size(); n_tiles += n_t[k] + n_w[k]; }
+    const size_t ns = enum_slots.size();
+    const size_t off_jb_al = (n_tiles * sizeof(EnumTile) + 7) & ~(size_t)7;  // sizeof(EnumTile) == 12
+    packed.resize(off_jb_al + (size_t)ng * 8 + ns * 4);
+    size_t t_off[NCLS], w_off[NCLS], cursor = 0;
+    EnumTile* pt = (EnumTile*)packed.data();
+    for (int k = 0; k < NCLS; k++) { t_off[k] = cursor; memcpy(pt + cursor, tiles[k].data(), n_t[k] * sizeof(EnumTile)); cursor += n_t[k]; }
+    for (int k = 0; k < NCLS; k++) { w_off[k] = cursor; memcpy(pt + cursor, wtiles[k].data(), n_w[k] * sizeof(EnumTile)); cursor += n_w[k]; }
+    memcpy(packed.data() + off_jb_al, job_base.data(), (size_t)ng * 8);
+    memcpy(packed.data() + off_jb_al + (size_t)ng * 8, enum_slots.data(), ns * 4);
+    PCHK(b_job.reserve(packed.size() + 64));
+    PCHK(b_obj.reserve((size_t)nj * 8 + (size_t)ng * 4 + 64));
+    PCHK(hipMemcpyAsync(b_job.p, packed.data(), packed.size(), hipMemcpyHostToDevice, stream));
+    const EnumTile* d_t = b_job.as<EnumTile>();
+    const int64_t* d_jb = (const int64_t*)(b_job.as<uint8_t>() + off_jb_al);
+    const int32_t* d_sl = (const int32_t*)(b_job.as<uint8_t>() + off_jb_al + (size_t)ng * 8);
+    long long* d_obj = b_obj.as<long long>();
+    uint32_t* d_win = (uint32_t*)(d_obj + nj);
+    n_big_blocks = std::max(n_t[4], n_w[4]);
+    PCHK(b_scr.reserve((size_t)stride * (n_big_blocks + chain_slots.size()) + 64));   // chain regions use the tail
+    P.scratch = b_scr.as<int8_t>();
+    auto launch = [&](const size_t* cnt, const size_t* off, const uint32_t* win) {
+      const dim3 blk(64 * ENUM_WAVES);
+      if (cnt[2]) hipLaunchKernelGGL(k4_enum_reg<32>, dim3((unsigned)cnt[2]), blk, lds_need[2], stream, P, d_t + off[2], d_jb, d_obj, win);
+      if (cnt[3]) hipLaunchKernelGGL(k4_enum_reg<0>, dim3((unsigned)cnt[3]), blk, lds_need[3], stream, P, d_t + off[3], d_jb, d_obj, win);
+      if (cnt[4]) hipLaunchKernelGGL(k4_enum_big, dim3((unsigned)cnt[4]), dim3(LCR_BLOCK), 0, stream, P, d_t + off[4], d_jb, d_obj, win);
+    };
+    launch(n_t, t_off, nullptr);
+    hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)ns), dim3(64), 0, stream, d_sl, (int32_t)ns, P.reg, d_jb, d_obj, d_win);
+    launch(n_w, w_off, d_win);
+    if (dev_post) hipLaunchKernelGGL(k4_post<LCR_BLOCK>, dim3((unsigned)ns), dim3(LCR_BLOCK), post_lds, stream, pin, d_sl, (int32_t)ns, plut);
+    PCHK(hipGetLastError());
+  }
+  int8_t* const st1 = h_pin[4].as<int8_t>();   // enumeration results
+  int8_t* const st2 = h_pin[6].as<int8_t>();   // chain results
+  if (ng && !dev_post) PCHK(hipMemcpyAsync(st1, b_st.p, st_bytes, hipMemcpyDeviceToHost, stream));
+  lap("enum launch");
+
 
   // ---- chain regions on queue `side` (their own copy of the state arrays)
   if (!chain_slots.empty()) {
