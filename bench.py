@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--depth", type=float, default=40.0)
     ap.add_argument("--prewarm", type=int, default=40,
                     help="untimed passes during setup, before the W warm-up steps: allocations, thread pool, GPU clocks")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="batches in flight per GPU: N contexts driven by N host threads (a context per worker thread, as "
+                         "the reference's rayon workers would hold); 1 = one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     a = ap.parse_args()
@@ -148,41 +151,94 @@ def main():
     reads, regions, keep = to_device(batch, torch, dev)
     torch.cuda.synchronize()
 
-    E = api.Engine(local, params, timing=True)
-    E.set_stream(torch.cuda.current_stream().cuda_stream)  # torch.cuda.synchronize() then covers liblcr
+    F = max(1, a.inflight)
+    engines = [api.Engine(local, params, timing=True) for _ in range(F)]
+    E = engines[0]
+    if F == 1:
+        E.set_stream(torch.cuda.current_stream().cuda_stream)  # torch.cuda.synchronize() then covers liblcr
 
     G = shard.RecordGather(dist, dev, _abi.CAND_DTYPE) if dist is not None else None
     pending = [None]
 
-    def step():
-        E.load_batch((reads, regions, keep))
-        E.fill_data_into_freq_vec()
-        t_pile = (E.kernel_ms(_abi.K_PILEUP), E.kernel_ms(_abi.K_SPANS))  # HIP events on the ctx stream
-        E.get_candidate_snps().get_fragments().phase()
-        if G is not None:   # the gather of this batch's records (HBM to rank 0's HBM) overlaps the next batch's kernels
-            h = G.start(E.candidates_device())
-            if pending[0] is not None:
-                G.finish(pending[0], parse=False)
-            pending[0] = h
+    def step(Ej):
+        Ej.load_batch((reads, regions, keep))
+        Ej.fill_data_into_freq_vec()
+        t_pile = (Ej.kernel_ms(_abi.K_PILEUP), Ej.kernel_ms(_abi.K_SPANS))  # HIP events on the ctx stream
+        Ej.get_candidate_snps().get_fragments().phase()
         return t_pile
+
+    def publish(Ej):   # the gather of this batch's records (HBM to rank 0's HBM) overlaps the next batch's kernels
+        if G is None:
+            return
+        h = G.start(Ej.candidates_device())
+        if pending[0] is not None:
+            G.finish(pending[0], parse=False)
+        pending[0] = h
 
     def drain():   # the last batch is also brought to rank 0's host and decoded
         if G is not None and pending[0] is not None:
             G.finish(pending[0], parse=True)
             pending[0] = None
 
-    for _ in range(a.prewarm + a.warmup):
-        step()
+    def run_steps(n):
+        """n passes; with F > 1 batches in flight, thread j drives context j over passes j, j + F, ... and the
+        gathers are issued in pass order on every rank (collectives must line up across ranks)."""
+        piles = [None] * n
+        if F == 1:
+            for k in range(n):
+                piles[k] = step(E)
+                publish(E)
+            return piles
+        import threading
+        turn = threading.Condition()
+        nxt = [0]
+        errs = []
+
+        def worker(j):
+            try:
+                torch.cuda.set_device(local)
+                for k in range(j, n, F):
+                    piles[k] = step(engines[j])
+                    if G is not None:
+                        with turn:
+                            while nxt[0] < k:
+                                turn.wait()
+                            if nxt[0] != k:
+                                raise RuntimeError("another worker failed")
+                        publish(engines[j])
+                        torch.cuda.current_stream().synchronize()   # the records left the context's buffer
+                        with turn:
+                            nxt[0] = k + 1
+                            turn.notify_all()
+            except BaseException as e:   # noqa: BLE001 -- re-raised by the caller
+                errs.append(e)
+                with turn:
+                    nxt[0] = 1 << 60
+                    turn.notify_all()
+
+        ths = [threading.Thread(target=worker, args=(j,)) for j in range(F)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
+        return piles
+
+    def sync_all():
+        for Ej in engines:
+            Ej.sync()
+        torch.cuda.synchronize()
+
+    run_steps(a.prewarm + a.warmup)
     drain()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync_all()
     t0 = time.perf_counter()
-    pile_ms = []
-    for _ in range(a.steps):
-        pile_ms.append(step())
+    pile_ms = run_steps(a.steps)
     drain()   # the last batch's records are on rank 0 before the clock stops
-    torch.cuda.synchronize()
+    sync_all()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -237,7 +293,8 @@ def main():
                                       a.unique_genes, copies, synth.preset_for(a.profile)),
                        "columns_per_gpu": cols, "aligned_bases_per_gpu": int(batch.bases.size), "reads_per_gpu": batch.n_reads,
                        "candidates_per_gpu": int(cands.size), "fragment_nnz_per_gpu": int(fm["col"].size),
-                       "parallelism": "regions sharded over %d GPU(s), gather to rank 0" % world},
+                       "parallelism": "regions sharded over %d GPU(s), gather to rank 0" % world,
+                       "batches_in_flight_per_gpu": F},
             "roofline": {"bound": "hbm", "kernel": "k1_pileup", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "algorithmic_bytes": pbytes, "avg_ms": avg_ms,
                          "note": "k1_pileup (+ k1_zonefix on HiFi presets): read bases once + 8-byte records + 57 B/column",

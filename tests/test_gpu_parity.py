@@ -301,6 +301,50 @@ def test_dense_ops_span_several_pool_levels(engine_cls, orc):
     full_check(engine_cls, orc, b, _abi.make_params("ont-cdna", min_depth=3))
 
 
+def test_contexts_on_concurrent_host_threads(engine_cls):
+    """A context per worker thread (the reference runs its regions on a rayon pool): two contexts driven by
+    two host threads at the same time give, batch by batch, what one context gives alone."""
+    import threading
+    batches = [synth.make_batch("ont-cdna", n_genes=6, gene_len=9000, depth=35, seed=71),
+               synth.make_batch("ont-drna", n_genes=4, gene_len=20000, depth=40, seed=72)]
+    params = [_abi.make_params("ont-cdna", seed=3), _abi.make_params("ont-drna", seed=4)]
+
+    def snapshot(E):
+        c, off = E.candidates()
+        pr = E.phase_result()
+        return (E.columns().copy(), c.copy(), off.copy(), E.fragmat()["val"].copy(), pr["haplotag"].copy(),
+                pr["phase_set"].copy(), pr["objective"].copy())
+
+    want = []
+    for b, p in zip(batches, params):
+        E = engine_cls(0, p)
+        E.load_batch(b).run_all()
+        want.append(snapshot(E))
+        E.close()
+    got, errs = [[], []], []
+
+    def worker(j):
+        try:
+            E = engine_cls(0, params[j])
+            for _ in range(6):
+                E.load_batch(batches[j]).run_all()
+                got[j].append(snapshot(E))
+            E.close()
+        except BaseException as e:   # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker, args=(j,)) for j in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for j in range(2):
+        for snap in got[j]:
+            for a, b in zip(snap, want[j]):
+                assert a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
 def test_empty_batch_and_errors(engine_cls):
     from longcallr_amd.api import LcrError
     p = _abi.make_params()
