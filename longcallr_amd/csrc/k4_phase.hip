@@ -852,10 +852,10 @@ struct PostIn {
   const int8_t* st_sigma; const int8_t* st_delta; const int8_t* st_eta;
   int8_t* haplotag; uint8_t* assignment; uint32_t* phase_set;
   uint32_t min_linkers, max_enum_snps; uint64_t seed; double cutoff; float min_phase_score;
-  long long* dbg_clk;   // LCR_PHASE_PROF: 100 MHz timestamps of workgroup 0's steps (nullptr otherwise)
+  long long* dbg_clk;   // LCR_PHASE_PROF: 100 MHz timestamps of every workgroup's steps, 16 per region (nullptr otherwise)
 };
 constexpr int POST_MAX_ROWS = 8192, POST_MAX_ENTRIES = 8192, POST_MAX_SNPS = 512;
-struct PostLayout { uint32_t sps, rpa, rpb, sflags, soflags, parent, qcnt, rptr, ecol, erow, cent, ccptr, eval, tag, asg, fp, lok, shap, sgt, svt, rcode, total; };
+struct PostLayout { uint32_t sps, rpa, rpb, sflags, soflags, parent, qcnt, rptr, ecol, erow, cent, ccptr, eval, tag, asg, fp, lok, dirty, shap, sgt, svt, rcode, total; };
 __host__ __device__ inline PostLayout post_layout(uint32_t nrow, uint32_t E, uint32_t S) {
   PostLayout L;
   uint32_t o = 64 * 8;                       // le[32] | l1e[32]
@@ -868,6 +868,7 @@ __host__ __device__ inline PostLayout post_layout(uint32_t nrow, uint32_t E, uin
   L.ccptr = o; o += 2 * (S + 2);
   L.eval = o; o += E;
   L.tag = o; o += nrow; L.asg = o; o += nrow; L.fp = o; o += nrow; L.lok = o; o += nrow;
+  L.dirty = o; o += nrow;                    // rescue: rows whose fp / tag changed in the current round
   L.shap = o; o += S; L.sgt = o; o += S; L.svt = o; o += S; L.rcode = o; o += S;
   L.total = (o + 15) & ~15u;
   return L;
@@ -878,7 +879,7 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr int NW = NT / 64;
   __shared__ int sm[2][16];
-  __shared__ int s_flag;
+  __shared__ int s_flag, s_chg;
   __shared__ double stage[NW][4 * 65];
   if ((int)blockIdx.x >= n_slots) return;
   const int g = slots[blockIdx.x], tid = threadIdx.x, lane = tid & 63;
@@ -897,12 +898,13 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
   uint16_t* ccptr = (uint16_t*)(lds + L.ccptr);
   uint8_t* ev = lds + L.eval;
   int8_t* tag = (int8_t*)(lds + L.tag); uint8_t* asg = lds + L.asg; uint8_t* fp = lds + L.fp; uint8_t* lok = lds + L.lok;
+  uint8_t* dirty = lds + L.dirty;
   int8_t* shap = (int8_t*)(lds + L.shap); int8_t* sgt = (int8_t*)(lds + L.sgt); int8_t* svt = (int8_t*)(lds + L.svt);
   uint8_t* rcode = lds + L.rcode;
   lcr_candidate* cand = in.cand + c0;
 
   int n_mark = 0;
-  auto mark = [&]() { if (in.dbg_clk && blockIdx.x == 0 && tid == 0) in.dbg_clk[n_mark] = (long long)wall_clock64(); n_mark++; };
+  auto mark = [&]() { if (in.dbg_clk && tid == 0) in.dbg_clk[(size_t)g * 16 + n_mark] = (long long)wall_clock64(); n_mark++; };
   mark();
   // ---- stage: LUT, SNP state, rows (phasing-row index by scan), entries, row-ordered column index
   if (tid < 31) { le[tid] = lut.le[tid]; l1e[tid] = lut.l1e[tid]; }
@@ -1067,7 +1069,8 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
     }
     __syncthreads();
   };
-  // snpfrags.rs:378-546, one wave per SNP (all lanes hold the same values; lane 0 writes)
+  // snpfrags.rs:378-546, one wave per SNP (all lanes hold the same values; lane 0 writes).  s_chg is raised when a
+  // SNP's haplotype / genotype / variant type really change (see the pass sequence at the end).
   auto snp_hap = [&]() {
     for (int ti = wave; ti < S; ti += NW) {
       if (!(sflags[ti] & LCR_F_FOR_PHASING)) { if (lane == 0) sflags[ti] |= LCR_F_NON_SELECTED; continue; }
@@ -1109,15 +1112,20 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
         } else ps = -10.0 * log10(1.0 - psl(ti, nh, ng_, het_skip));
       }
       else ps = 0.19940219;
-      if (lane == 0) { shap[ti] = (int8_t)nh; sgt[ti] = (int8_t)ng_; svt[ti] = (int8_t)nv; sflags[ti] = fl; sps[ti] = ps; }
+      if (lane == 0) {
+        if (shap[ti] != nh || sgt[ti] != ng_ || svt[ti] != nv) s_chg = 1;   // (fl only ORs bits neither half reads)
+        shap[ti] = (int8_t)nh; sgt[ti] = (int8_t)ng_; svt[ti] = (int8_t)nv; sflags[ti] = fl; sps[ti] = ps;
+      }
     }
     __syncthreads();
   };
   // snpfrags.rs:191-376.  The list is walked in index order and a successful rescue changes fp / tag of
-  // its reads (and draws random numbers), which later list members see: all pending members are
-  // evaluated in parallel (a wave each) against the current state, thread 0 commits them in order up to
-  // and including the first success, and the members after it are evaluated again.
-  unsigned long long ctr = 0;   // thread 0: draws so far (thread.rs call order, see PhaseHost::run)
+  // its reads (and draws random numbers), which later list members see.  All pending members are
+  // evaluated in parallel (a wave each) against the current state; wave 0 then commits them in order,
+  // marking the rows a success really changes (fp 0 -> 1, tag drawn): a later member whose column holds
+  // no such row was evaluated on the state the reference would show it and is committed in the same
+  // round, the first member that does see a changed row starts the next round.
+  unsigned long long ctr = 0;   // wave 0: draws so far (thread.rs call order, see PhaseHost::run)
   {
     const unsigned long long Su = (unsigned long long)S, Fu = (unsigned long long)F;
     ctr = (uint32_t)S <= in.max_enum_snps ? Su + Fu + (1ull << S) * Fu : 2 * (Su + Fu) + (Su / 4 + 1) * (Su + Fu);
@@ -1125,6 +1133,7 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
   auto rescue = [&](uint32_t list_flag, float min_ps, bool low_frac, uint64_t rseed) {
     int start = 0;
     for (;;) {
+      for (int r = tid; r < nrow; r += NT) dirty[r] = 0;
       for (int ti = start + wave; ti < S; ti += NW) {
         uint8_t code = 0;
         if (soflags[ti] & list_flag) {
@@ -1146,34 +1155,53 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
         if (lane == 0) rcode[ti] = code;
       }
       __syncthreads();
-      if (tid == 0) {
+      if (wave == 0) {
         int ti = start;
+        bool changed = false;   // (wave-uniform) a success of this round changed some row
         for (; ti < S; ti++) {
           const uint8_t code = rcode[ti];
           if (code == 0) continue;
-          if (code == 1 || code == 3) { sflags[ti] |= LCR_F_SINGLE; continue; }
-          if (code == 2) { sflags[ti] |= LCR_F_NON_SELECTED; continue; }
-          sflags[ti] &= ~(uint32_t)LCR_F_SINGLE;
-          if (code == 5) {
-            sflags[ti] |= LCR_F_NON_SELECTED;
-            if (low_frac) { sflags[ti] |= LCR_F_CAND_SOMATIC; sflags[ti] &= ~(uint32_t)LCR_F_FOR_PHASING; }
-            else sflags[ti] |= LCR_F_RNA_EDIT;
-            continue;
+          if (code >= 3 && changed) {   // codes 1 / 2 do not look at the rows
+            bool stale = false;
+            for (int k = ccptr[ti] + lane; k < ccptr[ti + 1]; k += 64) stale = stale || dirty[erow[cent[k]]];
+            if (__any(stale)) break;    // evaluated on an outdated state: next round starts here
           }
-          sflags[ti] &= ~(uint32_t)(LCR_F_NON_SELECTED | LCR_F_RNA_EDIT);
-          if (low_frac) sflags[ti] &= ~(uint32_t)LCR_F_CAND_SOMATIC;
-          sflags[ti] |= LCR_F_FOR_PHASING;
-          for (int k = ccptr[ti]; k < ccptr[ti + 1]; k++) {
-            const int r = erow[cent[k]];
-            fp[r] = 1;
-            if (tag[r] == 0 || asg[r] == 0) tag[r] = u01(rseed, ctr++) < 0.5 ? -1 : 1;
+          if (code == 4) {
+            for (int k0 = ccptr[ti]; k0 < ccptr[ti + 1]; k0 += 64) {   // rows in column order: the draws keep their order
+              const int k = k0 + lane;
+              const bool in_col = k < ccptr[ti + 1];
+              const int r = in_col ? erow[cent[k]] : 0;
+              const bool draw = in_col && (tag[r] == 0 || asg[r] == 0);
+              const unsigned long long dm = __ballot(draw);
+              if (in_col && (draw || !fp[r])) dirty[r] = 1;
+              if (__any(in_col && (draw || !fp[r]))) changed = true;
+              if (in_col) fp[r] = 1;
+              if (draw) tag[r] = u01(rseed, ctr + (unsigned long long)__popcll(dm & ((1ull << lane) - 1ull))) < 0.5 ? -1 : 1;
+              ctr += (unsigned long long)__popcll(dm);
+            }
           }
-          shap[ti] = rpa[ti] >= rpb[ti] ? 1 : -1;
-          sgt[ti] = 0; svt[ti] = 1; sps[ti] = fmax(rpa[ti], rpb[ti]);
-          ti++;
-          break;
+          if (lane == 0) {
+            const uint32_t fl_old = sflags[ti];
+            if (code == 1 || code == 3) sflags[ti] |= LCR_F_SINGLE;
+            else if (code == 2) sflags[ti] |= LCR_F_NON_SELECTED;
+            else if (code == 5) {
+              sflags[ti] &= ~(uint32_t)LCR_F_SINGLE;
+              sflags[ti] |= LCR_F_NON_SELECTED;
+              if (low_frac) { sflags[ti] |= LCR_F_CAND_SOMATIC; sflags[ti] &= ~(uint32_t)LCR_F_FOR_PHASING; }
+              else sflags[ti] |= LCR_F_RNA_EDIT;
+            } else {   // rescued
+              sflags[ti] &= ~(uint32_t)(LCR_F_SINGLE | LCR_F_NON_SELECTED | LCR_F_RNA_EDIT);
+              if (low_frac) sflags[ti] &= ~(uint32_t)LCR_F_CAND_SOMATIC;
+              sflags[ti] |= LCR_F_FOR_PHASING;
+              shap[ti] = rpa[ti] >= rpb[ti] ? 1 : -1;
+              sgt[ti] = 0; svt[ti] = 1; sps[ti] = fmax(rpa[ti], rpb[ti]);
+              s_chg = 1;
+            }
+            if ((sflags[ti] ^ fl_old) & LCR_F_FOR_PHASING) s_chg = 1;
+          }
+          wave_lds_sync();
         }
-        s_flag = ti;
+        if (lane == 0) s_flag = ti;
       }
       __syncthreads();
       start = s_flag;
@@ -1243,13 +1271,33 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
   };
 
   const uint64_t rseed = region_seed(in.seed, in.start0[g]);
+  // thread.rs:168-201 runs (assign reads, assign SNPs) twice, the two rescue lists, and the pair once more.  The
+  // pair reads the SNPs' haplotype / genotype / variant type / FOR_PHASING bit and the rows' fp / tag and is
+  // idempotent on them: reads_hap applied to its own output under the same SNP state changes nothing (a flipped
+  // row's q / qn swap, bit for bit), snp_hap then recomputes the same values and ORs the same flag bits.  So a
+  // pair is a no-op -- and skipped -- when neither the previous snp_hap nor the rescues changed one of those
+  // fields (s_chg); the other flag bits are only ever written.
+  if (tid == 0) s_chg = 0;
+  __syncthreads();
   reads_hap(); mark(); snp_hap(); mark();
-  reads_hap(); snp_hap(); mark();
+  bool redo = s_chg != 0;
+  __syncthreads();
+  if (tid == 0) s_chg = 0;
+  __syncthreads();
+  if (redo) {
+    reads_hap(); snp_hap();
+    redo = s_chg != 0;
+    __syncthreads();
+    if (tid == 0) s_chg = 0;
+    __syncthreads();
+  }
+  mark();
   const float relaxed = in.min_phase_score - 3.0f;
   rescue(LCR_F_RNA_EDIT, relaxed, false, rseed);
   rescue(LCR_F_CAND_SOMATIC, relaxed, true, rseed);
   mark();
-  reads_hap(); snp_hap(); mark();
+  if (redo || s_chg != 0) { reads_hap(); snp_hap(); }
+  mark();
   phase_set();
   mark();
   for (int i = tid; i < S; i += NT) {
@@ -1846,7 +1894,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   PostIn pin{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, const_cast<lcr_candidate*>(in.d_cand), in.d_cand_off,
              in.d_row_region_off, in.d_start0, P.st_sigma, P.st_delta, P.st_eta, b_htag.as<int8_t>(), b_asg.as<uint8_t>(),
              b_ps.as<uint32_t>(), prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr};
-  if (prof) { PCHK(d_state[20].reserve(32 * 8)); pin.dbg_clk = d_state[20].as<long long>(); }
+  if (prof) { PCHK(d_state[20].reserve((size_t)std::max(ng, 1) * 16 * 8)); PCHK(hipMemsetAsync(d_state[20].p, 0, (size_t)std::max(ng, 1) * 16 * 8, stream)); pin.dbg_clk = d_state[20].as<long long>(); }
   if (dev_post && nrow) {
     PCHK(hipMemsetAsync(b_htag.p, 0, (size_t)nrow, stream)); PCHK(hipMemsetAsync(b_asg.p, 0, (size_t)nrow, stream));
     PCHK(hipMemsetAsync(b_ps.p, 0, (size_t)nrow * 4, stream));
@@ -2059,12 +2107,26 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       objective[g] = (double)(*((const long long*)(st + st_obj) + g)) / FX_SCALE;
     }
     r_haplotag = h_tag; r_assignment = h_asg; r_phase_set = h_ps;
-    if (prof && pin.dbg_clk) {   // steps of k4_post, first workgroup of the last launch on either queue
-      long long clk[16];
-      PCHK(hipMemcpy(clk, pin.dbg_clk, sizeof(clk), hipMemcpyDeviceToHost));
+    if (prof && pin.dbg_clk) {   // steps of k4_post: the slowest workgroup of each kind of region, and the median total
+      std::vector<long long> clk((size_t)ng * 16);
+      PCHK(hipMemcpy(clk.data(), pin.dbg_clk, clk.size() * 8, hipMemcpyDeviceToHost));
       static const char* nm[] = {"stage rows", "stage entries + column index", "reads_hap", "snp_hap", "reads_hap + snp_hap", "rescue x2",
                                  "reads_hap + snp_hap", "phase_set", "write back"};
-      for (int k = 0; k < 9; k++) fprintf(stderr, "[phase]   k4_post %-30s %7.1f us\n", nm[k], (double)(clk[k + 1] - clk[k]) / 100.0);
+      for (int chain = 0; chain < 2; chain++) {
+        std::vector<std::pair<long long, int>> tot;
+        for (int g = 0; g < ng; g++) {
+          const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
+          if (S == 0 || ((uint32_t)S > prm.max_enum_snps) != (chain == 1)) continue;
+          tot.push_back({clk[(size_t)g * 16 + 9] - clk[(size_t)g * 16], g});
+        }
+        if (tot.empty()) continue;
+        std::sort(tot.begin(), tot.end());
+        const int g = tot.back().second;
+        fprintf(stderr, "[phase]   k4_post %s regions: %zu workgroups, median %.1f us, slowest %.1f us (region %d: %d rows, %d entries, %d SNPs)\n",
+                chain ? "chain" : "enumeration", tot.size(), (double)tot[tot.size() / 2].first / 100.0, (double)tot.back().first / 100.0, g,
+                in.row_region_off[g + 1] - in.row_region_off[g], stat[g].E_all, in.cand_region_off[g + 1] - in.cand_region_off[g]);
+        for (int k = 0; k < 9; k++) fprintf(stderr, "[phase]     %-30s %7.1f us\n", nm[k], (double)(clk[(size_t)g * 16 + k + 1] - clk[(size_t)g * 16 + k]) / 100.0);
+      }
     }
     lap("device epilogue + results");
     return LCR_OK;
