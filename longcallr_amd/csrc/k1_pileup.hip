@@ -54,6 +54,42 @@ __global__ void __launch_bounds__(LCR_BLOCK) k0_tiles(const int32_t* __restrict_
   const int g = blockIdx.x, t0 = first_tile[g], t1 = first_tile[g + 1];
   for (int t = t0 + threadIdx.x; t < t1; t += blockDim.x) { tile_region[t] = g; tile_col0[t] = (t - t0) * LCR_TILE; }
 }
+// region table setup, one workgroup: first tile of every region (prefix sum of ceil(len / LCR_TILE)) and, for a
+// device-resident batch, the four small region arrays written straight into pinned host memory (one kernel
+// instead of four copies; the host validates them after its wait)
+__global__ void __launch_bounds__(1024) k0_region_setup(const int64_t* __restrict__ start0, const int32_t* __restrict__ len,
+                                                         const int64_t* __restrict__ col_off, const int32_t* __restrict__ read_begin,
+                                                         int32_t ng, int32_t* __restrict__ first_tile, int64_t* h_start0,
+                                                         int32_t* h_len, int64_t* h_col_off, int32_t* h_read_begin) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (h_start0) {
+    for (int g = tid; g < ng; g += 1024) { h_start0[g] = start0[g]; h_len[g] = len[g]; }
+    for (int g = tid; g <= ng; g += 1024) { h_col_off[g] = col_off[g]; h_read_begin[g] = read_begin[g]; }
+  }
+  if (tid == 0) { base_s = 0; first_tile[0] = 0; }
+  __syncthreads();
+  for (int g0 = 0; g0 < ng; g0 += 1024) {
+    const int g = g0 + tid;
+    const int n = g < ng ? (max(len[g], 0) + LCR_TILE - 1) / LCR_TILE : 0;
+    const int incl = wave_incl_scan(n);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = base_s;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    if (g < ng) first_tile[g + 1] = before + incl;
+    __syncthreads();
+    if (tid == 1023) base_s = before + incl;
+    __syncthreads();
+  }
+}
+void launch_k0_region_setup(const int64_t* start0, const int32_t* len, const int64_t* col_off, const int32_t* read_begin, int32_t ng,
+                            int32_t* first_tile, int64_t* h_start0, int32_t* h_len, int64_t* h_col_off, int32_t* h_read_begin,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(k0_region_setup, dim3(1), dim3(1024), 0, s, start0, len, col_off, read_begin, ng, first_tile, h_start0, h_len,
+                     h_col_off, h_read_begin);
+}
 void launch_k0_tiles(const int32_t* first_tile, int32_t n_regions, int32_t* tile_region, int32_t* tile_col0, hipStream_t s) {
   if (n_regions > 0) hipLaunchKernelGGL(k0_tiles, dim3(n_regions), dim3(LCR_BLOCK), 0, s, first_tile, tile_region, tile_col0);
 }
@@ -113,7 +149,7 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* _
   const unsigned long long rowmask = 0xFFFFull << rbase;
   const int n_groups = gridDim.x * (LCR_BLOCK / 16);
   const int n_steps = (b.n_reads + n_groups - 1) / n_groups;
-  unsigned int n_items = 0;
+  unsigned int n_items = 0, n_recs = 0;   // lane 0: M / D / I items; every lane: records it reserved slots for
   auto lvl_wait = [&](int tile, int lvl) {   // pool offset of a tile's level (bounded wait on its allocator)
     int at, spins = 0;
     while ((at = __hip_atomic_load(&tile_lvl[tile * LCR_REC_LEVELS + lvl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
@@ -210,7 +246,7 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* _
       {
         int cn[4], bs[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { cn[j] = R.ctr[l16 + 16 * j]; bs[j] = 0; }
+        for (int j = 0; j < 4; j++) { cn[j] = R.ctr[l16 + 16 * j]; bs[j] = 0; n_recs += (unsigned int)cn[j]; }
 #pragma unroll
         for (int j = 0; j < 4; j++)
           if (cn[j] > 0) bs[j] = atomicAdd(&tile_fill[ftile + tw0 + l16 + 16 * j], cn[j]);
@@ -277,6 +313,8 @@ k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* _
     }
   }
   if (lane == 0 && n_items) atomicAdd(pool_top + 1, n_items);
+  n_recs = (unsigned int)wave_incl_scan((int)n_recs);   // byte accounting and pool sizing: records of all tiles
+  if (lane == 63 && n_recs) atomicAdd(pool_top + 2, n_recs);
 }
 
 // workgroups of K0 that are resident at once on the current device: the persistent kernel strides over the

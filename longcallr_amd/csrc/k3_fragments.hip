@@ -26,6 +26,31 @@ void launch_k3_rows(const BatchView& b, const lcr_candidate* cand, const int32_t
   hipLaunchKernelGGL(k3_rows, dim3((b.n_regions + 255) / 256), dim3(256), 0, s, b, cand, cand_region_off, region_rows);
 }
 
+// first row of every region: exclusive prefix sum of region_rows (one workgroup; a batch has at most a few
+// thousand regions), so that lcr_fragments starts without an upload
+__global__ void __launch_bounds__(1024) k3_row_offsets(const int32_t* __restrict__ region_rows, int32_t ng, int32_t* __restrict__ row_region_off) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { base_s = 0; row_region_off[0] = 0; }
+  __syncthreads();
+  for (int g0 = 0; g0 < ng; g0 += 1024) {
+    const int g = g0 + tid;
+    const int incl = wave_incl_scan(g < ng ? region_rows[g] : 0);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = base_s;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    if (g < ng) row_region_off[g + 1] = before + incl;
+    __syncthreads();
+    if (tid == 1023) base_s = before + incl;
+    __syncthreads();
+  }
+}
+void launch_k3_row_offsets(const int32_t* region_rows, int32_t ng, int32_t* row_region_off, hipStream_t s) {
+  hipLaunchKernelGGL(k3_row_offsets, dim3(1), dim3(1024), 0, s, region_rows, ng, row_region_off);
+}
+
 // Sixteen lanes per row (row16_walk_sites, lcr_dev.h): the region's candidates inside the read's reference
 // span are located against the CIGAR spread over the lanes; a row without such candidates never loads
 // its CIGAR.  No trimming here: the reference's fragment walk takes every aligned base.

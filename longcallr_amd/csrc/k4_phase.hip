@@ -850,7 +850,8 @@ struct PostIn {
   const int64_t* row_ptr; const int32_t* col; const uint8_t* val; const uint32_t* links;
   lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off; const int64_t* start0;
   const int8_t* st_sigma; const int8_t* st_delta; const int8_t* st_eta;
-  int8_t* haplotag; uint8_t* assignment; uint32_t* phase_set;
+  int8_t* haplotag; uint8_t* assignment; uint32_t* phase_set;   // per-row results: pinned host memory, written by the kernel
+  const long long* st_obj; long long* h_obj; lcr_candidate* h_cand;   // objective / candidate mirror in pinned host memory
   uint32_t min_linkers, max_enum_snps; uint64_t seed; double cutoff; float min_phase_score;
   long long* dbg_clk;   // LCR_PHASE_PROF: 100 MHz timestamps of every workgroup's steps, 16 per region (nullptr otherwise)
 };
@@ -1300,10 +1301,13 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
   mark();
   phase_set();
   mark();
+  // results straight into pinned host memory (device-visible): the host only waits for the kernels, no copies follow
   for (int i = tid; i < S; i += NT) {
     cand[i].haplotype = shap[i]; cand[i].genotype = sgt[i]; cand[i].variant_type = svt[i];
     cand[i].flags = sflags[i]; cand[i].phase_score = sps[i];
+    in.h_cand[c0 + i] = cand[i];   // (phase_set was written by this thread above)
   }
+  if (tid == 0) in.h_obj[g] = in.st_obj[g];
   for (int r = tid; r < nrow; r += NT) { in.haplotag[r0 + r] = tag[r]; in.assignment[r0 + r] = asg[r]; }
   mark();
 }
@@ -1637,6 +1641,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     PCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
     PCHK(hipEventCreateWithFlags(&ev_csr, hipEventDisableTiming));
+    PCHK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+    PCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    PCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
   }
   const HostLut& L = hlut();
 
@@ -1644,7 +1651,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   DevBuf &b_reg = d_state[0], &b_prp = d_state[1], &b_pc = d_state[2], &b_pv = d_state[3], &b_cp = d_state[4],
          &b_cr = d_state[5], &b_cv = d_state[6], &b_snp = d_state[7], &b_st = d_state[8], &b_scr = d_state[9],
          &b_job = d_state[10], &b_obj = d_state[11], &b_sc = d_state[12], &b_stat = d_state[13], &b_cur = d_state[14],
-         &b_stc = d_state[15], &b_slots = d_state[16], &b_htag = d_state[17], &b_asg = d_state[18], &b_ps = d_state[19];
+         &b_stc = d_state[15], &b_slots = d_state[16];
   const size_t nnz1 = (size_t)std::max<int64_t>(nnz, 1), nc1 = (size_t)std::max(ncand, 1), nr1 = (size_t)std::max(nrow, 1);
   PCHK(b_reg.reserve((size_t)std::max(ng, 1) * sizeof(RegionDev)));
   PCHK(b_stat.reserve((size_t)std::max(ng, 1) * sizeof(StageStat)));
@@ -1660,8 +1667,15 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   PCHK(h_pin[2].reserve(nnz1)); PCHK(h_pin[3].reserve(nr1 * 4));
   PCHK(h_pin[4].reserve(st_bytes + 16)); PCHK(h_pin[5].reserve((size_t)std::max(ng, 1) * sizeof(StageStat)));
   PCHK(h_pin[6].reserve(st_bytes + 16));
-  PCHK(b_htag.reserve(nr1)); PCHK(b_asg.reserve(nr1)); PCHK(b_ps.reserve(nr1 * 4));
-  PCHK(h_pin[7].reserve(nr1)); PCHK(h_pin[8].reserve(nr1)); PCHK(h_pin[9].reserve(nr1 * 4));
+  // results of the device epilogue live in pinned host memory that k4_post writes itself (every row belongs to a
+  // region with candidates, fragment.rs:24-26, so every row is written): phase set u32 | haplotag | assignment, and
+  // candidate mirror | objectives
+  const size_t res_ps = 0, res_tag = nr1 * 4, res_asg = nr1 * 5, res_bytes = nr1 * 6;
+  const size_t hc_obj = (nc1 * sizeof(lcr_candidate) + 15) & ~(size_t)15;
+  PCHK(h_pin[7].reserve(res_bytes)); PCHK(h_pin[9].reserve(hc_obj + (size_t)std::max(ng, 1) * 8));
+  uint8_t* d_res = nullptr; uint8_t* d_hc = nullptr;   // device-side addresses of the two pinned blocks
+  PCHK(hipHostGetDevicePointer((void**)&d_res, h_pin[7].p, 0));
+  PCHK(hipHostGetDevicePointer((void**)&d_hc, h_pin[9].p, 0));
 
   PhaseDev P{};
   P.reg = b_reg.as<RegionDev>();
@@ -1710,8 +1724,6 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     if ((uint32_t)S <= prm.max_enum_snps) enum_slots.push_back(g); else chain_slots.push_back(g);
   }
   // ---- host views of the regions (epilogue structures; LD blocks of the chain regions)
-  PCHK(hipEventSynchronize(ev_csr));
-  lap("wait fragment matrix");
   struct Arr64 { int64_t* p; int64_t& operator[](size_t i) const { return p[i]; } int64_t* data() const { return p; } } row_ptr{row_ptr_p};
   struct Arr32 { int32_t* p; int32_t& operator[](size_t i) const { return p[i]; } int32_t* data() const { return p; } } col{col_p};
   struct Arr8 { uint8_t* p; uint8_t& operator[](size_t i) const { return p[i]; } uint8_t* data() const { return p; } } val{val_p};
@@ -1869,8 +1881,22 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     pool = new HostPool(nthreads > 1 ? nthreads : 0);
   }
   auto for_regions = [&](const std::function<void(int)>& fn) { pool->parallel_for(ng, fn); };
-  pool->parallel_for((int)chain_slots.size(), [&](int k) { prep(chain_slots[k]); });
-  lap("host region prep + LD");
+  // a helper thread waits for the fragment matrix and prepares the chain regions while this thread sizes and
+  // launches the enumeration; joined before the chain kernels (and on every early return)
+  struct Helper {
+    std::thread t; hipError_t err = hipSuccess;
+    void join() { if (t.joinable()) t.join(); }
+    ~Helper() { join(); }
+  } helper;
+  {
+    int dev = 0;
+    PCHK(hipGetDevice(&dev));
+    helper.t = std::thread([&, dev]() {
+      if ((helper.err = hipSetDevice(dev)) != hipSuccess) return;
+      if ((helper.err = hipEventSynchronize(ev_csr)) != hipSuccess) return;
+      pool->parallel_for((int)chain_slots.size(), [&](int k) { prep(chain_slots[k]); });
+    });
+  }
   if (ng) PCHK(hipStreamSynchronize(stream));
   lap("stage + sizes");
 
@@ -1892,15 +1918,15 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   for (int q = 0; q < 31; q++) { plut.le[q] = L.le[q]; plut.l1e[q] = L.l1e[q]; }
   plut.p_homref = L.p_homref; plut.p_homvar = L.p_homvar; plut.log_theta = L.log_theta; plut.log2 = L.log2;
   PostIn pin{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, const_cast<lcr_candidate*>(in.d_cand), in.d_cand_off,
-             in.d_row_region_off, in.d_start0, P.st_sigma, P.st_delta, P.st_eta, b_htag.as<int8_t>(), b_asg.as<uint8_t>(),
-             b_ps.as<uint32_t>(), prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr};
+             in.d_row_region_off, in.d_start0, P.st_sigma, P.st_delta, P.st_eta, (int8_t*)(d_res + res_tag), d_res + res_asg,
+             (uint32_t*)(d_res + res_ps), P.st_obj, (long long*)(d_hc + hc_obj), (lcr_candidate*)d_hc, prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr};
   if (prof) { PCHK(d_state[20].reserve((size_t)std::max(ng, 1) * 16 * 8)); PCHK(hipMemsetAsync(d_state[20].p, 0, (size_t)std::max(ng, 1) * 16 * 8, stream)); pin.dbg_clk = d_state[20].as<long long>(); }
-  if (dev_post && nrow) {
-    PCHK(hipMemsetAsync(b_htag.p, 0, (size_t)nrow, stream)); PCHK(hipMemsetAsync(b_asg.p, 0, (size_t)nrow, stream));
-    PCHK(hipMemsetAsync(b_ps.p, 0, (size_t)nrow * 4, stream));
-  }
   if (!dev_post) { haplotag.assign(nrow, 0); assignment.assign(nrow, 0); phase_set.assign(nrow, 0); }
-  if (!dev_post)   // host epilogue: every region needs its host view (the chain regions have theirs)
+  if (!dev_post) {   // host epilogue: every region needs its host view (the chain regions get theirs from the helper)
+    helper.join();
+    PCHK(helper.err);
+  }
+  if (!dev_post)
     for_regions([&](int g) { if ((uint32_t)(in.cand_region_off[g + 1] - in.cand_region_off[g]) <= prm.max_enum_snps) prep(g); });
   const int32_t stride = (max_state + 63) & ~63;
   P.scratch_stride = stride;
@@ -1949,7 +1975,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     memcpy(packed.data() + off_jb_al + (size_t)ng * 8, enum_slots.data(), ns * 4);
     PCHK(b_job.reserve(packed.size() + 64));
     PCHK(b_obj.reserve((size_t)nj * 8 + (size_t)ng * 4 + 64));
-    PCHK(hipMemcpyAsync(b_job.p, packed.data(), packed.size(), hipMemcpyHostToDevice, stream));
+    PCHK(h_pin[8].reserve(packed.size() + 64));   // pinned: the upload is queued, not staged
+    memcpy(h_pin[8].p, packed.data(), packed.size());
+    PCHK(hipMemcpyAsync(b_job.p, h_pin[8].p, packed.size(), hipMemcpyHostToDevice, stream));
     const EnumTile* d_t = b_job.as<EnumTile>();
     const int64_t* d_jb = (const int64_t*)(b_job.as<uint8_t>() + off_jb_al);
     const int32_t* d_sl = (const int32_t*)(b_job.as<uint8_t>() + off_jb_al + (size_t)ng * 8);
@@ -1958,15 +1986,22 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     n_big_blocks = std::max(n_t[4], n_w[4]);
     PCHK(b_scr.reserve((size_t)stride * (n_big_blocks + chain_slots.size()) + 64));   // chain regions use the tail
     P.scratch = b_scr.as<int8_t>();
-    auto launch = [&](const size_t* cnt, const size_t* off, const uint32_t* win) {
+    // the classes touch disjoint regions: class 2 on `stream`, classes 3 / 4 beside it on `aux` (their tails overlap)
+    auto launch = [&](const size_t* cnt, const size_t* off, const uint32_t* win) -> hipError_t {
       const dim3 blk(64 * ENUM_WAVES);
+      const bool fork = cnt[2] && (cnt[3] || cnt[4]);
+      hipStream_t s34 = fork ? aux : stream;
+      hipError_t e = hipSuccess;
+      if (fork) { if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e; }
       if (cnt[2]) hipLaunchKernelGGL(k4_enum_reg<32>, dim3((unsigned)cnt[2]), blk, lds_need[2], stream, P, d_t + off[2], d_jb, d_obj, win);
-      if (cnt[3]) hipLaunchKernelGGL(k4_enum_reg<0>, dim3((unsigned)cnt[3]), blk, lds_need[3], stream, P, d_t + off[3], d_jb, d_obj, win);
-      if (cnt[4]) hipLaunchKernelGGL(k4_enum_big, dim3((unsigned)cnt[4]), dim3(LCR_BLOCK), 0, stream, P, d_t + off[4], d_jb, d_obj, win);
+      if (cnt[3]) hipLaunchKernelGGL(k4_enum_reg<0>, dim3((unsigned)cnt[3]), blk, lds_need[3], s34, P, d_t + off[3], d_jb, d_obj, win);
+      if (cnt[4]) hipLaunchKernelGGL(k4_enum_big, dim3((unsigned)cnt[4]), dim3(LCR_BLOCK), 0, s34, P, d_t + off[4], d_jb, d_obj, win);
+      if (fork) { if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e; }
+      return e;
     };
-    launch(n_t, t_off, nullptr);
+    PCHK(launch(n_t, t_off, nullptr));
     hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)ns), dim3(64), 0, stream, d_sl, (int32_t)ns, P.reg, d_jb, d_obj, d_win);
-    launch(n_w, w_off, d_win);
+    PCHK(launch(n_w, w_off, d_win));
     if (dev_post) hipLaunchKernelGGL(k4_post<LCR_BLOCK>, dim3((unsigned)ns), dim3(LCR_BLOCK), post_lds, stream, pin, d_sl, (int32_t)ns, plut);
     PCHK(hipGetLastError());
   }
@@ -1974,6 +2009,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   int8_t* const st2 = h_pin[6].as<int8_t>();   // chain results
   if (ng && !dev_post) PCHK(hipMemcpyAsync(st1, b_st.p, st_bytes, hipMemcpyDeviceToHost, stream));
   lap("enum launch");
+  helper.join();
+  PCHK(helper.err);
+  lap("chain regions prepared (helper thread)");
 
 
   // ---- chain regions on queue `side` (their own copy of the state arrays)
@@ -2075,12 +2113,11 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     hipLaunchKernelGGL(k4_chain_b, dim3(nc), dim3(CHAIN_THREADS), dyn_bytes + (size_t)Pc.lds_mat, side, Pc, b_slots.as<int32_t>(), nc);
     if (dev_post) {
       PostIn pinc = pin;
-      pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta;
+      pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta; pinc.st_obj = Pc.st_obj;
       // 33 KB of static stage buffers + up to 64 KB of region image (set per call: the attribute is per device)
       PCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_post<CHAIN_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       hipLaunchKernelGGL(k4_post<CHAIN_THREADS>, dim3(nc), dim3(CHAIN_THREADS), post_lds, side, pinc, b_slots.as<int32_t>(), nc, plut);
       PCHK(hipGetLastError());
-      PCHK(hipMemcpyAsync(st2 + st_obj, b_stc.as<int8_t>() + st_obj, (size_t)ng * 8, hipMemcpyDeviceToHost, side));
     } else {
       PCHK(hipGetLastError());
       PCHK(hipMemcpyAsync(st2, b_stc.p, st_bytes, hipMemcpyDeviceToHost, side));
@@ -2089,23 +2126,16 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   }
   lap("chain kernels + block pass");
   if (dev_post) {
-    // results: per-row haplotag / assignment / phase set, the candidates (updated in place on the device), objectives
-    int8_t* const h_tag = h_pin[7].as<int8_t>(); uint8_t* const h_asg = h_pin[8].as<uint8_t>(); uint32_t* const h_ps = h_pin[9].as<uint32_t>();
-    if (nrow) {
-      PCHK(hipMemcpyAsync(h_tag, b_htag.p, (size_t)nrow, hipMemcpyDeviceToHost, stream));
-      PCHK(hipMemcpyAsync(h_asg, b_asg.p, (size_t)nrow, hipMemcpyDeviceToHost, stream));
-      PCHK(hipMemcpyAsync(h_ps, b_ps.p, (size_t)nrow * 4, hipMemcpyDeviceToHost, stream));
-    }
-    if (ncand) PCHK(hipMemcpyAsync(cand.data(), in.d_cand, (size_t)ncand * sizeof(lcr_candidate), hipMemcpyDeviceToHost, stream));
-    if (ng) PCHK(hipMemcpyAsync(st1 + st_obj, b_st.as<int8_t>() + st_obj, (size_t)ng * 8, hipMemcpyDeviceToHost, stream));
+    // results: per-row haplotag / assignment / phase set, candidates and objectives were written to pinned host
+    // memory by k4_post on either queue (`side` is settled above)
+    uint8_t* const h_res = h_pin[7].as<uint8_t>();
+    int8_t* const h_tag = (int8_t*)(h_res + res_tag); uint8_t* const h_asg = h_res + res_asg; uint32_t* const h_ps = (uint32_t*)(h_res + res_ps);
     PCHK(hipStreamSynchronize(stream));
     PCHK(hipGetLastError());
-    for (int g = 0; g < ng; g++) {
-      const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
-      if (S == 0) continue;
-      const int8_t* st = (uint32_t)S > prm.max_enum_snps ? st2 : st1;
-      objective[g] = (double)(*((const long long*)(st + st_obj) + g)) / FX_SCALE;
-    }
+    if (ncand) memcpy(cand.data(), h_pin[9].p, (size_t)ncand * sizeof(lcr_candidate));
+    const long long* const h_obj = (const long long*)(h_pin[9].as<uint8_t>() + hc_obj);
+    for (int g = 0; g < ng; g++)
+      if (in.cand_region_off[g + 1] > in.cand_region_off[g]) objective[g] = (double)h_obj[g] / FX_SCALE;
     r_haplotag = h_tag; r_assignment = h_asg; r_phase_set = h_ps;
     if (prof && pin.dbg_clk) {   // steps of k4_post: the slowest workgroup of each kind of region, and the median total
       std::vector<long long> clk((size_t)ng * 16);

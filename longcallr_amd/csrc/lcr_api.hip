@@ -23,7 +23,7 @@ struct lcr_ctx {
   std::vector<int64_t> h_start0, h_col_off;
   std::vector<int32_t> h_len, h_read_begin, h_region_first_tile;
   DevBuf in_[16];  // device copies of host inputs (LCR_MEM_HOST)
-  DevBuf scan_tmp, read_region, read_bin, read_rend, errflag, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_off, k0_tile_fill, k0_items, ndiff, nscan;
+  DevBuf scan_tmp, read_region, read_bin, read_rend, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_fill, k0_items, ndiff, nscan;
   int64_t n_items = 0;
 
   // K1
@@ -32,6 +32,9 @@ struct lcr_ctx {
   DevParams dp{};
   float sor_thr = -1.f;
   HostBuf h_planes;
+  HostBuf h_nnz;              // pinned: entry count of the fragment matrix (lcr_fragments -> frag_settle)
+  hipEvent_t ev_nnz = nullptr;
+  bool nnz_pending = false;
   HostBuf h_stage[4];   // pinned staging of lcr_candidates / lcr_fragments: survivor offsets, candidate records, keep flags, region rows
 
   // K2
@@ -140,13 +143,14 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto& b : c->in_) b.release();
   DevBuf* bufs[] = {&c->rd_start, &c->rd_end, &c->rd_diff, &c->rd_ex, &c->rd_cnt, &c->rd_off, &c->rd_s, &c->rd_e, &c->rd_max,
-                    &c->scan_tmp, &c->read_region, &c->read_bin, &c->read_rend, &c->errflag, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, &c->k0_tile_off,
+                    &c->scan_tmp, &c->read_region, &c->read_bin, &c->read_rend, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, 
                     &c->k0_tile_fill, &c->k0_items, &c->ndiff, &c->nscan, &c->planes, &c->flags,
                     &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
                     &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
                     &c->row_links, &c->row_ptr, &c->col, &c->val};
   for (auto* b : bufs) b->release();
-  HostBuf* hb[] = {&c->h_stage[0], &c->h_stage[1], &c->h_stage[2], &c->h_stage[3], &c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
+  if (c->ev_nnz) (void)hipEventDestroy(c->ev_nnz);
+  HostBuf* hb[] = {&c->h_nnz, &c->h_stage[0], &c->h_stage[1], &c->h_stage[2], &c->h_stage[3], &c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
   for (auto* b : hb) b->release();
   c->phase.release();
   for (int k = 0; k < LCR_NKERNELS; k++) for (int j = 0; j < 2; j++) if (c->ev[k][j]) (void)hipEventDestroy(c->ev[k][j]);
@@ -205,17 +209,15 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
     if (ng) { memcpy(c->h_start0.data(), rg->start0, ng * sizeof(int64_t)); memcpy(c->h_len.data(), rg->len, ng * sizeof(int32_t)); }
     memcpy(c->h_col_off.data(), rg->col_off, (ng + 1) * sizeof(int64_t));
     memcpy(c->h_read_begin.data(), rg->read_begin, (ng + 1) * sizeof(int32_t));
-  } else {   // device-resident batch: the four small region arrays through one pinned buffer, one wait
+  } else {   // device-resident batch: one kernel writes the four small region arrays into pinned host memory, one wait
     const size_t o1 = (size_t)ng * 8, o2 = o1 + (size_t)(ng + 1) * 8, o3 = o2 + (size_t)ng * 4, tot = o3 + (size_t)(ng + 1) * 4;
     HIPCHK(c, c->h_stage[0].reserve(tot + 16));
+    HIPCHK(c, c->first_tile.reserve((ng + 1) * 4));
     uint8_t* st = c->h_stage[0].as<uint8_t>();
-    if (ng) {
-      HIPCHK(c, hipMemcpyAsync(st, rg->start0, ng * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(st + o2, rg->len, ng * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHK(c, hipMemcpyAsync(st + o1, rg->col_off, (ng + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(st + o3, rg->read_begin, (ng + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    launch_k0_region_setup(rg->start0, rg->len, rg->col_off, rg->read_begin, ng, c->first_tile.as<int32_t>(), (int64_t*)st,
+                           (int32_t*)(st + o2), (int64_t*)(st + o1), (int32_t*)(st + o3), c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
     if (ng) { memcpy(c->h_start0.data(), st, ng * sizeof(int64_t)); memcpy(c->h_len.data(), st + o2, ng * sizeof(int32_t)); }
     memcpy(c->h_col_off.data(), st + o1, (ng + 1) * sizeof(int64_t));
     memcpy(c->h_read_begin.data(), st + o3, (ng + 1) * sizeof(int32_t));
@@ -244,26 +246,27 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   if ((rc = upload<int32_t>(c, c->in_[14], rg->read_begin, ng + 1, &b.read_begin, mem))) return rc;
   if ((rc = upload<uint8_t>(c, c->in_[15], rg->ref, c->n_cols, &b.ref, mem))) return rc;
 
-  // tile table: tiles never cross a region; first tile per region on the host, the table itself on the device
+  // tile table: tiles never cross a region; the host only needs the tile count, the table is built on the device
   c->h_region_first_tile.assign(ng + 1, 0);
   for (int g = 0; g < ng; g++) c->h_region_first_tile[g + 1] = c->h_region_first_tile[g] + (c->h_len[g] + LCR_TILE - 1) / LCR_TILE;
   c->n_tiles = c->h_region_first_tile[ng];
   HIPCHK(c, c->tile_region.reserve(std::max<size_t>(c->n_tiles, 1) * 4));
   HIPCHK(c, c->tile_col0.reserve(std::max<size_t>(c->n_tiles, 1) * 4));
   HIPCHK(c, c->first_tile.reserve((ng + 1) * 4));
-  HIPCHK(c, hipMemcpyAsync(c->first_tile.p, c->h_region_first_tile.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  if (mem == LCR_MEM_HOST)   // (a device-resident batch had its prefix sums computed with the region fetch above)
+    launch_k0_region_setup(b.start0, b.len, b.col_off, b.read_begin, ng, c->first_tile.as<int32_t>(), nullptr, nullptr, nullptr, nullptr, c->stream);
   launch_k0_tiles(c->first_tile.as<int32_t>(), ng, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), c->stream);
-  HIPCHK(c, c->errflag.reserve(4));
   HIPCHK(c, c->read_rend.reserve(std::max<size_t>(nr, 1) * 4));
   b.read_rend = c->read_rend.as<int32_t>();
   HIPCHK(c, c->read_region.reserve(std::max(nr, 1) * 4));
   b.read_region = c->read_region.as<int32_t>();
   launch_k0_read_region(b, c->read_region.as<int32_t>(), c->stream);
-  b.region_first_tile = c->first_tile.as<int32_t>(); b.error_flag = c->errflag.as<int32_t>();
-  HIPCHK(c, hipMemsetAsync(b.error_flag, 0, 4, c->stream));
+  b.region_first_tile = c->first_tile.as<int32_t>(); b.error_flag = nullptr;   // set by lcr_pileup
   HIPCHK(c, c->read_bin.reserve(std::max<size_t>(nr, 1) * sizeof(ReadBin)));
   launch_k0_pack(b, c->read_bin.as<ReadBin>(), c->stream);
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // host batch: the caller's arrays are free again when this returns; device batch: no wait, the next stage queues
+  // behind these kernels on the same stream (the arrays stay the caller's to keep alive, include/lcr.h)
+  if (mem == LCR_MEM_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   c->loaded = true;
   return LCR_OK;
@@ -287,18 +290,20 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   // slots.  Long D runs can exceed the estimate: K0 then flags an overflow (writes are bounds-checked) and the
   // stage is repeated with a larger pool.
   size_t pool_cap64 = 2 * ((size_t)c->n_cigar + (size_t)b.n_reads + (size_t)c->n_bases / LCR_TILE) + 64 * (size_t)nt + 64;
-  HIPCHK(c, c->k0_tile_off.reserve((nt + 2) * 4));
-  HIPCHK(c, c->k0_tile_fill.reserve((nt + 1) * 4 + 16));    // [nt + 1]: pool top
+  // control block behind the tile fill counters: [nt + 1] pool top, [nt + 2] M / D / I items, [nt + 3] records,
+  // [nt + 4] error flag -- cleared with the counters, fetched with one copy
+  HIPCHK(c, c->k0_tile_fill.reserve((nt + 8) * 4));
+  b.error_flag = c->k0_tile_fill.as<int32_t>() + nt + 4;
   HIPCHK(c, c->k0_tile_count.reserve(std::max<size_t>((size_t)nt * LCR_REC_LEVELS, 1) * 4));   // level table
   HIPCHK(c, c->ndiff.reserve(nd * 4));
   HIPCHK(c, c->nscan.reserve(nd * 4));
+  HIPCHK(c, c->h_stage[0].reserve(64));
   int32_t n_recs = 0, bad = 0, n_ops = 0;
   for (;;) {
     if (pool_cap64 > 0xFFFFFFF0ull) { c->err = "batch too large for the 32-bit record pool: split it"; return LCR_E_ARG; }
     const unsigned int pool_cap = (unsigned int)pool_cap64;
     HIPCHK(c, c->k0_items.reserve((size_t)pool_cap * 8));
-    HIPCHK(c, hipMemsetAsync(b.error_flag, 0, 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->k0_tile_fill.p, 0, (nt + 1) * 4 + 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->k0_tile_fill.p, 0, (nt + 8) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->k0_tile_count.p, 0xFF, std::max<size_t>((size_t)nt * LCR_REC_LEVELS, 1) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->ndiff.p, 0, nd * 4, c->stream));
     { Timer t(c, LCR_K_SPANS);
@@ -314,12 +319,11 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
       if (!c->dp.ont && c->dp.dist_to_end > 0)
         launch_k1_zonefix(b, c->read_bin.as<ReadBin>(), c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->stream); }
     // record count (byte accounting) and CIGAR validation result
-    launch_scan_i32(c->scan_tmp, c->k0_tile_fill.as<int32_t>(), c->k0_tile_off.as<int32_t>(), nt, c->k0_tile_off.as<int32_t>() + nt, c->stream);
-    HIPCHK(c, hipMemcpyAsync(&n_recs, c->k0_tile_off.as<int32_t>() + nt, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&bad, b.error_flag, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&n_ops, c->k0_tile_fill.as<int32_t>() + nt + 2, 4, hipMemcpyDeviceToHost, c->stream));
+    int32_t* const ctl = c->h_stage[0].as<int32_t>();
+    HIPCHK(c, hipMemcpyAsync(ctl, c->k0_tile_fill.as<int32_t>() + nt + 1, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
+    n_ops = ctl[1]; n_recs = ctl[2]; bad = ctl[3];
     if (bad == 1) { c->err = "unknown CIGAR operation (reference panics: util.rs:944)"; return LCR_E_CIGAR; }
     if (bad == 2) { c->err = "CIGAR inconsistent with l_seq / soft clips"; return LCR_E_CIGAR; }
     if (bad == 4) { c->err = "K0 record level wait timed out (internal error)"; return LCR_E_DEVICE; }
@@ -408,6 +412,8 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->region_rows.reserve(std::max(ng, 1) * 4));
   HIPCHK(c, c->h_stage[3].reserve(std::max(ng, 1) * 4));
   launch_k3_rows(c->bv, c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->region_rows.as<int32_t>(), c->stream);
+  HIPCHK(c, c->row_region_off.reserve((ng + 1) * 4));
+  launch_k3_row_offsets(c->region_rows.as<int32_t>(), ng, c->row_region_off.as<int32_t>(), c->stream);
   if (ng) HIPCHK(c, hipMemcpyAsync(c->h_stage[3].p, c->region_rows.p, ng * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
@@ -428,6 +434,15 @@ int lcr_get_candidates(lcr_ctx* c, lcr_candidate_list* out) {
   return LCR_OK;
 }
 
+// lcr_fragments leaves the fill pass running; the entry count arrives on the host before that pass ends
+static int frag_settle(lcr_ctx* c) {
+  if (!c->nnz_pending) return LCR_OK;
+  HIPCHK(c, hipEventSynchronize(c->ev_nnz));
+  c->nnz = *c->h_nnz.as<int64_t>();
+  c->nnz_pending = false;
+  return LCR_OK;
+}
+
 int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   if (!c || !p) return LCR_E_ARG;
   if (!c->have_cand) { c->err = "lcr_fragments before lcr_candidates"; return LCR_E_STATE; }
@@ -440,22 +455,30 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   for (int g = 0; g < ng; g++) c->h_row_region_off[g + 1] = c->h_row_region_off[g] + rr[g];
   c->n_rows = c->h_row_region_off[ng];
   const int nrow = c->n_rows;
-  HIPCHK(c, c->row_region_off.reserve((ng + 1) * 4));
-  HIPCHK(c, hipMemcpyAsync(c->row_region_off.p, c->h_row_region_off.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, c->row_cnt.reserve(std::max(nrow, 1) * 4));
+  HIPCHK(c, c->row_cnt.reserve(std::max(nrow, 1) * 4));   // (row_region_off is on the device since lcr_candidates)
   HIPCHK(c, c->row_links.reserve(std::max(nrow, 1) * 4));
   HIPCHK(c, c->row_ptr.reserve((std::max(nrow, 1) + 1) * 8));
   { Timer t(c, LCR_K_FRAG_COUNT);
     launch_k3_count(c->bv, c->read_bin.as<ReadBin>(), c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nrow,
                     c->row_cnt.as<int32_t>(), c->row_links.as<uint32_t>(), c->stream);
     launch_scan_i32_to_i64(c->scan_tmp, c->row_cnt.as<int32_t>(), c->row_ptr.as<int64_t>(), nrow, c->stream); }
-  int64_t nnz = 0;
-  HIPCHK(c, hipMemcpyAsync(&nnz, c->row_ptr.as<int64_t>() + nrow, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipGetLastError());
-  c->nnz = nnz;
-  HIPCHK(c, c->col.reserve(std::max<int64_t>(nnz, 1) * 4));
-  HIPCHK(c, c->val.reserve(std::max<int64_t>(nnz, 1)));
+  // entries: at most rows x candidates per region.  When that bound is affordable the fill pass is queued right
+  // behind the count pass and the true count is picked up later (frag_settle); otherwise wait for it first.
+  int64_t bound = 0;
+  for (int g = 0; g < ng; g++) bound += (int64_t)rr[g] * (c->h_cand_off[g + 1] - c->h_cand_off[g]);
+  HIPCHK(c, c->h_nnz.reserve(8));
+  if (!c->ev_nnz) HIPCHK(c, hipEventCreateWithFlags(&c->ev_nnz, hipEventDisableTiming));
+  HIPCHK(c, hipMemcpyAsync(c->h_nnz.p, c->row_ptr.as<int64_t>() + nrow, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_nnz, c->stream));
+  c->nnz_pending = true;
+  int64_t cap = bound;
+  if (bound > ((int64_t)1 << 28)) {
+    int rc = frag_settle(c);
+    if (rc) return rc;
+    cap = c->nnz;
+  }
+  HIPCHK(c, c->col.reserve(std::max<int64_t>(cap, 1) * 4));
+  HIPCHK(c, c->val.reserve(std::max<int64_t>(cap, 1)));
   { Timer t(c, LCR_K_FRAG_FILL);
     launch_k3_fill(c->bv, c->read_bin.as<ReadBin>(), c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nrow,
                    c->row_ptr.as<int64_t>(), c->col.as<int32_t>(), c->val.as<uint8_t>(), c->stream); }
@@ -476,6 +499,7 @@ int lcr_get_candidates_device(lcr_ctx* c, const lcr_candidate** dev_cand, int32_
 int lcr_get_fragmat(lcr_ctx* c, lcr_fragmat* out) {
   if (!c || !out) return LCR_E_ARG;
   if (!c->have_frag) { c->err = "lcr_get_fragmat before lcr_fragments"; return LCR_E_STATE; }
+  { int rc = frag_settle(c); if (rc) return rc; }
   const int nrow = c->n_rows, ng = c->bv.n_regions;
   const int64_t nnz = c->nnz;
   HIPCHK(c, c->h_row_ptr.reserve((nrow + 1) * 8));
@@ -508,6 +532,7 @@ int lcr_phase(lcr_ctx* c, const lcr_params* p) {
   if (!c || !p) return LCR_E_ARG;
   if (!c->have_frag) { c->err = "lcr_phase before lcr_fragments"; return LCR_E_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
+  { int rc = frag_settle(c); if (rc) return rc; }
   PhaseInputs in;
   in.n_regions = c->bv.n_regions; in.n_rows = c->n_rows; in.nnz = c->nnz;
   in.row_region_off = c->h_row_region_off.data(); in.cand_region_off = c->h_cand_off.data();

@@ -127,6 +127,9 @@ struct PhaseLutDev {
 
 // ---- kernel launchers (defined in the .hip files) ----
 // K0: pass 0 counts records per tile (+ intron difference array, CIGAR validation); pass 1 writes them
+void launch_k0_region_setup(const int64_t* start0, const int32_t* len, const int64_t* col_off, const int32_t* read_begin, int32_t ng,
+                            int32_t* first_tile, int64_t* h_start0, int32_t* h_len, int64_t* h_col_off, int32_t* h_read_begin,
+                            hipStream_t s);
 void launch_k0_tiles(const int32_t* first_tile, int32_t n_regions, int32_t* tile_region, int32_t* tile_col0, hipStream_t s);
 void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s);
 void launch_k0_pack(const BatchView& b, ReadBin* out, hipStream_t s);
@@ -152,6 +155,7 @@ void launch_k2_gt(const DevParams& p, const Survivor* sv, int32_t n_sv, const ui
 void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t* keep, int32_t n_sv, const int32_t* sv_region_off,
                       int32_t n_regions, int32_t* pos, int32_t* idx, lcr_candidate* out, int32_t* cand_off, uint32_t dense_win,
                       uint32_t min_dense_cnt, hipStream_t s);
+void launch_k3_row_offsets(const int32_t* region_rows, int32_t ng, int32_t* row_region_off, hipStream_t s);
 void launch_k3_count(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
                      const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, uint32_t* row_links,
                      hipStream_t s);

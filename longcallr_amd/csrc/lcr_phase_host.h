@@ -83,7 +83,8 @@ struct PhaseHost {
   DevBuf d_state[21];
   HostBuf h_pin[10];   // pinned staging: row_ptr, col, val, links, enum state, region sizes, chain state
   hipStream_t side = nullptr;   // second queue: fragment matrix download + chain regions
-  hipEvent_t ev_in = nullptr, ev_csr = nullptr;
+  hipEvent_t ev_in = nullptr, ev_csr = nullptr, ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t aux = nullptr;   // enumeration classes 3 / 4 beside class 2
   HostPool* pool = nullptr;
   void* work = nullptr;   // PhaseWork (k4_phase.hip): per-region host state reused across calls
   void free_work();
@@ -94,6 +95,9 @@ struct PhaseHost {
     if (side) { (void)hipStreamDestroy(side); side = nullptr; }
     if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
     if (ev_csr) { (void)hipEventDestroy(ev_csr); ev_csr = nullptr; }
+    if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+    if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
+    if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
     delete pool; pool = nullptr;
     free_work();
   }
