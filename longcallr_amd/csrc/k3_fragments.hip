@@ -51,6 +51,16 @@ void launch_k3_row_offsets(const int32_t* region_rows, int32_t ng, int32_t* row_
   hipLaunchKernelGGL(k3_row_offsets, dim3(1), dim3(1024), 0, s, region_rows, ng, row_region_off);
 }
 
+// first entry of every region: row_ptr at the regions' first rows ([ng] = all entries)
+__global__ void k3_region_entries(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ row_region_off, int32_t ng,
+                                  int64_t* __restrict__ region_e_off) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g <= ng) region_e_off[g] = row_ptr[row_region_off[g]];
+}
+void launch_k3_region_entries(const int64_t* row_ptr, const int32_t* row_region_off, int32_t ng, int64_t* region_e_off, hipStream_t s) {
+  hipLaunchKernelGGL(k3_region_entries, dim3((ng + 256) / 256), dim3(256), 0, s, row_ptr, row_region_off, ng, region_e_off);
+}
+
 // Sixteen lanes per row (row16_walk_sites, lcr_dev.h): the region's candidates inside the read's reference
 // span are located against the CIGAR spread over the lanes; a row without such candidates never loads
 // its CIGAR.  No trimming here: the reference's fragment walk takes every aligned base.

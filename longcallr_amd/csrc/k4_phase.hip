@@ -582,6 +582,7 @@ __device__ __forceinline__ void block_scan2(int a, int b, int& ea, int& eb, int&
 }
 
 constexpr int STAGE_THREADS = 256;    // (1024 threads per region were measured: more barrier cost than latency saved)
+constexpr int STG_E = 8192, STG_R = 4096, STG_S = 512;   // k4_stage: a region's slice of the fragment matrix that is staged in LDS
 __global__ void __launch_bounds__(STAGE_THREADS) k4_stage(StageIn in, StageOut out, PhaseLutDev lut) {
   constexpr int NW = STAGE_THREADS / 64;
   __shared__ int sm[2][16];
@@ -601,81 +602,109 @@ __global__ void __launch_bounds__(STAGE_THREADS) k4_stage(StageIn in, StageOut o
   }
   if (tid < 32) { s_fe[tid] = tid < 31 ? lut.fe[tid] : 0; s_f1e[tid] = tid < 31 ? lut.f1e[tid] : 0; }
   if (tid < 2) s_max[tid] = 0;
+  // The region's slice of the fragment matrix is brought into LDS with coalesced loads when it fits (any
+  // realistic region does): the per-row entry loops below are chains of dependent loads, a microsecond per link
+  // from HBM, and there are four of them per row.  Larger regions run the same code on global memory.
+  __shared__ uint16_t s_col[STG_E];
+  __shared__ uint8_t s_val[STG_E];
+  __shared__ uint16_t s_rp[STG_R + 1];
+  __shared__ uint8_t s_isp[STG_R];
+  __shared__ uint8_t s_fp[STG_S];
+  __shared__ int s_cur[STG_S];
+  const int64_t E_all = in.row_ptr[r0 + nrow] - e_base;
+  const bool staged = nrow <= STG_R && E_all <= STG_E && S <= STG_S;
   for (int i = tid; i < S; i += STAGE_THREADS) {
     const lcr_candidate& c = in.cand[c0 + i];
-    out.snp_fp[c0 + i] = (c.flags & LCR_F_FOR_PHASING) ? 1 : 0;
+    const uint8_t fp = (c.flags & LCR_F_FOR_PHASING) ? 1 : 0;
+    out.snp_fp[c0 + i] = fp;
     out.snp_vt[c0 + i] = (int8_t)c.variant_type;
     out.snp_cons[c0 + i] = 0;
-    out.cursor[c0 + i] = 0;
+    if (staged) { s_fp[i] = fp; s_cur[i] = 0; } else out.cursor[c0 + i] = 0;
+  }
+  if (staged) {
+    for (int e = tid; e < (int)E_all; e += STAGE_THREADS) { s_col[e] = (uint16_t)(in.col[e_base + e] - c0); s_val[e] = in.val[e_base + e]; }
+    for (int r = tid; r <= nrow; r += STAGE_THREADS) s_rp[r] = (uint16_t)(in.row_ptr[r0 + r] - e_base);
+    for (int r = tid; r < nrow; r += STAGE_THREADS) s_isp[r] = in.links[r0 + r] >= in.min_linkers ? 1 : 0;
   }
   __syncthreads();
   int32_t* prp = out.prow_ptr + rd.rp_off;
   int32_t* pcp = out.ccol_ptr + rd.cp_off;
-  // ---- pass 1: phasing rows and their phase-site entries (CSR), column counts
   int R = 0, E = 0;
-  for (int base = 0; base < nrow; base += STAGE_THREADS) {
-    const int r = base + tid;
-    int isp = 0, cnt = 0;
-    int64_t eb = 0, ee = 0;
-    if (r < nrow) {
-      isp = in.links[r0 + r] >= in.min_linkers ? 1 : 0;
-      if (isp) {
-        eb = in.row_ptr[r0 + r]; ee = in.row_ptr[r0 + r + 1];
-        for (int64_t e = eb; e < ee; e++) cnt += out.snp_fp[in.col[e]];
-      }
-    }
-    int k, eo, tk, te;
-    block_scan2n<NW, 16>(isp, cnt, k, eo, tk, te, sm);
-    if (isp) {
-      k += R; eo += E;
-      prp[k] = eo;
-      for (int64_t e = eb; e < ee; e++) {
-        const int ci = in.col[e];
-        if (!out.snp_fp[ci]) continue;
-        out.pcol[e_base + eo] = ci - c0; out.pval[e_base + eo] = in.val[e] & 63;
-        atomicAdd(&out.cursor[ci], 1);
-        eo++;
-      }
-    }
-    R += tk; E += te;
-  }
-  if (tid == 0) prp[R] = E;
-  __syncthreads();
-  // ---- column offsets
-  {
-    int carry = 0;
-    for (int base = 0; base < S; base += STAGE_THREADS) {
-      const int i = base + tid;
-      const int v = i < S ? out.cursor[c0 + i] : 0;
-      int ex, dummy, tot, tdummy;
-      block_scan2n<NW, 16>(v, 0, ex, dummy, tot, tdummy, sm);
-      if (i < S) { pcp[i] = carry + ex; out.cursor[c0 + i] = carry + ex; }
-      carry += tot;
-    }
-    if (tid == 0) pcp[S] = carry;
-  }
-  __syncthreads();
-  // ---- pass 2: CSC mirror (phasing-row index, value)
-  {
-    int Rk = 0;
+  auto build = [&](auto staged_tag) {
+    constexpr bool ST = decltype(staged_tag)::value;
+    auto isp_of = [&](int r) -> int { if constexpr (ST) return s_isp[r]; else return in.links[r0 + r] >= in.min_linkers ? 1 : 0; };
+    auto rp_of = [&](int r) -> int { if constexpr (ST) return s_rp[r]; else return (int)(in.row_ptr[r0 + r] - e_base); };   // region relative
+    auto col_of = [&](int e) -> int { if constexpr (ST) return s_col[e]; else return in.col[e_base + e] - c0; };              // region relative
+    auto val_of = [&](int e) -> uint8_t { if constexpr (ST) return s_val[e]; else return in.val[e_base + e]; };
+    auto fp_of = [&](int i) -> bool { if constexpr (ST) return s_fp[i] != 0; else return out.snp_fp[c0 + i] != 0; };
+    auto bump = [&](int i) -> int { if constexpr (ST) return atomicAdd(&s_cur[i], 1); else return atomicAdd(&out.cursor[c0 + i], 1); };
+    // ---- pass 1: phasing rows and their phase-site entries (CSR), column counts
     for (int base = 0; base < nrow; base += STAGE_THREADS) {
       const int r = base + tid;
-      const int isp = (r < nrow && in.links[r0 + r] >= in.min_linkers) ? 1 : 0;
-      int k, dummy, tk, tdummy;
-      block_scan2n<NW, 16>(isp, 0, k, dummy, tk, tdummy, sm);
-      if (isp) {
-        k += Rk;
-        for (int64_t e = in.row_ptr[r0 + r]; e < in.row_ptr[r0 + r + 1]; e++) {
-          const int ci = in.col[e];
-          if (!out.snp_fp[ci]) continue;
-          const int pos = atomicAdd(&out.cursor[ci], 1);
-          out.crow[e_base + pos] = k; out.cval[e_base + pos] = in.val[e] & 63;
+      int isp = 0, cnt = 0, eb = 0, ee = 0;
+      if (r < nrow) {
+        isp = isp_of(r);
+        if (isp) {
+          eb = rp_of(r); ee = rp_of(r + 1);
+          for (int e = eb; e < ee; e++) cnt += fp_of(col_of(e)) ? 1 : 0;
         }
       }
-      Rk += tk;
+      int k, eo, tk, te;
+      block_scan2n<NW, 16>(isp, cnt, k, eo, tk, te, sm);
+      if (isp) {
+        k += R; eo += E;
+        prp[k] = eo;
+        for (int e = eb; e < ee; e++) {
+          const int ci = col_of(e);
+          if (!fp_of(ci)) continue;
+          out.pcol[e_base + eo] = ci; out.pval[e_base + eo] = val_of(e) & 63;
+          bump(ci);
+          eo++;
+        }
+      }
+      R += tk; E += te;
     }
-  }
-  __syncthreads();
+    if (tid == 0) prp[R] = E;
+    __syncthreads();
+    // ---- column offsets
+    {
+      int carry = 0;
+      for (int base = 0; base < S; base += STAGE_THREADS) {
+        const int i = base + tid;
+        int v = 0;
+        if (i < S) { if constexpr (ST) v = s_cur[i]; else v = out.cursor[c0 + i]; }
+        int ex, dummy, tot, tdummy;
+        block_scan2n<NW, 16>(v, 0, ex, dummy, tot, tdummy, sm);
+        if (i < S) { pcp[i] = carry + ex; if constexpr (ST) s_cur[i] = carry + ex; else out.cursor[c0 + i] = carry + ex; }
+        carry += tot;
+      }
+      if (tid == 0) pcp[S] = carry;
+    }
+    __syncthreads();
+    // ---- pass 2: CSC mirror (phasing-row index, value)
+    {
+      int Rk = 0;
+      for (int base = 0; base < nrow; base += STAGE_THREADS) {
+        const int r = base + tid;
+        const int isp = r < nrow ? isp_of(r) : 0;
+        int k, dummy, tk, tdummy;
+        block_scan2n<NW, 16>(isp, 0, k, dummy, tk, tdummy, sm);
+        if (isp) {
+          k += Rk;
+          const int ee = rp_of(r + 1);
+          for (int e = rp_of(r); e < ee; e++) {
+            const int ci = col_of(e);
+            if (!fp_of(ci)) continue;
+            const int pos = bump(ci);
+            out.crow[e_base + pos] = k; out.cval[e_base + pos] = val_of(e) & 63;
+          }
+        }
+        Rk += tk;
+      }
+    }
+    __syncthreads();
+  };
+  if (staged) build(std::true_type{}); else build(std::false_type{});
   // ---- per-SNP constants: F = sum fe, W = sum w, Cref = sum (p==+1 ? f1e : fe), Cvar = sum (p==-1 ? f1e : fe)
   long long ft = 0;
   for (int i = wave; i < S; i += NW) {
@@ -705,7 +734,7 @@ __global__ void __launch_bounds__(STAGE_THREADS) k4_stage(StageIn in, StageOut o
     for (int w = 0; w < NW; w++) ftot += s_ft[w];
     rd.R = R; rd.f_total = ftot;
     out.reg[g] = rd;
-    out.stat[g] = StageStat{R, E, max(s_max[0], (int)enum_chunk((uint32_t)E)), s_max[1], (int)(in.row_ptr[r0 + nrow] - e_base), 0};
+    out.stat[g] = StageStat{R, E, max(s_max[0], (int)enum_chunk((uint32_t)E)), s_max[1], (int)E_all, 0};
   }
 }
 
@@ -845,6 +874,23 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k4_chain_b(PhaseDev P, const in
 // device libm.  The region's fragment rows are staged in LDS with a row-ordered column index (stable
 // counting sort by one wave); a batch with a region too large for that takes the host epilogue.
 // ---------------------------------------------------------------------------------------------
+// Chain regions only: their rows / entries of the fragment matrix gathered into one contiguous block that goes
+// to the host with a single copy (the block-flip pass and the LD blocks are host code); the whole matrix is
+// only downloaded when the host epilogue has to run.
+struct PackItem { int32_t r0, nrow; int64_t e0, ne; int64_t rp_at, lk_at, col_at, val_at; };   // byte offsets into the block
+__global__ void __launch_bounds__(LCR_BLOCK) k4_pack_chain(const PackItem* __restrict__ items, const int64_t* __restrict__ row_ptr,
+                                                            const int32_t* __restrict__ col, const uint8_t* __restrict__ val,
+                                                            const uint32_t* __restrict__ links, uint8_t* __restrict__ block) {
+  const PackItem it = items[blockIdx.x];
+  int64_t* rp = reinterpret_cast<int64_t*>(block + it.rp_at);
+  uint32_t* lk = reinterpret_cast<uint32_t*>(block + it.lk_at);
+  int32_t* cl = reinterpret_cast<int32_t*>(block + it.col_at);
+  uint8_t* vl = block + it.val_at;
+  for (int r = threadIdx.x; r <= it.nrow; r += LCR_BLOCK) rp[r] = row_ptr[it.r0 + r];
+  for (int r = threadIdx.x; r < it.nrow; r += LCR_BLOCK) lk[r] = links[it.r0 + r];
+  for (int64_t e = threadIdx.x; e < it.ne; e += LCR_BLOCK) { cl[e] = col[it.e0 + e]; vl[e] = val[it.e0 + e]; }
+}
+
 struct PostLut { double le[31], l1e[31]; double p_homref, p_homvar, log_theta, log2; };
 struct PostIn {
   const int64_t* row_ptr; const int32_t* col; const uint8_t* val; const uint32_t* links;
@@ -1663,8 +1709,6 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   const size_t st_obj = st_eta + ((nc1 + 15) & ~(size_t)15);
   const size_t st_bytes = st_obj + (size_t)std::max(ng, 1) * 8;
   PCHK(b_st.reserve(st_bytes + 16)); PCHK(b_stc.reserve(st_bytes + 16));
-  PCHK(h_pin[0].reserve((nr1 + 1) * 8)); PCHK(h_pin[1].reserve(nnz1 * 4));
-  PCHK(h_pin[2].reserve(nnz1)); PCHK(h_pin[3].reserve(nr1 * 4));
   PCHK(h_pin[4].reserve(st_bytes + 16)); PCHK(h_pin[5].reserve((size_t)std::max(ng, 1) * sizeof(StageStat)));
   PCHK(h_pin[6].reserve(st_bytes + 16));
   // results of the device epilogue live in pinned host memory that k4_post writes itself (every row belongs to a
@@ -1687,19 +1731,72 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   P.st_obj = (long long*)(b_st.as<int8_t>() + st_obj);
   P.lut = L.dev;
 
-  // ---- queue `side`: fragment matrix to the host (pinned)
-  int64_t* const row_ptr_p = h_pin[0].as<int64_t>();
-  int32_t* const col_p = h_pin[1].as<int32_t>();
-  uint8_t* const val_p = h_pin[2].as<uint8_t>();
-  uint32_t* const links_p = h_pin[3].as<uint32_t>();
+  // enumeration (S <= max_enum_snps) and chain regions
+  std::vector<int32_t> enum_slots, chain_slots;
+  for (int g = 0; g < ng; g++) {
+    const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
+    if (S == 0) continue;
+    if ((uint32_t)S <= prm.max_enum_snps) enum_slots.push_back(g); else chain_slots.push_back(g);
+  }
+  // post-phase epilogue on the device (k4_post) unless a region does not fit its LDS image; the regions' sizes
+  // are on the host already (lcr_fragments), so this is known before anything is queued
+  bool dev_post = getenv("LCR_POST_HOST") == nullptr;
+  uint32_t post_lds = 0;
+  for (int g = 0; g < ng; g++) {
+    const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
+    if (S == 0) continue;
+    const int nr_g = in.row_region_off[g + 1] - in.row_region_off[g];
+    const int64_t E_all = in.region_e_off[g + 1] - in.region_e_off[g];
+    if (nr_g > POST_MAX_ROWS || E_all > POST_MAX_ENTRIES || S > POST_MAX_SNPS) { dev_post = false; continue; }
+    const uint32_t need = post_layout(nr_g, (uint32_t)E_all, S).total;
+    if (need > 64 * 1024) dev_post = false;
+    post_lds = std::max(post_lds, need);
+  }
+
+  // ---- queue `side`: fragment matrix to the host (pinned) -- all of it for the host epilogue, else only the
+  // chain regions' rows and entries, gathered into one block by k4_pack_chain
+  struct CsrView { const int64_t* row_ptr; const int32_t* col; const uint8_t* val; const uint32_t* links; };   // indexed by global row / entry
+  std::vector<CsrView> view(ng, CsrView{nullptr, nullptr, nullptr, nullptr});
   PCHK(hipEventRecord(ev_in, stream));
   PCHK(hipStreamWaitEvent(side, ev_in, 0));
-  PCHK(hipMemcpyAsync(row_ptr_p, in.d_row_ptr, (size_t)(nrow + 1) * 8, hipMemcpyDeviceToHost, side));
-  if (nnz) {
-    PCHK(hipMemcpyAsync(col_p, in.d_col, (size_t)nnz * 4, hipMemcpyDeviceToHost, side));
-    PCHK(hipMemcpyAsync(val_p, in.d_val, (size_t)nnz, hipMemcpyDeviceToHost, side));
+  if (!dev_post) {
+    PCHK(h_pin[0].reserve((nr1 + 1) * 8)); PCHK(h_pin[1].reserve(nnz1 * 4));
+    PCHK(h_pin[2].reserve(nnz1)); PCHK(h_pin[3].reserve(nr1 * 4));
+    PCHK(hipMemcpyAsync(h_pin[0].p, in.d_row_ptr, (size_t)(nrow + 1) * 8, hipMemcpyDeviceToHost, side));
+    if (nnz) {
+      PCHK(hipMemcpyAsync(h_pin[1].p, in.d_col, (size_t)nnz * 4, hipMemcpyDeviceToHost, side));
+      PCHK(hipMemcpyAsync(h_pin[2].p, in.d_val, (size_t)nnz, hipMemcpyDeviceToHost, side));
+    }
+    if (nrow) PCHK(hipMemcpyAsync(h_pin[3].p, in.d_row_links, (size_t)nrow * 4, hipMemcpyDeviceToHost, side));
+    for (int g = 0; g < ng; g++) view[g] = CsrView{h_pin[0].as<int64_t>(), h_pin[1].as<int32_t>(), h_pin[2].as<uint8_t>(), h_pin[3].as<uint32_t>()};
+  } else if (!chain_slots.empty()) {
+    const size_t nc = chain_slots.size();
+    std::vector<PackItem> items(nc);
+    size_t at = (nc * sizeof(PackItem) + 15) & ~(size_t)15;   // the items themselves lead the block (upload), data follows
+    for (size_t k = 0; k < nc; k++) {
+      const int g = chain_slots[k];
+      PackItem& it = items[k];
+      it.r0 = in.row_region_off[g]; it.nrow = in.row_region_off[g + 1] - it.r0;
+      it.e0 = in.region_e_off[g]; it.ne = in.region_e_off[g + 1] - it.e0;
+      it.rp_at = (int64_t)at; at += ((size_t)(it.nrow + 1) * 8 + 15) & ~(size_t)15;
+      it.lk_at = (int64_t)at; at += ((size_t)it.nrow * 4 + 15) & ~(size_t)15;
+      it.col_at = (int64_t)at; at += ((size_t)it.ne * 4 + 15) & ~(size_t)15;
+      it.val_at = (int64_t)at; at += ((size_t)it.ne + 15) & ~(size_t)15;
+    }
+    PCHK(h_pin[0].reserve(at)); PCHK(d_state[17].reserve(at));
+    uint8_t* const hb = h_pin[0].as<uint8_t>(); uint8_t* const db = d_state[17].as<uint8_t>();
+    memcpy(hb, items.data(), nc * sizeof(PackItem));
+    PCHK(hipMemcpyAsync(db, hb, nc * sizeof(PackItem), hipMemcpyHostToDevice, side));
+    hipLaunchKernelGGL(k4_pack_chain, dim3((unsigned)nc), dim3(LCR_BLOCK), 0, side, (const PackItem*)db, in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, db);
+    PCHK(hipGetLastError());
+    const size_t head = (nc * sizeof(PackItem) + 15) & ~(size_t)15;
+    PCHK(hipMemcpyAsync(hb + head, db + head, at - head, hipMemcpyDeviceToHost, side));
+    for (size_t k = 0; k < nc; k++) {   // views keep the global row / entry numbering of the region
+      const PackItem& it = items[k];
+      view[chain_slots[k]] = CsrView{reinterpret_cast<const int64_t*>(hb + it.rp_at) - it.r0, reinterpret_cast<const int32_t*>(hb + it.col_at) - it.e0,
+                                     hb + it.val_at - it.e0, reinterpret_cast<const uint32_t*>(hb + it.lk_at) - it.r0};
+    }
   }
-  if (nrow) PCHK(hipMemcpyAsync(links_p, in.d_row_links, (size_t)nrow * 4, hipMemcpyDeviceToHost, side));
   PCHK(hipEventRecord(ev_csr, side));
 
   // ---- queue `stream`: stage the phase matrices, fetch the per-region sizes
@@ -1715,19 +1812,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(hipMemcpyAsync(stat, b_stat.p, (size_t)ng * sizeof(StageStat), hipMemcpyDeviceToHost, stream));
     PCHK(hipMemsetAsync(b_st.p, 0, st_bytes, stream));
   }
-  // enumeration (S <= max_enum_snps) and chain regions; the chain regions' host preparation (LD blocks) only
-  // needs the fragment matrix and runs while k4_stage is busy
-  std::vector<int32_t> enum_slots, chain_slots;
-  for (int g = 0; g < ng; g++) {
-    const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
-    if (S == 0) continue;
-    if ((uint32_t)S <= prm.max_enum_snps) enum_slots.push_back(g); else chain_slots.push_back(g);
-  }
   // ---- host views of the regions (epilogue structures; LD blocks of the chain regions)
-  struct Arr64 { int64_t* p; int64_t& operator[](size_t i) const { return p[i]; } int64_t* data() const { return p; } } row_ptr{row_ptr_p};
-  struct Arr32 { int32_t* p; int32_t& operator[](size_t i) const { return p[i]; } int32_t* data() const { return p; } } col{col_p};
-  struct Arr8 { uint8_t* p; uint8_t& operator[](size_t i) const { return p[i]; } uint8_t* data() const { return p; } } val{val_p};
-  struct ArrU { uint32_t* p; uint32_t& operator[](size_t i) const { return p[i]; } uint32_t* data() const { return p; } } links{links_p};
   // per-region host state lives across calls (PhaseWork): a batch has hundreds of regions with a dozen
   // vectors each, and re-allocating / freeing them every call cost more than the work done with them
   if (!work) work = new PhaseWork();
@@ -1743,14 +1828,14 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     RegionBuild& rb = RB[g];
     rh.g = g; rh.c0 = in.cand_region_off[g]; rh.S = in.cand_region_off[g + 1] - rh.c0;
     rh.r0 = in.row_region_off[g]; rh.nrow = in.row_region_off[g + 1] - rh.r0;
-    rh.row_ptr = row_ptr.data(); rh.col = col.data(); rh.val = val.data(); rh.links = links.data();
+    rh.row_ptr = view[g].row_ptr; rh.col = view[g].col; rh.val = view[g].val; rh.links = view[g].links;
     rh.cand = cand.data() + rh.c0;
     rh.seed = region_seed(prm.seed, in.region_start0[g]);
     rh.min_linkers = prm.min_linkers;
-    rh.e0 = nrow ? row_ptr[rh.r0] : 0;
+    rh.e0 = nrow ? rh.row_ptr[rh.r0] : 0;
     if (rh.S == 0) return;
     const bool chain = (uint32_t)rh.S > prm.max_enum_snps;
-    const int64_t e1 = row_ptr[rh.r0 + rh.nrow];
+    const int64_t e1 = rh.row_ptr[rh.r0 + rh.nrow];
     rh.phase_site.assign((size_t)(e1 - rh.e0), 0);
     rh.tag.assign(rh.nrow, 0); rh.asg.assign(rh.nrow, 0); rh.fp.assign(rh.nrow, 0);
     if ((int)rh.cover.size() < rh.S) rh.cover.resize(rh.S);
@@ -1766,12 +1851,12 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
         rh.cover[i].push_back(r);
         if (rh.fphase(i)) rh.phase_site[e - rh.e0] = 1;  // fragment.rs:144-146 snapshot
       }
-      if (links[rh.r0 + r] >= prm.min_linkers) {          // fragment.rs:253-255
+      if (rh.links[rh.r0 + r] >= prm.min_linkers) {          // fragment.rs:253-255
         rh.fp[r] = 1;
         rh.fp_rows.push_back(r);
         if (chain) {
           for (int64_t e = rh.eb(r); e < rh.ee(r); e++)
-            if (rh.phase_site[e - rh.e0]) { rb.pcol.push_back(rh.lc(e)); rb.pval.push_back((uint8_t)(val[e] & 63)); }
+            if (rh.phase_site[e - rh.e0]) { rb.pcol.push_back(rh.lc(e)); rb.pval.push_back((uint8_t)(rh.val[e] & 63)); }
           rb.prow_ptr.push_back((int32_t)rb.pcol.size());
         }
       }
@@ -1902,17 +1987,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
 
   // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
   int32_t max_state = 0;
-  // post-phase epilogue on the device (k4_post) unless a region does not fit its LDS image
-  bool dev_post = getenv("LCR_POST_HOST") == nullptr;
-  uint32_t post_lds = 0;
   for (int g = 0; g < ng; g++) {
     const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
-    if (S == 0) continue;
-    max_state = std::max(max_state, stat[g].R + 2 * S);
-    const int nr_g = in.row_region_off[g + 1] - in.row_region_off[g];
-    const uint32_t need = post_layout(nr_g, stat[g].E_all, S).total;
-    if (nr_g > POST_MAX_ROWS || stat[g].E_all > POST_MAX_ENTRIES || S > POST_MAX_SNPS || need > 64 * 1024) dev_post = false;
-    post_lds = std::max(post_lds, need);
+    if (S) max_state = std::max(max_state, stat[g].R + 2 * S);
   }
   PostLut plut;
   for (int q = 0; q < 31; q++) { plut.le[q] = L.le[q]; plut.l1e[q] = L.l1e[q]; }
@@ -2064,7 +2141,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
                 if (rh.lc(e) == idx) {
                   if (!rh.phase_site[e - rh.e0]) continue;
                   const int s = rh.tag[r], sf = flip_read ? -s : s;
-                  o.push_back({s, val[e]}); oflip.push_back({sf, val[e]});
+                  o.push_back({s, rh.val[e]}); oflip.push_back({sf, rh.val[e]});
                   flipv[r] = (int8_t)sf;
                   if (!hasflip[r]) { hasflip[r] = 1; touched.push_back(r); }
                 }

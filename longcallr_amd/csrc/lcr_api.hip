@@ -32,7 +32,8 @@ struct lcr_ctx {
   DevParams dp{};
   float sor_thr = -1.f;
   HostBuf h_planes;
-  HostBuf h_nnz;              // pinned: entry count of the fragment matrix (lcr_fragments -> frag_settle)
+  HostBuf h_nnz;              // pinned: first entry of every region of the fragment matrix, [ng] = entry count (lcr_fragments -> frag_settle)
+  DevBuf region_e_off;
   hipEvent_t ev_nnz = nullptr;
   bool nnz_pending = false;
   HostBuf h_stage[4];   // pinned staging of lcr_candidates / lcr_fragments: survivor offsets, candidate records, keep flags, region rows
@@ -144,7 +145,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   for (auto& b : c->in_) b.release();
   DevBuf* bufs[] = {&c->rd_start, &c->rd_end, &c->rd_diff, &c->rd_ex, &c->rd_cnt, &c->rd_off, &c->rd_s, &c->rd_e, &c->rd_max,
                     &c->scan_tmp, &c->read_region, &c->read_bin, &c->read_rend, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, 
-                    &c->k0_tile_fill, &c->k0_items, &c->ndiff, &c->nscan, &c->planes, &c->flags,
+                    &c->k0_tile_fill, &c->k0_items, &c->region_e_off, &c->ndiff, &c->nscan, &c->planes, &c->flags,
                     &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
                     &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
                     &c->row_links, &c->row_ptr, &c->col, &c->val};
@@ -438,7 +439,7 @@ int lcr_get_candidates(lcr_ctx* c, lcr_candidate_list* out) {
 static int frag_settle(lcr_ctx* c) {
   if (!c->nnz_pending) return LCR_OK;
   HIPCHK(c, hipEventSynchronize(c->ev_nnz));
-  c->nnz = *c->h_nnz.as<int64_t>();
+  c->nnz = c->h_nnz.as<int64_t>()[c->bv.n_regions];
   c->nnz_pending = false;
   return LCR_OK;
 }
@@ -466,9 +467,13 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   // behind the count pass and the true count is picked up later (frag_settle); otherwise wait for it first.
   int64_t bound = 0;
   for (int g = 0; g < ng; g++) bound += (int64_t)rr[g] * (c->h_cand_off[g + 1] - c->h_cand_off[g]);
-  HIPCHK(c, c->h_nnz.reserve(8));
+  // the regions' first entries ([ng] = all entries) follow the count pass to the host: the phase stage sizes its
+  // work from them without a round trip of its own
+  HIPCHK(c, c->h_nnz.reserve((size_t)(ng + 1) * 8));
+  HIPCHK(c, c->region_e_off.reserve((size_t)(ng + 1) * 8));
   if (!c->ev_nnz) HIPCHK(c, hipEventCreateWithFlags(&c->ev_nnz, hipEventDisableTiming));
-  HIPCHK(c, hipMemcpyAsync(c->h_nnz.p, c->row_ptr.as<int64_t>() + nrow, 8, hipMemcpyDeviceToHost, c->stream));
+  launch_k3_region_entries(c->row_ptr.as<int64_t>(), c->row_region_off.as<int32_t>(), ng, c->region_e_off.as<int64_t>(), c->stream);
+  HIPCHK(c, hipMemcpyAsync(c->h_nnz.p, c->region_e_off.p, (size_t)(ng + 1) * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipEventRecord(c->ev_nnz, c->stream));
   c->nnz_pending = true;
   int64_t cap = bound;
@@ -537,6 +542,7 @@ int lcr_phase(lcr_ctx* c, const lcr_params* p) {
   in.n_regions = c->bv.n_regions; in.n_rows = c->n_rows; in.nnz = c->nnz;
   in.row_region_off = c->h_row_region_off.data(); in.cand_region_off = c->h_cand_off.data();
   in.region_start0 = c->h_start0.data();
+  in.region_e_off = c->h_nnz.as<int64_t>();
   in.d_row_ptr = c->row_ptr.as<int64_t>(); in.d_col = c->col.as<int32_t>(); in.d_val = c->val.as<uint8_t>();
   in.d_row_links = c->row_links.as<uint32_t>();
   in.cand = &c->h_cand;

@@ -156,6 +156,7 @@ void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t*
                       int32_t n_regions, int32_t* pos, int32_t* idx, lcr_candidate* out, int32_t* cand_off, uint32_t dense_win,
                       uint32_t min_dense_cnt, hipStream_t s);
 void launch_k3_row_offsets(const int32_t* region_rows, int32_t ng, int32_t* row_region_off, hipStream_t s);
+void launch_k3_region_entries(const int64_t* row_ptr, const int32_t* row_region_off, int32_t ng, int64_t* region_e_off, hipStream_t s);
 void launch_k3_count(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
                      const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, uint32_t* row_links,
                      hipStream_t s);

@@ -14,6 +14,7 @@ struct PhaseInputs {
   const int32_t* row_region_off = nullptr;   // host, n_regions+1
   const int32_t* cand_region_off = nullptr;  // host, n_regions+1
   const int64_t* region_start0 = nullptr;    // host
+  const int64_t* region_e_off = nullptr;     // host, n_regions+1: first entry of every region in the fragment matrix
   const int64_t* d_row_ptr = nullptr;        // device CSR
   const int32_t* d_col = nullptr;
   const uint8_t* d_val = nullptr;

@@ -345,6 +345,13 @@ def test_contexts_on_concurrent_host_threads(engine_cls):
                 assert a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
 
 
+def test_deep_region_beyond_the_lds_images(engine_cls, orc):
+    """A region with more rows / entries than the LDS images of k4_stage (4096 rows, 8192 entries) and k4_post
+    hold: the phase stage then works from global memory and finishes with the host epilogue."""
+    b = synth.make_batch("ont-cdna", n_genes=1, gene_len=9000, depth=600, seed=91)
+    full_check(engine_cls, orc, b, _abi.make_params("ont-cdna", seed=9))
+
+
 def test_empty_batch_and_errors(engine_cls):
     from longcallr_amd.api import LcrError
     p = _abi.make_params()
