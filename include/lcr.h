@@ -231,6 +231,38 @@ typedef struct {
 int lcr_discover_regions(lcr_ctx*, int32_t mem, int32_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
                          int64_t contig_len, lcr_region_list* out);
 
+/* ---- BGZF / BAM decode -> lcr_reads on the host -------------------------------------------
+ * Replaces the rust-htslib IndexedReader calls of util.rs:636-691 and fragment.rs:19-59 (and the read pass of
+ * region discovery, util.rs:256-287): the file is inflated once (all BGZF blocks in parallel on n_threads host
+ * threads, <= 0: all hardware threads), every record is indexed once, and the batches for lcr_load_batch are cut
+ * out of that index, so the pileup and the fragment stage share one decode (the reference inflates every
+ * region's blocks twice).  The file must be coordinate-sorted (the reference needs its .bai too).  No GPU is
+ * involved; a handle is used by one thread at a time, output pointers stay valid until the next call on the
+ * handle or lcr_bam_close. */
+typedef struct lcr_bam lcr_bam;
+typedef struct {            /* util.rs:652-668 / fragment.rs:32-49                                        */
+  uint8_t min_mapq;         /* mapq < min_mapq is dropped                                                 */
+  int32_t min_read_length;  /* l_seq < min_read_length is dropped                                         */
+  float divergence;         /* a `de` tag of type f with value >= divergence drops the read               */
+} lcr_read_filter;          /* unmapped / secondary / supplementary records are always dropped            */
+/* *out is set even when the call fails (unless out of memory): lcr_bam_last_error explains, lcr_bam_close frees */
+int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out);
+void lcr_bam_close(lcr_bam*);
+const char* lcr_bam_last_error(const lcr_bam*);
+int lcr_bam_refs(lcr_bam*, int32_t* n_ref, const char* const** names, const int64_t** lengths);
+int lcr_bam_n_records(lcr_bam*, int64_t* n);
+/* record.reference_start() / reference_end() of the reads of contig ref_id that pass the filter, in file order:
+ * the input of lcr_discover_regions (util.rs:264-285) */
+int lcr_bam_spans(lcr_bam*, int32_t ref_id, const lcr_read_filter*, int32_t* n, const int32_t** ref_start,
+                  const int32_t** ref_end);
+/* The passing reads of contig ref_id grouped by region with htslib's fetch rule on the reference's numbers
+ * (util.rs:637: [start0 + 1, start0 + len + 1) as 0-based half-open; a read that overlaps two regions is listed
+ * in both): fills *reads (mem = LCR_MEM_HOST) and *read_begin (n_regions + 1) for lcr_load_batch.  name_off /
+ * names (optional): read names, NUL-terminated, name i at names + name_off[i] (the qname maps of thread.rs). */
+int lcr_bam_batch(lcr_bam*, int32_t ref_id, const lcr_read_filter*, int32_t n_regions, const int64_t* start0,
+                  const int32_t* len, lcr_reads* reads, const int32_t** read_begin, const uint64_t** name_off,
+                  const char** names);
+
 /* Timing: HIP-event time (ms) of the last launch of each kernel on the ctx's stream. */
 enum { LCR_K_SPANS = 0 /* K0: CIGAR decode + binning */, LCR_K_PILEUP, LCR_K_CAND_FILTER, LCR_K_CAND_HIST, LCR_K_CAND_GT,
        LCR_K_FRAG_COUNT, LCR_K_FRAG_FILL, LCR_K_PHASE, LCR_NKERNELS };

@@ -31,6 +31,10 @@ class LcrReads(C.Structure):
     ]
 
 
+class LcrReadFilter(C.Structure):   # include/lcr.h lcr_read_filter (util.rs:652-668)
+    _fields_ = [("min_mapq", C.c_uint8), ("min_read_length", C.c_int32), ("divergence", C.c_float)]
+
+
 class LcrRegions(C.Structure):
     _fields_ = [
         ("mem", C.c_int32), ("n_regions", C.c_int32), ("start0", C.c_void_p), ("len", C.c_void_p),

@@ -13,6 +13,7 @@ SYMBOLS = [
     "lcr_ctx_sync", "lcr_load_batch", "lcr_pileup", "lcr_get_columns", "lcr_candidates",
     "lcr_get_candidates", "lcr_get_candidates_device", "lcr_fragments", "lcr_get_fragmat", "lcr_phase", "lcr_get_phase_result",
     "lcr_enable_timing", "lcr_kernel_ms", "lcr_pileup_bytes", "lcr_pileup_stage_bytes", "lcr_discover_regions", "lcr_version",
+    "lcr_bam_open", "lcr_bam_close", "lcr_bam_last_error", "lcr_bam_refs", "lcr_bam_n_records", "lcr_bam_spans", "lcr_bam_batch",
 ]
 
 _lib = None
@@ -61,5 +62,16 @@ def load():
     l.lcr_kernel_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     l.lcr_pileup_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
     l.lcr_pileup_stage_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
+    flt = C.POINTER(_abi.LcrReadFilter)
+    l.lcr_bam_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(vp)]
+    l.lcr_bam_close.argtypes = [vp]
+    l.lcr_bam_close.restype = None
+    l.lcr_bam_last_error.argtypes = [vp]
+    l.lcr_bam_last_error.restype = C.c_char_p
+    l.lcr_bam_refs.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_int64))]
+    l.lcr_bam_n_records.argtypes = [vp, C.POINTER(C.c_int64)]
+    l.lcr_bam_spans.argtypes = [vp, C.c_int32, flt, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]
+    l.lcr_bam_batch.argtypes = [vp, C.c_int32, flt, C.c_int32, vp, vp, C.POINTER(_abi.LcrReads), C.POINTER(C.POINTER(C.c_int32)),
+                                C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_char_p)]
     _lib = l
     return l

@@ -1,4 +1,8 @@
-"""Minimal host-side BGZF/BAM decoder -> ReadBatch (SoA) for liblcr.
+"""Host-side BGZF/BAM decoding -> ReadBatch (SoA) for liblcr.
+
+`NativeBam` is the product path: liblcr's multithreaded decoder (csrc/lcr_bam.cpp,
+`lcr_bam_*` in include/lcr.h).  The pure-Python functions below restate the same rules record by record;
+tests use them as the checker of the native decoder and to build the demo fixture.
 
 Host plumbing only: the reference uses rust-htslib for this
 (src/util.rs:636-691, src/fragment.rs:19-59).  Implements exactly what the hot path needs:
@@ -6,6 +10,7 @@ record decode, the read filter of util.rs:652-668, `leading/trailing_softclips`,
 `ts:A` aux tags, htslib's region-overlap rule for `fetch`, and the coverage-island region
 discovery of util.rs:236-332.
 """
+import os
 import struct
 import zlib
 
@@ -200,3 +205,83 @@ def build_batch(recs, regions, ref_windows):
         bases=cat(bases, np.uint8), quals=cat(quals, np.uint8), cigar=cat(cigars, np.uint32),
         start0=[s for s, _ in regions], len=[l for _, l in regions], read_begin=read_begin,
         ref=cat(list(ref_windows), np.uint8), names=names, **cols)
+
+
+class NativeBam:
+    """liblcr's BAM decoder (lcr_bam_* in include/lcr.h): one parallel inflate + record index per file, batches
+    for `Engine.load_batch` cut out of it.  Mirrors read_bam / passes_filter / build_batch above."""
+
+    def __init__(self, path, threads=0):
+        import ctypes as C
+        from . import _lib
+        self._C, self._l = C, _lib.load()
+        self._h = C.c_void_p()
+        rc = self._l.lcr_bam_open(os.fsencode(path), threads, C.byref(self._h))
+        if rc:
+            msg = self._l.lcr_bam_last_error(self._h).decode() if self._h else "out of memory"
+            self.close()
+            raise _lib.LcrError("lcr_bam_open(%s): %s" % (path, msg))
+        n, names, lens = C.c_int32(), C.POINTER(C.c_char_p)(), C.POINTER(C.c_int64)()
+        self._chk(self._l.lcr_bam_refs(self._h, C.byref(n), C.byref(names), C.byref(lens)))
+        self.refs = [(names[i].decode(), int(lens[i])) for i in range(n.value)]
+        nrec = C.c_int64()
+        self._chk(self._l.lcr_bam_n_records(self._h, C.byref(nrec)))
+        self.n_records = nrec.value
+
+    def _chk(self, rc):
+        if rc:
+            from . import _lib
+            raise _lib.LcrError(self._l.lcr_bam_last_error(self._h).decode())
+
+    def _filter(self, min_mapq=20, min_read_length=500, divergence=0.5):
+        from . import _abi
+        return _abi.LcrReadFilter(min_mapq, min_read_length, divergence)
+
+    def spans(self, ref_id, **flt):
+        """(reference_start, reference_end) of the passing reads of a contig: input of lcr_discover_regions."""
+        C = self._C
+        f, n = self._filter(**flt), C.c_int32()
+        s, e = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        self._chk(self._l.lcr_bam_spans(self._h, ref_id, C.byref(f), C.byref(n), C.byref(s), C.byref(e)))
+        return (np.ctypeslib.as_array(s, (n.value,)).copy() if n.value else np.zeros(0, np.int32),
+                np.ctypeslib.as_array(e, (n.value,)).copy() if n.value else np.zeros(0, np.int32))
+
+    def batch(self, ref_id, regions, ref_windows, **flt):
+        """ReadBatch of the passing reads grouped by region (fetch rule of util.rs:637); arrays are copies."""
+        C = self._C
+        from . import _abi
+        f = self._filter(**flt)
+        start0 = np.ascontiguousarray([s for s, _ in regions], dtype=np.int64)
+        length = np.ascontiguousarray([l for _, l in regions], dtype=np.int32)
+        rd, rb = _abi.LcrReads(), C.POINTER(C.c_int32)()
+        noff, names = C.POINTER(C.c_uint64)(), C.c_char_p()
+        self._chk(self._l.lcr_bam_batch(self._h, ref_id, C.byref(f), len(regions), start0.ctypes.data, length.ctypes.data,
+                                        C.byref(rd), C.byref(rb), C.byref(noff), C.byref(names)))
+        nr = rd.n_reads
+
+        def arr(ptr, n, dt):
+            if n == 0 or not ptr:
+                return np.zeros(0, dt)
+            return np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt).copy()
+        kw = {fld: arr(getattr(rd, fld), nr, _abi.ReadBatch.DTYPES[fld])
+              for fld in ("pos", "seq_len", "lead_clip", "trail_clip", "flags", "seq_off", "cig_off", "n_cig")}
+        kw["bases"] = arr(rd.bases, rd.n_bases, np.uint8)
+        kw["quals"] = arr(rd.quals, rd.n_bases, np.uint8)
+        kw["cigar"] = arr(rd.cigar, rd.n_cigar, np.uint32)
+        offs = np.ctypeslib.as_array(noff, (nr + 1,)).copy() if nr else np.zeros(1, np.uint64)
+        blob = C.string_at(C.cast(names, C.c_void_p), int(offs[-1])) if nr else b""
+        nm = [blob[int(offs[i]):int(offs[i + 1]) - 1].decode() for i in range(nr)]
+        read_begin = np.ctypeslib.as_array(rb, (len(regions) + 1,)).copy()
+        cat = np.concatenate([np.asarray(w, np.uint8) for w in ref_windows]) if len(ref_windows) else np.zeros(0, np.uint8)
+        return ReadBatch(start0=start0, len=length, read_begin=read_begin, ref=cat, names=nm, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.lcr_bam_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass

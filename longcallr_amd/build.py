@@ -6,7 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "liblcr.so")
-SOURCES = ["k1_pileup.hip", "k2_candidates.hip", "k3_fragments.hip", "k4_phase.hip", "k5_regions.hip", "lcr_api.hip"]
+SOURCES = ["k1_pileup.hip", "k2_candidates.hip", "k3_fragments.hip", "k4_phase.hip", "k5_regions.hip", "lcr_api.hip",
+           "lcr_bam.cpp"]   # lcr_bam.cpp: host-only BGZF / BAM decode (zlib)
 HEADERS = ["lcr_dev.h", "lcr_phase_host.h", os.path.join("..", "..", "include", "lcr.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function"]
@@ -26,7 +27,7 @@ def build(force=False, verbose=False):
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, procs = [], []
     for src in SOURCES:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [os.path.join(CSRC, src)] + hdrs):
             cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
@@ -40,7 +41,7 @@ def build(force=False, verbose=False):
         if verbose and out:
             print(out.decode(), file=sys.stderr)
     if force or procs or _stale(SO, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", SO] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", SO] + objs + ["-lz"]
         subprocess.check_call(cmd)
     return SO
 

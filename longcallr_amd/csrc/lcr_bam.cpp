@@ -1,0 +1,364 @@
+// lcr_bam.cpp — SURVEY §8(f) N1: BGZF / BAM decode -> lcr_reads on the host (no GPU code in this file).
+//
+// Replaces the rust-htslib IndexedReader use of the reference (src/util.rs:636-691, src/fragment.rs:19-59;
+// region discovery's pass over the file, util.rs:256-287): the reference inflates every region's blocks
+// twice (once for the pileup, once for the fragments) and decodes records one at a time; here the file is
+// inflated once, all BGZF blocks in parallel, every record is indexed once, and the batches handed to
+// lcr_load_batch are cut out of that index (one decode shared by K1 and K3).
+//
+// What is kept from the reference, by line:
+//   * read filter: mapq < min_mapq | l_seq < min_read_length | unmapped | secondary | supplementary, then
+//     `de:f` >= divergence only if the tag exists with type f (util.rs:652-668, fragment.rs:32-49);
+//   * record.pos(), cigar().leading_softclips() / trailing_softclips() (look past one hard clip),
+//     seq() decoded to upper-case =ACMGRSVTWYHKDBN, qual() raw phred, the `ts:A` aux tag (util.rs:674-691);
+//   * fetch((chr, start, end)) takes the 1-based region numbers as a 0-based half-open interval
+//     (util.rs:637): a record is returned iff pos < end && bam_endpos > beg, with
+//     bam_endpos = pos + max(reference length of the CIGAR, 1);
+//   * reference_start() / reference_end() for region discovery (util.rs:281-285).
+// The input must be coordinate-sorted (the reference needs a .bai, i.e. a sorted file, too); batches list a
+// region's reads in file order.
+#include "../../include/lcr.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Rec {
+  uint64_t off;        // first byte after block_size in the inflated stream
+  uint32_t size;       // block_size
+  int32_t ref_id, pos, l_seq, ref_len, lead, trail;
+  uint32_t n_cig, l_rn;
+  uint16_t flag;
+  uint8_t mapq, ts, has_de;
+  float de;
+};
+
+inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline int32_t rdi32(const uint8_t* p) { return (int32_t)rd32(p); }
+
+// n items over up to nt threads, chunked through an atomic counter; fn(i) must not throw
+void parallel_for(int64_t n, int nt, int64_t chunk, const std::function<void(int64_t)>& fn) {
+  if (n <= 0) return;
+  nt = (int)std::max<int64_t>(1, std::min<int64_t>(nt, (n + chunk - 1) / chunk));
+  if (nt == 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
+  std::atomic<int64_t> next{0};
+  auto work = [&]() {
+    for (;;) {
+      const int64_t b = next.fetch_add(chunk);
+      if (b >= n) return;
+      const int64_t e = std::min(n, b + chunk);
+      for (int64_t i = b; i < e; i++) fn(i);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+}
+
+}  // namespace
+
+struct lcr_bam {
+  std::string err;
+  int n_threads = 1;
+  std::unique_ptr<uint8_t[]> data;   // inflated stream (not value-initialised: every byte is written by inflate)
+  size_t data_size = 0;
+  std::vector<std::string> ref_names;
+  std::vector<const char*> ref_name_ptrs;
+  std::vector<int64_t> ref_len;
+  std::vector<Rec> recs;
+  // results of the last lcr_bam_spans / lcr_bam_batch call
+  std::vector<int32_t> sp_start, sp_end;
+  std::vector<int32_t> b_pos, b_seq_len, b_lead, b_trail, b_read_begin;
+  std::vector<uint8_t> b_flags, b_bases, b_quals;
+  std::vector<uint64_t> b_seq_off, b_cig_off, b_name_off;
+  std::vector<uint32_t> b_n_cig, b_cigar;
+  std::vector<char> b_names;
+};
+
+namespace {
+
+bool passes(const Rec& r, const lcr_read_filter& f) {   // util.rs:652-668
+  if (r.mapq < f.min_mapq || r.l_seq < f.min_read_length) return false;
+  if (r.flag & (0x4 | 0x100 | 0x800)) return false;
+  if (r.has_de && r.de >= f.divergence) return false;
+  return true;
+}
+inline int32_t end_pos(const Rec& r) { return r.pos + (r.ref_len > 0 ? r.ref_len : 1); }   // htslib bam_endpos
+
+// aux block: the `de` tag of type f and the `ts` tag of type A; every other tag is skipped by its type
+bool aux_scan(const uint8_t* p, const uint8_t* end, Rec& r) {
+  r.has_de = 0; r.de = 0.f; r.ts = 0;
+  while (p + 3 <= end) {
+    const uint8_t t0 = p[0], t1 = p[1], typ = p[2];
+    p += 3;
+    switch (typ) {
+      case 'A': case 'c': case 'C':
+        if (p + 1 > end) return false;
+        if (typ == 'A' && t0 == 't' && t1 == 's') r.ts = p[0] == '+' ? 1 : (p[0] == '-' ? 2 : 0);
+        p += 1; break;
+      case 's': case 'S': p += 2; break;
+      case 'i': case 'I': p += 4; break;
+      case 'f':
+        if (p + 4 > end) return false;
+        if (t0 == 'd' && t1 == 'e') { uint32_t u = rd32(p); memcpy(&r.de, &u, 4); r.has_de = 1; }
+        p += 4; break;
+      case 'Z': case 'H':
+        while (p < end && *p) p++;
+        if (p >= end) return false;
+        p++; break;
+      case 'B': {
+        if (p + 5 > end) return false;
+        const uint8_t sub = p[0]; const uint32_t cnt = rd32(p + 1);
+        size_t w = 0;
+        switch (sub) { case 'c': case 'C': w = 1; break; case 's': case 'S': w = 2; break; case 'i': case 'I': case 'f': w = 4; break; default: return false; }
+        p += 5 + (size_t)cnt * w; break;
+      }
+      default: return false;
+    }
+    if (p > end) return false;
+  }
+  return true;
+}
+
+int fail(lcr_bam* b, int code, const std::string& msg) { b->err = msg; return code; }
+
+}  // namespace
+
+extern "C" {
+
+int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
+  if (!path || !out) return LCR_E_ARG;
+  *out = nullptr;
+  lcr_bam* b = new (std::nothrow) lcr_bam();
+  if (!b) return LCR_E_NOMEM;
+  *out = b;   // returned even on failure so that lcr_bam_last_error can explain; the caller closes it
+  if (n_threads < 1) n_threads = (int32_t)std::max(1u, std::thread::hardware_concurrency());
+  b->n_threads = n_threads;
+  // ---- the compressed file
+  std::vector<uint8_t> raw;
+  {
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(b, LCR_E_ARG, std::string("cannot open ") + path);
+    if (fseek(f, 0, SEEK_END) != 0) { fclose(f); return fail(b, LCR_E_ARG, "seek failed"); }
+    const long sz = ftell(f);
+    if (sz < 0) { fclose(f); return fail(b, LCR_E_ARG, "tell failed"); }
+    rewind(f);
+    try { raw.resize((size_t)sz); } catch (...) { fclose(f); return fail(b, LCR_E_NOMEM, "out of memory reading the file"); }
+    const size_t got = sz ? fread(raw.data(), 1, (size_t)sz, f) : 0;
+    fclose(f);
+    if (got != (size_t)sz) return fail(b, LCR_E_ARG, "short read");
+  }
+  // ---- BGZF block table (gzip member with the BC extra subfield; SAM spec 4.1)
+  struct Blk { size_t coff, clen; uint32_t crc, isize; uint64_t uoff; };
+  std::vector<Blk> blks;
+  uint64_t total = 0;
+  for (size_t off = 0; off < raw.size();) {
+    if (off + 18 > raw.size() || raw[off] != 0x1f || raw[off + 1] != 0x8b || raw[off + 2] != 8 || !(raw[off + 3] & 4))
+      return fail(b, LCR_E_ARG, "not a BGZF block at offset " + std::to_string(off));
+    const size_t xlen = rd16(&raw[off + 10]);
+    if (off + 12 + xlen > raw.size()) return fail(b, LCR_E_ARG, "truncated BGZF header");
+    int64_t bsize = -1;
+    for (size_t p = off + 12; p + 4 <= off + 12 + xlen;) {
+      const size_t slen = rd16(&raw[p + 2]);
+      if (raw[p] == 66 && raw[p + 1] == 67 && slen == 2 && p + 6 <= off + 12 + xlen) bsize = rd16(&raw[p + 4]);
+      p += 4 + slen;
+    }
+    if (bsize < 0) return fail(b, LCR_E_ARG, "BGZF block without BC subfield at offset " + std::to_string(off));
+    const size_t blen = (size_t)bsize + 1;
+    if (blen < 12 + xlen + 8 || off + blen > raw.size()) return fail(b, LCR_E_ARG, "truncated BGZF block at offset " + std::to_string(off));
+    Blk k;
+    k.coff = off + 12 + xlen; k.clen = blen - (12 + xlen) - 8;
+    k.crc = rd32(&raw[off + blen - 8]); k.isize = rd32(&raw[off + blen - 4]);
+    if (k.isize > 65536) return fail(b, LCR_E_ARG, "BGZF block larger than 64 KiB");
+    k.uoff = total; total += k.isize;
+    blks.push_back(k);
+    off += blen;
+  }
+  b->data.reset(new (std::nothrow) uint8_t[(size_t)total + 1]);
+  if (!b->data) return fail(b, LCR_E_NOMEM, "out of memory for the inflated stream");
+  b->data_size = (size_t)total;
+  // ---- inflate: blocks are independent
+  std::atomic<int> bad{-1};
+  parallel_for((int64_t)blks.size(), n_threads, 16, [&](int64_t i) {
+    const Blk& k = blks[(size_t)i];
+    if (k.isize == 0) return;   // EOF marker and other empty blocks
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) { bad.store((int)i); return; }
+    zs.next_in = const_cast<Bytef*>(raw.data() + k.coff); zs.avail_in = (uInt)k.clen;
+    zs.next_out = b->data.get() + k.uoff; zs.avail_out = k.isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.total_out == k.isize;
+    inflateEnd(&zs);
+    if (!ok || crc32(crc32(0L, Z_NULL, 0), b->data.get() + k.uoff, k.isize) != k.crc) bad.store((int)i);
+  });
+  if (bad.load() >= 0) return fail(b, LCR_E_ARG, "BGZF block " + std::to_string(bad.load()) + " does not inflate / CRC mismatch");
+  raw.clear(); raw.shrink_to_fit();
+  // ---- BAM header (SAM spec 4.2)
+  const uint8_t* const d = b->data.get();
+  const size_t n = b->data_size;
+  if (n < 12 || memcmp(d, "BAM\1", 4) != 0) return fail(b, LCR_E_ARG, "not a BAM file");
+  size_t p = 8 + (size_t)rd32(&d[4]);
+  if (p + 4 > n) return fail(b, LCR_E_ARG, "truncated BAM header");
+  const int32_t n_ref = rdi32(&d[p]);
+  p += 4;
+  if (n_ref < 0) return fail(b, LCR_E_ARG, "bad reference count");
+  for (int32_t i = 0; i < n_ref; i++) {
+    if (p + 4 > n) return fail(b, LCR_E_ARG, "truncated reference table");
+    const uint32_t l_name = rd32(&d[p]);
+    if (l_name == 0 || p + 4 + (size_t)l_name + 4 > n) return fail(b, LCR_E_ARG, "truncated reference table");
+    b->ref_names.emplace_back(reinterpret_cast<const char*>(&d[p + 4]), l_name - 1);
+    b->ref_len.push_back(rdi32(&d[p + 4 + l_name]));
+    p += 8 + l_name;
+  }
+  for (auto& s : b->ref_names) b->ref_name_ptrs.push_back(s.c_str());
+  // ---- record index: the block_size chain is sequential, the records' fields are not
+  while (p < n) {
+    if (p + 4 > n) return fail(b, LCR_E_ARG, "truncated record header");
+    const uint32_t bs = rd32(&d[p]);
+    if (bs < 32 || p + 4 + (size_t)bs > n) return fail(b, LCR_E_ARG, "truncated record at inflated offset " + std::to_string(p));
+    Rec r{};
+    r.off = p + 4; r.size = bs;
+    b->recs.push_back(r);
+    p += 4 + (size_t)bs;
+  }
+  std::atomic<int64_t> bad_rec{-1};
+  parallel_for((int64_t)b->recs.size(), n_threads, 1024, [&](int64_t i) {
+    Rec& r = b->recs[(size_t)i];
+    const uint8_t* q = &d[r.off];
+    r.ref_id = rdi32(q); r.pos = rdi32(q + 4); r.l_rn = q[8]; r.mapq = q[9];
+    r.n_cig = rd16(q + 12); r.flag = rd16(q + 14); r.l_seq = rdi32(q + 16);
+    const uint64_t need = 32ull + r.l_rn + 4ull * r.n_cig + (uint64_t)((r.l_seq + 1) / 2) + (uint64_t)r.l_seq;
+    if (r.l_seq < 0 || r.l_rn == 0 || need > r.size) { bad_rec.store(i); return; }
+    const uint8_t* cg = q + 32 + r.l_rn;
+    int64_t rl = 0;
+    for (uint32_t k = 0; k < r.n_cig; k++) {
+      const uint32_t w = rd32(cg + 4 * k), op = w & 15;
+      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += w >> 4;   // M D N = X consume the reference
+    }
+    r.ref_len = (int32_t)rl;
+    r.lead = r.trail = 0;
+    if (r.n_cig) {   // leading / trailing soft clips, looking past one hard clip
+      const uint32_t w0 = rd32(cg), wl = rd32(cg + 4 * (r.n_cig - 1));
+      if ((w0 & 15) == 4) r.lead = (int32_t)(w0 >> 4);
+      else if ((w0 & 15) == 5 && r.n_cig > 1 && (rd32(cg + 4) & 15) == 4) r.lead = (int32_t)(rd32(cg + 4) >> 4);
+      if ((wl & 15) == 4) r.trail = (int32_t)(wl >> 4);
+      else if ((wl & 15) == 5 && r.n_cig > 1 && (rd32(cg + 4 * (r.n_cig - 2)) & 15) == 4) r.trail = (int32_t)(rd32(cg + 4 * (r.n_cig - 2)) >> 4);
+    }
+    if (!aux_scan(q + need, q + r.size, r)) bad_rec.store(i);
+  });
+  if (bad_rec.load() >= 0) return fail(b, LCR_E_ARG, "malformed record " + std::to_string(bad_rec.load()));
+  return LCR_OK;
+}
+
+void lcr_bam_close(lcr_bam* b) { delete b; }
+
+const char* lcr_bam_last_error(const lcr_bam* b) { return b ? b->err.c_str() : "null handle"; }
+
+int lcr_bam_refs(lcr_bam* b, int32_t* n_ref, const char* const** names, const int64_t** lengths) {
+  if (!b || !n_ref || !names || !lengths) return LCR_E_ARG;
+  *n_ref = (int32_t)b->ref_names.size();
+  *names = b->ref_name_ptrs.data();
+  *lengths = b->ref_len.data();
+  return LCR_OK;
+}
+
+int lcr_bam_n_records(lcr_bam* b, int64_t* n) {
+  if (!b || !n) return LCR_E_ARG;
+  *n = (int64_t)b->recs.size();
+  return LCR_OK;
+}
+
+int lcr_bam_spans(lcr_bam* b, int32_t ref_id, const lcr_read_filter* f, int32_t* n, const int32_t** ref_start, const int32_t** ref_end) {
+  if (!b || !f || !n || !ref_start || !ref_end) return LCR_E_ARG;
+  b->sp_start.clear(); b->sp_end.clear();
+  for (const Rec& r : b->recs)
+    if (r.ref_id == ref_id && passes(r, *f)) { b->sp_start.push_back(r.pos); b->sp_end.push_back(end_pos(r)); }
+  *n = (int32_t)b->sp_start.size();
+  *ref_start = b->sp_start.data(); *ref_end = b->sp_end.data();
+  return LCR_OK;
+}
+
+int lcr_bam_batch(lcr_bam* b, int32_t ref_id, const lcr_read_filter* f, int32_t n_regions, const int64_t* start0, const int32_t* len,
+                  lcr_reads* reads, const int32_t** read_begin, const uint64_t** name_off, const char** names) {
+  if (!b || !f || !reads || !read_begin || n_regions < 0 || (n_regions && (!start0 || !len))) return LCR_E_ARG;
+  // passing records of the contig, by position (file order for a sorted file), with a running maximum of their ends
+  std::vector<uint32_t> idx;
+  for (size_t i = 0; i < b->recs.size(); i++)
+    if (b->recs[i].ref_id == ref_id && passes(b->recs[i], *f)) idx.push_back((uint32_t)i);
+  for (size_t i = 1; i < idx.size(); i++)
+    if (b->recs[idx[i]].pos < b->recs[idx[i - 1]].pos) return fail(b, LCR_E_ARG, "BAM is not coordinate-sorted");
+  std::vector<int32_t> ipos(idx.size()), iend_max(idx.size());
+  int32_t run = INT32_MIN;
+  for (size_t i = 0; i < idx.size(); i++) {
+    ipos[i] = b->recs[idx[i]].pos;
+    run = std::max(run, end_pos(b->recs[idx[i]]));
+    iend_max[i] = run;
+  }
+  // fetch rule per region: pos < end && end_pos > beg over [beg, end) = [start0 + 1, start0 + len + 1)  (util.rs:637)
+  std::vector<uint32_t> take;
+  b->b_read_begin.assign((size_t)n_regions + 1, 0);
+  for (int32_t g = 0; g < n_regions; g++) {
+    if (len[g] < 0) return fail(b, LCR_E_ARG, "negative region length");
+    const int64_t beg = start0[g] + 1, end = start0[g] + len[g] + 1;
+    const size_t hi = (size_t)(std::lower_bound(ipos.begin(), ipos.end(), end, [](int32_t v, int64_t e) { return (int64_t)v < e; }) - ipos.begin());
+    size_t lo = (size_t)(std::upper_bound(iend_max.begin(), iend_max.end(), beg, [](int64_t bg, int32_t v) { return bg < (int64_t)v; }) - iend_max.begin());
+    for (; lo < hi; lo++)
+      if ((int64_t)end_pos(b->recs[idx[lo]]) > beg) take.push_back(idx[lo]);
+    if (take.size() > (size_t)INT32_MAX) return fail(b, LCR_E_ARG, "more than 2^31 reads in one batch");
+    b->b_read_begin[(size_t)g + 1] = (int32_t)take.size();
+  }
+  const size_t nr = take.size();
+  b->b_pos.resize(nr); b->b_seq_len.resize(nr); b->b_lead.resize(nr); b->b_trail.resize(nr); b->b_flags.resize(nr);
+  b->b_seq_off.resize(nr); b->b_cig_off.resize(nr); b->b_n_cig.resize(nr); b->b_name_off.resize(nr + 1);
+  uint64_t so = 0, co = 0, no = 0;
+  for (size_t k = 0; k < nr; k++) {
+    const Rec& r = b->recs[take[k]];
+    b->b_seq_off[k] = so; b->b_cig_off[k] = co; b->b_name_off[k] = no;
+    so += (uint64_t)r.l_seq; co += r.n_cig; no += r.l_rn;   // names keep their NUL
+  }
+  b->b_name_off[nr] = no;
+  b->b_bases.resize(so); b->b_quals.resize(so); b->b_cigar.resize(co); b->b_names.resize(no);
+  static const char NT16[] = "=ACMGRSVTWYHKDBN";
+  const uint8_t* d = b->data.get();
+  parallel_for((int64_t)nr, b->n_threads, 256, [&](int64_t k) {
+    const Rec& r = b->recs[take[(size_t)k]];
+    const uint8_t* q = d + r.off;
+    b->b_pos[k] = r.pos; b->b_seq_len[k] = r.l_seq; b->b_lead[k] = r.lead; b->b_trail[k] = r.trail;
+    b->b_flags[k] = (uint8_t)(((r.flag & 0x10) ? 1 : 0) | (r.ts << 1));
+    b->b_n_cig[k] = r.n_cig;
+    memcpy(b->b_names.data() + b->b_name_off[k], q + 32, r.l_rn);
+    const uint8_t* cg = q + 32 + r.l_rn;
+    uint32_t* co_ = b->b_cigar.data() + b->b_cig_off[k];
+    for (uint32_t c = 0; c < r.n_cig; c++) co_[c] = rd32(cg + 4 * c);
+    const uint8_t* sq = cg + 4 * (size_t)r.n_cig;
+    uint8_t* bo = b->b_bases.data() + b->b_seq_off[k];
+    for (int32_t i = 0; i + 1 < r.l_seq; i += 2) { const uint8_t v = sq[i >> 1]; bo[i] = (uint8_t)NT16[v >> 4]; bo[i + 1] = (uint8_t)NT16[v & 15]; }
+    if (r.l_seq & 1) bo[r.l_seq - 1] = (uint8_t)NT16[sq[r.l_seq >> 1] >> 4];
+    memcpy(b->b_quals.data() + b->b_seq_off[k], sq + (r.l_seq + 1) / 2, (size_t)r.l_seq);
+  });
+  memset(reads, 0, sizeof(*reads));
+  reads->mem = LCR_MEM_HOST;
+  reads->n_reads = (int32_t)nr; reads->n_bases = (int64_t)so; reads->n_cigar = (int64_t)co;
+  reads->pos = b->b_pos.data(); reads->seq_len = b->b_seq_len.data(); reads->lead_clip = b->b_lead.data(); reads->trail_clip = b->b_trail.data();
+  reads->flags = b->b_flags.data(); reads->seq_off = b->b_seq_off.data(); reads->cig_off = b->b_cig_off.data(); reads->n_cig = b->b_n_cig.data();
+  reads->bases = b->b_bases.data(); reads->quals = b->b_quals.data(); reads->cigar = b->b_cigar.data();
+  *read_begin = b->b_read_begin.data();
+  if (name_off) *name_off = b->b_name_off.data();
+  if (names) *names = b->b_names.data();
+  return LCR_OK;
+}
+
+}  // extern "C"

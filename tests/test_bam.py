@@ -1,0 +1,163 @@
+"""liblcr's BGZF / BAM decoder (csrc/lcr_bam.cpp, lcr_bam_* in include/lcr.h) against the
+record-by-record Python restatement of the same rules (longcallr_amd/bamio.py) — on demo.bam, the reference's
+own fixture, and on hand-written BAM files that exercise the corners of the format the hot path depends on
+(util.rs:636-691, fragment.rs:19-59).  Host only: no GPU needed."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import helpers
+from longcallr_amd import _abi, _lib, bamio
+
+DEMO = os.path.join(helpers.GOLDEN, "demo.bam")
+CIG = {c: i for i, c in enumerate("MIDNSHP=X")}
+NT16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+
+
+def bgzf(payload, block=300):
+    """BGZF stream of `payload` in blocks of `block` inflated bytes (+ the empty EOF block)."""
+    out = []
+    for off in list(range(0, len(payload), block)) + [None]:
+        chunk = b"" if off is None else payload[off:off + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        cdata = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(cdata) + 8 - 1
+        out.append(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize)
+                   + cdata + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+    return b"".join(out)
+
+
+def bam_bytes(refs, reads):
+    """reads: dict(ref, pos, name, mapq, flag, cigar 'str', seq 'str', qual [..], aux bytes)."""
+    import re
+    text = b"@HD\tVN:1.6\tSO:coordinate\n"
+    buf = [b"BAM\1", struct.pack("<i", len(text)), text, struct.pack("<i", len(refs))]
+    for name, ln in refs:
+        buf.append(struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", ln))
+    for r in reads:
+        ops = [(int(n), CIG[c]) for n, c in re.findall(r"(\d+)([MIDNSHP=X])", r.get("cigar", ""))]
+        seq = r["seq"]
+        packed = bytearray((len(seq) + 1) // 2)
+        for i, c in enumerate(seq):
+            packed[i // 2] |= NT16[c] << (4 if i % 2 == 0 else 0)
+        qual = bytes(r.get("qual", [30] * len(seq)))
+        name = r["name"].encode() + b"\0"
+        body = (struct.pack("<iiBBHHHiiii", r["ref"], r["pos"], len(name), r.get("mapq", 60), 4680, len(ops), r.get("flag", 0),
+                            len(seq), -1, -1, 0)
+                + name + b"".join(struct.pack("<I", (n << 4) | o) for n, o in ops) + bytes(packed) + qual + r.get("aux", b""))
+        buf.append(struct.pack("<i", len(body)) + body)
+    return b"".join(buf)
+
+
+def same_batch(a, b):
+    for f in _abi.ReadBatch.FIELDS + ["start0", "len", "read_begin", "ref", "col_off"]:
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+        assert getattr(a, f).dtype == getattr(b, f).dtype, f
+    assert a.names == b.names
+
+
+@pytest.mark.parametrize("threads", [1, 8])
+def test_demo_bam_native_vs_python(threads):
+    refs, recs = bamio.read_bam(DEMO)
+    nb = bamio.NativeBam(DEMO, threads)
+    assert nb.refs == refs and nb.n_records == len(recs)
+    keep = [r for r in recs if bamio.passes_filter(r, **_abi.READ_FILTER)]
+    rid = keep[0]["ref_id"]
+    s, e = nb.spans(rid, **_abi.READ_FILTER)
+    assert np.array_equal(s, [r["pos"] for r in keep]) and np.array_equal(e, [r["pos"] + max(r["ref_len"], 1) for r in keep])
+    assert nb.spans(rid + 1, **_abi.READ_FILTER)[0].size == 0
+    (start0, length, _), = bamio.discover_regions(keep, rid, refs[rid][1])
+    ref = helpers.load_pseudo_ref()
+    same_batch(bamio.build_batch(keep, [(start0, length)], [ref]), nb.batch(rid, [(start0, length)], [ref], **_abi.READ_FILTER))
+    # several regions: a read that overlaps two windows is listed in both (fetch rule of util.rs:637), an
+    # uncovered window is empty
+    cuts = [(start0, 4000), (start0 + 4000, 3000), (start0 + 7000, length - 7000), (start0 + length + 50000, 100)]
+    wins = [ref[0:4000], ref[4000:7000], ref[7000:], np.full(100, ord("N"), np.uint8)]
+    a, b = bamio.build_batch(keep, cuts, wins), nb.batch(rid, cuts, wins, **_abi.READ_FILTER)
+    same_batch(a, b)
+    assert b.n_reads > len(keep) and b.read_begin[-1] == b.read_begin[-2]
+    # a different filter
+    flt = dict(min_mapq=0, min_read_length=2000, divergence=0.02)
+    keep2 = [r for r in recs if bamio.passes_filter(r, **flt) and r["ref_id"] == rid]
+    same_batch(bamio.build_batch(keep2, cuts[:3], wins[:3]), nb.batch(rid, cuts[:3], wins[:3], **flt))
+    nb.close()
+
+
+def test_handwritten_bam_format_corners(tmp_path):
+    f32 = lambda v: struct.pack("<f", v)
+    reads = [
+        # hard clip before the soft clip; odd l_seq; IUPAC codes; de:f below the cut; ts '+'
+        dict(ref=0, pos=100, name="r1", cigar="3H5S20M2I10M1D7M4S2H", seq="ACGTN" + "ACGTRYKMSWBDHV" * 3 + "ACG", aux=b"def" + f32(0.01) + b"tsA+"),
+        # de of another type is ignored (util.rs:660-666 looks at Aux::Float only); ts '-' ; B array, Z string, ints
+        dict(ref=0, pos=100, name="r2", cigar="30M", seq="A" * 30, flag=16,
+             aux=b"deC\x63" + b"NMi" + struct.pack("<i", 3) + b"MDZ10A19\0" + b"xxBs" + struct.pack("<I", 3) + struct.pack("<hhh", 1, -2, 3) + b"tsA-"),
+        dict(ref=0, pos=105, name="dropped_de", cigar="30M", seq="C" * 30, aux=b"def" + f32(0.5)),            # de >= divergence
+        dict(ref=0, pos=106, name="dropped_mapq", cigar="30M", seq="C" * 30, mapq=5),
+        dict(ref=0, pos=107, name="dropped_unmapped", cigar="30M", seq="C" * 30, flag=4),
+        dict(ref=0, pos=108, name="dropped_secondary", cigar="30M", seq="C" * 30, flag=256),
+        dict(ref=0, pos=109, name="dropped_supp", cigar="30M", seq="C" * 30, flag=2048),
+        dict(ref=0, pos=110, name="dropped_short", cigar="9M", seq="C" * 9),
+        # spliced read; = and X ops; ts of a non-A type is not a ts tag
+        dict(ref=0, pos=120, name="r3", cigar="10=1X500N12M", seq="G" * 23, aux=b"tsi" + struct.pack("<i", 1)),
+        # no CIGAR at all: reference length 0 -> bam_endpos = pos + 1
+        dict(ref=0, pos=700, name="r4_nocigar", cigar="", seq="T" * 12),
+        dict(ref=0, pos=701, name="r5", cigar="12S12M", seq="T" * 24, qual=list(range(24))),
+        dict(ref=1, pos=5, name="other_contig", cigar="40M", seq="A" * 40),
+    ]
+    refs = [("chrA", 5000), ("chrB", 900)]
+    raw = bam_bytes(refs, reads)
+    for block in (64, 300, 60000):   # records span many blocks / everything in one block
+        path = str(tmp_path / ("t%d.bam" % block))
+        open(path, "wb").write(bgzf(raw, block))
+        prefs, recs = bamio.read_bam(path)
+        nb = bamio.NativeBam(path, 3)
+        assert nb.refs == prefs == refs and nb.n_records == len(reads)
+        flt = dict(min_mapq=20, min_read_length=10, divergence=0.5)
+        for rid in (0, 1):
+            keep = [r for r in recs if r["ref_id"] == rid and bamio.passes_filter(r, **flt)]
+            s, e = nb.spans(rid, **flt)
+            assert np.array_equal(s, [r["pos"] for r in keep]) and np.array_equal(e, [r["pos"] + max(r["ref_len"], 1) for r in keep])
+            regions = [(90, 100), (190, 400), (590, 200)] if rid == 0 else [(0, 900)]
+            wins = [np.full(l, ord("A"), np.uint8) for _, l in regions]
+            a, b = bamio.build_batch(keep, regions, wins), nb.batch(rid, regions, wins, **flt)
+            same_batch(a, b)
+            if rid == 0:
+                assert a.names == ["r1", "r2", "r3", "r3", "r3", "r4_nocigar", "r5"]   # r3's intron spans the middle window
+                assert list(b.lead_clip[:2]) == [5, 0] and list(b.trail_clip[:2]) == [4, 0]
+                assert list(b.flags) == [2, 1 | 4, 0, 0, 0, 0, 0]
+        nb.close()
+
+
+def test_bad_inputs_are_errors_not_crashes(tmp_path):
+    with pytest.raises(_lib.LcrError, match="cannot open"):
+        bamio.NativeBam(str(tmp_path / "missing.bam"))
+    p = str(tmp_path / "garbage.bam")
+    open(p, "wb").write(b"this is not a BGZF file at all, not even close......")
+    with pytest.raises(_lib.LcrError, match="BGZF"):
+        bamio.NativeBam(p)
+    raw = bam_bytes([("c", 100)], [dict(ref=0, pos=1, name="x", cigar="10M", seq="A" * 10)])
+    good = bgzf(raw, 64)
+    p = str(tmp_path / "trunc.bam")
+    open(p, "wb").write(good[:len(good) // 2])
+    with pytest.raises(_lib.LcrError):
+        bamio.NativeBam(p)
+    corrupt = bytearray(good)
+    corrupt[40] ^= 0xFF   # inside the first block's deflate data
+    p = str(tmp_path / "crc.bam")
+    open(p, "wb").write(bytes(corrupt))
+    with pytest.raises(_lib.LcrError):
+        bamio.NativeBam(p)
+    p = str(tmp_path / "notbam.bam")
+    open(p, "wb").write(bgzf(b"SAM\1" + b"\0" * 40, 64))
+    with pytest.raises(_lib.LcrError, match="not a BAM"):
+        bamio.NativeBam(p)
+    # unsorted file: refused when a batch is cut (the reference needs a sorted, indexed file as well)
+    raw = bam_bytes([("c", 1000)], [dict(ref=0, pos=50, name="a", cigar="10M", seq="A" * 10), dict(ref=0, pos=10, name="b", cigar="10M", seq="A" * 10)])
+    p = str(tmp_path / "unsorted.bam")
+    open(p, "wb").write(bgzf(raw, 64))
+    nb = bamio.NativeBam(p)
+    with pytest.raises(_lib.LcrError, match="sorted"):
+        nb.batch(0, [(0, 100)], [np.zeros(100, np.uint8)], min_mapq=0, min_read_length=1, divergence=1.0)

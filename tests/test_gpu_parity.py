@@ -352,6 +352,27 @@ def test_deep_region_beyond_the_lds_images(engine_cls, orc):
     full_check(engine_cls, orc, b, _abi.make_params("ont-cdna", seed=9))
 
 
+def test_bam_file_to_vcf_through_the_native_decoder(engine_cls, orc):
+    """The caller's side of the path, end to end: liblcr's BAM decoder (N1) -> GPU region discovery (N3) -> batch ->
+    pileup / candidates / fragments / phase, against the oracle on the batch the Python reader builds."""
+    import os
+    from longcallr_amd import bamio
+    nb = bamio.NativeBam(os.path.join(helpers.GOLDEN, "demo.bam"), 4)
+    rid = [n for n, _ in nb.refs].index("chr20")
+    p = _abi.make_params("hifi-masseq")
+    E = engine_cls(0, p)
+    rs, re_ = nb.spans(rid, **_abi.READ_FILTER)
+    regions = E.discover_regions(rs, re_, nb.refs[rid][1])
+    assert regions == [(16729960, 13256, 1649)]
+    E.close()
+    b = nb.batch(rid, [(s, l) for s, l, _ in regions], [helpers.load_pseudo_ref()], **_abi.READ_FILTER)
+    ref_b = helpers.demo_batch()
+    for f in _abi.ReadBatch.FIELDS + ["start0", "len", "read_begin", "ref"]:
+        assert np.array_equal(getattr(b, f), getattr(ref_b, f)), f
+    c = full_check(engine_cls, orc, b, p, "chr20")
+    assert len(c) == 19
+
+
 def test_empty_batch_and_errors(engine_cls):
     from longcallr_amd.api import LcrError
     p = _abi.make_params()
