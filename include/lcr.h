@@ -263,6 +263,19 @@ int lcr_bam_batch(lcr_bam*, int32_t ref_id, const lcr_read_filter*, int32_t n_re
                   const int32_t* len, lcr_reads* reads, const int32_t** read_begin, const uint64_t** name_off,
                   const char** names);
 
+/* ---- phased BAM, replaces thread.rs:307-361 ------------------------------------------------
+ * Writes to out_path the header of the opened file and, region by region in the order given (region i = columns
+ * [start0[i], start0[i] + len[i]) of contig region_ref[i]), the records the reference's loop keeps: fetched by the
+ * region (util.rs:637 rule), not unmapped / secondary / supplementary, and lying inside the region
+ * (reference_start + 1 >= start && reference_end + 1 <= end, thread.rs:340-345).  A record whose name is among the
+ * n_tagged names gets `HP:i:<hp>` (int32) appended when hp is 1 or 2 and `PS:I:<ps>` (uint32) when ps != 0, unless
+ * it already carries that tag; of several entries with one name the first counts (hp < 0: no assignment entry,
+ * thread.rs:308-325).  BGZF blocks of 0xff00 bytes are deflated on n_threads threads (<= 0: as lcr_bam_open) at
+ * `level` (-1 = zlib default, as the reference's writer).  Parity is defined on the inflated stream. */
+int lcr_bam_write_phased(lcr_bam*, const char* out_path, int32_t n_regions, const int32_t* region_ref, const int64_t* start0,
+                         const int32_t* len, int64_t n_tagged, const uint64_t* name_off, const char* names, const int32_t* hp,
+                         const uint32_t* ps, int32_t level, int32_t n_threads);
+
 /* Timing: HIP-event time (ms) of the last launch of each kernel on the ctx's stream. */
 enum { LCR_K_SPANS = 0 /* K0: CIGAR decode + binning */, LCR_K_PILEUP, LCR_K_CAND_FILTER, LCR_K_CAND_HIST, LCR_K_CAND_GT,
        LCR_K_FRAG_COUNT, LCR_K_FRAG_FILL, LCR_K_PHASE, LCR_NKERNELS };

@@ -73,8 +73,10 @@ def _aux_scan(buf, p, end):
     return de, ts
 
 
-def read_bam(path):
-    """Decode a BAM file. Returns (refs [(name, length)], records list of dicts) in file order."""
+def read_bam(path, keep_raw=False):
+    """Decode a BAM file. Returns (refs [(name, length)], records list of dicts) in file order; with keep_raw every
+    record also carries its bytes (`raw`, without block_size), the offset of its aux block (`aux_off`) and the
+    first record carries the inflated header bytes (`header`)."""
     buf = bgzf_decompress(path)
     if buf[:4] != b"BAM\x01":
         raise ValueError("not a BAM file")
@@ -90,6 +92,7 @@ def read_bam(path):
         refs.append((name, l_ref))
         p += 8 + l_name
     recs = []
+    header_end = p
     while p < len(buf):
         (bs, ref_id, pos, l_rn, mapq, _bin, n_cig, flag, l_seq, _nr, _np, _tl) = struct.unpack_from(
             "<iiiBBHHHiiii", buf, p)
@@ -122,6 +125,11 @@ def read_bam(path):
         recs.append(dict(name=name, ref_id=ref_id, pos=pos, mapq=mapq, flag=flag, l_seq=l_seq,
                          cigar=cigar, seq=seq, qual=qual, de=de, ts=ts, ref_len=ref_len,
                          lead=lead, trail=trail))
+        if keep_raw:
+            recs[-1]["raw"] = bytes(buf[p + 4:p + 4 + bs])
+            recs[-1]["aux_off"] = q - (p + 4)
+            if len(recs) == 1:
+                recs[-1]["header"] = bytes(buf[:header_end])
         p += 4 + bs
     return refs, recs
 
@@ -207,6 +215,58 @@ def build_batch(recs, regions, ref_windows):
         ref=cat(list(ref_windows), np.uint8), names=names, **cols)
 
 
+def phased_stream(recs, regions, names, hp, ps):
+    """Record-by-record restatement of thread.rs:307-361 on read_bam(keep_raw=True) records: the inflated bytes of
+    the phased BAM (header + kept records with HP:i / PS:I appended).  regions = [(ref_id, start0, len)]."""
+    m_hp, m_ps = {}, {}
+    for n, h, p in zip(names, hp, ps):
+        if h >= 0 and n not in m_hp:
+            m_hp[n] = int(h)
+        if p != 0 and n not in m_ps:
+            m_ps[n] = int(p)
+
+    def has_tag(raw, q, tag):
+        while q + 3 <= len(raw):
+            if raw[q:q + 2] == tag:
+                return True
+            typ = chr(raw[q + 2])
+            q += 3
+            if typ in "AcC":
+                q += 1
+            elif typ in "sS":
+                q += 2
+            elif typ in "iIf":
+                q += 4
+            elif typ in "ZH":
+                q = raw.index(b"\0", q) + 1
+            elif typ == "B":
+                sub, cnt = chr(raw[q]), struct.unpack_from("<I", raw, q + 1)[0]
+                q += 5 + cnt * {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[sub]
+            else:
+                raise ValueError("bad aux type")
+        return False
+    out = [recs[0]["header"]] if recs else []
+    for ref_id, start0, length in regions:
+        beg, end = start0 + 1, start0 + length + 1
+        for r in recs:
+            rend = r["pos"] + (r["ref_len"] if r["ref_len"] > 0 else 1)
+            if r["ref_id"] != ref_id or not (r["pos"] < end and rend > beg):
+                continue
+            if r["flag"] & (0x4 | 0x100 | 0x800):
+                continue
+            if r["pos"] + 1 < beg or rend + 1 > end:
+                continue
+            raw = r["raw"]
+            h = m_hp.get(r["name"])
+            if h is not None and h != 0 and not has_tag(raw, r["aux_off"], b"HP"):
+                raw = raw + b"HPi" + struct.pack("<i", h)
+            p = m_ps.get(r["name"])
+            if p is not None and not has_tag(r["raw"], r["aux_off"], b"PS"):
+                raw = raw + b"PSI" + struct.pack("<I", p)
+            out.append(struct.pack("<i", len(raw)) + raw)
+    return b"".join(out)
+
+
 class NativeBam:
     """liblcr's BAM decoder (lcr_bam_* in include/lcr.h): one parallel inflate + record index per file, batches
     for `Engine.load_batch` cut out of it.  Mirrors read_bam / passes_filter / build_batch above."""
@@ -274,6 +334,25 @@ class NativeBam:
         read_begin = np.ctypeslib.as_array(rb, (len(regions) + 1,)).copy()
         cat = np.concatenate([np.asarray(w, np.uint8) for w in ref_windows]) if len(ref_windows) else np.zeros(0, np.uint8)
         return ReadBatch(start0=start0, len=length, read_begin=read_begin, ref=cat, names=nm, **kw)
+
+    def write_phased(self, out_path, regions, names, hp, ps, level=-1, threads=0):
+        """thread.rs:307-361: regions = [(ref_id, start0, len)] in output order; names / hp / ps = the read
+        assignment and phase-set entries in queue order (hp < 0: no assignment entry, ps == 0: no phase set)."""
+        C = self._C
+        ref = np.ascontiguousarray([r for r, _, _ in regions], dtype=np.int32)
+        start0 = np.ascontiguousarray([s for _, s, _ in regions], dtype=np.int64)
+        length = np.ascontiguousarray([l for _, _, l in regions], dtype=np.int32)
+        enc = [n.encode() + b"\0" for n in names]
+        off = np.zeros(len(enc) + 1, dtype=np.uint64)
+        if enc:
+            off[1:] = np.cumsum([len(e) for e in enc])
+        blob = b"".join(enc)
+        hp = np.ascontiguousarray(hp, dtype=np.int32)
+        ps = np.ascontiguousarray(ps, dtype=np.uint32)
+        assert hp.size == ps.size == len(enc)
+        self._chk(self._l.lcr_bam_write_phased(self._h, os.fsencode(out_path), len(regions), ref.ctypes.data, start0.ctypes.data,
+                                               length.ctypes.data, len(enc), off.ctypes.data, blob, hp.ctypes.data, ps.ctypes.data,
+                                               level, threads))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -29,6 +29,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -78,6 +79,7 @@ struct lcr_bam {
   std::vector<const char*> ref_name_ptrs;
   std::vector<int64_t> ref_len;
   std::vector<Rec> recs;
+  size_t header_size = 0;   // inflated bytes before the first record (magic, text, reference table)
   // results of the last lcr_bam_spans / lcr_bam_batch call
   std::vector<int32_t> sp_start, sp_end;
   std::vector<int32_t> b_pos, b_seq_len, b_lead, b_trail, b_read_begin;
@@ -130,6 +132,29 @@ bool aux_scan(const uint8_t* p, const uint8_t* end, Rec& r) {
     if (p > end) return false;
   }
   return true;
+}
+
+// true iff the aux block [p, end) holds a field with this two-letter tag (bam_aux_get)
+bool aux_has(const uint8_t* p, const uint8_t* end, char a, char c) {
+  while (p + 3 <= end) {
+    if (p[0] == (uint8_t)a && p[1] == (uint8_t)c) return true;
+    const uint8_t typ = p[2];
+    p += 3;
+    switch (typ) {
+      case 'A': case 'c': case 'C': p += 1; break;
+      case 's': case 'S': p += 2; break;
+      case 'i': case 'I': case 'f': p += 4; break;
+      case 'Z': case 'H': while (p < end && *p) p++; p++; break;
+      case 'B': {
+        if (p + 5 > end) return false;
+        const uint8_t sub = p[0]; const uint32_t cnt = rd32(p + 1);
+        const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+        p += 5 + (size_t)cnt * w; break;
+      }
+      default: return false;
+    }
+  }
+  return false;
 }
 
 int fail(lcr_bam* b, int code, const std::string& msg) { b->err = msg; return code; }
@@ -224,6 +249,7 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
     p += 8 + l_name;
   }
   for (auto& s : b->ref_names) b->ref_name_ptrs.push_back(s.c_str());
+  b->header_size = p;
   // ---- record index: the block_size chain is sequential, the records' fields are not
   while (p < n) {
     if (p + 4 > n) return fail(b, LCR_E_ARG, "truncated record header");
@@ -358,6 +384,123 @@ int lcr_bam_batch(lcr_bam* b, int32_t ref_id, const lcr_read_filter* f, int32_t 
   *read_begin = b->b_read_begin.data();
   if (name_off) *name_off = b->b_name_off.data();
   if (names) *names = b->b_names.data();
+  return LCR_OK;
+}
+
+
+// ---- phased BAM (thread.rs:307-361) ---------------------------------------------------------
+int lcr_bam_write_phased(lcr_bam* b, const char* out_path, int32_t n_regions, const int32_t* region_ref, const int64_t* start0,
+                         const int32_t* len, int64_t n_tagged, const uint64_t* name_off, const char* names, const int32_t* hp,
+                         const uint32_t* ps, int32_t level, int32_t n_threads) {
+  if (!b || !out_path || n_regions < 0 || n_tagged < 0 || (n_regions && (!region_ref || !start0 || !len)) ||
+      (n_tagged && (!name_off || !names || !hp || !ps)) || level < -1 || level > 9)
+    return LCR_E_ARG;
+  if (n_threads < 1) n_threads = b->n_threads;
+  // qname -> HP / PS, first entry wins (thread.rs:308-325: the queues are drained in order; a read of two regions
+  // keeps what its first region said).  hp < 0: no assignment entry; ps == 0: no phase-set entry.
+  std::unordered_map<std::string, int32_t> m_hp;
+  std::unordered_map<std::string, uint32_t> m_ps;
+  for (int64_t i = 0; i < n_tagged; i++) {
+    const std::string nm(names + name_off[i]);
+    if (hp[i] >= 0) m_hp.emplace(nm, hp[i]);
+    if (ps[i] != 0) m_ps.emplace(nm, ps[i]);
+  }
+  // records per contig by position with a running maximum of their ends (all records: the writer's fetch has no
+  // mapq / length filter, thread.rs:337-340)
+  const uint8_t* d = b->data.get();
+  struct Out { uint32_t rec; int32_t hp; uint32_t ps; uint8_t add_hp, add_ps; uint64_t at; };
+  std::vector<Out> outs;
+  std::vector<uint32_t> idx;
+  std::vector<int32_t> ipos, iend_max;
+  int32_t cur_ref = INT32_MIN;
+  for (int32_t g = 0; g < n_regions; g++) {
+    if (len[g] < 0) return fail(b, LCR_E_ARG, "negative region length");
+    if (region_ref[g] != cur_ref) {
+      cur_ref = region_ref[g];
+      idx.clear(); ipos.clear(); iend_max.clear();
+      int32_t run = INT32_MIN;
+      for (size_t i = 0; i < b->recs.size(); i++) {
+        const Rec& r = b->recs[i];
+        if (r.ref_id != cur_ref) continue;
+        if (!ipos.empty() && r.pos < ipos.back()) return fail(b, LCR_E_ARG, "BAM is not coordinate-sorted");
+        idx.push_back((uint32_t)i); ipos.push_back(r.pos);
+        run = std::max(run, end_pos(r)); iend_max.push_back(run);
+      }
+    }
+    const int64_t beg = start0[g] + 1, end = start0[g] + len[g] + 1;   // fetch((chr, start, end)), thread.rs:332-334
+    const size_t hi = (size_t)(std::lower_bound(ipos.begin(), ipos.end(), end, [](int32_t v, int64_t e) { return (int64_t)v < e; }) - ipos.begin());
+    size_t lo = (size_t)(std::upper_bound(iend_max.begin(), iend_max.end(), beg, [](int64_t bg, int32_t v) { return bg < (int64_t)v; }) - iend_max.begin());
+    for (; lo < hi; lo++) {
+      const Rec& r = b->recs[idx[lo]];
+      if ((int64_t)end_pos(r) <= beg) continue;
+      if (r.flag & (0x4 | 0x100 | 0x800)) continue;                                      // thread.rs:337-339
+      // reference_start + 1 < region.start || reference_end + 1 > region.end -> skipped (thread.rs:340-345);
+      // reference_end is htslib's bam_endpos
+      if ((int64_t)r.pos + 1 < beg || (int64_t)end_pos(r) + 1 > end) continue;
+      Out o{idx[lo], 0, 0, 0, 0, 0};
+      const uint8_t* q = d + r.off;
+      const std::string nm(reinterpret_cast<const char*>(q + 32));
+      const uint64_t fixed = 32ull + r.l_rn + 4ull * r.n_cig + (uint64_t)((r.l_seq + 1) / 2) + (uint64_t)r.l_seq;
+      auto fh = m_hp.find(nm);
+      if (fh != m_hp.end() && fh->second != 0 && !aux_has(q + fixed, q + r.size, 'H', 'P')) { o.add_hp = 1; o.hp = fh->second; }   // thread.rs:347-352
+      auto fp = m_ps.find(nm);
+      if (fp != m_ps.end() && !aux_has(q + fixed, q + r.size, 'P', 'S')) { o.add_ps = 1; o.ps = fp->second; }                         // thread.rs:353-356
+      outs.push_back(o);
+    }
+  }
+  // ---- payload: header as in the input, then the records with HP:i (int32) / PS:I (uint32) appended to the aux block
+  uint64_t total = b->header_size;
+  for (Out& o : outs) { o.at = total; total += 4ull + b->recs[o.rec].size + 7ull * o.add_hp + 7ull * o.add_ps; }
+  std::unique_ptr<uint8_t[]> pay(new (std::nothrow) uint8_t[(size_t)total + 1]);
+  if (!pay) return fail(b, LCR_E_NOMEM, "out of memory for the output stream");
+  memcpy(pay.get(), d, b->header_size);
+  parallel_for((int64_t)outs.size(), n_threads, 512, [&](int64_t i) {
+    const Out& o = outs[(size_t)i];
+    const Rec& r = b->recs[o.rec];
+    uint8_t* w = pay.get() + o.at;
+    const uint32_t bs = r.size + 7u * o.add_hp + 7u * o.add_ps;
+    w[0] = (uint8_t)bs; w[1] = (uint8_t)(bs >> 8); w[2] = (uint8_t)(bs >> 16); w[3] = (uint8_t)(bs >> 24);
+    memcpy(w + 4, d + r.off, r.size);
+    w += 4 + r.size;
+    if (o.add_hp) { w[0] = 'H'; w[1] = 'P'; w[2] = 'i'; const uint32_t v = (uint32_t)o.hp; w[3] = (uint8_t)v; w[4] = (uint8_t)(v >> 8); w[5] = (uint8_t)(v >> 16); w[6] = (uint8_t)(v >> 24); w += 7; }
+    if (o.add_ps) { w[0] = 'P'; w[1] = 'S'; w[2] = 'I'; const uint32_t v = o.ps; w[3] = (uint8_t)v; w[4] = (uint8_t)(v >> 8); w[5] = (uint8_t)(v >> 16); w[6] = (uint8_t)(v >> 24); }
+  });
+  // ---- BGZF: 0xff00-byte blocks (htslib's BGZF_BLOCK_SIZE), deflated in parallel, then the empty EOF block
+  const uint64_t BLK = 0xff00;
+  const size_t nblk = (size_t)((total + BLK - 1) / BLK);
+  std::vector<std::vector<uint8_t>> comp(nblk + 1);
+  std::atomic<int> bad{0};
+  parallel_for((int64_t)nblk + 1, n_threads, 4, [&](int64_t i) {
+    const uint64_t off = (uint64_t)i * BLK;
+    const uint32_t n = (size_t)i == nblk ? 0u : (uint32_t)std::min<uint64_t>(BLK, total - off);
+    std::vector<uint8_t>& c = comp[(size_t)i];
+    c.resize(18 + compressBound(n) + 8);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad.store(1); return; }
+    zs.next_in = pay.get() + off; zs.avail_in = n;
+    zs.next_out = c.data() + 18; zs.avail_out = (uInt)(c.size() - 18 - 8);
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END || 18 + clen + 8 > 65536) { bad.store(1); return; }
+    static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    memcpy(c.data(), head, 16);
+    const uint32_t bsize = (uint32_t)(18 + clen + 8 - 1);
+    c[16] = (uint8_t)bsize; c[17] = (uint8_t)(bsize >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), pay.get() + off, n);
+    uint8_t* t = c.data() + 18 + clen;
+    t[0] = (uint8_t)crc; t[1] = (uint8_t)(crc >> 8); t[2] = (uint8_t)(crc >> 16); t[3] = (uint8_t)(crc >> 24);
+    t[4] = (uint8_t)n; t[5] = (uint8_t)(n >> 8); t[6] = (uint8_t)(n >> 16); t[7] = (uint8_t)(n >> 24);
+    c.resize(18 + clen + 8);
+  });
+  if (bad.load()) return fail(b, LCR_E_ARG, "deflate failed");
+  FILE* f = fopen(out_path, "wb");
+  if (!f) return fail(b, LCR_E_ARG, std::string("cannot create ") + out_path);
+  bool ok = true;
+  for (auto& c : comp) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) return fail(b, LCR_E_ARG, std::string("write failed: ") + out_path);
   return LCR_OK;
 }
 

@@ -161,3 +161,59 @@ def test_bad_inputs_are_errors_not_crashes(tmp_path):
     nb = bamio.NativeBam(p)
     with pytest.raises(_lib.LcrError, match="sorted"):
         nb.batch(0, [(0, 100)], [np.zeros(100, np.uint8)], min_mapq=0, min_read_length=1, divergence=1.0)
+
+
+def test_phased_bam_writer(tmp_path):
+    """SURVEY §8(f) N4 (thread.rs:307-361): lcr_bam_write_phased against the record-by-record restatement, on the
+    inflated stream; the output is a valid BAM again (both readers take it)."""
+    f32 = lambda v: struct.pack("<f", v)
+    reads = [
+        dict(ref=0, pos=100, name="inside_hp1", cigar="30M", seq="A" * 30),
+        dict(ref=0, pos=101, name="inside_hp0", cigar="30M", seq="A" * 30, aux=b"NMi" + struct.pack("<i", 1)),
+        dict(ref=0, pos=102, name="has_hp_already", cigar="30M", seq="A" * 30, aux=b"HPi" + struct.pack("<i", 2) + b"xyZabc\0"),
+        dict(ref=0, pos=103, name="has_ps_already", cigar="30M", seq="A" * 30, aux=b"abBc" + struct.pack("<I", 2) + b"\1\2" + b"PSI" + struct.pack("<I", 7)),
+        dict(ref=0, pos=104, name="secondary", cigar="30M", seq="A" * 30, flag=256),
+        dict(ref=0, pos=105, name="low_mapq_is_written_too", cigar="30M", seq="A" * 30, mapq=0),
+        dict(ref=0, pos=106, name="not_in_maps", cigar="30M", seq="A" * 30),
+        dict(ref=0, pos=180, name="sticks_out_right", cigar="30M", seq="A" * 30),       # ends beyond the region
+        dict(ref=0, pos=199, name="ends_exactly", cigar="1M", seq="A"),                  # reference_end + 1 == region.end
+        dict(ref=0, pos=300, name="second_region", cigar="10M5D10M", seq="C" * 20),
+        dict(ref=0, pos=300, name="inside_hp1", cigar="20M", seq="C" * 20),              # same name again: first entry counts
+        dict(ref=1, pos=10, name="other_contig", cigar="25M", seq="G" * 25, aux=b"def" + f32(0.2)),
+    ]
+    refs = [("chrA", 5000), ("chrB", 900)]
+    src = str(tmp_path / "in.bam")
+    open(src, "wb").write(bgzf(bam_bytes(refs, reads), 120))
+    regions = [(0, 99, 101), (0, 290, 100), (1, 0, 900), (0, 99, 101)]   # the last repeats the first: written again, as the loop would
+    names = ["inside_hp1", "inside_hp0", "has_hp_already", "has_ps_already", "secondary", "low_mapq_is_written_too",
+             "sticks_out_right", "ends_exactly", "second_region", "inside_hp1", "other_contig", "no_such_read"]
+    hp = [1, 0, 1, 2, 1, 2, 1, -1, 2, 2, 1, 1]
+    ps = [101, 0, 101, 101, 101, 0, 101, 200, 301, 999, 11, 5]
+    _, recs = bamio.read_bam(src, keep_raw=True)
+    want = bamio.phased_stream(recs, regions, names, hp, ps)
+    nb = bamio.NativeBam(src, 2)
+    for level, threads in ((-1, 1), (1, 4)):
+        out = str(tmp_path / ("out%d.bam" % threads))
+        nb.write_phased(out, regions, names, hp, ps, level=level, threads=threads)
+        assert bamio.bgzf_decompress(out) == want
+        assert open(out, "rb").read()[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")   # BGZF EOF marker
+        prefs, precs = bamio.read_bam(out)
+        nb2 = bamio.NativeBam(out, 2)
+        assert prefs == nb2.refs == refs and nb2.n_records == len(precs)
+        got = [r["name"] for r in precs]
+        assert got == ["inside_hp1", "inside_hp0", "has_hp_already", "has_ps_already", "low_mapq_is_written_too", "not_in_maps", "ends_exactly",
+                       "second_region", "inside_hp1", "other_contig",
+                       "inside_hp1", "inside_hp0", "has_hp_already", "has_ps_already", "low_mapq_is_written_too", "not_in_maps", "ends_exactly"]
+        nb2.close()
+    # demo.bam with made-up tags for every third read
+    refs, recs = bamio.read_bam(DEMO, keep_raw=True)
+    keep = [r for r in recs if bamio.passes_filter(r, **_abi.READ_FILTER)]
+    rid = keep[0]["ref_id"]
+    (start0, length, _), = bamio.discover_regions(keep, rid, refs[rid][1])
+    names = [r["name"] for r in keep[::3]]
+    hp = [(i % 3) for i in range(len(names))]
+    ps = [(start0 + 1 if i % 2 else 0) for i in range(len(names))]
+    nb = bamio.NativeBam(DEMO, 4)
+    out = str(tmp_path / "demo_phased.bam")
+    nb.write_phased(out, [(rid, start0, length)], names, hp, ps)
+    assert bamio.bgzf_decompress(out) == bamio.phased_stream(recs, [(rid, start0, length)], names, hp, ps)

@@ -373,6 +373,40 @@ def test_bam_file_to_vcf_through_the_native_decoder(engine_cls, orc):
     assert len(c) == 19
 
 
+def test_phased_bam_from_the_gpu_results(engine_cls, tmp_path):
+    """N4 end to end: demo.bam -> pipeline -> lcr_bam_write_phased; every written record carries exactly the HP / PS
+    the phase stage gave its read (thread.rs:204-221, 346-357)."""
+    import os
+    import struct
+    from longcallr_amd import bamio
+    src = os.path.join(helpers.GOLDEN, "demo.bam")
+    nb = bamio.NativeBam(src, 4)
+    b = helpers.demo_batch()
+    E = engine_cls(0, _abi.make_params("hifi-masseq"))
+    E.load_batch(b).run_all()
+    fm, pr = E.fragmat(), E.phase_result()
+    names = [b.names[r] for r in fm["row_read"]]
+    asg, ps = pr["assignment"].astype(np.int32), pr["phase_set"]
+    hp = np.where((fm["row_for_phasing"] != 0) | (asg != 0), asg, -1)
+    assert (asg != 0).sum() > 500 and (ps != 0).sum() > 500
+    rid = [n for n, _ in nb.refs].index("chr20")
+    out = str(tmp_path / "phased.bam")
+    nb.write_phased(out, [(rid, int(b.start0[0]), int(b.len[0]))], names, hp, ps)
+    _, recs = bamio.read_bam(out, keep_raw=True)
+    want_hp = {n: int(h) for n, h in zip(names, hp) if h > 0}
+    want_ps = {n: int(p) for n, p in zip(names, ps) if p != 0}
+    seen = 0
+    for r in recs:
+        tail = r["raw"][-14:]
+        got_ps = struct.unpack("<I", tail[-4:])[0] if tail[-7:-4] == b"PSI" else None
+        rest = tail[:-7] if got_ps is not None else tail
+        got_hp = struct.unpack("<i", rest[-4:])[0] if rest[-7:-4] == b"HPi" else None
+        assert got_hp == want_hp.get(r["name"]) and got_ps == want_ps.get(r["name"]), r["name"]
+        seen += got_hp is not None
+    assert seen == len(want_hp) and len(recs) >= len(names)
+    E.close()
+
+
 def test_empty_batch_and_errors(engine_cls):
     from longcallr_amd.api import LcrError
     p = _abi.make_params()
