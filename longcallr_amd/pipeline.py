@@ -1,0 +1,133 @@
+"""The driver loop around the hot path: BAM + reference FASTA -> phased VCF (+ phased BAM).
+
+Host orchestration only; the work is done behind the C ABI (include/lcr.h).  It replaces what
+`multithread_phase_haplotag_germline` (reference src/thread.rs:26-361) and its callers in src/main.rs do around
+the five hot-path calls, with one context per GPU instead of one rayon task per region:
+
+  util.rs:214-234 load_reference / parse_fai                 -> load_reference / parse_fai below
+  util.rs:558-600 extract_isolated_regions_parallel          -> lcr_bam_spans + lcr_discover_regions per contig
+  thread.rs:77-221 the per-region closure                    -> one lcr_load_batch + pileup / candidates /
+                                                                fragments / phase per contig (all its regions)
+  thread.rs:223-305 VCF header + records                     -> write_vcf (records from vcf.format_records)
+  thread.rs:307-361 phased BAM                               -> lcr_bam_write_phased
+
+Not here (out of scope): gene annotation / exon filter, external VCF candidates, down-sampling,
+region truncation, the somatic model.  Records are written in contig order of the .fai and position order inside
+a contig (the reference writes them in region-completion order, thread.rs:216-221: compare as a set)."""
+import os
+
+import numpy as np
+
+from . import _abi, api, bamio, vcf
+
+VCF_HEADER_TAIL = (   # thread.rs:232-262, verbatim
+    '##FILTER=<ID=PASS,Description="All filters passed">\n'
+    '##FILTER=<ID=LowQual,Description="Low phasing quality">\n'
+    '##FILTER=<ID=HomRef,Description="Homo reference">\n'
+    '##FILTER=<ID=RnaEdit,Description="RNA editing">\n'
+    '##FILTER=<ID=Multiallelic,Description="Multiallelic SNP">\n'
+    '##FILTER=<ID=dn,Description="Dense cluster of variants">\n'
+    '##INFO=<ID=RDS,Number=1,Type=String,Description="RNA editing or Dense SNP or Single SNP.">\n'
+    '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n'
+    '##FORMAT=<ID=PS,Number=1,Type=Integer,Description="Phase Set">\n'
+    '##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="Genotype Quality">\n'
+    '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="Read Depth">\n'
+    '##FORMAT=<ID=AF,Number=A,Type=Float,Description="Allele Frequency">\n'
+    '##FORMAT=<ID=PQ,Number=1,Type=Float,Description="Phasing Quality">\n'
+    '##FORMAT=<ID=AE,Number=A,Type=Integer,Description="Haplotype expression of two alleles">\n'
+    '##FORMAT=<ID=SQ,Number=1,Type=Float,Description="Somatic Score">\n'
+    "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSample\n")
+
+
+def load_reference(path):
+    """util.rs:214-222: record id (first word of the '>' line) -> sequence bytes, case preserved."""
+    seqs, name, parts = {}, None, []
+    with open(path, "rb") as f:
+        for line in f:
+            if line.startswith(b">"):
+                if name is not None:
+                    seqs[name] = np.frombuffer(b"".join(parts), dtype=np.uint8)
+                name, parts = line[1:].split()[0].decode(), []
+            else:
+                parts.append(line.strip())
+    if name is not None:
+        seqs[name] = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    return seqs
+
+
+def parse_fai(path):
+    """util.rs:224-234: [(contig, length)] in file order."""
+    out = []
+    with open(path) as f:
+        for line in f:
+            p = line.rstrip("\n").split("\t")
+            if len(p) >= 2:
+                out.append((p[0], int(p[1])))
+    return out
+
+
+def write_vcf(path, contig_lengths, body_lines):
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.3\n")
+        for name, length in contig_lengths:   # thread.rs:225-230
+            f.write("##contig=<ID=%s,length=%d>\n" % (name, length))
+        f.write(VCF_HEADER_TAIL)
+        f.writelines(body_lines)
+
+
+def run(bam_path, ref_path, out_vcf, out_bam=None, preset="hifi-masseq", contigs=None, device=0, threads=0, seed=2025,
+        read_filter=None, **param_overrides):
+    """BAM + FASTA (+ .fai) -> phased VCF and, with out_bam, the phased BAM.  Returns a dict of counts."""
+    fai = ref_path + ".fai"
+    if not os.path.exists(fai):
+        raise FileNotFoundError("Reference index file .fai does not exist.")   # util.rs:575-577
+    contig_lengths = parse_fai(fai)
+    refs = load_reference(ref_path)
+    flt = dict(_abi.READ_FILTER)
+    flt.update(read_filter or {})
+    params = _abi.make_params(preset, seed=seed, **param_overrides)
+    nb = bamio.NativeBam(bam_path, threads)
+    bam_ids = {n: i for i, (n, _) in enumerate(nb.refs)}
+    E = api.Engine(device, params)
+    body, regions_out, names_out, hp_out, ps_out = [], [], [], [], []
+    stats = dict(contigs=0, regions=0, reads=0, candidates=0, vcf_records=0)
+    for name, length in contig_lengths:
+        if contigs is not None and name not in contigs:
+            continue
+        if name not in bam_ids or name not in refs:
+            continue
+        rid = bam_ids[name]
+        rs, re_ = nb.spans(rid, **flt)
+        if rs.size == 0:
+            continue
+        regions = E.discover_regions(rs, re_, length)     # util.rs:236-332
+        if not regions:
+            continue
+        ref = refs[name]
+        wins = [ref[s:s + l] if s + l <= ref.size else np.concatenate([ref[s:], np.full(s + l - ref.size, ord("N"), np.uint8)])
+                for s, l, _ in regions]
+        batch = nb.batch(rid, [(s, l) for s, l, _ in regions], wins, **flt)
+        E.load_batch(batch).run_all()
+        cands, off = E.candidates()
+        lines = vcf.format_records(cands, name, params.min_phase_score)
+        body.append(lines if isinstance(lines, str) else "".join(lines))
+        stats["contigs"] += 1; stats["regions"] += len(regions); stats["reads"] += batch.n_reads
+        stats["candidates"] += int(cands.size)
+        if out_bam is not None:
+            fm, pr = E.fragmat(), E.phase_result()
+            asg = pr["assignment"].astype(np.int32)
+            # thread.rs:204-214: every for_phasing fragment has an assignment entry (0 / 1 / 2), a phase set only if set
+            hp = np.where((fm["row_for_phasing"] != 0) | (asg != 0), asg, -1)
+            names_out.extend(batch.names[r] for r in fm["row_read"])
+            hp_out.append(hp); ps_out.append(pr["phase_set"])
+            regions_out.extend((rid, s, l) for s, l, _ in regions)
+    E.close()
+    text = "".join(body)
+    stats["vcf_records"] = text.count("\n")
+    write_vcf(out_vcf, contig_lengths, [text])
+    if out_bam is not None:
+        hp = np.concatenate(hp_out) if hp_out else np.zeros(0, np.int32)
+        ps = np.concatenate(ps_out) if ps_out else np.zeros(0, np.uint32)
+        nb.write_phased(out_bam, regions_out, names_out, hp, ps, threads=threads)
+    nb.close()
+    return stats

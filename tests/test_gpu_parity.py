@@ -407,6 +407,37 @@ def test_phased_bam_from_the_gpu_results(engine_cls, tmp_path):
     E.close()
 
 
+def test_driver_bam_and_fasta_to_vcf_and_phased_bam(engine_cls, orc, tmp_path):
+    """longcallr_amd.pipeline.run: the loop of thread.rs:26-361 around the hot path, files in, files out."""
+    import os
+    from longcallr_amd import bamio, pipeline
+    src = os.path.join(helpers.GOLDEN, "demo.bam")
+    refs, _ = bamio.read_bam(src)
+    b = helpers.demo_batch()
+    start0, length = int(b.start0[0]), int(b.len[0])
+    fa = str(tmp_path / "pseudo.fa")
+    with open(fa, "wb") as f, open(fa + ".fai", "w") as fi:   # chr20 = N everywhere but the demo window (pseudo-reference)
+        for name, ln in refs:
+            if name not in ("chr19", "chr20"):
+                continue
+            seq = np.full(ln, ord("N"), np.uint8)
+            if name == "chr20":
+                seq[start0:start0 + length] = helpers.load_pseudo_ref()
+            f.write(b">" + name.encode() + b" pseudo\n" + seq.tobytes() + b"\n")
+            fi.write("%s\t%d\t0\t%d\t%d\n" % (name, ln, ln, ln + 1))
+    out_vcf, out_bam = str(tmp_path / "out.vcf"), str(tmp_path / "out.bam")
+    st = pipeline.run(src, fa, out_vcf, out_bam, preset="hifi-masseq", threads=4)
+    assert st["contigs"] == 1 and st["regions"] == 1 and st["reads"] == b.n_reads and st["candidates"] == 19
+    text = open(out_vcf).read()
+    head, body = text[:text.index("#CHROM")], text[text.index("#CHROM"):].split("\n", 1)[1]
+    assert head.startswith("##fileformat=VCFv4.3\n##contig=<ID=chr19,length=58617616>\n##contig=<ID=chr20,length=64444167>\n##FILTER=<ID=PASS")
+    p = _abi.make_params("hifi-masseq")
+    R = oracle_all(orc, b, p)[0]
+    assert body == R.vcf_text("chr20") and st["vcf_records"] == body.count("\n")
+    _, recs = bamio.read_bam(out_bam)
+    assert len(recs) >= b.n_reads and all(r["ref_id"] == [n for n, _ in refs].index("chr20") for r in recs)
+
+
 def test_empty_batch_and_errors(engine_cls):
     from longcallr_amd.api import LcrError
     p = _abi.make_params()
