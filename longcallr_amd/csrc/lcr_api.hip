@@ -215,8 +215,10 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
     HIPCHK(c, c->h_stage[0].reserve(tot + 16));
     HIPCHK(c, c->first_tile.reserve((ng + 1) * 4));
     uint8_t* st = c->h_stage[0].as<uint8_t>();
-    launch_k0_region_setup(rg->start0, rg->len, rg->col_off, rg->read_begin, ng, c->first_tile.as<int32_t>(), (int64_t*)st,
-                           (int32_t*)(st + o2), (int64_t*)(st + o1), (int32_t*)(st + o3), c->stream);
+    uint8_t* dst = nullptr;   // the pinned buffer as the device sees it
+    HIPCHK(c, hipHostGetDevicePointer((void**)&dst, st, 0));
+    launch_k0_region_setup(rg->start0, rg->len, rg->col_off, rg->read_begin, ng, c->first_tile.as<int32_t>(), (int64_t*)dst,
+                           (int32_t*)(dst + o2), (int64_t*)(dst + o1), (int32_t*)(dst + o3), c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     if (ng) { memcpy(c->h_start0.data(), st, ng * sizeof(int64_t)); memcpy(c->h_len.data(), st + o2, ng * sizeof(int32_t)); }
