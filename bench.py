@@ -10,7 +10,8 @@ span ranks, the only collective is the final gather of candidate records to rank
 Prints ONE JSON line on rank 0 (see the driver contract): value = candidate sites (pileup columns
 evaluated) per second, whole job, over the full step time; roofline = the pileup kernel's
 algorithmic bytes / its HIP-event time; cpu_baseline = the CPU oracle (a C++ restatement of the
-reference, NOT the Rust binary) timed on a bounded sample of the same workload, rank 0 only.
+reference, NOT the Rust binary) timed on a bounded sample of the same workload, rank 0 at N = 1 only.
+--inflight N: N contexts on N host threads keep N batches in flight per GPU (default 1).
 """
 import argparse
 import ctypes as C
@@ -306,7 +307,7 @@ def main():
                        "sites_per_sec_pileup_gt": cols / t_call, "phased_reads_per_sec": n_phased / t_phase,
                        "api_ms": api_ms, "kernel_ms": kms},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks of a node would sit idle behind it
             out["cpu_baseline"] = cpu_baseline(batch, params, a.cpu_budget)
         print(json.dumps(out))
     if dist is not None:
