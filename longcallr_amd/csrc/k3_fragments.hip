@@ -64,6 +64,10 @@ void launch_k3_region_entries(const int64_t* row_ptr, const int32_t* row_region_
 // Sixteen lanes per row (row16_walk_sites, lcr_dev.h): the region's candidates inside the read's reference
 // span are located against the CIGAR spread over the lanes; a row without such candidates never loads
 // its CIGAR.  No trimming here: the reference's fragment walk takes every aligned base.
+// The count pass keeps the first K3_INLINE entries of every row in a provisional per-row slot (most rows have
+// fewer: a read crosses a handful of candidates), so the second pass is a copy for those rows (k3_place) and
+// only longer rows are walked again (FILL: rows with more than K3_INLINE entries).
+#define K3_INLINE 16
 template <bool FILL>
 __global__ void __launch_bounds__(LCR_BLOCK)
 k3_walk(BatchView b, const ReadBin* __restrict__ rbin, const lcr_candidate* __restrict__ cand,
@@ -76,8 +80,12 @@ k3_walk(BatchView b, const ReadBin* __restrict__ rbin, const lcr_candidate* __re
   const int g = region_of_read(b, r);
   const int k = r - b.read_begin[g];
   const int row0 = row_region_off[g];
-  const bool live = r_ < b.n_reads && k < row_region_off[g + 1] - row0;
+  bool live = r_ < b.n_reads && k < row_region_off[g + 1] - row0;
   const int row = live ? row0 + k : 0;
+  if (FILL) {   // shorter rows were placed from their provisional slots: most waves have nothing left to do
+    live = live && row_cnt[row] > K3_INLINE;
+    if (!__any(live)) return;
+  }
   const int l16 = threadIdx.x & 15;
   const int c_lo = cand_region_off[g], c_hi = cand_region_off[g + 1];
   const ReadBin h = rbin[r];
@@ -86,7 +94,8 @@ k3_walk(BatchView b, const ReadBin* __restrict__ rbin, const lcr_candidate* __re
   const uint8_t* __restrict__ qual = b.quals + h.seq_off;
   int cnt = 0;
   uint32_t links = 0;
-  int64_t w = FILL ? row_ptr[row] : 0;
+  // FILL: final position of the row's entries; count pass: the row's provisional slot
+  int64_t w = FILL ? row_ptr[row] : (int64_t)row * K3_INLINE;
   const int rbase = threadIdx.x & 48;
   row16_walk_sites(b, live, h, b.read_rend[r], c_lo, c_hi,
     [&](int i) { return (int)(cand[i].pos - start0); },
@@ -102,31 +111,46 @@ k3_walk(BatchView b, const ReadBin* __restrict__ rbin, const lcr_candidate* __re
       }
       const unsigned int em = (unsigned int)(__ballot(p != 0) >> rbase) & 0xffffu;
       const unsigned int ph = (unsigned int)(__ballot(p != 0 && fphase) >> rbase) & 0xffffu;
-      if (FILL && p != 0) {
-        const int64_t at = w + __popc(em & ((1u << l16) - 1u));
-        const uint8_t bq = qual[qq] < 30 ? qual[qq] : 30;                              // fragment.rs:127-131
-        col[at] = idx;
-        val[at] = (uint8_t)(bq | (p == 1 ? 32 : 0) | (base_code(base) << 6));
+      if (p != 0) {
+        const int at = cnt + __popc(em & ((1u << l16) - 1u));
+        if (FILL || at < K3_INLINE) {
+          const uint8_t bq = qual[qq] < 30 ? qual[qq] : 30;                            // fragment.rs:127-131
+          col[w + at] = idx;
+          val[w + at] = (uint8_t)(bq | (p == 1 ? 32 : 0) | (base_code(base) << 6));
+        }
       }
-      w += __popc(em); cnt += __popc(em); links += __popc(ph);
+      cnt += __popc(em); links += __popc(ph);
     });
   if (!FILL && live && l16 == 0) { row_cnt[row] = cnt; row_links[row] = links; }
 }
 
+// rows with at most K3_INLINE entries: provisional slot -> final CSR position (one thread per row)
+__global__ void __launch_bounds__(LCR_BLOCK)
+k3_place(int32_t n_rows, const int32_t* __restrict__ row_cnt, const int64_t* __restrict__ row_ptr,
+         const int32_t* __restrict__ tmp_col, const uint8_t* __restrict__ tmp_val, int32_t* __restrict__ col, uint8_t* __restrict__ val) {
+  const int row = blockIdx.x * LCR_BLOCK + threadIdx.x;
+  if (row >= n_rows) return;
+  const int n = row_cnt[row];
+  if (n > K3_INLINE) return;
+  const int64_t at = row_ptr[row], from = (int64_t)row * K3_INLINE;
+  for (int e = 0; e < n; e++) { col[at + e] = tmp_col[from + e]; val[at + e] = tmp_val[from + e]; }
+}
+
 void launch_k3_count(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
-                     const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, uint32_t* row_links,
-                     hipStream_t s) {
+                     const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, uint32_t* row_links, int32_t* tmp_col,
+                     uint8_t* tmp_val, hipStream_t s) {
   if (n_rows == 0) return;
   const int per = LCR_BLOCK / 16;
   hipLaunchKernelGGL(k3_walk<false>, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, rbin, cand,
-                     cand_region_off, row_region_off, n_rows, row_cnt, row_links, (const int64_t*)nullptr,
-                     (int32_t*)nullptr, (uint8_t*)nullptr);
+                     cand_region_off, row_region_off, n_rows, row_cnt, row_links, (const int64_t*)nullptr, tmp_col, tmp_val);
 }
 void launch_k3_fill(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
-                    const int32_t* row_region_off, int32_t n_rows, const int64_t* row_ptr, int32_t* col, uint8_t* val,
-                    hipStream_t s) {
+                    const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, const int64_t* row_ptr, const int32_t* tmp_col,
+                    const uint8_t* tmp_val, int32_t* col, uint8_t* val, hipStream_t s) {
   if (n_rows == 0) return;
   const int per = LCR_BLOCK / 16;
+  hipLaunchKernelGGL(k3_place, dim3((n_rows + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, n_rows, row_cnt, row_ptr, tmp_col, tmp_val, col, val);
   hipLaunchKernelGGL(k3_walk<true>, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, rbin, cand,
-                     cand_region_off, row_region_off, n_rows, (int32_t*)nullptr, (uint32_t*)nullptr, row_ptr, col, val);
+                     cand_region_off, row_region_off, n_rows, row_cnt, (uint32_t*)nullptr, row_ptr, col, val);
 }
+int launch_k3_inline() { return K3_INLINE; }

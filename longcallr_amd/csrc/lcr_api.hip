@@ -33,7 +33,7 @@ struct lcr_ctx {
   float sor_thr = -1.f;
   HostBuf h_planes;
   HostBuf h_nnz;              // pinned: first entry of every region of the fragment matrix, [ng] = entry count (lcr_fragments -> frag_settle)
-  DevBuf region_e_off;
+  DevBuf region_e_off, frag_tmp_col, frag_tmp_val;
   hipEvent_t ev_nnz = nullptr;
   bool nnz_pending = false;
   HostBuf h_stage[4];   // pinned staging of lcr_candidates / lcr_fragments: survivor offsets, candidate records, keep flags, region rows
@@ -145,7 +145,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   for (auto& b : c->in_) b.release();
   DevBuf* bufs[] = {&c->rd_start, &c->rd_end, &c->rd_diff, &c->rd_ex, &c->rd_cnt, &c->rd_off, &c->rd_s, &c->rd_e, &c->rd_max,
                     &c->scan_tmp, &c->read_region, &c->read_bin, &c->read_rend, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, 
-                    &c->k0_tile_fill, &c->k0_items, &c->region_e_off, &c->ndiff, &c->nscan, &c->planes, &c->flags,
+                    &c->k0_tile_fill, &c->k0_items, &c->region_e_off, &c->frag_tmp_col, &c->frag_tmp_val, &c->ndiff, &c->nscan, &c->planes, &c->flags,
                     &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
                     &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
                     &c->row_links, &c->row_ptr, &c->col, &c->val};
@@ -459,11 +459,13 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   c->n_rows = c->h_row_region_off[ng];
   const int nrow = c->n_rows;
   HIPCHK(c, c->row_cnt.reserve(std::max(nrow, 1) * 4));   // (row_region_off is on the device since lcr_candidates)
+  HIPCHK(c, c->frag_tmp_col.reserve((size_t)std::max(nrow, 1) * launch_k3_inline() * 4));   // provisional entries of the count pass
+  HIPCHK(c, c->frag_tmp_val.reserve((size_t)std::max(nrow, 1) * launch_k3_inline()));
   HIPCHK(c, c->row_links.reserve(std::max(nrow, 1) * 4));
   HIPCHK(c, c->row_ptr.reserve((std::max(nrow, 1) + 1) * 8));
   { Timer t(c, LCR_K_FRAG_COUNT);
     launch_k3_count(c->bv, c->read_bin.as<ReadBin>(), c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nrow,
-                    c->row_cnt.as<int32_t>(), c->row_links.as<uint32_t>(), c->stream);
+                    c->row_cnt.as<int32_t>(), c->row_links.as<uint32_t>(), c->frag_tmp_col.as<int32_t>(), c->frag_tmp_val.as<uint8_t>(), c->stream);
     launch_scan_i32_to_i64(c->scan_tmp, c->row_cnt.as<int32_t>(), c->row_ptr.as<int64_t>(), nrow, c->stream); }
   // entries: at most rows x candidates per region.  When that bound is affordable the fill pass is queued right
   // behind the count pass and the true count is picked up later (frag_settle); otherwise wait for it first.
@@ -488,7 +490,8 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->val.reserve(std::max<int64_t>(cap, 1)));
   { Timer t(c, LCR_K_FRAG_FILL);
     launch_k3_fill(c->bv, c->read_bin.as<ReadBin>(), c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nrow,
-                   c->row_ptr.as<int64_t>(), c->col.as<int32_t>(), c->val.as<uint8_t>(), c->stream); }
+                   c->row_cnt.as<int32_t>(), c->row_ptr.as<int64_t>(), c->frag_tmp_col.as<int32_t>(), c->frag_tmp_val.as<uint8_t>(),
+                   c->col.as<int32_t>(), c->val.as<uint8_t>(), c->stream); }
   HIPCHK(c, hipGetLastError());
   c->have_frag = true;
   c->have_phase = false;

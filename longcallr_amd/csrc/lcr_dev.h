@@ -158,11 +158,12 @@ void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t*
 void launch_k3_row_offsets(const int32_t* region_rows, int32_t ng, int32_t* row_region_off, hipStream_t s);
 void launch_k3_region_entries(const int64_t* row_ptr, const int32_t* row_region_off, int32_t ng, int64_t* region_e_off, hipStream_t s);
 void launch_k3_count(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
-                     const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, uint32_t* row_links,
-                     hipStream_t s);
+                     const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, uint32_t* row_links, int32_t* tmp_col,
+                     uint8_t* tmp_val, hipStream_t s);   // tmp_*: launch_k3_inline() provisional entries per row
 void launch_k3_fill(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
-                    const int32_t* row_region_off, int32_t n_rows, const int64_t* row_ptr, int32_t* col, uint8_t* val,
-                    hipStream_t s);
+                    const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, const int64_t* row_ptr, const int32_t* tmp_col,
+                    const uint8_t* tmp_val, int32_t* col, uint8_t* val, hipStream_t s);
+int launch_k3_inline();
 void launch_k3_rows(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off, int32_t* region_rows,
                     hipStream_t s);
 void launch_scan_i32_to_i64(DevBuf& tmp, const int32_t* in, int64_t* out_excl, int32_t n, hipStream_t s);
