@@ -214,8 +214,12 @@ __device__ __forceinline__ ColEval eval_column(const uint32_t* __restrict__ plan
 
 __global__ void __launch_bounds__(LCR_BLOCK)
 k2_filter(BatchView b, DevParams prm, BinomTable bt, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0,
-          int64_t n_cols, const uint32_t* __restrict__ planes, uint8_t* __restrict__ flags, int32_t* __restrict__ tile_count) {
+          int64_t n_cols, const uint32_t* __restrict__ planes, const int32_t* __restrict__ tile_fill, uint8_t* __restrict__ flags,
+          int32_t* __restrict__ tile_count) {
   __shared__ int cnt_s;
+  // a tile without M / D / I records (K0's fill counter) has depth 0 everywhere: no survivor, its planes and flags
+  // are never read (k2_compact skips tiles whose count is 0) -- most tiles of spliced reads are like this
+  if (tile_fill[blockIdx.x] == 0) { if (threadIdx.x == 0) tile_count[blockIdx.x] = 0; return; }
   const int g = tile_region[blockIdx.x], tc0 = tile_col0[blockIdx.x];
   const int tlen = min(LCR_TILE, b.len[g] - tc0);
   const int64_t gcol0 = b.col_off[g] + tc0;
@@ -254,20 +258,22 @@ static BinomTable make_binom_table() {
 }
 
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
-                      int32_t n_tiles, int64_t n_cols, const uint32_t* planes, uint8_t* flags, int32_t* tile_count,
-                      hipStream_t s) {
+                      int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const int32_t* tile_fill, uint8_t* flags,
+                      int32_t* tile_count, hipStream_t s) {
   static const BinomTable bt = make_binom_table();
   if (n_tiles == 0) return;
   hipLaunchKernelGGL(k2_filter, dim3(n_tiles), dim3(LCR_BLOCK), 0, s, b, p, bt, tile_region, tile_col0, n_cols, planes,
-                     flags, tile_count);
+                     tile_fill, flags, tile_count);
 }
 
 // ordered compaction of pass-1 survivors (tile order = (region, column) order)
 __global__ void __launch_bounds__(LCR_BLOCK)
 k2_compact(BatchView b, DevParams prm, BinomTable bt, const int32_t* __restrict__ tile_region,
            const int32_t* __restrict__ tile_col0, int64_t n_cols, const uint32_t* __restrict__ planes,
-           const uint8_t* __restrict__ flags, const int32_t* __restrict__ tile_off, Survivor* __restrict__ out) {
+           const uint8_t* __restrict__ flags, const int32_t* __restrict__ tile_count, const int32_t* __restrict__ tile_off,
+           Survivor* __restrict__ out) {
   __shared__ int wsum[4];
+  if (tile_count[blockIdx.x] == 0) return;   // (its flags were not even written if the tile holds no records)
   const int g = tile_region[blockIdx.x], tc0 = tile_col0[blockIdx.x];
   const int tlen = min(LCR_TILE, b.len[g] - tc0);
   const int64_t gcol0 = b.col_off[g] + tc0;
@@ -458,11 +464,11 @@ void launch_k2_gt(const DevParams& p, const Survivor* sv, int32_t n_sv, const ui
 
 void launch_k2_compact(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                        int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const uint8_t* flags,
-                       const int32_t* tile_off, Survivor* out, hipStream_t s) {
+                       const int32_t* tile_count, const int32_t* tile_off, Survivor* out, hipStream_t s) {
   static const BinomTable bt = make_binom_table();
   if (n_tiles == 0) return;
   hipLaunchKernelGGL(k2_compact, dim3(n_tiles), dim3(LCR_BLOCK), 0, s, b, p, bt, tile_region, tile_col0, n_cols,
-                     planes, flags, tile_off, out);
+                     planes, flags, tile_count, tile_off, out);
 }
 
 float lcr_device_sor_threshold(hipStream_t s) {

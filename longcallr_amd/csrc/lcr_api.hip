@@ -368,7 +368,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->total.reserve(16));
   { Timer t(c, LCR_K_CAND_FILTER);
     launch_k2_filter(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
-                     c->planes.as<uint32_t>(), c->flags.as<uint8_t>(), c->tile_count.as<int32_t>(), c->stream);
+                     c->planes.as<uint32_t>(), c->k0_tile_fill.as<int32_t>(), c->flags.as<uint8_t>(), c->tile_count.as<int32_t>(), c->stream);
     launch_scan_i32(c->scan_tmp, c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(), nt, c->total.as<int32_t>(), c->stream); }
   // survivors per region = tile offsets at the regions' first tiles (gathered on the device, pinned D2H)
   HIPCHK(c, c->sv_region_off.reserve((ng + 1) * 4));
@@ -394,7 +394,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
     HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (size_t)n_sv * 124 * 4, c->stream));
     { Timer t(c, LCR_K_CAND_HIST);
       launch_k2_compact(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
-                        c->planes.as<uint32_t>(), c->flags.as<uint8_t>(), c->tile_off.as<int32_t>(),
+                        c->planes.as<uint32_t>(), c->flags.as<uint8_t>(), c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(),
                         c->survivors.as<Survivor>(), c->stream);
       launch_k2_hist(c->bv, c->dp, c->read_bin.as<ReadBin>(), c->survivors.as<Survivor>(), c->sv_region_off.as<int32_t>(), c->hist.as<uint32_t>(),
                      c->stream); }

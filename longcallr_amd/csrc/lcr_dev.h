@@ -140,13 +140,13 @@ void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* til
                       const unsigned long long* recs, const int32_t* nscan, uint32_t* planes, hipStream_t s);
 void launch_k1_zonefix(const BatchView& b, const ReadBin* rbin, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s);
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
-                      int32_t n_tiles, int64_t n_cols, const uint32_t* planes, uint8_t* flags, int32_t* tile_count,
-                      hipStream_t s);
+                      int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const int32_t* tile_fill, uint8_t* flags,
+                      int32_t* tile_count, hipStream_t s);   // tile_fill: K0's record counters of the last lcr_pileup
 void launch_gather_i32(const int32_t* src, const int32_t* idx, int32_t n, int32_t n_src, const int32_t* total, int32_t* out, hipStream_t s);
 void launch_scan_i32(DevBuf& tmp, const int32_t* in, int32_t* out_excl, int32_t n, int32_t* total, hipStream_t s);
 void launch_k2_compact(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                        int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const uint8_t* flags,
-                       const int32_t* tile_off, Survivor* out, hipStream_t s);
+                       const int32_t* tile_count, const int32_t* tile_off, Survivor* out, hipStream_t s);
 float lcr_device_sor_threshold(hipStream_t s);
 void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin, const Survivor* sv, const int32_t* sv_region_off,
                     uint32_t* hist /* n_sv * 4 * 31 */, hipStream_t s);
