@@ -82,7 +82,7 @@ struct PhaseHost {
   const uint8_t* r_assignment = nullptr;
   const uint32_t* r_phase_set = nullptr;
   DevBuf d_state[21];
-  HostBuf h_pin[10];   // pinned staging: row_ptr, col, val, links, enum state, region sizes, chain state
+  HostBuf h_pin[11];   // pinned staging: row_ptr, col, val, links, enum state, region sizes, chain state, results, job tables, chain start
   hipStream_t side = nullptr;   // second queue: fragment matrix download + chain regions
   hipEvent_t ev_in = nullptr, ev_csr = nullptr, ev_fork = nullptr, ev_join = nullptr;
   hipStream_t aux = nullptr;   // enumeration classes 3 / 4 beside class 2
