@@ -250,6 +250,35 @@ __device__ __forceinline__ int8_t init_genotype(int8_t vt) { return vt == 0 ? 1 
 //                holds (sigma does not change after it) -- no extra pass over the matrix.
 // ---------------------------------------------------------------------------------------------
 struct EnumTile { int32_t slot; uint32_t e0, ne; };   // restarts e0 .. e0+ne-1 of one region
+// The grid of an enumeration kernel is the concatenation of its regions' tiles; the host uploads one span per region
+// (a few hundred) instead of one record per tile (tens of thousands), the workgroup finds its span with two rounds
+// of a 64-way search (spans are sorted by tile0).  Winner re-runs have one workgroup per span.
+struct EnumSpan { int32_t slot; uint32_t tile0; };
+__device__ __forceinline__ EnumTile enum_tile_of(const PhaseDev& P, const EnumSpan* __restrict__ spans, int n_spans, uint32_t per, bool winner) {
+  EnumTile t;
+  const uint32_t bid = blockIdx.x;
+  if (winner) { t.slot = spans[bid].slot; t.e0 = 0; t.ne = 1; return t; }
+  const int lane = threadIdx.x & 63;
+  // level 1: 64 evenly spaced spans; level 2: the spans of the hit segment (n_spans <= 4096), else a plain search
+  int lo = 0, hi = n_spans;   // answer in [lo, hi): last span with tile0 <= bid
+  if (n_spans <= 4096) {
+    const int step = (n_spans + 63) / 64;
+    const int i1 = lane * step;
+    const unsigned long long m1 = __ballot(i1 < n_spans && spans[min(i1, n_spans - 1)].tile0 <= bid);
+    const int seg = __popcll(m1) - 1;          // spans[0].tile0 == 0 <= bid: at least one bit
+    lo = seg * step; hi = min(n_spans, lo + step);
+    const int i2 = lo + lane;
+    const unsigned long long m2 = __ballot(i2 < hi && spans[min(i2, n_spans - 1)].tile0 <= bid);
+    lo = lo + __popcll(m2) - 1;
+  } else {
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (spans[mid].tile0 <= bid) lo = mid; else hi = mid; }
+  }
+  t.slot = spans[lo].slot;
+  const uint32_t n = 1u << P.reg[t.slot].S;
+  t.e0 = (bid - spans[lo].tile0) * per;
+  t.ne = min(per, n - t.e0);
+  return t;
+}
 constexpr int ENUM_WAVES = 4;
 constexpr uint32_t ENUM_TILE_JOBS = 16;
 constexpr uint32_t ENUM_LDS_BYTES = 48 * 1024;
@@ -299,10 +328,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 // re-run restart win_e[slot] of each tile's region and store its state.
 template <int CK>
 __global__ void __launch_bounds__(64 * ENUM_WAVES)
-k4_enum_reg(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __restrict__ job_base,
+k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uint32_t per, const int64_t* __restrict__ job_base,
             long long* __restrict__ job_obj, const uint32_t* __restrict__ win_e) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  const EnumTile t = tiles[blockIdx.x];
+  const EnumTile t = enum_tile_of(P, spans, n_spans, per, win_e != nullptr);
   const RegionDev rd = P.reg[t.slot];
   const int R = rd.R, S = rd.S;
   const uint32_t E = (uint32_t)P.prow_ptr[rd.rp_off + R];
@@ -740,11 +769,11 @@ __global__ void __launch_bounds__(STAGE_THREADS) k4_stage(StageIn in, StageOut o
 
 // the same tiles for regions whose matrix does not fit the LDS budget: one restart at a time per workgroup
 __global__ void __launch_bounds__(LCR_BLOCK)
-k4_enum_big(PhaseDev P, const EnumTile* __restrict__ tiles, const int64_t* __restrict__ job_base,
+k4_enum_big(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uint32_t per, const int64_t* __restrict__ job_base,
             long long* __restrict__ job_obj, const uint32_t* __restrict__ win_e) {
   __shared__ long long red[LCR_BLOCK / 64];
   __shared__ long long wl[32];
-  const EnumTile t = tiles[blockIdx.x];
+  const EnumTile t = enum_tile_of(P, spans, n_spans, per, win_e != nullptr);
   const RegionDev rd = P.reg[t.slot];
   load_w(P, wl);
   int8_t* base = P.scratch + (size_t)blockIdx.x * P.scratch_stride;
@@ -2013,7 +2042,6 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   P.scratch_stride = stride;
   const size_t dyn_bytes = stride <= 48 * 1024 ? (size_t)stride : 0;  // chain working state in LDS when it fits
   P.lds_state = dyn_bytes ? 1 : 0;
-  std::vector<uint8_t> packed;   // pageable upload source; must outlive the copy (synchronised below)
   size_t n_big_blocks = 0;
   if (!enum_slots.empty()) {
     const bool force_big = getenv("LCR_ENUM_FORCE_BIG") != nullptr;        // test hooks: exercise the fallback kernels
@@ -2023,7 +2051,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     // streaming its entries from LDS (any share size); class 4: global-memory kernel (matrix larger than the
     // LDS budget); classes 0 / 1 unused
     constexpr int NCLS = 5;
-    std::vector<EnumTile> tiles[NCLS], wtiles[NCLS];
+    std::vector<EnumSpan> spans[NCLS];
+    size_t n_t[NCLS] = {0, 0, 0, 0, 0};   // tiles per class = grid of the class's kernel
+    const uint32_t per_of[NCLS] = {1u, 1u, ENUM_TILE_JOBS, 2u * ENUM_WAVES, 1u};
     std::vector<int64_t> job_base(ng, 0);
     int64_t nj = 0;
     uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0};
@@ -2036,30 +2066,27 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
         cls = force_stream ? 3 : (st.max_n <= 32 ? 2 : 3);   // (the 8 / 16 instantiations: one launch has one tail)
       if (cls < 4) lds_need[cls] = std::max(lds_need[cls], EL.total);
       job_base[g] = nj;
-      const uint32_t n = 1u << S;
-      const uint32_t per = cls == 4 ? 1u : (cls == 3 ? 2u * ENUM_WAVES : ENUM_TILE_JOBS);
-      for (uint32_t e0 = 0; e0 < n; e0 += per) tiles[cls].push_back({g, e0, std::min(per, n - e0)});
-      wtiles[cls].push_back({g, 0, 1});
-      nj += n;
+      const uint64_t n = 1ull << S;
+      if (n_t[cls] + (n + per_of[cls] - 1) / per_of[cls] > 0x7fffffffull) { if (err) *err = "too many enumeration restarts for one launch"; return LCR_E_ARG; }
+      spans[cls].push_back({g, (uint32_t)n_t[cls]});
+      n_t[cls] += (size_t)((n + per_of[cls] - 1) / per_of[cls]);
+      nj += (int64_t)n;
     }
-    // one upload: tiles | winner tiles | job_base | slots ; then job objectives and winners
-    size_t n_t[NCLS], n_w[NCLS], n_tiles = 0;
-    for (int k = 0; k < NCLS; k++) { n_t[k] = tiles[k].size(); n_w[k] = wtiles[k].size(); n_tiles += n_t[k] + n_w[k]; }
+    // one upload: spans of every class | job_base | slots ; then job objectives and winners
+    size_t n_w[NCLS], s_off[NCLS], n_spans = 0;
+    for (int k = 0; k < NCLS; k++) { n_w[k] = spans[k].size(); s_off[k] = n_spans; n_spans += n_w[k]; }
     const size_t ns = enum_slots.size();
-    const size_t off_jb_al = (n_tiles * sizeof(EnumTile) + 7) & ~(size_t)7;  // sizeof(EnumTile) == 12
-    packed.resize(off_jb_al + (size_t)ng * 8 + ns * 4);
-    size_t t_off[NCLS], w_off[NCLS], cursor = 0;
-    EnumTile* pt = (EnumTile*)packed.data();
-    for (int k = 0; k < NCLS; k++) { t_off[k] = cursor; memcpy(pt + cursor, tiles[k].data(), n_t[k] * sizeof(EnumTile)); cursor += n_t[k]; }
-    for (int k = 0; k < NCLS; k++) { w_off[k] = cursor; memcpy(pt + cursor, wtiles[k].data(), n_w[k] * sizeof(EnumTile)); cursor += n_w[k]; }
-    memcpy(packed.data() + off_jb_al, job_base.data(), (size_t)ng * 8);
-    memcpy(packed.data() + off_jb_al + (size_t)ng * 8, enum_slots.data(), ns * 4);
-    PCHK(b_job.reserve(packed.size() + 64));
+    const size_t off_jb_al = (n_spans * sizeof(EnumSpan) + 7) & ~(size_t)7;
+    const size_t up_bytes = off_jb_al + (size_t)ng * 8 + ns * 4;
+    PCHK(b_job.reserve(up_bytes + 64));
     PCHK(b_obj.reserve((size_t)nj * 8 + (size_t)ng * 4 + 64));
-    PCHK(h_pin[8].reserve(packed.size() + 64));   // pinned: the upload is queued, not staged
-    memcpy(h_pin[8].p, packed.data(), packed.size());
-    PCHK(hipMemcpyAsync(b_job.p, h_pin[8].p, packed.size(), hipMemcpyHostToDevice, stream));
-    const EnumTile* d_t = b_job.as<EnumTile>();
+    PCHK(h_pin[8].reserve(up_bytes + 64));   // pinned: the upload is queued, not staged
+    uint8_t* const up = h_pin[8].as<uint8_t>();
+    for (int k = 0; k < NCLS; k++) memcpy(up + s_off[k] * sizeof(EnumSpan), spans[k].data(), n_w[k] * sizeof(EnumSpan));
+    memcpy(up + off_jb_al, job_base.data(), (size_t)ng * 8);
+    memcpy(up + off_jb_al + (size_t)ng * 8, enum_slots.data(), ns * 4);
+    PCHK(hipMemcpyAsync(b_job.p, up, up_bytes, hipMemcpyHostToDevice, stream));
+    const EnumSpan* d_sp = b_job.as<EnumSpan>();
     const int64_t* d_jb = (const int64_t*)(b_job.as<uint8_t>() + off_jb_al);
     const int32_t* d_sl = (const int32_t*)(b_job.as<uint8_t>() + off_jb_al + (size_t)ng * 8);
     long long* d_obj = b_obj.as<long long>();
@@ -2068,21 +2095,21 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(b_scr.reserve((size_t)stride * (n_big_blocks + chain_slots.size()) + 64));   // chain regions use the tail
     P.scratch = b_scr.as<int8_t>();
     // the classes touch disjoint regions: class 2 on `stream`, classes 3 / 4 beside it on `aux` (their tails overlap)
-    auto launch = [&](const size_t* cnt, const size_t* off, const uint32_t* win) -> hipError_t {
+    auto launch = [&](const size_t* cnt, const uint32_t* win) -> hipError_t {
       const dim3 blk(64 * ENUM_WAVES);
       const bool fork = cnt[2] && (cnt[3] || cnt[4]);
       hipStream_t s34 = fork ? aux : stream;
       hipError_t e = hipSuccess;
       if (fork) { if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e; }
-      if (cnt[2]) hipLaunchKernelGGL(k4_enum_reg<32>, dim3((unsigned)cnt[2]), blk, lds_need[2], stream, P, d_t + off[2], d_jb, d_obj, win);
-      if (cnt[3]) hipLaunchKernelGGL(k4_enum_reg<0>, dim3((unsigned)cnt[3]), blk, lds_need[3], s34, P, d_t + off[3], d_jb, d_obj, win);
-      if (cnt[4]) hipLaunchKernelGGL(k4_enum_big, dim3((unsigned)cnt[4]), dim3(LCR_BLOCK), 0, s34, P, d_t + off[4], d_jb, d_obj, win);
+      if (cnt[2]) hipLaunchKernelGGL(k4_enum_reg<32>, dim3((unsigned)cnt[2]), blk, lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, win);
+      if (cnt[3]) hipLaunchKernelGGL(k4_enum_reg<0>, dim3((unsigned)cnt[3]), blk, lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, win);
+      if (cnt[4]) hipLaunchKernelGGL(k4_enum_big, dim3((unsigned)cnt[4]), dim3(LCR_BLOCK), 0, s34, P, d_sp + s_off[4], (int32_t)n_w[4], per_of[4], d_jb, d_obj, win);
       if (fork) { if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e; }
       return e;
     };
-    PCHK(launch(n_t, t_off, nullptr));
+    PCHK(launch(n_t, nullptr));
     hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)ns), dim3(64), 0, stream, d_sl, (int32_t)ns, P.reg, d_jb, d_obj, d_win);
-    PCHK(launch(n_w, w_off, d_win));
+    PCHK(launch(n_w, d_win));
     if (dev_post) hipLaunchKernelGGL(k4_post<LCR_BLOCK>, dim3((unsigned)ns), dim3(LCR_BLOCK), post_lds, stream, pin, d_sl, (int32_t)ns, plut);
     PCHK(hipGetLastError());
   }
