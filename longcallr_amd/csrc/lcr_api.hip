@@ -34,8 +34,8 @@ struct lcr_ctx {
   HostBuf h_planes;
   HostBuf h_nnz;              // pinned: first entry of every region of the fragment matrix, [ng] = entry count (lcr_fragments -> frag_settle)
   DevBuf region_e_off, frag_tmp_col, frag_tmp_val;
-  hipEvent_t ev_nnz = nullptr;
-  bool nnz_pending = false;
+  hipEvent_t ev_nnz = nullptr, ev_cand = nullptr;
+  bool nnz_pending = false, cand_pending = false;
   HostBuf h_stage[4];   // pinned staging of lcr_candidates / lcr_fragments: survivor offsets, candidate records, keep flags, region rows
 
   // K2
@@ -151,6 +151,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
                     &c->row_links, &c->row_ptr, &c->col, &c->val};
   for (auto* b : bufs) b->release();
   if (c->ev_nnz) (void)hipEventDestroy(c->ev_nnz);
+  if (c->ev_cand) (void)hipEventDestroy(c->ev_cand);
   HostBuf* hb[] = {&c->h_nnz, &c->h_stage[0], &c->h_stage[1], &c->h_stage[2], &c->h_stage[3], &c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
   for (auto* b : hb) b->release();
   c->phase.release();
@@ -356,6 +357,8 @@ int lcr_get_columns(lcr_ctx* c, lcr_columns* out) {
   return LCR_OK;
 }
 
+static int cand_settle(lcr_ctx* c);
+
 int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   if (!c || !p) return LCR_E_ARG;
   if (!c->have_planes) { c->err = "lcr_candidates before lcr_pileup"; return LCR_E_STATE; }
@@ -418,10 +421,12 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->row_region_off.reserve((ng + 1) * 4));
   launch_k3_row_offsets(c->region_rows.as<int32_t>(), ng, c->row_region_off.as<int32_t>(), c->stream);
   if (ng) HIPCHK(c, hipMemcpyAsync(c->h_stage[3].p, c->region_rows.p, ng * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // no wait here: the host copies are picked up by whoever needs them first (cand_settle) -- lcr_fragments queues its
+  // count pass before it does, so the GPU does not idle across the call boundary
+  if (!c->ev_cand) HIPCHK(c, hipEventCreateWithFlags(&c->ev_cand, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->ev_cand, c->stream));
   HIPCHK(c, hipGetLastError());
-  memcpy(c->h_cand_off.data(), c->h_stage[2].p, (size_t)(ng + 1) * 4);
-  c->h_cand.assign(c->h_stage[1].as<lcr_candidate>(), c->h_stage[1].as<lcr_candidate>() + c->h_cand_off[ng]);
+  c->cand_pending = true;
   c->have_cand = true;
   c->have_frag = c->have_phase = false;
   return LCR_OK;
@@ -430,10 +435,22 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
 int lcr_get_candidates(lcr_ctx* c, lcr_candidate_list* out) {
   if (!c || !out) return LCR_E_ARG;
   if (!c->have_cand) { c->err = "lcr_get_candidates before lcr_candidates"; return LCR_E_STATE; }
+  { int rc = cand_settle(c); if (rc) return rc; }
   out->n_cand = (int32_t)c->h_cand.size();
   out->n_regions = c->bv.n_regions;
   out->cand = c->h_cand.data();
   out->region_off = c->h_cand_off.data();
+  return LCR_OK;
+}
+
+// lcr_candidates leaves its last copies in flight: candidate records, per-region offsets, rows per region
+static int cand_settle(lcr_ctx* c) {
+  if (!c->cand_pending) return LCR_OK;
+  HIPCHK(c, hipEventSynchronize(c->ev_cand));
+  const int ng = c->bv.n_regions;
+  memcpy(c->h_cand_off.data(), c->h_stage[2].p, (size_t)(ng + 1) * 4);
+  c->h_cand.assign(c->h_stage[1].as<lcr_candidate>(), c->h_stage[1].as<lcr_candidate>() + c->h_cand_off[ng]);
+  c->cand_pending = false;
   return LCR_OK;
 }
 
@@ -453,24 +470,20 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, hipSetDevice(c->device));
   const int ng = c->bv.n_regions;
   c->min_linkers = p->min_linkers;
-  const int32_t* rr = c->h_stage[3].as<int32_t>();   // rows per region, from lcr_candidates
-  c->h_row_region_off.assign(ng + 1, 0);
-  for (int g = 0; g < ng; g++) c->h_row_region_off[g + 1] = c->h_row_region_off[g] + rr[g];
-  c->n_rows = c->h_row_region_off[ng];
-  const int nrow = c->n_rows;
-  HIPCHK(c, c->row_cnt.reserve(std::max(nrow, 1) * 4));   // (row_region_off is on the device since lcr_candidates)
-  HIPCHK(c, c->frag_tmp_col.reserve((size_t)std::max(nrow, 1) * launch_k3_inline() * 4));   // provisional entries of the count pass
-  HIPCHK(c, c->frag_tmp_val.reserve((size_t)std::max(nrow, 1) * launch_k3_inline()));
-  HIPCHK(c, c->row_links.reserve(std::max(nrow, 1) * 4));
-  HIPCHK(c, c->row_ptr.reserve((std::max(nrow, 1) + 1) * 8));
+  // The count pass is queued before the host knows the row count: buffers are sized for one row per read (rows are
+  // a prefix of every region's reads), counts of the unused tail stay 0, so the scan puts the entry total at
+  // row_ptr[n_rows] as well as at its end.
+  const int nr_cap = c->bv.n_reads;
+  HIPCHK(c, c->row_cnt.reserve(std::max(nr_cap, 1) * 4));   // (row_region_off is on the device since lcr_candidates)
+  HIPCHK(c, c->frag_tmp_col.reserve((size_t)std::max(nr_cap, 1) * launch_k3_inline() * 4));   // provisional entries of the count pass
+  HIPCHK(c, c->frag_tmp_val.reserve((size_t)std::max(nr_cap, 1) * launch_k3_inline()));
+  HIPCHK(c, c->row_links.reserve(std::max(nr_cap, 1) * 4));
+  HIPCHK(c, c->row_ptr.reserve((std::max(nr_cap, 1) + 1) * 8));
+  if (nr_cap) HIPCHK(c, hipMemsetAsync(c->row_cnt.p, 0, (size_t)nr_cap * 4, c->stream));
   { Timer t(c, LCR_K_FRAG_COUNT);
-    launch_k3_count(c->bv, c->read_bin.as<ReadBin>(), c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nrow,
+    launch_k3_count(c->bv, c->read_bin.as<ReadBin>(), c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nr_cap,
                     c->row_cnt.as<int32_t>(), c->row_links.as<uint32_t>(), c->frag_tmp_col.as<int32_t>(), c->frag_tmp_val.as<uint8_t>(), c->stream);
-    launch_scan_i32_to_i64(c->scan_tmp, c->row_cnt.as<int32_t>(), c->row_ptr.as<int64_t>(), nrow, c->stream); }
-  // entries: at most rows x candidates per region.  When that bound is affordable the fill pass is queued right
-  // behind the count pass and the true count is picked up later (frag_settle); otherwise wait for it first.
-  int64_t bound = 0;
-  for (int g = 0; g < ng; g++) bound += (int64_t)rr[g] * (c->h_cand_off[g + 1] - c->h_cand_off[g]);
+    launch_scan_i32_to_i64(c->scan_tmp, c->row_cnt.as<int32_t>(), c->row_ptr.as<int64_t>(), nr_cap, c->stream); }
   // the regions' first entries ([ng] = all entries) follow the count pass to the host: the phase stage sizes its
   // work from them without a round trip of its own
   HIPCHK(c, c->h_nnz.reserve((size_t)(ng + 1) * 8));
@@ -480,6 +493,17 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, hipMemcpyAsync(c->h_nnz.p, c->region_e_off.p, (size_t)(ng + 1) * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipEventRecord(c->ev_nnz, c->stream));
   c->nnz_pending = true;
+  // now the candidates' host copies (long since there): rows per region, candidates per region
+  { int rc = cand_settle(c); if (rc) return rc; }
+  const int32_t* rr = c->h_stage[3].as<int32_t>();   // rows per region, from lcr_candidates
+  c->h_row_region_off.assign(ng + 1, 0);
+  for (int g = 0; g < ng; g++) c->h_row_region_off[g + 1] = c->h_row_region_off[g] + rr[g];
+  c->n_rows = c->h_row_region_off[ng];
+  const int nrow = c->n_rows;
+  // entries: at most rows x candidates per region.  When that bound is affordable the fill pass is queued right
+  // behind the count pass and the true count is picked up later (frag_settle); otherwise wait for it first.
+  int64_t bound = 0;
+  for (int g = 0; g < ng; g++) bound += (int64_t)rr[g] * (c->h_cand_off[g + 1] - c->h_cand_off[g]);
   int64_t cap = bound;
   if (bound > ((int64_t)1 << 28)) {
     int rc = frag_settle(c);
@@ -501,6 +525,7 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
 int lcr_get_candidates_device(lcr_ctx* c, const lcr_candidate** dev_cand, int32_t* n_cand) {
   if (!c || !dev_cand || !n_cand) return LCR_E_ARG;
   if (!c->have_cand) { c->err = "lcr_get_candidates_device before lcr_candidates"; return LCR_E_STATE; }
+  { int rc = cand_settle(c); if (rc) return rc; }
   *dev_cand = c->d_cand.as<lcr_candidate>();
   *n_cand = (int32_t)c->h_cand.size();
   return LCR_OK;
