@@ -164,9 +164,9 @@ def main():
     def step(Ej):
         Ej.load_batch((reads, regions, keep))
         Ej.fill_data_into_freq_vec()
-        t_pile = (Ej.kernel_ms(_abi.K_PILEUP), Ej.kernel_ms(_abi.K_SPANS))  # HIP events on the ctx stream
         Ej.get_candidate_snps().get_fragments().phase()
-        return t_pile
+        # HIP events on the ctx stream, read after the step (lcr_pileup returns while K1 is still running)
+        return (Ej.kernel_ms(_abi.K_PILEUP), Ej.kernel_ms(_abi.K_SPANS))
 
     def publish(Ej):   # the gather of this batch's records (HBM to rank 0's HBM) overlaps the next batch's kernels
         if G is None:

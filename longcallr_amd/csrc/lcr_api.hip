@@ -34,7 +34,7 @@ struct lcr_ctx {
   HostBuf h_planes;
   HostBuf h_nnz;              // pinned: first entry of every region of the fragment matrix, [ng] = entry count (lcr_fragments -> frag_settle)
   DevBuf region_e_off, frag_tmp_col, frag_tmp_val;
-  hipEvent_t ev_nnz = nullptr, ev_cand = nullptr;
+  hipEvent_t ev_nnz = nullptr, ev_cand = nullptr, ev_ctl = nullptr;
   bool nnz_pending = false, cand_pending = false;
   HostBuf h_stage[4];   // pinned staging of lcr_candidates / lcr_fragments: survivor offsets, candidate records, keep flags, region rows
 
@@ -152,6 +152,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   for (auto* b : bufs) b->release();
   if (c->ev_nnz) (void)hipEventDestroy(c->ev_nnz);
   if (c->ev_cand) (void)hipEventDestroy(c->ev_cand);
+  if (c->ev_ctl) (void)hipEventDestroy(c->ev_ctl);
   HostBuf* hb[] = {&c->h_nnz, &c->h_stage[0], &c->h_stage[1], &c->h_stage[2], &c->h_stage[3], &c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
   for (auto* b : hb) b->release();
   c->phase.release();
@@ -315,18 +316,22 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
                     (unsigned int*)(c->k0_tile_fill.as<int32_t>() + nt + 1), pool_cap, c->k0_items.as<unsigned long long>(),
                     c->ndiff.as<uint32_t>(), c->stream);
       launch_scan_i32(c->scan_tmp, (const int32_t*)c->ndiff.p, c->nscan.as<int32_t>(), (int32_t)nd, nullptr, c->stream); }
-    // ---- K1: per-tile tally from the records; K1z: poly-A / homopolymer mask of the HiFi presets
+    // K0's verdict (CIGAR validation, pool overflow) and counts leave for the host before K1 is queued: the host
+    // waits for them while K1 runs and returns without waiting for K1 -- later calls queue behind it
+    int32_t* const ctl = c->h_stage[0].as<int32_t>();
+    HIPCHK(c, hipMemcpyAsync(ctl, c->k0_tile_fill.as<int32_t>() + nt + 1, 16, hipMemcpyDeviceToHost, c->stream));
+    if (!c->ev_ctl) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ctl, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_ctl, c->stream));
+    // ---- K1: per-tile tally from the records (leaves at once if K0 flagged an error); K1z: poly-A / homopolymer
+    // mask of the HiFi presets
     { Timer t(c, LCR_K_PILEUP);
       launch_k1_pileup(b, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
                        c->k0_tile_fill.as<int32_t>(), c->k0_tile_count.as<int32_t>(), c->k0_items.as<unsigned long long>(),
                        c->nscan.as<int32_t>(), c->planes.as<uint32_t>(), c->stream);
       if (!c->dp.ont && c->dp.dist_to_end > 0)
         launch_k1_zonefix(b, c->read_bin.as<ReadBin>(), c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->stream); }
-    // record count (byte accounting) and CIGAR validation result
-    int32_t* const ctl = c->h_stage[0].as<int32_t>();
-    HIPCHK(c, hipMemcpyAsync(ctl, c->k0_tile_fill.as<int32_t>() + nt + 1, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventSynchronize(c->ev_ctl));
     n_ops = ctl[1]; n_recs = ctl[2]; bad = ctl[3];
     if (bad == 1) { c->err = "unknown CIGAR operation (reference panics: util.rs:944)"; return LCR_E_CIGAR; }
     if (bad == 2) { c->err = "CIGAR inconsistent with l_seq / soft clips"; return LCR_E_CIGAR; }
