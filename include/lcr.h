@@ -193,6 +193,9 @@ int lcr_ctx_sync(lcr_ctx*);
  * inputs are used in place and must outlive the calls below. */
 int lcr_load_batch(lcr_ctx*, const lcr_reads*, const lcr_regions*);
 
+/* The four stage calls below queue their kernels on the context's stream and return as soon as the host has what it
+ * needs to go on (error verdicts, sizes); the last kernels of a stage may still be running.  Later stage calls queue
+ * behind them; the lcr_get_* calls and lcr_ctx_sync wait.  An error a stage can raise is always raised by that call. */
 /* replaces Profile::fill_data_into_freq_vec (util.rs:621-949); thread.rs:93-103.
  * Returns LCR_E_CIGAR for an unknown CIGAR op or a CIGAR inconsistent with l_seq / soft clips. */
 int lcr_pileup(lcr_ctx*, const lcr_params*);
