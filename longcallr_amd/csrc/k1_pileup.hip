@@ -558,15 +558,33 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   }
   __syncthreads();
 
-  // prefix-scan the five difference arrays, K1_CPT consecutive columns per thread
-  for (int p = P_DIFF_DEPTH_F; p <= P_DIFF_D; p++) {
-    uint32_t* d = pl + p * TSTRIDE;
-    int v[K1_CPT], run = 0;
+  // prefix-scan the five difference arrays together (one pair of barriers instead of five), K1_CPT consecutive
+  // columns per thread
+  {
+    constexpr int NP = P_DIFF_D - P_DIFF_DEPTH_F + 1;
+    static_assert(NP == 5, "five difference arrays");
+    __shared__ int wsum5[NP][K1_WAVES];
+    const int lane = tid & 63, w = tid >> 6;
+    int v[NP][K1_CPT], incl[NP];
 #pragma unroll
-    for (int x = 0; x < K1_CPT; x++) { run += (int)d[tid * K1_CPT + x]; v[x] = run; }
-    const int excl = block_incl_scan(run, wsum) - run;
+    for (int p = 0; p < NP; p++) {
+      const uint32_t* d = pl + (P_DIFF_DEPTH_F + p) * TSTRIDE;
+      int run = 0;
 #pragma unroll
-    for (int x = 0; x < K1_CPT; x++) d[tid * K1_CPT + x] = (uint32_t)(excl + v[x]);
+      for (int x = 0; x < K1_CPT; x++) { run += (int)d[tid * K1_CPT + x]; v[p][x] = run; }
+      incl[p] = wave_incl_scan(run);
+      if (lane == 63) wsum5[p][w] = incl[p];
+      incl[p] -= run;   // exclusive inside the wave
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      int add = incl[p];
+      for (int i = 0; i < w; i++) add += wsum5[p][i];
+      uint32_t* d = pl + (P_DIFF_DEPTH_F + p) * TSTRIDE;
+#pragma unroll
+      for (int x = 0; x < K1_CPT; x++) d[tid * K1_CPT + x] = (uint32_t)(add + v[p][x]);
+    }
     __syncthreads();
   }
 
