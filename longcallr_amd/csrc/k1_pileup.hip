@@ -356,7 +356,7 @@ enum {
 #define TSTRIDE (LCR_TILE + 1)
 #define REF_PAD 16  // reference bytes are stored at refl[REF_PAD + column] so that piece starts may be "negative"
 
-// inclusive scan of one int per thread over the whole block
+// inclusive scan of one int per thread over the whole block; the caller must pass a barrier before wsum is used again
 __device__ __forceinline__ int block_incl_scan(int v, int* wsum /* K1_WAVES ints of LDS */) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int s = wave_incl_scan(v);
@@ -364,7 +364,6 @@ __device__ __forceinline__ int block_incl_scan(int v, int* wsum /* K1_WAVES ints
   __syncthreads();
   int add = 0;
   for (int i = 0; i < w; i++) add += wsum[i];
-  __syncthreads();
   return s + add;
 }
 
@@ -472,21 +471,22 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
       nsum += npc[x];
     }
     int run = block_incl_scan(nsum, wsum) - nsum;   // exclusive prefix of this thread's first record
+    int P = 0;                                      // pieces of the batch (every thread sums the wave totals)
+#pragma unroll
+    for (int i = 0; i < K1_WAVES; i++) P += wsum[i];
+    // piece -> record map (short segments: a handful of pieces per record); larger batches search pstart[].
+    // A thread fills the map entries of its own records straight from its registers: one barrier covers
+    // pstart[] and pown[].
+    const bool mapped = P <= K1_PMAP;
     if (tid == 0) pstart[0] = 0;
 #pragma unroll
-    for (int x = 0; x < K1_RPB; x++) { run += npc[x]; pstart[tid * K1_RPB + x + 1] = run; }
-    __syncthreads();
-    const int P = pstart[K1_RPB * K1_THREADS];
-    // piece -> record map (short segments: a handful of pieces per record); larger batches search pstart[]
-    const bool mapped = P <= K1_PMAP;
-    if (mapped) {
-#pragma unroll
-      for (int x = 0; x < K1_RPB; x++) {
-        const int slot = tid * K1_RPB + x;
-        for (int q = pstart[slot]; q < pstart[slot + 1]; q++) pown[q] = (uint16_t)slot;
-      }
-      __syncthreads();
+    for (int x = 0; x < K1_RPB; x++) {
+      const int first = run;
+      run += npc[x];
+      pstart[tid * K1_RPB + x + 1] = run;
+      if (mapped) for (int q = first; q < run; q++) pown[q] = (uint16_t)(tid * K1_RPB + x);
     }
+    __syncthreads();
     // ---- phase 2: one 16-byte aligned piece of read bases per thread, four pieces in flight per thread
     struct Piece { uint4 v; int colA, k_lo, k_hi, strand; bool ok; };
     auto fetch = [&](int p) -> Piece {
