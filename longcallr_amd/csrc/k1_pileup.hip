@@ -411,7 +411,18 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
     return;
   }
   __shared__ int lvl_at[LCR_REC_LEVELS];
+  // valid-byte masks of a 16-byte piece in the layout of the mismatch word below (bit 8k + j <-> byte 4j + k):
+  // vge[lo] = bytes >= lo, vlt[hi] = bytes < hi
+  __shared__ uint32_t vge[17], vlt[17];
   if (tid < LCR_REC_LEVELS) lvl_at[tid] = tile_lvl[blockIdx.x * LCR_REC_LEVELS + tid];
+  if (tid >= 64 && tid < 64 + 34) {
+    const int v = (tid - 64) % 17;
+    uint32_t m = 0;
+    for (int j = 0; j < 4; j++)
+      for (int kk = 0; kk < 4; kk++)
+        if (tid - 64 < 17 ? 4 * j + kk >= v : 4 * j + kk < v) m |= 1u << (8 * kk + j);
+    if (tid - 64 < 17) vge[v] = m; else vlt[v] = m;
+  }
   for (int i = tid; i < P_NPL * TSTRIDE; i += K1_THREADS) pl[i] = 0;
   for (int i = tid; i < REF_PAD + LCR_TILE + 32; i += K1_THREADS) {
     const int col = i - REF_PAD;
@@ -500,12 +511,14 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
         for (int st = K1_RPB * K1_THREADS / 2; st >= 1; st >>= 1) if (pstart[lo + st] <= p) lo += st;
       }
       const unsigned long long rc = rec_s[lo];
+      const uint32_t rhi = (uint32_t)(rc >> 32);
       const long long soff = (long long)(rc & REC_OFF_MASK);
-      const int scol = (int)((rc >> 40) & 1023u), slen = (int)((rc >> 50) & 1023u) + 1;
-      q.strand = (int)((rc >> 60) & 1u);
-      const long long A = (soff & ~15ll) + 16ll * (p - pstart[lo]);      // byte address of the piece
-      q.k_lo = (int)max(0ll, soff - A); q.k_hi = (int)min(16ll, soff + slen - A);   // valid bytes
-      q.colA = scol + (int)(A - soff);                                    // column of byte 0 (may be < 0)
+      const int scol = (int)((rhi >> 8) & 1023u), slen = (int)((rhi >> 18) & 1023u) + 1;
+      q.strand = (int)((rhi >> 28) & 1u);
+      const int s15 = (int)((uint32_t)rc & 15u), d16 = 16 * (p - pstart[lo]);   // piece d16 / 16 of the segment
+      const long long A = (soff - s15) + d16;                             // byte address of the piece
+      q.k_lo = max(0, s15 - d16); q.k_hi = min(16, s15 + slen - d16);     // valid bytes
+      q.colA = scol - s15 + d16;                                          // column of byte 0 (may be < 0)
       if (A + 16 <= b.n_bases) q.v = *reinterpret_cast<const uint4*>(b.bases + A);
       else {  // last partial 16 bytes of the whole base array
         uint32_t t[4] = {0, 0, 0, 0};
@@ -523,21 +536,21 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
       const uint32_t r0 = rl32[di], r1 = rl32[di + 1], r2 = rl32[di + 2], r3 = rl32[di + 3], r4 = rl32[di + 4];
       const uint32_t x0 = q.v.x ^ __builtin_amdgcn_alignbyte(r1, r0, sh), x1 = q.v.y ^ __builtin_amdgcn_alignbyte(r2, r1, sh);
       const uint32_t x2 = q.v.z ^ __builtin_amdgcn_alignbyte(r3, r2, sh), x3 = q.v.w ^ __builtin_amdgcn_alignbyte(r4, r3, sh);
-      // 16-bit mask of mismatching bytes among the valid ones
-      auto nz4 = [](uint32_t x) -> uint32_t {
-        return ((x & 0xffu) ? 1u : 0u) | ((x & 0xff00u) ? 2u : 0u) | ((x & 0xff0000u) ? 4u : 0u) | ((x & 0xff000000u) ? 8u : 0u);
-      };
-      uint32_t mm = nz4(x0) | (nz4(x1) << 4) | (nz4(x2) << 8) | (nz4(x3) << 12);
-      mm &= ((1u << q.k_hi) - 1u) & ~((1u << q.k_lo) - 1u);
+      // mismatching bytes among the valid ones as one word: bit 8k + j <-> byte k of dword j.  Per dword a carry-free
+      // SWAR test (bit 7 of every non-zero byte), then the four flag words are interleaved by shifts; the valid range
+      // comes from two table words in the same layout.
+      auto nzf = [](uint32_t x) -> uint32_t { return (x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u; };
+      uint32_t mm = (nzf(x0) >> 7) | (nzf(x1) >> 6) | (nzf(x2) >> 5) | (nzf(x3) >> 4);
+      mm &= vge[q.k_lo] & vlt[q.k_hi];
       if (prm.dbg == 5) mm = 0;
       uint32_t* dp = pl + (q.strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
       uint32_t* mp = pl + (q.strand ? P_MM_R : P_MM_F) * TSTRIDE;
       while (mm) {  // rare: a few % of the bases
-        const int kx = __ffs(mm) - 1;
+        const int pb = __ffs(mm) - 1, jd = pb & 7, kb = pb >> 3;   // dword jd, byte kb
         mm &= mm - 1;
-        const uint32_t w = kx < 4 ? q.v.x : kx < 8 ? q.v.y : kx < 12 ? q.v.z : q.v.w;
-        const uint32_t base = (w >> (8 * (kx & 3))) & 0xffu;
-        const int col = q.colA + kx;
+        const uint32_t w = jd == 0 ? q.v.x : jd == 1 ? q.v.y : jd == 2 ? q.v.z : q.v.w;
+        const uint32_t base = (w >> (8 * kb)) & 0xffu;
+        const int col = q.colA + 4 * jd + kb;
         // branch-free classification: A,C,G,T (either case) -> 0..3; anything else is "Invalid nucleotide
         // base" (util.rs:890-892): no allele count (depth - 1), transcript strand still counted
         const uint32_t h = (base >> 1) & 3u;
