@@ -438,6 +438,80 @@ def test_driver_bam_and_fasta_to_vcf_and_phased_bam(engine_cls, orc, tmp_path):
     assert len(recs) >= b.n_reads and all(r["ref_id"] == [n for n, _ in refs].index("chr20") for r in recs)
 
 
+def _random_batch(seed):
+    """Reads with random CIGAR structure (M / = / X runs, insertions, deletions, introns, soft and hard clips,
+    ops of length 1 next to ops of hundreds of bases), random strands / ts tags / qualities (0 .. 50), two haplotypes
+    with het SNPs, in 1 - 3 regions whose lengths are not multiples of the tile size."""
+    rng = np.random.default_rng(seed)
+    regions, reads = [], []
+    start = 1000
+    for g in range(int(rng.integers(1, 4))):
+        L = int(rng.integers(700, 2600))
+        ref = rng.choice(list("ACGT"), size=L)
+        if rng.random() < 0.5:
+            ref[int(rng.integers(0, L))] = "N"
+        snps = sorted(rng.choice(np.arange(50, L - 50), size=int(rng.integers(2, 14)), replace=False).tolist())
+        alt = {p_: rng.choice([c for c in "ACGT" if c != ref[p_]]) for p_ in snps}
+        n_reads = int(rng.integers(25, 70))
+        rr = []
+        for k in range(n_reads):
+            hap = k % 2
+            pos = int(rng.integers(0, L // 2))
+            rp, seq, cig = pos, [], []
+            if rng.random() < 0.3:
+                cig.append("%dH" % rng.integers(1, 9))
+            if rng.random() < 0.5:
+                n = int(rng.integers(1, 25)); cig.append("%dS" % n); seq.extend(rng.choice(list("ACGT"), size=n))
+            budget = int(rng.integers(150, 900))
+            first = True
+            while rp < L - 5 and budget > 0:
+                u = rng.random()
+                if first or u < 0.62:
+                    n = int(min(L - rp, budget, rng.choice([1, 2, 7, 40, 150, 400])))
+                    for c in range(rp, rp + n):
+                        bse = ref[c] if ref[c] != "N" else "A"
+                        if c in alt and hap == 1:
+                            bse = alt[c]
+                        if rng.random() < 0.02:
+                            bse = rng.choice(list("ACGTN"))
+                        seq.append(bse)
+                    cig.append("%d%s" % (n, rng.choice(["M", "M", "M", "=", "X"]))); rp += n; budget -= n
+                elif u < 0.74:
+                    n = int(rng.choice([1, 1, 2, 5])); cig.append("%dI" % n); seq.extend(rng.choice(list("ACGT"), size=n))
+                elif u < 0.86:
+                    n = int(min(L - rp - 1, rng.choice([1, 1, 3, 30]))); 
+                    if n > 0:
+                        cig.append("%dD" % n); rp += n
+                else:
+                    n = int(min(L - rp - 1, rng.choice([20, 120, 700])))
+                    if n > 0:
+                        cig.append("%dN" % n); rp += n
+                first = False
+            if not cig or cig[-1][-1] in "DNI":   # end on an aligned block
+                n = int(min(L - rp, 10))
+                if n <= 0:
+                    continue
+                seq.extend((ref[c] if ref[c] != "N" else "A") for c in range(rp, rp + n)); cig.append("%dM" % n)
+            if rng.random() < 0.4:
+                n = int(rng.integers(1, 20)); cig.append("%dS" % n); seq.extend(rng.choice(list("ACGT"), size=n))
+            if rng.random() < 0.2:
+                cig.append("%dH" % rng.integers(1, 5))
+            rr.append(dict(pos=start + pos, seq="".join(seq), qual=rng.integers(0, 51, size=len(seq)).tolist(), cigar="".join(cig),
+                           rev=int(rng.integers(0, 2)), ts=int(rng.integers(0, 3)), region=g))
+        rr.sort(key=lambda r: r["pos"])
+        reads.extend(rr)
+        regions.append((start, "".join(ref)))
+        start += L + int(rng.integers(500, 5000))
+    return helpers.mk_batch(reads, regions)
+
+
+@pytest.mark.parametrize("seed", list(range(100, 112)))
+def test_random_cigar_structures(engine_cls, orc, seed):
+    b = _random_batch(seed)
+    preset = ["hifi-masseq", "hifi-isoseq", "ont-cdna", "ont-drna"][seed % 4]
+    full_check(engine_cls, orc, b, _abi.make_params(preset, seed=seed, min_depth=3))
+
+
 def test_empty_batch_and_errors(engine_cls):
     from longcallr_amd.api import LcrError
     p = _abi.make_params()
