@@ -512,6 +512,79 @@ def test_random_cigar_structures(engine_cls, orc, seed):
     full_check(engine_cls, orc, b, _abi.make_params(preset, seed=seed, min_depth=3))
 
 
+def test_driver_on_a_synthetic_two_contig_bam(engine_cls, tmp_path):
+    """pipeline.run (native decode, GPU region discovery, native batching) against the same steps done by the
+    Python restatements (bamio.read_bam / discover_regions / build_batch) on a BAM written from synthetic
+    spliced reads on two contigs: identical VCF text, region for region."""
+    import struct
+    import zlib
+    from longcallr_amd import bamio, pipeline, vcf as vcfmod
+    b = synth.make_batch("ont-cdna", n_genes=6, gene_len=8000, depth=30, seed=77)
+    contig_of = [0, 0, 0, 1, 1, 1]
+    names = ["ctgA", "ctgB"]
+    clen = [int(max(b.start0[g] + b.len[g] for g in range(6) if contig_of[g] == c)) + 777 for c in range(2)]
+    recs = []
+    for g in range(6):
+        for r in range(b.read_begin[g], b.read_begin[g + 1]):
+            so, co, n, nc = int(b.seq_off[r]), int(b.cig_off[r]), int(b.seq_len[r]), int(b.n_cig[r])
+            seq = b.bases[so:so + n]
+            packed = np.zeros((n + 1) // 2, np.uint8)
+            code = np.array([("=ACMGRSVTWYHKDBN").index(chr(c)) for c in seq], np.uint8)
+            packed[:len(code[0::2])] |= code[0::2] << 4
+            packed[:len(code[1::2])] |= code[1::2]
+            fl = int(b.flags[r])
+            aux = (b"tsA+" if (fl >> 1) == 1 else b"tsA-" if (fl >> 1) == 2 else b"") + b"def" + struct.pack("<f", 0.01)
+            name = ("r%d_%d" % (g, r)).encode() + b"\0"
+            body = (struct.pack("<iiBBHHHiiii", contig_of[g], int(b.pos[r]), len(name), 60, 4680, nc, 16 if fl & 1 else 0, n, -1, -1, 0)
+                    + name + b.cigar[co:co + nc].astype("<u4").tobytes() + packed.tobytes() + b.quals[so:so + n].tobytes() + aux)
+            recs.append((contig_of[g], int(b.pos[r]), len(recs), struct.pack("<i", len(body)) + body))
+    recs.sort(key=lambda t: t[:3])
+    text = b"@HD\tVN:1.6\tSO:coordinate\n"
+    raw = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 2)
+    for nm, ln in zip(names, clen):
+        raw += struct.pack("<i", len(nm) + 1) + nm.encode() + b"\0" + struct.pack("<i", ln)
+    raw += b"".join(t[3] for t in recs)
+    out = []
+    for off in list(range(0, len(raw), 60000)) + [None]:
+        chunk = b"" if off is None else raw[off:off + 60000]
+        co_ = zlib.compressobj(1, zlib.DEFLATED, -15)
+        cd = co_.compress(chunk) + co_.flush()
+        out.append(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(cd) + 8 - 1)
+                   + cd + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+    bam = str(tmp_path / "syn.bam")
+    open(bam, "wb").write(b"".join(out))
+    fa = str(tmp_path / "syn.fa")
+    ctg_seq = [np.full(clen[c], ord("N"), np.uint8) for c in range(2)]
+    for g in range(6):
+        o = int(b.col_off[g])
+        ctg_seq[contig_of[g]][int(b.start0[g]):int(b.start0[g]) + int(b.len[g])] = b.ref[o:o + int(b.len[g])]
+    with open(fa, "wb") as f, open(fa + ".fai", "w") as fi:
+        for c in range(2):
+            f.write(b">" + names[c].encode() + b"\n" + ctg_seq[c].tobytes() + b"\n")
+            fi.write("%s\t%d\t0\t%d\t%d\n" % (names[c], clen[c], clen[c], clen[c] + 1))
+    out_vcf = str(tmp_path / "syn.vcf")
+    st = pipeline.run(bam, fa, out_vcf, preset="ont-cdna", threads=4, seed=2025)
+    assert st["contigs"] == 2 and st["reads"] == b.n_reads
+    body = open(out_vcf).read().split("#CHROM")[1].split("\n", 1)[1]
+    # the same with the Python restatements
+    refs, precs = bamio.read_bam(bam)
+    p = _abi.make_params("ont-cdna", seed=2025)
+    want = []
+    n_regions = 0
+    for c in range(2):
+        keep = [r for r in precs if r["ref_id"] == c and bamio.passes_filter(r, **_abi.READ_FILTER)]
+        regions = bamio.discover_regions(keep, c, clen[c])
+        n_regions += len(regions)
+        wins = [ctg_seq[c][s_:s_ + l_] for s_, l_, _ in regions]
+        pb = bamio.build_batch(keep, [(s_, l_) for s_, l_, _ in regions], wins)
+        E = engine_cls(0, p)
+        E.load_batch(pb).run_all()
+        want.append(vcfmod.format_records(E.candidates()[0], names[c], p.min_phase_score))
+        E.close()
+    assert st["regions"] == n_regions == 6
+    assert body == "".join(want) and body.count("\n") >= 8
+
+
 def test_empty_batch_and_errors(engine_cls):
     from longcallr_amd.api import LcrError
     p = _abi.make_params()
