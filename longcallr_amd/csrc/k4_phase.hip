@@ -1995,7 +1995,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
     int nthreads = (int)std::thread::hardware_concurrency() / ndev;
     if (const char* e = getenv("LCR_HOST_THREADS")) nthreads = atoi(e);
-    nthreads = std::max(1, std::min(nthreads, 48));
+    nthreads = std::max(1, std::min(nthreads, getenv("LCR_HOST_THREADS") ? 256 : 48));
     pool = new HostPool(nthreads > 1 ? nthreads : 0);
   }
   auto for_regions = [&](const std::function<void(int)>& fn) { pool->parallel_for(ng, fn); };
