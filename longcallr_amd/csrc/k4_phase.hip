@@ -1999,17 +1999,18 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     pool = new HostPool(nthreads > 1 ? nthreads : 0);
   }
   auto for_regions = [&](const std::function<void(int)>& fn) { pool->parallel_for(ng, fn); };
-  // a helper thread waits for the fragment matrix and prepares the chain regions while this thread sizes and
-  // launches the enumeration; joined before the chain kernels (and on every early return)
+  // the context's helper thread waits for the fragment matrix and prepares the chain regions while this thread sizes
+  // and launches the enumeration; joined before the chain kernels (and on every early return)
+  if (!helper_thread) helper_thread = new HelperThread();
   struct Helper {
-    std::thread t; hipError_t err = hipSuccess;
-    void join() { if (t.joinable()) t.join(); }
+    HelperThread* t; hipError_t err = hipSuccess;
+    void join() { t->join(); }
     ~Helper() { join(); }
-  } helper;
+  } helper{helper_thread};
   {
     int dev = 0;
     PCHK(hipGetDevice(&dev));
-    helper.t = std::thread([&, dev]() {
+    helper_thread->start([&, dev]() {
       if ((helper.err = hipSetDevice(dev)) != hipSuccess) return;
       if ((helper.err = hipEventSynchronize(ev_csr)) != hipSuccess) return;
       pool->parallel_for((int)chain_slots.size(), [&](int k) { prep(chain_slots[k]); });

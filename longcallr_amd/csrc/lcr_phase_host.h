@@ -3,7 +3,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
+#include <semaphore.h>
 #include <thread>
 
 #include "lcr_dev.h"
@@ -28,49 +30,82 @@ struct PhaseInputs {
 
 // Persistent host worker pool: regions are independent units of host-side work (the reference runs
 // them as rayon tasks, thread.rs:77); parallel_for hands out region indices through an atomic counter.
+// Only as many workers as there are items are woken (one semaphore each: a broadcast on a condition variable
+// made every worker take the mutex in turn, ~3 us apiece, whatever the number of items), the caller takes a
+// share of the items itself, and the last worker to finish posts the completion semaphore.
 class HostPool {
  public:
   explicit HostPool(int n) {
-    for (int i = 0; i < n; i++) workers_.emplace_back([this]() { loop(); });
+    sem_init(&done_, 0, 0);
+    for (int i = 0; i < n; i++) {
+      w_.emplace_back(new Worker());
+      sem_init(&w_.back()->go, 0, 0);
+    }
+    for (int i = 0; i < n; i++) w_[i]->t = std::thread([this, i]() { loop(i); });
   }
   ~HostPool() {
-    { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_++; }
-    cv_.notify_all();
-    for (auto& w : workers_) w.join();
+    stop_.store(true);
+    for (auto& w : w_) sem_post(&w->go);
+    for (auto& w : w_) { w->t.join(); sem_destroy(&w->go); }
+    sem_destroy(&done_);
   }
-  int size() const { return (int)workers_.size(); }
+  int size() const { return (int)w_.size(); }
   void parallel_for(int n, const std::function<void(int)>& fn) {
     if (n <= 0) return;
-    if (workers_.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
-    { std::lock_guard<std::mutex> l(m_); fn_ = &fn; n_ = n; next_.store(0); pending_ = (int)workers_.size(); gen_++; }
-    cv_.notify_all();
-    std::unique_lock<std::mutex> l(m_);
-    done_.wait(l, [this]() { return pending_ == 0; });
+    if (w_.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    const int k = std::min(n - 1, (int)w_.size());
+    fn_ = &fn; n_ = n;
+    next_.store(0, std::memory_order_relaxed);
+    pending_.store(k, std::memory_order_release);
+    for (int i = 0; i < k; i++) sem_post(&w_[i]->go);
+    for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) fn(i);
+    while (sem_wait(&done_) != 0) {}   // (EINTR)
     fn_ = nullptr;
   }
  private:
-  void loop() {
-    unsigned long seen = 0;
+  struct Worker { std::thread t; sem_t go; };
+  void loop(int w) {
     for (;;) {
-      const std::function<void(int)>* fn;
-      int n;
-      { std::unique_lock<std::mutex> l(m_);
-        cv_.wait(l, [&]() { return gen_ != seen; });
-        seen = gen_;
-        if (stop_) return;
-        fn = fn_; n = n_; }
+      while (sem_wait(&w_[w]->go) != 0) {}
+      if (stop_.load()) return;
+      const std::function<void(int)>* fn = fn_;
+      const int n = n_;
       for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*fn)(i);
-      { std::lock_guard<std::mutex> l(m_); if (--pending_ == 0) done_.notify_all(); }
+      if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) sem_post(&done_);
     }
   }
-  std::vector<std::thread> workers_;
-  std::mutex m_;
-  std::condition_variable cv_, done_;
+  std::vector<std::unique_ptr<Worker>> w_;
+  sem_t done_;
   const std::function<void(int)>* fn_ = nullptr;
-  int n_ = 0, pending_ = 0;
-  unsigned long gen_ = 0;
-  bool stop_ = false;
-  std::atomic<int> next_{0};
+  int n_ = 0;
+  std::atomic<int> next_{0}, pending_{0};
+  std::atomic<bool> stop_{false};
+};
+
+// One persistent helper thread per context: runs a job beside the calling thread (creating a thread per call costs
+// tens of microseconds at the head of the chain regions' critical path).
+class HelperThread {
+ public:
+  HelperThread() {
+    sem_init(&go_, 0, 0); sem_init(&done_, 0, 0);
+    t_ = std::thread([this]() {
+      for (;;) {
+        while (sem_wait(&go_) != 0) {}
+        if (stop_) return;
+        job_();
+        sem_post(&done_);
+      }
+    });
+  }
+  ~HelperThread() { stop_ = true; sem_post(&go_); t_.join(); sem_destroy(&go_); sem_destroy(&done_); }
+  void start(std::function<void()> job) { job_ = std::move(job); busy_ = true; sem_post(&go_); }
+  void join() { if (busy_) { while (sem_wait(&done_) != 0) {} busy_ = false; } }
+ private:
+  std::thread t_;
+  sem_t go_, done_;
+  std::function<void()> job_;
+  bool busy_ = false;
+  std::atomic<bool> stop_{false};
 };
 
 struct PhaseHost {
@@ -87,6 +122,7 @@ struct PhaseHost {
   hipEvent_t ev_in = nullptr, ev_csr = nullptr, ev_fork = nullptr, ev_join = nullptr;
   hipStream_t aux = nullptr;   // enumeration classes 3 / 4 beside class 2
   HostPool* pool = nullptr;
+  HelperThread* helper_thread = nullptr;
   void* work = nullptr;   // PhaseWork (k4_phase.hip): per-region host state reused across calls
   void free_work();
   int run(const PhaseInputs& in, const lcr_params& p, hipStream_t s, std::string* err);
@@ -99,6 +135,7 @@ struct PhaseHost {
     if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
     if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
     if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
+    delete helper_thread; helper_thread = nullptr;
     delete pool; pool = nullptr;
     free_work();
   }
