@@ -585,6 +585,14 @@ def test_driver_on_a_synthetic_two_contig_bam(engine_cls, tmp_path):
     assert body == "".join(want) and body.count("\n") >= 8
 
 
+@pytest.mark.parametrize("max_enum_snps", [0, 3, 12])
+def test_enumeration_threshold_variants(engine_cls, orc, max_enum_snps):
+    """max_enum_snps moves regions between the 2^S enumeration (12: a region with 11 SNPs = 2048 restarts) and the
+    chain path (0 / 3: every region, phase.rs:1097-1123)."""
+    b = synth.make_batch("ont-drna", n_genes=2, gene_len=12000, depth=35, seed=5)
+    full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=9, max_enum_snps=max_enum_snps))
+
+
 def test_empty_batch_and_errors(engine_cls):
     from longcallr_amd.api import LcrError
     p = _abi.make_params()
