@@ -28,14 +28,15 @@ def test_exports_every_declared_symbol(lib):
 
 def test_struct_layouts_match_the_header(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include "lcr.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include "lcr.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(lcr_reads),sizeof(lcr_regions),sizeof(lcr_params),sizeof(lcr_candidate),sizeof(lcr_fragmat),'
-                   'offsetof(lcr_candidate,loglik),offsetof(lcr_params,seed));return 0;}')
+                   'offsetof(lcr_candidate,loglik),offsetof(lcr_params,seed),sizeof(lcr_read_filter),offsetof(lcr_read_filter,divergence));return 0;}')
     exe = tmp_path / "sz"
     assert os.system("gcc -I%s %s -o %s" % (os.path.join(ROOT, "include"), src, exe)) == 0
     got = [int(x) for x in os.popen(str(exe)).read().split()]
     want = [C.sizeof(_abi.LcrReads), C.sizeof(_abi.LcrRegions), C.sizeof(_abi.LcrParams), _abi.CAND_DTYPE.itemsize,
-            C.sizeof(_abi.LcrFragmat), _abi.CAND_DTYPE.fields["loglik"][1], _abi.LcrParams.seed.offset]
+            C.sizeof(_abi.LcrFragmat), _abi.CAND_DTYPE.fields["loglik"][1], _abi.LcrParams.seed.offset,
+            C.sizeof(_abi.LcrReadFilter), _abi.LcrReadFilter.divergence.offset]
     assert got == want
 
 
