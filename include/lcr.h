@@ -218,6 +218,11 @@ int lcr_get_fragmat(lcr_ctx*, lcr_fragmat* out);
  * eval_rna_edit_var_phase, eval_low_frac_var_phase, assign_phase_set). */
 int lcr_phase(lcr_ctx*, const lcr_params*);
 int lcr_get_phase_result(lcr_ctx*, lcr_phase_result* out);
+/* LD blocks of one region of the last lcr_phase (SNPFrag.ld_blocks, snpfrags.rs:29; built by divide_snps_into_blocks,
+ * candidate.rs:615-747): block b = snp_idx[block_off[b] .. block_off[b + 1]) (candidate indices inside the region), in
+ * the reference's block and node order.  Only regions with more than max_enum_snps candidates build blocks (the
+ * enumeration branch, phase.rs:1097-1122, never reads them): others report n_blocks = 0. */
+int lcr_get_ld_blocks(lcr_ctx*, int32_t region, int32_t* n_blocks, const int32_t** block_off, const int32_t** snp_idx);
 
 /* Region discovery: replaces find_isolated_regions_with_depth (util.rs:236-332, truncation
  * off) for one contig.  ref_start / ref_end are record.reference_start() / reference_end() of the reads that

@@ -130,6 +130,12 @@ class Engine:
                     phase_set=_view(o.phase_set, np.uint32, o.n_rows),
                     objective=_view(o.objective, np.float64, o.n_regions))
 
+    def ld_blocks(self, region):
+        """SNPFrag.ld_blocks of one region after phase(): list of lists of candidate indices (reference order)."""
+        n, off, idx = C.c_int32(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        self._chk(self.lib.lcr_get_ld_blocks(self.h, int(region), C.byref(n), C.byref(off), C.byref(idx)), "lcr_get_ld_blocks")
+        return [[idx[k] for k in range(off[b], off[b + 1])] for b in range(n.value)]
+
     def kernel_ms(self, k):
         ms = C.c_float()
         self._chk(self.lib.lcr_kernel_ms(self.h, k, C.byref(ms)), "lcr_kernel_ms")

@@ -1,0 +1,222 @@
+// k4_dev.h — device code shared by the K4 translation units (k4_phase.hip, k4_grid.hip): counter-based RNG,
+// region / matrix descriptors, the one-workgroup cross_optimize (phase.rs:810-976), wave and workgroup scans.
+// Plain kernel-argument structs are global types; functions live in an anonymous namespace (one copy per translation unit, no RDC).
+#pragma once
+#include "lcr_phase_host.h"   // (pulls in k4_types.h)
+
+namespace {
+
+const double FX_SCALE = 1099511627776.0;  // 2^40
+
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline double u01(uint64_t seed, uint64_t ctr) {
+  uint64_t z = mix64(seed + (ctr + 1) * 0x9E3779B97F4A7C15ULL);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+__host__ __device__ inline uint64_t region_seed(uint64_t seed, int64_t start0) { return mix64(seed + 0xD1B54A32D192ED03ULL * (uint64_t)(start0 + 1)); }
+
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// one cross_optimize (phase.rs:810-976); returns the exact objective (phase.rs:257-276) to all threads.
+// Every emission term is fe[q] + hit * w[q] with w[q] = f1e[q] - fe[q] > 0 and hit = [p == x]
+// (aki, phase.rs:32-49), so per row / column only the data dependent sum of w over the hits is
+// accumulated; the sigma/delta independent parts are per-SNP constants (PhaseDev::snp_const).
+// a region's phase matrix: global memory, or a copy the calling kernel staged in LDS
+struct MatView { const int32_t* rp; const int32_t* pc; const uint8_t* pv; const int32_t* cp; const int32_t* cr; const uint8_t* cv;
+                 const uint8_t* fp; const uint8_t* cons; };
+__device__ __forceinline__ MatView global_view(const PhaseDev& P, const RegionDev& rd) {
+  return MatView{P.prow_ptr + rd.rp_off, P.pcol + rd.e_off, P.pval + rd.e_off, P.ccol_ptr + rd.cp_off, P.crow + rd.e_off,
+                 P.cval + rd.e_off, P.snp_fp + rd.snp_off, P.snp_cons + rd.snp_off};
+}
+__host__ __device__ inline uint32_t matview_bytes(uint32_t R, uint32_t S, uint32_t E) {
+  return 4 * (R + 1) + 4 * (S + 1) + 8 * E + 2 * ((E + 3) & ~3u) + 2 * ((S + 3) & ~3u);
+}
+// copy the region's matrix into LDS at `dst` (4-byte aligned); all threads of the workgroup call
+__device__ __forceinline__ MatView stage_view(const PhaseDev& P, const RegionDev& rd, uint8_t* dst, uint32_t E) {
+  const MatView g = global_view(P, rd);
+  int32_t* rp = (int32_t*)dst; int32_t* cp = rp + rd.R + 1; int32_t* pc = cp + rd.S + 1; int32_t* cr = pc + E;
+  uint8_t* pv = (uint8_t*)(cr + E); uint8_t* cv = pv + ((E + 3) & ~3u); uint8_t* fp = cv + ((E + 3) & ~3u); uint8_t* cons = fp + ((rd.S + 3) & ~3u);
+  for (int i = threadIdx.x; i <= rd.R; i += blockDim.x) rp[i] = g.rp[i];
+  for (int i = threadIdx.x; i <= rd.S; i += blockDim.x) cp[i] = g.cp[i];
+  for (int i = threadIdx.x; i < (int)E; i += blockDim.x) { pc[i] = g.pc[i]; cr[i] = g.cr[i]; pv[i] = g.pv[i]; cv[i] = g.cv[i]; }
+  for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { fp[i] = g.fp[i]; cons[i] = g.cons[i]; }
+  __syncthreads();
+  return MatView{rp, pc, pv, cp, cr, cv, fp, cons};
+}
+
+constexpr int CROSS_MACC = 2048;   // SNPs with a per-column accumulator in LDS (entry-balanced delta step)
+__device__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, const MatView& mv, int8_t* sg, int8_t* dl, int8_t* et,
+                                    bool keep_conserved, bool with_genotype, long long* red, const long long* wl,
+                                    unsigned long long* macc = nullptr /* CROSS_MACC zeros in LDS, or nullptr */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int32_t* rp = mv.rp;
+  const int32_t* pc = mv.pc;
+  const uint8_t* pv = mv.pv;
+  const int32_t* cp = mv.cp;
+  const int32_t* cr = mv.cr;
+  const uint8_t* cv = mv.cv;
+  const uint8_t* fp = mv.fp;
+  const uint8_t* cons = mv.cons;
+  const long long* sc = P.snp_const + 4ll * rd.snp_off;
+  bool hg_inc = true, h_inc = true;
+  int iters = 0;
+  while (hg_inc | h_inc) {
+    // ---- sigma step (phase.rs:824-862): A - B = sum over het sites of (+w if p == sigma*delta else -w);
+    //      flip every row with A < B (sites with eta != 0 contribute equally to both)
+    int any = 0;
+    for (int row = tid; row < rd.R; row += blockDim.x) {
+      const int s = sg[row];
+      long long diff = 0;
+      for (int e = rp[row]; e < rp[row + 1]; e++) {
+        const int i = pc[e];
+        const uint8_t v = pv[e];
+        if (et[i] == 0) { const long long w = wl[v & 31]; diff += (((v & 32) ? 1 : -1) == s * dl[i]) ? w : -w; }
+      }
+      if (diff < 0) { sg[row] = (int8_t)(-s); any = 1; }
+    }
+    any = __syncthreads_or(any);
+    if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
+    // ---- delta/eta step (phase.rs:872-959): per SNP the best of (d,0) (-d,0) (d,+1) (d,-1)
+    any = 0;
+    auto decide = [&](int i, long long M, int ncol) {
+      const int d = dl[i], h = et[i];
+      const long long het = P.lut.f_het0 - (long long)ncol * P.lut.f_log2;  // phase.rs:136-144
+      const long long F = sc[4 * i], W = sc[4 * i + 1];
+      long long N[4] = {F + M + het, F + W - M + het, sc[4 * i + 2] + P.lut.f_homref, sc[4 * i + 3] + P.lut.f_homvar};
+      int ch;
+      if (with_genotype) { ch = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch]) ch = t; }   // phase.rs:908-921
+      else if (h == 0) ch = N[1] > N[0] ? 1 : 0;                                                // phase.rs:923-930
+      else ch = N[3] > N[2] ? 3 : 2;                                                            // phase.rs:931-938
+      const int cur = h == 0 ? 0 : (h == 1 ? 2 : 3);
+      if (N[ch] > N[cur]) any = 1;
+      dl[i] = (int8_t)(ch == 1 ? -d : d);
+      et[i] = (int8_t)(ch <= 1 ? 0 : (ch == 2 ? 1 : -1));
+    };
+    if (macc && rd.S <= CROSS_MACC) {
+      // balanced over the CSC entries (not over the SNPs): thread t takes entries [t*c, (t+1)*c), walks them
+      // in column order and flushes its per-column sum of w over the hits into macc[] (LDS, integer, order-free)
+      const int E = cp[rd.S];
+      const int c = (E + (int)blockDim.x - 1) / (int)blockDim.x;
+      const int e0 = min(E, tid * c), e1 = min(E, e0 + c);
+      if (e0 < e1) {
+        int i; { int lo = 0, hi = rd.S; while (lo < hi) { const int mid = (lo + hi) >> 1; if (cp[mid + 1] <= e0) lo = mid + 1; else hi = mid; } i = lo; }
+        int d = dl[i]; int cend = cp[i + 1];
+        long long M = 0;
+        for (int e = e0; e < e1; e++) {
+          if (e >= cend) {
+            if (M) atomicAdd(&macc[i], (unsigned long long)M);
+            M = 0;
+            do { i++; cend = cp[i + 1]; } while (e >= cend);
+            d = dl[i];
+          }
+          const uint8_t v = cv[e];
+          if (((v & 32) ? 1 : -1) == sg[cr[e]] * d) M += wl[v & 31];
+        }
+        if (M) atomicAdd(&macc[i], (unsigned long long)M);
+      }
+      __syncthreads();
+      for (int i = tid; i < rd.S; i += blockDim.x) {
+        const long long M = (long long)macc[i];
+        macc[i] = 0;
+        if (!fp[i] || (keep_conserved && cons[i]) || cp[i + 1] == cp[i]) continue;
+        decide(i, M, cp[i + 1] - cp[i]);
+      }
+    } else {
+      for (int i = wave; i < rd.S; i += nw) {
+        if (!fp[i]) continue;
+        if (keep_conserved && cons[i]) continue;
+        const int c0 = cp[i], c1 = cp[i + 1];
+        if (c1 == c0) continue;
+        const int d = dl[i];
+        long long M = 0;  // sum of w over the entries with p == sigma * d
+        for (int e = c0 + lane; e < c1; e += 64) {
+          const uint8_t v = cv[e];
+          if (((v & 32) ? 1 : -1) == sg[cr[e]] * d) M += wl[v & 31];
+        }
+        M = wave_sum_ll(M);
+        if (lane == 0) decide(i, M, c1 - c0);
+      }
+    }
+    any = __syncthreads_or(any);
+    if (!any) hg_inc = false; else { hg_inc = true; h_inc = true; }
+    if (++iters > 20) break;  // phase.rs:967-972
+  }
+  // ---- objective (phase.rs:257-276) = f_total + sum of w over the hits
+  long long acc = 0;
+  for (int row = tid; row < rd.R; row += blockDim.x) {
+    const int s = sg[row];
+    for (int e = rp[row]; e < rp[row + 1]; e++) {
+      const int i = pc[e];
+      const uint8_t v = pv[e];
+      const int x = et[i] == 0 ? s * dl[i] : et[i];
+      if (((v & 32) ? 1 : -1) == x) acc += wl[v & 31];
+    }
+  }
+  acc = wave_sum_ll(acc);
+  __syncthreads();
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  long long total = rd.f_total;
+  for (int w = 0; w < nw; w++) total += red[w];
+  __syncthreads();
+  return total;
+}
+
+// w[q] = f1e[q] - fe[q] into LDS (dynamic indexing of a kernel-argument table would go through memory)
+__device__ __forceinline__ void load_w(const PhaseDev& P, long long* wl) {
+  if (threadIdx.x < 32) wl[threadIdx.x] = threadIdx.x < 31 ? P.lut.f1e[threadIdx.x] - P.lut.fe[threadIdx.x] : 0;
+  __syncthreads();
+}
+
+__device__ __forceinline__ int8_t init_genotype(int8_t vt) { return vt == 0 ? 1 : (vt == 1 ? 0 : -1); }  // phase.rs:682-691
+
+#define LCR_DPP_LL(v, ctrl, rmask) \
+  (((long long)__builtin_amdgcn_update_dpp(0, (int)((v) >> 32), ctrl, rmask, 0xf, false) << 32) | \
+   (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xf, false))
+// wave64 sum of int64 through DPP row shifts / broadcasts; every lane gets the total
+__device__ __forceinline__ long long wave_sum_ll_dpp(long long v) {
+  v += LCR_DPP_LL(v, 0x111, 0xf);
+  v += LCR_DPP_LL(v, 0x112, 0xf);
+  v += LCR_DPP_LL(v, 0x114, 0xf);
+  v += LCR_DPP_LL(v, 0x118, 0xf);
+  v += LCR_DPP_LL(v, 0x142, 0xa);
+  v += LCR_DPP_LL(v, 0x143, 0xc);
+  const int lo = __builtin_amdgcn_readlane((int)v, 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+  return ((long long)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// exclusive scan of two ints over a workgroup of NW waves; returns the totals through ta / tb
+template <int NW, int SMW>
+__device__ __forceinline__ void block_scan2n(int a, int b, int& ea, int& eb, int& ta, int& tb, int (*sm)[SMW]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int ia = a, ib = b;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int ua = __shfl_up(ia, d, 64), ub = __shfl_up(ib, d, 64);
+    if (lane >= d) { ia += ua; ib += ub; }
+  }
+  __syncthreads();
+  if (lane == 63) { sm[0][wave] = ia; sm[1][wave] = ib; }
+  __syncthreads();
+  int oa = 0, ob = 0; ta = 0; tb = 0;
+  for (int w = 0; w < NW; w++) { if (w < wave) { oa += sm[0][w]; ob += sm[1][w]; } ta += sm[0][w]; tb += sm[1][w]; }
+  ea = oa + ia - a; eb = ob + ib - b;
+}
+__device__ __forceinline__ void block_scan2(int a, int b, int& ea, int& eb, int& ta, int& tb, int (*sm)[8]) {
+  block_scan2n<4, 8>(a, b, ea, eb, ta, tb, sm);
+}
+
+}  // namespace

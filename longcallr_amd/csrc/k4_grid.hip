@@ -1,0 +1,756 @@
+// k4_grid.hip — the chain regions (S > max_enum_snps, phase.rs:1123-1233) entirely on the device.
+//
+// One code path, two scopes.  Every step of the chain is written against a "scope" that supplies the thread
+// numbering and the barrier: WgScope = one workgroup per region (barrier = __syncthreads; the usual case, a few
+// hundred regions of a batch side by side), GridScope = ALL workgroups of a persistent launch work on ONE region
+// (barrier = a grid-wide barrier on an atomic counter, sigma / delta / eta in HBM, per-SNP sums by 64-bit global
+// atomics) for regions whose matrix is far beyond one CU (BASELINE config C5: one 1 Mb island, 4 10^5 reads x
+// 5 10^3 SNPs, 2 503 cross_optimize calls).  Both scopes compute the same integers in the same fixed-point
+// arithmetic and the same ordered f64 sums, so their results are bit-identical (tested against each other and
+// against the oracle).
+//
+// Steps (reference file:line under /root/reference/src):
+//   ordered_columns   per SNP the phase entries in row order = snp_cover_fragments order (fragment.rs:293-306)
+//   ld_pair_table     allele-pair counts of every SNP pair a read links (fragment.rs:208-240), banded S x W table
+//   ld_graph          perfect-LD pairs (snp.rs:158-188, candidate.rs:626-692) as sorted adjacency lists
+//   ld_components     kosaraju_scc of petgraph on that graph (candidate.rs:733): blocks and their node order
+//   ld_seed           init_haplotypes_LD2 (phase.rs:609-671): random delta, BFS sign propagation inside a block
+//   cross_optimize    phase.rs:810-976 (WgScope: k4_dev.h; GridScope: cross_optimize_grid below)
+//   block_flip        cross_optimize_by_block (phase.rs:1298-1394): f64 sums of ratios in the reference's order
+//   perturbation      phase.rs:1197-1233
+// petgraph facts used (0.6.4; restated, the crate is not in /root/reference): GraphMap keeps nodes in insertion
+// order and adjacency lists in edge-insertion order.  The edges are inserted in (i asc, j asc) order, so every
+// adjacency list is ascending, the first-inserted node of a component is its smallest index, kosaraju_scc emits
+// the components in DESCENDING order of that node, and inside a component the nodes come out in the preorder of
+// a DFS from that node which takes the LARGEST unvisited neighbour first (Dfs pops a stack it pushed in ascending
+// order).  Bfs marks nodes when it pushes them; the first visited node that has a perfect-LD pair with `nx`
+// (phase.rs:628-657) is therefore nx's BFS parent.  With ld_weight_threshold = 1 (thread.rs:166 hard-codes it) no
+// edge is ever removed; other values are rejected by lcr_phase.
+#include "k4_dev.h"
+#include "k4_grid.h"
+
+namespace {
+
+constexpr int CH_THREADS = 1024;
+constexpr int CH_WAVES = CH_THREADS / 64;
+
+// ------------------------------------------------------------------------------------------------------------
+// scopes
+// ------------------------------------------------------------------------------------------------------------
+struct WgScope {
+  long long* red;   // LDS, one per wave
+  __device__ int tid() const { return threadIdx.x; }
+  __device__ int nt() const { return blockDim.x; }
+  __device__ int wave() const { return threadIdx.x >> 6; }
+  __device__ int nwaves() const { return blockDim.x >> 6; }
+  __device__ int blk() const { return 0; }
+  __device__ int nblk() const { return 1; }
+  __device__ void sync() { __syncthreads(); }
+  __device__ int sync_or(int v) { return __syncthreads_or(v); }
+  __device__ long long sync_sum(long long v) {
+    v = wave_sum_ll(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    long long t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += red[w];
+    __syncthreads();
+    return t;
+  }
+};
+
+// All workgroups of the launch are resident (the host sizes the grid with the occupancy API), so spinning on
+// the generation counter cannot starve an unscheduled workgroup.  __threadfence() is an agent-scope fence: it
+// writes this XCD's L2 back before the arrival and invalidates it after the release, which is what makes the
+// other XCDs' plain stores visible (MI355X has one L2 per XCD).
+struct GridScope {
+  GridCtl* c;
+  long long* red;      // LDS, one per wave
+  unsigned long long* bc;   // LDS broadcast slot
+  unsigned gen;        // barriers passed so far (uniform over the grid)
+  __device__ int tid() const { return blockIdx.x * blockDim.x + threadIdx.x; }
+  __device__ int nt() const { return gridDim.x * blockDim.x; }
+  __device__ int wave() const { return tid() >> 6; }
+  __device__ int nwaves() const { return nt() >> 6; }
+  __device__ int blk() const { return blockIdx.x; }
+  __device__ int nblk() const { return gridDim.x; }
+  __device__ void arrive_wait_() {   // thread 0 of the workgroup
+    const unsigned g = gen;
+    __threadfence();
+    if (atomicAdd(&c->arrive, 1u) == gridDim.x - 1) {
+      // last arriver: the slots of parity (g+1) were read before their readers arrived here and are written again
+      // only after this barrier opens
+      __hip_atomic_store(&c->flag[(g + 1) & 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&c->acc[(g + 1) & 1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&c->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+      __hip_atomic_store(&c->gen, g + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(&c->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) __builtin_amdgcn_s_sleep(1);
+    }
+    __threadfence();
+  }
+  __device__ void sync() {
+    __syncthreads();
+    if (threadIdx.x == 0) arrive_wait_();
+    gen++;
+    __syncthreads();
+  }
+  __device__ int sync_or(int v) {
+    v = __syncthreads_or(v);
+    if (threadIdx.x == 0) {
+      if (v) atomicOr(&c->flag[gen & 1], 1u);
+      arrive_wait_();
+      *bc = __hip_atomic_load(&c->flag[gen & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gen++;
+    __syncthreads();
+    const int r = (int)*bc;
+    __syncthreads();
+    return r;
+  }
+  __device__ long long sync_sum(long long v) {
+    v = wave_sum_ll(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long t = 0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += red[w];
+      if (t) atomicAdd(&c->acc[gen & 1], (unsigned long long)t);
+      arrive_wait_();
+      *bc = __hip_atomic_load(&c->acc[gen & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gen++;
+    __syncthreads();
+    const long long r = (long long)*bc;
+    __syncthreads();
+    return r;
+  }
+};
+
+// a wave's own stores, made by one lane, before loads of the same addresses by its other lanes
+__device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
+// region-relative views the chain steps work on
+struct ChainView {
+  int g, S, R, nrow, c0, r0, W, n_parts;
+  int64_t e_base;                 // first entry of the region in K3's matrix
+  MatView mv;                     // phase matrix (global memory)
+  int8_t *sg, *dl, *et;           // working state
+  int8_t *bsg, *bdl, *bet;        // best state
+  uint32_t* tbl; int32_t* adj; int32_t* pcnt;
+  int32_t *adj_ptr, *blk_ptr, *blk_of, *blk_pos, *blk_nodes, *stack, *queue, *blk_info, *flipcol, *erow, *cent;
+  uint8_t *seen, *ok, *cons; int8_t* new_hap;
+  double *qs, *qfs;
+  const int8_t* vt; const uint8_t* fp;
+  const int32_t* prow_src;
+};
+
+__device__ ChainView make_view(const ChainDev& C, const ChainDesc& d, const RegionDev& rd) {
+  ChainView v;
+  v.g = d.slot; v.S = rd.S; v.R = rd.R; v.W = d.W; v.n_parts = d.n_parts;
+  v.r0 = C.row_region_off[v.g]; v.nrow = C.row_region_off[v.g + 1] - v.r0;
+  v.c0 = C.cand_off[v.g];
+  v.e_base = C.row_ptr[v.r0];
+  v.mv = global_view(C.P, rd);
+  v.bsg = C.P.st_sigma + rd.sig_off; v.bdl = C.P.st_delta + rd.snp_off; v.bet = C.P.st_eta + rd.snp_off;
+  v.sg = C.w_sigma + rd.sig_off; v.dl = C.w_delta + rd.snp_off; v.et = C.w_eta + rd.snp_off;
+  v.tbl = C.ld_tbl + 2 * d.tbl_off; v.adj = C.ld_adj + d.adj_off; v.pcnt = C.part_cnt + d.part_off;
+  v.adj_ptr = C.adj_ptr + rd.cp_off; v.blk_ptr = C.blk_ptr + rd.cp_off;
+  v.blk_of = C.blk_of + rd.snp_off; v.blk_pos = C.blk_pos + rd.snp_off; v.blk_nodes = C.blk_nodes + rd.snp_off;
+  v.stack = C.stack + 2 * (int64_t)rd.snp_off; v.queue = C.queue + rd.snp_off; v.blk_info = C.blk_info + 2 * v.g;
+  v.flipcol = C.flipcol + rd.sig_off; v.erow = C.erow + rd.e_off; v.cent = C.cent + rd.e_off;
+  v.seen = C.seen + rd.snp_off; v.ok = C.ld_ok + rd.snp_off; v.cons = const_cast<uint8_t*>(C.P.snp_cons) + rd.snp_off;
+  v.new_hap = C.new_hap + rd.snp_off;
+  v.qs = C.qs + rd.snp_off; v.qfs = C.qfs + rd.snp_off;
+  v.vt = C.P.snp_vt + rd.snp_off; v.fp = C.P.snp_fp + rd.snp_off;
+  v.prow_src = C.prow_src + rd.sig_off;
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// ordered column index: cent[cp[i] .. cp[i+1]) = the phase entries (indices into the CSR) of SNP i in row order,
+// erow[e] = phasing row of entry e.  Stable counting sort by column: the rows are cut into n_parts runs, entries
+// are counted per (part, SNP), and each part is filled by one wave, 64 entries at a time in CSR order.
+// ------------------------------------------------------------------------------------------------------------
+template <class SC>
+__device__ void ordered_columns(SC& sc, const ChainView& v) {
+  const int S = v.S, R = v.R, np = v.n_parts;
+  const int rq = max(1, (R + np - 1) / np);
+  const int32_t* rp = v.mv.rp; const int32_t* pc = v.mv.pc; const int32_t* cp = v.mv.cp;
+  for (int64_t i = sc.tid(); i < (int64_t)np * S; i += sc.nt()) v.pcnt[i] = 0;
+  sc.sync();
+  for (int row = sc.tid(); row < R; row += sc.nt()) {
+    int32_t* cnt = v.pcnt + (int64_t)(row / rq) * S;
+    for (int e = rp[row]; e < rp[row + 1]; e++) { v.erow[e] = row; atomicAdd(&cnt[pc[e]], 1); }
+  }
+  sc.sync();
+  for (int i = sc.tid(); i < S; i += sc.nt()) {
+    int at = cp[i];
+    for (int q = 0; q < np; q++) { int32_t* p = v.pcnt + (int64_t)q * S + i; const int n = *p; *p = at; at += n; }
+  }
+  sc.sync();
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int q = sc.wave(); q < np; q += sc.nwaves()) {
+    int32_t* cur = v.pcnt + (int64_t)q * S;
+    const int e_lo = rp[min(q * rq, R)], e_hi = rp[(int)min((int64_t)(q + 1) * rq, (int64_t)R)];
+    for (int base = e_lo; base < e_hi; base += 64) {
+      const int e = base + lane;
+      const bool valid = e < e_hi;
+      const int c = valid ? pc[e] : -1;
+      const int at = valid ? cur[c] : 0;          // all cursor reads of the chunk precede its cursor writes
+      unsigned long long rem = __ballot(valid), mine = 0;
+      while (rem) {                               // lanes with equal columns, in lane (= row) order
+        const int cc = __shfl(c, __ffsll((long long)rem) - 1, 64);
+        const unsigned long long m = __ballot(c == cc);
+        if (c == cc) mine = m;
+        rem &= ~m;
+      }
+      if (valid) {
+        const int rank = __popcll(mine & below);
+        v.cent[at + rank] = e;
+        if (rank == 0) cur[c] = at + __popcll(mine);
+      }
+      wave_mem_sync();
+    }
+  }
+  sc.sync();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LD blocks: pair table -> graph -> components (kosaraju order) -> LD-seeded start haplotypes
+// ------------------------------------------------------------------------------------------------------------
+template <class SC>
+__device__ void ld_pair_table(SC& sc, const ChainDev& C, const ChainView& v) {
+  const int S = v.S, W = v.W;
+  for (int64_t i = sc.tid(); i < 2ll * S * W; i += sc.nt()) v.tbl[i] = 0;
+  for (int i = sc.tid(); i < S; i += sc.nt()) {
+    const lcr_candidate& c = C.cand[v.c0 + i];
+    // for_phasing, exactly one of the two major alleles is the reference (candidate.rs:637-660), both fractions non-zero
+    v.ok[i] = (v.fp[i] && ((c.allele1 == c.ref_base) != (c.allele2 == c.ref_base)) && c.af1 != 0.0f && c.af2 != 0.0f) ? 1 : 0;
+    v.blk_of[i] = -1; v.seen[i] = 0; v.cons[i] = 0;
+  }
+  sc.sync();
+  // every fragment row, every pair of its entries (fragment.rs:208-240); only pairs of eligible SNPs are ever looked up
+  for (int r = sc.tid(); r < v.nrow; r += sc.nt()) {
+    const int64_t eb = C.row_ptr[v.r0 + r], ee = C.row_ptr[v.r0 + r + 1];
+    for (int64_t x = eb; x < ee; x++) {
+      const int i = C.col[x] - v.c0;
+      if (!v.ok[i]) continue;
+      const int pi = C.val[x] & 32;
+      for (int64_t y = x + 1; y < ee; y++) {
+        const int j = C.col[y] - v.c0;
+        if (!v.ok[j]) continue;
+        atomicAdd(&v.tbl[2 * ((int64_t)i * W + (j - i - 1)) + (((C.val[y] & 32) != pi) ? 1 : 0)], 1u);
+      }
+    }
+  }
+  sc.sync();
+}
+
+// perfect LD (snp.rs:158-188: score = c1 / c2 == 0 with c2 > 0): reads support cis or trans, never both
+__device__ __forceinline__ int ld_pass(const ChainView& v, int a, int b) {   // a < b <= a + W; 0: no edge, 1: cis (+), 2: trans (-)
+  if (!v.ok[a] || !v.ok[b]) return 0;
+  const uint32_t* t = v.tbl + 2 * ((int64_t)a * v.W + (b - a - 1));
+  const uint32_t cis = t[0], trans = t[1];
+  if ((cis > 0) == (trans > 0)) return 0;
+  return cis > 0 ? 1 : 2;
+}
+
+template <class SC>
+__device__ void ld_graph(SC& sc, const ChainView& v, int (*sm)[16]) {
+  const int S = v.S, W = v.W;
+  for (int i = sc.tid(); i < S; i += sc.nt()) {
+    int deg = 0;
+    if (v.ok[i]) {
+      for (int a = max(0, i - W); a < i; a++) deg += ld_pass(v, a, i) ? 1 : 0;
+      for (int b = i + 1; b <= min(S - 1, i + W); b++) deg += ld_pass(v, i, b) ? 1 : 0;
+    }
+    v.queue[i] = deg;
+  }
+  sc.sync();
+  if (sc.blk() == 0) {   // exclusive scan of the degrees (one workgroup)
+    int carry = 0;
+    for (int base = 0; base < S; base += CH_THREADS) {
+      const int i = base + threadIdx.x;
+      const int d = i < S ? v.queue[i] : 0;
+      int ex, d0, tot, d1;
+      block_scan2n<CH_WAVES, 16>(d, 0, ex, d0, tot, d1, sm);
+      if (i < S) v.adj_ptr[i] = carry + ex;
+      carry += tot;
+    }
+    if (threadIdx.x == 0) v.adj_ptr[S] = carry;
+  }
+  sc.sync();
+  for (int i = sc.tid(); i < S; i += sc.nt()) {
+    if (!v.ok[i]) continue;
+    int at = v.adj_ptr[i];
+    for (int a = max(0, i - W); a < i; a++) { const int p = ld_pass(v, a, i); if (p) v.adj[at++] = a | (p == 2 ? (int)0x80000000 : 0); }
+    for (int b = i + 1; b <= min(S - 1, i + W); b++) { const int p = ld_pass(v, i, b); if (p) v.adj[at++] = b | (p == 2 ? (int)0x80000000 : 0); }
+  }
+  sc.sync();
+}
+
+// kosaraju_scc's output for this graph (see the header): blocks numbered in ASCENDING order of their smallest node
+// (block 0 is the one the reference visits LAST), nodes of a block in the reference's order.  One wave.
+__device__ void ld_components_wave(const ChainView& v) {
+  const int S = v.S, lane = threadIdx.x & 63;
+  int nb = 0, out = 0;
+  for (int r = 0; r < S; r++) {
+    if (v.adj_ptr[r + 1] == v.adj_ptr[r] || v.seen[r]) continue;   // (uniform)
+    const int start = out;
+    int sp = 0;
+    auto visit = [&](int x) {
+      if (lane == 0) { v.seen[x] = 1; v.blk_nodes[out] = x; v.blk_of[x] = nb; v.blk_pos[x] = out - start; }
+      out++;
+    };
+    visit(r);
+    int x = r, cur = v.adj_ptr[r + 1] - v.adj_ptr[r];   // top of the stack in registers
+    wave_mem_sync();
+    for (;;) {
+      // the largest unvisited neighbour of x below position cur
+      int found = -1;
+      const int base = v.adj_ptr[x];
+      while (cur > 0 && found < 0) {
+        const int lo = max(0, cur - 64), idx = lo + lane;
+        const bool valid = idx < cur;
+        const int y = valid ? (v.adj[base + idx] & 0x7fffffff) : 0;
+        const bool uns = valid && !v.seen[y];
+        const unsigned long long m = __ballot(uns);
+        if (m) { const int hi = 63 - __clzll((long long)m); found = __shfl(y, hi, 64); cur = lo + hi; }
+        else cur = lo;
+      }
+      if (found < 0) {
+        if (sp == 0) break;
+        sp--;
+        int px = 0, pc_ = 0;
+        if (lane == 0) { px = v.stack[2 * sp]; pc_ = v.stack[2 * sp + 1]; }
+        x = __shfl(px, 0, 64); cur = __shfl(pc_, 0, 64);
+      } else {
+        if (lane == 0) { v.stack[2 * sp] = x; v.stack[2 * sp + 1] = cur; }
+        sp++;
+        visit(found);
+        x = found; cur = v.adj_ptr[found + 1] - v.adj_ptr[found];
+        wave_mem_sync();
+      }
+    }
+    nb++;
+    if (lane == 0) v.blk_ptr[nb] = out;
+  }
+  if (lane == 0) { v.blk_ptr[0] = 0; v.blk_info[0] = nb; v.blk_info[1] = 0; }
+  wave_mem_sync();
+}
+
+// init_haplotypes_LD2 (phase.rs:609-671) for the blocks: first node = hap 1, every other node takes its BFS parent's
+// haplotype times the sign of their pair's weight; block members are "conserved".  One wave; delta holds the random draws.
+__device__ void ld_seed_wave(const ChainView& v) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int nb = v.blk_info[0];
+  for (int b = 0; b < nb; b++) {
+    const int n0 = v.blk_ptr[b], n1 = v.blk_ptr[b + 1];
+    const int start = v.blk_nodes[n0];
+    int qh = 0, qt = 1;
+    if (lane == 0) { v.queue[0] = start; v.seen[start] = 2; v.dl[start] = 1; }
+    wave_mem_sync();
+    while (qh < qt) {
+      const int nx = v.queue[qh++];
+      const int hnx = v.dl[nx];
+      const int a0 = v.adj_ptr[nx], a1 = v.adj_ptr[nx + 1];
+      for (int base = a0; base < a1; base += 64) {
+        const int idx = base + lane;
+        const bool valid = idx < a1;
+        const int raw = valid ? v.adj[idx] : 0;
+        const int y = raw & 0x7fffffff;
+        const bool und = valid && v.seen[y] != 2;
+        const unsigned long long m = __ballot(und);
+        if (und) { v.seen[y] = 2; v.dl[y] = (int8_t)(raw < 0 ? -hnx : hnx); v.queue[qt + __popcll(m & below)] = y; }
+        qt += __popcll(m);
+        wave_mem_sync();
+      }
+    }
+    for (int k = n0 + lane; k < n1; k += 64) v.cons[v.blk_nodes[k]] = 1;
+  }
+  wave_mem_sync();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// cross_optimize at grid scope (phase.rs:810-976): the arithmetic of k4_dev.h's cross_optimize with the state in
+// HBM; the per-SNP sums are entry-balanced (a thread owns a fixed run of CSC entries for the whole launch).
+// ------------------------------------------------------------------------------------------------------------
+__device__ long long cross_optimize_scope(GridScope& sc, const PhaseDev& P, const RegionDev& rd, const ChainView& v, bool keep_conserved,
+                                          bool with_genotype, const long long* wl, unsigned long long* macc, int e0, int e1, int i_first) {
+  const int32_t* rp = v.mv.rp; const int32_t* pc = v.mv.pc; const uint8_t* pv = v.mv.pv;
+  const int32_t* cp = v.mv.cp; const int32_t* cr = v.mv.cr; const uint8_t* cv = v.mv.cv;
+  const uint8_t* fp = v.mv.fp; const uint8_t* cons = v.mv.cons;
+  int8_t* sg = v.sg; int8_t* dl = v.dl; int8_t* et = v.et;
+  const long long* scn = P.snp_const + 4ll * rd.snp_off;
+  const int tid = sc.tid(), nt = sc.nt();
+  bool hg_inc = true, h_inc = true;
+  int iters = 0;
+  while (hg_inc | h_inc) {
+    int any = 0;
+    for (int row = tid; row < rd.R; row += nt) {
+      const int s = sg[row];
+      long long diff = 0;
+      for (int e = rp[row]; e < rp[row + 1]; e++) {
+        const int i = pc[e];
+        const uint8_t x = pv[e];
+        if (et[i] == 0) { const long long w = wl[x & 31]; diff += (((x & 32) ? 1 : -1) == s * dl[i]) ? w : -w; }
+      }
+      if (diff < 0) { sg[row] = (int8_t)(-s); any = 1; }
+    }
+    any = sc.sync_or(any);
+    if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
+    if (e0 < e1) {
+      int i = i_first;
+      int d = dl[i]; int cend = cp[i + 1];
+      long long M = 0;
+      for (int e = e0; e < e1; e++) {
+        if (e >= cend) {
+          if (M) atomicAdd(&macc[i], (unsigned long long)M);
+          M = 0;
+          do { i++; cend = cp[i + 1]; } while (e >= cend);
+          d = dl[i];
+        }
+        const uint8_t x = cv[e];
+        if (((x & 32) ? 1 : -1) == sg[cr[e]] * d) M += wl[x & 31];
+      }
+      if (M) atomicAdd(&macc[i], (unsigned long long)M);
+    }
+    sc.sync();
+    any = 0;
+    for (int i = tid; i < rd.S; i += nt) {
+      const long long M = (long long)macc[i];
+      macc[i] = 0;
+      const int ncol = cp[i + 1] - cp[i];
+      if (!fp[i] || (keep_conserved && cons[i]) || ncol == 0) continue;
+      const int d = dl[i], h = et[i];
+      const long long het = P.lut.f_het0 - (long long)ncol * P.lut.f_log2;
+      const long long F = scn[4 * i], Wt = scn[4 * i + 1];
+      const long long N[4] = {F + M + het, F + Wt - M + het, scn[4 * i + 2] + P.lut.f_homref, scn[4 * i + 3] + P.lut.f_homvar};
+      int ch;
+      if (with_genotype) { ch = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch]) ch = t; }
+      else if (h == 0) ch = N[1] > N[0] ? 1 : 0;
+      else ch = N[3] > N[2] ? 3 : 2;
+      const int cur = h == 0 ? 0 : (h == 1 ? 2 : 3);
+      if (N[ch] > N[cur]) any = 1;
+      dl[i] = (int8_t)(ch == 1 ? -d : d);
+      et[i] = (int8_t)(ch <= 1 ? 0 : (ch == 2 ? 1 : -1));
+    }
+    any = sc.sync_or(any);
+    if (!any) hg_inc = false; else { hg_inc = true; h_inc = true; }
+    if (++iters > 20) break;
+  }
+  long long acc = 0;
+  for (int row = tid; row < rd.R; row += nt) {
+    const int s = sg[row];
+    for (int e = rp[row]; e < rp[row + 1]; e++) {
+      const int i = pc[e];
+      const uint8_t x = pv[e];
+      const int xx = et[i] == 0 ? s * dl[i] : et[i];
+      if (((x & 32) ? 1 : -1) == xx) acc += wl[x & 31];
+    }
+  }
+  return rd.f_total + sc.sync_sum(acc);
+}
+
+// exact objective of the working state (phase.rs:257-276)
+template <class SC>
+__device__ long long objective_scope(SC& sc, const RegionDev& rd, const ChainView& v, const long long* wl) {
+  long long acc = 0;
+  for (int row = sc.tid(); row < rd.R; row += sc.nt()) {
+    const int s = v.sg[row];
+    for (int e = v.mv.rp[row]; e < v.mv.rp[row + 1]; e++) {
+      const int i = v.mv.pc[e];
+      const uint8_t x = v.mv.pv[e];
+      const int xx = v.et[i] == 0 ? s * v.dl[i] : v.et[i];
+      if (((x & 32) ? 1 : -1) == xx) acc += wl[x & 31];
+    }
+  }
+  return rd.f_total + sc.sync_sum(acc);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// cross_optimize_by_block (phase.rs:1298-1394).  For every block: q = sum over its SNPs (block order) of
+// cal_delta_eta_sigma_log on the current state, q_flip = the same with delta negated and the haplotag negated for the
+// observations whose read has only block members up to and including that SNP (`flip_read`, phase.rs:1331-1349: an
+// entry BEFORE the SNP that is not in the block vetoes, entries after it are not looked at yet).  q < q_flip flips the
+// block's SNPs; every block rewrites the haplotag of every read (phase.rs:1364-1378), so only the version of the block
+// the reference visits last (block 0 here) survives.  f64 sums in the reference's observation order.
+// ------------------------------------------------------------------------------------------------------------
+struct FlipLut { double le[32], l1e[32]; double p_homref, p_homvar, log_theta, log2; };
+__device__ __forceinline__ double lgf(const FlipLut& L, int sigma, int delta, int eta, uint8_t x) {   // log10(aki(...)), phase.rs:32-49
+  const int pp = (x & 32) ? 1 : -1, xx = eta == 0 ? sigma * delta : eta;
+  return pp == xx ? L.l1e[x & 31] : L.le[x & 31];
+}
+constexpr int SSTR = 65;   // stage row stride in doubles
+
+// ordered sums over the phase entries of column i (row order): lane a < 4 accumulates term a of every entry in order
+template <class Term>
+__device__ __forceinline__ void col_sums4(double* stg, const ChainView& v, int i, Term term, double* acc) {
+  const int lane = threadIdx.x & 63;
+  double mine = 0.0;
+  const int kb = v.mv.cp[i], ke = v.mv.cp[i + 1];
+  for (int k0 = kb; k0 < ke; k0 += 64) {
+    const int k = k0 + lane;
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    if (k < ke) { const int e = v.cent[k]; term(v.erow[e], v.mv.pv[e], t); }
+#pragma unroll
+    for (int a = 0; a < 4; a++) stg[a * SSTR + lane] = t[a];
+    wave_lds_sync();
+    const int nk = min(64, ke - k0);
+    if (lane < 4) {
+      const double* src = stg + lane * SSTR;
+      int j = 0;
+      for (; j + 8 <= nk; j += 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = src[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) mine += x[u];
+      }
+      for (; j < nk; j++) mine += src[j];
+    }
+    wave_lds_sync();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+    acc[a] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), a), __builtin_amdgcn_readlane(__double2loint(mine), a));
+}
+
+template <class SC>
+__device__ void block_flip(SC& sc, const ChainDev& C, const ChainView& v, const FlipLut& L, double* stage /* per wave 4*SSTR */) {
+  const int lane = threadIdx.x & 63;
+  const int nb = __hip_atomic_load(&v.blk_info[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (nb == 0) return;   // (uniform) no block: the pass changes nothing and the objective equals launch A's
+  // flip_read of (row, SNP idx) <=> idx <= flipcol[row]: the last column of the row's leading run of entries that all
+  // belong to the block of its first entry
+  for (int k = sc.tid(); k < v.R; k += sc.nt()) {
+    const int r = v.prow_src[k];
+    const int64_t eb = C.row_ptr[v.r0 + r], ee = C.row_ptr[v.r0 + r + 1];
+    int last = -1;
+    if (eb < ee) {
+      const int b0 = v.blk_of[C.col[eb] - v.c0];
+      if (b0 >= 0)
+        for (int64_t e = eb; e < ee; e++) { const int ci = C.col[e] - v.c0; if (v.blk_of[ci] != b0) break; last = ci; }
+    }
+    v.flipcol[k] = last;
+  }
+  sc.sync();
+  // per block SNP: the two ratio scores (ColScores of the host path = cal_delta_eta_sigma_log, phase.rs:128-176)
+  double* stg = stage + (threadIdx.x >> 6) * (4 * SSTR);
+  const int n_nodes = v.blk_ptr[nb];
+  for (int t = sc.wave(); t < n_nodes; t += sc.nwaves()) {
+    const int idx = v.blk_nodes[t];
+    const int d = v.dl[idx], h = v.et[idx];
+    const int n = v.mv.cp[idx + 1] - v.mv.cp[idx];
+    const double p_het = n == 0 ? L.log_theta : L.log_theta - (double)(uint32_t)n * L.log2;
+    auto score = [&](const double* s) -> double {   // s = {het_d, het_nd, homref, homvar}; score(+1, h)
+      double q1 = h == 0 ? s[0] : (h == 1 ? s[2] : s[3]);
+      q1 += h == 0 ? p_het : (h == 1 ? L.p_homref : L.p_homvar);
+      const double q2 = s[3] + L.p_homvar, q3 = s[0] + p_het, q4 = s[2] + L.p_homref, q5 = s[1] + p_het;
+      return 1.0 - q1 / (q2 + q3 + q4 + q5);
+    };
+    double a[4], b[4];
+    col_sums4(stg, v, idx, [&](int k, uint8_t x, double* tt) {
+      const int s = v.sg[k];
+      tt[0] = lgf(L, s, d, 0, x); tt[1] = lgf(L, s, -d, 0, x); tt[2] = lgf(L, s, d, 1, x); tt[3] = lgf(L, s, d, -1, x);
+    }, a);
+    col_sums4(stg, v, idx, [&](int k, uint8_t x, double* tt) {
+      const int s = idx <= v.flipcol[k] ? -v.sg[k] : v.sg[k];
+      tt[0] = lgf(L, s, -d, 0, x); tt[1] = lgf(L, s, d, 0, x); tt[2] = lgf(L, s, -d, 1, x); tt[3] = lgf(L, s, -d, -1, x);
+    }, b);
+    if (lane == 0) { v.qs[idx] = score(a); v.qfs[idx] = score(b); }
+  }
+  sc.sync();
+  // per block: sums in block order, verdict, new haplotypes (a wave per block; lane 0 adds in order)
+  for (int bk = sc.wave(); bk < nb; bk += sc.nwaves()) {
+    const int n0 = v.blk_ptr[bk], n1 = v.blk_ptr[bk + 1];
+    double q = 0.0, qf = 0.0;
+    for (int k0 = n0; k0 < n1; k0 += 64) {
+      const int k = k0 + lane;
+      double x = 0.0, y = 0.0;
+      if (k < n1) { const int idx = v.blk_nodes[k]; x = v.qs[idx]; y = v.qfs[idx]; }
+      const int nk = min(64, n1 - k0);
+      for (int j = 0; j < nk; j++) {
+        q += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), j), __builtin_amdgcn_readlane(__double2loint(x), j));
+        qf += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y), j), __builtin_amdgcn_readlane(__double2loint(y), j));
+      }
+    }
+    const bool flip = q < qf;
+    for (int k = n0 + lane; k < n1; k += 64) { const int idx = v.blk_nodes[k]; v.new_hap[idx] = (int8_t)(flip ? -v.dl[idx] : v.dl[idx]); }
+    if (bk == 0 && lane == 0) v.blk_info[1] = flip ? 1 : 0;
+  }
+  sc.sync();
+  // haplotags: the flipped version of block 0 if it flips -- per read the value written for the last SNP (block order)
+  // it covers (phase.rs:1343-1349 inserts in SNP order, later inserts overwrite)
+  const int flip0 = __hip_atomic_load(&v.blk_info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (flip0)
+    for (int k = sc.tid(); k < v.R; k += sc.nt()) {
+      int best_pos = -1, best_ci = -1;
+      for (int e = v.mv.rp[k]; e < v.mv.rp[k + 1]; e++) {
+        const int ci = v.mv.pc[e];
+        if (v.blk_of[ci] == 0 && v.blk_pos[ci] > best_pos) { best_pos = v.blk_pos[ci]; best_ci = ci; }
+      }
+      if (best_ci >= 0 && best_ci <= v.flipcol[k]) v.sg[k] = (int8_t)(-v.sg[k]);
+    }
+  for (int t = sc.tid(); t < n_nodes; t += sc.nt()) { const int idx = v.blk_nodes[t]; v.dl[idx] = v.new_hap[idx]; }
+  sc.sync();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the chain, written once for both scopes
+// ------------------------------------------------------------------------------------------------------------
+template <class SC, class Cross>
+__device__ void chain_run(SC& sc, const ChainDev& C, const RegionDev& rd, const ChainView& v, const long long* wl, const FlipLut& L,
+                          double* stage, int (*sm)[16], Cross cross, int slot) {
+  const int S = rd.S, R = rd.R;
+  ordered_columns(sc, v);
+  ld_pair_table(sc, C, v);
+  ld_graph(sc, v, sm);
+  // start state (phase.rs:1124-1131): random delta (draws S+F ..), genotype from the variant type, random sigma
+  const uint64_t SF = (uint64_t)S + (uint64_t)R;
+  for (int i = sc.tid(); i < S; i += sc.nt()) { v.dl[i] = u01(rd.seed, SF + i) < 0.5 ? 1 : -1; v.et[i] = init_genotype(v.vt[i]); }
+  for (int row = sc.tid(); row < R; row += sc.nt()) v.sg[row] = u01(rd.seed, SF + S + row) < 0.5 ? -1 : 1;
+  sc.sync();
+  if (sc.blk() == 0 && (threadIdx.x >> 6) == 0) { ld_components_wave(v); ld_seed_wave(v); }
+  sc.sync();
+  long long best = cross(true, false);
+  auto save = [&]() {
+    for (int i = sc.tid(); i < S; i += sc.nt()) { v.bdl[i] = v.dl[i]; v.bet[i] = v.et[i]; }
+    for (int row = sc.tid(); row < R; row += sc.nt()) v.bsg[row] = v.sg[row];
+  };
+  auto load = [&]() {
+    for (int i = sc.tid(); i < S; i += sc.nt()) { v.dl[i] = v.bdl[i]; v.et[i] = v.bet[i]; }
+    for (int row = sc.tid(); row < R; row += sc.nt()) v.sg[row] = v.bsg[row];
+  };
+  save();   // (every thread saves / loads / perturbs the same elements: no barrier between those steps)
+  block_flip(sc, C, v, L, stage);
+  {
+    const long long obj = objective_scope(sc, rd, v, wl);
+    if (obj > best) { best = obj; save(); }   // `prob > largest_prob` (phase.rs:1140-1144)
+    load();
+  }
+  for (int tidx = 0; tidx <= S / 4; tidx++) {   // phase.rs:1198-1233
+    const uint64_t ctr_t = 2 * SF + (uint64_t)tidx * SF;
+    const bool flip = (tidx & 1) == 1;
+    for (int i = sc.tid(); i < S; i += sc.nt()) {
+      const double rg = u01(rd.seed, ctr_t + i);
+      if (rg < 0.1) v.dl[i] = flip ? 1 : -1;
+      else if (rg >= 0.9) v.dl[i] = flip ? -1 : 1;
+    }
+    sc.sync();
+    long long obj = cross(false, false);
+    if (obj > best) { best = obj; save(); }
+    load();
+    for (int row = sc.tid(); row < R; row += sc.nt())
+      if (u01(rd.seed, ctr_t + S + row) < 0.1) v.sg[row] = (int8_t)(-v.sg[row]);
+    sc.sync();
+    obj = cross(false, false);
+    if (obj > best) { best = obj; save(); }
+    load();
+  }
+  if (sc.tid() == 0) C.P.st_obj[slot] = best;
+}
+
+__device__ __forceinline__ void load_flip_lut(const ChainDev& C, FlipLut* L) {
+  if (threadIdx.x < 32) { L->le[threadIdx.x] = threadIdx.x < 31 ? C.le[threadIdx.x] : 0.0; L->l1e[threadIdx.x] = threadIdx.x < 31 ? C.l1e[threadIdx.x] : 0.0; }
+  if (threadIdx.x == 0) { L->p_homref = C.p_homref; L->p_homvar = C.p_homvar; L->log_theta = C.log_theta; L->log2 = C.log2; }
+}
+
+// one workgroup per chain region; the working state (and the matrix, when it fits) lives in dynamic LDS
+__global__ void __launch_bounds__(CH_THREADS) k4_chain_wg(ChainDev C, int32_t first, int32_t n) {
+  __shared__ long long red[CH_WAVES];
+  __shared__ unsigned long long macc[CROSS_MACC];
+  __shared__ long long wl[32];
+  __shared__ FlipLut L;
+  __shared__ int sm[2][16];
+  __shared__ double stage[CH_WAVES * 4 * SSTR];
+  extern __shared__ __attribute__((aligned(16))) int8_t dyn_state[];
+  if ((int)blockIdx.x >= n) return;
+  for (int i = threadIdx.x; i < CROSS_MACC; i += blockDim.x) macc[i] = 0;
+  load_flip_lut(C, &L);
+  load_w(C.P, wl);
+  const ChainDesc d = C.desc[first + blockIdx.x];
+  const RegionDev rd = C.P.reg[d.slot];
+  ChainView v = make_view(C, d, rd);
+  if (C.P.lds_state) { v.sg = dyn_state; v.dl = v.sg + rd.R; v.et = v.dl + rd.S; }
+  const uint32_t E = (uint32_t)C.P.prow_ptr[rd.rp_off + rd.R];
+  WgScope sc{red};
+  bool staged = false;
+  MatView mvl = v.mv;
+  auto cross = [&](bool keep_conserved, bool with_genotype) -> long long {
+    // the perturbation rounds sweep the matrix dozens of times: keep it in LDS when it fits behind the state
+    if (!staged) {
+      staged = true;
+      if (C.P.lds_state && matview_bytes(rd.R, rd.S, E) <= (uint32_t)C.P.lds_mat) mvl = stage_view(C.P, rd, (uint8_t*)dyn_state + C.P.scratch_stride, E);
+    }
+    return cross_optimize(C.P, rd, mvl, v.sg, v.dl, v.et, keep_conserved, with_genotype, red, wl, macc);
+  };
+  chain_run(sc, C, rd, v, wl, L, stage, sm, cross, d.slot);
+}
+
+// all workgroups of the launch on one region (desc[which])
+__global__ void __launch_bounds__(CH_THREADS) k4_chain_grid(ChainDev C, int32_t which) {
+  __shared__ long long red[CH_WAVES];
+  __shared__ unsigned long long bc;
+  __shared__ long long wl[32];
+  __shared__ FlipLut L;
+  __shared__ int sm[2][16];
+  __shared__ double stage[CH_WAVES * 4 * SSTR];
+  load_flip_lut(C, &L);
+  load_w(C.P, wl);
+  const ChainDesc d = C.desc[which];
+  const RegionDev rd = C.P.reg[d.slot];
+  const ChainView v = make_view(C, d, rd);
+  GridScope sc{C.ctl, red, &bc, 0u};
+  unsigned long long* macc = C.macc + rd.snp_off;
+  for (int i = sc.tid(); i < rd.S; i += sc.nt()) macc[i] = 0;
+  // this thread's fixed run of CSC entries and the column its first entry lies in
+  const int E = v.mv.cp[rd.S];
+  const int c = (int)(((int64_t)E + sc.nt() - 1) / sc.nt());
+  const int e0 = (int)min((int64_t)E, (int64_t)sc.tid() * c), e1 = min(E, e0 + c);
+  int i_first = 0;
+  if (e0 < e1) { int lo = 0, hi = rd.S; while (lo < hi) { const int mid = (lo + hi) >> 1; if (v.mv.cp[mid + 1] <= e0) lo = mid + 1; else hi = mid; } i_first = lo; }
+  sc.sync();
+  auto cross = [&](bool keep_conserved, bool with_genotype) -> long long {
+    return cross_optimize_scope(sc, C.P, rd, v, keep_conserved, with_genotype, wl, macc, e0, e1, i_first);
+  };
+  chain_run(sc, C, rd, v, wl, L, stage, sm, cross, d.slot);
+}
+
+}  // namespace
+
+size_t k4_chain_wg_static_lds() { return sizeof(long long) * (CH_WAVES + 32) + 8 * CROSS_MACC + sizeof(FlipLut) + sizeof(int) * 32 + 8 * CH_WAVES * 4 * SSTR; }
+
+hipError_t k4_chain_launch_wg(const ChainDev& C, int first, int n, size_t dyn_lds, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_chain_wg), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k4_chain_wg, dim3((unsigned)n), dim3(CH_THREADS), dyn_lds, s, C, (int32_t)first, (int32_t)n);
+  return hipGetLastError();
+}
+
+int k4_grid_blocks() {
+  static int blocks = 0;
+  if (blocks) return blocks;
+  int dev = 0, ncu = 0, per = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, reinterpret_cast<const void*>(&k4_chain_grid), CH_THREADS, 0) != hipSuccess) return 0;
+  if (per < 1 || ncu < 1) return 0;
+  blocks = ncu;   // one workgroup per CU: fewer arrivals per barrier, and co-resident with room to spare
+  return blocks;
+}
+
+hipError_t k4_chain_launch_grid(const ChainDev& C, int which, hipStream_t s) {
+  const int nb = k4_grid_blocks();
+  if (nb <= 0) return hipErrorInvalidDevice;
+  hipError_t e = hipMemsetAsync(C.ctl, 0, sizeof(GridCtl), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k4_chain_grid, dim3((unsigned)nb), dim3(CH_THREADS), 0, s, C, (int32_t)which);
+  return hipGetLastError();
+}

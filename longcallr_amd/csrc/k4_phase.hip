@@ -36,205 +36,11 @@
 #include <functional>
 #include <thread>
 
-#include "lcr_phase_host.h"
+#include "k4_dev.h"
+#include "k4_grid.h"
 
 namespace {
 
-const double FX_SCALE = 1099511627776.0;  // 2^40
-
-__host__ __device__ inline uint64_t mix64(uint64_t z) {
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-  return z ^ (z >> 31);
-}
-__host__ __device__ inline double u01(uint64_t seed, uint64_t ctr) {
-  uint64_t z = mix64(seed + (ctr + 1) * 0x9E3779B97F4A7C15ULL);
-  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
-}
-__host__ __device__ inline uint64_t region_seed(uint64_t seed, int64_t start0) { return mix64(seed + 0xD1B54A32D192ED03ULL * (uint64_t)(start0 + 1)); }
-
-struct RegionDev {
-  int32_t R, S;          // phasing rows, candidates
-  int32_t rp_off;        // prow_ptr offset (R+1 entries)
-  int32_t cp_off;        // ccol_ptr offset (S+1 entries)
-  int64_t e_off;         // offset of this region's entries in pcol/pval and crow/cval
-  int32_t sig_off;       // offset into per-row state arrays
-  int32_t snp_off;       // offset into per-SNP arrays
-  uint64_t seed;
-  long long f_total;     // sum of fe[q] over all phase entries (the sigma/delta independent part of the objective)
-};
-
-struct PhaseDev {
-  const RegionDev* reg;
-  const int32_t* prow_ptr; const int32_t* pcol; const uint8_t* pval;
-  const int32_t* ccol_ptr; const int32_t* crow; const uint8_t* cval;
-  const uint8_t* snp_fp; const int8_t* snp_vt; const uint8_t* snp_cons;
-  const long long* snp_const;  // per SNP: F = sum fe, W = sum w, Cref = sum (p==+1 ? f1e : fe), Cvar = sum (p==-1 ? f1e : fe)
-  int8_t* st_sigma; int8_t* st_delta; int8_t* st_eta; long long* st_obj;  // per region best / result state
-  int8_t* scratch; int32_t scratch_stride;                                // per block working state
-  int32_t lds_state;                                                      // 1: working state lives in dynamic LDS
-  int32_t lds_mat;                                                        // bytes of dynamic LDS behind the state for a matrix copy
-  PhaseLutDev lut;
-};
-
-__device__ __forceinline__ long long wave_sum_ll(long long v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
-}
-
-// one cross_optimize (phase.rs:810-976); returns the exact objective (phase.rs:257-276) to all threads.
-// Every emission term is fe[q] + hit * w[q] with w[q] = f1e[q] - fe[q] > 0 and hit = [p == x]
-// (aki, phase.rs:32-49), so per row / column only the data dependent sum of w over the hits is
-// accumulated; the sigma/delta independent parts are per-SNP constants (PhaseDev::snp_const).
-// a region's phase matrix: global memory, or a copy the calling kernel staged in LDS
-struct MatView { const int32_t* rp; const int32_t* pc; const uint8_t* pv; const int32_t* cp; const int32_t* cr; const uint8_t* cv;
-                 const uint8_t* fp; const uint8_t* cons; };
-__device__ __forceinline__ MatView global_view(const PhaseDev& P, const RegionDev& rd) {
-  return MatView{P.prow_ptr + rd.rp_off, P.pcol + rd.e_off, P.pval + rd.e_off, P.ccol_ptr + rd.cp_off, P.crow + rd.e_off,
-                 P.cval + rd.e_off, P.snp_fp + rd.snp_off, P.snp_cons + rd.snp_off};
-}
-__host__ __device__ inline uint32_t matview_bytes(uint32_t R, uint32_t S, uint32_t E) {
-  return 4 * (R + 1) + 4 * (S + 1) + 8 * E + 2 * ((E + 3) & ~3u) + 2 * ((S + 3) & ~3u);
-}
-// copy the region's matrix into LDS at `dst` (4-byte aligned); all threads of the workgroup call
-__device__ __forceinline__ MatView stage_view(const PhaseDev& P, const RegionDev& rd, uint8_t* dst, uint32_t E) {
-  const MatView g = global_view(P, rd);
-  int32_t* rp = (int32_t*)dst; int32_t* cp = rp + rd.R + 1; int32_t* pc = cp + rd.S + 1; int32_t* cr = pc + E;
-  uint8_t* pv = (uint8_t*)(cr + E); uint8_t* cv = pv + ((E + 3) & ~3u); uint8_t* fp = cv + ((E + 3) & ~3u); uint8_t* cons = fp + ((rd.S + 3) & ~3u);
-  for (int i = threadIdx.x; i <= rd.R; i += blockDim.x) rp[i] = g.rp[i];
-  for (int i = threadIdx.x; i <= rd.S; i += blockDim.x) cp[i] = g.cp[i];
-  for (int i = threadIdx.x; i < (int)E; i += blockDim.x) { pc[i] = g.pc[i]; cr[i] = g.cr[i]; pv[i] = g.pv[i]; cv[i] = g.cv[i]; }
-  for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { fp[i] = g.fp[i]; cons[i] = g.cons[i]; }
-  __syncthreads();
-  return MatView{rp, pc, pv, cp, cr, cv, fp, cons};
-}
-
-constexpr int CROSS_MACC = 2048;   // SNPs with a per-column accumulator in LDS (entry-balanced delta step)
-__device__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, const MatView& mv, int8_t* sg, int8_t* dl, int8_t* et,
-                                    bool keep_conserved, bool with_genotype, long long* red, const long long* wl,
-                                    unsigned long long* macc = nullptr /* CROSS_MACC zeros in LDS, or nullptr */) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int32_t* rp = mv.rp;
-  const int32_t* pc = mv.pc;
-  const uint8_t* pv = mv.pv;
-  const int32_t* cp = mv.cp;
-  const int32_t* cr = mv.cr;
-  const uint8_t* cv = mv.cv;
-  const uint8_t* fp = mv.fp;
-  const uint8_t* cons = mv.cons;
-  const long long* sc = P.snp_const + 4ll * rd.snp_off;
-  bool hg_inc = true, h_inc = true;
-  int iters = 0;
-  while (hg_inc | h_inc) {
-    // ---- sigma step (phase.rs:824-862): A - B = sum over het sites of (+w if p == sigma*delta else -w);
-    //      flip every row with A < B (sites with eta != 0 contribute equally to both)
-    int any = 0;
-    for (int row = tid; row < rd.R; row += blockDim.x) {
-      const int s = sg[row];
-      long long diff = 0;
-      for (int e = rp[row]; e < rp[row + 1]; e++) {
-        const int i = pc[e];
-        const uint8_t v = pv[e];
-        if (et[i] == 0) { const long long w = wl[v & 31]; diff += (((v & 32) ? 1 : -1) == s * dl[i]) ? w : -w; }
-      }
-      if (diff < 0) { sg[row] = (int8_t)(-s); any = 1; }
-    }
-    any = __syncthreads_or(any);
-    if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
-    // ---- delta/eta step (phase.rs:872-959): per SNP the best of (d,0) (-d,0) (d,+1) (d,-1)
-    any = 0;
-    auto decide = [&](int i, long long M, int ncol) {
-      const int d = dl[i], h = et[i];
-      const long long het = P.lut.f_het0 - (long long)ncol * P.lut.f_log2;  // phase.rs:136-144
-      const long long F = sc[4 * i], W = sc[4 * i + 1];
-      long long N[4] = {F + M + het, F + W - M + het, sc[4 * i + 2] + P.lut.f_homref, sc[4 * i + 3] + P.lut.f_homvar};
-      int ch;
-      if (with_genotype) { ch = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch]) ch = t; }   // phase.rs:908-921
-      else if (h == 0) ch = N[1] > N[0] ? 1 : 0;                                                // phase.rs:923-930
-      else ch = N[3] > N[2] ? 3 : 2;                                                            // phase.rs:931-938
-      const int cur = h == 0 ? 0 : (h == 1 ? 2 : 3);
-      if (N[ch] > N[cur]) any = 1;
-      dl[i] = (int8_t)(ch == 1 ? -d : d);
-      et[i] = (int8_t)(ch <= 1 ? 0 : (ch == 2 ? 1 : -1));
-    };
-    if (macc && rd.S <= CROSS_MACC) {
-      // balanced over the CSC entries (not over the SNPs): thread t takes entries [t*c, (t+1)*c), walks them
-      // in column order and flushes its per-column sum of w over the hits into macc[] (LDS, integer, order-free)
-      const int E = cp[rd.S];
-      const int c = (E + (int)blockDim.x - 1) / (int)blockDim.x;
-      const int e0 = min(E, tid * c), e1 = min(E, e0 + c);
-      if (e0 < e1) {
-        int i; { int lo = 0, hi = rd.S; while (lo < hi) { const int mid = (lo + hi) >> 1; if (cp[mid + 1] <= e0) lo = mid + 1; else hi = mid; } i = lo; }
-        int d = dl[i]; int cend = cp[i + 1];
-        long long M = 0;
-        for (int e = e0; e < e1; e++) {
-          if (e >= cend) {
-            if (M) atomicAdd(&macc[i], (unsigned long long)M);
-            M = 0;
-            do { i++; cend = cp[i + 1]; } while (e >= cend);
-            d = dl[i];
-          }
-          const uint8_t v = cv[e];
-          if (((v & 32) ? 1 : -1) == sg[cr[e]] * d) M += wl[v & 31];
-        }
-        if (M) atomicAdd(&macc[i], (unsigned long long)M);
-      }
-      __syncthreads();
-      for (int i = tid; i < rd.S; i += blockDim.x) {
-        const long long M = (long long)macc[i];
-        macc[i] = 0;
-        if (!fp[i] || (keep_conserved && cons[i]) || cp[i + 1] == cp[i]) continue;
-        decide(i, M, cp[i + 1] - cp[i]);
-      }
-    } else {
-      for (int i = wave; i < rd.S; i += nw) {
-        if (!fp[i]) continue;
-        if (keep_conserved && cons[i]) continue;
-        const int c0 = cp[i], c1 = cp[i + 1];
-        if (c1 == c0) continue;
-        const int d = dl[i];
-        long long M = 0;  // sum of w over the entries with p == sigma * d
-        for (int e = c0 + lane; e < c1; e += 64) {
-          const uint8_t v = cv[e];
-          if (((v & 32) ? 1 : -1) == sg[cr[e]] * d) M += wl[v & 31];
-        }
-        M = wave_sum_ll(M);
-        if (lane == 0) decide(i, M, c1 - c0);
-      }
-    }
-    any = __syncthreads_or(any);
-    if (!any) hg_inc = false; else { hg_inc = true; h_inc = true; }
-    if (++iters > 20) break;  // phase.rs:967-972
-  }
-  // ---- objective (phase.rs:257-276) = f_total + sum of w over the hits
-  long long acc = 0;
-  for (int row = tid; row < rd.R; row += blockDim.x) {
-    const int s = sg[row];
-    for (int e = rp[row]; e < rp[row + 1]; e++) {
-      const int i = pc[e];
-      const uint8_t v = pv[e];
-      const int x = et[i] == 0 ? s * dl[i] : et[i];
-      if (((v & 32) ? 1 : -1) == x) acc += wl[v & 31];
-    }
-  }
-  acc = wave_sum_ll(acc);
-  __syncthreads();
-  if (lane == 0) red[wave] = acc;
-  __syncthreads();
-  long long total = rd.f_total;
-  for (int w = 0; w < nw; w++) total += red[w];
-  __syncthreads();
-  return total;
-}
-
-// w[q] = f1e[q] - fe[q] into LDS (dynamic indexing of a kernel-argument table would go through memory)
-__device__ __forceinline__ void load_w(const PhaseDev& P, long long* wl) {
-  if (threadIdx.x < 32) wl[threadIdx.x] = threadIdx.x < 31 ? P.lut.f1e[threadIdx.x] - P.lut.fe[threadIdx.x] : 0;
-  __syncthreads();
-}
-
-__device__ __forceinline__ int8_t init_genotype(int8_t vt) { return vt == 0 ? 1 : (vt == 1 ? 0 : -1); }  // phase.rs:682-691
 
 // ---------------------------------------------------------------------------------------------
 // Enumeration restarts, register-resident form.  A region's phase matrix is a few KB (rows x <= 31
@@ -304,25 +110,6 @@ __host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E) {
 // lane l owns the rows whose first entry index lies in [l*c, (l+1)*c), c = ceil(E / 64)
 __host__ __device__ inline uint32_t enum_chunk(uint32_t E) { return E ? (E + 63) / 64 : 1; }
 
-#define LCR_DPP_LL(v, ctrl, rmask) \
-  (((long long)__builtin_amdgcn_update_dpp(0, (int)((v) >> 32), ctrl, rmask, 0xf, false) << 32) | \
-   (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xf, false))
-// wave64 sum of int64 through DPP row shifts / broadcasts; every lane gets the total
-__device__ __forceinline__ long long wave_sum_ll_dpp(long long v) {
-  v += LCR_DPP_LL(v, 0x111, 0xf);
-  v += LCR_DPP_LL(v, 0x112, 0xf);
-  v += LCR_DPP_LL(v, 0x114, 0xf);
-  v += LCR_DPP_LL(v, 0x118, 0xf);
-  v += LCR_DPP_LL(v, 0x142, 0xa);
-  v += LCR_DPP_LL(v, 0x143, 0xc);
-  const int lo = __builtin_amdgcn_readlane((int)v, 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
-  return ((long long)hi << 32) | (unsigned)lo;
-}
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // tiles of restarts of regions whose per-lane share is <= CK entries (host decides); win_e != nullptr:
 // re-run restart win_e[slot] of each tile's region and store its state.
@@ -582,40 +369,20 @@ struct StageIn {
   const lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off; const int64_t* start0;
   uint32_t min_linkers, max_enum_snps; uint64_t seed;
 };
-struct StageStat { int32_t R, E, max_n, max_rows, E_all, pad_; };   // max_*: per-lane share of k4_enum_reg's row partition; E_all: all entries
 struct StageOut {
   RegionDev* reg; StageStat* stat;
   int32_t* prow_ptr; int32_t* pcol; uint8_t* pval; int32_t* ccol_ptr; int32_t* crow; uint8_t* cval;
   uint8_t* snp_fp; int8_t* snp_vt; uint8_t* snp_cons; long long* snp_const; int32_t* cursor;
+  int32_t* prow_src;   // per phasing row (at r0 + k): its fragment row, region relative
 };
 
-// exclusive scan of two ints over a workgroup of NW waves; returns the totals through ta / tb
-template <int NW, int SMW>
-__device__ __forceinline__ void block_scan2n(int a, int b, int& ea, int& eb, int& ta, int& tb, int (*sm)[SMW]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int ia = a, ib = b;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int ua = __shfl_up(ia, d, 64), ub = __shfl_up(ib, d, 64);
-    if (lane >= d) { ia += ua; ib += ub; }
-  }
-  __syncthreads();
-  if (lane == 63) { sm[0][wave] = ia; sm[1][wave] = ib; }
-  __syncthreads();
-  int oa = 0, ob = 0; ta = 0; tb = 0;
-  for (int w = 0; w < NW; w++) { if (w < wave) { oa += sm[0][w]; ob += sm[1][w]; } ta += sm[0][w]; tb += sm[1][w]; }
-  ea = oa + ia - a; eb = ob + ib - b;
-}
-__device__ __forceinline__ void block_scan2(int a, int b, int& ea, int& eb, int& ta, int& tb, int (*sm)[8]) {
-  block_scan2n<4, 8>(a, b, ea, eb, ta, tb, sm);
-}
 
 constexpr int STAGE_THREADS = 256;    // (1024 threads per region were measured: more barrier cost than latency saved)
 constexpr int STG_E = 8192, STG_R = 4096, STG_S = 512;   // k4_stage: a region's slice of the fragment matrix that is staged in LDS
 __global__ void __launch_bounds__(STAGE_THREADS) k4_stage(StageIn in, StageOut out, PhaseLutDev lut) {
   constexpr int NW = STAGE_THREADS / 64;
   __shared__ int sm[2][16];
-  __shared__ int s_max[2];
+  __shared__ int s_max[3];   // [2]: largest distance between two for_phasing entries of one fragment row (LD band width)
   __shared__ long long s_ft[NW];
   __shared__ long long s_fe[32], s_f1e[32];
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -630,7 +397,7 @@ __global__ void __launch_bounds__(STAGE_THREADS) k4_stage(StageIn in, StageOut o
     return;
   }
   if (tid < 32) { s_fe[tid] = tid < 31 ? lut.fe[tid] : 0; s_f1e[tid] = tid < 31 ? lut.f1e[tid] : 0; }
-  if (tid < 2) s_max[tid] = 0;
+  if (tid < 3) s_max[tid] = 0;
   // The region's slice of the fragment matrix is brought into LDS with coalesced loads when it fits (any
   // realistic region does): the per-row entry loops below are chains of dependent loads, a microsecond per link
   // from HBM, and there are four of them per row.  Larger regions run the same code on global memory.
@@ -673,16 +440,18 @@ __global__ void __launch_bounds__(STAGE_THREADS) k4_stage(StageIn in, StageOut o
       int isp = 0, cnt = 0, eb = 0, ee = 0;
       if (r < nrow) {
         isp = isp_of(r);
-        if (isp) {
-          eb = rp_of(r); ee = rp_of(r + 1);
-          for (int e = eb; e < ee; e++) cnt += fp_of(col_of(e)) ? 1 : 0;
-        }
+        eb = rp_of(r); ee = rp_of(r + 1);
+        int first = -1, last = -1;   // every fragment row counts for the LD pair table (fragment.rs:208-240)
+        for (int e = eb; e < ee; e++) { const int ci = col_of(e); if (fp_of(ci)) { cnt++; if (first < 0) first = ci; last = ci; } }
+        if (last > first) atomicMax(&s_max[2], last - first);
+        if (!isp) cnt = 0;
       }
       int k, eo, tk, te;
       block_scan2n<NW, 16>(isp, cnt, k, eo, tk, te, sm);
       if (isp) {
         k += R; eo += E;
         prp[k] = eo;
+        out.prow_src[r0 + k] = r;
         for (int e = eb; e < ee; e++) {
           const int ci = col_of(e);
           if (!fp_of(ci)) continue;
@@ -763,7 +532,7 @@ __global__ void __launch_bounds__(STAGE_THREADS) k4_stage(StageIn in, StageOut o
     for (int w = 0; w < NW; w++) ftot += s_ft[w];
     rd.R = R; rd.f_total = ftot;
     out.reg[g] = rd;
-    out.stat[g] = StageStat{R, E, max(s_max[0], (int)enum_chunk((uint32_t)E)), s_max[1], (int)E_all, 0};
+    out.stat[g] = StageStat{R, E, max(s_max[0], (int)enum_chunk((uint32_t)E)), s_max[1], (int)E_all, s_max[2]};
   }
 }
 
@@ -814,82 +583,7 @@ __global__ void __launch_bounds__(64) k4_enum_pick(const int32_t* __restrict__ s
   if (threadIdx.x == 0) win_e[slot] = be;
 }
 
-// chain, part A (phase.rs:1124-1132): delta from init_haplotypes_LD2 (host), random sigma, keep_conserved
-constexpr int CHAIN_THREADS = 1024;   // a chain region is one workgroup: 16 waves shorten its sequential rounds
-__global__ void __launch_bounds__(CHAIN_THREADS) k4_chain_a(PhaseDev P, const int32_t* __restrict__ slots, int32_t n) {
-  __shared__ long long red[CHAIN_THREADS / 64];
-  __shared__ unsigned long long macc[CROSS_MACC];
-  for (int i = threadIdx.x; i < CROSS_MACC; i += blockDim.x) macc[i] = 0;
-  __shared__ long long wl[32];
-  if ((int)blockIdx.x >= n) return;
-  load_w(P, wl);
-  const int slot = slots[blockIdx.x];
-  const RegionDev rd = P.reg[slot];
-  int8_t* sg = P.st_sigma + rd.sig_off; int8_t* dl = P.st_delta + rd.snp_off; int8_t* et = P.st_eta + rd.snp_off;
-  const int8_t* vt = P.snp_vt + rd.snp_off;
-  for (int i = threadIdx.x; i < rd.S; i += blockDim.x) et[i] = init_genotype(vt[i]);
-  const uint64_t ctr0 = 2 * (uint64_t)rd.S + (uint64_t)rd.R;  // after S+F (thread.rs) and S (init_haplotypes_LD2)
-  for (int row = threadIdx.x; row < rd.R; row += blockDim.x) sg[row] = u01(rd.seed, ctr0 + row) < 0.5 ? -1 : 1;
-  __syncthreads();
-  const long long obj = cross_optimize(P, rd, global_view(P, rd), sg, dl, et, true, false, red, wl, macc);
-  if (threadIdx.x == 0) P.st_obj[slot] = obj;
-}
-
-// chain, part B (phase.rs:1197-1233): perturbation rounds with best-state tracking
-__global__ void __launch_bounds__(CHAIN_THREADS) k4_chain_b(PhaseDev P, const int32_t* __restrict__ slots, int32_t n) {
-  __shared__ long long red[CHAIN_THREADS / 64];
-  __shared__ unsigned long long macc[CROSS_MACC];
-  for (int i = threadIdx.x; i < CROSS_MACC; i += blockDim.x) macc[i] = 0;
-  __shared__ long long wl[32];
-  if ((int)blockIdx.x >= n) return;
-  load_w(P, wl);
-  const int slot = slots[blockIdx.x];
-  const RegionDev rd = P.reg[slot];
-  int8_t* bsg = P.st_sigma + rd.sig_off; int8_t* bdl = P.st_delta + rd.snp_off; int8_t* bet = P.st_eta + rd.snp_off;
-  extern __shared__ __attribute__((aligned(16))) int8_t dyn_state[];
-  int8_t* sg = P.lds_state ? dyn_state : P.scratch + (size_t)blockIdx.x * P.scratch_stride;
-  int8_t* dl = sg + rd.R; int8_t* et = dl + rd.S;
-  // the perturbation rounds sweep the matrix dozens of times: keep it in LDS when it fits next to the state
-  const uint32_t E = (uint32_t)P.prow_ptr[rd.rp_off + rd.R];
-  const MatView mv = (P.lds_state && matview_bytes(rd.R, rd.S, E) <= (uint32_t)P.lds_mat)
-                         ? stage_view(P, rd, (uint8_t*)dyn_state + P.scratch_stride, E) : global_view(P, rd);
-  long long best = P.st_obj[slot];
-  auto load_best = [&]() {
-    for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { dl[i] = bdl[i]; et[i] = bet[i]; }
-    for (int row = threadIdx.x; row < rd.R; row += blockDim.x) sg[row] = bsg[row];
-    __syncthreads();
-  };
-  auto save_if_better = [&](long long obj) {
-    if (obj > best) {  // uniform: every thread holds the same obj / best
-      best = obj;
-      for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { bdl[i] = dl[i]; bet[i] = et[i]; }
-      for (int row = threadIdx.x; row < rd.R; row += blockDim.x) bsg[row] = sg[row];
-    }
-    __syncthreads();
-  };
-  load_best();
-  const uint64_t SF = (uint64_t)rd.S + (uint64_t)rd.R;
-  for (int tidx = 0; tidx <= rd.S / 4; tidx++) {
-    const uint64_t ctr_t = 2 * SF + (uint64_t)tidx * SF;
-    const bool flip = (tidx & 1) == 1;
-    for (int i = threadIdx.x; i < rd.S; i += blockDim.x) {  // phase.rs:1199-1208
-      const double rg = u01(rd.seed, ctr_t + i);
-      if (rg < 0.1) dl[i] = flip ? 1 : -1;
-      else if (rg >= 0.9) dl[i] = flip ? -1 : 1;
-    }
-    __syncthreads();
-    long long obj = cross_optimize(P, rd, mv, sg, dl, et, false, false, red, wl, macc);
-    save_if_better(obj);
-    load_best();
-    for (int row = threadIdx.x; row < rd.R; row += blockDim.x)  // phase.rs:1217-1224
-      if (u01(rd.seed, ctr_t + rd.S + row) < 0.1) sg[row] = (int8_t)(-sg[row]);
-    __syncthreads();
-    obj = cross_optimize(P, rd, mv, sg, dl, et, false, false, red, wl, macc);
-    save_if_better(obj);
-    load_best();
-  }
-  if (threadIdx.x == 0) P.st_obj[slot] = best;
-}
+constexpr int CHAIN_THREADS = 1024;   // k4_post of the chain regions: 16 waves
 
 // ---------------------------------------------------------------------------------------------
 // k4_post: the post-phase sequence of thread.rs:168-201 on the device, one workgroup per region:
@@ -903,24 +597,6 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k4_chain_b(PhaseDev P, const in
 // device libm.  The region's fragment rows are staged in LDS with a row-ordered column index (stable
 // counting sort by one wave); a batch with a region too large for that takes the host epilogue.
 // ---------------------------------------------------------------------------------------------
-// Chain regions only: their rows / entries of the fragment matrix gathered into one contiguous block that goes
-// to the host with a single copy (the block-flip pass and the LD blocks are host code); the whole matrix is
-// only downloaded when the host epilogue has to run.
-struct PackItem { int32_t r0, nrow; int64_t e0, ne; int64_t rp_at, lk_at, col_at, val_at; };   // byte offsets into the block
-__global__ void __launch_bounds__(LCR_BLOCK) k4_pack_chain(const PackItem* __restrict__ items, const int64_t* __restrict__ row_ptr,
-                                                            const int32_t* __restrict__ col, const uint8_t* __restrict__ val,
-                                                            const uint32_t* __restrict__ links, uint8_t* __restrict__ block) {
-  const PackItem it = items[blockIdx.x];
-  int64_t* rp = reinterpret_cast<int64_t*>(block + it.rp_at);
-  uint32_t* lk = reinterpret_cast<uint32_t*>(block + it.lk_at);
-  int32_t* cl = reinterpret_cast<int32_t*>(block + it.col_at);
-  uint8_t* vl = block + it.val_at;
-  for (int r = threadIdx.x; r <= it.nrow; r += LCR_BLOCK) rp[r] = row_ptr[it.r0 + r];
-  for (int r = threadIdx.x; r < it.nrow; r += LCR_BLOCK) lk[r] = links[it.r0 + r];
-  for (int64_t e = threadIdx.x; e < it.ne; e += LCR_BLOCK) { cl[e] = col[it.e0 + e]; vl[e] = val[it.e0 + e]; }
-}
-
-struct PostLut { double le[31], l1e[31]; double p_homref, p_homvar, log_theta, log2; };
 struct PostIn {
   const int64_t* row_ptr; const int32_t* col; const uint8_t* val; const uint32_t* links;
   lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off; const int64_t* start0;
@@ -1389,54 +1065,6 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
 
 // ================================= host side ====================================================
 
-// petgraph 0.6.4 GraphMap<usize,_,Undirected> semantics needed by the reference: node order =
-// insertion order, adjacency in edge-insertion order, kosaraju_scc = DfsPostOrder pass over nodes in
-// insertion order followed by a LIFO Dfs in reverse finish order (candidate.rs:733, snpfrags.rs:704).
-struct PGraph {   // nodes are SNP indices 0..n-1; callers add every undirected pair at most once
-  std::vector<int> order;
-  std::vector<std::vector<int>> adj;
-  std::vector<uint8_t> present;
-  explicit PGraph(int n) : adj(n), present(n, 0) {}
-  void add_node(int a) { if (!present[a]) { present[a] = 1; order.push_back(a); } }
-  void add_edge(int a, int b) {
-    add_node(a); adj[a].push_back(b);
-    if (a != b) { add_node(b); adj[b].push_back(a); }
-  }
-  void remove_edge(int a, int b) {   // petgraph swap_remove on both adjacency lists
-    auto rm = [&](int x, int y) { auto& v = adj[x]; auto f = std::find(v.begin(), v.end(), y); if (f != v.end()) { *f = v.back(); v.pop_back(); } };
-    rm(a, b); rm(b, a);
-  }
-  std::vector<std::vector<int>> components() const {
-    std::vector<uint8_t> seen(adj.size(), 0), done(adj.size(), 0);
-    std::vector<int> fin, st;
-    for (int r : order) {
-      if (seen[r]) continue;
-      st.assign(1, r);
-      while (!st.empty()) {
-        const int x = st.back();
-        if (!seen[x]) { seen[x] = 1; for (int y : adj[x]) if (!seen[y]) st.push_back(y); }
-        else { st.pop_back(); if (!done[x]) { done[x] = 1; fin.push_back(x); } }
-      }
-    }
-    std::vector<std::vector<int>> out;
-    std::fill(seen.begin(), seen.end(), 0);
-    for (auto it = fin.rbegin(); it != fin.rend(); ++it) {
-      if (seen[*it]) continue;
-      st.assign(1, *it);
-      std::vector<int> comp;
-      while (!st.empty()) {
-        const int x = st.back(); st.pop_back();
-        if (seen[x]) continue;
-        seen[x] = 1;
-        for (int y : adj[x]) if (!seen[y]) st.push_back(y);
-        comp.push_back(x);
-      }
-      out.push_back(comp);
-    }
-    return out;
-  }
-};
-
 struct HostLut {
   double le[31], l1e[31];  // log10(eps), log10(1-eps), eps = 10^(-q/10) (fragment.rs:132); q=0 treated as q=1
   double p_homref, p_homvar, log_theta, log2;
@@ -1666,42 +1294,49 @@ struct RegionHost {
     }
   }
 
-  // exact objective of the current state over the phase matrix (flat CSR of the phasing rows)
-  long long objective_fx(const std::vector<int32_t>& prow_ptr, const std::vector<int32_t>& pcol,
-                         const std::vector<uint8_t>& pval) const {
-    long long s = 0;
-    const PhaseLutDev& L = hlut().dev;
-    for (size_t k = 0; k < fp_rows.size(); k++) {
-      const int sg = tag[fp_rows[k]];
-      for (int e = prow_ptr[k]; e < prow_ptr[k + 1]; e++) {
-        const int p = (pval[e] & 32) ? 1 : -1;
-        const int x = cand[pcol[e]].genotype == 0 ? sg * cand[pcol[e]].haplotype : cand[pcol[e]].genotype;
-        s += p == x ? L.f1e[pval[e] & 31] : L.fe[pval[e] & 31];
-      }
-    }
-    return s;
-  }
 };
 
-struct RegionBuild {  // chain regions only: host copy of the phase matrix rows for the block-flip objective
-  std::vector<int32_t> prow_ptr, pcol;
-  std::vector<uint8_t> pval;
-};
-struct PhaseWork {
+struct PhaseWork {   // host epilogue structures, reused across calls
   std::vector<RegionHost> R;
-  std::vector<std::vector<std::vector<int>>> ld_blocks;
-  std::vector<RegionBuild> RB;
 };
 
 }  // namespace
 
 void PhaseHost::free_work() { delete static_cast<PhaseWork*>(work); work = nullptr; }
 
+int PhaseHost::ld_blocks(const PhaseInputs& in, int region, std::vector<int32_t>* off, std::vector<int32_t>* snps, hipStream_t s, std::string* err) {
+  off->assign(1, 0); snps->clear();
+  for (const ChainDesc& d : chain_desc) {
+    if (d.slot != region) continue;
+    const int c0 = in.cand_region_off[region];
+    int32_t info[2] = {0, 0};
+    auto chk = [&](hipError_t e) { if (e != hipSuccess && err) *err = hipGetErrorString(e); return e == hipSuccess; };
+    if (!chk(hipMemcpyAsync(info, chain_dev.blk_info + 2 * region, 8, hipMemcpyDeviceToHost, s)) || !chk(hipStreamSynchronize(s))) return LCR_E_DEVICE;
+    const int nb = info[0];
+    if (nb == 0) return LCR_OK;
+    std::vector<int32_t> ptr(nb + 1);
+    if (!chk(hipMemcpyAsync(ptr.data(), chain_dev.blk_ptr + c0 + region, (size_t)(nb + 1) * 4, hipMemcpyDeviceToHost, s)) || !chk(hipStreamSynchronize(s))) return LCR_E_DEVICE;
+    std::vector<int32_t> nodes(ptr[nb]);
+    if (!chk(hipMemcpyAsync(nodes.data(), chain_dev.blk_nodes + c0, (size_t)ptr[nb] * 4, hipMemcpyDeviceToHost, s)) || !chk(hipStreamSynchronize(s))) return LCR_E_DEVICE;
+    for (int b = nb - 1; b >= 0; b--) {   // kosaraju_scc emits the blocks in descending order of their smallest node
+      snps->insert(snps->end(), nodes.begin() + ptr[b], nodes.begin() + ptr[b + 1]);
+      off->push_back((int32_t)snps->size());
+    }
+    return LCR_OK;
+  }
+  return LCR_OK;   // not a chain region: no blocks are built (phase.rs:1097-1122 never looks at them)
+}
+
 int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t stream, std::string* err) {
 #define PCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e_); return LCR_E_DEVICE; } } while (0)
-  // Two queues: `stream` stages the phase matrices on the device and runs the enumeration regions;
-  // `side` brings the fragment matrix to the host (LD blocks, block-flip pass and the post-phase
-  // epilogue need it) and runs the few chain regions.  Host work overlaps the enumeration kernels.
+  // Two queues: `stream` stages the phase matrices and runs the enumeration regions (S <= max_enum_snps) with their
+  // post-phase kernel; `side` runs the chain regions (S > max_enum_snps): LD blocks, LD-seeded start, block-flip pass
+  // and perturbation rounds in ONE kernel per region class (k4_grid.hip: a workgroup per region, or all CUs on one
+  // large region), then their post-phase kernel.  The host only sizes buffers and launches.
+  if (prm.ld_weight_threshold != 1) {
+    if (err) *err = "ld_weight_threshold must be 1: SNPFrag::phase is only ever called with 1 (thread.rs:166)";
+    return LCR_E_ARG;
+  }
   const int ng = in.n_regions, nrow = in.n_rows;
   const int64_t nnz = in.nnz;
   const int ncand = in.cand_region_off[ng];
@@ -1724,20 +1359,23 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   DevBuf &b_reg = d_state[0], &b_prp = d_state[1], &b_pc = d_state[2], &b_pv = d_state[3], &b_cp = d_state[4],
          &b_cr = d_state[5], &b_cv = d_state[6], &b_snp = d_state[7], &b_st = d_state[8], &b_scr = d_state[9],
          &b_job = d_state[10], &b_obj = d_state[11], &b_sc = d_state[12], &b_stat = d_state[13], &b_cur = d_state[14],
-         &b_stc = d_state[15], &b_slots = d_state[16];
+         &b_stc = d_state[15], &b_slots = d_state[16], &b_psrc = d_state[21], &b_desc = d_state[22], &b_tbl = d_state[23],
+         &b_adj = d_state[24], &b_part = d_state[25], &b_snpi = d_state[26], &b_snpb = d_state[27], &b_q = d_state[28],
+         &b_info = d_state[29], &b_rowi = d_state[30], &b_enti = d_state[31], &b_work = d_state[32], &b_macc = d_state[33],
+         &b_ctl = d_state[34];
   const size_t nnz1 = (size_t)std::max<int64_t>(nnz, 1), nc1 = (size_t)std::max(ncand, 1), nr1 = (size_t)std::max(nrow, 1);
   PCHK(b_reg.reserve((size_t)std::max(ng, 1) * sizeof(RegionDev)));
   PCHK(b_stat.reserve((size_t)std::max(ng, 1) * sizeof(StageStat)));
   PCHK(b_prp.reserve((nr1 + ng + 1) * 4)); PCHK(b_pc.reserve(nnz1 * 4)); PCHK(b_pv.reserve(nnz1));
   PCHK(b_cp.reserve((nc1 + ng + 1) * 4)); PCHK(b_cr.reserve(nnz1 * 4)); PCHK(b_cv.reserve(nnz1));
   PCHK(b_snp.reserve(nc1 * 3 + 16)); PCHK(b_sc.reserve(nc1 * 4 * sizeof(long long))); PCHK(b_cur.reserve(nc1 * 4));
+  PCHK(b_psrc.reserve(nr1 * 4));
   // state: sigma[n_rows] | delta[n_cand] | eta[n_cand] | obj[n_regions] (8-byte aligned); one copy per queue
   const size_t st_sig = 0, st_del = (nr1 + 15) & ~(size_t)15, st_eta = st_del + ((nc1 + 15) & ~(size_t)15);
   const size_t st_obj = st_eta + ((nc1 + 15) & ~(size_t)15);
   const size_t st_bytes = st_obj + (size_t)std::max(ng, 1) * 8;
   PCHK(b_st.reserve(st_bytes + 16)); PCHK(b_stc.reserve(st_bytes + 16));
-  PCHK(h_pin[4].reserve(st_bytes + 16)); PCHK(h_pin[5].reserve((size_t)std::max(ng, 1) * sizeof(StageStat)));
-  PCHK(h_pin[6].reserve(st_bytes + 16));
+  PCHK(h_pin[5].reserve((size_t)std::max(ng, 1) * sizeof(StageStat)));
   // results of the device epilogue live in pinned host memory that k4_post writes itself (every row belongs to a
   // region with candidates, fragment.rs:24-26, so every row is written): phase set u32 | haplotag | assignment, and
   // candidate mirror | objectives
@@ -1765,28 +1403,29 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     if (S == 0) continue;
     if ((uint32_t)S <= prm.max_enum_snps) enum_slots.push_back(g); else chain_slots.push_back(g);
   }
-  // post-phase epilogue on the device (k4_post) unless a region does not fit its LDS image; the regions' sizes
-  // are on the host already (lcr_fragments), so this is known before anything is queued
-  bool dev_post = getenv("LCR_POST_HOST") == nullptr;
+  // post-phase epilogue: k4_post (a workgroup per region, the region in LDS) for every region that fits its LDS image;
+  // the host epilogue (RegionHost) for the others and, as a cross-check, for all regions under LCR_POST_HOST=1.  The
+  // regions' sizes are on the host already (lcr_fragments), so this is known before anything is queued.
+  const bool force_host_post = getenv("LCR_POST_HOST") != nullptr;
+  std::vector<uint8_t> host_post(ng, 0);
+  bool any_host_post = false;
   uint32_t post_lds = 0;
   for (int g = 0; g < ng; g++) {
     const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
     if (S == 0) continue;
     const int nr_g = in.row_region_off[g + 1] - in.row_region_off[g];
     const int64_t E_all = in.region_e_off[g + 1] - in.region_e_off[g];
-    if (nr_g > POST_MAX_ROWS || E_all > POST_MAX_ENTRIES || S > POST_MAX_SNPS) { dev_post = false; continue; }
-    const uint32_t need = post_layout(nr_g, (uint32_t)E_all, S).total;
-    if (need > 64 * 1024) dev_post = false;
-    post_lds = std::max(post_lds, need);
+    bool fits = !(nr_g > POST_MAX_ROWS || E_all > POST_MAX_ENTRIES || S > POST_MAX_SNPS);
+    uint32_t need = 0;
+    if (fits) { need = post_layout(nr_g, (uint32_t)E_all, S).total; if (need > 64 * 1024) fits = false; }
+    if (force_host_post || !fits) { host_post[g] = 1; any_host_post = true; }
+    else post_lds = std::max(post_lds, need);
   }
 
-  // ---- queue `side`: fragment matrix to the host (pinned) -- all of it for the host epilogue, else only the
-  // chain regions' rows and entries, gathered into one block by k4_pack_chain
-  struct CsrView { const int64_t* row_ptr; const int32_t* col; const uint8_t* val; const uint32_t* links; };   // indexed by global row / entry
-  std::vector<CsrView> view(ng, CsrView{nullptr, nullptr, nullptr, nullptr});
+  // ---- queue `side`: the fragment matrix goes to the host (pinned) only when a region takes the host epilogue
   PCHK(hipEventRecord(ev_in, stream));
   PCHK(hipStreamWaitEvent(side, ev_in, 0));
-  if (!dev_post) {
+  if (any_host_post) {
     PCHK(h_pin[0].reserve((nr1 + 1) * 8)); PCHK(h_pin[1].reserve(nnz1 * 4));
     PCHK(h_pin[2].reserve(nnz1)); PCHK(h_pin[3].reserve(nr1 * 4));
     PCHK(hipMemcpyAsync(h_pin[0].p, in.d_row_ptr, (size_t)(nrow + 1) * 8, hipMemcpyDeviceToHost, side));
@@ -1795,36 +1434,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       PCHK(hipMemcpyAsync(h_pin[2].p, in.d_val, (size_t)nnz, hipMemcpyDeviceToHost, side));
     }
     if (nrow) PCHK(hipMemcpyAsync(h_pin[3].p, in.d_row_links, (size_t)nrow * 4, hipMemcpyDeviceToHost, side));
-    for (int g = 0; g < ng; g++) view[g] = CsrView{h_pin[0].as<int64_t>(), h_pin[1].as<int32_t>(), h_pin[2].as<uint8_t>(), h_pin[3].as<uint32_t>()};
-  } else if (!chain_slots.empty()) {
-    const size_t nc = chain_slots.size();
-    std::vector<PackItem> items(nc);
-    size_t at = (nc * sizeof(PackItem) + 15) & ~(size_t)15;   // the items themselves lead the block (upload), data follows
-    for (size_t k = 0; k < nc; k++) {
-      const int g = chain_slots[k];
-      PackItem& it = items[k];
-      it.r0 = in.row_region_off[g]; it.nrow = in.row_region_off[g + 1] - it.r0;
-      it.e0 = in.region_e_off[g]; it.ne = in.region_e_off[g + 1] - it.e0;
-      it.rp_at = (int64_t)at; at += ((size_t)(it.nrow + 1) * 8 + 15) & ~(size_t)15;
-      it.lk_at = (int64_t)at; at += ((size_t)it.nrow * 4 + 15) & ~(size_t)15;
-      it.col_at = (int64_t)at; at += ((size_t)it.ne * 4 + 15) & ~(size_t)15;
-      it.val_at = (int64_t)at; at += ((size_t)it.ne + 15) & ~(size_t)15;
-    }
-    PCHK(h_pin[0].reserve(at)); PCHK(d_state[17].reserve(at));
-    uint8_t* const hb = h_pin[0].as<uint8_t>(); uint8_t* const db = d_state[17].as<uint8_t>();
-    memcpy(hb, items.data(), nc * sizeof(PackItem));
-    PCHK(hipMemcpyAsync(db, hb, nc * sizeof(PackItem), hipMemcpyHostToDevice, side));
-    hipLaunchKernelGGL(k4_pack_chain, dim3((unsigned)nc), dim3(LCR_BLOCK), 0, side, (const PackItem*)db, in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, db);
-    PCHK(hipGetLastError());
-    const size_t head = (nc * sizeof(PackItem) + 15) & ~(size_t)15;
-    PCHK(hipMemcpyAsync(hb + head, db + head, at - head, hipMemcpyDeviceToHost, side));
-    for (size_t k = 0; k < nc; k++) {   // views keep the global row / entry numbering of the region
-      const PackItem& it = items[k];
-      view[chain_slots[k]] = CsrView{reinterpret_cast<const int64_t*>(hb + it.rp_at) - it.r0, reinterpret_cast<const int32_t*>(hb + it.col_at) - it.e0,
-                                     hb + it.val_at - it.e0, reinterpret_cast<const uint32_t*>(hb + it.lk_at) - it.r0};
-    }
   }
-  PCHK(hipEventRecord(ev_csr, side));
 
   // ---- queue `stream`: stage the phase matrices, fetch the per-region sizes
   StageStat* const stat = h_pin[5].as<StageStat>();
@@ -1833,162 +1443,13 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
                prm.min_linkers, prm.max_enum_snps, prm.seed};
     StageOut so{b_reg.as<RegionDev>(), b_stat.as<StageStat>(), b_prp.as<int32_t>(), b_pc.as<int32_t>(), b_pv.as<uint8_t>(),
                 b_cp.as<int32_t>(), b_cr.as<int32_t>(), b_cv.as<uint8_t>(), b_snp.as<uint8_t>(), b_snp.as<int8_t>() + nc1,
-                b_snp.as<uint8_t>() + 2 * nc1, b_sc.as<long long>(), b_cur.as<int32_t>()};
+                b_snp.as<uint8_t>() + 2 * nc1, b_sc.as<long long>(), b_cur.as<int32_t>(), b_psrc.as<int32_t>()};
     hipLaunchKernelGGL(k4_stage, dim3(ng), dim3(STAGE_THREADS), 0, stream, si, so, L.dev);
     PCHK(hipGetLastError());
     PCHK(hipMemcpyAsync(stat, b_stat.p, (size_t)ng * sizeof(StageStat), hipMemcpyDeviceToHost, stream));
     PCHK(hipMemsetAsync(b_st.p, 0, st_bytes, stream));
+    PCHK(hipEventRecord(ev_csr, stream));   // the chain kernels on `side` read the staged matrices
   }
-  // ---- host views of the regions (epilogue structures; LD blocks of the chain regions)
-  // per-region host state lives across calls (PhaseWork): a batch has hundreds of regions with a dozen
-  // vectors each, and re-allocating / freeing them every call cost more than the work done with them
-  if (!work) work = new PhaseWork();
-  PhaseWork& W = *static_cast<PhaseWork*>(work);
-  if ((int)W.R.size() < ng) { W.R.resize(ng); W.ld_blocks.resize(ng); W.RB.resize(ng); }
-  std::vector<RegionHost>& R = W.R;
-  std::vector<std::vector<std::vector<int>>>& ld_blocks = W.ld_blocks;
-  std::vector<RegionBuild>& RB = W.RB;
-  // chain start state (LD-seeded haplotypes, conserved flags) and the chain slot list: pinned, so that their uploads
-  // are queued instead of staged (three staged copies cost 0.1 ms between the enumeration launch and k4_chain_a)
-  PCHK(h_pin[10].reserve(2 * nc1 + (size_t)std::max(ng, 1) * 4 + 64));
-  struct PinVec8 { int8_t* p; int8_t* data() const { return p; } } h_delta0{h_pin[10].as<int8_t>()};
-  struct PinVecU8 { uint8_t* p; uint8_t* data() const { return p; } } h_cons{h_pin[10].as<uint8_t>() + nc1};
-  int32_t* const h_chain_slots = reinterpret_cast<int32_t*>(h_pin[10].as<uint8_t>() + ((2 * nc1 + 15) & ~(size_t)15));
-  memset(h_delta0.data(), 1, nc1); memset(h_cons.data(), 0, nc1);
-  memcpy(h_chain_slots, chain_slots.data(), chain_slots.size() * 4);
-  auto prep = [&](int g) {
-    RegionHost& rh = R[g];
-    RegionBuild& rb = RB[g];
-    rh.g = g; rh.c0 = in.cand_region_off[g]; rh.S = in.cand_region_off[g + 1] - rh.c0;
-    rh.r0 = in.row_region_off[g]; rh.nrow = in.row_region_off[g + 1] - rh.r0;
-    rh.row_ptr = view[g].row_ptr; rh.col = view[g].col; rh.val = view[g].val; rh.links = view[g].links;
-    rh.cand = cand.data() + rh.c0;
-    rh.seed = region_seed(prm.seed, in.region_start0[g]);
-    rh.min_linkers = prm.min_linkers;
-    rh.e0 = nrow ? rh.row_ptr[rh.r0] : 0;
-    if (rh.S == 0) return;
-    const bool chain = (uint32_t)rh.S > prm.max_enum_snps;
-    const int64_t e1 = rh.row_ptr[rh.r0 + rh.nrow];
-    rh.phase_site.assign((size_t)(e1 - rh.e0), 0);
-    rh.tag.assign(rh.nrow, 0); rh.asg.assign(rh.nrow, 0); rh.fp.assign(rh.nrow, 0);
-    if ((int)rh.cover.size() < rh.S) rh.cover.resize(rh.S);
-    for (int i = 0; i < rh.S; i++) rh.cover[i].clear();
-    rh.fp_rows.clear();
-    rb.prow_ptr.clear(); rb.pcol.clear(); rb.pval.clear();
-    rh.orig_flags.resize(rh.S);
-    for (int i = 0; i < rh.S; i++) rh.orig_flags[i] = rh.cand[i].flags;
-    if (chain) rb.prow_ptr.push_back(0);
-    for (int r = 0; r < rh.nrow; r++) {
-      for (int64_t e = rh.eb(r); e < rh.ee(r); e++) {
-        const int i = rh.lc(e);
-        rh.cover[i].push_back(r);
-        if (rh.fphase(i)) rh.phase_site[e - rh.e0] = 1;  // fragment.rs:144-146 snapshot
-      }
-      if (rh.links[rh.r0 + r] >= prm.min_linkers) {          // fragment.rs:253-255
-        rh.fp[r] = 1;
-        rh.fp_rows.push_back(r);
-        if (chain) {
-          for (int64_t e = rh.eb(r); e < rh.ee(r); e++)
-            if (rh.phase_site[e - rh.e0]) { rb.pcol.push_back(rh.lc(e)); rb.pval.push_back((uint8_t)(rh.val[e] & 63)); }
-          rb.prow_ptr.push_back((int32_t)rb.pcol.size());
-        }
-      }
-    }
-    // thread.rs:162-163: init_haplotypes + init_assignment consume S + F draws; both are overwritten
-    if (!chain) return;
-    const size_t n_prow = rh.fp_rows.size();
-    // ---- divide_snps_into_blocks (candidate.rs:615-747) + init_haplotypes_LD2 (phase.rs:609-671), host
-    const int F = (int)rh.fp_rows.size();
-    auto one_ref = [&](int i) {  // exactly one of the two major alleles is the reference (candidate.rs:637-660)
-      const lcr_candidate& c = rh.cand[i];
-      return (c.allele1 == c.ref_base) != (c.allele2 == c.ref_base);
-    };
-    // perfect-LD pairs (score == 0) in (i asc, j asc) order with their weights; weight_of(i<j) = 0 if absent
-    std::vector<std::pair<int, int>> pass;
-    std::vector<int> pass_w;
-    const bool flat = rh.S <= 512;
-    static thread_local std::vector<int> wtab;
-    std::map<std::pair<int, int>, int> wmap;
-    if (flat) wtab.assign((size_t)rh.S * rh.S, 0);
-    auto weight_of = [&](int i, int j) -> int {
-      if (flat) return wtab[(size_t)i * rh.S + j];
-      auto f = wmap.find({i, j});
-      return f == wmap.end() ? 0 : f->second;
-    };
-    auto consider = [&](int i, int j, const std::array<int, 4>& c) {   // snp.rs:158-188
-      if (!one_ref(i) || !one_ref(j)) return;
-      const lcr_candidate &si = rh.cand[i], &sj = rh.cand[j];
-      if (si.af1 == 0.0f || si.af2 == 0.0f || sj.af1 == 0.0f || sj.af2 == 0.0f) return;
-      const int cis = c[0] + c[3], trans = c[1] + c[2];
-      const int c1 = std::min(cis, trans), c2 = std::max(cis, trans);
-      const int weight = cis > trans ? c2 : -c2;
-      if (c2 > 0 && c1 == 0) {
-        pass.push_back({i, j}); pass_w.push_back(weight);
-        if (flat) wtab[(size_t)i * rh.S + j] = weight; else wmap[{i, j}] = weight;
-      }
-    };
-    // pair counts (i<j) -> [ref/alt i][ref/alt j]; visited in (i asc, j asc) order like the reference's sorted map
-    if (flat) {   // flat S x S table (the map version cost 1.6 ms per batch on the ont-drna profile)
-      static thread_local std::vector<std::array<int, 4>> tbl;
-      static thread_local std::vector<uint8_t> seen;
-      const size_t SS = (size_t)rh.S * rh.S;
-      tbl.assign(SS, std::array<int, 4>{0, 0, 0, 0}); seen.assign(SS, 0);
-      for (size_t k = 0; k < n_prow; k++)
-        for (int x = rb.prow_ptr[k]; x < rb.prow_ptr[k + 1]; x++)
-          for (int y = x + 1; y < rb.prow_ptr[k + 1]; y++) {
-            int i = rb.pcol[x], j = rb.pcol[y];
-            int pi = (rb.pval[x] & 32) ? 0 : 1, pj = (rb.pval[y] & 32) ? 0 : 1;
-            if (i > j) { std::swap(i, j); std::swap(pi, pj); }
-            tbl[(size_t)i * rh.S + j][pi * 2 + pj]++; seen[(size_t)i * rh.S + j] = 1;
-          }
-      for (int i = 0; i < rh.S; i++)
-        for (int j = i; j < rh.S; j++) if (seen[(size_t)i * rh.S + j]) consider(i, j, tbl[(size_t)i * rh.S + j]);
-    } else {
-      std::map<std::pair<int, int>, std::array<int, 4>> pairs;
-      for (size_t k = 0; k < n_prow; k++)
-        for (int x = rb.prow_ptr[k]; x < rb.prow_ptr[k + 1]; x++)
-          for (int y = x + 1; y < rb.prow_ptr[k + 1]; y++) {
-            int i = rb.pcol[x], j = rb.pcol[y];
-            int pi = (rb.pval[x] & 32) ? 0 : 1, pj = (rb.pval[y] & 32) ? 0 : 1;
-            if (i > j) { std::swap(i, j); std::swap(pi, pj); }
-            pairs[{i, j}][pi * 2 + pj]++;
-          }
-      for (auto& kv : pairs) consider(kv.first.first, kv.first.second, kv.second);
-    }
-    PGraph lg(rh.S);
-    for (auto& pq : pass) lg.add_edge(pq.first, pq.second);  // (i asc, j asc) = the reference's sorted-map loop order
-    // edges with |weight| < ld_weight_threshold are removed (candidate.rs:703-711), in the same order
-    for (size_t k = 0; k < pass.size(); k++)
-      if ((uint32_t)std::abs(pass_w[k]) < prm.ld_weight_threshold) lg.remove_edge(pass[k].first, pass[k].second);
-    ld_blocks[g] = lg.components();
-    // init_haplotypes_LD2: S random draws (ctr S+F ..), then BFS propagation inside each block
-    const uint64_t c_ld = (uint64_t)rh.S + (uint64_t)F;
-    int8_t* d0 = h_delta0.data() + rh.c0;
-    uint8_t* cons = h_cons.data() + rh.c0;
-    for (int i = 0; i < rh.S; i++) d0[i] = u01(rh.seed, c_ld + i) < 0.5 ? 1 : -1;
-    const int thr = (int)prm.ld_weight_threshold;
-    for (auto& block : ld_blocks[g]) {
-      if (block.size() < 2) continue;
-      std::vector<uint8_t> disc(rh.S, 0); std::vector<int> queue, visited;
-      size_t qh = 0;
-      disc[block[0]] = 1; queue.push_back(block[0]);
-      d0[block[0]] = 1;
-      visited.push_back(block[0]);
-      while (qh < queue.size()) {  // petgraph Bfs: pop front, push unseen neighbours
-        const int nx = queue[qh++];
-        for (int y : lg.adj[nx]) if (!disc[y]) { disc[y] = 1; queue.push_back(y); }
-        for (int vis : visited) {
-          if (vis == nx) continue;
-          const int w = weight_of(std::min(vis, nx), std::max(vis, nx));
-          if (w == 0) continue;  // pair absent, not valid, or not perfect LD
-          if (w >= thr) { d0[nx] = d0[vis]; break; }
-          if (w <= -thr) { d0[nx] = (int8_t)(-d0[vis]); break; }
-        }
-        visited.push_back(nx);
-      }
-      for (int i : block) cons[i] = 1;
-    }
-  };
   if (!pool) {
     // one ctx per GPU: share the host's hardware threads between the GPUs of the node
     int ndev = 1;
@@ -1998,33 +1459,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     nthreads = std::max(1, std::min(nthreads, getenv("LCR_HOST_THREADS") ? 256 : 48));
     pool = new HostPool(nthreads > 1 ? nthreads : 0);
   }
-  auto for_regions = [&](const std::function<void(int)>& fn) { pool->parallel_for(ng, fn); };
-  // the context's helper thread waits for the fragment matrix and prepares the chain regions while this thread sizes
-  // and launches the enumeration; joined before the chain kernels (and on every early return)
-  if (!helper_thread) helper_thread = new HelperThread();
-  struct Helper {
-    HelperThread* t; hipError_t err = hipSuccess;
-    void join() { t->join(); }
-    ~Helper() { join(); }
-  } helper{helper_thread};
-  {
-    int dev = 0;
-    PCHK(hipGetDevice(&dev));
-    helper_thread->start([&, dev]() {
-      if ((helper.err = hipSetDevice(dev)) != hipSuccess) return;
-      if ((helper.err = hipEventSynchronize(ev_csr)) != hipSuccess) return;
-      pool->parallel_for((int)chain_slots.size(), [&](int k) { prep(chain_slots[k]); });
-    });
-  }
   if (ng) PCHK(hipStreamSynchronize(stream));
   lap("stage + sizes");
 
-  // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
-  int32_t max_state = 0;
-  for (int g = 0; g < ng; g++) {
-    const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
-    if (S) max_state = std::max(max_state, stat[g].R + 2 * S);
-  }
   PostLut plut;
   for (int q = 0; q < 31; q++) { plut.le[q] = L.le[q]; plut.l1e[q] = L.l1e[q]; }
   plut.p_homref = L.p_homref; plut.p_homvar = L.p_homvar; plut.log_theta = L.log_theta; plut.log2 = L.log2;
@@ -2032,19 +1469,13 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
              in.d_row_region_off, in.d_start0, P.st_sigma, P.st_delta, P.st_eta, (int8_t*)(d_res + res_tag), d_res + res_asg,
              (uint32_t*)(d_res + res_ps), P.st_obj, (long long*)(d_hc + hc_obj), (lcr_candidate*)d_hc, prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr};
   if (prof) { PCHK(d_state[20].reserve((size_t)std::max(ng, 1) * 16 * 8)); PCHK(hipMemsetAsync(d_state[20].p, 0, (size_t)std::max(ng, 1) * 16 * 8, stream)); pin.dbg_clk = d_state[20].as<long long>(); }
-  if (!dev_post) { haplotag.assign(nrow, 0); assignment.assign(nrow, 0); phase_set.assign(nrow, 0); }
-  if (!dev_post) {   // host epilogue: every region needs its host view (the chain regions get theirs from the helper)
-    helper.join();
-    PCHK(helper.err);
-  }
-  if (!dev_post)
-    for_regions([&](int g) { if ((uint32_t)(in.cand_region_off[g + 1] - in.cand_region_off[g]) <= prm.max_enum_snps) prep(g); });
-  const int32_t stride = (max_state + 63) & ~63;
-  P.scratch_stride = stride;
-  const size_t dyn_bytes = stride <= 48 * 1024 ? (size_t)stride : 0;  // chain working state in LDS when it fits
-  P.lds_state = dyn_bytes ? 1 : 0;
-  size_t n_big_blocks = 0;
+
+  // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
   if (!enum_slots.empty()) {
+    int32_t max_state = 0;
+    for (int g : enum_slots) max_state = std::max(max_state, stat[g].R + 2 * (in.cand_region_off[g + 1] - in.cand_region_off[g]));
+    const int32_t stride = (max_state + 63) & ~63;
+    P.scratch_stride = stride;
     const bool force_big = getenv("LCR_ENUM_FORCE_BIG") != nullptr;        // test hooks: exercise the fallback kernels
     const bool force_stream = getenv("LCR_ENUM_FORCE_STREAM") != nullptr;
     // class 2: register-resident kernel (<= 32 entries per lane; smaller instantiations were measured: separate
@@ -2058,6 +1489,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     std::vector<int64_t> job_base(ng, 0);
     int64_t nj = 0;
     uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0};
+    std::vector<int32_t> post_slots;   // enumeration regions with the device epilogue
     for (int g : enum_slots) {
       const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
       const StageStat& st = stat[g];
@@ -2072,13 +1504,14 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       spans[cls].push_back({g, (uint32_t)n_t[cls]});
       n_t[cls] += (size_t)((n + per_of[cls] - 1) / per_of[cls]);
       nj += (int64_t)n;
+      if (!host_post[g]) post_slots.push_back(g);
     }
-    // one upload: spans of every class | job_base | slots ; then job objectives and winners
+    // one upload: spans of every class | job_base | slots | post slots ; then job objectives and winners
     size_t n_w[NCLS], s_off[NCLS], n_spans = 0;
     for (int k = 0; k < NCLS; k++) { n_w[k] = spans[k].size(); s_off[k] = n_spans; n_spans += n_w[k]; }
-    const size_t ns = enum_slots.size();
+    const size_t ns = enum_slots.size(), nps = post_slots.size();
     const size_t off_jb_al = (n_spans * sizeof(EnumSpan) + 7) & ~(size_t)7;
-    const size_t up_bytes = off_jb_al + (size_t)ng * 8 + ns * 4;
+    const size_t up_bytes = off_jb_al + (size_t)ng * 8 + (ns + nps) * 4;
     PCHK(b_job.reserve(up_bytes + 64));
     PCHK(b_obj.reserve((size_t)nj * 8 + (size_t)ng * 4 + 64));
     PCHK(h_pin[8].reserve(up_bytes + 64));   // pinned: the upload is queued, not staged
@@ -2086,14 +1519,16 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     for (int k = 0; k < NCLS; k++) memcpy(up + s_off[k] * sizeof(EnumSpan), spans[k].data(), n_w[k] * sizeof(EnumSpan));
     memcpy(up + off_jb_al, job_base.data(), (size_t)ng * 8);
     memcpy(up + off_jb_al + (size_t)ng * 8, enum_slots.data(), ns * 4);
+    memcpy(up + off_jb_al + (size_t)ng * 8 + ns * 4, post_slots.data(), nps * 4);
     PCHK(hipMemcpyAsync(b_job.p, up, up_bytes, hipMemcpyHostToDevice, stream));
     const EnumSpan* d_sp = b_job.as<EnumSpan>();
     const int64_t* d_jb = (const int64_t*)(b_job.as<uint8_t>() + off_jb_al);
     const int32_t* d_sl = (const int32_t*)(b_job.as<uint8_t>() + off_jb_al + (size_t)ng * 8);
+    const int32_t* d_psl = d_sl + ns;
     long long* d_obj = b_obj.as<long long>();
     uint32_t* d_win = (uint32_t*)(d_obj + nj);
-    n_big_blocks = std::max(n_t[4], n_w[4]);
-    PCHK(b_scr.reserve((size_t)stride * (n_big_blocks + chain_slots.size()) + 64));   // chain regions use the tail
+    const size_t n_big_blocks = std::max(n_t[4], n_w[4]);
+    PCHK(b_scr.reserve((size_t)stride * n_big_blocks + 64));
     P.scratch = b_scr.as<int8_t>();
     // the classes touch disjoint regions: class 2 on `stream`, classes 3 / 4 beside it on `aux` (their tails overlap)
     auto launch = [&](const size_t* cnt, const uint32_t* win) -> hipError_t {
@@ -2111,190 +1546,188 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(launch(n_t, nullptr));
     hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)ns), dim3(64), 0, stream, d_sl, (int32_t)ns, P.reg, d_jb, d_obj, d_win);
     PCHK(launch(n_w, d_win));
-    if (dev_post) hipLaunchKernelGGL(k4_post<LCR_BLOCK>, dim3((unsigned)ns), dim3(LCR_BLOCK), post_lds, stream, pin, d_sl, (int32_t)ns, plut);
+    if (nps) hipLaunchKernelGGL(k4_post<LCR_BLOCK>, dim3((unsigned)nps), dim3(LCR_BLOCK), post_lds, stream, pin, d_psl, (int32_t)nps, plut);
     PCHK(hipGetLastError());
   }
-  int8_t* const st1 = h_pin[4].as<int8_t>();   // enumeration results
-  int8_t* const st2 = h_pin[6].as<int8_t>();   // chain results
-  if (ng && !dev_post) PCHK(hipMemcpyAsync(st1, b_st.p, st_bytes, hipMemcpyDeviceToHost, stream));
   lap("enum launch");
-  helper.join();
-  PCHK(helper.err);
-  lap("chain regions prepared (helper thread)");
-
 
   // ---- chain regions on queue `side` (their own copy of the state arrays)
+  PhaseDev Pc = P;
+  Pc.st_sigma = b_stc.as<int8_t>() + st_sig; Pc.st_delta = b_stc.as<int8_t>() + st_del; Pc.st_eta = b_stc.as<int8_t>() + st_eta;
+  Pc.st_obj = (long long*)(b_stc.as<int8_t>() + st_obj);
   if (!chain_slots.empty()) {
-    PhaseDev Pc = P;
-    Pc.st_sigma = b_stc.as<int8_t>() + st_sig; Pc.st_delta = b_stc.as<int8_t>() + st_del; Pc.st_eta = b_stc.as<int8_t>() + st_eta;
-    Pc.st_obj = (long long*)(b_stc.as<int8_t>() + st_obj);
-    const int nc = (int)chain_slots.size();
-    PCHK(b_scr.reserve((size_t)stride * (n_big_blocks + nc) + 64));   // no-op when the enumeration branch sized it
-    Pc.scratch = b_scr.as<int8_t>() + (size_t)stride * n_big_blocks;
-    PCHK(b_slots.reserve((size_t)nc * 4 + 64));
-    PCHK(hipMemsetAsync(b_stc.p, 0, st_bytes, side));
-    PCHK(hipMemcpyAsync(b_stc.as<int8_t>() + st_del, h_delta0.data(), (size_t)ncand, hipMemcpyHostToDevice, side));
-    PCHK(hipMemcpyAsync(b_snp.as<uint8_t>() + 2 * nc1, h_cons.data(), (size_t)ncand, hipMemcpyHostToDevice, side));
-    PCHK(hipMemcpyAsync(b_slots.p, h_chain_slots, (size_t)nc * 4, hipMemcpyHostToDevice, side));
-    hipLaunchKernelGGL(k4_chain_a, dim3(nc), dim3(LCR_BLOCK), 0, side, Pc, b_slots.as<int32_t>(), nc);
-    PCHK(hipGetLastError());
-    PCHK(hipMemcpyAsync(st2, b_stc.p, st_bytes, hipMemcpyDeviceToHost, side));
-    PCHK(hipStreamSynchronize(side));
-    lap("  chain: launch A + state to host");
-    // LD-block flip pass on the host (phase.rs:1298-1394): a sum-of-ratios f64 decision per block
-    struct StHost { int8_t* p; int8_t* data() const { return p; } } st_host{st2};
-      auto block_pass = [&](int g) {
-        if (R[g].S == 0 || (uint32_t)R[g].S <= prm.max_enum_snps) return;
-        RegionHost& rh = R[g];
-        struct { int32_t sig_off, snp_off; } rd{R[g].r0, R[g].c0};
-        int8_t* sg = st_host.data() + st_sig + rd.sig_off; int8_t* dl = st_host.data() + st_del + rd.snp_off;
-        int8_t* et = st_host.data() + st_eta + rd.snp_off;
-        long long* ob = (long long*)(st_host.data() + st_obj) + g;
-        for (size_t k = 0; k < rh.fp_rows.size(); k++) rh.tag[rh.fp_rows[k]] = sg[k];
-        for (int i = 0; i < rh.S; i++) { rh.cand[i].haplotype = dl[i]; rh.cand[i].genotype = et[i]; }
-        // (flat arrays instead of the reference's maps: same contents, the maps cost 0.3 ms per batch)
-        std::vector<int> new_hap(rh.S, 0);
-        std::vector<int8_t> hap_set(rh.S, 0), in_block(rh.S, 0), flipv(rh.nrow, 0), hasflip(rh.nrow, 0), new_tag;
-        std::vector<int> touched;
-        std::vector<Obs> o, oflip;
-        const size_t n_blocks = ld_blocks[g].size();
-        for (size_t bi = 0; bi < n_blocks; bi++) {
-          const auto& block = ld_blocks[g][bi];
-          for (int idx : block) in_block[idx] = 1;
-          touched.clear();
-          double q = 0.0, qf = 0.0;
-          for (int idx : block) {
-            o.clear(); oflip.clear();
-            for (int r : rh.cover[idx]) {
-              if (!rh.fp[r] || rh.tag[r] == 0) continue;
-              bool flip_read = true;  // only entries *before* idx in the row can veto (phase.rs:1331-1349)
-              for (int64_t e = rh.eb(r); e < rh.ee(r); e++) {
-                if (!in_block[rh.lc(e)]) flip_read = false;
-                if (rh.lc(e) == idx) {
-                  if (!rh.phase_site[e - rh.e0]) continue;
-                  const int s = rh.tag[r], sf = flip_read ? -s : s;
-                  o.push_back({s, rh.val[e]}); oflip.push_back({sf, rh.val[e]});
-                  flipv[r] = (int8_t)sf;
-                  if (!hasflip[r]) { hasflip[r] = 1; touched.push_back(r); }
-                }
-              }
-            }
-            q += delta_eta_sigma_log(rh.cand[idx].haplotype, rh.cand[idx].genotype, o);      // phase.rs:178-236
-            qf += delta_eta_sigma_log(-rh.cand[idx].haplotype, rh.cand[idx].genotype, oflip);
-          }
-          const bool do_flip = q < qf;
-          for (int idx : block) { new_hap[idx] = do_flip ? -rh.cand[idx].haplotype : rh.cand[idx].haplotype; hap_set[idx] = 1; }
-          // every block rewrites the tag of every row (phase.rs:1364-1378): only the last block's version survives
-          if (bi + 1 == n_blocks) {
-            new_tag.resize(rh.nrow);
-            for (int r = 0; r < rh.nrow; r++) new_tag[r] = (do_flip && hasflip[r]) ? flipv[r] : rh.tag[r];
-          }
-          for (int idx : block) in_block[idx] = 0;
-          for (int r : touched) hasflip[r] = 0;
-        }
-        std::vector<int8_t> old_tag(rh.tag), old_hap(rh.S);
-        for (int i = 0; i < rh.S; i++) old_hap[i] = (int8_t)rh.cand[i].haplotype;
-        for (int i = 0; i < rh.S; i++) if (hap_set[i]) rh.cand[i].haplotype = new_hap[i];
-        for (size_t r = 0; r < new_tag.size(); r++) rh.tag[r] = new_tag[r];
-        const long long obj2 = rh.objective_fx(RB[g].prow_ptr, RB[g].pcol, RB[g].pval);
-        if (obj2 > *ob) {  // `prob > largest_prob` (phase.rs:1140-1144): keep the flipped state
-          *ob = obj2;
-          for (size_t k = 0; k < rh.fp_rows.size(); k++) sg[k] = rh.tag[rh.fp_rows[k]];
-          for (int i = 0; i < rh.S; i++) dl[i] = (int8_t)rh.cand[i].haplotype;
-        } else {             // load_best_configuration: back to launch A's state
-          rh.tag = old_tag;
-          for (int i = 0; i < rh.S; i++) rh.cand[i].haplotype = old_hap[i];
-        }
-      };
-      pool->parallel_for(nc, [&](int k) { block_pass(chain_slots[k]); });
-    lap("  chain: host block-flip pass");
-    PCHK(hipMemcpyAsync(b_stc.p, st2, st_bytes, hipMemcpyHostToDevice, side));
-    {   // room behind the working state for the largest chain matrix that fits 64 KB of LDS in total
+    // a region whose phase matrix is far beyond one CU gets all of them (persistent launch with grid barriers); the
+    // others run side by side, one workgroup each.  LCR_GRID_MIN_ENTRIES moves the boundary (tests: 0 = every region).
+    int64_t grid_min = 1 << 17;
+    if (const char* e = getenv("LCR_GRID_MIN_ENTRIES")) grid_min = atoll(e);
+    std::vector<int32_t> small, big;
+    for (int g : chain_slots) ((int64_t)stat[g].E >= grid_min ? big : small).push_back(g);
+    const int n_small = (int)small.size(), n_big = (int)big.size(), nc = n_small + n_big;
+    const int grid_waves = std::max(1, k4_grid_blocks()) * 16;
+    std::vector<ChainDesc> desc(nc);
+    int64_t tbl_cells = 0, adj_n = 0, part_n = 0;
+    int32_t max_state = 0;
+    for (int k = 0; k < nc; k++) {
+      const int g = k < n_small ? small[k] : big[k - n_small];
+      const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
+      ChainDesc& d = desc[k];
+      d.slot = g; d.W = std::max(1, std::min(stat[g].W, S)); d.pad_ = 0;
+      d.tbl_off = tbl_cells; tbl_cells += (int64_t)S * d.W;
+      d.adj_off = adj_n; adj_n += 2 * (int64_t)S * d.W;
+      d.n_parts = k < n_small ? 16 : (int32_t)std::max<int64_t>(16, std::min<int64_t>(grid_waves, (int64_t)(1 << 23) / S));
+      d.part_off = part_n; part_n += (int64_t)d.n_parts * S;
+      if (k < n_small) max_state = std::max(max_state, stat[g].R + 2 * S);
+    }
+    // post-phase: device epilogue for the chain regions that fit it
+    std::vector<int32_t> post_slots;
+    for (int k = 0; k < nc; k++) if (!host_post[desc[k].slot]) post_slots.push_back(desc[k].slot);
+    const size_t nps = post_slots.size();
+    const size_t desc_bytes = ((size_t)nc * sizeof(ChainDesc) + 15) & ~(size_t)15;
+    PCHK(h_pin[10].reserve(desc_bytes + nps * 4 + 64));
+    PCHK(b_desc.reserve(desc_bytes + 64)); PCHK(b_slots.reserve(nps * 4 + 64));
+    memcpy(h_pin[10].p, desc.data(), (size_t)nc * sizeof(ChainDesc));
+    memcpy(h_pin[10].as<uint8_t>() + desc_bytes, post_slots.data(), nps * 4);
+    PCHK(b_tbl.reserve((size_t)tbl_cells * 8 + 64)); PCHK(b_adj.reserve((size_t)adj_n * 4 + 64)); PCHK(b_part.reserve((size_t)part_n * 4 + 64));
+    const size_t ni = nc1 + (size_t)ng + 1;   // per-SNP int32 arrays: adj_ptr, blk_ptr (ni each), blk_of, blk_pos, blk_nodes, queue (nc1), stack (2 nc1)
+    PCHK(b_snpi.reserve((2 * ni + 6 * nc1) * 4 + 64)); PCHK(b_snpb.reserve(3 * nc1 + 64)); PCHK(b_q.reserve(2 * nc1 * 8 + 64));
+    PCHK(b_info.reserve((size_t)std::max(ng, 1) * 8 + 64)); PCHK(b_rowi.reserve(nr1 * 4 + 64)); PCHK(b_enti.reserve(2 * nnz1 * 4 + 64));
+    PCHK(b_work.reserve(st_bytes + 64)); PCHK(b_macc.reserve(nc1 * 8 + 64)); PCHK(b_ctl.reserve(sizeof(GridCtl)));
+    ChainDev C{};
+    const int32_t stride = (max_state + 63) & ~63;
+    Pc.scratch = nullptr; Pc.scratch_stride = stride;
+    const size_t dyn_state = (n_small && stride <= 48 * 1024) ? (size_t)stride : 0;   // working state in LDS when it fits
+    Pc.lds_state = dyn_state ? 1 : 0;
+    {   // room behind the working state for the largest chain matrix that fits 64 KB of dynamic LDS in total
       uint32_t want = 0;
-      for (int g : chain_slots) {
+      for (int g : small) {
         const uint32_t m = matview_bytes(stat[g].R, in.cand_region_off[g + 1] - in.cand_region_off[g], stat[g].E);
-        if (dyn_bytes && dyn_bytes + m + 64 <= 64 * 1024) want = std::max(want, m);
+        if (dyn_state && dyn_state + m + 64 <= 64 * 1024) want = std::max(want, m);
       }
       Pc.lds_mat = (int32_t)want;
     }
-    // 17 KB static (column accumulators) + up to 64 KB of state and matrix copy (per call: the attribute is per device)
-    PCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_chain_b), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    hipLaunchKernelGGL(k4_chain_b, dim3(nc), dim3(CHAIN_THREADS), dyn_bytes + (size_t)Pc.lds_mat, side, Pc, b_slots.as<int32_t>(), nc);
-    if (dev_post) {
+    C.P = Pc;
+    C.desc = b_desc.as<ChainDesc>();
+    C.row_ptr = in.d_row_ptr; C.col = in.d_col; C.val = in.d_val;
+    C.cand = in.d_cand; C.cand_off = in.d_cand_off; C.row_region_off = in.d_row_region_off;
+    C.prow_src = b_psrc.as<int32_t>();
+    C.ld_tbl = b_tbl.as<uint32_t>(); C.ld_adj = b_adj.as<int32_t>(); C.part_cnt = b_part.as<int32_t>();
+    int32_t* si32 = b_snpi.as<int32_t>();
+    C.adj_ptr = si32; C.blk_ptr = si32 + ni; C.blk_of = si32 + 2 * ni; C.blk_pos = C.blk_of + nc1; C.blk_nodes = C.blk_pos + nc1;
+    C.queue = C.blk_nodes + nc1; C.stack = C.queue + nc1;
+    C.seen = b_snpb.as<uint8_t>(); C.ld_ok = C.seen + nc1; C.new_hap = (int8_t*)(C.ld_ok + nc1);
+    C.qs = b_q.as<double>(); C.qfs = C.qs + nc1;
+    C.blk_info = b_info.as<int32_t>();
+    C.flipcol = b_rowi.as<int32_t>(); C.erow = b_enti.as<int32_t>(); C.cent = C.erow + nnz1;
+    C.w_sigma = b_work.as<int8_t>() + st_sig; C.w_delta = b_work.as<int8_t>() + st_del; C.w_eta = b_work.as<int8_t>() + st_eta;
+    C.macc = b_macc.as<unsigned long long>(); C.ctl = b_ctl.as<GridCtl>();
+    for (int q = 0; q < 31; q++) { C.le[q] = L.le[q]; C.l1e[q] = L.l1e[q]; }
+    C.p_homref = L.p_homref; C.p_homvar = L.p_homvar; C.log_theta = L.log_theta; C.log2 = L.log2;
+    chain_dev = C; chain_desc = desc;   // (lcr_get_ld_blocks reads the blocks back)
+    PCHK(hipStreamWaitEvent(side, ev_csr, 0));
+    PCHK(hipMemcpyAsync(b_desc.p, h_pin[10].p, (size_t)nc * sizeof(ChainDesc), hipMemcpyHostToDevice, side));
+    if (nps) PCHK(hipMemcpyAsync(b_slots.p, h_pin[10].as<uint8_t>() + desc_bytes, nps * 4, hipMemcpyHostToDevice, side));
+    PCHK(k4_chain_launch_wg(C, 0, n_small, dyn_state + (size_t)Pc.lds_mat, side));
+    for (int k = 0; k < n_big; k++) PCHK(k4_chain_launch_grid(C, n_small + k, side));
+    if (nps) {
       PostIn pinc = pin;
       pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta; pinc.st_obj = Pc.st_obj;
       // 33 KB of static stage buffers + up to 64 KB of region image (set per call: the attribute is per device)
       PCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_post<CHAIN_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      hipLaunchKernelGGL(k4_post<CHAIN_THREADS>, dim3(nc), dim3(CHAIN_THREADS), post_lds, side, pinc, b_slots.as<int32_t>(), nc, plut);
+      hipLaunchKernelGGL(k4_post<CHAIN_THREADS>, dim3((unsigned)nps), dim3(CHAIN_THREADS), post_lds, side, pinc, b_slots.as<int32_t>(), (int32_t)nps, plut);
       PCHK(hipGetLastError());
-    } else {
-      PCHK(hipGetLastError());
-      PCHK(hipMemcpyAsync(st2, b_stc.p, st_bytes, hipMemcpyDeviceToHost, side));
     }
-    PCHK(hipStreamSynchronize(side));
-  }
-  lap("chain kernels + block pass");
-  if (dev_post) {
-    // results: per-row haplotag / assignment / phase set, candidates and objectives were written to pinned host
-    // memory by k4_post on either queue (`side` is settled above)
-    uint8_t* const h_res = h_pin[7].as<uint8_t>();
-    int8_t* const h_tag = (int8_t*)(h_res + res_tag); uint8_t* const h_asg = h_res + res_asg; uint32_t* const h_ps = (uint32_t*)(h_res + res_ps);
-    PCHK(hipStreamSynchronize(stream));
-    PCHK(hipGetLastError());
-    if (ncand) memcpy(cand.data(), h_pin[9].p, (size_t)ncand * sizeof(lcr_candidate));
-    const long long* const h_obj = (const long long*)(h_pin[9].as<uint8_t>() + hc_obj);
-    for (int g = 0; g < ng; g++)
-      if (in.cand_region_off[g + 1] > in.cand_region_off[g]) objective[g] = (double)h_obj[g] / FX_SCALE;
-    r_haplotag = h_tag; r_assignment = h_asg; r_phase_set = h_ps;
-    if (prof && pin.dbg_clk) {   // steps of k4_post: the slowest workgroup of each kind of region, and the median total
-      std::vector<long long> clk((size_t)ng * 16);
-      PCHK(hipMemcpy(clk.data(), pin.dbg_clk, clk.size() * 8, hipMemcpyDeviceToHost));
-      static const char* nm[] = {"stage rows", "stage entries + column index", "reads_hap", "snp_hap", "reads_hap + snp_hap", "rescue x2",
-                                 "reads_hap + snp_hap", "phase_set", "write back"};
-      for (int chain = 0; chain < 2; chain++) {
-        std::vector<std::pair<long long, int>> tot;
-        for (int g = 0; g < ng; g++) {
-          const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
-          if (S == 0 || ((uint32_t)S > prm.max_enum_snps) != (chain == 1)) continue;
-          tot.push_back({clk[(size_t)g * 16 + 9] - clk[(size_t)g * 16], g});
-        }
-        if (tot.empty()) continue;
-        std::sort(tot.begin(), tot.end());
-        const int g = tot.back().second;
-        fprintf(stderr, "[phase]   k4_post %s regions: %zu workgroups, median %.1f us, slowest %.1f us (region %d: %d rows, %d entries, %d SNPs)\n",
-                chain ? "chain" : "enumeration", tot.size(), (double)tot[tot.size() / 2].first / 100.0, (double)tot.back().first / 100.0, g,
-                in.row_region_off[g + 1] - in.row_region_off[g], stat[g].E_all, in.cand_region_off[g + 1] - in.cand_region_off[g]);
-        for (int k = 0; k < 9; k++) fprintf(stderr, "[phase]     %-30s %7.1f us\n", nm[k], (double)(clk[(size_t)g * 16 + k + 1] - clk[(size_t)g * 16 + k]) / 100.0);
-      }
-    }
-    lap("device epilogue + results");
-    return LCR_OK;
-  }
+  } else chain_desc.clear();
+  lap("chain launch");
+  PCHK(hipStreamSynchronize(side));
+  lap("chain kernels");
   PCHK(hipStreamSynchronize(stream));
   PCHK(hipGetLastError());
-  lap("wait enum");
-  // ---- scatter device results into the host region views
-  auto scatter = [&](int g) {
+  lap("enumeration kernels");
+
+  // ---- results: per-row haplotag / assignment / phase set, candidates and objectives were written to pinned host
+  // memory by k4_post on either queue
+  uint8_t* const h_res = h_pin[7].as<uint8_t>();
+  int8_t* const h_tag = (int8_t*)(h_res + res_tag); uint8_t* const h_asg = h_res + res_asg; uint32_t* const h_ps = (uint32_t*)(h_res + res_ps);
+  const long long* const h_obj = (const long long*)(h_pin[9].as<uint8_t>() + hc_obj);
+  for (int g = 0; g < ng; g++) {
+    const int c0 = in.cand_region_off[g], S = in.cand_region_off[g + 1] - c0;
+    if (S == 0 || host_post[g]) continue;
+    memcpy(cand.data() + c0, h_pin[9].as<lcr_candidate>() + c0, (size_t)S * sizeof(lcr_candidate));
+    objective[g] = (double)h_obj[g] / FX_SCALE;
+  }
+  r_haplotag = h_tag; r_assignment = h_asg; r_phase_set = h_ps;
+  if (prof && pin.dbg_clk) {   // steps of k4_post: the slowest workgroup of each kind of region, and the median total
+    std::vector<long long> clk((size_t)ng * 16);
+    PCHK(hipMemcpy(clk.data(), pin.dbg_clk, clk.size() * 8, hipMemcpyDeviceToHost));
+    static const char* nm[] = {"stage rows", "stage entries + column index", "reads_hap", "snp_hap", "reads_hap + snp_hap", "rescue x2",
+                               "reads_hap + snp_hap", "phase_set", "write back"};
+    for (int chain = 0; chain < 2; chain++) {
+      std::vector<std::pair<long long, int>> tot;
+      for (int g = 0; g < ng; g++) {
+        const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
+        if (S == 0 || host_post[g] || ((uint32_t)S > prm.max_enum_snps) != (chain == 1)) continue;
+        tot.push_back({clk[(size_t)g * 16 + 9] - clk[(size_t)g * 16], g});
+      }
+      if (tot.empty()) continue;
+      std::sort(tot.begin(), tot.end());
+      const int g = tot.back().second;
+      fprintf(stderr, "[phase]   k4_post %s regions: %zu workgroups, median %.1f us, slowest %.1f us (region %d: %d rows, %d entries, %d SNPs)\n",
+              chain ? "chain" : "enumeration", tot.size(), (double)tot[tot.size() / 2].first / 100.0, (double)tot.back().first / 100.0, g,
+              in.row_region_off[g + 1] - in.row_region_off[g], stat[g].E_all, in.cand_region_off[g + 1] - in.cand_region_off[g]);
+      for (int k = 0; k < 9; k++) fprintf(stderr, "[phase]     %-30s %7.1f us\n", nm[k], (double)(clk[(size_t)g * 16 + k + 1] - clk[(size_t)g * 16 + k]) / 100.0);
+    }
+  }
+  if (!any_host_post) { lap("results"); return LCR_OK; }
+
+  // ---- host epilogue (thread.rs:168-201) for the regions that did not take k4_post.  Regions are independent (the
+  // reference runs them as rayon tasks, thread.rs:77): a small host thread pool walks them; results do not depend
+  // on the thread count (per-region RNG stream, disjoint output rows).
+  PCHK(h_pin[4].reserve(st_bytes + 16)); PCHK(h_pin[6].reserve(st_bytes + 16));
+  int8_t* const st1 = h_pin[4].as<int8_t>();   // enumeration results
+  int8_t* const st2 = h_pin[6].as<int8_t>();   // chain results
+  PCHK(hipMemcpyAsync(st1, b_st.p, st_bytes, hipMemcpyDeviceToHost, stream));
+  PCHK(hipMemcpyAsync(st2, b_stc.p, st_bytes, hipMemcpyDeviceToHost, stream));
+  PCHK(hipStreamSynchronize(stream));
+  if (!work) work = new PhaseWork();
+  PhaseWork& W = *static_cast<PhaseWork*>(work);
+  if ((int)W.R.size() < ng) W.R.resize(ng);
+  std::vector<RegionHost>& R = W.R;
+  auto epilogue = [&](int g) {
+    if (!host_post[g]) return;
     RegionHost& rh = R[g];
-    if (rh.S == 0) return;
+    rh.g = g; rh.c0 = in.cand_region_off[g]; rh.S = in.cand_region_off[g + 1] - rh.c0;
+    rh.r0 = in.row_region_off[g]; rh.nrow = in.row_region_off[g + 1] - rh.r0;
+    rh.row_ptr = h_pin[0].as<int64_t>(); rh.col = h_pin[1].as<int32_t>(); rh.val = h_pin[2].as<uint8_t>(); rh.links = h_pin[3].as<uint32_t>();
+    rh.cand = cand.data() + rh.c0;
+    rh.seed = region_seed(prm.seed, in.region_start0[g]);
+    rh.min_linkers = prm.min_linkers;
+    rh.e0 = rh.row_ptr[rh.r0];
     const bool chain = (uint32_t)rh.S > prm.max_enum_snps;
+    const int64_t e1 = rh.row_ptr[rh.r0 + rh.nrow];
+    rh.phase_site.assign((size_t)(e1 - rh.e0), 0);
+    rh.tag.assign(rh.nrow, 0); rh.asg.assign(rh.nrow, 0); rh.fp.assign(rh.nrow, 0);
+    if ((int)rh.cover.size() < rh.S) rh.cover.resize(rh.S);
+    for (int i = 0; i < rh.S; i++) rh.cover[i].clear();
+    rh.fp_rows.clear();
+    rh.orig_flags.resize(rh.S);
+    for (int i = 0; i < rh.S; i++) rh.orig_flags[i] = rh.cand[i].flags;
+    for (int r = 0; r < rh.nrow; r++) {
+      for (int64_t e = rh.eb(r); e < rh.ee(r); e++) {
+        const int i = rh.lc(e);
+        rh.cover[i].push_back(r);
+        if (rh.fphase(i)) rh.phase_site[e - rh.e0] = 1;  // fragment.rs:144-146 snapshot
+      }
+      if (rh.links[rh.r0 + r] >= prm.min_linkers) { rh.fp[r] = 1; rh.fp_rows.push_back(r); }   // fragment.rs:253-255
+    }
+    // the optimiser's result
     const int8_t* st = chain ? st2 : st1;
     const int8_t* sg = st + st_sig + rh.r0; const int8_t* dl = st + st_del + rh.c0; const int8_t* et = st + st_eta + rh.c0;
-    const long long ob = *((const long long*)(st + st_obj) + g);
-    std::fill(rh.tag.begin(), rh.tag.end(), 0);
     for (size_t k = 0; k < rh.fp_rows.size(); k++) rh.tag[rh.fp_rows[k]] = sg[k];
     for (int i = 0; i < rh.S; i++) { rh.cand[i].haplotype = dl[i]; rh.cand[i].genotype = et[i]; }
-    objective[g] = (double)ob / FX_SCALE;
+    objective[g] = (double)(*((const long long*)(st + st_obj) + g)) / FX_SCALE;
+    // draws so far: thread.rs:162-163 (S + F, overwritten), then the optimiser's (see k4_post)
     const uint64_t S = rh.S, F = rh.fp_rows.size();
     rh.ctr = !chain ? S + F + ((uint64_t)1 << S) * F : 2 * (S + F) + (S / 4 + 1) * (S + F);
-  };
-  // ---- post-phase epilogue, thread.rs:168-201.  Regions are independent (the reference runs them as
-  // rayon tasks, thread.rs:77): a small host thread pool walks them; results do not depend on the
-  // thread count (per-region RNG stream, disjoint output rows).
-  auto epilogue = [&](int g) {
-    RegionHost& rh = R[g];
-    if (rh.S == 0) return;
-    scatter(g);
     rh.assign_reads_haplotype(prm.read_assign_cutoff);
     rh.assign_snp_haplotype_genotype();
     rh.assign_reads_haplotype(prm.read_assign_cutoff);
@@ -2304,20 +1737,18 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     rh.eval_rescue(LCR_F_CAND_SOMATIC, relaxed, true);
     rh.assign_reads_haplotype(prm.read_assign_cutoff);
     rh.assign_snp_haplotype_genotype();
-    rh.assign_phase_set(prm.min_phase_score, phase_set.data());
-    for (int r = 0; r < rh.nrow; r++) { haplotag[rh.r0 + r] = rh.tag[r]; assignment[rh.r0 + r] = rh.asg[r]; }
+    for (int r = 0; r < rh.nrow; r++) h_ps[rh.r0 + r] = 0;
+    rh.assign_phase_set(prm.min_phase_score, h_ps);
+    for (int r = 0; r < rh.nrow; r++) { h_tag[rh.r0 + r] = rh.tag[r]; h_asg[rh.r0 + r] = rh.asg[r]; }
   };
-  if (prof) {   // per-region cost of the epilogue (serial sum / max), to tell work from pool overhead
-    std::vector<double> tr(ng, 0.0);
-    for_regions([&](int g) { auto t0 = std::chrono::steady_clock::now(); epilogue(g); tr[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); });
-    double sum = 0, mx = 0; for (double v : tr) { sum += v; mx = std::max(mx, v); }
-    fprintf(stderr, "[phase] epilogue per-region: sum %.3f ms, max %.3f ms over %d regions, %d threads\n", sum, mx, ng, pool->size());
-  } else
-  for_regions(epilogue);
-  lap("scatter + post-phase epilogue");
-  r_haplotag = haplotag.data(); r_assignment = assignment.data(); r_phase_set = phase_set.data();
+  pool->parallel_for(ng, epilogue);
+  lap("host post-phase epilogue");
   // keep the device copy of the candidates current (lcr_get_candidates_device)
-  if (ncand) { PCHK(hipMemcpyAsync(const_cast<lcr_candidate*>(in.d_cand), cand.data(), (size_t)ncand * sizeof(lcr_candidate), hipMemcpyHostToDevice, stream)); PCHK(hipStreamSynchronize(stream)); }
+  for (int g = 0; g < ng; g++) {
+    const int c0 = in.cand_region_off[g], S = in.cand_region_off[g + 1] - c0;
+    if (S && host_post[g]) PCHK(hipMemcpyAsync(const_cast<lcr_candidate*>(in.d_cand) + c0, cand.data() + c0, (size_t)S * sizeof(lcr_candidate), hipMemcpyHostToDevice, stream));
+  }
+  PCHK(hipStreamSynchronize(stream));
   return LCR_OK;
 #undef PCHK
 }

@@ -1,0 +1,65 @@
+// k4_types.h — plain kernel-argument structs of the K4 kernels (shared by k4_phase.hip, k4_grid.hip and the host driver).
+#pragma once
+#include "lcr_dev.h"
+
+struct RegionDev {
+  int32_t R, S;          // phasing rows, candidates
+  int32_t rp_off;        // prow_ptr offset (R+1 entries)
+  int32_t cp_off;        // ccol_ptr offset (S+1 entries)
+  int64_t e_off;         // offset of this region's entries in pcol/pval and crow/cval
+  int32_t sig_off;       // offset into per-row state arrays
+  int32_t snp_off;       // offset into per-SNP arrays
+  uint64_t seed;
+  long long f_total;     // sum of fe[q] over all phase entries (the sigma/delta independent part of the objective)
+};
+
+struct PhaseDev {
+  const RegionDev* reg;
+  const int32_t* prow_ptr; const int32_t* pcol; const uint8_t* pval;
+  const int32_t* ccol_ptr; const int32_t* crow; const uint8_t* cval;
+  const uint8_t* snp_fp; const int8_t* snp_vt; const uint8_t* snp_cons;
+  const long long* snp_const;  // per SNP: F = sum fe, W = sum w, Cref = sum (p==+1 ? f1e : fe), Cvar = sum (p==-1 ? f1e : fe)
+  int8_t* st_sigma; int8_t* st_delta; int8_t* st_eta; long long* st_obj;  // per region best / result state
+  int8_t* scratch; int32_t scratch_stride;                                // per block working state
+  int32_t lds_state;                                                      // 1: working state lives in dynamic LDS
+  int32_t lds_mat;                                                        // bytes of dynamic LDS behind the state for a matrix copy
+  PhaseLutDev lut;
+};
+
+// per-region sizes k4_stage reports to the host
+struct StageStat { int32_t R, E, max_n, max_rows, E_all, W; };   // max_*: per-lane share of k4_enum_reg's row partition; E_all: all entries;
+                                                                  // W: largest distance (in SNP indices) between two for_phasing entries of one fragment row
+struct PostLut { double le[31], l1e[31]; double p_homref, p_homvar, log_theta, log2; };
+
+
+// ---- chain regions on the device (k4_grid.hip): LD blocks, LD-seeded start, block-flip pass, perturbation rounds
+struct ChainDesc {
+  int32_t slot;        // region index
+  int32_t W;           // band width of the pair table (>= 1)
+  int64_t tbl_off;     // pair table of the region: S x W cells of {cis, trans} u32 counters, offset in cells
+  int64_t adj_off;     // adjacency lists (<= 2 S W entries), offset in entries
+  int64_t part_off;    // per (row part, SNP) counters of the ordered column index, offset in int32
+  int32_t n_parts, pad_;
+};
+struct GridCtl { unsigned arrive, gen, flag[2]; unsigned long long acc[2]; unsigned pad_[8]; };   // grid barrier + reductions
+struct ChainDev {
+  PhaseDev P;                     // phase matrices; st_* = best / result state of every region
+  const ChainDesc* desc;
+  // K3's fragment matrix and the candidates (pair counts and the flip veto look at every entry of a row)
+  const int64_t* row_ptr; const int32_t* col; const uint8_t* val;
+  const lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off;
+  const int32_t* prow_src;        // phasing row -> fragment row (region relative), at sig_off + k
+  uint32_t* ld_tbl; int32_t* ld_adj; int32_t* part_cnt;
+  // per SNP (at snp_off + i, *_ptr arrays at cp_off + i)
+  int32_t* adj_ptr; int32_t* blk_ptr; int32_t* blk_of; int32_t* blk_pos; int32_t* blk_nodes;
+  int32_t* stack; int32_t* queue; uint8_t* seen; uint8_t* ld_ok; int8_t* new_hap;
+  double* qs; double* qfs;
+  int32_t* blk_info;              // per region: number of blocks, flip verdict of the last block
+  // per phasing row (at sig_off + k) / per phase entry (at e_off + e)
+  int32_t* flipcol; int32_t* erow; int32_t* cent;
+  // working state of the grid path (global memory; the one-workgroup path keeps it in LDS)
+  int8_t* w_sigma; int8_t* w_delta; int8_t* w_eta; unsigned long long* macc;
+  GridCtl* ctl;
+  double le[31], l1e[31], p_homref, p_homvar, log_theta, log2;   // libm values of the block-flip sums (host table)
+};
+

@@ -57,6 +57,7 @@ struct lcr_ctx {
   // K4 + post-phase
   bool have_phase = false;
   PhaseHost phase;
+  std::vector<int32_t> ld_off, ld_snps;   // lcr_get_ld_blocks
 
   // region discovery (N3)
   DevBuf rd_start, rd_end, rd_diff, rd_ex, rd_cnt, rd_off, rd_s, rd_e, rd_max;
@@ -652,6 +653,19 @@ int lcr_get_phase_result(lcr_ctx* c, lcr_phase_result* out) {
   out->n_rows = c->n_rows; out->n_regions = c->bv.n_regions;
   out->haplotag = c->phase.r_haplotag; out->assignment = c->phase.r_assignment;
   out->phase_set = c->phase.r_phase_set; out->objective = c->phase.objective.data();
+  return LCR_OK;
+}
+
+int lcr_get_ld_blocks(lcr_ctx* c, int32_t region, int32_t* n_blocks, const int32_t** block_off, const int32_t** snp_idx) {
+  if (!c || !n_blocks || !block_off || !snp_idx) return LCR_E_ARG;
+  if (!c->have_phase) { c->err = "lcr_get_ld_blocks before lcr_phase"; return LCR_E_STATE; }
+  if (region < 0 || region >= c->bv.n_regions) { c->err = "lcr_get_ld_blocks: no such region"; return LCR_E_ARG; }
+  PhaseInputs in;
+  in.n_regions = c->bv.n_regions;
+  in.cand_region_off = c->h_cand_off.data();
+  const int rc = c->phase.ld_blocks(in, region, &c->ld_off, &c->ld_snps, c->stream, &c->err);
+  if (rc != LCR_OK) return rc;
+  *n_blocks = (int32_t)c->ld_off.size() - 1; *block_off = c->ld_off.data(); *snp_idx = c->ld_snps.data();
   return LCR_OK;
 }
 

@@ -9,6 +9,7 @@
 #include <thread>
 
 #include "lcr_dev.h"
+#include "k4_types.h"
 
 struct PhaseInputs {
   int32_t n_regions = 0, n_rows = 0;
@@ -116,7 +117,7 @@ struct PhaseHost {
   const int8_t* r_haplotag = nullptr;      // results of the last run (host vectors above or pinned buffers)
   const uint8_t* r_assignment = nullptr;
   const uint32_t* r_phase_set = nullptr;
-  DevBuf d_state[21];
+  DevBuf d_state[36];
   HostBuf h_pin[11];   // pinned staging: row_ptr, col, val, links, enum state, region sizes, chain state, results, job tables, chain start
   hipStream_t side = nullptr;   // second queue: fragment matrix download + chain regions
   hipEvent_t ev_in = nullptr, ev_csr = nullptr, ev_fork = nullptr, ev_join = nullptr;
@@ -124,6 +125,10 @@ struct PhaseHost {
   HostPool* pool = nullptr;
   HelperThread* helper_thread = nullptr;
   void* work = nullptr;   // PhaseWork (k4_phase.hip): per-region host state reused across calls
+  ChainDev chain_dev{};                // chain-region buffers of the last run (LD blocks are read back from them)
+  std::vector<ChainDesc> chain_desc;
+  // LD blocks of one region of the last run in the reference's order (candidate.rs:733-745): off[n_blocks + 1], SNP indices
+  int ld_blocks(const PhaseInputs& in, int region, std::vector<int32_t>* off, std::vector<int32_t>* snps, hipStream_t s, std::string* err);
   void free_work();
   int run(const PhaseInputs& in, const lcr_params& p, hipStream_t s, std::string* err);
   void release() {

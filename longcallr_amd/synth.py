@@ -9,7 +9,9 @@ against the oracle.  q >= 1 always (q = 0 makes the reference's optimiser NaN-pa
 Profiles:
   ont-cdna  (C3): both strands, sub 3 % / ins 1 % / del 1.5 %, quals {3,7,12,18,25,35}
   masseq    (C4): forward strand only, error 0.3 %, quals {40,27,22,17,10,3}
-  ont-drna  (C5): forward transcript strand, error 6 %, one dense island
+  ont-drna  (C3-shaped dRNA runs): forward transcript strand, 6 % errors in total (4 % substitutions)
+  ont-drna-c5 (C5): 6 % substitutions + 1 % ins + 1.5 % del, ~one candidate site per 200 bp of window (het SNPs and
+            recurrent-error hot-spots); `make_island` lays its loci out as ONE coverage island
 """
 import numpy as np
 
@@ -25,14 +27,22 @@ PROFILES = {
     "ont-drna": dict(sub=0.04, ins=0.008, dele=0.012, both_strands=False,
                      quals=([3, 7, 12, 18, 25, 35], [0.03, 0.07, 0.15, 0.30, 0.30, 0.15]),
                      mean_len=1500, sigma_len=0.4, het_per_exonic_bp=1 / 400.0, hom_frac=0.05, edit_frac=0.1),
+    # 25 % exonic => one site per 200 bp of window = one per 50 exonic bp; 70 % het SNPs,
+    # 30 % recurrent-error hot-spots (alt allele on a haplotype-independent 15-45 % of the reads)
+    "ont-drna-c5": dict(sub=0.06, ins=0.01, dele=0.015, both_strands=False,
+                        quals=([3, 7, 12, 18, 25, 35], [0.03, 0.07, 0.15, 0.30, 0.30, 0.15]),
+                        mean_len=1500, sigma_len=0.4, het_per_exonic_bp=0.7 / 50.0, hom_frac=0.02, edit_frac=0.03,
+                        hotspot_per_exonic_bp=0.3 / 50.0),
 }
 _ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 _COMP = {0: 3, 1: 2, 2: 1, 3: 0}
 OP_M, OP_I, OP_D, OP_N, OP_S = 0, 1, 2, 3, 4
 
 
-def _gene(rng, prof, gene_len, depth, gene_start, exon_frac=0.25):
-    """One gene: returns per-read arrays + concatenated bases/quals/cigar (gene-local offsets)."""
+def _gene(rng, prof, gene_len, depth, gene_start, exon_frac=0.25, ref_in=None, ref_guard=0):
+    """One gene: returns per-read arrays + concatenated bases/quals/cigar (gene-local offsets).
+    ref_in: a writable slice of a shared reference (>= gene_len + 64 + slack) to use instead of a private one;
+    the first and last ref_guard columns of the gene are then left unmodified (they belong to the neighbours too)."""
     # ---- exon structure: 8-14 exons of 300-800 bp, scaled to ~exon_frac of the gene
     n_ex = int(rng.integers(8, 15))
     ex_len = rng.integers(300, 801, size=n_ex)
@@ -47,16 +57,25 @@ def _gene(rng, prof, gene_len, depth, gene_start, exon_frac=0.25):
         ex_start[k] = ex_start[k - 1] + ex_len[k - 1] + in_len[k - 1]
     span = int(ex_start[-1] + ex_len[-1])
     tx2g = np.concatenate([np.arange(s, s + l) for s, l in zip(ex_start, ex_len)])  # exonic -> gene coords
-    ref = _ACGT[rng.integers(0, 4, size=span + 64)]
+    if ref_in is None:
+        ref = _ACGT[rng.integers(0, 4, size=span + 64)]
+    else:
+        assert ref_in.size >= span + 64, (ref_in.size, span)
+        ref = ref_in[:span + 64]
     plus_gene = bool(rng.integers(0, 2)) if prof["both_strands"] else True
     # ---- variants at exonic positions
     n_het = max(1, int(rng.poisson(T * prof["het_per_exonic_bp"])))
     n_hom = int(round(n_het * prof["hom_frac"]))
     n_edit = int(round(n_het * prof["edit_frac"]))
-    vpos = rng.choice(T, size=min(T, n_het + n_hom + n_edit), replace=False)
-    het_t, hom_t, edit_t = vpos[:n_het], vpos[n_het:n_het + n_hom], vpos[n_het + n_hom:]
+    n_hot = int(rng.poisson(T * prof.get("hotspot_per_exonic_bp", 0.0)))
+    vpos = rng.choice(T, size=min(T, n_het + n_hom + n_edit + n_hot), replace=False)
+    het_t, hom_t = vpos[:n_het], vpos[n_het:n_het + n_hom]
+    edit_t, hot_t = vpos[n_het + n_hom:n_het + n_hom + n_edit], vpos[n_het + n_hom + n_edit:]
     refi = np.searchsorted(_ACGT, ref[:span])  # 0..3
     alt_of = (refi + rng.integers(1, 4, size=span)) % 4
+    if ref_guard and edit_t.size:
+        g = tx2g[edit_t]
+        edit_t = edit_t[(g >= ref_guard) & (g < span - ref_guard)]
     if edit_t.size:  # A>G on + genes, T>C on - genes (candidate.rs:382-407)
         g = tx2g[edit_t]
         ref[g] = ord("A") if plus_gene else ord("T")
@@ -89,6 +108,10 @@ def _gene(rng, prof, gene_len, depth, gene_start, exon_frac=0.25):
     b[m] = alt_of[gpos[m]]
     if edit_t.size:
         af_t = np.zeros(T); af_t[edit_t] = edit_af
+        m = rng.random(N) < af_t[tpos]
+        b[m] = alt_of[gpos[m]]
+    if hot_t.size:   # recurrent errors: one fixed wrong base, haplotype-independent
+        af_t = np.zeros(T); af_t[hot_t] = rng.uniform(0.15, 0.45, size=hot_t.size)
         m = rng.random(N) < af_t[tpos]
         b[m] = alt_of[gpos[m]]
     u = rng.random(N)
@@ -230,5 +253,54 @@ def make_batch(profile="ont-cdna", n_genes=4, gene_len=25000, depth=40.0, seed=1
                      start0=regions_start, len=regions_len, read_begin=read_begin, ref=np.concatenate(refs))
 
 
+def make_island(profile="ont-drna-c5", n_loci=40, locus_len=25000, depth=500.0, seed=1, overlap=400, min_q1=True):
+    """ONE region.  n_loci gene loci are laid out on a shared reference so that consecutive loci
+    overlap by `overlap` columns (the last exon of a locus reaches into the first exon of the next), which makes the
+    whole window a single coverage island (util.rs:236-332 would emit it as one region): n_loci x locus_len columns
+    at mean aligned depth `depth`, reads sorted by position.  C5 = 40 x 25 kb at 500x."""
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    rng = np.random.default_rng(seed)
+    prof = PROFILES[profile]
+    origin = 100000
+    stride = locus_len - overlap - 16          # a locus spans (locus_len - 15, locus_len] columns
+    ref_all = _ACGT[rng.integers(0, 4, size=n_loci * stride + locus_len + 4096)]
+
+    def locus(k):   # loci are independent given their seed: generated on a few threads (numpy releases the GIL)
+        return _gene(np.random.default_rng([seed, k]), prof, locus_len, depth, origin + k * stride,
+                     ref_in=ref_all[k * stride:k * stride + locus_len + 2048], ref_guard=overlap + 64)
+    with ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1, n_loci))) as ex:
+        parts = list(ex.map(locus, range(n_loci)))
+    cat = lambda k, dt: np.concatenate([p[k] for p in parts]).astype(dt)
+    pos = cat("pos", np.int64)
+    seq_len, n_cig = cat("seq_len", np.int64), cat("n_cig", np.int64)
+    bases, quals, cigar = cat("bases", np.uint8), cat("quals", np.uint8), cat("cigar", np.uint32)
+    order = np.argsort(pos, kind="stable")          # reads of a region must be sorted by pos
+
+    def regroup(flat, cnt):   # reorder variable-length segments without a Python loop
+        st = np.cumsum(cnt) - cnt
+        c2 = cnt[order]
+        dst0 = np.cumsum(c2) - c2
+        idx = np.repeat(st[order] - dst0, c2) + np.arange(int(c2.sum()))
+        return flat[idx]
+    bases, quals, cigar = regroup(bases, seq_len), regroup(quals, seq_len), regroup(cigar, n_cig)
+    pos, seq_len, n_cig = pos[order], seq_len[order], n_cig[order]
+    lead, trail, flags = cat("lead_clip", np.int64)[order], cat("trail_clip", np.int64)[order], cat("flags", np.uint8)[order]
+    ops, lens = cigar & 15, (cigar >> 4).astype(np.int64)
+    consume = np.isin(ops, [0, 2, 3, 7, 8])
+    cig_read = np.repeat(np.arange(n_cig.size), n_cig)
+    ref_len = np.bincount(cig_read, weights=np.where(consume, lens, 0), minlength=n_cig.size).astype(np.int64)
+    lo, hi = int(pos.min()), int((pos + ref_len).max())
+    assert lo >= origin and hi - origin <= ref_all.size, (lo, hi, ref_all.size)
+    if min_q1:
+        quals = np.maximum(quals, 1)
+    return ReadBatch(pos=pos.astype(np.int32), seq_len=seq_len.astype(np.int32), lead_clip=lead.astype(np.int32),
+                     trail_clip=trail.astype(np.int32), flags=flags,
+                     seq_off=(np.cumsum(seq_len) - seq_len).astype(np.uint64),
+                     cig_off=(np.cumsum(n_cig) - n_cig).astype(np.uint64), n_cig=n_cig.astype(np.uint32),
+                     bases=bases, quals=quals, cigar=cigar, start0=[lo], len=[hi - lo], read_begin=[0, pos.size],
+                     ref=ref_all[lo - origin:hi - origin].copy())
+
+
 def preset_for(profile):
-    return {"ont-cdna": "ont-cdna", "masseq": "hifi-masseq", "ont-drna": "ont-drna"}[profile]
+    return {"ont-cdna": "ont-cdna", "masseq": "hifi-masseq", "ont-drna": "ont-drna", "ont-drna-c5": "ont-drna"}[profile]

@@ -111,6 +111,8 @@ def full_check(engine_cls, orc, batch, params, chrom="chrS"):
     check_phase(E, regs, fm)
     for g, R in enumerate(regs):
         assert vcf.format_records(c[off[g]:off[g + 1]], chrom, params.min_phase_score) == R.vcf_text(chrom)
+        if off[g + 1] - off[g] > params.max_enum_snps:   # chain region: LD blocks in the reference's block / node order
+            assert E.ld_blocks(g) == R.ld_blocks(), "LD blocks region %d" % g
     E.close()
     return c
 
@@ -132,6 +134,26 @@ def test_chain_path_many_snps(engine_cls, orc):
     b = synth.make_batch("ont-drna", n_genes=2, gene_len=40000, depth=50, seed=21)
     c = full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=5))
     assert max(np.bincount(c["region"])) > 10
+
+
+@pytest.mark.parametrize("grid_min", ["0", "100000000"])
+def test_chain_scopes_agree_with_the_oracle(engine_cls, orc, monkeypatch, grid_min):
+    """The chain regions' kernel in both scopes -- all CUs on one region behind grid barriers (LCR_GRID_MIN_ENTRIES=0)
+    and one workgroup per region -- gives the oracle's LD blocks, sigma / delta / eta, objective and VCF text."""
+    monkeypatch.setenv("LCR_GRID_MIN_ENTRIES", grid_min)
+    b = synth.make_batch("ont-drna", n_genes=3, gene_len=30000, depth=60, seed=23)
+    c = full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=7))
+    assert max(np.bincount(c["region"])) > 10
+    b = synth.make_batch("ont-cdna", n_genes=2, gene_len=40000, depth=80, seed=24)
+    full_check(engine_cls, orc, b, _abi.make_params("ont-cdna", seed=8))
+
+
+def test_min_linkers_above_one(engine_cls, orc):
+    """min_linkers = 2: reads with a single phase site are not phasing rows, but their entries still count in the
+    allele-pair table the LD blocks come from (fragment.rs:208-240 runs before the for_phasing test)."""
+    b = synth.make_batch("ont-drna", n_genes=2, gene_len=30000, depth=50, seed=25)
+    full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=3, min_linkers=2))
+    full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=3, min_linkers=3))
 
 
 def test_k0_cigar_lengths(engine_cls, orc):
