@@ -219,4 +219,128 @@ __device__ __forceinline__ void block_scan2(int a, int b, int& ea, int& eb, int&
   block_scan2n<4, 8>(a, b, ea, eb, ta, tb, sm);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// scopes: the thread numbering and the barrier a step is written against.  WgScope = one workgroup (barrier =
+// __syncthreads); GridScope = all workgroups of a persistent launch (barrier = grid-wide, on an atomic counter).
+// All workgroups of a grid launch are resident (the host sizes the grid by the CU count), so spinning on the
+// generation counter cannot starve an unscheduled workgroup.  __threadfence() is an agent-scope fence: it writes this
+// XCD's L2 back before the arrival and invalidates it after the release, which is what makes the other XCDs' plain
+// stores visible (MI355X has one L2 per XCD).
+// ------------------------------------------------------------------------------------------------------------
+struct WgScope {
+  long long* red;   // LDS, one per wave
+  int* bc;          // LDS broadcast slot
+  __device__ int tid() const { return threadIdx.x; }
+  __device__ int nt() const { return blockDim.x; }
+  __device__ int wave() const { return threadIdx.x >> 6; }
+  __device__ int nwaves() const { return blockDim.x >> 6; }
+  __device__ int blk() const { return 0; }
+  __device__ int nblk() const { return 1; }
+  __device__ void sync() { __syncthreads(); }
+  __device__ int sync_or(int v) { return __syncthreads_or(v); }
+  __device__ int bcast(int v) {   // value of thread 0 to everybody
+    __syncthreads();
+    if (threadIdx.x == 0) *bc = v;
+    __syncthreads();
+    const int r = *bc;
+    __syncthreads();
+    return r;
+  }
+  __device__ int ld(const int32_t* p) const { return *p; }
+  __device__ long long sync_sum(long long v) {
+    v = wave_sum_ll(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    long long t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += red[w];
+    __syncthreads();
+    return t;
+  }
+};
+
+struct GridScope {
+  GridCtl* c;
+  long long* red;      // LDS, one per wave
+  unsigned long long* bc;   // LDS broadcast slot
+  unsigned gen;        // barriers passed so far (uniform over the grid)
+  __device__ int tid() const { return blockIdx.x * blockDim.x + threadIdx.x; }
+  __device__ int nt() const { return gridDim.x * blockDim.x; }
+  __device__ int wave() const { return tid() >> 6; }
+  __device__ int nwaves() const { return nt() >> 6; }
+  __device__ int blk() const { return blockIdx.x; }
+  __device__ int nblk() const { return gridDim.x; }
+  __device__ void arrive_wait_() {   // thread 0 of the workgroup
+    const unsigned g = gen;
+    __threadfence();
+    if (atomicAdd(&c->arrive, 1u) == gridDim.x - 1) {
+      // last arriver: the slots of parity (g+1) were read before their readers arrived here and are written again
+      // only after this barrier opens
+      __hip_atomic_store(&c->flag[(g + 1) & 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&c->acc[(g + 1) & 1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&c->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+      __hip_atomic_store(&c->gen, g + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(&c->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) __builtin_amdgcn_s_sleep(1);
+    }
+    __threadfence();
+  }
+  __device__ void sync() {
+    __syncthreads();
+    if (threadIdx.x == 0) arrive_wait_();
+    gen++;
+    __syncthreads();
+  }
+  __device__ int sync_or(int v) {
+    v = __syncthreads_or(v);
+    if (threadIdx.x == 0) {
+      if (v) atomicOr(&c->flag[gen & 1], 1u);
+      arrive_wait_();
+      *bc = __hip_atomic_load(&c->flag[gen & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gen++;
+    __syncthreads();
+    const int r = (int)*bc;
+    __syncthreads();
+    return r;
+  }
+  __device__ int bcast(int v) {   // value of thread 0 of workgroup 0 to everybody
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (blockIdx.x == 0) __hip_atomic_store(&c->slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      arrive_wait_();
+      *bc = (unsigned long long)(unsigned)__hip_atomic_load(&c->slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gen++;
+    __syncthreads();
+    const int r = (int)(unsigned)*bc;
+    __syncthreads();
+    return r;
+  }
+  __device__ int ld(const int32_t* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ long long sync_sum(long long v) {
+    v = wave_sum_ll(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long t = 0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += red[w];
+      if (t) atomicAdd(&c->acc[gen & 1], (unsigned long long)t);
+      arrive_wait_();
+      *bc = __hip_atomic_load(&c->acc[gen & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gen++;
+    __syncthreads();
+    const long long r = (long long)*bc;
+    __syncthreads();
+    return r;
+  }
+};
+
+// a wave's own stores, made by one lane, before loads of the same addresses by its other lanes
+__device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
 }  // namespace

@@ -8,3 +8,7 @@ hipError_t k4_chain_launch_wg(const ChainDev& C, int first, int n, size_t dyn_ld
 hipError_t k4_chain_launch_grid(const ChainDev& C, int which, hipStream_t s);
 // workgroups of a grid launch (co-resident by construction); 0 = no device
 int k4_grid_blocks();
+// k4_stage for one large region with all CUs; blk_tot: 2 * k4_grid_blocks() + 1 int32 of scratch
+hipError_t k4_stage_launch_grid(const StageIn& in, const StageOut& out, const PhaseLutDev& lut, int g, GridCtl* ctl, int32_t* blk_tot, hipStream_t s);
+// post-phase steps for one large region with all CUs (post_in: the PostIn of k4_post.h)
+hipError_t k4_post_launch_grid(const void* post_in, const PostScratch& ps, int g, const PostLut& lut, hipStream_t s);

@@ -28,109 +28,12 @@
 // edge is ever removed; other values are rejected by lcr_phase.
 #include "k4_dev.h"
 #include "k4_grid.h"
+#include "k4_post.h"
 
 namespace {
 
 constexpr int CH_THREADS = 1024;
 constexpr int CH_WAVES = CH_THREADS / 64;
-
-// ------------------------------------------------------------------------------------------------------------
-// scopes
-// ------------------------------------------------------------------------------------------------------------
-struct WgScope {
-  long long* red;   // LDS, one per wave
-  __device__ int tid() const { return threadIdx.x; }
-  __device__ int nt() const { return blockDim.x; }
-  __device__ int wave() const { return threadIdx.x >> 6; }
-  __device__ int nwaves() const { return blockDim.x >> 6; }
-  __device__ int blk() const { return 0; }
-  __device__ int nblk() const { return 1; }
-  __device__ void sync() { __syncthreads(); }
-  __device__ int sync_or(int v) { return __syncthreads_or(v); }
-  __device__ long long sync_sum(long long v) {
-    v = wave_sum_ll(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    long long t = 0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += red[w];
-    __syncthreads();
-    return t;
-  }
-};
-
-// All workgroups of the launch are resident (the host sizes the grid with the occupancy API), so spinning on
-// the generation counter cannot starve an unscheduled workgroup.  __threadfence() is an agent-scope fence: it
-// writes this XCD's L2 back before the arrival and invalidates it after the release, which is what makes the
-// other XCDs' plain stores visible (MI355X has one L2 per XCD).
-struct GridScope {
-  GridCtl* c;
-  long long* red;      // LDS, one per wave
-  unsigned long long* bc;   // LDS broadcast slot
-  unsigned gen;        // barriers passed so far (uniform over the grid)
-  __device__ int tid() const { return blockIdx.x * blockDim.x + threadIdx.x; }
-  __device__ int nt() const { return gridDim.x * blockDim.x; }
-  __device__ int wave() const { return tid() >> 6; }
-  __device__ int nwaves() const { return nt() >> 6; }
-  __device__ int blk() const { return blockIdx.x; }
-  __device__ int nblk() const { return gridDim.x; }
-  __device__ void arrive_wait_() {   // thread 0 of the workgroup
-    const unsigned g = gen;
-    __threadfence();
-    if (atomicAdd(&c->arrive, 1u) == gridDim.x - 1) {
-      // last arriver: the slots of parity (g+1) were read before their readers arrived here and are written again
-      // only after this barrier opens
-      __hip_atomic_store(&c->flag[(g + 1) & 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&c->acc[(g + 1) & 1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&c->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence();
-      __hip_atomic_store(&c->gen, g + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      while (__hip_atomic_load(&c->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) __builtin_amdgcn_s_sleep(1);
-    }
-    __threadfence();
-  }
-  __device__ void sync() {
-    __syncthreads();
-    if (threadIdx.x == 0) arrive_wait_();
-    gen++;
-    __syncthreads();
-  }
-  __device__ int sync_or(int v) {
-    v = __syncthreads_or(v);
-    if (threadIdx.x == 0) {
-      if (v) atomicOr(&c->flag[gen & 1], 1u);
-      arrive_wait_();
-      *bc = __hip_atomic_load(&c->flag[gen & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    gen++;
-    __syncthreads();
-    const int r = (int)*bc;
-    __syncthreads();
-    return r;
-  }
-  __device__ long long sync_sum(long long v) {
-    v = wave_sum_ll(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      long long t = 0;
-      for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += red[w];
-      if (t) atomicAdd(&c->acc[gen & 1], (unsigned long long)t);
-      arrive_wait_();
-      *bc = __hip_atomic_load(&c->acc[gen & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    gen++;
-    __syncthreads();
-    const long long r = (long long)*bc;
-    __syncthreads();
-    return r;
-  }
-};
-
-// a wave's own stores, made by one lane, before loads of the same addresses by its other lanes
-__device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
 // region-relative views the chain steps work on
 struct ChainView {
@@ -175,27 +78,44 @@ __device__ ChainView make_view(const ChainDev& C, const ChainDesc& d, const Regi
 // are counted per (part, SNP), and each part is filled by one wave, 64 entries at a time in CSR order.
 // ------------------------------------------------------------------------------------------------------------
 template <class SC>
-__device__ void ordered_columns(SC& sc, const ChainView& v) {
-  const int S = v.S, R = v.R, np = v.n_parts;
+__device__ void ordered_index(SC& sc, int R, int S, const int32_t* rp, const int32_t* pc, const int32_t* cp /* or nullptr */, int32_t* cp_out,
+                              int32_t* erow, int32_t* cent, int32_t* pcnt, int np, int (*sm)[16]) {
   const int rq = max(1, (R + np - 1) / np);
-  const int32_t* rp = v.mv.rp; const int32_t* pc = v.mv.pc; const int32_t* cp = v.mv.cp;
-  for (int64_t i = sc.tid(); i < (int64_t)np * S; i += sc.nt()) v.pcnt[i] = 0;
+  for (int64_t i = sc.tid(); i < (int64_t)np * S; i += sc.nt()) pcnt[i] = 0;
   sc.sync();
   for (int row = sc.tid(); row < R; row += sc.nt()) {
-    int32_t* cnt = v.pcnt + (int64_t)(row / rq) * S;
-    for (int e = rp[row]; e < rp[row + 1]; e++) { v.erow[e] = row; atomicAdd(&cnt[pc[e]], 1); }
+    int32_t* cnt = pcnt + (int64_t)(row / rq) * S;
+    for (int e = rp[row]; e < rp[row + 1]; e++) { erow[e] = row; atomicAdd(&cnt[pc[e]], 1); }
   }
   sc.sync();
+  if (!cp) {   // column offsets from the counts
+    for (int i = sc.tid(); i < S; i += sc.nt()) { int t = 0; for (int q = 0; q < np; q++) t += pcnt[(int64_t)q * S + i]; cp_out[i] = t; }
+    sc.sync();
+    if (sc.blk() == 0) {
+      int carry = 0;
+      for (int base = 0; base < S; base += CH_THREADS) {
+        const int i = base + threadIdx.x;
+        const int d = i < S ? cp_out[i] : 0;
+        int ex, d0, tot, d1;
+        block_scan2n<CH_WAVES, 16>(d, 0, ex, d0, tot, d1, sm);
+        if (i < S) cp_out[i] = carry + ex;
+        carry += tot;
+      }
+      if (threadIdx.x == 0) cp_out[S] = carry;
+    }
+    sc.sync();
+    cp = cp_out;
+  }
   for (int i = sc.tid(); i < S; i += sc.nt()) {
     int at = cp[i];
-    for (int q = 0; q < np; q++) { int32_t* p = v.pcnt + (int64_t)q * S + i; const int n = *p; *p = at; at += n; }
+    for (int q = 0; q < np; q++) { int32_t* p = pcnt + (int64_t)q * S + i; const int n = *p; *p = at; at += n; }
   }
   sc.sync();
   const int lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
   for (int q = sc.wave(); q < np; q += sc.nwaves()) {
-    int32_t* cur = v.pcnt + (int64_t)q * S;
-    const int e_lo = rp[min(q * rq, R)], e_hi = rp[(int)min((int64_t)(q + 1) * rq, (int64_t)R)];
+    int32_t* cur = pcnt + (int64_t)q * S;
+    const int e_lo = rp[(int)min((int64_t)q * rq, (int64_t)R)], e_hi = rp[(int)min((int64_t)(q + 1) * rq, (int64_t)R)];
     for (int base = e_lo; base < e_hi; base += 64) {
       const int e = base + lane;
       const bool valid = e < e_hi;
@@ -210,7 +130,7 @@ __device__ void ordered_columns(SC& sc, const ChainView& v) {
       }
       if (valid) {
         const int rank = __popcll(mine & below);
-        v.cent[at + rank] = e;
+        cent[at + rank] = e;
         if (rank == 0) cur[c] = at + __popcll(mine);
       }
       wave_mem_sync();
@@ -608,7 +528,7 @@ template <class SC, class Cross>
 __device__ void chain_run(SC& sc, const ChainDev& C, const RegionDev& rd, const ChainView& v, const long long* wl, const FlipLut& L,
                           double* stage, int (*sm)[16], Cross cross, int slot) {
   const int S = rd.S, R = rd.R;
-  ordered_columns(sc, v);
+  ordered_index(sc, v.R, v.S, v.mv.rp, v.mv.pc, v.mv.cp, nullptr, v.erow, v.cent, v.pcnt, v.n_parts, sm);
   ld_pair_table(sc, C, v);
   ld_graph(sc, v, sm);
   // start state (phase.rs:1124-1131): random delta (draws S+F ..), genotype from the variant type, random sigma
@@ -679,7 +599,8 @@ __global__ void __launch_bounds__(CH_THREADS) k4_chain_wg(ChainDev C, int32_t fi
   ChainView v = make_view(C, d, rd);
   if (C.P.lds_state) { v.sg = dyn_state; v.dl = v.sg + rd.R; v.et = v.dl + rd.S; }
   const uint32_t E = (uint32_t)C.P.prow_ptr[rd.rp_off + rd.R];
-  WgScope sc{red};
+  __shared__ int wg_bc;
+  WgScope sc{red, &wg_bc};
   bool staged = false;
   MatView mvl = v.mv;
   auto cross = [&](bool keep_conserved, bool with_genotype) -> long long {
@@ -722,6 +643,186 @@ __global__ void __launch_bounds__(CH_THREADS) k4_chain_grid(ChainDev C, int32_t 
   chain_run(sc, C, rd, v, wl, L, stage, sm, cross, d.slot);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// k4_stage_grid: k4_stage (k4_phase.hip) for ONE large region with all CUs: phasing rows x phase sites as CSR + CSC,
+// per-SNP constants, region descriptor.  Workgroup b owns a contiguous slab of fragment rows; slab totals give every
+// slab its offsets, so the CSR comes out in row order; the CSC is filled through per-column cursors (any order inside
+// a column: its consumers only sum, and the chain kernel builds its own row-ordered index).
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(CH_THREADS) k4_stage_grid(StageIn in, StageOut out, PhaseLutDev lut, int32_t g, GridCtl* ctl, int32_t* blk_tot) {
+  __shared__ long long red[CH_WAVES];
+  __shared__ unsigned long long bc;
+  __shared__ int sm[2][16];
+  __shared__ int s_sum[5];
+  __shared__ long long s_fe[32], s_f1e[32];
+  GridScope sc{ctl, red, &bc, 0u};
+  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x, nb = gridDim.x;
+  const int r0 = in.row_region_off[g], nrow = in.row_region_off[g + 1] - r0;
+  const int c0 = in.cand_off[g], S = in.cand_off[g + 1] - c0;
+  const int64_t e_base = in.row_ptr[r0];
+  const int64_t E_all = in.row_ptr[r0 + nrow] - e_base;
+  RegionDev rd{};
+  rd.S = S; rd.rp_off = r0 + g; rd.cp_off = c0 + g; rd.e_off = e_base; rd.sig_off = r0; rd.snp_off = c0;
+  rd.seed = region_seed(in.seed, in.start0[g]);
+  if (tid < 32) { s_fe[tid] = tid < 31 ? lut.fe[tid] : 0; s_f1e[tid] = tid < 31 ? lut.f1e[tid] : 0; }
+  int32_t* wmax = blk_tot + 2 * nb;
+  for (int i = sc.tid(); i < S; i += sc.nt()) {
+    const lcr_candidate& c = in.cand[c0 + i];
+    out.snp_fp[c0 + i] = (c.flags & LCR_F_FOR_PHASING) ? 1 : 0;
+    out.snp_vt[c0 + i] = (int8_t)c.variant_type;
+    out.snp_cons[c0 + i] = 0;
+    out.cursor[c0 + i] = 0;
+  }
+  if (sc.tid() == 0) *wmax = 0;
+  sc.sync();
+  const uint8_t* fp = out.snp_fp + c0;
+  const int rs = (((nrow + nb - 1) / nb) + 63) & ~63;         // rows per slab
+  const int s0 = min(nrow, b * rs), s1 = min(nrow, s0 + rs);
+  auto row_info = [&](int r, int& isp, int& cnt, int& span) {
+    isp = in.links[r0 + r] >= in.min_linkers ? 1 : 0;
+    cnt = 0; span = 0;
+    int first = -1, last = -1;
+    for (int64_t e = in.row_ptr[r0 + r]; e < in.row_ptr[r0 + r + 1]; e++) { const int ci = in.col[e] - c0; if (fp[ci]) { cnt++; if (first < 0) first = ci; last = ci; } }
+    if (last > first) span = last - first;
+    if (!isp) cnt = 0;
+  };
+  // ---- slab totals
+  if (tid < 5) s_sum[tid] = 0;
+  __syncthreads();
+  {
+    int rows = 0, ents = 0, w = 0;
+    for (int r = s0 + tid; r < s1; r += CH_THREADS) { int isp, cnt, span; row_info(r, isp, cnt, span); rows += isp; ents += cnt; w = max(w, span); }
+    atomicAdd(&s_sum[0], rows); atomicAdd(&s_sum[1], ents); atomicMax(&s_sum[2], w);
+  }
+  __syncthreads();
+  if (tid == 0) { blk_tot[2 * b] = s_sum[0]; blk_tot[2 * b + 1] = s_sum[1]; if (s_sum[2]) atomicMax(wmax, s_sum[2]); }
+  sc.sync();
+  // ---- offsets of this slab, totals of the region
+  if (tid < 5) s_sum[tid] = 0;
+  __syncthreads();
+  for (int k = tid; k < nb; k += CH_THREADS) {
+    const int rr = blk_tot[2 * k], ee = blk_tot[2 * k + 1];
+    if (k < b) { atomicAdd(&s_sum[0], rr); atomicAdd(&s_sum[1], ee); }
+    atomicAdd(&s_sum[3], rr); atomicAdd(&s_sum[4], ee);
+  }
+  __syncthreads();
+  int R = s_sum[0], E = s_sum[1];
+  const int R_tot = s_sum[3], E_tot = s_sum[4];
+  int32_t* prp = out.prow_ptr + rd.rp_off;
+  int32_t* pcp = out.ccol_ptr + rd.cp_off;
+  // ---- CSR of the slab (row order), column counts
+  for (int base = s0; base < s1; base += CH_THREADS) {
+    const int r = base + tid;
+    int isp = 0, cnt = 0, span = 0;
+    if (r < s1) row_info(r, isp, cnt, span);
+    int k, eo, tk, te;
+    block_scan2n<CH_WAVES, 16>(isp, cnt, k, eo, tk, te, sm);
+    if (isp) {
+      k += R; eo += E;
+      prp[k] = eo;
+      out.prow_src[r0 + k] = r;
+      for (int64_t e = in.row_ptr[r0 + r]; e < in.row_ptr[r0 + r + 1]; e++) {
+        const int ci = in.col[e] - c0;
+        if (!fp[ci]) continue;
+        out.pcol[e_base + eo] = ci; out.pval[e_base + eo] = in.val[e] & 63;
+        atomicAdd(&out.cursor[c0 + ci], 1);
+        eo++;
+      }
+    }
+    R += tk; E += te;
+  }
+  if (b == nb - 1 && tid == 0) prp[R_tot] = E_tot;
+  sc.sync();
+  // ---- column offsets (one workgroup)
+  if (b == 0) {
+    int carry = 0;
+    for (int base = 0; base < S; base += CH_THREADS) {
+      const int i = base + tid;
+      const int x = i < S ? out.cursor[c0 + i] : 0;
+      int ex, d0, tot, d1;
+      block_scan2n<CH_WAVES, 16>(x, 0, ex, d0, tot, d1, sm);
+      if (i < S) { pcp[i] = carry + ex; out.cursor[c0 + i] = carry + ex; }
+      carry += tot;
+    }
+    if (tid == 0) pcp[S] = carry;
+  }
+  sc.sync();
+  // ---- CSC mirror (phasing-row index, value)
+  for (int k = sc.tid(); k < R_tot; k += sc.nt())
+    for (int e = prp[k]; e < prp[k + 1]; e++) {
+      const int pos = atomicAdd(&out.cursor[c0 + out.pcol[e_base + e]], 1);
+      out.crow[e_base + pos] = k; out.cval[e_base + pos] = out.pval[e_base + e];
+    }
+  sc.sync();
+  // ---- per-SNP constants: F = sum fe, W = sum w, Cref = sum (p==+1 ? f1e : fe), Cvar = sum (p==-1 ? f1e : fe)
+  long long ft = 0;
+  for (int i = sc.wave(); i < S; i += sc.nwaves()) {
+    long long F = 0, W = 0, Cr = 0, Cv = 0;
+    for (int e = pcp[i] + lane; e < pcp[i + 1]; e += 64) {
+      const uint8_t x = out.cval[e_base + e];
+      const long long fe = s_fe[x & 31], f1 = s_f1e[x & 31];
+      F += fe; W += f1 - fe;
+      Cr += (x & 32) ? f1 : fe; Cv += (x & 32) ? fe : f1;
+    }
+    F = wave_sum_ll_dpp(F); W = wave_sum_ll_dpp(W); Cr = wave_sum_ll_dpp(Cr); Cv = wave_sum_ll_dpp(Cv);
+    if (lane == 0) { long long* scn = out.snp_const + 4ll * (c0 + i); scn[0] = F; scn[1] = W; scn[2] = Cr; scn[3] = Cv; ft += F; }
+  }
+  const long long ftot = sc.sync_sum(ft);
+  if (sc.tid() == 0) {
+    rd.R = R_tot; rd.f_total = ftot;
+    out.reg[g] = rd;
+    out.stat[g] = StageStat{R_tot, E_tot, INT_MAX, INT_MAX, (int)std::min<int64_t>(E_all, INT_MAX), *wmax};
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k4_gpost: the post-phase sequence (k4_post.h) with all CUs on ONE region, the region image in HBM
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(CH_THREADS) k4_gpost(PostIn in, PostScratch ps, int32_t g, PostLut lut) {
+  __shared__ long long red[CH_WAVES];
+  __shared__ unsigned long long bc;
+  __shared__ int sm[2][16];
+  __shared__ double s_lut[64];
+  __shared__ double stage[CH_WAVES * 4 * POST_SSTR];
+  GridScope sc{ps.ctl, red, &bc, 0u};
+  const int r0 = in.row_region_off[g], nrow = in.row_region_off[g + 1] - r0;
+  const int c0 = in.cand_off[g], S = in.cand_off[g + 1] - c0;
+  const int64_t e_base = in.row_ptr[r0];
+  const int E = (int)(in.row_ptr[r0 + nrow] - e_base);
+  PostView<int32_t> v;
+  v.g = g; v.S = S; v.nrow = nrow; v.E = E; v.F = in.reg[g].R; v.r0 = r0; v.c0 = c0;
+  v.le = s_lut; v.l1e = s_lut + 32;
+  v.sps = ps.sps; v.rpa = ps.rpa; v.rpb = ps.rpb; v.sflags = ps.sflags; v.soflags = ps.soflags; v.parent = ps.parent;
+  v.rptr = ps.rptr; v.ecol = ps.ecol; v.erow = ps.erow; v.cent = ps.cent; v.ccptr = ps.ccptr; v.ev = ps.ev;
+  v.tag = ps.tag; v.asg = ps.asg; v.fp = ps.fp; v.lok = ps.lok; v.dirty = ps.dirty;
+  v.shap = ps.shap; v.sgt = ps.sgt; v.svt = ps.svt; v.rcode = ps.rcode;
+  v.cand = in.cand + c0;
+  v.stage = stage;
+  int n_mark = 0;
+  auto mark = [&]() { if (in.dbg_clk && sc.tid() == 0) in.dbg_clk[(size_t)g * 16 + n_mark] = (long long)wall_clock64(); n_mark++; };
+  mark();
+  if (threadIdx.x < 31) { v.le[threadIdx.x] = lut.le[threadIdx.x]; v.l1e[threadIdx.x] = lut.l1e[threadIdx.x]; }
+  for (int i = sc.tid(); i < S; i += sc.nt()) {
+    v.sflags[i] = v.soflags[i] = v.cand[i].flags;
+    v.shap[i] = in.st_delta[c0 + i]; v.sgt[i] = in.st_eta[c0 + i]; v.svt[i] = (int8_t)v.cand[i].variant_type;
+    v.sps[i] = v.cand[i].phase_score;
+    v.parent[i] = 0;
+  }
+  for (int r = sc.tid(); r < nrow; r += sc.nt()) {
+    const int isp = in.links[r0 + r] >= in.min_linkers ? 1 : 0;
+    v.rptr[r] = (int32_t)(in.row_ptr[r0 + r] - e_base);
+    v.lok[r] = (uint8_t)isp; v.fp[r] = (uint8_t)isp; v.asg[r] = 0; v.tag[r] = 0;
+  }
+  if (sc.tid() == 0) v.rptr[nrow] = E;
+  for (int e = sc.tid(); e < E; e += sc.nt()) { v.ecol[e] = in.col[e_base + e] - c0; v.ev[e] = in.val[e_base + e]; }
+  sc.sync();
+  for (int k = sc.tid(); k < v.F; k += sc.nt()) v.tag[in.prow_src[r0 + k]] = in.st_sigma[r0 + k];
+  mark();
+  ordered_index(sc, nrow, S, v.rptr, v.ecol, nullptr, v.ccptr, v.erow, v.cent, ps.pcnt, ps.n_parts, sm);
+  mark();
+  post_run(sc, in, lut, v, mark);
+}
 }  // namespace
 
 size_t k4_chain_wg_static_lds() { return sizeof(long long) * (CH_WAVES + 32) + 8 * CROSS_MACC + sizeof(FlipLut) + sizeof(int) * 32 + 8 * CH_WAVES * 4 * SSTR; }
@@ -752,5 +853,23 @@ hipError_t k4_chain_launch_grid(const ChainDev& C, int which, hipStream_t s) {
   hipError_t e = hipMemsetAsync(C.ctl, 0, sizeof(GridCtl), s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k4_chain_grid, dim3((unsigned)nb), dim3(CH_THREADS), 0, s, C, (int32_t)which);
+  return hipGetLastError();
+}
+
+hipError_t k4_stage_launch_grid(const StageIn& in, const StageOut& out, const PhaseLutDev& lut, int g, GridCtl* ctl, int32_t* blk_tot, hipStream_t s) {
+  const int nb = k4_grid_blocks();
+  if (nb <= 0) return hipErrorInvalidDevice;
+  hipError_t e = hipMemsetAsync(ctl, 0, sizeof(GridCtl), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k4_stage_grid, dim3((unsigned)nb), dim3(CH_THREADS), 0, s, in, out, lut, (int32_t)g, ctl, blk_tot);
+  return hipGetLastError();
+}
+
+hipError_t k4_post_launch_grid(const void* post_in, const PostScratch& ps, int g, const PostLut& lut, hipStream_t s) {
+  const int nb = k4_grid_blocks();
+  if (nb <= 0) return hipErrorInvalidDevice;
+  hipError_t e = hipMemsetAsync(ps.ctl, 0, sizeof(GridCtl), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k4_gpost, dim3((unsigned)nb), dim3(CH_THREADS), 0, s, *static_cast<const PostIn*>(post_in), ps, (int32_t)g, lut);
   return hipGetLastError();
 }

@@ -35,9 +35,14 @@
 #include <atomic>
 #include <functional>
 #include <thread>
+#include <mutex>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 
 #include "k4_dev.h"
 #include "k4_grid.h"
+#include "k4_post.h"
 
 namespace {
 
@@ -364,17 +369,6 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
 // (rows: r0 + g, SNPs: c0 + g, entries: row_ptr[r0]) so no cross-region scan is needed.  The CSC fill
 // order inside a column is whatever the atomics give: every consumer only sums over a column.
 // ---------------------------------------------------------------------------------------------
-struct StageIn {
-  const int64_t* row_ptr; const int32_t* col; const uint8_t* val; const uint32_t* links;
-  const lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off; const int64_t* start0;
-  uint32_t min_linkers, max_enum_snps; uint64_t seed;
-};
-struct StageOut {
-  RegionDev* reg; StageStat* stat;
-  int32_t* prow_ptr; int32_t* pcol; uint8_t* pval; int32_t* ccol_ptr; int32_t* crow; uint8_t* cval;
-  uint8_t* snp_fp; int8_t* snp_vt; uint8_t* snp_cons; long long* snp_const; int32_t* cursor;
-  int32_t* prow_src;   // per phasing row (at r0 + k): its fragment row, region relative
-};
 
 
 constexpr int STAGE_THREADS = 256;    // (1024 threads per region were measured: more barrier cost than latency saved)
@@ -408,6 +402,7 @@ __global__ void __launch_bounds__(STAGE_THREADS) k4_stage(StageIn in, StageOut o
   __shared__ uint8_t s_fp[STG_S];
   __shared__ int s_cur[STG_S];
   const int64_t E_all = in.row_ptr[r0 + nrow] - e_base;
+  if (S > 0 && E_all >= in.grid_min) return;   // k4_stage_grid (k4_grid.hip) stages this region with all CUs
   const bool staged = nrow <= STG_R && E_all <= STG_E && S <= STG_S;
   for (int i = tid; i < S; i += STAGE_THREADS) {
     const lcr_candidate& c = in.cand[c0 + i];
@@ -586,26 +581,10 @@ __global__ void __launch_bounds__(64) k4_enum_pick(const int32_t* __restrict__ s
 constexpr int CHAIN_THREADS = 1024;   // k4_post of the chain regions: 16 waves
 
 // ---------------------------------------------------------------------------------------------
-// k4_post: the post-phase sequence of thread.rs:168-201 on the device, one workgroup per region:
-//   assign_reads_haplotype + assign_het_var_haplotype (x2), eval_rna_edit_var_phase,
-//   eval_low_frac_var_phase, assign_reads_haplotype + assign_het_var_haplotype, assign_phase_set
-//   (snpfrags.rs:191-733).
-// These are f64 sum-of-ratio decisions: every log10(eps) / log10(1-eps) term comes from the table of
-// libm values the host path uses (kernel argument), sums run in the reference's observation order (a
-// read's entries in column order, a SNP's reads in row order) and -ffp-contract=off keeps a*b+c
-// unfused, so the decisions are the host path's bit for bit; only phase_score's final log10 is the
-// device libm.  The region's fragment rows are staged in LDS with a row-ordered column index (stable
-// counting sort by one wave); a batch with a region too large for that takes the host epilogue.
+// k4_post: the post-phase sequence of thread.rs:168-201, one workgroup per region with the region's fragment rows
+// staged in LDS and a row-ordered column index (stable counting sort by one wave per row part); the steps
+// themselves are k4_post.h's post_run, shared with the all-CUs-on-one-region form (k4_gpost, k4_grid.hip).
 // ---------------------------------------------------------------------------------------------
-struct PostIn {
-  const int64_t* row_ptr; const int32_t* col; const uint8_t* val; const uint32_t* links;
-  lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off; const int64_t* start0;
-  const int8_t* st_sigma; const int8_t* st_delta; const int8_t* st_eta;
-  int8_t* haplotag; uint8_t* assignment; uint32_t* phase_set;   // per-row results: pinned host memory, written by the kernel
-  const long long* st_obj; long long* h_obj; lcr_candidate* h_cand;   // objective / candidate mirror in pinned host memory
-  uint32_t min_linkers, max_enum_snps; uint64_t seed; double cutoff; float min_phase_score;
-  long long* dbg_clk;   // LCR_PHASE_PROF: 100 MHz timestamps of every workgroup's steps, 16 per region (nullptr otherwise)
-};
 constexpr int POST_MAX_ROWS = 8192, POST_MAX_ENTRIES = 8192, POST_MAX_SNPS = 512;
 struct PostLayout { uint32_t sps, rpa, rpb, sflags, soflags, parent, qcnt, rptr, ecol, erow, cent, ccptr, eval, tag, asg, fp, lok, dirty, shap, sgt, svt, rcode, total; };
 __host__ __device__ inline PostLayout post_layout(uint32_t nrow, uint32_t E, uint32_t S) {
@@ -631,8 +610,9 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr int NW = NT / 64;
   __shared__ int sm[2][16];
-  __shared__ int s_flag, s_chg;
-  __shared__ double stage[NW][4 * 65];
+  __shared__ long long red[NW];
+  __shared__ int wg_bc;
+  __shared__ double stage[NW * 4 * POST_SSTR];
   if ((int)blockIdx.x >= n_slots) return;
   const int g = slots[blockIdx.x], tid = threadIdx.x, lane = tid & 63;
   const int r0 = in.row_region_off[g], nrow = in.row_region_off[g + 1] - r0;
@@ -641,49 +621,46 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
   const int64_t e_base = in.row_ptr[r0];
   const int E = (int)(in.row_ptr[r0 + nrow] - e_base);
   const PostLayout L = post_layout(nrow, E, S);
-  double* le = (double*)lds; double* l1e = le + 32;
-  double* sps = (double*)(lds + L.sps); double* rpa = (double*)(lds + L.rpa); double* rpb = (double*)(lds + L.rpb);
-  uint32_t* sflags = (uint32_t*)(lds + L.sflags); uint32_t* soflags = (uint32_t*)(lds + L.soflags);
-  int32_t* parent = (int32_t*)(lds + L.parent);
-  uint16_t* rptr = (uint16_t*)(lds + L.rptr); uint16_t* ecol = (uint16_t*)(lds + L.ecol);
-  uint16_t* erow = (uint16_t*)(lds + L.erow); uint16_t* cent = (uint16_t*)(lds + L.cent);
-  uint16_t* ccptr = (uint16_t*)(lds + L.ccptr);
-  uint8_t* ev = lds + L.eval;
-  int8_t* tag = (int8_t*)(lds + L.tag); uint8_t* asg = lds + L.asg; uint8_t* fp = lds + L.fp; uint8_t* lok = lds + L.lok;
-  uint8_t* dirty = lds + L.dirty;
-  int8_t* shap = (int8_t*)(lds + L.shap); int8_t* sgt = (int8_t*)(lds + L.sgt); int8_t* svt = (int8_t*)(lds + L.svt);
-  uint8_t* rcode = lds + L.rcode;
-  lcr_candidate* cand = in.cand + c0;
+  PostView<uint16_t> v;
+  v.g = g; v.S = S; v.nrow = nrow; v.E = E; v.F = in.reg[g].R; v.r0 = r0; v.c0 = c0;
+  v.le = (double*)lds; v.l1e = v.le + 32;
+  v.sps = (double*)(lds + L.sps); v.rpa = (double*)(lds + L.rpa); v.rpb = (double*)(lds + L.rpb);
+  v.sflags = (uint32_t*)(lds + L.sflags); v.soflags = (uint32_t*)(lds + L.soflags);
+  v.parent = (int32_t*)(lds + L.parent);
+  v.rptr = (uint16_t*)(lds + L.rptr); v.ecol = (uint16_t*)(lds + L.ecol);
+  v.erow = (uint16_t*)(lds + L.erow); v.cent = (uint16_t*)(lds + L.cent);
+  v.ccptr = (uint16_t*)(lds + L.ccptr);
+  v.ev = lds + L.eval;
+  v.tag = (int8_t*)(lds + L.tag); v.asg = lds + L.asg; v.fp = lds + L.fp; v.lok = lds + L.lok;
+  v.dirty = lds + L.dirty;
+  v.shap = (int8_t*)(lds + L.shap); v.sgt = (int8_t*)(lds + L.sgt); v.svt = (int8_t*)(lds + L.svt);
+  v.rcode = lds + L.rcode;
+  v.cand = in.cand + c0;
+  v.stage = stage;
+  uint16_t* rptr = v.rptr; uint16_t* ecol = v.ecol; uint16_t* erow = v.erow; uint16_t* cent = v.cent; uint16_t* ccptr = v.ccptr;
 
   int n_mark = 0;
   auto mark = [&]() { if (in.dbg_clk && tid == 0) in.dbg_clk[(size_t)g * 16 + n_mark] = (long long)wall_clock64(); n_mark++; };
   mark();
-  // ---- stage: LUT, SNP state, rows (phasing-row index by scan), entries, row-ordered column index
-  if (tid < 31) { le[tid] = lut.le[tid]; l1e[tid] = lut.l1e[tid]; }
+  // ---- stage: LUT, SNP state, rows, entries, row-ordered column index
+  if (tid < 31) { v.le[tid] = lut.le[tid]; v.l1e[tid] = lut.l1e[tid]; }
   for (int i = tid; i < S; i += NT) {
-    sflags[i] = soflags[i] = cand[i].flags;
-    shap[i] = in.st_delta[c0 + i]; sgt[i] = in.st_eta[c0 + i]; svt[i] = (int8_t)cand[i].variant_type;
-    sps[i] = cand[i].phase_score;
-    parent[i] = 0;   // column counts, then fill cursors
+    v.sflags[i] = v.soflags[i] = v.cand[i].flags;
+    v.shap[i] = in.st_delta[c0 + i]; v.sgt[i] = in.st_eta[c0 + i]; v.svt[i] = (int8_t)v.cand[i].variant_type;
+    v.sps[i] = v.cand[i].phase_score;
+    v.parent[i] = 0;
   }
-  int F = 0;
-  for (int base = 0; base < nrow; base += NT) {
-    const int r = base + tid;
-    const int isp = (r < nrow && in.links[r0 + r] >= in.min_linkers) ? 1 : 0;
-    int k, d0, tk, d1;
-    block_scan2n<NW, 16>(isp, 0, k, d0, tk, d1, sm);
-    if (r < nrow) {
-      rptr[r] = (uint16_t)(in.row_ptr[r0 + r] - e_base);
-      lok[r] = (uint8_t)isp; fp[r] = (uint8_t)isp; asg[r] = 0;
-      tag[r] = isp ? in.st_sigma[r0 + F + k] : (int8_t)0;
-    }
-    F += tk;
+  for (int r = tid; r < nrow; r += NT) {
+    const int isp = in.links[r0 + r] >= in.min_linkers ? 1 : 0;
+    rptr[r] = (uint16_t)(in.row_ptr[r0 + r] - e_base);
+    v.lok[r] = (uint8_t)isp; v.fp[r] = (uint8_t)isp; v.asg[r] = 0; v.tag[r] = 0;
   }
   if (tid == 0) rptr[nrow] = (uint16_t)E;
   __syncthreads();
+  for (int k = tid; k < v.F; k += NT) v.tag[in.prow_src[r0 + k]] = in.st_sigma[r0 + k];   // the optimiser's haplotags
   mark();
-  // row-ordered column index: wave q fills the entries of the q-th quarter of the rows (stable inside a
-  // quarter: 64 entries at a time in (row, column) order, equal columns keep their order), the quarters'
+  // row-ordered column index: wave q fills the entries of the q-th part of the rows (stable inside a
+  // part: 64 entries at a time in (row, column) order, equal columns keep their order), the parts'
   // slots inside a column follow each other
   int32_t* qcnt = (int32_t*)(lds + L.qcnt);
   const int rq = (nrow + NW - 1) / NW;   // rows per part (one part per wave)
@@ -692,7 +669,7 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
   for (int r = tid; r < nrow; r += NT)
     for (int e = rptr[r]; e < rptr[r + 1]; e++) {
       const int ci = in.col[e_base + e] - c0;
-      ecol[e] = (uint16_t)ci; erow[e] = (uint16_t)r; ev[e] = in.val[e_base + e];
+      ecol[e] = (uint16_t)ci; erow[e] = (uint16_t)r; v.ev[e] = in.val[e_base + e];
       atomicAdd(&qcnt[(r / rq) * S + ci], 1);
     }
   __syncthreads();
@@ -700,10 +677,10 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
     int carry = 0;
     for (int base = 0; base < S; base += NT) {
       const int i = base + tid;
-      int v = 0;
-      if (i < S) for (int q = 0; q < NW; q++) v += qcnt[q * S + i];
+      int x = 0;
+      if (i < S) for (int q = 0; q < NW; q++) x += qcnt[q * S + i];
       int ex, d0, tot, d1;
-      block_scan2n<NW, 16>(v, 0, ex, d0, tot, d1, sm);
+      block_scan2n<NW, 16>(x, 0, ex, d0, tot, d1, sm);
       if (i < S) {
         int at = carry + ex;
         ccptr[i] = (uint16_t)at;
@@ -738,329 +715,8 @@ __global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restri
   }
   __syncthreads();
   mark();
-
-  auto lg = [&](int sigma, int delta, int eta, uint8_t v) -> double {   // log10(aki(...)), phase.rs:32-49
-    const int pp = (v & 32) ? 1 : -1, x = eta == 0 ? sigma * delta : eta;
-    return pp == x ? l1e[v & 31] : le[v & 31];
-  };
-  // Ordered sums over the observations of SNP column ti, one wave per column: 64 column entries at a time
-  // are loaded and filtered by the lanes (lane <-> entry) and each lane stages its NACC terms (or +0.0, the
-  // exact identity here: the sums start at +0.0 and every term is a finite log) in LDS; then lane a adds the
-  // 64 staged terms of accumulator a in entry order.  The additions are the host's, in the host's order;
-  // only the loads and the filter run in parallel.  Results are returned wave-uniform.
-  const int wave = tid >> 6;
-  constexpr int SSTR = 65;   // stage row stride in doubles (lanes a = 0..3 read different banks)
-  double* stg = &stage[wave][0];
-  auto col_sums = [&](int ti, bool skip_unassigned, auto term, double* acc, int nacc, int& hap1, int& hap2, int& nobs) {
-    hap1 = hap2 = nobs = 0;
-    double mine = 0.0;   // lane a < nacc: running sum of accumulator a
-    const int kb = ccptr[ti], ke = ccptr[ti + 1];
-    for (int k0 = kb; k0 < ke; k0 += 64) {
-      const int k = k0 + lane;
-      bool keep = false; int r = 0, e = 0;
-      if (k < ke) { e = cent[k]; r = erow[e]; keep = fp[r] && lok[r] && !(skip_unassigned && asg[r] == 0); }
-      double t[4] = {0.0, 0.0, 0.0, 0.0};
-      if (keep) term((int)tag[r], ev[e], t);
-      for (int a = 0; a < nacc; a++) stg[a * SSTR + lane] = t[a];
-      const unsigned long long km = __ballot(keep);
-      hap1 += __popcll(__ballot(keep && asg[r] == 1)); hap2 += __popcll(__ballot(keep && asg[r] == 2));
-      nobs += __popcll(km);
-      wave_lds_sync();
-      const int nk = min(64, ke - k0);
-      if (lane < nacc) {
-        const double* src = stg + lane * SSTR;
-        int j = 0;
-        for (; j + 8 <= nk; j += 8) {
-          double v[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) v[u] = src[j + u];
-#pragma unroll
-          for (int u = 0; u < 8; u++) mine += v[u];
-        }
-        for (; j < nk; j++) mine += src[j];
-      }
-      wave_lds_sync();
-    }
-    for (int a = 0; a < nacc; a++)
-      acc[a] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), a), __builtin_amdgcn_readlane(__double2loint(mine), a));
-  };
-  // phase.rs:238-255 over the kept observations of column ti (wave-uniform result)
-  auto psl = [&](int ti, int delta_i, int eta_i, bool skip_unassigned) -> double {
-    double q[3]; int h1, h2, nb;
-    col_sums(ti, skip_unassigned, [&](int sg, uint8_t v, double* t) {
-      t[0] = lg(sg, delta_i, eta_i, v); t[1] = lg(sg, 1, eta_i, v); t[2] = lg(sg, -1, eta_i, v);
-    }, q, 3, h1, h2, nb);
-    return 1.0 - q[0] / (q[1] + q[2]);
-  };
-  // snpfrags.rs:548-625
-  auto reads_hap = [&]() {
-    for (int r = tid; r < nrow; r += NT) {
-      if (!fp[r]) continue;
-      const int sigma_k = tag[r];
-      double q1 = 0, q2 = 0, q3 = 0, n1 = 0;
-      int n = 0;
-      for (int e = rptr[r]; e < rptr[r + 1]; e++) {
-        const int i = ecol[e];
-        if (!(sflags[i] & LCR_F_FOR_PHASING) || shap[i] == 0 || sgt[i] != 0) continue;
-        q1 += lg(sigma_k, shap[i], 0, ev[e]);
-        n1 += lg(-sigma_k, shap[i], 0, ev[e]);
-        n++;
-      }
-      if (sigma_k == 0 || n == 0) { asg[r] = 0; tag[r] = 0; continue; }
-      for (int e = rptr[r]; e < rptr[r + 1]; e++) {
-        const int i = ecol[e];
-        if (!(sflags[i] & LCR_F_FOR_PHASING) || shap[i] == 0 || sgt[i] != 0) continue;
-        q2 += lg(1, shap[i], 0, ev[e]); q3 += lg(-1, shap[i], 0, ev[e]);
-      }
-      const double q = 1.0 - q1 / (q2 + q3), qn = 1.0 - n1 / (q2 + q3);
-      if (fabs(q - qn) >= in.cutoff) {
-        if (q >= qn) asg[r] = sigma_k == 1 ? 1 : 2;
-        else if (sigma_k == 1) { asg[r] = 2; tag[r] = -1; }
-        else { asg[r] = 1; tag[r] = 1; }
-      } else { asg[r] = 0; tag[r] = 0; }
-    }
-    __syncthreads();
-  };
-  // snpfrags.rs:378-546, one wave per SNP (all lanes hold the same values; lane 0 writes).  s_chg is raised when a
-  // SNP's haplotype / genotype / variant type really change (see the pass sequence at the end).
-  auto snp_hap = [&]() {
-    for (int ti = wave; ti < S; ti += NW) {
-      if (!(sflags[ti] & LCR_F_FOR_PHASING)) { if (lane == 0) sflags[ti] |= LCR_F_NON_SELECTED; continue; }
-      if (ccptr[ti] == ccptr[ti + 1]) { if (lane == 0) sflags[ti] |= LCR_F_SINGLE; continue; }
-      const int delta_i = shap[ti];
-      const bool het_skip = svt[ti] == 1;
-      int hap1, hap2, nobs;
-      double sum[4];   // het_d, het_nd, homref, homvar
-      col_sums(ti, het_skip, [&](int sg, uint8_t v, double* t) {
-        t[0] = lg(sg, delta_i, 0, v); t[1] = lg(sg, -delta_i, 0, v); t[2] = lg(sg, delta_i, 1, v); t[3] = lg(sg, delta_i, -1, v);
-      }, sum, 4, hap1, hap2, nobs);
-      if (nobs == 0) { if (lane == 0) sflags[ti] |= LCR_F_NON_SELECTED; continue; }
-      const double het_d = sum[0], het_nd = sum[1], homref = sum[2], homvar = sum[3];
-      const double p_het = lut.log_theta - (double)(uint32_t)nobs * lut.log2;
-      auto score = [&](int sign, int eta_i) -> double {   // cal_delta_eta_sigma_log, phase.rs:128-176
-        const double hd = sign > 0 ? het_d : het_nd, hn = sign > 0 ? het_nd : het_d;
-        double q1 = eta_i == 0 ? hd : (eta_i == 1 ? homref : homvar);
-        q1 += eta_i == 0 ? p_het : (eta_i == 1 ? lut.p_homref : lut.p_homvar);
-        const double q2 = homvar + lut.p_homvar, q3 = hd + p_het, q4 = homref + lut.p_homref, q5 = hn + p_het;
-        return 1.0 - q1 / (q2 + q3 + q4 + q5);
-      };
-      const double q1 = score(1, 0), q2 = score(-1, 0), q3 = score(1, 1), q4 = score(1, -1);
-      const double mx = fmax(q1, fmax(q2, fmax(q3, q4)));
-      int nh = delta_i, ng_ = 0, nv = svt[ti];
-      if (q1 == mx) { nh = delta_i; ng_ = 0; nv = 1; }
-      else if (q2 == mx) { nh = -delta_i; ng_ = 0; nv = 1; }
-      else if (q3 == mx) { nh = delta_i; ng_ = 1; nv = 0; }
-      else if (q4 == mx) { nh = delta_i; ng_ = -1; if (nv != 2 && nv != 3) nv = 2; }
-      else continue;  // NaN scores: the reference panics here
-      double ps = sps[ti];
-      uint32_t fl = sflags[ti];
-      if (ng_ != 0) fl |= LCR_F_NON_SELECTED;
-      else if (hap1 >= 1 && hap2 >= 1) {
-        // phase_score_log(nh, 0): q2 / q3 = sums of lg(sigma, +1 / -1, 0, v), q1 = the one of nh -- the very
-        // addition sequences of het_d / het_nd above (same observations, same order) when delta_i = +-1
-        if (delta_i == 1 || delta_i == -1) {
-          const double s2 = delta_i == 1 ? het_d : het_nd, s3 = delta_i == 1 ? het_nd : het_d;
-          ps = -10.0 * log10(1.0 - (1.0 - (nh == 1 ? s2 : s3) / (s2 + s3)));
-        } else ps = -10.0 * log10(1.0 - psl(ti, nh, ng_, het_skip));
-      }
-      else ps = 0.19940219;
-      if (lane == 0) {
-        if (shap[ti] != nh || sgt[ti] != ng_ || svt[ti] != nv) s_chg = 1;   // (fl only ORs bits neither half reads)
-        shap[ti] = (int8_t)nh; sgt[ti] = (int8_t)ng_; svt[ti] = (int8_t)nv; sflags[ti] = fl; sps[ti] = ps;
-      }
-    }
-    __syncthreads();
-  };
-  // snpfrags.rs:191-376.  The list is walked in index order and a successful rescue changes fp / tag of
-  // its reads (and draws random numbers), which later list members see.  All pending members are
-  // evaluated in parallel (a wave each) against the current state; wave 0 then commits them in order,
-  // marking the rows a success really changes (fp 0 -> 1, tag drawn): a later member whose column holds
-  // no such row was evaluated on the state the reference would show it and is committed in the same
-  // round, the first member that does see a changed row starts the next round.
-  unsigned long long ctr = 0;   // wave 0: draws so far (thread.rs call order, see PhaseHost::run)
-  {
-    const unsigned long long Su = (unsigned long long)S, Fu = (unsigned long long)F;
-    ctr = (uint32_t)S <= in.max_enum_snps ? Su + Fu + (1ull << S) * Fu : 2 * (Su + Fu) + (Su / 4 + 1) * (Su + Fu);
-  }
-  auto rescue = [&](uint32_t list_flag, float min_ps, bool low_frac, uint64_t rseed) {
-    int start = 0;
-    for (;;) {
-      for (int r = tid; r < nrow; r += NT) dirty[r] = 0;
-      for (int ti = start + wave; ti < S; ti += NW) {
-        uint8_t code = 0;
-        if (soflags[ti] & list_flag) {
-          if (ccptr[ti] == ccptr[ti + 1]) code = 1;
-          else if (svt[ti] != 1) code = 2;
-          else {
-            double q[2]; int hap1, hap2, nobs;   // gather(need_assigned); phase_score_log(+-1, 0) share q2 / q3
-            col_sums(ti, true, [&](int sg, uint8_t v, double* t) { t[0] = lg(sg, 1, 0, v); t[1] = lg(sg, -1, 0, v); },
-                     q, 2, hap1, hap2, nobs);
-            if (nobs == 0 || hap1 < 2 || hap2 < 2) code = 3;
-            else {
-              const double pa = -10.0 * log10(1.0 - (1.0 - q[0] / (q[0] + q[1])));
-              const double pb = -10.0 * log10(1.0 - (1.0 - q[1] / (q[0] + q[1])));
-              if (lane == 0) { rpa[ti] = pa; rpb[ti] = pb; }
-              code = fmax(pa, pb) >= (double)min_ps ? 4 : 5;
-            }
-          }
-        }
-        if (lane == 0) rcode[ti] = code;
-      }
-      __syncthreads();
-      if (wave == 0) {
-        int ti = start;
-        bool changed = false;   // (wave-uniform) a success of this round changed some row
-        for (; ti < S; ti++) {
-          const uint8_t code = rcode[ti];
-          if (code == 0) continue;
-          if (code >= 3 && changed) {   // codes 1 / 2 do not look at the rows
-            bool stale = false;
-            for (int k = ccptr[ti] + lane; k < ccptr[ti + 1]; k += 64) stale = stale || dirty[erow[cent[k]]];
-            if (__any(stale)) break;    // evaluated on an outdated state: next round starts here
-          }
-          if (code == 4) {
-            for (int k0 = ccptr[ti]; k0 < ccptr[ti + 1]; k0 += 64) {   // rows in column order: the draws keep their order
-              const int k = k0 + lane;
-              const bool in_col = k < ccptr[ti + 1];
-              const int r = in_col ? erow[cent[k]] : 0;
-              const bool draw = in_col && (tag[r] == 0 || asg[r] == 0);
-              const unsigned long long dm = __ballot(draw);
-              if (in_col && (draw || !fp[r])) dirty[r] = 1;
-              if (__any(in_col && (draw || !fp[r]))) changed = true;
-              if (in_col) fp[r] = 1;
-              if (draw) tag[r] = u01(rseed, ctr + (unsigned long long)__popcll(dm & ((1ull << lane) - 1ull))) < 0.5 ? -1 : 1;
-              ctr += (unsigned long long)__popcll(dm);
-            }
-          }
-          if (lane == 0) {
-            const uint32_t fl_old = sflags[ti];
-            if (code == 1 || code == 3) sflags[ti] |= LCR_F_SINGLE;
-            else if (code == 2) sflags[ti] |= LCR_F_NON_SELECTED;
-            else if (code == 5) {
-              sflags[ti] &= ~(uint32_t)LCR_F_SINGLE;
-              sflags[ti] |= LCR_F_NON_SELECTED;
-              if (low_frac) { sflags[ti] |= LCR_F_CAND_SOMATIC; sflags[ti] &= ~(uint32_t)LCR_F_FOR_PHASING; }
-              else sflags[ti] |= LCR_F_RNA_EDIT;
-            } else {   // rescued
-              sflags[ti] &= ~(uint32_t)(LCR_F_SINGLE | LCR_F_NON_SELECTED | LCR_F_RNA_EDIT);
-              if (low_frac) sflags[ti] &= ~(uint32_t)LCR_F_CAND_SOMATIC;
-              sflags[ti] |= LCR_F_FOR_PHASING;
-              shap[ti] = rpa[ti] >= rpb[ti] ? 1 : -1;
-              sgt[ti] = 0; svt[ti] = 1; sps[ti] = fmax(rpa[ti], rpb[ti]);
-              s_chg = 1;
-            }
-            if ((sflags[ti] ^ fl_old) & LCR_F_FOR_PHASING) s_chg = 1;
-          }
-          wave_lds_sync();
-        }
-        if (lane == 0) s_flag = ti;
-      }
-      __syncthreads();
-      start = s_flag;
-      __syncthreads();
-      if (start >= S) break;
-    }
-  };
-
-  // snpfrags.rs:628-733: connected components of the PASS het SNPs (edges = allele-consistent SNP pairs of
-  // a read); component label = smallest SNP index (see RegionHost::assign_phase_set), by min-label
-  // propagation over the reads + pointer jumping until no edge joins two labels
-  auto phase_set = [&]() {
-    for (int i = tid; i < S; i += NT) {
-      const bool node = sgt[i] == 0 && svt[i] == 1 && !(sflags[i] & (LCR_F_DENSE | LCR_F_RNA_EDIT)) &&
-                        !(sps[i] < (double)in.min_phase_score);
-      parent[i] = node ? i : -1;
-    }
-    __syncthreads();
-    // pairs (x < y) among the first 64 PASS-het entries of a row whose alleles agree with the haplotypes
-    auto for_pairs = [&](int r, auto fn) -> int {
-      int nx = 0;
-      for (int e1 = rptr[r]; e1 < rptr[r + 1] && nx < 64; e1++) {
-        const int x = ecol[e1];
-        if (parent[x] < 0) continue;
-        int ny = nx + 1;
-        for (int e2 = e1 + 1; e2 < rptr[r + 1] && ny < 64; e2++) {
-          const int y = ecol[e2];
-          if (parent[y] < 0) continue;
-          if (shap[x] * shap[y] == (((ev[e1] ^ ev[e2]) & 32) ? -1 : 1)) fn(x, y);
-          ny++;
-        }
-        nx++;
-      }
-      return nx;
-    };
-    for (;;) {
-      if (tid == 0) s_flag = 0;
-      __syncthreads();
-      for (int r = tid; r < nrow; r += NT) {
-        if (!fp[r] || asg[r] == 0) continue;
-        for_pairs(r, [&](int x, int y) {
-          const int lx = parent[x], ly = parent[y];
-          if (lx != ly) { const int m = min(lx, ly); atomicMin(&parent[x], m); atomicMin(&parent[y], m); s_flag = 1; }
-        });
-      }
-      __syncthreads();
-      for (int i = tid; i < S; i += NT) if (parent[i] >= 0) { int l = parent[i]; while (parent[l] != l) l = parent[l]; atomicMin(&parent[i], l); }
-      __syncthreads();
-      if (!s_flag) break;
-      __syncthreads();
-    }
-    for (int i = tid; i < S; i += NT) if (parent[i] >= 0) cand[i].phase_set = (uint32_t)(cand[parent[i]].pos + 1);
-    for (int r = tid; r < nrow; r += NT) {
-      uint32_t ps = 0;
-      if (fp[r] && asg[r] != 0) {
-        int best = -1, first = -1;  // largest component root among the components that own an edge of this read
-        const int n = for_pairs(r, [&](int x, int y) { (void)y; best = max(best, parent[x]); });
-        if (n == 1) {               // self loop (snpfrags.rs:659-665)
-          for (int e = rptr[r]; e < rptr[r + 1]; e++) if (parent[ecol[e]] >= 0) { first = ecol[e]; break; }
-          best = parent[first];
-        }
-        if (best >= 0) ps = (uint32_t)(cand[best].pos + 1);
-      }
-      in.phase_set[r0 + r] = ps;
-    }
-    __syncthreads();
-  };
-
-  const uint64_t rseed = region_seed(in.seed, in.start0[g]);
-  // thread.rs:168-201 runs (assign reads, assign SNPs) twice, the two rescue lists, and the pair once more.  The
-  // pair reads the SNPs' haplotype / genotype / variant type / FOR_PHASING bit and the rows' fp / tag and is
-  // idempotent on them: reads_hap applied to its own output under the same SNP state changes nothing (a flipped
-  // row's q / qn swap, bit for bit), snp_hap then recomputes the same values and ORs the same flag bits.  So a
-  // pair is a no-op -- and skipped -- when neither the previous snp_hap nor the rescues changed one of those
-  // fields (s_chg); the other flag bits are only ever written.
-  if (tid == 0) s_chg = 0;
-  __syncthreads();
-  reads_hap(); mark(); snp_hap(); mark();
-  bool redo = s_chg != 0;
-  __syncthreads();
-  if (tid == 0) s_chg = 0;
-  __syncthreads();
-  if (redo) {
-    reads_hap(); snp_hap();
-    redo = s_chg != 0;
-    __syncthreads();
-    if (tid == 0) s_chg = 0;
-    __syncthreads();
-  }
-  mark();
-  const float relaxed = in.min_phase_score - 3.0f;
-  rescue(LCR_F_RNA_EDIT, relaxed, false, rseed);
-  rescue(LCR_F_CAND_SOMATIC, relaxed, true, rseed);
-  mark();
-  if (redo || s_chg != 0) { reads_hap(); snp_hap(); }
-  mark();
-  phase_set();
-  mark();
-  // results straight into pinned host memory (device-visible): the host only waits for the kernels, no copies follow
-  for (int i = tid; i < S; i += NT) {
-    cand[i].haplotype = shap[i]; cand[i].genotype = sgt[i]; cand[i].variant_type = svt[i];
-    cand[i].flags = sflags[i]; cand[i].phase_score = sps[i];
-    in.h_cand[c0 + i] = cand[i];   // (phase_set was written by this thread above)
-  }
-  if (tid == 0) in.h_obj[g] = in.st_obj[g];
-  for (int r = tid; r < nrow; r += NT) { in.haplotag[r0 + r] = tag[r]; in.assignment[r0 + r] = asg[r]; }
-  mark();
+  WgScope sc{red, &wg_bc};
+  post_run(sc, in, lut, v, mark);
 }
 
 // ================================= host side ====================================================
@@ -1302,6 +958,31 @@ struct PhaseWork {   // host epilogue structures, reused across calls
 
 }  // namespace
 
+// One persistent (grid-barrier) kernel at a time per device, across host threads and processes: two such launches
+// that each hold a part of the CUs would wait for each other's workgroups forever.
+struct GridLock {
+  int fd = -1;
+  bool held = false;
+  static std::mutex& mu() { static std::mutex m; return m; }
+  void acquire() {
+    if (held) return;
+    mu().lock();
+    int dev = 0;
+    char bus[64] = "gpu";
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetPCIBusId(bus, sizeof(bus), dev);
+    std::string path = std::string("/tmp/liblcr_grid_") + bus + ".lock";
+    for (char& ch : path) if (ch == ':') ch = '_';
+    fd = open(path.c_str(), O_CREAT | O_RDWR, 0666);
+    if (fd >= 0) while (flock(fd, LOCK_EX) != 0 && errno == EINTR) {}
+    held = true;
+  }
+  ~GridLock() {
+    if (!held) return;
+    if (fd >= 0) { (void)flock(fd, LOCK_UN); close(fd); }
+    mu().unlock();
+  }
+};
+
 void PhaseHost::free_work() { delete static_cast<PhaseWork*>(work); work = nullptr; }
 
 int PhaseHost::ld_blocks(const PhaseInputs& in, int region, std::vector<int32_t>* off, std::vector<int32_t>* snps, hipStream_t s, std::string* err) {
@@ -1362,7 +1043,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
          &b_stc = d_state[15], &b_slots = d_state[16], &b_psrc = d_state[21], &b_desc = d_state[22], &b_tbl = d_state[23],
          &b_adj = d_state[24], &b_part = d_state[25], &b_snpi = d_state[26], &b_snpb = d_state[27], &b_q = d_state[28],
          &b_info = d_state[29], &b_rowi = d_state[30], &b_enti = d_state[31], &b_work = d_state[32], &b_macc = d_state[33],
-         &b_ctl = d_state[34];
+         &b_ctl = d_state[34], &b_btot = d_state[35], &b_ps = d_state[36], &b_pse = d_state[37], &b_psp = d_state[38];
   const size_t nnz1 = (size_t)std::max<int64_t>(nnz, 1), nc1 = (size_t)std::max(ncand, 1), nr1 = (size_t)std::max(nrow, 1);
   PCHK(b_reg.reserve((size_t)std::max(ng, 1) * sizeof(RegionDev)));
   PCHK(b_stat.reserve((size_t)std::max(ng, 1) * sizeof(StageStat)));
@@ -1407,20 +1088,30 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   // the host epilogue (RegionHost) for the others and, as a cross-check, for all regions under LCR_POST_HOST=1.  The
   // regions' sizes are on the host already (lcr_fragments), so this is known before anything is queued.
   const bool force_host_post = getenv("LCR_POST_HOST") != nullptr;
-  std::vector<uint8_t> host_post(ng, 0);
+  int64_t grid_min = 1 << 17;   // chain regions with at least this many phase entries get all CUs (tests: 0 = every region)
+  if (const char* e = getenv("LCR_GRID_MIN_ENTRIES")) grid_min = atoll(e);
+  std::vector<uint8_t> host_post(ng, 0), grid_post(ng, 0), grid_stage(ng, 0);
   bool any_host_post = false;
   uint32_t post_lds = 0;
+  std::vector<int32_t> gpost_slots, gstage_slots;
+  size_t gp_S = 1, gp_rows = 1, gp_E = 1;   // largest region image of k4_gpost
   for (int g = 0; g < ng; g++) {
     const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
     if (S == 0) continue;
     const int nr_g = in.row_region_off[g + 1] - in.row_region_off[g];
     const int64_t E_all = in.region_e_off[g + 1] - in.region_e_off[g];
+    if (E_all > INT_MAX - 64) { if (err) *err = "a region's fragment matrix has more than 2^31 entries"; return LCR_E_ARG; }
+    if (E_all >= std::max<int64_t>(grid_min, 1)) { grid_stage[g] = 1; gstage_slots.push_back(g); }
     bool fits = !(nr_g > POST_MAX_ROWS || E_all > POST_MAX_ENTRIES || S > POST_MAX_SNPS);
     uint32_t need = 0;
     if (fits) { need = post_layout(nr_g, (uint32_t)E_all, S).total; if (need > 64 * 1024) fits = false; }
-    if (force_host_post || !fits) { host_post[g] = 1; any_host_post = true; }
-    else post_lds = std::max(post_lds, need);
+    if (force_host_post) { host_post[g] = 1; any_host_post = true; }
+    else if (!fits || (grid_min == 0 && (uint32_t)S > prm.max_enum_snps)) {
+      grid_post[g] = 1; gpost_slots.push_back(g);
+      gp_S = std::max(gp_S, (size_t)S); gp_rows = std::max(gp_rows, (size_t)nr_g); gp_E = std::max(gp_E, (size_t)E_all);
+    } else post_lds = std::max(post_lds, need);
   }
+  GridLock grid_lock;   // held from the first persistent launch until this call returns (all queues are drained by then)
 
   // ---- queue `side`: the fragment matrix goes to the host (pinned) only when a region takes the host epilogue
   PCHK(hipEventRecord(ev_in, stream));
@@ -1440,12 +1131,19 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   StageStat* const stat = h_pin[5].as<StageStat>();
   if (ng) {
     StageIn si{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, in.d_cand, in.d_cand_off, in.d_row_region_off, in.d_start0,
-               prm.min_linkers, prm.max_enum_snps, prm.seed};
+               prm.min_linkers, prm.max_enum_snps, prm.seed, std::max<int64_t>(grid_min, 1)};
     StageOut so{b_reg.as<RegionDev>(), b_stat.as<StageStat>(), b_prp.as<int32_t>(), b_pc.as<int32_t>(), b_pv.as<uint8_t>(),
                 b_cp.as<int32_t>(), b_cr.as<int32_t>(), b_cv.as<uint8_t>(), b_snp.as<uint8_t>(), b_snp.as<int8_t>() + nc1,
                 b_snp.as<uint8_t>() + 2 * nc1, b_sc.as<long long>(), b_cur.as<int32_t>(), b_psrc.as<int32_t>()};
     hipLaunchKernelGGL(k4_stage, dim3(ng), dim3(STAGE_THREADS), 0, stream, si, so, L.dev);
     PCHK(hipGetLastError());
+    if (!gstage_slots.empty()) {   // large regions: all CUs on one region at a time (every persistent launch goes to `side`)
+      grid_lock.acquire();
+      PCHK(b_ctl.reserve(4 * sizeof(GridCtl))); PCHK(b_btot.reserve((size_t)(2 * std::max(1, k4_grid_blocks()) + 1) * 4 + 64));
+      for (int g : gstage_slots) PCHK(k4_stage_launch_grid(si, so, L.dev, g, b_ctl.as<GridCtl>(), b_btot.as<int32_t>(), side));
+      PCHK(hipEventRecord(ev_join, side));
+      PCHK(hipStreamWaitEvent(stream, ev_join, 0));
+    }
     PCHK(hipMemcpyAsync(stat, b_stat.p, (size_t)ng * sizeof(StageStat), hipMemcpyDeviceToHost, stream));
     PCHK(hipMemsetAsync(b_st.p, 0, st_bytes, stream));
     PCHK(hipEventRecord(ev_csr, stream));   // the chain kernels on `side` read the staged matrices
@@ -1467,7 +1165,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   plut.p_homref = L.p_homref; plut.p_homvar = L.p_homvar; plut.log_theta = L.log_theta; plut.log2 = L.log2;
   PostIn pin{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, const_cast<lcr_candidate*>(in.d_cand), in.d_cand_off,
              in.d_row_region_off, in.d_start0, P.st_sigma, P.st_delta, P.st_eta, (int8_t*)(d_res + res_tag), d_res + res_asg,
-             (uint32_t*)(d_res + res_ps), P.st_obj, (long long*)(d_hc + hc_obj), (lcr_candidate*)d_hc, prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr};
+             (uint32_t*)(d_res + res_ps), P.st_obj, (long long*)(d_hc + hc_obj), (lcr_candidate*)d_hc, prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr, P.reg, b_psrc.as<int32_t>()};
   if (prof) { PCHK(d_state[20].reserve((size_t)std::max(ng, 1) * 16 * 8)); PCHK(hipMemsetAsync(d_state[20].p, 0, (size_t)std::max(ng, 1) * 16 * 8, stream)); pin.dbg_clk = d_state[20].as<long long>(); }
 
   // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
@@ -1504,7 +1202,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       spans[cls].push_back({g, (uint32_t)n_t[cls]});
       n_t[cls] += (size_t)((n + per_of[cls] - 1) / per_of[cls]);
       nj += (int64_t)n;
-      if (!host_post[g]) post_slots.push_back(g);
+      if (!host_post[g] && !grid_post[g]) post_slots.push_back(g);
     }
     // one upload: spans of every class | job_base | slots | post slots ; then job objectives and winners
     size_t n_w[NCLS], s_off[NCLS], n_spans = 0;
@@ -1580,7 +1278,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     }
     // post-phase: device epilogue for the chain regions that fit it
     std::vector<int32_t> post_slots;
-    for (int k = 0; k < nc; k++) if (!host_post[desc[k].slot]) post_slots.push_back(desc[k].slot);
+    for (int k = 0; k < nc; k++) if (!host_post[desc[k].slot] && !grid_post[desc[k].slot]) post_slots.push_back(desc[k].slot);
     const size_t nps = post_slots.size();
     const size_t desc_bytes = ((size_t)nc * sizeof(ChainDesc) + 15) & ~(size_t)15;
     PCHK(h_pin[10].reserve(desc_bytes + nps * 4 + 64));
@@ -1591,7 +1289,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     const size_t ni = nc1 + (size_t)ng + 1;   // per-SNP int32 arrays: adj_ptr, blk_ptr (ni each), blk_of, blk_pos, blk_nodes, queue (nc1), stack (2 nc1)
     PCHK(b_snpi.reserve((2 * ni + 6 * nc1) * 4 + 64)); PCHK(b_snpb.reserve(3 * nc1 + 64)); PCHK(b_q.reserve(2 * nc1 * 8 + 64));
     PCHK(b_info.reserve((size_t)std::max(ng, 1) * 8 + 64)); PCHK(b_rowi.reserve(nr1 * 4 + 64)); PCHK(b_enti.reserve(2 * nnz1 * 4 + 64));
-    PCHK(b_work.reserve(st_bytes + 64)); PCHK(b_macc.reserve(nc1 * 8 + 64)); PCHK(b_ctl.reserve(sizeof(GridCtl)));
+    PCHK(b_work.reserve(st_bytes + 64)); PCHK(b_macc.reserve(nc1 * 8 + 64)); PCHK(b_ctl.reserve(4 * sizeof(GridCtl)));
     ChainDev C{};
     const int32_t stride = (max_state + 63) & ~63;
     Pc.scratch = nullptr; Pc.scratch_stride = stride;
@@ -1627,6 +1325,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(hipMemcpyAsync(b_desc.p, h_pin[10].p, (size_t)nc * sizeof(ChainDesc), hipMemcpyHostToDevice, side));
     if (nps) PCHK(hipMemcpyAsync(b_slots.p, h_pin[10].as<uint8_t>() + desc_bytes, nps * 4, hipMemcpyHostToDevice, side));
     PCHK(k4_chain_launch_wg(C, 0, n_small, dyn_state + (size_t)Pc.lds_mat, side));
+    if (n_big) grid_lock.acquire();
     for (int k = 0; k < n_big; k++) PCHK(k4_chain_launch_grid(C, n_small + k, side));
     if (nps) {
       PostIn pinc = pin;
@@ -1637,6 +1336,40 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       PCHK(hipGetLastError());
     }
   } else chain_desc.clear();
+  // ---- post-phase steps of the regions beyond k4_post's LDS image: all CUs on one region at a time, on `side`
+  if (!gpost_slots.empty()) {
+    grid_lock.acquire();
+    const int grid_waves = std::max(1, k4_grid_blocks()) * 16;
+    PostScratch ps{};
+    ps.n_parts = (int32_t)std::max<int64_t>(16, std::min<int64_t>(grid_waves, (int64_t)(1 << 23) / (int64_t)gp_S));
+    const size_t S8 = (gp_S + 8) & ~(size_t)7, R8 = (gp_rows + 8) & ~(size_t)7, E8 = (gp_E + 8) & ~(size_t)7;
+    PCHK(b_ps.reserve(S8 * (3 * 8 + 4 * 4 + 4) + R8 * (4 + 5) + 64));   // per SNP: 3 doubles, 4 int32, 4 bytes; per row: rptr + 5 bytes
+    PCHK(b_pse.reserve(E8 * (3 * 4 + 1) + 64));
+    PCHK(b_psp.reserve((size_t)ps.n_parts * gp_S * 4 + 64));
+    PCHK(b_ctl.reserve(4 * sizeof(GridCtl)));
+    uint8_t* p = b_ps.as<uint8_t>();
+    ps.sps = (double*)p; p += 8 * S8; ps.rpa = (double*)p; p += 8 * S8; ps.rpb = (double*)p; p += 8 * S8;
+    ps.sflags = (uint32_t*)p; p += 4 * S8; ps.soflags = (uint32_t*)p; p += 4 * S8; ps.parent = (int32_t*)p; p += 4 * S8; ps.ccptr = (int32_t*)p; p += 4 * S8;
+    ps.rptr = (int32_t*)p; p += 4 * R8;
+    ps.shap = (int8_t*)p; p += S8; ps.sgt = (int8_t*)p; p += S8; ps.svt = (int8_t*)p; p += S8; ps.rcode = p; p += S8;
+    ps.tag = (int8_t*)p; p += R8; ps.asg = p; p += R8; ps.fp = p; p += R8; ps.lok = p; p += R8; ps.dirty = p; p += R8;
+    uint8_t* q = b_pse.as<uint8_t>();
+    ps.ecol = (int32_t*)q; q += 4 * E8; ps.erow = (int32_t*)q; q += 4 * E8; ps.cent = (int32_t*)q; q += 4 * E8; ps.ev = q;
+    ps.pcnt = b_psp.as<int32_t>();
+    ps.ctl = b_ctl.as<GridCtl>() + 1;
+    PostIn pinc = pin;
+    pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta; pinc.st_obj = Pc.st_obj;
+    bool waited = false;
+    for (int g : gpost_slots) {
+      const bool chain = (uint32_t)(in.cand_region_off[g + 1] - in.cand_region_off[g]) > prm.max_enum_snps;
+      if (!chain && !waited) {   // an enumeration region: its winner is materialised on `stream`
+        PCHK(hipEventRecord(ev_fork, stream));
+        PCHK(hipStreamWaitEvent(side, ev_fork, 0));
+        waited = true;
+      }
+      PCHK(k4_post_launch_grid(chain ? &pinc : &pin, ps, g, plut, side));
+    }
+  }
   lap("chain launch");
   PCHK(hipStreamSynchronize(side));
   lap("chain kernels");
@@ -1665,7 +1398,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       std::vector<std::pair<long long, int>> tot;
       for (int g = 0; g < ng; g++) {
         const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
-        if (S == 0 || host_post[g] || ((uint32_t)S > prm.max_enum_snps) != (chain == 1)) continue;
+        if (S == 0 || host_post[g] || grid_post[g] || ((uint32_t)S > prm.max_enum_snps) != (chain == 1)) continue;
         tot.push_back({clk[(size_t)g * 16 + 9] - clk[(size_t)g * 16], g});
       }
       if (tot.empty()) continue;

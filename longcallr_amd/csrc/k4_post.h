@@ -1,0 +1,366 @@
+// k4_post.h — the post-phase sequence of thread.rs:168-201 on the device, written once for two scopes:
+//   assign_reads_haplotype + assign_het_var_haplotype (x2), eval_rna_edit_var_phase, eval_low_frac_var_phase,
+//   assign_reads_haplotype + assign_het_var_haplotype, assign_phase_set   (snpfrags.rs:191-733).
+// WgScope  (k4_post, k4_phase.hip): one workgroup per region, the region's fragment rows in LDS (16-bit indices);
+// GridScope (k4_gpost, k4_grid.hip): all workgroups on one region, the same arrays in HBM (32-bit indices) — for
+// regions beyond the LDS image (config C5).  These are f64 sum-of-ratio decisions: every log10(eps) / log10(1-eps)
+// term comes from the table of libm values the host path uses (kernel argument), sums run in the reference's
+// observation order (a read's entries in column order, a SNP's reads in row order) and -ffp-contract=off keeps
+// a*b+c unfused, so the decisions are the host path's bit for bit; only phase_score's final log10 is the device libm.
+#pragma once
+#include "k4_dev.h"
+
+namespace {
+
+struct PostIn {
+  const int64_t* row_ptr; const int32_t* col; const uint8_t* val; const uint32_t* links;
+  lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off; const int64_t* start0;
+  const int8_t* st_sigma; const int8_t* st_delta; const int8_t* st_eta;
+  int8_t* haplotag; uint8_t* assignment; uint32_t* phase_set;   // per-row results: pinned host memory, written by the kernel
+  const long long* st_obj; long long* h_obj; lcr_candidate* h_cand;   // objective / candidate mirror in pinned host memory
+  uint32_t min_linkers, max_enum_snps; uint64_t seed; double cutoff; float min_phase_score;
+  long long* dbg_clk;   // LCR_PHASE_PROF: 100 MHz timestamps of every workgroup's steps, 16 per region (nullptr otherwise)
+  const RegionDev* reg; const int32_t* prow_src;   // phasing rows of the region (k4_stage): count, and their fragment rows
+};
+
+// the region image the steps work on: LDS (IDX = uint16_t) or HBM (IDX = int32_t)
+template <class IDX>
+struct PostView {
+  int g, S, nrow, E, F;          // region, candidates, fragment rows, entries, phasing rows
+  int r0, c0;
+  double *le, *l1e;              // LDS in both scopes
+  double *sps, *rpa, *rpb;
+  uint32_t *sflags, *soflags; int32_t* parent;
+  IDX *rptr, *ecol, *erow, *cent, *ccptr;
+  uint8_t* ev;
+  int8_t* tag; uint8_t *asg, *fp, *lok, *dirty;
+  int8_t *shap, *sgt, *svt; uint8_t* rcode;
+  lcr_candidate* cand;
+  double* stage;                 // LDS: per wave 4 * 65 doubles
+};
+
+constexpr int POST_SSTR = 65;   // stage row stride in doubles (lanes a = 0..3 read different banks)
+
+// everything after the staging of the region image; `mark` records step timestamps (profiling)
+template <class SC, class IDX, class Mark>
+__device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<IDX>& v, Mark mark) {
+  const int lane = threadIdx.x & 63;
+  const int S = v.S, nrow = v.nrow;
+  double* le = v.le; double* l1e = v.l1e;
+  double* sps = v.sps; double* rpa = v.rpa; double* rpb = v.rpb;
+  uint32_t* sflags = v.sflags; uint32_t* soflags = v.soflags; int32_t* parent = v.parent;
+  IDX* rptr = v.rptr; IDX* ecol = v.ecol; IDX* erow = v.erow; IDX* cent = v.cent; IDX* ccptr = v.ccptr;
+  uint8_t* ev = v.ev; int8_t* tag = v.tag; uint8_t* asg = v.asg; uint8_t* fp = v.fp; uint8_t* lok = v.lok; uint8_t* dirty = v.dirty;
+  int8_t* shap = v.shap; int8_t* sgt = v.sgt; int8_t* svt = v.svt; uint8_t* rcode = v.rcode;
+  lcr_candidate* cand = v.cand;
+
+  auto lg = [&](int sigma, int delta, int eta, uint8_t x) -> double {   // log10(aki(...)), phase.rs:32-49
+    const int pp = (x & 32) ? 1 : -1, xx = eta == 0 ? sigma * delta : eta;
+    return pp == xx ? l1e[x & 31] : le[x & 31];
+  };
+  // Ordered sums over the observations of SNP column ti, one wave per column: 64 column entries at a time
+  // are loaded and filtered by the lanes (lane <-> entry) and each lane stages its NACC terms (or +0.0, the
+  // exact identity here: the sums start at +0.0 and every term is a finite log) in LDS; then lane a adds the
+  // 64 staged terms of accumulator a in entry order.  The additions are the host's, in the host's order;
+  // only the loads and the filter run in parallel.  Results are returned wave-uniform.
+  double* stg = v.stage + (threadIdx.x >> 6) * (4 * POST_SSTR);
+  auto col_sums = [&](int ti, bool skip_unassigned, auto term, double* acc, int nacc, int& hap1, int& hap2, int& nobs) {
+    hap1 = hap2 = nobs = 0;
+    double mine = 0.0;   // lane a < nacc: running sum of accumulator a
+    const int kb = ccptr[ti], ke = ccptr[ti + 1];
+    for (int k0 = kb; k0 < ke; k0 += 64) {
+      const int k = k0 + lane;
+      bool keep = false; int r = 0, e = 0;
+      if (k < ke) { e = cent[k]; r = erow[e]; keep = fp[r] && lok[r] && !(skip_unassigned && asg[r] == 0); }
+      double t[4] = {0.0, 0.0, 0.0, 0.0};
+      if (keep) term((int)tag[r], ev[e], t);
+      for (int a = 0; a < nacc; a++) stg[a * POST_SSTR + lane] = t[a];
+      const unsigned long long km = __ballot(keep);
+      hap1 += __popcll(__ballot(keep && asg[r] == 1)); hap2 += __popcll(__ballot(keep && asg[r] == 2));
+      nobs += __popcll(km);
+      wave_lds_sync();
+      const int nk = min(64, ke - k0);
+      if (lane < nacc) {
+        const double* src = stg + lane * POST_SSTR;
+        int j = 0;
+        for (; j + 8 <= nk; j += 8) {
+          double x[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) x[u] = src[j + u];
+#pragma unroll
+          for (int u = 0; u < 8; u++) mine += x[u];
+        }
+        for (; j < nk; j++) mine += src[j];
+      }
+      wave_lds_sync();
+    }
+    for (int a = 0; a < nacc; a++)
+      acc[a] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), a), __builtin_amdgcn_readlane(__double2loint(mine), a));
+  };
+  // phase.rs:238-255 over the kept observations of column ti (wave-uniform result)
+  auto psl = [&](int ti, int delta_i, int eta_i, bool skip_unassigned) -> double {
+    double q[3]; int h1, h2, nb;
+    col_sums(ti, skip_unassigned, [&](int sg, uint8_t x, double* t) {
+      t[0] = lg(sg, delta_i, eta_i, x); t[1] = lg(sg, 1, eta_i, x); t[2] = lg(sg, -1, eta_i, x);
+    }, q, 3, h1, h2, nb);
+    return 1.0 - q[0] / (q[1] + q[2]);
+  };
+  // snpfrags.rs:548-625
+  auto reads_hap = [&]() {
+    for (int r = sc.tid(); r < nrow; r += sc.nt()) {
+      if (!fp[r]) continue;
+      const int sigma_k = tag[r];
+      double q1 = 0, q2 = 0, q3 = 0, n1 = 0;
+      int n = 0;
+      for (int e = rptr[r]; e < (int)rptr[r + 1]; e++) {
+        const int i = ecol[e];
+        if (!(sflags[i] & LCR_F_FOR_PHASING) || shap[i] == 0 || sgt[i] != 0) continue;
+        q1 += lg(sigma_k, shap[i], 0, ev[e]);
+        n1 += lg(-sigma_k, shap[i], 0, ev[e]);
+        n++;
+      }
+      if (sigma_k == 0 || n == 0) { asg[r] = 0; tag[r] = 0; continue; }
+      for (int e = rptr[r]; e < (int)rptr[r + 1]; e++) {
+        const int i = ecol[e];
+        if (!(sflags[i] & LCR_F_FOR_PHASING) || shap[i] == 0 || sgt[i] != 0) continue;
+        q2 += lg(1, shap[i], 0, ev[e]); q3 += lg(-1, shap[i], 0, ev[e]);
+      }
+      const double q = 1.0 - q1 / (q2 + q3), qn = 1.0 - n1 / (q2 + q3);
+      if (fabs(q - qn) >= in.cutoff) {
+        if (q >= qn) asg[r] = sigma_k == 1 ? 1 : 2;
+        else if (sigma_k == 1) { asg[r] = 2; tag[r] = -1; }
+        else { asg[r] = 1; tag[r] = 1; }
+      } else { asg[r] = 0; tag[r] = 0; }
+    }
+    sc.sync();
+  };
+  // snpfrags.rs:378-546, one wave per SNP (all lanes hold the same values; lane 0 writes).  Returns (to every thread)
+  // whether a SNP's haplotype / genotype / variant type really changed (see the pass sequence at the end).
+  auto snp_hap = [&]() -> bool {
+    int chg = 0;
+    for (int ti = sc.wave(); ti < S; ti += sc.nwaves()) {
+      if (!(sflags[ti] & LCR_F_FOR_PHASING)) { if (lane == 0) sflags[ti] |= LCR_F_NON_SELECTED; continue; }
+      if (ccptr[ti] == ccptr[ti + 1]) { if (lane == 0) sflags[ti] |= LCR_F_SINGLE; continue; }
+      const int delta_i = shap[ti];
+      const bool het_skip = svt[ti] == 1;
+      int hap1, hap2, nobs;
+      double sum[4];   // het_d, het_nd, homref, homvar
+      col_sums(ti, het_skip, [&](int sg, uint8_t x, double* t) {
+        t[0] = lg(sg, delta_i, 0, x); t[1] = lg(sg, -delta_i, 0, x); t[2] = lg(sg, delta_i, 1, x); t[3] = lg(sg, delta_i, -1, x);
+      }, sum, 4, hap1, hap2, nobs);
+      if (nobs == 0) { if (lane == 0) sflags[ti] |= LCR_F_NON_SELECTED; continue; }
+      const double het_d = sum[0], het_nd = sum[1], homref = sum[2], homvar = sum[3];
+      const double p_het = lut.log_theta - (double)(uint32_t)nobs * lut.log2;
+      auto score = [&](int sign, int eta_i) -> double {   // cal_delta_eta_sigma_log, phase.rs:128-176
+        const double hd = sign > 0 ? het_d : het_nd, hn = sign > 0 ? het_nd : het_d;
+        double q1 = eta_i == 0 ? hd : (eta_i == 1 ? homref : homvar);
+        q1 += eta_i == 0 ? p_het : (eta_i == 1 ? lut.p_homref : lut.p_homvar);
+        const double q2 = homvar + lut.p_homvar, q3 = hd + p_het, q4 = homref + lut.p_homref, q5 = hn + p_het;
+        return 1.0 - q1 / (q2 + q3 + q4 + q5);
+      };
+      const double q1 = score(1, 0), q2 = score(-1, 0), q3 = score(1, 1), q4 = score(1, -1);
+      const double mx = fmax(q1, fmax(q2, fmax(q3, q4)));
+      int nh = delta_i, ng_ = 0, nv = svt[ti];
+      if (q1 == mx) { nh = delta_i; ng_ = 0; nv = 1; }
+      else if (q2 == mx) { nh = -delta_i; ng_ = 0; nv = 1; }
+      else if (q3 == mx) { nh = delta_i; ng_ = 1; nv = 0; }
+      else if (q4 == mx) { nh = delta_i; ng_ = -1; if (nv != 2 && nv != 3) nv = 2; }
+      else continue;  // NaN scores: the reference panics here
+      double ps = sps[ti];
+      uint32_t fl = sflags[ti];
+      if (ng_ != 0) fl |= LCR_F_NON_SELECTED;
+      else if (hap1 >= 1 && hap2 >= 1) {
+        // phase_score_log(nh, 0): q2 / q3 = sums of lg(sigma, +1 / -1, 0, v), q1 = the one of nh -- the very
+        // addition sequences of het_d / het_nd above (same observations, same order) when delta_i = +-1
+        if (delta_i == 1 || delta_i == -1) {
+          const double s2 = delta_i == 1 ? het_d : het_nd, s3 = delta_i == 1 ? het_nd : het_d;
+          ps = -10.0 * log10(1.0 - (1.0 - (nh == 1 ? s2 : s3) / (s2 + s3)));
+        } else ps = -10.0 * log10(1.0 - psl(ti, nh, ng_, het_skip));
+      }
+      else ps = 0.19940219;
+      if (lane == 0) {
+        if (shap[ti] != nh || sgt[ti] != ng_ || svt[ti] != nv) chg = 1;   // (fl only ORs bits neither half reads)
+        shap[ti] = (int8_t)nh; sgt[ti] = (int8_t)ng_; svt[ti] = (int8_t)nv; sflags[ti] = fl; sps[ti] = ps;
+      }
+    }
+    return sc.sync_or(chg) != 0;
+  };
+  // snpfrags.rs:191-376.  The list is walked in index order and a successful rescue changes fp / tag of
+  // its reads (and draws random numbers), which later list members see.  All pending members are
+  // evaluated in parallel (a wave each) against the current state; the first wave of the scope then commits them in
+  // order, marking the rows a success really changes (fp 0 -> 1, tag drawn): a later member whose column holds
+  // no such row was evaluated on the state the reference would show it and is committed in the same
+  // round, the first member that does see a changed row starts the next round.
+  unsigned long long ctr = 0;   // first wave: draws so far (thread.rs call order, see PhaseHost::run)
+  {
+    const unsigned long long Su = (unsigned long long)S, Fu = (unsigned long long)v.F;
+    ctr = (uint32_t)S <= in.max_enum_snps ? Su + Fu + (1ull << S) * Fu : 2 * (Su + Fu) + (Su / 4 + 1) * (Su + Fu);
+  }
+  auto rescue = [&](uint32_t list_flag, float min_ps, bool low_frac, uint64_t rseed) -> bool {   // true: some SNP state changed
+    int start = 0, chg = 0;
+    for (;;) {
+      for (int r = sc.tid(); r < nrow; r += sc.nt()) dirty[r] = 0;
+      for (int ti = start + sc.wave(); ti < S; ti += sc.nwaves()) {
+        uint8_t code = 0;
+        if (soflags[ti] & list_flag) {
+          if (ccptr[ti] == ccptr[ti + 1]) code = 1;
+          else if (svt[ti] != 1) code = 2;
+          else {
+            double q[2]; int hap1, hap2, nobs;   // gather(need_assigned); phase_score_log(+-1, 0) share q2 / q3
+            col_sums(ti, true, [&](int sg, uint8_t x, double* t) { t[0] = lg(sg, 1, 0, x); t[1] = lg(sg, -1, 0, x); },
+                     q, 2, hap1, hap2, nobs);
+            if (nobs == 0 || hap1 < 2 || hap2 < 2) code = 3;
+            else {
+              const double pa = -10.0 * log10(1.0 - (1.0 - q[0] / (q[0] + q[1])));
+              const double pb = -10.0 * log10(1.0 - (1.0 - q[1] / (q[0] + q[1])));
+              if (lane == 0) { rpa[ti] = pa; rpb[ti] = pb; }
+              code = fmax(pa, pb) >= (double)min_ps ? 4 : 5;
+            }
+          }
+        }
+        if (lane == 0) rcode[ti] = code;
+      }
+      sc.sync();
+      int ti = start;
+      if (sc.wave() == 0) {
+        bool changed = false;   // (wave-uniform) a success of this round changed some row
+        for (; ti < S; ti++) {
+          const uint8_t code = rcode[ti];
+          if (code == 0) continue;
+          if (code >= 3 && changed) {   // codes 1 / 2 do not look at the rows
+            bool stale = false;
+            for (int k = ccptr[ti] + lane; k < (int)ccptr[ti + 1]; k += 64) stale = stale || dirty[erow[cent[k]]];
+            if (__any(stale)) break;    // evaluated on an outdated state: next round starts here
+          }
+          if (code == 4) {
+            for (int k0 = ccptr[ti]; k0 < (int)ccptr[ti + 1]; k0 += 64) {   // rows in column order: the draws keep their order
+              const int k = k0 + lane;
+              const bool in_col = k < (int)ccptr[ti + 1];
+              const int r = in_col ? (int)erow[cent[k]] : 0;
+              const bool draw = in_col && (tag[r] == 0 || asg[r] == 0);
+              const unsigned long long dm = __ballot(draw);
+              if (in_col && (draw || !fp[r])) dirty[r] = 1;
+              if (__any(in_col && (draw || !fp[r]))) changed = true;
+              if (in_col) fp[r] = 1;
+              if (draw) tag[r] = u01(rseed, ctr + (unsigned long long)__popcll(dm & ((1ull << lane) - 1ull))) < 0.5 ? -1 : 1;
+              ctr += (unsigned long long)__popcll(dm);
+            }
+          }
+          if (lane == 0) {
+            const uint32_t fl_old = sflags[ti];
+            if (code == 1 || code == 3) sflags[ti] |= LCR_F_SINGLE;
+            else if (code == 2) sflags[ti] |= LCR_F_NON_SELECTED;
+            else if (code == 5) {
+              sflags[ti] &= ~(uint32_t)LCR_F_SINGLE;
+              sflags[ti] |= LCR_F_NON_SELECTED;
+              if (low_frac) { sflags[ti] |= LCR_F_CAND_SOMATIC; sflags[ti] &= ~(uint32_t)LCR_F_FOR_PHASING; }
+              else sflags[ti] |= LCR_F_RNA_EDIT;
+            } else {   // rescued
+              sflags[ti] &= ~(uint32_t)(LCR_F_SINGLE | LCR_F_NON_SELECTED | LCR_F_RNA_EDIT);
+              if (low_frac) sflags[ti] &= ~(uint32_t)LCR_F_CAND_SOMATIC;
+              sflags[ti] |= LCR_F_FOR_PHASING;
+              shap[ti] = rpa[ti] >= rpb[ti] ? 1 : -1;
+              sgt[ti] = 0; svt[ti] = 1; sps[ti] = fmax(rpa[ti], rpb[ti]);
+              chg = 1;
+            }
+            if ((sflags[ti] ^ fl_old) & LCR_F_FOR_PHASING) chg = 1;
+          }
+          wave_mem_sync();
+        }
+      }
+      start = sc.bcast(ti);   // (a barrier: the committed state is visible to everybody)
+      if (start >= S) break;
+    }
+    return sc.sync_or(chg) != 0;
+  };
+
+  // snpfrags.rs:628-733: connected components of the PASS het SNPs (edges = allele-consistent SNP pairs of
+  // a read); component label = smallest SNP index (see RegionHost::assign_phase_set), by min-label
+  // propagation over the reads + pointer jumping until no edge joins two labels
+  auto phase_set = [&]() {
+    for (int i = sc.tid(); i < S; i += sc.nt()) {
+      const bool node = sgt[i] == 0 && svt[i] == 1 && !(sflags[i] & (LCR_F_DENSE | LCR_F_RNA_EDIT)) &&
+                        !(sps[i] < (double)in.min_phase_score);
+      parent[i] = node ? i : -1;
+    }
+    sc.sync();
+    // pairs (x < y) among the first 64 PASS-het entries of a row whose alleles agree with the haplotypes
+    auto for_pairs = [&](int r, auto fn) -> int {
+      int nx = 0;
+      for (int e1 = rptr[r]; e1 < (int)rptr[r + 1] && nx < 64; e1++) {
+        const int x = ecol[e1];
+        if (parent[x] < 0) continue;
+        int ny = nx + 1;
+        for (int e2 = e1 + 1; e2 < (int)rptr[r + 1] && ny < 64; e2++) {
+          const int y = ecol[e2];
+          if (parent[y] < 0) continue;
+          if (shap[x] * shap[y] == (((ev[e1] ^ ev[e2]) & 32) ? -1 : 1)) fn(x, y);
+          ny++;
+        }
+        nx++;
+      }
+      return nx;
+    };
+    for (;;) {
+      int any = 0;
+      for (int r = sc.tid(); r < nrow; r += sc.nt()) {
+        if (!fp[r] || asg[r] == 0) continue;
+        for_pairs(r, [&](int x, int y) {
+          const int lx = sc.ld(&parent[x]), ly = sc.ld(&parent[y]);
+          if (lx != ly) { const int m = min(lx, ly); atomicMin(&parent[x], m); atomicMin(&parent[y], m); any = 1; }
+        });
+      }
+      any = sc.sync_or(any);
+      for (int i = sc.tid(); i < S; i += sc.nt())
+        if (parent[i] >= 0) { int l = sc.ld(&parent[i]); for (;;) { const int p = sc.ld(&parent[l]); if (p == l) break; l = p; } atomicMin(&parent[i], l); }
+      sc.sync();
+      if (!any) break;
+    }
+    for (int i = sc.tid(); i < S; i += sc.nt()) if (parent[i] >= 0) cand[i].phase_set = (uint32_t)(cand[parent[i]].pos + 1);
+    for (int r = sc.tid(); r < nrow; r += sc.nt()) {
+      uint32_t ps = 0;
+      if (fp[r] && asg[r] != 0) {
+        int best = -1, first = -1;  // largest component root among the components that own an edge of this read
+        const int n = for_pairs(r, [&](int x, int y) { (void)y; best = max(best, parent[x]); });
+        if (n == 1) {               // self loop (snpfrags.rs:659-665)
+          for (int e = rptr[r]; e < (int)rptr[r + 1]; e++) if (parent[ecol[e]] >= 0) { first = ecol[e]; break; }
+          best = parent[first];
+        }
+        if (best >= 0) ps = (uint32_t)(cand[best].pos + 1);
+      }
+      in.phase_set[v.r0 + r] = ps;
+    }
+    sc.sync();
+  };
+
+  const uint64_t rseed = region_seed(in.seed, in.start0[v.g]);
+  // thread.rs:168-201 runs (assign reads, assign SNPs) twice, the two rescue lists, and the pair once more.  The
+  // pair reads the SNPs' haplotype / genotype / variant type / FOR_PHASING bit and the rows' fp / tag and is
+  // idempotent on them: reads_hap applied to its own output under the same SNP state changes nothing (a flipped
+  // row's q / qn swap, bit for bit), snp_hap then recomputes the same values and ORs the same flag bits.  So a
+  // pair is a no-op -- and skipped -- when neither the previous snp_hap nor the rescues changed one of those
+  // fields; the other flag bits are only ever written.
+  reads_hap(); mark();
+  bool redo = snp_hap(); mark();
+  if (redo) { reads_hap(); redo = snp_hap(); }
+  mark();
+  const float relaxed = in.min_phase_score - 3.0f;
+  const bool c1 = rescue(LCR_F_RNA_EDIT, relaxed, false, rseed);
+  const bool c2 = rescue(LCR_F_CAND_SOMATIC, relaxed, true, rseed);
+  mark();
+  if (redo || c1 || c2) { reads_hap(); snp_hap(); }
+  mark();
+  phase_set();
+  mark();
+  // results straight into pinned host memory (device-visible): the host only waits for the kernels, no copies follow
+  for (int i = sc.tid(); i < S; i += sc.nt()) {
+    cand[i].haplotype = shap[i]; cand[i].genotype = sgt[i]; cand[i].variant_type = svt[i];
+    cand[i].flags = sflags[i]; cand[i].phase_score = sps[i];
+    in.h_cand[v.c0 + i] = cand[i];   // (phase_set was written by this thread above)
+  }
+  if (sc.tid() == 0) in.h_obj[v.g] = in.st_obj[v.g];
+  for (int r = sc.tid(); r < nrow; r += sc.nt()) { in.haplotag[v.r0 + r] = tag[r]; in.assignment[v.r0 + r] = asg[r]; }
+  mark();
+}
+
+}  // namespace

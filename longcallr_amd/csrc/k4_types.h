@@ -41,7 +41,7 @@ struct ChainDesc {
   int64_t part_off;    // per (row part, SNP) counters of the ordered column index, offset in int32
   int32_t n_parts, pad_;
 };
-struct GridCtl { unsigned arrive, gen, flag[2]; unsigned long long acc[2]; unsigned pad_[8]; };   // grid barrier + reductions
+struct GridCtl { unsigned arrive, gen, flag[2]; unsigned long long acc[2]; int slot; unsigned pad_[7]; };   // grid barrier + reductions
 struct ChainDev {
   PhaseDev P;                     // phase matrices; st_* = best / result state of every region
   const ChainDesc* desc;
@@ -63,3 +63,25 @@ struct ChainDev {
   double le[31], l1e[31], p_homref, p_homvar, log_theta, log2;   // libm values of the block-flip sums (host table)
 };
 
+
+// ---- staging of the phase matrices (k4_stage, k4_phase.hip; k4_stage_grid, k4_grid.hip)
+struct StageIn {
+  const int64_t* row_ptr; const int32_t* col; const uint8_t* val; const uint32_t* links;
+  const lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off; const int64_t* start0;
+  uint32_t min_linkers, max_enum_snps; uint64_t seed;
+  int64_t grid_min;    // regions with at least this many fragment entries are staged by k4_stage_grid
+};
+struct StageOut {
+  RegionDev* reg; StageStat* stat;
+  int32_t* prow_ptr; int32_t* pcol; uint8_t* pval; int32_t* ccol_ptr; int32_t* crow; uint8_t* cval;
+  uint8_t* snp_fp; int8_t* snp_vt; uint8_t* snp_cons; long long* snp_const; int32_t* cursor;
+  int32_t* prow_src;   // per phasing row (at r0 + k): its fragment row, region relative
+};
+// HBM image of ONE region for k4_gpost (post-phase steps with all CUs on the region)
+struct PostScratch {
+  double *sps, *rpa, *rpb; uint32_t *sflags, *soflags; int32_t *parent, *ccptr;
+  int32_t *rptr, *ecol, *erow, *cent; uint8_t* ev;
+  int8_t* tag; uint8_t *asg, *fp, *lok, *dirty; int8_t *shap, *sgt, *svt; uint8_t* rcode;
+  int32_t* pcnt; int32_t n_parts, pad_;
+  GridCtl* ctl;
+};

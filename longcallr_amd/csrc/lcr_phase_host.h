@@ -117,7 +117,7 @@ struct PhaseHost {
   const int8_t* r_haplotag = nullptr;      // results of the last run (host vectors above or pinned buffers)
   const uint8_t* r_assignment = nullptr;
   const uint32_t* r_phase_set = nullptr;
-  DevBuf d_state[36];
+  DevBuf d_state[40];
   HostBuf h_pin[11];   // pinned staging: row_ptr, col, val, links, enum state, region sizes, chain state, results, job tables, chain start
   hipStream_t side = nullptr;   // second queue: fragment matrix download + chain regions
   hipEvent_t ev_in = nullptr, ev_csr = nullptr, ev_fork = nullptr, ev_join = nullptr;
