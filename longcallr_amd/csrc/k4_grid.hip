@@ -524,9 +524,9 @@ __device__ void block_flip(SC& sc, const ChainDev& C, const ChainView& v, const 
 // ------------------------------------------------------------------------------------------------------------
 // the chain, written once for both scopes
 // ------------------------------------------------------------------------------------------------------------
-template <class SC, class Cross>
+template <class SC, class Cross, class FastRounds>
 __device__ void chain_run(SC& sc, const ChainDev& C, const RegionDev& rd, const ChainView& v, const long long* wl, const FlipLut& L,
-                          double* stage, int (*sm)[16], Cross cross, int slot) {
+                          double* stage, int (*sm)[16], Cross cross, FastRounds fast_rounds, int slot) {
   const int S = rd.S, R = rd.R;
   ordered_index(sc, v.R, v.S, v.mv.rp, v.mv.pc, v.mv.cp, nullptr, v.erow, v.cent, v.pcnt, v.n_parts, sm);
   ld_pair_table(sc, C, v);
@@ -554,6 +554,7 @@ __device__ void chain_run(SC& sc, const ChainDev& C, const RegionDev& rd, const 
     if (obj > best) { best = obj; save(); }   // `prob > largest_prob` (phase.rs:1140-1144)
     load();
   }
+  if (fast_rounds(best)) return;               // (grid scope: the rounds with device-coherent state, see below)
   for (int tidx = 0; tidx <= S / 4; tidx++) {   // phase.rs:1198-1233
     const uint64_t ctr_t = 2 * SF + (uint64_t)tidx * SF;
     const bool flip = (tidx & 1) == 1;
@@ -574,6 +575,152 @@ __device__ void chain_run(SC& sc, const ChainDev& C, const RegionDev& rd, const 
     load();
   }
   if (sc.tid() == 0) C.P.st_obj[slot] = best;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The perturbation rounds (phase.rs:1198-1233) at grid scope with DEVICE-COHERENT state.  A round is two
+// cross_optimize calls of ~6 half-step pairs each, and C5 has 1 251 rounds: the barrier count decides the run time.
+// Here the matrix (immutable) is read with plain cached loads and stays in the L2s, while everything that changes --
+// sigma as one 64-bit word per 64 rows, delta / eta as bytes -- is read and written with agent-scope relaxed atomics
+// only, so the barriers need no L2 write-back / invalidate (GridScope::sync_light).  Ownership is fixed: wave w owns
+// the 64-row groups j = w (mod #waves) and the SNPs i = w (mod #waves); save / load / perturb are owner-local and need
+// no barrier.  A half step first copies the other half's state into LDS (delta / eta bytes for the sigma step, the
+// whole sigma bit vector for the delta step).  The delta step is one wave per SNP -- sum, decision and the SNP's term
+// of the objective in one go -- so an iteration costs two barriers and the objective none.
+// Same integers as cross_optimize_scope / k4_dev.h's cross_optimize (bit-identical results, tested).
+// ------------------------------------------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ T cload(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void cstore(T* p, T x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ bool chain_rounds_fast(GridScope& sc, const ChainDev& C, const RegionDev& rd, const ChainView& v, const long long* wl,
+                                  uint8_t* dyn, long long best, int slot) {
+  const int S = rd.S, R = rd.R, lane = threadIdx.x & 63;
+  const int ng = (R + 63) >> 6;                         // 64-row groups
+  unsigned long long* wsw = C.sig_words + 2 * ((int64_t)(rd.sig_off >> 6) + slot);   // working sigma words
+  unsigned long long* bsw = wsw + ng;                   // best sigma words
+  uint32_t* s_sig = (uint32_t*)dyn;                     // LDS: sigma bits of every row
+  int8_t* s_dl = (int8_t*)(s_sig + 2 * ng); int8_t* s_et = s_dl + S;
+  const int32_t* rp = v.mv.rp; const int32_t* pc = v.mv.pc; const uint8_t* pv = v.mv.pv;
+  const int32_t* cp = v.mv.cp; const int32_t* cr = v.mv.cr; const uint8_t* cv = v.mv.cv;
+  const uint8_t* fp = v.mv.fp;
+  const long long* scn = C.P.snp_const + 4ll * rd.snp_off;
+  const PhaseLutDev& lut = C.P.lut;
+  const int w0 = sc.wave(), nw = sc.nwaves();
+  // ---- the byte state of the generic steps (best == working) into words
+  sc.sync();   // (fenced: the byte arrays were written with plain stores by other workgroups)
+  for (int j = w0; j < ng; j += nw) {
+    const int row = 64 * j + lane;
+    const unsigned long long word = __ballot(row < R && v.bsg[row] == 1);
+    if (lane == 0) { cstore(&wsw[j], word); cstore(&bsw[j], word); }
+  }
+  sc.sync();   // (fenced: the byte arrays were written with plain stores)
+  auto cross = [&]() -> long long {   // cross_optimize(keep_conserved = false, with_genotype = false)
+    bool hg_inc = true, h_inc = true;
+    int iters = 0;
+    long long obj = 0;
+    while (hg_inc | h_inc) {
+      // ---- sigma step: delta / eta of every SNP from LDS
+      for (int i = threadIdx.x; i < S; i += blockDim.x) { s_dl[i] = cload(&v.dl[i]); s_et[i] = cload(&v.et[i]); }
+      __syncthreads();
+      int any = 0;
+      for (int j = w0; j < ng; j += nw) {
+        const int row = 64 * j + lane;
+        const unsigned long long word = cload(&wsw[j]);
+        const int s = ((word >> lane) & 1ull) ? 1 : -1;
+        long long diff = 0;
+        if (row < R)
+          for (int e = rp[row]; e < rp[row + 1]; e++) {
+            const int i = pc[e];
+            const uint8_t x = pv[e];
+            if (s_et[i] == 0) { const long long w = wl[x & 31]; diff += (((x & 32) ? 1 : -1) == s * s_dl[i]) ? w : -w; }
+          }
+        const bool flip = row < R && diff < 0;
+        const unsigned long long nword = __ballot(row < R && (flip ? -s : s) == 1);
+        if (flip) any = 1;
+        if (lane == 0 && nword != word) cstore(&wsw[j], nword);
+      }
+      any = sc.sync_or_light(any);
+      if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
+      // ---- delta / eta step: one wave per SNP, sigma bits of every row from LDS
+      for (int j = threadIdx.x; j < ng; j += blockDim.x) { const unsigned long long word = cload(&wsw[j]); s_sig[2 * j] = (uint32_t)word; s_sig[2 * j + 1] = (uint32_t)(word >> 32); }
+      __syncthreads();
+      any = 0;
+      long long acc = 0;
+      for (int i = w0; i < S; i += nw) {
+        const int c0 = cp[i], c1 = cp[i + 1];
+        if (c0 == c1) continue;
+        const int d = s_dl[i], h = s_et[i];
+        long long M = 0;   // sum of w over the entries with p == sigma * d
+        for (int e = c0 + lane; e < c1; e += 64) {
+          const uint8_t x = cv[e];
+          const int row = cr[e];
+          const int s = ((s_sig[row >> 5] >> (row & 31)) & 1u) ? 1 : -1;
+          if (((x & 32) ? 1 : -1) == s * d) M += wl[x & 31];
+        }
+        M = wave_sum_ll_dpp(M);
+        if (lane == 0) {
+          const long long F = scn[4 * i], Wt = scn[4 * i + 1];
+          const long long D[4] = {F + M, F + Wt - M, scn[4 * i + 2], scn[4 * i + 3]};   // data terms of (d,0) (-d,0) (d,+1) (d,-1)
+          const int cur = h == 0 ? 0 : (h == 1 ? 2 : 3);
+          int ch = cur;
+          if (fp[i]) {
+            const long long het = lut.f_het0 - (long long)(c1 - c0) * lut.f_log2;
+            const long long N[4] = {D[0] + het, D[1] + het, D[2] + lut.f_homref, D[3] + lut.f_homvar};
+            if (h == 0) ch = N[1] > N[0] ? 1 : 0; else ch = N[3] > N[2] ? 3 : 2;
+            if (N[ch] > N[cur]) any = 1;
+            if (ch == 1) cstore(&v.dl[i], (int8_t)(-d));   // (with_genotype is false: a het site stays het, a hom site
+            if (ch >= 2 && ch != cur) cstore(&v.et[i], (int8_t)(ch == 2 ? 1 : -1));   //  may change between homref and homvar)
+          }
+          acc += D[ch];
+        }
+      }
+      any = sc.sync_or_sum_light(any, acc, &obj);
+      if (!any) hg_inc = false; else { hg_inc = true; h_inc = true; }
+      if (++iters > 20) break;
+    }
+    return obj;   // = f_total + sum of w over the hits: every phase entry lies in exactly one column
+  };
+  auto save = [&]() {
+    for (int j = w0; j < ng; j += nw) if (lane == 0) cstore(&bsw[j], cload(&wsw[j]));
+    for (int i = w0; i < S; i += nw) if (lane == 0) { cstore(&v.bdl[i], cload(&v.dl[i])); cstore(&v.bet[i], cload(&v.et[i])); }
+  };
+  auto load = [&]() {
+    for (int j = w0; j < ng; j += nw) if (lane == 0) cstore(&wsw[j], cload(&bsw[j]));
+    for (int i = w0; i < S; i += nw) if (lane == 0) { cstore(&v.dl[i], cload(&v.bdl[i])); cstore(&v.et[i], cload(&v.bet[i])); }
+  };
+  const uint64_t SF = (uint64_t)S + (uint64_t)R;
+  for (int tidx = 0; tidx <= S / 4; tidx++) {
+    const uint64_t ctr_t = 2 * SF + (uint64_t)tidx * SF;
+    const bool flip = (tidx & 1) == 1;
+    for (int i = w0; i < S; i += nw)
+      if (lane == 0) {
+        const double rg = u01(rd.seed, ctr_t + i);
+        if (rg < 0.1) cstore(&v.dl[i], (int8_t)(flip ? 1 : -1));
+        else if (rg >= 0.9) cstore(&v.dl[i], (int8_t)(flip ? -1 : 1));
+      }
+    sc.sync_light();
+    long long obj = cross();
+    if (obj > best) { best = obj; save(); }
+    load();
+    for (int j = w0; j < ng; j += nw) {
+      const int row = 64 * j + lane;
+      const unsigned long long word = cload(&wsw[j]);
+      const unsigned long long fm = __ballot(row < R && u01(rd.seed, ctr_t + S + row) < 0.1);
+      if (lane == 0 && fm) cstore(&wsw[j], word ^ fm);
+    }
+    sc.sync_light();
+    obj = cross();
+    if (obj > best) { best = obj; save(); }
+    load();
+  }
+  // ---- result: best sigma words back to bytes (delta / eta best arrays are up to date)
+  for (int j = w0; j < ng; j += nw) {
+    const int row = 64 * j + lane;
+    const unsigned long long word = cload(&bsw[j]);
+    if (row < R) v.bsg[row] = ((word >> lane) & 1ull) ? 1 : -1;
+  }
+  if (sc.tid() == 0) C.P.st_obj[slot] = best;
+  return true;
 }
 
 __device__ __forceinline__ void load_flip_lut(const ChainDev& C, FlipLut* L) {
@@ -611,13 +758,13 @@ __global__ void __launch_bounds__(CH_THREADS) k4_chain_wg(ChainDev C, int32_t fi
     }
     return cross_optimize(C.P, rd, mvl, v.sg, v.dl, v.et, keep_conserved, with_genotype, red, wl, macc);
   };
-  chain_run(sc, C, rd, v, wl, L, stage, sm, cross, d.slot);
+  chain_run(sc, C, rd, v, wl, L, stage, sm, cross, [](long long) { return false; }, d.slot);
 }
 
 // all workgroups of the launch on one region (desc[which])
 __global__ void __launch_bounds__(CH_THREADS) k4_chain_grid(ChainDev C, int32_t which) {
   __shared__ long long red[CH_WAVES];
-  __shared__ unsigned long long bc;
+  __shared__ unsigned long long bc[2];
   __shared__ long long wl[32];
   __shared__ FlipLut L;
   __shared__ int sm[2][16];
@@ -627,7 +774,7 @@ __global__ void __launch_bounds__(CH_THREADS) k4_chain_grid(ChainDev C, int32_t 
   const ChainDesc d = C.desc[which];
   const RegionDev rd = C.P.reg[d.slot];
   const ChainView v = make_view(C, d, rd);
-  GridScope sc{C.ctl, red, &bc, 0u};
+  GridScope sc{C.ctl, red, bc, 0u};
   unsigned long long* macc = C.macc + rd.snp_off;
   for (int i = sc.tid(); i < rd.S; i += sc.nt()) macc[i] = 0;
   // this thread's fixed run of CSC entries and the column its first entry lies in
@@ -640,7 +787,12 @@ __global__ void __launch_bounds__(CH_THREADS) k4_chain_grid(ChainDev C, int32_t 
   auto cross = [&](bool keep_conserved, bool with_genotype) -> long long {
     return cross_optimize_scope(sc, C.P, rd, v, keep_conserved, with_genotype, wl, macc, e0, e1, i_first);
   };
-  chain_run(sc, C, rd, v, wl, L, stage, sm, cross, d.slot);
+  extern __shared__ __attribute__((aligned(16))) uint8_t dyn_fast[];
+  auto fast_rounds = [&](long long best) -> bool {
+    if (!d.fast_lds) return false;
+    return chain_rounds_fast(sc, C, rd, v, wl, dyn_fast, best, d.slot);
+  };
+  chain_run(sc, C, rd, v, wl, L, stage, sm, cross, fast_rounds, d.slot);
 }
 
 
@@ -652,11 +804,11 @@ __global__ void __launch_bounds__(CH_THREADS) k4_chain_grid(ChainDev C, int32_t 
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(CH_THREADS) k4_stage_grid(StageIn in, StageOut out, PhaseLutDev lut, int32_t g, GridCtl* ctl, int32_t* blk_tot) {
   __shared__ long long red[CH_WAVES];
-  __shared__ unsigned long long bc;
+  __shared__ unsigned long long bc[2];
   __shared__ int sm[2][16];
   __shared__ int s_sum[5];
   __shared__ long long s_fe[32], s_f1e[32];
-  GridScope sc{ctl, red, &bc, 0u};
+  GridScope sc{ctl, red, bc, 0u};
   const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x, nb = gridDim.x;
   const int r0 = in.row_region_off[g], nrow = in.row_region_off[g + 1] - r0;
   const int c0 = in.cand_off[g], S = in.cand_off[g + 1] - c0;
@@ -781,11 +933,11 @@ __global__ void __launch_bounds__(CH_THREADS) k4_stage_grid(StageIn in, StageOut
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(CH_THREADS) k4_gpost(PostIn in, PostScratch ps, int32_t g, PostLut lut) {
   __shared__ long long red[CH_WAVES];
-  __shared__ unsigned long long bc;
+  __shared__ unsigned long long bc[2];
   __shared__ int sm[2][16];
   __shared__ double s_lut[64];
   __shared__ double stage[CH_WAVES * 4 * POST_SSTR];
-  GridScope sc{ps.ctl, red, &bc, 0u};
+  GridScope sc{ps.ctl, red, bc, 0u};
   const int r0 = in.row_region_off[g], nrow = in.row_region_off[g + 1] - r0;
   const int c0 = in.cand_off[g], S = in.cand_off[g + 1] - c0;
   const int64_t e_base = in.row_ptr[r0];
@@ -847,12 +999,14 @@ int k4_grid_blocks() {
   return blocks;
 }
 
-hipError_t k4_chain_launch_grid(const ChainDev& C, int which, hipStream_t s) {
+hipError_t k4_chain_launch_grid(const ChainDev& C, int which, size_t dyn_lds, hipStream_t s) {
   const int nb = k4_grid_blocks();
   if (nb <= 0) return hipErrorInvalidDevice;
   hipError_t e = hipMemsetAsync(C.ctl, 0, sizeof(GridCtl), s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k4_chain_grid, dim3((unsigned)nb), dim3(CH_THREADS), 0, s, C, (int32_t)which);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_chain_grid), hipFuncAttributeMaxDynamicSharedMemorySize, K4_GRID_FAST_LDS_MAX);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k4_chain_grid, dim3((unsigned)nb), dim3(CH_THREADS), dyn_lds, s, C, (int32_t)which);
   return hipGetLastError();
 }
 

@@ -1269,7 +1269,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       const int g = k < n_small ? small[k] : big[k - n_small];
       const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
       ChainDesc& d = desc[k];
-      d.slot = g; d.W = std::max(1, std::min(stat[g].W, S)); d.pad_ = 0;
+      d.slot = g; d.W = std::max(1, std::min(stat[g].W, S)); d.fast_lds = 0;
+      if (k >= n_small && !getenv("LCR_GRID_GENERIC")) { const size_t need = k4_grid_fast_lds(stat[g].R, S); if (need <= (size_t)K4_GRID_FAST_LDS_MAX) d.fast_lds = (int32_t)need; }
       d.tbl_off = tbl_cells; tbl_cells += (int64_t)S * d.W;
       d.adj_off = adj_n; adj_n += 2 * (int64_t)S * d.W;
       d.n_parts = k < n_small ? 16 : (int32_t)std::max<int64_t>(16, std::min<int64_t>(grid_waves, (int64_t)(1 << 23) / S));
@@ -1289,7 +1290,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     const size_t ni = nc1 + (size_t)ng + 1;   // per-SNP int32 arrays: adj_ptr, blk_ptr (ni each), blk_of, blk_pos, blk_nodes, queue (nc1), stack (2 nc1)
     PCHK(b_snpi.reserve((2 * ni + 6 * nc1) * 4 + 64)); PCHK(b_snpb.reserve(3 * nc1 + 64)); PCHK(b_q.reserve(2 * nc1 * 8 + 64));
     PCHK(b_info.reserve((size_t)std::max(ng, 1) * 8 + 64)); PCHK(b_rowi.reserve(nr1 * 4 + 64)); PCHK(b_enti.reserve(2 * nnz1 * 4 + 64));
-    PCHK(b_work.reserve(st_bytes + 64)); PCHK(b_macc.reserve(nc1 * 8 + 64)); PCHK(b_ctl.reserve(4 * sizeof(GridCtl)));
+    PCHK(b_work.reserve(st_bytes + 64)); PCHK(b_macc.reserve(nc1 * 8 + 64)); PCHK(d_state[39].reserve((2 * (nr1 / 64 + (size_t)ng + 2)) * 8 + 64)); PCHK(b_ctl.reserve(4 * sizeof(GridCtl)));
     ChainDev C{};
     const int32_t stride = (max_state + 63) & ~63;
     Pc.scratch = nullptr; Pc.scratch_stride = stride;
@@ -1317,7 +1318,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     C.blk_info = b_info.as<int32_t>();
     C.flipcol = b_rowi.as<int32_t>(); C.erow = b_enti.as<int32_t>(); C.cent = C.erow + nnz1;
     C.w_sigma = b_work.as<int8_t>() + st_sig; C.w_delta = b_work.as<int8_t>() + st_del; C.w_eta = b_work.as<int8_t>() + st_eta;
-    C.macc = b_macc.as<unsigned long long>(); C.ctl = b_ctl.as<GridCtl>();
+    C.macc = b_macc.as<unsigned long long>(); C.ctl = b_ctl.as<GridCtl>(); C.sig_words = d_state[39].as<unsigned long long>();
     for (int q = 0; q < 31; q++) { C.le[q] = L.le[q]; C.l1e[q] = L.l1e[q]; }
     C.p_homref = L.p_homref; C.p_homvar = L.p_homvar; C.log_theta = L.log_theta; C.log2 = L.log2;
     chain_dev = C; chain_desc = desc;   // (lcr_get_ld_blocks reads the blocks back)
@@ -1326,7 +1327,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     if (nps) PCHK(hipMemcpyAsync(b_slots.p, h_pin[10].as<uint8_t>() + desc_bytes, nps * 4, hipMemcpyHostToDevice, side));
     PCHK(k4_chain_launch_wg(C, 0, n_small, dyn_state + (size_t)Pc.lds_mat, side));
     if (n_big) grid_lock.acquire();
-    for (int k = 0; k < n_big; k++) PCHK(k4_chain_launch_grid(C, n_small + k, side));
+    for (int k = 0; k < n_big; k++) PCHK(k4_chain_launch_grid(C, n_small + k, (size_t)desc[n_small + k].fast_lds, side));
     if (nps) {
       PostIn pinc = pin;
       pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta; pinc.st_obj = Pc.st_obj;

@@ -39,7 +39,8 @@ struct ChainDesc {
   int64_t tbl_off;     // pair table of the region: S x W cells of {cis, trans} u32 counters, offset in cells
   int64_t adj_off;     // adjacency lists (<= 2 S W entries), offset in entries
   int64_t part_off;    // per (row part, SNP) counters of the ordered column index, offset in int32
-  int32_t n_parts, pad_;
+  int32_t n_parts;
+  int32_t fast_lds;    // grid scope: bytes of dynamic LDS for the device-coherent perturbation rounds (0: generic path)
 };
 struct GridCtl { unsigned arrive, gen, flag[2]; unsigned long long acc[2]; int slot; unsigned pad_[7]; };   // grid barrier + reductions
 struct ChainDev {
@@ -59,6 +60,7 @@ struct ChainDev {
   int32_t* flipcol; int32_t* erow; int32_t* cent;
   // working state of the grid path (global memory; the one-workgroup path keeps it in LDS)
   int8_t* w_sigma; int8_t* w_delta; int8_t* w_eta; unsigned long long* macc;
+  unsigned long long* sig_words;  // grid scope: sigma as bit vectors, 2 x ceil(R / 64) words per region at 2 * (sig_off / 64 + region)
   GridCtl* ctl;
   double le[31], l1e[31], p_homref, p_homvar, log_theta, log2;   // libm values of the block-flip sums (host table)
 };
