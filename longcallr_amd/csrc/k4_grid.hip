@@ -300,7 +300,7 @@ __device__ void ld_seed_wave(const ChainView& v) {
 // cross_optimize at grid scope (phase.rs:810-976): the arithmetic of k4_dev.h's cross_optimize with the state in
 // HBM; the per-SNP sums are entry-balanced (a thread owns a fixed run of CSC entries for the whole launch).
 // ------------------------------------------------------------------------------------------------------------
-__device__ long long cross_optimize_scope(GridScope& sc, const PhaseDev& P, const RegionDev& rd, const ChainView& v, bool keep_conserved,
+__device__ __forceinline__ long long cross_optimize_scope(GridScope& sc, const PhaseDev& P, const RegionDev& rd, const ChainView& v, bool keep_conserved,
                                           bool with_genotype, const long long* wl, unsigned long long* macc, int e0, int e1, int i_first) {
   const int32_t* rp = v.mv.rp; const int32_t* pc = v.mv.pc; const uint8_t* pv = v.mv.pv;
   const int32_t* cp = v.mv.cp; const int32_t* cr = v.mv.cr; const uint8_t* cv = v.mv.cv;
@@ -525,12 +525,18 @@ __device__ void block_flip(SC& sc, const ChainDev& C, const ChainView& v, const 
 // the chain, written once for both scopes
 // ------------------------------------------------------------------------------------------------------------
 template <class SC, class Cross, class FastRounds>
-__device__ void chain_run(SC& sc, const ChainDev& C, const RegionDev& rd, const ChainView& v, const long long* wl, const FlipLut& L,
+__device__ __forceinline__ void chain_run(SC& sc, const ChainDev& C, const RegionDev& rd, const ChainView& v, const long long* wl, const FlipLut& L,
                           double* stage, int (*sm)[16], Cross cross, FastRounds fast_rounds, int slot) {
   const int S = rd.S, R = rd.R;
+  int n_mark = 0;
+  auto mark = [&]() { if (C.dbg && sc.nblk() > 1 && sc.tid() == 0) C.dbg[n_mark] = (long long)wall_clock64(); n_mark++; };
+  mark();
   ordered_index(sc, v.R, v.S, v.mv.rp, v.mv.pc, v.mv.cp, nullptr, v.erow, v.cent, v.pcnt, v.n_parts, sm);
+  mark();
   ld_pair_table(sc, C, v);
+  mark();
   ld_graph(sc, v, sm);
+  mark();
   // start state (phase.rs:1124-1131): random delta (draws S+F ..), genotype from the variant type, random sigma
   const uint64_t SF = (uint64_t)S + (uint64_t)R;
   for (int i = sc.tid(); i < S; i += sc.nt()) { v.dl[i] = u01(rd.seed, SF + i) < 0.5 ? 1 : -1; v.et[i] = init_genotype(v.vt[i]); }
@@ -538,7 +544,9 @@ __device__ void chain_run(SC& sc, const ChainDev& C, const RegionDev& rd, const 
   sc.sync();
   if (sc.blk() == 0 && (threadIdx.x >> 6) == 0) { ld_components_wave(v); ld_seed_wave(v); }
   sc.sync();
+  mark();
   long long best = cross(true, false);
+  mark();
   auto save = [&]() {
     for (int i = sc.tid(); i < S; i += sc.nt()) { v.bdl[i] = v.dl[i]; v.bet[i] = v.et[i]; }
     for (int row = sc.tid(); row < R; row += sc.nt()) v.bsg[row] = v.sg[row];
@@ -554,7 +562,8 @@ __device__ void chain_run(SC& sc, const ChainDev& C, const RegionDev& rd, const 
     if (obj > best) { best = obj; save(); }   // `prob > largest_prob` (phase.rs:1140-1144)
     load();
   }
-  if (fast_rounds(best)) return;               // (grid scope: the rounds with device-coherent state, see below)
+  mark();
+  if (fast_rounds(best)) { mark(); return; }   // (grid scope: the rounds with device-coherent state, see below)
   for (int tidx = 0; tidx <= S / 4; tidx++) {   // phase.rs:1198-1233
     const uint64_t ctr_t = 2 * SF + (uint64_t)tidx * SF;
     const bool flip = (tidx & 1) == 1;
@@ -592,7 +601,7 @@ __device__ void chain_run(SC& sc, const ChainDev& C, const RegionDev& rd, const 
 template <class T> __device__ __forceinline__ T cload(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> __device__ __forceinline__ void cstore(T* p, T x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ bool chain_rounds_fast(GridScope& sc, const ChainDev& C, const RegionDev& rd, const ChainView& v, const long long* wl,
+__device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev& C, const RegionDev& rd, const ChainView& v, const long long* wl,
                                   uint8_t* dyn, long long best, int slot) {
   const int S = rd.S, R = rd.R, lane = threadIdx.x & 63;
   const int ng = (R + 63) >> 6;                         // 64-row groups
@@ -606,9 +615,15 @@ __device__ bool chain_rounds_fast(GridScope& sc, const ChainDev& C, const Region
   const long long* scn = C.P.snp_const + 4ll * rd.snp_off;
   const PhaseLutDev& lut = C.P.lut;
   const int w0 = sc.wave(), nw = sc.nwaves();
+  // row groups / SNPs of one workgroup lie far apart (neighbouring rows and columns are equally long: a workgroup that
+  // owned a run of them would be the slowest or the fastest of every half step)
+  const int wj0 = (int)(threadIdx.x >> 6) * sc.nblk() + sc.blk();
+  __shared__ unsigned long long t_sum[4][8];   // delta step: partial sums / arrivals of the four-wave teams
+  __shared__ unsigned t_cnt[4][8];
+  if (threadIdx.x < 32) { t_sum[threadIdx.x >> 3][threadIdx.x & 7] = 0; t_cnt[threadIdx.x >> 3][threadIdx.x & 7] = 0; }
   // ---- the byte state of the generic steps (best == working) into words
   sc.sync();   // (fenced: the byte arrays were written with plain stores by other workgroups)
-  for (int j = w0; j < ng; j += nw) {
+  for (int j = wj0; j < ng; j += nw) {
     const int row = 64 * j + lane;
     const unsigned long long word = __ballot(row < R && v.bsg[row] == 1);
     if (lane == 0) { cstore(&wsw[j], word); cstore(&bsw[j], word); }
@@ -620,72 +635,150 @@ __device__ bool chain_rounds_fast(GridScope& sc, const ChainDev& C, const Region
     long long obj = 0;
     while (hg_inc | h_inc) {
       // ---- sigma step: delta / eta of every SNP from LDS
+      long long tk0 = 0;
+      const bool tk = C.dbg && sc.tid() == 0;
+      auto tick = [&](int slot_) { if (tk) { const long long t = (long long)wall_clock64(); C.dbg[slot_] += t - tk0; tk0 = t; } };
+      if (tk) tk0 = (long long)wall_clock64();
       for (int i = threadIdx.x; i < S; i += blockDim.x) { s_dl[i] = cload(&v.dl[i]); s_et[i] = cload(&v.et[i]); }
       __syncthreads();
+      tick(8);
       int any = 0;
-      for (int j = w0; j < ng; j += nw) {
-        const int row = 64 * j + lane;
+      for (int j = wj0; j < ng; j += nw) {
+        // sixteen lanes per row, four rows per pass: a row's entries are one coalesced load (thread-per-row would touch
+        // every cache line of the group once per entry)
         const unsigned long long word = cload(&wsw[j]);
-        const int s = ((word >> lane) & 1ull) ? 1 : -1;
-        long long diff = 0;
-        if (row < R)
-          for (int e = rp[row]; e < rp[row + 1]; e++) {
-            const int i = pc[e];
-            const uint8_t x = pv[e];
-            if (s_et[i] == 0) { const long long w = wl[x & 31]; diff += (((x & 32) ? 1 : -1) == s * s_dl[i]) ? w : -w; }
+        const int rl = min(64 * j + lane, R);
+        const int my_b = rp[rl], my_e = rp[min(rl + 1, R)];          // lane <-> row of the group (empty past R)
+        unsigned long long nword = word;
+        const int sub = lane & 15, rsel = lane >> 4;
+        // pass q works on rows 4q .. 4q+3 of the group; eight passes at a time, the first 32 entries of each of their rows
+        // are loaded before anything is used (32 independent loads in flight per lane), longer rows finish in a tail loop
+#pragma unroll 1
+        for (int q0 = 0; q0 < 16; q0 += 8) {
+          int pi[8][2]; uint8_t px[8][2];
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const int rr = 4 * (q0 + q) + rsel;
+            const int eb = __shfl(my_b, rr, 64), ee = __shfl(my_e, rr, 64);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+              const int e = eb + sub + 16 * u;
+              const bool ok = e < ee;
+              pi[q][u] = ok ? pc[e] : -1;
+              px[q][u] = ok ? pv[e] : (uint8_t)0;
+            }
           }
-        const bool flip = row < R && diff < 0;
-        const unsigned long long nword = __ballot(row < R && (flip ? -s : s) == 1);
-        if (flip) any = 1;
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const int rr = 4 * (q0 + q) + rsel;
+            const int s = ((word >> rr) & 1ull) ? 1 : -1;
+            long long diff = 0;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+              const int i = pi[q][u];
+              if (i >= 0 && s_et[i] == 0) { const long long w = wl[px[q][u] & 31]; diff += (((px[q][u] & 32) ? 1 : -1) == s * s_dl[i]) ? w : -w; }
+            }
+            const int ee = __shfl(my_e, rr, 64);
+            for (int e = __shfl(my_b, rr, 64) + sub + 32; e < ee; e += 16) {
+              const int i = pc[e];
+              const uint8_t x = pv[e];
+              if (s_et[i] == 0) { const long long w = wl[x & 31]; diff += (((x & 32) ? 1 : -1) == s * s_dl[i]) ? w : -w; }
+            }
+            diff += LCR_DPP_LL(diff, 0x111, 0xf);   // sum over the 16 lanes of the DPP row (row_shr 1, 2, 4, 8)
+            diff += LCR_DPP_LL(diff, 0x112, 0xf);
+            diff += LCR_DPP_LL(diff, 0x114, 0xf);
+            diff += LCR_DPP_LL(diff, 0x118, 0xf);
+            const unsigned long long fb = __ballot(sub == 15 && diff < 0);   // lane 15 of each row holds the row's sum
+            if (fb) {
+              any = 1;
+#pragma unroll
+              for (int t = 0; t < 4; t++) if ((fb >> (16 * t + 15)) & 1ull) nword ^= 1ull << (4 * (q0 + q) + t);
+            }
+          }
+        }
         if (lane == 0 && nword != word) cstore(&wsw[j], nword);
       }
+      __syncthreads();
+      tick(9);
       any = sc.sync_or_light(any);
+      tick(10);
       if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
       // ---- delta / eta step: one wave per SNP, sigma bits of every row from LDS
       for (int j = threadIdx.x; j < ng; j += blockDim.x) { const unsigned long long word = cload(&wsw[j]); s_sig[2 * j] = (uint32_t)word; s_sig[2 * j + 1] = (uint32_t)(word >> 32); }
       __syncthreads();
+      tick(11);
       any = 0;
       long long acc = 0;
-      for (int i = w0; i < S; i += nw) {
-        const int c0 = cp[i], c1 = cp[i + 1];
-        if (c0 == c1) continue;
-        const int d = s_dl[i], h = s_et[i];
-        long long M = 0;   // sum of w over the entries with p == sigma * d
-        for (int e = c0 + lane; e < c1; e += 64) {
-          const uint8_t x = cv[e];
-          const int row = cr[e];
-          const int s = ((s_sig[row >> 5] >> (row & 31)) & 1u) ? 1 : -1;
-          if (((x & 32) ? 1 : -1) == s * d) M += wl[x & 31];
-        }
-        M = wave_sum_ll_dpp(M);
-        if (lane == 0) {
-          const long long F = scn[4 * i], Wt = scn[4 * i + 1];
-          const long long D[4] = {F + M, F + Wt - M, scn[4 * i + 2], scn[4 * i + 3]};   // data terms of (d,0) (-d,0) (d,+1) (d,-1)
-          const int cur = h == 0 ? 0 : (h == 1 ? 2 : 3);
-          int ch = cur;
-          if (fp[i]) {
-            const long long het = lut.f_het0 - (long long)(c1 - c0) * lut.f_log2;
-            const long long N[4] = {D[0] + het, D[1] + het, D[2] + lut.f_homref, D[3] + lut.f_homvar};
-            if (h == 0) ch = N[1] > N[0] ? 1 : 0; else ch = N[3] > N[2] ? 3 : 2;
-            if (N[ch] > N[cur]) any = 1;
-            if (ch == 1) cstore(&v.dl[i], (int8_t)(-d));   // (with_genotype is false: a het site stays het, a hom site
-            if (ch >= 2 && ch != cur) cstore(&v.et[i], (int8_t)(ch == 2 ? 1 : -1));   //  may change between homref and homvar)
+      // a team of four waves per SNP (a wave per SNP leaves the largest column as the critical path); the waves' partial
+      // sums meet in LDS and the last one to arrive decides -- no barrier inside the loop
+      {
+        const int team = threadIdx.x >> 8, wt = (threadIdx.x >> 6) & 3, nteams = sc.nblk() * 4, gteam = team * sc.nblk() + sc.blk();
+        int it = 0;
+        for (int base = 0; base < S; base += nteams, it++) {
+          if ((it & 7) == 0 && it) __syncthreads();   // the ring of 8 slots per team wraps (uniform trip count)
+          const int i = base + gteam;
+          if (i >= S) continue;
+          const int c0 = cp[i], c1 = cp[i + 1];
+          if (c0 == c1) continue;
+          const int d = s_dl[i], h = s_et[i];
+          long long M = 0;   // sum of w over the entries with p == sigma * d
+          for (int e = c0 + 64 * wt + lane; e < c1; e += 1024) {   // four independent loads in flight per lane
+            uint8_t x[4]; int row[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int eu = min(e + 256 * u, c1 - 1); x[u] = cv[eu]; row[u] = cr[eu]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int s = ((s_sig[row[u] >> 5] >> (row[u] & 31)) & 1u) ? 1 : -1;
+              if (e + 256 * u < c1 && ((x[u] & 32) ? 1 : -1) == s * d) M += wl[x[u] & 31];
+            }
           }
-          acc += D[ch];
+          M = wave_sum_ll_dpp(M);
+          if (lane == 0) {
+            unsigned long long* ts = &t_sum[team][it & 7];
+            unsigned* tc = &t_cnt[team][it & 7];
+            __hip_atomic_fetch_add(ts, (unsigned long long)M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned arrived = __hip_atomic_fetch_add(tc, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (arrived == 3) {
+              M = (long long)__hip_atomic_load(ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_store(ts, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_store(tc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              const long long F = scn[4 * i], Wt = scn[4 * i + 1];
+              // data terms of (d,0) (-d,0) (d,+1) (d,-1); with_genotype is false: a het site stays het (it may flip), a hom
+              // site may change between homref and homvar.  The priors are equal inside a class, so the data terms decide.
+              const long long D0 = F + M, D1 = F + Wt - M, D2 = scn[4 * i + 2], D3 = scn[4 * i + 3];
+              long long chosen = h == 0 ? D0 : (h == 1 ? D2 : D3);
+              if (fp[i]) {
+                if (h == 0) { if (D1 > D0) { chosen = D1; any = 1; cstore(&v.dl[i], (int8_t)(-d)); } }
+                else {
+                  const long long n2 = D2 + lut.f_homref, n3 = D3 + lut.f_homvar;
+                  const bool to3 = n3 > n2;                       // first maximum wins: homref on a tie
+                  const long long ncur = h == 1 ? n2 : n3, nch = to3 ? n3 : n2;
+                  if (nch > ncur) any = 1;
+                  if (to3 != (h == -1)) cstore(&v.et[i], (int8_t)(to3 ? -1 : 1));
+                  chosen = to3 ? D3 : D2;
+                }
+              }
+              acc += chosen;
+            }
+          }
         }
       }
+      __syncthreads();
+      tick(12);
       any = sc.sync_or_sum_light(any, acc, &obj);
+      tick(13);
       if (!any) hg_inc = false; else { hg_inc = true; h_inc = true; }
       if (++iters > 20) break;
     }
+    if (C.dbg && sc.tid() == 0) C.dbg[15] += iters;
     return obj;   // = f_total + sum of w over the hits: every phase entry lies in exactly one column
   };
   auto save = [&]() {
-    for (int j = w0; j < ng; j += nw) if (lane == 0) cstore(&bsw[j], cload(&wsw[j]));
+    for (int j = wj0; j < ng; j += nw) if (lane == 0) cstore(&bsw[j], cload(&wsw[j]));
     for (int i = w0; i < S; i += nw) if (lane == 0) { cstore(&v.bdl[i], cload(&v.dl[i])); cstore(&v.bet[i], cload(&v.et[i])); }
   };
   auto load = [&]() {
-    for (int j = w0; j < ng; j += nw) if (lane == 0) cstore(&wsw[j], cload(&bsw[j]));
+    for (int j = wj0; j < ng; j += nw) if (lane == 0) cstore(&wsw[j], cload(&bsw[j]));
     for (int i = w0; i < S; i += nw) if (lane == 0) { cstore(&v.dl[i], cload(&v.bdl[i])); cstore(&v.et[i], cload(&v.bet[i])); }
   };
   const uint64_t SF = (uint64_t)S + (uint64_t)R;
@@ -702,7 +795,7 @@ __device__ bool chain_rounds_fast(GridScope& sc, const ChainDev& C, const Region
     long long obj = cross();
     if (obj > best) { best = obj; save(); }
     load();
-    for (int j = w0; j < ng; j += nw) {
+    for (int j = wj0; j < ng; j += nw) {
       const int row = 64 * j + lane;
       const unsigned long long word = cload(&wsw[j]);
       const unsigned long long fm = __ballot(row < R && u01(rd.seed, ctr_t + S + row) < 0.1);
@@ -714,7 +807,7 @@ __device__ bool chain_rounds_fast(GridScope& sc, const ChainDev& C, const Region
     load();
   }
   // ---- result: best sigma words back to bytes (delta / eta best arrays are up to date)
-  for (int j = w0; j < ng; j += nw) {
+  for (int j = wj0; j < ng; j += nw) {
     const int row = 64 * j + lane;
     const unsigned long long word = cload(&bsw[j]);
     if (row < R) v.bsg[row] = ((word >> lane) & 1ull) ? 1 : -1;

@@ -1166,7 +1166,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   PostIn pin{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, const_cast<lcr_candidate*>(in.d_cand), in.d_cand_off,
              in.d_row_region_off, in.d_start0, P.st_sigma, P.st_delta, P.st_eta, (int8_t*)(d_res + res_tag), d_res + res_asg,
              (uint32_t*)(d_res + res_ps), P.st_obj, (long long*)(d_hc + hc_obj), (lcr_candidate*)d_hc, prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr, P.reg, b_psrc.as<int32_t>()};
-  if (prof) { PCHK(d_state[20].reserve((size_t)std::max(ng, 1) * 16 * 8)); PCHK(hipMemsetAsync(d_state[20].p, 0, (size_t)std::max(ng, 1) * 16 * 8, stream)); pin.dbg_clk = d_state[20].as<long long>(); }
+  if (prof) { PCHK(d_state[20].reserve((size_t)(ng + 1) * 16 * 8)); PCHK(hipMemsetAsync(d_state[20].p, 0, (size_t)(ng + 1) * 16 * 8, stream)); pin.dbg_clk = d_state[20].as<long long>(); }
 
   // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
   if (!enum_slots.empty()) {
@@ -1321,6 +1321,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     C.macc = b_macc.as<unsigned long long>(); C.ctl = b_ctl.as<GridCtl>(); C.sig_words = d_state[39].as<unsigned long long>();
     for (int q = 0; q < 31; q++) { C.le[q] = L.le[q]; C.l1e[q] = L.l1e[q]; }
     C.p_homref = L.p_homref; C.p_homvar = L.p_homvar; C.log_theta = L.log_theta; C.log2 = L.log2;
+    if (prof && n_big) { C.dbg = d_state[20].as<long long>() + (size_t)ng * 16; PCHK(hipMemsetAsync(C.dbg, 0, 16 * 8, side)); }
     chain_dev = C; chain_desc = desc;   // (lcr_get_ld_blocks reads the blocks back)
     PCHK(hipStreamWaitEvent(side, ev_csr, 0));
     PCHK(hipMemcpyAsync(b_desc.p, h_pin[10].p, (size_t)nc * sizeof(ChainDesc), hipMemcpyHostToDevice, side));
@@ -1374,6 +1375,15 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   lap("chain launch");
   PCHK(hipStreamSynchronize(side));
   lap("chain kernels");
+  if (prof && chain_dev.dbg && !chain_desc.empty()) {   // steps of the last grid-scope chain launch
+    long long clk[16];
+    PCHK(hipMemcpy(clk, chain_dev.dbg, sizeof(clk), hipMemcpyDeviceToHost));
+    static const char* nm[] = {"ordered column index", "pair table", "LD graph", "components + seed", "cross_optimize A", "block flip", "perturbation rounds"};
+    for (int k = 0; k < 7; k++) fprintf(stderr, "[phase]     grid chain: %-24s %9.1f us\n", nm[k], (double)(clk[k + 1] - clk[k]) / 100.0);
+    fprintf(stderr, "[phase]     grid chain: %lld iterations in the rounds\n", clk[15]);
+    static const char* nm2[] = {"stage delta/eta", "sigma step (workgroup 0)", "barrier 1", "stage sigma", "delta step (workgroup 0)", "barrier 2"};
+    for (int k = 0; k < 6; k++) fprintf(stderr, "[phase]     grid chain rounds: %-26s %9.1f us per iteration\n", nm2[k], (double)clk[8 + k] / 100.0 / (double)std::max<long long>(clk[15], 1));
+  }
   PCHK(hipStreamSynchronize(stream));
   PCHK(hipGetLastError());
   lap("enumeration kernels");

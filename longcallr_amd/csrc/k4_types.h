@@ -62,6 +62,7 @@ struct ChainDev {
   int8_t* w_sigma; int8_t* w_delta; int8_t* w_eta; unsigned long long* macc;
   unsigned long long* sig_words;  // grid scope: sigma as bit vectors, 2 x ceil(R / 64) words per region at 2 * (sig_off / 64 + region)
   GridCtl* ctl;
+  long long* dbg;                 // LCR_PHASE_PROF: 100 MHz timestamps of the chain steps of a grid launch, 16 per launch (else nullptr)
   double le[31], l1e[31], p_homref, p_homvar, log_theta, log2;   // libm values of the block-flip sums (host table)
 };
 
