@@ -658,14 +658,9 @@ def test_device_resident_inputs_and_idempotence(engine_cls):
         assert E2.candidates()[0].tobytes() == ref_c.tobytes()
 
 
-def test_full_size_properties(engine_cls):
-    """Size-independent properties at a bench-scale batch (too big for the oracle in seconds):
-    plane sums equal the number of kept aligned bases / intron / deletion positions computed with
-    plain numpy run-length arithmetic; fwd <= cnt; determinism across two runs."""
-    b = synth.make_batch("ont-cdna", n_genes=40, gene_len=25000, depth=40, seed=61)
-    p = _abi.make_params("ont-cdna")
-    E = engine_cls(0, p)
-    E.load_batch(b).fill_data_into_freq_vec()
+def _pileup_properties(E, b):
+    """plane sums equal the number of kept aligned bases / intron / deletion positions computed with plain numpy
+    run-length arithmetic; fwd <= cnt"""
     pl = E.columns()
     ops, lens = b.cigar & 15, (b.cigar >> 4).astype(np.int64)
     assert int(pl[_abi.PL_N].sum()) == int(lens[ops == 3].sum())      # windows cover every read fully
@@ -676,10 +671,130 @@ def test_full_size_properties(engine_cls):
     assert kept <= m_total and kept > 0.9 * m_total                     # ONT end-trim removes <= 2*20 per read
     assert np.all(pl[_abi.PL_FWD_A:_abi.PL_FWD_T + 1] <= pl[:4])
     assert np.all(pl[_abi.PL_TS_FWD] + pl[_abi.PL_TS_REV] == pl[:4].sum(axis=0))  # every read has ts, no non-ACGT
+    return pl
+
+
+def _result_bytes(E):
+    pr = E.phase_result()
+    return (E.candidates()[0].tobytes(), pr["haplotag"].tobytes(), pr["assignment"].tobytes(), pr["phase_set"].tobytes(),
+            pr["objective"].tobytes())
+
+
+def _phase_properties(E, max_enum_snps=10):
+    """structural properties of the phase stage's outputs that hold at any size"""
+    c, off = E.candidates()
+    fm, pr = E.fragmat(), E.phase_result()
+    assert set(np.unique(pr["haplotag"])) <= {-1, 0, 1} and set(np.unique(pr["assignment"])) <= {0, 1, 2}
+    assert np.all((pr["assignment"] == 0) == (pr["haplotag"] == 0))           # snpfrags.rs:548-625: unassigned <=> tag 0
+    assert np.all(np.where(pr["assignment"] == 1, pr["haplotag"] == 1, True)) and np.all(np.where(pr["assignment"] == 2, pr["haplotag"] == -1, True))
+    assert np.all(np.isfinite(pr["objective"])) and np.all(pr["objective"] <= 0)
+    for g in range(len(off) - 1):
+        cg = c[off[g]:off[g + 1]]
+        pos1 = set((cg["pos"] + 1).tolist())
+        ps = cg["phase_set"][cg["phase_set"] != 0]
+        assert set(ps.tolist()) <= pos1                                           # a phase set is named after one of its SNPs
+        r0, r1 = fm["row_region_off"][g], fm["row_region_off"][g + 1]
+        rps = pr["phase_set"][r0:r1]
+        assert set(rps[rps != 0].tolist()) <= set(ps.tolist())
+        assert np.all(pr["assignment"][r0:r1][rps != 0] != 0)                     # only assigned reads carry a phase set
+        if len(cg) > max_enum_snps:                                               # LD blocks: disjoint, >= 2 SNPs, smallest first, descending
+            blocks = E.ld_blocks(g)
+            flat = [i for bl in blocks for i in bl]
+            assert len(flat) == len(set(flat)) and all(len(bl) >= 2 and bl[0] == min(bl) for bl in blocks)
+            assert [bl[0] for bl in blocks] == sorted([bl[0] for bl in blocks], reverse=True)
+            assert all((cg["flags"][i] & _abi.F_FOR_PHASING) != 0 for i in flat)
+    return c, off, fm, pr
+
+
+def test_full_size_properties(engine_cls):
+    """BASELINE configs[2] at its full size (C3 as bench.py builds it: 400 regions x 25 kb, 40x; too big for the
+    oracle in seconds): size-independent properties of the pileup planes and of the phase stage's outputs, and
+    determinism across two runs."""
+    import bench
+    base = synth.make_batch("ont-cdna", n_genes=50, gene_len=25000, depth=40, seed=1000)
+    b = bench.tile_batch(base, 8)
+    assert b.n_regions == 400 and b.bases.size > 4.0e8
+    p = _abi.make_params("ont-cdna")
+    E = engine_cls(0, p)
+    E.load_batch(b).fill_data_into_freq_vec()
+    pl = _pileup_properties(E, b)
     E.get_candidate_snps().get_fragments().phase()
-    c1 = E.candidates()[0].tobytes()
+    c, off, fm, pr = _phase_properties(E)
+    # the 8 tiles are copies at shifted coordinates: per-region results repeat (regions are independent, thread.rs:77) --
+    # except the draws of the optimiser, which are seeded by the region's start position
+    n50 = off[50]
+    for k in range(1, 8):
+        ck = c[off[50 * k]:off[50 * (k + 1)]]
+        assert len(ck) == n50
+        for f in ("ref_base", "allele1", "allele2", "cnt1", "cnt2", "depth", "af1", "af2", "qual", "gq"):
+            assert np.array_equal(ck[f], c[:n50][f]), f
+    r1 = _result_bytes(E)
     E.load_batch(b).run_all()
-    assert np.array_equal(E.columns(), pl) and E.candidates()[0].tobytes() == c1
+    assert np.array_equal(E.columns(), pl) and _result_bytes(E) == r1
+
+
+def test_c5_island_against_the_oracle(engine_cls, orc):
+    """BASELINE configs[4] at a size the oracle finishes (4 loci = 100 kb x 200x as ONE region, ~480 candidates, chain
+    path): the region is staged, phased (LD blocks, block flip, 2 x 120 perturbation calls) and post-processed by the
+    all-CUs kernels (k4_stage_grid, k4_chain_grid with the device-coherent rounds, k4_gpost) -- bit-exact like every
+    other region."""
+    b = synth.make_island("ont-drna-c5", n_loci=4, locus_len=25000, depth=200, seed=3)
+    assert b.n_regions == 1
+    c = full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=11))
+    assert c.size > 400
+
+
+def test_c5_scopes_and_paths_agree(engine_cls, monkeypatch):
+    """One island (200 kb x 150x) through the three forms of the chain kernel -- all CUs with device-coherent rounds
+    (default at this size), all CUs with fenced barriers only (LCR_GRID_GENERIC), one workgroup -- and through the
+    host epilogue: identical bytes."""
+    b = synth.make_island("ont-drna-c5", n_loci=8, locus_len=25000, depth=150, seed=4)
+    p = _abi.make_params("ont-drna", seed=12)
+
+    def run():
+        E = engine_cls(0, p)
+        E.load_batch(b).run_all()
+        _phase_properties(E)
+        r = _result_bytes(E) + (repr(E.ld_blocks(0)),)
+        E.close()
+        return r
+    ref = run()
+    monkeypatch.setenv("LCR_GRID_GENERIC", "1")
+    assert run() == ref
+    monkeypatch.delenv("LCR_GRID_GENERIC")
+    monkeypatch.setenv("LCR_GRID_MIN_ENTRIES", "1000000000")
+    assert run() == ref
+    monkeypatch.delenv("LCR_GRID_MIN_ENTRIES")
+    monkeypatch.setenv("LCR_POST_HOST", "1")
+    got = run()
+    # (the host epilogue's phase_score goes through the host libm's log10: compare everything but the last bits of it)
+    assert got[1:] == ref[1:]
+    ca, cb = np.frombuffer(got[0], dtype=_abi.CAND_DTYPE), np.frombuffer(ref[0], dtype=_abi.CAND_DTYPE)
+    for f in INT_FIELDS:
+        assert np.array_equal(ca[f], cb[f]), f
+    assert np.all(np.abs(ca["phase_score"] - cb["phase_score"]) <= 1e-9)
+
+
+def test_c5_full_size(engine_cls):
+    """BASELINE configs[4] at full size: ONE region of ~1 Mb at ~500x ONT-dRNA (3.3 10^5 reads, ~4 700 candidate sites,
+    8 10^6 matrix entries, 2 345 cross_optimize calls).  Far beyond the oracle: size-independent properties of every
+    stage and bit-identical results of two runs."""
+    b = synth.make_island("ont-drna-c5", n_loci=40, locus_len=25000, depth=500, seed=5)
+    assert b.n_regions == 1 and b.len[0] > 900000 and b.bases.size > 5.0e8
+    p = _abi.make_params("ont-drna", seed=5)
+    E = engine_cls(0, p)
+    E.load_batch(b).fill_data_into_freq_vec()
+    pl = _pileup_properties(E, b)
+    covered = (pl[:4].sum(axis=0) + pl[_abi.PL_N] + pl[_abi.PL_D]) > 0
+    assert covered[100:-100].all()                                            # one coverage island (read ends are trimmed)
+    E.get_candidate_snps().get_fragments().phase()
+    c, off, fm, pr = _phase_properties(E)
+    assert 4000 < c.size < 6500 and fm["col"].size > 5e6
+    fp = (c["flags"] & _abi.F_FOR_PHASING) != 0
+    assert fp.sum() > 2000 and (pr["assignment"] != 0).mean() > 0.95            # the reads carry real haplotype signal
+    r1 = _result_bytes(E)
+    E.load_batch(b).run_all()
+    assert np.array_equal(E.columns(), pl) and _result_bytes(E) == r1
 
 
 def test_region_discovery_gpu(engine_cls):
