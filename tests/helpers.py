@@ -61,3 +61,38 @@ def mk_batch(reads, regions):  # noqa: C901
         bases=cat(bases, np.uint8), quals=cat(quals, np.uint8), cigar=cat(cigs, np.uint32),
         start0=[s for s, _ in regions], len=[len(x) for _, x in regions], read_begin=read_begin,
         ref=np.frombuffer("".join(x for _, x in regions).encode(), dtype=np.uint8), **cols)
+
+
+def two_haplotype_batch(n_snps=11, groups=1, n_reads=60, seed=0, edit_sites=(), edit_frac=0.6, qual=30):
+    """Hand-checkable phasing instance: error-free reads of two haplotypes over `groups` stretches of 2 kb that no read
+    connects, n_snps het sites per stretch (alt on haplotype A only), every read covers its whole stretch.  edit_sites:
+    offsets (inside stretch 0) of A>G sites whose G sits on `edit_frac` of haplotype A's reads -- with ts '+' reads
+    that is the RNA-editing class of candidate.rs:379-407."""
+    rng = np.random.default_rng(seed)
+    span, gap = 2000, 3000
+    L = groups * span + (groups - 1) * gap
+    ref = rng.choice(list("ACGT"), size=L)
+    alt_of = {"A": "C", "C": "A", "G": "T", "T": "G"}
+    sites = []
+    for gi in range(groups):
+        o = gi * (span + gap)
+        sites.append([o + 100 + (span - 200) * k // (n_snps - 1) for k in range(n_snps)])
+    for x in edit_sites:
+        ref[x] = "A"
+    ref = "".join(ref)
+    reads = []
+    for gi in range(groups):
+        o = gi * (span + gap)
+        for k in range(n_reads):
+            hap_a = k % 2 == 0
+            s = list(ref[o:o + span])
+            for x in sites[gi]:
+                if hap_a:
+                    s[x - o] = alt_of[ref[x]]
+            if gi == 0:
+                for x in edit_sites:
+                    if hap_a and rng.random() < edit_frac:
+                        s[x] = "G"
+            reads.append(dict(pos=5000 + o, seq="".join(s), qual=qual, cigar="%dM" % span, rev=k // 2 % 2, ts=1 + (k // 2 % 2), region=0))
+    reads.sort(key=lambda r: r["pos"])
+    return mk_batch(reads, [(5000, ref)]), [[5000 + x for x in g] for g in sites]

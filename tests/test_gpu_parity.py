@@ -43,6 +43,31 @@ def oracle_all(orc, batch, params, upto="post"):
     return regs
 
 
+F64_CHECKED = {"regions": 0, "tie_free": 0}
+
+
+def check_f64_mode(orc, batch, params, regs, chrom):
+    """The oracle's two decision arithmetics -- ORC_MODE_EXACT (fixed point: the GPU contract) and ORC_MODE_F64 (the
+    reference's f64 ratio scores in the reference's summation order) -- reach the same phasing whenever no decision of
+    the F64 run was a rounding-noise tie (DESIGN.md "Decision arithmetic"); the oracle counts those ties."""
+    for g, R in enumerate(regs):
+        if R.fm_snapshot["col"].size > 60000:
+            continue                                  # (the F64 oracle is the slow reference-order path)
+        A = orc.Region(batch, g, params).run_all(orc.MODE_F64)
+        F64_CHECKED["regions"] += 1
+        if A.stats()["noise_ties"] != 0:
+            continue
+        F64_CHECKED["tie_free"] += 1
+        pa, pb = A.phase_result(), R.phase_result()
+        for f in ("haplotag", "assignment", "phase_set"):
+            assert np.array_equal(pa[f], pb[f]), "F64 vs EXACT %s region %d" % (f, g)
+        assert abs(pa["objective"] - pb["objective"]) < 1e-6
+        ca, cb = A.cands(), R.cands()
+        for f in INT_FIELDS:
+            assert np.array_equal(ca[f], cb[f]), "F64 vs EXACT cand.%s region %d" % (f, g)
+        assert A.vcf_text(chrom) == R.vcf_text(chrom)
+
+
 def check_pileup(E, regs, batch):
     pl = E.columns()
     for g, R in enumerate(regs):
@@ -101,6 +126,7 @@ def check_phase(E, regs, fm):
 
 def full_check(engine_cls, orc, batch, params, chrom="chrS"):
     regs = oracle_all(orc, batch, params)
+    check_f64_mode(orc, batch, params, regs, chrom)
     E = engine_cls(0, params)
     E.load_batch(batch).fill_data_into_freq_vec()
     check_pileup(E, regs, batch)
@@ -154,6 +180,24 @@ def test_min_linkers_above_one(engine_cls, orc):
     b = synth.make_batch("ont-drna", n_genes=2, gene_len=30000, depth=50, seed=25)
     full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=3, min_linkers=2))
     full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=3, min_linkers=3))
+
+
+def test_hand_derived_phasing_instances(engine_cls, orc):
+    """The known-answer instances of tests/test_oracle_np_phase.py (both oracle restatements agree on them and with the
+    hand-derived answers) through the GPU: 11-SNP chain with one complete LD block, two phase sets, RNA-edit rescue."""
+    b, sites = helpers.two_haplotype_batch(n_snps=11, n_reads=40)
+    c = full_check(engine_cls, orc, b, _abi.make_params("hifi-masseq", seed=9))
+    assert c["pos"].tolist() == sites[0] and set(c["phase_set"].tolist()) == {sites[0][0] + 1}
+    b, sites = helpers.two_haplotype_batch(n_snps=6, groups=2, n_reads=40)
+    c = full_check(engine_cls, orc, b, _abi.make_params("hifi-masseq", seed=4))
+    assert c["phase_set"].tolist() == [sites[0][0] + 1] * 6 + [sites[1][0] + 1] * 6
+    for mps in (8.0, 60.0):
+        b, sites = helpers.two_haplotype_batch(n_snps=5, n_reads=60, edit_sites=(777,), edit_frac=0.95, seed=2)
+        b.flags[:] = 0 | (1 << 1)
+        c = full_check(engine_cls, orc, b, _abi.make_params("hifi-masseq", seed=4, min_phase_score=mps))
+        e = c[c["pos"] == 5000 + 777]
+        assert len(e) == 1 and bool(e["flags"][0] & _abi.F_FOR_PHASING) == (mps == 8.0)
+    assert F64_CHECKED["tie_free"] >= 4
 
 
 def test_k0_cigar_lengths(engine_cls, orc):
