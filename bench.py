@@ -2,15 +2,23 @@
 """bench.py — one "step" = one pass of the hot path (bind batch -> pileup -> candidates/GT ->
 fragment matrix -> phasing) over one synthetic batch already resident in HBM.
 
-Workload (config.workload): BASELINE.json configs[2], "synthetic 10 Mb ONT-cDNA, 40x" (C3) per GPU —
-the largest single-GPU configuration; demo.bam (configs[0]/[1]) is ~5 MB of traffic and is a parity
-fixture, not a bench line.  Weak scaling: every rank gets its own C3-sized region set; regions never
-span ranks, the only collective is the final gather of candidate records to rank 0 (RCCL).
+Workloads (config.workload):
+  N = 1   BASELINE.json configs[2], "synthetic 10 Mb ONT-cDNA, 40x" (C3: 400 regions x 25 kb) -- the largest configuration
+          whose metric is quoted on one GPU; demo.bam (configs[0]/[1]) is ~5 MB of traffic and a parity fixture, not a
+          bench line.  The C5 stress (configs[4], ONE 1 Mb island at 500x) is run once beside it and reported in
+          `stages.c5` (--no-c5 skips it).
+  N > 1   BASELINE.json configs[3], "synthetic 200 Mb PacBio MAS-Seq, 60x, region-sharded across 8 GPUs" scaled to
+          N GPUs: ONE list of N x 1 000 regions (25 Mb x 60x per GPU), partitioned over the ranks by
+          shard.assign_regions (longest-processing-time on len x max_coverage, the reference's unit of sharding is the
+          region, thread.rs:77); a rank materialises and processes only its own regions.  Weak scaling.
+`python bench.py --gpus N` starts the N ranks itself (re-exec under torch.distributed.run) when it is not already
+running under a launcher.  Regions never span ranks, the only collective is the final gather of candidate records to
+rank 0 (RCCL), overlapped with the next batch's kernels.
 
-Prints ONE JSON line on rank 0 (see the driver contract): value = candidate sites (pileup columns
-evaluated) per second, whole job, over the full step time; roofline = the pileup kernel's
-algorithmic bytes / its HIP-event time; cpu_baseline = the CPU oracle (a C++ restatement of the
-reference, NOT the Rust binary) timed on a bounded sample of the same workload, rank 0 at N = 1 only.
+Prints ONE JSON line on rank 0 (see the driver contract): value = candidate sites (pileup columns evaluated) per
+second, whole job, over the full step time; roofline = the pileup stage's algorithmic bytes / its HIP-event time
+(k1_pileup alone beside it); cpu_baseline = the CPU oracle (a C++ restatement of the reference, NOT the Rust binary)
+timed on a bounded sample of the same workload, rank 0 at N = 1 only.
 --inflight N: N contexts on N host threads keep N batches in flight per GPU (default 1).
 """
 import argparse
@@ -44,6 +52,85 @@ def tile_batch(base, copies, gap=1000):
         cig_off=rep(base.cig_off) + np.repeat(np.arange(copies, dtype=np.uint64) * np.uint64(nc), base.n_reads),
         n_cig=rep(base.n_cig), bases=rep(base.bases), quals=rep(base.quals), cigar=rep(base.cigar),
         start0=rep(base.start0) + shift_g, len=rep(base.len), read_begin=rb, ref=rep(base.ref))
+
+
+def region_max_coverage(b):
+    """Region.max_coverage (util.rs:28, 281-285: every reference position of a read span counts) per region."""
+    ops, lens = b.cigar & 15, (b.cigar >> 4).astype(np.int64)
+    cig_read = np.repeat(np.arange(b.n_reads), b.n_cig)
+    ref_len = np.bincount(cig_read, weights=np.where(np.isin(ops, [0, 2, 3, 7, 8]), lens, 0), minlength=b.n_reads).astype(np.int64)
+    out = np.zeros(b.n_regions, dtype=np.int64)
+    for g in range(b.n_regions):
+        r0, r1 = int(b.read_begin[g]), int(b.read_begin[g + 1])
+        d = np.zeros(int(b.len[g]) + 2, dtype=np.int64)
+        s = np.clip(b.pos[r0:r1].astype(np.int64) - int(b.start0[g]), 0, int(b.len[g]))
+        e = np.clip(s + ref_len[r0:r1], 0, int(b.len[g]) + 1)
+        np.add.at(d, s, 1); np.add.at(d, e, -1)
+        out[g] = int(np.cumsum(d).max()) if r1 > r0 else 0
+    return out
+
+
+def subset_batch(base, ids, gap=1000):
+    """The regions `ids` (ascending) of the global list whose region k is unique region k % U of `base` at copy k // U
+    (copies lie `span` apart): a rank's shard, built without materialising the other ranks' regions."""
+    from longcallr_amd import _abi
+    U = base.n_regions
+    span = int(base.start0[-1] + base.len[-1] - base.start0[0]) + gap
+    parts = {k: [] for k in ("pos", "seq_len", "lead_clip", "trail_clip", "flags", "n_cig", "bases", "quals", "cigar", "ref")}
+    start0, length, read_begin = [], [], [0]
+    base_off, cig_off = base.seq_off.astype(np.int64), base.cig_off.astype(np.int64)
+    for k in ids:
+        u, c = int(k) % U, int(k) // U
+        r0, r1 = int(base.read_begin[u]), int(base.read_begin[u + 1])
+        b0 = int(base_off[r0]) if r1 > r0 else 0
+        b1 = int(base_off[r1 - 1] + base.seq_len[r1 - 1]) if r1 > r0 else 0
+        c0 = int(cig_off[r0]) if r1 > r0 else 0
+        c1 = int(cig_off[r1 - 1] + base.n_cig[r1 - 1]) if r1 > r0 else 0
+        parts["pos"].append(base.pos[r0:r1].astype(np.int64) + c * span)
+        for f in ("seq_len", "lead_clip", "trail_clip", "flags", "n_cig"):
+            parts[f].append(getattr(base, f)[r0:r1])
+        parts["bases"].append(base.bases[b0:b1]); parts["quals"].append(base.quals[b0:b1]); parts["cigar"].append(base.cigar[c0:c1])
+        o = int(base.col_off[u])
+        parts["ref"].append(base.ref[o:o + int(base.len[u])])
+        start0.append(int(base.start0[u]) + c * span); length.append(int(base.len[u]))
+        read_begin.append(read_begin[-1] + (r1 - r0))
+    cat = lambda f, dt: np.concatenate(parts[f]).astype(dt) if parts[f] else np.zeros(0, dt)
+    seq_len, n_cig = cat("seq_len", np.int64), cat("n_cig", np.int64)
+    return _abi.ReadBatch(pos=cat("pos", np.int64), seq_len=seq_len, lead_clip=cat("lead_clip", np.int32),
+                          trail_clip=cat("trail_clip", np.int32), flags=cat("flags", np.uint8),
+                          seq_off=(np.cumsum(seq_len) - seq_len).astype(np.uint64), cig_off=(np.cumsum(n_cig) - n_cig).astype(np.uint64),
+                          n_cig=n_cig, bases=cat("bases", np.uint8), quals=cat("quals", np.uint8), cigar=cat("cigar", np.uint32),
+                          start0=start0, len=length, read_begin=read_begin, ref=cat("ref", np.uint8))
+
+
+WORKLOADS = {   # name -> (profile, regions per GPU, unique genes, gene_len, depth, BASELINE config it stands for)
+    "c3": ("ont-cdna", 400, 50, 25000, 40.0, "C3 = BASELINE configs[2]: synthetic 10 Mb ONT-cDNA, 40x"),
+    "c4": ("masseq", 1000, 50, 25000, 60.0, "C4 = BASELINE configs[3]: synthetic 200 Mb PacBio MAS-Seq, 60x, region-sharded (25 Mb per GPU)"),
+}
+
+
+def c5_stage(api, _abi, synth, device):
+    """BASELINE configs[4] once: ONE 1 Mb island at 500x ONT-dRNA, ~4 700 candidate sites; per-call wall times (ms)."""
+    t0 = time.perf_counter()
+    b = synth.make_island("ont-drna-c5", n_loci=40, locus_len=25000, depth=500, seed=5)
+    gen = time.perf_counter() - t0
+    E = api.Engine(device, _abi.make_params("ont-drna", seed=5))
+    ms = {}
+    for rep in range(2):   # the second pass has its buffers
+        for name, fn in (("lcr_load_batch", lambda: E.load_batch(b)), ("lcr_pileup", E.fill_data_into_freq_vec),
+                         ("lcr_candidates", E.get_candidate_snps), ("lcr_fragments", E.get_fragments), ("lcr_phase", E.phase)):
+            ts = time.perf_counter(); fn(); E.sync(); ms[name] = (time.perf_counter() - ts) * 1e3
+    c = E.candidates()[0]
+    fm = E.fragmat()
+    n_phased = int(fm["row_for_phasing"].sum())
+    t_phase = (ms["lcr_fragments"] + ms["lcr_phase"]) * 1e-3
+    out = dict(workload="C5 = BASELINE configs[4]: one island of %d columns, %d reads, %d aligned bases" % (int(b.len[0]), b.n_reads, int(b.bases.size)),
+               generate_s=gen, api_ms=ms, candidates=int(c.size), fragment_nnz=int(fm["col"].size), phasing_reads=n_phased,
+               cross_optimize_calls=1 + 2 * (int(c.size) // 4 + 1), phased_reads_per_sec=n_phased / t_phase,
+               sites_per_sec_full_step=int(b.len[0]) / (sum(ms.values()) * 1e-3),
+               note="phase stage: k4_stage_grid + k4_chain_grid + k4_gpost (all CUs on the one region, no host epilogue)")
+    E.close()
+    return out
 
 
 def to_device(batch, torch, dev):
@@ -116,11 +203,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--profile", default="ont-cdna")
-    ap.add_argument("--genes", type=int, default=400)
-    ap.add_argument("--unique-genes", type=int, default=50)
-    ap.add_argument("--gene-len", type=int, default=25000)
-    ap.add_argument("--depth", type=float, default=40.0)
+    ap.add_argument("--workload", default="auto", choices=["auto", "c3", "c4"],
+                    help="auto: C3 at N = 1, the region-sharded C4 at N > 1")
+    ap.add_argument("--profile", default=None, help="read profile of longcallr_amd.synth (default: the workload's)")
+    ap.add_argument("--genes", type=int, default=None, help="regions per GPU (default: the workload's)")
+    ap.add_argument("--unique-genes", type=int, default=None)
+    ap.add_argument("--gene-len", type=int, default=None)
+    ap.add_argument("--depth", type=float, default=None)
+    ap.add_argument("--no-c5", action="store_true", help="skip the single pass over the C5 island (N = 1)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: smoke-test the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs, records travel "
+                         "through host memory); the numbers of such a run mean nothing")
     ap.add_argument("--prewarm", type=int, default=40,
                     help="untimed passes during setup, before the W warm-up steps: allocations, thread pool, GPU clocks")
     ap.add_argument("--inflight", type=int, default=1,
@@ -133,21 +226,56 @@ def main():
     import torch
     from longcallr_amd import _abi, api, synth, shard
 
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # not under a launcher: start the N ranks ourselves, one per GPU over RCCL
+        have = torch.cuda.device_count()
+        if have < a.gpus and a.dist_backend == "nccl":
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (a.gpus, have))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP GPU (no CPU fallback)")
+    if a.dist_backend == "gloo":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if a.dist_backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
+    if a.gpus != world:
+        raise SystemExit("bench.py --gpus %d under a launcher with WORLD_SIZE=%d" % (a.gpus, world))
+    wl = a.workload if a.workload != "auto" else ("c3" if world == 1 else "c4")
+    w_profile, w_genes, w_unique, w_len, w_depth, w_name = WORKLOADS[wl]
+    a.profile = a.profile or w_profile
+    a.genes = a.genes or w_genes
+    a.unique_genes = a.unique_genes or w_unique
+    a.gene_len = a.gene_len or w_len
+    a.depth = a.depth or w_depth
     copies = max(1, a.genes // a.unique_genes)
-    base = synth.make_batch(a.profile, n_genes=a.unique_genes, gene_len=a.gene_len, depth=a.depth, seed=1000)  # every rank owns an identically distributed (same seed) C3-sized region set: weak scaling with equal work
-    batch = tile_batch(base, copies)
+    # ONE region list for the whole job: world x genes regions, region k = unique gene k % U at copy k // U (same seed on
+    # every rank).  LPT on len x max_coverage assigns them to the ranks; a rank builds only its own regions.
+    base = synth.make_batch(a.profile, n_genes=a.unique_genes, gene_len=a.gene_len, depth=a.depth, seed=1000)
+    n_global = world * copies * a.unique_genes
+    cost_u = base.len.astype(np.float64) * region_max_coverage(base)
+    costs = cost_u[np.arange(n_global) % a.unique_genes]
+    owner = shard.assign_regions(costs, world)
+    mine = owner[rank]
+    batch = tile_batch(base, copies) if world == 1 else subset_batch(base, mine)
+    assert batch.n_regions == len(mine)
     params = _abi.make_params(synth.preset_for(a.profile), seed=2025)
     reads, regions, keep = to_device(batch, torch, dev)
     torch.cuda.synchronize()
@@ -158,7 +286,7 @@ def main():
     if F == 1:
         E.set_stream(torch.cuda.current_stream().cuda_stream)  # torch.cuda.synchronize() then covers liblcr
 
-    G = shard.RecordGather(dist, dev, _abi.CAND_DTYPE) if dist is not None else None
+    G = shard.RecordGather(dist, cdev, _abi.CAND_DTYPE) if dist is not None else None
     pending = [None]
 
     def step(Ej):
@@ -171,7 +299,7 @@ def main():
     def publish(Ej):   # the gather of this batch's records (HBM to rank 0's HBM) overlaps the next batch's kernels
         if G is None:
             return
-        h = G.start(Ej.candidates_device())
+        h = G.start(Ej.candidates_device() if a.dist_backend == "nccl" else Ej.candidates()[0])
         if pending[0] is not None:
             G.finish(pending[0], parse=False)
         pending[0] = h
@@ -244,7 +372,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -267,14 +395,27 @@ def main():
                                           ("k2_gt", _abi.K_CAND_GT), ("k3_count", _abi.K_FRAG_COUNT),
                                           ("k3_fill", _abi.K_FRAG_FILL))}
 
+    # whole-job totals (the shards of an LPT partition differ slightly in size)
+    tot = np.array([int(batch.col_off[-1]), int(batch.bases.size), batch.n_reads, int(cands.size), int(fm["col"].size), n_phased], dtype=np.int64)
+    if dist is not None:
+        tt = torch.from_numpy(tot.copy()).to(cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        tot = tt.cpu().numpy()
     if rank == 0:
         cols = int(batch.col_off[-1])
+        # covered sites (depth >= min_depth on A+C+G+T, candidate.rs:90-94): counted on the unique genes, times the copies
+        Eb = api.Engine(local, params)
+        Eb.load_batch(base).fill_data_into_freq_vec()
+        cov_u = (Eb.columns()[:4].sum(axis=0) >= params.min_depth)
+        covered = int(sum(int(cov_u[int(base.col_off[int(k) % a.unique_genes]):int(base.col_off[int(k) % a.unique_genes + 1])].sum()) for k in mine))
+        Eb.close()
         pbytes = E.pileup_bytes()
         avg_ms = float(np.mean([t[0] for t in pile_ms]))
         avg_k0_ms = float(np.mean([t[1] for t in pile_ms]))
         achieved = pbytes / (avg_ms * 1e-3) / 1e9
         stage_bytes = E.pileup_stage_bytes()
-        traffic = None  # HBM bytes per K1 launch from the committed PMC passes (same workload only)
+        stage_ms = avg_ms + avg_k0_ms
+        traffic = None  # HBM bytes per launch from the committed PMC passes (same workload only; not a same-run measurement)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "k1_traffic.json")))
             w = tj["workload"]
@@ -283,30 +424,43 @@ def main():
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
+        nnz = int(fm["col"].size)
         out = {
-            "metric": "candidate_sites_per_sec", "value": cols * world * a.steps / dt, "unit": "sites/s",
+            "metric": "candidate_sites_per_sec", "value": int(tot[0]) * a.steps / dt, "unit": "sites/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 in, u32 counts, f64 likelihoods, i64 fixed-point phase scores", "data": "synthetic",
-            "config": {"workload": "%s: synthetic %s reads, %d regions x %d bp, %.0fx mean aligned depth per GPU "
-                                   "(%d unique genes tiled x%d), preset %s; step = bind+pileup+candidates+fragments+phase"
-                                   % ("C3" if a.profile == "ont-cdna" else "C3-shaped", a.profile, batch.n_regions, a.gene_len, a.depth,
-                                      a.unique_genes, copies, synth.preset_for(a.profile)),
-                       "columns_per_gpu": cols, "aligned_bases_per_gpu": int(batch.bases.size), "reads_per_gpu": batch.n_reads,
-                       "candidates_per_gpu": int(cands.size), "fragment_nnz_per_gpu": int(fm["col"].size),
-                       "parallelism": "regions sharded over %d GPU(s), gather to rank 0" % world,
+            "config": {"workload": "%s; synthetic %s reads, %d regions x %d bp per GPU at %.0fx mean aligned depth "
+                                   "(%d unique genes x %d copies; %d regions in the job, LPT-partitioned over %d rank(s)), preset %s; "
+                                   "step = bind+pileup+candidates+fragments+phase"
+                                   % (w_name, a.profile, copies * a.unique_genes, a.gene_len, a.depth, a.unique_genes, copies * world,
+                                      n_global, world, synth.preset_for(a.profile)),
+                       "columns": int(tot[0]), "aligned_bases": int(tot[1]), "reads": int(tot[2]), "candidates": int(tot[3]),
+                       "fragment_nnz": int(tot[4]), "phasing_reads": int(tot[5]),
+                       "columns_rank0": cols, "aligned_bases_rank0": int(batch.bases.size),
+                       "parallelism": "regions sharded over %d GPU(s) by shard.assign_regions (LPT on len x max_coverage), gather of records to rank 0" % world,
                        "batches_in_flight_per_gpu": F},
-            "roofline": {"bound": "hbm", "kernel": "k1_pileup", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "algorithmic_bytes": pbytes, "avg_ms": avg_ms,
-                         "note": "k1_pileup (+ k1_zonefix on HiFi presets): read bases once + 8-byte records + 57 B/column",
-                         "pileup_stage": {"kernels": "k0_bin + intron scan + k1_pileup", "ms": avg_ms + avg_k0_ms,
-                                          "algorithmic_bytes": stage_bytes,
-                                          "achieved": stage_bytes / ((avg_ms + avg_k0_ms) * 1e-3) / 1e9,
-                                          "frac": stage_bytes / ((avg_ms + avg_k0_ms) * 1e-3) / 1e9 / 8000.0}},
+            "roofline": {"bound": "hbm", "kernel": "pileup stage = k0_bin + intron scan + k1_pileup (+ k1_zonefix on HiFi presets): what replaces fill_data_into_freq_vec",
+                         "achieved": stage_bytes / (stage_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
+                         "algorithmic_bytes": stage_bytes, "avg_ms": stage_ms,
+                         "note": "algorithmic bytes B + 4C + 37R + 53L (bases once, CIGAR, read headers, ref byte + 13 u32 planes per column); "
+                                 "HIP events on the ctx stream, rank 0; traffic = committed PMC passes of the same workload (profiles/), not this run",
+                         "k1_pileup": {"algorithmic_bytes": pbytes, "avg_ms": avg_ms, "achieved": achieved, "frac": achieved / 8000.0,
+                                       "note": "the tally kernel alone: bases once + 8-byte records + 57 B/column"}},
             "stages": {"pileup_plus_candidates_s": t_call, "fragments_plus_phase_s": t_phase,
-                       "sites_per_sec_pileup_gt": cols / t_call, "phased_reads_per_sec": n_phased / t_phase,
+                       "sites_per_sec_pileup_gt": cols / t_call, "covered_sites_per_sec_pileup_gt": covered / t_call,
+                       "candidates_per_sec_pileup_gt": int(cands.size) / t_call, "phased_reads_per_sec": n_phased / t_phase,
+                       "covered_sites_rank0": covered,
+                       "k3_fragment_bytes": {"algorithmic_bytes": 4 * int(batch.cigar.size) + 64 * batch.n_reads + 15 * nnz,
+                                             "ms": kms["k3_count"] + kms["k3_fill"],
+                                             "achieved_GBps": (4 * int(batch.cigar.size) + 64 * batch.n_reads + 15 * nnz) / ((kms["k3_count"] + kms["k3_fill"]) * 1e-3 + 1e-12) / 1e9},
+                       "k4_phase": {"ms": api_ms["lcr_phase"], "nnz": nnz, "phasing_reads": n_phased,
+                                    "note": "per-kernel times: profiles/ (rocprofv3 --kernel-trace --stats of this command)"},
                        "api_ms": api_ms, "kernel_ms": kms},
         }
+        if world == 1 and not a.no_c5:
+            out["stages"]["c5"] = c5_stage(api, _abi, synth, local)
         if not a.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks of a node would sit idle behind it
             out["cpu_baseline"] = cpu_baseline(batch, params, a.cpu_budget)
         print(json.dumps(out))

@@ -1,0 +1,59 @@
+"""Worker of tests/test_gpu_parity.py::test_two_ranks_share_one_gpu (launched by torch.distributed.run, backend gloo):
+every rank takes its LPT shard of ONE region list (bench.py's construction: region k = unique gene k % U at copy
+k // U), runs the hot path on cuda:0 and the candidate / read records are gathered to rank 0, which compares them with
+a single-process run over all regions."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import bench
+    from longcallr_amd import _abi, api, shard, synth
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    base = synth.make_batch("ont-drna", n_genes=3, gene_len=12000, depth=35, seed=77)
+    U, copies = base.n_regions, 2
+    n_global = U * copies * world
+    costs = (base.len.astype(np.float64) * bench.region_max_coverage(base))[np.arange(n_global) % U]
+    owner = shard.assign_regions(costs, world)
+    assert sorted(sum(owner, [])) == list(range(n_global))
+    params = _abi.make_params("ont-drna", seed=31)
+
+    def run(ids):
+        b = bench.subset_batch(base, ids)
+        E = api.Engine(0, params)
+        E.load_batch(b).run_all()
+        c, off = E.candidates()
+        c = c.copy()
+        c["region"] = np.asarray(ids, dtype=np.int32)[c["region"]]        # batch-local -> global region index
+        pr, fm = E.phase_result(), E.fragmat()
+        reads = np.zeros(fm["row_read"].size, dtype=[("region", "<i4"), ("row", "<i4"), ("hp", "i1"), ("asg", "u1"), ("ps", "<u4")])
+        rr = np.repeat(np.arange(len(ids)), np.diff(fm["row_region_off"]))
+        reads["region"] = np.asarray(ids, dtype=np.int32)[rr]
+        reads["row"] = np.arange(reads.size) - fm["row_region_off"][rr]
+        reads["hp"], reads["asg"], reads["ps"] = pr["haplotag"], pr["assignment"], pr["phase_set"]
+        E.close()
+        return c, reads
+    c, reads = run(owner[rank])
+    gc = shard.gather_records(c, dist)
+    gr = shard.gather_records(reads, dist)
+    if rank == 0:
+        wc, wr = run(list(range(n_global)))
+        gc = gc[np.argsort(gc["region"], kind="stable")]
+        gr = gr[np.lexsort((gr["row"], gr["region"]))]
+        assert gc.tobytes() == wc.tobytes(), "gathered candidate records differ from the single-process run"
+        assert gr.tobytes() == wr.tobytes(), "gathered read records differ from the single-process run"
+        print("SHARD-OK %d candidates, %d reads, %d regions over %d ranks" % (gc.size, gr.size, n_global, world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -841,6 +841,25 @@ def test_c5_full_size(engine_cls):
     assert np.array_equal(E.columns(), pl) and _result_bytes(E) == r1
 
 
+@pytest.mark.parametrize("grid_min", [None, "0"])
+def test_two_ranks_share_one_gpu(grid_min):
+    """SURVEY §8(e) on the one GPU of the test box: two processes (torch.distributed.run, gloo), each on its
+    shard.assign_regions share of ONE region list, records gathered to rank 0 == the single-process run.  With
+    LCR_GRID_MIN_ENTRIES=0 both processes launch persistent all-CU kernels at the same time: the device-wide lock
+    (k4_phase.hip GridLock) keeps them from waiting for each other's workgroups."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    if grid_min is not None:
+        env["LCR_GRID_MIN_ENTRIES"] = grid_min
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_shard_worker.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29000 + os.getpid() % 2000), worker]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SHARD-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_region_discovery_gpu(engine_cls):
     """lcr_discover_regions vs the loop-for-loop restatement of util.rs:236-332."""
     import os

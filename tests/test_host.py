@@ -142,3 +142,34 @@ def test_region_discovery_quirks():
     assert want == [(5, 15, 2), (30, 11, 1), (50, 10, 1)]
     recs = [dict(ref_id=0, pos=s, ref_len=e - s) for s, e in spans]
     assert bamio.discover_regions(recs, 0, 80) == want
+
+
+def test_bench_shards_partition_one_region_list():
+    """bench.py at N > 1: ONE list of regions (region k = unique gene k % U at copy k // U), LPT-partitioned by
+    shard.assign_regions; a rank's subset_batch holds exactly its regions, and the shards together are the job."""
+    import bench
+    base = synth.make_batch("masseq", n_genes=3, gene_len=5000, depth=10, seed=5)
+    U, copies = base.n_regions, 4
+    whole = bench.tile_batch(base, copies)
+    every = bench.subset_batch(base, list(range(U * copies)))
+    for f in _abi.ReadBatch.FIELDS + ["start0", "len", "read_begin", "ref", "col_off"]:
+        assert np.array_equal(getattr(whole, f), getattr(every, f)), f
+    cov = bench.region_max_coverage(base)
+    assert cov.shape == (U,) and cov.min() > 0
+    for world in (2, 3):
+        costs = (base.len * cov)[np.arange(U * copies) % U]
+        owner = shard.assign_regions(costs, world)
+        assert sorted(sum(owner, [])) == list(range(U * copies))
+        loads = [float(costs[o].sum()) for o in owner]
+        assert max(loads) - min(loads) <= costs.max()          # LPT: no rank is more than one region ahead
+        got = {}
+        for r in range(world):
+            sb = bench.subset_batch(base, owner[r])
+            assert sb.n_regions == len(owner[r])
+            for j, k in enumerate(owner[r]):
+                r0, r1 = int(sb.read_begin[j]), int(sb.read_begin[j + 1])
+                got[k] = (int(sb.start0[j]), int(sb.len[j]), sb.pos[r0:r1].tobytes(), sb.bases[int(sb.seq_off[r0]):int(sb.seq_off[r1 - 1] + sb.seq_len[r1 - 1])].tobytes())
+        for k in range(U * copies):
+            r0, r1 = int(whole.read_begin[k]), int(whole.read_begin[k + 1])
+            assert got[k] == (int(whole.start0[k]), int(whole.len[k]), whole.pos[r0:r1].tobytes(),
+                              whole.bases[int(whole.seq_off[r0]):int(whole.seq_off[r1 - 1] + whole.seq_len[r1 - 1])].tobytes())
