@@ -43,8 +43,8 @@ def bgzf_decompress(path):
     return b"".join(out)
 
 
-def _aux_scan(buf, p, end):
-    """Return (de or None, ts code 0/1/2) from the aux block buf[p:end]."""
+def _aux_scan(buf, p, end, cg_out=None):
+    """Return (de or None, ts code 0/1/2) from the aux block buf[p:end]; a CG:B,I tag's values go to cg_out."""
     de, ts = None, 0
     while p + 3 <= end:
         tag, typ = buf[p:p + 2], chr(buf[p + 2])
@@ -67,6 +67,8 @@ def _aux_scan(buf, p, end):
             p += 1
         elif typ == "B":
             sub, cnt = chr(buf[p]), struct.unpack_from("<I", buf, p + 1)[0]
+            if tag == b"CG" and sub == "I" and cg_out is not None:
+                cg_out.append(np.frombuffer(buf, dtype="<u4", count=cnt, offset=p + 5).copy())
             p += 5 + cnt * {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[sub]
         else:
             raise ValueError("bad aux type %r" % typ)
@@ -109,7 +111,14 @@ def read_bam(path, keep_raw=False):
         q += (l_seq + 1) // 2
         qual = np.frombuffer(buf, dtype=np.uint8, count=l_seq, offset=q).copy()
         q += l_seq
-        de, ts = _aux_scan(buf, q, p + 4 + bs)
+        cg = []
+        de, ts = _aux_scan(buf, q, p + 4 + bs, cg)
+        # long CIGAR (SAM spec 4.2.2, htslib applies it when reading): placeholder <l_seq>S<n>N + the real CIGAR in CG:B,I
+        if n_cig == 2 and (cigar[0] & 15) == 4 and int(cigar[0] >> 4) == l_seq and (cigar[1] & 15) == 3:
+            if not cg:
+                raise ValueError("long-CIGAR placeholder without a CG:B,I tag")
+            cigar = cg[0]
+            n_cig = int(cigar.size)
         ops, lens = cigar & 15, cigar >> 4
         ref_len = int(lens[_CONSUMES_REF[np.minimum(ops, 8)] & (ops <= 8)].sum())
         lead = trail = 0

@@ -29,6 +29,13 @@
 
 #include "lcr_dev.h"
 
+// Ablation switches of the profiling experiments (tools/k1time.py): compile-time only (-DLCR_K1_ABLATE=n builds a
+// measurement library that computes WRONG planes); the product build has no switch that skips work.
+#ifdef LCR_K1_ABLATE
+#define K1_ABL LCR_K1_ABLATE
+#else
+#define K1_ABL 0
+#endif
 #define K1_THREADS 512
 #define K1_WAVES (K1_THREADS / 64)
 #define K1_CPT (LCR_TILE / K1_THREADS)  // columns per thread in the tile epilogue
@@ -100,10 +107,12 @@ void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t
 
 // ---------------------------------------------------------------------------------------------
 // per-read header pack (once per batch): everything K0 needs about a read in one 64-byte line
-__global__ void __launch_bounds__(LCR_BLOCK) k0_pack(BatchView b, ReadBin* __restrict__ out) {
+__global__ void __launch_bounds__(LCR_BLOCK) k0_pack(BatchView b, ReadBin* __restrict__ out, int32_t* order_flag) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= b.n_reads) return;
   const int g = region_of_read(b, r);
+  // precondition of k3_rows / lcr_fragments (binary searches on pos): a region's reads are sorted by position
+  if (r > b.read_begin[g] && b.pos[r] < b.pos[r - 1]) *order_flag = 1;
   ReadBin h;
   h.rel_pos = (int32_t)((int64_t)b.pos[r] - b.start0[g]);
   h.vec = b.len[g]; h.ftile = b.region_first_tile[g]; h.n_cig = (int32_t)b.n_cig[r];
@@ -113,9 +122,9 @@ __global__ void __launch_bounds__(LCR_BLOCK) k0_pack(BatchView b, ReadBin* __res
   h.flags = b.flags[r]; h.pad_ = 0; h.pad2_ = 0;
   out[r] = h;
 }
-void launch_k0_pack(const BatchView& b, ReadBin* out, hipStream_t s) {
+void launch_k0_pack(const BatchView& b, ReadBin* out, int32_t* order_flag, hipStream_t s) {
   if (b.n_reads == 0) return;
-  hipLaunchKernelGGL(k0_pack, dim3((b.n_reads + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, b, out);
+  hipLaunchKernelGGL(k0_pack, dim3((b.n_reads + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, b, out, order_flag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -444,7 +453,7 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   unsigned long long rec_nx[K1_RPB];
 #pragma unroll
   for (int x = 0; x < K1_RPB; x++) rec_nx[x] = load_rec(i0 + tid * K1_RPB + x);
-  for (int rbase = i0; rbase < i1 && prm.dbg != 3; rbase += K1_RPB * K1_THREADS) {
+  for (int rbase = i0; rbase < i1 && K1_ABL != 3; rbase += K1_RPB * K1_THREADS) {
     // ---- phase 1: K1_RPB records per thread (thread t owns batch slots K1_RPB*t .. K1_RPB*t + K1_RPB-1)
     int npc[K1_RPB], nsum = 0;
     unsigned long long rec_cur[K1_RPB];
@@ -478,7 +487,7 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
         }
       }
       rec_s[slot] = rec;
-      npc[x] = prm.dbg == 1 ? 0 : npieces;
+      npc[x] = K1_ABL == 1 ? 0 : npieces;
       nsum += npc[x];
     }
     int run = block_incl_scan(nsum, wsum) - nsum;   // exclusive prefix of this thread's first record
@@ -542,7 +551,7 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
       auto nzf = [](uint32_t x) -> uint32_t { return (x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u; };
       uint32_t mm = (nzf(x0) >> 7) | (nzf(x1) >> 6) | (nzf(x2) >> 5) | (nzf(x3) >> 4);
       mm &= vge[q.k_lo] & vlt[q.k_hi];
-      if (prm.dbg == 5) mm = 0;
+      if (K1_ABL == 5) mm = 0;
       uint32_t* dp = pl + (q.strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
       uint32_t* mp = pl + (q.strand ? P_MM_R : P_MM_F) * TSTRIDE;
       while (mm) {  // rare: a few % of the bases

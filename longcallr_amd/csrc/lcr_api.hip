@@ -36,6 +36,7 @@ struct lcr_ctx {
   DevBuf region_e_off, frag_tmp_col, frag_tmp_val;
   hipEvent_t ev_nnz = nullptr, ev_cand = nullptr, ev_ctl = nullptr;
   bool nnz_pending = false, cand_pending = false;
+  HostBuf h_order;      // pinned: k0_pack raises it when a region's reads are not sorted by position
   HostBuf h_stage[4];   // pinned staging of lcr_candidates / lcr_fragments: survivor offsets, candidate records, keep flags, region rows
 
   // K2
@@ -154,7 +155,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   if (c->ev_nnz) (void)hipEventDestroy(c->ev_nnz);
   if (c->ev_cand) (void)hipEventDestroy(c->ev_cand);
   if (c->ev_ctl) (void)hipEventDestroy(c->ev_ctl);
-  HostBuf* hb[] = {&c->h_nnz, &c->h_stage[0], &c->h_stage[1], &c->h_stage[2], &c->h_stage[3], &c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
+  HostBuf* hb[] = {&c->h_order, &c->h_nnz, &c->h_stage[0], &c->h_stage[1], &c->h_stage[2], &c->h_stage[3], &c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
   for (auto* b : hb) b->release();
   c->phase.release();
   for (int k = 0; k < LCR_NKERNELS; k++) for (int j = 0; j < 2; j++) if (c->ev[k][j]) (void)hipEventDestroy(c->ev[k][j]);
@@ -234,6 +235,8 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
       c->err = "region table inconsistent"; return LCR_E_ARG;
     }
   c->n_cols = c->h_col_off[ng];
+  // (tile column origins and the intron difference array are indexed with int32)
+  if (c->n_cols + ng + 1 > (int64_t)INT32_MAX) { c->err = "batch too large: columns + regions must stay below 2^31; split it"; return LCR_E_ARG; }
   c->n_bases = rd->n_bases; c->n_cigar = rd->n_cigar;
 
   BatchView& b = c->bv;
@@ -269,7 +272,10 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   launch_k0_read_region(b, c->read_region.as<int32_t>(), c->stream);
   b.region_first_tile = c->first_tile.as<int32_t>(); b.error_flag = nullptr;   // set by lcr_pileup
   HIPCHK(c, c->read_bin.reserve(std::max<size_t>(nr, 1) * sizeof(ReadBin)));
-  launch_k0_pack(b, c->read_bin.as<ReadBin>(), c->stream);
+  HIPCHK(c, c->h_order.reserve(64));
+  *c->h_order.as<int32_t>() = 0;   // (the previous batch's k0_pack finished long ago: every lcr_pileup waits behind it)
+  { int32_t* d_flag = nullptr; HIPCHK(c, hipHostGetDevicePointer((void**)&d_flag, c->h_order.p, 0));
+    launch_k0_pack(b, c->read_bin.as<ReadBin>(), d_flag, c->stream); }
   // host batch: the caller's arrays are free again when this returns; device batch: no wait, the next stage queues
   // behind these kernels on the same stream (the arrays stay the caller's to keep alive, include/lcr.h)
   if (mem == LCR_MEM_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -286,7 +292,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, hipSetDevice(c->device));
   if (c->sor_thr < 0.f) c->sor_thr = lcr_device_sor_threshold(c->stream);  // candidate.rs:49-51, evaluated by the device's logf
   c->dp = to_dev(p, c->sor_thr);
-  { const char* e = getenv("LCR_K1_DBG"); c->dp.dbg = e ? atoi(e) : 0; }
+  c->dp.dbg = 0;
   HIPCHK(c, c->planes.reserve(std::max<size_t>((size_t)c->n_cols * LCR_NPLANES, 1) * 4));
   BatchView& b = c->bv;
   const int ng = b.n_regions, nt = c->n_tiles;
@@ -334,6 +340,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventSynchronize(c->ev_ctl));
     n_ops = ctl[1]; n_recs = ctl[2]; bad = ctl[3];
+    if (*c->h_order.as<int32_t>() != 0) { c->err = "the reads of a region must be sorted by position (lcr_reads.pos)"; return LCR_E_ARG; }
     if (bad == 1) { c->err = "unknown CIGAR operation (reference panics: util.rs:944)"; return LCR_E_CIGAR; }
     if (bad == 2) { c->err = "CIGAR inconsistent with l_seq / soft clips"; return LCR_E_CIGAR; }
     if (bad == 4) { c->err = "K0 record level wait timed out (internal error)"; return LCR_E_DEVICE; }

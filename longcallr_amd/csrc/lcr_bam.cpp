@@ -38,7 +38,11 @@ struct Rec {
   uint64_t off;        // first byte after block_size in the inflated stream
   uint32_t size;       // block_size
   int32_t ref_id, pos, l_seq, ref_len, lead, trail;
-  uint32_t n_cig, l_rn;
+  uint32_t n_cig, l_rn;   // n_cig / cig_at: the real CIGAR (the CG:B,I tag's for a long-CIGAR record), n_cig_core: the core field
+  uint32_t n_cig_core;
+  uint64_t cig_at;        // offset of the real CIGAR's first op in the inflated stream
+  uint64_t cg_tag_at;     // offset of the CG:B,I tag's first op (0: none), with cg_tag_n ops
+  uint32_t cg_tag_n;
   uint16_t flag;
   uint8_t mapq, ts, has_de;
   float de;
@@ -100,8 +104,8 @@ bool passes(const Rec& r, const lcr_read_filter& f) {   // util.rs:652-668
 inline int32_t end_pos(const Rec& r) { return r.pos + (r.ref_len > 0 ? r.ref_len : 1); }   // htslib bam_endpos
 
 // aux block: the `de` tag of type f and the `ts` tag of type A; every other tag is skipped by its type
-bool aux_scan(const uint8_t* p, const uint8_t* end, Rec& r) {
-  r.has_de = 0; r.de = 0.f; r.ts = 0;
+bool aux_scan(const uint8_t* p, const uint8_t* end, Rec& r, const uint8_t* base) {
+  r.has_de = 0; r.de = 0.f; r.ts = 0; r.cg_tag_at = 0; r.cg_tag_n = 0;
   while (p + 3 <= end) {
     const uint8_t t0 = p[0], t1 = p[1], typ = p[2];
     p += 3;
@@ -125,6 +129,7 @@ bool aux_scan(const uint8_t* p, const uint8_t* end, Rec& r) {
         const uint8_t sub = p[0]; const uint32_t cnt = rd32(p + 1);
         size_t w = 0;
         switch (sub) { case 'c': case 'C': w = 1; break; case 's': case 'S': w = 2; break; case 'i': case 'I': case 'f': w = 4; break; default: return false; }
+        if (t0 == 'C' && t1 == 'G' && sub == 'I' && p + 5 + (size_t)cnt * 4 <= end) { r.cg_tag_at = (uint64_t)(p + 5 - base); r.cg_tag_n = cnt; }
         p += 5 + (size_t)cnt * w; break;
       }
       default: return false;
@@ -260,15 +265,23 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
     b->recs.push_back(r);
     p += 4 + (size_t)bs;
   }
-  std::atomic<int64_t> bad_rec{-1};
+  std::atomic<int64_t> bad_rec{-1}, long_cigar_bad{-1};
   parallel_for((int64_t)b->recs.size(), n_threads, 1024, [&](int64_t i) {
     Rec& r = b->recs[(size_t)i];
     const uint8_t* q = &d[r.off];
     r.ref_id = rdi32(q); r.pos = rdi32(q + 4); r.l_rn = q[8]; r.mapq = q[9];
-    r.n_cig = rd16(q + 12); r.flag = rd16(q + 14); r.l_seq = rdi32(q + 16);
+    r.n_cig = r.n_cig_core = rd16(q + 12); r.flag = rd16(q + 14); r.l_seq = rdi32(q + 16);
     const uint64_t need = 32ull + r.l_rn + 4ull * r.n_cig + (uint64_t)((r.l_seq + 1) / 2) + (uint64_t)r.l_seq;
     if (r.l_seq < 0 || r.l_rn == 0 || need > r.size) { bad_rec.store(i); return; }
+    if (!aux_scan(q + need, q + r.size, r, d)) { bad_rec.store(i); return; }
     const uint8_t* cg = q + 32 + r.l_rn;
+    r.cig_at = r.off + 32 + r.l_rn;
+    // long CIGAR (> 65535 ops; SAM spec 4.2.2, applied by htslib when it reads a record): the core field holds the
+    // placeholder <l_seq>S<ref_len>N and the real CIGAR travels in the CG:B,I tag
+    if (r.n_cig == 2 && (rd32(cg) & 15) == 4 && (int64_t)(rd32(cg) >> 4) == (int64_t)r.l_seq && (rd32(cg + 4) & 15) == 3) {
+      if (!r.cg_tag_n) { long_cigar_bad.store(i); return; }
+      cg = d + r.cg_tag_at; r.cig_at = r.cg_tag_at; r.n_cig = r.cg_tag_n;
+    }
     int64_t rl = 0;
     for (uint32_t k = 0; k < r.n_cig; k++) {
       const uint32_t w = rd32(cg + 4 * k), op = w & 15;
@@ -283,9 +296,10 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
       if ((wl & 15) == 4) r.trail = (int32_t)(wl >> 4);
       else if ((wl & 15) == 5 && r.n_cig > 1 && (rd32(cg + 4 * (r.n_cig - 2)) & 15) == 4) r.trail = (int32_t)(rd32(cg + 4 * (r.n_cig - 2)) >> 4);
     }
-    if (!aux_scan(q + need, q + r.size, r)) bad_rec.store(i);
   });
   if (bad_rec.load() >= 0) return fail(b, LCR_E_ARG, "malformed record " + std::to_string(bad_rec.load()));
+  if (long_cigar_bad.load() >= 0)
+    return fail(b, LCR_E_ARG, "record " + std::to_string(long_cigar_bad.load()) + " has the long-CIGAR placeholder (<l_seq>S<n>N) but no CG:B,I tag");
   return LCR_OK;
 }
 
@@ -366,10 +380,10 @@ int lcr_bam_batch(lcr_bam* b, int32_t ref_id, const lcr_read_filter* f, int32_t 
     b->b_flags[k] = (uint8_t)(((r.flag & 0x10) ? 1 : 0) | (r.ts << 1));
     b->b_n_cig[k] = r.n_cig;
     memcpy(b->b_names.data() + b->b_name_off[k], q + 32, r.l_rn);
-    const uint8_t* cg = q + 32 + r.l_rn;
+    const uint8_t* cg = d + r.cig_at;
     uint32_t* co_ = b->b_cigar.data() + b->b_cig_off[k];
     for (uint32_t c = 0; c < r.n_cig; c++) co_[c] = rd32(cg + 4 * c);
-    const uint8_t* sq = cg + 4 * (size_t)r.n_cig;
+    const uint8_t* sq = q + 32 + r.l_rn + 4 * (size_t)r.n_cig_core;
     uint8_t* bo = b->b_bases.data() + b->b_seq_off[k];
     for (int32_t i = 0; i + 1 < r.l_seq; i += 2) { const uint8_t v = sq[i >> 1]; bo[i] = (uint8_t)NT16[v >> 4]; bo[i + 1] = (uint8_t)NT16[v & 15]; }
     if (r.l_seq & 1) bo[r.l_seq - 1] = (uint8_t)NT16[sq[r.l_seq >> 1] >> 4];
@@ -440,7 +454,7 @@ int lcr_bam_write_phased(lcr_bam* b, const char* out_path, int32_t n_regions, co
       Out o{idx[lo], 0, 0, 0, 0, 0};
       const uint8_t* q = d + r.off;
       const std::string nm(reinterpret_cast<const char*>(q + 32));
-      const uint64_t fixed = 32ull + r.l_rn + 4ull * r.n_cig + (uint64_t)((r.l_seq + 1) / 2) + (uint64_t)r.l_seq;
+      const uint64_t fixed = 32ull + r.l_rn + 4ull * r.n_cig_core + (uint64_t)((r.l_seq + 1) / 2) + (uint64_t)r.l_seq;
       auto fh = m_hp.find(nm);
       if (fh != m_hp.end() && fh->second != 0 && !aux_has(q + fixed, q + r.size, 'H', 'P')) { o.add_hp = 1; o.hp = fh->second; }   // thread.rs:347-352
       auto fp = m_ps.find(nm);

@@ -62,7 +62,7 @@ struct DevParams {
   int32_t use_strand_bias;
   float min_af, min_af_intron, low_frac_cut;
   float sor_threshold;
-  int32_t dbg;  // ablation switches for profiling (LCR_K1_DBG), 0 in production
+  int32_t dbg;  // (unused; the K1 ablation switches are compile-time, see k1_pileup.hip)
 };
 
 // pass-1 survivor of the candidate filters (one per column that reaches the likelihood block)
@@ -132,7 +132,7 @@ void launch_k0_region_setup(const int64_t* start0, const int32_t* len, const int
                             hipStream_t s);
 void launch_k0_tiles(const int32_t* first_tile, int32_t n_regions, int32_t* tile_region, int32_t* tile_col0, hipStream_t s);
 void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s);
-void launch_k0_pack(const BatchView& b, ReadBin* out, hipStream_t s);
+void launch_k0_pack(const BatchView& b, ReadBin* out, int32_t* order_flag /* pinned host memory, device address */, hipStream_t s);
 void launch_k0_bin(const BatchView& b, const ReadBin* rb, int ont, int D, int32_t* tile_fill, int32_t* tile_lvl,
                    unsigned int* pool_top, unsigned int pool_cap, unsigned long long* recs, uint32_t* ndiff, hipStream_t s);
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,

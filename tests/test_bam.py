@@ -131,6 +131,37 @@ def test_handwritten_bam_format_corners(tmp_path):
         nb.close()
 
 
+def test_long_cigar_in_the_cg_tag(tmp_path):
+    """> 65535 ops do not fit the core field: BAM then stores the placeholder <l_seq>S<ref_len>N and the real CIGAR in a
+    CG:B,I tag (SAM spec 4.2.2); htslib -- the reference's reader -- restores it, so does liblcr.  A placeholder without
+    the tag is an error, not a silently empty read."""
+    real = [(10, 0), (1, 1), (12, 0), (300, 3), (8, 0), (2, 2), (9, 0)]          # 10M1I12M300N8M2D9M: l_seq 40, ref 341
+    tag = b"CGBI" + struct.pack("<I", len(real)) + b"".join(struct.pack("<I", (n << 4) | o) for n, o in real)
+    reads = [dict(ref=0, pos=50, name="long", cigar="40S341N", seq="ACGT" * 10, aux=b"tsA+" + tag + b"NMi" + struct.pack("<i", 2)),
+             dict(ref=0, pos=60, name="plain", cigar="40M", seq="TTGCA" * 8)]
+    refs = [("chrA", 2000)]
+    path = str(tmp_path / "cg.bam")
+    open(path, "wb").write(bgzf(bam_bytes(refs, reads), 300))
+    prefs, recs = bamio.read_bam(path)
+    assert [(int(w) >> 4, int(w) & 15) for w in recs[0]["cigar"]] == real and recs[0]["ref_len"] == 341 and recs[0]["lead"] == 0
+    nb = bamio.NativeBam(path, 2)
+    flt = dict(min_mapq=20, min_read_length=10, divergence=0.5)
+    s, e = nb.spans(0, **flt)
+    assert list(s) == [50, 60] and list(e) == [50 + 341, 100]
+    regions = [(40, 400)]
+    wins = [np.full(400, ord("A"), np.uint8)]
+    a, b = bamio.build_batch([r for r in recs if bamio.passes_filter(r, **flt)], regions, wins), nb.batch(0, regions, wins, **flt)
+    same_batch(a, b)
+    assert list(b.n_cig) == [7, 1] and [(int(w) >> 4, int(w) & 15) for w in b.cigar[:7]] == real
+    assert bytes(b.bases[:40]) == b"ACGT" * 10
+    nb.close()
+    bad = str(tmp_path / "cg_missing.bam")
+    reads[0]["aux"] = b"tsA+"
+    open(bad, "wb").write(bgzf(bam_bytes(refs, reads), 300))
+    with pytest.raises(Exception, match="CG"):
+        bamio.NativeBam(bad, 1)
+
+
 def test_bad_inputs_are_errors_not_crashes(tmp_path):
     with pytest.raises(_lib.LcrError, match="cannot open"):
         bamio.NativeBam(str(tmp_path / "missing.bam"))

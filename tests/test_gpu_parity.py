@@ -674,6 +674,12 @@ def test_empty_batch_and_errors(engine_cls):
     bad2 = helpers.mk_batch([dict(pos=10, seq="ACGT" * 5, cigar="10M")], [(0, "A" * 64)])  # l_seq 20 != 10
     with pytest.raises(LcrError, match="inconsistent"):
         engine_cls(0, p).load_batch(bad2).fill_data_into_freq_vec()
+    # preconditions a foreign caller can violate are LCR_E_ARG, not silently wrong results: a region's reads sorted by pos
+    unsorted = helpers.mk_batch([dict(pos=30, seq="ACGT" * 5, cigar="20M"), dict(pos=10, seq="ACGT" * 5, cigar="20M")], [(0, "A" * 64)])
+    with pytest.raises(LcrError, match="sorted"):
+        engine_cls(0, p).load_batch(unsorted).fill_data_into_freq_vec()
+    with pytest.raises(LcrError, match="ld_weight_threshold"):
+        engine_cls(0, _abi.make_params(ld_weight_threshold=2)).load_batch(helpers.demo_batch()).run_all()
 
 
 def test_device_resident_inputs_and_idempotence(engine_cls):

@@ -13,8 +13,8 @@ torch.cuda.synchronize()
 E = api.Engine(0, p, timing=True)
 E.load_batch((reads, regions, keep))
 print("bases", batch.bases.size, "cigar", batch.cigar.size, "reads", batch.n_reads)
-for dbg in sys.argv[2:] or ["0"]:
-    os.environ["LCR_K1_DBG"] = dbg
+# (ablations: rebuild liblcr with HIPCC flags -DLCR_K1_ABLATE=1|3|5, see k1_pileup.hip; the product build has no switch)
+for dbg in ["product build"]:
     ts = []
     for _ in range(4):
         E.fill_data_into_freq_vec(); ts.append(E.kernel_ms(_abi.K_PILEUP))
