@@ -53,9 +53,9 @@ __device__ __forceinline__ MatView stage_view(const PhaseDev& P, const RegionDev
 }
 
 constexpr int CROSS_MACC = 2048;   // SNPs with a per-column accumulator in LDS (entry-balanced delta step)
-__device__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, const MatView& mv, int8_t* sg, int8_t* dl, int8_t* et,
+__device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, const MatView& mv, int8_t* sg, int8_t* dl, int8_t* et,
                                     bool keep_conserved, bool with_genotype, long long* red, const long long* wl,
-                                    unsigned long long* macc = nullptr /* CROSS_MACC zeros in LDS, or nullptr */) {
+                                    unsigned long long* macc = nullptr /* macc_cap zeros in LDS, or nullptr */, int macc_cap = CROSS_MACC) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int32_t* rp = mv.rp;
   const int32_t* pc = mv.pc;
@@ -100,7 +100,7 @@ __device__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, cons
       dl[i] = (int8_t)(ch == 1 ? -d : d);
       et[i] = (int8_t)(ch <= 1 ? 0 : (ch == 2 ? 1 : -1));
     };
-    if (macc && rd.S <= CROSS_MACC) {
+    if (macc && rd.S <= macc_cap) {
       // balanced over the CSC entries (not over the SNPs): thread t takes entries [t*c, (t+1)*c), walks them
       // in column order and flushes its per-column sum of w over the hits into macc[] (LDS, integer, order-free)
       const int E = cp[rd.S];
@@ -213,6 +213,22 @@ __device__ __forceinline__ void block_scan2n(int a, int b, int& ea, int& eb, int
   __syncthreads();
   int oa = 0, ob = 0; ta = 0; tb = 0;
   for (int w = 0; w < NW; w++) { if (w < wave) { oa += sm[0][w]; ob += sm[1][w]; } ta += sm[0][w]; tb += sm[1][w]; }
+  ea = oa + ia - a; eb = ob + ib - b;
+}
+// the same for a workgroup whose number of waves is only known at run time (<= 16)
+__device__ __forceinline__ void block_scan2_rt(int a, int b, int& ea, int& eb, int& ta, int& tb, int (*sm)[16]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int ia = a, ib = b;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int ua = __shfl_up(ia, d, 64), ub = __shfl_up(ib, d, 64);
+    if (lane >= d) { ia += ua; ib += ub; }
+  }
+  __syncthreads();
+  if (lane == 63) { sm[0][wave] = ia; sm[1][wave] = ib; }
+  __syncthreads();
+  int oa = 0, ob = 0; ta = 0; tb = 0;
+  for (int w = 0; w < nw; w++) { if (w < wave) { oa += sm[0][w]; ob += sm[1][w]; } ta += sm[0][w]; tb += sm[1][w]; }
   ea = oa + ia - a; eb = ob + ib - b;
 }
 __device__ __forceinline__ void block_scan2(int a, int b, int& ea, int& eb, int& ta, int& tb, int (*sm)[8]) {

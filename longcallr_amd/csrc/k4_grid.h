@@ -15,3 +15,5 @@ int k4_grid_blocks();
 hipError_t k4_stage_launch_grid(const StageIn& in, const StageOut& out, const PhaseLutDev& lut, int g, GridCtl* ctl, int32_t* blk_tot, hipStream_t s);
 // post-phase steps for one large region with all CUs (post_in: the PostIn of k4_post.h)
 hipError_t k4_post_launch_grid(const void* post_in, const PostScratch& ps, int g, const PostLut& lut, hipStream_t s);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel slot 0..7, device)
+hipError_t k4_set_dyn_lds_once(const void* fn, int bytes, int slot);

@@ -93,11 +93,11 @@ __device__ void ordered_index(SC& sc, int R, int S, const int32_t* rp, const int
     sc.sync();
     if (sc.blk() == 0) {
       int carry = 0;
-      for (int base = 0; base < S; base += CH_THREADS) {
+      for (int base = 0; base < S; base += (int)blockDim.x) {
         const int i = base + threadIdx.x;
         const int d = i < S ? cp_out[i] : 0;
         int ex, d0, tot, d1;
-        block_scan2n<CH_WAVES, 16>(d, 0, ex, d0, tot, d1, sm);
+        block_scan2_rt(d, 0, ex, d0, tot, d1, sm);
         if (i < S) cp_out[i] = carry + ex;
         carry += tot;
       }
@@ -193,11 +193,11 @@ __device__ void ld_graph(SC& sc, const ChainView& v, int (*sm)[16]) {
   sc.sync();
   if (sc.blk() == 0) {   // exclusive scan of the degrees (one workgroup)
     int carry = 0;
-    for (int base = 0; base < S; base += CH_THREADS) {
+    for (int base = 0; base < S; base += (int)blockDim.x) {
       const int i = base + threadIdx.x;
       const int d = i < S ? v.queue[i] : 0;
       int ex, d0, tot, d1;
-      block_scan2n<CH_WAVES, 16>(d, 0, ex, d0, tot, d1, sm);
+      block_scan2_rt(d, 0, ex, d0, tot, d1, sm);
       if (i < S) v.adj_ptr[i] = carry + ex;
       carry += tot;
     }
@@ -821,17 +821,22 @@ __device__ __forceinline__ void load_flip_lut(const ChainDev& C, FlipLut* L) {
   if (threadIdx.x == 0) { L->p_homref = C.p_homref; L->p_homvar = C.p_homvar; L->log_theta = C.log_theta; L->log2 = C.log2; }
 }
 
-// one workgroup per chain region; the working state (and the matrix, when it fits) lives in dynamic LDS
-__global__ void __launch_bounds__(CH_THREADS) k4_chain_wg(ChainDev C, int32_t first, int32_t n) {
-  __shared__ long long red[CH_WAVES];
-  __shared__ unsigned long long macc[CROSS_MACC];
+// one workgroup of sixteen waves per chain region; the working state (and the matrix, when it fits) lives in dynamic
+// LDS.  (Eight-wave workgroups, two regions per CU, were measured for batches with more chain regions than CUs -- 368 on
+// the ONT-dRNA C3-shaped batch: every serial step of a region gets longer, phase stage 1.89 ms instead of 1.62 ms.)
+template <int NT>
+__global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int32_t n) {
+  constexpr int NW = NT / 64;
+  constexpr int MACC = CROSS_MACC;
+  __shared__ long long red[NW];
+  __shared__ unsigned long long macc[MACC];
   __shared__ long long wl[32];
   __shared__ FlipLut L;
   __shared__ int sm[2][16];
-  __shared__ double stage[CH_WAVES * 4 * SSTR];
+  __shared__ double stage[NW * 4 * SSTR];
   extern __shared__ __attribute__((aligned(16))) int8_t dyn_state[];
   if ((int)blockIdx.x >= n) return;
-  for (int i = threadIdx.x; i < CROSS_MACC; i += blockDim.x) macc[i] = 0;
+  for (int i = threadIdx.x; i < MACC; i += blockDim.x) macc[i] = 0;
   load_flip_lut(C, &L);
   load_w(C.P, wl);
   const ChainDesc d = C.desc[first + blockIdx.x];
@@ -849,7 +854,7 @@ __global__ void __launch_bounds__(CH_THREADS) k4_chain_wg(ChainDev C, int32_t fi
       staged = true;
       if (C.P.lds_state && matview_bytes(rd.R, rd.S, E) <= (uint32_t)C.P.lds_mat) mvl = stage_view(C.P, rd, (uint8_t*)dyn_state + C.P.scratch_stride, E);
     }
-    return cross_optimize(C.P, rd, mvl, v.sg, v.dl, v.et, keep_conserved, with_genotype, red, wl, macc);
+    return cross_optimize(C.P, rd, mvl, v.sg, v.dl, v.et, keep_conserved, with_genotype, red, wl, macc, MACC);
   };
   chain_run(sc, C, rd, v, wl, L, stage, sm, cross, [](long long) { return false; }, d.slot);
 }
@@ -1070,13 +1075,22 @@ __global__ void __launch_bounds__(CH_THREADS) k4_gpost(PostIn in, PostScratch ps
 }
 }  // namespace
 
-size_t k4_chain_wg_static_lds() { return sizeof(long long) * (CH_WAVES + 32) + 8 * CROSS_MACC + sizeof(FlipLut) + sizeof(int) * 32 + 8 * CH_WAVES * 4 * SSTR; }
+// hipFuncSetAttribute is per device and costs tens of microseconds of host time: once per (kernel, device)
+hipError_t k4_set_dyn_lds_once(const void* fn, int bytes, int slot) {
+  static unsigned char done[8][64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (done[slot & 7][dev]) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done[slot & 7][dev] = 1;
+  return e;
+}
 
 hipError_t k4_chain_launch_wg(const ChainDev& C, int first, int n, size_t dyn_lds, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_chain_wg), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipError_t e = k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_chain_wg<CH_THREADS>), 64 * 1024, 1);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k4_chain_wg, dim3((unsigned)n), dim3(CH_THREADS), dyn_lds, s, C, (int32_t)first, (int32_t)n);
+  hipLaunchKernelGGL(k4_chain_wg<CH_THREADS>, dim3((unsigned)n), dim3(CH_THREADS), dyn_lds, s, C, (int32_t)first, (int32_t)n);
   return hipGetLastError();
 }
 
@@ -1097,7 +1111,7 @@ hipError_t k4_chain_launch_grid(const ChainDev& C, int which, size_t dyn_lds, hi
   if (nb <= 0) return hipErrorInvalidDevice;
   hipError_t e = hipMemsetAsync(C.ctl, 0, sizeof(GridCtl), s);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_chain_grid), hipFuncAttributeMaxDynamicSharedMemorySize, K4_GRID_FAST_LDS_MAX);
+  e = k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_chain_grid), K4_GRID_FAST_LDS_MAX, 2);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k4_chain_grid, dim3((unsigned)nb), dim3(CH_THREADS), dyn_lds, s, C, (int32_t)which);
   return hipGetLastError();

@@ -1258,19 +1258,20 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     // others run side by side, one workgroup each.  LCR_GRID_MIN_ENTRIES moves the boundary (tests: 0 = every region).
     int64_t grid_min = 1 << 17;
     if (const char* e = getenv("LCR_GRID_MIN_ENTRIES")) grid_min = atoll(e);
-    std::vector<int32_t> small, big;
-    for (int g : chain_slots) ((int64_t)stat[g].E >= grid_min ? big : small).push_back(g);
-    const int n_small = (int)small.size(), n_big = (int)big.size(), nc = n_small + n_big;
+    std::vector<int32_t> wide, big;
+    const bool grid_generic = getenv("LCR_GRID_GENERIC") != nullptr;   // test hook
+    for (int g : chain_slots) ((int64_t)stat[g].E >= grid_min ? big : wide).push_back(g);
+    const int n_small = (int)wide.size(), n_big = (int)big.size(), nc = n_small + n_big;
     const int grid_waves = std::max(1, k4_grid_blocks()) * 16;
     std::vector<ChainDesc> desc(nc);
     int64_t tbl_cells = 0, adj_n = 0, part_n = 0;
     int32_t max_state = 0;
     for (int k = 0; k < nc; k++) {
-      const int g = k < n_small ? small[k] : big[k - n_small];
+      const int g = k < n_small ? wide[k] : big[k - n_small];
       const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
       ChainDesc& d = desc[k];
       d.slot = g; d.W = std::max(1, std::min(stat[g].W, S)); d.fast_lds = 0;
-      if (k >= n_small && !getenv("LCR_GRID_GENERIC")) { const size_t need = k4_grid_fast_lds(stat[g].R, S); if (need <= (size_t)K4_GRID_FAST_LDS_MAX) d.fast_lds = (int32_t)need; }
+      if (k >= n_small && !grid_generic) { const size_t need = k4_grid_fast_lds(stat[g].R, S); if (need <= (size_t)K4_GRID_FAST_LDS_MAX) d.fast_lds = (int32_t)need; }
       d.tbl_off = tbl_cells; tbl_cells += (int64_t)S * d.W;
       d.adj_off = adj_n; adj_n += 2 * (int64_t)S * d.W;
       d.n_parts = k < n_small ? 16 : (int32_t)std::max<int64_t>(16, std::min<int64_t>(grid_waves, (int64_t)(1 << 23) / S));
@@ -1292,18 +1293,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(b_info.reserve((size_t)std::max(ng, 1) * 8 + 64)); PCHK(b_rowi.reserve(nr1 * 4 + 64)); PCHK(b_enti.reserve(2 * nnz1 * 4 + 64));
     PCHK(b_work.reserve(st_bytes + 64)); PCHK(b_macc.reserve(nc1 * 8 + 64)); PCHK(d_state[39].reserve((2 * (nr1 / 64 + (size_t)ng + 2)) * 8 + 64)); PCHK(b_ctl.reserve(4 * sizeof(GridCtl)));
     ChainDev C{};
-    const int32_t stride = (max_state + 63) & ~63;
-    Pc.scratch = nullptr; Pc.scratch_stride = stride;
-    const size_t dyn_state = (n_small && stride <= 48 * 1024) ? (size_t)stride : 0;   // working state in LDS when it fits
-    Pc.lds_state = dyn_state ? 1 : 0;
-    {   // room behind the working state for the largest chain matrix that fits 64 KB of dynamic LDS in total
-      uint32_t want = 0;
-      for (int g : small) {
-        const uint32_t m = matview_bytes(stat[g].R, in.cand_region_off[g + 1] - in.cand_region_off[g], stat[g].E);
-        if (dyn_state && dyn_state + m + 64 <= 64 * 1024) want = std::max(want, m);
-      }
-      Pc.lds_mat = (int32_t)want;
-    }
+    Pc.scratch = nullptr; Pc.scratch_stride = 0; Pc.lds_state = 0; Pc.lds_mat = 0;
     C.P = Pc;
     C.desc = b_desc.as<ChainDesc>();
     C.row_ptr = in.d_row_ptr; C.col = in.d_col; C.val = in.d_val;
@@ -1326,17 +1316,32 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(hipStreamWaitEvent(side, ev_csr, 0));
     PCHK(hipMemcpyAsync(b_desc.p, h_pin[10].p, (size_t)nc * sizeof(ChainDesc), hipMemcpyHostToDevice, side));
     if (nps) PCHK(hipMemcpyAsync(b_slots.p, h_pin[10].as<uint8_t>() + desc_bytes, nps * 4, hipMemcpyHostToDevice, side));
-    PCHK(k4_chain_launch_wg(C, 0, n_small, dyn_state + (size_t)Pc.lds_mat, side));
+    // the working state lives in dynamic LDS when it fits, with room behind it for the largest matrix of the class
+    auto launch_class = [&](const std::vector<int32_t>& regs, int first, int32_t mstate, size_t lds_budget) -> hipError_t {
+      if (regs.empty()) return hipSuccess;
+      ChainDev Ck = C;
+      const int32_t stride = (mstate + 63) & ~63;
+      const size_t dyn_state = (size_t)stride <= lds_budget * 3 / 4 ? (size_t)stride : 0;
+      Ck.P.scratch_stride = stride; Ck.P.lds_state = dyn_state ? 1 : 0;
+      uint32_t want = 0;
+      for (int g : regs) {
+        const uint32_t m = matview_bytes(stat[g].R, in.cand_region_off[g + 1] - in.cand_region_off[g], stat[g].E);
+        if (dyn_state && dyn_state + m + 64 <= lds_budget) want = std::max(want, m);
+      }
+      Ck.P.lds_mat = (int32_t)want;
+      return k4_chain_launch_wg(Ck, first, (int)regs.size(), dyn_state + (size_t)want, side);
+    };
+    PCHK(launch_class(wide, 0, max_state, 64 * 1024));
     if (n_big) grid_lock.acquire();
     for (int k = 0; k < n_big; k++) PCHK(k4_chain_launch_grid(C, n_small + k, (size_t)desc[n_small + k].fast_lds, side));
+    PostIn pinc = pin;
+    pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta; pinc.st_obj = Pc.st_obj;
     if (nps) {
-      PostIn pinc = pin;
-      pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta; pinc.st_obj = Pc.st_obj;
-      // 33 KB of static stage buffers + up to 64 KB of region image (set per call: the attribute is per device)
-      PCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_post<CHAIN_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      // 33 KB of static stage buffers + up to 64 KB of region image
+      PCHK(k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_post<CHAIN_THREADS>), 96 * 1024, 4));
       hipLaunchKernelGGL(k4_post<CHAIN_THREADS>, dim3((unsigned)nps), dim3(CHAIN_THREADS), post_lds, side, pinc, b_slots.as<int32_t>(), (int32_t)nps, plut);
-      PCHK(hipGetLastError());
     }
+    PCHK(hipGetLastError());
   } else chain_desc.clear();
   // ---- post-phase steps of the regions beyond k4_post's LDS image: all CUs on one region at a time, on `side`
   if (!gpost_slots.empty()) {
