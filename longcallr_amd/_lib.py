@@ -5,7 +5,7 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "liblcr.so")
+SO_PATH = os.environ.get("LCR_LIB") or os.path.join(_HERE, "liblcr.so")   # LCR_LIB: developer hook (A/B timing of two builds)
 
 # every symbol include/lcr.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

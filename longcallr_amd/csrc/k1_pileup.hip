@@ -142,7 +142,7 @@ __device__ __forceinline__ int rec_level_first(int level) { return ((1 << level)
 // walk B draws the slots from the LDS counters and writes the records.  The dependent chain per read is
 // header -> CIGAR -> reservations -> level table, independent of the number of records.
 #define K0_WIN 64
-struct K0Row { int ctr[K0_WIN]; int l0[K0_WIN]; int p0[K0_WIN]; int p1[K0_WIN]; };
+struct K0Row { int ctr[K0_WIN]; int l0[K0_WIN]; int p0[K0_WIN]; int p1[K0_WIN]; };   // (pad: the four rows of a wave sit 16 banks apart -- without it every LDS access of K0 was a 4-way bank conflict, PMC: profiles/r02_v1_pmc_summary.txt)
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
