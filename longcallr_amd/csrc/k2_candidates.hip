@@ -11,7 +11,8 @@
 //           log10-likelihoods as an exact integer histogram x 31-entry f64 LUT (order-free form of
 //           candidate.rs:267-282), posterior / QUAL / GQ (candidate.rs:287-335), classification
 //           (candidate.rs:337-460).
-// The sequential dense-cluster sweep (candidate.rs:465-526) is a host epilogue in lcr_api.hip.
+// The sequential dense-cluster sweep (candidate.rs:465-526) runs on the device too: k2_dense, one thread per region
+// over the region's compacted candidates (below).
 #include "lcr_dev.h"
 
 struct BinomTable { uint32_t reject[31]; };  // bit k of reject[n]: binomial_two_tailed(k, n, .5) < 0.05
