@@ -529,7 +529,7 @@ __device__ __forceinline__ void chain_run(SC& sc, const ChainDev& C, const Regio
                           double* stage, int (*sm)[16], Cross cross, FastRounds fast_rounds, int slot) {
   const int S = rd.S, R = rd.R;
   int n_mark = 0;
-  auto mark = [&]() { if (C.dbg && sc.nblk() > 1 && sc.tid() == 0) C.dbg[n_mark] = (long long)wall_clock64(); n_mark++; };
+  auto mark = [&]() { if (C.dbg && sc.tid() == 0 && (sc.nblk() > 1 || blockIdx.x == 0)) C.dbg[n_mark] = (long long)wall_clock64(); n_mark++; };
   mark();
   ordered_index(sc, v.R, v.S, v.mv.rp, v.mv.pc, v.mv.cp, nullptr, v.erow, v.cent, v.pcnt, v.n_parts, sm);
   mark();
@@ -583,6 +583,7 @@ __device__ __forceinline__ void chain_run(SC& sc, const ChainDev& C, const Regio
     if (obj > best) { best = obj; save(); }
     load();
   }
+  mark();
   if (sc.tid() == 0) C.P.st_obj[slot] = best;
 }
 

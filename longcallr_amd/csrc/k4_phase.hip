@@ -1311,7 +1311,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     C.macc = b_macc.as<unsigned long long>(); C.ctl = b_ctl.as<GridCtl>(); C.sig_words = d_state[39].as<unsigned long long>();
     for (int q = 0; q < 31; q++) { C.le[q] = L.le[q]; C.l1e[q] = L.l1e[q]; }
     C.p_homref = L.p_homref; C.p_homvar = L.p_homvar; C.log_theta = L.log_theta; C.log2 = L.log2;
-    if (prof && n_big) { C.dbg = d_state[20].as<long long>() + (size_t)ng * 16; PCHK(hipMemsetAsync(C.dbg, 0, 16 * 8, side)); }
+    if (prof) { C.dbg = d_state[20].as<long long>() + (size_t)ng * 16; PCHK(hipMemsetAsync(C.dbg, 0, 16 * 8, side)); }
     chain_dev = C; chain_desc = desc;   // (lcr_get_ld_blocks reads the blocks back)
     PCHK(hipStreamWaitEvent(side, ev_csr, 0));
     PCHK(hipMemcpyAsync(b_desc.p, h_pin[10].p, (size_t)nc * sizeof(ChainDesc), hipMemcpyHostToDevice, side));
@@ -1384,6 +1384,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     long long clk[16];
     PCHK(hipMemcpy(clk, chain_dev.dbg, sizeof(clk), hipMemcpyDeviceToHost));
     static const char* nm[] = {"ordered column index", "pair table", "LD graph", "components + seed", "cross_optimize A", "block flip", "perturbation rounds"};
+    fprintf(stderr, "[phase]     chain steps of %s\n", chain_desc.back().fast_lds || (int64_t)0 ? "the last all-CU launch" : "the last launch (one-workgroup form: its first region)");
     for (int k = 0; k < 7; k++) fprintf(stderr, "[phase]     grid chain: %-24s %9.1f us\n", nm[k], (double)(clk[k + 1] - clk[k]) / 100.0);
     fprintf(stderr, "[phase]     grid chain: %lld iterations in the rounds\n", clk[15]);
     static const char* nm2[] = {"stage delta/eta", "sigma step (workgroup 0)", "barrier 1", "stage sigma", "delta step (workgroup 0)", "barrier 2"};
