@@ -244,7 +244,8 @@ int lcr_discover_regions(lcr_ctx*, int32_t mem, int32_t n_reads, const int32_t* 
  * region discovery, util.rs:256-287): the file is inflated once (all BGZF blocks in parallel on n_threads host
  * threads, <= 0: all hardware threads), every record is indexed once, and the batches for lcr_load_batch are cut
  * out of that index, so the pileup and the fragment stage share one decode (the reference inflates every
- * region's blocks twice).  The file must be coordinate-sorted (the reference needs its .bai too).  No GPU is
+ * region's blocks twice).  The compressed file is mapped; only ONE contig's inflated bytes and record index are
+ * resident at a time (loaded on demand, replaced when another contig is asked for).  The file must be coordinate-sorted (the reference needs its .bai too).  No GPU is
  * involved; a handle is used by one thread at a time, output pointers stay valid until the next call on the
  * handle or lcr_bam_close. */
 typedef struct lcr_bam lcr_bam;
@@ -259,6 +260,8 @@ void lcr_bam_close(lcr_bam*);
 const char* lcr_bam_last_error(const lcr_bam*);
 int lcr_bam_refs(lcr_bam*, int32_t* n_ref, const char* const** names, const int64_t** lengths);
 int lcr_bam_n_records(lcr_bam*, int64_t* n);
+/* bytes of inflated stream + record index held right now (one contig at a time) and their peak since lcr_bam_open */
+int lcr_bam_resident(lcr_bam*, int64_t* now, int64_t* peak);
 /* record.reference_start() / reference_end() of the reads of contig ref_id that pass the filter, in file order:
  * the input of lcr_discover_regions (util.rs:264-285) */
 int lcr_bam_spans(lcr_bam*, int32_t ref_id, const lcr_read_filter*, int32_t* n, const int32_t** ref_start,

@@ -13,7 +13,7 @@ SYMBOLS = [
     "lcr_ctx_sync", "lcr_load_batch", "lcr_pileup", "lcr_get_columns", "lcr_candidates",
     "lcr_get_candidates", "lcr_get_candidates_device", "lcr_fragments", "lcr_get_fragmat", "lcr_phase", "lcr_get_phase_result", "lcr_get_ld_blocks",
     "lcr_enable_timing", "lcr_kernel_ms", "lcr_pileup_bytes", "lcr_pileup_stage_bytes", "lcr_discover_regions", "lcr_version",
-    "lcr_bam_open", "lcr_bam_close", "lcr_bam_last_error", "lcr_bam_refs", "lcr_bam_n_records", "lcr_bam_spans", "lcr_bam_batch", "lcr_bam_write_phased",
+    "lcr_bam_open", "lcr_bam_close", "lcr_bam_last_error", "lcr_bam_refs", "lcr_bam_n_records", "lcr_bam_resident", "lcr_bam_spans", "lcr_bam_batch", "lcr_bam_write_phased",
 ]
 
 _lib = None
@@ -71,6 +71,7 @@ def load():
     l.lcr_bam_last_error.restype = C.c_char_p
     l.lcr_bam_refs.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_int64))]
     l.lcr_bam_n_records.argtypes = [vp, C.POINTER(C.c_int64)]
+    l.lcr_bam_resident.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     l.lcr_bam_spans.argtypes = [vp, C.c_int32, flt, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]
     l.lcr_bam_batch.argtypes = [vp, C.c_int32, flt, C.c_int32, vp, vp, C.POINTER(_abi.LcrReads), C.POINTER(C.POINTER(C.c_int32)),
                                 C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_char_p)]

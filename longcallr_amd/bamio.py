@@ -277,8 +277,9 @@ def phased_stream(recs, regions, names, hp, ps):
 
 
 class NativeBam:
-    """liblcr's BAM decoder (lcr_bam_* in include/lcr.h): one parallel inflate + record index per file, batches
-    for `Engine.load_batch` cut out of it.  Mirrors read_bam / passes_filter / build_batch above."""
+    """liblcr's BAM decoder (lcr_bam_* in include/lcr.h): the file is mapped, one contig at a time is inflated (in
+    parallel) and indexed, batches for `Engine.load_batch` are cut out of that index.  Mirrors read_bam /
+    passes_filter / build_batch above."""
 
     def __init__(self, path, threads=0):
         import ctypes as C
@@ -296,6 +297,12 @@ class NativeBam:
         nrec = C.c_int64()
         self._chk(self._l.lcr_bam_n_records(self._h, C.byref(nrec)))
         self.n_records = nrec.value
+
+    def resident(self):
+        """(bytes of inflated stream + record index held now, their peak since open)"""
+        now, peak = self._C.c_int64(), self._C.c_int64()
+        self._chk(self._l.lcr_bam_resident(self._h, self._C.byref(now), self._C.byref(peak)))
+        return int(now.value), int(peak.value)
 
     def _chk(self, rc):
         if rc:
@@ -315,8 +322,10 @@ class NativeBam:
         return (np.ctypeslib.as_array(s, (n.value,)).copy() if n.value else np.zeros(0, np.int32),
                 np.ctypeslib.as_array(e, (n.value,)).copy() if n.value else np.zeros(0, np.int32))
 
-    def batch(self, ref_id, regions, ref_windows, **flt):
-        """ReadBatch of the passing reads grouped by region (fetch rule of util.rs:637); arrays are copies."""
+    def batch(self, ref_id, regions, ref_windows, names="list", **flt):
+        """ReadBatch of the passing reads grouped by region (fetch rule of util.rs:637); arrays are copies.
+        names="list": `batch.names` is a list of str; names="blob": `batch.name_off` (uint64, n + 1) and
+        `batch.name_blob` (uint8, NUL-terminated names) -- no Python object per read."""
         C = self._C
         from . import _abi
         f = self._filter(**flt)
@@ -339,10 +348,13 @@ class NativeBam:
         kw["cigar"] = arr(rd.cigar, rd.n_cigar, np.uint32)
         offs = np.ctypeslib.as_array(noff, (nr + 1,)).copy() if nr else np.zeros(1, np.uint64)
         blob = C.string_at(C.cast(names, C.c_void_p), int(offs[-1])) if nr else b""
-        nm = [blob[int(offs[i]):int(offs[i + 1]) - 1].decode() for i in range(nr)]
+        nm = [blob[int(offs[i]):int(offs[i + 1]) - 1].decode() for i in range(nr)] if names == "list" else None
         read_begin = np.ctypeslib.as_array(rb, (len(regions) + 1,)).copy()
         cat = np.concatenate([np.asarray(w, np.uint8) for w in ref_windows]) if len(ref_windows) else np.zeros(0, np.uint8)
-        return ReadBatch(start0=start0, len=length, read_begin=read_begin, ref=cat, names=nm, **kw)
+        out = ReadBatch(start0=start0, len=length, read_begin=read_begin, ref=cat, names=nm, **kw)
+        if names == "blob":
+            out.name_off, out.name_blob = offs, np.frombuffer(blob, dtype=np.uint8)
+        return out
 
     def write_phased(self, out_path, regions, names, hp, ps, level=-1, threads=0):
         """thread.rs:307-361: regions = [(ref_id, start0, len)] in output order; names / hp / ps = the read
@@ -351,11 +363,16 @@ class NativeBam:
         ref = np.ascontiguousarray([r for r, _, _ in regions], dtype=np.int32)
         start0 = np.ascontiguousarray([s for _, s, _ in regions], dtype=np.int64)
         length = np.ascontiguousarray([l for _, _, l in regions], dtype=np.int32)
-        enc = [n.encode() + b"\0" for n in names]
-        off = np.zeros(len(enc) + 1, dtype=np.uint64)
-        if enc:
-            off[1:] = np.cumsum([len(e) for e in enc])
-        blob = b"".join(enc)
+        if isinstance(names, tuple):     # (name_off uint64[n + 1], blob of NUL-terminated names): no Python strings
+            off = np.ascontiguousarray(names[0], dtype=np.uint64)
+            blob = np.ascontiguousarray(names[1], dtype=np.uint8).tobytes()
+            enc = range(off.size - 1)
+        else:
+            enc = [n.encode() + b"\0" for n in names]
+            off = np.zeros(len(enc) + 1, dtype=np.uint64)
+            if enc:
+                off[1:] = np.cumsum([len(e) for e in enc])
+            blob = b"".join(enc)
         hp = np.ascontiguousarray(hp, dtype=np.int32)
         ps = np.ascontiguousarray(ps, dtype=np.uint32)
         assert hp.size == ps.size == len(enc)

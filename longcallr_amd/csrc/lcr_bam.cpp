@@ -2,9 +2,15 @@
 //
 // Replaces the rust-htslib IndexedReader use of the reference (src/util.rs:636-691, src/fragment.rs:19-59;
 // region discovery's pass over the file, util.rs:256-287): the reference inflates every region's blocks
-// twice (once for the pileup, once for the fragments) and decodes records one at a time; here the file is
-// inflated once, all BGZF blocks in parallel, every record is indexed once, and the batches handed to
-// lcr_load_batch are cut out of that index (one decode shared by K1 and K3).
+// twice (once for the pileup, once for the fragments) and decodes records one at a time; here a contig's blocks are
+// inflated in parallel, its records indexed once, and the batches handed to lcr_load_batch are cut out of that
+// index (one decode shared by K1 and K3).
+//
+// Memory: the compressed file is mapped, not read; lcr_bam_open keeps only the BGZF block table and, per contig, the
+// range of the inflated stream its records occupy (one bounded-window pass over the file: CRC check, record chain).
+// The inflated bytes and the record index of ONE contig at a time are resident (loaded on demand by lcr_bam_spans /
+// lcr_bam_batch / lcr_bam_write_phased, replaced when another contig is asked for); the phased-BAM writer deflates and
+// writes in chunks of 16 MB.  lcr_bam_resident reports the current and the peak size of those buffers.
 //
 // What is kept from the reference, by line:
 //   * read filter: mapq < min_mapq | l_seq < min_read_length | unmapped | secondary | supplementary, then
@@ -20,6 +26,10 @@
 #include "../../include/lcr.h"
 
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -74,16 +84,31 @@ void parallel_for(int64_t n, int nt, int64_t chunk, const std::function<void(int
 
 }  // namespace
 
+struct Blk { uint64_t coff; uint32_t clen, crc, isize; uint64_t uoff; };   // one BGZF block: compressed payload, its offset in the inflated stream
+
 struct lcr_bam {
   std::string err;
   int n_threads = 1;
-  std::unique_ptr<uint8_t[]> data;   // inflated stream (not value-initialised: every byte is written by inflate)
-  size_t data_size = 0;
+  // the compressed file, mapped read-only (pages are the kernel's to drop), and its block table
+  const uint8_t* mm = nullptr;
+  size_t mm_size = 0;
+  std::vector<Blk> blks;
+  uint64_t total_inflated = 0;
+  std::vector<uint8_t> header;   // inflated bytes before the first record (magic, text, reference table)
+  size_t header_size = 0;
   std::vector<std::string> ref_names;
   std::vector<const char*> ref_name_ptrs;
   std::vector<int64_t> ref_len;
+  int64_t n_records = 0;
+  // per contig (index ref_id + 1; 0 = unmapped tail): range of the inflated stream that holds its records, record count
+  std::vector<uint64_t> ctg_u0, ctg_u1;
+  std::vector<int64_t> ctg_n;
+  // the ONE resident contig: inflated bytes of its blocks and its record index (Rec::off is relative to `data`)
+  int32_t cur_ref = INT32_MIN;
+  std::unique_ptr<uint8_t[]> data;
+  size_t data_size = 0;
   std::vector<Rec> recs;
-  size_t header_size = 0;   // inflated bytes before the first record (magic, text, reference table)
+  int64_t resident_now = 0, resident_peak = 0;
   // results of the last lcr_bam_spans / lcr_bam_batch call
   std::vector<int32_t> sp_start, sp_end;
   std::vector<int32_t> b_pos, b_seq_len, b_lead, b_trail, b_read_begin;
@@ -91,6 +116,7 @@ struct lcr_bam {
   std::vector<uint64_t> b_seq_off, b_cig_off, b_name_off;
   std::vector<uint32_t> b_n_cig, b_cigar;
   std::vector<char> b_names;
+  ~lcr_bam() { if (mm && mm_size) munmap(const_cast<uint8_t*>(mm), mm_size); }
 };
 
 namespace {
@@ -168,6 +194,110 @@ int fail(lcr_bam* b, int code, const std::string& msg) { b->err = msg; return co
 
 extern "C" {
 
+}  // extern "C"
+
+namespace {
+
+// inflate the blocks [b0, b1) into dst (dst + (uoff - uoff of b0)); CRC-checked; returns the first bad block or -1
+int64_t inflate_blocks(const lcr_bam* b, size_t b0, size_t b1, uint8_t* dst, int n_threads) {
+  std::atomic<int64_t> bad{-1};
+  const uint64_t base = b0 < b->blks.size() ? b->blks[b0].uoff : 0;
+  parallel_for((int64_t)(b1 - b0), n_threads, 16, [&](int64_t i) {
+    const Blk& k = b->blks[b0 + (size_t)i];
+    if (k.isize == 0) return;   // EOF marker and other empty blocks
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) { bad.store((int64_t)(b0 + i)); return; }
+    zs.next_in = const_cast<Bytef*>(b->mm + k.coff); zs.avail_in = (uInt)k.clen;
+    zs.next_out = dst + (k.uoff - base); zs.avail_out = k.isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.total_out == k.isize;
+    inflateEnd(&zs);
+    if (!ok || crc32(crc32(0L, Z_NULL, 0), dst + (k.uoff - base), k.isize) != k.crc) bad.store((int64_t)(b0 + i));
+  });
+  return bad.load();
+}
+
+void note_resident(lcr_bam* b, int64_t extra) {
+  b->resident_now = (int64_t)b->data_size + (int64_t)(b->recs.capacity() * sizeof(Rec)) + extra;
+  b->resident_peak = std::max(b->resident_peak, b->resident_now);
+}
+
+// decode the fixed fields of record r (r.off / r.size set) from the buffer d; false = malformed, *long_bad = placeholder without CG
+bool index_record(Rec& r, const uint8_t* d, bool* long_bad) {
+  const uint8_t* q = &d[r.off];
+  r.ref_id = rdi32(q); r.pos = rdi32(q + 4); r.l_rn = q[8]; r.mapq = q[9];
+  r.n_cig = r.n_cig_core = rd16(q + 12); r.flag = rd16(q + 14); r.l_seq = rdi32(q + 16);
+  const uint64_t need = 32ull + r.l_rn + 4ull * r.n_cig + (uint64_t)((r.l_seq + 1) / 2) + (uint64_t)r.l_seq;
+  if (r.l_seq < 0 || r.l_rn == 0 || need > r.size) return false;
+  if (!aux_scan(q + need, q + r.size, r, d)) return false;
+  const uint8_t* cg = q + 32 + r.l_rn;
+  r.cig_at = r.off + 32 + r.l_rn;
+  // long CIGAR (> 65535 ops; SAM spec 4.2.2, applied by htslib when it reads a record): the core field holds the
+  // placeholder <l_seq>S<ref_len>N and the real CIGAR travels in the CG:B,I tag
+  if (r.n_cig == 2 && (rd32(cg) & 15) == 4 && (int64_t)(rd32(cg) >> 4) == (int64_t)r.l_seq && (rd32(cg + 4) & 15) == 3) {
+    if (!r.cg_tag_n) { *long_bad = true; return false; }
+    cg = d + r.cg_tag_at; r.cig_at = r.cg_tag_at; r.n_cig = r.cg_tag_n;
+  }
+  int64_t rl = 0;
+  for (uint32_t k = 0; k < r.n_cig; k++) {
+    const uint32_t w = rd32(cg + 4 * k), op = w & 15;
+    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += w >> 4;   // M D N = X consume the reference
+  }
+  r.ref_len = (int32_t)rl;
+  r.lead = r.trail = 0;
+  if (r.n_cig) {   // leading / trailing soft clips, looking past one hard clip
+    const uint32_t w0 = rd32(cg), wl = rd32(cg + 4 * (r.n_cig - 1));
+    if ((w0 & 15) == 4) r.lead = (int32_t)(w0 >> 4);
+    else if ((w0 & 15) == 5 && r.n_cig > 1 && (rd32(cg + 4) & 15) == 4) r.lead = (int32_t)(rd32(cg + 4) >> 4);
+    if ((wl & 15) == 4) r.trail = (int32_t)(wl >> 4);
+    else if ((wl & 15) == 5 && r.n_cig > 1 && (rd32(cg + 4 * (r.n_cig - 2)) & 15) == 4) r.trail = (int32_t)(rd32(cg + 4 * (r.n_cig - 2)) >> 4);
+  }
+  return true;
+}
+
+// make contig ref_id (-1: the unmapped tail) the resident one: inflate its blocks, index its records
+int load_contig(lcr_bam* b, int32_t ref_id) {
+  if (b->cur_ref == ref_id) return LCR_OK;
+  b->cur_ref = INT32_MIN;
+  b->recs.clear(); b->data.reset(); b->data_size = 0;
+  const size_t ci = (size_t)((int64_t)ref_id + 1);
+  if (ref_id < -1 || ci >= b->ctg_n.size() || b->ctg_n[ci] == 0) { b->cur_ref = ref_id; note_resident(b, 0); return LCR_OK; }   // no records
+  const uint64_t u0 = b->ctg_u0[ci], u1 = b->ctg_u1[ci];
+  // blocks that cover [u0, u1)
+  size_t b0 = (size_t)(std::upper_bound(b->blks.begin(), b->blks.end(), u0, [](uint64_t u, const Blk& k) { return u < k.uoff + k.isize; }) - b->blks.begin());
+  size_t b1 = (size_t)(std::lower_bound(b->blks.begin(), b->blks.end(), u1, [](const Blk& k, uint64_t u) { return k.uoff < u; }) - b->blks.begin());
+  if (b0 >= b1) return fail(b, LCR_E_ARG, "inconsistent contig range");
+  const uint64_t base = b->blks[b0].uoff, bytes = b->blks[b1 - 1].uoff + b->blks[b1 - 1].isize - base;
+  b->data.reset(new (std::nothrow) uint8_t[(size_t)bytes + 1]);
+  if (!b->data) return fail(b, LCR_E_NOMEM, "out of memory for the inflated contig");
+  b->data_size = (size_t)bytes;
+  if (inflate_blocks(b, b0, b1, b->data.get(), b->n_threads) >= 0) return fail(b, LCR_E_ARG, "BGZF block does not inflate / CRC mismatch");
+  const uint8_t* d = b->data.get();
+  try { b->recs.reserve((size_t)b->ctg_n[ci]); } catch (...) { return fail(b, LCR_E_NOMEM, "out of memory for the record index"); }
+  for (size_t p = (size_t)(u0 - base), e = (size_t)(u1 - base); p < e;) {
+    const uint32_t bs = rd32(&d[p]);
+    if (bs < 32 || p + 4 + (size_t)bs > e) return fail(b, LCR_E_ARG, "truncated record");
+    if (rdi32(&d[p + 4]) == ref_id) { Rec r{}; r.off = p + 4; r.size = bs; b->recs.push_back(r); }   // (an unsorted file interleaves contigs)
+    p += 4 + (size_t)bs;
+  }
+  std::atomic<int64_t> bad_rec{-1}, long_cigar_bad{-1};
+  parallel_for((int64_t)b->recs.size(), b->n_threads, 1024, [&](int64_t i) {
+    bool lb = false;
+    if (!index_record(b->recs[(size_t)i], d, &lb)) { if (lb) long_cigar_bad.store(i); else bad_rec.store(i); }
+  });
+  if (bad_rec.load() >= 0) return fail(b, LCR_E_ARG, "malformed record " + std::to_string(bad_rec.load()) + " of contig " + std::to_string(ref_id));
+  if (long_cigar_bad.load() >= 0)
+    return fail(b, LCR_E_ARG, "record " + std::to_string(long_cigar_bad.load()) + " has the long-CIGAR placeholder (<l_seq>S<n>N) but no CG:B,I tag");
+  b->cur_ref = ref_id;
+  note_resident(b, 0);
+  return LCR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
   if (!path || !out) return LCR_E_ARG;
   *out = nullptr;
@@ -176,29 +306,30 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
   *out = b;   // returned even on failure so that lcr_bam_last_error can explain; the caller closes it
   if (n_threads < 1) n_threads = (int32_t)std::max(1u, std::thread::hardware_concurrency());
   b->n_threads = n_threads;
-  // ---- the compressed file
-  std::vector<uint8_t> raw;
+  // ---- the compressed file: mapped, not read
   {
-    FILE* f = fopen(path, "rb");
-    if (!f) return fail(b, LCR_E_ARG, std::string("cannot open ") + path);
-    if (fseek(f, 0, SEEK_END) != 0) { fclose(f); return fail(b, LCR_E_ARG, "seek failed"); }
-    const long sz = ftell(f);
-    if (sz < 0) { fclose(f); return fail(b, LCR_E_ARG, "tell failed"); }
-    rewind(f);
-    try { raw.resize((size_t)sz); } catch (...) { fclose(f); return fail(b, LCR_E_NOMEM, "out of memory reading the file"); }
-    const size_t got = sz ? fread(raw.data(), 1, (size_t)sz, f) : 0;
-    fclose(f);
-    if (got != (size_t)sz) return fail(b, LCR_E_ARG, "short read");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(b, LCR_E_ARG, std::string("cannot open ") + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 0) { close(fd); return fail(b, LCR_E_ARG, "stat failed"); }
+    b->mm_size = (size_t)st.st_size;
+    if (b->mm_size) {
+      void* m = mmap(nullptr, b->mm_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m == MAP_FAILED) { close(fd); b->mm_size = 0; return fail(b, LCR_E_ARG, std::string("cannot map ") + path); }
+      b->mm = static_cast<const uint8_t*>(m);
+    }
+    close(fd);
   }
+  const uint8_t* raw = b->mm;
+  const size_t raw_size = b->mm_size;
   // ---- BGZF block table (gzip member with the BC extra subfield; SAM spec 4.1)
-  struct Blk { size_t coff, clen; uint32_t crc, isize; uint64_t uoff; };
-  std::vector<Blk> blks;
+  std::vector<Blk>& blks = b->blks;
   uint64_t total = 0;
-  for (size_t off = 0; off < raw.size();) {
-    if (off + 18 > raw.size() || raw[off] != 0x1f || raw[off + 1] != 0x8b || raw[off + 2] != 8 || !(raw[off + 3] & 4))
+  for (size_t off = 0; off < raw_size;) {
+    if (off + 18 > raw_size || raw[off] != 0x1f || raw[off + 1] != 0x8b || raw[off + 2] != 8 || !(raw[off + 3] & 4))
       return fail(b, LCR_E_ARG, "not a BGZF block at offset " + std::to_string(off));
     const size_t xlen = rd16(&raw[off + 10]);
-    if (off + 12 + xlen > raw.size()) return fail(b, LCR_E_ARG, "truncated BGZF header");
+    if (off + 12 + xlen > raw_size) return fail(b, LCR_E_ARG, "truncated BGZF header");
     int64_t bsize = -1;
     for (size_t p = off + 12; p + 4 <= off + 12 + xlen;) {
       const size_t slen = rd16(&raw[p + 2]);
@@ -207,99 +338,96 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
     }
     if (bsize < 0) return fail(b, LCR_E_ARG, "BGZF block without BC subfield at offset " + std::to_string(off));
     const size_t blen = (size_t)bsize + 1;
-    if (blen < 12 + xlen + 8 || off + blen > raw.size()) return fail(b, LCR_E_ARG, "truncated BGZF block at offset " + std::to_string(off));
+    if (blen < 12 + xlen + 8 || off + blen > raw_size) return fail(b, LCR_E_ARG, "truncated BGZF block at offset " + std::to_string(off));
     Blk k;
-    k.coff = off + 12 + xlen; k.clen = blen - (12 + xlen) - 8;
+    k.coff = off + 12 + xlen; k.clen = (uint32_t)(blen - (12 + xlen) - 8);
     k.crc = rd32(&raw[off + blen - 8]); k.isize = rd32(&raw[off + blen - 4]);
     if (k.isize > 65536) return fail(b, LCR_E_ARG, "BGZF block larger than 64 KiB");
     k.uoff = total; total += k.isize;
     blks.push_back(k);
     off += blen;
   }
-  b->data.reset(new (std::nothrow) uint8_t[(size_t)total + 1]);
-  if (!b->data) return fail(b, LCR_E_NOMEM, "out of memory for the inflated stream");
-  b->data_size = (size_t)total;
-  // ---- inflate: blocks are independent
-  std::atomic<int> bad{-1};
-  parallel_for((int64_t)blks.size(), n_threads, 16, [&](int64_t i) {
-    const Blk& k = blks[(size_t)i];
-    if (k.isize == 0) return;   // EOF marker and other empty blocks
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (inflateInit2(&zs, -15) != Z_OK) { bad.store((int)i); return; }
-    zs.next_in = const_cast<Bytef*>(raw.data() + k.coff); zs.avail_in = (uInt)k.clen;
-    zs.next_out = b->data.get() + k.uoff; zs.avail_out = k.isize;
-    const int rc = inflate(&zs, Z_FINISH);
-    const bool ok = rc == Z_STREAM_END && zs.total_out == k.isize;
-    inflateEnd(&zs);
-    if (!ok || crc32(crc32(0L, Z_NULL, 0), b->data.get() + k.uoff, k.isize) != k.crc) bad.store((int)i);
-  });
-  if (bad.load() >= 0) return fail(b, LCR_E_ARG, "BGZF block " + std::to_string(bad.load()) + " does not inflate / CRC mismatch");
-  raw.clear(); raw.shrink_to_fit();
-  // ---- BAM header (SAM spec 4.2)
-  const uint8_t* const d = b->data.get();
-  const size_t n = b->data_size;
-  if (n < 12 || memcmp(d, "BAM\1", 4) != 0) return fail(b, LCR_E_ARG, "not a BAM file");
-  size_t p = 8 + (size_t)rd32(&d[4]);
-  if (p + 4 > n) return fail(b, LCR_E_ARG, "truncated BAM header");
-  const int32_t n_ref = rdi32(&d[p]);
-  p += 4;
-  if (n_ref < 0) return fail(b, LCR_E_ARG, "bad reference count");
-  for (int32_t i = 0; i < n_ref; i++) {
-    if (p + 4 > n) return fail(b, LCR_E_ARG, "truncated reference table");
-    const uint32_t l_name = rd32(&d[p]);
-    if (l_name == 0 || p + 4 + (size_t)l_name + 4 > n) return fail(b, LCR_E_ARG, "truncated reference table");
-    b->ref_names.emplace_back(reinterpret_cast<const char*>(&d[p + 4]), l_name - 1);
-    b->ref_len.push_back(rdi32(&d[p + 4 + l_name]));
-    p += 8 + l_name;
+  b->total_inflated = total;
+  // ---- one pass over the inflated stream in windows of <= 1024 blocks (64 MiB): CRC check of every block, BAM header,
+  //      the block_size chain of the records -> per contig the range of the stream it occupies and its record count
+  const size_t WIN = 1024;
+  std::vector<uint8_t> buf;       // [carry of the previous window | this window]
+  size_t carry = 0;               // bytes at the front of buf that belong to an unfinished item
+  uint64_t buf_u0 = 0;            // inflated offset of buf[0]
+  bool have_header = false;
+  size_t hp = 0;                  // parse position inside buf
+  for (size_t w0 = 0; w0 < blks.size() || !have_header; w0 += WIN) {
+    const size_t w1 = std::min(blks.size(), w0 + WIN);
+    const size_t wbytes = w0 < blks.size() ? (size_t)(blks[w1 - 1].uoff + blks[w1 - 1].isize - blks[w0].uoff) : 0;
+    try { buf.resize(carry + wbytes + 1); } catch (...) { return fail(b, LCR_E_NOMEM, "out of memory for the scan window"); }
+    b->resident_peak = std::max(b->resident_peak, (int64_t)buf.size());
+    if (wbytes) {
+      const int64_t badb = inflate_blocks(b, w0, w1, buf.data() + carry, n_threads);
+      if (badb >= 0) return fail(b, LCR_E_ARG, "BGZF block " + std::to_string(badb) + " does not inflate / CRC mismatch");
+    }
+    const size_t n = carry + wbytes;
+    const uint8_t* d = buf.data();
+    const bool last = w1 >= blks.size();
+    size_t p = hp;
+    if (!have_header) {   // BAM header (SAM spec 4.2): may span windows, is parsed when it is complete
+      bool complete = false;
+      do {
+        if (n < 12) break;
+        if (memcmp(d, "BAM\1", 4) != 0) return fail(b, LCR_E_ARG, "not a BAM file");
+        size_t q = 8 + (size_t)rd32(&d[4]);
+        if (q + 4 > n) break;
+        const int32_t n_ref = rdi32(&d[q]);
+        q += 4;
+        if (n_ref < 0) return fail(b, LCR_E_ARG, "bad reference count");
+        std::vector<std::string> names; std::vector<int64_t> lens;
+        bool ok = true;
+        for (int32_t i = 0; i < n_ref; i++) {
+          if (q + 4 > n) { ok = false; break; }
+          const uint32_t l_name = rd32(&d[q]);
+          if (l_name == 0) return fail(b, LCR_E_ARG, "truncated reference table");
+          if (q + 4 + (size_t)l_name + 4 > n) { ok = false; break; }
+          names.emplace_back(reinterpret_cast<const char*>(&d[q + 4]), l_name - 1);
+          lens.push_back(rdi32(&d[q + 4 + l_name]));
+          q += 8 + l_name;
+        }
+        if (!ok) break;
+        b->ref_names = names; b->ref_len = lens;
+        b->header_size = q; b->header.assign(d, d + q);
+        complete = true;
+        p = q;
+      } while (false);
+      if (!complete) {
+        if (last) return fail(b, LCR_E_ARG, n < 12 || memcmp(d, "BAM\1", 4) != 0 ? "not a BAM file" : "truncated BAM header");
+        carry = n; hp = 0;   // keep everything, read on
+        continue;
+      }
+      have_header = true;
+      for (auto& s : b->ref_names) b->ref_name_ptrs.push_back(s.c_str());
+      b->ctg_u0.assign(b->ref_names.size() + 1, UINT64_MAX); b->ctg_u1.assign(b->ref_names.size() + 1, 0); b->ctg_n.assign(b->ref_names.size() + 1, 0);
+    }
+    // ---- records of this window
+    while (p < n) {
+      if (p + 4 > n) { if (last) return fail(b, LCR_E_ARG, "truncated record header"); break; }
+      const uint32_t bs = rd32(&d[p]);
+      if (bs < 32) return fail(b, LCR_E_ARG, "truncated record at inflated offset " + std::to_string(buf_u0 + p));
+      if (p + 4 + (size_t)bs > n) { if (last) return fail(b, LCR_E_ARG, "truncated record at inflated offset " + std::to_string(buf_u0 + p)); break; }
+      const int32_t rid = rdi32(&d[p + 4]);
+      const int64_t ci = (int64_t)rid + 1;
+      if (ci < 0 || (size_t)ci >= b->ctg_n.size()) return fail(b, LCR_E_ARG, "malformed record " + std::to_string(b->n_records) + ": reference id out of range");
+      b->ctg_u0[(size_t)ci] = std::min(b->ctg_u0[(size_t)ci], buf_u0 + p);
+      b->ctg_u1[(size_t)ci] = std::max(b->ctg_u1[(size_t)ci], buf_u0 + p + 4 + bs);
+      b->ctg_n[(size_t)ci]++; b->n_records++;
+      p += 4 + (size_t)bs;
+    }
+    // the unfinished tail moves to the front of the next window
+    carry = n - p;
+    if (carry) memmove(buf.data(), buf.data() + p, carry);
+    buf_u0 += p; hp = 0;
+    if (last) break;
   }
-  for (auto& s : b->ref_names) b->ref_name_ptrs.push_back(s.c_str());
-  b->header_size = p;
-  // ---- record index: the block_size chain is sequential, the records' fields are not
-  while (p < n) {
-    if (p + 4 > n) return fail(b, LCR_E_ARG, "truncated record header");
-    const uint32_t bs = rd32(&d[p]);
-    if (bs < 32 || p + 4 + (size_t)bs > n) return fail(b, LCR_E_ARG, "truncated record at inflated offset " + std::to_string(p));
-    Rec r{};
-    r.off = p + 4; r.size = bs;
-    b->recs.push_back(r);
-    p += 4 + (size_t)bs;
-  }
-  std::atomic<int64_t> bad_rec{-1}, long_cigar_bad{-1};
-  parallel_for((int64_t)b->recs.size(), n_threads, 1024, [&](int64_t i) {
-    Rec& r = b->recs[(size_t)i];
-    const uint8_t* q = &d[r.off];
-    r.ref_id = rdi32(q); r.pos = rdi32(q + 4); r.l_rn = q[8]; r.mapq = q[9];
-    r.n_cig = r.n_cig_core = rd16(q + 12); r.flag = rd16(q + 14); r.l_seq = rdi32(q + 16);
-    const uint64_t need = 32ull + r.l_rn + 4ull * r.n_cig + (uint64_t)((r.l_seq + 1) / 2) + (uint64_t)r.l_seq;
-    if (r.l_seq < 0 || r.l_rn == 0 || need > r.size) { bad_rec.store(i); return; }
-    if (!aux_scan(q + need, q + r.size, r, d)) { bad_rec.store(i); return; }
-    const uint8_t* cg = q + 32 + r.l_rn;
-    r.cig_at = r.off + 32 + r.l_rn;
-    // long CIGAR (> 65535 ops; SAM spec 4.2.2, applied by htslib when it reads a record): the core field holds the
-    // placeholder <l_seq>S<ref_len>N and the real CIGAR travels in the CG:B,I tag
-    if (r.n_cig == 2 && (rd32(cg) & 15) == 4 && (int64_t)(rd32(cg) >> 4) == (int64_t)r.l_seq && (rd32(cg + 4) & 15) == 3) {
-      if (!r.cg_tag_n) { long_cigar_bad.store(i); return; }
-      cg = d + r.cg_tag_at; r.cig_at = r.cg_tag_at; r.n_cig = r.cg_tag_n;
-    }
-    int64_t rl = 0;
-    for (uint32_t k = 0; k < r.n_cig; k++) {
-      const uint32_t w = rd32(cg + 4 * k), op = w & 15;
-      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += w >> 4;   // M D N = X consume the reference
-    }
-    r.ref_len = (int32_t)rl;
-    r.lead = r.trail = 0;
-    if (r.n_cig) {   // leading / trailing soft clips, looking past one hard clip
-      const uint32_t w0 = rd32(cg), wl = rd32(cg + 4 * (r.n_cig - 1));
-      if ((w0 & 15) == 4) r.lead = (int32_t)(w0 >> 4);
-      else if ((w0 & 15) == 5 && r.n_cig > 1 && (rd32(cg + 4) & 15) == 4) r.lead = (int32_t)(rd32(cg + 4) >> 4);
-      if ((wl & 15) == 4) r.trail = (int32_t)(wl >> 4);
-      else if ((wl & 15) == 5 && r.n_cig > 1 && (rd32(cg + 4 * (r.n_cig - 2)) & 15) == 4) r.trail = (int32_t)(rd32(cg + 4 * (r.n_cig - 2)) >> 4);
-    }
-  });
-  if (bad_rec.load() >= 0) return fail(b, LCR_E_ARG, "malformed record " + std::to_string(bad_rec.load()));
-  if (long_cigar_bad.load() >= 0)
-    return fail(b, LCR_E_ARG, "record " + std::to_string(long_cigar_bad.load()) + " has the long-CIGAR placeholder (<l_seq>S<n>N) but no CG:B,I tag");
+  // malformed fixed fields / aux blocks are reported at open, as before: every contig is loaded once (bounded: one at a time)
+  for (size_t ci = 0; ci < b->ctg_n.size(); ci++)
+    if (b->ctg_n[ci]) { const int rc = load_contig(b, (int32_t)ci - 1); if (rc != LCR_OK) return rc; }
   return LCR_OK;
 }
 
@@ -317,12 +445,19 @@ int lcr_bam_refs(lcr_bam* b, int32_t* n_ref, const char* const** names, const in
 
 int lcr_bam_n_records(lcr_bam* b, int64_t* n) {
   if (!b || !n) return LCR_E_ARG;
-  *n = (int64_t)b->recs.size();
+  *n = b->n_records;
+  return LCR_OK;
+}
+
+int lcr_bam_resident(lcr_bam* b, int64_t* now, int64_t* peak) {
+  if (!b || !now || !peak) return LCR_E_ARG;
+  *now = b->resident_now; *peak = b->resident_peak;
   return LCR_OK;
 }
 
 int lcr_bam_spans(lcr_bam* b, int32_t ref_id, const lcr_read_filter* f, int32_t* n, const int32_t** ref_start, const int32_t** ref_end) {
   if (!b || !f || !n || !ref_start || !ref_end) return LCR_E_ARG;
+  { const int rc = load_contig(b, ref_id); if (rc != LCR_OK) return rc; }
   b->sp_start.clear(); b->sp_end.clear();
   for (const Rec& r : b->recs)
     if (r.ref_id == ref_id && passes(r, *f)) { b->sp_start.push_back(r.pos); b->sp_end.push_back(end_pos(r)); }
@@ -334,6 +469,7 @@ int lcr_bam_spans(lcr_bam* b, int32_t ref_id, const lcr_read_filter* f, int32_t*
 int lcr_bam_batch(lcr_bam* b, int32_t ref_id, const lcr_read_filter* f, int32_t n_regions, const int64_t* start0, const int32_t* len,
                   lcr_reads* reads, const int32_t** read_begin, const uint64_t** name_off, const char** names) {
   if (!b || !f || !reads || !read_begin || n_regions < 0 || (n_regions && (!start0 || !len))) return LCR_E_ARG;
+  { const int rc = load_contig(b, ref_id); if (rc != LCR_OK) return rc; }
   // passing records of the contig, by position (file order for a sorted file), with a running maximum of their ends
   std::vector<uint32_t> idx;
   for (size_t i = 0; i < b->recs.size(); i++)
@@ -419,102 +555,115 @@ int lcr_bam_write_phased(lcr_bam* b, const char* out_path, int32_t n_regions, co
     if (hp[i] >= 0) m_hp.emplace(nm, hp[i]);
     if (ps[i] != 0) m_ps.emplace(nm, ps[i]);
   }
+  // ---- output: BGZF blocks of 0xff00 inflated bytes (htslib's BGZF_BLOCK_SIZE), deflated in parallel and written in
+  //      chunks of 256 blocks; the payload is the header as in the input, then the records with HP:i (int32) / PS:I
+  //      (uint32) appended to their aux blocks
+  FILE* f = fopen(out_path, "wb");
+  if (!f) return fail(b, LCR_E_ARG, std::string("cannot create ") + out_path);
+  const uint64_t BLK = 0xff00;
+  const size_t CHUNK_BLOCKS = 256;
+  std::vector<uint8_t> pend;   // inflated bytes not written yet
+  pend.reserve(std::max<size_t>(b->header.size(), CHUNK_BLOCKS * (size_t)BLK) + (1u << 20));
+  pend.assign(b->header.begin(), b->header.end());
+  std::vector<std::vector<uint8_t>> comp;
+  bool io_ok = true;
+  auto flush = [&](bool final_) -> bool {   // writes the complete blocks of `pend` (all of it, and the EOF block, at the end)
+    const size_t nfull = pend.size() / BLK;
+    const size_t nblk = final_ ? (pend.size() + BLK - 1) / BLK : nfull;
+    const size_t n_out = nblk + (final_ ? 1 : 0);
+    if (n_out == 0) return true;
+    comp.assign(n_out, {});
+    std::atomic<int> bad{0};
+    parallel_for((int64_t)n_out, n_threads, 4, [&](int64_t i) {
+      const uint64_t off = (uint64_t)i * BLK;
+      const uint32_t n = (size_t)i >= nblk ? 0u : (uint32_t)std::min<uint64_t>(BLK, pend.size() - off);
+      std::vector<uint8_t>& c = comp[(size_t)i];
+      c.resize(18 + compressBound(n) + 8);
+      z_stream zs;
+      memset(&zs, 0, sizeof(zs));
+      if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad.store(1); return; }
+      zs.next_in = n ? pend.data() + off : nullptr; zs.avail_in = n;
+      zs.next_out = c.data() + 18; zs.avail_out = (uInt)(c.size() - 18 - 8);
+      const int rc = deflate(&zs, Z_FINISH);
+      const size_t clen = zs.total_out;
+      deflateEnd(&zs);
+      if (rc != Z_STREAM_END || 18 + clen + 8 > 65536) { bad.store(1); return; }
+      static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+      memcpy(c.data(), head, 16);
+      const uint32_t bsize = (uint32_t)(18 + clen + 8 - 1);
+      c[16] = (uint8_t)bsize; c[17] = (uint8_t)(bsize >> 8);
+      const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), n ? pend.data() + off : nullptr, n);
+      uint8_t* t = c.data() + 18 + clen;
+      t[0] = (uint8_t)crc; t[1] = (uint8_t)(crc >> 8); t[2] = (uint8_t)(crc >> 16); t[3] = (uint8_t)(crc >> 24);
+      t[4] = (uint8_t)n; t[5] = (uint8_t)(n >> 8); t[6] = (uint8_t)(n >> 16); t[7] = (uint8_t)(n >> 24);
+      c.resize(18 + clen + 8);
+    });
+    if (bad.load()) return false;
+    for (auto& c : comp) io_ok = io_ok && fwrite(c.data(), 1, c.size(), f) == c.size();
+    const size_t done = std::min(pend.size(), nblk * (size_t)BLK);
+    pend.erase(pend.begin(), pend.begin() + (ptrdiff_t)done);
+    return true;
+  };
   // records per contig by position with a running maximum of their ends (all records: the writer's fetch has no
-  // mapq / length filter, thread.rs:337-340)
-  const uint8_t* d = b->data.get();
-  struct Out { uint32_t rec; int32_t hp; uint32_t ps; uint8_t add_hp, add_ps; uint64_t at; };
-  std::vector<Out> outs;
-  std::vector<uint32_t> idx;
+  // mapq / length filter, thread.rs:337-340); the contig's inflated bytes are loaded when a region needs them
   std::vector<int32_t> ipos, iend_max;
   int32_t cur_ref = INT32_MIN;
-  for (int32_t g = 0; g < n_regions; g++) {
-    if (len[g] < 0) return fail(b, LCR_E_ARG, "negative region length");
-    if (region_ref[g] != cur_ref) {
+  int rc_all = LCR_OK;
+  for (int32_t g = 0; g < n_regions && rc_all == LCR_OK; g++) {
+    if (len[g] < 0) { rc_all = fail(b, LCR_E_ARG, "negative region length"); break; }
+    if (region_ref[g] != cur_ref || b->cur_ref != region_ref[g]) {
       cur_ref = region_ref[g];
-      idx.clear(); ipos.clear(); iend_max.clear();
+      if ((rc_all = load_contig(b, cur_ref)) != LCR_OK) break;
+      ipos.clear(); iend_max.clear();
       int32_t run = INT32_MIN;
-      for (size_t i = 0; i < b->recs.size(); i++) {
-        const Rec& r = b->recs[i];
-        if (r.ref_id != cur_ref) continue;
-        if (!ipos.empty() && r.pos < ipos.back()) return fail(b, LCR_E_ARG, "BAM is not coordinate-sorted");
-        idx.push_back((uint32_t)i); ipos.push_back(r.pos);
+      for (const Rec& r : b->recs) {
+        if (!ipos.empty() && r.pos < ipos.back()) { rc_all = fail(b, LCR_E_ARG, "BAM is not coordinate-sorted"); break; }
+        ipos.push_back(r.pos);
         run = std::max(run, end_pos(r)); iend_max.push_back(run);
       }
+      if (rc_all != LCR_OK) break;
     }
+    const uint8_t* d = b->data.get();
     const int64_t beg = start0[g] + 1, end = start0[g] + len[g] + 1;   // fetch((chr, start, end)), thread.rs:332-334
     const size_t hi = (size_t)(std::lower_bound(ipos.begin(), ipos.end(), end, [](int32_t v, int64_t e) { return (int64_t)v < e; }) - ipos.begin());
     size_t lo = (size_t)(std::upper_bound(iend_max.begin(), iend_max.end(), beg, [](int64_t bg, int32_t v) { return bg < (int64_t)v; }) - iend_max.begin());
     for (; lo < hi; lo++) {
-      const Rec& r = b->recs[idx[lo]];
+      const Rec& r = b->recs[lo];
       if ((int64_t)end_pos(r) <= beg) continue;
       if (r.flag & (0x4 | 0x100 | 0x800)) continue;                                      // thread.rs:337-339
       // reference_start + 1 < region.start || reference_end + 1 > region.end -> skipped (thread.rs:340-345);
       // reference_end is htslib's bam_endpos
       if ((int64_t)r.pos + 1 < beg || (int64_t)end_pos(r) + 1 > end) continue;
-      Out o{idx[lo], 0, 0, 0, 0, 0};
       const uint8_t* q = d + r.off;
       const std::string nm(reinterpret_cast<const char*>(q + 32));
       const uint64_t fixed = 32ull + r.l_rn + 4ull * r.n_cig_core + (uint64_t)((r.l_seq + 1) / 2) + (uint64_t)r.l_seq;
+      int32_t add_hp = 0, hpv = 0; uint32_t add_ps = 0, psv = 0;
       auto fh = m_hp.find(nm);
-      if (fh != m_hp.end() && fh->second != 0 && !aux_has(q + fixed, q + r.size, 'H', 'P')) { o.add_hp = 1; o.hp = fh->second; }   // thread.rs:347-352
+      if (fh != m_hp.end() && fh->second != 0 && !aux_has(q + fixed, q + r.size, 'H', 'P')) { add_hp = 1; hpv = fh->second; }   // thread.rs:347-352
       auto fp = m_ps.find(nm);
-      if (fp != m_ps.end() && !aux_has(q + fixed, q + r.size, 'P', 'S')) { o.add_ps = 1; o.ps = fp->second; }                         // thread.rs:353-356
-      outs.push_back(o);
+      if (fp != m_ps.end() && !aux_has(q + fixed, q + r.size, 'P', 'S')) { add_ps = 1; psv = fp->second; }                         // thread.rs:353-356
+      const uint32_t bs = r.size + 7u * (uint32_t)add_hp + 7u * add_ps;
+      const size_t at = pend.size();
+      pend.resize(at + 4 + bs);
+      uint8_t* w = pend.data() + at;
+      w[0] = (uint8_t)bs; w[1] = (uint8_t)(bs >> 8); w[2] = (uint8_t)(bs >> 16); w[3] = (uint8_t)(bs >> 24);
+      memcpy(w + 4, q, r.size);
+      w += 4 + r.size;
+      if (add_hp) { w[0] = 'H'; w[1] = 'P'; w[2] = 'i'; const uint32_t x = (uint32_t)hpv; w[3] = (uint8_t)x; w[4] = (uint8_t)(x >> 8); w[5] = (uint8_t)(x >> 16); w[6] = (uint8_t)(x >> 24); w += 7; }
+      if (add_ps) { w[0] = 'P'; w[1] = 'S'; w[2] = 'I'; const uint32_t x = psv; w[3] = (uint8_t)x; w[4] = (uint8_t)(x >> 8); w[5] = (uint8_t)(x >> 16); w[6] = (uint8_t)(x >> 24); }
+      if (pend.size() >= CHUNK_BLOCKS * (size_t)BLK) {
+        note_resident(b, (int64_t)pend.capacity());
+        if (!flush(false)) { rc_all = fail(b, LCR_E_ARG, "deflate failed"); break; }
+      }
     }
   }
-  // ---- payload: header as in the input, then the records with HP:i (int32) / PS:I (uint32) appended to the aux block
-  uint64_t total = b->header_size;
-  for (Out& o : outs) { o.at = total; total += 4ull + b->recs[o.rec].size + 7ull * o.add_hp + 7ull * o.add_ps; }
-  std::unique_ptr<uint8_t[]> pay(new (std::nothrow) uint8_t[(size_t)total + 1]);
-  if (!pay) return fail(b, LCR_E_NOMEM, "out of memory for the output stream");
-  memcpy(pay.get(), d, b->header_size);
-  parallel_for((int64_t)outs.size(), n_threads, 512, [&](int64_t i) {
-    const Out& o = outs[(size_t)i];
-    const Rec& r = b->recs[o.rec];
-    uint8_t* w = pay.get() + o.at;
-    const uint32_t bs = r.size + 7u * o.add_hp + 7u * o.add_ps;
-    w[0] = (uint8_t)bs; w[1] = (uint8_t)(bs >> 8); w[2] = (uint8_t)(bs >> 16); w[3] = (uint8_t)(bs >> 24);
-    memcpy(w + 4, d + r.off, r.size);
-    w += 4 + r.size;
-    if (o.add_hp) { w[0] = 'H'; w[1] = 'P'; w[2] = 'i'; const uint32_t v = (uint32_t)o.hp; w[3] = (uint8_t)v; w[4] = (uint8_t)(v >> 8); w[5] = (uint8_t)(v >> 16); w[6] = (uint8_t)(v >> 24); w += 7; }
-    if (o.add_ps) { w[0] = 'P'; w[1] = 'S'; w[2] = 'I'; const uint32_t v = o.ps; w[3] = (uint8_t)v; w[4] = (uint8_t)(v >> 8); w[5] = (uint8_t)(v >> 16); w[6] = (uint8_t)(v >> 24); }
-  });
-  // ---- BGZF: 0xff00-byte blocks (htslib's BGZF_BLOCK_SIZE), deflated in parallel, then the empty EOF block
-  const uint64_t BLK = 0xff00;
-  const size_t nblk = (size_t)((total + BLK - 1) / BLK);
-  std::vector<std::vector<uint8_t>> comp(nblk + 1);
-  std::atomic<int> bad{0};
-  parallel_for((int64_t)nblk + 1, n_threads, 4, [&](int64_t i) {
-    const uint64_t off = (uint64_t)i * BLK;
-    const uint32_t n = (size_t)i == nblk ? 0u : (uint32_t)std::min<uint64_t>(BLK, total - off);
-    std::vector<uint8_t>& c = comp[(size_t)i];
-    c.resize(18 + compressBound(n) + 8);
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad.store(1); return; }
-    zs.next_in = pay.get() + off; zs.avail_in = n;
-    zs.next_out = c.data() + 18; zs.avail_out = (uInt)(c.size() - 18 - 8);
-    const int rc = deflate(&zs, Z_FINISH);
-    const size_t clen = zs.total_out;
-    deflateEnd(&zs);
-    if (rc != Z_STREAM_END || 18 + clen + 8 > 65536) { bad.store(1); return; }
-    static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-    memcpy(c.data(), head, 16);
-    const uint32_t bsize = (uint32_t)(18 + clen + 8 - 1);
-    c[16] = (uint8_t)bsize; c[17] = (uint8_t)(bsize >> 8);
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), pay.get() + off, n);
-    uint8_t* t = c.data() + 18 + clen;
-    t[0] = (uint8_t)crc; t[1] = (uint8_t)(crc >> 8); t[2] = (uint8_t)(crc >> 16); t[3] = (uint8_t)(crc >> 24);
-    t[4] = (uint8_t)n; t[5] = (uint8_t)(n >> 8); t[6] = (uint8_t)(n >> 16); t[7] = (uint8_t)(n >> 24);
-    c.resize(18 + clen + 8);
-  });
-  if (bad.load()) return fail(b, LCR_E_ARG, "deflate failed");
-  FILE* f = fopen(out_path, "wb");
-  if (!f) return fail(b, LCR_E_ARG, std::string("cannot create ") + out_path);
-  bool ok = true;
-  for (auto& c : comp) ok = ok && fwrite(c.data(), 1, c.size(), f) == c.size();
-  ok = (fclose(f) == 0) && ok;
-  if (!ok) return fail(b, LCR_E_ARG, std::string("write failed: ") + out_path);
+  if (rc_all == LCR_OK) {
+    note_resident(b, (int64_t)pend.capacity());
+    if (!flush(true)) rc_all = fail(b, LCR_E_ARG, "deflate failed");
+  }
+  io_ok = (fclose(f) == 0) && io_ok;
+  if (rc_all != LCR_OK) return rc_all;
+  if (!io_ok) return fail(b, LCR_E_ARG, std::string("write failed: ") + out_path);
   return LCR_OK;
 }
 

@@ -75,9 +75,43 @@ def write_vcf(path, contig_lengths, body_lines):
         f.writelines(body_lines)
 
 
+def chunk_regions(regions, max_cost=2.0e9, max_cols=2.0e8, max_regions=8192):
+    """Cut a contig's regions [(start0, len, max_cov)] into consecutive chunks whose estimated work (sum of
+    len x max_coverage, an upper bound of the aligned bases) and column count stay below the budgets: liblcr's
+    per-batch limits (32-bit record pool, 2^31 reads, 2^28 matrix entries) then never surface as a failed run.
+    Results are independent of batch composition, so the cut changes nothing in the output."""
+    chunks, cur, cost, cols = [], [], 0.0, 0
+    for r in regions:
+        c = float(r[1]) * max(int(r[2]), 1)
+        if cur and (cost + c > max_cost or cols + r[1] > max_cols or len(cur) >= max_regions):
+            chunks.append(cur)
+            cur, cost, cols = [], 0.0, 0
+        cur.append(r)
+        cost += c
+        cols += r[1]
+    if cur:
+        chunks.append(cur)
+    return chunks
+
+
+def _gather_names(name_off, blob, rows):
+    """(name_off, blob) of the reads `rows` out of a batch's name blob, without a Python object per read"""
+    off = name_off.astype(np.int64)
+    lens = off[rows + 1] - off[rows]
+    new_off = np.zeros(rows.size + 1, dtype=np.int64)
+    np.cumsum(lens, out=new_off[1:])
+    idx = np.repeat(off[rows] - new_off[:-1], lens) + np.arange(int(new_off[-1]))
+    return new_off.astype(np.uint64), blob[idx]
+
+
 def run(bam_path, ref_path, out_vcf, out_bam=None, preset="hifi-masseq", contigs=None, device=0, threads=0, seed=2025,
-        read_filter=None, **param_overrides):
-    """BAM + FASTA (+ .fai) -> phased VCF and, with out_bam, the phased BAM.  Returns a dict of counts."""
+        read_filter=None, devices=None, chunk_cost=2.0e9, **param_overrides):
+    """BAM + FASTA (+ .fai) -> phased VCF and, with out_bam, the phased BAM.  Returns a dict of counts.
+    devices: GPUs to use (default [device]); a contig's regions are cut into chunks (chunk_regions) that the engines --
+    one context and one host thread per device -- take in turn (regions are independent units, thread.rs:77; the BAM
+    decoder cuts the batches on the calling thread).  The output does not depend on devices or chunk_cost."""
+    from concurrent.futures import ThreadPoolExecutor
+    import threading
     fai = ref_path + ".fai"
     if not os.path.exists(fai):
         raise FileNotFoundError("Reference index file .fai does not exist.")   # util.rs:575-577
@@ -88,46 +122,79 @@ def run(bam_path, ref_path, out_vcf, out_bam=None, preset="hifi-masseq", contigs
     params = _abi.make_params(preset, seed=seed, **param_overrides)
     nb = bamio.NativeBam(bam_path, threads)
     bam_ids = {n: i for i, (n, _) in enumerate(nb.refs)}
-    E = api.Engine(device, params)
-    body, regions_out, names_out, hp_out, ps_out = [], [], [], [], []
-    stats = dict(contigs=0, regions=0, reads=0, candidates=0, vcf_records=0)
-    for name, length in contig_lengths:
-        if contigs is not None and name not in contigs:
-            continue
-        if name not in bam_ids or name not in refs:
-            continue
-        rid = bam_ids[name]
-        rs, re_ = nb.spans(rid, **flt)
-        if rs.size == 0:
-            continue
-        regions = E.discover_regions(rs, re_, length)     # util.rs:236-332
-        if not regions:
-            continue
-        ref = refs[name]
-        wins = [ref[s:s + l] if s + l <= ref.size else np.concatenate([ref[s:], np.full(s + l - ref.size, ord("N"), np.uint8)])
-                for s, l, _ in regions]
-        batch = nb.batch(rid, [(s, l) for s, l, _ in regions], wins, **flt)
-        E.load_batch(batch).run_all()
-        cands, off = E.candidates()
-        lines = vcf.format_records(cands, name, params.min_phase_score)
-        body.append(lines if isinstance(lines, str) else "".join(lines))
-        stats["contigs"] += 1; stats["regions"] += len(regions); stats["reads"] += batch.n_reads
-        stats["candidates"] += int(cands.size)
-        if out_bam is not None:
-            fm, pr = E.fragmat(), E.phase_result()
-            asg = pr["assignment"].astype(np.int32)
-            # thread.rs:204-214: every for_phasing fragment has an assignment entry (0 / 1 / 2), a phase set only if set
-            hp = np.where((fm["row_for_phasing"] != 0) | (asg != 0), asg, -1)
-            names_out.extend(batch.names[r] for r in fm["row_read"])
-            hp_out.append(hp); ps_out.append(pr["phase_set"])
-            regions_out.extend((rid, s, l) for s, l, _ in regions)
-    E.close()
-    text = "".join(body)
+    devices = list(devices) if devices else [device]
+    engines = [api.Engine(d, params) for d in devices]
+    free = list(range(len(engines)))
+    free_lock = threading.Condition()
+    stats = dict(contigs=0, regions=0, reads=0, candidates=0, vcf_records=0, chunks=0)
+
+    def work(batch, name, want_reads):   # one chunk on whichever engine is free
+        with free_lock:
+            while not free:
+                free_lock.wait()
+            k = free.pop()
+        try:
+            E = engines[k]
+            E.load_batch(batch).run_all()
+            cands, _ = E.candidates()
+            lines = vcf.format_records(cands, name, params.min_phase_score)
+            out = dict(text=lines if isinstance(lines, str) else "".join(lines), n_cand=int(cands.size))
+            if want_reads:
+                fm, pr = E.fragmat(), E.phase_result()
+                asg = pr["assignment"].astype(np.int32)
+                # thread.rs:204-214: every for_phasing fragment has an assignment entry (0 / 1 / 2), a phase set only if set
+                out["hp"] = np.where((fm["row_for_phasing"] != 0) | (asg != 0), asg, -1)
+                out["ps"] = pr["phase_set"]
+                out["names"] = _gather_names(batch.name_off, batch.name_blob, fm["row_read"].astype(np.int64))
+            return out
+        finally:
+            with free_lock:
+                free.append(k)
+                free_lock.notify()
+
+    results, regions_out = [], []
+    with ThreadPoolExecutor(max_workers=len(engines)) as pool:
+        pending = []
+        for name, length in contig_lengths:
+            if contigs is not None and name not in contigs:
+                continue
+            if name not in bam_ids or name not in refs:
+                continue
+            rid = bam_ids[name]
+            rs, re_ = nb.spans(rid, **flt)
+            if rs.size == 0:
+                continue
+            regions = engines[0].discover_regions(rs, re_, length)     # util.rs:236-332
+            if not regions:
+                continue
+            ref = refs[name]
+            stats["contigs"] += 1; stats["regions"] += len(regions)
+            for chunk in chunk_regions(regions, max_cost=chunk_cost):
+                wins = [ref[s:s + l] if s + l <= ref.size else np.concatenate([ref[s:], np.full(s + l - ref.size, ord("N"), np.uint8)])
+                        for s, l, _ in chunk]
+                batch = nb.batch(rid, [(s, l) for s, l, _ in chunk], wins, names="blob", **flt)
+                stats["reads"] += batch.n_reads; stats["chunks"] += 1
+                while len(pending) > len(engines):     # bounded: at most one batch waiting per engine
+                    results.append(pending.pop(0).result())
+                pending.append(pool.submit(work, batch, name, out_bam is not None))
+                regions_out.extend((rid, s, l) for s, l, _ in chunk)
+        results.extend(f.result() for f in pending)
+    for E in engines:
+        E.close()
+    text = "".join(r["text"] for r in results)
+    stats["candidates"] = sum(r["n_cand"] for r in results)
     stats["vcf_records"] = text.count("\n")
     write_vcf(out_vcf, contig_lengths, [text])
     if out_bam is not None:
-        hp = np.concatenate(hp_out) if hp_out else np.zeros(0, np.int32)
-        ps = np.concatenate(ps_out) if ps_out else np.zeros(0, np.uint32)
-        nb.write_phased(out_bam, regions_out, names_out, hp, ps, threads=threads)
+        hp = np.concatenate([r["hp"] for r in results]) if results else np.zeros(0, np.int32)
+        ps = np.concatenate([r["ps"] for r in results]) if results else np.zeros(0, np.uint32)
+        offs, blobs, base = [np.zeros(1, np.uint64)], [], 0
+        for r in results:
+            o, bl = r["names"]
+            offs.append(o[1:] + np.uint64(base)); blobs.append(bl)
+            base += int(o[-1])
+        name_off = np.concatenate(offs)
+        blob = np.concatenate(blobs) if blobs else np.zeros(0, np.uint8)
+        nb.write_phased(out_bam, regions_out, (name_off, blob), hp, ps, threads=threads)
     nb.close()
     return stats

@@ -162,6 +162,78 @@ def test_long_cigar_in_the_cg_tag(tmp_path):
         bamio.NativeBam(bad, 1)
 
 
+def test_decoder_holds_one_contig_at_a_time(tmp_path):
+    """The file is mapped and only ONE contig's inflated bytes + record index are resident (the reference streams region
+    by region through the .bai): three contigs made of 20 / 10 / 5 copies of demo.bam's records (128 MB inflated) never
+    need more than the largest contig (+ its index) or the 64 MiB scan window; batches and the phased-BAM writer give
+    what the all-in-memory restatement gives."""
+    src = os.path.join(helpers.GOLDEN, "demo.bam")
+    raw = bamio.bgzf_decompress(src)
+    p = 8 + struct.unpack_from("<i", raw, 4)[0]
+    n_ref = struct.unpack_from("<i", raw, p)[0]
+    p += 4
+    for _ in range(n_ref):
+        p += 8 + struct.unpack_from("<i", raw, p)[0]
+    body = bytearray(raw[p:])
+    hdr = b"BAM\1" + struct.pack("<i", 0) + struct.pack("<i", 3)
+    for nm in (b"cA", b"cB", b"cC"):
+        hdr += struct.pack("<i", len(nm) + 1) + nm + b"\0" + struct.pack("<i", 64444167)
+    offs, q = [], 0
+    while q < len(body):
+        offs.append(q)
+        q += 4 + struct.unpack_from("<i", body, q)[0]
+
+    def contig(rid, copies):   # every record `copies` times in a row: still sorted by position
+        out = bytearray()
+        for k, o in enumerate(offs):
+            e = offs[k + 1] if k + 1 < len(offs) else len(body)
+            rec = bytearray(body[o:e])
+            struct.pack_into("<i", rec, 4, rid)
+            out += rec * copies
+        return bytes(out)
+    parts = [contig(0, 20), contig(1, 10), contig(2, 5)]
+    path = str(tmp_path / "three.bam")
+    # (fast deflate: the test is about memory, not compression)
+    payload = hdr + b"".join(parts)
+    blocks = []
+    for off in list(range(0, len(payload), 65280)) + [None]:
+        chunk = b"" if off is None else payload[off:off + 65280]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        cdata = co.compress(chunk) + co.flush()
+        blocks.append(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(cdata) + 8 - 1)
+                      + cdata + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+    open(path, "wb").write(b"".join(blocks))
+    total = len(payload)
+    assert total > 120e6
+    nb = bamio.NativeBam(path, 8)
+    assert nb.n_records == len(offs) * 35
+    now, peak = nb.resident()
+    limit = max(len(parts[0]) * 1.15, 64 * 2 ** 20 + 2 ** 20)     # largest contig + ~80 B per record, or the scan window
+    assert peak <= limit < 0.7 * total, (peak, limit, total)
+    flt = dict(min_mapq=20, min_read_length=500, divergence=0.5)
+    s, e = nb.spans(1, **flt)
+    assert nb.resident()[0] <= len(parts[1]) * 1.2 + 2 ** 20 and len(s) > 10000
+    regions = [(16729960, 13256)]
+    win = [np.full(13256, ord("N"), np.uint8)]
+    b2 = nb.batch(2, regions, win, **flt)
+    assert nb.resident()[0] <= len(parts[2]) * 1.2 + 2 ** 20
+    refs, recs = bamio.read_bam(src)
+    keep = [r for r in recs if bamio.passes_filter(r, **flt)]
+    one = bamio.build_batch(keep, regions, win)
+    assert b2.n_reads == 5 * one.n_reads and np.array_equal(b2.pos[::5], one.pos) and np.array_equal(b2.bases[:one.seq_len[0]], one.bases[:one.seq_len[0]])
+    # the writer streams: contig A's records (20 copies) with an HP tag on one read name
+    out = str(tmp_path / "phased.bam")
+    name = recs[10]["name"]
+    nb.write_phased(out, [(0, 16729960, 13256)], [name], [1], [777], level=1)
+    assert nb.resident()[1] <= limit + 17 * 2 ** 20              # + the 16 MiB output chunk
+    orefs, orecs = bamio.read_bam(out, keep_raw=True)
+    want = [r for r in recs if not (r["flag"] & (0x4 | 0x100 | 0x800)) and r["pos"] + 1 >= 16729961 and r["pos"] + max(r["ref_len"], 1) + 1 <= 16729961 + 13256]
+    assert len(orecs) == 20 * len(want) and [r["name"] for r in orecs[::20]] == [r["name"] for r in want]
+    tagged = [r for r in orecs if r["name"] == name]
+    assert tagged and all(b"HPi" + struct.pack("<i", 1) in r["raw"][r["aux_off"]:] and b"PSI" + struct.pack("<I", 777) in r["raw"][r["aux_off"]:] for r in tagged)
+    nb.close()
+
+
 def test_bad_inputs_are_errors_not_crashes(tmp_path):
     with pytest.raises(_lib.LcrError, match="cannot open"):
         bamio.NativeBam(str(tmp_path / "missing.bam"))

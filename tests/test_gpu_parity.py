@@ -649,6 +649,14 @@ def test_driver_on_a_synthetic_two_contig_bam(engine_cls, tmp_path):
         E.close()
     assert st["regions"] == n_regions == 6
     assert body == "".join(want) and body.count("\n") >= 8
+    # sharded and chunked: two contexts on the device list [0, 0] (one host thread each), chunks of a single region --
+    # the same VCF and the same phased BAM, byte for byte on the inflated stream
+    out_bam1, out_bam2, out_vcf2 = str(tmp_path / "p1.bam"), str(tmp_path / "p2.bam"), str(tmp_path / "syn2.vcf")
+    pipeline.run(bam, fa, out_vcf, out_bam1, preset="ont-cdna", threads=4, seed=2025)
+    st2 = pipeline.run(bam, fa, out_vcf2, out_bam2, preset="ont-cdna", threads=4, seed=2025, devices=[0, 0], chunk_cost=1.0)
+    assert st2["chunks"] == 6 and st2["reads"] == st["reads"] and st2["candidates"] == st["candidates"]
+    assert open(out_vcf2).read() == open(out_vcf).read()
+    assert bamio.bgzf_decompress(out_bam1) == bamio.bgzf_decompress(out_bam2)
 
 
 @pytest.mark.parametrize("max_enum_snps", [0, 3, 12])
