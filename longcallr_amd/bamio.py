@@ -322,9 +322,9 @@ class NativeBam:
         return (np.ctypeslib.as_array(s, (n.value,)).copy() if n.value else np.zeros(0, np.int32),
                 np.ctypeslib.as_array(e, (n.value,)).copy() if n.value else np.zeros(0, np.int32))
 
-    def batch(self, ref_id, regions, ref_windows, names="list", **flt):
+    def batch(self, ref_id, regions, ref_windows, name_format="list", **flt):
         """ReadBatch of the passing reads grouped by region (fetch rule of util.rs:637); arrays are copies.
-        names="list": `batch.names` is a list of str; names="blob": `batch.name_off` (uint64, n + 1) and
+        name_format="list": `batch.names` is a list of str; "blob": `batch.name_off` (uint64, n + 1) and
         `batch.name_blob` (uint8, NUL-terminated names) -- no Python object per read."""
         C = self._C
         from . import _abi
@@ -348,11 +348,11 @@ class NativeBam:
         kw["cigar"] = arr(rd.cigar, rd.n_cigar, np.uint32)
         offs = np.ctypeslib.as_array(noff, (nr + 1,)).copy() if nr else np.zeros(1, np.uint64)
         blob = C.string_at(C.cast(names, C.c_void_p), int(offs[-1])) if nr else b""
-        nm = [blob[int(offs[i]):int(offs[i + 1]) - 1].decode() for i in range(nr)] if names == "list" else None
+        nm = [blob[int(offs[i]):int(offs[i + 1]) - 1].decode() for i in range(nr)] if name_format == "list" else None
         read_begin = np.ctypeslib.as_array(rb, (len(regions) + 1,)).copy()
         cat = np.concatenate([np.asarray(w, np.uint8) for w in ref_windows]) if len(ref_windows) else np.zeros(0, np.uint8)
         out = ReadBatch(start0=start0, len=length, read_begin=read_begin, ref=cat, names=nm, **kw)
-        if names == "blob":
+        if name_format == "blob":
             out.name_off, out.name_blob = offs, np.frombuffer(blob, dtype=np.uint8)
         return out
 

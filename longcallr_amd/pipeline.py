@@ -172,7 +172,7 @@ def run(bam_path, ref_path, out_vcf, out_bam=None, preset="hifi-masseq", contigs
             for chunk in chunk_regions(regions, max_cost=chunk_cost):
                 wins = [ref[s:s + l] if s + l <= ref.size else np.concatenate([ref[s:], np.full(s + l - ref.size, ord("N"), np.uint8)])
                         for s, l, _ in chunk]
-                batch = nb.batch(rid, [(s, l) for s, l, _ in chunk], wins, names="blob", **flt)
+                batch = nb.batch(rid, [(s, l) for s, l, _ in chunk], wins, name_format="blob", **flt)
                 stats["reads"] += batch.n_reads; stats["chunks"] += 1
                 while len(pending) > len(engines):     # bounded: at most one batch waiting per engine
                     results.append(pending.pop(0).result())
