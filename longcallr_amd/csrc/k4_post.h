@@ -8,6 +8,7 @@
 // observation order (a read's entries in column order, a SNP's reads in row order) and -ffp-contract=off keeps
 // a*b+c unfused, so the decisions are the host path's bit for bit; only phase_score's final log10 is the device libm.
 #pragma once
+#include <climits>
 #include "k4_dev.h"
 
 namespace {
@@ -284,31 +285,35 @@ __device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<
       parent[i] = node ? i : -1;
     }
     sc.sync();
-    // pairs (x < y) among the first 64 PASS-het entries of a row whose alleles agree with the haplotypes
-    auto for_pairs = [&](int r, auto fn) -> int {
-      int nx = 0;
-      for (int e1 = rptr[r]; e1 < (int)rptr[r + 1] && nx < 64; e1++) {
-        const int x = ecol[e1];
+    // The reference adds an edge for every pair (x < y) among the first 64 PASS-het entries of a row whose alleles
+    // agree with the haplotypes: hap[x] * hap[y] == (alleles differ ? -1 : 1), i.e. hap[x] * allele[x] == hap[y] *
+    // allele[y].  So a row's entries fall into two classes by the sign of hap * allele and every class is a clique:
+    // the components (all that is used of the graph) are those of "class members joined to their class", O(n) per
+    // row instead of O(n^2).  for_classes visits the members of both classes and returns the number of valid entries.
+    auto for_classes = [&](int r, auto fn) -> int {
+      int n = 0;
+      for (int e = rptr[r]; e < (int)rptr[r + 1] && n < 64; e++) {
+        const int x = ecol[e];
         if (parent[x] < 0) continue;
-        int ny = nx + 1;
-        for (int e2 = e1 + 1; e2 < (int)rptr[r + 1] && ny < 64; e2++) {
-          const int y = ecol[e2];
-          if (parent[y] < 0) continue;
-          if (shap[x] * shap[y] == (((ev[e1] ^ ev[e2]) & 32) ? -1 : 1)) fn(x, y);
-          ny++;
-        }
-        nx++;
+        const int c = shap[x] * ((ev[e] & 32) ? -1 : 1);
+        if (c) fn(x, c > 0 ? 0 : 1);
+        n++;
       }
-      return nx;
+      return n;
     };
     for (;;) {
       int any = 0;
       for (int r = sc.tid(); r < nrow; r += sc.nt()) {
         if (!fp[r] || asg[r] == 0) continue;
-        for_pairs(r, [&](int x, int y) {
-          const int lx = sc.ld(&parent[x]), ly = sc.ld(&parent[y]);
-          if (lx != ly) { const int m = min(lx, ly); atomicMin(&parent[x], m); atomicMin(&parent[y], m); any = 1; }
-        });
+        int lo[2] = {INT_MAX, INT_MAX}, hi[2] = {-1, -1};
+        for_classes(r, [&](int x, int k) { const int l = sc.ld(&parent[x]); lo[k] = min(lo[k], l); hi[k] = max(hi[k], l); });
+        if ((hi[0] >= 0 && lo[0] != hi[0]) || (hi[1] >= 0 && lo[1] != hi[1])) {
+          any = 1;
+          for_classes(r, [&](int x, int k) {
+            const int l = sc.ld(&parent[x]);
+            if (l != lo[k]) { atomicMin(&parent[x], lo[k]); atomicMin(&parent[l], lo[k]); }
+          });
+        }
       }
       any = sc.sync_or(any);
       for (int i = sc.tid(); i < S; i += sc.nt())
@@ -320,8 +325,10 @@ __device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<
     for (int r = sc.tid(); r < nrow; r += sc.nt()) {
       uint32_t ps = 0;
       if (fp[r] && asg[r] != 0) {
-        int best = -1, first = -1;  // largest component root among the components that own an edge of this read
-        const int n = for_pairs(r, [&](int x, int y) { (void)y; best = max(best, parent[x]); });
+        // largest component root among the components that own an edge of this read = among its classes of two or more
+        int root[2] = {-1, -1}, cnt[2] = {0, 0}, first = -1;
+        const int n = for_classes(r, [&](int x, int k) { root[k] = parent[x]; cnt[k]++; });
+        int best = max(cnt[0] >= 2 ? root[0] : -1, cnt[1] >= 2 ? root[1] : -1);
         if (n == 1) {               // self loop (snpfrags.rs:659-665)
           for (int e = rptr[r]; e < (int)rptr[r + 1]; e++) if (parent[ecol[e]] >= 0) { first = ecol[e]; break; }
           best = parent[first];
