@@ -52,10 +52,32 @@ __device__ __forceinline__ MatView stage_view(const PhaseDev& P, const RegionDev
   return MatView{rp, pc, pv, cp, cr, cv, fp, cons};
 }
 
+#define LCR_DPP_LL(v, ctrl, rmask) \
+  (((long long)__builtin_amdgcn_update_dpp(0, (int)((v) >> 32), ctrl, rmask, 0xf, false) << 32) | \
+   (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xf, false))
+// wave64 sum of int64 through DPP row shifts / broadcasts; every lane gets the total
+__device__ __forceinline__ long long wave_sum_ll_dpp(long long v) {
+  v += LCR_DPP_LL(v, 0x111, 0xf);
+  v += LCR_DPP_LL(v, 0x112, 0xf);
+  v += LCR_DPP_LL(v, 0x114, 0xf);
+  v += LCR_DPP_LL(v, 0x118, 0xf);
+  v += LCR_DPP_LL(v, 0x142, 0xa);
+  v += LCR_DPP_LL(v, 0x143, 0xc);
+  const int lo = __builtin_amdgcn_readlane((int)v, 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+  return ((long long)hi << 32) | (unsigned)lo;
+}
 constexpr int CROSS_MACC = 2048;   // SNPs with a per-column accumulator in LDS (entry-balanced delta step)
+// With accumulators in LDS (macc: one word per SNP, racc: one per row) all three sweeps -- sigma step, delta step,
+// objective -- are balanced over the CSC entries: thread t owns the entries [t*c, (t+1)*c), loads them four at a time
+// (row and value byte, then the row's sigma: independent LDS reads) and adds its terms into the accumulators (integer,
+// order-free).  A thread per row / a wave per SNP instead waits for the longest row or column in every iteration.
 __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, const MatView& mv, int8_t* sg, int8_t* dl, int8_t* et,
                                     bool keep_conserved, bool with_genotype, long long* red, const long long* wl,
-                                    unsigned long long* macc = nullptr /* macc_cap zeros in LDS, or nullptr */, int macc_cap = CROSS_MACC) {
+                                    unsigned long long* macc = nullptr /* macc_cap zeros in LDS, or nullptr */, int macc_cap = CROSS_MACC,
+                                    unsigned long long* racc = nullptr /* racc_cap words of LDS (any content), or nullptr */, int racc_cap = 0,
+                                    const long long* snp_const_lds = nullptr /* the region's 4 S per-SNP constants in LDS, or nullptr */,
+                                    int* iters_out = nullptr, long long* prof = nullptr /* thread 0: six step timers (LCR_PHASE_PROF) */,
+                                    int* flags = nullptr /* three ints of LDS: one barrier per iteration for both "anything changed" bits */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int32_t* rp = mv.rp;
   const int32_t* pc = mv.pc;
@@ -65,13 +87,127 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
   const uint8_t* cv = mv.cv;
   const uint8_t* fp = mv.fp;
   const uint8_t* cons = mv.cons;
-  const long long* sc = P.snp_const + 4ll * rd.snp_off;
+  const long long* sc = snp_const_lds ? snp_const_lds : P.snp_const + 4ll * rd.snp_off;   // (read in every delta step)
   bool hg_inc = true, h_inc = true;
   int iters = 0;
+  long long tk0 = prof ? (long long)wall_clock64() : 0;
+  auto tick = [&](int k) { if (prof) { const long long t = (long long)wall_clock64(); prof[k] += t - tk0; tk0 = t; } };
+  const bool cols_balanced = macc && rd.S <= macc_cap;
+  const bool rows_balanced = cols_balanced && racc && rd.R <= racc_cap;
+  int ce0 = 0, ce1 = 0, col_first = 0;   // this thread's CSC entries and the column of the first one
+  if (cols_balanced) {
+    const int E = cp[rd.S];
+    const int c = (E + (int)blockDim.x - 1) / (int)blockDim.x;
+    ce0 = min(E, tid * c); ce1 = min(E, ce0 + c);
+    if (ce0 < ce1) { int lo = 0, hi = rd.S; while (lo < hi) { const int mid = (lo + hi) >> 1; if (cp[mid + 1] <= ce0) lo = mid + 1; else hi = mid; } col_first = lo; }
+  }
+  if (rows_balanced) {
+    for (int row = tid; row < rd.R; row += blockDim.x) racc[row] = 0;
+    __syncthreads();
+  }
+  tick(0);
+  // fn(column, eta, delta, row, sigma of the row, value byte) for every entry of this thread, in column order
+  // (pending = true: the sigma step's sums are still in racc[], a row's new sigma is its old one times their sign)
+  auto sweep = [&](bool pending, auto fn) {
+    if (ce0 >= ce1) return;
+    int i = col_first, cend = cp[i + 1], d = dl[i], h = et[i];
+    for (int e = ce0; e < ce1; e += 4) {
+      int r4[4], v4[4], s4[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const int ee = min(e + k, ce1 - 1); r4[k] = cr[ee]; v4[k] = cv[ee]; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) s4[k] = sg[r4[k]];
+      if (pending) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if ((long long)racc[r4[k]] < 0) s4[k] = -s4[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (e + k < ce1) {
+          if (e + k >= cend) { do { i++; cend = cp[i + 1]; } while (e + k >= cend); d = dl[i]; h = et[i]; }
+          fn(i, h, d, r4[k], s4[k], v4[k]);
+        }
+    }
+  };
+  // per-SNP decision of the delta / eta step (phase.rs:872-959): the best of (d,0) (-d,0) (d,+1) (d,-1); true if it improves
+  auto decide_snp = [&](int i, long long M, int ncol) -> bool {
+    const int d = dl[i], h = et[i];
+    const long long het = P.lut.f_het0 - (long long)ncol * P.lut.f_log2;  // phase.rs:136-144
+    const long long F = sc[4 * i], W = sc[4 * i + 1];
+    long long N[4] = {F + M + het, F + W - M + het, sc[4 * i + 2] + P.lut.f_homref, sc[4 * i + 3] + P.lut.f_homvar};
+    int ch;
+    if (with_genotype) { ch = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch]) ch = t; }   // phase.rs:908-921
+    else if (h == 0) ch = N[1] > N[0] ? 1 : 0;                                                // phase.rs:923-930
+    else ch = N[3] > N[2] ? 3 : 2;                                                            // phase.rs:931-938
+    const int cur = h == 0 ? 0 : (h == 1 ? 2 : 3);
+    dl[i] = (int8_t)(ch == 1 ? -d : d);
+    et[i] = (int8_t)(ch <= 1 ? 0 : (ch == 2 ? 1 : -1));
+    return N[ch] > N[cur];
+  };
+  if (rows_balanced && flags) {
+    // Three barriers per iteration: sigma sweep | delta sweep (sigma taken from the pending sums) | row and SNP
+    // decisions + both "anything changed" bits through one LDS word (three words in rotation: the word of call k + 2
+    // is cleared after the barrier of call k, when its last readers -- call k - 1 -- are done).
+    if (tid < 3) flags[tid] = 0;
+    __syncthreads();
+    int fp_at = 0;
+    while (hg_inc | h_inc) {
+      sweep(false, [&](int, int h, int d, int row, int s, int v) {
+        if (h == 0) { const long long w = wl[v & 31]; atomicAdd(&racc[row], (unsigned long long)((((v & 32) ? 1 : -1) == s * d) ? w : -w)); }
+      });
+      __syncthreads();
+      tick(1);
+      {
+        long long M = 0;
+        int mi = -1;
+        sweep(true, [&](int i, int, int d, int, int s, int v) {
+          if (i != mi) { if (M) atomicAdd(&macc[mi], (unsigned long long)M); M = 0; mi = i; }
+          if (((v & 32) ? 1 : -1) == s * d) M += wl[v & 31];
+        });
+        if (M) atomicAdd(&macc[mi], (unsigned long long)M);
+      }
+      __syncthreads();
+      tick(3);
+      int chg = 0;
+      for (int row = tid; row < rd.R; row += blockDim.x) {
+        const long long diff = (long long)racc[row];
+        racc[row] = 0;
+        if (diff < 0) { sg[row] = (int8_t)(-sg[row]); chg |= 1; }
+      }
+      for (int i = tid; i < rd.S; i += blockDim.x) {
+        const long long M2 = (long long)macc[i];
+        macc[i] = 0;
+        if (!fp[i] || (keep_conserved && cons[i]) || cp[i + 1] == cp[i]) continue;
+        if (decide_snp(i, M2, cp[i + 1] - cp[i])) chg |= 2;
+      }
+      const int wchg = (__ballot(chg & 1) ? 1 : 0) | (__ballot(chg & 2) ? 2 : 0);
+      if (lane == 0 && wchg) atomicOr(&flags[fp_at], wchg);
+      __syncthreads();
+      const int r = flags[fp_at];
+      fp_at = fp_at == 2 ? 0 : fp_at + 1;
+      if (tid == 0) flags[fp_at == 2 ? 0 : fp_at + 1] = 0;
+      tick(4);
+      if (!(r & 1)) h_inc = false; else { h_inc = true; hg_inc = true; }     // after the sigma step
+      if (!(r & 2)) hg_inc = false; else { hg_inc = true; h_inc = true; }    // after the delta / eta step
+      if (++iters > 20) break;  // phase.rs:967-972
+    }
+  } else
   while (hg_inc | h_inc) {
     // ---- sigma step (phase.rs:824-862): A - B = sum over het sites of (+w if p == sigma*delta else -w);
     //      flip every row with A < B (sites with eta != 0 contribute equally to both)
     int any = 0;
+    if (rows_balanced) {
+      sweep(false, [&](int, int h, int d, int row, int s, int v) {
+        if (h == 0) { const long long w = wl[v & 31]; atomicAdd(&racc[row], (unsigned long long)((((v & 32) ? 1 : -1) == s * d) ? w : -w)); }
+      });
+      __syncthreads();
+      tick(1);
+      for (int row = tid; row < rd.R; row += blockDim.x) {
+        const long long diff = (long long)racc[row];
+        racc[row] = 0;
+        if (diff < 0) { sg[row] = (int8_t)(-sg[row]); any = 1; }
+      }
+    } else
     for (int row = tid; row < rd.R; row += blockDim.x) {
       const int s = sg[row];
       long long diff = 0;
@@ -83,6 +219,7 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
       if (diff < 0) { sg[row] = (int8_t)(-s); any = 1; }
     }
     any = __syncthreads_or(any);
+    tick(2);
     if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
     // ---- delta/eta step (phase.rs:872-959): per SNP the best of (d,0) (-d,0) (d,+1) (d,-1)
     any = 0;
@@ -100,34 +237,22 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
       dl[i] = (int8_t)(ch == 1 ? -d : d);
       et[i] = (int8_t)(ch <= 1 ? 0 : (ch == 2 ? 1 : -1));
     };
-    if (macc && rd.S <= macc_cap) {
-      // balanced over the CSC entries (not over the SNPs): thread t takes entries [t*c, (t+1)*c), walks them
-      // in column order and flushes its per-column sum of w over the hits into macc[] (LDS, integer, order-free)
-      const int E = cp[rd.S];
-      const int c = (E + (int)blockDim.x - 1) / (int)blockDim.x;
-      const int e0 = min(E, tid * c), e1 = min(E, e0 + c);
-      if (e0 < e1) {
-        int i; { int lo = 0, hi = rd.S; while (lo < hi) { const int mid = (lo + hi) >> 1; if (cp[mid + 1] <= e0) lo = mid + 1; else hi = mid; } i = lo; }
-        int d = dl[i]; int cend = cp[i + 1];
-        long long M = 0;
-        for (int e = e0; e < e1; e++) {
-          if (e >= cend) {
-            if (M) atomicAdd(&macc[i], (unsigned long long)M);
-            M = 0;
-            do { i++; cend = cp[i + 1]; } while (e >= cend);
-            d = dl[i];
-          }
-          const uint8_t v = cv[e];
-          if (((v & 32) ? 1 : -1) == sg[cr[e]] * d) M += wl[v & 31];
-        }
-        if (M) atomicAdd(&macc[i], (unsigned long long)M);
-      }
+    if (cols_balanced) {
+      // per-column sum of w over the hits; a thread's run of entries of one column is summed in a register first
+      long long M = 0;
+      int mi = -1;
+      sweep(false, [&](int i, int, int d, int, int s, int v) {
+        if (i != mi) { if (M) atomicAdd(&macc[mi], (unsigned long long)M); M = 0; mi = i; }
+        if (((v & 32) ? 1 : -1) == s * d) M += wl[v & 31];
+      });
+      if (M) atomicAdd(&macc[mi], (unsigned long long)M);
       __syncthreads();
+      tick(3);
       for (int i = tid; i < rd.S; i += blockDim.x) {
-        const long long M = (long long)macc[i];
+        const long long M2 = (long long)macc[i];
         macc[i] = 0;
         if (!fp[i] || (keep_conserved && cons[i]) || cp[i + 1] == cp[i]) continue;
-        decide(i, M, cp[i + 1] - cp[i]);
+        decide(i, M2, cp[i + 1] - cp[i]);
       }
     } else {
       for (int i = wave; i < rd.S; i += nw) {
@@ -146,11 +271,19 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
       }
     }
     any = __syncthreads_or(any);
+    tick(4);
     if (!any) hg_inc = false; else { hg_inc = true; h_inc = true; }
     if (++iters > 20) break;  // phase.rs:967-972
   }
+  if (iters_out) *iters_out = iters;
   // ---- objective (phase.rs:257-276) = f_total + sum of w over the hits
   long long acc = 0;
+  if (cols_balanced) {
+    sweep(false, [&](int, int h, int d, int, int s, int v) {
+      const int x = h == 0 ? s * d : h;
+      if (((v & 32) ? 1 : -1) == x) acc += wl[v & 31];
+    });
+  } else
   for (int row = tid; row < rd.R; row += blockDim.x) {
     const int s = sg[row];
     for (int e = rp[row]; e < rp[row + 1]; e++) {
@@ -160,13 +293,13 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
       if (((v & 32) ? 1 : -1) == x) acc += wl[v & 31];
     }
   }
-  acc = wave_sum_ll(acc);
-  __syncthreads();
+  acc = wave_sum_ll_dpp(acc);
+  __syncthreads();   // (red[] may still be read from the previous call)
   if (lane == 0) red[wave] = acc;
   __syncthreads();
   long long total = rd.f_total;
   for (int w = 0; w < nw; w++) total += red[w];
-  __syncthreads();
+  tick(5);
   return total;
 }
 
@@ -178,20 +311,6 @@ __device__ __forceinline__ void load_w(const PhaseDev& P, long long* wl) {
 
 __device__ __forceinline__ int8_t init_genotype(int8_t vt) { return vt == 0 ? 1 : (vt == 1 ? 0 : -1); }  // phase.rs:682-691
 
-#define LCR_DPP_LL(v, ctrl, rmask) \
-  (((long long)__builtin_amdgcn_update_dpp(0, (int)((v) >> 32), ctrl, rmask, 0xf, false) << 32) | \
-   (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xf, false))
-// wave64 sum of int64 through DPP row shifts / broadcasts; every lane gets the total
-__device__ __forceinline__ long long wave_sum_ll_dpp(long long v) {
-  v += LCR_DPP_LL(v, 0x111, 0xf);
-  v += LCR_DPP_LL(v, 0x112, 0xf);
-  v += LCR_DPP_LL(v, 0x114, 0xf);
-  v += LCR_DPP_LL(v, 0x118, 0xf);
-  v += LCR_DPP_LL(v, 0x142, 0xa);
-  v += LCR_DPP_LL(v, 0x143, 0xc);
-  const int lo = __builtin_amdgcn_readlane((int)v, 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
-  return ((long long)hi << 32) | (unsigned)lo;
-}
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -247,6 +366,9 @@ __device__ __forceinline__ void block_scan2(int a, int b, int& ea, int& eb, int&
 struct WgScope {
   long long* red;   // LDS, one per wave
   int* bc;          // LDS broadcast slot
+  uint8_t* scratch = nullptr;   // LDS the caller does not need before its first cross_optimize (16-byte aligned)
+  uint32_t scratch_bytes = 0;
+  __device__ uint8_t* lds_scratch(uint32_t* bytes) const { *bytes = scratch_bytes; return scratch; }
   __device__ int tid() const { return threadIdx.x; }
   __device__ int nt() const { return blockDim.x; }
   __device__ int wave() const { return threadIdx.x >> 6; }
@@ -281,6 +403,7 @@ struct GridScope {
   long long* red;      // LDS, one per wave
   unsigned long long* bc;   // LDS broadcast slots (two)
   unsigned gen;        // barriers passed so far (uniform over the grid)
+  __device__ uint8_t* lds_scratch(uint32_t* bytes) const { *bytes = 0; return nullptr; }
   __device__ int tid() const { return blockIdx.x * blockDim.x + threadIdx.x; }
   __device__ int nt() const { return gridDim.x * blockDim.x; }
   __device__ int wave() const { return tid() >> 6; }

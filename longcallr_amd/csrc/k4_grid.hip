@@ -27,6 +27,7 @@
 // (phase.rs:628-657) is therefore nx's BFS parent.  With ld_weight_threshold = 1 (thread.rs:166 hard-codes it) no
 // edge is ever removed; other values are rejected by lcr_phase.
 #include "k4_dev.h"
+#include <type_traits>
 #include "k4_grid.h"
 #include "k4_post.h"
 
@@ -145,12 +146,50 @@ __device__ void ordered_index(SC& sc, int R, int S, const int32_t* rp, const int
 template <class SC>
 __device__ void ld_pair_table(SC& sc, const ChainDev& C, const ChainView& v) {
   const int S = v.S, W = v.W;
-  for (int64_t i = sc.tid(); i < 2ll * S * W; i += sc.nt()) v.tbl[i] = 0;
+  const int64_t e_lo = C.row_ptr[v.r0], n_ent = C.row_ptr[v.r0 + v.nrow] - e_lo;
+  // one workgroup with spare LDS: entries (SNP | allele bit, row remainder) and the table itself live in LDS, the pairs
+  // are spread over the threads by their first entry (a thread per row waits for its longest row: 231 global atomics in
+  // a row of 22 entries), the table goes to HBM once at the end
+  uint32_t lds_bytes = 0;
+  uint8_t* const lds = sc.lds_scratch(&lds_bytes);
+  const uint64_t tbl_bytes = 8ull * (uint64_t)S * (uint64_t)W;
+  const bool in_lds = lds && S < 32768 && n_ent < 65536 && tbl_bytes + 4ull * (uint64_t)n_ent + 16 <= (uint64_t)lds_bytes;
+  if (!in_lds) for (int64_t i = sc.tid(); i < 2ll * S * W; i += sc.nt()) v.tbl[i] = 0;
   for (int i = sc.tid(); i < S; i += sc.nt()) {
     const lcr_candidate& c = C.cand[v.c0 + i];
     // for_phasing, exactly one of the two major alleles is the reference (candidate.rs:637-660), both fractions non-zero
     v.ok[i] = (v.fp[i] && ((c.allele1 == c.ref_base) != (c.allele2 == c.ref_base)) && c.af1 != 0.0f && c.af2 != 0.0f) ? 1 : 0;
     v.blk_of[i] = -1; v.seen[i] = 0; v.cons[i] = 0;
+  }
+  if (in_lds) {
+    uint32_t* const ltbl = reinterpret_cast<uint32_t*>(lds);
+    uint16_t* const eidx = reinterpret_cast<uint16_t*>(lds + ((tbl_bytes + 15) & ~15ull));   // SNP | allele << 15; 0xFFFF = not eligible
+    uint16_t* const erem = eidx + n_ent;                                                     // entries behind this one in its row
+    for (int i = sc.tid(); i < 2 * S * W; i += sc.nt()) ltbl[i] = 0;
+    sc.sync();
+    for (int e = sc.tid(); e < (int)n_ent; e += sc.nt()) {
+      const int i = C.col[e_lo + e] - v.c0;
+      eidx[e] = v.ok[i] ? (uint16_t)(i | ((C.val[e_lo + e] & 32) ? 0x8000 : 0)) : (uint16_t)0xFFFF;
+    }
+    for (int r = sc.tid(); r < v.nrow; r += sc.nt()) {
+      const int eb = (int)(C.row_ptr[v.r0 + r] - e_lo), ee = (int)(C.row_ptr[v.r0 + r + 1] - e_lo);
+      for (int e = eb; e < ee; e++) erem[e] = (uint16_t)(ee - e - 1);
+    }
+    sc.sync();
+    for (int x = sc.tid(); x < (int)n_ent; x += sc.nt()) {
+      const uint32_t a = eidx[x];
+      if (a == 0xFFFFu) continue;
+      const int i = (int)(a & 0x7FFFu), y1 = x + 1 + erem[x];
+      uint32_t* const row = ltbl + 2 * (i * W - i - 1);
+      for (int y = x + 1; y < y1; y++) {
+        const uint32_t bb = eidx[y];
+        if (bb != 0xFFFFu) atomicAdd(&row[2 * (int)(bb & 0x7FFFu) + (((bb ^ a) >> 15) & 1u)], 1u);
+      }
+    }
+    sc.sync();
+    for (int i = sc.tid(); i < 2 * S * W; i += sc.nt()) v.tbl[i] = ltbl[i];
+    sc.sync();
+    return;
   }
   sc.sync();
   // every fragment row, every pair of its entries (fragment.rs:208-240); only pairs of eligible SNPs are ever looked up
@@ -842,22 +881,38 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
   load_w(C.P, wl);
   const ChainDesc d = C.desc[first + blockIdx.x];
   const RegionDev rd = C.P.reg[d.slot];
-  ChainView v = make_view(C, d, rd);
-  if (C.P.lds_state) { v.sg = dyn_state; v.dl = v.sg + rd.R; v.et = v.dl + rd.S; }
   const uint32_t E = (uint32_t)C.P.prow_ptr[rd.rp_off + rd.R];
   __shared__ int wg_bc;
-  WgScope sc{red, &wg_bc};
-  bool staged = false;
-  MatView mvl = v.mv;
-  auto cross = [&](bool keep_conserved, bool with_genotype) -> long long {
-    // the perturbation rounds sweep the matrix dozens of times: keep it in LDS when it fits behind the state
-    if (!staged) {
-      staged = true;
-      if (C.P.lds_state && matview_bytes(rd.R, rd.S, E) <= (uint32_t)C.P.lds_mat) mvl = stage_view(C.P, rd, (uint8_t*)dyn_state + C.P.scratch_stride, E);
-    }
-    return cross_optimize(C.P, rd, mvl, v.sg, v.dl, v.et, keep_conserved, with_genotype, red, wl, macc, MACC);
+  constexpr int SCN = 256;   // SNPs whose constants (four words each, read by every delta step) are kept in LDS
+  __shared__ long long scn[4 * SCN];
+  if (rd.S <= SCN) for (int i = threadIdx.x; i < 4 * rd.S; i += blockDim.x) scn[i] = C.P.snp_const[4ll * rd.snp_off + i];
+  // Two instantiations of the same body: with state and matrix in LDS every pointer of the sweeps has ONE provenance,
+  // so the compiler emits ds_read / ds_write for them; a pointer that is "LDS or HBM" at run time makes them flat_load /
+  // flat_store, which take the long way round even when they hit LDS (the sweeps of cross_optimize were 3x slower).
+  auto body = [&](auto in_lds) {
+    ChainView v = make_view(C, d, rd);
+    MatView mvl = v.mv;
+    if constexpr (decltype(in_lds)::value) {
+      v.sg = dyn_state; v.dl = v.sg + rd.R; v.et = v.dl + rd.S;
+      mvl = stage_view(C.P, rd, (uint8_t*)dyn_state + C.P.scratch_stride, E);   // the chain sweeps it dozens of times
+      v.mv = mvl;
+      v.cons = const_cast<uint8_t*>(mvl.cons);   // (written by the LD seeding, read by cross_optimize: the LDS copy is the live one)
+    } else if (C.P.lds_state) { v.sg = dyn_state; v.dl = v.sg + rd.R; v.et = v.dl + rd.S; }
+    WgScope sc{red, &wg_bc};
+    sc.scratch = reinterpret_cast<uint8_t*>(stage); sc.scratch_bytes = (uint32_t)sizeof(stage);   // (block_flip's stage rows: free before it)
+    auto cross = [&](bool keep_conserved, bool with_genotype) -> long long {
+      const bool timed = C.dbg && blockIdx.x == 0 && threadIdx.x == 0;   // (LCR_PHASE_PROF)
+      int iters = 0;
+      const long long obj = cross_optimize(C.P, rd, mvl, v.sg, v.dl, v.et, keep_conserved, with_genotype, red, wl, macc, MACC,
+                                           reinterpret_cast<unsigned long long*>(stage), NW * 4 * SSTR,   // (free outside block_flip)
+                                           rd.S <= SCN ? scn : nullptr, &iters, timed ? C.dbg + 8 : nullptr, &sm[0][0]);
+      if (timed) { C.dbg[14] += 1; C.dbg[15] += iters; }
+      return obj;
+    };
+    chain_run(sc, C, rd, v, wl, L, stage, sm, cross, [](long long) { return false; }, d.slot);
   };
-  chain_run(sc, C, rd, v, wl, L, stage, sm, cross, [](long long) { return false; }, d.slot);
+  if (C.P.lds_state && matview_bytes(rd.R, rd.S, E) <= (uint32_t)C.P.lds_mat) body(std::true_type{});
+  else body(std::false_type{});
 }
 
 // all workgroups of the launch on one region (desc[which])

@@ -1386,6 +1386,11 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     static const char* nm[] = {"ordered column index", "pair table", "LD graph", "components + seed", "cross_optimize A", "block flip", "perturbation rounds"};
     fprintf(stderr, "[phase]     chain steps of %s\n", chain_desc.back().fast_lds || (int64_t)0 ? "the last all-CU launch" : "the last launch (one-workgroup form: its first region)");
     for (int k = 0; k < 7; k++) fprintf(stderr, "[phase]     grid chain: %-24s %9.1f us\n", nm[k], (double)(clk[k + 1] - clk[k]) / 100.0);
+    if (!chain_desc.back().fast_lds) fprintf(stderr, "[phase]     one-workgroup chain: %lld cross_optimize calls, %lld iterations\n", clk[14], clk[15]);
+    if (!chain_desc.back().fast_lds) {
+      static const char* nm3[] = {"setup", "sigma sweep", "row decisions", "delta sweep", "SNP decisions", "objective"};
+      for (int k = 0; k < 6; k++) fprintf(stderr, "[phase]     one-workgroup cross_optimize: %-16s %8.1f us in total\n", nm3[k], (double)clk[8 + k] / 100.0);
+    }
     fprintf(stderr, "[phase]     grid chain: %lld iterations in the rounds\n", clk[15]);
     static const char* nm2[] = {"stage delta/eta", "sigma step (workgroup 0)", "barrier 1", "stage sigma", "delta step (workgroup 0)", "barrier 2"};
     for (int k = 0; k < 6; k++) fprintf(stderr, "[phase]     grid chain rounds: %-26s %9.1f us per iteration\n", nm2[k], (double)clk[8 + k] / 100.0 / (double)std::max<long long>(clk[15], 1));
