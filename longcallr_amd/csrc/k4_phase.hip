@@ -1338,8 +1338,15 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta; pinc.st_obj = Pc.st_obj;
     if (nps) {
       // 33 KB of static stage buffers + up to 64 KB of region image
-      PCHK(k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_post<CHAIN_THREADS>), 96 * 1024, 4));
-      hipLaunchKernelGGL(k4_post<CHAIN_THREADS>, dim3((unsigned)nps), dim3(CHAIN_THREADS), post_lds, side, pinc, b_slots.as<int32_t>(), (int32_t)nps, plut);
+      // more chain regions than CUs (a sixteen-wave workgroup has a CU to itself): eight waves, two regions per CU --
+      // one generation of workgroups instead of two
+      if (((int)nps > std::max(1, k4_grid_blocks()) || getenv("LCR_POST_HALF") /* test hook */) && post_lds <= 56 * 1024) {
+        PCHK(k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_post<CHAIN_THREADS / 2>), 96 * 1024, 5));
+        hipLaunchKernelGGL(k4_post<CHAIN_THREADS / 2>, dim3((unsigned)nps), dim3(CHAIN_THREADS / 2), post_lds, side, pinc, b_slots.as<int32_t>(), (int32_t)nps, plut);
+      } else {
+        PCHK(k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_post<CHAIN_THREADS>), 96 * 1024, 4));
+        hipLaunchKernelGGL(k4_post<CHAIN_THREADS>, dim3((unsigned)nps), dim3(CHAIN_THREADS), post_lds, side, pinc, b_slots.as<int32_t>(), (int32_t)nps, plut);
+      }
     }
     PCHK(hipGetLastError());
   } else chain_desc.clear();

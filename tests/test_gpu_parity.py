@@ -210,10 +210,11 @@ def test_k0_cigar_lengths(engine_cls, orc):
     full_check(engine_cls, orc, b, _abi.make_params("hifi-masseq", seed=12))
 
 
-@pytest.mark.parametrize("hook", ["LCR_ENUM_FORCE_STREAM", "LCR_ENUM_FORCE_BIG", "LCR_POST_HOST"])
+@pytest.mark.parametrize("hook", ["LCR_ENUM_FORCE_STREAM", "LCR_ENUM_FORCE_BIG", "LCR_POST_HOST", "LCR_POST_HALF"])
 def test_fallback_device_paths(engine_cls, orc, monkeypatch, hook):
     """The size-dependent fallbacks of the phase stage give the same results as the default kernels:
-    enumeration restarts with LDS-streamed entries / from global memory, post-phase epilogue on the host."""
+    enumeration restarts with LDS-streamed entries / from global memory, post-phase epilogue on the host, the
+    eight-wave epilogue of the chain regions (taken when a batch has more chain regions than the device has CUs)."""
     monkeypatch.setenv(hook, "1")
     b = synth.make_batch("ont-drna", n_genes=3, gene_len=20000, depth=45, seed=14)
     full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=14))
