@@ -71,6 +71,9 @@ constexpr int CROSS_MACC = 2048;   // SNPs with a per-column accumulator in LDS 
 // objective -- are balanced over the CSC entries: thread t owns the entries [t*c, (t+1)*c), loads them four at a time
 // (row and value byte, then the row's sigma: independent LDS reads) and adds its terms into the accumulators (integer,
 // order-free).  A thread per row / a wave per SNP instead waits for the longest row or column in every iteration.
+// What bounds a sweep now is the LDS itself: ~7 bank-cycles per entry (row 4 B, value 1 B, sigma 1 B, w 8 B, atomic
+// 8 B; measured 2 900 cycles for 4 242 entries, the same with half the waves doing twice the batches, PMC-free check
+// with s_memtime), so fewer, wider accesses per entry are what would make it faster, not more parallelism.
 __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const RegionDev& rd, const MatView& mv, int8_t* sg, int8_t* dl, int8_t* et,
                                     bool keep_conserved, bool with_genotype, long long* red, const long long* wl,
                                     unsigned long long* macc = nullptr /* macc_cap zeros in LDS, or nullptr */, int macc_cap = CROSS_MACC,
@@ -110,22 +113,23 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
   // (pending = true: the sigma step's sums are still in racc[], a row's new sigma is its old one times their sign)
   auto sweep = [&](bool pending, auto fn) {
     if (ce0 >= ce1) return;
+    constexpr int K = 4;   // entries per batch of loads
     int i = col_first, cend = cp[i + 1], d = dl[i], h = et[i];
-    for (int e = ce0; e < ce1; e += 4) {
-      int r4[4], v4[4], s4[4];
+    for (int e = ce0; e < ce1; e += K) {
+      int r8[K], v8[K], s8[K];
 #pragma unroll
-      for (int k = 0; k < 4; k++) { const int ee = min(e + k, ce1 - 1); r4[k] = cr[ee]; v4[k] = cv[ee]; }
+      for (int k = 0; k < K; k++) { const int ee = min(e + k, ce1 - 1); r8[k] = cr[ee]; v8[k] = cv[ee]; }
 #pragma unroll
-      for (int k = 0; k < 4; k++) s4[k] = sg[r4[k]];
+      for (int k = 0; k < K; k++) s8[k] = sg[r8[k]];
       if (pending) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) if ((long long)racc[r4[k]] < 0) s4[k] = -s4[k];
+        for (int k = 0; k < K; k++) if (reinterpret_cast<const int*>(racc)[2 * r8[k] + 1] < 0) s8[k] = -s8[k];   // (sign = high dword)
       }
 #pragma unroll
-      for (int k = 0; k < 4; k++)
+      for (int k = 0; k < K; k++)
         if (e + k < ce1) {
           if (e + k >= cend) { do { i++; cend = cp[i + 1]; } while (e + k >= cend); d = dl[i]; h = et[i]; }
-          fn(i, h, d, r4[k], s4[k], v4[k]);
+          fn(i, h, d, r8[k], s8[k], v8[k]);
         }
     }
   };
@@ -148,9 +152,15 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
     // Three barriers per iteration: sigma sweep | delta sweep (sigma taken from the pending sums) | row and SNP
     // decisions + both "anything changed" bits through one LDS word (three words in rotation: the word of call k + 2
     // is cleared after the barrier of call k, when its last readers -- call k - 1 -- are done).
-    if (tid < 3) flags[tid] = 0;
+    // The objective comes out of the last iteration: when nothing changed in it, the delta sweep's column sums M_i
+    // are the het SNPs' hit sums of the final state and a hom SNP's are constants (Cref - F, Cvar - F), so the SNP
+    // decisions add them up (red[0..2] in rotation with the flag words) and the closing sweep is only needed after
+    // the iteration cap.
+    if (tid < 3) { flags[tid] = 0; red[tid] = 0; }
     __syncthreads();
     int fp_at = 0;
+    bool settled = false;
+    long long settled_sum = 0;
     while (hg_inc | h_inc) {
       sweep(false, [&](int, int h, int d, int row, int s, int v) {
         if (h == 0) { const long long w = wl[v & 31]; atomicAdd(&racc[row], (unsigned long long)((((v & 32) ? 1 : -1) == s * d) ? w : -w)); }
@@ -174,23 +184,39 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
         racc[row] = 0;
         if (diff < 0) { sg[row] = (int8_t)(-sg[row]); chg |= 1; }
       }
+      long long tsum = 0;
       for (int i = tid; i < rd.S; i += blockDim.x) {
         const long long M2 = (long long)macc[i];
         macc[i] = 0;
+        const int h = et[i];
+        const long long term = h == 0 ? M2 : (h == 1 ? sc[4 * i + 2] - sc[4 * i] : sc[4 * i + 3] - sc[4 * i]);
+        tsum += term;
         if (!fp[i] || (keep_conserved && cons[i]) || cp[i + 1] == cp[i]) continue;
         if (decide_snp(i, M2, cp[i + 1] - cp[i])) chg |= 2;
+      }
+      if (wave * 64 < rd.S) {   // (wave-uniform: the waves that own SNPs)
+        tsum = wave_sum_ll_dpp(tsum);
+        if (lane == 0 && tsum) atomicAdd(reinterpret_cast<unsigned long long*>(&red[fp_at]), (unsigned long long)tsum);
       }
       const int wchg = (__ballot(chg & 1) ? 1 : 0) | (__ballot(chg & 2) ? 2 : 0);
       if (lane == 0 && wchg) atomicOr(&flags[fp_at], wchg);
       __syncthreads();
       const int r = flags[fp_at];
+      settled = r == 0; settled_sum = red[fp_at];
       fp_at = fp_at == 2 ? 0 : fp_at + 1;
-      if (tid == 0) flags[fp_at == 2 ? 0 : fp_at + 1] = 0;
+      if (tid == 0) { flags[fp_at == 2 ? 0 : fp_at + 1] = 0; red[fp_at == 2 ? 0 : fp_at + 1] = 0; }
       tick(4);
       if (!(r & 1)) h_inc = false; else { h_inc = true; hg_inc = true; }     // after the sigma step
       if (!(r & 2)) hg_inc = false; else { hg_inc = true; h_inc = true; }    // after the delta / eta step
       if (++iters > 20) break;  // phase.rs:967-972
     }
+    if (settled) {
+      if (iters_out) *iters_out = iters;
+      __syncthreads();   // (red[] is the next call's)
+      tick(5);
+      return rd.f_total + settled_sum;
+    }
+    __syncthreads();
   } else
   while (hg_inc | h_inc) {
     // ---- sigma step (phase.rs:824-862): A - B = sum over het sites of (+w if p == sigma*delta else -w);
