@@ -1244,7 +1244,12 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(launch(n_t, nullptr));
     hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)ns), dim3(64), 0, stream, d_sl, (int32_t)ns, P.reg, d_jb, d_obj, d_win);
     PCHK(launch(n_w, d_win));
-    if (nps) hipLaunchKernelGGL(k4_post<LCR_BLOCK>, dim3((unsigned)nps), dim3(LCR_BLOCK), post_lds, stream, pin, d_psl, (int32_t)nps, plut);
+    if (nps) {
+      // eight waves per region: the slowest region (most rows) sets the kernel's length, and every row sweep of the
+      // epilogue is a pass of <threads> rows (148 -> 103 us on C3)
+      PCHK(k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_post<2 * LCR_BLOCK>), 96 * 1024, 5));
+      hipLaunchKernelGGL(k4_post<2 * LCR_BLOCK>, dim3((unsigned)nps), dim3(2 * LCR_BLOCK), post_lds, stream, pin, d_psl, (int32_t)nps, plut);
+    }
     PCHK(hipGetLastError());
   }
   lap("enum launch");
