@@ -439,22 +439,31 @@ struct GridScope {
   // FENCED = false: no L2 write-back / invalidate.  For phases whose cross-workgroup data is read and written with
   // device-coherent (agent-scope relaxed atomic, `sc1`) accesses only: immutable data then stays in the L2s across the
   // barrier (tools/grid_barrier_bench.hip: 4.7 us instead of 15-20 us per barrier, no stale reads).
+  // One barrier = one returning atomic on the arrival word + polling the generation word, and an OR over the grid
+  // rides along for free: a workgroup adds 1 (+ 0x10000 if its flag is set) to `arrive`, the last arriver publishes
+  // "any flag set" in bit 31 of the new generation, which is the word everybody polls.  (The OR used to be its own
+  // atomic before and its own load after the barrier: two more device round trips of ~2 us each, per barrier.)
   template <bool FENCED = true>
-  __device__ void arrive_wait_() {   // thread 0 of the workgroup
-    const unsigned g = gen;
+  __device__ unsigned arrive_wait_(unsigned vflag = 0) {   // thread 0 of the workgroup; returns the OR of the flags
+    const unsigned g = gen & 0x7FFFFFFFu;
     if (FENCED) __threadfence();
-    if (atomicAdd(&c->arrive, 1u) == gridDim.x - 1) {
+    const unsigned old = atomicAdd(&c->arrive, 1u + (vflag ? 0x10000u : 0u));
+    unsigned any;
+    if ((old & 0xFFFFu) == gridDim.x - 1) {
+      any = ((old >> 16) != 0u || vflag) ? 1u : 0u;
       // last arriver: the slots of parity (g+1) were read before their readers arrived here and are written again
       // only after this barrier opens
-      __hip_atomic_store(&c->flag[(g + 1) & 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&c->acc[(g + 1) & 1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&c->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (FENCED) __threadfence();
-      __hip_atomic_store(&c->gen, g + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&c->gen, ((g + 1) & 0x7FFFFFFFu) | (any << 31), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      while (__hip_atomic_load(&c->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) __builtin_amdgcn_s_sleep(1);
+      unsigned x;
+      while (((x = __hip_atomic_load(&c->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x7FFFFFFFu) == g) __builtin_amdgcn_s_sleep(1);
+      any = x >> 31;
     }
     if (FENCED) __threadfence();
+    return any;
   }
   __device__ void sync_light() {
     __syncthreads();
@@ -462,29 +471,32 @@ struct GridScope {
     gen++;
     __syncthreads();
   }
-  // OR of `v` and sum of `x` over the grid in one light barrier
+  // OR of `v` and sum of `x` over the grid in one light barrier (sum == nullptr: the OR alone, no reduction traffic)
   __device__ int sync_or_sum_light(int v, long long x, long long* sum) {
-    x = wave_sum_ll(x);
+    if (sum) x = wave_sum_ll(x);
     v = __syncthreads_or(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
-    __syncthreads();
+    if (sum) {
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+      __syncthreads();
+    }
     if (threadIdx.x == 0) {
-      long long t = 0;
-      for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += red[w];
-      if (t) atomicAdd(&c->acc[gen & 1], (unsigned long long)t);
-      if (v) atomicOr(&c->flag[gen & 1], 1u);
-      arrive_wait_<false>();
-      bc[0] = __hip_atomic_load(&c->acc[gen & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bc[1] = __hip_atomic_load(&c->flag[gen & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (sum) {
+        long long t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += red[w];
+        // (returning: this workgroup's share is in the sum before it is counted as arrived)
+        if (t) (void)__hip_atomic_fetch_add(&c->acc[gen & 1], (unsigned long long)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      bc[1] = arrive_wait_<false>(v ? 1u : 0u);
+      if (sum) bc[0] = __hip_atomic_load(&c->acc[gen & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     gen++;
     __syncthreads();
-    *sum = (long long)bc[0];
+    if (sum) *sum = (long long)bc[0];
     const int r = (int)bc[1];
     __syncthreads();
     return r;
   }
-  __device__ int sync_or_light(int v) { long long s; return sync_or_sum_light(v, 0, &s); }
+  __device__ int sync_or_light(int v) { return sync_or_sum_light(v, 0, nullptr); }
   __device__ void sync() {
     __syncthreads();
     if (threadIdx.x == 0) arrive_wait_();
@@ -493,11 +505,7 @@ struct GridScope {
   }
   __device__ int sync_or(int v) {
     v = __syncthreads_or(v);
-    if (threadIdx.x == 0) {
-      if (v) atomicOr(&c->flag[gen & 1], 1u);
-      arrive_wait_();
-      *bc = __hip_atomic_load(&c->flag[gen & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) *bc = arrive_wait_(v ? 1u : 0u);
     gen++;
     __syncthreads();
     const int r = (int)*bc;

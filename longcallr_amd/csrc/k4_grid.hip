@@ -661,6 +661,17 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
   __shared__ unsigned long long t_sum[4][8];   // delta step: partial sums / arrivals of the four-wave teams
   __shared__ unsigned t_cnt[4][8];
   if (threadIdx.x < 32) { t_sum[threadIdx.x >> 3][threadIdx.x & 7] = 0; t_cnt[threadIdx.x >> 3][threadIdx.x & 7] = 0; }
+  // ---- delta step order: SNPs by column length, dealt to the teams in serpentine order (longest to team 0, 1, .. T-1,
+  // the next T to team T-1 .. 0, ...): a team's share of the entries is then within a few % of the mean.  In index
+  // order the slowest workgroup took 24.5 us per iteration against a median of 12 (C5: columns of 300 .. 5 000 entries,
+  // 4.6 SNPs per team), and every workgroup waits for it at the barrier.
+  int32_t* const ord = v.queue;   // (free after the LD seeding)
+  for (int i = sc.tid(); i < S; i += sc.nt()) {
+    const int len = cp[i + 1] - cp[i];
+    int rank = 0;
+    for (int j = 0; j < S; j++) { const int lj = cp[j + 1] - cp[j]; rank += (lj > len || (lj == len && j < i)) ? 1 : 0; }
+    ord[rank] = i;
+  }
   // ---- the byte state of the generic steps (best == working) into words
   sc.sync();   // (fenced: the byte arrays were written with plain stores by other workgroups)
   for (int j = wj0; j < ng; j += nw) {
@@ -682,10 +693,16 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
       for (int i = threadIdx.x; i < S; i += blockDim.x) { s_dl[i] = cload(&v.dl[i]); s_et[i] = cload(&v.et[i]); }
       __syncthreads();
       tick(8);
+      const long long wg_t0 = C.dbg ? (long long)wall_clock64() : 0;   // (LCR_PHASE_PROF: every workgroup's own time in the half steps)
       int any = 0;
-      for (int j = wj0; j < ng; j += nw) {
+      // a wave's unit is HALF a 64-row group (eight passes of four rows): 10 400 units over 4 096 waves is 2 or 3 each,
+      // whole groups were 1 or 2 each and the waves with 2 set the step's length (26 -> 20 us per iteration on C5)
+      // (dealing the units through a stride coprime to their number narrows the spread between workgroups -- max 26.2 ->
+      // 24.4 us -- but costs locality: median 19.6 -> 20.3 us, rounds 528 -> 536 ms; not kept)
+      for (int u = wj0; u < 2 * ng; u += nw) {
         // sixteen lanes per row, four rows per pass: a row's entries are one coalesced load (thread-per-row would touch
         // every cache line of the group once per entry)
+        const int j = u >> 1, q0 = 8 * (u & 1);
         const unsigned long long word = cload(&wsw[j]);
         const int rl = min(64 * j + lane, R);
         const int my_b = rp[rl], my_e = rp[min(rl + 1, R)];          // lane <-> row of the group (empty past R)
@@ -693,8 +710,7 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
         const int sub = lane & 15, rsel = lane >> 4;
         // pass q works on rows 4q .. 4q+3 of the group; eight passes at a time, the first 32 entries of each of their rows
         // are loaded before anything is used (32 independent loads in flight per lane), longer rows finish in a tail loop
-#pragma unroll 1
-        for (int q0 = 0; q0 < 16; q0 += 8) {
+        {
           int pi[8][2]; uint8_t px[8][2];
 #pragma unroll
           for (int q = 0; q < 8; q++) {
@@ -736,9 +752,10 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
             }
           }
         }
-        if (lane == 0 && nword != word) cstore(&wsw[j], nword);
+        if (lane == 0 && nword != word) cstore(reinterpret_cast<uint32_t*>(&wsw[j]) + (u & 1), (uint32_t)(nword >> (32 * (u & 1))));   // (this unit's half of the word)
       }
       __syncthreads();
+      if (C.dbg && threadIdx.x == 0 && sc.blk() < 1024) C.dbg[16 + sc.blk()] += (long long)wall_clock64() - wg_t0;
       tick(9);
       any = sc.sync_or_light(any);
       tick(10);
@@ -747,6 +764,7 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
       for (int j = threadIdx.x; j < ng; j += blockDim.x) { const unsigned long long word = cload(&wsw[j]); s_sig[2 * j] = (uint32_t)word; s_sig[2 * j + 1] = (uint32_t)(word >> 32); }
       __syncthreads();
       tick(11);
+      const long long wg_t1 = C.dbg ? (long long)wall_clock64() : 0;
       any = 0;
       long long acc = 0;
       // a team of four waves per SNP (a wave per SNP leaves the largest column as the critical path); the waves' partial
@@ -756,8 +774,9 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
         int it = 0;
         for (int base = 0; base < S; base += nteams, it++) {
           if ((it & 7) == 0 && it) __syncthreads();   // the ring of 8 slots per team wraps (uniform trip count)
-          const int i = base + gteam;
-          if (i >= S) continue;
+          const int pos = base + ((it & 1) ? nteams - 1 - gteam : gteam);
+          if (pos >= S) continue;
+          const int i = ord[pos];
           const int c0 = cp[i], c1 = cp[i + 1];
           if (c0 == c1) continue;
           const int d = s_dl[i], h = s_et[i];
@@ -804,6 +823,7 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
         }
       }
       __syncthreads();
+      if (C.dbg && threadIdx.x == 0 && sc.blk() < 1024) C.dbg[16 + 1024 + sc.blk()] += (long long)wall_clock64() - wg_t1;
       tick(12);
       any = sc.sync_or_sum_light(any, acc, &obj);
       tick(13);

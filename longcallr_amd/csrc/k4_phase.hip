@@ -1166,7 +1166,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   PostIn pin{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, const_cast<lcr_candidate*>(in.d_cand), in.d_cand_off,
              in.d_row_region_off, in.d_start0, P.st_sigma, P.st_delta, P.st_eta, (int8_t*)(d_res + res_tag), d_res + res_asg,
              (uint32_t*)(d_res + res_ps), P.st_obj, (long long*)(d_hc + hc_obj), (lcr_candidate*)d_hc, prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr, P.reg, b_psrc.as<int32_t>()};
-  if (prof) { PCHK(d_state[20].reserve((size_t)(ng + 1) * 16 * 8)); PCHK(hipMemsetAsync(d_state[20].p, 0, (size_t)(ng + 1) * 16 * 8, stream)); pin.dbg_clk = d_state[20].as<long long>(); }
+  if (prof) { PCHK(d_state[20].reserve(((size_t)(ng + 1) * 16 + 2 * 1024) * 8)); PCHK(hipMemsetAsync(d_state[20].p, 0, ((size_t)(ng + 1) * 16 + 2 * 1024) * 8, stream)); pin.dbg_clk = d_state[20].as<long long>(); }
 
   // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
   if (!enum_slots.empty()) {
@@ -1316,7 +1316,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     C.macc = b_macc.as<unsigned long long>(); C.ctl = b_ctl.as<GridCtl>(); C.sig_words = d_state[39].as<unsigned long long>();
     for (int q = 0; q < 31; q++) { C.le[q] = L.le[q]; C.l1e[q] = L.l1e[q]; }
     C.p_homref = L.p_homref; C.p_homvar = L.p_homvar; C.log_theta = L.log_theta; C.log2 = L.log2;
-    if (prof) { C.dbg = d_state[20].as<long long>() + (size_t)ng * 16; PCHK(hipMemsetAsync(C.dbg, 0, 16 * 8, side)); }
+    if (prof) { C.dbg = d_state[20].as<long long>() + (size_t)ng * 16; PCHK(hipMemsetAsync(C.dbg, 0, (16 + 2 * 1024) * 8, side)); }   // 16 step timers + per-workgroup sigma / delta step times
     chain_dev = C; chain_desc = desc;   // (lcr_get_ld_blocks reads the blocks back)
     PCHK(hipStreamWaitEvent(side, ev_csr, 0));
     PCHK(hipMemcpyAsync(b_desc.p, h_pin[10].p, (size_t)nc * sizeof(ChainDesc), hipMemcpyHostToDevice, side));
@@ -1402,6 +1402,20 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     if (!chain_desc.back().fast_lds) {
       static const char* nm3[] = {"setup", "sigma sweep", "row decisions", "delta sweep", "SNP decisions", "objective"};
       for (int k = 0; k < 6; k++) fprintf(stderr, "[phase]     one-workgroup cross_optimize: %-16s %8.1f us in total\n", nm3[k], (double)clk[8 + k] / 100.0);
+    }
+    if (chain_desc.back().fast_lds) {   // per-workgroup work time of the two half steps (own work, without the barriers)
+      std::vector<long long> wg(2 * 1024);
+      PCHK(hipMemcpy(wg.data(), chain_dev.dbg + 16, wg.size() * 8, hipMemcpyDeviceToHost));
+      const int nb = std::max(1, k4_grid_blocks());
+      for (int h = 0; h < 2; h++) {
+        std::vector<std::pair<long long, int>> t;
+        for (int k = 0; k < nb && k < 1024; k++) t.push_back({wg[h * 1024 + k], k});
+        std::sort(t.begin(), t.end());
+        const double it = (double)std::max<long long>(clk[15], 1) * 100.0;
+        fprintf(stderr, "[phase]     grid chain rounds: %s step per workgroup and iteration: min %.1f (wg %d)  median %.1f  p90 %.1f  max %.1f us (wg %d)\n",
+                h ? "delta" : "sigma", t.front().first / it, t.front().second, t[t.size() / 2].first / it, t[t.size() * 9 / 10].first / it, t.back().first / it, t.back().second);
+        if (getenv("LCR_PHASE_PROF_WG")) { for (int k = 0; k < nb && k < 1024; k++) fprintf(stderr, "%s%.1f", k % 16 ? " " : "\n[phase]       ", wg[h * 1024 + k] / it); fprintf(stderr, "\n"); }
+      }
     }
     fprintf(stderr, "[phase]     grid chain: %lld iterations in the rounds\n", clk[15]);
     static const char* nm2[] = {"stage delta/eta", "sigma step (workgroup 0)", "barrier 1", "stage sigma", "delta step (workgroup 0)", "barrier 2"};
