@@ -825,6 +825,8 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
       __syncthreads();
       if (C.dbg && threadIdx.x == 0 && sc.blk() < 1024) C.dbg[16 + 1024 + sc.blk()] += (long long)wall_clock64() - wg_t1;
       tick(12);
+      // (summing the objective once after the last iteration instead -- the sum costs this barrier two more device
+      // round trips, 17.9 vs 11.7 us -- is a wash: 3.1 iterations per call save what the closing barrier costs)
       any = sc.sync_or_sum_light(any, acc, &obj);
       tick(13);
       if (!any) hg_inc = false; else { hg_inc = true; h_inc = true; }
