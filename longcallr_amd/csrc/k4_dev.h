@@ -96,7 +96,7 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
   long long tk0 = prof ? (long long)wall_clock64() : 0;
   auto tick = [&](int k) { if (prof) { const long long t = (long long)wall_clock64(); prof[k] += t - tk0; tk0 = t; } };
   const bool cols_balanced = macc && rd.S <= macc_cap;
-  const bool rows_balanced = cols_balanced && racc && rd.R <= racc_cap;
+  const bool rows_balanced = cols_balanced && racc && flags && rd.R <= racc_cap;   // (the three-barrier form below)
   int ce0 = 0, ce1 = 0, col_first = 0;   // this thread's CSC entries and the column of the first one
   if (cols_balanced) {
     const int E = cp[rd.S];
@@ -148,7 +148,7 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
     et[i] = (int8_t)(ch <= 1 ? 0 : (ch == 2 ? 1 : -1));
     return N[ch] > N[cur];
   };
-  if (rows_balanced && flags) {
+  if (rows_balanced) {
     // Three barriers per iteration: sigma sweep | delta sweep (sigma taken from the pending sums) | row and SNP
     // decisions + both "anything changed" bits through one LDS word (three words in rotation: the word of call k + 2
     // is cleared after the barrier of call k, when its last readers -- call k - 1 -- are done).
@@ -222,18 +222,6 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
     // ---- sigma step (phase.rs:824-862): A - B = sum over het sites of (+w if p == sigma*delta else -w);
     //      flip every row with A < B (sites with eta != 0 contribute equally to both)
     int any = 0;
-    if (rows_balanced) {
-      sweep(false, [&](int, int h, int d, int row, int s, int v) {
-        if (h == 0) { const long long w = wl[v & 31]; atomicAdd(&racc[row], (unsigned long long)((((v & 32) ? 1 : -1) == s * d) ? w : -w)); }
-      });
-      __syncthreads();
-      tick(1);
-      for (int row = tid; row < rd.R; row += blockDim.x) {
-        const long long diff = (long long)racc[row];
-        racc[row] = 0;
-        if (diff < 0) { sg[row] = (int8_t)(-sg[row]); any = 1; }
-      }
-    } else
     for (int row = tid; row < rd.R; row += blockDim.x) {
       const int s = sg[row];
       long long diff = 0;
