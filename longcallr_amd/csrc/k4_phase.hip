@@ -1396,7 +1396,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     long long clk[16];
     PCHK(hipMemcpy(clk, chain_dev.dbg, sizeof(clk), hipMemcpyDeviceToHost));
     static const char* nm[] = {"ordered column index", "pair table", "LD graph", "components + seed", "cross_optimize A", "block flip", "perturbation rounds"};
-    fprintf(stderr, "[phase]     chain steps of %s\n", chain_desc.back().fast_lds || (int64_t)0 ? "the last all-CU launch" : "the last launch (one-workgroup form: its first region)");
+    fprintf(stderr, "[phase]     chain steps of %s\n", chain_desc.back().fast_lds ? "the last all-CU launch" : "the last launch (one-workgroup form: its first region)");
     for (int k = 0; k < 7; k++) fprintf(stderr, "[phase]     grid chain: %-24s %9.1f us\n", nm[k], (double)(clk[k + 1] - clk[k]) / 100.0);
     if (!chain_desc.back().fast_lds) fprintf(stderr, "[phase]     one-workgroup chain: %lld cross_optimize calls, %lld iterations\n", clk[14], clk[15]);
     if (!chain_desc.back().fast_lds) {
