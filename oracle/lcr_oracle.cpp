@@ -1030,7 +1030,9 @@ struct orc_region {
     double largest_prob = -std::numeric_limits<double>::infinity();
     int64_t largest_fx = std::numeric_limits<int64_t>::min();
     auto better = [&](double prob) {  /* `prob > largest_prob` (phase.rs:1117,1129,...); EXACT compares the int64 sums */
-      const bool b = mode == ORC_MODE_F64 ? prob > largest_prob : last_obj_fx > largest_fx;
+      const bool b_f64 = prob > largest_prob, b_fx = last_obj_fx > largest_fx;
+      if (b_f64 != b_fx) stats[2]++;   /* two restarts of equal objective (an uninformative SNP flipped): the f64 sums differ by rounding noise */
+      const bool b = mode == ORC_MODE_F64 ? b_f64 : b_fx;
       if (b) { largest_prob = prob; largest_fx = last_obj_fx; }
       return b;
     };

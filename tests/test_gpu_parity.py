@@ -893,3 +893,24 @@ def test_region_discovery_gpu(engine_cls):
     keep = [r for r in recs if bamio.passes_filter(r)]
     rs = np.array([r["pos"] for r in keep]); re_ = rs + np.array([max(r["ref_len"], 1) for r in keep])
     assert E.discover_regions(rs, re_, 64444167) == bamio.discover_regions(keep, keep[0]["ref_id"], 64444167) == [(16729960, 13256, 1649)]
+
+
+def test_one_context_over_batches_of_different_sizes(engine_cls):
+    """A context keeps its buffers (and their capacities) across batches: one that sees a small batch, a ten times
+    larger one and the small one again gives the bytes a fresh context gives for each."""
+    small = synth.make_batch("ont-cdna", n_genes=1, gene_len=6000, depth=25, seed=71)
+    large = synth.make_batch("ont-drna", n_genes=6, gene_len=20000, depth=60, seed=72)
+    p = _abi.make_params("ont-cdna", seed=5)
+
+    def fresh(b):
+        E = engine_cls(0, p)
+        E.load_batch(b).run_all()
+        r = _result_bytes(E) + (E.fragmat()["col"].tobytes(),)
+        E.close()
+        return r
+    want = {id(small): fresh(small), id(large): fresh(large)}
+    E = engine_cls(0, p)
+    for b in (small, large, small, large, large, small):
+        E.load_batch(b).run_all()
+        assert _result_bytes(E) + (E.fragmat()["col"].tobytes(),) == want[id(b)]
+    E.close()
