@@ -494,17 +494,21 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
     int P = 0;                                      // pieces of the batch (every thread sums the wave totals)
 #pragma unroll
     for (int i = 0; i < K1_WAVES; i++) P += wsum[i];
-    // piece -> record map (short segments: a handful of pieces per record); larger batches search pstart[].
-    // A thread fills the map entries of its own records straight from its registers: one barrier covers
-    // pstart[] and pown[].
-    const bool mapped = P <= K1_PMAP;
+    // piece -> record map.  A thread fills the map entries of its own records straight from its registers: one
+    // barrier covers pstart[] and pown[].
+    // pown[k] = record of piece k * pstride: every piece when the batch has at most K1_PMAP of them (ONT: short
+    // segments, stride 1), every pstride-th one otherwise (HiFi: segments of up to 33 pieces, 25 000 pieces per batch) --
+    // a piece then starts at its map entry and steps forward over at most pstride records instead of a ten-step
+    // binary search over pstart[]
+    const int pstride = (P + K1_PMAP - 1) / K1_PMAP;   // (>= 1 unless the batch has no piece)
     if (tid == 0) pstart[0] = 0;
 #pragma unroll
     for (int x = 0; x < K1_RPB; x++) {
       const int first = run;
       run += npc[x];
       pstart[tid * K1_RPB + x + 1] = run;
-      if (mapped) for (int q = first; q < run; q++) pown[q] = (uint16_t)(tid * K1_RPB + x);
+      if (pstride == 1) for (int q = first; q < run; q++) pown[q] = (uint16_t)(tid * K1_RPB + x);
+      else if (pstride > 1) for (int k = (first + pstride - 1) / pstride; k * pstride < run; k++) pown[k] = (uint16_t)(tid * K1_RPB + x);
     }
     __syncthreads();
     // ---- phase 2: one 16-byte aligned piece of read bases per thread, four pieces in flight per thread
@@ -513,12 +517,9 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
       Piece q;
       q.ok = p < P;
       if (!q.ok) { q.v = make_uint4(0, 0, 0, 0); q.colA = 0; q.k_lo = q.k_hi = 0; q.strand = 0; return q; }
-      int lo = 0;  // last record with pstart <= p
-      if (mapped) lo = pown[p];
-      else {
-#pragma unroll
-        for (int st = K1_RPB * K1_THREADS / 2; st >= 1; st >>= 1) if (pstart[lo + st] <= p) lo += st;
-      }
+      int lo;  // last record with pstart <= p
+      if (pstride == 1) lo = pown[p];
+      else { lo = pown[p / pstride]; while (pstart[lo + 1] <= p) lo++; }
       const unsigned long long rc = rec_s[lo];
       const uint32_t rhi = (uint32_t)(rc >> 32);
       const long long soff = (long long)(rc & REC_OFF_MASK);
