@@ -1179,7 +1179,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     // class 2: register-resident kernel (<= 32 entries per lane; smaller instantiations were measured: separate
     // launches each pay their own tail, one CK=32 launch with early exits is faster); class 3: same kernel
     // streaming its entries from LDS (any share size); class 4: global-memory kernel (matrix larger than the
-    // LDS budget); classes 0 / 1 unused
+    // LDS budget); classes 0 / 1 unused.  (A second register-resident instantiation with 40 entries per lane -- three
+    // quarters of C4's restarts sit at 33 .. 36 -- needs 207 VGPRs, two waves per SIMD, and is slower than streaming
+    // from LDS at six: 0.61 vs 0.51 ms per launch pair on C4, 0.23 vs 0.13 on C3.)
     constexpr int NCLS = 5;
     std::vector<EnumSpan> spans[NCLS];
     size_t n_t[NCLS] = {0, 0, 0, 0, 0};   // tiles per class = grid of the class's kernel
@@ -1194,7 +1196,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       const EnumLayout EL = enum_layout(st.R, st.E);
       int cls = 4;
       if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_BYTES && st.max_rows <= 64)
-        cls = force_stream ? 3 : (st.max_n <= 32 ? 2 : 3);   // (the 8 / 16 instantiations: one launch has one tail)
+        cls = force_stream ? 3 : (st.max_n <= 32 ? 2 : 3);   // (the 8 / 16 instantiations: one launch has one tail; a 40-entry one: below)
       if (cls < 4) lds_need[cls] = std::max(lds_need[cls], EL.total);
       job_base[g] = nj;
       const uint64_t n = 1ull << S;
@@ -1251,6 +1253,17 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       hipLaunchKernelGGL(k4_post<2 * LCR_BLOCK>, dim3((unsigned)nps), dim3(2 * LCR_BLOCK), post_lds, stream, pin, d_psl, (int32_t)nps, plut);
     }
     PCHK(hipGetLastError());
+  }
+  if (prof && !enum_slots.empty()) {   // share sizes of the enumeration regions (entries per lane decide the kernel class)
+    std::vector<int> mn; uint64_t jobs[3] = {0, 0, 0};
+    for (int g : enum_slots) {
+      mn.push_back(stat[g].max_n);
+      const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
+      jobs[stat[g].max_n <= 32 ? 0 : stat[g].max_n <= 48 ? 1 : 2] += 1ull << S;
+    }
+    std::sort(mn.begin(), mn.end());
+    fprintf(stderr, "[phase]   enumeration regions: %zu, entries per lane min %d median %d p90 %d max %d; restarts with <= 32: %llu, 33-48: %llu, > 48: %llu\n",
+            mn.size(), mn.front(), mn[mn.size() / 2], mn[mn.size() * 9 / 10], mn.back(), (unsigned long long)jobs[0], (unsigned long long)jobs[1], (unsigned long long)jobs[2]);
   }
   lap("enum launch");
 
