@@ -914,3 +914,17 @@ def test_one_context_over_batches_of_different_sizes(engine_cls):
         E.load_batch(b).run_all()
         assert _result_bytes(E) + (E.fragmat()["col"].tobytes(),) == want[id(b)]
     E.close()
+
+
+@pytest.mark.parametrize("dist_to_end,polya_len", [(40, 5), (63, 16), (100, 7), (10, 3), (1, 1)])
+def test_poly_a_mask_zone_sizes(engine_cls, orc, dist_to_end, polya_len):
+    """The HiFi presets' poly-A / homopolymer mask (util.rs:754-789) for zones of several widths and window lengths: up to
+    63 offsets a thread per read end corrects K1's counts (k1_zonefix_ends), wider zones take a thread per offset
+    (k1_zonefix); MAS-Seq reads with aligned and soft-clipped poly-A tails, planes bit-exact against the oracle."""
+    b = synth.make_batch("masseq", n_genes=2, gene_len=8000, depth=40, seed=53)
+    p = _abi.make_params("hifi-masseq", seed=3, dist_to_end=dist_to_end, polya_len=polya_len)
+    regs = oracle_all(orc, b, p)
+    E = engine_cls(0, p)
+    E.load_batch(b).fill_data_into_freq_vec()
+    check_pileup(E, regs, b)
+    E.close()
