@@ -119,9 +119,9 @@ __host__ __device__ inline uint32_t enum_chunk(uint32_t E) { return E ? (E + 63)
 // tiles of restarts of regions whose per-lane share is <= CK entries (host decides); win_e != nullptr:
 // re-run restart win_e[slot] of each tile's region and store its state.
 template <int CK>
-__global__ void __launch_bounds__(64 * ENUM_WAVES)
+__global__ void __launch_bounds__(64 * ENUM_WAVES, 3)   // (three waves per SIMD: <= 168 VGPRs)
 k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uint32_t per, const int64_t* __restrict__ job_base,
-            long long* __restrict__ job_obj, const uint32_t* __restrict__ win_e) {
+            long long* __restrict__ job_obj, const uint32_t* __restrict__ win_e, uint32_t* __restrict__ tiles_done) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const EnumTile t = enum_tile_of(P, spans, n_spans, per, win_e != nullptr);
   const RegionDev rd = P.reg[t.slot];
@@ -212,8 +212,10 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
   const int nk = (R + 63) / 64;
   const int wsh = r_a & 63;
   const uint32_t ne = win_e ? 1u : t.ne;
-  for (uint32_t kk = wave; kk < ne; kk += ENUM_WAVES) {
-    const uint32_t e = win_e ? win_e[t.slot] : t.e0 + kk;
+  // one restart by this wave: its objective goes to job_obj[], or -- the winner's re-run -- its state to the region's slot
+  auto run_restart = [&](const uint32_t e_in, const bool mat_in) {
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_in);   // (wave-uniform: keep them in SGPRs)
+    const bool materialise = __builtin_amdgcn_readfirstlane((int)mat_in) != 0;
     uint32_t dneg = e & smask;            // bit i: delta_i == -1 (doubling order of phase.rs:1099-1106)
     uint32_t eta0 = e0_init, etap = ep_init;   // eta_i == 0 / eta_i == +1
     // init_assignment (phase.rs:673-680): u01() < 0.5  <=>  top bit of the draw clear  -> sigma = -1
@@ -346,7 +348,7 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
     }
     // objective (phase.rs:257-276) = sum over phase entries of fe + hit * w = sum_i (F_i + hits_i) over live SNPs
     const long long total = wave_sum_ll_dpp(obj_i);
-    if (win_e) {
+    if (materialise) {
       if (lane < S) {
         P.st_delta[rd.snp_off + lane] = (int8_t)(((dneg >> lane) & 1u) ? -1 : 1);
         P.st_eta[rd.snp_off + lane] = (int8_t)(((eta0 >> lane) & 1u) ? 0 : (((etap >> lane) & 1u) ? 1 : -1));
@@ -356,8 +358,45 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
         if (row < R) P.st_sigma[rd.sig_off + row] = (int8_t)(((sgb[k] >> lane) & 1ull) ? -1 : 1);
       }
       if (lane == 0) P.st_obj[t.slot] = total;
-    } else if (lane == 0) job_obj[job_base[t.slot] + e] = total;
+    } else if (lane == 0) __hip_atomic_store(&job_obj[job_base[t.slot] + e], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (device-coherent: read by the region's last tile)
     wave_lds_sync();
+  };
+  // Pass 0: this tile's restarts.  Then the tile that completes its region picks the winner (first maximum, `prob >
+  // largest_prob`, phase.rs:1113-1119) and -- pass 1, wave 0 -- runs that restart once more to leave its state: the matrix
+  // is still staged here, and neither a pick kernel nor a second launch sits between the enumeration and the post-phase
+  // kernel.  The objectives were stored device-coherently and every wave's stores are acknowledged before the barrier
+  // that lets thread 0 count the tile.  (One call site for both passes: a second inlined copy costs the 32-entry
+  // instantiation its third wave per SIMD.)
+  __shared__ uint32_t s_last, s_win;
+  __shared__ long long s_best[ENUM_WAVES];
+  __shared__ uint32_t s_be[ENUM_WAVES];
+  for (int pass = 0; pass < 2; pass++) {
+    const uint32_t n_run = pass == 0 ? ne : (wave == 0 ? 1u : 0u);
+    for (uint32_t kk = pass == 0 ? wave : 0u; kk < n_run; kk += ENUM_WAVES)
+      run_restart(pass == 1 ? s_win : (win_e ? win_e[t.slot] : t.e0 + kk), pass == 1 || win_e != nullptr);
+    if (pass == 1 || win_e || !tiles_done) break;
+    __syncthreads();
+    const uint32_t n_jobs = 1u << S;
+    if (tid == 0) s_last = atomicAdd(&tiles_done[t.slot], 1u) == (n_jobs + per - 1) / per - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) break;
+    const long long* o = job_obj + job_base[t.slot];
+    long long best = LLONG_MIN; uint32_t be = 0xffffffffu;
+    for (uint32_t e = tid; e < n_jobs; e += nt) {
+      const long long v = __hip_atomic_load(&o[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v > best) { best = v; be = e; }   // (ascending e per thread: the first maximum of its share)
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      const long long ob = __shfl_xor(best, d, 64); const uint32_t oe = __shfl_xor(be, d, 64);
+      if (ob > best || (ob == best && oe < be)) { best = ob; be = oe; }
+    }
+    if (lane == 0) { s_best[wave] = best; s_be[wave] = be; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < ENUM_WAVES; w++) if (s_best[w] > best || (s_best[w] == best && s_be[w] < be)) { best = s_best[w]; be = s_be[w]; }
+      s_win = be;
+    }
+    __syncthreads();
   }
 }
 
@@ -1168,109 +1207,11 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
              (uint32_t*)(d_res + res_ps), P.st_obj, (long long*)(d_hc + hc_obj), (lcr_candidate*)d_hc, prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr, P.reg, b_psrc.as<int32_t>()};
   if (prof) { PCHK(d_state[20].reserve(((size_t)(ng + 1) * 16 + 2 * 1024) * 8)); PCHK(hipMemsetAsync(d_state[20].p, 0, ((size_t)(ng + 1) * 16 + 2 * 1024) * 8, stream)); pin.dbg_clk = d_state[20].as<long long>(); }
 
-  // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
-  if (!enum_slots.empty()) {
-    int32_t max_state = 0;
-    for (int g : enum_slots) max_state = std::max(max_state, stat[g].R + 2 * (in.cand_region_off[g + 1] - in.cand_region_off[g]));
-    const int32_t stride = (max_state + 63) & ~63;
-    P.scratch_stride = stride;
-    const bool force_big = getenv("LCR_ENUM_FORCE_BIG") != nullptr;        // test hooks: exercise the fallback kernels
-    const bool force_stream = getenv("LCR_ENUM_FORCE_STREAM") != nullptr;
-    // class 2: register-resident kernel (<= 32 entries per lane; smaller instantiations were measured: separate
-    // launches each pay their own tail, one CK=32 launch with early exits is faster); class 3: same kernel
-    // streaming its entries from LDS (any share size); class 4: global-memory kernel (matrix larger than the
-    // LDS budget); classes 0 / 1 unused.  (A second register-resident instantiation with 40 entries per lane -- three
-    // quarters of C4's restarts sit at 33 .. 36 -- needs 207 VGPRs, two waves per SIMD, and is slower than streaming
-    // from LDS at six: 0.61 vs 0.51 ms per launch pair on C4, 0.23 vs 0.13 on C3.)
-    constexpr int NCLS = 5;
-    std::vector<EnumSpan> spans[NCLS];
-    size_t n_t[NCLS] = {0, 0, 0, 0, 0};   // tiles per class = grid of the class's kernel
-    const uint32_t per_of[NCLS] = {1u, 1u, ENUM_TILE_JOBS, 2u * ENUM_WAVES, 1u};
-    std::vector<int64_t> job_base(ng, 0);
-    int64_t nj = 0;
-    uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0};
-    std::vector<int32_t> post_slots;   // enumeration regions with the device epilogue
-    for (int g : enum_slots) {
-      const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
-      const StageStat& st = stat[g];
-      const EnumLayout EL = enum_layout(st.R, st.E);
-      int cls = 4;
-      if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_BYTES && st.max_rows <= 64)
-        cls = force_stream ? 3 : (st.max_n <= 32 ? 2 : 3);   // (the 8 / 16 instantiations: one launch has one tail; a 40-entry one: below)
-      if (cls < 4) lds_need[cls] = std::max(lds_need[cls], EL.total);
-      job_base[g] = nj;
-      const uint64_t n = 1ull << S;
-      if (n_t[cls] + (n + per_of[cls] - 1) / per_of[cls] > 0x7fffffffull) { if (err) *err = "too many enumeration restarts for one launch"; return LCR_E_ARG; }
-      spans[cls].push_back({g, (uint32_t)n_t[cls]});
-      n_t[cls] += (size_t)((n + per_of[cls] - 1) / per_of[cls]);
-      nj += (int64_t)n;
-      if (!host_post[g] && !grid_post[g]) post_slots.push_back(g);
-    }
-    // one upload: spans of every class | job_base | slots | post slots ; then job objectives and winners
-    size_t n_w[NCLS], s_off[NCLS], n_spans = 0;
-    for (int k = 0; k < NCLS; k++) { n_w[k] = spans[k].size(); s_off[k] = n_spans; n_spans += n_w[k]; }
-    const size_t ns = enum_slots.size(), nps = post_slots.size();
-    const size_t off_jb_al = (n_spans * sizeof(EnumSpan) + 7) & ~(size_t)7;
-    const size_t up_bytes = off_jb_al + (size_t)ng * 8 + (ns + nps) * 4;
-    PCHK(b_job.reserve(up_bytes + 64));
-    PCHK(b_obj.reserve((size_t)nj * 8 + (size_t)ng * 4 + 64));
-    PCHK(h_pin[8].reserve(up_bytes + 64));   // pinned: the upload is queued, not staged
-    uint8_t* const up = h_pin[8].as<uint8_t>();
-    for (int k = 0; k < NCLS; k++) memcpy(up + s_off[k] * sizeof(EnumSpan), spans[k].data(), n_w[k] * sizeof(EnumSpan));
-    memcpy(up + off_jb_al, job_base.data(), (size_t)ng * 8);
-    memcpy(up + off_jb_al + (size_t)ng * 8, enum_slots.data(), ns * 4);
-    memcpy(up + off_jb_al + (size_t)ng * 8 + ns * 4, post_slots.data(), nps * 4);
-    PCHK(hipMemcpyAsync(b_job.p, up, up_bytes, hipMemcpyHostToDevice, stream));
-    const EnumSpan* d_sp = b_job.as<EnumSpan>();
-    const int64_t* d_jb = (const int64_t*)(b_job.as<uint8_t>() + off_jb_al);
-    const int32_t* d_sl = (const int32_t*)(b_job.as<uint8_t>() + off_jb_al + (size_t)ng * 8);
-    const int32_t* d_psl = d_sl + ns;
-    long long* d_obj = b_obj.as<long long>();
-    uint32_t* d_win = (uint32_t*)(d_obj + nj);
-    const size_t n_big_blocks = std::max(n_t[4], n_w[4]);
-    PCHK(b_scr.reserve((size_t)stride * n_big_blocks + 64));
-    P.scratch = b_scr.as<int8_t>();
-    // the classes touch disjoint regions: class 2 on `stream`, classes 3 / 4 beside it on `aux` (their tails overlap)
-    auto launch = [&](const size_t* cnt, const uint32_t* win) -> hipError_t {
-      const dim3 blk(64 * ENUM_WAVES);
-      const bool fork = cnt[2] && (cnt[3] || cnt[4]);
-      hipStream_t s34 = fork ? aux : stream;
-      hipError_t e = hipSuccess;
-      if (fork) { if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e; }
-      if (cnt[2]) hipLaunchKernelGGL(k4_enum_reg<32>, dim3((unsigned)cnt[2]), blk, lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, win);
-      if (cnt[3]) hipLaunchKernelGGL(k4_enum_reg<0>, dim3((unsigned)cnt[3]), blk, lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, win);
-      if (cnt[4]) hipLaunchKernelGGL(k4_enum_big, dim3((unsigned)cnt[4]), dim3(LCR_BLOCK), 0, s34, P, d_sp + s_off[4], (int32_t)n_w[4], per_of[4], d_jb, d_obj, win);
-      if (fork) { if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e; }
-      return e;
-    };
-    PCHK(launch(n_t, nullptr));
-    hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)ns), dim3(64), 0, stream, d_sl, (int32_t)ns, P.reg, d_jb, d_obj, d_win);
-    PCHK(launch(n_w, d_win));
-    if (nps) {
-      // eight waves per region: the slowest region (most rows) sets the kernel's length, and every row sweep of the
-      // epilogue is a pass of <threads> rows (148 -> 103 us on C3)
-      PCHK(k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_post<2 * LCR_BLOCK>), 96 * 1024, 5));
-      hipLaunchKernelGGL(k4_post<2 * LCR_BLOCK>, dim3((unsigned)nps), dim3(2 * LCR_BLOCK), post_lds, stream, pin, d_psl, (int32_t)nps, plut);
-    }
-    PCHK(hipGetLastError());
-  }
-  if (prof && !enum_slots.empty()) {   // share sizes of the enumeration regions (entries per lane decide the kernel class)
-    std::vector<int> mn; uint64_t jobs[3] = {0, 0, 0};
-    for (int g : enum_slots) {
-      mn.push_back(stat[g].max_n);
-      const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
-      jobs[stat[g].max_n <= 32 ? 0 : stat[g].max_n <= 48 ? 1 : 2] += 1ull << S;
-    }
-    std::sort(mn.begin(), mn.end());
-    fprintf(stderr, "[phase]   enumeration regions: %zu, entries per lane min %d median %d p90 %d max %d; restarts with <= 32: %llu, 33-48: %llu, > 48: %llu\n",
-            mn.size(), mn.front(), mn[mn.size() / 2], mn[mn.size() * 9 / 10], mn.back(), (unsigned long long)jobs[0], (unsigned long long)jobs[1], (unsigned long long)jobs[2]);
-  }
-  lap("enum launch");
-
   // ---- chain regions on queue `side` (their own copy of the state arrays)
   PhaseDev Pc = P;
   Pc.st_sigma = b_stc.as<int8_t>() + st_sig; Pc.st_delta = b_stc.as<int8_t>() + st_del; Pc.st_eta = b_stc.as<int8_t>() + st_eta;
   Pc.st_obj = (long long*)(b_stc.as<int8_t>() + st_obj);
+  auto launch_chain_regions = [&]() -> int {
   if (!chain_slots.empty()) {
     // a region whose phase matrix is far beyond one CU gets all of them (persistent launch with grid barriers); the
     // others run side by side, one workgroup each.  LCR_GRID_MIN_ENTRIES moves the boundary (tests: 0 = every region).
@@ -1368,6 +1309,125 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     }
     PCHK(hipGetLastError());
   } else chain_desc.clear();
+  return LCR_OK;
+  };
+  auto launch_enum_regions = [&]() -> int {
+  // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
+  if (!enum_slots.empty()) {
+    int32_t max_state = 0;
+    for (int g : enum_slots) max_state = std::max(max_state, stat[g].R + 2 * (in.cand_region_off[g + 1] - in.cand_region_off[g]));
+    const int32_t stride = (max_state + 63) & ~63;
+    P.scratch_stride = stride;
+    const bool force_big = getenv("LCR_ENUM_FORCE_BIG") != nullptr;        // test hooks: exercise the fallback kernels
+    const bool force_stream = getenv("LCR_ENUM_FORCE_STREAM") != nullptr;
+    // class 2: register-resident kernel (<= 32 entries per lane; smaller instantiations were measured: separate
+    // launches each pay their own tail, one CK=32 launch with early exits is faster); class 3: same kernel
+    // streaming its entries from LDS (any share size); class 4: global-memory kernel (matrix larger than the
+    // LDS budget); classes 0 / 1 unused.  (A second register-resident instantiation with 40 entries per lane -- three
+    // quarters of C4's restarts sit at 33 .. 36 -- needs 207 VGPRs, two waves per SIMD, and is slower than streaming
+    // from LDS at six: 0.61 vs 0.51 ms per launch pair on C4, 0.23 vs 0.13 on C3.)
+    constexpr int NCLS = 5;
+    std::vector<EnumSpan> spans[NCLS];
+    size_t n_t[NCLS] = {0, 0, 0, 0, 0};   // tiles per class = grid of the class's kernel
+    const uint32_t per_of[NCLS] = {1u, 1u, ENUM_TILE_JOBS, 2u * ENUM_WAVES, 1u};
+    std::vector<int64_t> job_base(ng, 0);
+    int64_t nj = 0;
+    uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0};
+    std::vector<int32_t> post_slots;   // enumeration regions with the device epilogue
+    for (int g : enum_slots) {
+      const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
+      const StageStat& st = stat[g];
+      const EnumLayout EL = enum_layout(st.R, st.E);
+      int cls = 4;
+      if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_BYTES && st.max_rows <= 64)
+        cls = force_stream ? 3 : (st.max_n <= 32 ? 2 : 3);   // (the 8 / 16 instantiations: one launch has one tail; a 40-entry one: below)
+      if (cls < 4) lds_need[cls] = std::max(lds_need[cls], EL.total);
+      job_base[g] = nj;
+      const uint64_t n = 1ull << S;
+      if (n_t[cls] + (n + per_of[cls] - 1) / per_of[cls] > 0x7fffffffull) { if (err) *err = "too many enumeration restarts for one launch"; return LCR_E_ARG; }
+      spans[cls].push_back({g, (uint32_t)n_t[cls]});
+      n_t[cls] += (size_t)((n + per_of[cls] - 1) / per_of[cls]);
+      nj += (int64_t)n;
+      if (!host_post[g] && !grid_post[g]) post_slots.push_back(g);
+    }
+    // one upload: spans of every class | job_base | slots | post slots ; then job objectives and winners
+    size_t n_w[NCLS], s_off[NCLS], n_spans = 0;
+    for (int k = 0; k < NCLS; k++) { n_w[k] = spans[k].size(); s_off[k] = n_spans; n_spans += n_w[k]; }
+    const size_t ns = enum_slots.size(), nps = post_slots.size();
+    const size_t off_jb_al = (n_spans * sizeof(EnumSpan) + 7) & ~(size_t)7;
+    const size_t up_bytes = off_jb_al + (size_t)ng * 8 + (ns + nps) * 4;
+    PCHK(b_job.reserve(up_bytes + 64));
+    PCHK(b_obj.reserve((size_t)nj * 8 + (size_t)ng * 8 + 64));   // objectives | winners | tiles done
+    PCHK(h_pin[8].reserve(up_bytes + 64));   // pinned: the upload is queued, not staged
+    uint8_t* const up = h_pin[8].as<uint8_t>();
+    for (int k = 0; k < NCLS; k++) memcpy(up + s_off[k] * sizeof(EnumSpan), spans[k].data(), n_w[k] * sizeof(EnumSpan));
+    memcpy(up + off_jb_al, job_base.data(), (size_t)ng * 8);
+    memcpy(up + off_jb_al + (size_t)ng * 8, enum_slots.data(), ns * 4);
+    memcpy(up + off_jb_al + (size_t)ng * 8 + ns * 4, post_slots.data(), nps * 4);
+    PCHK(hipMemcpyAsync(b_job.p, up, up_bytes, hipMemcpyHostToDevice, stream));
+    const EnumSpan* d_sp = b_job.as<EnumSpan>();
+    const int64_t* d_jb = (const int64_t*)(b_job.as<uint8_t>() + off_jb_al);
+    const int32_t* d_sl = (const int32_t*)(b_job.as<uint8_t>() + off_jb_al + (size_t)ng * 8);
+    const int32_t* d_psl = d_sl + ns;
+    long long* d_obj = b_obj.as<long long>();
+    uint32_t* d_win = (uint32_t*)(d_obj + nj);
+    const size_t n_big_blocks = std::max(n_t[4], n_w[4]);
+    PCHK(b_scr.reserve((size_t)stride * n_big_blocks + 64));
+    P.scratch = b_scr.as<int8_t>();
+    // the classes touch disjoint regions: class 2 on `stream`, classes 3 / 4 beside it on `aux` (their tails overlap)
+    // (d_done: tiles finished per region -- the last tile of a region picks its winner and re-runs it, classes 2 / 3)
+    uint32_t* const d_done = d_win + ng;
+    PCHK(hipMemsetAsync(d_done, 0, (size_t)ng * 4, stream));
+    auto launch = [&](const size_t* cnt, const uint32_t* win) -> hipError_t {
+      const dim3 blk(64 * ENUM_WAVES);
+      uint32_t* const done = win ? nullptr : d_done;
+      const bool fork = cnt[2] && (cnt[3] || cnt[4]);
+      hipStream_t s34 = fork ? aux : stream;
+      hipError_t e = hipSuccess;
+      if (fork) { if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e; }
+      if (cnt[2]) hipLaunchKernelGGL(k4_enum_reg<32>, dim3((unsigned)cnt[2]), blk, lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, win, done);
+      if (cnt[3]) hipLaunchKernelGGL(k4_enum_reg<0>, dim3((unsigned)cnt[3]), blk, lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, win, done);
+      if (cnt[4]) hipLaunchKernelGGL(k4_enum_big, dim3((unsigned)cnt[4]), dim3(LCR_BLOCK), 0, s34, P, d_sp + s_off[4], (int32_t)n_w[4], per_of[4], d_jb, d_obj, win);
+      if (fork) { if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e; }
+      return e;
+    };
+    PCHK(launch(n_t, nullptr));
+    if (n_w[4]) {   // the global-memory fallback kernel keeps the separate pick and the winners' second launch
+      const size_t only4[NCLS] = {0, 0, 0, 0, n_w[4]};
+      hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)ns), dim3(64), 0, stream, d_sl, (int32_t)ns, P.reg, d_jb, d_obj, d_win);
+      PCHK(launch(only4, d_win));
+    }
+    if (nps) {
+      // eight waves per region: the slowest region (most rows) sets the kernel's length, and every row sweep of the
+      // epilogue is a pass of <threads> rows (148 -> 103 us on C3)
+      PCHK(k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_post<2 * LCR_BLOCK>), 96 * 1024, 5));
+      hipLaunchKernelGGL(k4_post<2 * LCR_BLOCK>, dim3((unsigned)nps), dim3(2 * LCR_BLOCK), post_lds, stream, pin, d_psl, (int32_t)nps, plut);
+    }
+    PCHK(hipGetLastError());
+  }
+  return LCR_OK;
+  };
+  // Order of the two queues' launches: the enumeration tiles (thousands of four-wave workgroups) and the chain regions'
+  // sixteen-wave workgroups (a CU's worth of LDS and wave slots each) compete for the same CUs, and whoever is launched
+  // second only finds room as the first drains.  A few chain regions go first (C3: sixteen of them, 0.2 ms of work that
+  // used to end with the enumeration 0.47 ms after its launch: phase stage 0.83 -> 0.72 ms); when they would fill the
+  // device themselves (ONT-dRNA: 368) the few enumeration regions go first.
+  const bool chain_first = !chain_slots.empty() && (int)chain_slots.size() * 4 <= std::max(1, k4_grid_blocks());
+  if (chain_first) { const int rc = launch_chain_regions(); if (rc) return rc; }
+  { const int rc = launch_enum_regions(); if (rc) return rc; }
+  if (!chain_first) { const int rc = launch_chain_regions(); if (rc) return rc; }
+  if (prof && !enum_slots.empty()) {   // share sizes of the enumeration regions (entries per lane decide the kernel class)
+    std::vector<int> mn; uint64_t jobs[3] = {0, 0, 0};
+    for (int g : enum_slots) {
+      mn.push_back(stat[g].max_n);
+      const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
+      jobs[stat[g].max_n <= 32 ? 0 : stat[g].max_n <= 48 ? 1 : 2] += 1ull << S;
+    }
+    std::sort(mn.begin(), mn.end());
+    fprintf(stderr, "[phase]   enumeration regions: %zu, entries per lane min %d median %d p90 %d max %d; restarts with <= 32: %llu, 33-48: %llu, > 48: %llu\n",
+            mn.size(), mn.front(), mn[mn.size() / 2], mn[mn.size() * 9 / 10], mn.back(), (unsigned long long)jobs[0], (unsigned long long)jobs[1], (unsigned long long)jobs[2]);
+  }
+  lap("enum launch");
   // ---- post-phase steps of the regions beyond k4_post's LDS image: all CUs on one region at a time, on `side`
   if (!gpost_slots.empty()) {
     grid_lock.acquire();
