@@ -1220,6 +1220,14 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     std::vector<int32_t> wide, big;
     const bool grid_generic = getenv("LCR_GRID_GENERIC") != nullptr;   // test hook
     for (int g : chain_slots) ((int64_t)stat[g].E >= grid_min ? big : wide).push_back(g);
+    // longest first: a batch with more chain regions than CUs runs them in two generations (one sixteen-wave workgroup
+    // per CU), and the workgroups are started in launch order -- the second generation should be the short regions
+    // (cost ~ entries x rounds, rounds ~ SNPs / 4)
+    std::stable_sort(wide.begin(), wide.end(), [&](int a, int b) {
+      const int64_t ca = (int64_t)stat[a].E * (in.cand_region_off[a + 1] - in.cand_region_off[a] + 8);
+      const int64_t cb = (int64_t)stat[b].E * (in.cand_region_off[b + 1] - in.cand_region_off[b] + 8);
+      return ca > cb;
+    });
     const int n_small = (int)wide.size(), n_big = (int)big.size(), nc = n_small + n_big;
     const int grid_waves = std::max(1, k4_grid_blocks()) * 16;
     std::vector<ChainDesc> desc(nc);
