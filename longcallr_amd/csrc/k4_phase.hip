@@ -1322,6 +1322,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   auto launch_enum_regions = [&]() -> int {
   // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
   if (!enum_slots.empty()) {
+    // heaviest regions first (tiles are started in grid order: the kernel's tail should be the light ones; the post-phase
+    // kernel's workgroups follow the same order)
+    std::stable_sort(enum_slots.begin(), enum_slots.end(), [&](int a, int b) { return stat[a].E > stat[b].E; });
     int32_t max_state = 0;
     for (int g : enum_slots) max_state = std::max(max_state, stat[g].R + 2 * (in.cand_region_off[g + 1] - in.cand_region_off[g]));
     const int32_t stride = (max_state + 63) & ~63;
