@@ -380,7 +380,8 @@ __global__ void __launch_bounds__(K1_THREADS)
 k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0,
           int64_t n_cols, const int32_t* __restrict__ tile_fill, const int32_t* __restrict__ tile_lvl,
           const unsigned long long* __restrict__ recs,
-          const int32_t* __restrict__ nscan, uint32_t* __restrict__ planes) {
+          const int32_t* __restrict__ nscan, uint32_t* __restrict__ planes, const int32_t* __restrict__ order) {
+  const int tile = order ? order[blockIdx.x] : (int)blockIdx.x;   // (k1_tile_order: tiles with the most records first)
   __shared__ uint32_t pl[P_NPL * TSTRIDE];
   __shared__ __attribute__((aligned(16))) uint8_t refl[REF_PAD + LCR_TILE + 32];
   __shared__ unsigned long long rec_s[K1_RPB * K1_THREADS];
@@ -389,13 +390,13 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   __shared__ int wsum[K1_WAVES];
 
   const int tid = threadIdx.x;
-  const int g = tile_region[blockIdx.x];
-  const int tc0 = tile_col0[blockIdx.x];               // first column of the tile inside the region
+  const int g = tile_region[tile];
+  const int tc0 = tile_col0[tile];               // first column of the tile inside the region
   const int vec = b.len[g];
   const int tlen = min(LCR_TILE, vec - tc0);
   const int64_t gcol0 = b.col_off[g] + tc0;            // global column of tile column 0
   if (*b.error_flag != 0) return;   // K0 failed (bad CIGAR or record pool overflow): the stage is rejected or repeated
-  const int i0 = 0, i1 = tile_fill[blockIdx.x];   // records of this tile: slots 0 .. i1-1 of its levels (K0)
+  const int i0 = 0, i1 = tile_fill[tile];   // records of this tile: slots 0 .. i1-1 of its levels (K0)
   if (i0 == i1) {
     // no M / D / I record touches this tile (pure intron or uncovered): every plane is 0 except the
     // intron plane, which comes from the global scan.  Most tiles of a spliced data set are like this.
@@ -423,7 +424,7 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   // valid-byte masks of a 16-byte piece in the layout of the mismatch word below (bit 8k + j <-> byte 4j + k):
   // vge[lo] = bytes >= lo, vlt[hi] = bytes < hi
   __shared__ uint32_t vge[17], vlt[17];
-  if (tid < LCR_REC_LEVELS) lvl_at[tid] = tile_lvl[blockIdx.x * LCR_REC_LEVELS + tid];
+  if (tid < LCR_REC_LEVELS) lvl_at[tid] = tile_lvl[tile * LCR_REC_LEVELS + tid];
   if (tid >= 64 && tid < 64 + 34) {
     const int v = (tid - 64) % 17;
     uint32_t m = 0;
@@ -642,12 +643,29 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   }
 }
 
+// Workgroups are started in grid order and a tile's time goes with its records (none: a few us; 15 000: ~150 us), so K1
+// takes its tiles through a permutation that puts the fullest first: one workgroup sorts the tile indices by
+// floor(log2(records + 1)), descending, with LDS counters (the order inside a class is whatever the atomics give -- every
+// tile writes only its own columns, so the planes do not depend on it).
+__global__ void __launch_bounds__(1024) k1_tile_order(const int32_t* __restrict__ tile_fill, int32_t n_tiles, int32_t* __restrict__ order) {
+  __shared__ int cnt[32], cur[32];
+  const int tid = threadIdx.x;
+  if (tid < 32) cnt[tid] = 0;
+  __syncthreads();
+  for (int t = tid; t < n_tiles; t += 1024) atomicAdd(&cnt[31 - (31 - __clz(tile_fill[t] + 1))], 1);   // class 0 = most records
+  __syncthreads();
+  if (tid == 0) { int run = 0; for (int k = 0; k < 32; k++) { cur[k] = run; run += cnt[k]; } }
+  __syncthreads();
+  for (int t = tid; t < n_tiles; t += 1024) order[atomicAdd(&cur[31 - (31 - __clz(tile_fill[t] + 1))], 1)] = t;
+}
+
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const int32_t* tile_fill, const int32_t* tile_lvl, const unsigned long long* recs,
-                      const int32_t* nscan, uint32_t* planes, hipStream_t s) {
+                      const int32_t* nscan, uint32_t* planes, int32_t* order /* n_tiles ints of scratch, or nullptr */, hipStream_t s) {
   if (n_tiles == 0) return;
+  if (order) hipLaunchKernelGGL(k1_tile_order, dim3(1), dim3(1024), 0, s, tile_fill, n_tiles, order);
   hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_fill, tile_lvl,
-                     recs, nscan, planes);
+                     recs, nscan, planes, order);
 }
 
 // ---------------------------------------------------------------------------------------------

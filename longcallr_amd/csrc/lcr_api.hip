@@ -23,7 +23,7 @@ struct lcr_ctx {
   std::vector<int64_t> h_start0, h_col_off;
   std::vector<int32_t> h_len, h_read_begin, h_region_first_tile;
   DevBuf in_[16];  // device copies of host inputs (LCR_MEM_HOST)
-  DevBuf scan_tmp, read_region, read_bin, read_rend, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_fill, k0_items, ndiff, nscan;
+  DevBuf scan_tmp, read_region, read_bin, read_rend, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_fill, k0_items, ndiff, nscan, tile_order;
   int64_t n_items = 0;
 
   // K1
@@ -150,7 +150,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
                     &c->k0_tile_fill, &c->k0_items, &c->region_e_off, &c->frag_tmp_col, &c->frag_tmp_val, &c->ndiff, &c->nscan, &c->planes, &c->flags,
                     &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
                     &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
-                    &c->row_links, &c->row_ptr, &c->col, &c->val};
+                    &c->row_links, &c->row_ptr, &c->col, &c->val, &c->tile_order};
   for (auto* b : bufs) b->release();
   if (c->ev_nnz) (void)hipEventDestroy(c->ev_nnz);
   if (c->ev_cand) (void)hipEventDestroy(c->ev_cand);
@@ -307,6 +307,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->k0_tile_fill.reserve((nt + 8) * 4));
   b.error_flag = c->k0_tile_fill.as<int32_t>() + nt + 4;
   HIPCHK(c, c->k0_tile_count.reserve(std::max<size_t>((size_t)nt * LCR_REC_LEVELS, 1) * 4));   // level table
+  HIPCHK(c, c->tile_order.reserve(std::max(nt, 1) * 4));
   HIPCHK(c, c->ndiff.reserve(nd * 4));
   HIPCHK(c, c->nscan.reserve(nd * 4));
   HIPCHK(c, c->h_stage[0].reserve(64));
@@ -334,7 +335,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
     { Timer t(c, LCR_K_PILEUP);
       launch_k1_pileup(b, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
                        c->k0_tile_fill.as<int32_t>(), c->k0_tile_count.as<int32_t>(), c->k0_items.as<unsigned long long>(),
-                       c->nscan.as<int32_t>(), c->planes.as<uint32_t>(), c->stream);
+                       c->nscan.as<int32_t>(), c->planes.as<uint32_t>(), c->tile_order.as<int32_t>(), c->stream);
       if (!c->dp.ont && c->dp.dist_to_end > 0)
         launch_k1_zonefix(b, c->read_bin.as<ReadBin>(), c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->stream); }
     HIPCHK(c, hipGetLastError());

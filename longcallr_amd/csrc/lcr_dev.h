@@ -137,7 +137,7 @@ void launch_k0_bin(const BatchView& b, const ReadBin* rb, int ont, int D, int32_
                    unsigned int* pool_top, unsigned int pool_cap, unsigned long long* recs, uint32_t* ndiff, hipStream_t s);
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const int32_t* tile_fill, const int32_t* tile_lvl,
-                      const unsigned long long* recs, const int32_t* nscan, uint32_t* planes, hipStream_t s);
+                      const unsigned long long* recs, const int32_t* nscan, uint32_t* planes, int32_t* order, hipStream_t s);
 void launch_k1_zonefix(const BatchView& b, const ReadBin* rbin, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s);
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const int32_t* tile_fill, uint8_t* flags,
