@@ -648,15 +648,51 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
 // floor(log2(records + 1)), descending, with LDS counters (the order inside a class is whatever the atomics give -- every
 // tile writes only its own columns, so the planes do not depend on it).
 __global__ void __launch_bounds__(1024) k1_tile_order(const int32_t* __restrict__ tile_fill, int32_t n_tiles, int32_t* __restrict__ order) {
-  __shared__ int cnt[32], cur[32];
-  const int tid = threadIdx.x;
-  if (tid < 32) cnt[tid] = 0;
+  // per-wave counters (one counter per class for the whole workgroup serialised 15 000 LDS atomics on the class of the
+  // record-free tiles: 22 us); the record-free tiles -- three quarters of them -- are ranked with ballots instead
+  __shared__ int cnt[16][32], n_empty[16], ecur[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int i = tid; i < 16 * 32; i += 1024) (&cnt[0][0])[i] = 0;
   __syncthreads();
-  for (int t = tid; t < n_tiles; t += 1024) atomicAdd(&cnt[31 - (31 - __clz(tile_fill[t] + 1))], 1);   // class 0 = most records
+  int my_empty = 0;
+  for (int t = tid; t < n_tiles; t += 8 * 1024) {   // (one workgroup: eight loads in flight per thread, or it is all latency)
+    int f[8];
+#pragma unroll
+    for (int x = 0; x < 8; x++) f[x] = t + x * 1024 < n_tiles ? tile_fill[t + x * 1024] : -1;
+#pragma unroll
+    for (int x = 0; x < 8; x++)
+      if (f[x] == 0) my_empty++; else if (f[x] > 0) atomicAdd(&cnt[w][__clz(f[x])], 1);   // class = leading zeros: more records, lower class
+  }
+  my_empty = wave_incl_scan(my_empty);
+  if (lane == 63) n_empty[w] = my_empty;
   __syncthreads();
-  if (tid == 0) { int run = 0; for (int k = 0; k < 32; k++) { cur[k] = run; run += cnt[k]; } }
+  if (tid < 32) {   // thread k: class k's base = everything in lower classes; then its per-wave cursors
+    int base = 0;
+    for (int k = 0; k < tid; k++) for (int v = 0; v < 16; v++) base += cnt[v][k];
+    for (int v = 0; v < 16; v++) { const int c = cnt[v][tid]; cnt[v][tid] = base; base += c; }
+  }
+  if (tid == 32) {   // record-free tiles go behind all the others
+    int tot = 0;
+    for (int v = 0; v < 16; v++) tot += n_empty[v];
+    int base = n_tiles - tot;
+    for (int v = 0; v < 16; v++) { ecur[v] = base; base += n_empty[v]; }
+  }
   __syncthreads();
-  for (int t = tid; t < n_tiles; t += 1024) order[atomicAdd(&cur[31 - (31 - __clz(tile_fill[t] + 1))], 1)] = t;
+  int e_at = ecur[w];
+  for (int t0 = w * 64; t0 < n_tiles; t0 += 8 * 1024) {   // (wave-uniform trip count: the ballots need every lane)
+    int f[8];
+#pragma unroll
+    for (int x = 0; x < 8; x++) { const int t = t0 + x * 1024 + lane; f[x] = t < n_tiles ? tile_fill[t] : -1; }
+#pragma unroll
+    for (int x = 0; x < 8; x++) {
+      const int t = t0 + x * 1024 + lane;
+      const unsigned long long m = __ballot(f[x] == 0);
+      if (f[x] == 0) order[e_at + __popcll(m & below)] = t;
+      else if (f[x] > 0) order[atomicAdd(&cnt[w][__clz(f[x])], 1)] = t;
+      e_at += __popcll(m);
+    }
+  }
 }
 
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
