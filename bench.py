@@ -440,14 +440,14 @@ def main():
                        "columns_rank0": cols, "aligned_bases_rank0": int(batch.bases.size),
                        "parallelism": "regions sharded over %d GPU(s) by shard.assign_regions (LPT on len x max_coverage), gather of records to rank 0" % world,
                        "batches_in_flight_per_gpu": F},
-            "roofline": {"bound": "hbm", "kernel": "pileup stage = k0_bin + intron scan + k1_pileup (+ k1_zonefix on HiFi presets): what replaces fill_data_into_freq_vec",
+            "roofline": {"bound": "hbm", "kernel": "pileup stage = k0_bin + intron scan + k1_tile_order + k1_pileup (+ k1_zonefix on HiFi presets): what replaces fill_data_into_freq_vec",
                          "achieved": stage_bytes / (stage_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
                          "algorithmic_bytes": stage_bytes, "avg_ms": stage_ms,
                          "note": "algorithmic bytes B + 4C + 37R + 53L (bases once, CIGAR, read headers, ref byte + 13 u32 planes per column); "
                                  "HIP events on the ctx stream, rank 0; traffic = committed PMC passes of the same workload (profiles/), not this run",
                          "k1_pileup": {"algorithmic_bytes": pbytes, "avg_ms": avg_ms, "achieved": achieved, "frac": achieved / 8000.0,
-                                       "note": "the tally kernel alone: bases once + 8-byte records + 57 B/column"}},
+                                       "note": "the tally kernel with its tile-ordering pass (k1_tile_order + k1_pileup): bases once + 8-byte records + 57 B/column"}},
             "stages": {"pileup_plus_candidates_s": t_call, "fragments_plus_phase_s": t_phase,
                        "sites_per_sec_pileup_gt": cols / t_call, "covered_sites_per_sec_pileup_gt": covered / t_call,
                        "candidates_per_sec_pileup_gt": int(cands.size) / t_call, "phased_reads_per_sec": n_phased / t_phase,
