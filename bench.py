@@ -6,7 +6,7 @@ Workloads (config.workload):
   N = 1   BASELINE.json configs[2], "synthetic 10 Mb ONT-cDNA, 40x" (C3: 400 regions x 25 kb) -- the largest configuration
           whose metric is quoted on one GPU; demo.bam (configs[0]/[1]) is ~5 MB of traffic and a parity fixture, not a
           bench line.  The C5 stress (configs[4], ONE 1 Mb island at 500x) is run once beside it and reported in
-          `stages.c5`, and the default workload once more with two batches in flight as `stages.two_batches_in_flight`
+          `stages.c5`, and the default workload once more with three batches in flight as `stages.batches_in_flight`
           (--no-c5 skips both).
   N > 1   BASELINE.json configs[3], "synthetic 200 Mb PacBio MAS-Seq, 60x, region-sharded across 8 GPUs" scaled to
           N GPUs: ONE list of N x 1 000 regions (25 Mb x 60x per GPU), partitioned over the ranks by
@@ -110,12 +110,12 @@ WORKLOADS = {   # name -> (profile, regions per GPU, unique genes, gene_len, dep
 }
 
 
-def two_in_flight_stage(api, torch, device, params, dev_batch, cols, steps=40):
-    """The same step with TWO batches in flight on the GPU (two contexts, two host threads): the queue gaps of one batch's
-    round trips are filled by the other's kernels.  Reported beside `value`, never as it: the co-scheduled kernels stretch
-    each other, so the roofline is quoted on the undisturbed single-batch run."""
+def batches_in_flight_stage(api, torch, device, params, dev_batch, cols, contexts=3, steps=60):
+    """The same step with several batches in flight on the GPU (one context and one host thread each): the queue gaps of
+    one batch's host round trips are filled by the others' kernels.  Reported beside `value`, never as it: the co-scheduled
+    kernels stretch each other, so the roofline is quoted on the undisturbed single-batch run."""
     import threading
-    engines = [api.Engine(device, params) for _ in range(2)]
+    engines = [api.Engine(device, params) for _ in range(contexts)]
     def run(E, n):
         torch.cuda.set_device(device)
         for _ in range(n):
@@ -126,7 +126,7 @@ def two_in_flight_stage(api, torch, device, params, dev_batch, cols, steps=40):
         run(E, 3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ths = [threading.Thread(target=run, args=(E, steps // 2)) for E in engines]
+    ths = [threading.Thread(target=run, args=(E, steps // contexts)) for E in engines]
     for t in ths:
         t.start()
     for t in ths:
@@ -135,9 +135,9 @@ def two_in_flight_stage(api, torch, device, params, dev_batch, cols, steps=40):
     dt = time.perf_counter() - t0
     for E in engines:
         E.close()
-    n = 2 * (steps // 2)
-    return {"steps": n, "ms_per_step": dt / n * 1e3, "sites_per_sec": cols * n / dt,
-            "note": "two contexts on two host threads share the GPU (bench.py --inflight 2 times the whole run this way)"}
+    n = contexts * (steps // contexts)
+    return {"contexts": contexts, "steps": n, "ms_per_step": dt / n * 1e3, "sites_per_sec": cols * n / dt,
+            "note": "%d contexts on %d host threads share the GPU (bench.py --inflight %d times the whole run this way)" % (contexts, contexts, contexts)}
 
 
 def c5_stage(api, _abi, synth, device):
@@ -491,7 +491,7 @@ def main():
                        "api_ms": api_ms, "kernel_ms": kms},
         }
         if world == 1 and F == 1 and not a.no_c5:
-            out["stages"]["two_batches_in_flight"] = two_in_flight_stage(api, torch, local, params, (reads, regions, keep), cols)
+            out["stages"]["batches_in_flight"] = batches_in_flight_stage(api, torch, local, params, (reads, regions, keep), cols)
         if world == 1 and not a.no_c5:
             out["stages"]["c5"] = c5_stage(api, _abi, synth, local)
         if not a.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks of a node would sit idle behind it
