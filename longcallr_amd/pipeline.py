@@ -109,7 +109,9 @@ def run(bam_path, ref_path, out_vcf, out_bam=None, preset="hifi-masseq", contigs
     """BAM + FASTA (+ .fai) -> phased VCF and, with out_bam, the phased BAM.  Returns a dict of counts.
     devices: GPUs to use (default [device]); a contig's regions are cut into chunks (chunk_regions) that the engines --
     one context and one host thread per device -- take in turn (regions are independent units, thread.rs:77; the BAM
-    decoder cuts the batches on the calling thread).  The output does not depend on devices or chunk_cost."""
+    decoder cuts the batches on the calling thread).  A GPU may be named more than once (devices=[0, 0, 0]): that many
+    chunks are then in flight on it, each filling the queue gaps of the others' host round trips (bench.py
+    stages.batches_in_flight: +25 % at three).  The output does not depend on devices or chunk_cost."""
     from concurrent.futures import ThreadPoolExecutor
     import threading
     fai = ref_path + ".fai"
