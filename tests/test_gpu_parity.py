@@ -928,3 +928,28 @@ def test_poly_a_mask_zone_sizes(engine_cls, orc, dist_to_end, polya_len):
     E.load_batch(b).fill_data_into_freq_vec()
     check_pileup(E, regs, b)
     E.close()
+
+
+def test_bench_line_contract():
+    """`python bench.py` prints ONE JSON line with the fields the driver reads: metric / value / unit / n_gpus / steps /
+    warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, a `roofline` object
+    (bound, achieved, peak, unit, frac = achieved / peak, traffic) and -- without --no-cpu-baseline -- `cpu_baseline`."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--prewarm", "1", "--no-c5",
+                          "--cpu-budget", "2"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "stages"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.0 < r["frac"] < 1.0 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert abs(d["value"] - d["config"]["columns"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
