@@ -953,3 +953,16 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - d["config"]["columns"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_bench_several_batches_in_flight():
+    """`bench.py --inflight 2`: two contexts on two host threads share the GPU; the line keeps its contract and says so."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--prewarm", "2", "--no-c5",
+                          "--no-cpu-baseline", "--inflight", "2"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"]["batches_in_flight_per_gpu"] == 2 and d["steps"] == 4 and d["value"] > 0 and "cpu_baseline" not in d
