@@ -104,10 +104,36 @@ def subset_batch(base, ids, gap=1000):
                           start0=start0, len=length, read_begin=read_begin, ref=cat("ref", np.uint8))
 
 
-WORKLOADS = {   # name -> (profile, regions per GPU, unique genes, gene_len, depth, BASELINE config it stands for)
-    "c3": ("ont-cdna", 400, 50, 25000, 40.0, "C3 = BASELINE configs[2]: synthetic 10 Mb ONT-cDNA, 40x"),
-    "c4": ("masseq", 1000, 50, 25000, 60.0, "C4 = BASELINE configs[3]: synthetic 200 Mb PacBio MAS-Seq, 60x, region-sharded (25 Mb per GPU)"),
+WORKLOADS = {   # name -> (profile, regions per GPU, gene_len, depth, BASELINE config it stands for)
+    "c3": ("ont-cdna", 400, 25000, 40.0, "C3 = BASELINE configs[2]: synthetic 10 Mb ONT-cDNA, 40x"),
+    "c4": ("masseq", 1000, 25000, 60.0, "C4 = BASELINE configs[3]: synthetic 200 Mb PacBio MAS-Seq, 60x, region-sharded (25 Mb per GPU)"),
 }
+
+
+def build_shard(name, world=1, rank=0, seed=1, genes=None, gene_len=None, depth=None, profile=None, workers=0):
+    """Rank `rank`'s regions of workload `name` on `world` GPUs.  The job is ONE list of world x (regions per GPU)
+    DISTINCT genes (synth.make_genes: gene k has its own generator); it is partitioned by
+    shard.assign_regions -- LPT on len x max_coverage, computed for the whole list from the genes' read spans without
+    building them (synth.gene_costs) -- and a rank builds only its own genes.  Returns (batch, ids, n_global)."""
+    from longcallr_amd import shard, synth
+    w_profile, w_genes, w_len, w_depth, _ = WORKLOADS[name]
+    profile, genes, gene_len, depth = profile or w_profile, genes or w_genes, gene_len or w_len, depth or w_depth
+    n_global = world * genes
+    if world == 1:
+        mine = list(range(n_global))
+    else:
+        costs = synth.gene_costs(profile, range(n_global), gene_len=gene_len, depth=depth, seed=seed)
+        mine = shard.assign_regions(costs, world)[rank]
+    if workers <= 0:   # the ranks of one node generate side by side
+        workers = max(1, min(64, (os.cpu_count() or 1) // max(1, world)))
+    batch = synth.make_genes(profile, gene_len=gene_len, depth=depth, seed=seed, workers=workers, gene_ids=mine)
+    return batch, mine, n_global
+
+
+def build_workload(name, seed=1, workers=0):
+    """The single-GPU form of a workload: "c3" = the 400 genes of BASELINE configs[2], "c4" = one GPU's 1 000 genes of
+    configs[3] (bench.py --workload c4; tests/test_gpu_parity.py compares both with the oracle at this size)."""
+    return build_shard(name, 1, 0, seed=seed, workers=workers)[0]
 
 
 def batches_in_flight_stage(api, torch, device, params, dev_batch, cols, contexts=3, steps=60):
@@ -238,7 +264,7 @@ def main():
                     help="auto: C3 at N = 1, the region-sharded C4 at N > 1")
     ap.add_argument("--profile", default=None, help="read profile of longcallr_amd.synth (default: the workload's)")
     ap.add_argument("--genes", type=int, default=None, help="regions per GPU (default: the workload's)")
-    ap.add_argument("--unique-genes", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=1, help="generator seed of the synthetic genes (SURVEY §8(d): seeds 1..5)")
     ap.add_argument("--gene-len", type=int, default=None)
     ap.add_argument("--depth", type=float, default=None)
     ap.add_argument("--no-c5", action="store_true", help="skip the single pass over the C5 island (N = 1)")
@@ -290,22 +316,14 @@ def main():
     if a.gpus != world:
         raise SystemExit("bench.py --gpus %d under a launcher with WORLD_SIZE=%d" % (a.gpus, world))
     wl = a.workload if a.workload != "auto" else ("c3" if world == 1 else "c4")
-    w_profile, w_genes, w_unique, w_len, w_depth, w_name = WORKLOADS[wl]
+    w_profile, w_genes, w_len, w_depth, w_name = WORKLOADS[wl]
     a.profile = a.profile or w_profile
     a.genes = a.genes or w_genes
-    a.unique_genes = a.unique_genes or w_unique
     a.gene_len = a.gene_len or w_len
     a.depth = a.depth or w_depth
-    copies = max(1, a.genes // a.unique_genes)
-    # ONE region list for the whole job: world x genes regions, region k = unique gene k % U at copy k // U (same seed on
-    # every rank).  LPT on len x max_coverage assigns them to the ranks; a rank builds only its own regions.
-    base = synth.make_batch(a.profile, n_genes=a.unique_genes, gene_len=a.gene_len, depth=a.depth, seed=1000)
-    n_global = world * copies * a.unique_genes
-    cost_u = base.len.astype(np.float64) * region_max_coverage(base)
-    costs = cost_u[np.arange(n_global) % a.unique_genes]
-    owner = shard.assign_regions(costs, world)
-    mine = owner[rank]
-    batch = tile_batch(base, copies) if world == 1 else subset_batch(base, mine)
+    # ONE region list for the whole job: world x genes distinct genes, LPT on len x max_coverage assigns them to the
+    # ranks; a rank builds only its own regions (build_shard)
+    batch, mine, n_global = build_shard(wl, world, rank, seed=a.seed, genes=a.genes, gene_len=a.gene_len, depth=a.depth, profile=a.profile)
     assert batch.n_regions == len(mine)
     params = _abi.make_params(synth.preset_for(a.profile), seed=2025)
     reads, regions, keep = to_device(batch, torch, dev)
@@ -434,12 +452,8 @@ def main():
         tot = tt.cpu().numpy()
     if rank == 0:
         cols = int(batch.col_off[-1])
-        # covered sites (depth >= min_depth on A+C+G+T, candidate.rs:90-94): counted on the unique genes, times the copies
-        Eb = api.Engine(local, params)
-        Eb.load_batch(base).fill_data_into_freq_vec()
-        cov_u = (Eb.columns()[:4].sum(axis=0) >= params.min_depth)
-        covered = int(sum(int(cov_u[int(base.col_off[int(k) % a.unique_genes]):int(base.col_off[int(k) % a.unique_genes + 1])].sum()) for k in mine))
-        Eb.close()
+        # covered sites (depth >= min_depth on A+C+G+T, candidate.rs:90-94) of this rank's batch
+        covered = int((E.columns()[:4].sum(axis=0) >= params.min_depth).sum())
         pbytes = E.pileup_bytes()
         avg_ms = float(np.mean([t[0] for t in pile_ms]))
         avg_k0_ms = float(np.mean([t[1] for t in pile_ms]))
@@ -450,8 +464,7 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "k1_traffic.json")))
             w = tj["workload"]
-            if (w["profile"], w["genes"], w["unique_genes"], w["gene_len"], w["depth"]) == (
-                    a.profile, a.genes, a.unique_genes, a.gene_len, a.depth):
+            if (w["profile"], w["genes"], w["gene_len"], w["depth"], w.get("seed")) == (a.profile, a.genes, a.gene_len, a.depth, a.seed):
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -461,11 +474,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 in, u32 counts, f64 likelihoods, i64 fixed-point phase scores", "data": "synthetic",
-            "config": {"workload": "%s; synthetic %s reads, %d regions x %d bp per GPU at %.0fx mean aligned depth "
-                                   "(%d unique genes x %d copies; %d regions in the job, LPT-partitioned over %d rank(s)), preset %s; "
+            "config": {"workload": "%s; synthetic %s reads, %d distinct genes (regions) x %d bp per GPU at %.0fx mean aligned depth, "
+                                   "generator seed %d; %d regions in the job, LPT-partitioned over %d rank(s), preset %s; "
                                    "step = bind+pileup+candidates+fragments+phase"
-                                   % (w_name, a.profile, copies * a.unique_genes, a.gene_len, a.depth, a.unique_genes, copies * world,
-                                      n_global, world, synth.preset_for(a.profile)),
+                                   % (w_name, a.profile, a.genes, a.gene_len, a.depth, a.seed, n_global, world, synth.preset_for(a.profile)),
                        "columns": int(tot[0]), "aligned_bases": int(tot[1]), "reads": int(tot[2]), "candidates": int(tot[3]),
                        "fragment_nnz": int(tot[4]), "phasing_reads": int(tot[5]),
                        "columns_rank0": cols, "aligned_bases_rank0": int(batch.bases.size),

@@ -39,7 +39,7 @@ _COMP = {0: 3, 1: 2, 2: 1, 3: 0}
 OP_M, OP_I, OP_D, OP_N, OP_S = 0, 1, 2, 3, 4
 
 
-def _gene(rng, prof, gene_len, depth, gene_start, exon_frac=0.25, ref_in=None, ref_guard=0):
+def _gene(rng, prof, gene_len, depth, gene_start, exon_frac=0.25, ref_in=None, ref_guard=0, structure_only=False):
     """One gene: returns per-read arrays + concatenated bases/quals/cigar (gene-local offsets).
     ref_in: a writable slice of a shared reference (>= gene_len + 64 + slack) to use instead of a private one;
     the first and last ref_guard columns of the gene are then left unmodified (they belong to the neighbours too)."""
@@ -90,6 +90,8 @@ def _gene(rng, prof, gene_len, depth, gene_start, exon_frac=0.25, ref_in=None, r
     tstart = (rng.random(n_reads) * (T - rlen + 1)).astype(np.int64)
     order = np.argsort(tx2g[tstart], kind="stable")
     tstart, rlen = tstart[order], rlen[order]
+    if structure_only:   # read spans before poly-A tails: what a scheduler's cost model needs (gene_cost)
+        return dict(start=tx2g[tstart] + gene_start, end=tx2g[tstart + rlen - 1] + 1 + gene_start, span=span, aligned=int(rlen.sum()))
     hap = rng.integers(0, 2, size=n_reads)
     rev = (rng.integers(0, 2, size=n_reads) if prof["both_strands"] else np.zeros(n_reads, dtype=np.int64))
     ts_plus = np.full(n_reads, plus_gene)
@@ -251,6 +253,100 @@ def make_batch(profile="ont-cdna", n_genes=4, gene_len=25000, depth=40.0, seed=1
                      cig_off=(np.cumsum(n_cig) - n_cig).astype(np.uint64), n_cig=n_cig.astype(np.uint32),
                      bases=cat("bases", np.uint8), quals=quals, cigar=cat("cigar", np.uint32),
                      start0=regions_start, len=regions_len, read_begin=read_begin, ref=np.concatenate(refs))
+
+
+def _gene_job(args):
+    profile, gene_len, depth, seed, k, start = args
+    g = _gene(np.random.default_rng([seed, k]), PROFILES[profile], gene_len, depth, start)
+    ops, lens = g["cigar"] & 15, (g["cigar"] >> 4).astype(np.int64)
+    cig_read = np.repeat(np.arange(len(g["n_cig"])), g["n_cig"])
+    ref_len = np.bincount(cig_read, weights=np.where(np.isin(ops, [0, 2, 3, 7, 8]), lens, 0), minlength=len(g["n_cig"])).astype(np.int64)
+    lo, hi = int(g["pos"].min()), int((g["pos"] + ref_len).max())
+    pad_l = start - lo   # aligned poly-T tails may start left of the gene
+    ref = g["ref"]
+    rr = np.random.default_rng([seed, k, 1])
+    if pad_l > 0:
+        ref = np.concatenate([_ACGT[rr.integers(0, 4, size=pad_l)], ref])
+    elif pad_l < 0:
+        ref = ref[-pad_l:]
+    if ref.size < hi - lo:
+        ref = np.concatenate([ref, _ACGT[rr.integers(0, 4, size=hi - lo - ref.size)]])
+    g["ref"], g["lo"], g["len"] = ref[:hi - lo], lo, hi - lo
+    return g
+
+
+def gene_costs(profile, gene_ids, gene_len=25000, depth=40.0, seed=1, gap=1000):
+    """len x max_coverage (Region.max_coverage, util.rs:28,281-285: every reference position of a read span counts) of
+    the genes `gene_ids` of make_genes' list WITHOUT building their reads: the structure draws of gene k (exons, read
+    starts and lengths) come first in its stream, so the read spans are known after a few milliseconds.  Poly-A tails
+    aligned past a gene's end (<= 40 columns) are not in the estimate."""
+    stride = gene_len + 4096 + gap
+    out = np.zeros(len(gene_ids), dtype=np.float64)
+    for i, k in enumerate(gene_ids):
+        g = _gene(np.random.default_rng([seed, int(k)]), PROFILES[profile], gene_len, depth, 100000 + int(k) * stride, structure_only=True)
+        lo = int(g["start"].min())
+        d = np.zeros(int(g["end"].max()) - lo + 2, dtype=np.int64)
+        np.add.at(d, g["start"] - lo, 1); np.add.at(d, g["end"] - lo, -1)
+        out[i] = float(g["end"].max() - lo) * float(np.cumsum(d).max())
+    return out
+
+
+def _worker_main():
+    import pickle, sys
+    jobs = pickle.loads(sys.stdin.buffer.read())
+    sys.stdout.buffer.write(pickle.dumps([_gene_job(j) for j in jobs], protocol=pickle.HIGHEST_PROTOCOL))
+
+
+def make_genes(profile="ont-cdna", n_genes=400, gene_len=25000, depth=40.0, seed=1, gap=1000, workers=0, min_q1=True, gene_ids=None):
+    """n_genes DISTINCT genes (C3 = 400 genes x 25 kb), gene k drawn from its own generator
+    default_rng([seed, k]) at a fixed origin 100000 + k x (gene_len + 4096 + gap), so the batch does not depend on the
+    number of worker processes that build it (workers = 0: all hardware threads, 1: in this process).  Same gene model
+    as make_batch (which draws its genes from ONE stream and packs them back to back).  gene_ids: build only these genes
+    of the list (a rank's shard of a region-sharded job)."""
+    import os
+    stride = gene_len + 4096 + gap
+    ids = list(range(n_genes)) if gene_ids is None else [int(k) for k in gene_ids]   # (gene_ids: a shard of a longer list, ascending)
+    n_genes = len(ids)
+    jobs = [(profile, gene_len, depth, seed, k, 100000 + k * stride) for k in ids]
+    workers = workers if workers > 0 else min(os.cpu_count() or 1, 64)
+    workers = min(workers, n_genes)
+    if workers > 1:
+        # plain child interpreters fed over pipes (no multiprocessing: neither a fork of a process that may hold a HIP
+        # context nor spawn's re-import of the caller's __main__); worker w builds genes w, w + workers, ...
+        import pickle, subprocess, sys, threading
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+        procs = [subprocess.Popen([sys.executable, "-c", "from longcallr_amd import synth; synth._worker_main()"],
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env) for _ in range(workers)]
+        outs = [None] * workers
+
+        def talk(w):
+            outs[w] = procs[w].communicate(pickle.dumps(jobs[w::workers]))[0]
+        ths = [threading.Thread(target=talk, args=(w,)) for w in range(workers)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        parts = [None] * n_genes
+        for w in range(workers):
+            if procs[w].returncode != 0:
+                raise RuntimeError("synth worker %d failed" % w)
+            parts[w::workers] = pickle.loads(outs[w])
+    else:
+        parts = [_gene_job(j) for j in jobs]
+    cat = lambda k, dt: np.concatenate([p[k] for p in parts]).astype(dt)
+    seq_len, n_cig = cat("seq_len", np.int64), cat("n_cig", np.int64)
+    quals = cat("quals", np.uint8)
+    if min_q1:
+        quals = np.maximum(quals, 1)
+    read_begin = np.concatenate([[0], np.cumsum([len(p["pos"]) for p in parts])])
+    return ReadBatch(pos=cat("pos", np.int32), seq_len=seq_len.astype(np.int32), lead_clip=cat("lead_clip", np.int32),
+                     trail_clip=cat("trail_clip", np.int32), flags=cat("flags", np.uint8),
+                     seq_off=(np.cumsum(seq_len) - seq_len).astype(np.uint64),
+                     cig_off=(np.cumsum(n_cig) - n_cig).astype(np.uint64), n_cig=n_cig.astype(np.uint32),
+                     bases=cat("bases", np.uint8), quals=quals, cigar=cat("cigar", np.uint32),
+                     start0=[p["lo"] for p in parts], len=[p["len"] for p in parts], read_begin=read_begin,
+                     ref=np.concatenate([p["ref"] for p in parts]))
 
 
 def make_island(profile="ont-drna-c5", n_loci=40, locus_len=25000, depth=500.0, seed=1, overlap=400, min_q1=True):

@@ -13,7 +13,9 @@
 #include "orc_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cassert>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -21,6 +23,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -805,7 +808,8 @@ struct orc_region {
   /* phase.rs:257-276 (F64) / exact fixed-point sum, compared as int64 and reported / 2^40 (EXACT) */
   mutable int64_t last_obj_fx = 0;
   double cal_overall_probability(int mode) const {
-    if (mode == ORC_MODE_F64) {
+    if (!orc_mode_fx(mode)) {
+      if (orc_mode_both(mode)) cal_overall_probability(ORC_MODE_EXACT_ONLY);   /* last_obj_fx for the tie counter of better() */
       double logp = 0.0;
       for (size_t k = 0; k < frags.size(); k++) {
         if (!frags[k].for_phasing || frags[k].haplotag == 0) continue;
@@ -832,6 +836,9 @@ struct orc_region {
   /* ---------- P12: cross_optimize (phase.rs:810-976) ---------- */
   double cross_optimize(int mode, const std::set<int>& conserved, bool keep_conserved, bool with_genotype) {
     stats[0]++;
+    /* by_fx: decisions by the exact fixed-point sums (else by the reference's f64 ratio scores); both: the other
+     * arithmetic is evaluated too and disagreements are counted (stats[2]); the *_ONLY modes skip it */
+    const bool by_fx = orc_mode_fx(mode), both = orc_mode_both(mode), use_fx = by_fx || both, use_f64 = !by_fx || both;
     bool hg_inc = true, h_inc = true;
     int num_iters = 0;
     RowView rv; ColView cv;
@@ -845,20 +852,24 @@ struct orc_region {
         const int sigma_k = frags[k].haplotag;
         row_gather(k, rv);
         if (rv.delta.empty()) continue;
-        const double q = cal_sigma_delta_eta_log(sigma_k, rv.delta, rv.eta, rv.ps, rv.probs);
-        const double qn = cal_sigma_delta_eta_log(-sigma_k, rv.delta, rv.eta, rv.ps, rv.probs);
+        double q = 0.0, qn = 0.0;
+        if (use_f64) {
+          q = cal_sigma_delta_eta_log(sigma_k, rv.delta, rv.eta, rv.ps, rv.probs);
+          qn = cal_sigma_delta_eta_log(-sigma_k, rv.delta, rv.eta, rv.ps, rv.probs);
+        }
         int64_t A = 0, B = 0;
-        for (size_t e = 0; e < rv.delta.size(); e++) { A += fx_aki(sigma_k, rv.delta[e], rv.eta[e], rv.ps[e], rv.q[e]); B += fx_aki(-sigma_k, rv.delta[e], rv.eta[e], rv.ps[e], rv.q[e]); }
+        if (use_fx)
+          for (size_t e = 0; e < rv.delta.size(); e++) { A += fx_aki(sigma_k, rv.delta[e], rv.eta[e], rv.ps[e], rv.q[e]); B += fx_aki(-sigma_k, rv.delta[e], rv.eta[e], rv.ps[e], rv.q[e]); }
         const bool flip_f64 = q < qn, flip_fx = A < B;
-        if (flip_f64 != flip_fx) stats[2]++;
-        const bool flip = mode == ORC_MODE_F64 ? flip_f64 : flip_fx;
+        if (both && flip_f64 != flip_fx) stats[2]++;
+        const bool flip = by_fx ? flip_fx : flip_f64;
         tmp_haplotag[k] = flip ? -sigma_k : sigma_k;
         /* check_new_haplotag, phase.rs:278-314 (sums in key order instead of HashMap order) */
         logp += flip ? qn : q; pre_logp += q;
         if (flip) any_strict = true;
       }
       int check_val;
-      if (mode == ORC_MODE_F64) { check_val = logp > pre_logp ? 1 : (logp == pre_logp ? 0 : -1); if (check_val < 0) { stats[3]++; check_val = 0; } }
+      if (!by_fx) { check_val = logp > pre_logp ? 1 : (logp == pre_logp ? 0 : -1); if (check_val < 0) { stats[3]++; check_val = 0; } }
       else check_val = any_strict ? 1 : 0;
       for (auto& kv : tmp_haplotag) frags[kv.first].haplotag = kv.second;
       if (check_val == 0) h_inc = false; else { h_inc = true; hg_inc = true; }
@@ -871,12 +882,15 @@ struct orc_region {
         const int delta_i = cands[i].haplotype, eta_i = cands[i].genotype;
         col_gather(i, cv);
         if (cv.sigma.empty()) continue;
-        const double q1 = cal_delta_eta_sigma_log(delta_i, 0, cv.sigma, cv.ps, cv.probs);
-        const double q2 = cal_delta_eta_sigma_log(-delta_i, 0, cv.sigma, cv.ps, cv.probs);
-        const double q3 = cal_delta_eta_sigma_log(delta_i, 1, cv.sigma, cv.ps, cv.probs);
-        const double q4 = cal_delta_eta_sigma_log(delta_i, -1, cv.sigma, cv.ps, cv.probs);
+        double q1 = 0.0, q2 = 0.0, q3 = 0.0, q4 = 0.0;
+        if (use_f64) {
+          q1 = cal_delta_eta_sigma_log(delta_i, 0, cv.sigma, cv.ps, cv.probs);
+          q2 = cal_delta_eta_sigma_log(-delta_i, 0, cv.sigma, cv.ps, cv.probs);
+          q3 = cal_delta_eta_sigma_log(delta_i, 1, cv.sigma, cv.ps, cv.probs);
+          q4 = cal_delta_eta_sigma_log(delta_i, -1, cv.sigma, cv.ps, cv.probs);
+        }
         int64_t N[4] = {0, 0, 0, 0};
-        for (size_t e = 0; e < cv.sigma.size(); e++) {
+        for (size_t e = 0; use_fx && e < cv.sigma.size(); e++) {
           N[0] += fx_aki(cv.sigma[e], delta_i, 0, cv.ps[e], cv.q[e]);
           N[1] += fx_aki(cv.sigma[e], -delta_i, 0, cv.ps[e], cv.q[e]);
           N[2] += fx_aki(cv.sigma[e], delta_i, 1, cv.ps[e], cv.q[e]);
@@ -898,8 +912,8 @@ struct orc_region {
           ch_f64 = q3 == max_q ? 2 : q4 == max_q ? 3 : -1;
           ch_fx = N[3] > N[2] ? 3 : 2;
         }
-        if (ch_f64 != ch_fx) stats[2]++;
-        const int ch = mode == ORC_MODE_F64 ? ch_f64 : ch_fx;
+        if (both && ch_f64 != ch_fx) stats[2]++;
+        const int ch = by_fx ? ch_fx : ch_f64;
         if (ch < 0) continue; /* NaN scores: the reference inserts nothing (or panics) */
         const std::pair<int, int> pick[4] = {{delta_i, 0}, {-delta_i, 0}, {delta_i, 1}, {delta_i, -1}};
         tmp_hg[i] = pick[ch];
@@ -909,7 +923,7 @@ struct orc_region {
         logp += qs[ch]; pre_logp += qs[cur];
         if (N[ch] > N[cur]) any_strict = true;
       }
-      if (mode == ORC_MODE_F64) { check_val = logp > pre_logp ? 1 : (logp == pre_logp ? 0 : -1); if (check_val < 0) { stats[3]++; check_val = 0; } }
+      if (!by_fx) { check_val = logp > pre_logp ? 1 : (logp == pre_logp ? 0 : -1); if (check_val < 0) { stats[3]++; check_val = 0; } }
       else check_val = any_strict ? 1 : 0;
       for (auto& kv : tmp_hg) { cands[kv.first].haplotype = kv.second.first; cands[kv.first].genotype = kv.second.second; }
       if (check_val == 0) hg_inc = false; else { hg_inc = true; h_inc = true; }
@@ -1031,8 +1045,8 @@ struct orc_region {
     int64_t largest_fx = std::numeric_limits<int64_t>::min();
     auto better = [&](double prob) {  /* `prob > largest_prob` (phase.rs:1117,1129,...); EXACT compares the int64 sums */
       const bool b_f64 = prob > largest_prob, b_fx = last_obj_fx > largest_fx;
-      if (b_f64 != b_fx) stats[2]++;   /* two restarts of equal objective (an uninformative SNP flipped): the f64 sums differ by rounding noise */
-      const bool b = mode == ORC_MODE_F64 ? b_f64 : b_fx;
+      if (orc_mode_both(mode) && b_f64 != b_fx) stats[2]++;   /* two restarts of equal objective (an uninformative SNP flipped): the f64 sums differ by rounding noise */
+      const bool b = orc_mode_fx(mode) ? b_fx : b_f64;
       if (b) { largest_prob = prob; largest_fx = last_obj_fx; }
       return b;
     };
@@ -1453,6 +1467,121 @@ int64_t orc_vcf_text(orc_region* r, const char* chrom, char* buf, int64_t cap) {
   if ((int64_t)s.size() < cap) memcpy(buf, s.c_str(), s.size() + 1);
   return (int64_t)s.size();
 }
+
+/* ---- batch runner: regions pulled from an atomic counter by n_threads native threads (thread.rs:77) ---- */
+struct orc_batch {
+  std::vector<orc_region*> regs;
+  std::vector<std::vector<uint32_t>> planes;   /* per region: LCR_NPLANES x len */
+  struct Snap { std::vector<int64_t> row_ptr; std::vector<int32_t> row_read, col; std::vector<uint8_t> val, fp; std::vector<uint32_t> links; };
+  std::vector<Snap> fm;
+  std::vector<int64_t> col_off;
+  int upto = 0, threads = 1;
+  double seconds = 0.0;
+  ~orc_batch() { for (auto* r : regs) delete r; }
+};
+
+orc_batch* orc_run_batch(const lcr_reads* reads, const lcr_regions* rg, const lcr_params* params, int mode, int n_threads,
+                         int upto, int keep_planes) {
+  orc_batch* B = new orc_batch();
+  const int ng = rg->n_regions;
+  B->regs.assign(ng, nullptr); B->planes.resize(ng); B->fm.resize(ng); B->upto = upto;
+  B->col_off.assign(rg->col_off, rg->col_off + ng + 1);
+  if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+  n_threads = std::max(1, std::min(n_threads, std::max(ng, 1)));
+  B->threads = n_threads;
+  std::atomic<int> next(0);
+  /* heaviest regions first (reads x length), like a work-stealing pool would end up balancing them */
+  std::vector<int> order(ng);
+  for (int g = 0; g < ng; g++) order[g] = g;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    return (int64_t)(rg->read_begin[a + 1] - rg->read_begin[a]) * rg->len[a] > (int64_t)(rg->read_begin[b + 1] - rg->read_begin[b]) * rg->len[b];
+  });
+  auto work = [&]() {
+    for (;;) {
+      const int k = next.fetch_add(1);
+      if (k >= ng) return;
+      const int g = order[k];
+      orc_region* r = orc_region_create(reads, rg->read_begin[g], rg->read_begin[g + 1], rg->start0[g], rg->len[g], rg->ref + rg->col_off[g], params);
+      B->regs[g] = r;
+      r->pileup();
+      if (keep_planes) { B->planes[g].assign((size_t)LCR_NPLANES * (size_t)r->len, 0u); orc_get_planes(r, B->planes[g].data()); }
+      if (upto >= 1) r->candidates();
+      if (upto >= 1 || !keep_planes) { std::vector<BaseFreq>().swap(r->freq); }
+      if (upto >= 2) {
+        r->fragments();
+        orc_batch::Snap& s = B->fm[g];
+        const size_t n = r->frags.size(); const int64_t nnz = orc_nnz(r);
+        s.row_ptr.resize(n + 1); s.row_read.resize(n); s.col.resize(nnz); s.val.resize(nnz); s.fp.resize(n); s.links.resize(n);
+        orc_get_fragmat(r, s.row_ptr.data(), s.row_read.data(), s.col.data(), s.val.data(), s.fp.data(), s.links.data());
+      }
+      if (upto >= 3) { r->phase(mode); r->post_phase(); }
+    }
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> pool;
+  for (int t = 1; t < n_threads; t++) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
+  B->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return B;
+}
+void orc_batch_destroy(orc_batch* B) { delete B; }
+double orc_batch_seconds(const orc_batch* B) { return B->seconds; }
+int32_t orc_batch_threads(const orc_batch* B) { return B->threads; }
+void orc_batch_offsets(const orc_batch* B, int32_t* cand_off, int32_t* row_off, int64_t* nnz_off) {
+  cand_off[0] = 0; row_off[0] = 0; nnz_off[0] = 0;
+  for (size_t g = 0; g < B->regs.size(); g++) {
+    cand_off[g + 1] = cand_off[g] + (int32_t)B->regs[g]->cands.size();
+    row_off[g + 1] = row_off[g] + (int32_t)B->fm[g].row_read.size();
+    nnz_off[g + 1] = nnz_off[g] + (int64_t)B->fm[g].col.size();
+  }
+}
+void orc_batch_planes(const orc_batch* B, uint32_t* out) {
+  const int64_t n_cols = B->col_off.back();
+  for (size_t g = 0; g < B->regs.size(); g++) {
+    const int64_t L = B->regs[g]->len, o = B->col_off[g];
+    if (B->planes[g].empty()) continue;
+    for (int k = 0; k < LCR_NPLANES; k++) memcpy(out + (int64_t)k * n_cols + o, B->planes[g].data() + (int64_t)k * L, (size_t)L * 4);
+  }
+}
+void orc_batch_cands(const orc_batch* B, lcr_candidate* out) {
+  for (size_t g = 0; g < B->regs.size(); g++) {
+    orc_get_cands(B->regs[g], out);
+    for (size_t i = 0; i < B->regs[g]->cands.size(); i++) out[i].region = (int32_t)g;
+    out += B->regs[g]->cands.size();
+  }
+}
+void orc_batch_fragmat(const orc_batch* B, int64_t* row_ptr, int32_t* row_read, int32_t* col, uint8_t* val, uint8_t* fp, uint32_t* links) {
+  int64_t e = 0; size_t r = 0;
+  for (size_t g = 0; g < B->regs.size(); g++) {
+    const orc_batch::Snap& s = B->fm[g];
+    const size_t n = s.row_read.size();
+    for (size_t k = 0; k < n; k++) { row_ptr[r + k] = e + s.row_ptr[k]; row_read[r + k] = s.row_read[k]; fp[r + k] = s.fp[k]; links[r + k] = s.links[k]; }
+    if (!s.col.empty()) { memcpy(col + e, s.col.data(), s.col.size() * 4); memcpy(val + e, s.val.data(), s.val.size()); }
+    e += (int64_t)s.col.size(); r += n;
+  }
+  row_ptr[r] = e;
+}
+void orc_batch_phase(const orc_batch* B, int8_t* haplotag, uint8_t* assignment, uint32_t* phase_set, double* objective) {
+  size_t r = 0;
+  for (size_t g = 0; g < B->regs.size(); g++) {
+    orc_get_phase(B->regs[g], haplotag + r, assignment + r, phase_set + r, objective + g);
+    r += B->regs[g]->frags.size();
+  }
+}
+void orc_batch_stats(const orc_batch* B, int64_t* out) { for (size_t g = 0; g < B->regs.size(); g++) orc_get_stats(B->regs[g], out + 4 * g); }
+int64_t orc_batch_vcf(orc_batch* B, const char* chrom, char* buf, int64_t cap, int64_t* off) {
+  int64_t n = 0;
+  for (size_t g = 0; g < B->regs.size(); g++) {
+    off[g] = n;
+    const std::string s = B->regs[g]->vcf_text(chrom);
+    if (n + (int64_t)s.size() < cap) memcpy(buf + n, s.data(), s.size());
+    n += (int64_t)s.size();
+  }
+  off[B->regs.size()] = n;
+  return n;
+}
+orc_region* orc_batch_region(orc_batch* B, int32_t g) { return B->regs[g]; }
 
 float orc_strand_odds_ratio(int a, int b, int c, int d) { return cal_strand_odds_ratio(a, b, c, d); }
 double orc_binomial_two_tailed(uint64_t s, uint64_t t) { return binomial_two_tailed(s, t); }

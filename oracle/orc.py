@@ -15,7 +15,7 @@ from longcallr_amd import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "liblcr_oracle.so")
-MODE_F64, MODE_EXACT = 0, 1
+MODE_F64, MODE_EXACT, MODE_F64_ONLY, MODE_EXACT_ONLY = 0, 1, 2, 3
 
 
 def build(force=False):
@@ -62,6 +62,25 @@ def lib():
         l.orc_get_stats.argtypes = [vp, vp]
         l.orc_vcf_text.argtypes = [vp, C.c_char_p, C.c_char_p, i64]
         l.orc_vcf_text.restype = i64
+        l.orc_run_batch.restype = vp
+        l.orc_run_batch.argtypes = [C.POINTER(_abi.LcrReads), C.POINTER(_abi.LcrRegions), C.POINTER(_abi.LcrParams),
+                                    C.c_int, C.c_int, C.c_int, C.c_int]
+        l.orc_batch_destroy.argtypes = [vp]
+        l.orc_batch_destroy.restype = None
+        l.orc_batch_seconds.argtypes = [vp]
+        l.orc_batch_seconds.restype = dbl
+        l.orc_batch_threads.argtypes = [vp]
+        l.orc_batch_threads.restype = i32
+        l.orc_batch_offsets.argtypes = [vp] * 4
+        l.orc_batch_planes.argtypes = [vp, vp]
+        l.orc_batch_cands.argtypes = [vp, vp]
+        l.orc_batch_fragmat.argtypes = [vp] * 7
+        l.orc_batch_phase.argtypes = [vp] * 5
+        l.orc_batch_stats.argtypes = [vp, vp]
+        l.orc_batch_vcf.argtypes = [vp, C.c_char_p, vp, i64, vp]
+        l.orc_batch_vcf.restype = i64
+        l.orc_batch_region.argtypes = [vp, i32]
+        l.orc_batch_region.restype = vp
         l.orc_strand_odds_ratio.argtypes = [C.c_int] * 4
         l.orc_strand_odds_ratio.restype = C.c_float
         l.orc_binomial_two_tailed.argtypes = [C.c_uint64, C.c_uint64]
@@ -181,3 +200,81 @@ class Region:
         buf = C.create_string_buffer(cap)
         n = lib().orc_vcf_text(self.h, chrom.encode(), buf, cap)
         return buf.raw[:n].decode()
+
+
+UPTO = {"pileup": 0, "cands": 1, "frag": 2, "post": 3}
+
+
+class Batch:
+    """A whole ReadBatch through the oracle on a native thread pool (orc_run_batch): the analogue of the reference's
+    rayon par_iter over regions (thread.rs:77).  Results come back concatenated in batch order, in the formats the
+    lcr_get_* calls of the HIP path use, so a full-size comparison is a handful of array compares."""
+
+    def __init__(self, batch, params, mode=MODE_EXACT_ONLY, threads=0, upto="post", keep_planes=True):
+        self.batch, self.params, self.ng = batch, params, batch.n_regions
+        self._reads, self._regions = batch.c_reads(), batch.c_regions()
+        self.upto = UPTO[upto]
+        self.h = lib().orc_run_batch(C.byref(self._reads), C.byref(self._regions), C.byref(params), mode, threads,
+                                     self.upto, 1 if keep_planes else 0)
+        self.seconds, self.threads = lib().orc_batch_seconds(self.h), lib().orc_batch_threads(self.h)
+        self.cand_off, self.row_off = np.zeros(self.ng + 1, np.int32), np.zeros(self.ng + 1, np.int32)
+        self.nnz_off = np.zeros(self.ng + 1, np.int64)
+        lib().orc_batch_offsets(self.h, _p(self.cand_off), _p(self.row_off), _p(self.nnz_off))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().orc_batch_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def planes(self):
+        out = np.zeros((_abi.NPLANES, int(self.batch.col_off[-1])), dtype=np.uint32)
+        lib().orc_batch_planes(self.h, _p(out))
+        return out
+
+    def cands(self):
+        out = np.zeros(int(self.cand_off[-1]), dtype=_abi.CAND_DTYPE)
+        if out.size:
+            lib().orc_batch_cands(self.h, _p(out))
+        return out
+
+    def fragmat(self):
+        n, nnz = int(self.row_off[-1]), int(self.nnz_off[-1])
+        d = dict(row_ptr=np.zeros(n + 1, np.int64), row_read=np.zeros(n, np.int32), col=np.zeros(nnz, np.int32),
+                 val=np.zeros(nnz, np.uint8), row_for_phasing=np.zeros(n, np.uint8), row_links=np.zeros(n, np.uint32))
+        lib().orc_batch_fragmat(self.h, *[_p(d[k]) for k in ("row_ptr", "row_read", "col", "val", "row_for_phasing", "row_links")])
+        d["row_region_off"] = self.row_off
+        return d
+
+    def phase_result(self):
+        n = int(self.row_off[-1])
+        d = dict(haplotag=np.zeros(n, np.int8), assignment=np.zeros(n, np.uint8), phase_set=np.zeros(n, np.uint32),
+                 objective=np.zeros(self.ng, np.float64))
+        lib().orc_batch_phase(self.h, *[_p(d[k]) for k in ("haplotag", "assignment", "phase_set", "objective")])
+        return d
+
+    def stats(self):
+        """per region: cross_optimize calls, iterations, noise ties (modes 0 / 1 only), assert violations"""
+        out = np.zeros((self.ng, 4), np.int64)
+        lib().orc_batch_stats(self.h, _p(out))
+        return out
+
+    def vcf_texts(self, chrom="chrS"):
+        off = np.zeros(self.ng + 1, np.int64)
+        cap = 1 << 16
+        while True:
+            buf = C.create_string_buffer(cap)
+            n = lib().orc_batch_vcf(self.h, chrom.encode(), buf, cap, _p(off))
+            if n < cap:
+                break
+            cap = int(n) + 16
+        raw = buf.raw
+        return [raw[off[g]:off[g + 1]].decode() for g in range(self.ng)]
+
+    def ld_blocks(self, g):
+        r = lib().orc_batch_region(self.h, g)
+        n = int(self.cand_off[g + 1] - self.cand_off[g])
+        off, mem = np.zeros(n + 2, np.int32), np.zeros(n + 1, np.int32)
+        nb = lib().orc_get_ld_blocks(r, _p(off), _p(mem), mem.size)
+        return [mem[off[b]:off[b + 1]].tolist() for b in range(nb)]

@@ -41,6 +41,14 @@ static inline uint64_t orc_region_seed(uint64_t seed, int64_t start0) {
 /* decision arithmetic of the optimiser (see DESIGN.md "Decision arithmetic") */
 #define ORC_MODE_F64 0   /* reference-order f64 running sums (faithful to phase.rs)            */
 #define ORC_MODE_EXACT 1 /* exact fixed-point sums, scale 2^40 (the GPU parity contract)      */
+/* Modes 0 / 1 evaluate BOTH arithmetics at every decision and count the decisions on which they disagree
+ * (orc_get_stats [2]: rounding-noise ties).  The *_ONLY modes take the same decisions as 0 / 1 without the other
+ * arithmetic: ORC_MODE_F64_ONLY is the reference's work, nothing more (bench.py's cpu_baseline); ORC_MODE_EXACT_ONLY
+ * drops the libm calls of the f64 scores (full-size parity runs). */
+#define ORC_MODE_F64_ONLY 2
+#define ORC_MODE_EXACT_ONLY 3
+static inline int orc_mode_fx(int mode) { return mode & 1; }
+static inline int orc_mode_both(int mode) { return mode < 2; }
 
 typedef struct orc_region orc_region;
 
@@ -78,6 +86,31 @@ void orc_get_phase(const orc_region*, int8_t* haplotag, uint8_t* assignment, uin
 void orc_get_stats(const orc_region*, int64_t* out4);
 /* VCF body text of this region (vcf.rs:27-306 + thread.rs:266-303); returns length */
 int64_t orc_vcf_text(orc_region*, const char* chrom, char* buf, int64_t cap);
+
+/* ---- a whole batch on a native thread pool: the analogue of the reference's rayon par_iter over regions
+ * (thread.rs:77); no Python per region.  upto: 0 = pileup, 1 = + candidates, 2 = + fragments, 3 = + phase and
+ * post-phase.  Results are kept per region and handed out concatenated in batch order, in the formats of
+ * include/lcr.h (what the lcr_get_* calls of the HIP path return for the same batch).  keep_planes = 0 drops the
+ * pileup columns of a region as soon as its candidates are known (memory of the full-size configs). */
+typedef struct orc_batch orc_batch;
+orc_batch* orc_run_batch(const lcr_reads* reads, const lcr_regions* regions, const lcr_params* params, int mode,
+                         int n_threads, int upto, int keep_planes);
+void orc_batch_destroy(orc_batch*);
+double orc_batch_seconds(const orc_batch*);        /* wall time of the pool                                   */
+int32_t orc_batch_threads(const orc_batch*);
+/* cand_off / row_off: n_regions + 1 int32; nnz_off: n_regions + 1 int64 (entries of the fragment matrix) */
+void orc_batch_offsets(const orc_batch*, int32_t* cand_off, int32_t* row_off, int64_t* nnz_off);
+void orc_batch_planes(const orc_batch*, uint32_t* out /* LCR_NPLANES x n_cols, plane-major over the batch */);
+void orc_batch_cands(const orc_batch*, lcr_candidate* out);   /* region field = region index */
+/* fragment matrix as it stood after get_fragments (the rescue steps of post-phase change for_phasing):
+ * row_ptr batch-wide (n_rows + 1), col = candidate index inside the region */
+void orc_batch_fragmat(const orc_batch*, int64_t* row_ptr, int32_t* row_read, int32_t* col, uint8_t* val,
+                       uint8_t* row_for_phasing, uint32_t* row_links);
+void orc_batch_phase(const orc_batch*, int8_t* haplotag, uint8_t* assignment, uint32_t* phase_set, double* objective /* n_regions */);
+void orc_batch_stats(const orc_batch*, int64_t* out /* n_regions x 4, as orc_get_stats */);
+/* VCF text of all regions back to back; off[g] .. off[g + 1] = region g's records; returns the total length */
+int64_t orc_batch_vcf(orc_batch*, const char* chrom, char* buf, int64_t cap, int64_t* off);
+orc_region* orc_batch_region(orc_batch*, int32_t g);   /* for the per-region getters (LD blocks ...) */
 
 /* scalar functions exposed for known-answer tests */
 float orc_strand_odds_ratio(int ref_fw, int ref_rv, int alt_fw, int alt_rv); /* candidate.rs:24-35 */

@@ -1,6 +1,5 @@
 """Worker of tests/test_gpu_parity.py::test_two_ranks_share_one_gpu (launched by torch.distributed.run, backend gloo):
-every rank takes its LPT shard of ONE region list (bench.py's construction: region k = unique gene k % U at copy
-k // U), runs the hot path on cuda:0 and the candidate / read records are gathered to rank 0, which compares them with
+every rank takes its LPT shard of ONE list of distinct MAS-Seq genes (bench.py's construction, build_shard), runs the hot path on cuda:0 and the candidate / read records are gathered to rank 0, which compares them with
 a single-process run over all regions."""
 import os
 import sys
@@ -18,16 +17,19 @@ def main():
     from longcallr_amd import _abi, api, shard, synth
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    base = synth.make_batch("ont-drna", n_genes=3, gene_len=12000, depth=35, seed=77)
-    U, copies = base.n_regions, 2
-    n_global = U * copies * world
-    costs = (base.len.astype(np.float64) * bench.region_max_coverage(base))[np.arange(n_global) % U]
+    # bench.py's construction at N > 1 (build_shard): ONE list of distinct MAS-Seq genes, LPT on len x max_coverage
+    # (LCR_TEST_SHARD_PROFILE=ont-drna: chain regions, so that LCR_GRID_MIN_ENTRIES=0 forces persistent all-CU launches)
+    profile = os.environ.get("LCR_TEST_SHARD_PROFILE", "masseq")
+    per_rank, kw = 4, dict(gene_len=12000, depth=35.0, seed=77)
+    n_global = per_rank * world
+    costs = synth.gene_costs(profile, range(n_global), **kw)
     owner = shard.assign_regions(costs, world)
     assert sorted(sum(owner, [])) == list(range(n_global))
-    params = _abi.make_params("ont-drna", seed=31)
+    assert bench.build_shard("c4", world, rank, genes=per_rank, workers=1, profile=profile, **kw)[1] == owner[rank]
+    params = _abi.make_params(synth.preset_for(profile), seed=31)
 
     def run(ids):
-        b = bench.subset_batch(base, ids)
+        b = synth.make_genes(profile, workers=2, gene_ids=ids, **kw)
         E = api.Engine(0, params)
         E.load_batch(b).run_all()
         c, off = E.candidates()

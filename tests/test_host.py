@@ -145,31 +145,34 @@ def test_region_discovery_quirks():
 
 
 def test_bench_shards_partition_one_region_list():
-    """bench.py at N > 1: ONE list of regions (region k = unique gene k % U at copy k // U), LPT-partitioned by
-    shard.assign_regions; a rank's subset_batch holds exactly its regions, and the shards together are the job."""
+    """bench.py at N > 1: ONE list of distinct genes (synth.make_genes), LPT-partitioned by shard.assign_regions on
+    len x max_coverage computed from the genes' read spans alone (synth.gene_costs); a rank builds exactly its regions
+    (build_shard), the shards together are the job, and the batch does not depend on the number of generator workers."""
     import bench
-    base = synth.make_batch("masseq", n_genes=3, gene_len=5000, depth=10, seed=5)
-    U, copies = base.n_regions, 4
-    whole = bench.tile_batch(base, copies)
-    every = bench.subset_batch(base, list(range(U * copies)))
+    kw = dict(genes=4, gene_len=5000, depth=10.0, seed=5)
+    whole, ids, n = bench.build_shard("c4", 1, 0, workers=1, **kw)
+    assert ids == [0, 1, 2, 3] and n == 4
+    again = bench.build_shard("c4", 1, 0, workers=3, **kw)[0]
     for f in _abi.ReadBatch.FIELDS + ["start0", "len", "read_begin", "ref", "col_off"]:
-        assert np.array_equal(getattr(whole, f), getattr(every, f)), f
-    cov = bench.region_max_coverage(base)
-    assert cov.shape == (U,) and cov.min() > 0
+        assert np.array_equal(getattr(whole, f), getattr(again, f)), f
+    # the cost model sees the read spans before poly-A tails: within a tail's length of the region table's numbers
+    cost = synth.gene_costs("masseq", range(4), gene_len=5000, depth=10.0, seed=5)
+    true = whole.len.astype(np.float64) * bench.region_max_coverage(whole)
+    assert np.all(np.abs(cost - true) <= 0.05 * true)
     for world in (2, 3):
-        costs = (base.len * cov)[np.arange(U * copies) % U]
+        big = bench.build_shard("c4", 1, 0, workers=2, genes=4 * world, gene_len=5000, depth=10.0, seed=5)[0]
+        costs = synth.gene_costs("masseq", range(4 * world), gene_len=5000, depth=10.0, seed=5)
         owner = shard.assign_regions(costs, world)
-        assert sorted(sum(owner, [])) == list(range(U * copies))
+        assert sorted(sum(owner, [])) == list(range(4 * world))
         loads = [float(costs[o].sum()) for o in owner]
         assert max(loads) - min(loads) <= costs.max()          # LPT: no rank is more than one region ahead
-        got = {}
         for r in range(world):
-            sb = bench.subset_batch(base, owner[r])
-            assert sb.n_regions == len(owner[r])
-            for j, k in enumerate(owner[r]):
-                r0, r1 = int(sb.read_begin[j]), int(sb.read_begin[j + 1])
-                got[k] = (int(sb.start0[j]), int(sb.len[j]), sb.pos[r0:r1].tobytes(), sb.bases[int(sb.seq_off[r0]):int(sb.seq_off[r1 - 1] + sb.seq_len[r1 - 1])].tobytes())
-        for k in range(U * copies):
-            r0, r1 = int(whole.read_begin[k]), int(whole.read_begin[k + 1])
-            assert got[k] == (int(whole.start0[k]), int(whole.len[k]), whole.pos[r0:r1].tobytes(),
-                              whole.bases[int(whole.seq_off[r0]):int(whole.seq_off[r1 - 1] + whole.seq_len[r1 - 1])].tobytes())
+            sb, mine, n_global = bench.build_shard("c4", world, r, workers=1, **kw)
+            assert mine == owner[r] and n_global == 4 * world and sb.n_regions == len(mine)
+            for j, k in enumerate(mine):
+                r0, r1, q0, q1 = int(sb.read_begin[j]), int(sb.read_begin[j + 1]), int(big.read_begin[k]), int(big.read_begin[k + 1])
+                assert (int(sb.start0[j]), int(sb.len[j])) == (int(big.start0[k]), int(big.len[k]))
+                assert np.array_equal(sb.pos[r0:r1], big.pos[q0:q1])
+                assert sb.bases[int(sb.seq_off[r0]):int(sb.seq_off[r1 - 1] + sb.seq_len[r1 - 1])].tobytes() == \
+                    big.bases[int(big.seq_off[q0]):int(big.seq_off[q1 - 1] + big.seq_len[q1 - 1])].tobytes()
+

@@ -1,0 +1,79 @@
+"""The oracle's native batch runner (orc_run_batch: regions on a std::thread pool, the analogue of the reference's
+rayon par_iter, thread.rs:77) returns what the per-region entry points return, and the *_ONLY decision modes take the
+decisions of modes F64 / EXACT without evaluating the other arithmetic."""
+import numpy as np
+import pytest
+
+import helpers
+from longcallr_amd import _abi, synth
+
+
+def _per_region(orc, b, p, mode):
+    regs = []
+    for g in range(b.n_regions):
+        R = orc.Region(b, g, p).pileup().candidates().fragments()
+        R.fm_snapshot = R.fragmat()
+        R.phase(mode).post_phase()
+        regs.append(R)
+    return regs
+
+
+@pytest.mark.parametrize("profile,preset,seed", [("ont-cdna", "ont-cdna", 3), ("masseq", "hifi-masseq", 4), ("ont-drna", "ont-drna", 5)])
+def test_batch_runner_equals_per_region_calls(orc, profile, preset, seed):
+    b = synth.make_batch(profile, n_genes=4, gene_len=9000, depth=30, seed=seed)
+    p = _abi.make_params(preset, seed=seed)
+    for mode in (orc.MODE_F64, orc.MODE_EXACT):
+        regs = _per_region(orc, b, p, mode)
+        for threads in (1, 3):
+            B = orc.Batch(b, p, mode=mode, threads=threads)
+            assert B.threads == min(threads, b.n_regions)
+            pl, c, fm, pr, st, vt = B.planes(), B.cands(), B.fragmat(), B.phase_result(), B.stats(), B.vcf_texts("chrS")
+            for g, R in enumerate(regs):
+                o, n = int(b.col_off[g]), int(b.len[g])
+                assert np.array_equal(pl[:, o:o + n], R.planes())
+                rc = R.cands()
+                assert c[B.cand_off[g]:B.cand_off[g + 1]].tobytes() == rc.tobytes()
+                r0, r1, e0, e1 = B.row_off[g], B.row_off[g + 1], B.nnz_off[g], B.nnz_off[g + 1]
+                f = R.fm_snapshot
+                assert np.array_equal(fm["row_ptr"][r0:r1 + 1] - e0, f["row_ptr"]) and np.array_equal(fm["col"][e0:e1], f["col"])
+                assert np.array_equal(fm["val"][e0:e1], f["val"]) and np.array_equal(fm["row_links"][r0:r1], f["row_links"])
+                assert np.array_equal(fm["row_for_phasing"][r0:r1], f["row_for_phasing"]) and np.array_equal(fm["row_read"][r0:r1], f["row_read"])
+                rp = R.phase_result()
+                for k in ("haplotag", "assignment", "phase_set"):
+                    assert np.array_equal(pr[k][r0:r1], rp[k])
+                assert pr["objective"][g] == rp["objective"]
+                assert st[g].tolist() == list(R.stats().values())
+                assert vt[g] == R.vcf_text("chrS")
+                assert B.ld_blocks(g) == R.ld_blocks()
+            B.close()
+
+
+def test_only_modes_take_the_same_decisions(orc):
+    """ORC_MODE_F64_ONLY == ORC_MODE_F64 and ORC_MODE_EXACT_ONLY == ORC_MODE_EXACT in every output (the *_ONLY modes
+    just do not count ties); chain and enumeration regions, demo.bam."""
+    cases = [(synth.make_batch("ont-drna", n_genes=3, gene_len=20000, depth=45, seed=14), _abi.make_params("ont-drna", seed=14)),
+             (synth.make_batch("ont-cdna", n_genes=3, gene_len=9000, depth=35, seed=12), _abi.make_params("ont-cdna", seed=12)),
+             (helpers.demo_batch(), _abi.make_params("hifi-masseq"))]
+    for b, p in cases:
+        for full, only in ((orc.MODE_F64, orc.MODE_F64_ONLY), (orc.MODE_EXACT, orc.MODE_EXACT_ONLY)):
+            A, B = orc.Batch(b, p, mode=full, threads=2), orc.Batch(b, p, mode=only, threads=2)
+            assert A.cands().tobytes() == B.cands().tobytes()
+            pa, pb = A.phase_result(), B.phase_result()
+            for k in pa:
+                assert np.array_equal(pa[k], pb[k]), k
+            assert A.vcf_texts() == B.vcf_texts()
+            sa, sb = A.stats(), B.stats()
+            assert np.array_equal(sa[:, :2], sb[:, :2]) and not sb[:, 2].any()   # same calls / iterations, no tie counting
+            A.close(); B.close()
+
+
+def test_batch_runner_stages_and_plane_dropping(orc):
+    b = synth.make_batch("ont-cdna", n_genes=3, gene_len=8000, depth=25, seed=8)
+    p = _abi.make_params("ont-cdna", seed=8)
+    full = orc.Batch(b, p)
+    P = orc.Batch(b, p, upto="pileup")
+    assert np.array_equal(P.planes(), full.planes()) and P.cand_off[-1] == 0 and P.row_off[-1] == 0
+    Cn = orc.Batch(b, p, upto="cands", keep_planes=False)
+    assert not Cn.planes().any() and np.array_equal(Cn.cand_off, full.cand_off)
+    Fr = orc.Batch(b, p, upto="frag")
+    assert np.array_equal(Fr.fragmat()["col"], full.fragmat()["col"]) and not Fr.phase_result()["haplotag"].any()
