@@ -126,6 +126,9 @@ def run(bam_path, ref_path, out_vcf, out_bam=None, preset="hifi-masseq", contigs
     bam_ids = {n: i for i, (n, _) in enumerate(nb.refs)}
     devices = list(devices) if devices else [device]
     engines = [api.Engine(d, params) for d in devices]
+    # a ctx is single-threaded (include/lcr.h): the producer thread below never touches a working engine -- region
+    # discovery has a context of its own (its kernels share scratch buffers and a stream with nothing else)
+    scout = api.Engine(devices[0], params)
     free = list(range(len(engines)))
     free_lock = threading.Condition()
     stats = dict(contigs=0, regions=0, reads=0, candidates=0, vcf_records=0, chunks=0)
@@ -166,7 +169,7 @@ def run(bam_path, ref_path, out_vcf, out_bam=None, preset="hifi-masseq", contigs
             rs, re_ = nb.spans(rid, **flt)
             if rs.size == 0:
                 continue
-            regions = engines[0].discover_regions(rs, re_, length)     # util.rs:236-332
+            regions = scout.discover_regions(rs, re_, length)     # util.rs:236-332
             if not regions:
                 continue
             ref = refs[name]
@@ -181,7 +184,7 @@ def run(bam_path, ref_path, out_vcf, out_bam=None, preset="hifi-masseq", contigs
                 pending.append(pool.submit(work, batch, name, out_bam is not None))
                 regions_out.extend((rid, s, l) for s, l, _ in chunk)
         results.extend(f.result() for f in pending)
-    for E in engines:
+    for E in engines + [scout]:
         E.close()
     text = "".join(r["text"] for r in results)
     stats["candidates"] = sum(r["n_cand"] for r in results)
