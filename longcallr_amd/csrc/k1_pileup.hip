@@ -48,6 +48,7 @@
 #define REC_OFF_MASK 0xFFFFFFFFFFull
 #define REC_KIND_D 0xFFFFFFFFFFull  // offset field of a D-run record
 #define REC_KIND_I 0xFFFFFFFFFEull  // offset field of an I-point record
+#define REC_KIND_N 0xFFFFFFFFFDull  // offset field of an N-run record (the part of an intron inside its first / last tile)
 
 // ---------------------------------------------------------------------------------------------
 // read -> region map (one block per region writes its read range)
@@ -128,228 +129,6 @@ void launch_k0_pack(const BatchView& b, ReadBin* out, int32_t* order_flag, hipSt
 }
 
 // ---------------------------------------------------------------------------------------------
-// K0: persistent waves, ONE kernel: validate ops, intron difference array, reference end of the read,
-// per-tile records.  Records of a tile live in geometrically growing levels (64, 128, 256, ... slots) of one
-// pool: a tile's k-th level is allocated -- one atomic on the pool top -- by the lane whose slot reservation
-// holds the level's first slot, so the waste is bounded by 2x and no global counting pass is needed.
-__device__ __forceinline__ int rec_level(int slot) { return 31 - __clz((slot >> 6) + 1); }       // level of a tile-relative slot
-__device__ __forceinline__ int rec_level_first(int level) { return ((1 << level) - 1) << 6; }    // its first slot
-
-// Sixteen lanes (one DPP row) per read, four reads per wave64, WITHOUT a global round trip per record: per read (and per window of K0_WIN
-// tiles of its span) the CIGAR is walked twice.  Walk A counts the records each tile will get (LDS
-// counters of the read's row), then ONE atomic per (read, tile) reserves that many slots and the pool
-// levels those slots lie in are resolved (allocated when the reservation holds a level's first slot);
-// walk B draws the slots from the LDS counters and writes the records.  The dependent chain per read is
-// header -> CIGAR -> reservations -> level table, independent of the number of records.
-#define K0_WIN 64
-struct K0Row { int ctr[K0_WIN]; int l0[K0_WIN]; int p0[K0_WIN]; int p1[K0_WIN]; };   // (pad: the four rows of a wave sit 16 banks apart -- without it every LDS access of K0 was a 4-way bank conflict, PMC: profiles/r02_v1_pmc_summary.txt)
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__global__ void __launch_bounds__(LCR_BLOCK)
-k0_bin(BatchView b, const ReadBin* __restrict__ rbin, int ont, int D, int32_t* __restrict__ tile_fill,
-         int32_t* __restrict__ tile_lvl, unsigned int* __restrict__ pool_top, unsigned int pool_cap,
-         unsigned long long* __restrict__ recs, uint32_t* __restrict__ ndiff) {
-  __shared__ K0Row rows[LCR_BLOCK / 16];
-  K0Row& R = rows[threadIdx.x >> 4];
-  const int lane = threadIdx.x & 63, l16 = lane & 15, rbase = lane & 48;
-  const unsigned long long rowmask = 0xFFFFull << rbase;
-  const int n_groups = gridDim.x * (LCR_BLOCK / 16);
-  const int n_steps = (b.n_reads + n_groups - 1) / n_groups;
-  unsigned int n_items = 0, n_recs = 0;   // lane 0: M / D / I items; every lane: records it reserved slots for
-  auto lvl_wait = [&](int tile, int lvl) {   // pool offset of a tile's level (bounded wait on its allocator)
-    int at, spins = 0;
-    while ((at = __hip_atomic_load(&tile_lvl[tile * LCR_REC_LEVELS + lvl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 24)) { atomicExch(b.error_flag, 4); at = (int)pool_cap; break; }
-    }
-    return at;
-  };
-  int r = (int)((blockIdx.x * LCR_BLOCK + threadIdx.x) >> 4);
-  for (int step = 0; step < n_steps; step++, r += n_groups) {
-    const bool live = r < b.n_reads;
-    const uint32_t hw = live ? reinterpret_cast<const uint32_t*>(rbin + r)[l16] : 0u;
-    auto hf = [&](int kx) { return (uint32_t)__shfl((int)hw, rbase + kx, 64); };
-    const int rel_pos = (int)hf(0), vec = (int)hf(1), ftile = (int)hf(2);
-    const uint32_t ncig = live ? hf(3) : 0u;
-    const int64_t gbase = (int64_t)(((unsigned long long)hf(5) << 32) | hf(4));
-    const unsigned long long seq_off = ((unsigned long long)hf(7) << 32) | hf(6);
-    const unsigned long long cig_off = ((unsigned long long)hf(9) << 32) | hf(8);
-    const int lead = (int)hf(10), reb = (int)hf(11), flags = (int)hf(12);
-    const uint32_t* __restrict__ cg = b.cigar + cig_off;
-    const int strand = flags & 1, ts = (flags >> 1) & 3;
-    const unsigned long long tscls = ts == 0 ? 0ull : ((strand == 0) == (ts == 1) ? 1ull : 2ull);
-    const unsigned long long hi_bits = ((unsigned long long)strand << 60) | (tscls << 61);
-    const int t_first = max(rel_pos - 1, 0) / LCR_TILE;   // no record lies in an earlier tile (a leading I counts on column rel_pos - 1)
-    uint32_t wq0[4];                                   // the first 64 ops stay in registers for both walks
-#pragma unroll
-    for (int j = 0; j < 4; j++) wq0[j] = (uint32_t)(16 * j + l16) < ncig ? cg[16 * j + l16] : 0u;
-
-    // one op per lane: the columns [a, e) it contributes records for (util.rs:692-947)
-    struct Op { int a, e, rs, qs, ir, iq; bool m, d, i, has; };
-    auto decode = [&](uint32_t w, bool act, int ref_cur, int q_cur, bool first_walk) {
-      Op o;
-      const int op = w & 15, len = (int)(w >> 4);
-      o.m = act && (op == 0 || op == 7 || op == 8);
-      o.d = act && op == 2; o.i = act && op == 1;
-      const bool is_n = act && op == 3;
-      if (first_walk && act && !(o.m || o.d || is_n || o.i || op == 4 || op == 5)) atomicExch(b.error_flag, 1);
-      const int dr = (o.m || o.d || is_n) ? len : 0;
-      const int dq = (o.m || o.i) ? len : 0;
-      o.ir = row16_incl_scan(dr); o.iq = row16_incl_scan(dq);
-      o.rs = ref_cur + o.ir - dr;   // region-relative column where this op starts
-      o.qs = q_cur + o.iq - dq;     // read offset where this op starts
-      o.a = max(o.rs, 0); o.e = min(o.rs + len, vec);
-      if (first_walk && is_n && o.e > o.a) {  // util.rs:930-942
-        atomicAdd(&ndiff[gbase + o.a], 1u);
-        atomicAdd(&ndiff[gbase + o.e], 0xFFFFFFFFu);
-      }
-      if (ont && o.m) {  // ONT end trim (util.rs:745-751)
-        o.a = max(o.a, o.rs + (lead + D - o.qs));
-        o.e = min(o.e, o.rs + (reb - D + 1 - o.qs));
-      }
-      o.has = (o.m || o.d) && len > 0 && o.e > o.a;
-      if (o.i && len > 0 && o.rs >= 1 && o.rs < vec) { o.has = true; o.a = o.rs - 1; o.e = o.rs; }
-      return o;
-    };
-
-    bool more = live;   // this row has a window left
-    for (int win = 0; __any(more); win++) {
-      const int tw0 = t_first + win * K0_WIN;
-      const uint32_t ncw = more ? ncig : 0u;
-#pragma unroll
-      for (int j = 0; j < 4; j++) R.ctr[l16 + 16 * j] = 0;
-      wave_lds_sync();
-        // ---- walk A: records per tile of the window
-      bool beyond = false;
-      {
-        int ref_cur = rel_pos, q_cur = lead > 0 ? lead : 0;
-        for (uint32_t g0 = 0; __any(g0 < ncw); g0 += 64) {
-          uint32_t wq[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            wq[j] = g0 == 0 ? wq0[j] : ((g0 + 16 * j + l16) < ncw ? cg[g0 + 16 * j + l16] : 0u);
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const uint32_t c0 = g0 + 16 * j;
-            if (!__any(c0 < ncw)) break;
-            const Op o = decode(wq[j], c0 + l16 < ncw, ref_cur, q_cur, win == 0);
-            if (win == 0) { const int nh = __popcll(__ballot(o.has)); if (lane == 0) n_items += (unsigned int)nh; }
-            if (o.has) {
-              const int tl = (o.e - 1) / LCR_TILE;
-              if (tl >= tw0 + K0_WIN) beyond = true;
-              const int te = min(tl, tw0 + K0_WIN - 1);
-              for (int t = max(o.a / LCR_TILE, tw0); t <= te; t++) atomicAdd(&R.ctr[t - tw0], 1);
-            }
-            ref_cur += __shfl(o.ir, rbase + 15, 64);
-            q_cur += __shfl(o.iq, rbase + 15, 64);
-            if (win == 0 && c0 < ncw && c0 + 16 >= ncw && l16 == 0 && q_cur != reb) atomicExch(b.error_flag, 2);
-          }
-        }
-        if (win == 0 && live && l16 == 0) b.read_rend[r] = ref_cur;
-      }
-      wave_lds_sync();
-        // ---- reservations: lane k owns the window's tiles k, k+16, k+32, k+48
-      {
-        int cn[4], bs[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) { cn[j] = R.ctr[l16 + 16 * j]; bs[j] = 0; n_recs += (unsigned int)cn[j]; }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (cn[j] > 0) bs[j] = atomicAdd(&tile_fill[ftile + tw0 + l16 + 16 * j], cn[j]);
-#pragma unroll
-        for (int j = 0; j < 4; j++)     // every level whose first slot is mine is allocated here, before any wait
-          if (cn[j] > 0) {
-            const int tile = ftile + tw0 + l16 + 16 * j;
-            const int l_last = rec_level(bs[j] + cn[j] - 1);
-            for (int l = rec_level(bs[j]); l <= l_last; l++)
-              if (rec_level_first(l) >= bs[j]) {
-                const unsigned int at = atomicAdd(pool_top, 64u << l);
-                if (at + (64u << l) > pool_cap) atomicExch(b.error_flag, 3);
-                __hip_atomic_store(&tile_lvl[tile * LCR_REC_LEVELS + l], (int)at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (relaxed: only the value itself is communicated)
-              }
-          }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (cn[j] > 0) {
-            const int o = l16 + 16 * j, tile = ftile + tw0 + o;
-            const int l_first = rec_level(bs[j]);
-            R.ctr[o] = bs[j];
-            R.l0[o] = l_first;
-            R.p0[o] = lvl_wait(tile, l_first);
-            R.p1[o] = rec_level(bs[j] + cn[j] - 1) > l_first ? lvl_wait(tile, l_first + 1) : 0;
-          }
-      }
-      wave_lds_sync();
-        // ---- walk B: the records
-      {
-        int ref_cur = rel_pos, q_cur = lead > 0 ? lead : 0;
-        for (uint32_t g0 = 0; __any(g0 < ncw); g0 += 64) {
-          uint32_t wq[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            wq[j] = g0 == 0 ? wq0[j] : ((g0 + 16 * j + l16) < ncw ? cg[g0 + 16 * j + l16] : 0u);
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const uint32_t c0 = g0 + 16 * j;
-            if (!__any(c0 < ncw)) break;
-            const Op o = decode(wq[j], c0 + l16 < ncw, ref_cur, q_cur, false);
-            if (o.has) {
-              const int te = min((o.e - 1) / LCR_TILE, tw0 + K0_WIN - 1);
-              for (int t = max(o.a / LCR_TILE, tw0); t <= te; t++) {
-                const int w_ = t - tw0;
-                const int slot = atomicAdd(&R.ctr[w_], 1);   // tile-relative
-                const int lvl = rec_level(slot), l0 = R.l0[w_];
-                const int at = lvl == l0 ? R.p0[w_] : lvl == l0 + 1 ? R.p1[w_] : lvl_wait(ftile + t, lvl);
-                const int c_lo = max(o.a, t * LCR_TILE), c_hi = min(o.e, (t + 1) * LCR_TILE);  // columns in this tile
-                unsigned long long rec = ((unsigned long long)(c_lo - t * LCR_TILE) << 40) |
-                                         ((unsigned long long)(c_hi - c_lo - 1) << 50);
-                if (o.m) rec |= ((seq_off + (unsigned long long)(o.qs + (c_lo - o.rs))) & REC_OFF_MASK) | hi_bits;
-                else rec |= o.d ? REC_KIND_D : REC_KIND_I;
-                const unsigned int at_slot = (unsigned int)at + (unsigned int)(slot - rec_level_first(lvl));
-                if (at_slot < pool_cap) recs[at_slot] = rec;
-              }
-            }
-            ref_cur += __shfl(o.ir, rbase + 15, 64);
-            q_cur += __shfl(o.iq, rbase + 15, 64);
-          }
-        }
-      }
-        more = more && (__ballot(beyond) & rowmask) != 0ull;
-      wave_lds_sync();
-    }
-  }
-  if (lane == 0 && n_items) atomicAdd(pool_top + 1, n_items);
-  n_recs = (unsigned int)wave_incl_scan((int)n_recs);   // byte accounting and pool sizing: records of all tiles
-  if (lane == 63 && n_recs) atomicAdd(pool_top + 2, n_recs);
-}
-
-// workgroups of K0 that are resident at once on the current device: the persistent kernel strides over the
-// reads, so a grid that does not fit would run a second, mostly idle generation
-static int k0_resident_blocks() {
-  static int cache[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (cache[dev] == 0) {
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k0_bin, LCR_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    cache[dev] = per_cu * cus;
-  }
-  return cache[dev];
-}
-
-void launch_k0_bin(const BatchView& b, const ReadBin* rb, int ont, int D, int32_t* tile_fill, int32_t* tile_lvl,
-                   unsigned int* pool_top, unsigned int pool_cap, unsigned long long* recs, uint32_t* ndiff, hipStream_t s) {
-  if (b.n_reads == 0) return;
-  const int per = LCR_BLOCK / 16;
-  const int blocks = std::min((b.n_reads + per - 1) / per, k0_resident_blocks());
-  hipLaunchKernelGGL(k0_bin, dim3(blocks), dim3(LCR_BLOCK), 0, s, b, rb, ont, D, tile_fill, tile_lvl, pool_top, pool_cap, recs, ndiff);
-}
-
-// ---------------------------------------------------------------------------------------------
 // LDS planes of one tile (u32 each, LCR_TILE + 1 entries so that "end" markers at tile_len fit)
 enum {
   P_DIFF_DEPTH_F = 0,  // difference array: kept aligned bases of forward reads
@@ -357,6 +136,7 @@ enum {
   P_DIFF_TS0,          // difference array: transcript_strands[0]
   P_DIFF_TS1,          //                   transcript_strands[1]
   P_DIFF_D,            // deletion runs
+  P_DIFF_N,            // intron runs that start or end in this tile (the tiles an intron covers entirely: tile_nbase)
   P_NI,                // insertions (plain counter)
   P_MM_F,              // 4 planes: mismatching base counts A,C,G,T of forward reads
   P_MM_R = P_MM_F + 4, // 4 planes: ... of reverse reads
@@ -378,10 +158,10 @@ __device__ __forceinline__ int block_incl_scan(int v, int* wsum /* K1_WAVES ints
 
 __global__ void __launch_bounds__(K1_THREADS)
 k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0,
-          int64_t n_cols, const int32_t* __restrict__ tile_fill, const int32_t* __restrict__ tile_lvl,
+          int64_t n_cols, const int32_t* __restrict__ tile_fill, const int32_t* __restrict__ ent_off, const uint2* __restrict__ ents,
           const unsigned long long* __restrict__ recs,
-          const int32_t* __restrict__ nscan, uint32_t* __restrict__ planes, const int32_t* __restrict__ order) {
-  const int tile = order ? order[blockIdx.x] : (int)blockIdx.x;   // (k1_tile_order: tiles with the most records first)
+          const int32_t* __restrict__ tile_nbase, uint32_t* __restrict__ planes, const int32_t* __restrict__ order) {
+  const int tile = order[blockIdx.x];   // (k1_tile_order: tiles with the most records first)
   __shared__ uint32_t pl[P_NPL * TSTRIDE];
   __shared__ __attribute__((aligned(16))) uint8_t refl[REF_PAD + LCR_TILE + 32];
   __shared__ unsigned long long rec_s[K1_RPB * K1_THREADS];
@@ -396,35 +176,31 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   const int tlen = min(LCR_TILE, vec - tc0);
   const int64_t gcol0 = b.col_off[g] + tc0;            // global column of tile column 0
   if (*b.error_flag != 0) return;   // K0 failed (bad CIGAR or record pool overflow): the stage is rejected or repeated
-  const int i0 = 0, i1 = tile_fill[tile];   // records of this tile: slots 0 .. i1-1 of its levels (K0)
-  if (i0 == i1) {
-    // no M / D / I record touches this tile (pure intron or uncovered): every plane is 0 except the
-    // intron plane, which comes from the global scan.  Most tiles of a spliced data set are like this.
+  const int i1 = tile_fill[tile];   // records of this tile, in the groups K0 announced for it (k0_ops.hip, k0_desc_bin)
+  if (i1 == 0) {
+    // no record touches this tile (uncovered, or inside introns only): every plane is 0 except the intron plane, which
+    // is the number of introns that cover the whole tile.  Most tiles of a spliced data set are like this.
     // 16-byte stores: 4 consecutive columns per thread and plane (dword-aligned addresses)
+    const uint32_t nb = (uint32_t)tile_nbase[tile];
     for (int col = tid * 4; col < tlen; col += K1_THREADS * 4) {
       const int64_t o = gcol0 + col;
       if (col + 4 <= tlen) {
 #pragma unroll
         for (int k = 0; k < LCR_NPLANES; k++)
-          if (k != LCR_PL_N) *reinterpret_cast<uint4*>(planes + (int64_t)k * n_cols + o) = make_uint4(0u, 0u, 0u, 0u);
-        *reinterpret_cast<uint4*>(planes + (int64_t)LCR_PL_N * n_cols + o) =
-            make_uint4((uint32_t)nscan[o + g + 1], (uint32_t)nscan[o + g + 2], (uint32_t)nscan[o + g + 3], (uint32_t)nscan[o + g + 4]);
+          *reinterpret_cast<uint4*>(planes + (int64_t)k * n_cols + o) = k == LCR_PL_N ? make_uint4(nb, nb, nb, nb) : make_uint4(0u, 0u, 0u, 0u);
       } else {
-        for (int c2 = col; c2 < tlen; c2++) {
+        for (int c2 = col; c2 < min(col + 4, tlen); c2++) {
           const int64_t o2 = gcol0 + c2;
 #pragma unroll
-          for (int k = 0; k < LCR_NPLANES; k++) planes[(int64_t)k * n_cols + o2] = 0u;
-          planes[(int64_t)LCR_PL_N * n_cols + o2] = (uint32_t)nscan[o2 + g + 1];
+          for (int k = 0; k < LCR_NPLANES; k++) planes[(int64_t)k * n_cols + o2] = k == LCR_PL_N ? nb : 0u;
         }
       }
     }
     return;
   }
-  __shared__ int lvl_at[LCR_REC_LEVELS];
   // valid-byte masks of a 16-byte piece in the layout of the mismatch word below (bit 8k + j <-> byte 4j + k):
   // vge[lo] = bytes >= lo, vlt[hi] = bytes < hi
   __shared__ uint32_t vge[17], vlt[17];
-  if (tid < LCR_REC_LEVELS) lvl_at[tid] = tile_lvl[tile * LCR_REC_LEVELS + tid];
   if (tid >= 64 && tid < 64 + 34) {
     const int v = (tid - 64) % 17;
     uint32_t m = 0;
@@ -444,27 +220,38 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   __syncthreads();
   const uint32_t* rl32 = reinterpret_cast<const uint32_t*>(refl);
 
-  // record batches of K1_RPB * K1_THREADS records: fewer block-wide barriers per record
-  // the records of the next batch are requested while the current batch is processed
-  auto load_rec = [&](int j) -> unsigned long long {
-    if (j >= i1) return 0ull;
-    const int lv = rec_level(j);
-    return recs[(unsigned int)lvl_at[lv] + (unsigned int)(j - rec_level_first(lv))];
+  // record batches of K1_RPB * K1_THREADS slots: fewer block-wide barriers per record.  The tile's records lie in groups of
+  // <= 16 (k0_desc_bin: one 8-byte entry per group = pool offset, count), so slot j is record (j & 15) of entry j >> 4 -- no
+  // search; the slots of a group beyond its count are idle.  The next batch is requested while this one is tallied.
+  const int e0 = ent_off[tile];
+  const int n_slots = (ent_off[tile + 1] - e0) * 16;
+  static_assert(K1_RPB == 2, "a thread's two slots lie in one entry");
+  auto load_recs = [&](int j, unsigned long long* out) -> int {   // slots j, j + 1 (j even); returns which of them hold a record
+    out[0] = 0ull; out[1] = 0ull;
+    int has = 0;
+    if (j < n_slots) {
+      const uint2 en = ents[e0 + (j >> 4)];
+      const unsigned int k = (unsigned int)j & 15u;
+      if (k < en.y) { out[0] = recs[en.x + k]; has |= 1; }
+      if (k + 1 < en.y) { out[1] = recs[en.x + k + 1]; has |= 2; }
+    }
+    return has;
   };
   unsigned long long rec_nx[K1_RPB];
-#pragma unroll
-  for (int x = 0; x < K1_RPB; x++) rec_nx[x] = load_rec(i0 + tid * K1_RPB + x);
-  for (int rbase = i0; rbase < i1 && K1_ABL != 3; rbase += K1_RPB * K1_THREADS) {
-    // ---- phase 1: K1_RPB records per thread (thread t owns batch slots K1_RPB*t .. K1_RPB*t + K1_RPB-1)
-    int npc[K1_RPB], nsum = 0;
+  int has_nx = load_recs(tid * K1_RPB, rec_nx);
+  for (int rbase = 0; rbase < n_slots && K1_ABL != 3; rbase += K1_RPB * K1_THREADS) {
     unsigned long long rec_cur[K1_RPB];
 #pragma unroll
-    for (int x = 0; x < K1_RPB; x++) { rec_cur[x] = rec_nx[x]; rec_nx[x] = load_rec(rbase + K1_RPB * K1_THREADS + tid * K1_RPB + x); }
+    for (int x = 0; x < K1_RPB; x++) rec_cur[x] = rec_nx[x];
+    const int has_cur = has_nx;
+    has_nx = load_recs(rbase + K1_RPB * K1_THREADS + tid * K1_RPB, rec_nx);
+    // ---- phase 1: K1_RPB records per thread (thread t owns batch slots K1_RPB*t .. K1_RPB*t + K1_RPB-1)
+    int npc[K1_RPB], nsum = 0;
 #pragma unroll
     for (int x = 0; x < K1_RPB; x++) {
       const int slot = tid * K1_RPB + x;
-      const bool hasrec = rbase + slot < i1;
       const unsigned long long rec = rec_cur[x];
+      const bool hasrec = (has_cur >> x) & 1;
       const unsigned long long off = rec & REC_OFF_MASK;
       const int col0 = (int)((rec >> 40) & 1023u), len = (int)((rec >> 50) & 1023u) + 1;
       int npieces = 0;
@@ -474,6 +261,9 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
           atomicAdd(&pl[P_DIFF_D * TSTRIDE + col0 + len], 0xFFFFFFFFu);
         } else if (off == REC_KIND_I) {   // util.rs:918-929
           atomicAdd(&pl[P_NI * TSTRIDE + col0], 1u);
+        } else if (off == REC_KIND_N) {   // util.rs:930-942: +1 per intron position (the part of the run inside this tile)
+          atomicAdd(&pl[P_DIFF_N * TSTRIDE + col0], 1u);
+          atomicAdd(&pl[P_DIFF_N * TSTRIDE + col0 + len], 0xFFFFFFFFu);
         } else {                          // M-segment: range update now, per-base corrections in phase 2
           const int strand = (int)((rec >> 60) & 1u), tscls = (int)((rec >> 61) & 3u);
           uint32_t* dp = pl + (strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
@@ -582,11 +372,11 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   }
   __syncthreads();
 
-  // prefix-scan the five difference arrays together (one pair of barriers instead of five), K1_CPT consecutive
+  // prefix-scan the six difference arrays together (one pair of barriers instead of six), K1_CPT consecutive
   // columns per thread
   {
-    constexpr int NP = P_DIFF_D - P_DIFF_DEPTH_F + 1;
-    static_assert(NP == 5, "five difference arrays");
+    constexpr int NP = P_DIFF_N - P_DIFF_DEPTH_F + 1;
+    static_assert(NP == 6, "six difference arrays");
     __shared__ int wsum5[NP][K1_WAVES];
     const int lane = tid & 63, w = tid >> 6;
     int v[NP][K1_CPT], incl[NP];
@@ -613,6 +403,7 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   }
 
   // assemble the ABI planes and write them out (coalesced: consecutive threads, consecutive columns)
+  const uint32_t nbase = (uint32_t)tile_nbase[tile];
   for (int col = tid; col < tlen; col += K1_THREADS) {
     const uint8_t R = refl[REF_PAD + col];
     const int ri = R == 'A' ? 0 : R == 'C' ? 1 : R == 'G' ? 2 : R == 'T' ? 3 : -1;
@@ -634,8 +425,8 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
       planes[(int64_t)(LCR_PL_A + k) * n_cols + o] = f[k] + rv[k];
       planes[(int64_t)(LCR_PL_FWD_A + k) * n_cols + o] = f[k];
     }
-    // intron plane: exclusive scan of the global difference array (one spare slot per region)
-    planes[(int64_t)LCR_PL_N * n_cols + o] = (uint32_t)nscan[o + g + 1];
+    // intron plane: introns that cover the whole tile + the runs that start or end inside it
+    planes[(int64_t)LCR_PL_N * n_cols + o] = nbase + pl[P_DIFF_N * TSTRIDE + col];
     planes[(int64_t)LCR_PL_D * n_cols + o] = pl[P_DIFF_D * TSTRIDE + col];
     planes[(int64_t)LCR_PL_NI * n_cols + o] = pl[P_NI * TSTRIDE + col];
     planes[(int64_t)LCR_PL_TS_FWD * n_cols + o] = pl[P_DIFF_TS0 * TSTRIDE + col];
@@ -647,12 +438,54 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
 // takes its tiles through a permutation that puts the fullest first: one workgroup sorts the tile indices by
 // floor(log2(records + 1)), descending, with LDS counters (the order inside a class is whatever the atomics give -- every
 // tile writes only its own columns, so the planes do not depend on it).
-__global__ void __launch_bounds__(1024) k1_tile_order(const int32_t* __restrict__ tile_fill, int32_t n_tiles, int32_t* __restrict__ order) {
+// The same workgroup turns K0's tile-level intron difference array into tile_nbase[t] = introns that cover tile t
+// entirely: a plain inclusive scan -- an intron adds +1 at the tile after its first and -1 at its last, both inside
+// its region, so every region's entries sum to zero and no segment handling is needed.
+__global__ void __launch_bounds__(1024) k1_tile_order(const int32_t* __restrict__ tile_fill, int32_t n_tiles, int32_t* __restrict__ order,
+                                                       const int32_t* __restrict__ tile_ndiff, int32_t* __restrict__ tile_nbase,
+                                                       const int32_t* __restrict__ tile_nchunks, int32_t* __restrict__ chunk_off,
+                                                       const unsigned int* __restrict__ acct, int32_t n_acct, unsigned int* __restrict__ ctl) {
   // per-wave counters (one counter per class for the whole workgroup serialised 15 000 LDS atomics on the class of the
   // record-free tiles: 22 us); the record-free tiles -- three quarters of them -- are ranked with ballots instead
   __shared__ int cnt[16][32], n_empty[16], ecur[16];
+  __shared__ int nb_ws[16], nc_ws[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
+  if (w == 0) {   // K0's accounting slots -> control block ([1] items, [2] records), fetched by the host behind this kernel
+    int it = 0, rc = 0, pt = 0, dt = 0;   // items, records; fullest pool / descriptor shard
+    for (int i = lane; i < n_acct; i += 64) { it += (int)acct[32 * i]; rc += (int)acct[32 * i + 1]; pt = max(pt, (int)acct[32 * i + 2]); dt = max(dt, (int)acct[32 * i + 3]); }
+    it = wave_incl_scan(it); rc = wave_incl_scan(rc);
+    for (int o = 32; o > 0; o >>= 1) { pt = max(pt, __shfl_xor(pt, o, 64)); dt = max(dt, __shfl_xor(dt, o, 64)); }
+    if (lane == 63) { ctl[0] = (unsigned int)pt; ctl[1] = (unsigned int)it; ctl[2] = (unsigned int)rc; ctl[4] = (unsigned int)dt; }
+  }
+  {   // tile_nbase: inclusive scan of tile_ndiff; chunk_off: exclusive scan of tile_nchunks ([n_tiles] = all chunks) -- a run
+      // of consecutive tiles per thread, its values loaded eight at a time before they are summed (one workgroup: or
+      // it is all load latency)
+    const int per = (n_tiles + 1023) / 1024, t0 = min(tid * per, n_tiles), t1 = min(t0 + per, n_tiles);
+    int sum_d = 0, sum_c = 0;
+    const int tl = max(n_tiles - 1, 0);   // (loads are unconditional with a clamped index: eight of each array in flight)
+    for (int t = t0; t < t1; t += 8) {
+      int vd[8], vc[8];
+#pragma unroll
+      for (int x = 0; x < 8; x++) { vd[x] = tile_ndiff[min(t + x, tl)]; vc[x] = tile_nchunks[min(t + x, tl)]; }
+#pragma unroll
+      for (int x = 0; x < 8; x++) if (t + x < t1) { sum_d += vd[x]; sum_c += vc[x]; }
+    }
+    const int incl_d = wave_incl_scan(sum_d), incl_c = wave_incl_scan(sum_c);
+    if (lane == 63) { nb_ws[w] = incl_d; nc_ws[w] = incl_c; }
+    __syncthreads();
+    int run_d = incl_d - sum_d, run_c = incl_c - sum_c;
+    for (int i = 0; i < w; i++) { run_d += nb_ws[i]; run_c += nc_ws[i]; }
+    for (int t = t0; t < t1; t += 8) {
+      int vd[8], vc[8];
+#pragma unroll
+      for (int x = 0; x < 8; x++) { vd[x] = tile_ndiff[min(t + x, tl)]; vc[x] = tile_nchunks[min(t + x, tl)]; }
+#pragma unroll
+      for (int x = 0; x < 8; x++)
+        if (t + x < t1) { run_d += vd[x]; tile_nbase[t + x] = run_d; chunk_off[t + x] = run_c; run_c += vc[x]; }
+    }
+    if (tid == 1023) chunk_off[n_tiles] = run_c;
+  }
   for (int i = tid; i < 16 * 32; i += 1024) (&cnt[0][0])[i] = 0;
   __syncthreads();
   int my_empty = 0;
@@ -696,12 +529,18 @@ __global__ void __launch_bounds__(1024) k1_tile_order(const int32_t* __restrict_
 }
 
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
-                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_fill, const int32_t* tile_lvl, const unsigned long long* recs,
-                      const int32_t* nscan, uint32_t* planes, int32_t* order /* n_tiles ints of scratch, or nullptr */, hipStream_t s) {
+                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_fill, const int32_t* ent_off, const void* ents,
+                      const unsigned long long* recs, const int32_t* tile_nbase, uint32_t* planes, const int32_t* order /* launch_k1_tile_order */,
+                      hipStream_t s) {
   if (n_tiles == 0) return;
-  if (order) hipLaunchKernelGGL(k1_tile_order, dim3(1), dim3(1024), 0, s, tile_fill, n_tiles, order);
-  hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_fill, tile_lvl,
-                     recs, nscan, planes, order);
+  hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_fill, ent_off,
+                     (const uint2*)ents, recs, tile_nbase, planes, order);
+}
+// the tile-order / intron-base / accounting pass alone (the host fetches K0's control block behind it, before K1 is queued)
+void launch_k1_tile_order(int32_t n_tiles, const int32_t* tile_fill, const int32_t* tile_ndiff, int32_t* tile_nbase, const int32_t* tile_nchunks,
+                          int32_t* chunk_off, const unsigned int* acct, int32_t n_acct, unsigned int* ctl, int32_t* order, hipStream_t s) {
+  hipLaunchKernelGGL(k1_tile_order, dim3(1), dim3(1024), 0, s, tile_fill, n_tiles, order, tile_ndiff, tile_nbase, tile_nchunks, chunk_off, acct,
+                     n_acct, ctl);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -23,7 +23,11 @@ struct lcr_ctx {
   std::vector<int64_t> h_start0, h_col_off;
   std::vector<int32_t> h_len, h_read_begin, h_region_first_tile;
   DevBuf in_[16];  // device copies of host inputs (LCR_MEM_HOST)
-  DevBuf scan_tmp, read_region, read_bin, read_rend, tile_region, tile_col0, first_tile, k0_tile_count, k0_tile_fill, k0_items, ndiff, nscan, tile_order;
+  DevBuf scan_tmp, read_region, read_bin, read_rend, tile_region, tile_col0, first_tile, k0_tile_fill, k0_items, tile_nbase, tile_order;
+  DevBuf desc_tile, desc_val, chunks, chunk_off;   // K0's chunk descriptors, the same sorted by tile, their per-tile offsets
+  DevBuf blk_first_read, read_scan, cig_compact, cig_off_new, cig_new_off32;   // K0 op blocks (k0_ops.hip)
+  uint64_t cig0 = 0;      // index of the batch's first op in bv.cigar
+  uint32_t n_ops = 0;     // ops of the batch (one flat op space)
   int64_t n_items = 0;
 
   // K1
@@ -146,8 +150,8 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto& b : c->in_) b.release();
   DevBuf* bufs[] = {&c->rd_start, &c->rd_end, &c->rd_diff, &c->rd_ex, &c->rd_cnt, &c->rd_off, &c->rd_s, &c->rd_e, &c->rd_max,
-                    &c->scan_tmp, &c->read_region, &c->read_bin, &c->read_rend, &c->tile_region, &c->tile_col0, &c->first_tile, &c->k0_tile_count, 
-                    &c->k0_tile_fill, &c->k0_items, &c->region_e_off, &c->frag_tmp_col, &c->frag_tmp_val, &c->ndiff, &c->nscan, &c->planes, &c->flags,
+                    &c->scan_tmp, &c->read_region, &c->read_bin, &c->read_rend, &c->tile_region, &c->tile_col0, &c->first_tile, &c->desc_tile, &c->desc_val, &c->chunks, &c->chunk_off,
+                    &c->k0_tile_fill, &c->k0_items, &c->region_e_off, &c->frag_tmp_col, &c->frag_tmp_val, &c->tile_nbase, &c->blk_first_read, &c->read_scan, &c->cig_compact, &c->cig_off_new, &c->cig_new_off32, &c->planes, &c->flags,
                     &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
                     &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
                     &c->row_links, &c->row_ptr, &c->col, &c->val, &c->tile_order};
@@ -223,6 +227,11 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
     HIPCHK(c, hipHostGetDevicePointer((void**)&dst, st, 0));
     launch_k0_region_setup(rg->start0, rg->len, rg->col_off, rg->read_begin, ng, c->first_tile.as<int32_t>(), (int64_t*)dst,
                            (int32_t*)(dst + o2), (int64_t*)(dst + o1), (int32_t*)(dst + o3), c->stream);
+    // the same wait brings the geometry of the flat op space: first op, end of the last read's ops, "CIGARs lie back to back"
+    HIPCHK(c, c->h_order.reserve(64));
+    memset(c->h_order.p, 0, 64);
+    { int32_t* d_flag = nullptr; HIPCHK(c, hipHostGetDevicePointer((void**)&d_flag, c->h_order.p, 0));
+      launch_k0_cig_check(rd->cig_off, rd->n_cig, nr, d_flag, c->stream); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     if (ng) { memcpy(c->h_start0.data(), st, ng * sizeof(int64_t)); memcpy(c->h_len.data(), st + o2, ng * sizeof(int32_t)); }
@@ -272,10 +281,45 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   launch_k0_read_region(b, c->read_region.as<int32_t>(), c->stream);
   b.region_first_tile = c->first_tile.as<int32_t>(); b.error_flag = nullptr;   // set by lcr_pileup
   HIPCHK(c, c->read_bin.reserve(std::max<size_t>(nr, 1) * sizeof(ReadBin)));
-  HIPCHK(c, c->h_order.reserve(64));
+  // ---- the flat op space of K0 (k0_ops.hip): ops [cig0, cig0 + n_ops) of bv.cigar, read after read
+  bool contiguous = true;
+  uint64_t cig0 = 0, cig_end = 0;
+  if (mem == LCR_MEM_HOST) {
+    HIPCHK(c, c->h_order.reserve(64));
+    memset(c->h_order.p, 0, 64);
+    if (nr) { cig0 = rd->cig_off[0]; cig_end = rd->cig_off[nr - 1] + rd->n_cig[nr - 1]; }
+    for (int r = 0; r + 1 < nr && contiguous; r++) contiguous = rd->cig_off[r + 1] == rd->cig_off[r] + rd->n_cig[r];
+  } else {
+    const uint64_t* g = reinterpret_cast<const uint64_t*>(c->h_order.as<uint8_t>() + 16);   // written by k0_cig_check, waited for above
+    contiguous = c->h_order.as<int32_t>()[1] == 0;
+    cig0 = g[0]; cig_end = g[1];
+  }
+  if (!contiguous) {   // the ABI allows any cig_off: copy the CIGARs back to back once (rare; every producer here is contiguous)
+    HIPCHK(c, c->cig_new_off32.reserve(((size_t)nr + 2) * 4));
+    HIPCHK(c, c->cig_off_new.reserve(std::max<size_t>(nr, 1) * 8));
+    int32_t* total = c->cig_new_off32.as<int32_t>() + nr;
+    launch_scan_i32(c->scan_tmp, (const int32_t*)b.n_cig, c->cig_new_off32.as<int32_t>(), nr, total, c->stream);
+    int32_t h_total = 0;
+    HIPCHK(c, hipMemcpyAsync(&h_total, total, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h_total < 0) { c->err = "batch too large: CIGAR ops must stay below 2^31; split it"; return LCR_E_ARG; }
+    HIPCHK(c, c->cig_compact.reserve(std::max<size_t>((size_t)h_total, 1) * 4));
+    launch_k0_cig_compact(b.cigar, b.cig_off, b.n_cig, c->cig_new_off32.as<int32_t>(), nr, c->cig_compact.as<uint32_t>(),
+                          c->cig_off_new.as<uint64_t>(), c->stream);
+    b.cigar = c->cig_compact.as<uint32_t>(); b.cig_off = c->cig_off_new.as<uint64_t>();
+    cig0 = 0; cig_end = (uint64_t)h_total;
+  }
+  if (cig_end < cig0 || cig_end - cig0 > 0xFFF00000ull || (contiguous && cig_end > (uint64_t)std::max<int64_t>(rd->n_cigar, 0))) {
+    c->err = "cig_off / n_cig inconsistent with n_cigar, or more than 2^32 CIGAR ops in one batch"; return LCR_E_ARG;
+  }
+  c->cig0 = cig0; c->n_ops = (uint32_t)(cig_end - cig0);
   *c->h_order.as<int32_t>() = 0;   // (the previous batch's k0_pack finished long ago: every lcr_pileup waits behind it)
   { int32_t* d_flag = nullptr; HIPCHK(c, hipHostGetDevicePointer((void**)&d_flag, c->h_order.p, 0));
     launch_k0_pack(b, c->read_bin.as<ReadBin>(), d_flag, c->stream); }
+  { const int opb = launch_k0_opb();
+    const int32_t n_blocks = (int32_t)(((uint64_t)c->n_ops + opb - 1) / opb);
+    HIPCHK(c, c->blk_first_read.reserve(((size_t)n_blocks + 2) * 4));
+    launch_k0_block_reads(c->read_bin.as<ReadBin>(), nr, c->cig0, opb, n_blocks, c->blk_first_read.as<int32_t>(), c->stream); }
   // host batch: the caller's arrays are free again when this returns; device batch: no wait, the next stage queues
   // behind these kernels on the same stream (the arrays stay the caller's to keep alive, include/lcr.h)
   if (mem == LCR_MEM_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -295,47 +339,63 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   c->dp.dbg = 0;
   HIPCHK(c, c->planes.reserve(std::max<size_t>((size_t)c->n_cols * LCR_NPLANES, 1) * 4));
   BatchView& b = c->bv;
-  const int ng = b.n_regions, nt = c->n_tiles;
-  // ---- K0: decode every CIGAR once into per-tile records (single pass, geometric levels) + intron plane
-  const size_t nd = (size_t)c->n_cols + ng + 1;
-  // records <= M/D/I ops + their tile crossings (M: <= bases / tile + ops); a tile's levels hold < 2 x fill + 64
-  // slots.  Long D runs can exceed the estimate: K0 then flags an overflow (writes are bounds-checked) and the
-  // stage is repeated with a larger pool.
-  size_t pool_cap64 = 2 * ((size_t)c->n_cigar + (size_t)b.n_reads + (size_t)c->n_bases / LCR_TILE) + 64 * (size_t)nt + 64;
-  // control block behind the tile fill counters: [nt + 1] pool top, [nt + 2] M / D / I items, [nt + 3] records,
-  // [nt + 4] error flag -- cleared with the counters, fetched with one copy
-  HIPCHK(c, c->k0_tile_fill.reserve((nt + 8) * 4));
-  b.error_flag = c->k0_tile_fill.as<int32_t>() + nt + 4;
-  HIPCHK(c, c->k0_tile_count.reserve(std::max<size_t>((size_t)nt * LCR_REC_LEVELS, 1) * 4));   // level table
+  const int nt = c->n_tiles;
+  // ---- K0: decode every CIGAR once into per-tile records (one op-parallel pass; a block's records lie back to back in the
+  // pool, grouped by tile, each group announced by a chunk descriptor)
+  // records <= M / D / I ops + their tile crossings (M: <= bases / tile) + at most two per intron.  Long D runs can exceed
+  // the estimate: K0 then flags an overflow (writes are bounds-checked) and the stage is repeated with larger pools.
+  const int opb = launch_k0_opb();
+  const int32_t n_blocks = (int32_t)(((uint64_t)c->n_ops + opb - 1) / opb);
+  // (a block's records of one tile take whole 16-slot units: + 15 slots per (block, tile) group at most)
+  size_t desc_cap64 = (size_t)n_blocks * 128 + (size_t)b.n_reads / 4 + 1024;
+  size_t pool_cap64 = (size_t)c->n_ops + (size_t)c->n_ops / 2 + (size_t)b.n_reads + (size_t)c->n_bases / LCR_TILE + 8 * desc_cap64 + 1024;
+  // one cleared buffer: tile fill counters [0, nt) | control block at nt + 1 (pool top, items, records, error flag, descriptor
+  // top) | tile-level intron difference array | chunks per tile | bin cursors | K0's accounting slots
+  const size_t o_ndiff = (size_t)nt + 16, o_nch = o_ndiff + nt + 8, o_cur = o_nch + nt + 8, o_acct = o_cur + nt + 8;
+  const size_t fill_words = o_acct + launch_k0_acct_words();
+  HIPCHK(c, c->k0_tile_fill.reserve(fill_words * 4));
+  int32_t* const fill = c->k0_tile_fill.as<int32_t>();
+  b.error_flag = fill + nt + 4;
   HIPCHK(c, c->tile_order.reserve(std::max(nt, 1) * 4));
-  HIPCHK(c, c->ndiff.reserve(nd * 4));
-  HIPCHK(c, c->nscan.reserve(nd * 4));
+  HIPCHK(c, c->tile_nbase.reserve(std::max(nt, 1) * 4));
+  HIPCHK(c, c->chunk_off.reserve(((size_t)nt + 2) * 4));
+  HIPCHK(c, c->read_scan.reserve(std::max<size_t>(b.n_reads, 1) * 8));
   HIPCHK(c, c->h_stage[0].reserve(64));
   int32_t n_recs = 0, bad = 0, n_ops = 0;
   for (;;) {
-    if (pool_cap64 > 0xFFFFFFF0ull) { c->err = "batch too large for the 32-bit record pool: split it"; return LCR_E_ARG; }
-    const unsigned int pool_cap = (unsigned int)pool_cap64;
-    HIPCHK(c, c->k0_items.reserve((size_t)pool_cap * 8));
-    HIPCHK(c, hipMemsetAsync(c->k0_tile_fill.p, 0, (nt + 8) * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->k0_tile_count.p, 0xFF, std::max<size_t>((size_t)nt * LCR_REC_LEVELS, 1) * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->ndiff.p, 0, nd * 4, c->stream));
+    // the pool and the descriptor array are cut into launch_k0_acct_slots() shards (a block allocates from shard blockIdx % shards)
+    const size_t nsh = (size_t)launch_k0_acct_slots();
+    const size_t pool_sub64 = (pool_cap64 + nsh - 1) / nsh + 256, desc_sub64 = (desc_cap64 + nsh - 1) / nsh + 64;
+    if (pool_sub64 * nsh > 0xFFFFFFF0ull || desc_sub64 * nsh > 0x7FFFFFF0ull) { c->err = "batch too large for the 32-bit record pool: split it"; return LCR_E_ARG; }
+    const unsigned int pool_sub = (unsigned int)pool_sub64, desc_sub = (unsigned int)desc_sub64;
+    HIPCHK(c, c->k0_items.reserve(pool_sub64 * nsh * 8));
+    HIPCHK(c, c->desc_tile.reserve(desc_sub64 * nsh * 4));
+    HIPCHK(c, c->desc_val.reserve(desc_sub64 * nsh * 8));
+    HIPCHK(c, c->chunks.reserve((pool_sub64 * nsh / 16 + 16) * 8));   // entries of 16 slots
+    HIPCHK(c, hipMemsetAsync(fill, 0, fill_words * 4, c->stream));
     { Timer t(c, LCR_K_SPANS);
-      launch_k0_bin(b, c->read_bin.as<ReadBin>(), c->dp.ont, c->dp.dist_to_end, c->k0_tile_fill.as<int32_t>(), c->k0_tile_count.as<int32_t>(),
-                    (unsigned int*)(c->k0_tile_fill.as<int32_t>() + nt + 1), pool_cap, c->k0_items.as<unsigned long long>(),
-                    c->ndiff.as<uint32_t>(), c->stream);
-      launch_scan_i32(c->scan_tmp, (const int32_t*)c->ndiff.p, c->nscan.as<int32_t>(), (int32_t)nd, nullptr, c->stream); }
-    // K0's verdict (CIGAR validation, pool overflow) and counts leave for the host before K1 is queued: the host
-    // waits for them while K1 runs and returns without waiting for K1 -- later calls queue behind it
+      launch_k0_ops(b, c->read_bin.as<ReadBin>(), c->blk_first_read.as<int32_t>(), c->cig0, c->n_ops, c->dp.ont, c->dp.dist_to_end, nt,
+                    fill, fill + o_nch, fill + o_ndiff, fill + nt + 1, (unsigned int*)(fill + o_acct), pool_sub, c->k0_items.as<unsigned long long>(),
+                    desc_sub, c->desc_tile.as<uint32_t>(), c->desc_val.p, c->read_scan.p, c->stream); }
+    // tile order for K1, introns per whole tile, chunk offsets, K0's accounting (one workgroup); K0's verdict (CIGAR
+    // validation, pool overflow) and counts then leave for the host before the rest is queued: the host waits for them while
+    // K1 runs and returns without waiting for K1 -- later calls queue behind it
     int32_t* const ctl = c->h_stage[0].as<int32_t>();
-    HIPCHK(c, hipMemcpyAsync(ctl, c->k0_tile_fill.as<int32_t>() + nt + 1, 16, hipMemcpyDeviceToHost, c->stream));
     if (!c->ev_ctl) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ctl, hipEventDisableTiming));
-    HIPCHK(c, hipEventRecord(c->ev_ctl, c->stream));
-    // ---- K1: per-tile tally from the records (leaves at once if K0 flagged an error); K1z: poly-A / homopolymer
-    // mask of the HiFi presets
-    { Timer t(c, LCR_K_PILEUP);
-      launch_k1_pileup(b, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
-                       c->k0_tile_fill.as<int32_t>(), c->k0_tile_count.as<int32_t>(), c->k0_items.as<unsigned long long>(),
-                       c->nscan.as<int32_t>(), c->planes.as<uint32_t>(), c->tile_order.as<int32_t>(), c->stream);
+    { Timer t(c, LCR_K_PILEUP);   // (the tally kernel with its ordering and chunk-binning passes)
+      if (nt > 0) launch_k1_tile_order(nt, fill, fill + o_ndiff, c->tile_nbase.as<int32_t>(), fill + o_nch, c->chunk_off.as<int32_t>(),
+                                       (unsigned int*)(fill + o_acct), launch_k0_acct_slots(), (unsigned int*)(fill + nt + 1),
+                                       c->tile_order.as<int32_t>(), c->stream);
+      HIPCHK(c, hipMemcpyAsync(ctl, fill + nt + 1, 32, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipEventRecord(c->ev_ctl, c->stream));
+      if (nt > 0 && c->n_ops > 0)
+        launch_k0_desc_bin(fill + nt + 1, (const unsigned int*)(fill + o_acct), desc_sub, c->desc_tile.as<uint32_t>(), c->desc_val.p, c->chunk_off.as<int32_t>(), fill + o_cur,
+                           c->chunks.p, n_blocks / 8 + 1, c->stream);
+      // ---- K1: per-tile tally from the records (leaves at once if K0 flagged an error); K1z: poly-A / homopolymer
+      // mask of the HiFi presets
+      launch_k1_pileup(b, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols, fill, c->chunk_off.as<int32_t>(),
+                       c->chunks.p, c->k0_items.as<unsigned long long>(), c->tile_nbase.as<int32_t>(), c->planes.as<uint32_t>(),
+                       c->tile_order.as<int32_t>(), c->stream);
       if (!c->dp.ont && c->dp.dist_to_end > 0)
         launch_k1_zonefix(b, c->read_bin.as<ReadBin>(), c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->stream); }
     HIPCHK(c, hipGetLastError());
@@ -344,15 +404,17 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
     if (*c->h_order.as<int32_t>() != 0) { c->err = "the reads of a region must be sorted by position (lcr_reads.pos)"; return LCR_E_ARG; }
     if (bad == 1) { c->err = "unknown CIGAR operation (reference panics: util.rs:944)"; return LCR_E_CIGAR; }
     if (bad == 2) { c->err = "CIGAR inconsistent with l_seq / soft clips"; return LCR_E_CIGAR; }
-    if (bad == 4) { c->err = "K0 record level wait timed out (internal error)"; return LCR_E_DEVICE; }
     if (bad == 0) break;
-    pool_cap64 = pool_cap64 * 2 + 4 * (size_t)std::max(n_recs, 0);   // overflow: the true record count is known now
+    // overflow: K0 kept counting -- the true record and descriptor counts are known now
+    // (ctl[0] / ctl[4]: what the fullest shard asked for)
+    pool_cap64 = std::max<size_t>(pool_cap64 * 2, ((size_t)(uint32_t)ctl[0] + 1024) * nsh);
+    desc_cap64 = std::max<size_t>(desc_cap64 * 2, ((size_t)(uint32_t)ctl[4] + 1024) * nsh);
   }
   c->n_items = n_recs;
-  // bytes K1 itself has to move: read bases once + 8-byte records + reference byte and
-  // intron-scan word per column, 13 u32 planes written per column
-  // (8 bytes per M / D / I item: the extra records of items that cross a tile boundary are overhead, not algorithm)
-  c->pileup_bytes = c->n_bases + 8 * (int64_t)n_ops + (4 * LCR_NPLANES + 1 + 4) * c->n_cols;
+  // bytes K1 itself has to move: read bases once + 8-byte records + reference byte per column, 13 u32
+  // planes written per column
+  // (8 bytes per M / D / I / N item: the extra records of items that cross a tile boundary are overhead, not algorithm)
+  c->pileup_bytes = c->n_bases + 8 * (int64_t)n_ops + (4 * LCR_NPLANES + 1) * c->n_cols;
   c->stage_bytes = c->n_bases + 4 * c->n_cigar + 37 * (int64_t)b.n_reads + (4 * LCR_NPLANES + 1) * c->n_cols;
   c->have_planes = true;
   c->have_cand = c->have_frag = c->have_phase = false;

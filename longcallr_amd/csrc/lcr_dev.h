@@ -10,7 +10,6 @@
 #include "../../include/lcr.h"
 
 #define LCR_TILE 512       // pileup columns per workgroup tile
-#define LCR_REC_LEVELS 20   // record levels per tile: 64, 128, 256, ... slots (K0 allocates, K1 reads)
 #define LCR_BLOCK 256      // threads per workgroup (4 wave64)
 #define LCR_WAVE 64
 
@@ -126,18 +125,32 @@ struct PhaseLutDev {
 };
 
 // ---- kernel launchers (defined in the .hip files) ----
-// K0: pass 0 counts records per tile (+ intron difference array, CIGAR validation); pass 1 writes them
 void launch_k0_region_setup(const int64_t* start0, const int32_t* len, const int64_t* col_off, const int32_t* read_begin, int32_t ng,
                             int32_t* first_tile, int64_t* h_start0, int32_t* h_len, int64_t* h_col_off, int32_t* h_read_begin,
                             hipStream_t s);
 void launch_k0_tiles(const int32_t* first_tile, int32_t n_regions, int32_t* tile_region, int32_t* tile_col0, hipStream_t s);
 void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s);
 void launch_k0_pack(const BatchView& b, ReadBin* out, int32_t* order_flag /* pinned host memory, device address */, hipStream_t s);
-void launch_k0_bin(const BatchView& b, const ReadBin* rb, int ont, int D, int32_t* tile_fill, int32_t* tile_lvl,
-                   unsigned int* pool_top, unsigned int pool_cap, unsigned long long* recs, uint32_t* ndiff, hipStream_t s);
+// K0 (k0_ops.hip): op-parallel CIGAR decode + per-tile record binning; load-time helpers
+void launch_k0_cig_check(const uint64_t* cig_off, const uint32_t* n_cig, int32_t nr, int32_t* flag /* pinned host, device address */, hipStream_t s);
+void launch_k0_cig_compact(const uint32_t* cigar, const uint64_t* cig_off, const uint32_t* n_cig, const int32_t* new_off, int32_t nr,
+                           uint32_t* out, uint64_t* out_off, hipStream_t s);
+int launch_k0_opb();   // ops per K0 workgroup
+void launch_k0_block_reads(const ReadBin* rbin, int32_t nr, uint64_t cig0, int32_t opb, int32_t n_blocks, int32_t* blk_first_read, hipStream_t s);
+void launch_k0_ops(const BatchView& b, const ReadBin* rb, const int32_t* blk_first_read, uint64_t cig0, uint32_t n_ops, int ont, int D,
+                   int32_t n_tiles, int32_t* tile_fill, int32_t* tile_nchunks, int32_t* tile_ndiff, void* ctl, unsigned int* acct /* launch_k0_acct_words() zeroed words */,
+                   unsigned int pool_sub /* slots per shard */, unsigned long long* recs, unsigned int desc_sub, uint32_t* desc_tile, void* desc_val /* uint2 */,
+                   void* read_scan /* n_reads x int2 scratch */, hipStream_t s);
+int launch_k0_acct_words();
+int launch_k0_acct_slots();
+void launch_k0_desc_bin(const void* ctl, const unsigned int* acct, unsigned int desc_sub, const uint32_t* desc_tile, const void* desc_val,
+                        const int32_t* chunk_off, int32_t* cursor /* n_tiles zeroed ints */, void* sorted /* uint2, all shards */, int32_t n_blocks_hint,
+                        hipStream_t s);
+void launch_k1_tile_order(int32_t n_tiles, const int32_t* tile_fill, const int32_t* tile_ndiff, int32_t* tile_nbase, const int32_t* tile_nchunks,
+                          int32_t* chunk_off, const unsigned int* acct, int32_t n_acct, unsigned int* ctl, int32_t* order, hipStream_t s);
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
-                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_fill, const int32_t* tile_lvl,
-                      const unsigned long long* recs, const int32_t* nscan, uint32_t* planes, int32_t* order, hipStream_t s);
+                      int32_t n_tiles, int64_t n_cols, const int32_t* tile_fill, const int32_t* chunk_off, const void* chunks,
+                      const unsigned long long* recs, const int32_t* tile_nbase, uint32_t* planes, const int32_t* order, hipStream_t s);
 void launch_k1_zonefix(const BatchView& b, const ReadBin* rbin, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s);
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const int32_t* tile_fill, uint8_t* flags,
