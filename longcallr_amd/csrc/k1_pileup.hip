@@ -36,11 +36,13 @@
 #else
 #define K1_ABL 0
 #endif
-#define K1_THREADS 512
+#ifndef K1_THREADS
+#define K1_THREADS LCR_TILE   // one column per thread in the tile epilogue
+#endif
 #define K1_WAVES (K1_THREADS / 64)
 #define K1_CPT (LCR_TILE / K1_THREADS)  // columns per thread in the tile epilogue
 #define K1_RPB 2                        // records per thread and batch
-#define K1_PMAP 4096                     // pieces per batch with a direct piece -> record map in LDS
+#define K1_PMAP (8 * K1_THREADS)         // pieces per batch with a direct piece -> record map in LDS
 #define K1_PIF 4                        // 16-byte pieces in flight per thread (a batch of 1024 records has ~2500 pieces)
 
 // record layout (64 bit): [0,40) byte offset of the first read base | [40,50) tile column |
@@ -160,8 +162,16 @@ __global__ void __launch_bounds__(K1_THREADS)
 k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0,
           int64_t n_cols, const int32_t* __restrict__ tile_fill, const int32_t* __restrict__ ent_off, const uint2* __restrict__ ents,
           const unsigned long long* __restrict__ recs,
-          const int32_t* __restrict__ tile_nbase, uint32_t* __restrict__ planes, const int32_t* __restrict__ order) {
-  const int tile = order[blockIdx.x];   // (k1_tile_order: tiles with the most records first)
+          const int32_t* __restrict__ tile_nbase, uint32_t* __restrict__ planes, const int32_t* __restrict__ order,
+          const int32_t* __restrict__ n_full) {
+  // (tiles with records first, fullest first, the record-free ones behind them: k1_tiles_b.  Dealing the record-free
+  // tiles -- pure streams of plane stores, 75 % of the stage's HBM writes -- between the full ones so that the stores run
+  // under the tally was measured: 0.74 instead of 0.43 ms, XCD-aware or not; the full tiles' dependent loads then queue
+  // behind a saturated write stream)
+  // Record-free tiles -- uncovered, or inside introns only: most tiles of a spliced data set -- are written by
+  // k1_empty_tiles; `order` lists them behind the tiles with records, whose number the tile pass left in *n_full.
+  if ((int)blockIdx.x >= *n_full) return;
+  const int tile = order[blockIdx.x];
   __shared__ uint32_t pl[P_NPL * TSTRIDE];
   __shared__ __attribute__((aligned(16))) uint8_t refl[REF_PAD + LCR_TILE + 32];
   __shared__ unsigned long long rec_s[K1_RPB * K1_THREADS];
@@ -176,28 +186,6 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   const int tlen = min(LCR_TILE, vec - tc0);
   const int64_t gcol0 = b.col_off[g] + tc0;            // global column of tile column 0
   if (*b.error_flag != 0) return;   // K0 failed (bad CIGAR or record pool overflow): the stage is rejected or repeated
-  const int i1 = tile_fill[tile];   // records of this tile, in the groups K0 announced for it (k0_ops.hip, k0_desc_bin)
-  if (i1 == 0) {
-    // no record touches this tile (uncovered, or inside introns only): every plane is 0 except the intron plane, which
-    // is the number of introns that cover the whole tile.  Most tiles of a spliced data set are like this.
-    // 16-byte stores: 4 consecutive columns per thread and plane (dword-aligned addresses)
-    const uint32_t nb = (uint32_t)tile_nbase[tile];
-    for (int col = tid * 4; col < tlen; col += K1_THREADS * 4) {
-      const int64_t o = gcol0 + col;
-      if (col + 4 <= tlen) {
-#pragma unroll
-        for (int k = 0; k < LCR_NPLANES; k++)
-          *reinterpret_cast<uint4*>(planes + (int64_t)k * n_cols + o) = k == LCR_PL_N ? make_uint4(nb, nb, nb, nb) : make_uint4(0u, 0u, 0u, 0u);
-      } else {
-        for (int c2 = col; c2 < min(col + 4, tlen); c2++) {
-          const int64_t o2 = gcol0 + c2;
-#pragma unroll
-          for (int k = 0; k < LCR_NPLANES; k++) planes[(int64_t)k * n_cols + o2] = k == LCR_PL_N ? nb : 0u;
-        }
-      }
-    }
-    return;
-  }
   // valid-byte masks of a 16-byte piece in the layout of the mismatch word below (bit 8k + j <-> byte 4j + k):
   // vge[lo] = bytes >= lo, vlt[hi] = bytes < hi
   __shared__ uint32_t vge[17], vlt[17];
@@ -274,7 +262,7 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
             atomicAdd(&tp[col0], 1u);
             atomicAdd(&tp[col0 + len], 0xFFFFFFFFu);
           }
-          npieces = (int)(((off & 15ull) + (unsigned long long)len + 15ull) >> 4);
+          npieces = (len + 15) >> 4;   // 16-byte pieces from the segment's first base on (dword-unaligned 16-byte loads are fine on gfx950)
         }
       }
       rec_s[slot] = rec;
@@ -316,10 +304,10 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
       const long long soff = (long long)(rc & REC_OFF_MASK);
       const int scol = (int)((rhi >> 8) & 1023u), slen = (int)((rhi >> 18) & 1023u) + 1;
       q.strand = (int)((rhi >> 28) & 1u);
-      const int s15 = (int)((uint32_t)rc & 15u), d16 = 16 * (p - pstart[lo]);   // piece d16 / 16 of the segment
-      const long long A = (soff - s15) + d16;                             // byte address of the piece
-      q.k_lo = max(0, s15 - d16); q.k_hi = min(16, s15 + slen - d16);     // valid bytes
-      q.colA = scol - s15 + d16;                                          // column of byte 0 (may be < 0)
+      const int d16 = 16 * (p - pstart[lo]);                              // piece d16 / 16 of the segment
+      const long long A = soff + d16;                                     // byte address of the piece
+      q.k_lo = 0; q.k_hi = min(16, slen - d16);                           // valid bytes
+      q.colA = scol + d16;                                                // column of byte 0
       if (A + 16 <= b.n_bases) q.v = *reinterpret_cast<const uint4*>(b.bases + A);
       else {  // last partial 16 bytes of the whole base array
         uint32_t t[4] = {0, 0, 0, 0};
@@ -342,7 +330,7 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
       // comes from two table words in the same layout.
       auto nzf = [](uint32_t x) -> uint32_t { return (x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u; };
       uint32_t mm = (nzf(x0) >> 7) | (nzf(x1) >> 6) | (nzf(x2) >> 5) | (nzf(x3) >> 4);
-      mm &= vge[q.k_lo] & vlt[q.k_hi];
+      mm &= vlt[q.k_hi];
       if (K1_ABL == 5) mm = 0;
       uint32_t* dp = pl + (q.strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
       uint32_t* mp = pl + (q.strand ? P_MM_R : P_MM_F) * TSTRIDE;
@@ -434,113 +422,172 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
   }
 }
 
+// Record-free tiles (uncovered, or inside introns only): every plane is 0 except the intron plane, which is the number of
+// introns that cover the whole tile.  Three quarters of the tiles of a spliced data set and 75 % of the stage's HBM writes
+// are like this: a pure store stream, written by small workgroups without LDS (inside k1_pileup's 512-thread, 52 KB
+// workgroups -- three per CU -- the same stores ran at 3.7 TB/s; hipMemset reaches 6.8 on this part).
+// One workgroup of 128 threads per tile: 16-byte stores, 4 consecutive columns per thread and plane.
+__global__ void __launch_bounds__(128) k1_empty_tiles(BatchView b, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0,
+                                                       int64_t n_cols, const int32_t* __restrict__ tile_nbase, uint32_t* __restrict__ planes,
+                                                       const int32_t* __restrict__ order, const int32_t* __restrict__ n_full) {
+  const int nf = *n_full;
+  if ((int)blockIdx.x + nf >= (int)gridDim.x) return;
+  if (*b.error_flag != 0) return;
+  const int tile = order[nf + blockIdx.x];
+  const int g = tile_region[tile], tc0 = tile_col0[tile];
+  const int tlen = min(LCR_TILE, b.len[g] - tc0);
+  const int64_t gcol0 = b.col_off[g] + tc0;
+  const uint32_t nb = (uint32_t)tile_nbase[tile];
+  for (int col = (int)threadIdx.x * 4; col < tlen; col += 128 * 4) {
+    const int64_t o = gcol0 + col;
+    if (col + 4 <= tlen) {
+#pragma unroll
+      for (int k = 0; k < LCR_NPLANES; k++)
+        *reinterpret_cast<uint4*>(planes + (int64_t)k * n_cols + o) = k == LCR_PL_N ? make_uint4(nb, nb, nb, nb) : make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      for (int c2 = col; c2 < tlen; c2++) {
+#pragma unroll
+        for (int k = 0; k < LCR_NPLANES; k++) planes[(int64_t)k * n_cols + gcol0 + c2] = k == LCR_PL_N ? nb : 0u;
+      }
+    }
+  }
+}
+
 // Workgroups are started in grid order and a tile's time goes with its records (none: a few us; 15 000: ~150 us), so K1
-// takes its tiles through a permutation that puts the fullest first: one workgroup sorts the tile indices by
-// floor(log2(records + 1)), descending, with LDS counters (the order inside a class is whatever the atomics give -- every
-// tile writes only its own columns, so the planes do not depend on it).
-// The same workgroup turns K0's tile-level intron difference array into tile_nbase[t] = introns that cover tile t
-// entirely: a plain inclusive scan -- an intron adds +1 at the tile after its first and -1 at its last, both inside
-// its region, so every region's entries sum to zero and no segment handling is needed.
-__global__ void __launch_bounds__(1024) k1_tile_order(const int32_t* __restrict__ tile_fill, int32_t n_tiles, int32_t* __restrict__ order,
-                                                       const int32_t* __restrict__ tile_ndiff, int32_t* __restrict__ tile_nbase,
-                                                       const int32_t* __restrict__ tile_nchunks, int32_t* __restrict__ chunk_off,
-                                                       const unsigned int* __restrict__ acct, int32_t n_acct, unsigned int* __restrict__ ctl) {
-  // per-wave counters (one counter per class for the whole workgroup serialised 15 000 LDS atomics on the class of the
-  // record-free tiles: 22 us); the record-free tiles -- three quarters of them -- are ranked with ballots instead
-  __shared__ int cnt[16][32], n_empty[16], ecur[16];
-  __shared__ int nb_ws[16], nc_ws[16];
+// takes its tiles through a permutation that puts the fullest first: a counting sort of the tile indices by
+// floor(log2(records)), descending (the order inside a class is whatever the cursors give -- every tile writes only its
+// own columns, so the planes do not depend on it).  The same two passes produce tile_nbase[t] = introns that cover tile t
+// entirely (inclusive scan of K0's tile-level difference array: an intron adds +1 at the tile after its first and -1 at its
+// last, both inside its region, so every region's entries sum to zero and no segment handling is needed), ent_off = the
+// tiles' offsets in the entry list (exclusive scan of their entry counts), and K0's accounting totals.
+// Two multi-block kernels (a single workgroup spent 60 us on load latency): pass A = class histogram + block sums,
+// pass B = offsets + scatter.  Class 32 = record-free tiles (three quarters of them), ranked by ballots.
+#define TS_TILES 1024   // tiles per workgroup (256 threads x 4)
+struct TileScanTmp {    // scratch in HBM, cleared with K0's counters
+  int cls_cnt[40];      // tiles per class
+  int cls_cur[40];      // scatter cursors
+  int n_full, pad_[7];  // tiles with records (pass B, for K1's two kernels)
+};
+__device__ __forceinline__ int tile_class(int fill) { return fill > 0 ? __clz(fill) : 32; }   // more records, lower class
+
+__global__ void __launch_bounds__(256) k1_tiles_a(const int32_t* __restrict__ tile_fill, const int32_t* __restrict__ tile_ndiff,
+                                                   const int32_t* __restrict__ tile_nent, int32_t n_tiles, TileScanTmp* __restrict__ tmp,
+                                                   int2* __restrict__ blk_sum, const unsigned int* __restrict__ acct, int32_t n_acct,
+                                                   unsigned int* __restrict__ ctl) {
+  __shared__ int hist[33], ws[4][2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  if (w == 0) {   // K0's accounting slots -> control block ([1] items, [2] records), fetched by the host behind this kernel
+  if (blockIdx.x == 0 && w == 0) {   // K0's accounting slots -> control block, fetched by the host behind this kernel
     int it = 0, rc = 0, pt = 0, dt = 0;   // items, records; fullest pool / descriptor shard
     for (int i = lane; i < n_acct; i += 64) { it += (int)acct[32 * i]; rc += (int)acct[32 * i + 1]; pt = max(pt, (int)acct[32 * i + 2]); dt = max(dt, (int)acct[32 * i + 3]); }
     it = wave_incl_scan(it); rc = wave_incl_scan(rc);
     for (int o = 32; o > 0; o >>= 1) { pt = max(pt, __shfl_xor(pt, o, 64)); dt = max(dt, __shfl_xor(dt, o, 64)); }
     if (lane == 63) { ctl[0] = (unsigned int)pt; ctl[1] = (unsigned int)it; ctl[2] = (unsigned int)rc; ctl[4] = (unsigned int)dt; }
   }
-  {   // tile_nbase: inclusive scan of tile_ndiff; chunk_off: exclusive scan of tile_nchunks ([n_tiles] = all chunks) -- a run
-      // of consecutive tiles per thread, its values loaded eight at a time before they are summed (one workgroup: or
-      // it is all load latency)
-    const int per = (n_tiles + 1023) / 1024, t0 = min(tid * per, n_tiles), t1 = min(t0 + per, n_tiles);
-    int sum_d = 0, sum_c = 0;
-    const int tl = max(n_tiles - 1, 0);   // (loads are unconditional with a clamped index: eight of each array in flight)
-    for (int t = t0; t < t1; t += 8) {
-      int vd[8], vc[8];
+  if (tid < 33) hist[tid] = 0;
+  __syncthreads();
+  const int t0 = blockIdx.x * TS_TILES + tid * 4;
+  int sd = 0, sc = 0, n_empty = 0;
 #pragma unroll
-      for (int x = 0; x < 8; x++) { vd[x] = tile_ndiff[min(t + x, tl)]; vc[x] = tile_nchunks[min(t + x, tl)]; }
-#pragma unroll
-      for (int x = 0; x < 8; x++) if (t + x < t1) { sum_d += vd[x]; sum_c += vc[x]; }
+  for (int x = 0; x < 4; x++) {
+    const int t = t0 + x;
+    if (t < n_tiles) {
+      sd += tile_ndiff[t]; sc += tile_nent[t];
+      const int c = tile_class(tile_fill[t]);
+      if (c == 32) n_empty++; else atomicAdd(&hist[c], 1);
     }
-    const int incl_d = wave_incl_scan(sum_d), incl_c = wave_incl_scan(sum_c);
-    if (lane == 63) { nb_ws[w] = incl_d; nc_ws[w] = incl_c; }
-    __syncthreads();
-    int run_d = incl_d - sum_d, run_c = incl_c - sum_c;
-    for (int i = 0; i < w; i++) { run_d += nb_ws[i]; run_c += nc_ws[i]; }
-    for (int t = t0; t < t1; t += 8) {
-      int vd[8], vc[8];
-#pragma unroll
-      for (int x = 0; x < 8; x++) { vd[x] = tile_ndiff[min(t + x, tl)]; vc[x] = tile_nchunks[min(t + x, tl)]; }
-#pragma unroll
-      for (int x = 0; x < 8; x++)
-        if (t + x < t1) { run_d += vd[x]; tile_nbase[t + x] = run_d; chunk_off[t + x] = run_c; run_c += vc[x]; }
-    }
-    if (tid == 1023) chunk_off[n_tiles] = run_c;
   }
-  for (int i = tid; i < 16 * 32; i += 1024) (&cnt[0][0])[i] = 0;
+  sd = wave_incl_scan(sd); sc = wave_incl_scan(sc); n_empty = wave_incl_scan(n_empty);
+  if (lane == 63) { ws[w][0] = sd; ws[w][1] = sc; atomicAdd(&hist[32], n_empty); }
   __syncthreads();
-  int my_empty = 0;
-  for (int t = tid; t < n_tiles; t += 8 * 1024) {   // (one workgroup: eight loads in flight per thread, or it is all latency)
-    int f[8];
-#pragma unroll
-    for (int x = 0; x < 8; x++) f[x] = t + x * 1024 < n_tiles ? tile_fill[t + x * 1024] : -1;
-#pragma unroll
-    for (int x = 0; x < 8; x++)
-      if (f[x] == 0) my_empty++; else if (f[x] > 0) atomicAdd(&cnt[w][__clz(f[x])], 1);   // class = leading zeros: more records, lower class
-  }
-  my_empty = wave_incl_scan(my_empty);
-  if (lane == 63) n_empty[w] = my_empty;
+  if (tid == 0) blk_sum[blockIdx.x] = make_int2(ws[0][0] + ws[1][0] + ws[2][0] + ws[3][0], ws[0][1] + ws[1][1] + ws[2][1] + ws[3][1]);
+  if (tid < 33 && hist[tid]) atomicAdd(&tmp->cls_cnt[tid], hist[tid]);
+}
+
+__global__ void __launch_bounds__(256) k1_tiles_b(const int32_t* __restrict__ tile_fill, const int32_t* __restrict__ tile_ndiff,
+                                                   const int32_t* __restrict__ tile_nent, int32_t n_tiles, TileScanTmp* __restrict__ tmp,
+                                                   const int2* __restrict__ blk_sum, int32_t* __restrict__ tile_nbase, int32_t* __restrict__ ent_off,
+                                                   int32_t* __restrict__ order) {
+  __shared__ int hist[33], base[33], ws[4][2], pre[2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid < 33) hist[tid] = 0;
+  // sums of the blocks in front of this one
+  int pd = 0, pc = 0;
+  for (int i = tid; i < (int)blockIdx.x; i += 256) { const int2 v = blk_sum[i]; pd += v.x; pc += v.y; }
+  pd = wave_incl_scan(pd); pc = wave_incl_scan(pc);
+  if (lane == 63) { ws[w][0] = pd; ws[w][1] = pc; }
   __syncthreads();
-  if (tid < 32) {   // thread k: class k's base = everything in lower classes; then its per-wave cursors
-    int base = 0;
-    for (int k = 0; k < tid; k++) for (int v = 0; v < 16; v++) base += cnt[v][k];
-    for (int v = 0; v < 16; v++) { const int c = cnt[v][tid]; cnt[v][tid] = base; base += c; }
-  }
-  if (tid == 32) {   // record-free tiles go behind all the others
-    int tot = 0;
-    for (int v = 0; v < 16; v++) tot += n_empty[v];
-    int base = n_tiles - tot;
-    for (int v = 0; v < 16; v++) { ecur[v] = base; base += n_empty[v]; }
-  }
+  if (tid == 0) { pre[0] = ws[0][0] + ws[1][0] + ws[2][0] + ws[3][0]; pre[1] = ws[0][1] + ws[1][1] + ws[2][1] + ws[3][1]; }
   __syncthreads();
-  int e_at = ecur[w];
-  for (int t0 = w * 64; t0 < n_tiles; t0 += 8 * 1024) {   // (wave-uniform trip count: the ballots need every lane)
-    int f[8];
+  const int t0 = blockIdx.x * TS_TILES + tid * 4;
+  int vd[4], vc[4], cls[4], sd = 0, sc = 0;
 #pragma unroll
-    for (int x = 0; x < 8; x++) { const int t = t0 + x * 1024 + lane; f[x] = t < n_tiles ? tile_fill[t] : -1; }
+  for (int x = 0; x < 4; x++) {
+    const int t = t0 + x;
+    vd[x] = t < n_tiles ? tile_ndiff[t] : 0; vc[x] = t < n_tiles ? tile_nent[t] : 0;
+    cls[x] = t < n_tiles ? tile_class(tile_fill[t]) : -1;
+    sd += vd[x]; sc += vc[x];
+    if (cls[x] >= 0 && cls[x] < 32) atomicAdd(&hist[cls[x]], 1);
+  }
+  const int id = wave_incl_scan(sd), ic = wave_incl_scan(sc);
+  __syncthreads();   // (pre[] was read by everyone? no: ws is rewritten below, pre is not) -- ws reuse
+  if (lane == 63) { ws[w][0] = id; ws[w][1] = ic; }
+  // record-free tiles of this block, ranked by ballots: per-wave counts first
+  int my_e = 0;
 #pragma unroll
-    for (int x = 0; x < 8; x++) {
-      const int t = t0 + x * 1024 + lane;
-      const unsigned long long m = __ballot(f[x] == 0);
-      if (f[x] == 0) order[e_at + __popcll(m & below)] = t;
-      else if (f[x] > 0) order[atomicAdd(&cnt[w][__clz(f[x])], 1)] = t;
-      e_at += __popcll(m);
+  for (int x = 0; x < 4; x++) my_e += cls[x] == 32 ? 1 : 0;
+  const int ie = wave_incl_scan(my_e);
+  __shared__ int we[4];
+  if (lane == 63) we[w] = ie;
+  __syncthreads();
+  if (tid == 0) hist[32] = we[0] + we[1] + we[2] + we[3];
+  __syncthreads();
+  // this block's span in every class: class bases (exclusive scan of the class counts, class 0 first) + a cursor draw
+  if (tid < 33 && hist[tid]) {
+    int b0 = 0;
+    for (int k = 0; k < tid; k++) b0 += tmp->cls_cnt[k];
+    base[tid] = b0 + atomicAdd(&tmp->cls_cur[tid], hist[tid]);
+  }
+  int run_d = pre[0] + id - sd, run_c = pre[1] + ic - sc;
+  for (int i = 0; i < w; i++) { run_d += ws[i][0]; run_c += ws[i][1]; }
+  int e_before = ie - my_e;
+  for (int i = 0; i < w; i++) e_before += we[i];
+  if (tid < 33) hist[tid] = 0;   // (reused as the block's cursors; the bases are in base[])
+  __syncthreads();
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    const int t = t0 + x;
+    if (t < n_tiles) {
+      run_d += vd[x]; tile_nbase[t] = run_d;
+      ent_off[t] = run_c; run_c += vc[x];
+      if (cls[x] == 32) order[base[32] + e_before++] = t;
+      else order[base[cls[x]] + atomicAdd(&hist[cls[x]], 1)] = t;
+      if (t == n_tiles - 1) { ent_off[n_tiles] = run_c; tmp->n_full = n_tiles - tmp->cls_cnt[32]; }
     }
   }
 }
 
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const int32_t* tile_fill, const int32_t* ent_off, const void* ents,
-                      const unsigned long long* recs, const int32_t* tile_nbase, uint32_t* planes, const int32_t* order /* launch_k1_tile_order */,
-                      hipStream_t s) {
+                      const unsigned long long* recs, const int32_t* tile_nbase, uint32_t* planes, const int32_t* order /* launch_k1_tiles_b */,
+                      const int32_t* tiles_tmp, hipStream_t s) {
   if (n_tiles == 0) return;
   hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_fill, ent_off,
-                     (const uint2*)ents, recs, tile_nbase, planes, order);
+                     (const uint2*)ents, recs, tile_nbase, planes, order, tiles_tmp + 80 /* TileScanTmp::n_full */);
+  hipLaunchKernelGGL(k1_empty_tiles, dim3(n_tiles), dim3(128), 0, s, b, tile_region, tile_col0, n_cols, tile_nbase, planes, order, tiles_tmp + 80);
 }
 // the tile-order / intron-base / accounting pass alone (the host fetches K0's control block behind it, before K1 is queued)
-void launch_k1_tile_order(int32_t n_tiles, const int32_t* tile_fill, const int32_t* tile_ndiff, int32_t* tile_nbase, const int32_t* tile_nchunks,
-                          int32_t* chunk_off, const unsigned int* acct, int32_t n_acct, unsigned int* ctl, int32_t* order, hipStream_t s) {
-  hipLaunchKernelGGL(k1_tile_order, dim3(1), dim3(1024), 0, s, tile_fill, n_tiles, order, tile_ndiff, tile_nbase, tile_nchunks, chunk_off, acct,
-                     n_acct, ctl);
+// the tile passes alone (the host fetches K0's control block behind pass A, before the rest is queued)
+size_t launch_k1_tiles_tmp_words(int32_t n_tiles) { return 88 + 2 * (size_t)((n_tiles + TS_TILES - 1) / TS_TILES) + 8; }
+void launch_k1_tiles_a(int32_t n_tiles, const int32_t* tile_fill, const int32_t* tile_ndiff, const int32_t* tile_nent, int32_t* tmp /* zeroed */,
+                       const unsigned int* acct, int32_t n_acct, unsigned int* ctl, hipStream_t s) {
+  const int nb = (n_tiles + TS_TILES - 1) / TS_TILES;
+  hipLaunchKernelGGL(k1_tiles_a, dim3(nb), dim3(256), 0, s, tile_fill, tile_ndiff, tile_nent, n_tiles, (TileScanTmp*)tmp, (int2*)(tmp + 88), acct, n_acct, ctl);
+}
+void launch_k1_tiles_b(int32_t n_tiles, const int32_t* tile_fill, const int32_t* tile_ndiff, const int32_t* tile_nent, int32_t* tmp,
+                       int32_t* tile_nbase, int32_t* ent_off, int32_t* order, hipStream_t s) {
+  const int nb = (n_tiles + TS_TILES - 1) / TS_TILES;
+  hipLaunchKernelGGL(k1_tiles_b, dim3(nb), dim3(256), 0, s, tile_fill, tile_ndiff, tile_nent, n_tiles, (TileScanTmp*)tmp, (const int2*)(tmp + 88),
+                     tile_nbase, ent_off, order);
 }
 
 // ---------------------------------------------------------------------------------------------

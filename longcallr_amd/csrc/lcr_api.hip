@@ -352,7 +352,8 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   // one cleared buffer: tile fill counters [0, nt) | control block at nt + 1 (pool top, items, records, error flag, descriptor
   // top) | tile-level intron difference array | chunks per tile | bin cursors | K0's accounting slots
   const size_t o_ndiff = (size_t)nt + 16, o_nch = o_ndiff + nt + 8, o_cur = o_nch + nt + 8, o_acct = o_cur + nt + 8;
-  const size_t fill_words = o_acct + launch_k0_acct_words();
+  const size_t o_tmp = o_acct + launch_k0_acct_words();   // scratch of the tile passes (class counts, cursors, block sums)
+  const size_t fill_words = o_tmp + launch_k1_tiles_tmp_words(nt);
   HIPCHK(c, c->k0_tile_fill.reserve(fill_words * 4));
   int32_t* const fill = c->k0_tile_fill.as<int32_t>();
   b.error_flag = fill + nt + 4;
@@ -383,11 +384,12 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
     int32_t* const ctl = c->h_stage[0].as<int32_t>();
     if (!c->ev_ctl) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ctl, hipEventDisableTiming));
     { Timer t(c, LCR_K_PILEUP);   // (the tally kernel with its ordering and chunk-binning passes)
-      if (nt > 0) launch_k1_tile_order(nt, fill, fill + o_ndiff, c->tile_nbase.as<int32_t>(), fill + o_nch, c->chunk_off.as<int32_t>(),
-                                       (unsigned int*)(fill + o_acct), launch_k0_acct_slots(), (unsigned int*)(fill + nt + 1),
-                                       c->tile_order.as<int32_t>(), c->stream);
+      if (nt > 0) launch_k1_tiles_a(nt, fill, fill + o_ndiff, fill + o_nch, fill + o_tmp, (unsigned int*)(fill + o_acct), launch_k0_acct_slots(),
+                                    (unsigned int*)(fill + nt + 1), c->stream);
       HIPCHK(c, hipMemcpyAsync(ctl, fill + nt + 1, 32, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipEventRecord(c->ev_ctl, c->stream));
+      if (nt > 0) launch_k1_tiles_b(nt, fill, fill + o_ndiff, fill + o_nch, fill + o_tmp, c->tile_nbase.as<int32_t>(), c->chunk_off.as<int32_t>(),
+                                    c->tile_order.as<int32_t>(), c->stream);
       if (nt > 0 && c->n_ops > 0)
         launch_k0_desc_bin(fill + nt + 1, (const unsigned int*)(fill + o_acct), desc_sub, c->desc_tile.as<uint32_t>(), c->desc_val.p, c->chunk_off.as<int32_t>(), fill + o_cur,
                            c->chunks.p, n_blocks / 8 + 1, c->stream);
@@ -395,7 +397,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
       // mask of the HiFi presets
       launch_k1_pileup(b, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols, fill, c->chunk_off.as<int32_t>(),
                        c->chunks.p, c->k0_items.as<unsigned long long>(), c->tile_nbase.as<int32_t>(), c->planes.as<uint32_t>(),
-                       c->tile_order.as<int32_t>(), c->stream);
+                       c->tile_order.as<int32_t>(), fill + o_tmp, c->stream);
       if (!c->dp.ont && c->dp.dist_to_end > 0)
         launch_k1_zonefix(b, c->read_bin.as<ReadBin>(), c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->stream); }
     HIPCHK(c, hipGetLastError());

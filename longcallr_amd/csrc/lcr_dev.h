@@ -9,7 +9,9 @@
 
 #include "../../include/lcr.h"
 
-#define LCR_TILE 512       // pileup columns per workgroup tile
+#ifndef LCR_TILE
+#define LCR_TILE 256       // pileup columns per workgroup tile (512: K1 0.385 instead of 0.334 ms on C3, K0 0.23 = 0.24)
+#endif
 #define LCR_BLOCK 256      // threads per workgroup (4 wave64)
 #define LCR_WAVE 64
 
@@ -146,11 +148,15 @@ int launch_k0_acct_slots();
 void launch_k0_desc_bin(const void* ctl, const unsigned int* acct, unsigned int desc_sub, const uint32_t* desc_tile, const void* desc_val,
                         const int32_t* chunk_off, int32_t* cursor /* n_tiles zeroed ints */, void* sorted /* uint2, all shards */, int32_t n_blocks_hint,
                         hipStream_t s);
-void launch_k1_tile_order(int32_t n_tiles, const int32_t* tile_fill, const int32_t* tile_ndiff, int32_t* tile_nbase, const int32_t* tile_nchunks,
-                          int32_t* chunk_off, const unsigned int* acct, int32_t n_acct, unsigned int* ctl, int32_t* order, hipStream_t s);
+size_t launch_k1_tiles_tmp_words(int32_t n_tiles);
+void launch_k1_tiles_a(int32_t n_tiles, const int32_t* tile_fill, const int32_t* tile_ndiff, const int32_t* tile_nent, int32_t* tmp /* zeroed */,
+                       const unsigned int* acct, int32_t n_acct, unsigned int* ctl, hipStream_t s);
+void launch_k1_tiles_b(int32_t n_tiles, const int32_t* tile_fill, const int32_t* tile_ndiff, const int32_t* tile_nent, int32_t* tmp,
+                       int32_t* tile_nbase, int32_t* ent_off, int32_t* order, hipStream_t s);
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const int32_t* tile_fill, const int32_t* chunk_off, const void* chunks,
-                      const unsigned long long* recs, const int32_t* tile_nbase, uint32_t* planes, const int32_t* order, hipStream_t s);
+                      const unsigned long long* recs, const int32_t* tile_nbase, uint32_t* planes, const int32_t* order,
+                      const int32_t* tiles_tmp /* scratch of launch_k1_tiles_a / _b */, hipStream_t s);
 void launch_k1_zonefix(const BatchView& b, const ReadBin* rbin, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s);
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const int32_t* tile_fill, uint8_t* flags,
