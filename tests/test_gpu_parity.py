@@ -201,13 +201,111 @@ def test_hand_derived_phasing_instances(engine_cls, orc):
 
 
 def test_k0_cigar_lengths(engine_cls, orc):
-    """K0 keeps a read's first 64 CIGAR ops in registers and reloads longer CIGARs in groups: HiFi reads
-    (~9 ops), ONT-like reads (~56 ops) and demo.bam (up to 118 ops, two groups) all give the oracle's planes."""
+    """HiFi reads (~9 ops), ONT-like reads (~56 ops) and demo.bam (up to 118 ops) through the op-parallel K0."""
     full_check(engine_cls, orc, helpers.demo_batch(), _abi.make_params("hifi-masseq"), "chr20")
     b = synth.make_batch("ont-cdna", n_genes=3, gene_len=9000, depth=35, seed=12)
     full_check(engine_cls, orc, b, _abi.make_params("ont-cdna", seed=12))
     b = synth.make_batch("masseq", n_genes=3, gene_len=9000, depth=35, seed=12)
     full_check(engine_cls, orc, b, _abi.make_params("hifi-masseq", seed=12))
+
+
+def _with_reads(b, **over):
+    kw = {f: getattr(b, f) for f in _abi.ReadBatch.FIELDS + ["start0", "len", "read_begin", "ref"]}
+    kw.update(over)
+    return _abi.ReadBatch(**kw)
+
+
+def test_k0_op_space_layouts(engine_cls, orc):
+    """The op-parallel K0 (k0_ops.hip) cuts ONE flat op space into blocks of 1 024 ops.  (i) CIGARs that do not lie back to
+    back (the ABI allows any cig_off: here reversed order with gaps) are copied into a contiguous array at load time;
+    (ii) host and device batches take different paths to the op-space geometry -- same planes, candidates, phasing."""
+    b = synth.make_batch("ont-cdna", n_genes=3, gene_len=9000, depth=30, seed=41)
+    p = _abi.make_params("ont-cdna", seed=41)
+    n = b.n_cig.astype(np.int64)
+    new_off = np.zeros(b.n_reads, dtype=np.int64)
+    cur = 7
+    for r in range(b.n_reads - 1, -1, -1):   # reads laid out back to front, 3 unused words between them
+        new_off[r] = cur
+        cur += int(n[r]) + 3
+    cig = np.full(cur + 5, 0xFFFFFFF6, dtype=np.uint32)   # (filler: an undefined op code -- must never be decoded)
+    for r in range(b.n_reads):
+        cig[new_off[r]:new_off[r] + n[r]] = b.cigar[int(b.cig_off[r]):int(b.cig_off[r]) + int(n[r])]
+    full_check(engine_cls, orc, _with_reads(b, cig_off=new_off.astype(np.uint64), cigar=cig), p)
+
+
+def test_k0_block_borders_and_empty_reads(engine_cls, orc):
+    """Reads whose ops straddle K0's op blocks (one read of ~2 600 ops spans three blocks: the carry-in of its earlier
+    blocks), reads WITHOUT any op (first, in the middle, last; reference end = start, l_seq must be 0), a block with more
+    reads than its LDS header table holds (hundreds of one-op reads), and a batch without a single op."""
+    rng = np.random.default_rng(5)
+    L = 6000
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    reads = []
+    # one long read: 1M 1I 1M 1D ... over ~1 300 columns -> ~2 600 ops
+    ops, seq, col = [], [], 100
+    for i in range(650):
+        ops += ["2M", "1I", "1M", "1D"]
+        seq += [ref[col:col + 2], "A", ref[col + 2]]
+        col += 4
+    reads.append(dict(pos=100, seq="".join(seq), qual=20, cigar="".join(ops), ts=1))
+    # 700 reads of one op each (a K0 block then holds > 160 reads), then ordinary reads
+    for i in range(700):
+        s = 200 + i
+        reads.append(dict(pos=s, seq=ref[s:s + 60], qual=25, cigar="60M", rev=i % 2, ts=1 + i % 2))
+    for i in range(60):
+        s = 1000 + 20 * i
+        sq = list(ref[s:s + 300])
+        if i % 2:
+            sq[150] = "A" if ref[s + 150] != "A" else "C"
+        reads.append(dict(pos=s, seq="".join(sq), qual=30, cigar="100M1D200M" if i % 3 else "300M", rev=i % 2, ts=1))
+    reads.sort(key=lambda r: r["pos"])
+    b = helpers.mk_batch(reads, [(0, ref)])
+    p = _abi.make_params("ont-cdna", seed=3, min_depth=2)
+    full_check(engine_cls, orc, b, p)
+    # reads without ops: index 0, one in the middle, the last one
+    nr = b.n_reads
+    ins = [0, nr // 2, nr]
+    def insert(a, vals):
+        return np.insert(a, ins, vals)
+    pos = insert(b.pos, [b.pos[0], b.pos[nr // 2], b.pos[-1]])
+    b2 = _with_reads(b, pos=pos, seq_len=insert(b.seq_len, 0), lead_clip=insert(b.lead_clip, 0), trail_clip=insert(b.trail_clip, 0),
+                     flags=insert(b.flags, 0), seq_off=insert(b.seq_off, [0, b.seq_off[nr // 2], b.bases.size]),
+                     cig_off=insert(b.cig_off, [0, b.cig_off[nr // 2], b.cigar.size]), n_cig=insert(b.n_cig, 0),
+                     read_begin=[0, nr + 3])
+    c2 = full_check(engine_cls, orc, b2, p)
+    E = engine_cls(0, p)
+    E.load_batch(b).run_all()
+    assert E.candidates()[0].tobytes() == c2.tobytes()   # the empty reads change nothing
+    # a batch of empty reads only: every stage runs, nothing is found; an empty read with l_seq != 0 is a CIGAR error
+    b3 = _abi.ReadBatch(pos=[10, 20], seq_len=[0, 0], lead_clip=[0, 0], trail_clip=[0, 0], flags=[0, 0], seq_off=[0, 0], cig_off=[0, 0],
+                        n_cig=[0, 0], bases=np.zeros(0, np.uint8), quals=np.zeros(0, np.uint8), cigar=np.zeros(0, np.uint32),
+                        start0=[0], len=[L], read_begin=[0, 2], ref=np.frombuffer(ref.encode(), np.uint8))
+    E.load_batch(b3).run_all()
+    assert E.candidates()[0].size == 0 and not E.columns().any()
+    from longcallr_amd._lib import LcrError
+    b4 = _with_reads(b3, seq_len=[0, 5], bases=np.full(5, 65, np.uint8), quals=np.full(5, 30, np.uint8))
+    with pytest.raises(LcrError, match="CIGAR inconsistent"):
+        E.load_batch(b4).run_all()
+    E.close()
+
+
+def test_k0_reads_beyond_the_tile_window(engine_cls, orc):
+    """A K0 block keeps the record counters of 256 tiles (65 536 columns from its first read on) in LDS; records beyond --
+    reads with introns of 100 kb and more -- take one pool allocation each.  Same planes / candidates / phasing."""
+    rng = np.random.default_rng(9)
+    L = 260000
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    reads = []
+    for i in range(40):
+        s = 500 + 3 * i
+        a = list(ref[s:s + 400]); c = list(ref[s + 400 + 200000:s + 800 + 200000])
+        if i % 2:
+            a[800 - s] = "G" if ref[800] != "G" else "T"                    # het sites at fixed columns: 800 and 200 950
+            c[200950 - (s + 400 + 200000)] = "G" if ref[200950] != "G" else "T"
+        reads.append(dict(pos=s, seq="".join(a + c), qual=28, cigar="400M200000N400M", rev=(i // 2) % 2, ts=1 + (i // 2) % 2))
+    b = helpers.mk_batch(reads, [(0, ref)])
+    c = full_check(engine_cls, orc, b, _abi.make_params("ont-cdna", seed=2, min_depth=2))
+    assert c.size >= 2
 
 
 @pytest.mark.parametrize("hook", ["LCR_ENUM_FORCE_STREAM", "LCR_ENUM_FORCE_BIG", "LCR_POST_HOST", "LCR_POST_HALF"])
