@@ -3,30 +3,36 @@
 fragment matrix -> phasing) over one synthetic batch already resident in HBM.
 
 Workloads (config.workload):
-  N = 1   BASELINE.json configs[2], "synthetic 10 Mb ONT-cDNA, 40x" (C3: 400 regions x 25 kb) -- the largest configuration
-          whose metric is quoted on one GPU; demo.bam (configs[0]/[1]) is ~5 MB of traffic and a parity fixture, not a
-          bench line.  The C5 stress (configs[4], ONE 1 Mb island at 500x) is run once beside it and reported in
-          `stages.c5`, and the default workload once more with three batches in flight as `stages.batches_in_flight`
-          (--no-c5 skips both).
+  N = 1   BASELINE.json configs[2], "synthetic 10 Mb ONT-cDNA, 40x" (C3: 400 distinct genes x 25 kb) -- the
+          largest configuration whose metric is quoted on one GPU; demo.bam (configs[0]/[1]) is ~5 MB of traffic and a
+          parity fixture.  Beside it, in `stages` (--quick / --no-extras skip them): the same step with three batches in
+          flight, generator seeds 2..5, one GPU's share of C4 (the workload N > 1 runs), the C5 stress (configs[4], ONE
+          1 Mb island at 500x), demo.bam from the file, and C3 end to end from a BAM file -- each with the CPU oracle timed
+          beside it.
   N > 1   BASELINE.json configs[3], "synthetic 200 Mb PacBio MAS-Seq, 60x, region-sharded across 8 GPUs" scaled to
-          N GPUs: ONE list of N x 1 000 regions (25 Mb x 60x per GPU), partitioned over the ranks by
+          N GPUs: ONE list of N x 1 000 distinct genes (25 Mb x 60x per GPU), partitioned over the ranks by
           shard.assign_regions (longest-processing-time on len x max_coverage, the reference's unit of sharding is the
-          region, thread.rs:77); a rank materialises and processes only its own regions.  Weak scaling.
+          region, thread.rs:77); a rank builds and processes only its own regions.  Weak scaling.
 `python bench.py --gpus N` starts the N ranks itself (re-exec under torch.distributed.run) when it is not already
-running under a launcher.  Regions never span ranks, the only collective is the final gather of candidate records to
-rank 0 (RCCL), overlapped with the next batch's kernels.
+running under a launcher.  Regions never span ranks, the only collective is the final gather of the two record types
+(candidate records, read -> HP / PS records; thread.rs:204-221) to rank 0 over RCCL, overlapped with the next batch's
+kernels.
 
 Prints ONE JSON line on rank 0 (see the driver contract): value = candidate sites (pileup columns evaluated) per
 second, whole job, over the full step time; roofline = the pileup stage's algorithmic bytes / its HIP-event time
-(k1_pileup alone beside it); cpu_baseline = the CPU oracle (a C++ restatement of the reference, NOT the Rust binary)
-timed on a bounded sample of the same workload, rank 0 at N = 1 only.
+(k1 alone beside it), roofline.traffic = HBM bytes of the stage's kernels from two rocprofv3 --pmc passes run by this
+script over the same batch; cpu_baseline = the CPU oracle (a C++ restatement of the reference, NOT the Rust binary) on a
+native thread pool over the same batch, rank 0 at N = 1 only.
 --inflight N: N contexts on N host threads keep N batches in flight per GPU (default 1).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -34,25 +40,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-
-def tile_batch(base, copies, gap=1000):
-    """Replicate a ReadBatch `copies` times at shifted coordinates (synthetic-data generation speed)."""
-    from longcallr_amd import _abi
-    if copies == 1:
-        return base
-    span = int(base.start0[-1] + base.len[-1] - base.start0[0]) + gap
-    rep = lambda a: np.concatenate([a] * copies)
-    shift_r = np.repeat(np.arange(copies, dtype=np.int64) * span, base.n_reads)
-    shift_g = np.repeat(np.arange(copies, dtype=np.int64) * span, base.n_regions)
-    nb, nc = int(base.bases.size), int(base.cigar.size)
-    rb = np.concatenate([base.read_begin[:-1] + k * base.n_reads for k in range(copies)] + [[copies * base.n_reads]])
-    return _abi.ReadBatch(
-        pos=(rep(base.pos).astype(np.int64) + shift_r), seq_len=rep(base.seq_len), lead_clip=rep(base.lead_clip),
-        trail_clip=rep(base.trail_clip), flags=rep(base.flags),
-        seq_off=rep(base.seq_off) + np.repeat(np.arange(copies, dtype=np.uint64) * np.uint64(nb), base.n_reads),
-        cig_off=rep(base.cig_off) + np.repeat(np.arange(copies, dtype=np.uint64) * np.uint64(nc), base.n_reads),
-        n_cig=rep(base.n_cig), bases=rep(base.bases), quals=rep(base.quals), cigar=rep(base.cigar),
-        start0=rep(base.start0) + shift_g, len=rep(base.len), read_begin=rb, ref=rep(base.ref))
+WORKLOADS = {   # name -> (profile, regions per GPU, gene_len, depth, BASELINE config it stands for)
+    "c3": ("ont-cdna", 400, 25000, 40.0, "C3 = BASELINE configs[2]: synthetic 10 Mb ONT-cDNA, 40x"),
+    "c4": ("masseq", 1000, 25000, 60.0, "C4 = BASELINE configs[3]: synthetic 200 Mb PacBio MAS-Seq, 60x, region-sharded (25 Mb per GPU)"),
+}
+PILEUP_KERNELS = ("k0_ops", "k1_tiles_a", "k1_tiles_b", "k0_desc_bin", "k1_pileup", "k1_empty_tiles", "k1_zonefix")
 
 
 def region_max_coverage(b):
@@ -69,45 +61,6 @@ def region_max_coverage(b):
         np.add.at(d, s, 1); np.add.at(d, e, -1)
         out[g] = int(np.cumsum(d).max()) if r1 > r0 else 0
     return out
-
-
-def subset_batch(base, ids, gap=1000):
-    """The regions `ids` (ascending) of the global list whose region k is unique region k % U of `base` at copy k // U
-    (copies lie `span` apart): a rank's shard, built without materialising the other ranks' regions."""
-    from longcallr_amd import _abi
-    U = base.n_regions
-    span = int(base.start0[-1] + base.len[-1] - base.start0[0]) + gap
-    parts = {k: [] for k in ("pos", "seq_len", "lead_clip", "trail_clip", "flags", "n_cig", "bases", "quals", "cigar", "ref")}
-    start0, length, read_begin = [], [], [0]
-    base_off, cig_off = base.seq_off.astype(np.int64), base.cig_off.astype(np.int64)
-    for k in ids:
-        u, c = int(k) % U, int(k) // U
-        r0, r1 = int(base.read_begin[u]), int(base.read_begin[u + 1])
-        b0 = int(base_off[r0]) if r1 > r0 else 0
-        b1 = int(base_off[r1 - 1] + base.seq_len[r1 - 1]) if r1 > r0 else 0
-        c0 = int(cig_off[r0]) if r1 > r0 else 0
-        c1 = int(cig_off[r1 - 1] + base.n_cig[r1 - 1]) if r1 > r0 else 0
-        parts["pos"].append(base.pos[r0:r1].astype(np.int64) + c * span)
-        for f in ("seq_len", "lead_clip", "trail_clip", "flags", "n_cig"):
-            parts[f].append(getattr(base, f)[r0:r1])
-        parts["bases"].append(base.bases[b0:b1]); parts["quals"].append(base.quals[b0:b1]); parts["cigar"].append(base.cigar[c0:c1])
-        o = int(base.col_off[u])
-        parts["ref"].append(base.ref[o:o + int(base.len[u])])
-        start0.append(int(base.start0[u]) + c * span); length.append(int(base.len[u]))
-        read_begin.append(read_begin[-1] + (r1 - r0))
-    cat = lambda f, dt: np.concatenate(parts[f]).astype(dt) if parts[f] else np.zeros(0, dt)
-    seq_len, n_cig = cat("seq_len", np.int64), cat("n_cig", np.int64)
-    return _abi.ReadBatch(pos=cat("pos", np.int64), seq_len=seq_len, lead_clip=cat("lead_clip", np.int32),
-                          trail_clip=cat("trail_clip", np.int32), flags=cat("flags", np.uint8),
-                          seq_off=(np.cumsum(seq_len) - seq_len).astype(np.uint64), cig_off=(np.cumsum(n_cig) - n_cig).astype(np.uint64),
-                          n_cig=n_cig, bases=cat("bases", np.uint8), quals=cat("quals", np.uint8), cigar=cat("cigar", np.uint32),
-                          start0=start0, len=length, read_begin=read_begin, ref=cat("ref", np.uint8))
-
-
-WORKLOADS = {   # name -> (profile, regions per GPU, gene_len, depth, BASELINE config it stands for)
-    "c3": ("ont-cdna", 400, 25000, 40.0, "C3 = BASELINE configs[2]: synthetic 10 Mb ONT-cDNA, 40x"),
-    "c4": ("masseq", 1000, 25000, 60.0, "C4 = BASELINE configs[3]: synthetic 200 Mb PacBio MAS-Seq, 60x, region-sharded (25 Mb per GPU)"),
-}
 
 
 def build_shard(name, world=1, rank=0, seed=1, genes=None, gene_len=None, depth=None, profile=None, workers=0):
@@ -136,58 +89,16 @@ def build_workload(name, seed=1, workers=0):
     return build_shard(name, 1, 0, seed=seed, workers=workers)[0]
 
 
-def batches_in_flight_stage(api, torch, device, params, dev_batch, cols, contexts=3, steps=60):
-    """The same step with several batches in flight on the GPU (one context and one host thread each): the queue gaps of
-    one batch's host round trips are filled by the others' kernels.  Reported beside `value`, never as it: the co-scheduled
-    kernels stretch each other, so the roofline is quoted on the undisturbed single-batch run."""
-    import threading
-    engines = [api.Engine(device, params) for _ in range(contexts)]
-    def run(E, n):
-        torch.cuda.set_device(device)
-        for _ in range(n):
-            E.load_batch(dev_batch)
-            E.fill_data_into_freq_vec().get_candidate_snps().get_fragments().phase()
-        E.sync()
-    for E in engines:
-        run(E, 3)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ths = [threading.Thread(target=run, args=(E, steps // contexts)) for E in engines]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    for E in engines:
-        E.close()
-    n = contexts * (steps // contexts)
-    return {"contexts": contexts, "steps": n, "ms_per_step": dt / n * 1e3, "sites_per_sec": cols * n / dt,
-            "note": "%d contexts on %d host threads share the GPU (bench.py --inflight %d times the whole run this way)" % (contexts, contexts, contexts)}
-
-
-def c5_stage(api, _abi, synth, device):
-    """BASELINE configs[4] once: ONE 1 Mb island at 500x ONT-dRNA, ~4 700 candidate sites; per-call wall times (ms)."""
-    t0 = time.perf_counter()
-    b = synth.make_island("ont-drna-c5", n_loci=40, locus_len=25000, depth=500, seed=5)
-    gen = time.perf_counter() - t0
-    E = api.Engine(device, _abi.make_params("ont-drna", seed=5))
-    ms = {}
-    for rep in range(2):   # the second pass has its buffers
-        for name, fn in (("lcr_load_batch", lambda: E.load_batch(b)), ("lcr_pileup", E.fill_data_into_freq_vec),
-                         ("lcr_candidates", E.get_candidate_snps), ("lcr_fragments", E.get_fragments), ("lcr_phase", E.phase)):
-            ts = time.perf_counter(); fn(); E.sync(); ms[name] = (time.perf_counter() - ts) * 1e3
-    c = E.candidates()[0]
-    fm = E.fragmat()
-    n_phased = int(fm["row_for_phasing"].sum())
-    t_phase = (ms["lcr_fragments"] + ms["lcr_phase"]) * 1e-3
-    out = dict(workload="C5 = BASELINE configs[4]: one island of %d columns, %d reads, %d aligned bases" % (int(b.len[0]), b.n_reads, int(b.bases.size)),
-               generate_s=gen, api_ms=ms, candidates=int(c.size), fragment_nnz=int(fm["col"].size), phasing_reads=n_phased,
-               cross_optimize_calls=1 + 2 * (int(c.size) // 4 + 1), phased_reads_per_sec=n_phased / t_phase,
-               sites_per_sec_full_step=int(b.len[0]) / (sum(ms.values()) * 1e-3),
-               note="phase stage: k4_stage_grid + k4_chain_grid + k4_gpost (all CUs on the one region, no host epilogue)")
-    E.close()
-    return out
+def head_batch(b, n_regions):
+    """The first n_regions regions of a batch (bounded CPU samples)."""
+    from longcallr_amd import _abi
+    g = min(n_regions, b.n_regions)
+    r = int(b.read_begin[g])
+    nb = int(b.seq_off[r - 1] + b.seq_len[r - 1]) if r else 0
+    nc = int(b.cig_off[r - 1] + b.n_cig[r - 1]) if r else 0
+    return _abi.ReadBatch(pos=b.pos[:r], seq_len=b.seq_len[:r], lead_clip=b.lead_clip[:r], trail_clip=b.trail_clip[:r], flags=b.flags[:r],
+                          seq_off=b.seq_off[:r], cig_off=b.cig_off[:r], n_cig=b.n_cig[:r], bases=b.bases[:nb], quals=b.quals[:nb],
+                          cigar=b.cigar[:nc], start0=b.start0[:g], len=b.len[:g], read_begin=b.read_begin[:g + 1], ref=b.ref[:int(b.col_off[g])])
 
 
 def to_device(batch, torch, dev):
@@ -209,53 +120,344 @@ def to_device(batch, torch, dev):
     return reads, regions, t
 
 
-def cpu_baseline(batch, params, budget_s=15.0):
-    """Oracle (kind 'port': C++ restatement of the reference's scalar loops, reference-order f64 arithmetic with libm
-    per observation) region-parallel over the host's cores, the analogue of the reference's rayon par_iter over regions
-    (thread.rs:77): worker threads pull region indices of the same batch for ~budget_s of wall time (ctypes releases
-    the GIL inside the oracle).  A 1-thread figure over the first regions is reported next to it."""
-    from concurrent.futures import ThreadPoolExecutor
-    import itertools
-    import threading
+def run_steps_simple(E, dev_batch, n):
+    for _ in range(n):
+        E.load_batch(dev_batch)
+        E.fill_data_into_freq_vec().get_candidate_snps().get_fragments().phase()
+    E.sync()
+
+
+def time_workload(api, _abi, torch, device, params, batch, steps=20, warm=5):
+    """ms per step, pileup-stage time and roofline fraction, per-call wall times of one more pass: a workload beside the headline one"""
+    dv = to_device(batch, torch, torch.device("cuda", device))
+    E = api.Engine(device, params, timing=True)
+    run_steps_simple(E, dv, warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pile = []
+    for _ in range(steps):
+        E.load_batch(dv)
+        E.fill_data_into_freq_vec().get_candidate_snps().get_fragments().phase()
+        pile.append(E.kernel_ms(_abi.K_SPANS) + E.kernel_ms(_abi.K_PILEUP))
+    E.sync()
+    dt = (time.perf_counter() - t0) / steps
+    ms = {}
+    for name, fn in (("lcr_load_batch", lambda: E.load_batch(dv)), ("lcr_pileup", E.fill_data_into_freq_vec),
+                     ("lcr_candidates", E.get_candidate_snps), ("lcr_fragments", E.get_fragments), ("lcr_phase", E.phase)):
+        ts = time.perf_counter(); fn(); E.sync(); ms[name] = (time.perf_counter() - ts) * 1e3
+    fm = E.fragmat()
+    out = dict(columns=int(batch.col_off[-1]), reads=batch.n_reads, aligned_bases=int(batch.bases.size), ms_per_step=dt * 1e3,
+               sites_per_sec=int(batch.col_off[-1]) / dt, pileup_stage_ms=float(np.mean(pile)),
+               pileup_stage_frac_of_hbm_peak=E.pileup_stage_bytes() / (float(np.mean(pile)) * 1e-3) / 8e12, api_ms=ms,
+               candidates=int(E.candidates()[0].size), phasing_reads=int(fm["row_for_phasing"].sum()), fragment_nnz=int(fm["col"].size))
+    out["phased_reads_per_sec"] = out["phasing_reads"] / ((ms["lcr_fragments"] + ms["lcr_phase"]) * 1e-3)
+    E.close()
+    del dv
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU side: the oracle on a native thread pool (orc_run_batch), decision arithmetic of the reference only (ORC_MODE_F64_ONLY)
+
+def cpu_pool(batch, params, threads=0, upto="post"):
+    from oracle import orc
+    B = orc.Batch(batch, params, mode=orc.MODE_F64_ONLY, threads=threads, upto=upto, keep_planes=False)
+    dt, th = B.seconds, B.threads
+    B.close()
+    return dt, th
+
+
+def cpu_baseline(batch, params, budget_s=20.0):
+    """Oracle (kind 'port': C++ restatement of the reference's scalar loops, reference-order f64 arithmetic with libm per
+    observation, no second arithmetic beside it) region-parallel on a NATIVE thread pool -- the analogue of the reference's
+    rayon par_iter over regions (thread.rs:77) -- over the regions of the same batch; the thread-scaling points beside it
+    run on the first regions of the batch so that everything stays inside ~budget_s of CPU wall time."""
     from oracle import orc
     orc.build()
+    ncpu = os.cpu_count() or 1
+    t_all, th_all = cpu_pool(batch, params, 0)                       # every region once, all hardware threads
+    cols = int(batch.col_off[-1])
+    out = dict(value=cols / t_all, unit="candidate_sites/s", cores=th_all, kind="port",
+               sample="all %d regions of the rank-0 batch (%d columns, %d reads) once through orc_run_batch (native std::thread pool, "
+                      "heaviest regions first), ORC_MODE_F64_ONLY = the reference's arithmetic, full hot path P1-P17: %.2f s on %d threads"
+                      % (batch.n_regions, cols, batch.n_reads, t_all, th_all))
+    # thread scaling on the first regions of the batch (a fixed number per point: ~2-6 s of wall time each)
+    scaling = {}
+    spent = t_all
+    for th, n_reg in ((1, 12), (16, 96), (64, 256)):
+        if th >= ncpu or spent > budget_s:
+            continue
+        hb = head_batch(batch, n_reg)
+        dt, _ = cpu_pool(hb, params, th)
+        spent += dt
+        scaling[str(th)] = dict(sites_per_sec=int(hb.col_off[-1]) / dt, regions=hb.n_regions, seconds=dt)
+    scaling[str(th_all)] = dict(sites_per_sec=cols / t_all, regions=batch.n_regions, seconds=t_all)
+    out["thread_scaling"] = scaling
+    if "1" in scaling:
+        out["single_thread_value"] = scaling["1"]["sites_per_sec"]
+    return out
 
-    def run_region(g):
-        R = orc.Region(batch, g, params)
-        R.run_all(orc.MODE_F64)
-        return int(batch.len[g]), int(batch.read_begin[g + 1] - batch.read_begin[g])
 
+# ---------------------------------------------------------------------------------------------------------------------
+# same-run HBM traffic of the pileup stage: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) over a
+# child process that loads the SAME batch and runs the pileup stage a few times
+
+def pmc_child(path):
+    import torch
+    from longcallr_amd import _abi, api
+    z = np.load(path)
+    b = _abi.ReadBatch(**{k: z[k] for k in z.files if k not in ("preset",)})
+    p = _abi.make_params(str(z["preset"]), seed=2025)
+    dv = to_device(b, torch, torch.device("cuda", 0))
+    E = api.Engine(0, p)
+    for _ in range(4):
+        E.load_batch(dv)
+        E.fill_data_into_freq_vec()
+        E.sync()
+    E.close()
+
+
+def measure_traffic(batch, preset):
+    """HBM bytes per launch of the pileup stage's kernels, or (None, reason).  FETCH_SIZE is doubled (gfx950 tallies a 128-byte
+    request of a wide coalesced read as 64, MI355X_MICROARCH.md "HBM"); WRITE_SIZE as reported; both are in KiB."""
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None, "rocprofv3 not found"
+    import csv, glob
+    tmp = tempfile.mkdtemp(prefix="lcr_pmc_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        path = os.path.join(tmp, "batch.npz")
+        np.savez(path, preset=np.array(preset), **{f: getattr(batch, f) for f in batch.FIELDS + ["start0", "len", "read_begin", "ref"]})
+        per = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            env = dict(os.environ, TMPDIR=tmp)
+            r = subprocess.run([rp, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "p", "--output-format", "csv", "--",
+                                sys.executable, os.path.abspath(__file__), "--pmc-child", path], cwd=tmp, env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (ctr, r.returncode, r.stdout.decode(errors="replace")[-300:])
+            agg = {}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != ctr:
+                    continue
+                k = next((n for n in PILEUP_KERNELS if n in row["Kernel_Name"]), None)
+                if k:
+                    a = agg.setdefault(k, [0.0, set()])
+                    a[0] += float(row["Counter_Value"]); a[1].add(row["Dispatch_Id"])
+            per[ctr] = {k: v[0] / max(len(v[1]), 1) for k, v in agg.items()}
+        kernels = {}
+        total = 0.0
+        for k in sorted(set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"])):
+            f, w = per["FETCH_SIZE"].get(k, 0.0), per["WRITE_SIZE"].get(k, 0.0)
+            kernels[k] = dict(fetch_kib=f, write_kib=w, bytes=int((2.0 * f + w) * 1024))
+            total += (2.0 * f + w) * 1024
+        return dict(bytes_per_launch=int(total), kernels=kernels,
+                    note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes of 4 pileup calls over this run's batch; FETCH x 2 per "
+                         "MI355X_MICROARCH.md (calibrated for 16 B/lane streaming reads only), WRITE as reported"), None
+    except Exception as e:   # noqa: BLE001 -- the bench line must not depend on the profiler
+        return None, "traffic pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stages beside the headline workload (rank 0, N = 1)
+
+def batches_in_flight_stage(api, torch, device, params, dev_batch, cols, contexts=3, steps=60):
+    """The same step with several batches in flight on the GPU (one context and one host thread each): the queue gaps of
+    one batch's host round trips are filled by the others' kernels.  Reported beside `value`, never as it: the co-scheduled
+    kernels stretch each other, so the roofline is quoted on the undisturbed single-batch run."""
+    import threading
+    engines = [api.Engine(device, params) for _ in range(contexts)]
+    def run(E, n):
+        torch.cuda.set_device(device)
+        run_steps_simple(E, dev_batch, n)
+    for E in engines:
+        run(E, 3)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    cols1 = g1 = 0
-    while g1 < batch.n_regions and (time.perf_counter() - t0 < budget_s / 4 or g1 < 2):
-        cols1 += run_region(g1)[0]
-        g1 += 1
-    single = cols1 / (time.perf_counter() - t0)
-
-    threads = max(1, min(os.cpu_count() or 1, 64))
-    counter = itertools.count()
-    lock = threading.Lock()
-    done = []
-    t0 = time.perf_counter()
-
-    def worker():
-        while time.perf_counter() - t0 < budget_s:
-            with lock:
-                k = next(counter)
-            done.append(run_region(k % batch.n_regions))   # the batch is re-walked if the budget outlasts it
-
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        for f in [ex.submit(worker) for _ in range(threads)]:
-            f.result()
+    ths = [threading.Thread(target=run, args=(E, steps // contexts)) for E in engines]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    cols, reads = sum(d[0] for d in done), sum(d[1] for d in done)
-    return dict(value=cols / dt, unit="candidate_sites/s", cores=threads, kind="port", single_thread_value=single,
-                sample="%d region passes over the %d regions of the rank-0 batch (%d columns, %d reads) by %d threads, "
-                       "full hot path, %.1f s; 1 thread: first %d regions"
-                       % (len(done), batch.n_regions, cols, reads, threads, dt, g1))
+    for E in engines:
+        E.close()
+    n = contexts * (steps // contexts)
+    return {"contexts": contexts, "steps": n, "ms_per_step": dt / n * 1e3, "sites_per_sec": cols * n / dt,
+            "note": "%d contexts on %d host threads share the GPU (bench.py --inflight %d times the whole run this way)" % (contexts, contexts, contexts)}
 
+
+def seeds_stage(api, _abi, torch, device, wl, params, seeds, steps=15):
+    """generator seeds 1..5 per config.  Seed 1 is the headline run; the others: ms per step and pileup fraction."""
+    out = {}
+    for s in seeds:
+        b = build_workload(wl, seed=s)
+        r = time_workload(api, _abi, torch, device, params, b, steps=steps, warm=4)
+        out[str(s)] = {k: r[k] for k in ("columns", "aligned_bases", "ms_per_step", "sites_per_sec", "pileup_stage_ms", "pileup_stage_frac_of_hbm_peak", "candidates")}
+    return out
+
+
+def c4_share_stage(api, _abi, synth, torch, device, cpu=True):
+    """One GPU's share of BASELINE configs[3] (the workload N > 1 runs: 1 000 distinct MAS-Seq genes x 25 kb, 60x) at N = 1, and the
+    CPU oracle pool on its first regions."""
+    t0 = time.perf_counter()
+    b = build_workload("c4")
+    gen = time.perf_counter() - t0
+    p = _abi.make_params("hifi-masseq", seed=2025)
+    out = time_workload(api, _abi, torch, device, p, b, steps=20, warm=5)
+    out["workload"], out["generate_s"] = WORKLOADS["c4"][4] + ": 1 000 distinct genes, hifi-masseq preset", gen
+    if cpu:
+        hb = head_batch(b, 256)
+        dt, th = cpu_pool(hb, p, 0)
+        out["cpu_oracle"] = dict(sites_per_sec=int(hb.col_off[-1]) / dt, threads=th, seconds=dt, kind="port",
+                                 sample="first %d regions (%d columns), full hot path, ORC_MODE_F64_ONLY" % (hb.n_regions, int(hb.col_off[-1])))
+        out["gpu_over_cpu_oracle"] = out["sites_per_sec"] / out["cpu_oracle"]["sites_per_sec"]
+    return out
+
+
+def c5_stage(api, _abi, synth, device, cpu=True):
+    """BASELINE configs[4] once: ONE 1 Mb island at 500x ONT-dRNA, ~4 700 candidate sites; per-call wall times (ms).  CPU: the oracle's
+    P1-P6 (pileup, candidates, fragment matrix) of the one region on ONE thread -- the reference's unit of parallelism is the region, and
+    its optimiser on this matrix is out of reach (phase.rs:890-898 is quadratic in a column's depth)."""
+    t0 = time.perf_counter()
+    b = synth.make_island("ont-drna-c5", n_loci=40, locus_len=25000, depth=500, seed=5)
+    gen = time.perf_counter() - t0
+    p = _abi.make_params("ont-drna", seed=5)
+    E = api.Engine(device, p)
+    ms = {}
+    for rep in range(2):   # the second pass has its buffers
+        for name, fn in (("lcr_load_batch", lambda: E.load_batch(b)), ("lcr_pileup", E.fill_data_into_freq_vec),
+                         ("lcr_candidates", E.get_candidate_snps), ("lcr_fragments", E.get_fragments), ("lcr_phase", E.phase)):
+            ts = time.perf_counter(); fn(); E.sync(); ms[name] = (time.perf_counter() - ts) * 1e3
+    c = E.candidates()[0]
+    fm = E.fragmat()
+    n_phased = int(fm["row_for_phasing"].sum())
+    t_phase = (ms["lcr_fragments"] + ms["lcr_phase"]) * 1e-3
+    t_p16 = (ms["lcr_load_batch"] + ms["lcr_pileup"] + ms["lcr_candidates"] + ms["lcr_fragments"]) * 1e-3
+    out = dict(workload="C5 = BASELINE configs[4]: one island of %d columns, %d reads, %d aligned bases" % (int(b.len[0]), b.n_reads, int(b.bases.size)),
+               generate_s=gen, api_ms=ms, candidates=int(c.size), fragment_nnz=int(fm["col"].size), phasing_reads=n_phased,
+               cross_optimize_calls=1 + 2 * (int(c.size) // 4 + 1), phased_reads_per_sec=n_phased / t_phase,
+               sites_per_sec_full_step=int(b.len[0]) / (sum(ms.values()) * 1e-3), sites_per_sec_p1_p6=int(b.len[0]) / t_p16,
+               note="phase stage: k4_stage_grid + k4_chain_grid + k4_gpost (all CUs on the one region, no host epilogue); inputs are host "
+                    "buffers here (lcr_load_batch includes the upload)")
+    E.close()
+    if cpu:
+        dt, th = cpu_pool(b, p, 1, upto="frag")
+        out["cpu_oracle_p1_p6"] = dict(sites_per_sec=int(b.len[0]) / dt, threads=th, seconds=dt, kind="port",
+                                       sample="the whole island through P1-P6 on one thread (one region = one rayon task)")
+        out["gpu_over_cpu_oracle_p1_p6"] = out["sites_per_sec_p1_p6"] / out["cpu_oracle_p1_p6"]["sites_per_sec"]
+    return out
+
+
+def demo_stage(api, _abi, device, cpu=True):
+    """BASELINE configs[0]/[1]: demo.bam from the file -- native decode, region discovery on the GPU, batch, the four stage calls -- wall time
+    per pass, against the oracle's compute on the same decoded reads (the oracle has no decoder of its own: its side is compute only)."""
+    from longcallr_amd import bamio
+    path = os.path.join(ROOT, "tests", "golden", "demo.bam")
+    lines = open(os.path.join(ROOT, "tests", "golden", "demo_pseudo_ref.fa")).read().split("\n")
+    ref = np.frombuffer("".join(lines[1:]).encode(), dtype=np.uint8).copy()
+    p = _abi.make_params("hifi-masseq")
+    E = api.Engine(device, p)
+
+    def one_pass():
+        nb = bamio.NativeBam(path, 8)
+        rid = [n for n, _ in nb.refs].index("chr20")
+        rs, re_ = nb.spans(rid, **_abi.READ_FILTER)
+        regions = E.discover_regions(rs, re_, nb.refs[rid][1])
+        b = nb.batch(rid, [(s, l) for s, l, _ in regions], [ref], name_format="blob", **_abi.READ_FILTER)
+        E.load_batch(b).run_all()
+        c = E.candidates()[0]
+        nb.close()
+        return b, c
+    for _ in range(3):
+        b, c = one_pass()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        b, c = one_pass()
+    gpu = (time.perf_counter() - t0) / n
+    # the four stage calls alone, inputs already decoded (host buffers, upload included)
+    for _ in range(20):
+        E.load_batch(b).run_all()
+    E.sync()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        E.load_batch(b).run_all()
+    E.sync()
+    stages_only = (time.perf_counter() - t0) / 50
+    E.close()
+    L = int(b.len[0])
+    out = dict(workload="demo.bam (chr20:16 729 961-16 743 217, %d reads pass the filter, %d columns, %d candidates), hifi-masseq preset, pseudo-reference"
+                        % (b.n_reads, L, int(c.size)),
+               file_to_candidates_ms=gpu * 1e3, stage_calls_ms=stages_only * 1e3, sites_per_sec_from_file=L / gpu, sites_per_sec_stage_calls=L / stages_only,
+               note="from the file = lcr_bam_open (inflate on 8 threads) + spans + lcr_discover_regions + lcr_bam_batch + load_batch + four stage "
+                    "calls + lcr_get_candidates, per pass; ~5 MB of traffic: launch- and latency-bound, not a roofline workload")
+    if cpu:
+        m = 3
+        cpu_t = sum(cpu_pool(b, p, 1)[0] for _ in range(m)) / m
+        out["cpu_oracle"] = dict(sites_per_sec=L / cpu_t, ms=cpu_t * 1e3, threads=1, kind="port",
+                                 sample="the one region on one thread (the reference runs one rayon task per region), compute only, ORC_MODE_F64_ONLY")
+        out["gpu_over_cpu_oracle_stage_calls"] = cpu_t / stages_only
+        out["gpu_from_file_over_cpu_oracle_compute"] = cpu_t / gpu
+    return out
+
+
+def end_to_end_stage(api, _abi, torch, device, batch, params, cpu_compute_s=None, cpu_threads=None):
+    """The headline batch once more, END TO END FROM A BAM FILE: the batch is written as a BAM (lcr_bam_write_reads, not timed), then
+    per pass: lcr_bam_open (inflate + index on all host threads) -> spans -> lcr_discover_regions -> lcr_bam_batch -> lcr_load_batch (host
+    buffers: 1 GB over PCIe) -> four stage calls -> candidates on the host.  CPU side: the same native decode + the oracle pool's compute."""
+    from longcallr_amd import bamio
+    tmp = tempfile.mkdtemp(prefix="lcr_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        path = os.path.join(tmp, "c3.bam")
+        t0 = time.perf_counter()
+        clen = bamio.write_reads_bam(path, batch, "chrS", level=1, threads=0)
+        t_write = time.perf_counter() - t0
+        size = os.path.getsize(path)
+        flt = dict(min_mapq=0, min_read_length=0, divergence=2.0)
+        E = api.Engine(device, params)
+        best = None
+        want = list(zip(batch.start0.tolist(), batch.len.tolist()))
+        wins = [batch.ref[int(batch.col_off[g]):int(batch.col_off[g + 1])] for g in range(batch.n_regions)]
+        for rep in range(3):
+            t = {}
+            t0 = time.perf_counter(); nb = bamio.NativeBam(path, 0); t["open_inflate_index"] = time.perf_counter() - t0
+            t0 = time.perf_counter(); rs, re_ = nb.spans(0, **flt); regions = E.discover_regions(rs, re_, clen); t["spans_discover"] = time.perf_counter() - t0
+            assert [(s, l) for s, l, _ in regions] == want, "region discovery must find the generator's genes"
+            t0 = time.perf_counter(); b2 = nb.batch(0, want, wins, name_format="blob", **flt); t["batch"] = time.perf_counter() - t0
+            t0 = time.perf_counter(); E.load_batch(b2); E.sync(); t["load_batch_h2d"] = time.perf_counter() - t0
+            t0 = time.perf_counter(); E.run_all(); c = E.candidates()[0]; t["stages"] = time.perf_counter() - t0
+            nb.close()
+            t["total"] = sum(t.values())
+            if best is None or t["total"] < best["total"]:
+                best = t
+        E.close()
+        cols = int(batch.col_off[-1])
+        out = dict(workload="the headline batch as a BAM file: %d reads, %.0f MB compressed (deflate level 1), %d columns" % (batch.n_reads, size / 1e6, cols),
+                   bam_write_s=t_write, gpu_path_s=best, sites_per_sec=cols / best["total"], candidates=int(c.size),
+                   note="best of 3 passes; decode = liblcr's native BGZF / BAM decoder on all host threads (the reference inflates every region "
+                        "twice through htslib); the kernels' share of the path is `stages`")
+        if cpu_compute_s is not None:
+            dec = best["open_inflate_index"] + best["spans_discover"] + best["batch"]
+            out["cpu_path_s"] = dict(decode=dec, oracle_compute=cpu_compute_s, total=dec + cpu_compute_s, threads=cpu_threads,
+                                     note="same native decode (the oracle has none) + the oracle pool over all regions (cpu_baseline)")
+            out["gpu_over_cpu_path"] = (dec + cpu_compute_s) / best["total"]
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--pmc-child":
+        return pmc_child(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -267,7 +469,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1, help="generator seed of the synthetic genes (SURVEY §8(d): seeds 1..5)")
     ap.add_argument("--gene-len", type=int, default=None)
     ap.add_argument("--depth", type=float, default=None)
-    ap.add_argument("--no-c5", action="store_true", help="skip the single pass over the C5 island (N = 1)")
+    ap.add_argument("--no-c5", action="store_true", help="alias of --no-extras")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline workload (+ cpu_baseline, + traffic)")
+    ap.add_argument("--quick", action="store_true", help="--no-extras --no-cpu-baseline --no-traffic")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: smoke-test the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs, records travel "
                          "through host memory); the numbers of such a run mean nothing")
@@ -277,8 +482,11 @@ def main():
                     help="batches in flight per GPU: N contexts driven by N host threads (a context per worker thread, as "
                          "the reference's rayon workers would hold); 1 = one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
+    if a.quick:
+        a.no_extras = a.no_cpu_baseline = a.no_traffic = True
+    a.no_extras = a.no_extras or a.no_c5
 
     import torch
     from longcallr_amd import _abi, api, synth, shard
@@ -323,9 +531,12 @@ def main():
     a.depth = a.depth or w_depth
     # ONE region list for the whole job: world x genes distinct genes, LPT on len x max_coverage assigns them to the
     # ranks; a rank builds only its own regions (build_shard)
+    t_gen = time.perf_counter()
     batch, mine, n_global = build_shard(wl, world, rank, seed=a.seed, genes=a.genes, gene_len=a.gene_len, depth=a.depth, profile=a.profile)
+    t_gen = time.perf_counter() - t_gen
     assert batch.n_regions == len(mine)
-    params = _abi.make_params(synth.preset_for(a.profile), seed=2025)
+    preset = synth.preset_for(a.profile)
+    params = _abi.make_params(preset, seed=2025)
     reads, regions, keep = to_device(batch, torch, dev)
     torch.cuda.synchronize()
 
@@ -335,8 +546,10 @@ def main():
     if F == 1:
         E.set_stream(torch.cuda.current_stream().cuda_stream)  # torch.cuda.synchronize() then covers liblcr
 
-    G = shard.RecordGather(dist, cdev, _abi.CAND_DTYPE) if dist is not None else None
+    # the two record types of the final gather (thread.rs:204-221): candidate records and read -> HP / PS records
+    G = (shard.RecordGather(dist, cdev, _abi.CAND_DTYPE), shard.RecordGather(dist, cdev, _abi.READ_REC_DTYPE)) if dist is not None else None
     pending = [None]
+    gathered = [0, 0]
 
     def step(Ej):
         Ej.load_batch((reads, regions, keep))
@@ -345,17 +558,27 @@ def main():
         # HIP events on the ctx stream, read after the step (lcr_pileup returns while K1 is still running)
         return (Ej.kernel_ms(_abi.K_PILEUP), Ej.kernel_ms(_abi.K_SPANS))
 
-    def publish(Ej):   # the gather of this batch's records (HBM to rank 0's HBM) overlaps the next batch's kernels
+    def read_records_host(Ej):
+        pr = Ej.phase_result()
+        r = np.zeros(pr["haplotag"].size, dtype=_abi.READ_REC_DTYPE)
+        r["row"], r["haplotag"], r["assignment"], r["phase_set"] = np.arange(r.size), pr["haplotag"], pr["assignment"], pr["phase_set"]
+        return r
+
+    def publish(Ej):   # the gathers of this batch's records (HBM to rank 0's HBM) overlap the next batch's kernels
         if G is None:
             return
-        h = G.start(Ej.candidates_device() if a.dist_backend == "nccl" else Ej.candidates()[0])
+        on_dev = a.dist_backend == "nccl"
+        h = (G[0].start(Ej.candidates_device() if on_dev else Ej.candidates()[0]),
+             G[1].start(Ej.read_records_device() if on_dev else read_records_host(Ej)))
         if pending[0] is not None:
-            G.finish(pending[0], parse=False)
+            G[0].finish(pending[0][0], parse=False); G[1].finish(pending[0][1], parse=False)
         pending[0] = h
 
     def drain():   # the last batch is also brought to rank 0's host and decoded
         if G is not None and pending[0] is not None:
-            G.finish(pending[0], parse=True)
+            c = G[0].finish(pending[0][0], parse=True); r = G[1].finish(pending[0][1], parse=True)
+            if c is not None:
+                gathered[0], gathered[1] = int(c.size), int(r.size)
             pending[0] = None
 
     def run_steps(n):
@@ -439,7 +662,7 @@ def main():
     fm = E.fragmat()
     n_phased = int(fm["row_for_phasing"].sum())
     cands = E.candidates()[0]
-    kms = {n: E.kernel_ms(k) for n, k in (("k0_bin", _abi.K_SPANS), ("k1_pileup", _abi.K_PILEUP),
+    kms = {n: E.kernel_ms(k) for n, k in (("k0_ops", _abi.K_SPANS), ("k1_tiles_bin_pileup", _abi.K_PILEUP),
                                           ("k2_filter", _abi.K_CAND_FILTER), ("k2_hist", _abi.K_CAND_HIST),
                                           ("k2_gt", _abi.K_CAND_GT), ("k3_count", _abi.K_FRAG_COUNT),
                                           ("k3_fill", _abi.K_FRAG_FILL))}
@@ -460,15 +683,13 @@ def main():
         achieved = pbytes / (avg_ms * 1e-3) / 1e9
         stage_bytes = E.pileup_stage_bytes()
         stage_ms = avg_ms + avg_k0_ms
-        traffic = None  # HBM bytes per launch from the committed PMC passes (same workload only; not a same-run measurement)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "k1_traffic.json")))
-            w = tj["workload"]
-            if (w["profile"], w["genes"], w["gene_len"], w["depth"], w.get("seed")) == (a.profile, a.genes, a.gene_len, a.depth, a.seed):
-                traffic = tj["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
         nnz = int(fm["col"].size)
+        n_items = int((pbytes - int(batch.bases.size) - 53 * cols) // 8)
+        for Ej in engines[1:]:
+            Ej.close()
+        traffic, traffic_note = (None, "skipped (--no-traffic, or N > 1)")
+        if world == 1 and not a.no_traffic:
+            traffic, traffic_note = measure_traffic(batch, preset)
         out = {
             "metric": "candidate_sites_per_sec", "value": int(tot[0]) * a.steps / dt, "unit": "sites/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -477,20 +698,26 @@ def main():
             "config": {"workload": "%s; synthetic %s reads, %d distinct genes (regions) x %d bp per GPU at %.0fx mean aligned depth, "
                                    "generator seed %d; %d regions in the job, LPT-partitioned over %d rank(s), preset %s; "
                                    "step = bind+pileup+candidates+fragments+phase"
-                                   % (w_name, a.profile, a.genes, a.gene_len, a.depth, a.seed, n_global, world, synth.preset_for(a.profile)),
+                                   % (w_name, a.profile, a.genes, a.gene_len, a.depth, a.seed, n_global, world, preset),
                        "columns": int(tot[0]), "aligned_bases": int(tot[1]), "reads": int(tot[2]), "candidates": int(tot[3]),
                        "fragment_nnz": int(tot[4]), "phasing_reads": int(tot[5]),
-                       "columns_rank0": cols, "aligned_bases_rank0": int(batch.bases.size),
-                       "parallelism": "regions sharded over %d GPU(s) by shard.assign_regions (LPT on len x max_coverage), gather of records to rank 0" % world,
+                       "columns_rank0": cols, "aligned_bases_rank0": int(batch.bases.size), "generate_s_rank0": t_gen,
+                       "parallelism": "regions sharded over %d GPU(s) by shard.assign_regions (LPT on len x max_coverage); final gather of candidate "
+                                      "records and read -> HP / PS records to rank 0 (RCCL), overlapped with the next batch" % world,
+                       "gathered_records_last_batch": {"candidates": gathered[0], "reads": gathered[1]} if dist is not None else None,
                        "batches_in_flight_per_gpu": F},
-            "roofline": {"bound": "hbm", "kernel": "pileup stage = k0_bin + intron scan + k1_tile_order + k1_pileup (+ k1_zonefix on HiFi presets): what replaces fill_data_into_freq_vec",
+            "roofline": {"bound": "hbm", "kernel": "pileup stage = k0_ops + k1_tiles_a/b + k0_desc_bin + k1_pileup + k1_empty_tiles (+ k1_zonefix on HiFi presets): what replaces fill_data_into_freq_vec",
                          "achieved": stage_bytes / (stage_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
+                         "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / 8000.0,
+                         "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic if traffic else traffic_note,
                          "algorithmic_bytes": stage_bytes, "avg_ms": stage_ms,
                          "note": "algorithmic bytes B + 4C + 37R + 53L (bases once, CIGAR, read headers, ref byte + 13 u32 planes per column); "
-                                 "HIP events on the ctx stream, rank 0; traffic = committed PMC passes of the same workload (profiles/), not this run",
-                         "k1_pileup": {"algorithmic_bytes": pbytes, "avg_ms": avg_ms, "achieved": achieved, "frac": achieved / 8000.0,
-                                       "note": "the tally kernel with its tile-ordering pass (k1_tile_order + k1_pileup): bases once + 8-byte records + 57 B/column"}},
+                                 "HIP events on the ctx stream, rank 0, mean over the timed steps",
+                         "k0_ops": {"avg_ms": avg_k0_ms, "algorithmic_bytes": 4 * int(batch.cigar.size) + 64 * batch.n_reads + 8 * n_items,
+                                    "frac": (4 * int(batch.cigar.size) + 64 * batch.n_reads + 8 * n_items) / (avg_k0_ms * 1e-3) / 8e12,
+                                    "note": "4C + 64R read, 8 B per record item written"},
+                         "k1": {"algorithmic_bytes": pbytes, "avg_ms": avg_ms, "achieved": achieved, "frac": achieved / 8000.0,
+                                "note": "the tally with its tile passes and the chunk binning (k1_tiles_a/b + k0_desc_bin + k1_pileup + k1_empty_tiles): bases once + 8 B per record item + 53 B/column"}},
             "stages": {"pileup_plus_candidates_s": t_call, "fragments_plus_phase_s": t_phase,
                        "sites_per_sec_pileup_gt": cols / t_call, "covered_sites_per_sec_pileup_gt": covered / t_call,
                        "candidates_per_sec_pileup_gt": int(cands.size) / t_call, "phased_reads_per_sec": n_phased / t_phase,
@@ -502,12 +729,27 @@ def main():
                                     "note": "per-kernel times: profiles/ (rocprofv3 --kernel-trace --stats of this command)"},
                        "api_ms": api_ms, "kernel_ms": kms},
         }
-        if world == 1 and F == 1 and not a.no_c5:
-            out["stages"]["batches_in_flight"] = batches_in_flight_stage(api, torch, local, params, (reads, regions, keep), cols)
-        if world == 1 and not a.no_c5:
-            out["stages"]["c5"] = c5_stage(api, _abi, synth, local)
+        extras = world == 1 and not a.no_extras
+        cpu = None
         if not a.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks of a node would sit idle behind it
-            out["cpu_baseline"] = cpu_baseline(batch, params, a.cpu_budget)
+            cpu = cpu_baseline(batch, params, a.cpu_budget)
+            out["cpu_baseline"] = cpu
+        st = out["stages"]
+        if extras and F == 1:
+            st["batches_in_flight"] = batches_in_flight_stage(api, torch, local, params, (reads, regions, keep), cols)
+            st["end_to_end_from_bam"] = end_to_end_stage(api, _abi, torch, local, batch, params,
+                                                         (cols / cpu["value"]) if cpu else None, cpu["cores"] if cpu else None)
+        E.close()
+        del keep, reads, regions
+        torch.cuda.empty_cache()
+        if extras:
+            st["demo"] = demo_stage(api, _abi, local, cpu=not a.no_cpu_baseline)
+            if wl == "c3" and a.seed == 1:
+                st["seeds"] = seeds_stage(api, _abi, torch, local, "c3", params, [2, 3, 4, 5])
+                st["seeds"]["1"] = {"columns": cols, "aligned_bases": int(batch.bases.size), "ms_per_step": out["ms_per_step"], "sites_per_sec": out["value"],
+                                    "pileup_stage_ms": stage_ms, "pileup_stage_frac_of_hbm_peak": out["roofline"]["frac"], "candidates": int(cands.size)}
+            st["c4_share"] = c4_share_stage(api, _abi, synth, torch, local, cpu=not a.no_cpu_baseline)
+            st["c5"] = c5_stage(api, _abi, synth, local, cpu=not a.no_cpu_baseline)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

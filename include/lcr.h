@@ -218,6 +218,18 @@ int lcr_get_fragmat(lcr_ctx*, lcr_fragmat* out);
  * eval_rna_edit_var_phase, eval_low_frac_var_phase, assign_phase_set). */
 int lcr_phase(lcr_ctx*, const lcr_params*);
 int lcr_get_phase_result(lcr_ctx*, lcr_phase_result* out);
+/* The per-row results once more as 12-byte records in device memory (HBM), current after lcr_phase: the second record type
+ * of the multi-GPU gather (the reference collects read -> HP / PS per region, thread.rs:204-221).  row = fragment row of
+ * lcr_get_fragmat (batch-wide).  The pointer is valid until the next lcr_phase / lcr_load_batch on this ctx. */
+typedef struct {
+  int32_t row;
+  int8_t haplotag;           /* sigma */
+  uint8_t assignment;        /* 0 unassigned, 1 hap1, 2 hap2 */
+  uint16_t pad_;
+  uint32_t phase_set;        /* 0 = none */
+} lcr_read_record;
+int lcr_get_read_records_device(lcr_ctx*, const lcr_read_record** dev_rec, int32_t* n_rows);
+
 /* LD blocks of one region of the last lcr_phase (SNPFrag.ld_blocks, snpfrags.rs:29; built by divide_snps_into_blocks,
  * candidate.rs:615-747): block b = snp_idx[block_off[b] .. block_off[b + 1]) (candidate indices inside the region), in
  * the reference's block and node order.  Only regions with more than max_enum_snps candidates build blocks (the
@@ -286,6 +298,11 @@ int lcr_bam_batch(lcr_bam*, int32_t ref_id, const lcr_read_filter*, int32_t n_re
 int lcr_bam_write_phased(lcr_bam*, const char* out_path, int32_t n_regions, const int32_t* region_ref, const int64_t* start0,
                          const int32_t* len, int64_t n_tagged, const uint64_t* name_off, const char* names, const int32_t* hp,
                          const uint32_t* ps, int32_t level, int32_t n_threads);
+
+/* Decoded reads -> BAM, the inverse of lcr_bam_batch (synthetic data sets, round-trip tests; the reference has no such
+ * writer: its inputs come from minimap2): one contig, the reads of `rd` (LCR_MEM_HOST, sorted by position) as records
+ * "r<index>", mapq 60, flag 0 / 16, `ts:A:+` / `-` from lcr_reads.flags; BGZF at `level`, deflated on n_threads threads. */
+int lcr_bam_write_reads(const char* out_path, const char* contig, int64_t contig_len, const lcr_reads* rd, int32_t level, int32_t n_threads);
 
 /* Timing: HIP-event time (ms) of the last launch of each kernel on the ctx's stream. */
 enum { LCR_K_SPANS = 0 /* K0: CIGAR decode + binning */, LCR_K_PILEUP, LCR_K_CAND_FILTER, LCR_K_CAND_HIST, LCR_K_CAND_GT,

@@ -124,6 +124,11 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+# lcr_read_record (include/lcr.h): per-row results in HBM for the multi-GPU gather
+READ_REC_DTYPE = np.dtype([("row", "<i4"), ("haplotag", "i1"), ("assignment", "u1"), ("pad_", "<u2"), ("phase_set", "<u4")])
+assert READ_REC_DTYPE.itemsize == 12
+
+
 class ReadBatch:
     """Host SoA of decoded reads + the regions that own them (numpy, C-contiguous)."""
 

@@ -113,6 +113,12 @@ class Engine:
         self._chk(self.lib.lcr_get_candidates_device(self.h, C.byref(ptr), C.byref(n)), "lcr_get_candidates_device")
         return int(ptr.value or 0), int(n.value)
 
+    def read_records_device(self):
+        """(device pointer, count) of the per-row results as 12-byte records in HBM (current after phase)."""
+        ptr, n = C.c_void_p(), C.c_int32()
+        self._chk(self.lib.lcr_get_read_records_device(self.h, C.byref(ptr), C.byref(n)), "lcr_get_read_records_device")
+        return int(ptr.value or 0), int(n.value)
+
     def fragmat(self):
         o = _abi.LcrFragmat()
         self._chk(self.lib.lcr_get_fragmat(self.h, C.byref(o)), "lcr_get_fragmat")

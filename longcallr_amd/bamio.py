@@ -276,6 +276,21 @@ def phased_stream(recs, regions, names, hp, ps):
     return b"".join(out)
 
 
+def write_reads_bam(path, batch, contig="chrS", contig_len=None, level=1, threads=0):
+    """A ReadBatch as a coordinate-sorted one-contig BAM (lcr_bam_write_reads): synthetic data sets from file, round trips.
+    The batch's reads must be sorted by position over ALL its regions (synth batches are: regions ascend)."""
+    import ctypes as C
+    from . import _lib
+    l = _lib.load()
+    rd = batch.c_reads()
+    if contig_len is None:
+        contig_len = int(batch.start0[-1] + batch.len[-1]) + 1000
+    rc = l.lcr_bam_write_reads(os.fsencode(path), contig.encode(), int(contig_len), C.byref(rd), level, threads)
+    if rc:
+        raise _lib.LcrError("lcr_bam_write_reads(%s) failed (%d)" % (path, rc))
+    return contig_len
+
+
 class NativeBam:
     """liblcr's BAM decoder (lcr_bam_* in include/lcr.h): the file is mapped, one contig at a time is inflated (in
     parallel) and indexed, batches for `Engine.load_batch` are cut out of that index.  Mirrors read_bam /

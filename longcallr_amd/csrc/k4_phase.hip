@@ -1102,6 +1102,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   const size_t res_ps = 0, res_tag = nr1 * 4, res_asg = nr1 * 5, res_bytes = nr1 * 6;
   const size_t hc_obj = (nc1 * sizeof(lcr_candidate) + 15) & ~(size_t)15;
   PCHK(h_pin[7].reserve(res_bytes)); PCHK(h_pin[9].reserve(hc_obj + (size_t)std::max(ng, 1) * 8));
+  PCHK(d_read_rec.reserve(nr1 * 12));   // per-row results once more, as records in HBM (lcr_get_read_records_device)
   uint8_t* d_res = nullptr; uint8_t* d_hc = nullptr;   // device-side addresses of the two pinned blocks
   PCHK(hipHostGetDevicePointer((void**)&d_res, h_pin[7].p, 0));
   PCHK(hipHostGetDevicePointer((void**)&d_hc, h_pin[9].p, 0));
@@ -1204,7 +1205,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   plut.p_homref = L.p_homref; plut.p_homvar = L.p_homvar; plut.log_theta = L.log_theta; plut.log2 = L.log2;
   PostIn pin{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, const_cast<lcr_candidate*>(in.d_cand), in.d_cand_off,
              in.d_row_region_off, in.d_start0, P.st_sigma, P.st_delta, P.st_eta, (int8_t*)(d_res + res_tag), d_res + res_asg,
-             (uint32_t*)(d_res + res_ps), P.st_obj, (long long*)(d_hc + hc_obj), (lcr_candidate*)d_hc, prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr, P.reg, b_psrc.as<int32_t>()};
+             (uint32_t*)(d_res + res_ps), d_read_rec.as<uint32_t>(), P.st_obj, (long long*)(d_hc + hc_obj), (lcr_candidate*)d_hc, prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr, P.reg, b_psrc.as<int32_t>()};
   if (prof) { PCHK(d_state[20].reserve(((size_t)(ng + 1) * 16 + 2 * 1024) * 8)); PCHK(hipMemsetAsync(d_state[20].p, 0, ((size_t)(ng + 1) * 16 + 2 * 1024) * 8, stream)); pin.dbg_clk = d_state[20].as<long long>(); }
 
   // ---- chain regions on queue `side` (their own copy of the state arrays)
@@ -1521,6 +1522,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     objective[g] = (double)h_obj[g] / FX_SCALE;
   }
   r_haplotag = h_tag; r_assignment = h_asg; r_phase_set = h_ps;
+  read_rec_stale = any_host_post;   // (rows of regions that took the host epilogue: records rebuilt on demand)
   if (prof && pin.dbg_clk) {   // steps of k4_post: the slowest workgroup of each kind of region, and the median total
     std::vector<long long> clk((size_t)ng * 16);
     PCHK(hipMemcpy(clk.data(), pin.dbg_clk, clk.size() * 8, hipMemcpyDeviceToHost));

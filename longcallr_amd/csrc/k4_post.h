@@ -18,6 +18,7 @@ struct PostIn {
   lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off; const int64_t* start0;
   const int8_t* st_sigma; const int8_t* st_delta; const int8_t* st_eta;
   int8_t* haplotag; uint8_t* assignment; uint32_t* phase_set;   // per-row results: pinned host memory, written by the kernel
+  uint32_t* d_rec;   // the same as 12-byte records in HBM (lcr_read_record: row, haplotag | assignment << 8, phase set) for consumers on the device (multi-GPU gather)
   const long long* st_obj; long long* h_obj; lcr_candidate* h_cand;   // objective / candidate mirror in pinned host memory
   uint32_t min_linkers, max_enum_snps; uint64_t seed; double cutoff; float min_phase_score;
   long long* dbg_clk;   // LCR_PHASE_PROF: 100 MHz timestamps of every workgroup's steps, 16 per region (nullptr otherwise)
@@ -336,6 +337,7 @@ __device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<
         if (best >= 0) ps = (uint32_t)(cand[best].pos + 1);
       }
       in.phase_set[v.r0 + r] = ps;
+      in.d_rec[3 * (size_t)(v.r0 + r) + 2] = ps;
     }
     sc.sync();
   };
@@ -366,7 +368,11 @@ __device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<
     in.h_cand[v.c0 + i] = cand[i];   // (phase_set was written by this thread above)
   }
   if (sc.tid() == 0) in.h_obj[v.g] = in.st_obj[v.g];
-  for (int r = sc.tid(); r < nrow; r += sc.nt()) { in.haplotag[v.r0 + r] = tag[r]; in.assignment[v.r0 + r] = asg[r]; }
+  for (int r = sc.tid(); r < nrow; r += sc.nt()) {
+    in.haplotag[v.r0 + r] = tag[r]; in.assignment[v.r0 + r] = asg[r];
+    in.d_rec[3 * (size_t)(v.r0 + r)] = (uint32_t)(v.r0 + r);
+    in.d_rec[3 * (size_t)(v.r0 + r) + 1] = (uint32_t)(uint8_t)tag[r] | ((uint32_t)asg[r] << 8);
+  }
   mark();
 }
 

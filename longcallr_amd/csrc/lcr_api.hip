@@ -728,6 +728,22 @@ int lcr_get_phase_result(lcr_ctx* c, lcr_phase_result* out) {
   return LCR_OK;
 }
 
+int lcr_get_read_records_device(lcr_ctx* c, const lcr_read_record** dev_rec, int32_t* n_rows) {
+  if (!c || !dev_rec || !n_rows) return LCR_E_ARG;
+  if (!c->have_phase) { c->err = "lcr_get_read_records_device before lcr_phase"; return LCR_E_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  static_assert(sizeof(lcr_read_record) == 12, "lcr_read_record is 12 bytes");
+  if (c->phase.read_rec_stale) {   // regions that took the host epilogue (debug hook / fallback): rebuild from the host arrays
+    std::vector<lcr_read_record> h((size_t)std::max(c->n_rows, 0));
+    for (int r = 0; r < c->n_rows; r++) h[r] = lcr_read_record{r, c->phase.r_haplotag[r], c->phase.r_assignment[r], 0, c->phase.r_phase_set[r]};
+    if (c->n_rows) HIPCHK(c, hipMemcpy(c->phase.d_read_rec.p, h.data(), h.size() * sizeof(lcr_read_record), hipMemcpyHostToDevice));
+    c->phase.read_rec_stale = false;
+  }
+  *dev_rec = c->phase.d_read_rec.as<lcr_read_record>();
+  *n_rows = c->n_rows;
+  return LCR_OK;
+}
+
 int lcr_get_ld_blocks(lcr_ctx* c, int32_t region, int32_t* n_blocks, const int32_t** block_off, const int32_t** snp_idx) {
   if (!c || !n_blocks || !block_off || !snp_idx) return LCR_E_ARG;
   if (!c->have_phase) { c->err = "lcr_get_ld_blocks before lcr_phase"; return LCR_E_STATE; }

@@ -667,4 +667,94 @@ int lcr_bam_write_phased(lcr_bam* b, const char* out_path, int32_t n_regions, co
   return LCR_OK;
 }
 
+// ---- decoded reads -> BAM (one contig): the inverse of lcr_bam_batch, for synthetic data sets and round-trip tests.
+// Records: name "r<index>", mapq 60, flag 0 / 16 (lcr_reads.flags bit 0), CIGAR as given, bases packed 4-bit, qualities,
+// `ts:A:+/-` when flags bits 1-2 say so.  Reads must be sorted by position (they are written in the order given).
+int lcr_bam_write_reads(const char* out_path, const char* contig, int64_t contig_len, const lcr_reads* rd, int32_t level, int32_t n_threads) {
+  if (!out_path || !contig || !rd || rd->mem != LCR_MEM_HOST || rd->n_reads < 0 || contig_len < 0 || level < -1 || level > 9) return LCR_E_ARG;
+  if (n_threads < 1) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+  const int64_t nr = rd->n_reads;
+  // header: magic, l_text, text, n_ref, (l_name, name, l_ref)
+  std::string text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:" + std::string(contig) + "\tLN:" + std::to_string(contig_len) + "\n";
+  std::vector<uint8_t> head;
+  auto put32 = [](std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i < 4; i++) v.push_back((uint8_t)(x >> (8 * i))); };
+  head.insert(head.end(), {'B', 'A', 'M', 1});
+  put32(head, (uint32_t)text.size()); head.insert(head.end(), text.begin(), text.end());
+  put32(head, 1); put32(head, (uint32_t)strlen(contig) + 1);
+  head.insert(head.end(), contig, contig + strlen(contig) + 1);
+  put32(head, (uint32_t)contig_len);
+  // record offsets
+  std::vector<uint64_t> off((size_t)nr + 1);
+  off[0] = head.size();
+  for (int64_t r = 0; r < nr; r++) {
+    char nm[24];
+    const int ln = snprintf(nm, sizeof nm, "r%lld", (long long)r) + 1;
+    const int ts = (rd->flags[r] >> 1) & 3;
+    const uint64_t l = (uint64_t)rd->seq_len[r];
+    off[(size_t)r + 1] = off[(size_t)r] + 4 + 32 + (uint64_t)ln + 4ull * rd->n_cig[r] + (l + 1) / 2 + l + (ts ? 4 : 0);
+  }
+  std::vector<uint8_t> pay(off[(size_t)nr]);
+  memcpy(pay.data(), head.data(), head.size());
+  static const uint8_t code[256] = {};   // (filled below: ASCII -> 4-bit BAM code)
+  uint8_t enc[256];
+  memset(enc, 15, sizeof enc);
+  { const char* a = "=ACMGRSVTWYHKDBN"; for (int i = 0; i < 16; i++) enc[(uint8_t)a[i]] = (uint8_t)i; }
+  (void)code;
+  parallel_for(nr, n_threads, 256, [&](int64_t r) {
+    uint8_t* w = pay.data() + off[(size_t)r];
+    auto w32 = [&](uint32_t x) { w[0] = (uint8_t)x; w[1] = (uint8_t)(x >> 8); w[2] = (uint8_t)(x >> 16); w[3] = (uint8_t)(x >> 24); w += 4; };
+    char nm[24];
+    const int ln = snprintf(nm, sizeof nm, "r%lld", (long long)r) + 1;
+    const uint32_t l = (uint32_t)rd->seq_len[r], nc = rd->n_cig[r];
+    const int ts = (rd->flags[r] >> 1) & 3;
+    w32((uint32_t)(off[(size_t)r + 1] - off[(size_t)r] - 4));
+    w32(0);                                            // refID
+    w32((uint32_t)rd->pos[r]);
+    w32((uint32_t)ln | (60u << 8) | (4680u << 16));     // l_read_name, mapq, bin (unused by sequential readers)
+    w32(nc | ((rd->flags[r] & 1 ? 16u : 0u) << 16));    // n_cigar_op, flag
+    w32(l); w32(0xFFFFFFFFu); w32(0xFFFFFFFFu); w32(0);
+    memcpy(w, nm, (size_t)ln); w += ln;
+    memcpy(w, rd->cigar + rd->cig_off[r], 4ull * nc); w += 4ull * nc;
+    const uint8_t* bs = rd->bases + rd->seq_off[r];
+    for (uint32_t i = 0; i + 1 < l; i += 2) *w++ = (uint8_t)((enc[bs[i]] << 4) | enc[bs[i + 1]]);
+    if (l & 1) *w++ = (uint8_t)(enc[bs[l - 1]] << 4);
+    memcpy(w, rd->quals + rd->seq_off[r], l); w += l;
+    if (ts) { w[0] = 't'; w[1] = 's'; w[2] = 'A'; w[3] = ts == 1 ? '+' : '-'; }
+  });
+  // BGZF
+  FILE* f = fopen(out_path, "wb");
+  if (!f) return LCR_E_ARG;
+  const uint64_t BLK = 0xff00;
+  const size_t nblk = (pay.size() + BLK - 1) / BLK, n_out = nblk + 1;
+  std::vector<std::vector<uint8_t>> comp(n_out);
+  std::atomic<int> bad{0};
+  parallel_for((int64_t)n_out, n_threads, 4, [&](int64_t i) {
+    const uint64_t o = (uint64_t)i * BLK;
+    const uint32_t n = (size_t)i >= nblk ? 0u : (uint32_t)std::min<uint64_t>(BLK, pay.size() - o);
+    std::vector<uint8_t>& c = comp[(size_t)i];
+    c.resize(18 + compressBound(n) + 8);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad.store(1); return; }
+    zs.next_in = n ? pay.data() + o : nullptr; zs.avail_in = n;
+    zs.next_out = c.data() + 18; zs.avail_out = (uInt)(c.size() - 18 - 8);
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END || 18 + clen + 8 > 65536) { bad.store(1); return; }
+    static const uint8_t hd[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    memcpy(c.data(), hd, 16);
+    const uint32_t bsize = (uint32_t)(18 + clen + 8 - 1);
+    c[16] = (uint8_t)bsize; c[17] = (uint8_t)(bsize >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), n ? pay.data() + o : nullptr, n);
+    uint8_t* t = c.data() + 18 + clen;
+    for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)(n >> (8 * k)); }
+    c.resize(18 + clen + 8);
+  });
+  bool io_ok = !bad.load();
+  for (auto& c : comp) io_ok = io_ok && fwrite(c.data(), 1, c.size(), f) == c.size();
+  io_ok = (fclose(f) == 0) && io_ok;
+  return io_ok ? LCR_OK : LCR_E_ARG;
+}
+
 }  // extern "C"

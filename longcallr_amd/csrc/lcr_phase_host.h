@@ -118,6 +118,8 @@ struct PhaseHost {
   const uint8_t* r_assignment = nullptr;
   const uint32_t* r_phase_set = nullptr;
   DevBuf d_state[40];
+  DevBuf d_read_rec;             // per-row results as 12-byte records in HBM, written by k4_post
+  bool read_rec_stale = false;   // some regions took the host epilogue: the records are rebuilt from the host arrays on demand
   HostBuf h_pin[11];   // pinned staging: row_ptr, col, val, links, enum state, region sizes, chain state, results, job tables, chain start
   hipStream_t side = nullptr;   // second queue: fragment matrix download + chain regions
   hipEvent_t ev_in = nullptr, ev_csr = nullptr, ev_fork = nullptr, ev_join = nullptr;
@@ -133,6 +135,7 @@ struct PhaseHost {
   int run(const PhaseInputs& in, const lcr_params& p, hipStream_t s, std::string* err);
   void release() {
     for (auto& b : d_state) b.release();
+    d_read_rec.release();
     for (auto& b : h_pin) b.release();
     if (side) { (void)hipStreamDestroy(side); side = nullptr; }
     if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }

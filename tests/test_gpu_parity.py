@@ -1181,7 +1181,7 @@ def test_bench_several_batches_in_flight():
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--prewarm", "2", "--no-c5",
-                          "--no-cpu-baseline", "--inflight", "2"], capture_output=True, text=True, timeout=600, cwd=root)
+                          "--no-cpu-baseline", "--no-traffic", "--inflight", "2"], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
