@@ -304,6 +304,18 @@ int lcr_bam_write_phased(lcr_bam*, const char* out_path, int32_t n_regions, cons
  * "r<index>", mapq 60, flag 0 / 16, `ts:A:+` / `-` from lcr_reads.flags; BGZF at `level`, deflated on n_threads threads. */
 int lcr_bam_write_reads(const char* out_path, const char* contig, int64_t contig_len, const lcr_reads* rd, int32_t level, int32_t n_threads);
 
+/* Regions whose phase matrix is far beyond one CU are phased by persistent all-CU kernels; two such launches on one GPU --
+ * of two contexts or two processes -- must not overlap, so they are serialised per device by a process-local mutex and an
+ * flock on <dir>/grid_<pci bus id>.lock.  dir defaults to /tmp/liblcr-<uid> (created 0700); processes that share a GPU must
+ * see the same directory (containers without a common /tmp: name one on a shared mount).  A lock that cannot be taken makes
+ * lcr_phase fail with LCR_E_DEVICE -- it is never skipped. */
+int lcr_ctx_set_lock_dir(lcr_ctx*, const char* dir);
+
+/* Debug / test switches (the library reads no environment variable): key = "phase_prof", "post_host", "grid_min_entries",
+ * "grid_generic", "post_half", "enum_force_big", "enum_force_stream", "host_threads"; see PhaseDebug in
+ * csrc/lcr_phase_host.h.  Unknown key: LCR_E_ARG.  The defaults are the product behaviour. */
+int lcr_debug_set(lcr_ctx*, const char* key, int64_t value);
+
 /* Timing: HIP-event time (ms) of the last launch of each kernel on the ctx's stream. */
 enum { LCR_K_SPANS = 0 /* K0: CIGAR decode + binning */, LCR_K_PILEUP, LCR_K_CAND_FILTER, LCR_K_CAND_HIST, LCR_K_CAND_GT,
        LCR_K_FRAG_COUNT, LCR_K_FRAG_FILL, LCR_K_PHASE, LCR_NKERNELS };

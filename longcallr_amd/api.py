@@ -23,6 +23,11 @@ def _view(ptr, dtype, n):
     return np.frombuffer(buf, dtype=dtype, count=n).copy()
 
 
+_DEBUG_ENV = {"LCR_PHASE_PROF": "phase_prof", "LCR_POST_HOST": "post_host", "LCR_GRID_MIN_ENTRIES": "grid_min_entries",
+              "LCR_GRID_GENERIC": "grid_generic", "LCR_POST_HALF": "post_half", "LCR_ENUM_FORCE_BIG": "enum_force_big",
+              "LCR_ENUM_FORCE_STREAM": "enum_force_stream", "LCR_HOST_THREADS": "host_threads"}
+
+
 class Engine:
     def __init__(self, device=0, params=None, timing=False):
         self.lib = _lib.load()
@@ -36,6 +41,18 @@ class Engine:
         self._keep = None
         if timing:
             self.lib.lcr_enable_timing(self.h, 1)
+        # developer / test hooks: the library reads no environment variable; this mirror hands LCR_* switches on (tests, tools)
+        import os
+        for env, key in _DEBUG_ENV.items():
+            v = os.environ.get(env)
+            if v is not None:
+                self.debug_set(key, int(v) if v.lstrip("-").isdigit() else 1)
+        if os.environ.get("LCR_LOCK_DIR"):
+            self._chk(self.lib.lcr_ctx_set_lock_dir(self.h, os.fsencode(os.environ["LCR_LOCK_DIR"])), "lcr_ctx_set_lock_dir")
+
+    def debug_set(self, key, value):
+        self._chk(self.lib.lcr_debug_set(self.h, key.encode(), int(value)), "lcr_debug_set")
+        return self
 
     def close(self):
         if getattr(self, "h", None):

@@ -67,7 +67,7 @@ def _aux_scan(buf, p, end, cg_out=None):
             p += 1
         elif typ == "B":
             sub, cnt = chr(buf[p]), struct.unpack_from("<I", buf, p + 1)[0]
-            if tag == b"CG" and sub == "I" and cg_out is not None:
+            if tag == b"CG" and sub in "Ii" and cg_out is not None:
                 cg_out.append(np.frombuffer(buf, dtype="<u4", count=cnt, offset=p + 5).copy())
             p += 5 + cnt * {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[sub]
         else:
@@ -114,9 +114,8 @@ def read_bam(path, keep_raw=False):
         cg = []
         de, ts = _aux_scan(buf, q, p + 4 + bs, cg)
         # long CIGAR (SAM spec 4.2.2, htslib applies it when reading): placeholder <l_seq>S<n>N + the real CIGAR in CG:B,I
-        if n_cig == 2 and (cigar[0] & 15) == 4 and int(cigar[0] >> 4) == l_seq and (cigar[1] & 15) == 3:
-            if not cg:
-                raise ValueError("long-CIGAR placeholder without a CG:B,I tag")
+        # (htslib's bam_tag2cigar: mapped record, first op <l_seq>S, CG:B,I or B,i present; without the tag the record stays as it is)
+        if n_cig >= 1 and ref_id >= 0 and pos >= 0 and (cigar[0] & 15) == 4 and int(cigar[0] >> 4) == l_seq and cg:
             cigar = cg[0]
             n_cig = int(cigar.size)
         ops, lens = cigar & 15, cigar >> 4

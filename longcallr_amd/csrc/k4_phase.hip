@@ -39,6 +39,8 @@
 #include <fcntl.h>
 #include <sys/file.h>
 #include <unistd.h>
+#include <sys/stat.h>
+#include <cerrno>
 
 #include "k4_dev.h"
 #include "k4_grid.h"
@@ -999,26 +1001,54 @@ struct PhaseWork {   // host epilogue structures, reused across calls
 
 // One persistent (grid-barrier) kernel at a time per device, across host threads and processes: two such launches
 // that each hold a part of the CUs would wait for each other's workgroups forever.
+// Persistent all-CU launches of different processes (or contexts) on one GPU would wait for each other's workgroups forever:
+// they are serialised per DEVICE -- a process-local mutex keyed by the PCI bus id, and across processes an flock on
+// <lock_dir>/grid_<bus id>.lock (lock_dir: lcr_ctx_set_lock_dir; default /tmp/liblcr-<uid>, created 0700 and refused unless it
+// is a directory of this user; the file is opened O_NOFOLLOW | O_CLOEXEC).  A lock that cannot be taken is an error, never
+// silently skipped.  The destructor drains the queues it was given before it lets go (error paths return early).
 struct GridLock {
   int fd = -1;
   bool held = false;
-  static std::mutex& mu() { static std::mutex m; return m; }
-  void acquire() {
-    if (held) return;
-    mu().lock();
+  std::mutex* dev_mu = nullptr;
+  hipStream_t q[3] = {nullptr, nullptr, nullptr};
+  static std::mutex& device_mutex(const std::string& bus) {
+    static std::mutex table_mu;
+    static std::map<std::string, std::mutex*> table;
+    std::lock_guard<std::mutex> g(table_mu);
+    auto it = table.find(bus);
+    if (it == table.end()) it = table.emplace(bus, new std::mutex()).first;
+    return *it->second;
+  }
+  // returns an error text, or "" when the lock is held
+  std::string acquire(const std::string& lock_dir, hipStream_t a, hipStream_t b, hipStream_t c) {
+    if (held) return "";
+    q[0] = a; q[1] = b; q[2] = c;
     int dev = 0;
     char bus[64] = "gpu";
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetPCIBusId(bus, sizeof(bus), dev);
-    std::string path = std::string("/tmp/liblcr_grid_") + bus + ".lock";
-    for (char& ch : path) if (ch == ':') ch = '_';
-    fd = open(path.c_str(), O_CREAT | O_RDWR, 0666);
-    if (fd >= 0) while (flock(fd, LOCK_EX) != 0 && errno == EINTR) {}
+    for (char* ch = bus; *ch; ch++) if (*ch == ':' || *ch == '/') *ch = '_';
+    std::string dir = lock_dir;
+    if (dir.empty()) dir = "/tmp/liblcr-" + std::to_string((long long)getuid());
+    if (mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) return "cannot create lock directory " + dir + ": " + strerror(errno);
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid())
+      return "lock directory " + dir + " is not a directory owned by this user (lcr_ctx_set_lock_dir names another one)";
+    const std::string path = dir + "/grid_" + bus + ".lock";
+    dev_mu = &device_mutex(bus);
+    dev_mu->lock();
+    fd = open(path.c_str(), O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) { const std::string e = "cannot open " + path + ": " + strerror(errno); dev_mu->unlock(); dev_mu = nullptr; return e; }
+    int rc;
+    while ((rc = flock(fd, LOCK_EX)) != 0 && errno == EINTR) {}
+    if (rc != 0) { const std::string e = "flock(" + path + "): " + strerror(errno); close(fd); fd = -1; dev_mu->unlock(); dev_mu = nullptr; return e; }
     held = true;
+    return "";
   }
   ~GridLock() {
     if (!held) return;
+    for (hipStream_t s : q) if (s) (void)hipStreamSynchronize(s);   // (a persistent kernel may still be running on an error path)
     if (fd >= 0) { (void)flock(fd, LOCK_UN); close(fd); }
-    mu().unlock();
+    if (dev_mu) dev_mu->unlock();
   }
 };
 
@@ -1060,7 +1090,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   const int ng = in.n_regions, nrow = in.n_rows;
   const int64_t nnz = in.nnz;
   const int ncand = in.cand_region_off[ng];
-  const bool prof = getenv("LCR_PHASE_PROF") != nullptr;
+  const bool prof = dbg.prof != 0;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) { if (!prof) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[phase] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
   std::vector<lcr_candidate>& cand = *in.cand;
@@ -1127,9 +1157,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   // post-phase epilogue: k4_post (a workgroup per region, the region in LDS) for every region that fits its LDS image;
   // the host epilogue (RegionHost) for the others and, as a cross-check, for all regions under LCR_POST_HOST=1.  The
   // regions' sizes are on the host already (lcr_fragments), so this is known before anything is queued.
-  const bool force_host_post = getenv("LCR_POST_HOST") != nullptr;
-  int64_t grid_min = 1 << 17;   // chain regions with at least this many phase entries get all CUs (tests: 0 = every region)
-  if (const char* e = getenv("LCR_GRID_MIN_ENTRIES")) grid_min = atoll(e);
+  const bool force_host_post = dbg.post_host != 0;
+  const int64_t grid_min = dbg.grid_min >= 0 ? dbg.grid_min : (1 << 17);   // chain regions with at least this many phase entries get all CUs (tests: 0 = every region)
   std::vector<uint8_t> host_post(ng, 0), grid_post(ng, 0), grid_stage(ng, 0);
   bool any_host_post = false;
   uint32_t post_lds = 0;
@@ -1152,6 +1181,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     } else post_lds = std::max(post_lds, need);
   }
   GridLock grid_lock;   // held from the first persistent launch until this call returns (all queues are drained by then)
+#define GRID_LOCK() do { const std::string e_ = grid_lock.acquire(lock_dir, stream, side, aux); if (!e_.empty()) { if (err) *err = "device lock of the persistent launches: " + e_; return LCR_E_DEVICE; } } while (0)
 
   // ---- queue `side`: the fragment matrix goes to the host (pinned) only when a region takes the host epilogue
   PCHK(hipEventRecord(ev_in, stream));
@@ -1178,7 +1208,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     hipLaunchKernelGGL(k4_stage, dim3(ng), dim3(STAGE_THREADS), 0, stream, si, so, L.dev);
     PCHK(hipGetLastError());
     if (!gstage_slots.empty()) {   // large regions: all CUs on one region at a time (every persistent launch goes to `side`)
-      grid_lock.acquire();
+      GRID_LOCK();
       PCHK(b_ctl.reserve(4 * sizeof(GridCtl))); PCHK(b_btot.reserve((size_t)(2 * std::max(1, k4_grid_blocks()) + 1) * 4 + 64));
       for (int g : gstage_slots) PCHK(k4_stage_launch_grid(si, so, L.dev, g, b_ctl.as<GridCtl>(), b_btot.as<int32_t>(), side));
       PCHK(hipEventRecord(ev_join, side));
@@ -1193,8 +1223,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     int ndev = 1;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
     int nthreads = (int)std::thread::hardware_concurrency() / ndev;
-    if (const char* e = getenv("LCR_HOST_THREADS")) nthreads = atoi(e);
-    nthreads = std::max(1, std::min(nthreads, getenv("LCR_HOST_THREADS") ? 256 : 48));
+    if (dbg.host_threads > 0) nthreads = dbg.host_threads;
+    nthreads = std::max(1, std::min(nthreads, dbg.host_threads > 0 ? 256 : 48));
     pool = new HostPool(nthreads > 1 ? nthreads : 0);
   }
   if (ng) PCHK(hipStreamSynchronize(stream));
@@ -1216,10 +1246,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   if (!chain_slots.empty()) {
     // a region whose phase matrix is far beyond one CU gets all of them (persistent launch with grid barriers); the
     // others run side by side, one workgroup each.  LCR_GRID_MIN_ENTRIES moves the boundary (tests: 0 = every region).
-    int64_t grid_min = 1 << 17;
-    if (const char* e = getenv("LCR_GRID_MIN_ENTRIES")) grid_min = atoll(e);
     std::vector<int32_t> wide, big;
-    const bool grid_generic = getenv("LCR_GRID_GENERIC") != nullptr;   // test hook
+    const bool grid_generic = dbg.grid_generic != 0;   // test hook
     for (int g : chain_slots) ((int64_t)stat[g].E >= grid_min ? big : wide).push_back(g);
     // longest first: a batch with more chain regions than CUs runs them in two generations (one sixteen-wave workgroup
     // per CU), and the workgroups are started in launch order -- the second generation should be the short regions
@@ -1300,7 +1328,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       return k4_chain_launch_wg(Ck, first, (int)regs.size(), dyn_state + (size_t)want, side);
     };
     PCHK(launch_class(wide, 0, max_state, 64 * 1024));
-    if (n_big) grid_lock.acquire();
+    if (n_big) GRID_LOCK();
     for (int k = 0; k < n_big; k++) PCHK(k4_chain_launch_grid(C, n_small + k, (size_t)desc[n_small + k].fast_lds, side));
     PostIn pinc = pin;
     pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta; pinc.st_obj = Pc.st_obj;
@@ -1308,7 +1336,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       // 33 KB of static stage buffers + up to 64 KB of region image
       // more chain regions than CUs (a sixteen-wave workgroup has a CU to itself): eight waves, two regions per CU --
       // one generation of workgroups instead of two
-      if (((int)nps > std::max(1, k4_grid_blocks()) || getenv("LCR_POST_HALF") /* test hook */) && post_lds <= 56 * 1024) {
+      if (((int)nps > std::max(1, k4_grid_blocks()) || dbg.post_half /* test hook */) && post_lds <= 56 * 1024) {
         PCHK(k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_post<CHAIN_THREADS / 2>), 96 * 1024, 5));
         hipLaunchKernelGGL(k4_post<CHAIN_THREADS / 2>, dim3((unsigned)nps), dim3(CHAIN_THREADS / 2), post_lds, side, pinc, b_slots.as<int32_t>(), (int32_t)nps, plut);
       } else {
@@ -1330,8 +1358,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     for (int g : enum_slots) max_state = std::max(max_state, stat[g].R + 2 * (in.cand_region_off[g + 1] - in.cand_region_off[g]));
     const int32_t stride = (max_state + 63) & ~63;
     P.scratch_stride = stride;
-    const bool force_big = getenv("LCR_ENUM_FORCE_BIG") != nullptr;        // test hooks: exercise the fallback kernels
-    const bool force_stream = getenv("LCR_ENUM_FORCE_STREAM") != nullptr;
+    const bool force_big = dbg.enum_force_big != 0;        // test hooks: exercise the fallback kernels
+    const bool force_stream = dbg.enum_force_stream != 0;
     // class 2: register-resident kernel (<= 32 entries per lane; smaller instantiations were measured: separate
     // launches each pay their own tail, one CK=32 launch with early exits is faster); class 3: same kernel
     // streaming its entries from LDS (any share size); class 4: global-memory kernel (matrix larger than the
@@ -1442,7 +1470,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   lap("enum launch");
   // ---- post-phase steps of the regions beyond k4_post's LDS image: all CUs on one region at a time, on `side`
   if (!gpost_slots.empty()) {
-    grid_lock.acquire();
+    GRID_LOCK();
     const int grid_waves = std::max(1, k4_grid_blocks()) * 16;
     PostScratch ps{};
     ps.n_parts = (int32_t)std::max<int64_t>(16, std::min<int64_t>(grid_waves, (int64_t)(1 << 23) / (int64_t)gp_S));
@@ -1499,7 +1527,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
         const double it = (double)std::max<long long>(clk[15], 1) * 100.0;
         fprintf(stderr, "[phase]     grid chain rounds: %s step per workgroup and iteration: min %.1f (wg %d)  median %.1f  p90 %.1f  max %.1f us (wg %d)\n",
                 h ? "delta" : "sigma", t.front().first / it, t.front().second, t[t.size() / 2].first / it, t[t.size() * 9 / 10].first / it, t.back().first / it, t.back().second);
-        if (getenv("LCR_PHASE_PROF_WG")) { for (int k = 0; k < nb && k < 1024; k++) fprintf(stderr, "%s%.1f", k % 16 ? " " : "\n[phase]       ", wg[h * 1024 + k] / it); fprintf(stderr, "\n"); }
+        if (dbg.prof > 1) { for (int k = 0; k < nb && k < 1024; k++) fprintf(stderr, "%s%.1f", k % 16 ? " " : "\n[phase]       ", wg[h * 1024 + k] / it); fprintf(stderr, "\n"); }
       }
     }
     fprintf(stderr, "[phase]     grid chain: %lld iterations in the rounds\n", clk[15]);

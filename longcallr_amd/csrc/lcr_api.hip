@@ -744,6 +744,28 @@ int lcr_get_read_records_device(lcr_ctx* c, const lcr_read_record** dev_rec, int
   return LCR_OK;
 }
 
+int lcr_ctx_set_lock_dir(lcr_ctx* c, const char* dir) {
+  if (!c || !dir) return LCR_E_ARG;
+  c->phase.lock_dir = dir;
+  return LCR_OK;
+}
+
+int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
+  if (!c || !key) return LCR_E_ARG;
+  PhaseDebug& d = c->phase.dbg;
+  const std::string k(key);
+  if (k == "phase_prof") d.prof = (int)value;
+  else if (k == "post_host") d.post_host = (int)value;
+  else if (k == "grid_min_entries") d.grid_min = value;
+  else if (k == "grid_generic") d.grid_generic = (int)value;
+  else if (k == "post_half") d.post_half = (int)value;
+  else if (k == "enum_force_big") d.enum_force_big = (int)value;
+  else if (k == "enum_force_stream") d.enum_force_stream = (int)value;
+  else if (k == "host_threads") d.host_threads = (int)value;
+  else { c->err = "lcr_debug_set: unknown key " + k; return LCR_E_ARG; }
+  return LCR_OK;
+}
+
 int lcr_get_ld_blocks(lcr_ctx* c, int32_t region, int32_t* n_blocks, const int32_t** block_off, const int32_t** snp_idx) {
   if (!c || !n_blocks || !block_off || !snp_idx) return LCR_E_ARG;
   if (!c->have_phase) { c->err = "lcr_get_ld_blocks before lcr_phase"; return LCR_E_STATE; }

@@ -155,7 +155,7 @@ bool aux_scan(const uint8_t* p, const uint8_t* end, Rec& r, const uint8_t* base)
         const uint8_t sub = p[0]; const uint32_t cnt = rd32(p + 1);
         size_t w = 0;
         switch (sub) { case 'c': case 'C': w = 1; break; case 's': case 'S': w = 2; break; case 'i': case 'I': case 'f': w = 4; break; default: return false; }
-        if (t0 == 'C' && t1 == 'G' && sub == 'I' && p + 5 + (size_t)cnt * 4 <= end) { r.cg_tag_at = (uint64_t)(p + 5 - base); r.cg_tag_n = cnt; }
+        if (t0 == 'C' && t1 == 'G' && (sub == 'I' || sub == 'i') && p + 5 + (size_t)cnt * 4 <= end) { r.cg_tag_at = (uint64_t)(p + 5 - base); r.cg_tag_n = cnt; }
         p += 5 + (size_t)cnt * w; break;
       }
       default: return false;
@@ -235,10 +235,12 @@ bool index_record(Rec& r, const uint8_t* d, bool* long_bad) {
   r.cig_at = r.off + 32 + r.l_rn;
   // long CIGAR (> 65535 ops; SAM spec 4.2.2, applied by htslib when it reads a record): the core field holds the
   // placeholder <l_seq>S<ref_len>N and the real CIGAR travels in the CG:B,I tag
-  if (r.n_cig == 2 && (rd32(cg) & 15) == 4 && (int64_t)(rd32(cg) >> 4) == (int64_t)r.l_seq && (rd32(cg + 4) & 15) == 3) {
-    if (!r.cg_tag_n) { *long_bad = true; return false; }
+  // htslib's bam_tag2cigar: mapped record (tid >= 0, pos >= 0) whose first op is <l_seq>S and that carries CG:B,I (or B,i);
+  // a placeholder without the tag is left as it is (one soft clip + one intron: it covers nothing)
+  if (r.n_cig >= 1 && r.ref_id >= 0 && r.pos >= 0 && (rd32(cg) & 15) == 4 && (int64_t)(rd32(cg) >> 4) == (int64_t)r.l_seq && r.cg_tag_n) {
     cg = d + r.cg_tag_at; r.cig_at = r.cg_tag_at; r.n_cig = r.cg_tag_n;
   }
+  (void)long_bad;
   int64_t rl = 0;
   for (uint32_t k = 0; k < r.n_cig; k++) {
     const uint32_t w = rd32(cg + 4 * k), op = w & 15;

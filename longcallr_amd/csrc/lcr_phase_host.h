@@ -1,5 +1,6 @@
 // lcr_phase_host.h — host driver of the phasing stage (K4 kernels + sequential control).
 #pragma once
+#include <string>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -109,7 +110,22 @@ class HelperThread {
   std::atomic<bool> stop_{false};
 };
 
+// Debug / test switches of the phase stage (lcr_debug_set, include/lcr.h): none of them is read from the environment inside
+// the library; the defaults are the product behaviour.
+struct PhaseDebug {
+  int prof = 0;                 // "phase_prof": per-step timers to stderr (2: also the per-workgroup histogram)
+  int post_host = 0;            // "post_host": every region through the host epilogue (cross-check of k4_post)
+  long long grid_min = -1;      // "grid_min_entries": chain regions with at least this many phase entries get all CUs (-1: 2^17)
+  int grid_generic = 0;         // "grid_generic": fenced grid barriers only
+  int post_half = 0;            // "post_half": the eight-wave epilogue of the chain regions
+  int enum_force_big = 0;       // "enum_force_big" / "enum_force_stream": the fallback enumeration kernels
+  int enum_force_stream = 0;
+  int host_threads = 0;         // "host_threads": size of the host pool of the host epilogue (0: hardware threads / devices, <= 48)
+};
+
 struct PhaseHost {
+  PhaseDebug dbg;
+  std::string lock_dir;          // directory of the per-GPU lock file of persistent launches ("" = /tmp/liblcr-<uid>)
   std::vector<int8_t> haplotag;
   std::vector<uint8_t> assignment;
   std::vector<uint32_t> phase_set;
