@@ -417,13 +417,17 @@ struct GridScope {
   long long* red;      // LDS, one per wave
   unsigned long long* bc;   // LDS broadcast slots (two)
   unsigned gen;        // barriers passed so far (uniform over the grid)
+  // a SUB-GRID: workgroups {b : b % stride == first} of the launch as a scope of their own (own GridCtl).  The speculative
+  // rounds (k4_grid.hip) run one half-round per sub-grid: stride 8 puts a sub-grid on ONE XCD (workgroups go to the XCDs
+  // round-robin), so its barriers stay inside one L2's neighbourhood.  stride 0 = the whole launch.
+  int stride = 0, first = 0;
   __device__ uint8_t* lds_scratch(uint32_t* bytes) const { *bytes = 0; return nullptr; }
-  __device__ int tid() const { return blockIdx.x * blockDim.x + threadIdx.x; }
-  __device__ int nt() const { return gridDim.x * blockDim.x; }
+  __device__ int blk() const { return stride ? (int)blockIdx.x / stride : (int)blockIdx.x; }
+  __device__ int nblk() const { return stride ? (int)gridDim.x / stride : (int)gridDim.x; }
+  __device__ int tid() const { return blk() * blockDim.x + threadIdx.x; }
+  __device__ int nt() const { return nblk() * blockDim.x; }
   __device__ int wave() const { return tid() >> 6; }
   __device__ int nwaves() const { return nt() >> 6; }
-  __device__ int blk() const { return blockIdx.x; }
-  __device__ int nblk() const { return gridDim.x; }
   // FENCED = false: no L2 write-back / invalidate.  For phases whose cross-workgroup data is read and written with
   // device-coherent (agent-scope relaxed atomic, `sc1`) accesses only: immutable data then stays in the L2s across the
   // barrier (tools/grid_barrier_bench.hip: 4.7 us instead of 15-20 us per barrier, no stale reads).
@@ -437,7 +441,7 @@ struct GridScope {
     if (FENCED) __threadfence();
     const unsigned old = atomicAdd(&c->arrive, 1u + (vflag ? 0x10000u : 0u));
     unsigned any;
-    if ((old & 0xFFFFu) == gridDim.x - 1) {
+    if ((old & 0xFFFFu) == (unsigned)nblk() - 1u) {
       any = ((old >> 16) != 0u || vflag) ? 1u : 0u;
       // last arriver: the slots of parity (g+1) were read before their readers arrived here and are written again
       // only after this barrier opens

@@ -26,6 +26,7 @@
 // order).  Bfs marks nodes when it pushes them; the first visited node that has a perfect-LD pair with `nx`
 // (phase.rs:628-657) is therefore nx's BFS parent.  With ld_weight_threshold = 1 (thread.rs:166 hard-codes it) no
 // edge is ever removed; other values are rejected by lcr_phase.
+#include <climits>
 #include "k4_dev.h"
 #include <type_traits>
 #include "k4_grid.h"
@@ -645,8 +646,24 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
                                   uint8_t* dyn, long long best, int slot) {
   const int S = rd.S, R = rd.R, lane = threadIdx.x & 63;
   const int ng = (R + 63) >> 6;                         // 64-row groups
-  unsigned long long* wsw = C.sig_words + 2 * ((int64_t)(rd.sig_off >> 6) + slot);   // working sigma words
-  unsigned long long* bsw = wsw + ng;                   // best sigma words
+  unsigned long long* wsw0 = C.sig_words + 2 * ((int64_t)(rd.sig_off >> 6) + slot);   // working sigma words (sequential form)
+  unsigned long long* bsw = wsw0 + ng;                  // best sigma words
+  // SPECULATIVE HALF-ROUNDS.  Every half-round of phase.rs:1198-1233 starts from the BEST state (load_best_configuration
+  // after every cross_optimize) and draws from a fixed place of the random stream, and very few of them raise the best
+  // objective (3 of 240 / 11 of 426 on the 100 - 200 kb islands of the tests): so `lanes` consecutive half-rounds run at the
+  // same time, each on a sub-grid of every lanes-th workgroup (with 8 lanes: the workgroups of ONE XCD) with a working state
+  // of its own, and are committed in order -- the first one that raises the best objective becomes the new best and the
+  // half-rounds behind it are run again from there.  Same integers, same order of commits: bit-identical to the sequential
+  // form (lanes = 1; tests compare the two and the oracle).
+  const int lanes = (C.spec_lanes > 1 && gridDim.x % C.spec_lanes == 0 && (int)gridDim.x >= 2 * C.spec_lanes && ng <= C.spec_ng && S <= C.spec_s8) ? C.spec_lanes : 1;
+  const bool spec = lanes > 1;
+  const int my = spec ? (int)blockIdx.x % lanes : 0;
+  GridScope lane_sc = sc;                               // the scope a half-round runs in: the whole launch, or this workgroup's lane
+  if (spec) { lane_sc.c = C.spec_ctl + my; lane_sc.gen = 0; lane_sc.stride = lanes; lane_sc.first = my; }
+  GridScope& sub = spec ? lane_sc : sc;
+  unsigned long long* wsw = spec ? C.spec_sig + (int64_t)my * C.spec_ng : wsw0;
+  int8_t* dlw = spec ? C.spec_de + (int64_t)my * 2 * C.spec_s8 : v.dl;
+  int8_t* etw = spec ? dlw + C.spec_s8 : v.et;
   uint32_t* s_sig = (uint32_t*)dyn;                     // LDS: sigma bits of every row
   int8_t* s_dl = (int8_t*)(s_sig + 2 * ng); int8_t* s_et = s_dl + S;
   const int32_t* rp = v.mv.rp; const int32_t* pc = v.mv.pc; const uint8_t* pv = v.mv.pv;
@@ -654,10 +671,12 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
   const uint8_t* fp = v.mv.fp;
   const long long* scn = C.P.snp_const + 4ll * rd.snp_off;
   const PhaseLutDev& lut = C.P.lut;
-  const int w0 = sc.wave(), nw = sc.nwaves();
+  const int fw0 = sc.wave(), fnw = sc.nwaves();                          // ownership over the whole launch (set-up, commits)
+  const int fwj0 = (int)(threadIdx.x >> 6) * sc.nblk() + sc.blk();
+  const int w0 = sub.wave(), nw = sub.nwaves();                          // ownership inside a half-round's scope
   // row groups / SNPs of one workgroup lie far apart (neighbouring rows and columns are equally long: a workgroup that
   // owned a run of them would be the slowest or the fastest of every half step)
-  const int wj0 = (int)(threadIdx.x >> 6) * sc.nblk() + sc.blk();
+  const int wj0 = (int)(threadIdx.x >> 6) * sub.nblk() + sub.blk();
   __shared__ unsigned long long t_sum[4][8];   // delta step: partial sums / arrivals of the four-wave teams
   __shared__ unsigned t_cnt[4][8];
   if (threadIdx.x < 32) { t_sum[threadIdx.x >> 3][threadIdx.x & 7] = 0; t_cnt[threadIdx.x >> 3][threadIdx.x & 7] = 0; }
@@ -674,10 +693,10 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
   }
   // ---- the byte state of the generic steps (best == working) into words
   sc.sync();   // (fenced: the byte arrays were written with plain stores by other workgroups)
-  for (int j = wj0; j < ng; j += nw) {
+  for (int j = fwj0; j < ng; j += fnw) {
     const int row = 64 * j + lane;
     const unsigned long long word = __ballot(row < R && v.bsg[row] == 1);
-    if (lane == 0) { cstore(&wsw[j], word); cstore(&bsw[j], word); }
+    if (lane == 0) { cstore(&wsw0[j], word); cstore(&bsw[j], word); }
   }
   sc.sync();   // (fenced: the byte arrays were written with plain stores)
   auto cross = [&]() -> long long {   // cross_optimize(keep_conserved = false, with_genotype = false)
@@ -687,10 +706,10 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
     while (hg_inc | h_inc) {
       // ---- sigma step: delta / eta of every SNP from LDS
       long long tk0 = 0;
-      const bool tk = C.dbg && sc.tid() == 0;
+      const bool tk = C.dbg && sub.tid() == 0 && my == 0;
       auto tick = [&](int slot_) { if (tk) { const long long t = (long long)wall_clock64(); C.dbg[slot_] += t - tk0; tk0 = t; } };
       if (tk) tk0 = (long long)wall_clock64();
-      for (int i = threadIdx.x; i < S; i += blockDim.x) { s_dl[i] = cload(&v.dl[i]); s_et[i] = cload(&v.et[i]); }
+      for (int i = threadIdx.x; i < S; i += blockDim.x) { s_dl[i] = cload(&dlw[i]); s_et[i] = cload(&etw[i]); }
       __syncthreads();
       tick(8);
       const long long wg_t0 = C.dbg ? (long long)wall_clock64() : 0;   // (LCR_PHASE_PROF: every workgroup's own time in the half steps)
@@ -755,9 +774,9 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
         if (lane == 0 && nword != word) cstore(reinterpret_cast<uint32_t*>(&wsw[j]) + (u & 1), (uint32_t)(nword >> (32 * (u & 1))));   // (this unit's half of the word)
       }
       __syncthreads();
-      if (C.dbg && threadIdx.x == 0 && sc.blk() < 1024) C.dbg[16 + sc.blk()] += (long long)wall_clock64() - wg_t0;
+      if (C.dbg && threadIdx.x == 0 && my == 0 && sub.blk() < 1024) C.dbg[16 + sub.blk()] += (long long)wall_clock64() - wg_t0;
       tick(9);
-      any = sc.sync_or_light(any);
+      any = sub.sync_or_light(any);
       tick(10);
       if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
       // ---- delta / eta step: one wave per SNP, sigma bits of every row from LDS
@@ -770,7 +789,7 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
       // a team of four waves per SNP (a wave per SNP leaves the largest column as the critical path); the waves' partial
       // sums meet in LDS and the last one to arrive decides -- no barrier inside the loop
       {
-        const int team = threadIdx.x >> 8, wt = (threadIdx.x >> 6) & 3, nteams = sc.nblk() * 4, gteam = team * sc.nblk() + sc.blk();
+        const int team = threadIdx.x >> 8, wt = (threadIdx.x >> 6) & 3, nteams = sub.nblk() * 4, gteam = team * sub.nblk() + sub.blk();
         int it = 0;
         for (int base = 0; base < S; base += nteams, it++) {
           if ((it & 7) == 0 && it) __syncthreads();   // the ring of 8 slots per team wraps (uniform trip count)
@@ -807,13 +826,13 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
               const long long D0 = F + M, D1 = F + Wt - M, D2 = scn[4 * i + 2], D3 = scn[4 * i + 3];
               long long chosen = h == 0 ? D0 : (h == 1 ? D2 : D3);
               if (fp[i]) {
-                if (h == 0) { if (D1 > D0) { chosen = D1; any = 1; cstore(&v.dl[i], (int8_t)(-d)); } }
+                if (h == 0) { if (D1 > D0) { chosen = D1; any = 1; cstore(&dlw[i], (int8_t)(-d)); } }
                 else {
                   const long long n2 = D2 + lut.f_homref, n3 = D3 + lut.f_homvar;
                   const bool to3 = n3 > n2;                       // first maximum wins: homref on a tie
                   const long long ncur = h == 1 ? n2 : n3, nch = to3 ? n3 : n2;
                   if (nch > ncur) any = 1;
-                  if (to3 != (h == -1)) cstore(&v.et[i], (int8_t)(to3 ? -1 : 1));
+                  if (to3 != (h == -1)) cstore(&etw[i], (int8_t)(to3 ? -1 : 1));
                   chosen = to3 ? D3 : D2;
                 }
               }
@@ -823,53 +842,86 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
         }
       }
       __syncthreads();
-      if (C.dbg && threadIdx.x == 0 && sc.blk() < 1024) C.dbg[16 + 1024 + sc.blk()] += (long long)wall_clock64() - wg_t1;
+      if (C.dbg && threadIdx.x == 0 && my == 0 && sub.blk() < 1024) C.dbg[16 + 1024 + sub.blk()] += (long long)wall_clock64() - wg_t1;
       tick(12);
       // (summing the objective once after the last iteration instead -- the sum costs this barrier two more device
       // round trips, 17.9 vs 11.7 us -- is a wash: 3.1 iterations per call save what the closing barrier costs)
-      any = sc.sync_or_sum_light(any, acc, &obj);
+      any = sub.sync_or_sum_light(any, acc, &obj);
       tick(13);
       if (!any) hg_inc = false; else { hg_inc = true; h_inc = true; }
       if (++iters > 20) break;
     }
-    if (C.dbg && sc.tid() == 0) C.dbg[15] += iters;
+    if (C.dbg && sub.tid() == 0) C.dbg[15] += iters;
     return obj;   // = f_total + sum of w over the hits: every phase entry lies in exactly one column
   };
-  auto save = [&]() {
-    for (int j = wj0; j < ng; j += nw) if (lane == 0) cstore(&bsw[j], cload(&wsw[j]));
-    for (int i = w0; i < S; i += nw) if (lane == 0) { cstore(&v.bdl[i], cload(&v.dl[i])); cstore(&v.bet[i], cload(&v.et[i])); }
-  };
-  auto load = [&]() {
-    for (int j = wj0; j < ng; j += nw) if (lane == 0) cstore(&wsw[j], cload(&bsw[j]));
-    for (int i = w0; i < S; i += nw) if (lane == 0) { cstore(&v.dl[i], cload(&v.bdl[i])); cstore(&v.et[i], cload(&v.bet[i])); }
-  };
   const uint64_t SF = (uint64_t)S + (uint64_t)R;
-  for (int tidx = 0; tidx <= S / 4; tidx++) {
+  // the state of half-round h (0 .. 2 T - 1: even = delta perturbation, odd = sigma flips of round h / 2) applied to the working
+  // copy of this scope, which holds the best state; owner-local, no barrier inside
+  auto perturb = [&](int h) {
+    const int tidx = h >> 1;
     const uint64_t ctr_t = 2 * SF + (uint64_t)tidx * SF;
     const bool flip = (tidx & 1) == 1;
-    for (int i = w0; i < S; i += nw)
-      if (lane == 0) {
-        const double rg = u01(rd.seed, ctr_t + i);
-        if (rg < 0.1) cstore(&v.dl[i], (int8_t)(flip ? 1 : -1));
-        else if (rg >= 0.9) cstore(&v.dl[i], (int8_t)(flip ? -1 : 1));
+    if ((h & 1) == 0) {
+      for (int i = w0; i < S; i += nw)
+        if (lane == 0) {
+          const double rg = u01(rd.seed, ctr_t + i);
+          if (rg < 0.1) cstore(&dlw[i], (int8_t)(flip ? 1 : -1));
+          else if (rg >= 0.9) cstore(&dlw[i], (int8_t)(flip ? -1 : 1));
+        }
+    } else {
+      for (int j = wj0; j < ng; j += nw) {
+        const int row = 64 * j + lane;
+        const unsigned long long word = cload(&wsw[j]);
+        const unsigned long long fm = __ballot(row < R && u01(rd.seed, ctr_t + S + row) < 0.1);
+        if (lane == 0 && fm) cstore(&wsw[j], word ^ fm);
       }
-    sc.sync_light();
-    long long obj = cross();
-    if (obj > best) { best = obj; save(); }
-    load();
-    for (int j = wj0; j < ng; j += nw) {
-      const int row = 64 * j + lane;
-      const unsigned long long word = cload(&wsw[j]);
-      const unsigned long long fm = __ballot(row < R && u01(rd.seed, ctr_t + S + row) < 0.1);
-      if (lane == 0 && fm) cstore(&wsw[j], word ^ fm);
     }
-    sc.sync_light();
-    obj = cross();
-    if (obj > best) { best = obj; save(); }
-    load();
+  };
+  auto load = [&]() {   // best -> this scope's working copy (owner-local)
+    for (int j = wj0; j < ng; j += nw) if (lane == 0) cstore(&wsw[j], cload(&bsw[j]));
+    for (int i = w0; i < S; i += nw) if (lane == 0) { cstore(&dlw[i], cload(&v.bdl[i])); cstore(&etw[i], cload(&v.bet[i])); }
+  };
+  const int H = 2 * (S / 4 + 1);
+  if (!spec) {
+    auto save = [&]() {
+      for (int j = wj0; j < ng; j += nw) if (lane == 0) cstore(&bsw[j], cload(&wsw[j]));
+      for (int i = w0; i < S; i += nw) if (lane == 0) { cstore(&v.bdl[i], cload(&dlw[i])); cstore(&v.bet[i], cload(&etw[i])); }
+    };
+    for (int h = 0; h < H; h++) {   // (the working copy holds the best state here: set-up, or the load below)
+      perturb(h);
+      sub.sync_light();
+      const long long obj = cross();
+      if (obj > best) { best = obj; save(); }
+      load();
+    }
+  } else {
+    for (int h = 0; h < H;) {
+      const int mine = h + my;
+      if (mine < H) {
+        load();                 // (the best state was settled before the barrier that ended the previous batch)
+        perturb(mine);          // (owner-local on top of the owner's own loads: no barrier between them)
+        sub.sync_light();
+        const long long obj = cross();
+        if (sub.tid() == 0) cstore(&C.spec_res[my], obj);
+      } else if (sub.tid() == 0) cstore(&C.spec_res[my], (long long)LLONG_MIN);
+      sc.sync_light();
+      // commit in order: the first half-round of the batch that raises the best objective
+      int win = -1;
+      long long wobj = best;
+      for (int l = 0; l < lanes; l++) { const long long o = cload(&C.spec_res[l]); if (win < 0 && o > best) { win = l; wobj = o; } }
+      if (win >= 0) {
+        best = wobj;
+        const unsigned long long* ssrc = C.spec_sig + (int64_t)win * C.spec_ng;
+        const int8_t* dsrc = C.spec_de + (int64_t)win * 2 * C.spec_s8; const int8_t* esrc = dsrc + C.spec_s8;
+        for (int j = fwj0; j < ng; j += fnw) if (lane == 0) cstore(&bsw[j], cload(&ssrc[j]));
+        for (int i = fw0; i < S; i += fnw) if (lane == 0) { cstore(&v.bdl[i], cload(&dsrc[i])); cstore(&v.bet[i], cload(&esrc[i])); }
+        h += win + 1;
+      } else h += lanes;
+      sc.sync_light();          // the new best is in place (and spec_res may be written again)
+    }
   }
   // ---- result: best sigma words back to bytes (delta / eta best arrays are up to date)
-  for (int j = wj0; j < ng; j += nw) {
+  for (int j = fwj0; j < ng; j += fnw) {
     const int row = 64 * j + lane;
     const unsigned long long word = cload(&bsw[j]);
     if (row < R) v.bsg[row] = ((word >> lane) & 1ull) ? 1 : -1;
@@ -1189,6 +1241,7 @@ hipError_t k4_chain_launch_grid(const ChainDev& C, int which, size_t dyn_lds, hi
   if (nb <= 0) return hipErrorInvalidDevice;
   hipError_t e = hipMemsetAsync(C.ctl, 0, sizeof(GridCtl), s);
   if (e != hipSuccess) return e;
+  if (C.spec_lanes > 1) { e = hipMemsetAsync(C.spec_ctl, 0, sizeof(GridCtl) * (size_t)C.spec_lanes, s); if (e != hipSuccess) return e; }
   e = k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_chain_grid), K4_GRID_FAST_LDS_MAX, 2);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k4_chain_grid, dim3((unsigned)nb), dim3(CH_THREADS), dyn_lds, s, C, (int32_t)which);

@@ -1209,7 +1209,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(hipGetLastError());
     if (!gstage_slots.empty()) {   // large regions: all CUs on one region at a time (every persistent launch goes to `side`)
       GRID_LOCK();
-      PCHK(b_ctl.reserve(4 * sizeof(GridCtl))); PCHK(b_btot.reserve((size_t)(2 * std::max(1, k4_grid_blocks()) + 1) * 4 + 64));
+      PCHK(b_ctl.reserve((4 + 16) * sizeof(GridCtl))); PCHK(b_btot.reserve((size_t)(2 * std::max(1, k4_grid_blocks()) + 1) * 4 + 64));
       for (int g : gstage_slots) PCHK(k4_stage_launch_grid(si, so, L.dev, g, b_ctl.as<GridCtl>(), b_btot.as<int32_t>(), side));
       PCHK(hipEventRecord(ev_join, side));
       PCHK(hipStreamWaitEvent(stream, ev_join, 0));
@@ -1287,8 +1287,16 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     const size_t ni = nc1 + (size_t)ng + 1;   // per-SNP int32 arrays: adj_ptr, blk_ptr (ni each), blk_of, blk_pos, blk_nodes, queue (nc1), stack (2 nc1)
     PCHK(b_snpi.reserve((2 * ni + 6 * nc1) * 4 + 64)); PCHK(b_snpb.reserve(3 * nc1 + 64)); PCHK(b_q.reserve(2 * nc1 * 8 + 64));
     PCHK(b_info.reserve((size_t)std::max(ng, 1) * 8 + 64)); PCHK(b_rowi.reserve(nr1 * 4 + 64)); PCHK(b_enti.reserve(2 * nnz1 * 4 + 64));
-    PCHK(b_work.reserve(st_bytes + 64)); PCHK(b_macc.reserve(nc1 * 8 + 64)); PCHK(d_state[39].reserve((2 * (nr1 / 64 + (size_t)ng + 2)) * 8 + 64)); PCHK(b_ctl.reserve(4 * sizeof(GridCtl)));
+    PCHK(b_work.reserve(st_bytes + 64)); PCHK(b_macc.reserve(nc1 * 8 + 64)); PCHK(d_state[39].reserve((2 * (nr1 / 64 + (size_t)ng + 2)) * 8 + 64)); PCHK(b_ctl.reserve((4 + 16) * sizeof(GridCtl)));
     ChainDev C{};
+    {   // speculative half-rounds of the all-CU regions: lanes x (sigma words | delta, eta bytes | result) of the largest such region
+      size_t ng_max = 1, s_max = 16;
+      for (int k = n_small; k < nc; k++) { const int g = desc[k].slot; ng_max = std::max(ng_max, (size_t)(stat[g].R + 63) / 64 + 1); s_max = std::max(s_max, (size_t)(in.cand_region_off[g + 1] - in.cand_region_off[g])); }
+      const size_t s8 = (s_max + 15) & ~(size_t)15, lanes = (size_t)std::max(1, dbg.spec_lanes);
+      PCHK(d_spec_sig.reserve(lanes * ng_max * 8 + 64)); PCHK(d_spec_de.reserve(lanes * 2 * s8 + 64)); PCHK(d_spec_res.reserve(lanes * 8 + 64));
+      C.spec_sig = d_spec_sig.as<unsigned long long>(); C.spec_de = d_spec_de.as<int8_t>(); C.spec_res = d_spec_res.as<long long>();
+      C.spec_lanes = (int32_t)lanes; C.spec_ng = (int32_t)ng_max; C.spec_s8 = (int32_t)s8;
+    }
     Pc.scratch = nullptr; Pc.scratch_stride = 0; Pc.lds_state = 0; Pc.lds_mat = 0;
     C.P = Pc;
     C.desc = b_desc.as<ChainDesc>();
@@ -1304,7 +1312,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     C.blk_info = b_info.as<int32_t>();
     C.flipcol = b_rowi.as<int32_t>(); C.erow = b_enti.as<int32_t>(); C.cent = C.erow + nnz1;
     C.w_sigma = b_work.as<int8_t>() + st_sig; C.w_delta = b_work.as<int8_t>() + st_del; C.w_eta = b_work.as<int8_t>() + st_eta;
-    C.macc = b_macc.as<unsigned long long>(); C.ctl = b_ctl.as<GridCtl>(); C.sig_words = d_state[39].as<unsigned long long>();
+    C.macc = b_macc.as<unsigned long long>(); C.ctl = b_ctl.as<GridCtl>(); C.spec_ctl = b_ctl.as<GridCtl>() + 4; C.sig_words = d_state[39].as<unsigned long long>();
     for (int q = 0; q < 31; q++) { C.le[q] = L.le[q]; C.l1e[q] = L.l1e[q]; }
     C.p_homref = L.p_homref; C.p_homvar = L.p_homvar; C.log_theta = L.log_theta; C.log2 = L.log2;
     if (prof) { C.dbg = d_state[20].as<long long>() + (size_t)ng * 16; PCHK(hipMemsetAsync(C.dbg, 0, (16 + 2 * 1024) * 8, side)); }   // 16 step timers + per-workgroup sigma / delta step times
@@ -1478,7 +1486,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(b_ps.reserve(S8 * (3 * 8 + 4 * 4 + 4) + R8 * (4 + 5) + 64));   // per SNP: 3 doubles, 4 int32, 4 bytes; per row: rptr + 5 bytes
     PCHK(b_pse.reserve(E8 * (3 * 4 + 1) + 64));
     PCHK(b_psp.reserve((size_t)ps.n_parts * gp_S * 4 + 64));
-    PCHK(b_ctl.reserve(4 * sizeof(GridCtl)));
+    PCHK(b_ctl.reserve((4 + 16) * sizeof(GridCtl)));
     uint8_t* p = b_ps.as<uint8_t>();
     ps.sps = (double*)p; p += 8 * S8; ps.rpa = (double*)p; p += 8 * S8; ps.rpb = (double*)p; p += 8 * S8;
     ps.sflags = (uint32_t*)p; p += 4 * S8; ps.soflags = (uint32_t*)p; p += 4 * S8; ps.parent = (int32_t*)p; p += 4 * S8; ps.ccptr = (int32_t*)p; p += 4 * S8;

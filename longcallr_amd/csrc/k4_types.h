@@ -62,6 +62,10 @@ struct ChainDev {
   int8_t* w_sigma; int8_t* w_delta; int8_t* w_eta; unsigned long long* macc;
   unsigned long long* sig_words;  // grid scope: sigma as bit vectors, 2 x ceil(R / 64) words per region at 2 * (sig_off / 64 + region)
   GridCtl* ctl;
+  // speculative rounds at grid scope (k4_grid.hip chain_rounds_fast): spec_lanes sub-grids, each with a working state of its own
+  // (sigma words: spec_ng per lane; delta | eta bytes: 2 x spec_s8 per lane), its result and its barrier words
+  unsigned long long* spec_sig; int8_t* spec_de; long long* spec_res; GridCtl* spec_ctl;
+  int32_t spec_lanes, spec_ng, spec_s8;
   long long* dbg;                 // LCR_PHASE_PROF: 100 MHz timestamps of the chain steps of a grid launch, 16 per launch (else nullptr)
   double le[31], l1e[31], p_homref, p_homvar, log_theta, log2;   // libm values of the block-flip sums (host table)
 };

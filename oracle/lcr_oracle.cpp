@@ -329,6 +329,7 @@ struct orc_region {
   double best_objective = 0;
   int64_t stats[4] = {0, 0, 0, 0};
   std::map<int, uint32_t> read_phase_set; /* fragment idx -> PS */
+  std::vector<uint8_t>* round_log = nullptr; /* orc_round_log: 1 per half-round of phase.rs:1198-1233 that raised largest_prob */
 
   double rnd() { return orc_u01(seed, ctr++); }
 
@@ -1086,14 +1087,14 @@ struct orc_region {
           else if (rg >= 0.9) c.haplotype = flip ? -1 : 1;
         }
         prob = cross_optimize(mode, conserved, false, false);
-        if (better(prob)) save_best(best);
+        { const bool b_ = better(prob); if (b_) save_best(best); if (round_log) round_log->push_back(b_ ? 1 : 0); }
         load_best(best);
         for (auto& f : frags) {
           if (!f.for_phasing || f.haplotag == 0) continue;
           if (rnd() < 0.1) f.haplotag *= -1;
         }
         prob = cross_optimize(mode, conserved, false, false);
-        if (better(prob)) save_best(best);
+        { const bool b_ = better(prob); if (b_) save_best(best); if (round_log) round_log->push_back(b_ ? 1 : 0); }
         load_best(best);
       }
       load_best(best);
@@ -1460,6 +1461,14 @@ void orc_get_phase(const orc_region* r, int8_t* haplotag, uint8_t* assignment, u
     phase_set[k] = f == r->read_phase_set.end() ? 0 : f->second;
   }
   *objective = r->best_objective;
+}
+/* which half-rounds of the perturbation loop (phase.rs:1198-1233) improved the best objective: call before orc_phase; returns
+ * the number of half-rounds logged so far, copies min(n, cap) flags */
+int32_t orc_round_log(orc_region* r, uint8_t* out, int32_t cap) {
+  if (!r->round_log) { r->round_log = new std::vector<uint8_t>(); return 0; }
+  const int32_t n = (int32_t)r->round_log->size();
+  for (int32_t i = 0; i < n && i < cap; i++) out[i] = (*r->round_log)[i];
+  return n;
 }
 void orc_get_stats(const orc_region* r, int64_t* out4) { for (int i = 0; i < 4; i++) out4[i] = r->stats[i]; }
 int64_t orc_vcf_text(orc_region* r, const char* chrom, char* buf, int64_t cap) {

@@ -84,6 +84,9 @@ void orc_get_phase(const orc_region*, int8_t* haplotag, uint8_t* assignment, uin
 /* counters: [0] cross_optimize calls, [1] total iterations, [2] f64-vs-exact decision
  * disagreements seen (rounding-noise ties), [3] monotonicity assert violations */
 void orc_get_stats(const orc_region*, int64_t* out4);
+/* first call (before orc_phase): start logging which half-rounds of the perturbation loop (phase.rs:1198-1233) raise the best
+ * objective; later calls return the flags (what a speculative execution of several half-rounds at once can count on) */
+int32_t orc_round_log(orc_region*, uint8_t* out, int32_t cap);
 /* VCF body text of this region (vcf.rs:27-306 + thread.rs:266-303); returns length */
 int64_t orc_vcf_text(orc_region*, const char* chrom, char* buf, int64_t cap);
 
