@@ -1013,8 +1013,8 @@ def test_c5_island_against_the_oracle(engine_cls, orc):
 
 
 def test_c5_scopes_and_paths_agree(engine_cls, monkeypatch):
-    """One island (200 kb x 150x) through the forms of the chain kernel -- all CUs with device-coherent rounds run eight
-    half-rounds at a time speculatively (default at this size), the same with 1 / 4 / 16 lanes, all CUs with fenced
+    """One island (200 kb x 150x) through the forms of the chain kernel -- all CUs with device-coherent rounds run four
+    half-rounds at a time speculatively (default at this size), the same with 1 / 8 / 16 lanes, all CUs with fenced
     barriers only (LCR_GRID_GENERIC), one workgroup -- and through the host epilogue: identical bytes."""
     b = synth.make_island("ont-drna-c5", n_loci=8, locus_len=25000, depth=150, seed=4)
     p = _abi.make_params("ont-drna", seed=12)
@@ -1026,8 +1026,8 @@ def test_c5_scopes_and_paths_agree(engine_cls, monkeypatch):
         r = _result_bytes(E) + (repr(E.ld_blocks(0)),)
         E.close()
         return r
-    ref = run()      # (default: eight speculative half-rounds at a time, one per XCD-sized sub-grid)
-    for lanes in ("1", "4", "16"):   # one half-round after the other; other batch widths: same commits, same bytes
+    ref = run()      # (default: four speculative half-rounds at a time, each on a quarter of the workgroups)
+    for lanes in ("1", "8", "16"):   # one half-round after the other; other batch widths: same commits, same bytes
         monkeypatch.setenv("LCR_GRID_SPEC_LANES", lanes)
         assert run() == ref, "speculative rounds with %s lanes" % lanes
     monkeypatch.delenv("LCR_GRID_SPEC_LANES")
