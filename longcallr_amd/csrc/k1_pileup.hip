@@ -692,14 +692,14 @@ k1_zonefix(BatchView b, int D, int L, int64_t n_cols, uint32_t* __restrict__ pla
 void launch_k1_zonefix_slots(const BatchView& b, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s);
 // K1z, one thread per read END (dist_to_end <= 63): the per-offset kernel above loads and scans an overlapping
 // 2L+1 byte window for each of the 2D offsets of a read; here a thread loads the <= D + 2L bytes its zone's
-// windows can touch once (16-byte loads into LDS), finds every homopolymer window [t, t+L-1] of X in {A,C,G,T}
-// in one pass and marks the offsets c in [t-1, t+L] it masks (the same rule: window start in [c-L, c+1]) in a
-// 64-bit mask per base; most read ends have none and stop there.  The marked offsets are then walked with a CIGAR
-// cursor (forwards in the leading zone, backwards from the read's reference end in the trailing zone).
-#define ZF_BYTES 112   // LDS bytes per thread: (63 + 2 * 16) zone bytes + 15 alignment slack, rounded to 16
+// windows can touch once (seven 16-byte loads into registers), finds the homopolymer windows four bytes per step
+// (adjacent-byte equality flags -> a 128-bit mask -> L-1 consecutive flags = a window start) and, per run of
+// window starts [t, t'] of X in {A,C,G,T}, marks the offsets c in [t-1, t'+L] it masks (the same rule: window
+// start in [c-L, c+1]) in a 64-bit mask per base; most read ends have none and stop there.  The marked offsets are
+// then walked with a CIGAR cursor (forwards in the leading zone, backwards from the read's reference end in the
+// trailing zone).
 __global__ void __launch_bounds__(LCR_BLOCK)
 k1_zonefix_ends(BatchView b, const ReadBin* __restrict__ rbin, int D, int L, int64_t n_cols, uint32_t* __restrict__ planes) {
-  __shared__ __attribute__((aligned(16))) uint8_t zb[LCR_BLOCK * ZF_BYTES];
   const int id = blockIdx.x * LCR_BLOCK + threadIdx.x;
   const int r = id >> 1, end = id & 1;
   if (r >= b.n_reads) return;
@@ -708,37 +708,67 @@ k1_zonefix_ends(BatchView b, const ReadBin* __restrict__ rbin, int D, int L, int
   const int zhi = end == 0 ? min(lead + D, reb) - 1 : reb - 1;
   if (zlo > zhi) return;
   const int lo = max(zlo - L, 0), hi = min(zhi + L, seq_len - 1);
+  const int n = hi - lo + 1;                                  // <= 63 + 2 * 16 = 95 bytes
+  if (n < L) return;
+  const uint8_t* __restrict__ seq = b.bases + b.seq_off[r];
   const long long g0 = (long long)b.seq_off[r] + lo, ga = g0 & ~15ll;
   const int sh = (int)(g0 - ga);
-  uint8_t* mine = zb + threadIdx.x * ZF_BYTES;
-  for (int o = 0; o < sh + (hi - lo + 1); o += 16) {
+  // the <= 112 bytes [ga, ga + 112) in registers: seven 16-byte loads in flight at once, byte i of the window is read byte lo + i - sh
+  uint32_t d[29];
+#pragma unroll
+  for (int o = 0; o < 7; o++) {
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (ga + o + 16 <= b.n_bases) v = *reinterpret_cast<const uint4*>(b.bases + ga + o);
-    else { uint32_t t[4] = {0, 0, 0, 0}; for (int x = 0; x < 16; x++) if (ga + o + x < b.n_bases) t[x >> 2] |= (uint32_t)b.bases[ga + o + x] << (8 * (x & 3)); v = make_uint4(t[0], t[1], t[2], t[3]); }
-    *reinterpret_cast<uint4*>(mine + o) = v;
+    if (o * 16 < sh + n) {
+      if (ga + o * 16 + 16 <= b.n_bases) v = *reinterpret_cast<const uint4*>(b.bases + ga + o * 16);
+      else { uint32_t t[4] = {0, 0, 0, 0}; for (int x = 0; x < 16; x++) if (ga + o * 16 + x < b.n_bases) t[x >> 2] |= (uint32_t)b.bases[ga + o * 16 + x] << (8 * (x & 3)); v = make_uint4(t[0], t[1], t[2], t[3]); }
+    }
+    d[4 * o] = v.x; d[4 * o + 1] = v.y; d[4 * o + 2] = v.z; d[4 * o + 3] = v.w;
   }
-  const uint8_t* by = mine + sh - lo;   // by[i] = read byte i for lo <= i <= hi
+  d[28] = 0;
+  // eq bit i: byte i == byte i + 1 (four bytes per step: xor with the stream shifted by one byte, exact zero-byte flags, gathered to a nibble)
+  uint32_t ew[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 28; k++) {
+    const uint32_t x = d[k] ^ __builtin_amdgcn_alignbyte(d[k + 1], d[k], 1);
+    const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);      // 0x80 in every zero byte of x
+    ew[k >> 3] |= (((z >> 7) * 0x10204080u) >> 28) << (4 * (k & 7));
+  }
+  unsigned long long e0 = (unsigned long long)ew[0] | ((unsigned long long)ew[1] << 32), e1 = (unsigned long long)ew[2] | ((unsigned long long)ew[3] << 32);
+  {   // only pairs inside the window: bits [sh, sh + n - 2]
+    const int a0 = sh, a1 = sh + n - 2;   // a1 <= 15 + 93 = 108
+    const unsigned long long below0 = a0 >= 64 ? ~0ull : ((1ull << a0) - 1ull), below1 = a0 >= 64 ? ((1ull << (a0 - 64)) - 1ull) : 0ull;
+    const unsigned long long upto0 = a1 >= 63 ? ~0ull : ((2ull << a1) - 1ull), upto1 = a1 >= 64 ? ((2ull << (a1 - 64)) - 1ull) : 0ull;
+    e0 &= upto0 & ~below0; e1 &= upto1 & ~below1;
+  }
+  // w bit i: a window of L identical bytes starts at byte i  (eq[i] & eq[i+1] & ... & eq[i+L-2])
+  unsigned long long w0 = e0, w1 = e1;
+  for (int j = 1; j <= L - 2; j++) { w0 &= (e0 >> j) | (e1 << (64 - j)); w1 &= e1 >> j; }
   unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};   // per base X: offsets c - zlo masked by a window of X
-  {
-    int run = 0; uint32_t prev = 0x100u;
-    for (int i = lo; i <= hi; i++) {
-      const uint32_t cur = by[i];
-      run = cur == prev ? run + 1 : 1;
-      prev = cur;
-      if (run >= L) {
-        const int x = cur == 'A' ? 0 : cur == 'C' ? 1 : cur == 'G' ? 2 : cur == 'T' ? 3 : -1;
-        if (x >= 0) {   // window start t = i - L + 1 masks c in [t-1, t+L] = [i-L, i+1]
-          const int c0 = max(i - L, zlo) - zlo, c1 = min(i + 1, zhi) - zlo;
-          if (c0 <= c1) {
-            const unsigned long long rng = (c1 >= 63 ? ~0ull : ((2ull << c1) - 1ull)) & ~((1ull << c0) - 1ull);
-            m[x] |= rng;
-          }
-        }
-      }
+  while ((w0 | w1) != 0ull) {
+    // one homopolymer run: its window starts are the consecutive set bits [t0, t0 + cnt)
+    const int t0 = w0 != 0ull ? __builtin_ctzll(w0) : 64 + __builtin_ctzll(w1);
+    unsigned long long s0, s1;   // the mask shifted down to t0
+    if (t0 >= 64) { s0 = w1 >> (t0 - 64); s1 = 0ull; } else if (t0 == 0) { s0 = w0; s1 = w1; } else { s0 = (w0 >> t0) | (w1 << (64 - t0)); s1 = w1 >> t0; }
+    const int cnt = ~s0 != 0ull ? __builtin_ctzll(~s0) : 64 + __builtin_ctzll(~s1);
+    {   // clear bits [t0, t0 + cnt)
+      const int c1 = t0 + cnt;   // exclusive, <= 128
+      const unsigned long long lo0 = t0 >= 64 ? ~0ull : ((1ull << t0) - 1ull), lo1 = t0 >= 64 ? ((1ull << (t0 - 64)) - 1ull) : 0ull;
+      const unsigned long long hi0 = c1 >= 64 ? ~0ull : ((1ull << c1) - 1ull), hi1 = c1 >= 128 ? ~0ull : c1 > 64 ? ((1ull << (c1 - 64)) - 1ull) : 0ull;
+      w0 &= ~(hi0 & ~lo0); w1 &= ~(hi1 & ~lo1);
+    }
+    const int tr = lo + (t0 - sh);                          // read offset of the first window start
+    const uint32_t cur = seq[tr];
+    const int x = cur == 'A' ? 0 : cur == 'C' ? 1 : cur == 'G' ? 2 : cur == 'T' ? 3 : -1;
+    if (x >= 0) {   // window start t masks c in [t-1, t+L]; starts tr .. tr+cnt-1
+      const int c0 = max(tr - 1, zlo) - zlo, c1 = min(tr + cnt - 1 + L, zhi) - zlo;
+      if (c0 <= c1) m[x] |= (c1 >= 63 ? ~0ull : ((2ull << c1) - 1ull)) & ~((1ull << c0) - 1ull);
     }
   }
   unsigned long long any = m[0] | m[1] | m[2] | m[3];
   if (any == 0ull) return;
+#if defined(ZF_ABL) && ZF_ABL == 1
+  if (any != 0x1234567ull) return;
+#endif
   const int g = region_of_read(b, r);
   const int vec = b.len[g];
   const uint32_t* __restrict__ cg = b.cigar + b.cig_off[r];
@@ -749,44 +779,62 @@ k1_zonefix_ends(BatchView b, const ReadBin* __restrict__ rbin, int D, int L, int
   auto fix = [&](int c, int col) {   // base at read offset c sits on column col: undo its counts if a window of X != ref masks it
     if (col < 0 || col >= vec) return;
     const int64_t o = cbase + col;
+#if defined(ZF_ABL) && ZF_ABL == 2
+    const uint8_t R = 'N';
+#else
     const uint8_t R = b.ref[o];
+#endif
     const int k = c - zlo;
     const uint32_t mm = (uint32_t)((m[0] >> k) & 1ull) | ((uint32_t)((m[1] >> k) & 1ull) << 1) | ((uint32_t)((m[2] >> k) & 1ull) << 2) |
                         ((uint32_t)((m[3] >> k) & 1ull) << 3);
     const uint32_t rbit = R == 'A' ? 1u : R == 'C' ? 2u : R == 'G' ? 4u : R == 'T' ? 8u : 0u;
     if ((mm & ~rbit) == 0) return;
-    const int bi = base_code(by[c]);
+    const int bi = base_code(seq[c]);
     if (bi >= 0) {
       atomicSub(&planes[(int64_t)(LCR_PL_A + bi) * n_cols + o], 1u);
       if (strand == 0) atomicSub(&planes[(int64_t)(LCR_PL_FWD_A + bi) * n_cols + o], 1u);
     }
     if (ts != 0) atomicSub(&planes[(int64_t)(((strand == 0) == (ts == 1)) ? LCR_PL_TS_FWD : LCR_PL_TS_REV) * n_cols + o], 1u);
   };
-  if (end == 0) {   // forwards: ops in read order, every marked offset inside an M op gets its column
-    int p = (int)((int64_t)b.pos[r] - b.start0[g]), q = lead > 0 ? lead : 0;
-    for (int i = 0; i < ncig && q <= zhi; i++) {
-      const int op = cg[i] & 15, len = (int)(cg[i] >> 4);
-      if (op == 0 || op == 7 || op == 8) {
-        for (int c = max(q, zlo); c < q + len && c <= zhi; c++) if ((any >> (c - zlo)) & 1ull) fix(c, p + (c - q));
-        p += len; q += len;
-      } else if (op == 1) q += len;
-      else if (op == 2 || op == 3) p += len;
+  // one pass over the MARKED offsets only (ascending in the leading zone, descending in the trailing one) with a CIGAR cursor
+  // that moves monotonically: the lanes of a wave diverge here, so the trip count is the number of marked bases, not the zone size
+  if (end == 0) {
+    int i = 0, p = (int)((int64_t)b.pos[r] - b.start0[g]), q = lead > 0 ? lead : 0;
+    uint32_t cv = ncig > 0 ? cg[0] : 0u;
+    while (any != 0ull && i < ncig) {
+      const int c = zlo + __builtin_ctzll(any);
+      const int op = (int)(cv & 15u), len = (int)(cv >> 4);
+      const bool isM = op == 0 || op == 7 || op == 8;
+      const int ql = (isM || op == 1) ? len : 0;
+      if (c < q + ql) {                   // the op holding read offset c (an insertion has no column)
+        any &= any - 1ull;
+        if (isM) fix(c, p + (c - q));
+      } else {
+        q += ql; p += (isM || op == 2 || op == 3) ? len : 0;
+        i++; cv = i < ncig ? cg[i] : 0u;
+      }
     }
   } else {          // backwards from the read's reference end (recorded by K0)
-    int p = b.read_rend[r], q = reb;
-    for (int i = ncig - 1; i >= 0 && q > zlo; i--) {
-      const int op = cg[i] & 15, len = (int)(cg[i] >> 4);
-      if (op == 0 || op == 7 || op == 8) {
-        for (int c = min(q - 1, zhi); c >= q - len && c >= zlo; c--) if ((any >> (c - zlo)) & 1ull) fix(c, p - (q - c));
-        p -= len; q -= len;
-      } else if (op == 1) q -= len;
-      else if (op == 2 || op == 3) p -= len;
+    int i = ncig - 1, p = b.read_rend[r], q = reb;   // one past the last column / aligned read offset of op i
+    uint32_t cv = ncig > 0 ? cg[ncig - 1] : 0u;
+    while (any != 0ull && i >= 0) {
+      const int c = zlo + 63 - __builtin_clzll(any);
+      const int op = (int)(cv & 15u), len = (int)(cv >> 4);
+      const bool isM = op == 0 || op == 7 || op == 8;
+      const int ql = (isM || op == 1) ? len : 0;
+      if (c >= q - ql) {
+        any &= ~(1ull << (c - zlo));
+        if (isM) fix(c, p - (q - c));
+      } else {
+        q -= ql; p -= (isM || op == 2 || op == 3) ? len : 0;
+        i--; cv = i >= 0 ? cg[i] : 0u;
+      }
     }
   }
 }
 
 void launch_k1_zonefix(const BatchView& b, const ReadBin* rbin, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s) {
-  if (b.n_reads > 0 && D > 0 && D <= 63 && L <= 16) {
+  if (b.n_reads > 0 && D > 0 && D <= 63 && L >= 2 && L <= 16) {   // (L = 1: every base is a window, the per-offset kernel)
     const int n = 2 * b.n_reads;
     hipLaunchKernelGGL(k1_zonefix_ends, dim3((unsigned)((n + LCR_BLOCK - 1) / LCR_BLOCK)), dim3(LCR_BLOCK), 0, s, b, rbin, D, L, n_cols, planes);
     return;
