@@ -13,7 +13,7 @@ inline size_t k4_grid_fast_lds(int64_t R, int64_t S) { return (size_t)(8 * ((R +
 int k4_grid_blocks();
 // k4_stage for one large region with all CUs; blk_tot: 2 * k4_grid_blocks() + 1 int32 of scratch
 hipError_t k4_stage_launch_grid(const StageIn& in, const StageOut& out, const PhaseLutDev& lut, int g, GridCtl* ctl, int32_t* blk_tot, hipStream_t s);
-// post-phase steps for one large region with all CUs (post_in: the PostIn of k4_post.h)
-hipError_t k4_post_launch_grid(const void* post_in, const PostScratch& ps, int g, const PostLut& lut, hipStream_t s);
+// post-phase steps for one large region with all CUs
+hipError_t k4_post_launch_grid(const PostIn& post_in, const PostScratch& ps, int g, const PostLut& lut, hipStream_t s);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel slot 0..7, device)
 hipError_t k4_set_dyn_lds_once(const void* fn, int bytes, int slot);

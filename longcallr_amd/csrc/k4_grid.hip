@@ -1257,11 +1257,11 @@ hipError_t k4_stage_launch_grid(const StageIn& in, const StageOut& out, const Ph
   return hipGetLastError();
 }
 
-hipError_t k4_post_launch_grid(const void* post_in, const PostScratch& ps, int g, const PostLut& lut, hipStream_t s) {
+hipError_t k4_post_launch_grid(const PostIn& post_in, const PostScratch& ps, int g, const PostLut& lut, hipStream_t s) {
   const int nb = k4_grid_blocks();
   if (nb <= 0) return hipErrorInvalidDevice;
   hipError_t e = hipMemsetAsync(ps.ctl, 0, sizeof(GridCtl), s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k4_gpost, dim3((unsigned)nb), dim3(CH_THREADS), 0, s, *static_cast<const PostIn*>(post_in), ps, (int32_t)g, lut);
+  hipLaunchKernelGGL(k4_gpost, dim3((unsigned)nb), dim3(CH_THREADS), 0, s, post_in, ps, (int32_t)g, lut);
   return hipGetLastError();
 }

@@ -1,19 +1,18 @@
-// k4_phase.hip — K4: haplotype phasing on gfx950 (matrix staging, optimiser, post-phase) + its host control.
+// k4_phase.hip — K4: haplotype phasing on gfx950, HOST CONTROL (buffer sizing, launches, the LD-block flip pass, host epilogue).
 //
 // Replaces SNPFrag::phase (reference src/phase.rs:1087-1296) with its kernel cross_optimize
 // (phase.rs:810-976) and the probability functions phase.rs:32-49,77-96,128-176,257-276, plus the
 // post-phase sequence of src/thread.rs:168-201 (snpfrags.rs:191-733).
 //
-// Kernels (in launch order; one queue stages + enumerates + post-processes, a second queue carries the
-// few chain regions, see PhaseHost::run):
-//   k4_stage      phase matrices (CSR + CSC, per-SNP constants) of every region from K3's fragment CSR
-//   k4_enum_reg   S <= max_enum_snps: all 2^S enumeration restarts (phase.rs:1097-1122), one wave64 per
-//                 restart with the matrix in registers; k4_enum_big = fallback on global memory
-//   k4_enum_pick  winner = first maximum (`prob > largest_prob`); it is re-run to materialise its state
-//   k4_chain_a/b  S > max_enum_snps: the sequential chain (phase.rs:1123-1233), one workgroup per region:
-//                 launch A = first cross_optimize; the host does the LD-block flip pass (sum-of-ratios f64
-//                 decision, phase.rs:1298-1394); launch B = all perturbation rounds with best-state tracking
-//   k4_post       post-phase assignment, rescue and phase sets (f64, reference observation order)
+// Kernel units (in launch order; one queue stages + enumerates + post-processes, a second queue carries the
+// few chain regions, see PhaseHost::run); k4_kernels.h / k4_grid.h hold their launchers and LDS layouts:
+//   k4_stage.hip  k4_stage      phase matrices (CSR + CSC, per-SNP constants) of every region from K3's fragment CSR
+//   k4_enum.hip   k4_enum_reg   S <= max_enum_snps: all 2^S enumeration restarts (phase.rs:1097-1122), one wave64 per
+//                               restart with the matrix in registers; k4_enum_big = fallback on global memory
+//                 k4_enum_pick  winner = first maximum (`prob > largest_prob`); it is re-run to materialise its state
+//   k4_grid.hip   k4_chain_wg / k4_chain_grid   S > max_enum_snps: the sequential chain (phase.rs:1123-1233) with one
+//                               workgroup per region, or all CUs on one large region (LD-block flip pass, perturbation rounds)
+//   k4_post.hip   k4_post       post-phase assignment, rescue and phase sets (f64, reference observation order)
 // cross_optimize alternates sigma / delta-eta Jacobi steps until neither improves (<= 21 iterations).
 // Its decision arithmetic is exact: every emission term log10(eps_q) / log10(1-eps_q) comes from a
 // 31-entry table in fixed point (scale 2^40, int64), so sums are order-free and every comparison
@@ -45,720 +44,9 @@
 #include "k4_dev.h"
 #include "k4_grid.h"
 #include "k4_post.h"
+#include "k4_kernels.h"
 
 namespace {
-
-
-// ---------------------------------------------------------------------------------------------
-// Enumeration restarts, register-resident form.  A region's phase matrix is a few KB (rows x <= 31
-// SNPs) while its 2^S restarts each sweep it ~7 times: one workgroup stages the matrix in LDS once,
-// every wave64 copies "its lane's share" of the entries into VGPRs, and then runs complete restarts
-// with the matrix in registers, delta / eta in wave-uniform bit masks and sigma as a bit vector in LDS.
-// Only wave-level synchronisation inside a restart.  Same decisions as cross_optimize() above.
-//   sigma step : lane <-> a run of whole rows in CSR order (~E/64 entries); two VGPRs per entry hold the
-//                23-bit + signed 24-bit limbs of w[q] with the metadata in the bits v_mad_i32_i24 ignores
-//   delta step : lane <-> a contiguous chunk of the CSC entries; per-SNP sums M[i] by LDS atomics
-//                (integer, order-free), then lane i takes SNP i's four-way decision
-//   objective  : sum over SNPs of the chosen branch's data term, which the last delta step already
-//                holds (sigma does not change after it) -- no extra pass over the matrix.
-// ---------------------------------------------------------------------------------------------
-struct EnumTile { int32_t slot; uint32_t e0, ne; };   // restarts e0 .. e0+ne-1 of one region
-// The grid of an enumeration kernel is the concatenation of its regions' tiles; the host uploads one span per region
-// (a few hundred) instead of one record per tile (tens of thousands), the workgroup finds its span with two rounds
-// of a 64-way search (spans are sorted by tile0).  Winner re-runs have one workgroup per span.
-struct EnumSpan { int32_t slot; uint32_t tile0; };
-__device__ __forceinline__ EnumTile enum_tile_of(const PhaseDev& P, const EnumSpan* __restrict__ spans, int n_spans, uint32_t per, bool winner) {
-  EnumTile t;
-  const uint32_t bid = blockIdx.x;
-  if (winner) { t.slot = spans[bid].slot; t.e0 = 0; t.ne = 1; return t; }
-  const int lane = threadIdx.x & 63;
-  // level 1: 64 evenly spaced spans; level 2: the spans of the hit segment (n_spans <= 4096), else a plain search
-  int lo = 0, hi = n_spans;   // answer in [lo, hi): last span with tile0 <= bid
-  if (n_spans <= 4096) {
-    const int step = (n_spans + 63) / 64;
-    const int i1 = lane * step;
-    const unsigned long long m1 = __ballot(i1 < n_spans && spans[min(i1, n_spans - 1)].tile0 <= bid);
-    const int seg = __popcll(m1) - 1;          // spans[0].tile0 == 0 <= bid: at least one bit
-    lo = seg * step; hi = min(n_spans, lo + step);
-    const int i2 = lo + lane;
-    const unsigned long long m2 = __ballot(i2 < hi && spans[min(i2, n_spans - 1)].tile0 <= bid);
-    lo = lo + __popcll(m2) - 1;
-  } else {
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (spans[mid].tile0 <= bid) lo = mid; else hi = mid; }
-  }
-  t.slot = spans[lo].slot;
-  const uint32_t n = 1u << P.reg[t.slot].S;
-  t.e0 = (bid - spans[lo].tile0) * per;
-  t.ne = min(per, n - t.e0);
-  return t;
-}
-constexpr int ENUM_WAVES = 4;
-constexpr uint32_t ENUM_TILE_JOBS = 16;
-constexpr uint32_t ENUM_LDS_BYTES = 48 * 1024;
-
-// LDS image: wl2[32] {lo23, hi24 (signed)} | csr[E] {lo | meta << 24, hi | row_in_lane << 24} | csc[E] | rp[R+1] u16 |
-//            first_row[65] u16 | per wave: sigma bits (u64 words, +1 pad) and M[32]
-//   csr meta : bits 0-4 SNP, 5 allele (1: p == +1), 6 last entry of its row, 7 valid
-//   csc      : bits 0-15 row, 16-20 SNP, 21 allele, 22-26 q, 31 valid
-struct EnumLayout { uint32_t csr, csc, rp, first_row, state, stride, total; };
-__host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E) {
-  EnumLayout L;
-  uint32_t o = 256;
-  L.csr = o; o += 8 * E;
-  L.csc = o; o += 4 * E;
-  L.rp = o; o += 2 * (R + 1);
-  L.first_row = o; o += 2 * 65;
-  o = (o + 15) & ~15u;
-  L.state = o;
-  L.stride = 8 * ((R + 63) / 64 + 1) + 8 * 32;
-  L.total = o + ENUM_WAVES * L.stride;
-  return L;
-}
-// lane l owns the rows whose first entry index lies in [l*c, (l+1)*c), c = ceil(E / 64)
-__host__ __device__ inline uint32_t enum_chunk(uint32_t E) { return E ? (E + 63) / 64 : 1; }
-
-
-// tiles of restarts of regions whose per-lane share is <= CK entries (host decides); win_e != nullptr:
-// re-run restart win_e[slot] of each tile's region and store its state.
-template <int CK>
-__global__ void __launch_bounds__(64 * ENUM_WAVES, 3)   // (three waves per SIMD: <= 168 VGPRs)
-k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uint32_t per, const int64_t* __restrict__ job_base,
-            long long* __restrict__ job_obj, const uint32_t* __restrict__ win_e, uint32_t* __restrict__ tiles_done) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  const EnumTile t = enum_tile_of(P, spans, n_spans, per, win_e != nullptr);
-  const RegionDev rd = P.reg[t.slot];
-  const int R = rd.R, S = rd.S;
-  const uint32_t E = (uint32_t)P.prow_ptr[rd.rp_off + R];
-  const EnumLayout L = enum_layout(R, E);
-  uint2* wl2 = (uint2*)lds;
-  uint2* csr = (uint2*)(lds + L.csr);
-  uint32_t* csc = (uint32_t*)(lds + L.csc);
-  uint16_t* rp = (uint16_t*)(lds + L.rp); uint16_t* first_row = (uint16_t*)(lds + L.first_row);
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const uint32_t c = enum_chunk(E);
-  // ---- stage the region (once per workgroup)
-  if (tid < 32) {
-    const long long w = tid < 31 ? P.lut.f1e[tid] - P.lut.fe[tid] : 0;
-    wl2[tid] = make_uint2((uint32_t)w & 0x7fffffu, (uint32_t)(w >> 23) & 0xffffffu);   // w = hi * 2^23 + lo, hi signed (w < 0 for q <= 3)
-  }
-  const int32_t* g_rp = P.prow_ptr + rd.rp_off;
-  for (int r = tid; r <= R; r += nt) rp[r] = (uint16_t)g_rp[r];
-  __shared__ int32_t cps[33];
-  if (tid <= S && tid < 33) cps[tid] = P.ccol_ptr[rd.cp_off + tid];
-  __syncthreads();
-  for (int l = tid; l <= 64; l += nt) {   // first row whose start offset is >= l * c
-    const uint32_t target = (uint32_t)l * c;
-    int lo = 0, hi = R;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (rp[mid] < target) lo = mid + 1; else hi = mid; }
-    first_row[l] = (uint16_t)lo;
-  }
-  for (int e = tid; e < (int)E; e += nt) {
-    const uint32_t cv = P.cval[rd.e_off + e];
-    int col = 0;
-    for (int i = 0; i < S; i++) col += (int)((uint32_t)e >= (uint32_t)cps[i + 1]);
-    csc[e] = (uint32_t)P.crow[rd.e_off + e] | ((uint32_t)col << 16) | ((cv & 32u) << 16) | ((cv & 31u) << 22) | 0x80000000u;
-  }
-  __syncthreads();
-  for (int r = tid; r < R; r += nt) {
-    const int e0 = rp[r], e1 = rp[r + 1];
-    if (e0 == e1) continue;
-    const uint32_t owner = (uint32_t)e0 / c;
-    const uint32_t roff = (uint32_t)r - first_row[owner];
-    for (int e = e0; e < e1; e++) {
-      const uint32_t v = P.pval[rd.e_off + e];
-      const uint32_t meta = (uint32_t)P.pcol[rd.e_off + e] | (v & 32u) | (e + 1 == e1 ? 64u : 0u) | 128u;
-      const uint2 w = wl2[v & 31u];
-      csr[e] = make_uint2(w.x | (meta << 24), w.y | (roff << 24));
-    }
-  }
-  __syncthreads();
-  // ---- per wave: my share of the matrix into registers
-  const int lane = tid & 63, wave = tid >> 6;
-  unsigned long long* sgb = (unsigned long long*)(lds + L.state + wave * L.stride);   // bit = 1: sigma == -1
-  unsigned long long* Macc = sgb + (R + 63) / 64 + 1;
-  const int r_a = first_row[lane];
-  // CK > 0: the lane's entries live in VGPRs; CK == 0: any share size, entries are re-read from LDS
-  constexpr int NREG = CK > 0 ? CK : 1;
-  uint32_t re0[NREG], re1[NREG], ce[NREG];
-  const int s0 = rp[r_a], s1 = rp[first_row[lane + 1]];
-  const int c0 = min((int)E, lane * (int)c), c1 = min((int)E, (lane + 1) * (int)c);
-  if (CK > 0) {
-#pragma unroll
-    for (int x = 0; x < NREG; x++) {
-      const uint2 v = s0 + x < s1 ? csr[s0 + x] : make_uint2(0, 0);
-      re0[x] = v.x; re1[x] = v.y;
-      ce[x] = c0 + x < c1 ? csc[c0 + x] : 0;
-    }
-  }
-  // wave-uniform trip counts of the two unrolled entry loops
-  int n_sig, n_del;
-  {
-    int n = rp[first_row[lane + 1]] - rp[r_a];
-    for (int d = 32; d >= 1; d >>= 1) n = max(n, __shfl_xor(n, d, 64));
-    n_sig = __builtin_amdgcn_readfirstlane(n);
-    n_del = (int)min(c, E);
-  }
-  const uint32_t smask = S >= 32 ? 0xffffffffu : ((1u << S) - 1u);
-  // lane i < S owns SNP i
-  long long cF = 0, cW = 0, cRef = 0, cVar = 0, het = 0;
-  bool live = false; int eta_init = 0;
-  if (lane < S) {
-    const long long* sc = P.snp_const + 4ll * (rd.snp_off + lane);
-    cF = sc[0]; cW = sc[1]; cRef = sc[2] + P.lut.f_homref; cVar = sc[3] + P.lut.f_homvar;
-    const int n = P.ccol_ptr[rd.cp_off + lane + 1] - P.ccol_ptr[rd.cp_off + lane];
-    het = P.lut.f_het0 - (long long)n * P.lut.f_log2;                     // phase.rs:136-144
-    live = P.snp_fp[rd.snp_off + lane] != 0 && n > 0;
-    eta_init = init_genotype(P.snp_vt[rd.snp_off + lane]);
-  }
-  const uint32_t e0_init = (uint32_t)__ballot(lane < S && eta_init == 0), ep_init = (uint32_t)__ballot(lane < S && eta_init == 1);
-  const int nk = (R + 63) / 64;
-  const int wsh = r_a & 63;
-  const uint32_t ne = win_e ? 1u : t.ne;
-  // one restart by this wave: its objective goes to job_obj[], or -- the winner's re-run -- its state to the region's slot
-  auto run_restart = [&](const uint32_t e_in, const bool mat_in) {
-    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_in);   // (wave-uniform: keep them in SGPRs)
-    const bool materialise = __builtin_amdgcn_readfirstlane((int)mat_in) != 0;
-    uint32_t dneg = e & smask;            // bit i: delta_i == -1 (doubling order of phase.rs:1099-1106)
-    uint32_t eta0 = e0_init, etap = ep_init;   // eta_i == 0 / eta_i == +1
-    // init_assignment (phase.rs:673-680): u01() < 0.5  <=>  top bit of the draw clear  -> sigma = -1
-    const uint64_t ctr0 = (uint64_t)S + (uint64_t)R + (uint64_t)e * (uint64_t)R;
-    for (int k = 0; k <= nk; k++) {
-      const int row = lane + 64 * k;
-      const bool neg = row < R && (mix64(rd.seed + (ctr0 + row + 1) * 0x9E3779B97F4A7C15ULL) >> 63) == 0;
-      const unsigned long long b = __ballot(neg);
-      if (lane == 0) sgb[k] = b;
-    }
-    if (lane < 32) Macc[lane] = 0;
-    wave_lds_sync();
-    bool hg_inc = true, h_inc = true;
-    int iters = 0;
-    long long obj_i = 0;
-    while (hg_inc | h_inc) {
-      // ---- sigma step (phase.rs:824-862)
-      {
-        const unsigned long long w0 = sgb[r_a >> 6], w1 = sgb[(r_a >> 6) + 1];
-        const unsigned long long win = wsh ? (w0 >> wsh) | (w1 << (64 - wsh)) : w0;
-        int alo = 0, ahi = 0;
-        unsigned long long fm = 0;
-        auto sig_one = [&](uint32_t v0, uint32_t v1) {
-          const uint32_t m = v0 >> 24, i = m & 31u, roff = v1 >> 24;
-          const uint32_t sneg = (uint32_t)(win >> roff);
-          const uint32_t use = (m >> 7) & (eta0 >> i) & 1u;                 // het sites only
-          const uint32_t hit = ((m >> 5) ^ sneg ^ (dneg >> i)) & use;       // p == sigma * delta
-          const uint32_t mis = hit ^ use;
-          alo += __mul24((int)hit, (int)v0) - __mul24((int)mis, (int)v0);   // A - B of phase.rs:824-862
-          ahi += __mul24((int)hit, (int)v1) - __mul24((int)mis, (int)v1);
-          const bool end = (m >> 6) & 1u;
-          // sign of ahi * 2^23 + alo: fold alo's carry into ahi, the remainder is in [0, 2^23)
-          if (end && ahi + (alo >> 23) < 0) fm |= 1ull << roff;
-          alo = end ? 0 : alo; ahi = end ? 0 : ahi;
-        };
-        if (CK > 0) {
-#pragma unroll
-          for (int x = 0; x < NREG; x++) {
-            if (x >= n_sig) break;
-            // opaque to the optimiser: otherwise every field extraction is hoisted out of the restart loop
-            // into its own VGPR (x CK entries) and the kernel drops to one wave per SIMD
-            asm volatile("" : "+v"(re0[x]), "+v"(re1[x]));
-            sig_one(re0[x], re1[x]);
-          }
-        } else {
-          for (int x0 = 0; x0 < n_sig; x0 += 4) {
-            uint2 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = s0 + x0 + u < s1 ? csr[s0 + x0 + u] : make_uint2(0, 0);
-#pragma unroll
-            for (int u = 0; u < 4; u++) sig_one(v[u].x, v[u].y);
-          }
-        }
-        const bool any = __ballot(fm != 0) != 0;
-        if (fm) {
-          atomicXor(&sgb[r_a >> 6], fm << wsh);
-          if (wsh && (fm >> (64 - wsh))) atomicXor(&sgb[(r_a >> 6) + 1], fm >> (64 - wsh));
-        }
-        wave_lds_sync();
-        if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
-      }
-      // ---- delta / eta step (phase.rs:872-959): a lane's chunk is CSC-ordered (SNP index non-decreasing)
-      {
-        constexpr int HB = 8;   // look-ups of one batch in flight, then its run-length flush
-        int cur = -1; int alo = 0, ahi = 0;
-        auto del_batch = [&](const uint32_t* v8) {
-          uint32_t sw[HB]; uint2 wq[HB];
-#pragma unroll
-          for (int x = 0; x < HB; x++) {
-            const uint32_t row = v8[x] & 0xffffu;
-            sw[x] = ((const uint32_t*)sgb)[row >> 5];
-            wq[x] = wl2[(v8[x] >> 22) & 31u];
-          }
-#pragma unroll
-          for (int x = 0; x < HB; x++) {
-            const uint32_t v = v8[x];
-            const int i = (v >> 16) & 31;
-            const uint32_t hit = ((v >> 21) ^ (sw[x] >> (v & 31u)) ^ (dneg >> i)) & (v >> 31);
-            if ((v >> 31) && i != cur) {
-              if (alo | ahi) atomicAdd(&Macc[cur], (unsigned long long)(((long long)ahi << 23) + alo));
-              cur = i; alo = 0; ahi = 0;
-            }
-            alo += __mul24((int)hit, (int)wq[x].x);
-            ahi += __mul24((int)hit, (int)wq[x].y);   // sign-extends the 24-bit hi limb
-          }
-        };
-        if (CK > 0) {
-#pragma unroll
-          for (int h = 0; h < NREG; h += HB) {
-            if (h >= n_del) break;
-            uint32_t v8[HB];
-#pragma unroll
-            for (int x = 0; x < HB; x++) { asm volatile("" : "+v"(ce[h + x < NREG ? h + x : 0])); v8[x] = ce[h + x < NREG ? h + x : 0]; }
-            del_batch(v8);
-          }
-        } else {
-          for (int h = 0; h < n_del; h += HB) {
-            uint32_t v8[HB];
-#pragma unroll
-            for (int x = 0; x < HB; x++) v8[x] = c0 + h + x < c1 ? csc[c0 + h + x] : 0;
-            del_batch(v8);
-          }
-        }
-        if (alo | ahi) atomicAdd(&Macc[cur], (unsigned long long)(((long long)ahi << 23) + alo));
-      }
-      wave_lds_sync();
-      bool changed = false;
-      int d_new = (dneg >> lane) & 1u, h_new = ((eta0 >> lane) & 1u) ? 0 : (((etap >> lane) & 1u) ? 1 : -1);
-      if (live) {
-        const long long M = (long long)Macc[lane];
-        Macc[lane] = 0;
-        const long long N0 = cF + M + het, N1 = cF + cW - M + het;
-        int ch = 0; long long nb = N0;                       // first maximum (phase.rs:908-921)
-        if (N1 > nb) { ch = 1; nb = N1; }
-        if (cRef > nb) { ch = 2; nb = cRef; }
-        if (cVar > nb) { ch = 3; nb = cVar; }
-        const long long ncur = h_new == 0 ? N0 : (h_new == 1 ? cRef : cVar);
-        changed = nb > ncur;
-        if (ch == 1) d_new ^= 1;
-        h_new = ch <= 1 ? 0 : (ch == 2 ? 1 : -1);
-        obj_i = ch <= 1 ? nb - het : (ch == 2 ? cRef - P.lut.f_homref : cVar - P.lut.f_homvar);
-      }
-      dneg = (uint32_t)__ballot(lane < S && d_new);
-      eta0 = (uint32_t)__ballot(lane < S && h_new == 0);
-      etap = (uint32_t)__ballot(lane < S && h_new == 1);
-      const bool any2 = __ballot(changed) != 0;
-      wave_lds_sync();
-      if (!any2) hg_inc = false; else { hg_inc = true; h_inc = true; }
-      if (++iters > 20) break;  // phase.rs:967-972
-    }
-    // objective (phase.rs:257-276) = sum over phase entries of fe + hit * w = sum_i (F_i + hits_i) over live SNPs
-    const long long total = wave_sum_ll_dpp(obj_i);
-    if (materialise) {
-      if (lane < S) {
-        P.st_delta[rd.snp_off + lane] = (int8_t)(((dneg >> lane) & 1u) ? -1 : 1);
-        P.st_eta[rd.snp_off + lane] = (int8_t)(((eta0 >> lane) & 1u) ? 0 : (((etap >> lane) & 1u) ? 1 : -1));
-      }
-      for (int k = 0; k < nk; k++) {
-        const int row = lane + 64 * k;
-        if (row < R) P.st_sigma[rd.sig_off + row] = (int8_t)(((sgb[k] >> lane) & 1ull) ? -1 : 1);
-      }
-      if (lane == 0) P.st_obj[t.slot] = total;
-    } else if (lane == 0) __hip_atomic_store(&job_obj[job_base[t.slot] + e], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (device-coherent: read by the region's last tile)
-    wave_lds_sync();
-  };
-  // Pass 0: this tile's restarts.  Then the tile that completes its region picks the winner (first maximum, `prob >
-  // largest_prob`, phase.rs:1113-1119) and -- pass 1, wave 0 -- runs that restart once more to leave its state: the matrix
-  // is still staged here, and neither a pick kernel nor a second launch sits between the enumeration and the post-phase
-  // kernel.  The objectives were stored device-coherently and every wave's stores are acknowledged before the barrier
-  // that lets thread 0 count the tile.  (One call site for both passes: a second inlined copy costs the 32-entry
-  // instantiation its third wave per SIMD.)
-  __shared__ uint32_t s_last, s_win;
-  __shared__ long long s_best[ENUM_WAVES];
-  __shared__ uint32_t s_be[ENUM_WAVES];
-  for (int pass = 0; pass < 2; pass++) {
-    const uint32_t n_run = pass == 0 ? ne : (wave == 0 ? 1u : 0u);
-    for (uint32_t kk = pass == 0 ? wave : 0u; kk < n_run; kk += ENUM_WAVES)
-      run_restart(pass == 1 ? s_win : (win_e ? win_e[t.slot] : t.e0 + kk), pass == 1 || win_e != nullptr);
-    if (pass == 1 || win_e || !tiles_done) break;
-    __syncthreads();
-    const uint32_t n_jobs = 1u << S;
-    if (tid == 0) s_last = atomicAdd(&tiles_done[t.slot], 1u) == (n_jobs + per - 1) / per - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) break;
-    const long long* o = job_obj + job_base[t.slot];
-    long long best = LLONG_MIN; uint32_t be = 0xffffffffu;
-    for (uint32_t e = tid; e < n_jobs; e += nt) {
-      const long long v = __hip_atomic_load(&o[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (v > best) { best = v; be = e; }   // (ascending e per thread: the first maximum of its share)
-    }
-    for (int d = 32; d >= 1; d >>= 1) {
-      const long long ob = __shfl_xor(best, d, 64); const uint32_t oe = __shfl_xor(be, d, 64);
-      if (ob > best || (ob == best && oe < be)) { best = ob; be = oe; }
-    }
-    if (lane == 0) { s_best[wave] = best; s_be[wave] = be; }
-    __syncthreads();
-    if (tid == 0) {
-      for (int w = 1; w < ENUM_WAVES; w++) if (s_best[w] > best || (s_best[w] == best && s_be[w] < be)) { best = s_best[w]; be = s_be[w]; }
-      s_win = be;
-    }
-    __syncthreads();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k4_stage: phase matrices on the device, one workgroup per region, straight from K3's fragment CSR.
-// For every region: the rows with >= min_linkers linked SNPs (fragment.rs:253-255) restricted to the
-// phase sites (for_phasing candidates, fragment.rs:144-146) as CSR + CSC mirror, the per-SNP constants
-// of cross_optimize and the region descriptor.  Slices sit at offsets derived from K3's own offsets
-// (rows: r0 + g, SNPs: c0 + g, entries: row_ptr[r0]) so no cross-region scan is needed.  The CSC fill
-// order inside a column is whatever the atomics give: every consumer only sums over a column.
-// ---------------------------------------------------------------------------------------------
-
-
-constexpr int STAGE_THREADS = 256;    // (1024 threads per region were measured: more barrier cost than latency saved)
-constexpr int STG_E = 8192, STG_R = 4096, STG_S = 512;   // k4_stage: a region's slice of the fragment matrix that is staged in LDS
-__global__ void __launch_bounds__(STAGE_THREADS) k4_stage(StageIn in, StageOut out, PhaseLutDev lut) {
-  constexpr int NW = STAGE_THREADS / 64;
-  __shared__ int sm[2][16];
-  __shared__ int s_max[3];   // [2]: largest distance between two for_phasing entries of one fragment row (LD band width)
-  __shared__ long long s_ft[NW];
-  __shared__ long long s_fe[32], s_f1e[32];
-  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0 = in.row_region_off[g], nrow = in.row_region_off[g + 1] - r0;
-  const int c0 = in.cand_off[g], S = in.cand_off[g + 1] - c0;
-  const int64_t e_base = in.row_ptr[r0];
-  RegionDev rd{};
-  rd.S = S; rd.rp_off = r0 + g; rd.cp_off = c0 + g; rd.e_off = e_base; rd.sig_off = r0; rd.snp_off = c0;
-  rd.seed = region_seed(in.seed, in.start0[g]);
-  if (S == 0) {
-    if (tid == 0) { out.reg[g] = rd; out.stat[g] = StageStat{0, 0, 0, 0, 0, 0}; out.prow_ptr[rd.rp_off] = 0; out.ccol_ptr[rd.cp_off] = 0; }
-    return;
-  }
-  if (tid < 32) { s_fe[tid] = tid < 31 ? lut.fe[tid] : 0; s_f1e[tid] = tid < 31 ? lut.f1e[tid] : 0; }
-  if (tid < 3) s_max[tid] = 0;
-  // The region's slice of the fragment matrix is brought into LDS with coalesced loads when it fits (any
-  // realistic region does): the per-row entry loops below are chains of dependent loads, a microsecond per link
-  // from HBM, and there are four of them per row.  Larger regions run the same code on global memory.
-  __shared__ uint16_t s_col[STG_E];
-  __shared__ uint8_t s_val[STG_E];
-  __shared__ uint16_t s_rp[STG_R + 1];
-  __shared__ uint8_t s_isp[STG_R];
-  __shared__ uint8_t s_fp[STG_S];
-  __shared__ int s_cur[STG_S];
-  const int64_t E_all = in.row_ptr[r0 + nrow] - e_base;
-  if (S > 0 && E_all >= in.grid_min) return;   // k4_stage_grid (k4_grid.hip) stages this region with all CUs
-  const bool staged = nrow <= STG_R && E_all <= STG_E && S <= STG_S;
-  for (int i = tid; i < S; i += STAGE_THREADS) {
-    const lcr_candidate& c = in.cand[c0 + i];
-    const uint8_t fp = (c.flags & LCR_F_FOR_PHASING) ? 1 : 0;
-    out.snp_fp[c0 + i] = fp;
-    out.snp_vt[c0 + i] = (int8_t)c.variant_type;
-    out.snp_cons[c0 + i] = 0;
-    if (staged) { s_fp[i] = fp; s_cur[i] = 0; } else out.cursor[c0 + i] = 0;
-  }
-  if (staged) {
-    for (int e = tid; e < (int)E_all; e += STAGE_THREADS) { s_col[e] = (uint16_t)(in.col[e_base + e] - c0); s_val[e] = in.val[e_base + e]; }
-    for (int r = tid; r <= nrow; r += STAGE_THREADS) s_rp[r] = (uint16_t)(in.row_ptr[r0 + r] - e_base);
-    for (int r = tid; r < nrow; r += STAGE_THREADS) s_isp[r] = in.links[r0 + r] >= in.min_linkers ? 1 : 0;
-  }
-  __syncthreads();
-  int32_t* prp = out.prow_ptr + rd.rp_off;
-  int32_t* pcp = out.ccol_ptr + rd.cp_off;
-  int R = 0, E = 0;
-  auto build = [&](auto staged_tag) {
-    constexpr bool ST = decltype(staged_tag)::value;
-    auto isp_of = [&](int r) -> int { if constexpr (ST) return s_isp[r]; else return in.links[r0 + r] >= in.min_linkers ? 1 : 0; };
-    auto rp_of = [&](int r) -> int { if constexpr (ST) return s_rp[r]; else return (int)(in.row_ptr[r0 + r] - e_base); };   // region relative
-    auto col_of = [&](int e) -> int { if constexpr (ST) return s_col[e]; else return in.col[e_base + e] - c0; };              // region relative
-    auto val_of = [&](int e) -> uint8_t { if constexpr (ST) return s_val[e]; else return in.val[e_base + e]; };
-    auto fp_of = [&](int i) -> bool { if constexpr (ST) return s_fp[i] != 0; else return out.snp_fp[c0 + i] != 0; };
-    auto bump = [&](int i) -> int { if constexpr (ST) return atomicAdd(&s_cur[i], 1); else return atomicAdd(&out.cursor[c0 + i], 1); };
-    // ---- pass 1: phasing rows and their phase-site entries (CSR), column counts
-    for (int base = 0; base < nrow; base += STAGE_THREADS) {
-      const int r = base + tid;
-      int isp = 0, cnt = 0, eb = 0, ee = 0;
-      if (r < nrow) {
-        isp = isp_of(r);
-        eb = rp_of(r); ee = rp_of(r + 1);
-        int first = -1, last = -1;   // every fragment row counts for the LD pair table (fragment.rs:208-240)
-        for (int e = eb; e < ee; e++) { const int ci = col_of(e); if (fp_of(ci)) { cnt++; if (first < 0) first = ci; last = ci; } }
-        if (last > first) atomicMax(&s_max[2], last - first);
-        if (!isp) cnt = 0;
-      }
-      int k, eo, tk, te;
-      block_scan2n<NW, 16>(isp, cnt, k, eo, tk, te, sm);
-      if (isp) {
-        k += R; eo += E;
-        prp[k] = eo;
-        out.prow_src[r0 + k] = r;
-        for (int e = eb; e < ee; e++) {
-          const int ci = col_of(e);
-          if (!fp_of(ci)) continue;
-          out.pcol[e_base + eo] = ci; out.pval[e_base + eo] = val_of(e) & 63;
-          bump(ci);
-          eo++;
-        }
-      }
-      R += tk; E += te;
-    }
-    if (tid == 0) prp[R] = E;
-    __syncthreads();
-    // ---- column offsets
-    {
-      int carry = 0;
-      for (int base = 0; base < S; base += STAGE_THREADS) {
-        const int i = base + tid;
-        int v = 0;
-        if (i < S) { if constexpr (ST) v = s_cur[i]; else v = out.cursor[c0 + i]; }
-        int ex, dummy, tot, tdummy;
-        block_scan2n<NW, 16>(v, 0, ex, dummy, tot, tdummy, sm);
-        if (i < S) { pcp[i] = carry + ex; if constexpr (ST) s_cur[i] = carry + ex; else out.cursor[c0 + i] = carry + ex; }
-        carry += tot;
-      }
-      if (tid == 0) pcp[S] = carry;
-    }
-    __syncthreads();
-    // ---- pass 2: CSC mirror (phasing-row index, value)
-    {
-      int Rk = 0;
-      for (int base = 0; base < nrow; base += STAGE_THREADS) {
-        const int r = base + tid;
-        const int isp = r < nrow ? isp_of(r) : 0;
-        int k, dummy, tk, tdummy;
-        block_scan2n<NW, 16>(isp, 0, k, dummy, tk, tdummy, sm);
-        if (isp) {
-          k += Rk;
-          const int ee = rp_of(r + 1);
-          for (int e = rp_of(r); e < ee; e++) {
-            const int ci = col_of(e);
-            if (!fp_of(ci)) continue;
-            const int pos = bump(ci);
-            out.crow[e_base + pos] = k; out.cval[e_base + pos] = val_of(e) & 63;
-          }
-        }
-        Rk += tk;
-      }
-    }
-    __syncthreads();
-  };
-  if (staged) build(std::true_type{}); else build(std::false_type{});
-  // ---- per-SNP constants: F = sum fe, W = sum w, Cref = sum (p==+1 ? f1e : fe), Cvar = sum (p==-1 ? f1e : fe)
-  long long ft = 0;
-  for (int i = wave; i < S; i += NW) {
-    long long F = 0, W = 0, Cr = 0, Cv = 0;
-    for (int e = pcp[i] + lane; e < pcp[i + 1]; e += 64) {
-      const uint8_t v = out.cval[e_base + e];
-      const long long fe = s_fe[v & 31], f1 = s_f1e[v & 31];
-      F += fe; W += f1 - fe;
-      Cr += (v & 32) ? f1 : fe; Cv += (v & 32) ? fe : f1;
-    }
-    F = wave_sum_ll_dpp(F); W = wave_sum_ll_dpp(W); Cr = wave_sum_ll_dpp(Cr); Cv = wave_sum_ll_dpp(Cv);
-    if (lane == 0) { long long* sc = out.snp_const + 4ll * (c0 + i); sc[0] = F; sc[1] = W; sc[2] = Cr; sc[3] = Cv; }
-    ft += F;
-  }
-  if (lane == 0) s_ft[wave] = ft;
-  // ---- per-lane share of k4_enum_reg's row partition (enumeration regions only)
-  if (S <= (int)in.max_enum_snps && tid < 64) {
-    const uint32_t c = enum_chunk((uint32_t)E);
-    auto lower = [&](uint32_t target) { int lo = 0, hi = R; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)prp[mid] < target) lo = mid + 1; else hi = mid; } return lo; };
-    const int f0 = lower((uint32_t)tid * c), f1 = lower((uint32_t)(tid + 1) * c);
-    atomicMax(&s_max[0], prp[f1] - prp[f0]);
-    atomicMax(&s_max[1], f1 - f0);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    long long ftot = 0;
-    for (int w = 0; w < NW; w++) ftot += s_ft[w];
-    rd.R = R; rd.f_total = ftot;
-    out.reg[g] = rd;
-    out.stat[g] = StageStat{R, E, max(s_max[0], (int)enum_chunk((uint32_t)E)), s_max[1], (int)E_all, s_max[2]};
-  }
-}
-
-// the same tiles for regions whose matrix does not fit the LDS budget: one restart at a time per workgroup
-__global__ void __launch_bounds__(LCR_BLOCK)
-k4_enum_big(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uint32_t per, const int64_t* __restrict__ job_base,
-            long long* __restrict__ job_obj, const uint32_t* __restrict__ win_e) {
-  __shared__ long long red[LCR_BLOCK / 64];
-  __shared__ long long wl[32];
-  const EnumTile t = enum_tile_of(P, spans, n_spans, per, win_e != nullptr);
-  const RegionDev rd = P.reg[t.slot];
-  load_w(P, wl);
-  int8_t* base = P.scratch + (size_t)blockIdx.x * P.scratch_stride;
-  int8_t* sg = base; int8_t* dl = base + rd.R; int8_t* et = dl + rd.S;
-  const int8_t* vt = P.snp_vt + rd.snp_off;
-  const uint32_t ne = win_e ? 1u : t.ne;
-  for (uint32_t k = 0; k < ne; k++) {
-    const uint32_t e = win_e ? win_e[t.slot] : t.e0 + k;
-    for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { dl[i] = ((e >> i) & 1u) ? -1 : 1; et[i] = init_genotype(vt[i]); }
-    const uint64_t ctr0 = (uint64_t)rd.S + (uint64_t)rd.R + (uint64_t)e * (uint64_t)rd.R;
-    for (int row = threadIdx.x; row < rd.R; row += blockDim.x) sg[row] = u01(rd.seed, ctr0 + row) < 0.5 ? -1 : 1;
-    __syncthreads();
-    const long long obj = cross_optimize(P, rd, global_view(P, rd), sg, dl, et, false, true, red, wl);
-    if (win_e) {
-      for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { P.st_delta[rd.snp_off + i] = dl[i]; P.st_eta[rd.snp_off + i] = et[i]; }
-      for (int row = threadIdx.x; row < rd.R; row += blockDim.x) P.st_sigma[rd.sig_off + row] = sg[row];
-      if (threadIdx.x == 0) P.st_obj[t.slot] = obj;
-    } else if (threadIdx.x == 0) job_obj[job_base[t.slot] + e] = obj;
-    __syncthreads();
-  }
-}
-
-// winner of each enumeration region: first maximum over e (`prob > largest_prob`, phase.rs:1113-1119)
-__global__ void __launch_bounds__(64) k4_enum_pick(const int32_t* __restrict__ slots, int32_t n, const RegionDev* __restrict__ reg,
-                                                    const int64_t* __restrict__ job_base, const long long* __restrict__ job_obj,
-                                                    uint32_t* __restrict__ win_e) {
-  const int k = blockIdx.x;
-  if (k >= n) return;
-  const int slot = slots[k];
-  const uint32_t nj = 1u << reg[slot].S;
-  const long long* o = job_obj + job_base[slot];
-  long long best = LLONG_MIN; uint32_t be = 0xffffffffu;
-  for (uint32_t e = threadIdx.x; e < nj; e += 64) { const long long v = o[e]; if (v > best) { best = v; be = e; } }
-  for (int d = 32; d >= 1; d >>= 1) {
-    const long long ob = __shfl_xor(best, d, 64); const uint32_t oe = __shfl_xor(be, d, 64);
-    if (ob > best || (ob == best && oe < be)) { best = ob; be = oe; }
-  }
-  if (threadIdx.x == 0) win_e[slot] = be;
-}
-
-constexpr int CHAIN_THREADS = 1024;   // k4_post of the chain regions: 16 waves
-
-// ---------------------------------------------------------------------------------------------
-// k4_post: the post-phase sequence of thread.rs:168-201, one workgroup per region with the region's fragment rows
-// staged in LDS and a row-ordered column index (stable counting sort by one wave per row part); the steps
-// themselves are k4_post.h's post_run, shared with the all-CUs-on-one-region form (k4_gpost, k4_grid.hip).
-// ---------------------------------------------------------------------------------------------
-constexpr int POST_MAX_ROWS = 8192, POST_MAX_ENTRIES = 8192, POST_MAX_SNPS = 512;
-struct PostLayout { uint32_t sps, rpa, rpb, sflags, soflags, parent, qcnt, rptr, ecol, erow, cent, ccptr, eval, tag, asg, fp, lok, dirty, shap, sgt, svt, rcode, total; };
-__host__ __device__ inline PostLayout post_layout(uint32_t nrow, uint32_t E, uint32_t S) {
-  PostLayout L;
-  uint32_t o = 64 * 8;                       // le[32] | l1e[32]
-  L.sps = o; o += 8 * S;                     // phase_score
-  L.rpa = o; o += 8 * S; L.rpb = o; o += 8 * S;   // rescue: the two candidate phase scores
-  L.sflags = o; o += 4 * S; L.soflags = o; o += 4 * S; L.parent = o; o += 4 * S;
-  L.qcnt = o; o += 4 * 16 * S;                // per (row part, SNP): entry count, then fill cursor (<= 16 waves)
-  L.rptr = o; o += 2 * (nrow + 2);
-  L.ecol = o; o += 2 * E; L.erow = o; o += 2 * E; L.cent = o; o += 2 * E;
-  L.ccptr = o; o += 2 * (S + 2);
-  L.eval = o; o += E;
-  L.tag = o; o += nrow; L.asg = o; o += nrow; L.fp = o; o += nrow; L.lok = o; o += nrow;
-  L.dirty = o; o += nrow;                    // rescue: rows whose fp / tag changed in the current round
-  L.shap = o; o += S; L.sgt = o; o += S; L.svt = o; o += S; L.rcode = o; o += S;
-  L.total = (o + 15) & ~15u;
-  return L;
-}
-
-template <int NT>
-__global__ void __launch_bounds__(NT) k4_post(PostIn in, const int32_t* __restrict__ slots, int32_t n_slots, PostLut lut) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  constexpr int NW = NT / 64;
-  __shared__ int sm[2][16];
-  __shared__ long long red[NW];
-  __shared__ int wg_bc;
-  __shared__ double stage[NW * 4 * POST_SSTR];
-  if ((int)blockIdx.x >= n_slots) return;
-  const int g = slots[blockIdx.x], tid = threadIdx.x, lane = tid & 63;
-  const int r0 = in.row_region_off[g], nrow = in.row_region_off[g + 1] - r0;
-  const int c0 = in.cand_off[g], S = in.cand_off[g + 1] - c0;
-  if (S == 0) return;
-  const int64_t e_base = in.row_ptr[r0];
-  const int E = (int)(in.row_ptr[r0 + nrow] - e_base);
-  const PostLayout L = post_layout(nrow, E, S);
-  PostView<uint16_t> v;
-  v.g = g; v.S = S; v.nrow = nrow; v.E = E; v.F = in.reg[g].R; v.r0 = r0; v.c0 = c0;
-  v.le = (double*)lds; v.l1e = v.le + 32;
-  v.sps = (double*)(lds + L.sps); v.rpa = (double*)(lds + L.rpa); v.rpb = (double*)(lds + L.rpb);
-  v.sflags = (uint32_t*)(lds + L.sflags); v.soflags = (uint32_t*)(lds + L.soflags);
-  v.parent = (int32_t*)(lds + L.parent);
-  v.rptr = (uint16_t*)(lds + L.rptr); v.ecol = (uint16_t*)(lds + L.ecol);
-  v.erow = (uint16_t*)(lds + L.erow); v.cent = (uint16_t*)(lds + L.cent);
-  v.ccptr = (uint16_t*)(lds + L.ccptr);
-  v.ev = lds + L.eval;
-  v.tag = (int8_t*)(lds + L.tag); v.asg = lds + L.asg; v.fp = lds + L.fp; v.lok = lds + L.lok;
-  v.dirty = lds + L.dirty;
-  v.shap = (int8_t*)(lds + L.shap); v.sgt = (int8_t*)(lds + L.sgt); v.svt = (int8_t*)(lds + L.svt);
-  v.rcode = lds + L.rcode;
-  v.cand = in.cand + c0;
-  v.stage = stage;
-  uint16_t* rptr = v.rptr; uint16_t* ecol = v.ecol; uint16_t* erow = v.erow; uint16_t* cent = v.cent; uint16_t* ccptr = v.ccptr;
-
-  int n_mark = 0;
-  auto mark = [&]() { if (in.dbg_clk && tid == 0) in.dbg_clk[(size_t)g * 16 + n_mark] = (long long)wall_clock64(); n_mark++; };
-  mark();
-  // ---- stage: LUT, SNP state, rows, entries, row-ordered column index
-  if (tid < 31) { v.le[tid] = lut.le[tid]; v.l1e[tid] = lut.l1e[tid]; }
-  for (int i = tid; i < S; i += NT) {
-    v.sflags[i] = v.soflags[i] = v.cand[i].flags;
-    v.shap[i] = in.st_delta[c0 + i]; v.sgt[i] = in.st_eta[c0 + i]; v.svt[i] = (int8_t)v.cand[i].variant_type;
-    v.sps[i] = v.cand[i].phase_score;
-    v.parent[i] = 0;
-  }
-  for (int r = tid; r < nrow; r += NT) {
-    const int isp = in.links[r0 + r] >= in.min_linkers ? 1 : 0;
-    rptr[r] = (uint16_t)(in.row_ptr[r0 + r] - e_base);
-    v.lok[r] = (uint8_t)isp; v.fp[r] = (uint8_t)isp; v.asg[r] = 0; v.tag[r] = 0;
-  }
-  if (tid == 0) rptr[nrow] = (uint16_t)E;
-  __syncthreads();
-  for (int k = tid; k < v.F; k += NT) v.tag[in.prow_src[r0 + k]] = in.st_sigma[r0 + k];   // the optimiser's haplotags
-  mark();
-  // row-ordered column index: wave q fills the entries of the q-th part of the rows (stable inside a
-  // part: 64 entries at a time in (row, column) order, equal columns keep their order), the parts'
-  // slots inside a column follow each other
-  int32_t* qcnt = (int32_t*)(lds + L.qcnt);
-  const int rq = (nrow + NW - 1) / NW;   // rows per part (one part per wave)
-  for (int i = tid; i < NW * S; i += NT) qcnt[i] = 0;
-  __syncthreads();
-  for (int r = tid; r < nrow; r += NT)
-    for (int e = rptr[r]; e < rptr[r + 1]; e++) {
-      const int ci = in.col[e_base + e] - c0;
-      ecol[e] = (uint16_t)ci; erow[e] = (uint16_t)r; v.ev[e] = in.val[e_base + e];
-      atomicAdd(&qcnt[(r / rq) * S + ci], 1);
-    }
-  __syncthreads();
-  {
-    int carry = 0;
-    for (int base = 0; base < S; base += NT) {
-      const int i = base + tid;
-      int x = 0;
-      if (i < S) for (int q = 0; q < NW; q++) x += qcnt[q * S + i];
-      int ex, d0, tot, d1;
-      block_scan2n<NW, 16>(x, 0, ex, d0, tot, d1, sm);
-      if (i < S) {
-        int at = carry + ex;
-        ccptr[i] = (uint16_t)at;
-        for (int q = 0; q < NW; q++) { const int n = qcnt[q * S + i]; qcnt[q * S + i] = at; at += n; }
-      }
-      carry += tot;
-    }
-    if (tid == 0) ccptr[S] = (uint16_t)carry;
-  }
-  __syncthreads();
-  {
-    const int q = tid >> 6;
-    int32_t* cur = qcnt + q * S;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int e_lo = rptr[min(q * rq, nrow)], e_hi = rptr[min((q + 1) * rq, nrow)];
-    for (int base = e_lo; base < e_hi; base += 64) {
-      const int e = base + lane;
-      const bool valid = e < e_hi;
-      const int c = valid ? (int)ecol[e] : -1;
-      unsigned long long rem = __ballot(valid);
-      while (rem) {
-        const int cc = __shfl(c, __ffsll((long long)rem) - 1, 64);
-        const unsigned long long m = __ballot(c == cc);
-        const int at = cur[cc];
-        if (c == cc) cent[at + __popcll(m & below)] = (uint16_t)e;
-        wave_lds_sync();
-        if (lane == 0) cur[cc] = at + __popcll(m);
-        rem &= ~m;
-      }
-      wave_lds_sync();
-    }
-  }
-  __syncthreads();
-  mark();
-  WgScope sc{red, &wg_bc};
-  post_run(sc, in, lut, v, mark);
-}
 
 // ================================= host side ====================================================
 
@@ -1205,7 +493,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     StageOut so{b_reg.as<RegionDev>(), b_stat.as<StageStat>(), b_prp.as<int32_t>(), b_pc.as<int32_t>(), b_pv.as<uint8_t>(),
                 b_cp.as<int32_t>(), b_cr.as<int32_t>(), b_cv.as<uint8_t>(), b_snp.as<uint8_t>(), b_snp.as<int8_t>() + nc1,
                 b_snp.as<uint8_t>() + 2 * nc1, b_sc.as<long long>(), b_cur.as<int32_t>(), b_psrc.as<int32_t>()};
-    hipLaunchKernelGGL(k4_stage, dim3(ng), dim3(STAGE_THREADS), 0, stream, si, so, L.dev);
+    launch_k4_stage((int32_t)ng, stream, si, so, L.dev);
     PCHK(hipGetLastError());
     if (!gstage_slots.empty()) {   // large regions: all CUs on one region at a time (every persistent launch goes to `side`)
       GRID_LOCK();
@@ -1345,11 +633,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       // more chain regions than CUs (a sixteen-wave workgroup has a CU to itself): eight waves, two regions per CU --
       // one generation of workgroups instead of two
       if (((int)nps > std::max(1, k4_grid_blocks()) || dbg.post_half /* test hook */) && post_lds <= 56 * 1024) {
-        PCHK(k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_post<CHAIN_THREADS / 2>), 96 * 1024, 5));
-        hipLaunchKernelGGL(k4_post<CHAIN_THREADS / 2>, dim3((unsigned)nps), dim3(CHAIN_THREADS / 2), post_lds, side, pinc, b_slots.as<int32_t>(), (int32_t)nps, plut);
+        PCHK(launch_k4_post(CHAIN_THREADS / 2, (unsigned)nps, post_lds, side, pinc, b_slots.as<int32_t>(), (int32_t)nps, plut));
       } else {
-        PCHK(k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_post<CHAIN_THREADS>), 96 * 1024, 4));
-        hipLaunchKernelGGL(k4_post<CHAIN_THREADS>, dim3((unsigned)nps), dim3(CHAIN_THREADS), post_lds, side, pinc, b_slots.as<int32_t>(), (int32_t)nps, plut);
+        PCHK(launch_k4_post(CHAIN_THREADS, (unsigned)nps, post_lds, side, pinc, b_slots.as<int32_t>(), (int32_t)nps, plut));
       }
     }
     PCHK(hipGetLastError());
@@ -1427,29 +713,27 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     uint32_t* const d_done = d_win + ng;
     PCHK(hipMemsetAsync(d_done, 0, (size_t)ng * 4, stream));
     auto launch = [&](const size_t* cnt, const uint32_t* win) -> hipError_t {
-      const dim3 blk(64 * ENUM_WAVES);
       uint32_t* const done = win ? nullptr : d_done;
       const bool fork = cnt[2] && (cnt[3] || cnt[4]);
       hipStream_t s34 = fork ? aux : stream;
       hipError_t e = hipSuccess;
       if (fork) { if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e; }
-      if (cnt[2]) hipLaunchKernelGGL(k4_enum_reg<32>, dim3((unsigned)cnt[2]), blk, lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, win, done);
-      if (cnt[3]) hipLaunchKernelGGL(k4_enum_reg<0>, dim3((unsigned)cnt[3]), blk, lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, win, done);
-      if (cnt[4]) hipLaunchKernelGGL(k4_enum_big, dim3((unsigned)cnt[4]), dim3(LCR_BLOCK), 0, s34, P, d_sp + s_off[4], (int32_t)n_w[4], per_of[4], d_jb, d_obj, win);
+      if (cnt[2]) launch_k4_enum_reg(32, (unsigned)cnt[2], lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, win, done);
+      if (cnt[3]) launch_k4_enum_reg(0, (unsigned)cnt[3], lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, win, done);
+      if (cnt[4]) launch_k4_enum_big((unsigned)cnt[4], s34, P, d_sp + s_off[4], (int32_t)n_w[4], per_of[4], d_jb, d_obj, win);
       if (fork) { if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e; }
       return e;
     };
     PCHK(launch(n_t, nullptr));
     if (n_w[4]) {   // the global-memory fallback kernel keeps the separate pick and the winners' second launch
       const size_t only4[NCLS] = {0, 0, 0, 0, n_w[4]};
-      hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)ns), dim3(64), 0, stream, d_sl, (int32_t)ns, P.reg, d_jb, d_obj, d_win);
+      launch_k4_enum_pick((int32_t)ns, stream, d_sl, P.reg, d_jb, d_obj, d_win);
       PCHK(launch(only4, d_win));
     }
     if (nps) {
       // eight waves per region: the slowest region (most rows) sets the kernel's length, and every row sweep of the
       // epilogue is a pass of <threads> rows (148 -> 103 us on C3)
-      PCHK(k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_post<2 * LCR_BLOCK>), 96 * 1024, 5));
-      hipLaunchKernelGGL(k4_post<2 * LCR_BLOCK>, dim3((unsigned)nps), dim3(2 * LCR_BLOCK), post_lds, stream, pin, d_psl, (int32_t)nps, plut);
+      PCHK(launch_k4_post(2 * LCR_BLOCK, (unsigned)nps, post_lds, stream, pin, d_psl, (int32_t)nps, plut));
     }
     PCHK(hipGetLastError());
   }
@@ -1507,7 +791,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
         PCHK(hipStreamWaitEvent(side, ev_fork, 0));
         waited = true;
       }
-      PCHK(k4_post_launch_grid(chain ? &pinc : &pin, ps, g, plut, side));
+      PCHK(k4_post_launch_grid(chain ? pinc : pin, ps, g, plut, side));
     }
   }
   lap("chain launch");

@@ -13,18 +13,6 @@
 
 namespace {
 
-struct PostIn {
-  const int64_t* row_ptr; const int32_t* col; const uint8_t* val; const uint32_t* links;
-  lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off; const int64_t* start0;
-  const int8_t* st_sigma; const int8_t* st_delta; const int8_t* st_eta;
-  int8_t* haplotag; uint8_t* assignment; uint32_t* phase_set;   // per-row results: pinned host memory, written by the kernel
-  uint32_t* d_rec;   // the same as 12-byte records in HBM (lcr_read_record: row, haplotag | assignment << 8, phase set) for consumers on the device (multi-GPU gather)
-  const long long* st_obj; long long* h_obj; lcr_candidate* h_cand;   // objective / candidate mirror in pinned host memory
-  uint32_t min_linkers, max_enum_snps; uint64_t seed; double cutoff; float min_phase_score;
-  long long* dbg_clk;   // LCR_PHASE_PROF: 100 MHz timestamps of every workgroup's steps, 16 per region (nullptr otherwise)
-  const RegionDev* reg; const int32_t* prow_src;   // phasing rows of the region (k4_stage): count, and their fragment rows
-};
-
 // the region image the steps work on: LDS (IDX = uint16_t) or HBM (IDX = int32_t)
 template <class IDX>
 struct PostView {

@@ -92,3 +92,15 @@ struct PostScratch {
   int32_t* pcnt; int32_t n_parts, pad_;
   GridCtl* ctl;
 };
+// arguments of the post-phase kernels (k4_post: one workgroup per region; k4_gpost: all CUs on one region)
+struct PostIn {
+  const int64_t* row_ptr; const int32_t* col; const uint8_t* val; const uint32_t* links;
+  lcr_candidate* cand; const int32_t* cand_off; const int32_t* row_region_off; const int64_t* start0;
+  const int8_t* st_sigma; const int8_t* st_delta; const int8_t* st_eta;
+  int8_t* haplotag; uint8_t* assignment; uint32_t* phase_set;   // per-row results: pinned host memory, written by the kernel
+  uint32_t* d_rec;   // the same as 12-byte records in HBM (lcr_read_record: row, haplotag | assignment << 8, phase set) for consumers on the device (multi-GPU gather)
+  const long long* st_obj; long long* h_obj; lcr_candidate* h_cand;   // objective / candidate mirror in pinned host memory
+  uint32_t min_linkers, max_enum_snps; uint64_t seed; double cutoff; float min_phase_score;
+  long long* dbg_clk;   // LCR_PHASE_PROF: 100 MHz timestamps of every workgroup's steps, 16 per region (nullptr otherwise)
+  const RegionDev* reg; const int32_t* prow_src;   // phasing rows of the region (k4_stage): count, and their fragment rows
+};

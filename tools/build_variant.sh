@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p gpurun_in/obj_$name
 objs=""
-for f in k0_ops k1_pileup k2_candidates k3_fragments k4_phase k4_grid k5_regions lcr_api; do
+for f in k0_ops k1_pileup k2_candidates k3_fragments k4_phase k4_enum k4_stage k4_post k4_grid k5_regions lcr_api; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $@ -c longcallr_amd/csrc/$f.hip -o gpurun_in/obj_$name/$f.o &
   objs="$objs gpurun_in/obj_$name/$f.o"
 done
