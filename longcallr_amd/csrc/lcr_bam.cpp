@@ -355,6 +355,7 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
   const size_t WIN = 1024;
   std::vector<uint8_t> buf;       // [carry of the previous window | this window]
   size_t carry = 0;               // bytes at the front of buf that belong to an unfinished item
+  std::vector<std::pair<uint64_t, uint32_t>> win_recs;   // (offset past block_size, block_size) of the complete records of the window
   uint64_t buf_u0 = 0;            // inflated offset of buf[0]
   bool have_header = false;
   size_t hp = 0;                  // parse position inside buf
@@ -407,7 +408,9 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
       for (auto& s : b->ref_names) b->ref_name_ptrs.push_back(s.c_str());
       b->ctg_u0.assign(b->ref_names.size() + 1, UINT64_MAX); b->ctg_u1.assign(b->ref_names.size() + 1, 0); b->ctg_n.assign(b->ref_names.size() + 1, 0);
     }
-    // ---- records of this window
+    // ---- records of this window: contig ranges, and the fixed fields / aux block of every record validated here (in parallel,
+    //      on the window that is inflated anyway) so that a malformed file is refused at open without a second inflate
+    win_recs.clear();
     while (p < n) {
       if (p + 4 > n) { if (last) return fail(b, LCR_E_ARG, "truncated record header"); break; }
       const uint32_t bs = rd32(&d[p]);
@@ -419,7 +422,18 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
       b->ctg_u0[(size_t)ci] = std::min(b->ctg_u0[(size_t)ci], buf_u0 + p);
       b->ctg_u1[(size_t)ci] = std::max(b->ctg_u1[(size_t)ci], buf_u0 + p + 4 + bs);
       b->ctg_n[(size_t)ci]++; b->n_records++;
+      win_recs.push_back(std::make_pair((uint64_t)(p + 4), bs));
       p += 4 + (size_t)bs;
+    }
+    {
+      std::atomic<int64_t> bad_rec{-1};
+      parallel_for((int64_t)win_recs.size(), n_threads, 1024, [&](int64_t i) {
+        Rec r{}; r.off = win_recs[(size_t)i].first; r.size = win_recs[(size_t)i].second;
+        bool lb = false;
+        if (!index_record(r, d, &lb)) bad_rec.store(i);
+      });
+      if (bad_rec.load() >= 0)
+        return fail(b, LCR_E_ARG, "malformed record " + std::to_string(b->n_records - (int64_t)win_recs.size() + bad_rec.load()) + " (fixed fields / aux block)");
     }
     // the unfinished tail moves to the front of the next window
     carry = n - p;
@@ -427,9 +441,7 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
     buf_u0 += p; hp = 0;
     if (last) break;
   }
-  // malformed fixed fields / aux blocks are reported at open, as before: every contig is loaded once (bounded: one at a time)
-  for (size_t ci = 0; ci < b->ctg_n.size(); ci++)
-    if (b->ctg_n[ci]) { const int rc = load_contig(b, (int32_t)ci - 1); if (rc != LCR_OK) return rc; }
+  // (contigs are inflated and indexed on demand, load_contig; nothing is resident after open)
   return LCR_OK;
 }
 

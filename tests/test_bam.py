@@ -213,6 +213,7 @@ def test_decoder_holds_one_contig_at_a_time(tmp_path):
     nb = bamio.NativeBam(path, 8)
     assert nb.n_records == len(offs) * 35
     now, peak = nb.resident()
+    assert now <= 2 ** 20, now                                     # open validates in the scan window: no contig is resident afterwards
     limit = max(len(parts[0]) * 1.15, 64 * 2 ** 20 + 2 ** 20)     # largest contig + ~80 B per record, or the scan window
     assert peak <= limit < 0.7 * total, (peak, limit, total)
     flt = dict(min_mapq=20, min_read_length=500, divergence=0.5)
@@ -261,6 +262,15 @@ def test_bad_inputs_are_errors_not_crashes(tmp_path):
     p = str(tmp_path / "notbam.bam")
     open(p, "wb").write(bgzf(b"SAM\1" + b"\0" * 40, 64))
     with pytest.raises(_lib.LcrError, match="not a BAM"):
+        bamio.NativeBam(p)
+    # malformed fixed fields (l_read_name = 0) are refused at open, in the same pass that inflates the file once
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    rec0 = 4 + 4 + l_text + 4 + (4 + 2 + 4)
+    assert struct.unpack_from("<i", raw, rec0 + 4)[0] == 0 and raw[rec0 + 12] == 2    # refID 0, l_read_name = len("x\0")
+    bad = bytearray(raw); bad[rec0 + 12] = 0
+    p = str(tmp_path / "badrec.bam")
+    open(p, "wb").write(bgzf(bytes(bad), 64))
+    with pytest.raises(_lib.LcrError, match="malformed record 0"):
         bamio.NativeBam(p)
     # unsorted file: refused when a batch is cut (the reference needs a sorted, indexed file as well)
     raw = bam_bytes([("c", 1000)], [dict(ref=0, pos=50, name="a", cigar="10M", seq="A" * 10), dict(ref=0, pos=10, name="b", cigar="10M", seq="A" * 10)])
