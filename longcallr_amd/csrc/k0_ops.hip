@@ -275,7 +275,7 @@ k0_ops(BatchView b, const ReadBin* __restrict__ rbin, const int32_t* __restrict_
   int a[OPT], e[OPT], tb[OPT], kind[OPT];   // columns, region's first tile, kind: 0 none, 1 M, 2 D, 3 I, 4 N
   unsigned int rlo[OPT], rhi[OPT];          // record bits that do not depend on the tile: M: offset of the base on column 0 (low word, high byte), strand, ts
   unsigned int my_items = 0;
-  const int win0 = hdr[0].ftile + max(hdr[0].rel_pos - 1, 0) / LCR_TILE;   // first tile of the LDS window
+  const int win0 = hdr[0].ftile + (int)((unsigned int)max(hdr[0].rel_pos - 1, 0) / (unsigned int)LCR_TILE);   // first tile of the LDS window
 #pragma unroll
   for (int k = 0; k < OPT; k++) {
     const int p = OPT * tid + k;
@@ -310,7 +310,7 @@ k0_ops(BatchView b, const ReadBin* __restrict__ rbin, const int32_t* __restrict_
       if (qs + dq[k] != H.reb) atomicExch(&ctl->error, 2);
     }
     if (kd == 4) {   // tiles an intron covers entirely: +1 from the tile after its first to the tile before its last
-      const int ta = H.ftile + aa / LCR_TILE, te = H.ftile + (ee - 1) / LCR_TILE;
+      const int ta = H.ftile + (int)((unsigned int)aa / (unsigned int)LCR_TILE), te = H.ftile + (int)((unsigned int)(ee - 1) / (unsigned int)LCR_TILE);
       if (te > ta + 1) { atomicAdd(&tile_ndiff[ta + 1], 1); atomicAdd(&tile_ndiff[te], -1); }
     }
   }
@@ -328,8 +328,9 @@ k0_ops(BatchView b, const ReadBin* __restrict__ rbin, const int32_t* __restrict_
     }
     return ((unsigned long long)hi << 32) | lo;
   };
-  auto first_tile = [&](int k) { return tb[k] + a[k] / LCR_TILE; };
-  auto last_tile = [&](int k) { return tb[k] + (e[k] - 1) / LCR_TILE; };
+  // (kind != 0: 0 <= a < e, so the divisions are unsigned shifts)
+  auto first_tile = [&](int k) { return tb[k] + (int)((unsigned int)a[k] / (unsigned int)LCR_TILE); };
+  auto last_tile = [&](int k) { return tb[k] + (int)((unsigned int)(e[k] - 1) / (unsigned int)LCR_TILE); };
   // an intron only leaves records in its first and last tile; the other kinds in every tile they span
   auto next_tile = [&](int k, int t, int te) { return kind[k] == 4 ? te : t + 1; };
 

@@ -140,7 +140,7 @@ enum {
   P_DIFF_D,            // deletion runs
   P_DIFF_N,            // intron runs that start or end in this tile (the tiles an intron covers entirely: tile_nbase)
   P_NI,                // insertions (plain counter)
-  P_MM_F,              // 4 planes: mismatching base counts A,C,G,T of forward reads
+  P_MM_F,              // 4 planes: mismatching base counts A,C,T,G (bits 1-2 of the ASCII code) of forward reads
   P_MM_R = P_MM_F + 4, // 4 planes: ... of reverse reads
   P_NPL = P_MM_R + 4
 };
@@ -332,21 +332,23 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
       uint32_t mm = (nzf(x0) >> 7) | (nzf(x1) >> 6) | (nzf(x2) >> 5) | (nzf(x3) >> 4);
       mm &= vlt[q.k_hi];
       if (K1_ABL == 5) mm = 0;
-      uint32_t* dp = pl + (q.strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE;
-      uint32_t* mp = pl + (q.strand ? P_MM_R : P_MM_F) * TSTRIDE;
-      while (mm) {  // rare: a few % of the bases
-        const int pb = __ffs(mm) - 1, jd = pb & 7, kb = pb >> 3;   // dword jd, byte kb
+      // per mismatch (a few % of the bases; the lanes of a wave run as many trips as the worst piece has mismatches, so the
+      // body is kept short and branch-free): the byte comes out of the piece's registers with one v_perm_b32
+      uint32_t* dp = pl + (q.strand ? P_DIFF_DEPTH_R : P_DIFF_DEPTH_F) * TSTRIDE + q.colA;
+      uint32_t* mp = pl + (q.strand ? P_MM_R : P_MM_F) * TSTRIDE + q.colA;
+      while (mm) {
+        const uint32_t pb = (uint32_t)__builtin_ctz(mm), jd = pb & 3u, kb = pb >> 3;   // dword jd, byte kb
         mm &= mm - 1;
-        const uint32_t w = jd == 0 ? q.v.x : jd == 1 ? q.v.y : jd == 2 ? q.v.z : q.v.w;
-        const uint32_t base = (w >> (8 * kb)) & 0xffu;
-        const int col = q.colA + 4 * jd + kb;
-        // branch-free classification: A,C,G,T (either case) -> 0..3; anything else is "Invalid nucleotide
-        // base" (util.rs:890-892): no allele count (depth - 1), transcript strand still counted
+        const uint32_t lo = (jd & 2u) ? q.v.z : q.v.x, hi = (jd & 2u) ? q.v.w : q.v.y;
+        const uint32_t base = __builtin_amdgcn_perm(hi, lo, 0x0c0c0c00u | ((jd & 1u) << 2) | kb);   // byte kb of (jd & 1 ? hi : lo)
+        const uint32_t dcol = 4u * jd + kb;
+        // A,C,G,T (either case) -> plane h = bits 1-2 of the byte (A 0, C 1, T 2, G 3: the LDS mismatch planes are kept in THAT
+        // order); anything else is "Invalid nucleotide base" (util.rs:890-892): no allele count (depth - 1), transcript strand
+        // still counted.  Valid iff the byte, upper-cased, is the letter of its own class (one v_perm_b32 from "ACTG").
         const uint32_t h = (base >> 1) & 3u;
-        const uint32_t bi = h ^ (h >> 1);
-        const bool acgt = ((base & 0xC0u) == 0x40u) && ((0x0010008Au >> (base & 31u)) & 1u);
-        if (acgt) atomicAdd(&mp[bi * TSTRIDE + col], 1u);
-        else { atomicAdd(&dp[col], 0xFFFFFFFFu); atomicAdd(&dp[col + 1], 1u); }
+        const bool acgt = (base & 0xDFu) == __builtin_amdgcn_perm(0u, 0x47544341u /* 'A','C','T','G' */, 0x0c0c0c00u | h);
+        if (acgt) atomicAdd(mp + h * TSTRIDE + dcol, 1u);
+        else { atomicAdd(dp + dcol, 0xFFFFFFFFu); atomicAdd(dp + dcol + 1, 1u); }
       }
     };
     for (int p = tid; p < P; p += K1_PIF * K1_THREADS) {
@@ -398,8 +400,9 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
     uint32_t f[4], rv[4];
     uint32_t sf = 0, sr = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      f[k] = pl[(P_MM_F + k) * TSTRIDE + col]; rv[k] = pl[(P_MM_R + k) * TSTRIDE + col];
+    for (int k = 0; k < 4; k++) {   // ABI order A,C,G,T <- LDS order A,C,T,G (the mismatch loop's class h)
+      const int hk = k < 2 ? k : 5 - k;
+      f[k] = pl[(P_MM_F + hk) * TSTRIDE + col]; rv[k] = pl[(P_MM_R + hk) * TSTRIDE + col];
       sf += f[k]; sr += rv[k];
     }
     if (ri >= 0) {

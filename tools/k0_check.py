@@ -30,7 +30,11 @@ for name, b, p in cases:
     E.close()
 import torch
 for wl in (["c3"] + (["c4"] if "--c4" in sys.argv else [])):
-    b = bench.build_workload(wl)
+    if os.environ.get("K0_SUB"):   # experiment: substitution rate of the generator (in-process, a quarter of the genes)
+        synth.PROFILES[bench.WORKLOADS[wl][0]]["sub"] = float(os.environ["K0_SUB"])
+        b = bench.build_shard(wl, 1, 0, genes=bench.WORKLOADS[wl][1] // 4, workers=1)[0]
+    else:
+        b = bench.build_workload(wl)
     p = _abi.make_params(synth.preset_for(bench.WORKLOADS[wl][0]), seed=2025)
     dv = bench.to_device(b, torch, torch.device("cuda", 0))
     E = api.Engine(0, p, timing=True)
