@@ -430,7 +430,7 @@ def end_to_end_stage(api, _abi, torch, device, batch, params, cpu_compute_s=None
             t0 = time.perf_counter(); nb = bamio.NativeBam(path, 0); t["open_inflate_index"] = time.perf_counter() - t0
             t0 = time.perf_counter(); rs, re_ = nb.spans(0, **flt); regions = E.discover_regions(rs, re_, clen); t["spans_discover"] = time.perf_counter() - t0
             assert [(s, l) for s, l, _ in regions] == want, "region discovery must find the generator's genes"
-            t0 = time.perf_counter(); b2 = nb.batch(0, want, wins, name_format="blob", **flt); t["batch"] = time.perf_counter() - t0
+            t0 = time.perf_counter(); b2 = nb.batch(0, want, wins, name_format="blob", copy=False, **flt); t["batch"] = time.perf_counter() - t0
             t0 = time.perf_counter(); E.load_batch(b2); E.sync(); t["load_batch_h2d"] = time.perf_counter() - t0
             t0 = time.perf_counter(); E.run_all(); c = E.candidates()[0]; t["stages"] = time.perf_counter() - t0
             nb.close()

@@ -336,8 +336,11 @@ class NativeBam:
         return (np.ctypeslib.as_array(s, (n.value,)).copy() if n.value else np.zeros(0, np.int32),
                 np.ctypeslib.as_array(e, (n.value,)).copy() if n.value else np.zeros(0, np.int32))
 
-    def batch(self, ref_id, regions, ref_windows, name_format="list", **flt):
-        """ReadBatch of the passing reads grouped by region (fetch rule of util.rs:637); arrays are copies.
+    def batch(self, ref_id, regions, ref_windows, name_format="list", copy=True, **flt):
+        """ReadBatch of the passing reads grouped by region (fetch rule of util.rs:637).
+        copy=True: the arrays are copies; copy=False: the large arrays (bases, quals, cigar) are VIEWS of the decoder's buffers,
+        as the C ABI hands them out -- valid until the next batch() / close() of this handle (a caller that loads the batch
+        into an engine straight away saves a GB of memcpy).
         name_format="list": `batch.names` is a list of str; "blob": `batch.name_off` (uint64, n + 1) and
         `batch.name_blob` (uint8, NUL-terminated names) -- no Python object per read."""
         C = self._C
@@ -351,15 +354,16 @@ class NativeBam:
                                         C.byref(rd), C.byref(rb), C.byref(noff), C.byref(names)))
         nr = rd.n_reads
 
-        def arr(ptr, n, dt):
+        def arr(ptr, n, dt, view=False):
             if n == 0 or not ptr:
                 return np.zeros(0, dt)
-            return np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt).copy()
+            a = np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt)
+            return a if view else a.copy()
         kw = {fld: arr(getattr(rd, fld), nr, _abi.ReadBatch.DTYPES[fld])
               for fld in ("pos", "seq_len", "lead_clip", "trail_clip", "flags", "seq_off", "cig_off", "n_cig")}
-        kw["bases"] = arr(rd.bases, rd.n_bases, np.uint8)
-        kw["quals"] = arr(rd.quals, rd.n_bases, np.uint8)
-        kw["cigar"] = arr(rd.cigar, rd.n_cigar, np.uint32)
+        kw["bases"] = arr(rd.bases, rd.n_bases, np.uint8, not copy)
+        kw["quals"] = arr(rd.quals, rd.n_bases, np.uint8, not copy)
+        kw["cigar"] = arr(rd.cigar, rd.n_cigar, np.uint32, not copy)
         offs = np.ctypeslib.as_array(noff, (nr + 1,)).copy() if nr else np.zeros(1, np.uint64)
         blob = C.string_at(C.cast(names, C.c_void_p), int(offs[-1])) if nr else b""
         nm = [blob[int(offs[i]):int(offs[i + 1]) - 1].decode() for i in range(nr)] if name_format == "list" else None

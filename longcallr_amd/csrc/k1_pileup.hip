@@ -43,7 +43,9 @@
 #define K1_CPT (LCR_TILE / K1_THREADS)  // columns per thread in the tile epilogue
 #define K1_RPB 2                        // records per thread and batch
 #define K1_PMAP (8 * K1_THREADS)         // pieces per batch with a direct piece -> record map in LDS
+#ifndef K1_PIF
 #define K1_PIF 4                        // 16-byte pieces in flight per thread (a batch of 1024 records has ~2500 pieces)
+#endif
 
 // record layout (64 bit): [0,40) byte offset of the first read base | [40,50) tile column |
 // [50,60) length-1 | [60] reverse strand | [61,63) transcript-strand class (0 none, 1 -> [0], 2 -> [1])

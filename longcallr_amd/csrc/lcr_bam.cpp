@@ -33,6 +33,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -62,13 +65,64 @@ inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); 
 inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline int32_t rdi32(const uint8_t* p) { return (int32_t)rd32(p); }
 
+// Persistent host workers: a parallel_for per 64 MB window (open) or per output chunk (writers) would otherwise create and join
+// up to hardware_concurrency threads each time (~10 us per thread).  One pool per process, grown on demand; one parallel loop
+// runs on it at a time -- a second caller (another host thread with its own lcr_bam), or a forked child, falls back to threads
+// of its own.
+class Pool {
+ public:
+  // runs job() on the caller and on n_workers pool threads; false: the pool is busy (the caller spawns its own threads)
+  bool run(int n_workers, const std::function<void()>& job) {
+    if (getpid() != pid_) return false;   // a forked child has the object but none of its threads
+    std::unique_lock<std::mutex> own(run_m_, std::try_to_lock);
+    if (!own.owns_lock()) return false;
+    try { while ((int)th_.size() < n_workers) th_.emplace_back([this] { worker(); }); } catch (...) { n_workers = (int)th_.size(); }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &job; want_ = n_workers; started_ = 0; finished_ = 0; gen_++;
+    }
+    cv_.notify_all();
+    job();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return finished_ == want_; });
+    job_ = nullptr;
+    return true;
+  }
+
+ private:
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(m_);
+      cv_.wait(lk, [&] { return stop_ || (gen_ != seen && started_ < want_); });
+      if (stop_) return;
+      seen = gen_; started_++;
+      const std::function<void()>* j = job_;
+      lk.unlock();
+      (*j)();
+      lk.lock();
+      if (++finished_ == want_) done_.notify_all();
+    }
+  }
+  std::mutex run_m_, m_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> th_;
+  const std::function<void()>* job_ = nullptr;
+  uint64_t gen_ = 0;
+  int want_ = 0, started_ = 0, finished_ = 0;
+  bool stop_ = false;
+  const pid_t pid_ = getpid();
+};
+// (never destroyed: the workers sleep on the condition variable until the process exits)
+Pool& pool() { static Pool* p = new Pool; return *p; }
+
 // n items over up to nt threads, chunked through an atomic counter; fn(i) must not throw
 void parallel_for(int64_t n, int nt, int64_t chunk, const std::function<void(int64_t)>& fn) {
   if (n <= 0) return;
   nt = (int)std::max<int64_t>(1, std::min<int64_t>(nt, (n + chunk - 1) / chunk));
   if (nt == 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
   std::atomic<int64_t> next{0};
-  auto work = [&]() {
+  const std::function<void()> work = [&]() {
     for (;;) {
       const int64_t b = next.fetch_add(chunk);
       if (b >= n) return;
@@ -76,11 +130,49 @@ void parallel_for(int64_t n, int nt, int64_t chunk, const std::function<void(int
       for (int64_t i = b; i < e; i++) fn(i);
     }
   };
+  if (pool().run(nt - 1, work)) return;
   std::vector<std::thread> th;
   for (int t = 1; t < nt; t++) th.emplace_back(work);
   work();
   for (auto& t : th) t.join();
 }
+
+// uninitialised, growable byte storage for the large arrays (the inflated contig, a batch's bases / qualities / CIGARs / names):
+// std::vector::resize would zero-fill -- and first-touch -- hundreds of MB on the calling thread before the workers overwrite
+// them.  2 MB-aligned with a transparent-huge-page hint from 4 MB on (fewer page faults when the workers fill it in parallel).
+template <class T>
+struct RawBuf {
+  T* p = nullptr;
+  size_t n = 0, cap = 0;
+  RawBuf() = default;
+  RawBuf(const RawBuf&) = delete;
+  RawBuf& operator=(const RawBuf&) = delete;
+  ~RawBuf() { free(p); }
+  void reset() { free(p); p = nullptr; n = cap = 0; }
+  bool resize(size_t want) {   // contents are NOT kept
+    if (want > cap) {
+      free(p); p = nullptr; cap = n = 0;
+      const size_t bytes = std::max<size_t>(want * sizeof(T), 64);
+      void* q = nullptr;
+      if (bytes >= (4u << 20)) {
+        const size_t rounded = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        if (posix_memalign(&q, 2u << 20, rounded) != 0) q = nullptr;
+        if (q) (void)madvise(q, rounded, MADV_HUGEPAGE);
+      } else q = malloc(bytes);
+      if (!q) return false;
+      p = static_cast<T*>(q); cap = want;
+    }
+    n = want;
+    return true;
+  }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  T* get() { return p; }
+  const T* get() const { return p; }
+  size_t size() const { return n; }
+  size_t capacity() const { return cap; }
+  explicit operator bool() const { return p != nullptr; }
+};
 
 }  // namespace
 
@@ -105,17 +197,19 @@ struct lcr_bam {
   std::vector<int64_t> ctg_n;
   // the ONE resident contig: inflated bytes of its blocks and its record index (Rec::off is relative to `data`)
   int32_t cur_ref = INT32_MIN;
-  std::unique_ptr<uint8_t[]> data;
+  RawBuf<uint8_t> data;
   size_t data_size = 0;
   std::vector<Rec> recs;
   int64_t resident_now = 0, resident_peak = 0;
   // results of the last lcr_bam_spans / lcr_bam_batch call
   std::vector<int32_t> sp_start, sp_end;
   std::vector<int32_t> b_pos, b_seq_len, b_lead, b_trail, b_read_begin;
-  std::vector<uint8_t> b_flags, b_bases, b_quals;
+  std::vector<uint8_t> b_flags;
+  RawBuf<uint8_t> b_bases, b_quals;
   std::vector<uint64_t> b_seq_off, b_cig_off, b_name_off;
-  std::vector<uint32_t> b_n_cig, b_cigar;
-  std::vector<char> b_names;
+  std::vector<uint32_t> b_n_cig;
+  RawBuf<uint32_t> b_cigar;
+  RawBuf<char> b_names;
   ~lcr_bam() { if (mm && mm_size) munmap(const_cast<uint8_t*>(mm), mm_size); }
 };
 
@@ -202,7 +296,7 @@ namespace {
 int64_t inflate_blocks(const lcr_bam* b, size_t b0, size_t b1, uint8_t* dst, int n_threads) {
   std::atomic<int64_t> bad{-1};
   const uint64_t base = b0 < b->blks.size() ? b->blks[b0].uoff : 0;
-  parallel_for((int64_t)(b1 - b0), n_threads, 16, [&](int64_t i) {
+  parallel_for((int64_t)(b1 - b0), n_threads, 4, [&](int64_t i) {
     const Blk& k = b->blks[b0 + (size_t)i];
     if (k.isize == 0) return;   // EOF marker and other empty blocks
     z_stream zs;
@@ -271,8 +365,7 @@ int load_contig(lcr_bam* b, int32_t ref_id) {
   size_t b1 = (size_t)(std::lower_bound(b->blks.begin(), b->blks.end(), u1, [](const Blk& k, uint64_t u) { return k.uoff < u; }) - b->blks.begin());
   if (b0 >= b1) return fail(b, LCR_E_ARG, "inconsistent contig range");
   const uint64_t base = b->blks[b0].uoff, bytes = b->blks[b1 - 1].uoff + b->blks[b1 - 1].isize - base;
-  b->data.reset(new (std::nothrow) uint8_t[(size_t)bytes + 1]);
-  if (!b->data) return fail(b, LCR_E_NOMEM, "out of memory for the inflated contig");
+  if (!b->data.resize((size_t)bytes + 1)) return fail(b, LCR_E_NOMEM, "out of memory for the inflated contig");
   b->data_size = (size_t)bytes;
   if (inflate_blocks(b, b0, b1, b->data.get(), b->n_threads) >= 0) return fail(b, LCR_E_ARG, "BGZF block does not inflate / CRC mismatch");
   const uint8_t* d = b->data.get();
@@ -520,7 +613,7 @@ int lcr_bam_batch(lcr_bam* b, int32_t ref_id, const lcr_read_filter* f, int32_t 
     so += (uint64_t)r.l_seq; co += r.n_cig; no += r.l_rn;   // names keep their NUL
   }
   b->b_name_off[nr] = no;
-  b->b_bases.resize(so); b->b_quals.resize(so); b->b_cigar.resize(co); b->b_names.resize(no);
+  if (!b->b_bases.resize(so) || !b->b_quals.resize(so) || !b->b_cigar.resize(co) || !b->b_names.resize(no)) return fail(b, LCR_E_NOMEM, "out of memory for the batch");
   static const char NT16[] = "=ACMGRSVTWYHKDBN";
   const uint8_t* d = b->data.get();
   parallel_for((int64_t)nr, b->n_threads, 256, [&](int64_t k) {

@@ -77,6 +77,7 @@ def test_demo_bam_native_vs_python(threads):
     cuts = [(start0, 4000), (start0 + 4000, 3000), (start0 + 7000, length - 7000), (start0 + length + 50000, 100)]
     wins = [ref[0:4000], ref[4000:7000], ref[7000:], np.full(100, ord("N"), np.uint8)]
     a, b = bamio.build_batch(keep, cuts, wins), nb.batch(rid, cuts, wins, **_abi.READ_FILTER)
+    same_batch(a, nb.batch(rid, cuts, wins, copy=False, **_abi.READ_FILTER))   # views of the decoder's buffers, as the C ABI hands them out
     same_batch(a, b)
     assert b.n_reads > len(keep) and b.read_begin[-1] == b.read_begin[-2]
     # a different filter
