@@ -33,6 +33,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <mutex>
@@ -165,6 +166,15 @@ struct RawBuf {
     n = want;
     return true;
   }
+  bool resize_keep(size_t want) {   // the first min(n, want) elements are kept
+    if (want <= cap) { n = want; return true; }
+    RawBuf<T> nb;
+    if (!nb.resize(want + want / 4)) return false;
+    if (n) memcpy(nb.p, p, n * sizeof(T));
+    free(p); p = nb.p; cap = nb.cap; nb.p = nullptr;
+    n = want;
+    return true;
+  }
   T* data() { return p; }
   const T* data() const { return p; }
   T* get() { return p; }
@@ -195,6 +205,11 @@ struct lcr_bam {
   // per contig (index ref_id + 1; 0 = unmapped tail): range of the inflated stream that holds its records, record count
   std::vector<uint64_t> ctg_u0, ctg_u1;
   std::vector<int64_t> ctg_n;
+  // block_size of every record in stream order (4 B per record) and, per contig, its first record: a contig whose records lie
+  // back to back (a sorted file) is indexed from this table without walking the block_size chain through the inflated bytes again
+  std::vector<uint32_t> rec_bs;
+  std::vector<int64_t> ctg_first;
+  std::vector<uint8_t> ctg_scattered;
   // the ONE resident contig: inflated bytes of its blocks and its record index (Rec::off is relative to `data`)
   int32_t cur_ref = INT32_MIN;
   RawBuf<uint8_t> data;
@@ -284,6 +299,20 @@ bool aux_has(const uint8_t* p, const uint8_t* end, char a, char c) {
 
 int fail(lcr_bam* b, int code, const std::string& msg) { b->err = msg; return code; }
 
+#ifdef LCR_BAM_PROF   // measurement builds only (tools/build_variant.sh ... -DLCR_BAM_PROF): phase times on stderr
+struct ProfT {
+  const char* what; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); double acc[8] = {0}; const char* nm[8] = {nullptr};
+  explicit ProfT(const char* w) : what(w) {}
+  void lap(int k, const char* name) { const auto t = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double>(t - t0).count(); nm[k] = name; t0 = t; }
+  ~ProfT() { fprintf(stderr, "[lcr_bam %s]", what); for (int k = 0; k < 8; k++) if (nm[k]) fprintf(stderr, " %s %.1f ms", nm[k], acc[k] * 1e3); fprintf(stderr, "\n"); }
+};
+#define PROF(name) ProfT prof_(name)
+#define LAP(k, name) prof_.lap(k, name)
+#else
+#define PROF(name)
+#define LAP(k, name)
+#endif
+
 }  // namespace
 
 extern "C" {
@@ -299,21 +328,27 @@ int64_t inflate_blocks(const lcr_bam* b, size_t b0, size_t b1, uint8_t* dst, int
   parallel_for((int64_t)(b1 - b0), n_threads, 4, [&](int64_t i) {
     const Blk& k = b->blks[b0 + (size_t)i];
     if (k.isize == 0) return;   // EOF marker and other empty blocks
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (inflateInit2(&zs, -15) != Z_OK) { bad.store((int64_t)(b0 + i)); return; }
+    // one inflate state per worker thread, reset per block (inflateInit2 allocates ~40 KB: 10^4 blocks on 256 threads would
+    // spend their time in the allocator)
+    struct Inflater {
+      z_stream zs; bool ok;
+      Inflater() { memset(&zs, 0, sizeof(zs)); ok = inflateInit2(&zs, -15) == Z_OK; }
+      ~Inflater() { if (ok) inflateEnd(&zs); }
+    };
+    static thread_local Inflater inf;
+    if (!inf.ok || inflateReset2(&inf.zs, -15) != Z_OK) { bad.store((int64_t)(b0 + i)); return; }
+    z_stream& zs = inf.zs;
     zs.next_in = const_cast<Bytef*>(b->mm + k.coff); zs.avail_in = (uInt)k.clen;
     zs.next_out = dst + (k.uoff - base); zs.avail_out = k.isize;
     const int rc = inflate(&zs, Z_FINISH);
     const bool ok = rc == Z_STREAM_END && zs.total_out == k.isize;
-    inflateEnd(&zs);
     if (!ok || crc32(crc32(0L, Z_NULL, 0), dst + (k.uoff - base), k.isize) != k.crc) bad.store((int64_t)(b0 + i));
   });
   return bad.load();
 }
 
 void note_resident(lcr_bam* b, int64_t extra) {
-  b->resident_now = (int64_t)b->data_size + (int64_t)(b->recs.capacity() * sizeof(Rec)) + extra;
+  b->resident_now = (int64_t)b->data_size + (int64_t)(b->recs.capacity() * sizeof(Rec)) + (int64_t)(b->rec_bs.capacity() * 4) + extra;
   b->resident_peak = std::max(b->resident_peak, b->resident_now);
 }
 
@@ -365,17 +400,29 @@ int load_contig(lcr_bam* b, int32_t ref_id) {
   size_t b1 = (size_t)(std::lower_bound(b->blks.begin(), b->blks.end(), u1, [](const Blk& k, uint64_t u) { return k.uoff < u; }) - b->blks.begin());
   if (b0 >= b1) return fail(b, LCR_E_ARG, "inconsistent contig range");
   const uint64_t base = b->blks[b0].uoff, bytes = b->blks[b1 - 1].uoff + b->blks[b1 - 1].isize - base;
+  PROF("load_contig");
   if (!b->data.resize((size_t)bytes + 1)) return fail(b, LCR_E_NOMEM, "out of memory for the inflated contig");
+  LAP(0, "alloc");
   b->data_size = (size_t)bytes;
   if (inflate_blocks(b, b0, b1, b->data.get(), b->n_threads) >= 0) return fail(b, LCR_E_ARG, "BGZF block does not inflate / CRC mismatch");
+  LAP(1, "inflate");
   const uint8_t* d = b->data.get();
   try { b->recs.reserve((size_t)b->ctg_n[ci]); } catch (...) { return fail(b, LCR_E_NOMEM, "out of memory for the record index"); }
-  for (size_t p = (size_t)(u0 - base), e = (size_t)(u1 - base); p < e;) {
-    const uint32_t bs = rd32(&d[p]);
-    if (bs < 32 || p + 4 + (size_t)bs > e) return fail(b, LCR_E_ARG, "truncated record");
-    if (rdi32(&d[p + 4]) == ref_id) { Rec r{}; r.off = p + 4; r.size = bs; b->recs.push_back(r); }   // (an unsorted file interleaves contigs)
-    p += 4 + (size_t)bs;
+  if (!b->ctg_scattered[ci]) {   // sorted file: the contig's records lie back to back, their sizes are known from the open pass
+    size_t p = (size_t)(u0 - base);
+    const uint32_t* bsz = b->rec_bs.data() + b->ctg_first[ci];
+    b->recs.resize((size_t)b->ctg_n[ci]);
+    for (int64_t k = 0; k < b->ctg_n[ci]; k++) { Rec r{}; r.off = p + 4; r.size = bsz[k]; b->recs[(size_t)k] = r; p += 4 + (size_t)bsz[k]; }
+    if (p != (size_t)(u1 - base)) return fail(b, LCR_E_ARG, "inconsistent record table");
+  } else {
+    for (size_t p = (size_t)(u0 - base), e = (size_t)(u1 - base); p < e;) {
+      const uint32_t bs = rd32(&d[p]);
+      if (bs < 32 || p + 4 + (size_t)bs > e) return fail(b, LCR_E_ARG, "truncated record");
+      if (rdi32(&d[p + 4]) == ref_id) { Rec r{}; r.off = p + 4; r.size = bs; b->recs.push_back(r); }   // (an unsorted file interleaves contigs)
+      p += 4 + (size_t)bs;
+    }
   }
+  LAP(2, "chain");
   std::atomic<int64_t> bad_rec{-1}, long_cigar_bad{-1};
   parallel_for((int64_t)b->recs.size(), b->n_threads, 1024, [&](int64_t i) {
     bool lb = false;
@@ -384,6 +431,7 @@ int load_contig(lcr_bam* b, int32_t ref_id) {
   if (bad_rec.load() >= 0) return fail(b, LCR_E_ARG, "malformed record " + std::to_string(bad_rec.load()) + " of contig " + std::to_string(ref_id));
   if (long_cigar_bad.load() >= 0)
     return fail(b, LCR_E_ARG, "record " + std::to_string(long_cigar_bad.load()) + " has the long-CIGAR placeholder (<l_seq>S<n>N) but no CG:B,I tag");
+  LAP(3, "index");
   b->cur_ref = ref_id;
   note_resident(b, 0);
   return LCR_OK;
@@ -445,8 +493,9 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
   b->total_inflated = total;
   // ---- one pass over the inflated stream in windows of <= 1024 blocks (64 MiB): CRC check of every block, BAM header,
   //      the block_size chain of the records -> per contig the range of the stream it occupies and its record count
+  PROF("open");
   const size_t WIN = 1024;
-  std::vector<uint8_t> buf;       // [carry of the previous window | this window]
+  RawBuf<uint8_t> buf;            // [carry of the previous window | this window]
   size_t carry = 0;               // bytes at the front of buf that belong to an unfinished item
   std::vector<std::pair<uint64_t, uint32_t>> win_recs;   // (offset past block_size, block_size) of the complete records of the window
   uint64_t buf_u0 = 0;            // inflated offset of buf[0]
@@ -455,12 +504,15 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
   for (size_t w0 = 0; w0 < blks.size() || !have_header; w0 += WIN) {
     const size_t w1 = std::min(blks.size(), w0 + WIN);
     const size_t wbytes = w0 < blks.size() ? (size_t)(blks[w1 - 1].uoff + blks[w1 - 1].isize - blks[w0].uoff) : 0;
-    try { buf.resize(carry + wbytes + 1); } catch (...) { return fail(b, LCR_E_NOMEM, "out of memory for the scan window"); }
+    LAP(0, "other");
+    if (!buf.resize_keep(carry + wbytes + 1)) return fail(b, LCR_E_NOMEM, "out of memory for the scan window");
+    LAP(1, "resize");
     b->resident_peak = std::max(b->resident_peak, (int64_t)buf.size());
     if (wbytes) {
       const int64_t badb = inflate_blocks(b, w0, w1, buf.data() + carry, n_threads);
       if (badb >= 0) return fail(b, LCR_E_ARG, "BGZF block " + std::to_string(badb) + " does not inflate / CRC mismatch");
     }
+    LAP(2, "inflate");
     const size_t n = carry + wbytes;
     const uint8_t* d = buf.data();
     const bool last = w1 >= blks.size();
@@ -500,6 +552,7 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
       have_header = true;
       for (auto& s : b->ref_names) b->ref_name_ptrs.push_back(s.c_str());
       b->ctg_u0.assign(b->ref_names.size() + 1, UINT64_MAX); b->ctg_u1.assign(b->ref_names.size() + 1, 0); b->ctg_n.assign(b->ref_names.size() + 1, 0);
+      b->ctg_first.assign(b->ref_names.size() + 1, -1); b->ctg_scattered.assign(b->ref_names.size() + 1, 0);
     }
     // ---- records of this window: contig ranges, and the fixed fields / aux block of every record validated here (in parallel,
     //      on the window that is inflated anyway) so that a malformed file is refused at open without a second inflate
@@ -514,10 +567,14 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
       if (ci < 0 || (size_t)ci >= b->ctg_n.size()) return fail(b, LCR_E_ARG, "malformed record " + std::to_string(b->n_records) + ": reference id out of range");
       b->ctg_u0[(size_t)ci] = std::min(b->ctg_u0[(size_t)ci], buf_u0 + p);
       b->ctg_u1[(size_t)ci] = std::max(b->ctg_u1[(size_t)ci], buf_u0 + p + 4 + bs);
+      if (b->ctg_n[(size_t)ci] == 0) b->ctg_first[(size_t)ci] = b->n_records;
+      else if (b->ctg_first[(size_t)ci] + b->ctg_n[(size_t)ci] != b->n_records) b->ctg_scattered[(size_t)ci] = 1;
+      try { b->rec_bs.push_back(bs); } catch (...) { return fail(b, LCR_E_NOMEM, "out of memory for the record table"); }
       b->ctg_n[(size_t)ci]++; b->n_records++;
       win_recs.push_back(std::make_pair((uint64_t)(p + 4), bs));
       p += 4 + (size_t)bs;
     }
+    LAP(3, "chain");
     {
       std::atomic<int64_t> bad_rec{-1};
       parallel_for((int64_t)win_recs.size(), n_threads, 1024, [&](int64_t i) {
@@ -528,6 +585,7 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
       if (bad_rec.load() >= 0)
         return fail(b, LCR_E_ARG, "malformed record " + std::to_string(b->n_records - (int64_t)win_recs.size() + bad_rec.load()) + " (fixed fields / aux block)");
     }
+    LAP(4, "validate");
     // the unfinished tail moves to the front of the next window
     carry = n - p;
     if (carry) memmove(buf.data(), buf.data() + p, carry);

@@ -9,7 +9,7 @@ for f in k0_ops k1_pileup k2_candidates k3_fragments k4_phase k4_enum k4_stage k
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $@ -c longcallr_amd/csrc/$f.hip -o gpurun_in/obj_$name/$f.o &
   objs="$objs gpurun_in/obj_$name/$f.o"
 done
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -c longcallr_amd/csrc/lcr_bam.cpp -o gpurun_in/obj_$name/lcr_bam.o &
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC $@ -c longcallr_amd/csrc/lcr_bam.cpp -o gpurun_in/obj_$name/lcr_bam.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o gpurun_in/liblcr_$name.so $objs gpurun_in/obj_$name/lcr_bam.o -lz
 rm -rf gpurun_in/obj_$name
