@@ -17,17 +17,19 @@ cp $O/prof_c5/p_kernel_stats.csv $O/c5_kernel_stats.csv
 P="--steps 2 --warmup 1 --prewarm 2 $Q"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_sq -o p --output-format csv -- python bench.py $P > $O/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $O/pmc_lds -o p --output-format csv -- python bench.py $P > $O/pmc_lds.log 2>&1
-python - <<PY > $O/pmc_summary.txt
+python - "$O" "$P" <<'PY' > $O/pmc_summary.txt
 import csv, glob, collections
-print("rocprofv3 --pmc passes over: python bench.py $P  (C3: 400 distinct genes x 25 kb ONT-cDNA, 40x)")
+import sys
+O, P = sys.argv[1], sys.argv[2]
+print("rocprofv3 --pmc passes over: python bench.py %s  (C3: 400 distinct genes x 25 kb ONT-cDNA, 40x)" % P)
 print("per-launch averages; SQ_* = wave-level counts summed over the device (WAVE_CYCLES / WAIT_* / ACTIVE_* in quad-cycles); waves per SIMD = SQ_WAVE_CYCLES x 4 / (SQ_BUSY_CYCLES / 32 x 1024)")
 for tag in ("pmc_sq", "pmc_lds"):
-    f = glob.glob("$O/%s/*counter_collection.csv" % tag)
+    f = glob.glob("%s/%s/*counter_collection.csv" % (O, tag))
     if not f:
         print(tag, "no counter file"); continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); seen = set(); n = collections.Counter()
     for row in csv.DictReader(open(f[0])):
-        k = row["Kernel_Name"].split("(")[0][-40:]
+        k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-40:]
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         key = (k, row["Dispatch_Id"])
         if key not in seen:
