@@ -355,6 +355,50 @@ def c5_stage(api, _abi, synth, device, cpu=True):
     return out
 
 
+def host_fed_stage(api, device, batch, params, cols, steps=8):
+    """The headline step for a caller whose reads are decoded on the HOST (the reference's loop): (a) lcr_load_batch of
+    pageable host arrays, stages behind it; (b) the asynchronous input path -- page-locked arrays, lcr_load_batch_async of batch i + 1
+    into the other staging slot while batch i's stages run, lcr_bind_batch.  1.06 GB cross PCIe per step either way (never part of `value`)."""
+    E = api.Engine(device, params)
+    out = {}
+    try:
+        E.load_batch(batch).run_all(); E.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            E.load_batch(batch).run_all()
+        E.sync()
+        out["sync_pageable_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3
+        pinned = api.host_register(batch.bases, batch.quals, batch.cigar, batch.ref, batch.pos, batch.seq_len, batch.seq_off, batch.cig_off, batch.n_cig)
+        try:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                E.load_batch(batch).run_all()
+            E.sync()
+            out["sync_pinned_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3
+            E.load_batch_async(batch, 0)
+            E.bind_batch(0); E.load_batch_async(batch, 1); E.run_all()   # (warm: the slots' buffers are allocated)
+            E.bind_batch(1); E.load_batch_async(batch, 0); E.run_all()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                E.bind_batch(k & 1)
+                E.load_batch_async(batch, (k + 1) & 1)
+                E.run_all()
+            E.sync()
+            out["async_pinned_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3
+        finally:
+            E.close()
+            api.host_unregister(pinned)
+    finally:
+        E.close()
+    nbytes = int(batch.bases.nbytes + batch.quals.nbytes + batch.cigar.nbytes + batch.ref.nbytes) + 36 * batch.n_reads
+    out["bytes_over_pcie_per_step"] = nbytes
+    out["async_pcie_GBps"] = nbytes / (out["async_pinned_ms_per_step"] * 1e-3) / 1e9
+    out["sites_per_sec_async"] = cols / (out["async_pinned_ms_per_step"] * 1e-3)
+    out["note"] = ("host-fed steps are PCIe-bound: %.2f GB per step at >= 17 ms on a Gen5 x16 link against ~2 ms of kernels; the asynchronous path hides "
+                   "the kernels under the upload of the next batch, it cannot go below the link time" % (nbytes / 1e9))
+    return out
+
+
 def demo_stage(api, _abi, device, cpu=True):
     """BASELINE configs[0]/[1]: demo.bam from the file -- native decode, region discovery on the GPU, batch, the four stage calls -- wall time
     per pass, against the oracle's compute on the same decoded reads (the oracle has no decoder of its own: its side is compute only)."""
@@ -739,6 +783,7 @@ def main():
             st["batches_in_flight"] = batches_in_flight_stage(api, torch, local, params, (reads, regions, keep), cols)
             st["end_to_end_from_bam"] = end_to_end_stage(api, _abi, torch, local, batch, params,
                                                          (cols / cpu["value"]) if cpu else None, cpu["cores"] if cpu else None)
+            st["host_fed"] = host_fed_stage(api, local, batch, params, cols)
         E.close()
         del keep, reads, regions
         torch.cuda.empty_cache()

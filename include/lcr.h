@@ -20,6 +20,7 @@
  */
 #ifndef LCR_H
 #define LCR_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -192,6 +193,21 @@ int lcr_ctx_sync(lcr_ctx*);
 /* Bind a batch (reads + regions).  LCR_MEM_HOST inputs are copied to HBM here; LCR_MEM_DEVICE
  * inputs are used in place and must outlive the calls below. */
 int lcr_load_batch(lcr_ctx*, const lcr_reads*, const lcr_regions*);
+/* Asynchronous input path for a caller whose reads are decoded on the host (the reference's loop, thread.rs:77-143, decodes the
+ * next region while the current one is processed).  A ctx has two staging slots in HBM and an upload stream of its own:
+ *   lcr_load_batch_async(ctx, reads, regions, slot)  enqueues the H2D copies of a LCR_MEM_HOST batch into slot 0 / 1 and returns;
+ *       the host arrays must stay valid -- and should be page-locked (lcr_host_alloc / lcr_host_register), otherwise the
+ *       runtime stages the copy and the call blocks for most of it -- until lcr_bind_batch(slot) has returned.
+ *   lcr_bind_batch(ctx, slot)  makes that batch the current one (waits for its upload, then as lcr_load_batch of a
+ *       device-resident batch); the stage calls follow.  Uploading into the slot that is bound invalidates the bound batch.
+ * So batch i + 1 crosses PCIe while batch i's kernels run; results are those of lcr_load_batch on the same arrays. */
+int lcr_load_batch_async(lcr_ctx*, const lcr_reads*, const lcr_regions*, int32_t slot);
+int lcr_bind_batch(lcr_ctx*, int32_t slot);
+/* page-locked host memory for the arrays of lcr_reads / lcr_regions (hipHostMalloc), or page-lock memory the caller owns */
+int lcr_host_alloc(size_t bytes, void** out);
+void lcr_host_free(void* p);
+int lcr_host_register(void* p, size_t bytes);
+int lcr_host_unregister(void* p);
 
 /* The four stage calls below queue their kernels on the context's stream and return as soon as the host has what it
  * needs to go on (error verdicts, sizes); the last kernels of a stage may still be running.  Later stage calls queue

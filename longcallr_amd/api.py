@@ -83,6 +83,20 @@ class Engine:
         self._chk(self.lib.lcr_load_batch(self.h, C.byref(reads), C.byref(regions)), "lcr_load_batch")
         return self
 
+    def load_batch_async(self, batch, slot):
+        """Enqueue the upload of a host batch (_abi.ReadBatch) into staging slot 0 / 1 and return; bind_batch(slot) makes it the
+        current batch.  The batch's arrays should be page-locked (host_register) for the copy to run beside the kernels."""
+        reads, regions = batch.c_reads(), batch.c_regions()
+        if not hasattr(self, "_keep_slot"):
+            self._keep_slot = {}
+        self._chk(self.lib.lcr_load_batch_async(self.h, C.byref(reads), C.byref(regions), int(slot)), "lcr_load_batch_async")
+        self._keep_slot[int(slot)] = (batch, reads, regions)
+        return self
+
+    def bind_batch(self, slot):
+        self._chk(self.lib.lcr_bind_batch(self.h, int(slot)), "lcr_bind_batch")
+        return self
+
     def discover_regions(self, ref_start, ref_end, contig_len):
         """find_isolated_regions_with_depth (util.rs:236-332) for one contig -> [(start0, len, max_cov)]."""
         rs = np.ascontiguousarray(ref_start, dtype=np.int32)
@@ -173,3 +187,24 @@ class Engine:
         b = C.c_int64()
         self._chk(self.lib.lcr_pileup_stage_bytes(self.h, C.byref(b)), "lcr_pileup_stage_bytes")
         return int(b.value)
+
+
+def host_register(*arrays):
+    """Page-lock the memory of numpy arrays (lcr_host_register) so that lcr_load_batch_async copies them without staging;
+    returns the list to hand to host_unregister."""
+    lib = _lib.load()
+    done = []
+    for a in arrays:
+        if a is None or a.nbytes == 0:
+            continue
+        if lib.lcr_host_register(C.c_void_p(a.ctypes.data), a.nbytes) != 0:
+            host_unregister(done)
+            raise LcrError("lcr_host_register failed")
+        done.append(a)
+    return done
+
+
+def host_unregister(arrays):
+    lib = _lib.load()
+    for a in arrays:
+        lib.lcr_host_unregister(C.c_void_p(a.ctypes.data))

@@ -23,6 +23,10 @@ struct lcr_ctx {
   std::vector<int64_t> h_start0, h_col_off;
   std::vector<int32_t> h_len, h_read_begin, h_region_first_tile;
   DevBuf in_[16];  // device copies of host inputs (LCR_MEM_HOST)
+  // asynchronous input path (lcr_load_batch_async / lcr_bind_batch): two staging slots, filled on an upload stream
+  struct UploadSlot { DevBuf buf[16]; hipEvent_t ev = nullptr; bool filled = false; lcr_reads rd{}; lcr_regions rg{}; } up[2];
+  hipStream_t up_stream = nullptr;
+  int bound_slot = -1;
   DevBuf scan_tmp, read_region, read_bin, read_rend, tile_region, tile_col0, first_tile, k0_tile_fill, k0_items, tile_nbase, tile_order;
   DevBuf desc_tile, desc_val, chunks, chunk_off;   // K0's chunk descriptors, the same sorted by tile, their per-tile offsets
   DevBuf blk_first_read, read_scan, cig_compact, cig_off_new, cig_new_off32;   // K0 op blocks (k0_ops.hip)
@@ -149,6 +153,9 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto& b : c->in_) b.release();
+  if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
+  for (auto& u : c->up) { for (auto& b : u.buf) b.release(); if (u.ev) (void)hipEventDestroy(u.ev); }
+  if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
   DevBuf* bufs[] = {&c->rd_start, &c->rd_end, &c->rd_diff, &c->rd_ex, &c->rd_cnt, &c->rd_off, &c->rd_s, &c->rd_e, &c->rd_max,
                     &c->scan_tmp, &c->read_region, &c->read_bin, &c->read_rend, &c->tile_region, &c->tile_col0, &c->first_tile, &c->desc_tile, &c->desc_val, &c->chunks, &c->chunk_off,
                     &c->k0_tile_fill, &c->k0_items, &c->region_e_off, &c->frag_tmp_col, &c->frag_tmp_val, &c->tile_nbase, &c->blk_first_read, &c->read_scan, &c->cig_compact, &c->cig_off_new, &c->cig_new_off32, &c->planes, &c->flags,
@@ -211,6 +218,7 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   if (rd->n_reads < 0 || rg->n_regions < 0 || rd->mem != rg->mem) { c->err = "bad batch header"; return LCR_E_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   c->loaded = c->have_planes = c->have_cand = c->have_frag = c->have_phase = false;
+  c->bound_slot = -1;
   const int nr = rd->n_reads, ng = rg->n_regions, mem = rd->mem;
   // host copies of the small per-region arrays
   c->h_start0.assign(ng, 0); c->h_len.assign(ng, 0); c->h_col_off.assign(ng + 1, 0); c->h_read_begin.assign(ng + 1, 0);
@@ -327,6 +335,74 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   c->loaded = true;
   return LCR_OK;
 }
+
+int lcr_load_batch_async(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg, int32_t slot) {
+  if (!c || !rd || !rg) return LCR_E_ARG;
+  if (slot < 0 || slot > 1) { c->err = "lcr_load_batch_async: slot must be 0 or 1"; return LCR_E_ARG; }
+  if (rd->mem != LCR_MEM_HOST || rg->mem != LCR_MEM_HOST) { c->err = "lcr_load_batch_async takes LCR_MEM_HOST batches (a device-resident batch needs no upload)"; return LCR_E_ARG; }
+  if (rd->n_reads < 0 || rg->n_regions < 0 || rd->n_bases < 0 || rd->n_cigar < 0) { c->err = "bad batch header"; return LCR_E_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->up_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+  lcr_ctx::UploadSlot& u = c->up[slot];
+  if (!u.ev) HIPCHK(c, hipEventCreateWithFlags(&u.ev, hipEventDisableTiming));
+  if (c->bound_slot == slot) {   // the bound batch lives in this slot: its kernels must be done before it is overwritten
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->loaded = c->have_planes = c->have_cand = c->have_frag = c->have_phase = false;
+    c->bound_slot = -1;
+  }
+  u.filled = false;
+  const int nr = rd->n_reads, ng = rg->n_regions;
+  int64_t n_cols = 0;
+  if (ng) { if (!rg->col_off) { c->err = "col_off missing"; return LCR_E_ARG; } n_cols = rg->col_off[ng]; }
+  if (n_cols < 0) { c->err = "region table inconsistent"; return LCR_E_ARG; }
+  u.rd = lcr_reads{}; u.rg = lcr_regions{};
+  u.rd.mem = LCR_MEM_DEVICE; u.rg.mem = LCR_MEM_DEVICE;
+  u.rd.n_reads = nr; u.rd.n_bases = rd->n_bases; u.rd.n_cigar = rd->n_cigar; u.rg.n_regions = ng;
+  auto put = [&](int i, const void* src, size_t bytes, const void** dst) -> int {
+    HIPCHK(c, u.buf[i].reserve(std::max<size_t>(bytes, 1)));
+    if (bytes) {
+      if (!src) { c->err = "lcr_load_batch_async: null array"; return LCR_E_ARG; }
+      HIPCHK(c, hipMemcpyAsync(u.buf[i].p, src, bytes, hipMemcpyHostToDevice, c->up_stream));
+    }
+    *dst = u.buf[i].p;
+    return LCR_OK;
+  };
+  int rc;
+#define PUT(i, obj, field, T, n) if ((rc = put(i, (obj)->field, (size_t)(n) * sizeof(T), (const void**)&u.obj.field))) return rc
+  PUT(0, rd, pos, int32_t, nr); PUT(1, rd, seq_len, int32_t, nr); PUT(2, rd, lead_clip, int32_t, nr); PUT(3, rd, trail_clip, int32_t, nr);
+  PUT(4, rd, flags, uint8_t, nr); PUT(5, rd, seq_off, uint64_t, nr); PUT(6, rd, cig_off, uint64_t, nr); PUT(7, rd, n_cig, uint32_t, nr);
+  PUT(8, rd, bases, uint8_t, rd->n_bases); PUT(9, rd, quals, uint8_t, rd->n_bases); PUT(10, rd, cigar, uint32_t, rd->n_cigar);
+  PUT(11, rg, start0, int64_t, ng); PUT(12, rg, len, int32_t, ng); PUT(13, rg, col_off, int64_t, ng + 1); PUT(14, rg, read_begin, int32_t, ng + 1);
+  PUT(15, rg, ref, uint8_t, n_cols);
+#undef PUT
+  HIPCHK(c, hipEventRecord(u.ev, c->up_stream));
+  u.filled = true;
+  return LCR_OK;
+}
+
+int lcr_bind_batch(lcr_ctx* c, int32_t slot) {
+  if (!c) return LCR_E_ARG;
+  if (slot < 0 || slot > 1) { c->err = "lcr_bind_batch: slot must be 0 or 1"; return LCR_E_ARG; }
+  lcr_ctx::UploadSlot& u = c->up[slot];
+  if (!u.filled) { c->err = "lcr_bind_batch before lcr_load_batch_async on this slot"; return LCR_E_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, u.ev, 0));   // the ctx stream continues behind the slot's upload
+  const int rc = lcr_load_batch(c, &u.rd, &u.rg);      // (device-resident form: region tables fetched with one wait; the upload is complete when it returns)
+  if (rc == LCR_OK) c->bound_slot = slot;
+  return rc;
+}
+
+int lcr_host_alloc(size_t bytes, void** out) {
+  if (!out) return LCR_E_ARG;
+  *out = nullptr;
+  return hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault) == hipSuccess ? LCR_OK : LCR_E_NOMEM;
+}
+void lcr_host_free(void* p) { if (p) (void)hipHostFree(p); }
+int lcr_host_register(void* p, size_t bytes) {
+  if (!p || !bytes) return LCR_E_ARG;
+  return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? LCR_OK : LCR_E_DEVICE;
+}
+int lcr_host_unregister(void* p) { return p && hipHostUnregister(p) == hipSuccess ? LCR_OK : LCR_E_ARG; }
 
 int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   if (!c || !p) return LCR_E_ARG;

@@ -815,6 +815,53 @@ def test_device_resident_inputs_and_idempotence(engine_cls):
         assert E2.candidates()[0].tobytes() == ref_c.tobytes()
 
 
+@pytest.mark.gpu
+def test_async_input_path_double_buffered(engine_cls):
+    """lcr_load_batch_async / lcr_bind_batch: batch i + 1 is uploaded into the other staging slot while batch i's stages run; the
+    results are byte-identical to lcr_load_batch of the same host arrays, whatever the slot and the order; page-locked arrays."""
+    from longcallr_amd import api
+    p = _abi.make_params("ont-cdna", seed=9)
+    batches = [synth.make_batch("ont-cdna", n_genes=3, gene_len=7000, depth=30, seed=60 + k) for k in range(3)]
+    batches.append(synth.make_batch("ont-cdna", n_genes=1, gene_len=3000, depth=12, seed=70))
+
+    def results(E):
+        pr, fm = E.phase_result(), E.fragmat()
+        return (E.columns().tobytes(), E.candidates()[0].tobytes(), fm["col"].tobytes(), fm["val"].tobytes(),
+                pr["haplotag"].tobytes(), pr["phase_set"].tobytes())
+    want = []
+    E = engine_cls(0, p)
+    for b in batches:
+        E.load_batch(b).run_all()
+        want.append(results(E))
+    E.close()
+    E = engine_cls(0, p)
+    with pytest.raises(Exception, match="before lcr_load_batch_async"):
+        E.bind_batch(1)
+    with pytest.raises(Exception, match="slot must be 0 or 1"):
+        E.load_batch_async(batches[0], 2)
+    pinned = api.host_register(*[getattr(b, f) for b in batches for f in ("bases", "quals", "cigar")])
+    try:
+        E.load_batch_async(batches[0], 0)
+        for k in range(len(batches)):
+            E.bind_batch(k & 1)
+            if k + 1 < len(batches):
+                E.load_batch_async(batches[k + 1], (k + 1) & 1)     # crosses PCIe while this batch's kernels run
+            E.run_all()
+            assert results(E) == want[k], "batch %d through the asynchronous input path differs" % k
+        # uploading into the BOUND slot invalidates the bound batch (the call waits for its kernels first)
+        E.load_batch_async(batches[1], (len(batches) - 1) & 1)
+        with pytest.raises(Exception, match="before lcr_load_batch"):
+            E.fill_data_into_freq_vec()
+        E.bind_batch((len(batches) - 1) & 1).run_all()
+        assert results(E) == want[1]
+        # the synchronous path still works on the same ctx afterwards
+        E.load_batch(batches[2]).run_all()
+        assert results(E) == want[2]
+    finally:
+        E.close()
+        api.host_unregister(pinned)
+
+
 def _pileup_properties(E, b):
     """plane sums equal the number of kept aligned bases / intron / deletion positions computed with plain numpy
     run-length arithmetic; fwd <= cnt"""
