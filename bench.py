@@ -749,7 +749,9 @@ def main():
                        "parallelism": "regions sharded over %d GPU(s) by shard.assign_regions (LPT on len x max_coverage); final gather of candidate "
                                       "records and read -> HP / PS records to rank 0 (RCCL), overlapped with the next batch" % world,
                        "gathered_records_last_batch": {"candidates": gathered[0], "reads": gathered[1]} if dist is not None else None,
-                       "batches_in_flight_per_gpu": F},
+                       "batches_in_flight_per_gpu": F,
+                       "scaling_reference": ("the N = 1 point of THIS workload (one GPU's 1 000-gene share of C4) is `stages.c4_share.sites_per_sec` of the "
+                                             "N = 1 line; the N = 1 headline `value` is C3, a different workload") if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": "pileup stage = k0_ops + k1_tiles_a/b + k0_desc_bin + k1_pileup + k1_empty_tiles (+ k1_zonefix on HiFi presets): what replaces fill_data_into_freq_vec",
                          "achieved": stage_bytes / (stage_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / 8000.0,
