@@ -47,13 +47,7 @@
                       // [2] pool top, [3] descriptor top (10^5 blocks allocating from ONE word queue up at its memory channel)
 #define K0_HCAP 160   // read headers of a block kept in LDS (more reads in a block: the rest come from global memory)
 
-// record layout (64 bit): [0,40) byte offset of the first read base | [40,50) tile column | [50,60) length-1 |
-// [60] reverse strand | [61,63) transcript-strand class (0 none, 1 -> [0], 2 -> [1]); D / I / N records carry a
-// marker in the offset field
-#define REC_OFF_MASK 0xFFFFFFFFFFull
-#define REC_KIND_D 0xFFFFFFFFFFull
-#define REC_KIND_I 0xFFFFFFFFFEull
-#define REC_KIND_N 0xFFFFFFFFFDull
+// (record layout: lcr_dev.h)
 
 // wave64 inclusive max-scan (same DPP pattern as wave_incl_scan; identity 0: the scanned marks are >= 0)
 __device__ __forceinline__ int wave_incl_max(int v) {

@@ -47,12 +47,7 @@
 #define K1_PIF 4                        // 16-byte pieces in flight per thread (a batch of 1024 records has ~2500 pieces)
 #endif
 
-// record layout (64 bit): [0,40) byte offset of the first read base | [40,50) tile column |
-// [50,60) length-1 | [60] reverse strand | [61,63) transcript-strand class (0 none, 1 -> [0], 2 -> [1])
-#define REC_OFF_MASK 0xFFFFFFFFFFull
-#define REC_KIND_D 0xFFFFFFFFFFull  // offset field of a D-run record
-#define REC_KIND_I 0xFFFFFFFFFEull  // offset field of an I-point record
-#define REC_KIND_N 0xFFFFFFFFFDull  // offset field of an N-run record (the part of an intron inside its first / last tile)
+// (record layout: lcr_dev.h)
 
 // ---------------------------------------------------------------------------------------------
 // read -> region map (one block per region writes its read range)

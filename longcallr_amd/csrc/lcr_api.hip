@@ -50,6 +50,7 @@ struct lcr_ctx {
   // K2
   bool have_cand = false;
   DevBuf flags, tile_count, tile_off, total, survivors, sv_region_off, hist, cand_tmp, keep;
+  int dbg_hist_tiles = 0;   // lcr_debug_set("hist_tiles"): 0 = by survivor density, 1 = the tile form whenever it applies, -1 = never
   std::vector<lcr_candidate> h_cand;
   std::vector<int32_t> h_cand_off;
   DevBuf d_cand, d_cand_off;
@@ -294,6 +295,8 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   uint64_t cig0 = 0, cig_end = 0;
   if (mem == LCR_MEM_HOST) {
     HIPCHK(c, c->h_order.reserve(64));
+    // (a device-resident batch bound before this one returned without a wait: its k0_pack may still be about to raise the flag)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     memset(c->h_order.p, 0, 64);
     if (nr) { cig0 = rd->cig_off[0]; cig_end = rd->cig_off[nr - 1] + rd->n_cig[nr - 1]; }
     for (int r = 0; r + 1 < nr && contiguous; r++) contiguous = rd->cig_off[r + 1] == rd->cig_off[r] + rd->n_cig[r];
@@ -548,13 +551,22 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   c->h_cand.clear();
   c->h_cand_off.assign(ng + 1, 0);
   if (n_sv) {
+    // quality histograms of the survivors: from K0's per-tile records when the survivors are dense (>= 1 per 8 columns: a second
+    // pileup -- C5), else by walking the reads that cover them.  The tile form needs the ONT presets (end trim already cut out of
+    // the records) and u16 counters (a survivor's depth is <= max_depth).
+    const bool tiles_ok = c->dp.ont && p->max_depth <= 65535u;
+    const bool hist_tiles = tiles_ok && c->dbg_hist_tiles >= 0 && (c->dbg_hist_tiles > 0 || (int64_t)n_sv * 8 >= c->n_cols);
     HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (size_t)n_sv * 124 * 4, c->stream));
     { Timer t(c, LCR_K_CAND_HIST);
       launch_k2_compact(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
                         c->planes.as<uint32_t>(), c->flags.as<uint8_t>(), c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(),
                         c->survivors.as<Survivor>(), c->stream);
-      launch_k2_hist(c->bv, c->dp, c->read_bin.as<ReadBin>(), c->survivors.as<Survivor>(), c->sv_region_off.as<int32_t>(), c->hist.as<uint32_t>(),
-                     c->stream); }
+      if (hist_tiles)
+        launch_k2_hist_tiles(c->bv, c->tile_col0.as<int32_t>(), nt, c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(), c->survivors.as<Survivor>(),
+                             c->chunk_off.as<int32_t>(), c->chunks.p, c->k0_items.as<unsigned long long>(), c->hist.as<uint32_t>(), c->stream);
+      else
+        launch_k2_hist(c->bv, c->dp, c->read_bin.as<ReadBin>(), c->survivors.as<Survivor>(), c->sv_region_off.as<int32_t>(), c->hist.as<uint32_t>(),
+                       c->stream); }
     { Timer t(c, LCR_K_CAND_GT);
       launch_k2_gt(c->dp, c->survivors.as<Survivor>(), n_sv, c->hist.as<uint32_t>(), c->bv.start0,
                    c->cand_tmp.as<lcr_candidate>(), d_keep, c->stream); }
@@ -838,6 +850,7 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
   else if (k == "enum_force_big") d.enum_force_big = (int)value;
   else if (k == "enum_force_stream") d.enum_force_stream = (int)value;
   else if (k == "host_threads") d.host_threads = (int)value;
+  else if (k == "hist_tiles") c->dbg_hist_tiles = value > 0 ? 1 : value < 0 ? -1 : 0;
   else if (k == "grid_spec_lanes") d.spec_lanes = (int)std::max<int64_t>(1, std::min<int64_t>(value, 16));
   else { c->err = "lcr_debug_set: unknown key " + k; return LCR_E_ARG; }
   return LCR_OK;

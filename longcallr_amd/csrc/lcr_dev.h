@@ -67,6 +67,14 @@ struct DevParams {
 };
 
 // pass-1 survivor of the candidate filters (one per column that reaches the likelihood block)
+// K0's per-tile records (k0_ops.hip writes them, k1_pileup.hip and k2_hist_tiles read them), 64 bit:
+// [0,40) byte offset of the first read base | [40,50) tile column | [50,60) length-1 | [60] reverse strand |
+// [61,63) transcript-strand class (0 none, 1 -> [0], 2 -> [1]); D / I / N records carry a marker in the offset field
+#define REC_OFF_MASK 0xFFFFFFFFFFull
+#define REC_KIND_D 0xFFFFFFFFFFull  // offset field of a D-run record
+#define REC_KIND_I 0xFFFFFFFFFEull  // offset field of an I-point record
+#define REC_KIND_N 0xFFFFFFFFFDull  // offset field of an N-run record (the part of an intron inside its first / last tile)
+
 struct Survivor {
   int64_t gcol;      // global column index (col_off[region] + column)
   int32_t region;
@@ -169,6 +177,10 @@ void launch_k2_compact(const BatchView& b, const DevParams& p, const int32_t* ti
 float lcr_device_sor_threshold(hipStream_t s);
 void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin, const Survivor* sv, const int32_t* sv_region_off,
                     uint32_t* hist /* n_sv * 4 * 31 */, hipStream_t s);
+// the same histograms from K0's per-tile records instead of a walk over the reads (ONT presets, batches whose survivors are dense)
+void launch_k2_hist_tiles(const BatchView& b, const int32_t* tile_col0, int32_t n_tiles, const int32_t* tile_count,
+                          const int32_t* tile_off, const Survivor* sv, const int32_t* ent_off, const void* ents, const unsigned long long* recs,
+                          uint32_t* hist, hipStream_t s);
 void launch_k2_gt(const DevParams& p, const Survivor* sv, int32_t n_sv, const uint32_t* hist, const int64_t* start0,
                   lcr_candidate* out, int32_t* keep, hipStream_t s);
 void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t* keep, int32_t n_sv, const int32_t* sv_region_off,

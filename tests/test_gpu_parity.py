@@ -816,6 +816,34 @@ def test_device_resident_inputs_and_idempotence(engine_cls):
 
 
 @pytest.mark.gpu
+def test_quality_histograms_from_the_tile_records(engine_cls, orc):
+    """k2_hist_tiles (dense survivors: the histograms are taken from K0's per-tile records, u16 counters in LDS) against the walk
+    over the reads and the oracle: forced on sparse ONT batches (lcr_debug_set hist_tiles), taken unasked by a deep island."""
+    for prof, preset, seed in (("ont-cdna", "ont-cdna", 21), ("ont-drna", "ont-drna", 22)):
+        b = synth.make_batch(prof, n_genes=4, gene_len=8000, depth=45, seed=seed)
+        p = _abi.make_params(preset, seed=5)
+        E = engine_cls(0, p)
+        E.debug_set("hist_tiles", -1)
+        E.load_batch(b).run_all()
+        want = (E.candidates()[0].tobytes(), E.phase_result()["haplotag"].tobytes())
+        E.debug_set("hist_tiles", 1)
+        E.load_batch(b).run_all()
+        assert (E.candidates()[0].tobytes(), E.phase_result()["haplotag"].tobytes()) == want, prof
+        E.close()
+    deep = synth.make_island("ont-drna-c5", n_loci=2, locus_len=6000, depth=400, seed=8)
+    full_check(engine_cls, orc, deep, _abi.make_params("ont-drna", seed=5))    # (survivors on most covered columns: the tile form by itself)
+    # HiFi presets keep the walk (the poly-A mask is not in the records), whatever the switch says
+    b = synth.make_batch("masseq", n_genes=3, gene_len=7000, depth=35, seed=23)
+    p = _abi.make_params("hifi-masseq", seed=5)
+    E = engine_cls(0, p)
+    E.load_batch(b).run_all(); want = E.candidates()[0].tobytes()
+    E.debug_set("hist_tiles", 1)
+    E.load_batch(b).run_all()
+    assert E.candidates()[0].tobytes() == want
+    E.close()
+
+
+@pytest.mark.gpu
 def test_async_input_path_double_buffered(engine_cls):
     """lcr_load_batch_async / lcr_bind_batch: batch i + 1 is uploaded into the other staging slot while batch i's stages run; the
     results are byte-identical to lcr_load_batch of the same host arrays, whatever the slot and the order; page-locked arrays."""
