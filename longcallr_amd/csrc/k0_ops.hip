@@ -34,7 +34,9 @@
 
 #include "lcr_dev.h"
 
+#ifndef K0_THREADS
 #define K0_THREADS 256
+#endif
 #ifndef K0_OPT
 #define K0_OPT 4      // ops per thread: a block takes K0_OPT * K0_THREADS consecutive ops of the flat CIGAR array
 #endif
@@ -42,10 +44,13 @@
 #define K0_ABL 0      // measurement builds only (tools/build_variant.sh -DK0_ABL=n): leave the kernel after phase n -- WRONG planes
 #endif
 #define K0_NW (K0_THREADS / 64)
-#define K0_WIN 256    // tiles of a block's LDS window (one counter per thread)
+#define K0_WIN K0_THREADS   // tiles of a block's LDS window (one counter per thread)
 #define K0_ACC 64     // shards of the record pool / descriptor array, each with its own 128-byte line of counters: [0] items, [1] records,
                       // [2] pool top, [3] descriptor top (10^5 blocks allocating from ONE word queue up at its memory channel)
-#define K0_HCAP 160   // read headers of a block kept in LDS (more reads in a block: the rest come from global memory)
+#ifndef K0_HCAP
+#define K0_HCAP 160
+#endif
+// K0_HCAP: read headers of a block kept in LDS (more reads in a block: the rest come from global memory)
 
 // (record layout: lcr_dev.h)
 
