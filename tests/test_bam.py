@@ -241,6 +241,28 @@ def test_decoder_holds_one_contig_at_a_time(tmp_path):
     nb.close()
 
 
+def test_interleaved_contigs_fall_back_to_the_record_chain(tmp_path):
+    """A file whose contigs interleave (records of c1, c2, c1): the record-size table of the open pass only indexes contigs
+    whose records lie back to back; the others are found by walking the block_size chain of their range, as before."""
+    recs = [dict(ref=0, pos=10, name="a", cigar="20M", seq="ACGT" * 5), dict(ref=1, pos=5, name="b", cigar="12M", seq="ACG" * 4),
+            dict(ref=0, pos=40, name="c", cigar="8M2D8M", seq="ACGT" * 4), dict(ref=1, pos=30, name="d", cigar="16M", seq="ACGT" * 4),
+            dict(ref=1, pos=31, name="e", cigar="16M", seq="TTGA" * 4)]
+    p = str(tmp_path / "mixed.bam")
+    open(p, "wb").write(bgzf(bam_bytes([("c1", 1000), ("c2", 1000)], recs), 90))
+    flt = dict(min_mapq=0, min_read_length=1, divergence=2.0)
+    nb = bamio.NativeBam(p, 4)
+    assert nb.n_records == 5
+    s0, e0 = nb.spans(0, **flt)
+    s1, e1 = nb.spans(1, **flt)
+    assert s0.tolist() == [10, 40] and e0.tolist() == [30, 58]
+    assert s1.tolist() == [5, 30, 31] and e1.tolist() == [17, 46, 47]
+    s0b, _ = nb.spans(0, **flt)                       # and back: contigs are loaded on demand, one at a time
+    assert s0b.tolist() == [10, 40]
+    b = nb.batch(1, [(0, 100)], [np.full(100, ord("A"), np.uint8)], **flt)
+    assert b.n_reads == 3 and b.names == ["b", "d", "e"]
+    nb.close()
+
+
 def test_bad_inputs_are_errors_not_crashes(tmp_path):
     with pytest.raises(_lib.LcrError, match="cannot open"):
         bamio.NativeBam(str(tmp_path / "missing.bam"))
