@@ -666,8 +666,19 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
   int8_t* etw = spec ? dlw + C.spec_s8 : v.et;
   uint32_t* s_sig = (uint32_t*)dyn;                     // LDS: sigma bits of every row
   int8_t* s_dl = (int8_t*)(s_sig + 2 * ng); int8_t* s_et = s_dl + S;
-  const int32_t* rp = v.mv.rp; const int32_t* pc = v.mv.pc; const uint8_t* pv = v.mv.pv;
-  const int32_t* cp = v.mv.cp; const int32_t* cr = v.mv.cr; const uint8_t* cv = v.mv.cv;
+  const int32_t* rp = v.mv.rp; const int32_t* cp = v.mv.cp;
+  // the entries as one dword each (value byte << 24 | SNP in row order, | row in column order): a lane reads four with one
+  // 16-byte load.  (A dword + a byte load per entry kept the texture addressers as busy as the VALUs, 34 % each on C5, with the
+  // matrix streaming from beyond L2 in every half step.)
+  uint32_t* const pkr = C.pk_csr; uint32_t* const pkc = C.pk_csc;
+  {
+    const int32_t* pc = v.mv.pc; const uint8_t* pv = v.mv.pv; const int32_t* cr = v.mv.cr; const uint8_t* cv = v.mv.cv;
+    const int E = cp[S];
+    for (int e = sc.tid(); e < E + 8; e += sc.nt()) {
+      pkr[e] = e < E ? ((uint32_t)pv[e] << 24) | (uint32_t)pc[e] : 0u;
+      pkc[e] = e < E ? ((uint32_t)cv[e] << 24) | (uint32_t)cr[e] : 0u;
+    }
+  }
   const uint8_t* fp = v.mv.fp;
   const long long* scn = C.P.snp_const + 4ll * rd.snp_off;
   const PhaseLutDev& lut = C.P.lut;
@@ -719,55 +730,55 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
       // (dealing the units through a stride coprime to their number narrows the spread between workgroups -- max 26.2 ->
       // 24.4 us -- but costs locality: median 19.6 -> 20.3 us, rounds 528 -> 536 ms; not kept)
       for (int u = wj0; u < 2 * ng; u += nw) {
-        // sixteen lanes per row, four rows per pass: a row's entries are one coalesced load (thread-per-row would touch
+        // eight lanes per row, eight rows per pass: a row's entries are one coalesced load (thread-per-row would touch
         // every cache line of the group once per entry)
-        const int j = u >> 1, q0 = 8 * (u & 1);
+        const int j = u >> 1;
         const unsigned long long word = cload(&wsw[j]);
         const int rl = min(64 * j + lane, R);
         const int my_b = rp[rl], my_e = rp[min(rl + 1, R)];          // lane <-> row of the group (empty past R)
         unsigned long long nword = word;
-        const int sub = lane & 15, rsel = lane >> 4;
-        // pass q works on rows 4q .. 4q+3 of the group; eight passes at a time, the first 32 entries of each of their rows
-        // are loaded before anything is used (32 independent loads in flight per lane), longer rows finish in a tail loop
+        const int l8 = lane & 7, rsel = lane >> 3;
+        // pass q works on rows 8q .. 8q+7 of the half group: eight lanes per row, four entries per lane and load; the four
+        // passes' first 32 entries per row are requested before anything is used, longer rows finish in a tail loop.
+        // (Requesting the NEXT unit's row pointers and entries while this one is summed -- two dependent trips to memory per
+        // unit, ~10 units per wave and step -- was measured: 83 instead of 27 spilled VGPRs under the 128 of a sixteen-wave
+        // workgroup, rounds 322 -> 335 ms.)
         {
-          int pi[8][2]; uint8_t px[8][2];
+          uint4 pe[4];
 #pragma unroll
-          for (int q = 0; q < 8; q++) {
-            const int rr = 4 * (q0 + q) + rsel;
+          for (int q = 0; q < 4; q++) {
+            const int rr = 8 * (4 * (u & 1) + q) + rsel;
             const int eb = __shfl(my_b, rr, 64), ee = __shfl(my_e, rr, 64);
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-              const int e = eb + sub + 16 * u;
-              const bool ok = e < ee;
-              pi[q][u] = ok ? pc[e] : -1;
-              px[q][u] = ok ? pv[e] : (uint8_t)0;
-            }
+            const int e = eb + 4 * l8;
+            pe[q] = e < ee ? *reinterpret_cast<const uint4*>(pkr + e) : make_uint4(0, 0, 0, 0);   // (up to three entries past the row: masked below)
           }
 #pragma unroll
-          for (int q = 0; q < 8; q++) {
-            const int rr = 4 * (q0 + q) + rsel;
+          for (int q = 0; q < 4; q++) {
+            const int rr = 8 * (4 * (u & 1) + q) + rsel;
             const int s = ((word >> rr) & 1ull) ? 1 : -1;
+            const int eb = __shfl(my_b, rr, 64), ee = __shfl(my_e, rr, 64);
             long long diff = 0;
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-              const int i = pi[q][u];
-              if (i >= 0 && s_et[i] == 0) { const long long w = wl[px[q][u] & 31]; diff += (((px[q][u] & 32) ? 1 : -1) == s * s_dl[i]) ? w : -w; }
+            auto term = [&](uint32_t ent, bool ok) {
+              const int i = (int)(ent & 0xFFFFFFu);
+              const uint32_t x = ent >> 24;
+              if (ok && s_et[i] == 0) { const long long w = wl[x & 31]; diff += (((x & 32) ? 1 : -1) == s * s_dl[i]) ? w : -w; }
+            };
+            {
+              const int e = eb + 4 * l8;
+              term(pe[q].x, e < ee); term(pe[q].y, e + 1 < ee); term(pe[q].z, e + 2 < ee); term(pe[q].w, e + 3 < ee);
             }
-            const int ee = __shfl(my_e, rr, 64);
-            for (int e = __shfl(my_b, rr, 64) + sub + 32; e < ee; e += 16) {
-              const int i = pc[e];
-              const uint8_t x = pv[e];
-              if (s_et[i] == 0) { const long long w = wl[x & 31]; diff += (((x & 32) ? 1 : -1) == s * s_dl[i]) ? w : -w; }
+            for (int e = eb + 4 * l8 + 32; e < ee; e += 32) {
+              const uint4 t = *reinterpret_cast<const uint4*>(pkr + e);
+              term(t.x, true); term(t.y, e + 1 < ee); term(t.z, e + 2 < ee); term(t.w, e + 3 < ee);
             }
-            diff += LCR_DPP_LL(diff, 0x111, 0xf);   // sum over the 16 lanes of the DPP row (row_shr 1, 2, 4, 8)
+            diff += LCR_DPP_LL(diff, 0x111, 0xf);   // sum over the 8 lanes of the row (row_shr 1, 2, 4: lanes 7 and 15 of a DPP row)
             diff += LCR_DPP_LL(diff, 0x112, 0xf);
             diff += LCR_DPP_LL(diff, 0x114, 0xf);
-            diff += LCR_DPP_LL(diff, 0x118, 0xf);
-            const unsigned long long fb = __ballot(sub == 15 && diff < 0);   // lane 15 of each row holds the row's sum
+            const unsigned long long fb = __ballot(l8 == 7 && diff < 0);   // lane 7 of each row holds the row's sum
             if (fb) {
               any = 1;
 #pragma unroll
-              for (int t = 0; t < 4; t++) if ((fb >> (16 * t + 15)) & 1ull) nword ^= 1ull << (4 * (q0 + q) + t);
+              for (int t = 0; t < 8; t++) if ((fb >> (8 * t + 7)) & 1ull) nword ^= 1ull << (8 * (4 * (u & 1) + q) + t);
             }
           }
         }
@@ -800,14 +811,14 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
           if (c0 == c1) continue;
           const int d = s_dl[i], h = s_et[i];
           long long M = 0;   // sum of w over the entries with p == sigma * d
-          for (int e = c0 + 64 * wt + lane; e < c1; e += 1024) {   // four independent loads in flight per lane
-            uint8_t x[4]; int row[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int eu = min(e + 256 * u, c1 - 1); x[u] = cv[eu]; row[u] = cr[eu]; }
+          for (int e = c0 + 4 * (64 * wt + lane); e < c1; e += 1024) {   // four consecutive entries per lane and load
+            const uint4 t = *reinterpret_cast<const uint4*>(pkc + e);     // (up to three entries past the column: masked)
+            const uint32_t en[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-              const int s = ((s_sig[row[u] >> 5] >> (row[u] & 31)) & 1u) ? 1 : -1;
-              if (e + 256 * u < c1 && ((x[u] & 32) ? 1 : -1) == s * d) M += wl[x[u] & 31];
+              const uint32_t row = en[u] & 0xFFFFFFu, x = en[u] >> 24;
+              const int s = ((s_sig[row >> 5] >> (row & 31)) & 1u) ? 1 : -1;
+              if (e + u < c1 && ((x & 32) ? 1 : -1) == s * d) M += wl[x & 31];
             }
           }
           M = wave_sum_ll_dpp(M);
@@ -1017,7 +1028,7 @@ __global__ void __launch_bounds__(CH_THREADS) k4_chain_grid(ChainDev C, int32_t 
   };
   extern __shared__ __attribute__((aligned(16))) uint8_t dyn_fast[];
   auto fast_rounds = [&](long long best) -> bool {
-    if (!d.fast_lds) return false;
+    if (!d.fast_lds || !C.pk_csr || (int64_t)v.mv.cp[rd.S] > C.pk_cap) return false;
     return chain_rounds_fast(sc, C, rd, v, wl, dyn_fast, best, d.slot);
   };
   chain_run(sc, C, rd, v, wl, L, stage, sm, cross, fast_rounds, d.slot);

@@ -584,6 +584,10 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       PCHK(d_spec_sig.reserve(lanes * ng_max * 8 + 64)); PCHK(d_spec_de.reserve(lanes * 2 * s8 + 64)); PCHK(d_spec_res.reserve(lanes * 8 + 64));
       C.spec_sig = d_spec_sig.as<unsigned long long>(); C.spec_de = d_spec_de.as<int8_t>(); C.spec_res = d_spec_res.as<long long>();
       C.spec_lanes = (int32_t)lanes; C.spec_ng = (int32_t)ng_max; C.spec_s8 = (int32_t)s8;
+      size_t e_max = 0;   // packed entries of the largest all-CU region with device-coherent rounds
+      for (int k = n_small; k < nc; k++) if (desc[k].fast_lds) e_max = std::max(e_max, (size_t)stat[desc[k].slot].E);
+      C.pk_cap = (int64_t)e_max;
+      if (e_max) { PCHK(d_pk.reserve(2 * (e_max + 8) * 4 + 64)); C.pk_csr = d_pk.as<uint32_t>(); C.pk_csc = C.pk_csr + (e_max + 8); }
     }
     Pc.scratch = nullptr; Pc.scratch_stride = 0; Pc.lds_state = 0; Pc.lds_mat = 0;
     C.P = Pc;

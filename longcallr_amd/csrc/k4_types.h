@@ -66,6 +66,9 @@ struct ChainDev {
   // (sigma words: spec_ng per lane; delta | eta bytes: 2 x spec_s8 per lane), its result and its barrier words
   unsigned long long* spec_sig; int8_t* spec_de; long long* spec_res; GridCtl* spec_ctl;
   int32_t spec_lanes, spec_ng, spec_s8;
+  // the region's phase entries as one dword each -- value byte << 24 | SNP (row order) / value byte << 24 | row (column order) --
+  // so that the rounds read four entries per 16-byte load; pk_cap entries each (+ 8 of padding), filled when the rounds begin
+  uint32_t* pk_csr; uint32_t* pk_csc; int64_t pk_cap;
   long long* dbg;                 // LCR_PHASE_PROF: 100 MHz timestamps of the chain steps of a grid launch, 16 per launch (else nullptr)
   double le[31], l1e[31], p_homref, p_homvar, log_theta, log2;   // libm values of the block-flip sums (host table)
 };

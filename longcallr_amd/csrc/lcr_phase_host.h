@@ -135,7 +135,7 @@ struct PhaseHost {
   const uint8_t* r_assignment = nullptr;
   const uint32_t* r_phase_set = nullptr;
   DevBuf d_state[40];
-  DevBuf d_spec_sig, d_spec_de, d_spec_res;   // working states / results of the speculative half-rounds (k4_grid.hip)
+  DevBuf d_spec_sig, d_spec_de, d_spec_res, d_pk;   // working states / results of the speculative half-rounds (k4_grid.hip)
   DevBuf d_read_rec;             // per-row results as 12-byte records in HBM, written by k4_post
   bool read_rec_stale = false;   // some regions took the host epilogue: the records are rebuilt from the host arrays on demand
   HostBuf h_pin[11];   // pinned staging: row_ptr, col, val, links, enum state, region sizes, chain state, results, job tables, chain start
@@ -153,7 +153,7 @@ struct PhaseHost {
   int run(const PhaseInputs& in, const lcr_params& p, hipStream_t s, std::string* err);
   void release() {
     for (auto& b : d_state) b.release();
-    d_read_rec.release(); d_spec_sig.release(); d_spec_de.release(); d_spec_res.release();
+    d_read_rec.release(); d_spec_sig.release(); d_spec_de.release(); d_spec_res.release(); d_pk.release();
     for (auto& b : h_pin) b.release();
     if (side) { (void)hipStreamDestroy(side); side = nullptr; }
     if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
