@@ -120,7 +120,7 @@ struct PhaseDebug {
   int post_half = 0;            // "post_half": the eight-wave epilogue of the chain regions
   int enum_force_big = 0;       // "enum_force_big" / "enum_force_stream": the fallback enumeration kernels
   int enum_force_stream = 0;
-  int spec_lanes = 4;           // "grid_spec_lanes": half-rounds of the perturbation loop run at once at grid scope (1: one after the other; C5: 581 / 446 / 476 / 455 ms with 1 / 4 / 8 / 16)
+  int spec_lanes = 8;           // "grid_spec_lanes": half-rounds of the perturbation loop run at once at grid scope (1: one after the other; C5 with packed entries: 454 / 370 / 348 / 366 ms with 2 / 4 / 8 / 16 -- eight lanes = one XCD each)
   int host_threads = 0;         // "host_threads": size of the host pool of the host epilogue (0: hardware threads / devices, <= 48)
 };
 

@@ -1101,8 +1101,8 @@ def test_c5_scopes_and_paths_agree(engine_cls, monkeypatch):
         r = _result_bytes(E) + (repr(E.ld_blocks(0)),)
         E.close()
         return r
-    ref = run()      # (default: four speculative half-rounds at a time, each on a quarter of the workgroups)
-    for lanes in ("1", "8", "16"):   # one half-round after the other; other batch widths: same commits, same bytes
+    ref = run()      # (default: eight speculative half-rounds at a time, each on an eighth of the workgroups -- one XCD)
+    for lanes in ("1", "4", "16"):   # one half-round after the other; other batch widths: same commits, same bytes
         monkeypatch.setenv("LCR_GRID_SPEC_LANES", lanes)
         assert run() == ref, "speculative rounds with %s lanes" % lanes
     monkeypatch.delenv("LCR_GRID_SPEC_LANES")
