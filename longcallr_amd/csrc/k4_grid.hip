@@ -667,17 +667,18 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
   uint32_t* s_sig = (uint32_t*)dyn;                     // LDS: sigma bits of every row
   int8_t* s_dl = (int8_t*)(s_sig + 2 * ng); int8_t* s_et = s_dl + S;
   const int32_t* rp = v.mv.rp; const int32_t* cp = v.mv.cp;
-  // the entries as one dword each (value byte << 24 | SNP in row order, | row in column order): a lane reads four with one
-  // 16-byte load.  (A dword + a byte load per entry kept the texture addressers as busy as the VALUs, 34 % each on C5, with the
+  // the entries as one dword each (value byte << 24 | row-in-unit << 18 | SNP in row order, value byte << 24 | row in column
+  // order): a lane reads four with one 16-byte load.  (A dword + a byte load per entry kept the texture addressers as busy as the VALUs, 34 % each on C5, with the
   // matrix streaming from beyond L2 in every half step.)
   uint32_t* const pkr = C.pk_csr; uint32_t* const pkc = C.pk_csc;
   {
     const int32_t* pc = v.mv.pc; const uint8_t* pv = v.mv.pv; const int32_t* cr = v.mv.cr; const uint8_t* cv = v.mv.cv;
     const int E = cp[S];
-    for (int e = sc.tid(); e < E + 8; e += sc.nt()) {
-      pkr[e] = e < E ? ((uint32_t)pv[e] << 24) | (uint32_t)pc[e] : 0u;
-      pkc[e] = e < E ? ((uint32_t)cv[e] << 24) | (uint32_t)cr[e] : 0u;
-    }
+    for (int e = sc.tid(); e < E + 8; e += sc.nt()) pkc[e] = e < E ? ((uint32_t)cv[e] << 24) | (uint32_t)cr[e] : 0u;
+    // row order: value byte << 24 | row inside its 32-row unit << 18 | SNP (S < 2^18, checked by the caller)
+    for (int row = sc.tid(); row < R; row += sc.nt())
+      for (int e = rp[row]; e < rp[row + 1]; e++) pkr[e] = ((uint32_t)pv[e] << 24) | ((uint32_t)(row & 31) << 18) | (uint32_t)pc[e];
+    for (int e = E + sc.tid(); e < E + 8; e += sc.nt()) pkr[e] = 0u;
   }
   const uint8_t* fp = v.mv.fp;
   const long long* scn = C.P.snp_const + 4ll * rd.snp_off;
@@ -689,6 +690,8 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
   // owned a run of them would be the slowest or the fastest of every half step)
   const int wj0 = (int)(threadIdx.x >> 6) * sub.nblk() + sub.blk();
   __shared__ unsigned long long t_sum[4][8];   // delta step: partial sums / arrivals of the four-wave teams
+  __shared__ long long rsum_all[CH_THREADS / 64][32];   // sigma step: row sums of the unit a wave is working on
+  long long* const rsum = rsum_all[threadIdx.x >> 6];
   __shared__ unsigned t_cnt[4][8];
   if (threadIdx.x < 32) { t_sum[threadIdx.x >> 3][threadIdx.x & 7] = 0; t_cnt[threadIdx.x >> 3][threadIdx.x & 7] = 0; }
   // ---- delta step order: SNPs by column length, dealt to the teams in serpentine order (longest to team 0, 1, .. T-1,
@@ -725,64 +728,55 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
       tick(8);
       const long long wg_t0 = C.dbg ? (long long)wall_clock64() : 0;   // (LCR_PHASE_PROF: every workgroup's own time in the half steps)
       int any = 0;
-      // a wave's unit is HALF a 64-row group (eight passes of four rows): 10 400 units over 4 096 waves is 2 or 3 each,
-      // whole groups were 1 or 2 each and the waves with 2 set the step's length (26 -> 20 us per iteration on C5)
-      // (dealing the units through a stride coprime to their number narrows the spread between workgroups -- max 26.2 ->
-      // 24.4 us -- but costs locality: median 19.6 -> 20.3 us, rounds 528 -> 536 ms; not kept)
-      for (int u = wj0; u < 2 * ng; u += nw) {
-        // eight lanes per row, eight rows per pass: a row's entries are one coalesced load (thread-per-row would touch
-        // every cache line of the group once per entry)
-        const int j = u >> 1;
-        const unsigned long long word = cload(&wsw[j]);
-        const int rl = min(64 * j + lane, R);
-        const int my_b = rp[rl], my_e = rp[min(rl + 1, R)];          // lane <-> row of the group (empty past R)
-        unsigned long long nword = word;
-        const int l8 = lane & 7, rsel = lane >> 3;
-        // pass q works on rows 8q .. 8q+7 of the half group: eight lanes per row, four entries per lane and load; the four
-        // passes' first 32 entries per row are requested before anything is used, longer rows finish in a tail loop.
-        // (Requesting the NEXT unit's row pointers and entries while this one is summed -- two dependent trips to memory per
-        // unit, ~10 units per wave and step -- was measured: 83 instead of 27 spilled VGPRs under the 128 of a sixteen-wave
-        // workgroup, rounds 322 -> 335 ms.)
-        {
-          uint4 pe[4];
+      // a wave's unit is HALF a 64-row group (32 rows): 10 400 units on C5.  The unit's entries are one dense run of the packed row
+      // array: the lanes read it four entries per load whatever the rows' lengths (every lane busy, every load coalesced), an
+      // entry names its row inside the unit, a lane sums its run of entries per row and adds the run to the row's accumulator
+      // in LDS (integer, order-free); lanes 0-31 then take the rows' decisions.  The units of a wave are fixed, so where each
+      // begins is fetched once per step for all of them: no load of a unit waits for another.  (Before: a group of lanes per
+      // row -- row pointers, then entries: two dependent trips per unit, 78 % of the lanes with an entry, DPP row sums.)
+      {
+        const int n_units = 2 * ng;
+        for (int k0 = 0; wj0 + k0 * nw < n_units; k0 += 64) {
+          const int uk = wj0 + (k0 + lane) * nw;                        // lane <-> one of the wave's next 64 units
+          const int ub_l = uk < n_units ? rp[min(32 * uk, R)] : 0, ue_l = uk < n_units ? rp[min(32 * uk + 32, R)] : 0;
+          for (int k = 0; k < 64 && wj0 + (k0 + k) * nw < n_units; k++) {
+            const int u = wj0 + (k0 + k) * nw, j = u >> 1;
+            const int ub = __shfl(ub_l, k, 64), ue = __shfl(ue_l, k, 64);
+            const unsigned long long word = cload(&wsw[j]);
+            const uint32_t sbits = (uint32_t)(word >> (32 * (u & 1)));   // sigma of the unit's rows
+            if (lane < 32) rsum[lane] = 0;
+            wave_lds_sync();
+            auto run4 = [&](const uint4& t, int e) {
+              const uint32_t en[4] = {t.x, t.y, t.z, t.w};
+              long long acc = 0; uint32_t cur = 32u;
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int rr = 8 * (4 * (u & 1) + q) + rsel;
-            const int eb = __shfl(my_b, rr, 64), ee = __shfl(my_e, rr, 64);
-            const int e = eb + 4 * l8;
-            pe[q] = e < ee ? *reinterpret_cast<const uint4*>(pkr + e) : make_uint4(0, 0, 0, 0);   // (up to three entries past the row: masked below)
-          }
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int rr = 8 * (4 * (u & 1) + q) + rsel;
-            const int s = ((word >> rr) & 1ull) ? 1 : -1;
-            const int eb = __shfl(my_b, rr, 64), ee = __shfl(my_e, rr, 64);
-            long long diff = 0;
-            auto term = [&](uint32_t ent, bool ok) {
-              const int i = (int)(ent & 0xFFFFFFu);
-              const uint32_t x = ent >> 24;
-              if (ok && s_et[i] == 0) { const long long w = wl[x & 31]; diff += (((x & 32) ? 1 : -1) == s * s_dl[i]) ? w : -w; }
+              for (int x4 = 0; x4 < 4; x4++) {
+                if (e + x4 < ue) {
+                  const uint32_t i = en[x4] & 0x3FFFFu, rid = (en[x4] >> 18) & 31u, x = en[x4] >> 24;
+                  if (rid != cur) { if (cur < 32u && acc) atomicAdd(reinterpret_cast<unsigned long long*>(&rsum[cur]), (unsigned long long)acc); cur = rid; acc = 0; }
+                  if (s_et[i] == 0) { const long long w = wl[x & 31]; const int sg1 = ((sbits >> rid) & 1u) ? 1 : -1; acc += (((x & 32) ? 1 : -1) == sg1 * s_dl[i]) ? w : -w; }
+                }
+              }
+              if (cur < 32u && acc) atomicAdd(reinterpret_cast<unsigned long long*>(&rsum[cur]), (unsigned long long)acc);
             };
-            {
-              const int e = eb + 4 * l8;
-              term(pe[q].x, e < ee); term(pe[q].y, e + 1 < ee); term(pe[q].z, e + 2 < ee); term(pe[q].w, e + 3 < ee);
+            {   // the first 1 024 entries of the unit are requested before any is used
+              uint4 t4[4];
+#pragma unroll
+              for (int q = 0; q < 4; q++) { const int e = ub + 4 * lane + 256 * q; t4[q] = e < ue ? *reinterpret_cast<const uint4*>(pkr + e) : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+              for (int q = 0; q < 4; q++) { const int e = ub + 4 * lane + 256 * q; if (e < ue) run4(t4[q], e); }
+              for (int e = ub + 4 * lane + 1024; e < ue; e += 256) run4(*reinterpret_cast<const uint4*>(pkr + e), e);
             }
-            for (int e = eb + 4 * l8 + 32; e < ee; e += 32) {
-              const uint4 t = *reinterpret_cast<const uint4*>(pkr + e);
-              term(t.x, true); term(t.y, e + 1 < ee); term(t.z, e + 2 < ee); term(t.w, e + 3 < ee);
-            }
-            diff += LCR_DPP_LL(diff, 0x111, 0xf);   // sum over the 8 lanes of the row (row_shr 1, 2, 4: lanes 7 and 15 of a DPP row)
-            diff += LCR_DPP_LL(diff, 0x112, 0xf);
-            diff += LCR_DPP_LL(diff, 0x114, 0xf);
-            const unsigned long long fb = __ballot(l8 == 7 && diff < 0);   // lane 7 of each row holds the row's sum
+            wave_lds_sync();
+            const long long diff = lane < 32 ? rsum[lane] : 0;
+            const unsigned long long fb = __ballot(lane < 32 && diff < 0);
+            wave_lds_sync();
             if (fb) {
               any = 1;
-#pragma unroll
-              for (int t = 0; t < 8; t++) if ((fb >> (8 * t + 7)) & 1ull) nword ^= 1ull << (8 * (4 * (u & 1) + q) + t);
+              if (lane == 0) cstore(reinterpret_cast<uint32_t*>(&wsw[j]) + (u & 1), sbits ^ (uint32_t)fb);   // (this unit's half of the word)
             }
           }
         }
-        if (lane == 0 && nword != word) cstore(reinterpret_cast<uint32_t*>(&wsw[j]) + (u & 1), (uint32_t)(nword >> (32 * (u & 1))));   // (this unit's half of the word)
       }
       __syncthreads();
       if (C.dbg && threadIdx.x == 0 && my == 0 && sub.blk() < 1024) C.dbg[16 + sub.blk()] += (long long)wall_clock64() - wg_t0;
@@ -1028,7 +1022,7 @@ __global__ void __launch_bounds__(CH_THREADS) k4_chain_grid(ChainDev C, int32_t 
   };
   extern __shared__ __attribute__((aligned(16))) uint8_t dyn_fast[];
   auto fast_rounds = [&](long long best) -> bool {
-    if (!d.fast_lds || !C.pk_csr || (int64_t)v.mv.cp[rd.S] > C.pk_cap) return false;
+    if (!d.fast_lds || !C.pk_csr || (int64_t)v.mv.cp[rd.S] > C.pk_cap || rd.S >= (1 << 18)) return false;
     return chain_rounds_fast(sc, C, rd, v, wl, dyn_fast, best, d.slot);
   };
   chain_run(sc, C, rd, v, wl, L, stage, sm, cross, fast_rounds, d.slot);
