@@ -795,18 +795,30 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
       // sums meet in LDS and the last one to arrive decides -- no barrier inside the loop
       {
         const int team = threadIdx.x >> 8, wt = (threadIdx.x >> 6) & 3, nteams = sub.nblk() * 4, gteam = team * sub.nblk() + sub.blk();
-        int it = 0;
+        // the team's SNPs are fixed: which they are and where their columns lie is fetched once for 64 of them (a lane each), not
+        // SNP by SNP in front of the column's entries (order -> column pointers -> entries were three dependent trips to memory
+        // for each of a team's ~37 SNPs: the whole step's length)
+        int it = 0, i_l = -1, c0_l = 0, c1_l = 0, fp_l = 0;
+        long long F_l = 0, Wt_l = 0, D2_l = 0, D3_l = 0;   // the SNP's constants travel with its pointers (the deciding lane used to fetch them last)
+        auto shfl_ll = [&](long long x, int k) -> long long {
+          return ((long long)__shfl((int)(x >> 32), k, 64) << 32) | (unsigned int)__shfl((int)x, k, 64);
+        };
         for (int base = 0; base < S; base += nteams, it++) {
+          if ((it & 63) == 0) {
+            const int itl = it + lane, pl = itl * nteams + ((itl & 1) ? nteams - 1 - gteam : gteam);
+            i_l = ((int64_t)itl * nteams < S && pl < S) ? ord[pl] : -1;
+            c0_l = i_l >= 0 ? cp[i_l] : 0; c1_l = i_l >= 0 ? cp[i_l + 1] : 0;
+            if (i_l >= 0) { F_l = scn[4 * i_l]; Wt_l = scn[4 * i_l + 1]; D2_l = scn[4 * i_l + 2]; D3_l = scn[4 * i_l + 3]; fp_l = fp[i_l]; }
+          }
           if ((it & 7) == 0 && it) __syncthreads();   // the ring of 8 slots per team wraps (uniform trip count)
-          const int pos = base + ((it & 1) ? nteams - 1 - gteam : gteam);
-          if (pos >= S) continue;
-          const int i = ord[pos];
-          const int c0 = cp[i], c1 = cp[i + 1];
+          const int k = it & 63;
+          const int i = __shfl(i_l, k, 64);
+          const int c0 = __shfl(c0_l, k, 64), c1 = __shfl(c1_l, k, 64);
+          if (i < 0) continue;
           if (c0 == c1) continue;
           const int d = s_dl[i], h = s_et[i];
           long long M = 0;   // sum of w over the entries with p == sigma * d
-          for (int e = c0 + 4 * (64 * wt + lane); e < c1; e += 1024) {   // four consecutive entries per lane and load
-            const uint4 t = *reinterpret_cast<const uint4*>(pkc + e);     // (up to three entries past the column: masked)
+          auto run4 = [&](const uint4& t, int e) {
             const uint32_t en[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -814,8 +826,19 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
               const int s = ((s_sig[row >> 5] >> (row & 31)) & 1u) ? 1 : -1;
               if (e + u < c1 && ((x & 32) ? 1 : -1) == s * d) M += wl[x & 31];
             }
+          };
+          // (requesting the NEXT column's entries under this column's sums was measured: 47 instead of 8 spilled VGPRs, 277 vs 274 ms)
+          {   // four consecutive entries per lane and load; the column's first 2 048 entries (C5: all of them) leave together
+            const int ea = c0 + 4 * (64 * wt + lane), eb2 = ea + 1024;
+            const uint4 ta = ea < c1 ? *reinterpret_cast<const uint4*>(pkc + ea) : make_uint4(0, 0, 0, 0);
+            const uint4 tb = eb2 < c1 ? *reinterpret_cast<const uint4*>(pkc + eb2) : make_uint4(0, 0, 0, 0);
+            if (ea < c1) run4(ta, ea);
+            if (eb2 < c1) run4(tb, eb2);
+            for (int e = ea + 2048; e < c1; e += 1024) run4(*reinterpret_cast<const uint4*>(pkc + e), e);
           }
           M = wave_sum_ll_dpp(M);
+          const long long F = shfl_ll(F_l, k), Wt = shfl_ll(Wt_l, k), D2 = shfl_ll(D2_l, k), D3 = shfl_ll(D3_l, k);
+          const int fpi = __shfl(fp_l, k, 64);
           if (lane == 0) {
             unsigned long long* ts = &t_sum[team][it & 7];
             unsigned* tc = &t_cnt[team][it & 7];
@@ -825,12 +848,11 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
               M = (long long)__hip_atomic_load(ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               __hip_atomic_store(ts, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               __hip_atomic_store(tc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              const long long F = scn[4 * i], Wt = scn[4 * i + 1];
               // data terms of (d,0) (-d,0) (d,+1) (d,-1); with_genotype is false: a het site stays het (it may flip), a hom
               // site may change between homref and homvar.  The priors are equal inside a class, so the data terms decide.
-              const long long D0 = F + M, D1 = F + Wt - M, D2 = scn[4 * i + 2], D3 = scn[4 * i + 3];
+              const long long D0 = F + M, D1 = F + Wt - M;
               long long chosen = h == 0 ? D0 : (h == 1 ? D2 : D3);
-              if (fp[i]) {
+              if (fpi) {
                 if (h == 0) { if (D1 > D0) { chosen = D1; any = 1; cstore(&dlw[i], (int8_t)(-d)); } }
                 else {
                   const long long n2 = D2 + lut.f_homref, n3 = D3 + lut.f_homvar;
