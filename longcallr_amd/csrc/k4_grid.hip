@@ -739,11 +739,13 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
         for (int k0 = 0; wj0 + k0 * nw < n_units; k0 += 64) {
           const int uk = wj0 + (k0 + lane) * nw;                        // lane <-> one of the wave's next 64 units
           const int ub_l = uk < n_units ? rp[min(32 * uk, R)] : 0, ue_l = uk < n_units ? rp[min(32 * uk + 32, R)] : 0;
+          // (sigma of the unit's rows as well: the unit's half of its word is written by this wave only)
+          const unsigned long long wd_l = uk < n_units ? cload(&wsw[uk >> 1]) : 0ull;
+          const uint32_t sb_l = (uint32_t)(wd_l >> (32 * (uk & 1)));
           for (int k = 0; k < 64 && wj0 + (k0 + k) * nw < n_units; k++) {
             const int u = wj0 + (k0 + k) * nw, j = u >> 1;
             const int ub = __shfl(ub_l, k, 64), ue = __shfl(ue_l, k, 64);
-            const unsigned long long word = cload(&wsw[j]);
-            const uint32_t sbits = (uint32_t)(word >> (32 * (u & 1)));   // sigma of the unit's rows
+            const uint32_t sbits = (uint32_t)__shfl((int)sb_l, k, 64);   // sigma of the unit's rows
             if (lane < 32) rsum[lane] = 0;
             wave_lds_sync();
             auto run4 = [&](const uint4& t, int e) {
