@@ -6,9 +6,9 @@
 hipError_t k4_chain_launch_wg(const ChainDev& C, int first, int n, size_t dyn_lds, hipStream_t s);
 // all CUs on the single region desc[which] (persistent launch with grid barriers; C.ctl is reset here)
 hipError_t k4_chain_launch_grid(const ChainDev& C, int which, size_t dyn_lds, hipStream_t s);
-// dynamic LDS the device-coherent perturbation rounds may use (sigma bit vector + delta / eta bytes of the region)
+// dynamic LDS the device-coherent perturbation rounds may use (sigma bit vector + delta / eta / het-delta bytes of the region)
 constexpr int K4_GRID_FAST_LDS_MAX = 96 * 1024;
-inline size_t k4_grid_fast_lds(int64_t R, int64_t S) { return (size_t)(8 * ((R + 63) / 64) + 2 * S + 64); }
+inline size_t k4_grid_fast_lds(int64_t R, int64_t S) { return (size_t)(8 * ((R + 63) / 64) + 3 * S + 64); }
 // workgroups of a grid launch (co-resident by construction); 0 = no device
 int k4_grid_blocks();
 // k4_stage for one large region with all CUs; blk_tot: 2 * k4_grid_blocks() + 1 int32 of scratch

@@ -666,6 +666,7 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
   int8_t* etw = spec ? dlw + C.spec_s8 : v.et;
   uint32_t* s_sig = (uint32_t*)dyn;                     // LDS: sigma bits of every row
   int8_t* s_dl = (int8_t*)(s_sig + 2 * ng); int8_t* s_et = s_dl + S;
+  int8_t* s_de = s_et + S;                              // delta of the het SNPs, 0 for the others (sigma step: one byte per entry)
   const int32_t* rp = v.mv.rp; const int32_t* cp = v.mv.cp;
   // the entries as one dword each (value byte << 24 | row-in-unit << 18 | SNP in row order, value byte << 24 | row in column
   // order): a lane reads four with one 16-byte load.  (A dword + a byte load per entry kept the texture addressers as busy as the VALUs, 34 % each on C5, with the
@@ -723,7 +724,7 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
       const bool tk = C.dbg && sub.tid() == 0 && my == 0;
       auto tick = [&](int slot_) { if (tk) { const long long t = (long long)wall_clock64(); C.dbg[slot_] += t - tk0; tk0 = t; } };
       if (tk) tk0 = (long long)wall_clock64();
-      for (int i = threadIdx.x; i < S; i += blockDim.x) { s_dl[i] = cload(&dlw[i]); s_et[i] = cload(&etw[i]); }
+      for (int i = threadIdx.x; i < S; i += blockDim.x) { const int8_t dv = cload(&dlw[i]), ev = cload(&etw[i]); s_dl[i] = dv; s_et[i] = ev; s_de[i] = ev == 0 ? (dv == 0 ? (int8_t)2 : dv) : (int8_t)0; }   // (2: het with delta 0 -- never a hit)
       __syncthreads();
       tick(8);
       const long long wg_t0 = C.dbg ? (long long)wall_clock64() : 0;   // (LCR_PHASE_PROF: every workgroup's own time in the half steps)
@@ -756,7 +757,11 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
                 if (e + x4 < ue) {
                   const uint32_t i = en[x4] & 0x3FFFFu, rid = (en[x4] >> 18) & 31u, x = en[x4] >> 24;
                   if (rid != cur) { if (cur < 32u && acc) atomicAdd(reinterpret_cast<unsigned long long*>(&rsum[cur]), (unsigned long long)acc); cur = rid; acc = 0; }
-                  if (s_et[i] == 0) { const long long w = wl[x & 31]; const int sg1 = ((sbits >> rid) & 1u) ? 1 : -1; acc += (((x & 32) ? 1 : -1) == sg1 * s_dl[i]) ? w : -w; }
+                  // +w when the entry's allele equals sigma * delta, -w when not, nothing at a hom site: the three signs as bits
+                  const int t = s_de[i];
+                  const long long w = wl[x & 31];
+                  const uint32_t neg = ((x >> 5) ^ (sbits >> rid) ^ ((uint32_t)t >> 31)) & 1u;
+                  acc += t == 0 ? 0ll : ((neg | (uint32_t)(t == 2)) ? -w : w);
                 }
               }
               if (cur < 32u && acc) atomicAdd(reinterpret_cast<unsigned long long*>(&rsum[cur]), (unsigned long long)acc);
@@ -819,14 +824,16 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
           if (i < 0) continue;
           if (c0 == c1) continue;
           const int d = s_dl[i], h = s_et[i];
+          const uint32_t dneg = d < 0 ? 1u : 0u;
+          const bool dzero = d == 0;   // (never a hit)
           long long M = 0;   // sum of w over the entries with p == sigma * d
           auto run4 = [&](const uint4& t, int e) {
             const uint32_t en[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
             for (int u = 0; u < 4; u++) {
               const uint32_t row = en[u] & 0xFFFFFFu, x = en[u] >> 24;
-              const int s = ((s_sig[row >> 5] >> (row & 31)) & 1u) ? 1 : -1;
-              if (e + u < c1 && ((x & 32) ? 1 : -1) == s * d) M += wl[x & 31];
+              const uint32_t miss = ((x >> 5) ^ (s_sig[row >> 5] >> (row & 31)) ^ dneg) & 1u;   // allele != sigma * d
+              if (e + u < c1 && !miss && !dzero) M += wl[x & 31];
             }
           };
           // (requesting the NEXT column's entries under this column's sums was measured: 47 instead of 8 spilled VGPRs, 277 vs 274 ms)
