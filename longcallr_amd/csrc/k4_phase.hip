@@ -868,6 +868,19 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       for (int k = 0; k < 9; k++) fprintf(stderr, "[phase]     %-30s %7.1f us\n", nm[k], (double)(clk[(size_t)g * 16 + k + 1] - clk[(size_t)g * 16 + k]) / 100.0);
     }
   }
+  if (prof && pin.dbg_clk)   // the same steps for the regions that took k4_gpost (all CUs on the region)
+    {
+      std::vector<long long> clk((size_t)ng * 16);
+      PCHK(hipMemcpy(clk.data(), pin.dbg_clk, clk.size() * 8, hipMemcpyDeviceToHost));
+      static const char* nm[] = {"stage rows + entries", "column index", "reads_hap", "snp_hap", "reads_hap + snp_hap", "rescue x2",
+                                 "reads_hap + snp_hap", "phase_set", "write back"};
+      for (int g = 0; g < ng; g++) {
+        if (!grid_post[g]) continue;
+        fprintf(stderr, "[phase]   k4_gpost region %d: %.1f us\n", g, (double)(clk[(size_t)g * 16 + 9] - clk[(size_t)g * 16]) / 100.0);
+        for (int k = 0; k < 9; k++) fprintf(stderr, "[phase]     %-30s %7.1f us\n", nm[k], (double)(clk[(size_t)g * 16 + k + 1] - clk[(size_t)g * 16 + k]) / 100.0);
+        fprintf(stderr, "[phase]     rescue rounds: RNA-edit list %lld, low-fraction list %lld\n", clk[(size_t)g * 16 + 11], clk[(size_t)g * 16 + 12]);
+      }
+    }
   if (!any_host_post) { lap("results"); return LCR_OK; }
 
   // ---- host epilogue (thread.rs:168-201) for the regions that did not take k4_post.  Regions are independent (the

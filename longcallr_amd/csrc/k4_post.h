@@ -218,22 +218,44 @@ __device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<
           const uint8_t code = rcode[ti];
           if (code == 0) continue;
           if (code >= 3 && changed) {   // codes 1 / 2 do not look at the rows
+            // (eight independent cent -> erow -> dirty chains per lane in flight: one at a time, the three dependent loads per
+            // 64 entries of a 1 770-entry column made this check -- by ONE wave, member after member -- 17 of k4_gpost's 25 ms on C5)
             bool stale = false;
-            for (int k = ccptr[ti] + lane; k < (int)ccptr[ti + 1]; k += 64) stale = stale || dirty[erow[cent[k]]];
+            const int kb = (int)ccptr[ti], ke = (int)ccptr[ti + 1];
+            for (int k0 = kb; k0 < ke; k0 += 64 * 8) {
+              int rr[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) { const int k = k0 + 64 * u + lane; rr[u] = k < ke ? (int)erow[cent[k]] : -1; }
+#pragma unroll
+              for (int u = 0; u < 8; u++) if (rr[u] >= 0 && dirty[rr[u]]) stale = true;
+            }
             if (__any(stale)) break;    // evaluated on an outdated state: next round starts here
           }
           if (code == 4) {
-            for (int k0 = ccptr[ti]; k0 < (int)ccptr[ti + 1]; k0 += 64) {   // rows in column order: the draws keep their order
-              const int k = k0 + lane;
-              const bool in_col = k < (int)ccptr[ti + 1];
-              const int r = in_col ? (int)erow[cent[k]] : 0;
-              const bool draw = in_col && (tag[r] == 0 || asg[r] == 0);
-              const unsigned long long dm = __ballot(draw);
-              if (in_col && (draw || !fp[r])) dirty[r] = 1;
-              if (__any(in_col && (draw || !fp[r]))) changed = true;
-              if (in_col) fp[r] = 1;
-              if (draw) tag[r] = u01(rseed, ctr + (unsigned long long)__popcll(dm & ((1ull << lane) - 1ull))) < 0.5 ? -1 : 1;
-              ctr += (unsigned long long)__popcll(dm);
+            // rows in column order: the draws keep their order.  The rows of a column are distinct, so the states of 8 x 64 of them
+            // are fetched together (cent -> erow -> tag / asg / fp one 64-entry slice at a time was three dependent trips to memory
+            // per slice, by the one committing wave: most of k4_gpost's 25 ms on C5) and then walked slice by slice.
+            const int kb4 = (int)ccptr[ti], ke4 = (int)ccptr[ti + 1];
+            for (int k0 = kb4; k0 < ke4; k0 += 64 * 8) {
+              int rr[8]; int tg[8], ag[8], fv[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) { const int k = k0 + 64 * u + lane; rr[u] = k < ke4 ? (int)erow[cent[k]] : -1; }
+#pragma unroll
+              for (int u = 0; u < 8; u++) { const int r = max(rr[u], 0); tg[u] = tag[r]; ag[u] = asg[r]; fv[u] = fp[r]; }
+#pragma unroll
+              for (int u = 0; u < 8; u++) {
+                if (k0 + 64 * u >= ke4) break;
+                const bool in_col = rr[u] >= 0;
+                const int r = max(rr[u], 0);
+                const bool draw = in_col && (tg[u] == 0 || ag[u] == 0);
+                const unsigned long long dm = __ballot(draw);
+                const bool touch = in_col && (draw || !fv[u]);
+                if (touch) dirty[r] = 1;
+                if (__any(touch)) changed = true;
+                if (in_col) fp[r] = 1;
+                if (draw) tag[r] = u01(rseed, ctr + (unsigned long long)__popcll(dm & ((1ull << lane) - 1ull))) < 0.5 ? -1 : 1;
+                ctr += (unsigned long long)__popcll(dm);
+              }
             }
           }
           if (lane == 0) {
@@ -259,6 +281,7 @@ __device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<
         }
       }
       start = sc.bcast(ti);   // (a barrier: the committed state is visible to everybody)
+      if (in.dbg_clk && sc.tid() == 0) in.dbg_clk[(size_t)v.g * 16 + (low_frac ? 12 : 11)] += 1;   // LCR_PHASE_PROF: rounds of the list
       if (start >= S) break;
     }
     return sc.sync_or(chg) != 0;
