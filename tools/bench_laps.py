@@ -5,8 +5,7 @@ import numpy as np, torch
 from longcallr_amd import _abi, api, synth
 import bench
 prof = sys.argv[1] if len(sys.argv) > 1 else "ont-cdna"
-base = synth.make_batch(prof, n_genes=50, gene_len=25000, depth=40, seed=1000)
-batch = bench.tile_batch(base, 8)
+batch = synth.make_genes(prof, n_genes=400, gene_len=25000, depth=40, seed=1)   # (C3: 400 distinct genes, bench.py's workload)
 p = _abi.make_params(synth.preset_for(prof))
 dev = torch.device("cuda", 0)
 dv = bench.to_device(batch, torch, dev)

@@ -7,8 +7,7 @@ from longcallr_amd import _abi, api, synth
 import bench
 prof = sys.argv[1] if len(sys.argv) > 1 else "ont-cdna"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-base = synth.make_batch(prof, n_genes=50, gene_len=25000, depth=40, seed=1000)
-batch = bench.tile_batch(base, 4)
+batch = synth.make_genes(prof, n_genes=200, gene_len=25000, depth=40, seed=1000)
 p = _abi.make_params(synth.preset_for(prof), seed=7)
 dv = bench.to_device(batch, torch, torch.device("cuda", 0))
 E = api.Engine(0, p)

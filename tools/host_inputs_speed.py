@@ -4,8 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from longcallr_amd import _abi, api, synth
 import bench
-base = synth.make_batch("ont-cdna", n_genes=50, gene_len=25000, depth=40, seed=1000)
-batch = bench.tile_batch(base, 8)
+batch = synth.make_genes("ont-cdna", n_genes=400, gene_len=25000, depth=40, seed=1)   # (C3: 400 distinct genes, bench.py's workload)
 p = _abi.make_params("ont-cdna")
 E = api.Engine(0, p)
 for _ in range(5): E.load_batch(batch).run_all()
