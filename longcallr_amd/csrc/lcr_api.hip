@@ -451,7 +451,10 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
     HIPCHK(c, c->k0_items.reserve(pool_sub64 * nsh * 8));
     HIPCHK(c, c->desc_tile.reserve(desc_sub64 * nsh * 4));
     HIPCHK(c, c->desc_val.reserve(desc_sub64 * nsh * 8));
-    HIPCHK(c, c->chunks.reserve((pool_sub64 * nsh / 16 + 16) * 8));   // entries of 16 slots
+    // entries of 16 slots: a group of c records inside a block's tile window takes ceil(c / 16) entries AND ceil(c / 16) * 16
+    // pool slots, a record outside the window one pool slot, one descriptor and one entry of its own -- so the entry list is
+    // bounded by pool / 16 + descriptors, not by pool / 16 (thousands of reads across an intron of > 65 536 columns)
+    HIPCHK(c, c->chunks.reserve((pool_sub64 * nsh / 16 + desc_sub64 * nsh + 16) * 8));
     HIPCHK(c, hipMemsetAsync(fill, 0, fill_words * 4, c->stream));
     { Timer t(c, LCR_K_SPANS);
       launch_k0_ops(b, c->read_bin.as<ReadBin>(), c->blk_first_read.as<int32_t>(), c->cig0, c->n_ops, c->dp.ont, c->dp.dist_to_end, nt,

@@ -308,6 +308,37 @@ def test_k0_reads_beyond_the_tile_window(engine_cls, orc):
     assert c.size >= 2
 
 
+def test_k0_thousands_of_records_beyond_the_tile_window(engine_cls, orc):
+    """3 000 reads whose 200 short ops all lie behind an intron of 100 kb: every record behind the intron is outside its
+    block's LDS window of 256 tiles and takes a pool slot, a descriptor and an ENTRY of its own -- 6*10^5 entries where
+    pool / 16 is 10^5 (the entry list was sized by the pool alone once: ADVICE round 3).  Same planes / candidates / phasing."""
+    rng = np.random.default_rng(19)
+    L = 102000
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    alt = lambda x: "G" if ref[x] != "G" else "T"
+    tail = "3M1D" * 100                                        # 200 ops, 300 read bases over 400 reference positions
+    reads = []
+    for i in range(3000):
+        s = 500 + i // 10
+        a = list(ref[s:s + 100])
+        t0 = s + 100 + 100000
+        c = []
+        for k in range(100):
+            c += list(ref[t0 + 4 * k:t0 + 4 * k + 3])
+        hap = i % 2
+        if hap:
+            if 0 <= 650 - s < 100:
+                a[650 - s] = alt(650)                          # het sites at fixed columns: 650 (before the intron) ...
+            for x in (100960, 101002):                         # ... and two behind it, on M positions of every read
+                k, o = divmod(x - t0, 4)
+                if 0 <= k < 100 and o < 3:
+                    c[3 * k + o] = alt(x)
+        reads.append(dict(pos=s, seq="".join(a + c), qual=27, cigar="100M100000N" + tail, rev=(i // 2) % 2, ts=1 + (i // 2) % 2))
+    b = helpers.mk_batch(reads, [(0, ref)])
+    c = full_check(engine_cls, orc, b, _abi.make_params("ont-cdna", seed=4, min_depth=2))
+    assert c.size >= 2
+
+
 @pytest.mark.parametrize("hook", ["LCR_ENUM_FORCE_STREAM", "LCR_ENUM_FORCE_BIG", "LCR_POST_HOST", "LCR_POST_HALF"])
 def test_fallback_device_paths(engine_cls, orc, monkeypatch, hook):
     """The size-dependent fallbacks of the phase stage give the same results as the default kernels:
