@@ -16,6 +16,9 @@
 #include <atomic>
 #include <cassert>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -58,6 +61,7 @@ struct Cand {
   int haplotype = 0;
   double phase_score = 0;
   std::vector<int> cover; /* snp_cover_fragments */
+  std::vector<int> cover_pos; /* oracle-only index: cover[j]'s entry of this SNP is frags[cover[j]].list[cover_pos[j]] */
   bool rna_editing = false, dense = false, het_var = false, for_phasing = false, hom_var = false,
        single = false, non_selected = false, cand_somatic = false;
   uint32_t phase_set = 0;
@@ -308,6 +312,62 @@ inline int64_t fx_aki(int sigma, int delta, int eta, int p, uint8_t q) {
   return (p == x) ? plut().f1e[q] : plut().fe[q];
 }
 
+/* log10(aki(...)) from the table: aki returns eps or 1 - eps with eps = phase_prob(q), so its log10 is one of 62 libm
+ * values -- the SAME bits the reference-order code gets from its libm call per observation (indexed form, orc_set_fast). */
+inline double lut_laki(int sigma, int delta, int eta, int p, uint8_t q) {
+  const int x = (eta == 0) ? sigma * delta : eta;
+  return (p == x) ? plut().l1e[q] : plut().le[q];
+}
+
+/* a small persistent pool for the indexed form's Jacobi steps: run(n, fn) calls fn(i) for i in [0, n) on all threads */
+class ParPool {
+ public:
+  explicit ParPool(int n_threads) : nt_(std::max(1, n_threads)) {
+    for (int t = 1; t < nt_; t++) th_.emplace_back([this]() { loop(); });
+  }
+  ~ParPool() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  int threads() const { return nt_; }
+  void run(int64_t n, int64_t chunk, const std::function<void(int64_t)>& fn) {
+    if (nt_ == 1 || n <= chunk) { for (int64_t i = 0; i < n; i++) fn(i); return; }
+    { std::lock_guard<std::mutex> l(m_); fn_ = &fn; n_ = n; chunk_ = chunk; next_.store(0); left_ = nt_ - 1; gen_++; }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> l(m_);
+    done_.wait(l, [this]() { return left_ == 0; });
+  }
+ private:
+  void work() {
+    for (;;) {
+      const int64_t b = next_.fetch_add(chunk_);
+      if (b >= n_) return;
+      const int64_t e = std::min(n_, b + chunk_);
+      for (int64_t i = b; i < e; i++) (*fn_)(i);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&]() { return gen_ != seen; }); seen = gen_; if (stop_) return; }
+      work();
+      { std::lock_guard<std::mutex> l(m_); if (--left_ == 0) done_.notify_one(); }
+    }
+  }
+  int nt_;
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int64_t)>* fn_ = nullptr;
+  int64_t n_ = 0, chunk_ = 1;
+  std::atomic<int64_t> next_{0};
+  int left_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
 }  // namespace
 
 /* ================================================================================== */
@@ -330,6 +390,11 @@ struct orc_region {
   int64_t stats[4] = {0, 0, 0, 0};
   std::map<int, uint32_t> read_phase_set; /* fragment idx -> PS */
   std::vector<uint8_t>* round_log = nullptr; /* orc_round_log: 1 per half-round of phase.rs:1198-1233 that raised largest_prob */
+  int fast_threads = 0;   /* orc_set_fast: 0 = the reference's linear searches, >= 1 = indexed gathers on that many threads */
+  int tie_mask = 15;      /* ORC_MODE_TIE: tie classes resolved by the f64 scores */
+  int64_t census[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  ParPool* pool = nullptr;
+  ~orc_region() { delete pool; delete round_log; }
 
   double rnd() { return orc_u01(seed, ctr++); }
 
@@ -650,7 +715,7 @@ struct orc_region {
   /* ---------- P6: SNPFrag::get_fragments (fragment.rs:10-309) ---------- */
   void fragments() {
     frags.clear(); allele_pairs.clear();
-    for (auto& c : cands) c.cover.clear();
+    for (auto& c : cands) { c.cover.clear(); c.cover_pos.clear(); }
     if (cands.empty()) return;
     const int ncand = (int)cands.size();
     for (int r = rb; r < re; r++) {
@@ -725,7 +790,7 @@ struct orc_region {
       fragment.num_hete_links = hete_links;
       fragment.for_phasing = hete_links >= prm.min_linkers; /* fragment.rs:253-255 */
       /* adjacent-SNP `edges` (fragment.rs:256-292) are written but never read on the live path */
-      for (auto& fe : fragment.list) cands[fe.snp_idx].cover.push_back(fragment.fragment_idx);
+      for (size_t e = 0; e < fragment.list.size(); e++) { Cand& c = cands[fragment.list[e].snp_idx]; c.cover.push_back(fragment.fragment_idx); c.cover_pos.push_back((int)e); }
       frags.push_back(fragment);
     }
   }
@@ -806,20 +871,83 @@ struct orc_region {
     }
   }
 
-  /* phase.rs:257-276 (F64) / exact fixed-point sum, compared as int64 and reported / 2^40 (EXACT) */
+  /* ---------- indexed form (orc_set_fast): the phase entries of phase() as CSR (rows, list order) + CSC (SNPs, cover
+   * order).  for_phasing of rows / SNPs and phase_site of entries do not change inside phase(), haplotags do. ---------- */
+  struct PhaseIdx {
+    std::vector<int64_t> rptr, cptr;
+    std::vector<int32_t> rsnp, crow;
+    std::vector<int8_t> rp, cp;
+    std::vector<uint8_t> rq, cq;
+  } pidx;
+  void build_phase_index() {
+    const size_t nf = frags.size(), nc = cands.size();
+    pidx = PhaseIdx();
+    pidx.rptr.assign(nf + 1, 0); pidx.cptr.assign(nc + 1, 0);
+    for (size_t k = 0; k < nf; k++) {
+      if (frags[k].for_phasing)
+        for (const FragElem& fe : frags[k].list)
+          if (fe.phase_site) { pidx.rsnp.push_back(fe.snp_idx); pidx.rp.push_back((int8_t)fe.p); pidx.rq.push_back(fe.baseq); }
+      pidx.rptr[k + 1] = (int64_t)pidx.rsnp.size();
+    }
+    for (size_t i = 0; i < nc; i++) {
+      if (cands[i].for_phasing)
+        for (size_t j = 0; j < cands[i].cover.size(); j++) {
+          const int k = cands[i].cover[j];
+          if (!frags[k].for_phasing) continue;
+          const FragElem& fe = frags[k].list[cands[i].cover_pos[j]];   /* == the entry the linear search finds */
+          if (!fe.phase_site) continue;
+          pidx.crow.push_back(k); pidx.cp.push_back((int8_t)fe.p); pidx.cq.push_back(fe.baseq);
+        }
+      pidx.cptr[i + 1] = (int64_t)pidx.crow.size();
+    }
+  }
+  void par_for(int64_t n, int64_t chunk, const std::function<void(int64_t)>& fn) {
+    if (fast_threads > 1) { if (!pool || pool->threads() != fast_threads) { delete pool; pool = new ParPool(fast_threads); } pool->run(n, chunk, fn); }
+    else for (int64_t i = 0; i < n; i++) fn(i);
+  }
+
+  /* phase.rs:257-276 (F64) / exact fixed-point sum, compared as int64 and reported / 2^40 (EXACT, TIE) */
   mutable int64_t last_obj_fx = 0;
-  double cal_overall_probability(int mode) const {
-    if (!orc_mode_fx(mode)) {
-      if (orc_mode_both(mode)) cal_overall_probability(ORC_MODE_EXACT_ONLY);   /* last_obj_fx for the tie counter of better() */
-      double logp = 0.0;
+  mutable double last_obj_f64 = 0.0;
+  double overall_f64() const {
+    double logp = 0.0;
+    if (fast_threads) {   /* same entries, same order; log10 from the table of the same libm values */
       for (size_t k = 0; k < frags.size(); k++) {
         if (!frags[k].for_phasing || frags[k].haplotag == 0) continue;
-        for (const FragElem& fe : frags[k].list) {
-          if (!fe.phase_site) continue;
-          logp += std::log10(aki(frags[k].haplotag, cands[fe.snp_idx].haplotype, cands[fe.snp_idx].genotype, fe.p, fe.prob));
+        for (int64_t e = pidx.rptr[k]; e < pidx.rptr[k + 1]; e++) {
+          const Cand& c = cands[pidx.rsnp[e]];
+          logp += lut_laki(frags[k].haplotag, c.haplotype, c.genotype, pidx.rp[e], pidx.rq[e]);
         }
       }
       return logp;
+    }
+    for (size_t k = 0; k < frags.size(); k++) {
+      if (!frags[k].for_phasing || frags[k].haplotag == 0) continue;
+      for (const FragElem& fe : frags[k].list) {
+        if (!fe.phase_site) continue;
+        logp += std::log10(aki(frags[k].haplotag, cands[fe.snp_idx].haplotype, cands[fe.snp_idx].genotype, fe.p, fe.prob));
+      }
+    }
+    return logp;
+  }
+  int64_t overall_fx() {
+    if (fast_threads) {
+      const int64_t nf = (int64_t)frags.size(), CH = 4096, nch = (nf + CH - 1) / CH;
+      std::vector<int64_t> part((size_t)nch, 0);
+      par_for(nch, 1, [&](int64_t ci) {
+        int64_t sum = 0;
+        for (int64_t k = ci * CH; k < std::min(nf, (ci + 1) * CH); k++) {
+          if (!frags[k].for_phasing || frags[k].haplotag == 0) continue;
+          for (int64_t e = pidx.rptr[k]; e < pidx.rptr[k + 1]; e++) {
+            const Cand& c = cands[pidx.rsnp[e]];
+            sum += fx_aki(frags[k].haplotag, c.haplotype, c.genotype, pidx.rp[e], pidx.rq[e]);
+          }
+        }
+        part[(size_t)ci] = sum;
+      });
+      int64_t sum = 0;
+      for (int64_t v : part) sum += v;   /* integers: any order */
+      return sum;
     }
     int64_t sum = 0;
     for (size_t k = 0; k < frags.size(); k++) {
@@ -830,101 +958,232 @@ struct orc_region {
         sum += fx_aki(frags[k].haplotag, c.haplotype, c.genotype, fe.p, fe.baseq);
       }
     }
-    last_obj_fx = sum;
-    return (double)sum / FX_SCALE;
+    return sum;
+  }
+  double cal_overall_probability(int mode) {
+    if (orc_mode_tie(mode)) {   /* the fixed-point sum decides; the f64 sum is kept for ties between configurations (better()) */
+      last_obj_fx = overall_fx();
+      last_obj_f64 = overall_f64();
+      return (double)last_obj_fx / FX_SCALE;
+    }
+    if (!orc_mode_fx(mode)) {
+      if (orc_mode_both(mode)) last_obj_fx = overall_fx();   /* for the tie counter of better() */
+      return last_obj_f64 = overall_f64();
+    }
+    last_obj_fx = overall_fx();
+    return (double)last_obj_fx / FX_SCALE;
+  }
+
+  /* one row's / one SNP's scores in both arithmetics */
+  struct RowDec { bool has = false; int64_t A = 0, B = 0; double q = 0.0, qn = 0.0; };
+  struct ColDec { bool has = false; int64_t N[4] = {0, 0, 0, 0}; double q[4] = {0.0, 0.0, 0.0, 0.0}; };
+  /* q = cal_sigma_delta_eta_log(sigma_k, ...), qn = the same for -sigma_k (phase.rs:77-96); A / B their fixed-point log sums */
+  void row_scores(int k, bool use_fx, bool use_f64, RowView& rv, RowDec& d) const {
+    d = RowDec();
+    const int sigma_k = frags[k].haplotag;
+    if (fast_threads) {
+      const int64_t e0 = pidx.rptr[k], e1 = pidx.rptr[k + 1];
+      if (e0 == e1) return;
+      d.has = true;
+      if (use_f64) {   /* the three running sums of phase.rs:82-90, entry order; log_q1 of sigma_k = +1 IS log_q2 */
+        double lp = 0.0, lm = 0.0;
+        for (int64_t e = e0; e < e1; e++) {
+          const Cand& c = cands[pidx.rsnp[e]];
+          lp += lut_laki(1, c.haplotype, c.genotype, pidx.rp[e], pidx.rq[e]);
+          lm += lut_laki(-1, c.haplotype, c.genotype, pidx.rp[e], pidx.rq[e]);
+        }
+        const double l1 = sigma_k == 1 ? lp : lm, l1n = sigma_k == 1 ? lm : lp;
+        d.q = 1.0 - l1 / (lp + lm); d.qn = 1.0 - l1n / (lp + lm);
+      }
+      if (use_fx)
+        for (int64_t e = e0; e < e1; e++) {
+          const Cand& c = cands[pidx.rsnp[e]];
+          d.A += fx_aki(sigma_k, c.haplotype, c.genotype, pidx.rp[e], pidx.rq[e]);
+          d.B += fx_aki(-sigma_k, c.haplotype, c.genotype, pidx.rp[e], pidx.rq[e]);
+        }
+      return;
+    }
+    row_gather(k, rv);
+    if (rv.delta.empty()) return;
+    d.has = true;
+    if (use_f64) {
+      d.q = cal_sigma_delta_eta_log(sigma_k, rv.delta, rv.eta, rv.ps, rv.probs);
+      d.qn = cal_sigma_delta_eta_log(-sigma_k, rv.delta, rv.eta, rv.ps, rv.probs);
+    }
+    if (use_fx)
+      for (size_t e = 0; e < rv.delta.size(); e++) { d.A += fx_aki(sigma_k, rv.delta[e], rv.eta[e], rv.ps[e], rv.q[e]); d.B += fx_aki(-sigma_k, rv.delta[e], rv.eta[e], rv.ps[e], rv.q[e]); }
+  }
+  /* q[0..3] = cal_delta_eta_sigma_log of (d,0) (-d,0) (d,1) (d,-1) (phase.rs:128-176); N[0..3] their fixed-point numerators */
+  void col_scores(int i, bool use_fx, bool use_f64, ColView& cv, ColDec& d) const {
+    d = ColDec();
+    const int delta_i = cands[i].haplotype;
+    size_t cov = 0;
+    if (fast_threads) {
+      /* the five running sums of one call are taken over the same entries in the same order whatever (delta, eta) is asked
+       * for, so the four calls share four sums: Sd = sum log aki(s, delta_i, 0), Sn = (.., -delta_i, 0), Shr = (.., 1),
+       * Shv = (.., -1); each call then adds its priors and forms its own denominator in its own order */
+      double Sd = 0.0, Sn = 0.0, Shr = 0.0, Shv = 0.0;
+      for (int64_t e = pidx.cptr[i]; e < pidx.cptr[i + 1]; e++) {
+        const int sg = frags[pidx.crow[e]].haplotag;
+        if (sg == 0) continue;
+        cov++;
+        const int pp = pidx.cp[e]; const uint8_t qq = pidx.cq[e];
+        if (use_f64) {
+          Sd += lut_laki(sg, delta_i, 0, pp, qq); Sn += lut_laki(sg, -delta_i, 0, pp, qq);
+          Shr += lut_laki(sg, delta_i, 1, pp, qq); Shv += lut_laki(sg, delta_i, -1, pp, qq);
+        }
+        if (use_fx) {
+          d.N[0] += fx_aki(sg, delta_i, 0, pp, qq); d.N[1] += fx_aki(sg, -delta_i, 0, pp, qq);
+          d.N[2] += fx_aki(sg, delta_i, 1, pp, qq); d.N[3] += fx_aki(sg, delta_i, -1, pp, qq);
+        }
+      }
+      if (cov == 0) return;
+      d.has = true;
+      if (use_f64) {
+        const double p_homref = prior_homref_log(), p_homvar = prior_homvar_log(), p_het = prior_hetvar_log(cov);
+        /* call (dd, ee): log_q1 = S(dd, ee) + prior(ee); log_q2 = Shv + homvar; log_q3 = S(dd, 0) + het; log_q4 = Shr + homref;
+         * log_q5 = S(-dd, 0) + het; 1 - log_q1 / (((log_q2 + log_q3) + log_q4) + log_q5) */
+        const double hv = Shv + p_homvar, hr = Shr + p_homref, hd = Sd + p_het, hn = Sn + p_het;
+        const double den_d = hv + hd + hr + hn;   /* delta_i asked: log_q3 = hd, log_q5 = hn */
+        const double den_n = hv + hn + hr + hd;   /* -delta_i asked */
+        d.q[0] = 1.0 - hd / den_d; d.q[1] = 1.0 - hn / den_n; d.q[2] = 1.0 - hr / den_d; d.q[3] = 1.0 - hv / den_d;
+      }
+    } else {
+      col_gather(i, cv);
+      if (cv.sigma.empty()) return;
+      d.has = true; cov = cv.sigma.size();
+      if (use_f64) {
+        d.q[0] = cal_delta_eta_sigma_log(delta_i, 0, cv.sigma, cv.ps, cv.probs);
+        d.q[1] = cal_delta_eta_sigma_log(-delta_i, 0, cv.sigma, cv.ps, cv.probs);
+        d.q[2] = cal_delta_eta_sigma_log(delta_i, 1, cv.sigma, cv.ps, cv.probs);
+        d.q[3] = cal_delta_eta_sigma_log(delta_i, -1, cv.sigma, cv.ps, cv.probs);
+      }
+      for (size_t e = 0; use_fx && e < cv.sigma.size(); e++) {
+        d.N[0] += fx_aki(cv.sigma[e], delta_i, 0, cv.ps[e], cv.q[e]);
+        d.N[1] += fx_aki(cv.sigma[e], -delta_i, 0, cv.ps[e], cv.q[e]);
+        d.N[2] += fx_aki(cv.sigma[e], delta_i, 1, cv.ps[e], cv.q[e]);
+        d.N[3] += fx_aki(cv.sigma[e], delta_i, -1, cv.ps[e], cv.q[e]);
+      }
+    }
+    if (use_fx) {
+      const int64_t het = plut().f_het0 - (int64_t)cov * plut().f_log2;
+      d.N[0] += het; d.N[1] += het; d.N[2] += plut().f_homref; d.N[3] += plut().f_homvar;
+    }
+  }
+  /* the reference's choice among the four scores: first maximum (phase.rs:905-940); -1 = NaN scores */
+  static int choose_f64(const double q[4], bool with_genotype, int eta_i) {
+    if (with_genotype) {
+      const double max_q = std::fmax(q[0], std::fmax(q[1], std::fmax(q[2], q[3])));
+      return q[0] == max_q ? 0 : q[1] == max_q ? 1 : q[2] == max_q ? 2 : q[3] == max_q ? 3 : -1;
+    }
+    if (eta_i == 0) { const double max_q = std::fmax(q[0], q[1]); return q[0] == max_q ? 0 : q[1] == max_q ? 1 : -1; }
+    const double max_q = std::fmax(q[2], q[3]);
+    return q[2] == max_q ? 2 : q[3] == max_q ? 3 : -1;
+  }
+  static int choose_fx(const int64_t N[4], bool with_genotype, int eta_i, bool* tie) {
+    int ch;
+    if (with_genotype) { ch = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch]) ch = t; *tie = false; for (int t = 0; t < 4; t++) if (t != ch && N[t] == N[ch]) *tie = true; }
+    else if (eta_i == 0) { ch = N[1] > N[0] ? 1 : 0; *tie = N[1] == N[0]; }
+    else { ch = N[3] > N[2] ? 3 : 2; *tie = N[3] == N[2]; }
+    return ch;
   }
 
   /* ---------- P12: cross_optimize (phase.rs:810-976) ---------- */
   double cross_optimize(int mode, const std::set<int>& conserved, bool keep_conserved, bool with_genotype) {
     stats[0]++;
     /* by_fx: decisions by the exact fixed-point sums (else by the reference's f64 ratio scores); both: the other
-     * arithmetic is evaluated too and disagreements are counted (stats[2]); the *_ONLY modes skip it */
-    const bool by_fx = orc_mode_fx(mode), both = orc_mode_both(mode), use_fx = by_fx || both, use_f64 = !by_fx || both;
+     * arithmetic is evaluated too and disagreements are counted (stats[2]); the *_ONLY modes skip it; tie: fixed point,
+     * exact ties by the f64 scores (ORC_MODE_TIE) */
+    const bool by_fx = orc_mode_fx(mode), both = orc_mode_both(mode), tie = orc_mode_tie(mode);
+    const bool use_fx = by_fx || both || tie, use_f64 = !by_fx || both;   /* (TIE evaluates the f64 scores of every row too: the oracle is not the place to save them) */
     bool hg_inc = true, h_inc = true;
     int num_iters = 0;
     RowView rv; ColView cv;
+    const int nf = (int)frags.size(), nc = (int)cands.size();
+    std::vector<RowDec> rdec; std::vector<ColDec> cdec;
+    if (fast_threads) { rdec.resize(nf); cdec.resize(nc); }
     while (hg_inc | h_inc) {
       stats[1]++;
       /* sigma step, phase.rs:824-862 */
       std::map<int, int> tmp_haplotag;
-      double logp = 0.0, pre_logp = 0.0; bool any_strict = false;
-      for (int k = 0; k < (int)frags.size(); k++) {
+      double logp = 0.0, pre_logp = 0.0; bool any_strict = false, any_tie_change = false;
+      if (fast_threads)   /* Jacobi: every row is scored against the old state (phase.rs:859-862) -- independent */
+        par_for(nf, 512, [&](int64_t k) {
+          rdec[k] = RowDec();
+          if (!frags[k].for_phasing || frags[k].haplotag == 0) return;
+          RowView dummy; row_scores((int)k, use_fx, use_f64, dummy, rdec[k]);
+        });
+      for (int k = 0; k < nf; k++) {
         if (!frags[k].for_phasing || frags[k].haplotag == 0) continue;
         const int sigma_k = frags[k].haplotag;
-        row_gather(k, rv);
-        if (rv.delta.empty()) continue;
-        double q = 0.0, qn = 0.0;
-        if (use_f64) {
-          q = cal_sigma_delta_eta_log(sigma_k, rv.delta, rv.eta, rv.ps, rv.probs);
-          qn = cal_sigma_delta_eta_log(-sigma_k, rv.delta, rv.eta, rv.ps, rv.probs);
-        }
-        int64_t A = 0, B = 0;
-        if (use_fx)
-          for (size_t e = 0; e < rv.delta.size(); e++) { A += fx_aki(sigma_k, rv.delta[e], rv.eta[e], rv.ps[e], rv.q[e]); B += fx_aki(-sigma_k, rv.delta[e], rv.eta[e], rv.ps[e], rv.q[e]); }
-        const bool flip_f64 = q < qn, flip_fx = A < B;
+        RowDec d;
+        if (fast_threads) d = rdec[k]; else row_scores(k, use_fx, use_f64, rv, d);
+        if (!d.has) continue;
+        const bool flip_f64 = d.q < d.qn, flip_fx = d.A < d.B;
         if (both && flip_f64 != flip_fx) stats[2]++;
-        const bool flip = by_fx ? flip_fx : flip_f64;
+        bool flip = by_fx ? flip_fx : flip_f64;
+        if (use_fx && d.A == d.B) {
+          census[0]++; if (flip_f64) census[4]++;
+          bool het = false;   /* a row without an entry at a het site scores the same for both signs, term by term */
+          for (const FragElem& fe : frags[k].list) if (fe.phase_site && cands[fe.snp_idx].genotype == 0) het = true;
+          if (het) census[8]++;
+          if (d.q != d.qn) census[9]++;
+        }
+        if (tie) {
+          flip = flip_fx;
+          if (d.A == d.B && (tie_mask & 1)) flip = flip_f64;
+          if (d.A < d.B) any_strict = true; else if (flip) any_tie_change = true;
+        }
         tmp_haplotag[k] = flip ? -sigma_k : sigma_k;
         /* check_new_haplotag, phase.rs:278-314 (sums in key order instead of HashMap order) */
-        logp += flip ? qn : q; pre_logp += q;
-        if (flip) any_strict = true;
+        logp += flip ? d.qn : d.q; pre_logp += d.q;
+        if (!tie && flip) any_strict = true;
       }
       int check_val;
-      if (!by_fx) { check_val = logp > pre_logp ? 1 : (logp == pre_logp ? 0 : -1); if (check_val < 0) { stats[3]++; check_val = 0; } }
+      if (tie) {
+        check_val = any_strict ? 1 : 0;
+        if (!any_strict && any_tie_change) { census[2]++; if (logp > pre_logp) census[6]++; if (tie_mask & 4) check_val = logp > pre_logp ? 1 : 0; }
+      } else if (!by_fx) { check_val = logp > pre_logp ? 1 : (logp == pre_logp ? 0 : -1); if (check_val < 0) { stats[3]++; check_val = 0; } }
       else check_val = any_strict ? 1 : 0;
       for (auto& kv : tmp_haplotag) frags[kv.first].haplotag = kv.second;
       if (check_val == 0) h_inc = false; else { h_inc = true; hg_inc = true; }
       /* delta/eta step, phase.rs:872-959 */
       std::map<int, std::pair<int, int>> tmp_hg;
-      logp = 0.0; pre_logp = 0.0; any_strict = false;
-      for (int i = 0; i < (int)cands.size(); i++) {
+      logp = 0.0; pre_logp = 0.0; any_strict = false; any_tie_change = false;
+      if (fast_threads)
+        par_for(nc, 1, [&](int64_t i) {
+          cdec[i] = ColDec();
+          if (!cands[i].for_phasing) return;
+          if (keep_conserved && conserved.count((int)i)) return;
+          ColView dummy; col_scores((int)i, use_fx, use_f64, dummy, cdec[i]);
+        });
+      for (int i = 0; i < nc; i++) {
         if (!cands[i].for_phasing) continue;
         if (keep_conserved && conserved.count(i)) continue;
         const int delta_i = cands[i].haplotype, eta_i = cands[i].genotype;
-        col_gather(i, cv);
-        if (cv.sigma.empty()) continue;
-        double q1 = 0.0, q2 = 0.0, q3 = 0.0, q4 = 0.0;
-        if (use_f64) {
-          q1 = cal_delta_eta_sigma_log(delta_i, 0, cv.sigma, cv.ps, cv.probs);
-          q2 = cal_delta_eta_sigma_log(-delta_i, 0, cv.sigma, cv.ps, cv.probs);
-          q3 = cal_delta_eta_sigma_log(delta_i, 1, cv.sigma, cv.ps, cv.probs);
-          q4 = cal_delta_eta_sigma_log(delta_i, -1, cv.sigma, cv.ps, cv.probs);
-        }
-        int64_t N[4] = {0, 0, 0, 0};
-        for (size_t e = 0; use_fx && e < cv.sigma.size(); e++) {
-          N[0] += fx_aki(cv.sigma[e], delta_i, 0, cv.ps[e], cv.q[e]);
-          N[1] += fx_aki(cv.sigma[e], -delta_i, 0, cv.ps[e], cv.q[e]);
-          N[2] += fx_aki(cv.sigma[e], delta_i, 1, cv.ps[e], cv.q[e]);
-          N[3] += fx_aki(cv.sigma[e], delta_i, -1, cv.ps[e], cv.q[e]);
-        }
-        const int64_t het = plut().f_het0 - (int64_t)cv.sigma.size() * plut().f_log2;
-        N[0] += het; N[1] += het; N[2] += plut().f_homref; N[3] += plut().f_homvar;
+        ColDec d;
+        if (fast_threads) d = cdec[i]; else col_scores(i, use_fx, use_f64, cv, d);
+        if (!d.has) continue;
         int ch_f64 = -1, ch_fx = -1; /* 0:(d,0) 1:(-d,0) 2:(d,1) 3:(d,-1) */
-        if (with_genotype) {
-          const double max_q = std::fmax(q1, std::fmax(q2, std::fmax(q3, q4)));
-          ch_f64 = q1 == max_q ? 0 : q2 == max_q ? 1 : q3 == max_q ? 2 : q4 == max_q ? 3 : -1;
-          ch_fx = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch_fx]) ch_fx = t;
-        } else if (eta_i == 0) {
-          const double max_q = std::fmax(q1, q2);
-          ch_f64 = q1 == max_q ? 0 : q2 == max_q ? 1 : -1;
-          ch_fx = N[1] > N[0] ? 1 : 0;
-        } else {
-          const double max_q = std::fmax(q3, q4);
-          ch_f64 = q3 == max_q ? 2 : q4 == max_q ? 3 : -1;
-          ch_fx = N[3] > N[2] ? 3 : 2;
-        }
+        bool fx_tie = false;
+        if (use_f64) ch_f64 = choose_f64(d.q, with_genotype, eta_i);
+        if (use_fx) ch_fx = choose_fx(d.N, with_genotype, eta_i, &fx_tie);
         if (both && ch_f64 != ch_fx) stats[2]++;
-        const int ch = by_fx ? ch_fx : ch_f64;
+        if (use_fx && fx_tie) { census[1]++; if (ch_f64 != ch_fx) census[5]++; }
+        int ch = by_fx ? ch_fx : ch_f64;
+        if (tie) { ch = ch_fx; if (fx_tie && (tie_mask & 2)) ch = ch_f64; }
         if (ch < 0) continue; /* NaN scores: the reference inserts nothing (or panics) */
         const std::pair<int, int> pick[4] = {{delta_i, 0}, {-delta_i, 0}, {delta_i, 1}, {delta_i, -1}};
         tmp_hg[i] = pick[ch];
         /* check_new_haplotype_genotype, phase.rs:316-355 */
-        const double qs[4] = {q1, q2, q3, q4};
         const int cur = eta_i == 0 ? 0 : (eta_i == 1 ? 2 : 3);
-        logp += qs[ch]; pre_logp += qs[cur];
-        if (N[ch] > N[cur]) any_strict = true;
+        logp += d.q[ch]; pre_logp += d.q[cur];
+        if (d.N[ch] > d.N[cur]) any_strict = true; else if (ch != cur) any_tie_change = true;
       }
-      if (!by_fx) { check_val = logp > pre_logp ? 1 : (logp == pre_logp ? 0 : -1); if (check_val < 0) { stats[3]++; check_val = 0; } }
+      if (tie) {
+        check_val = any_strict ? 1 : 0;
+        if (!any_strict && any_tie_change) { census[2]++; if (logp > pre_logp) census[6]++; if (tie_mask & 4) check_val = logp > pre_logp ? 1 : 0; }
+      } else if (!by_fx) { check_val = logp > pre_logp ? 1 : (logp == pre_logp ? 0 : -1); if (check_val < 0) { stats[3]++; check_val = 0; } }
       else check_val = any_strict ? 1 : 0;
       for (auto& kv : tmp_hg) { cands[kv.first].haplotype = kv.second.first; cands[kv.first].genotype = kv.second.second; }
       if (check_val == 0) hg_inc = false; else { hg_inc = true; h_inc = true; }
@@ -944,16 +1203,23 @@ struct orc_region {
       std::vector<std::vector<double>> probs_block;
       std::map<int, int> sigma_flip_map;
       std::set<int> block_set(block.begin(), block.end());
+      std::vector<char> in_blk;   /* indexed form: the same membership test as a marker array */
+      if (fast_threads) { in_blk.assign(cands.size(), 0); for (int x : block) in_blk[x] = 1; }
       for (int idx : block) {
         delta_block.push_back(cands[idx].haplotype);
         delta_block_flip.push_back(-cands[idx].haplotype);
         eta_block.push_back(cands[idx].genotype);
         std::vector<int> sigma, sigma_flip, ps; std::vector<double> probs;
-        for (int k : cands[idx].cover) {
+        for (size_t cj = 0; cj < cands[idx].cover.size(); cj++) {
+          const int k = cands[idx].cover[cj];
           if (!frags[k].for_phasing || frags[k].haplotag == 0) continue;
           bool flip_read = true;
-          for (const FragElem& fe : frags[k].list) {
-            if (!block_set.count(fe.snp_idx)) flip_read = false;
+          /* indexed form: the walk stops at the SNP's own entry (list[cover_pos]) -- nothing behind it is looked at by the
+           * reference's loop either: flip_read is consumed at the match and no second entry matches */
+          const size_t e_end = fast_threads ? (size_t)cands[idx].cover_pos[cj] + 1 : frags[k].list.size();
+          for (size_t e = 0; e < e_end; e++) {
+            const FragElem& fe = frags[k].list[e];
+            if (fast_threads ? !in_blk[fe.snp_idx] : !block_set.count(fe.snp_idx)) flip_read = false;
             if (fe.snp_idx == idx) {
               if (!fe.phase_site) continue;
               ps.push_back(fe.p); probs.push_back(fe.prob);
@@ -1040,15 +1306,22 @@ struct orc_region {
   /* ---------- thread.rs:162-166 + P13 SNPFrag::phase (phase.rs:1087-1296) ---------- */
   void phase(int mode) {
     ctr = 0;
+    for (int i = 0; i < 10; i++) census[i] = 0;
+    if (fast_threads) build_phase_index();
     for (auto& c : cands) c.haplotype = rnd() < 0.5 ? 1 : -1; /* init_haplotypes, phase.rs:443-448 */
     init_assignment();
     double largest_prob = -std::numeric_limits<double>::infinity();
     int64_t largest_fx = std::numeric_limits<int64_t>::min();
+    double largest_f64 = -std::numeric_limits<double>::infinity();   /* ORC_MODE_TIE: the f64 objective of the best configuration */
     auto better = [&](double prob) {  /* `prob > largest_prob` (phase.rs:1117,1129,...); EXACT compares the int64 sums */
       const bool b_f64 = prob > largest_prob, b_fx = last_obj_fx > largest_fx;
       if (orc_mode_both(mode) && b_f64 != b_fx) stats[2]++;   /* two restarts of equal objective (an uninformative SNP flipped): the f64 sums differ by rounding noise */
-      const bool b = orc_mode_fx(mode) ? b_fx : b_f64;
-      if (b) { largest_prob = prob; largest_fx = last_obj_fx; }
+      bool b = orc_mode_fx(mode) ? b_fx : b_f64;
+      if (orc_mode_tie(mode)) {   /* equal fixed-point objectives: the reference's f64 sums of the two configurations decide */
+        b = b_fx;
+        if (last_obj_fx == largest_fx) { census[3]++; if (last_obj_f64 > largest_f64) census[7]++; if (tie_mask & 8) b = last_obj_f64 > largest_f64; }
+      } else if (orc_mode_both(mode) && last_obj_fx == largest_fx) { census[3]++; if (b_f64) census[7]++; }
+      if (b) { largest_prob = prob; largest_fx = last_obj_fx; largest_f64 = last_obj_f64; }
       return b;
     };
     Best best;
@@ -1137,10 +1410,14 @@ struct orc_region {
       const int delta_i = snp.haplotype;
       std::vector<int> sigma, ps; std::vector<double> probs;
       int hap1 = 0, hap2 = 0;
-      for (int k : snp.cover) {
+      for (size_t cj = 0; cj < snp.cover.size(); cj++) {
+        const int k = snp.cover[cj];
         if (!frags[k].for_phasing || frags[k].num_hete_links < prm.min_linkers) continue;
         if (snp.variant_type == 1 && frags[k].assignment == 0) continue;
-        for (const FragElem& fe : frags[k].list) {
+        /* (indexed form: the one matching entry directly instead of the search for it) */
+        const size_t e0 = fast_threads ? (size_t)snp.cover_pos[cj] : 0, e1 = fast_threads ? e0 + 1 : frags[k].list.size();
+        for (size_t e = e0; e < e1; e++) {
+          const FragElem& fe = frags[k].list[e];
           if (fe.snp_idx == ti) {
             if (frags[k].assignment == 1) hap1++; else if (frags[k].assignment == 2) hap2++;
             ps.push_back(fe.p); probs.push_back(fe.prob); sigma.push_back(frags[k].haplotag);
@@ -1174,9 +1451,12 @@ struct orc_region {
       if (snp.variant_type != 1) { snp.non_selected = true; continue; }
       std::vector<int> sigma, ps; std::vector<double> probs;
       int hap1 = 0, hap2 = 0;
-      for (int k : snp.cover) {
+      for (size_t cj = 0; cj < snp.cover.size(); cj++) {
+        const int k = snp.cover[cj];
         if (!frags[k].for_phasing || frags[k].assignment == 0 || frags[k].num_hete_links < prm.min_linkers) continue;
-        for (const FragElem& fe : frags[k].list) {
+        const size_t e0 = fast_threads ? (size_t)snp.cover_pos[cj] : 0, e1 = fast_threads ? e0 + 1 : frags[k].list.size();
+        for (size_t e = e0; e < e1; e++) {
+          const FragElem& fe = frags[k].list[e];
           if (fe.snp_idx == ti) {
             if (frags[k].assignment == 1) hap1++; else if (frags[k].assignment == 2) hap2++;
             ps.push_back(fe.p); probs.push_back(fe.prob); sigma.push_back(frags[k].haplotag);
@@ -1371,6 +1651,9 @@ void orc_candidates(orc_region* r) { r->candidates(); }
 void orc_fragments(orc_region* r) { r->fragments(); }
 void orc_phase(orc_region* r, int mode) { r->phase(mode); }
 void orc_post_phase(orc_region* r) { r->post_phase(); }
+void orc_set_fast(orc_region* r, int n_threads) { r->fast_threads = n_threads < 0 ? 0 : n_threads; }
+void orc_set_tie_mask(orc_region* r, int mask) { r->tie_mask = mask; }
+void orc_get_tie_census(const orc_region* r, int64_t* out10) { for (int i = 0; i < 10; i++) out10[i] = r->census[i]; }
 
 void orc_get_planes(const orc_region* r, uint32_t* out) {
   const int64_t L = r->len;
@@ -1489,8 +1772,14 @@ struct orc_batch {
   ~orc_batch() { for (auto* r : regs) delete r; }
 };
 
+orc_batch* orc_run_batch_opts(const lcr_reads* reads, const lcr_regions* rg, const lcr_params* params, int mode, int n_threads,
+                              int upto, int keep_planes, int fast_threads, int tie_mask);
 orc_batch* orc_run_batch(const lcr_reads* reads, const lcr_regions* rg, const lcr_params* params, int mode, int n_threads,
                          int upto, int keep_planes) {
+  return orc_run_batch_opts(reads, rg, params, mode, n_threads, upto, keep_planes, 0, 15);
+}
+orc_batch* orc_run_batch_opts(const lcr_reads* reads, const lcr_regions* rg, const lcr_params* params, int mode, int n_threads,
+                              int upto, int keep_planes, int fast_threads, int tie_mask) {
   orc_batch* B = new orc_batch();
   const int ng = rg->n_regions;
   B->regs.assign(ng, nullptr); B->planes.resize(ng); B->fm.resize(ng); B->upto = upto;
@@ -1512,6 +1801,7 @@ orc_batch* orc_run_batch(const lcr_reads* reads, const lcr_regions* rg, const lc
       const int g = order[k];
       orc_region* r = orc_region_create(reads, rg->read_begin[g], rg->read_begin[g + 1], rg->start0[g], rg->len[g], rg->ref + rg->col_off[g], params);
       B->regs[g] = r;
+      r->fast_threads = fast_threads < 0 ? 0 : fast_threads; r->tie_mask = tie_mask;
       r->pileup();
       if (keep_planes) { B->planes[g].assign((size_t)LCR_NPLANES * (size_t)r->len, 0u); orc_get_planes(r, B->planes[g].data()); }
       if (upto >= 1) r->candidates();
@@ -1578,6 +1868,7 @@ void orc_batch_phase(const orc_batch* B, int8_t* haplotag, uint8_t* assignment, 
     r += B->regs[g]->frags.size();
   }
 }
+void orc_batch_tie_census(const orc_batch* B, int64_t* out) { for (size_t g = 0; g < B->regs.size(); g++) orc_get_tie_census(B->regs[g], out + 10 * g); }
 void orc_batch_stats(const orc_batch* B, int64_t* out) { for (size_t g = 0; g < B->regs.size(); g++) orc_get_stats(B->regs[g], out + 4 * g); }
 int64_t orc_batch_vcf(orc_batch* B, const char* chrom, char* buf, int64_t cap, int64_t* off) {
   int64_t n = 0;

@@ -15,7 +15,7 @@ from longcallr_amd import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "liblcr_oracle.so")
-MODE_F64, MODE_EXACT, MODE_F64_ONLY, MODE_EXACT_ONLY = 0, 1, 2, 3
+MODE_F64, MODE_EXACT, MODE_F64_ONLY, MODE_EXACT_ONLY, MODE_TIE = 0, 1, 2, 3, 4
 
 
 def build(force=False):
@@ -65,6 +65,15 @@ def lib():
         l.orc_run_batch.restype = vp
         l.orc_run_batch.argtypes = [C.POINTER(_abi.LcrReads), C.POINTER(_abi.LcrRegions), C.POINTER(_abi.LcrParams),
                                     C.c_int, C.c_int, C.c_int, C.c_int]
+        l.orc_run_batch_opts.restype = vp
+        l.orc_run_batch_opts.argtypes = [C.POINTER(_abi.LcrReads), C.POINTER(_abi.LcrRegions), C.POINTER(_abi.LcrParams),
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        l.orc_batch_tie_census.argtypes = [vp, vp]
+        l.orc_set_fast.argtypes = [vp, C.c_int]
+        l.orc_set_fast.restype = None
+        l.orc_set_tie_mask.argtypes = [vp, C.c_int]
+        l.orc_set_tie_mask.restype = None
+        l.orc_get_tie_census.argtypes = [vp, vp]
         l.orc_batch_destroy.argtypes = [vp]
         l.orc_batch_destroy.restype = None
         l.orc_batch_seconds.argtypes = [vp]
@@ -120,6 +129,20 @@ class Region:
         if getattr(self, "h", None):
             lib().orc_region_destroy(self.h)
             self.h = None
+
+    def set_fast(self, threads=1):
+        """indexed gathers (same entries, same order) on `threads` threads; 0 = the reference's linear searches"""
+        lib().orc_set_fast(self.h, threads)
+        return self
+
+    def set_tie_mask(self, mask):
+        lib().orc_set_tie_mask(self.h, mask)
+        return self
+
+    def tie_census(self):
+        out = np.zeros(10, np.int64)
+        lib().orc_get_tie_census(self.h, _p(out))
+        return out
 
     def pileup(self):
         lib().orc_pileup(self.h)
@@ -210,12 +233,12 @@ class Batch:
     rayon par_iter over regions (thread.rs:77).  Results come back concatenated in batch order, in the formats the
     lcr_get_* calls of the HIP path use, so a full-size comparison is a handful of array compares."""
 
-    def __init__(self, batch, params, mode=MODE_EXACT_ONLY, threads=0, upto="post", keep_planes=True):
+    def __init__(self, batch, params, mode=MODE_EXACT_ONLY, threads=0, upto="post", keep_planes=True, fast=0, tie_mask=15):
         self.batch, self.params, self.ng = batch, params, batch.n_regions
         self._reads, self._regions = batch.c_reads(), batch.c_regions()
         self.upto = UPTO[upto]
-        self.h = lib().orc_run_batch(C.byref(self._reads), C.byref(self._regions), C.byref(params), mode, threads,
-                                     self.upto, 1 if keep_planes else 0)
+        self.h = lib().orc_run_batch_opts(C.byref(self._reads), C.byref(self._regions), C.byref(params), mode, threads,
+                                          self.upto, 1 if keep_planes else 0, fast, tie_mask)
         self.seconds, self.threads = lib().orc_batch_seconds(self.h), lib().orc_batch_threads(self.h)
         self.cand_off, self.row_off = np.zeros(self.ng + 1, np.int32), np.zeros(self.ng + 1, np.int32)
         self.nnz_off = np.zeros(self.ng + 1, np.int64)
@@ -258,6 +281,13 @@ class Batch:
         """per region: cross_optimize calls, iterations, noise ties (modes 0 / 1 only), assert violations"""
         out = np.zeros((self.ng, 4), np.int64)
         lib().orc_batch_stats(self.h, _p(out))
+        return out
+
+    def tie_census(self):
+        """per region, ORC_MODE_TIE / F64 / EXACT: ties among sigma decisions, delta/eta decisions, tie-only steps, best-pick
+        compares, then the same four where the f64 scores decide differently from `a tie changes nothing`"""
+        out = np.zeros((self.ng, 10), np.int64)
+        lib().orc_batch_tie_census(self.h, _p(out))
         return out
 
     def vcf_texts(self, chrom="chrS"):

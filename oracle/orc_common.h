@@ -40,15 +40,24 @@ static inline uint64_t orc_region_seed(uint64_t seed, int64_t start0) {
 
 /* decision arithmetic of the optimiser (see DESIGN.md "Decision arithmetic") */
 #define ORC_MODE_F64 0   /* reference-order f64 running sums (faithful to phase.rs)            */
-#define ORC_MODE_EXACT 1 /* exact fixed-point sums, scale 2^40 (the GPU parity contract)      */
+#define ORC_MODE_EXACT 1 /* exact fixed-point sums, scale 2^40 (liblcr's contract of rounds 1-3) */
 /* Modes 0 / 1 evaluate BOTH arithmetics at every decision and count the decisions on which they disagree
  * (orc_get_stats [2]: rounding-noise ties).  The *_ONLY modes take the same decisions as 0 / 1 without the other
  * arithmetic: ORC_MODE_F64_ONLY is the reference's work, nothing more (bench.py's cpu_baseline); ORC_MODE_EXACT_ONLY
  * drops the libm calls of the f64 scores (full-size parity runs). */
 #define ORC_MODE_F64_ONLY 2
 #define ORC_MODE_EXACT_ONLY 3
-static inline int orc_mode_fx(int mode) { return mode & 1; }
+/* ORC_MODE_TIE (round 4, liblcr's contract now): every decision by the exact fixed-point sums, and a decision whose
+ * fixed-point sums TIE exactly is taken by the reference-order f64 ratio scores of that row / column / configuration --
+ * the arithmetic of phase.rs on exactly the decisions where arithmetic matters (the rest are sign tests of sums that
+ * differ macroscopically).  Four classes of ties, selectable with orc_set_tie_mask for the residual tables:
+ *   1 sigma flips (phase.rs:845-858)          2 the delta / eta choice (phase.rs:905-940)
+ *   4 "did the step improve" after an iteration whose only changes were tie changes (check_new_*, phase.rs:278-355)
+ *   8 `prob > largest_prob` between configurations of equal fixed-point objective (phase.rs:1117,1129 ...)        */
+#define ORC_MODE_TIE 4
+static inline int orc_mode_fx(int mode) { return mode == 1 || mode == 3; }
 static inline int orc_mode_both(int mode) { return mode < 2; }
+static inline int orc_mode_tie(int mode) { return mode == 4; }
 
 typedef struct orc_region orc_region;
 
@@ -62,6 +71,19 @@ void orc_candidates(orc_region*); /* candidate.rs:54-528                        
 void orc_fragments(orc_region*);  /* fragment.rs:10-309                                         */
 void orc_phase(orc_region*, int mode); /* thread.rs:162-166 + phase.rs:1087-1296               */
 void orc_post_phase(orc_region*); /* thread.rs:168-201 (snpfrags.rs:191-733)                    */
+/* Indexed gathers (round 4): n_threads >= 1 replaces the reference's per-fragment linear searches
+ * (`for fe in list if fe.snp_idx == i`, phase.rs:890-898, snpfrags.rs:403-414 ...) by a position index built with the
+ * fragments -- the SAME entries in the SAME order, libm log10 of the 62 possible emission values from a table of the
+ * same libm values -- and runs the Jacobi steps of cross_optimize (independent per row / per SNP by construction,
+ * phase.rs:859-862,943-946) on n_threads threads; every f64 sum keeps its order.  0 (default) = the structure-faithful
+ * gathers (what bench.py's cpu_baseline times).  Equality of the two forms is a test (tests/test_oracle_batch.py). */
+void orc_set_fast(orc_region*, int n_threads);
+void orc_set_tie_mask(orc_region*, int mask);   /* ORC_MODE_TIE: which tie classes the f64 scores resolve (default 15) */
+/* tie census of the last orc_phase (any mode that evaluates the fixed-point sums): [0] sigma decisions with A == B,
+ * [1] delta/eta decisions with a tie at the maximum, [2] steps whose only changes were tie changes, [3] best-configuration
+ * compares at equal fixed-point objective, [4..7] the same four counted only where the f64 scores then decide differently
+ * from "a tie changes nothing", [8] sigma ties of rows with an entry at a het site, [9] sigma ties whose two f64 scores differ */
+void orc_get_tie_census(const orc_region*, int64_t* out10);
 
 /* getters (flat copies, same formats as include/lcr.h) */
 void orc_get_planes(const orc_region*, uint32_t* out /* LCR_NPLANES*len */);
@@ -98,6 +120,10 @@ int64_t orc_vcf_text(orc_region*, const char* chrom, char* buf, int64_t cap);
 typedef struct orc_batch orc_batch;
 orc_batch* orc_run_batch(const lcr_reads* reads, const lcr_regions* regions, const lcr_params* params, int mode,
                          int n_threads, int upto, int keep_planes);
+/* the same with the indexed gathers on fast_threads threads per region (orc_set_fast) and a tie mask (orc_set_tie_mask) */
+orc_batch* orc_run_batch_opts(const lcr_reads* reads, const lcr_regions* regions, const lcr_params* params, int mode,
+                              int n_threads, int upto, int keep_planes, int fast_threads, int tie_mask);
+void orc_batch_tie_census(const orc_batch*, int64_t* out /* n_regions x 10, as orc_get_tie_census */);
 void orc_batch_destroy(orc_batch*);
 double orc_batch_seconds(const orc_batch*);        /* wall time of the pool                                   */
 int32_t orc_batch_threads(const orc_batch*);

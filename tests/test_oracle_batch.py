@@ -77,3 +77,42 @@ def test_batch_runner_stages_and_plane_dropping(orc):
     assert not Cn.planes().any() and np.array_equal(Cn.cand_off, full.cand_off)
     Fr = orc.Batch(b, p, upto="frag")
     assert np.array_equal(Fr.fragmat()["col"], full.fragmat()["col"]) and not Fr.phase_result()["haplotag"].any()
+
+
+def _batch_bytes(B):
+    pr = B.phase_result()
+    return (B.cands().tobytes(), pr["haplotag"].tobytes(), pr["assignment"].tobytes(), pr["phase_set"].tobytes(),
+            pr["objective"].tobytes(), "".join(B.vcf_texts()), B.stats().tobytes(), B.tie_census().tobytes())
+
+
+@pytest.mark.parametrize("profile,preset,seed,glen", [("ont-cdna", "ont-cdna", 21, 9000), ("masseq", "hifi-masseq", 22, 9000), ("ont-drna", "ont-drna", 23, 20000)])
+def test_indexed_gathers_equal_the_linear_searches(orc, profile, preset, seed, glen):
+    """orc_set_fast: the position index (cover_pos) names the entry the reference's per-fragment linear search finds
+    (phase.rs:890-898, snpfrags.rs:403-414, phase.rs:1331-1349), the table of libm values gives the bits of libm per
+    observation, and the threaded Jacobi steps keep every f64 sum in its order -- every output of every decision mode is
+    identical byte for byte, counters included (enumeration and chain regions, 1 and 3 threads per region)."""
+    b = synth.make_batch(profile, n_genes=4, gene_len=glen, depth=40, seed=seed)
+    p = _abi.make_params(preset, seed=seed)
+    for mode in (orc.MODE_F64, orc.MODE_EXACT, orc.MODE_F64_ONLY, orc.MODE_EXACT_ONLY, orc.MODE_TIE):
+        slow = _batch_bytes(orc.Batch(b, p, mode=mode, threads=2))
+        for fast in (1, 3):
+            assert _batch_bytes(orc.Batch(b, p, mode=mode, threads=2, fast=fast)) == slow, (mode, fast)
+
+
+def test_tie_mode_is_the_f64_mode(orc):
+    """ORC_MODE_TIE -- decisions by the exact fixed-point sums, exact ties by the reference-order f64 scores of that row /
+    column / configuration -- reaches the phasing of ORC_MODE_F64 (reference-order f64 everywhere) on regions WITH
+    rounding-noise ties (the census says which classes occurred); with no tie class resolved (mask 0) it is ORC_MODE_EXACT."""
+    b = synth.make_batch("ont-drna", n_genes=6, gene_len=20000, depth=45, seed=31)
+    p = _abi.make_params("ont-drna", seed=31)
+    F = orc.Batch(b, p, mode=orc.MODE_F64, threads=2, fast=1)
+    T = orc.Batch(b, p, mode=orc.MODE_TIE, threads=2, fast=1)
+    X = orc.Batch(b, p, mode=orc.MODE_EXACT, threads=2, fast=1)
+    T0 = orc.Batch(b, p, mode=orc.MODE_TIE, threads=2, fast=1, tie_mask=0)
+    assert F.stats()[:, 2].sum() > 0 and F.tie_census()[:, 4].sum() > 0        # the case has sigma ties that f64 noise flips
+    fb, tb, xb, t0b = _batch_bytes(F), _batch_bytes(T), _batch_bytes(X), _batch_bytes(T0)
+    assert tb[:4] == fb[:4] and tb[5] == fb[5]                                 # candidates, sigma, assignment, phase sets, VCF text
+    assert np.array_equal(T.stats()[:, :2], F.stats()[:, :2])                  # ... along the same trajectory
+    assert t0b[:6] == xb[:6]
+    po, pf = T.phase_result()["objective"], F.phase_result()["objective"]
+    assert np.all(np.abs(po - pf) < 1e-6)                                      # fixed-point vs f64 value of the same optimum
