@@ -252,6 +252,21 @@ int lcr_get_read_records_device(lcr_ctx*, const lcr_read_record** dev_rec, int32
  * enumeration branch, phase.rs:1097-1122, never reads them): others report n_blocks = 0. */
 int lcr_get_ld_blocks(lcr_ctx*, int32_t region, int32_t* n_blocks, const int32_t** block_off, const int32_t** snp_idx);
 
+/* Decision arithmetic of the optimiser and its census (round 4).  The reference decides sigma flips, the delta / eta choice and
+ * `prob > largest_prob` on f64 ratio scores / sums accumulated in list order (phase.rs:77-96, 128-176, 257-276, 845-858, 905-940,
+ * 1117); every term is one of 62 constants, so liblcr takes each decision on the EXACT fixed-point sums (order-free, hence
+ * parallel and reproducible) and, where those sums tie exactly -- the only decisions on which summation order can matter --,
+ * on the reference-order f64 scores of that row / configuration.  lcr_get_tie_census reports the ties of the last lcr_phase:
+ *   out[0] sigma decisions with A == B at rows with an entry at a het site, decided by the f64 scores of phase.rs:77-96
+ *   out[1] ... of which flipped (q < qn)
+ *   out[2] delta / eta choices with a tie at the maximum -- the first maximum was kept (UNRESOLVED class)
+ *   out[3] steps whose only changes were tie changes, taken as "no improvement" (check_new_*, phase.rs:278-355; UNRESOLVED)
+ *   out[4] regions whose configurations of maximal objective differ and were compared by their f64 sums (phase.rs:257-276)
+ *   out[5] regions where that compare fell to "first maximum wins" (fallback kernels; UNRESOLVED)
+ *   out[6] sigma ties met by kernels without the f64 path (UNRESOLVED)      out[7] reserved
+ * All UNRESOLVED counts zero = every decision of the call was the reference arithmetic's decision. */
+int lcr_get_tie_census(lcr_ctx*, uint64_t out[8]);
+
 /* Region discovery: replaces find_isolated_regions_with_depth (util.rs:236-332, truncation
  * off) for one contig.  ref_start / ref_end are record.reference_start() / reference_end() of the reads that
  * pass the filters of util.rs:264-279 (mem = LCR_MEM_HOST or LCR_MEM_DEVICE).  Region i covers 0-based columns

@@ -434,6 +434,13 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   P.st_sigma = b_st.as<int8_t>() + st_sig; P.st_delta = b_st.as<int8_t>() + st_del; P.st_eta = b_st.as<int8_t>() + st_eta;
   P.st_obj = (long long*)(b_st.as<int8_t>() + st_obj);
   P.lut = L.dev;
+  PostLut plut;
+  for (int q = 0; q < 31; q++) { plut.le[q] = L.le[q]; plut.l1e[q] = L.l1e[q]; }
+  plut.p_homref = L.p_homref; plut.p_homvar = L.p_homvar; plut.log_theta = L.log_theta; plut.log2 = L.log2;
+  PCHK(d_lut64.reserve(sizeof(PostLut))); PCHK(d_tie.reserve(TIE_NCTR * 8)); PCHK(h_pin[11].reserve(TIE_NCTR * 8));
+  if (!lut64_ready) { PCHK(hipMemcpyAsync(d_lut64.p, &plut, sizeof(PostLut), hipMemcpyHostToDevice, stream)); PCHK(hipStreamSynchronize(stream)); lut64_ready = true; }
+  PCHK(hipMemsetAsync(d_tie.p, 0, TIE_NCTR * 8, stream));   // (before ev_in: every queue of this call starts behind it)
+  P.lut64 = d_lut64.as<PostLut>(); P.tie_ctr = d_tie.as<unsigned long long>();
 
   // enumeration (S <= max_enum_snps) and chain regions
   std::vector<int32_t> enum_slots, chain_slots;
@@ -518,9 +525,6 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   if (ng) PCHK(hipStreamSynchronize(stream));
   lap("stage + sizes");
 
-  PostLut plut;
-  for (int q = 0; q < 31; q++) { plut.le[q] = L.le[q]; plut.l1e[q] = L.l1e[q]; }
-  plut.p_homref = L.p_homref; plut.p_homvar = L.p_homvar; plut.log_theta = L.log_theta; plut.log2 = L.log2;
   PostIn pin{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, const_cast<lcr_candidate*>(in.d_cand), in.d_cand_off,
              in.d_row_region_off, in.d_start0, P.st_sigma, P.st_delta, P.st_eta, (int8_t*)(d_res + res_tag), d_res + res_asg,
              (uint32_t*)(d_res + res_ps), d_read_rec.as<uint32_t>(), P.st_obj, (long long*)(d_hc + hc_obj), (lcr_candidate*)d_hc, prm.min_linkers, prm.max_enum_snps, prm.seed, prm.read_assign_cutoff, prm.min_phase_score, nullptr, P.reg, b_psrc.as<int32_t>()};
@@ -668,8 +672,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     std::vector<EnumSpan> spans[NCLS];
     size_t n_t[NCLS] = {0, 0, 0, 0, 0};   // tiles per class = grid of the class's kernel
     const uint32_t per_of[NCLS] = {1u, 1u, ENUM_TILE_JOBS, 2u * ENUM_WAVES, 1u};
-    std::vector<int64_t> job_base(ng, 0);
-    int64_t nj = 0;
+    std::vector<int64_t> job_base(ng, 0), st_base(ng, 0);   // st_base: first word of the region's saved restart states (classes 2 / 3)
+    int64_t nj = 0, st_words = 0;
     uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0};
     std::vector<int32_t> post_slots;   // enumeration regions with the device epilogue
     for (int g : enum_slots) {
@@ -682,6 +686,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       if (cls < 4) lds_need[cls] = std::max(lds_need[cls], EL.total);
       job_base[g] = nj;
       const uint64_t n = 1ull << S;
+      if (cls < 4) { st_base[g] = st_words; st_words += (int64_t)n * enum_state_words((uint32_t)st.R); }
       if (n_t[cls] + (n + per_of[cls] - 1) / per_of[cls] > 0x7fffffffull) { if (err) *err = "too many enumeration restarts for one launch"; return LCR_E_ARG; }
       spans[cls].push_back({g, (uint32_t)n_t[cls]});
       n_t[cls] += (size_t)((n + per_of[cls] - 1) / per_of[cls]);
@@ -693,19 +698,23 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     for (int k = 0; k < NCLS; k++) { n_w[k] = spans[k].size(); s_off[k] = n_spans; n_spans += n_w[k]; }
     const size_t ns = enum_slots.size(), nps = post_slots.size();
     const size_t off_jb_al = (n_spans * sizeof(EnumSpan) + 7) & ~(size_t)7;
-    const size_t up_bytes = off_jb_al + (size_t)ng * 8 + (ns + nps) * 4;
+    const size_t off_sb = off_jb_al + (size_t)ng * 8;   // st_base
+    const size_t up_bytes = off_sb + (size_t)ng * 8 + (ns + nps) * 4;
+    PCHK(d_enum_st.reserve((size_t)std::max<int64_t>(st_words, 1) * 8));
     PCHK(b_job.reserve(up_bytes + 64));
     PCHK(b_obj.reserve((size_t)nj * 8 + (size_t)ng * 8 + 64));   // objectives | winners | tiles done
     PCHK(h_pin[8].reserve(up_bytes + 64));   // pinned: the upload is queued, not staged
     uint8_t* const up = h_pin[8].as<uint8_t>();
     for (int k = 0; k < NCLS; k++) memcpy(up + s_off[k] * sizeof(EnumSpan), spans[k].data(), n_w[k] * sizeof(EnumSpan));
     memcpy(up + off_jb_al, job_base.data(), (size_t)ng * 8);
-    memcpy(up + off_jb_al + (size_t)ng * 8, enum_slots.data(), ns * 4);
-    memcpy(up + off_jb_al + (size_t)ng * 8 + ns * 4, post_slots.data(), nps * 4);
+    memcpy(up + off_sb, st_base.data(), (size_t)ng * 8);
+    memcpy(up + off_sb + (size_t)ng * 8, enum_slots.data(), ns * 4);
+    memcpy(up + off_sb + (size_t)ng * 8 + ns * 4, post_slots.data(), nps * 4);
     PCHK(hipMemcpyAsync(b_job.p, up, up_bytes, hipMemcpyHostToDevice, stream));
     const EnumSpan* d_sp = b_job.as<EnumSpan>();
     const int64_t* d_jb = (const int64_t*)(b_job.as<uint8_t>() + off_jb_al);
-    const int32_t* d_sl = (const int32_t*)(b_job.as<uint8_t>() + off_jb_al + (size_t)ng * 8);
+    const int64_t* d_sb = (const int64_t*)(b_job.as<uint8_t>() + off_sb);
+    const int32_t* d_sl = (const int32_t*)(b_job.as<uint8_t>() + off_sb + (size_t)ng * 8);
     const int32_t* d_psl = d_sl + ns;
     long long* d_obj = b_obj.as<long long>();
     uint32_t* d_win = (uint32_t*)(d_obj + nj);
@@ -722,8 +731,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       hipStream_t s34 = fork ? aux : stream;
       hipError_t e = hipSuccess;
       if (fork) { if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e; }
-      if (cnt[2]) launch_k4_enum_reg(32, (unsigned)cnt[2], lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, win, done);
-      if (cnt[3]) launch_k4_enum_reg(0, (unsigned)cnt[3], lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, win, done);
+      if (cnt[2]) launch_k4_enum_reg(32, (unsigned)cnt[2], lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), done);
+      if (cnt[3]) launch_k4_enum_reg(0, (unsigned)cnt[3], lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), done);
       if (cnt[4]) launch_k4_enum_big((unsigned)cnt[4], s34, P, d_sp + s_off[4], (int32_t)n_w[4], per_of[4], d_jb, d_obj, win);
       if (fork) { if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e; }
       return e;
@@ -731,7 +740,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(launch(n_t, nullptr));
     if (n_w[4]) {   // the global-memory fallback kernel keeps the separate pick and the winners' second launch
       const size_t only4[NCLS] = {0, 0, 0, 0, n_w[4]};
-      launch_k4_enum_pick((int32_t)ns, stream, d_sl, P.reg, d_jb, d_obj, d_win);
+      launch_k4_enum_pick((int32_t)n_w[4], stream, d_sp + s_off[4], P.reg, d_jb, d_obj, d_win, P.tie_ctr);
       PCHK(launch(only4, d_win));
     }
     if (nps) {
@@ -830,8 +839,10 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     static const char* nm2[] = {"stage delta/eta", "sigma step (workgroup 0)", "barrier 1", "stage sigma", "delta step (workgroup 0)", "barrier 2"};
     for (int k = 0; k < 6; k++) fprintf(stderr, "[phase]     grid chain rounds: %-26s %9.1f us per iteration\n", nm2[k], (double)clk[8 + k] / 100.0 / (double)std::max<long long>(clk[15], 1));
   }
+  PCHK(hipMemcpyAsync(h_pin[11].p, d_tie.p, TIE_NCTR * 8, hipMemcpyDeviceToHost, stream));   // (`side` is drained: every kernel that counts is done or ahead in `stream`)
   PCHK(hipStreamSynchronize(stream));
   PCHK(hipGetLastError());
+  memcpy(tie_census, h_pin[11].p, TIE_NCTR * 8);
   lap("enumeration kernels");
 
   // ---- results: per-row haplotag / assignment / phase set, candidates and objectives were written to pinned host

@@ -24,7 +24,23 @@ struct PhaseDev {
   int32_t lds_state;                                                      // 1: working state lives in dynamic LDS
   int32_t lds_mat;                                                        // bytes of dynamic LDS behind the state for a matrix copy
   PhaseLutDev lut;
+  // Decision arithmetic (round 4, DESIGN.md "Decision arithmetic"): every decision by the exact fixed-point sums; a decision whose
+  // sums TIE exactly is taken by the reference-order f64 ratio scores of that row / configuration (phase.rs:77-96, 257-276) --
+  // lut64 = the host's libm values of log10(eps_q), log10(1 - eps_q); tie_ctr = the census of the ties met (TIE_* below)
+  const struct PostLut* lut64;
+  unsigned long long* tie_ctr;
 };
+// census of exact fixed-point ties of one lcr_phase call (lcr_get_tie_census): the RESOLVED classes follow the reference's f64
+// arithmetic; an UNRESOLVED count other than zero means a decision fell to "a tie changes nothing" where the reference's f64
+// rounding noise might have decided otherwise
+enum { TIE_SIGMA_F64 = 0,      // sigma decisions with A == B at a row with an entry at a het site: decided by the f64 scores
+       TIE_SIGMA_FLIPS = 1,    // ... of which flipped (q < qn)
+       TIE_DELTA_UNRES = 2,    // delta / eta choices with a tie at the maximum (phase.rs:905-940): first maximum kept
+       TIE_STEP_UNRES = 3,     // steps whose only changes were tie changes (check_new_*, phase.rs:278-355): taken as "no improvement"
+       TIE_BEST_F64 = 4,       // regions whose configurations of maximal objective differ: `prob > largest_prob` by the f64 sums
+       TIE_BEST_UNRES = 5,     // ... left to "first maximum wins" (fallback kernels)
+       TIE_SIGMA_UNRES = 6,    // sigma ties in kernels without the f64 path
+       TIE_NCTR = 8 };
 
 // per-region sizes k4_stage reports to the host
 struct StageStat { int32_t R, E, max_n, max_rows, E_all, W; };   // max_*: per-lane share of k4_enum_reg's row partition; E_all: all entries;

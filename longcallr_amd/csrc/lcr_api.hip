@@ -872,4 +872,11 @@ int lcr_get_ld_blocks(lcr_ctx* c, int32_t region, int32_t* n_blocks, const int32
   return LCR_OK;
 }
 
+int lcr_get_tie_census(lcr_ctx* c, uint64_t out[8]) {
+  if (!c || !out) return LCR_E_ARG;
+  if (!c->have_phase) { c->err = "lcr_get_tie_census before lcr_phase"; return LCR_E_STATE; }
+  for (int i = 0; i < 8; i++) out[i] = i < TIE_NCTR ? (uint64_t)c->phase.tie_census[i] : 0;
+  return LCR_OK;
+}
+
 }  // extern "C"

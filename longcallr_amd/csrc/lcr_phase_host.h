@@ -137,8 +137,11 @@ struct PhaseHost {
   DevBuf d_state[40];
   DevBuf d_spec_sig, d_spec_de, d_spec_res, d_pk;   // working states / results of the speculative half-rounds (k4_grid.hip)
   DevBuf d_read_rec;             // per-row results as 12-byte records in HBM, written by k4_post
+  DevBuf d_lut64, d_tie, d_enum_st;   // f64 table of the tie paths (PostLut), census counters, final states of the enumeration restarts
+  bool lut64_ready = false;
+  unsigned long long tie_census[TIE_NCTR] = {0, 0, 0, 0, 0, 0, 0, 0};   // of the last run (lcr_get_tie_census)
   bool read_rec_stale = false;   // some regions took the host epilogue: the records are rebuilt from the host arrays on demand
-  HostBuf h_pin[11];   // pinned staging: row_ptr, col, val, links, enum state, region sizes, chain state, results, job tables, chain start
+  HostBuf h_pin[12];   // pinned staging: row_ptr, col, val, links, enum state, region sizes, chain state, results, job tables, chain start
   hipStream_t side = nullptr;   // second queue: fragment matrix download + chain regions
   hipEvent_t ev_in = nullptr, ev_csr = nullptr, ev_fork = nullptr, ev_join = nullptr;
   hipStream_t aux = nullptr;   // enumeration classes 3 / 4 beside class 2
@@ -153,6 +156,7 @@ struct PhaseHost {
   int run(const PhaseInputs& in, const lcr_params& p, hipStream_t s, std::string* err);
   void release() {
     for (auto& b : d_state) b.release();
+    d_lut64.release(); d_tie.release(); d_enum_st.release(); lut64_ready = false;
     d_read_rec.release(); d_spec_sig.release(); d_spec_de.release(); d_spec_res.release(); d_pk.release();
     for (auto& b : h_pin) b.release();
     if (side) { (void)hipStreamDestroy(side); side = nullptr; }
