@@ -1,6 +1,7 @@
 // k4_enum.hip — K4, enumeration branch: all 2^S restarts of cross_optimize for regions with S <= max_enum_snps
 // (reference src/phase.rs:1097-1122 over cross_optimize :810-976).  Host control: k4_phase.hip (PhaseHost::run).
 #include <climits>
+#include <type_traits>
 #include "k4_dev.h"
 #include "k4_kernels.h"
 
@@ -50,130 +51,397 @@ __device__ __forceinline__ EnumTile enum_tile_of(const PhaseDev& P, const EnumSp
 // `prob > largest_prob` over the restarts of one region (phase.rs:1113-1119), run by the tile that completes the region.
 // The fixed-point objectives decide; among the restarts of MAXIMAL objective the reference keeps the first one unless a
 // later one's f64 sum (cal_overall_probability, phase.rs:257-276: every phase entry's log10 term, fragment by fragment,
-// in one running sum) is greater by rounding noise.  Every restart left its final state in st_words, so:
-//   1. the restarts of maximal objective, in ascending order, ENUM_TCAP - 1 at a time beside the best so far;
-//   2. a signature per configuration (a hash of the match bits of all entries in row order): equal signatures = the same
-//      sequence of terms = the same f64 sum -- the usual case (restarts that reach one optimum, or its mirror image);
-//   3. only if signatures differ: a lane per configuration adds its terms in the reference's order (f64, LUT of the
-//      host's libm values), then thread 0 walks the list: strictly greater replaces;
-//   4. the winner's state goes to the region's result slots (no re-run of the winning restart).
+// in ONE running sum) is greater by rounding noise.  Every restart left its final state and a SIGNATURE in st_words -- a
+// hash of the match bits of all entries (k4_enum_reg): equal signatures = the same sequence of terms = the same f64 sum.
+//   0. all restarts of maximal objective carry one signature (restarts that reached one optimum with the same sigma
+//      everywhere): the first of them wins, nothing is summed;
+//   1. else the first one is the REFERENCE configuration: one lane adds its terms in the reference's order (f64, LUT of
+//      the host's libm values) and keeps the running sum at every row boundary, ps[0 .. R];
+//   2. the others, a lane each, ENUM_TCAP at a time in ascending order.  A configuration of the reference's class -- same
+//      eta, the same or the mirrored delta at the het sites -- differs from it in the sigma of a few rows only (rows whose
+//      two orientations score alike: their sigma is whatever init_assignment drew).  Such a row is re-added alone from the
+//      reference's running sum ps[k]: if it arrives at ps[k + 1] bit for bit, everything behind it is the reference's sum
+//      again (f64 addition inside one binade rounds every term on its own, so this is the rule); when all its rows do, its
+//      sum IS ps[R].  Otherwise -- another class, or a row that rounds differently -- the lane adds all of its terms;
+//   3. strictly-greater-replaces over the list in order (phase.rs:1117); the winner's state goes to the region's result
+//      slots (no re-run of the winning restart).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void enum_resolve(const PhaseDev& P, const RegionDev& rd, int slot, uint8_t* lds, const EnumLayout& L, uint32_t E,
-                                             const long long* __restrict__ o, const unsigned long long* __restrict__ st, uint32_t n_jobs) {
+__global__ void __launch_bounds__(64 * ENUM_WAVES)
+k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* __restrict__ job_base, const long long* __restrict__ job_obj,
+                const int64_t* __restrict__ st_base, const unsigned long long* __restrict__ st_words) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int slot = spans[blockIdx.x].slot;
+  const RegionDev rd = P.reg[slot];
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int R = rd.R, S = rd.S;
+  const uint32_t E = (uint32_t)P.prow_ptr[rd.rp_off + R];
+  const uint32_t n_jobs = 1u << S;
+  const long long* const o = job_obj + job_base[slot];
+  const unsigned long long* const st = st_words + st_base[slot];
   const uint32_t nk = (uint32_t)(R + 63) / 64, sw = enum_state_words((uint32_t)R);
-  const uint2* csr = (const uint2*)(lds + L.csr);
-  const uint16_t* rp = (const uint16_t*)(lds + L.rp);
-  const uint8_t* qrow = lds + L.qrow;
-  const double* lut = (const double*)(lds + L.lut);
-  uint32_t* t_e = (uint32_t*)(lds + L.res);                                   // [ENUM_TCAP] restart
-  unsigned long long* t_sig = (unsigned long long*)(lds + L.res + 4 * ENUM_TCAP + 4 * ENUM_TCAP);   // [ENUM_TCAP] signature (8-byte aligned)
-  double* t_sum = (double*)(lds + L.res + 16 * ENUM_TCAP);                    // [ENUM_TCAP] f64 objective
+  const ResolveLayout L = resolve_layout((uint32_t)R, E, (uint32_t)S);
+  uint16_t* rp = (uint16_t*)(lds + L.rp);
+  uint16_t* ent16 = (uint16_t*)(lds + L.ent16);
+  double* lut = (double*)(lds + L.lut);
+  double* pse = (double*)(lds + L.pse);                                                 // [E] running sum of the reference configuration behind every entry
+  unsigned long long* sg_ref = (unsigned long long*)(lds + L.sg_ref);                  // [nk] its sigma words
+  unsigned long long* hetw = (unsigned long long*)(lds + L.hetw);                      // [nk] rows with an entry at one of its het sites
+  unsigned long long* repmask = (unsigned long long*)(lds + L.repmask);                // [S][nk] rows whose first het site (of the reference's eta) is SNP i
+  uint32_t* rowsnps = (uint32_t*)(lds + L.rowsnps);                                    // [R] the SNPs of a row's entries as a mask
+  __shared__ uint32_t s_adj[32], s_grp[32];                                             // het sites a site shares a row with; the same closed under "shares a row" (its group)
+  uint32_t* t_e = (uint32_t*)(lds + L.res);                                             // [ENUM_TCAP] restart
+  double* t_sum = (double*)(lds + L.res + 8 * ENUM_TCAP);                               // [ENUM_TCAP] f64 objective
+  constexpr uint32_t EVCAP = 96;
+  double* ev_t = (double*)(lds + L.res + 16 * ENUM_TCAP);                              // [EVCAP] events of the reference's chain: its term there ...
+  uint16_t* ev_x = (uint16_t*)(lds + L.res + 16 * ENUM_TCAP + 8 * EVCAP);              // ... and the entry
+  __shared__ uint32_t s_nev;
   __shared__ long long s_best[ENUM_WAVES];
-  __shared__ uint32_t s_n, s_cursor, s_differ, s_win;
+  __shared__ uint32_t s_wcnt[ENUM_WAVES], s_dif[ENUM_WAVES], s_ntied;
+  constexpr uint32_t TLCAP = 2048;
+  uint16_t* tl = (uint16_t*)(lds + L.res + 16 * ENUM_TCAP + 96 * 10 + 16);   // [TLCAP] the restarts of maximal objective
+  __shared__ uint32_t s_win;
   __shared__ double s_winsum;
-  __shared__ int s_have_sum;
+  __shared__ int s_flat;
   auto ld_obj = [&](uint32_t e) { return __hip_atomic_load(&o[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   auto ld_st = [&](uint32_t e, uint32_t w) { return __hip_atomic_load(&st[(size_t)e * sw + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  // ---- the maximal objective
+  // ---- stage the region: row pointers, the row-order entries (SNP | allele | q | last-of-row), the table of libm values
+  if (tid < 64) lut[tid] = (tid & 31) < 31 ? (tid < 32 ? P.lut64->le[tid] : P.lut64->l1e[tid - 32]) : 0.0;
+  { const int32_t* g_rp = P.prow_ptr + rd.rp_off; for (int r = tid; r <= R; r += nt) rp[r] = (uint16_t)g_rp[r]; }
+  __syncthreads();
+  for (int r = tid; r < R; r += nt) {
+    const int e0 = rp[r], e1 = rp[r + 1];
+    for (int e = e0; e < e1; e++) {
+      const uint32_t v = P.pval[rd.e_off + e];
+      ent16[e] = (uint16_t)(((uint32_t)P.pcol[rd.e_off + e] & 31u) | (v & 32u) | ((v & 31u) << 6) | (e + 1 == e1 ? 0x800u : 0u));
+    }
+  }
+  const long long prof_t0 = (long long)wall_clock64(); (void)prof_t0;
+  // ---- the maximal objective and the restarts that have it, in ascending order (tl[0 .. n_tied)); do all of them carry the
+  // first one's signature?  (the objectives of the first 1 024 restarts stay in registers between the two sweeps)
+  constexpr int OV = 4;
+  long long ov[OV];
   long long best = LLONG_MIN;
-  for (uint32_t e = tid; e < n_jobs; e += nt) { const long long v = ld_obj(e); if (v > best) best = v; }
+#pragma unroll
+  for (int k = 0; k < OV; k++) { const uint32_t e = (uint32_t)tid + (uint32_t)k * 256u; ov[k] = e < n_jobs ? ld_obj(e) : LLONG_MIN; }
+#pragma unroll
+  for (int k = 0; k < OV; k++) if (ov[k] > best) best = ov[k];
+  for (uint32_t e = tid + OV * 256u; e < n_jobs; e += nt) { const long long v = ld_obj(e); if (v > best) best = v; }
   for (int d = 32; d >= 1; d >>= 1) { const long long ob = __shfl_xor(best, d, 64); if (ob > best) best = ob; }
   if (lane == 0) s_best[wave] = best;
-  if (tid == 0) { s_cursor = 0; s_win = 0xffffffffu; s_have_sum = 0; s_winsum = 0.0; }
+  if (tid == 0) s_ntied = 0;
   __syncthreads();
   for (int w = 0; w < ENUM_WAVES; w++) if (s_best[w] > best) best = s_best[w];
-  // ---- chunks of the restarts of maximal objective, in ascending order; slot 0 of a chunk = the best so far
-  for (;;) {
-    const uint32_t cur = s_cursor;
-    if (cur >= n_jobs) break;
+  for (uint32_t p0 = 0; p0 < n_jobs; p0 += 256u) {   // a pass of 256 restarts, thread = restart: ranks by ballot, wave offsets through LDS
+    const uint32_t e = p0 + (uint32_t)tid;
+    const long long v = p0 < OV * 256u ? ov[p0 >> 8] : (e < n_jobs ? ld_obj(e) : LLONG_MIN);
+    const bool hit = e < n_jobs && v == best;
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(m);
     __syncthreads();
-    // wave 0 collects the next <= TCAP - 1 (first chunk: TCAP) restarts with o[e] == best from `cur` on, 64 candidates per step
-    if (wave == 0) {
-      const bool first = s_win == 0xffffffffu;
-      uint32_t n = first ? 0u : 1u, e0 = cur;
-      if (!first && lane == 0) t_e[0] = s_win;
-      while (e0 < n_jobs && n < ENUM_TCAP) {
-        const uint32_t e = e0 + lane;
-        const bool hit = e < n_jobs && ld_obj(e) == best;
-        const unsigned long long m = __ballot(hit);
-        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (hit && n + rank < ENUM_TCAP) t_e[n + rank] = e;
-        const uint32_t c = (uint32_t)__popcll(m);
-        if (n + c > ENUM_TCAP) {   // the chunk is full inside this step: resume behind the last restart taken
-          const uint32_t take = ENUM_TCAP - n;
-          // position of the take-th set bit
-          uint32_t last = 0;
-          { const unsigned long long sel = __ballot(hit && rank == take - 1); last = (uint32_t)__ffsll((long long)sel) - 1u; }
-          e0 = e0 + last + 1; n = ENUM_TCAP;
-          break;
-        }
-        n += c; e0 += 64;
-      }
-      if (lane == 0) { s_n = n; s_cursor = e0 < n_jobs ? e0 : n_jobs; }
+    uint32_t off = s_ntied, tot = 0;
+    for (int w = 0; w < ENUM_WAVES; w++) { if (w < wave) off += s_wcnt[w]; tot += s_wcnt[w]; }
+    const uint32_t at = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (hit && at < TLCAP) tl[at] = (uint16_t)e;
+    __syncthreads();
+    if (tid == 0) s_ntied += tot;
+    __syncthreads();
+  }
+  const uint32_t n_tied_all = s_ntied, n_tied = min(n_tied_all, TLCAP);
+  const uint32_t first = tl[0];
+  const unsigned long long sig0 = ld_st(first, nk + 2);
+  uint32_t dif = 0;
+  for (uint32_t j = tid; j < n_tied; j += nt) if (ld_st(tl[j], nk + 2) != sig0) dif = 1;
+  dif = __ballot(dif != 0) ? 1u : 0u;
+  if (lane == 0) s_dif[wave] = dif;
+  if (n_tied_all > TLCAP || n_jobs > 65536u) {   // (more configurations of maximal objective than the list holds: first maximum wins, counted)
+    if (tid == 0) atomicAdd(&P.tie_ctr[TIE_BEST_UNRES], 1ull);
+    dif = 0;
+    if (lane == 0) s_dif[wave] = 0;
+  }
+  if (tid == 0) { s_win = first; s_winsum = 0.0; s_flat = 1; }
+  __syncthreads();
+  for (int w = 0; w < ENUM_WAVES; w++) dif |= s_dif[w];
+#ifdef ENUM_ABL_NOSUM
+  dif = 0;
+#endif
+  if (dif && P.tie_arith < 1) { if (tid == 0) atomicAdd(&P.tie_ctr[TIE_BEST_UNRES], 1ull); dif = 0; }
+  if (dif) {
+    if (tid == 0) atomicAdd(&P.tie_ctr[TIE_BEST_F64], 1ull);
+    // ---- the reference configuration
+    const unsigned long long rm0 = ld_st(first, nk);
+    const uint32_t r_dneg = (uint32_t)rm0, r_eta0 = (uint32_t)(rm0 >> 32), r_etap = (uint32_t)ld_st(first, nk + 1);
+    { int empty = 0; for (int k = tid; k < R; k += nt) empty |= rp[k] == rp[k + 1] ? 1 : 0; if (empty) s_flat = 0; }   // (rows without an entry: min_linkers = 0)
+    for (uint32_t x = E + tid; x < ((E + 3u) & ~3u); x += nt) ent16[x] = 0;   // padding of the last 8-byte read
+    for (uint32_t k = tid; k < nk; k += nt) sg_ref[k] = ld_st(first, k);
+    // rows by their first het site, and the groups of het sites that rows tie together: a configuration whose delta is mirrored
+    // on whole groups (independent groups of SNPs settle independently) differs from the reference exactly in the rows whose
+    // sigma is not mirrored along with their group
+    const bool rows_ok = true;
+    if (tid < 32) s_adj[tid] = 0;
+    __syncthreads();
+    for (uint32_t k0 = wave * 64; k0 < (uint32_t)R; k0 += 64 * ENUM_WAVES) {   // a lane per row
+      const uint32_t k = k0 + lane;
+      uint32_t ms = 0;
+      if (k < (uint32_t)R) for (int x = rp[k]; x < rp[k + 1]; x++) ms |= 1u << (ent16[x] & 31u);
+      if (k < (uint32_t)R) rowsnps[k] = ms;
+      const uint32_t hs = ms & r_eta0;
+      const unsigned long long m = __ballot(hs != 0);
+      if (lane == 0) hetw[k0 >> 6] = m;
+      const int rep = hs ? __ffs((int)hs) - 1 : -1;
+      if (hs & (hs - 1)) for (uint32_t rest = hs; rest; rest &= rest - 1) atomicOr(&s_adj[__ffs((int)rest) - 1], hs);   // (a row with two or more het sites ties them together)
+      if (rows_ok) for (int i = 0; i < S; i++) { const unsigned long long mi = __ballot(rep == i); if (lane == 0) repmask[(uint32_t)i * nk + (k0 >> 6)] = mi; }
     }
     __syncthreads();
-    const uint32_t n = s_n;
-    // ---- signatures: a wave per configuration, a lane per row
-    unsigned long long* sgw = (unsigned long long*)(lds + L.state + wave * L.stride);   // (the waves' sigma words: free now)
-    for (uint32_t j = wave; j < n; j += ENUM_WAVES) {
-      const uint32_t e = t_e[j];
-      for (uint32_t k = lane; k < nk; k += 64) sgw[k] = ld_st(e, k);
-      const unsigned long long m0 = ld_st(e, nk);
-      const uint32_t dneg = (uint32_t)m0, eta0 = (uint32_t)(m0 >> 32), etap = (uint32_t)ld_st(e, nk + 1);
-      wave_lds_sync();
-      unsigned long long h = 0;
-      for (int k = lane; k < R; k += 64) {
-        const uint32_t sneg = (uint32_t)(sgw[k >> 6] >> (k & 63)) & 1u;
-        uint32_t word = 0;
-        int bit = 0;
-        for (int x = rp[k]; x < rp[k + 1]; x++, bit++) {
-          const uint32_t m = csr[x].x >> 24, i = m & 31u, pbit = (m >> 5) & 1u;
-          const uint32_t match = ((eta0 >> i) & 1u) ? (pbit ^ sneg ^ ((dneg >> i) & 1u)) : (((etap >> i) & 1u) ? pbit : pbit ^ 1u);
-          word |= match << bit;
-        }
-        h += mix64(((unsigned long long)(uint32_t)k << 32 | word) + 0x9E3779B97F4A7C15ULL);
-      }
-      h = (unsigned long long)wave_sum_ll((long long)h);
-      if (lane == 0) t_sig[j] = h;
-      wave_lds_sync();
+    if (wave == 0) {   // groups = connected components over "shares a row" (<= 32 sites): lane i holds site i's set, five doubling rounds
+      uint32_t g = lane < 32 && ((r_eta0 >> lane) & 1u) ? (1u << lane) | s_adj[lane & 31] : 0u;
+      for (int round = 0; round < 5; round++)
+        for (int j2 = 0; j2 < 32; j2++) { const uint32_t v = (uint32_t)__shfl((int)g, j2, 64); if ((g >> j2) & 1u) g |= v; }
+      if (lane < 32) s_grp[lane] = g;
     }
     __syncthreads();
-    if (tid == 0) { uint32_t d = 0; for (uint32_t j = 1; j < n; j++) d |= t_sig[j] != t_sig[0] ? 1u : 0u; s_differ = d; }
-    __syncthreads();
-    if (s_differ) {
-      // ---- f64 objectives (phase.rs:257-276): a lane per configuration, every lane walks the whole matrix in row order
-      if (tid == 0) atomicAdd(&P.tie_ctr[TIE_BEST_F64], 1ull);
-      for (uint32_t j = tid; j < n; j += nt) {
-        const uint32_t e = t_e[j];
-        if (j == 0 && s_have_sum) { t_sum[0] = s_winsum; continue; }
-        const unsigned long long m0 = ld_st(e, nk);
-        const uint32_t dneg = (uint32_t)m0, eta0 = (uint32_t)(m0 >> 32), etap = (uint32_t)ld_st(e, nk + 1);
-        double acc = 0.0;
+    const bool prefix_ok = true;
+    // a configuration's terms added in the reference's order; ps_out != nullptr: the running sum before every row is kept
+    auto full_sum = [&](const uint32_t e, const uint32_t dneg, const uint32_t eta0, const uint32_t etap, double* ps_out) -> double {
+      // match = [p == x] as three bit operations per entry (x depends on sigma only at het sites):
+      //   het site: p == sigma * delta <=> pbit ^ sneg ^ dneg_i = 1;  hom site: p == eta <=> pbit ^ [eta_i == -1] = 1
+      //   => match = pbit ^ c_i ^ (sneg & het_i),  c = (dneg & eta0) | (~etap & ~eta0)
+      const uint32_t cm = (dneg & eta0) | (~etap & ~eta0);
+      double acc = 0.0;
+      if (s_flat) {
+        // the entries as one flat run (every row has an entry: the last-entry flags count the rows), four per 8-byte read;
+        // the entry words are the same for every lane: decoded on the scalar unit
+        unsigned long long wsg = ld_st(e, 0), wnext = 0;
+        int k = 0;
+        uint32_t sneg = 0u - ((uint32_t)wsg & 1u);   // all ones: sigma == -1
+        const uint32_t E4 = (E + 3u) & ~3u;
+        if (ps_out) ps_out[0] = 0.0;
+        for (uint32_t x = 0; x < E4; x += 4) {
+          const uint2 raw = *(const uint2*)(ent16 + x);
+          const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.x), r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.y);
+          const uint32_t v[4] = {r0 & 0xffffu, r0 >> 16, r1 & 0xffffu, r1 >> 16};
+          double tv[4];
+          uint32_t rowend = 0;
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t i = v[u] & 31u, pbit = (v[u] >> 5) & 1u, q = (v[u] >> 6) & 31u;   // (scalar)
+            const uint32_t match = (pbit ^ (cm >> i) ^ ((sneg & eta0) >> i)) & 1u;
+            tv[u] = lut[(match << 5) + q];
+            if (v[u] & 0x800u) {   // row end (uniform): the next row's sigma
+              rowend |= 1u << u;
+              k++;
+              if ((k & 63) == 32 && (uint32_t)(k >> 6) + 1 < nk) wnext = ld_st(e, (uint32_t)(k >> 6) + 1);
+              if ((k & 63) == 0) wsg = wnext;
+              sneg = 0u - ((uint32_t)(wsg >> (k & 63)) & 1u);
+            }
+          }
+          int kk = k - __popc(rowend);
+#pragma unroll
+          for (int u = 0; u < 4; u++) if (x + u < E) { acc += tv[u]; if (ps_out && (rowend >> u & 1u)) ps_out[++kk] = acc; }
+        }
+      } else {
         unsigned long long wsg = 0;
         for (int k = 0; k < R; k++) {
           if ((k & 63) == 0) wsg = ld_st(e, (uint32_t)k >> 6);
-          const uint32_t sneg = (uint32_t)(wsg >> (k & 63)) & 1u;
+          const uint32_t sneg = 0u - ((uint32_t)(wsg >> (k & 63)) & 1u);
           for (int x = rp[k]; x < rp[k + 1]; x++) {
-            const uint32_t m = csr[x].x >> 24, i = m & 31u, pbit = (m >> 5) & 1u;
-            const uint32_t match = ((eta0 >> i) & 1u) ? (pbit ^ sneg ^ ((dneg >> i) & 1u)) : (((etap >> i) & 1u) ? pbit : pbit ^ 1u);
-            acc += lut[(match ? 32u : 0u) + qrow[x]];
+            const uint32_t m = ent16[x], i = m & 31u, pbit = (m >> 5) & 1u;
+            const uint32_t match = (pbit ^ (cm >> i) ^ ((sneg & eta0) >> i)) & 1u;
+            acc += lut[(match << 5) + ((m >> 6) & 31u)];
           }
         }
-        t_sum[j] = acc;
+      }
+      return acc;
+    };
+    // the reference configuration's terms, a thread per entry (row by row: a lane per row) ...
+    {
+      const uint32_t cm = (r_dneg & r_eta0) | (~r_etap & ~r_eta0);
+      for (int k = tid; k < R; k += nt) {
+        const uint32_t sneg = 0u - ((uint32_t)(sg_ref[k >> 6] >> (k & 63)) & 1u);
+        for (int x = rp[k]; x < rp[k + 1]; x++) {
+          const uint32_t m = ent16[x], i = m & 31u, pbit = (m >> 5) & 1u;
+          const uint32_t match = (pbit ^ (cm >> i) ^ ((sneg & r_eta0) >> i)) & 1u;
+          pse[x] = lut[(match << 5) + ((m >> 6) & 31u)];
+        }
+      }
+      for (uint32_t x = E + tid; x < ((E + 7u) & ~7u); x += nt) pse[x] = 0.0;   // (padding of the last batch)
+    }
+    __syncthreads();
+    // ... and their running sum by ONE lane: the adds are the reference's chain (phase.rs:257-276), eight terms per round trip
+    if (tid == 0) {
+      double acc = 0.0;
+      const uint32_t E8 = (E + 7u) & ~7u;
+      uint32_t x = 0;
+      for (; x < E8; x += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = pse[x + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { acc += t[u]; t[u] = acc; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) pse[x + u] = t[u];
+      }
+      for (; x < E; x++) { acc += pse[x]; pse[x] = acc; }
+    }
+    __syncthreads();
+    // EVENTS of the reference's chain: an addition s + t that stays inside s's binade rounds t on its own (s is a multiple of the
+    // binade's ulp), so two running sums a few ulps apart that take the same terms KEEP their distance -- except where the sum
+    // crosses a power of two (the ulp doubles) or s + t lies exactly half way between two doubles (ties-to-even looks at s).
+    // Those entries (a dozen or two), with the reference's term, in ascending order; a thread per row finds them.
+    if (tid == 0) s_nev = 0;
+    __syncthreads();
+    {
+      const uint32_t cm = (r_dneg & r_eta0) | (~r_etap & ~r_eta0);
+      for (int k = tid; k < R; k += nt) {
+        const uint32_t sneg = 0u - ((uint32_t)(sg_ref[k >> 6] >> (k & 63)) & 1u);
+        for (int x = rp[k]; x < rp[k + 1]; x++) {
+          const uint32_t m = ent16[x], i = m & 31u, pbit = (m >> 5) & 1u;
+          const uint32_t match = (pbit ^ (cm >> i) ^ ((sneg & r_eta0) >> i)) & 1u;
+          const double t = lut[(match << 5) + ((m >> 6) & 31u)];
+          const double a = x ? pse[x - 1] : 0.0, c = pse[x];
+          // crossing zone: the exponent of |a| less 4096 ulps differs from that of |c| plus 4096 ulps
+          const unsigned long long ba = (unsigned long long)__double_as_longlong(fabs(a)), bc = (unsigned long long)__double_as_longlong(fabs(c));
+          const bool cross = ((ba > 4096ull ? ba - 4096ull : 0ull) >> 52) != ((bc + 4096ull) >> 52);
+          // exact tie: the error of fl(a + t) (TwoSum) is half an ulp of the result
+          const double bb = c - a, err = (a - (c - bb)) + (t - bb);
+          const double half_ulp = __longlong_as_double((long long)((((bc >> 52) & 0x7ffull) - 53ull) << 52));
+          const bool tie = ((bc >> 52) & 0x7ffull) > 53ull && fabs(err) == half_ulp;
+          if (cross || tie) { const uint32_t at = atomicAdd(&s_nev, 1u); if (at < EVCAP) { ev_x[at] = (uint16_t)x; ev_t[at] = t; } }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {   // ascending order (a few dozen)
+      const uint32_t ne = min(s_nev, EVCAP);
+      for (uint32_t a2 = 1; a2 < ne; a2++) {
+        const uint16_t xx = ev_x[a2]; const double tt = ev_t[a2];
+        int b2 = (int)a2 - 1;
+        while (b2 >= 0 && ev_x[b2] > xx) { ev_x[b2 + 1] = ev_x[b2]; ev_t[b2 + 1] = ev_t[b2]; b2--; }
+        ev_x[b2 + 1] = xx; ev_t[b2 + 1] = tt;
+      }
+    }
+    __syncthreads();
+    const bool events_ok = s_nev <= EVCAP;
+#ifdef ENUM_VERIFY
+    if (tid == 0) { atomicMax(&P.tie_ctr[3], (unsigned long long)s_nev); if (!events_ok) atomicAdd(&P.tie_ctr[5], 1ull); atomicAdd(&P.tie_ctr[1], (unsigned long long)s_nev); }
+#endif
+    const uint32_t n_ev = min(s_nev, EVCAP);
+#ifdef ENUM_PROF
+    if (tid == 0) atomicAdd(&P.tie_ctr[6], (unsigned long long)((long long)wall_clock64() - prof_t0));
+#endif
+    // ---- chunks of the restarts of maximal objective, in ascending order
+    for (uint32_t cur = 0; cur < n_tied; cur += ENUM_TCAP) {
+      __syncthreads();
+      const uint32_t n = min(ENUM_TCAP, n_tied - cur);
+      if ((uint32_t)tid < n) t_e[tid] = tl[cur + tid];
+      __syncthreads();
+      // ---- a lane per configuration: rows that differ from the reference's, each re-added from the reference's running sum
+      bool fallback = false;
+      uint32_t my_e = 0, dneg = 0, eta0 = 0, etap = 0;
+      if ((uint32_t)tid < n) {
+        my_e = t_e[tid];
+        const unsigned long long m0 = ld_st(my_e, nk);
+        dneg = (uint32_t)m0; eta0 = (uint32_t)(m0 >> 32); etap = (uint32_t)ld_st(my_e, nk + 1);
+        const uint32_t dd = (dneg ^ r_dneg) & r_eta0;
+        // the same eta: an entry's term differs from the reference's iff it is a het entry with (delta_i differs) != (sigma_k differs)
+        const bool same_class = prefix_ok && events_ok && eta0 == r_eta0 && etap == r_etap;
+        const uint32_t cm = (dneg & eta0) | (~etap & ~eta0);
+        // The walk over the rows whose terms differ from the reference's, in ascending order.  In step with the reference
+        // (dl == 0) a row is re-added alone from the reference's running sum; once a row arrives elsewhere (dl != 0: this
+        // configuration's sum = the reference's + dl) the distance is carried from event to event of the reference's chain,
+        // each of them and each further row of its own added explicitly from (reference's sum before it) + dl.
+        double dl = 0.0;
+        uint32_t evp = 0;
+        auto row_check = [&](const int k, const uint32_t sneg) {
+          const int xa = rp[k], xb = rp[k + 1];
+          if (dl != 0.0)
+            for (; evp < n_ev && (int)ev_x[evp] < xa; evp++) {   // the reference's events on the way (its own terms there)
+              const int x = ev_x[evp];
+              const double s1 = ((x ? pse[x - 1] : 0.0) + dl) + ev_t[evp];
+              dl = s1 - pse[x];
+            }
+          double s2 = (xa ? pse[xa - 1] : 0.0) + dl;
+          for (int x = xa; x < xb; x += 8) {   // eight entries per round trip: their words, their table values, then the adds in order
+            uint32_t m8[8]; double t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) m8[u] = ent16[min(x + u, xb - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const uint32_t i = m8[u] & 31u, pbit = (m8[u] >> 5) & 1u;
+              const uint32_t match = (pbit ^ (cm >> i) ^ ((sneg & eta0) >> i)) & 1u;
+              t8[u] = lut[(match << 5) + ((m8[u] >> 6) & 31u)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (x + u < xb) s2 += t8[u];
+          }
+          dl = s2 - pse[xb - 1];
+          while (evp < n_ev && (int)ev_x[evp] < xb) evp++;   // (events inside this row were added with it)
+          if (fabs(dl) > fabs(s2) * 0x1p-42) fallback = true;   // (more than ~1000 ulps apart: outside what the crossing zones cover)
+        };
+        auto finish = [&]() -> double {
+          if (dl != 0.0)
+            for (; evp < n_ev; evp++) {
+              const int x = ev_x[evp];
+              const double s1 = ((x ? pse[x - 1] : 0.0) + dl) + ev_t[evp];
+              dl = s1 - pse[x];
+            }
+          return (E ? pse[E - 1] : 0.0) + dl;
+        };
+        // delta mirrored on whole groups of het sites only (else some row mixes mirrored and unmirrored sites: add everything)
+        bool whole = true;
+        for (uint32_t rest = dd; rest && whole;) { const int i = __ffs((int)rest) - 1; const uint32_t gm = s_grp[i]; whole = (dd & gm) == gm; rest &= ~gm; }
+        if (!same_class) { fallback = true;
+#ifdef ENUM_VERIFY
+          atomicAdd(&P.tie_ctr[4], 1ull);
+#endif
+        }
+        else if (!whole) fallback = true;   // delta differs inside a group (a site whose two orientations score alike): its rows' sums differ by more than rounding
+        else {
+          const bool all = dd == r_eta0 && dd != 0u;   // the mirror image of the whole configuration: sigma and delta negated together
+          for (uint32_t w0 = 0; w0 < nk && !fallback; w0 += 8) {
+            unsigned long long d4[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) d4[u] = w0 + u < nk ? ld_st(my_e, w0 + u) : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              if (w0 + u >= nk) break;
+              unsigned long long flip = all ? ~0ull : 0ull;   // rows whose group is mirrored
+              if (!all) for (uint32_t rest = dd; rest; rest &= rest - 1) flip |= repmask[(uint32_t)(__ffs((int)rest) - 1) * nk + w0 + u];
+              unsigned long long d = (d4[u] ^ sg_ref[w0 + u] ^ flip) & hetw[w0 + u];
+              while (d && !fallback) {
+                const int b = __ffsll((long long)d) - 1;
+                d &= d - 1;
+                row_check((int)(w0 + u) * 64 + b, 0u - ((uint32_t)(d4[u] >> b) & 1u));
+              }
+            }
+          }
+          if (!fallback) t_sum[tid] = finish();
+        }
+      }
+#ifdef ENUM_PROF
+      const long long pf0 = (long long)wall_clock64();
+#endif
+      if (__ballot(fallback)) { if (fallback) t_sum[tid] = full_sum(my_e, dneg, eta0, etap, nullptr);
+#ifdef ENUM_PROF
+        if (lane == 0) { atomicAdd(&P.tie_ctr[7], (unsigned long long)((long long)wall_clock64() - pf0)); atomicAdd(&P.tie_ctr[4], 1ull); atomicAdd(&P.tie_ctr[3], (unsigned long long)E); }
+#endif
+      }
+#ifdef ENUM_VERIFY   // (measurement build: every sum that left the reference's chain, once more by adding all terms)
+      { const bool dv = (uint32_t)tid < n && !fallback && t_sum[tid] != (E ? pse[E - 1] : 0.0);
+        if (__ballot(dv)) { if (dv) { atomicAdd(&P.tie_ctr[7], 1ull); if (full_sum(my_e, dneg, eta0, etap, nullptr) != t_sum[tid]) atomicAdd(&P.tie_ctr[2], 1ull); } }
+        if (fallback) atomicAdd(&P.tie_ctr[6], 1ull); }
+#endif
+      __syncthreads();
+      if (tid == 0) {   // phase.rs:1117: strictly greater replaces; the first restart of the list is the first "best"
+        uint32_t j0 = 0;
+        if (cur == 0) { s_win = t_e[0]; s_winsum = t_sum[0]; j0 = 1; }
+        for (uint32_t j = j0; j < n; j++) if (t_sum[j] > s_winsum) { s_win = t_e[j]; s_winsum = t_sum[j]; }
       }
       __syncthreads();
     }
-    if (tid == 0) {   // phase.rs:1117: strictly greater replaces (equal signatures: equal sums, the earlier one stays)
-      uint32_t bj = 0;
-      if (s_differ) for (uint32_t j = 1; j < n; j++) if (t_sum[j] > t_sum[bj]) bj = j;
-      s_win = t_e[bj];
-      if (s_differ) { s_winsum = t_sum[bj]; s_have_sum = 1; }
-      // (equal signatures throughout: the best so far keeps its sum, known or not -- a later chunk that differs computes it)
-    }
-    __syncthreads();
   }
+#ifdef ENUM_PROF
+  if (tid == 0 && dif) atomicAdd(&P.tie_ctr[5], (unsigned long long)((long long)wall_clock64() - prof_t0));
+#endif
   // ---- the winner's state -> the region's result slots
   const uint32_t we = s_win;
   const unsigned long long m0 = ld_st(we, nk);
@@ -186,13 +454,49 @@ __device__ __forceinline__ void enum_resolve(const PhaseDev& P, const RegionDev&
   if (tid == 0) P.st_obj[slot] = best;
 }
 
-// tiles of restarts of regions whose per-lane share is <= CK entries (host decides).  Every restart stores its objective and
-// its final state; the tile that completes its region decides the winner (enum_resolve).
+// the f64 scores of the rows in `tm` (fixed-point ties at rows with a het entry; bit = row - r_a): q < qn of phase.rs:77-96, 845-858
+// -> flip
+__device__ __forceinline__ unsigned long long enum_tie_rows_f64(unsigned long long tm, const unsigned long long win, const uint32_t dneg, const uint32_t eta0,
+                                                             const uint32_t etap, const int r_a, const uint16_t* rp, const uint16_t* ent16, const double* lut) {
+  unsigned long long ft = 0;
+  while (tm) {
+    const int roff = __ffsll((long long)tm) - 1;
+    tm &= tm - 1;
+    const int row = r_a + roff;
+    const uint32_t sneg = (uint32_t)(win >> roff) & 1u;
+    double lp = 0.0, lm = 0.0;   // the running sums log_q2 (sigma = +1) and log_q3 (sigma = -1), entry order
+    const int x1 = rp[row + 1];
+    for (int x = rp[row]; x < x1; x += 4) {   // four entries per round trip: their words, then their table values, then the adds in order
+      uint32_t v[4]; double tp[4], tm4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = ent16[min(x + u, x1 - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t i = v[u] & 31u, pbit = (v[u] >> 5) & 1u, q = (v[u] >> 6) & 31u;
+        const uint32_t isHet = (eta0 >> i) & 1u;
+        const uint32_t mp = isHet ? (pbit ^ ((dneg >> i) & 1u)) : (((etap >> i) & 1u) ? pbit : pbit ^ 1u);
+        const uint32_t mm = isHet ? mp ^ 1u : mp;
+        tp[u] = lut[(mp ? 32u : 0u) + q]; tm4[u] = lut[(mm ? 32u : 0u) + q];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (x + u < x1) { lp += tp[u]; lm += tm4[u]; }
+    }
+    if (lp == lm) continue;   // q == qn: nothing to decide (the usual case: the het entries' terms pair up in place)
+    const double l1 = sneg ? lm : lp, l1n = sneg ? lp : lm;
+    const double den = lp + lm;
+    const double q = 1.0 - l1 / den, qn = 1.0 - l1n / den;
+    if (q < qn) ft |= 1ull << roff;
+  }
+  return ft;
+}
+
+// tiles of restarts of regions whose per-lane share is <= CK entries (host decides).  Every restart stores its objective and --
+// unless a better one is known already -- its final state and signature; k4_enum_resolve decides the winner afterwards.
 template <int CK>
 __global__ void __launch_bounds__(64 * ENUM_WAVES, 3)   // (three waves per SIMD: <= 168 VGPRs)
 k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uint32_t per, const int64_t* __restrict__ job_base,
             long long* __restrict__ job_obj, const int64_t* __restrict__ st_base, unsigned long long* __restrict__ st_words,
-            uint32_t* __restrict__ tiles_done) {
+            long long* __restrict__ region_best) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const EnumTile t = enum_tile_of(P, spans, n_spans, per, false);
   const RegionDev rd = P.reg[t.slot];
@@ -204,7 +508,7 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
   uint2* csr = (uint2*)(lds + L.csr);
   uint32_t* csc = (uint32_t*)(lds + L.csc);
   uint16_t* rp = (uint16_t*)(lds + L.rp); uint16_t* first_row = (uint16_t*)(lds + L.first_row);
-  uint8_t* qrow = lds + L.qrow;
+  uint16_t* ent16 = (uint16_t*)(lds + L.ent16);
   const int tid = threadIdx.x, nt = blockDim.x;
   const uint32_t c = enum_chunk(E);
   // ---- stage the region (once per workgroup)
@@ -241,7 +545,7 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
       const uint32_t meta = (uint32_t)P.pcol[rd.e_off + e] | (v & 32u) | (e + 1 == e1 ? 64u : 0u) | 128u;
       const uint2 w = wl2[v & 31u];
       csr[e] = make_uint2(w.x | (meta << 24), w.y | (roff << 24));
-      qrow[e] = (uint8_t)(v & 31u);
+      ent16[e] = (uint16_t)((meta & 63u) | ((v & 31u) << 6) | (e + 1 == e1 ? 0x800u : 0u));
     }
   }
   __syncthreads();
@@ -289,32 +593,10 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
   const uint32_t ne = t.ne;
   unsigned long long* const st_reg = st_words + st_base[t.slot];
   const uint32_t stw = enum_state_words((uint32_t)R);
-  uint32_t n_tie_f64 = 0, n_tie_flip = 0, n_dtie = 0, n_step = 0;   // census of this wave's restarts (lane 0 adds them up at the end)
-  // the f64 scores of the rows in `tm` (fixed-point ties at rows with a het entry): q < qn of phase.rs:77-96, 845-858 -> flip
-  auto tie_rows_f64 = [&](unsigned long long tm, const unsigned long long win, const uint32_t dneg, const uint32_t eta0, const uint32_t etap) -> unsigned long long {
-    unsigned long long ft = 0;
-    while (tm) {
-      const int roff = __ffsll((long long)tm) - 1;
-      tm &= tm - 1;
-      const int row = r_a + roff;
-      const uint32_t sneg = (uint32_t)(win >> roff) & 1u;
-      double lp = 0.0, lm = 0.0;   // the running sums log_q2 (sigma = +1) and log_q3 (sigma = -1), entry order
-      for (int x = rp[row]; x < rp[row + 1]; x++) {
-        const uint32_t m = csr[x].x >> 24, i = m & 31u, pbit = (m >> 5) & 1u;
-        const uint32_t isHet = (eta0 >> i) & 1u;
-        const uint32_t mp = isHet ? (pbit ^ ((dneg >> i) & 1u)) : (((etap >> i) & 1u) ? pbit : pbit ^ 1u);
-        const uint32_t mm = isHet ? mp ^ 1u : mp;
-        const uint32_t q = qrow[x];
-        lp += lut[(mp ? 32u : 0u) + q];
-        lm += lut[(mm ? 32u : 0u) + q];
-      }
-      const double l1 = sneg ? lm : lp, l1n = sneg ? lp : lm;
-      const double den = lp + lm;
-      const double q = 1.0 - l1 / den, qn = 1.0 - l1n / den;
-      if (q < qn) ft |= 1ull << roff;
-    }
-    return ft;
-  };
+  uint32_t n_tie_f64 = 0, n_tie_flip = 0, n_dtie = 0, n_step = 0, n_tie_unres = 0;   // census of this wave's restarts (lane 0 adds them up at the end)
+  // rows of a lane as bits of a mask: 32 bits in the register-resident form (the host sends a region there only if no lane owns
+  // more than 32 rows), 64 in the streaming form
+  using mask_t = typename std::conditional<(CK > 0), uint32_t, unsigned long long>::type;
   // one restart by this wave: its objective goes to job_obj[], its final state to st_words
   auto run_restart = [&](const uint32_t e_in) {
     const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_in);   // (wave-uniform: keep it in SGPRs)
@@ -337,10 +619,10 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
       // ---- sigma step (phase.rs:824-862)
       {
         const unsigned long long w0 = sgb[r_a >> 6], w1 = sgb[(r_a >> 6) + 1];
-        const unsigned long long win = wsh ? (w0 >> wsh) | (w1 << (64 - wsh)) : w0;
+        const mask_t win = (mask_t)(wsh ? (w0 >> wsh) | (w1 << (64 - wsh)) : w0);
         int alo = 0, ahi = 0;
         uint32_t uacc = 0;
-        unsigned long long fm = 0, tm = 0;
+        mask_t fm = 0, tm = 0;
         auto sig_one = [&](uint32_t v0, uint32_t v1) {
           const uint32_t m = v0 >> 24, i = m & 31u, roff = v1 >> 24;
           const uint32_t sneg = (uint32_t)(win >> roff);
@@ -353,9 +635,10 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
           const bool end = (m >> 6) & 1u;
           // sign of ahi * 2^23 + alo: fold alo's carry into ahi, the remainder is in [0, 2^23)
           const int top = ahi + (alo >> 23);
-          if (end && top < 0) fm |= 1ull << roff;
+          const mask_t bit = end ? (mask_t)1 << roff : (mask_t)0;
+          if (top < 0) fm |= bit;
           // A == B at a row with a het entry: the f64 scores decide (a row without one scores the same for both signs, term by term)
-          if (end && uacc && top == 0 && (alo & 0x7fffff) == 0) tm |= 1ull << roff;
+          if (uacc && (top | (alo << 9)) == 0) tm |= bit;
           alo = end ? 0 : alo; ahi = end ? 0 : ahi; uacc = end ? 0u : uacc;
         };
         if (CK > 0) {
@@ -377,16 +660,21 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
           }
         }
         const bool any = __ballot(fm != 0) != 0;   // a strict improvement (A < B somewhere)
-        if (__ballot(tm != 0)) {
-          n_tie_f64 += (uint32_t)__popcll(tm);
-          const unsigned long long ft = tie_rows_f64(tm, win, dneg, eta0, etap);
-          n_tie_flip += (uint32_t)__popcll(ft);
+#ifdef ENUM_ABL_NOTIE
+        tm = 0;
+#endif
+        if (P.tie_arith < 2) { if (tm) n_tie_unres += (uint32_t)__popcll((unsigned long long)tm); }
+        else if (__ballot(tm != 0)) {
+          n_tie_f64 += (uint32_t)__popcll((unsigned long long)tm);
+          const mask_t ft = (mask_t)enum_tie_rows_f64((unsigned long long)tm, (unsigned long long)win, dneg, eta0, etap, r_a, rp, ent16, lut);
+          n_tie_flip += (uint32_t)__popcll((unsigned long long)ft);
           fm |= ft;
           if (!any && __ballot(ft != 0)) n_step++;   // only tie flips: "no improvement" (check_new_haplotag's sums are not formed)
         }
         if (fm) {
-          atomicXor(&sgb[r_a >> 6], fm << wsh);
-          if (wsh && (fm >> (64 - wsh))) atomicXor(&sgb[(r_a >> 6) + 1], fm >> (64 - wsh));
+          const unsigned long long fm64 = (unsigned long long)fm;
+          atomicXor(&sgb[r_a >> 6], fm64 << wsh);
+          if (wsh && (fm64 >> (64 - wsh))) atomicXor(&sgb[(r_a >> 6) + 1], fm64 >> (64 - wsh));
         }
         wave_lds_sync();
         if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
@@ -466,33 +754,75 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
     }
     // objective (phase.rs:257-276) = sum over phase entries of fe + hit * w = sum_i (F_i + hits_i) over live SNPs
     const long long total = wave_sum_ll_dpp(obj_i);
+    // a restart below the best objective seen so far in this region can never win: neither signature nor state is kept
+    // (region_best: monotone, device-coherent; a stale smaller value only costs a store that is not needed)
+    const long long seen = __hip_atomic_load(&region_best[t.slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool keep = __builtin_amdgcn_readfirstlane((int)(total >= seen)) != 0;
+    if (total > seen && lane == 0) (void)__hip_atomic_fetch_max(&region_best[t.slot], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // signature of the final configuration: a hash of the match bits [p == x] of all entries -- what the f64 form of the
+    // objective (a running sum of LUT[match][q] over the entries in row order) depends on beside the matrix (enum_resolve)
+    unsigned long long sig = 0;
+    if (keep) {
+      const unsigned long long w0 = sgb[r_a >> 6], w1 = sgb[(r_a >> 6) + 1];
+      const mask_t win = (mask_t)(wsh ? (w0 >> wsh) | (w1 << (64 - wsh)) : w0);
+      unsigned long long hs = 0;
+      uint32_t word = 0; int nb = 0, widx = 0;
+      auto sig_bit = [&](uint32_t v0, uint32_t v1) {
+        const uint32_t m = v0 >> 24, i = m & 31u, roff = v1 >> 24, pbit = (m >> 5) & 1u;
+        const uint32_t sneg = (uint32_t)(win >> roff) & 1u;
+        const uint32_t match = ((eta0 >> i) & 1u) ? (pbit ^ sneg ^ ((dneg >> i) & 1u)) : (((etap >> i) & 1u) ? pbit : pbit ^ 1u);
+        word |= (match & (m >> 7)) << nb;
+        if (++nb == 32) { hs = mix64(hs ^ (word + (unsigned long long)(lane * 64 + widx + 1) * 0x9E3779B97F4A7C15ULL)); word = 0; nb = 0; widx++; }
+      };
+#ifdef ENUM_ABL_NOSIG
+      if (false) {
+#else
+      if (CK > 0) {
+#endif
+#pragma unroll
+        for (int x = 0; x < NREG; x++) {
+          if (x >= n_sig) break;
+          asm volatile("" : "+v"(re0[x]), "+v"(re1[x]));
+          sig_bit(re0[x], re1[x]);
+        }
+#ifdef ENUM_ABL_NOSIG
+      } else if (false) {
+#else
+      } else {
+#endif
+        for (int x0 = 0; x0 < n_sig; x0 += 4) {
+          uint2 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) v[u] = s0 + x0 + u < s1 ? csr[s0 + x0 + u] : make_uint2(0, 0);
+#pragma unroll
+          for (int u = 0; u < 4; u++) sig_bit(v[u].x, v[u].y);
+        }
+      }
+      if (nb) hs = mix64(hs ^ (word + (unsigned long long)(lane * 64 + widx + 1) * 0x9E3779B97F4A7C15ULL));
+      sig = (unsigned long long)wave_sum_ll((long long)hs);
+    }
     // (device-coherent stores: read by the region's last tile, possibly on another XCD)
     unsigned long long* stp = st_reg + (size_t)e * stw;
-    for (int k = lane; k < nk; k += 64) __hip_atomic_store(&stp[k], sgb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (keep) for (int k = lane; k < nk; k += 64) __hip_atomic_store(&stp[k], sgb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane == 0) {
-      __hip_atomic_store(&stp[nk], (unsigned long long)dneg | ((unsigned long long)eta0 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&stp[nk + 1], (unsigned long long)etap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (keep) {
+        __hip_atomic_store(&stp[nk], (unsigned long long)dneg | ((unsigned long long)eta0 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&stp[nk + 1], (unsigned long long)etap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&stp[nk + 2], sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       __hip_atomic_store(&job_obj[job_base[t.slot] + e], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     wave_lds_sync();
   };
   for (uint32_t kk = wave; kk < ne; kk += ENUM_WAVES) run_restart(t.e0 + kk);
+  n_tie_f64 = (uint32_t)wave_sum_ll((long long)n_tie_f64); n_tie_flip = (uint32_t)wave_sum_ll((long long)n_tie_flip); n_tie_unres = (uint32_t)wave_sum_ll((long long)n_tie_unres);   // (per-lane counts of the lanes' own rows)
   if (lane == 0) {
     if (n_tie_f64) atomicAdd(&P.tie_ctr[TIE_SIGMA_F64], (unsigned long long)n_tie_f64);
     if (n_tie_flip) atomicAdd(&P.tie_ctr[TIE_SIGMA_FLIPS], (unsigned long long)n_tie_flip);
+    if (n_tie_unres) atomicAdd(&P.tie_ctr[TIE_SIGMA_UNRES], (unsigned long long)n_tie_unres);
     if (n_dtie) atomicAdd(&P.tie_ctr[TIE_DELTA_UNRES], (unsigned long long)n_dtie);
     if (n_step) atomicAdd(&P.tie_ctr[TIE_STEP_UNRES], (unsigned long long)n_step);
   }
-  // The tile that completes its region decides the winner (`prob > largest_prob`, phase.rs:1113-1119) from the objectives and
-  // states all tiles stored device-coherently; every wave's stores are acknowledged before the barrier that lets thread 0
-  // count the tile.  The matrix is still staged here.
-  __shared__ uint32_t s_last;
-  __syncthreads();
-  const uint32_t n_jobs = 1u << S;
-  if (tid == 0) s_last = atomicAdd(&tiles_done[t.slot], 1u) == (n_jobs + per - 1) / per - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  enum_resolve(P, rd, t.slot, lds, L, E, job_obj + job_base[t.slot], st_reg, n_jobs);
 }
 
 // the same tiles for regions whose matrix does not fit the LDS budget: one restart at a time per workgroup
@@ -548,10 +878,15 @@ __global__ void __launch_bounds__(64) k4_enum_pick(const EnumSpan* __restrict__ 
 }  // namespace
 
 void launch_k4_enum_reg(int ck, unsigned n_blocks, size_t dyn_lds, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, int32_t n_spans,
-                        uint32_t per, const int64_t* job_base, long long* job_obj, const int64_t* st_base, unsigned long long* st_words, uint32_t* done) {
+                        uint32_t per, const int64_t* job_base, long long* job_obj, const int64_t* st_base, unsigned long long* st_words,
+                        long long* region_best) {
   const dim3 blk(64 * ENUM_WAVES);
-  if (ck == 32) hipLaunchKernelGGL(k4_enum_reg<32>, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, done);
-  else hipLaunchKernelGGL(k4_enum_reg<0>, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, done);
+  if (ck == 32) hipLaunchKernelGGL(k4_enum_reg<32>, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, region_best);
+  else hipLaunchKernelGGL(k4_enum_reg<0>, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, region_best);
+}
+void launch_k4_enum_resolve(unsigned n_regions, size_t dyn_lds, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, const int64_t* job_base,
+                            const long long* job_obj, const int64_t* st_base, const unsigned long long* st_words) {
+  hipLaunchKernelGGL(k4_enum_resolve, dim3(n_regions), dim3(64 * ENUM_WAVES), dyn_lds, s, P, spans, job_base, job_obj, st_base, st_words);
 }
 void launch_k4_enum_big(unsigned n_blocks, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, int32_t n_spans, uint32_t per,
                         const int64_t* job_base, long long* job_obj, const uint32_t* win_e) {

@@ -13,12 +13,13 @@ constexpr uint32_t ENUM_TILE_JOBS = 16;
 constexpr uint32_t ENUM_LDS_BYTES = 48 * 1024;
 
 // LDS image: wl2[32] {lo23, hi24 (signed)} | lut64[64] (log10 eps_q, log10 (1 - eps_q): the f64 tie path) | csr[E] {lo | meta << 24,
-//            hi | row_in_lane << 24} | csc[E] | rp[R+1] u16 | first_row[65] u16 | qrow[E] u8 (q of the entries in row order) |
-//            per wave: sigma bits (u64 words, +1 pad) and M[32] | scratch of the region's last tile (enum_resolve)
+//            hi | row_in_lane << 24} | csc[E] | rp[R+1] u16 | first_row[65] u16 | ent16[E] (row-order entries of the f64 tie paths) |
+//            per wave: sigma bits (u64 words, +1 pad) and M[32]
 //   csr meta : bits 0-4 SNP, 5 allele (1: p == +1), 6 last entry of its row, 7 valid
 //   csc      : bits 0-15 row, 16-20 SNP, 21 allele, 22-26 q, 31 valid
-constexpr uint32_t ENUM_TCAP = 128;   // configurations of maximal objective compared at a time (enum_resolve)
-struct EnumLayout { uint32_t lut, csr, csc, rp, first_row, qrow, state, stride, res, total; };
+//   ent16    : bits 0-4 SNP, 5 allele, 6-10 q, 11 last entry of its row
+constexpr uint32_t ENUM_TCAP = 256;   // configurations of maximal objective compared at a time (enum_resolve): a lane each
+struct EnumLayout { uint32_t lut, csr, csc, rp, first_row, ent16, state, stride, total; };
 __host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E) {
   EnumLayout L;
   uint32_t o = 256;
@@ -27,24 +28,50 @@ __host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E) {
   L.csc = o; o += 4 * E;
   L.rp = o; o += 2 * (R + 1);
   L.first_row = o; o += 2 * 65;
-  L.qrow = o; o += E;
+  o = (o + 7) & ~7u;
+  L.ent16 = o; o += 2 * ((E + 3) & ~3u);
   o = (o + 15) & ~15u;
   L.state = o;
   L.stride = 8 * ((R + 63) / 64 + 1) + 8 * 32;
   o += ENUM_WAVES * L.stride;
-  L.res = o; o += ENUM_TCAP * 24;      // per compared configuration: restart, signature, f64 objective
   L.total = o;
   return L;
 }
-// words of one restart's saved final state: sigma bits | delta, eta == 0 masks | eta == +1 mask
-__host__ __device__ inline uint32_t enum_state_words(uint32_t R) { return (R + 63) / 64 + 2; }
+// words of one restart's saved final state: sigma bits | delta, eta == 0 masks | eta == +1 mask | signature of its term sequence
+__host__ __device__ inline uint32_t enum_state_words(uint32_t R) { return (R + 63) / 64 + 3; }
+// LDS image of k4_enum_resolve (one workgroup per region): table | rp u16 | ent16 | pse f64[E + 8] | sigma words of the reference
+// configuration | rows with a het entry | rows by first het site [S][nk] | per compared configuration: restart, f64 objective |
+// events of the reference's chain
+struct ResolveLayout { uint32_t lut, rp, ent16, pse, sg_ref, hetw, repmask, rowsnps, res, total; };
+__host__ __device__ inline ResolveLayout resolve_layout(uint32_t R, uint32_t E, uint32_t S) {
+  ResolveLayout L;
+  const uint32_t nk = (R + 63) / 64;
+  uint32_t o = 0;
+  L.lut = o; o += 512;
+  L.rp = o; o += 2 * (R + 2);
+  o = (o + 7) & ~7u;
+  L.ent16 = o; o += 2 * ((E + 7) & ~7u);
+  o = (o + 15) & ~15u;
+  L.pse = o; o += 8 * ((E + 8) & ~7u);
+  L.sg_ref = o; o += 8 * (nk + 1);
+  L.hetw = o; o += 8 * (nk + 1);
+  L.repmask = o; o += 8 * nk * (S ? S : 1);
+  L.rowsnps = o; o += 4 * (R + 1);        // the SNPs of a row's entries as a mask
+  o = (o + 7) & ~7u;
+  L.res = o; o += ENUM_TCAP * 16 + 96 * 10 + 16 + 2 * 2048;   // + the list of the restarts of maximal objective
+  L.total = (o + 15) & ~15u;
+  return L;
+}
 // lane l owns the rows whose first entry index lies in [l*c, (l+1)*c), c = ceil(E / 64)
 __host__ __device__ inline uint32_t enum_chunk(uint32_t E) { return E ? (E + 63) / 64 : 1; }
 
 // CK = 32 | 0: k4_enum_reg<CK> (the per-lane share of the region's entries held in registers; 0 = streamed from LDS)
 // st_base[slot]: first word of the region's 2^S saved states in st_words
 void launch_k4_enum_reg(int ck, unsigned n_blocks, size_t dyn_lds, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, int32_t n_spans,
-                        uint32_t per, const int64_t* job_base, long long* job_obj, const int64_t* st_base, unsigned long long* st_words, uint32_t* done);
+                        uint32_t per, const int64_t* job_base, long long* job_obj, const int64_t* st_base, unsigned long long* st_words,
+                        long long* region_best /* per region, far below any objective before the launch */);
+void launch_k4_enum_resolve(unsigned n_regions, size_t dyn_lds, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, const int64_t* job_base,
+                            const long long* job_obj, const int64_t* st_base, const unsigned long long* st_words);
 void launch_k4_enum_big(unsigned n_blocks, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, int32_t n_spans, uint32_t per,
                         const int64_t* job_base, long long* job_obj, const uint32_t* win_e);
 void launch_k4_enum_pick(int32_t n, hipStream_t s, const EnumSpan* spans, const RegionDev* reg, const int64_t* job_base, const long long* job_obj,

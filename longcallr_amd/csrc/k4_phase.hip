@@ -440,7 +440,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   PCHK(d_lut64.reserve(sizeof(PostLut))); PCHK(d_tie.reserve(TIE_NCTR * 8)); PCHK(h_pin[11].reserve(TIE_NCTR * 8));
   if (!lut64_ready) { PCHK(hipMemcpyAsync(d_lut64.p, &plut, sizeof(PostLut), hipMemcpyHostToDevice, stream)); PCHK(hipStreamSynchronize(stream)); lut64_ready = true; }
   PCHK(hipMemsetAsync(d_tie.p, 0, TIE_NCTR * 8, stream));   // (before ev_in: every queue of this call starts behind it)
-  P.lut64 = d_lut64.as<PostLut>(); P.tie_ctr = d_tie.as<unsigned long long>();
+  P.lut64 = d_lut64.as<PostLut>(); P.tie_ctr = d_tie.as<unsigned long long>(); P.tie_arith = dbg.tie_arith;
 
   // enumeration (S <= max_enum_snps) and chain regions
   std::vector<int32_t> enum_slots, chain_slots;
@@ -674,7 +674,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     const uint32_t per_of[NCLS] = {1u, 1u, ENUM_TILE_JOBS, 2u * ENUM_WAVES, 1u};
     std::vector<int64_t> job_base(ng, 0), st_base(ng, 0);   // st_base: first word of the region's saved restart states (classes 2 / 3)
     int64_t nj = 0, st_words = 0;
-    uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0};
+    uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0}, res_lds[NCLS] = {0, 0, 0, 0, 0};   // (res_lds: k4_enum_resolve's image of the class's largest region)
     std::vector<int32_t> post_slots;   // enumeration regions with the device epilogue
     for (int g : enum_slots) {
       const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
@@ -682,8 +682,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       const EnumLayout EL = enum_layout(st.R, st.E);
       int cls = 4;
       if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_BYTES && st.max_rows <= 64)
-        cls = force_stream ? 3 : (st.max_n <= 32 ? 2 : 3);   // (the 8 / 16 instantiations: one launch has one tail; a 40-entry one: below)
-      if (cls < 4) lds_need[cls] = std::max(lds_need[cls], EL.total);
+        cls = force_stream ? 3 : (st.max_n <= 32 && st.max_rows <= 32 ? 2 : 3);   // (register-resident form: <= 32 entries and <= 32 rows per lane)   // (the 8 / 16 instantiations: one launch has one tail; a 40-entry one: below)
+      if (cls < 4) { lds_need[cls] = std::max(lds_need[cls], EL.total); res_lds[cls] = std::max(res_lds[cls], resolve_layout((uint32_t)st.R, (uint32_t)st.E, (uint32_t)S).total); }
       job_base[g] = nj;
       const uint64_t n = 1ull << S;
       if (cls < 4) { st_base[g] = st_words; st_words += (int64_t)n * enum_state_words((uint32_t)st.R); }
@@ -702,7 +702,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     const size_t up_bytes = off_sb + (size_t)ng * 8 + (ns + nps) * 4;
     PCHK(d_enum_st.reserve((size_t)std::max<int64_t>(st_words, 1) * 8));
     PCHK(b_job.reserve(up_bytes + 64));
-    PCHK(b_obj.reserve((size_t)nj * 8 + (size_t)ng * 8 + 64));   // objectives | winners | tiles done
+    PCHK(b_obj.reserve((size_t)nj * 8 + (size_t)ng * 8 + (size_t)ng * 8 + 64));   // objectives | winners | tiles done | best objective seen per region
     PCHK(h_pin[8].reserve(up_bytes + 64));   // pinned: the upload is queued, not staged
     uint8_t* const up = h_pin[8].as<uint8_t>();
     for (int k = 0; k < NCLS; k++) memcpy(up + s_off[k] * sizeof(EnumSpan), spans[k].data(), n_w[k] * sizeof(EnumSpan));
@@ -722,17 +722,24 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(b_scr.reserve((size_t)stride * n_big_blocks + 64));
     P.scratch = b_scr.as<int8_t>();
     // the classes touch disjoint regions: class 2 on `stream`, classes 3 / 4 beside it on `aux` (their tails overlap)
-    // (d_done: tiles finished per region -- the last tile of a region picks its winner and re-runs it, classes 2 / 3)
-    uint32_t* const d_done = d_win + ng;
-    PCHK(hipMemsetAsync(d_done, 0, (size_t)ng * 4, stream));
+    long long* const d_rbest = (long long*)(d_win + 2 * (size_t)ng);   // (8-byte aligned: behind the 2 x 4 x ng bytes of winners | tiles done)
+    PCHK(hipMemsetAsync(d_rbest, 0x80, (size_t)ng * 8, stream));        // 0x8080...: far below any objective
     auto launch = [&](const size_t* cnt, const uint32_t* win) -> hipError_t {
-      uint32_t* const done = win ? nullptr : d_done;
       const bool fork = cnt[2] && (cnt[3] || cnt[4]);
       hipStream_t s34 = fork ? aux : stream;
       hipError_t e = hipSuccess;
       if (fork) { if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e; }
-      if (cnt[2]) launch_k4_enum_reg(32, (unsigned)cnt[2], lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), done);
-      if (cnt[3]) launch_k4_enum_reg(0, (unsigned)cnt[3], lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), done);
+      // classes 2 / 3: all restarts, then `prob > largest_prob` over each region's restarts from the objectives, signatures and
+      // states they left (phase.rs:1113-1119; ties between configurations of maximal objective by their f64 sums) -- a workgroup
+      // per region, each class's behind its own restarts (the streaming class's regions are resolved under the other's restarts)
+      if (cnt[2]) {
+        launch_k4_enum_reg(32, (unsigned)cnt[2], lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), d_rbest);
+        if (!win) launch_k4_enum_resolve((unsigned)n_w[2], res_lds[2], stream, P, d_sp + s_off[2], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());
+      }
+      if (cnt[3]) {
+        launch_k4_enum_reg(0, (unsigned)cnt[3], lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), d_rbest);
+        if (!win) launch_k4_enum_resolve((unsigned)n_w[3], res_lds[3], s34, P, d_sp + s_off[3], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());
+      }
       if (cnt[4]) launch_k4_enum_big((unsigned)cnt[4], s34, P, d_sp + s_off[4], (int32_t)n_w[4], per_of[4], d_jb, d_obj, win);
       if (fork) { if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e; }
       return e;

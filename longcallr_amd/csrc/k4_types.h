@@ -29,6 +29,8 @@ struct PhaseDev {
   // lut64 = the host's libm values of log10(eps_q), log10(1 - eps_q); tie_ctr = the census of the ties met (TIE_* below)
   const struct PostLut* lut64;
   unsigned long long* tie_ctr;
+  int32_t tie_arith;   // 0: fixed point only (ties change nothing), 1: + configurations of equal objective by their f64 sums, 2: + sigma ties by the f64 scores
+  int32_t pad_;
 };
 // census of exact fixed-point ties of one lcr_phase call (lcr_get_tie_census): the RESOLVED classes follow the reference's f64
 // arithmetic; an UNRESOLVED count other than zero means a decision fell to "a tie changes nothing" where the reference's f64

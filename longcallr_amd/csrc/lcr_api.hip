@@ -853,6 +853,7 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
   else if (k == "enum_force_big") d.enum_force_big = (int)value;
   else if (k == "enum_force_stream") d.enum_force_stream = (int)value;
   else if (k == "host_threads") d.host_threads = (int)value;
+  else if (k == "tie_arith") d.tie_arith = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2));
   else if (k == "hist_tiles") c->dbg_hist_tiles = value > 0 ? 1 : value < 0 ? -1 : 0;
   else if (k == "grid_spec_lanes") d.spec_lanes = (int)std::max<int64_t>(1, std::min<int64_t>(value, 16));
   else { c->err = "lcr_debug_set: unknown key " + k; return LCR_E_ARG; }
