@@ -2,6 +2,7 @@
 // region / matrix descriptors, the one-workgroup cross_optimize (phase.rs:810-976), wave and workgroup scans.
 // Plain kernel-argument structs are global types; functions live in an anonymous namespace (one copy per translation unit, no RDC).
 #pragma once
+#include <climits>
 #include "lcr_phase_host.h"   // (pulls in k4_types.h)
 
 namespace {
@@ -23,6 +24,44 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
   return v;
+}
+
+// A sigma decision whose fixed-point sums tie exactly (A == B): the reference-order f64 scores of the row decide
+// (cal_sigma_delta_eta_log, phase.rs:77-96: the three running sums over the row's entries in list order, q = 1 - log_q1 /
+// (log_q2 + log_q3); flip iff q < qn, phase.rs:845-858).  le / l1e = the host's libm values of log10(eps_q), log10(1 - eps_q).
+// *het: the row has an entry at a het site (a row without one scores the same for both signs, term by term: no census entry).
+__device__ __forceinline__ bool tie_row_flips(const int32_t* rp, const int32_t* pc, const uint8_t* pv, int row, const int8_t* dl, const int8_t* et,
+                                              int sigma, const double* le, const double* l1e, bool* het) {
+  double lp = 0.0, lm = 0.0;   // log_q2 (sigma = +1), log_q3 (sigma = -1)
+  bool h = false;
+  for (int e = rp[row]; e < rp[row + 1]; e++) {
+    const int i = pc[e];
+    const uint8_t v = pv[e];
+    const int p = (v & 32) ? 1 : -1, q = v & 31, eta = et[i], d = dl[i];
+    const int xp = eta == 0 ? d : eta, xm = eta == 0 ? -d : eta;   // x of aki for sigma = +1 / -1 (phase.rs:32-49)
+    h |= eta == 0;
+    lp += p == xp ? l1e[q] : le[q];
+    lm += p == xm ? l1e[q] : le[q];
+  }
+  *het = h;
+  if (!h || lp == lm) return false;
+  const double l1 = sigma == 1 ? lp : lm, l1n = sigma == 1 ? lm : lp, den = lp + lm;
+  const double q = 1.0 - l1 / den, qn = 1.0 - l1n / den;
+  return q < qn;
+}
+// census + decision of one tied row (all sigma-step forms): true = flip
+__device__ __forceinline__ bool tie_row_decide(const PhaseDev& P, const int32_t* rp, const int32_t* pc, const uint8_t* pv, int row, const int8_t* dl,
+                                               const int8_t* et, int sigma, const double* le, const double* l1e) {
+  bool het;
+  if (P.tie_arith < 2) {
+    het = false;
+    for (int e = rp[row]; e < rp[row + 1]; e++) het |= et[pc[e]] == 0;
+    if (het) atomicAdd(&P.tie_ctr[TIE_SIGMA_UNRES], 1ull);
+    return false;
+  }
+  const bool f = tie_row_flips(rp, pc, pv, row, dl, et, sigma, le, l1e, &het);
+  if (het) { atomicAdd(&P.tie_ctr[TIE_SIGMA_F64], 1ull); if (f) atomicAdd(&P.tie_ctr[TIE_SIGMA_FLIPS], 1ull); }
+  return f;
 }
 
 // one cross_optimize (phase.rs:810-976); returns the exact objective (phase.rs:257-276) to all threads.
@@ -91,6 +130,7 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
   const uint8_t* fp = mv.fp;
   const uint8_t* cons = mv.cons;
   const long long* sc = snp_const_lds ? snp_const_lds : P.snp_const + 4ll * rd.snp_off;   // (read in every delta step)
+  const double* const le64 = P.lut64->le; const double* const l1e64 = P.lut64->l1e;   // (the f64 tie path: rare, from global memory)
   bool hg_inc = true, h_inc = true;
   int iters = 0;
   long long tk0 = prof ? (long long)wall_clock64() : 0;
@@ -167,6 +207,12 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
       });
       __syncthreads();
       tick(1);
+      // rows whose sums tie exactly: the f64 scores decide (before the delta sweep takes the rows' new sigma from the signs)
+      {
+        for (int row = tid; row < rd.R; row += blockDim.x)
+          if (racc[row] == 0ull && rp[row + 1] > rp[row] && tie_row_decide(P, rp, pc, pv, row, dl, et, sg[row], le64, l1e64)) racc[row] = 0x8000000000000000ull;   // (the marker of a tie flip: negative, and no sum of table values)
+      }
+      __syncthreads();
       {
         long long M = 0;
         int mi = -1;
@@ -182,7 +228,7 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
       for (int row = tid; row < rd.R; row += blockDim.x) {
         const long long diff = (long long)racc[row];
         racc[row] = 0;
-        if (diff < 0) { sg[row] = (int8_t)(-sg[row]); chg |= 1; }
+        if (diff < 0) { sg[row] = (int8_t)(-sg[row]); if (diff != LLONG_MIN) chg |= 1; }   // (LLONG_MIN: the marker of a tie flip -- not an improvement)
       }
       long long tsum = 0;
       for (int i = tid; i < rd.S; i += blockDim.x) {
@@ -231,6 +277,7 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
         if (et[i] == 0) { const long long w = wl[v & 31]; diff += (((v & 32) ? 1 : -1) == s * dl[i]) ? w : -w; }
       }
       if (diff < 0) { sg[row] = (int8_t)(-s); any = 1; }
+      else if (diff == 0 && rp[row + 1] > rp[row] && tie_row_decide(P, rp, pc, pv, row, dl, et, s, le64, l1e64)) sg[row] = (int8_t)(-s);   // (Jacobi: a row reads its own sigma only)
     }
     any = __syncthreads_or(any);
     tick(2);

@@ -361,6 +361,7 @@ __device__ __forceinline__ long long cross_optimize_scope(GridScope& sc, const P
         if (et[i] == 0) { const long long w = wl[x & 31]; diff += (((x & 32) ? 1 : -1) == s * dl[i]) ? w : -w; }
       }
       if (diff < 0) { sg[row] = (int8_t)(-s); any = 1; }
+      else if (diff == 0 && rp[row + 1] > rp[row] && tie_row_decide(P, rp, pc, pv, row, dl, et, s, P.lut64->le, P.lut64->l1e)) sg[row] = (int8_t)(-s);
     }
     any = sc.sync_or(any);
     if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
@@ -643,7 +644,7 @@ template <class T> __device__ __forceinline__ T cload(const T* p) { return __hip
 template <class T> __device__ __forceinline__ void cstore(T* p, T x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev& C, const RegionDev& rd, const ChainView& v, const long long* wl,
-                                  uint8_t* dyn, long long best, int slot) {
+                                  uint8_t* dyn, long long best, int slot, const FlipLut& FL) {
   const int S = rd.S, R = rd.R, lane = threadIdx.x & 63;
   const int ng = (R + 63) >> 6;                         // 64-row groups
   unsigned long long* wsw0 = C.sig_words + 2 * ((int64_t)(rd.sig_off >> 6) + slot);   // working sigma words (sequential form)
@@ -693,6 +694,8 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
   __shared__ unsigned long long t_sum[4][8];   // delta step: partial sums / arrivals of the four-wave teams
   __shared__ long long rsum_all[CH_THREADS / 64][32];   // sigma step: row sums of the unit a wave is working on
   long long* const rsum = rsum_all[threadIdx.x >> 6];
+  __shared__ uint32_t rhet_all[CH_THREADS / 64];        // ... and which of its rows have an entry at a het site
+  uint32_t* const rhet = &rhet_all[threadIdx.x >> 6];
   __shared__ unsigned t_cnt[4][8];
   if (threadIdx.x < 32) { t_sum[threadIdx.x >> 3][threadIdx.x & 7] = 0; t_cnt[threadIdx.x >> 3][threadIdx.x & 7] = 0; }
   // ---- delta step order: SNPs by column length, dealt to the teams in serpentine order (longest to team 0, 1, .. T-1,
@@ -748,7 +751,9 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
             const int ub = __shfl(ub_l, k, 64), ue = __shfl(ue_l, k, 64);
             const uint32_t sbits = (uint32_t)__shfl((int)sb_l, k, 64);   // sigma of the unit's rows
             if (lane < 32) rsum[lane] = 0;
+            if (lane == 0) *rhet = 0;
             wave_lds_sync();
+            uint32_t hm = 0;
             auto run4 = [&](const uint4& t, int e) {
               const uint32_t en[4] = {t.x, t.y, t.z, t.w};
               long long acc = 0; uint32_t cur = 32u;
@@ -759,6 +764,7 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
                   if (rid != cur) { if (cur < 32u && acc) atomicAdd(reinterpret_cast<unsigned long long*>(&rsum[cur]), (unsigned long long)acc); cur = rid; acc = 0; }
                   // +w when the entry's allele equals sigma * delta, -w when not, nothing at a hom site: the three signs as bits
                   const int t = s_de[i];
+                  hm |= (uint32_t)(t != 0) << rid;
                   const long long w = wl[x & 31];
                   const uint32_t neg = ((x >> 5) ^ (sbits >> rid) ^ ((uint32_t)t >> 31)) & 1u;
                   acc += t == 0 ? 0ll : ((neg | (uint32_t)(t == 2)) ? -w : w);
@@ -774,14 +780,22 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
               for (int q = 0; q < 4; q++) { const int e = ub + 4 * lane + 256 * q; if (e < ue) run4(t4[q], e); }
               for (int e = ub + 4 * lane + 1024; e < ue; e += 256) run4(*reinterpret_cast<const uint4*>(pkr + e), e);
             }
+            if (hm) atomicOr(rhet, hm);
             wave_lds_sync();
             const long long diff = lane < 32 ? rsum[lane] : 0;
-            const unsigned long long fb = __ballot(lane < 32 && diff < 0);
-            wave_lds_sync();
-            if (fb) {
-              any = 1;
-              if (lane == 0) cstore(reinterpret_cast<uint32_t*>(&wsw[j]) + (u & 1), sbits ^ (uint32_t)fb);   // (this unit's half of the word)
+            unsigned long long fb = __ballot(lane < 32 && diff < 0);
+            if (fb) any = 1;
+            // rows whose sums tie exactly, with an entry at a het site: the reference-order f64 scores decide (a lane per row;
+            // a few dozen rows per step on C5)
+            const uint32_t tmask = (uint32_t)__ballot(lane < 32 && diff == 0 && 32 * u + lane < R) & *rhet;
+            if (tmask) {
+              bool tf = false;
+              if (lane < 32 && ((tmask >> lane) & 1u))
+                tf = tie_row_decide(C.P, rp, v.mv.pc, v.mv.pv, 32 * u + lane, s_dl, s_et, ((sbits >> lane) & 1u) ? 1 : -1, FL.le, FL.l1e);
+              fb |= __ballot(tf);
             }
+            wave_lds_sync();
+            if (fb && lane == 0) cstore(reinterpret_cast<uint32_t*>(&wsw[j]) + (u & 1), sbits ^ (uint32_t)fb);   // (this unit's half of the word)
           }
         }
       }
@@ -1054,7 +1068,7 @@ __global__ void __launch_bounds__(CH_THREADS) k4_chain_grid(ChainDev C, int32_t 
   extern __shared__ __attribute__((aligned(16))) uint8_t dyn_fast[];
   auto fast_rounds = [&](long long best) -> bool {
     if (!d.fast_lds || !C.pk_csr || (int64_t)v.mv.cp[rd.S] > C.pk_cap || rd.S >= (1 << 18)) return false;
-    return chain_rounds_fast(sc, C, rd, v, wl, dyn_fast, best, d.slot);
+    return chain_rounds_fast(sc, C, rd, v, wl, dyn_fast, best, d.slot, L);
   };
   chain_run(sc, C, rd, v, wl, L, stage, sm, cross, fast_rounds, d.slot);
 }

@@ -1307,6 +1307,8 @@ struct orc_region {
   void phase(int mode) {
     ctr = 0;
     for (int i = 0; i < 10; i++) census[i] = 0;
+    const int tie_mask_all = tie_mask;   /* bit 16: bits 8-15 are the mask of the chain branch (S > max_enum_snps) */
+    if (tie_mask_all & 0x10000) tie_mask = cands.size() <= prm.max_enum_snps ? (tie_mask_all & 255) : ((tie_mask_all >> 8) & 255);
     if (fast_threads) build_phase_index();
     for (auto& c : cands) c.haplotype = rnd() < 0.5 ? 1 : -1; /* init_haplotypes, phase.rs:443-448 */
     init_assignment();
@@ -1373,6 +1375,7 @@ struct orc_region {
       load_best(best);
     }
     best_objective = largest_prob;
+    tie_mask = tie_mask_all;
   }
 
   /* ---------- P14: assign_reads_haplotype (snpfrags.rs:548-625) ---------- */

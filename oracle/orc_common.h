@@ -78,7 +78,8 @@ void orc_post_phase(orc_region*); /* thread.rs:168-201 (snpfrags.rs:191-733)    
  * phase.rs:859-862,943-946) on n_threads threads; every f64 sum keeps its order.  0 (default) = the structure-faithful
  * gathers (what bench.py's cpu_baseline times).  Equality of the two forms is a test (tests/test_oracle_batch.py). */
 void orc_set_fast(orc_region*, int n_threads);
-void orc_set_tie_mask(orc_region*, int mask);   /* ORC_MODE_TIE: which tie classes the f64 scores resolve (default 15) */
+void orc_set_tie_mask(orc_region*, int mask);   /* ORC_MODE_TIE: which tie classes the f64 scores resolve (default 15); mask | chain_mask << 8 | 1 << 16
+                                                 * gives the chain branch (S > max_enum_snps) a mask of its own */
 /* tie census of the last orc_phase (any mode that evaluates the fixed-point sums): [0] sigma decisions with A == B,
  * [1] delta/eta decisions with a tie at the maximum, [2] steps whose only changes were tie changes, [3] best-configuration
  * compares at equal fixed-point objective, [4..7] the same four counted only where the f64 scores then decide differently

@@ -124,11 +124,11 @@ def test_vcf_formatter_matches_oracle_text(orc):
     """longcallr_amd.vcf (product formatter) on oracle candidates == the oracle's own text."""
     from longcallr_amd import vcf
     p = _abi.make_params("hifi-masseq")
-    R = orc.Region(helpers.demo_batch(), 0, p).run_all(orc.MODE_EXACT)
+    R = orc.Region(helpers.demo_batch(), 0, p).set_tie_mask(orc.TIE_MASK_LIBLCR).run_all(orc.MODE_TIE)
     assert vcf.format_records(R.cands(), "chr20", p.min_phase_score) == R.vcf_text("chr20")
     b = synth.make_batch("ont-drna", n_genes=1, gene_len=12000, depth=30, seed=2)
     p = _abi.make_params("ont-drna")
-    R = orc.Region(b, 0, p).run_all(orc.MODE_EXACT)
+    R = orc.Region(b, 0, p).set_tie_mask(orc.TIE_MASK_LIBLCR).run_all(orc.MODE_TIE)
     assert vcf.format_records(R.cands(), "c", p.min_phase_score) == R.vcf_text("c")
 
 

@@ -13,6 +13,8 @@ if which == "small":
     b, preset = synth.make_batch("ont-cdna", n_genes=24, gene_len=12000, depth=40, seed=5), "ont-cdna"
 elif which == "drna":
     b, preset = synth.make_batch("ont-drna", n_genes=24, gene_len=20000, depth=45, seed=31), "ont-drna"
+elif which == "island":
+    b, preset = synth.make_island("ont-drna-c5", n_loci=4, locus_len=25000, depth=200, seed=3), "ont-drna"
 else:
     b, preset = bench.build_workload(which), ("ont-cdna" if which == "c3" else "hifi-masseq")
 p = _abi.make_params(preset, seed=2025)
@@ -37,6 +39,6 @@ for name, kw in modes.items():
             bad.append(g)
     cen = O.tie_census()
     en = S <= p.max_enum_snps
-    print("%-8s regions differing from HIP: %d %s (enum %d, chain %d) | oracle census enum regions: sigma ties w/ het %d flips %d delta ties %d tie-only steps %d best-pick f64 %d | chain regions: sigma ties w/ het %d flips %d"
-          % (name, len(bad), bad[:12], sum(1 for g in bad if en[g]), sum(1 for g in bad if not en[g]), cen[en, 8].sum(), cen[en, 4].sum(), cen[en, 1].sum(), cen[en, 2].sum(), cen[en, 7].sum(), cen[~en, 8].sum(), cen[~en, 4].sum()))
+    print("%-8s regions differing from HIP: %d %s (enum %d, chain %d) | oracle census enum regions: sigma ties w/ het %d flips %d delta ties %d tie-only steps %d best-pick f64 %d | chain regions: sigma ties w/ het %d flips %d equal-objective compares %d (f64 greater %d)"
+          % (name, len(bad), bad[:12], sum(1 for g in bad if en[g]), sum(1 for g in bad if not en[g]), cen[en, 8].sum(), cen[en, 4].sum(), cen[en, 1].sum(), cen[en, 2].sum(), cen[en, 7].sum(), cen[~en, 8].sum(), cen[~en, 4].sum(), cen[~en, 3].sum(), cen[~en, 7].sum()))
     O.close()
