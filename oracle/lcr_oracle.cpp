@@ -13,6 +13,7 @@
 #include "orc_common.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cassert>
 #include <chrono>
@@ -1107,37 +1108,69 @@ struct orc_region {
       /* sigma step, phase.rs:824-862 */
       std::map<int, int> tmp_haplotag;
       double logp = 0.0, pre_logp = 0.0; bool any_strict = false, any_tie_change = false;
-      if (fast_threads)   /* Jacobi: every row is scored against the old state (phase.rs:859-862) -- independent */
-        par_for(nf, 512, [&](int64_t k) {
-          rdec[k] = RowDec();
-          if (!frags[k].for_phasing || frags[k].haplotag == 0) return;
-          RowView dummy; row_scores((int)k, use_fx, use_f64, dummy, rdec[k]);
-        });
-      for (int k = 0; k < nf; k++) {
-        if (!frags[k].for_phasing || frags[k].haplotag == 0) continue;
+      /* one row's decision from its scores: new haplotag, the two terms of check_new_haplotag's sums, counters */
+      struct RowOut { bool has = false, strict = false, tiechg = false; int newtag = 0; double q_old = 0.0, q_new = 0.0; int c[5] = {0, 0, 0, 0, 0}; };
+      auto row_decide = [&](int k, const RowDec& d) -> RowOut {
+        RowOut o;
+        if (!d.has) return o;
+        o.has = true;
         const int sigma_k = frags[k].haplotag;
-        RowDec d;
-        if (fast_threads) d = rdec[k]; else row_scores(k, use_fx, use_f64, rv, d);
-        if (!d.has) continue;
         const bool flip_f64 = d.q < d.qn, flip_fx = d.A < d.B;
-        if (both && flip_f64 != flip_fx) stats[2]++;
+        if (both && flip_f64 != flip_fx) o.c[4] = 1;   /* stats[2] */
         bool flip = by_fx ? flip_fx : flip_f64;
         if (use_fx && d.A == d.B) {
-          census[0]++; if (flip_f64) census[4]++;
+          o.c[0] = 1; if (flip_f64) o.c[1] = 1;         /* census[0], [4] */
           bool het = false;   /* a row without an entry at a het site scores the same for both signs, term by term */
           for (const FragElem& fe : frags[k].list) if (fe.phase_site && cands[fe.snp_idx].genotype == 0) het = true;
-          if (het) census[8]++;
-          if (d.q != d.qn) census[9]++;
+          if (het) o.c[2] = 1;                           /* census[8] */
+          if (d.q != d.qn) o.c[3] = 1;                   /* census[9] */
         }
         if (tie) {
           flip = flip_fx;
           if (d.A == d.B && (tie_mask & 1)) flip = flip_f64;
-          if (d.A < d.B) any_strict = true; else if (flip) any_tie_change = true;
-        }
-        tmp_haplotag[k] = flip ? -sigma_k : sigma_k;
+          if (d.A < d.B) o.strict = true; else if (flip) o.tiechg = true;
+        } else if (flip) o.strict = true;
+        o.newtag = flip ? -sigma_k : sigma_k;
         /* check_new_haplotag, phase.rs:278-314 (sums in key order instead of HashMap order) */
-        logp += flip ? d.qn : d.q; pre_logp += d.q;
-        if (!tie && flip) any_strict = true;
+        o.q_new = flip ? d.qn : d.q; o.q_old = d.q;
+        return o;
+      };
+      std::vector<RowOut> rout;
+      if (fast_threads) {   /* Jacobi: every row is scored against the old state (phase.rs:859-862) -- independent */
+        rout.resize(nf);
+        par_for(nf, 512, [&](int64_t k) {
+          rdec[k] = RowDec(); rout[k] = RowOut();
+          if (!frags[k].for_phasing || frags[k].haplotag == 0) return;
+          RowView dummy; row_scores((int)k, use_fx, use_f64, dummy, rdec[k]);
+          rout[k] = row_decide((int)k, rdec[k]);
+        });
+        const int64_t CH = 4096, nch = (nf + CH - 1) / CH;
+        std::vector<std::array<int64_t, 7>> part((size_t)nch);
+        par_for(nch, 1, [&](int64_t ci) {
+          std::array<int64_t, 7> a = {0, 0, 0, 0, 0, 0, 0};
+          for (int64_t k = ci * CH; k < std::min<int64_t>(nf, (ci + 1) * CH); k++) {
+            const RowOut& o = rout[k];
+            if (!o.has) continue;
+            for (int x = 0; x < 5; x++) a[x] += o.c[x];
+            a[5] |= o.strict ? 1 : 0; a[6] |= o.tiechg ? 1 : 0;
+          }
+          part[(size_t)ci] = a;
+        });
+        for (const auto& a : part) { census[0] += a[0]; census[4] += a[1]; census[8] += a[2]; census[9] += a[3]; stats[2] += a[4]; any_strict |= a[5] != 0; any_tie_change |= a[6] != 0; }
+        /* the sums of check_new_haplotag, in key order -- wherever their value is looked at */
+        if (!tie ? !by_fx : (!any_strict && any_tie_change))
+          for (int k = 0; k < nf; k++) if (rout[k].has) { logp += rout[k].q_new; pre_logp += rout[k].q_old; }
+      } else
+      for (int k = 0; k < nf; k++) {
+        if (!frags[k].for_phasing || frags[k].haplotag == 0) continue;
+        RowDec d;
+        row_scores(k, use_fx, use_f64, rv, d);
+        const RowOut o = row_decide(k, d);
+        if (!o.has) continue;
+        census[0] += o.c[0]; census[4] += o.c[1]; census[8] += o.c[2]; census[9] += o.c[3]; stats[2] += o.c[4];
+        any_strict |= o.strict; any_tie_change |= o.tiechg;
+        tmp_haplotag[k] = o.newtag;
+        logp += o.q_new; pre_logp += o.q_old;
       }
       int check_val;
       if (tie) {
@@ -1145,6 +1178,7 @@ struct orc_region {
         if (!any_strict && any_tie_change) { census[2]++; if (logp > pre_logp) census[6]++; if (tie_mask & 4) check_val = logp > pre_logp ? 1 : 0; }
       } else if (!by_fx) { check_val = logp > pre_logp ? 1 : (logp == pre_logp ? 0 : -1); if (check_val < 0) { stats[3]++; check_val = 0; } }
       else check_val = any_strict ? 1 : 0;
+      if (fast_threads) par_for(nf, 4096, [&](int64_t k) { if (rout[k].has) frags[k].haplotag = rout[k].newtag; });
       for (auto& kv : tmp_haplotag) frags[kv.first].haplotag = kv.second;
       if (check_val == 0) h_inc = false; else { h_inc = true; hg_inc = true; }
       /* delta/eta step, phase.rs:872-959 */

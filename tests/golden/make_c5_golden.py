@@ -1,0 +1,48 @@
+"""Generates tests/golden/c5_full_size_oracle.npz: the ORACLE's results (oracle/lcr_oracle.cpp, ORC_MODE_TIE with the tie classes liblcr
+resolves, indexed gathers + threaded Jacobi steps: orc_set_fast) for BASELINE configs[4] at full size -- ONE region of ~1 Mb at
+~500x ONT-dRNA, 4 687 candidates, 8.3 10^6 matrix entries, 2 345 cross_optimize calls (phase.rs:1123-1233).  The oracle needs
+~3.5 minutes on 64 threads for it (the GPU suite has ~3 for everything), so its output is kept as a fixture: haplotag /
+assignment / phase set of the 333 250 fragment rows, the candidate records, the VCF text, the LD blocks, the objective -- DATA
+produced by this repository's own oracle from this repository's own generator (synth.make_island, seed 5); nothing of the
+reference is in it.  tests/test_gpu_parity.py::test_c5_full_size compares the HIP path with it (and, LCR_C5_ORACLE=1, with a live
+oracle run).  Run on the GPU box:  python tests/golden/make_c5_golden.py [threads]  -> gpurun_out/c5_full_size_oracle.npz"""
+import hashlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+from longcallr_amd import _abi, synth
+from oracle import orc
+
+
+def build():
+    b = synth.make_island("ont-drna-c5", n_loci=40, locus_len=25000, depth=500, seed=5)
+    return b, _abi.make_params("ont-drna", seed=5)
+
+
+def input_digest(b):
+    h = hashlib.sha256()
+    for a in (b.pos, b.seq_len, b.flags, b.cigar, b.bases, b.quals, b.ref):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def run_oracle(b, p, threads):
+    R = orc.Region(b, 0, p).set_fast(threads).set_tie_mask(orc.TIE_MASK_LIBLCR)
+    t = time.time()
+    R.run_all(orc.MODE_TIE)
+    return R, time.time() - t
+
+
+if __name__ == "__main__":
+    threads = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    b, p = build()
+    R, secs = run_oracle(b, p, threads)
+    pr, c = R.phase_result(), R.cands()
+    blocks = R.ld_blocks()
+    out = os.path.join(ROOT, "gpurun_out", "c5_full_size_oracle.npz")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    np.savez_compressed(out, input_sha256=np.frombuffer(input_digest(b).encode(), np.uint8), haplotag=pr["haplotag"], assignment=pr["assignment"],
+                        phase_set=pr["phase_set"], objective=np.float64(pr["objective"]), cands=c.view(np.uint8), vcf=np.frombuffer(R.vcf_text("chrS").encode(), np.uint8),
+                        ld_off=np.cumsum([0] + [len(x) for x in blocks]).astype(np.int32), ld_snps=np.array([i for x in blocks for i in x], np.int32),
+                        stats=np.array(list(R.stats().values()), np.int64), tie_census=R.tie_census(), oracle_seconds=np.float64(secs), oracle_threads=np.int32(threads))
+    print("wrote", out, os.path.getsize(out), "bytes; oracle %.1f s on %d threads" % (secs, threads), R.stats())

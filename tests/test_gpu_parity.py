@@ -48,7 +48,7 @@ def oracle_all(orc, batch, params, upto="post"):
 
 
 F64_CHECKED = {"regions": 0, "no_unresolved_tie": 0}
-ORACLE_TIE_MASK = [None]     # None: orc.TIE_MASK_LIBLCR (a test of a fallback kernel or of the tie_arith switch sets its own)
+ORACLE_TIE_MASK = {0: None}     # None: orc.TIE_MASK_LIBLCR (a test of a fallback kernel or of the tie_arith switch sets its own)
 
 
 def unresolved_ties(census_tie, census_f64, is_chain):
@@ -208,7 +208,7 @@ def test_hand_derived_phasing_instances(engine_cls, orc):
         c = full_check(engine_cls, orc, b, _abi.make_params("hifi-masseq", seed=4, min_phase_score=mps))
         e = c[c["pos"] == 5000 + 777]
         assert len(e) == 1 and bool(e["flags"][0] & _abi.F_FOR_PHASING) == (mps == 8.0)
-    assert F64_CHECKED["tie_free"] >= 4
+    assert F64_CHECKED["no_unresolved_tie"] >= 4
 
 
 def test_k0_cigar_lengths(engine_cls, orc):
@@ -1195,13 +1195,18 @@ def test_c5_scopes_and_paths_agree(engine_cls, monkeypatch):
 
 def test_c5_full_size(engine_cls, orc):
     """BASELINE configs[4] at full size: ONE region of ~1 Mb at ~500x ONT-dRNA (3.3 10^5 reads, ~4 700 candidate sites,
-    8 10^6 matrix entries, 2 345 cross_optimize calls).  Pileup planes, candidates and the fragment matrix (P1-P6) are
-    compared with the oracle at full size; the oracle's optimiser is out of reach here (phase.rs:890-898 is quadratic in
-    a column's depth), so the phase stage is checked through size-independent properties and bit-identical results of
-    two runs, and against the oracle on islands of 100-200 kb (the two tests above)."""
-    b = synth.make_island("ont-drna-c5", n_loci=40, locus_len=25000, depth=500, seed=5)
+    8 10^6 matrix entries, 2 345 cross_optimize calls).  Pileup planes, candidates and the fragment matrix (P1-P6) against a
+    live oracle run; the phase stage (LD blocks, LD-seeded start, block flip, 1 172 perturbation rounds: phase.rs:1123-1233) and
+    the post-phase steps against the oracle's results for the same input kept in tests/golden/c5_full_size_oracle.npz (the oracle
+    with indexed gathers and threaded Jacobi steps needs 3.5 minutes for it; make_c5_golden.py; LCR_C5_ORACLE=1 runs it live):
+    sigma of every row, assignments, phase sets, every candidate field, the VCF text, the LD blocks, the objective exactly."""
+    import hashlib, importlib.util, os
+    spec = importlib.util.spec_from_file_location("make_c5_golden", os.path.join(helpers.GOLDEN, "make_c5_golden.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    b, p = mk.build()
     assert b.n_regions == 1 and b.len[0] > 900000 and b.bases.size > 5.0e8
-    p = _abi.make_params("ont-drna", seed=5)
+    G = np.load(os.path.join(helpers.GOLDEN, "c5_full_size_oracle.npz"))
+    assert mk.input_digest(b) == G["input_sha256"].tobytes().decode(), "synth.make_island no longer builds the input the fixture was made from"
     E = engine_cls(0, p)
     E.load_batch(b).fill_data_into_freq_vec()
     pl = _pileup_properties(E, b)
@@ -1213,11 +1218,36 @@ def test_c5_full_size(engine_cls, orc):
     O = orc.Batch(b, p, mode=orc.MODE_EXACT_ONLY, upto="frag")
     batch_check(E, O, b, p, upto="frag")
     FULL_SIZE_STATS["c5_p1_p6"] = dict(oracle_seconds=O.seconds, oracle_threads=int(O.threads), candidates=int(O.cand_off[-1]), fragment_nnz=int(O.nnz_off[-1]))
-    _dump_full_size_stats()
     O.close()
     E.phase()
     c, off, fm, pr = _phase_properties(E)
     assert 4000 < c.size < 6500 and fm["col"].size > 5e6
+    # ---- the phase stage and the post-phase steps against the oracle's results
+    if os.environ.get("LCR_C5_ORACLE"):
+        R, secs = mk.run_oracle(b, p, int(os.environ.get("LCR_C5_ORACLE_THREADS", "64")))
+        op, oc, otext, oblocks = R.phase_result(), R.cands(), R.vcf_text("chrS"), R.ld_blocks()
+        oobj = op["objective"]
+    else:
+        op = {f: G[f] for f in ("haplotag", "assignment", "phase_set")}
+        oc = G["cands"].view(_abi.CAND_DTYPE)
+        otext, oobj = G["vcf"].tobytes().decode(), float(G["objective"])
+        oblocks = [G["ld_snps"][G["ld_off"][k]:G["ld_off"][k + 1]].tolist() for k in range(G["ld_off"].size - 1)]
+    for f in ("haplotag", "assignment", "phase_set"):
+        assert np.array_equal(pr[f], op[f]), f
+    assert pr["objective"][0] == oobj, "fixed-point objective must match exactly"
+    for f in INT_FIELDS:
+        if f != "region":
+            assert np.array_equal(c[f], oc[f]), "cand.%s" % f
+    assert np.all(np.abs(c["phase_score"] - oc["phase_score"]) <= 1e-4)
+    assert vcf.format_records(c, "chrS", p.min_phase_score) == otext
+    assert E.ld_blocks(0) == oblocks
+    hc = E.tie_census()
+    assert hc["sigma_unresolved"] == 0 and hc["delta_unresolved"] == 0 and hc["sigma_f64"] >= int(G["tie_census"][8])
+    FULL_SIZE_STATS["c5_phase"] = dict(oracle_seconds=float(G["oracle_seconds"]), oracle_threads=int(G["oracle_threads"]), cross_optimize_calls=int(G["stats"][0]),
+                                       iterations=int(G["stats"][1]), oracle_sigma_ties_at_rows_with_a_het_entry=int(G["tie_census"][8]),
+                                       oracle_sigma_ties_flipped_by_f64=int(G["tie_census"][4]), oracle_equal_objective_compares=int(G["tie_census"][3]),
+                                       oracle_equal_objective_f64_greater=int(G["tie_census"][7]), hip_census=hc, live_oracle=bool(os.environ.get("LCR_C5_ORACLE")))
+    _dump_full_size_stats()
     fp = (c["flags"] & _abi.F_FOR_PHASING) != 0
     assert fp.sum() > 2000 and (pr["assignment"] != 0).mean() > 0.95            # the reads carry real haplotype signal
     r1 = _result_bytes(E)
