@@ -69,18 +69,23 @@ __device__ __forceinline__ int wave_incl_max(int v) {
 // load-time helpers (lcr_load_batch)
 
 // the op-parallel kernel indexes ONE flat op space: every read's ops must follow the previous read's.
-// out (pinned host memory): int32 [1] = 1 if they do not; uint64 at byte 16: first op, byte 24: end of the last read's ops
+// out (pinned host memory, zeroed): int32 [1] = 1 if they do not; uint64 at byte 16: first op, byte 24: end of the last read's ops
 __global__ void __launch_bounds__(LCR_BLOCK) k0_cig_check(const uint64_t* __restrict__ cig_off, const uint32_t* __restrict__ n_cig,
-                                                           int32_t nr, int32_t* out) {
+                                                           int32_t nr, int64_t n_cigar, int32_t* out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r + 1 < nr && cig_off[r + 1] != cig_off[r] + n_cig[r]) out[1] = 1;
+  // out[2]: a read's ops reach beyond the caller's array (cig_off + n_cig > n_cigar); uint64 at byte 32: the sum of n_cig
+  unsigned long long mine = 0;
+  if (r < nr) { mine = n_cig[r]; if (cig_off[r] > (uint64_t)n_cigar || (uint64_t)n_cig[r] > (uint64_t)n_cigar - cig_off[r]) out[2] = 1; }
+  for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(reinterpret_cast<unsigned long long*>(out + 8), mine);
   if (r == 0) {
     uint64_t* g = reinterpret_cast<uint64_t*>(out + 4);
     g[0] = cig_off[0]; g[1] = cig_off[nr - 1] + n_cig[nr - 1];
   }
 }
-void launch_k0_cig_check(const uint64_t* cig_off, const uint32_t* n_cig, int32_t nr, int32_t* out, hipStream_t s) {
-  if (nr > 0) hipLaunchKernelGGL(k0_cig_check, dim3((nr + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, cig_off, n_cig, nr, out);
+void launch_k0_cig_check(const uint64_t* cig_off, const uint32_t* n_cig, int32_t nr, int64_t n_cigar, int32_t* out, hipStream_t s) {
+  if (nr > 0) hipLaunchKernelGGL(k0_cig_check, dim3((nr + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, cig_off, n_cig, nr, n_cigar, out);
 }
 // CIGARs that do not lie back to back (the ABI allows any cig_off) are copied into a contiguous array once per batch:
 // new_off = exclusive scan of n_cig (launch_scan_i32), one wave per read copies
@@ -206,7 +211,9 @@ k0_ops(BatchView b, const ReadBin* __restrict__ rbin, const int32_t* __restrict_
   for (int rr = tid; rr < n_blk_reads; rr += K0_THREADS) {
     uint64_t cb; int ncig;
     const K0Hdr x = load_hdr(r_lo + rr, &cb, &ncig);
-    if (rr == 0 || cb < (uint64_t)jend || (last_block && cb == (uint64_t)jend)) {
+    // (a read without ops whose offset is the block's end sits in front of the read that owns that op: it is this block's --
+    // the next block starts at the owner)
+    if (rr == 0 || cb < (uint64_t)jend || (cb == (uint64_t)jend && (last_block || ncig == 0))) {
       if (rr < K0_HCAP) hdr[rr] = x;
       if (rr > 0) { if (ncig > 0) ridh[cb - j0] = (uint16_t)rr; else settle_empty(r_lo + rr, x); }
     }

@@ -240,7 +240,7 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
     HIPCHK(c, c->h_order.reserve(64));
     memset(c->h_order.p, 0, 64);
     { int32_t* d_flag = nullptr; HIPCHK(c, hipHostGetDevicePointer((void**)&d_flag, c->h_order.p, 0));
-      launch_k0_cig_check(rd->cig_off, rd->n_cig, nr, d_flag, c->stream); }
+      launch_k0_cig_check(rd->cig_off, rd->n_cig, nr, rd->n_cigar, d_flag, c->stream); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     if (ng) { memcpy(c->h_start0.data(), st, ng * sizeof(int64_t)); memcpy(c->h_len.data(), st + o2, ng * sizeof(int32_t)); }
@@ -291,8 +291,8 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   b.region_first_tile = c->first_tile.as<int32_t>(); b.error_flag = nullptr;   // set by lcr_pileup
   HIPCHK(c, c->read_bin.reserve(std::max<size_t>(nr, 1) * sizeof(ReadBin)));
   // ---- the flat op space of K0 (k0_ops.hip): ops [cig0, cig0 + n_ops) of bv.cigar, read after read
-  bool contiguous = true;
-  uint64_t cig0 = 0, cig_end = 0;
+  bool contiguous = true, cig_oob = false;
+  uint64_t cig0 = 0, cig_end = 0, cig_total = 0;
   if (mem == LCR_MEM_HOST) {
     HIPCHK(c, c->h_order.reserve(64));
     // (a device-resident batch bound before this one returned without a wait: its k0_pack may still be about to raise the flag)
@@ -300,11 +300,18 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
     memset(c->h_order.p, 0, 64);
     if (nr) { cig0 = rd->cig_off[0]; cig_end = rd->cig_off[nr - 1] + rd->n_cig[nr - 1]; }
     for (int r = 0; r + 1 < nr && contiguous; r++) contiguous = rd->cig_off[r + 1] == rd->cig_off[r] + rd->n_cig[r];
+    for (int r = 0; r < nr; r++) {   // (any layout: every read's ops inside the caller's array; the total in 64 bits)
+      cig_total += rd->n_cig[r];
+      cig_oob |= rd->cig_off[r] > (uint64_t)rd->n_cigar || (uint64_t)rd->n_cig[r] > (uint64_t)rd->n_cigar - rd->cig_off[r];
+    }
   } else {
     const uint64_t* g = reinterpret_cast<const uint64_t*>(c->h_order.as<uint8_t>() + 16);   // written by k0_cig_check, waited for above
     contiguous = c->h_order.as<int32_t>()[1] == 0;
-    cig0 = g[0]; cig_end = g[1];
+    cig_oob = c->h_order.as<int32_t>()[2] != 0;
+    cig0 = g[0]; cig_end = g[1]; cig_total = g[2];
   }
+  if (cig_oob) { c->err = "cig_off / n_cig reach beyond n_cigar"; return LCR_E_ARG; }
+  if (cig_total > 0x7FFFFFF0ull && !contiguous) { c->err = "batch too large: CIGAR ops must stay below 2^31; split it"; return LCR_E_ARG; }
   if (!contiguous) {   // the ABI allows any cig_off: copy the CIGARs back to back once (rare; every producer here is contiguous)
     HIPCHK(c, c->cig_new_off32.reserve(((size_t)nr + 2) * 4));
     HIPCHK(c, c->cig_off_new.reserve(std::max<size_t>(nr, 1) * 8));

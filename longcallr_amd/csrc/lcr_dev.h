@@ -142,7 +142,7 @@ void launch_k0_tiles(const int32_t* first_tile, int32_t n_regions, int32_t* tile
 void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s);
 void launch_k0_pack(const BatchView& b, ReadBin* out, int32_t* order_flag /* pinned host memory, device address */, hipStream_t s);
 // K0 (k0_ops.hip): op-parallel CIGAR decode + per-tile record binning; load-time helpers
-void launch_k0_cig_check(const uint64_t* cig_off, const uint32_t* n_cig, int32_t nr, int32_t* flag /* pinned host, device address */, hipStream_t s);
+void launch_k0_cig_check(const uint64_t* cig_off, const uint32_t* n_cig, int32_t nr, int64_t n_cigar, int32_t* out, hipStream_t s);
 void launch_k0_cig_compact(const uint32_t* cigar, const uint64_t* cig_off, const uint32_t* n_cig, const int32_t* new_off, int32_t nr,
                            uint32_t* out, uint64_t* out_off, hipStream_t s);
 int launch_k0_opb();   // ops per K0 workgroup

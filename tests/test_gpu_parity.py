@@ -300,6 +300,35 @@ def test_k0_block_borders_and_empty_reads(engine_cls, orc):
     E.close()
 
 
+def test_k0_empty_read_on_a_block_border(engine_cls, orc):
+    """A read without CIGAR ops whose cig_off is exactly the end of a K0 block (1 024 ops) belongs to that block, not to the next
+    one (which starts at the read that owns the op): its reference end is set and its l_seq is checked."""
+    rng = np.random.default_rng(23)
+    L = 2400
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    reads = []
+    for i in range(1034):
+        s = 100 + i
+        sq = list(ref[s:s + 60])
+        if i % 2 and s <= 700 < s + 60:
+            sq[700 - s] = "A" if ref[700] != "A" else "C"
+        reads.append(dict(pos=s, seq="".join(sq), qual=25, cigar="60M", rev=i % 2, ts=1 + i % 2))
+    b = helpers.mk_batch(reads, [(0, ref)])
+    assert int(b.cig_off[1024]) == 1024
+    ins = [1024]
+    mk = lambda seq_len: _with_reads(b, pos=np.insert(b.pos, ins, b.pos[1024]), seq_len=np.insert(b.seq_len, ins, seq_len), lead_clip=np.insert(b.lead_clip, ins, 0),
+                                     trail_clip=np.insert(b.trail_clip, ins, 0), flags=np.insert(b.flags, ins, 0), seq_off=np.insert(b.seq_off, ins, b.seq_off[1024]),
+                                     cig_off=np.insert(b.cig_off, ins, 1024), n_cig=np.insert(b.n_cig, ins, 0), read_begin=[0, b.n_reads + 1])
+    p = _abi.make_params("ont-cdna", seed=3, min_depth=2)
+    c = full_check(engine_cls, orc, mk(0), p)
+    assert c.size >= 1
+    from longcallr_amd._lib import LcrError
+    E = engine_cls(0, p)
+    with pytest.raises(LcrError, match="CIGAR inconsistent"):
+        E.load_batch(mk(5)).run_all()          # five bases and no op to carry them
+    E.close()
+
+
 def test_k0_reads_beyond_the_tile_window(engine_cls, orc):
     """A K0 block keeps the record counters of 256 tiles (65 536 columns from its first read on) in LDS; records beyond --
     reads with introns of 100 kb and more -- take one pool allocation each.  Same planes / candidates / phasing."""
@@ -856,6 +885,16 @@ def test_empty_batch_and_errors(engine_cls):
         engine_cls(0, p).load_batch(unsorted).fill_data_into_freq_vec()
     with pytest.raises(LcrError, match="ld_weight_threshold"):
         engine_cls(0, _abi.make_params(ld_weight_threshold=2)).load_batch(helpers.demo_batch()).run_all()
+    # CIGARs anywhere in the caller's array are fine (test_k0_op_space_layouts) -- beyond its end they are an argument error,
+    # from host arrays and from device arrays alike
+    two = helpers.mk_batch([dict(pos=10, seq="ACGT" * 5, cigar="20M"), dict(pos=12, seq="ACGT" * 5, cigar="10M1D10M")], [(0, "A" * 64)])
+    oob = _with_reads(two, cig_off=np.array([0, 2], np.uint64))     # the second read's three ops end at 5 > n_cigar = 4
+    with pytest.raises(LcrError, match="beyond n_cigar"):
+        engine_cls(0, p).load_batch(oob)
+    import torch
+    import bench
+    with pytest.raises(LcrError, match="beyond n_cigar"):
+        engine_cls(0, p).load_batch(bench.to_device(oob, torch, torch.device("cuda", 0)))
 
 
 def test_device_resident_inputs_and_idempotence(engine_cls):
