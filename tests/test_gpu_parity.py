@@ -312,7 +312,7 @@ def test_k0_empty_read_on_a_block_border(engine_cls, orc):
         sq = list(ref[s:s + 60])
         if i % 2 and s <= 700 < s + 60:
             sq[700 - s] = "A" if ref[700] != "A" else "C"
-        reads.append(dict(pos=s, seq="".join(sq), qual=25, cigar="60M", rev=i % 2, ts=1 + i % 2))
+        reads.append(dict(pos=s, seq="".join(sq), qual=25, cigar="60M", rev=(i // 2) % 2, ts=1 + (i // 2) % 2))
     b = helpers.mk_batch(reads, [(0, ref)])
     assert int(b.cig_off[1024]) == 1024
     ins = [1024]
