@@ -74,11 +74,8 @@ __global__ void __launch_bounds__(LCR_BLOCK) k0_cig_check(const uint64_t* __rest
                                                            int32_t nr, int64_t n_cigar, int32_t* out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r + 1 < nr && cig_off[r + 1] != cig_off[r] + n_cig[r]) out[1] = 1;
-  // out[2]: a read's ops reach beyond the caller's array (cig_off + n_cig > n_cigar); uint64 at byte 32: the sum of n_cig
-  unsigned long long mine = 0;
-  if (r < nr) { mine = n_cig[r]; if (cig_off[r] > (uint64_t)n_cigar || (uint64_t)n_cig[r] > (uint64_t)n_cigar - cig_off[r]) out[2] = 1; }
-  for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
-  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(reinterpret_cast<unsigned long long*>(out + 8), mine);
+  // out[2]: a read's ops reach beyond the caller's array (cig_off + n_cig > n_cigar)
+  if (r < nr && (cig_off[r] > (uint64_t)n_cigar || (uint64_t)n_cig[r] > (uint64_t)n_cigar - cig_off[r])) out[2] = 1;
   if (r == 0) {
     uint64_t* g = reinterpret_cast<uint64_t*>(out + 4);
     g[0] = cig_off[0]; g[1] = cig_off[nr - 1] + n_cig[nr - 1];
