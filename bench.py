@@ -63,6 +63,9 @@ def region_max_coverage(b):
     return out
 
 
+bench_costs = None
+
+
 def build_shard(name, world=1, rank=0, seed=1, genes=None, gene_len=None, depth=None, profile=None, workers=0):
     """Rank `rank`'s regions of workload `name` on `world` GPUs.  The job is ONE list of world x (regions per GPU)
     DISTINCT genes (synth.make_genes: gene k has its own generator); it is partitioned by
@@ -72,11 +75,14 @@ def build_shard(name, world=1, rank=0, seed=1, genes=None, gene_len=None, depth=
     w_profile, w_genes, w_len, w_depth, _ = WORKLOADS[name]
     profile, genes, gene_len, depth = profile or w_profile, genes or w_genes, gene_len or w_len, depth or w_depth
     n_global = world * genes
+    global bench_costs
     if world == 1:
         mine = list(range(n_global))
+        bench_costs = None
     else:
         costs = synth.gene_costs(profile, range(n_global), gene_len=gene_len, depth=depth, seed=seed)
         mine = shard.assign_regions(costs, world)[rank]
+        bench_costs = np.asarray(costs, dtype=np.float64)   # (the LPT costs of the whole job: the N > 1 line reports every rank's share)
     if workers <= 0:   # the ranks of one node generate side by side
         workers = max(1, min(64, (os.cpu_count() or 1) // max(1, world)))
     batch = synth.make_genes(profile, gene_len=gene_len, depth=depth, seed=seed, workers=workers, gene_ids=mine)
@@ -596,6 +602,7 @@ def main():
     G = (shard.RecordGather(dist, cdev, _abi.CAND_DTYPE), shard.RecordGather(dist, cdev, _abi.READ_REC_DTYPE)) if dist is not None else None
     pending = [None]
     gathered = [0, 0]
+    gstat = {"wait_s": 0.0, "bytes": 0, "batches": 0}   # this rank's share of the final gathers: time spent waiting for them, bytes sent
 
     def step(Ej):
         Ej.load_batch((reads, regions, keep))
@@ -614,15 +621,23 @@ def main():
         if G is None:
             return
         on_dev = a.dist_backend == "nccl"
-        h = (G[0].start(Ej.candidates_device() if on_dev else Ej.candidates()[0]),
-             G[1].start(Ej.read_records_device() if on_dev else read_records_host(Ej)))
+        cr = Ej.candidates_device() if on_dev else Ej.candidates()[0]
+        rr = Ej.read_records_device() if on_dev else read_records_host(Ej)
+        nb = lambda x, dt: (int(x[1]) if isinstance(x, tuple) else int(x.size)) * np.dtype(dt).itemsize
+        h = (G[0].start(cr) + (nb(cr, _abi.CAND_DTYPE),), G[1].start(rr) + (nb(rr, _abi.READ_REC_DTYPE),))
         if pending[0] is not None:
-            G[0].finish(pending[0][0], parse=False); G[1].finish(pending[0][1], parse=False)
+            tw = time.perf_counter()
+            G[0].finish(pending[0][0][:2], parse=False); G[1].finish(pending[0][1][:2], parse=False)
+            gstat["wait_s"] += time.perf_counter() - tw
+        gstat["bytes"] += h[0][2] + h[1][2]
+        gstat["batches"] += 1
         pending[0] = h
 
     def drain():   # the last batch is also brought to rank 0's host and decoded
         if G is not None and pending[0] is not None:
-            c = G[0].finish(pending[0][0], parse=True); r = G[1].finish(pending[0][1], parse=True)
+            tw = time.perf_counter()
+            c = G[0].finish(pending[0][0][:2], parse=True); r = G[1].finish(pending[0][1][:2], parse=True)
+            gstat["wait_s"] += time.perf_counter() - tw
             if c is not None:
                 gathered[0], gathered[1] = int(c.size), int(r.size)
             pending[0] = None
@@ -682,17 +697,37 @@ def main():
     if dist is not None:
         dist.barrier()
     sync_all()
+    gstat.update(wait_s=0.0, bytes=0, batches=0)
     t0 = time.perf_counter()
     pile_ms = run_steps(a.steps)
     drain()   # the last batch's records are on rank 0 before the clock stops
     sync_all()
+    dt_own = time.perf_counter() - t0      # this rank's K steps + its share of the gathers, before the closing barrier
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
+        assert dist.get_world_size() == a.gpus and dist.get_backend() == a.dist_backend, (dist.get_world_size(), dist.get_backend())
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # what makes the first N > 1 line explain itself: every rank's own time, its share of the work, the LPT cost it was
+        # dealt (len x max_coverage of its regions) and what the gathers cost it
+        lpt = float(np.sum(bench_costs[mine])) if bench_costs is not None else 0.0
+        mine_v = torch.tensor([dt_own / a.steps * 1e3, float(batch.col_off[-1]), float(batch.bases.size), float(batch.n_reads), float(batch.n_regions), lpt,
+                               gstat["wait_s"] / max(a.steps, 1) * 1e3, float(gstat["bytes"]) / max(gstat["batches"], 1)], dtype=torch.float64, device=cdev)
+        allv = [torch.zeros_like(mine_v) for _ in range(world)]
+        dist.all_gather(allv, mine_v)
+        tab = np.stack([v.cpu().numpy() for v in allv])
+        ms = tab[:, 0]
+        per_rank = {"ms_per_step": ms.tolist(), "columns": tab[:, 1].astype(np.int64).tolist(), "aligned_bases": tab[:, 2].astype(np.int64).tolist(),
+                    "reads": tab[:, 3].astype(np.int64).tolist(), "regions": tab[:, 4].astype(np.int64).tolist(), "lpt_cost": tab[:, 5].tolist(),
+                    "gather_wait_ms_per_step": tab[:, 6].tolist(), "gather_bytes_per_step": tab[:, 7].astype(np.int64).tolist(),
+                    "time_imbalance_max_over_mean": float(ms.max() / ms.mean()), "lpt_cost_imbalance_max_over_mean": float(tab[:, 5].max() / max(tab[:, 5].mean(), 1e-30)),
+                    "ms_per_lpt_cost_unit_spread": float((ms / np.maximum(tab[:, 5], 1e-30)).max() / max((ms / np.maximum(tab[:, 5], 1e-30)).min(), 1e-30)),
+                    "backend": dist.get_backend(), "world_size": int(dist.get_world_size()),
+                    "note": "ms_per_step = a rank's own K steps incl. its share of the gathers, before the closing barrier; `value` uses the slowest rank"}
 
     # stage breakdown (untimed extra pass: wall clock per ABI call with a sync after each, + HIP events)
     api_ms = {}
@@ -751,6 +786,7 @@ def main():
                        "parallelism": "regions sharded over %d GPU(s) by shard.assign_regions (LPT on len x max_coverage); final gather of candidate "
                                       "records and read -> HP / PS records to rank 0 (RCCL), overlapped with the next batch" % world,
                        "gathered_records_last_batch": {"candidates": gathered[0], "reads": gathered[1]} if dist is not None else None,
+                       "per_rank": per_rank,
                        "batches_in_flight_per_gpu": F,
                        "scaling_reference": ("the N = 1 point of THIS workload (one GPU's 1 000-gene share of C4) is `stages.c4_share.sites_per_sec` of the "
                                              "N = 1 line; the N = 1 headline `value` is C3, a different workload") if world > 1 else None},
