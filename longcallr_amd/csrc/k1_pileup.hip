@@ -429,19 +429,19 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
 // One workgroup of 128 threads per tile: 16-byte stores, 4 consecutive columns per thread and plane.
 __global__ void __launch_bounds__(128) k1_empty_tiles(BatchView b, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0,
                                                        int64_t n_cols, const int32_t* __restrict__ tile_nbase, uint32_t* __restrict__ planes,
-                                                       const int32_t* __restrict__ order, const int32_t* __restrict__ n_full, int zeroed) {
+                                                       const int32_t* __restrict__ order, const int32_t* __restrict__ n_full, int zeroed, int n_tiles, int bg_tiles) {
   const int nf = *n_full;
-  if ((int)blockIdx.x + nf >= (int)gridDim.x) return;
   if (*b.error_flag != 0) return;
-  const int tile = order[nf + blockIdx.x];
+  // bg_tiles > 0: a few workgroups walk all record-free tiles (a throttled store stream beside the tally, launch_k1_pileup)
+  for (int bt = blockIdx.x; bt + nf < n_tiles; bt += bg_tiles > 0 ? (int)gridDim.x : n_tiles) {
+  const int tile = order[nf + bt];
   const int g = tile_region[tile], tc0 = tile_col0[tile];
   const int tlen = min(LCR_TILE, b.len[g] - tc0);
   const int64_t gcol0 = b.col_off[g] + tc0;
   const uint32_t nb = (uint32_t)tile_nbase[tile];
   if (zeroed) {   // the planes were zeroed while K0 ran (lcr_pileup): only the intron plane of a tile inside introns is left to write
-    if (nb == 0) return;
-    for (int col = (int)threadIdx.x; col < tlen; col += 128) planes[(int64_t)LCR_PL_N * n_cols + gcol0 + col] = nb;
-    return;
+    if (nb != 0) for (int col = (int)threadIdx.x; col < tlen; col += 128) planes[(int64_t)LCR_PL_N * n_cols + gcol0 + col] = nb;
+    continue;
   }
   for (int col = (int)threadIdx.x * 4; col < tlen; col += 128 * 4) {
     const int64_t o = gcol0 + col;
@@ -455,6 +455,7 @@ __global__ void __launch_bounds__(128) k1_empty_tiles(BatchView b, const int32_t
         for (int k = 0; k < LCR_NPLANES; k++) planes[(int64_t)k * n_cols + gcol0 + c2] = k == LCR_PL_N ? nb : 0u;
       }
     }
+  }
   }
 }
 
@@ -574,11 +575,17 @@ __global__ void __launch_bounds__(256) k1_tiles_b(const int32_t* __restrict__ ti
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const int32_t* tile_fill, const int32_t* ent_off, const void* ents,
                       const unsigned long long* recs, const int32_t* tile_nbase, uint32_t* planes, const int32_t* order /* launch_k1_tiles_b */,
-                      const int32_t* tiles_tmp, int zeroed, hipStream_t s) {
+                      const int32_t* tiles_tmp, int zeroed, hipStream_t s, hipStream_t bg, hipEvent_t ev0, hipEvent_t ev1, int bg_wgs) {
   if (n_tiles == 0) return;
+  if (bg && bg_wgs > 0) {   // the record-free tiles' stores as a throttled stream on a second queue, beside the tally
+    hipEventRecord(ev0, s); hipStreamWaitEvent(bg, ev0, 0);
+    hipLaunchKernelGGL(k1_empty_tiles, dim3(bg_wgs), dim3(128), 0, bg, b, tile_region, tile_col0, n_cols, tile_nbase, planes, order, tiles_tmp + 80, zeroed, n_tiles, 1);
+    hipEventRecord(ev1, bg);
+  }
   hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_fill, ent_off,
                      (const uint2*)ents, recs, tile_nbase, planes, order, tiles_tmp + 80 /* TileScanTmp::n_full */);
-  hipLaunchKernelGGL(k1_empty_tiles, dim3(n_tiles), dim3(128), 0, s, b, tile_region, tile_col0, n_cols, tile_nbase, planes, order, tiles_tmp + 80, zeroed);
+  if (bg && bg_wgs > 0) hipStreamWaitEvent(s, ev1, 0);
+  else hipLaunchKernelGGL(k1_empty_tiles, dim3(n_tiles), dim3(128), 0, s, b, tile_region, tile_col0, n_cols, tile_nbase, planes, order, tiles_tmp + 80, zeroed, n_tiles, 0);
 }
 // the tile-order / intron-base / accounting pass alone (the host fetches K0's control block behind it, before K1 is queued)
 // the tile passes alone (the host fetches K0's control block behind pass A, before the rest is queued)

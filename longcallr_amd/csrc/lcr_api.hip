@@ -52,6 +52,7 @@ struct lcr_ctx {
   // K2
   bool have_cand = false;
   DevBuf flags, tile_count, tile_off, total, survivors, sv_region_off, hist, cand_tmp, keep;
+  int dbg_bg_tiles = 0;     // lcr_debug_set("bg_tiles"): > 0 = the record-free tiles' stores by this many workgroups on a second queue beside the tally
   int dbg_prefill = 0;      // lcr_debug_set("plane_prefill"): 1 = the count planes are zeroed on a second queue while K0 runs -- measured: 0.69 instead of 0.63 ms for the stage; 0: k1_empty_tiles writes the record-free tiles
   int dbg_hist_tiles = 0;   // lcr_debug_set("hist_tiles"): 0 = by survivor density, 1 = the tile form whenever it applies, -1 = never
   std::vector<lcr_candidate> h_cand;
@@ -461,6 +462,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   // ALL planes are zeroed on a second queue while K0 runs, K1 then writes the tiles with records and the intron constants.
   // (Under the tally the same stream hurts: the tiles' dependent loads queue behind it.  DESIGN.md K1.)
   const bool prefill = c->dbg_prefill != 0 && nt > 0;
+  if ((prefill || c->dbg_bg_tiles > 0) && !c->fill_stream) { HIPCHK(c, hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fill0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fill1, hipEventDisableTiming)); }
   if (prefill) {
     if (!c->fill_stream) { HIPCHK(c, hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fill0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fill1, hipEventDisableTiming)); }
     HIPCHK(c, hipEventRecord(c->ev_fill0, c->stream));            // (the planes' last readers of the previous batch are ahead in the ctx stream)
@@ -506,7 +508,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
       if (prefill) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fill1, 0));
       launch_k1_pileup(b, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols, fill, c->chunk_off.as<int32_t>(),
                        c->chunks.p, c->k0_items.as<unsigned long long>(), c->tile_nbase.as<int32_t>(), c->planes.as<uint32_t>(),
-                       c->tile_order.as<int32_t>(), fill + o_tmp, prefill ? 1 : 0, c->stream);
+                       c->tile_order.as<int32_t>(), fill + o_tmp, prefill ? 1 : 0, c->stream, c->dbg_bg_tiles > 0 ? c->fill_stream : nullptr, c->ev_fill0, c->ev_fill1, c->dbg_bg_tiles);
       if (!c->dp.ont && c->dp.dist_to_end > 0)
         launch_k1_zonefix(b, c->read_bin.as<ReadBin>(), c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->stream); }
     HIPCHK(c, hipGetLastError());
@@ -882,6 +884,7 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
   else if (k == "host_threads") d.host_threads = (int)value;
   else if (k == "tie_arith") d.tie_arith = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2));
   else if (k == "plane_prefill") c->dbg_prefill = value != 0;
+  else if (k == "bg_tiles") c->dbg_bg_tiles = (int)std::max<int64_t>(0, std::min<int64_t>(value, 4096));
   else if (k == "hist_tiles") c->dbg_hist_tiles = value > 0 ? 1 : value < 0 ? -1 : 0;
   else if (k == "grid_spec_lanes") d.spec_lanes = (int)std::max<int64_t>(1, std::min<int64_t>(value, 16));
   else { c->err = "lcr_debug_set: unknown key " + k; return LCR_E_ARG; }
