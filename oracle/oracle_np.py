@@ -287,3 +287,39 @@ def discover_regions(spans, ref_len):
     if region_end > region_start:
         out.append((region_start, region_end - region_start + 1, max_coverage))
     return out
+
+
+def phased_bam_records(records, regions, haplotag_queue, phaseset_queue):
+    """The phased-BAM loop of thread.rs:307-361 restated on plain tuples -- which records are written, in which order, with which tags.
+      records          [(ref_id, reference_start, reference_end, flag, qname, has_HP_tag, has_PS_tag)] in file order (one
+                       coordinate-sorted file; reference_end as htslib reports it: start + reference length, at least start + 1)
+      regions          [(ref_id, start, end)] = Region.start / Region.end as the reference holds them (1-based start, exclusive end)
+      haplotag_queue   [(qname, assignment)], phaseset_queue [(qname, phase_set)] in queue order
+    Returns [(record index, HP or None, PS or None)] in output order.
+      thread.rs:308-325  the FIRST entry of a name wins in both maps (later ones are skipped)
+      thread.rs:331-334  fetch((chr, start, end)): htslib takes the numbers as a 0-based half-open interval -- records that OVERLAP it
+      thread.rs:336-338  unmapped / secondary / supplementary records are skipped (duplicates, QC-fail, low MAPQ are NOT)
+      thread.rs:339-345  reference_start + 1 < start or reference_end + 1 > end: skipped ("reads beyond the region boundary")
+      thread.rs:347-352  HP:i only for a non-zero assignment; :353-356 PS for every name in the map; rust-htslib's push_aux
+                         refuses a tag the record already carries (the Result is dropped: the record keeps its own tag)
+      every region is walked in list order: a record inside two regions is written twice (the TODO of thread.rs:332)."""
+    hp, ps = {}, {}
+    for name, a in haplotag_queue:
+        if name not in hp:
+            hp[name] = a
+    for name, p in phaseset_queue:
+        if name not in ps:
+            ps[name] = p
+    out = []
+    for ref_id, start, end in regions:
+        for idx, (rid, rs, re_, flag, name, has_hp, has_ps) in enumerate(records):
+            if rid != ref_id or not (rs < end and re_ > start):
+                continue
+            if flag & 0x4 or flag & 0x100 or flag & 0x800:
+                continue
+            if rs + 1 < start or re_ + 1 > end:
+                continue
+            h = hp.get(name)
+            p = ps.get(name)
+            out.append((idx, h if (h is not None and h != 0 and not has_hp) else None, p if (p is not None and not has_ps) else None))
+    return out

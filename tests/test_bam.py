@@ -360,6 +360,94 @@ def test_phased_bam_writer(tmp_path):
     assert bamio.bgzf_decompress(out) == bamio.phased_stream(recs, [(rid, start0, length)], names, hp, ps)
 
 
+def _aux_tags(raw, q):
+    """{tag: value} of a BAM record's aux block (the integer / float / string types the tests write)"""
+    out = {}
+    fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f"}
+    while q + 3 <= len(raw):
+        tag, typ = raw[q:q + 2].decode(), chr(raw[q + 2])
+        q += 3
+        if typ == "A":
+            out[tag] = chr(raw[q]); q += 1
+        elif typ in fmt:
+            out[tag] = struct.unpack_from(fmt[typ], raw, q)[0]; q += struct.calcsize(fmt[typ])
+        elif typ in "ZH":
+            e = raw.index(b"\0", q); out[tag] = raw[q:e].decode(); q = e + 1
+        elif typ == "B":
+            sub, cnt = chr(raw[q]), struct.unpack_from("<I", raw, q + 1)[0]
+            q += 5 + cnt * struct.calcsize(fmt[sub]); out[tag] = "array"
+        else:
+            raise ValueError(typ)
+    return out
+
+
+def test_phased_bam_against_the_oracle_of_the_loop(tmp_path):
+    """lcr_bam_write_phased against oracle_np.phased_bam_records -- thread.rs:307-361 restated on plain tuples in oracle/ (which
+    records, in which order, which tags): boundary rule `reference_start + 1 >= start && reference_end + 1 <= end`
+    (thread.rs:340-345), first-entry-wins maps, tags already present, a record inside two regions, deletions / introns in the
+    reference length, a zero-length alignment (htslib: reference_end = start + 1), 400 random cases and demo.bam."""
+    from oracle import oracle_np
+    rng = np.random.default_rng(17)
+
+    def check(src, regions, names, hp, ps):
+        _, recs = bamio.read_bam(src, keep_raw=True)
+        tup = []
+        for r in recs:
+            t = _aux_tags(r["raw"], r["aux_off"])
+            tup.append((r["ref_id"], r["pos"], r["pos"] + (r["ref_len"] if r["ref_len"] > 0 else 1), r["flag"], r["name"], "HP" in t, "PS" in t))
+        want = oracle_np.phased_bam_records(tup, [(rid, s0 + 1, s0 + ln + 1) for rid, s0, ln in regions],
+                                            [(n, h) for n, h in zip(names, hp) if h >= 0], [(n, p) for n, p in zip(names, ps) if p != 0])
+        out = str(tmp_path / "o.bam")
+        nb = bamio.NativeBam(src, 2)
+        nb.write_phased(out, regions, names, hp, ps, level=1, threads=2)
+        nb.close()
+        _, got = bamio.read_bam(out, keep_raw=True)
+        assert len(got) == len(want)
+        for g, (idx, h, p) in zip(got, want):
+            src_r = recs[idx]
+            assert (g["name"], g["pos"], g["flag"]) == (src_r["name"], src_r["pos"], src_r["flag"])
+            t0, t1 = _aux_tags(src_r["raw"], src_r["aux_off"]), _aux_tags(g["raw"], g["aux_off"])
+            exp = dict(t0)
+            if h is not None:
+                exp["HP"] = h
+            if p is not None:
+                exp["PS"] = p
+            assert t1 == exp, (g["name"], t1, exp)
+        return len(want)
+    refs = [("chrA", 4000), ("chrB", 1500)]
+    total = 0
+    for case in range(40):
+        reads = []
+        for i in range(30):
+            ref = int(rng.integers(0, 2))
+            pos = int(rng.integers(0, 900))
+            kind = int(rng.integers(0, 5))
+            cigar = ["40M", "10M30D10M", "15M200N15M", "5S20M5S", "*"][kind]
+            ln = {0: 40, 1: 20, 2: 30, 3: 30, 4: 12}[kind]
+            aux = [b"", b"HPi" + struct.pack("<i", 2), b"PSI" + struct.pack("<I", 9), b"NMi" + struct.pack("<i", 3)][int(rng.integers(0, 4))]
+            flag = [0, 16, 256, 2048, 1024, 512][int(rng.integers(0, 6))]
+            reads.append(dict(ref=ref, pos=pos, name="q%d" % int(rng.integers(0, 40)), cigar=cigar, seq="A" * ln, aux=aux, flag=flag))
+        reads.sort(key=lambda r: (r["ref"], r["pos"]))
+        src = str(tmp_path / ("r%d.bam" % case))
+        open(src, "wb").write(bgzf(bam_bytes(refs, reads), 300))
+        regions = []
+        for _ in range(int(rng.integers(1, 4))):
+            s0 = int(rng.integers(0, 600))
+            regions.append((int(rng.integers(0, 2)), s0, int(rng.integers(50, 900))))
+        names = ["q%d" % int(rng.integers(0, 44)) for _ in range(30)]
+        hp = [int(rng.integers(-1, 3)) for _ in names]
+        ps = [int(rng.integers(0, 3)) * 501 for _ in names]
+        total += check(src, regions, names, hp, ps)
+    assert total > 100
+    refs, recs = bamio.read_bam(DEMO)
+    keep = [r for r in recs if bamio.passes_filter(r, **_abi.READ_FILTER)]
+    rid = keep[0]["ref_id"]
+    (start0, length, _), = bamio.discover_regions(keep, rid, refs[rid][1])
+    names = [r["name"] for r in keep[::2]]
+    n = check(DEMO, [(rid, start0, length), (rid, start0 + 2000, 3000)], names, [i % 3 for i in range(len(names))], [(start0 + 1) * (i % 2) for i in range(len(names))])
+    assert n > 1000
+
+
 def test_reads_to_bam_and_back(tmp_path):
     """lcr_bam_write_reads is the inverse of lcr_bam_batch: a synthetic batch written as BAM and decoded again by the
     native decoder (and by the record-by-record Python reader) gives the arrays it was made of -- positions, CIGARs,
