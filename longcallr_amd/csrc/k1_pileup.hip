@@ -610,12 +610,13 @@ void launch_k1_tiles_b(int32_t n_tiles, const int32_t* tile_fill, const int32_t*
 // counted by K1 like any other base; they are rare, so they are subtracted with global atomics.
 __global__ void __launch_bounds__(LCR_BLOCK)
 k1_zonefix(BatchView b, int D, int L, int64_t n_cols, uint32_t* __restrict__ planes) {
-  // one workgroup handles LCR_BLOCK / per reads: 32-bit index math only
+  // a thread per (read, slot), 2 D slots per read (any D: the index runs over n_reads x 2 D)
   const int per = 2 * D;
-  const int rpb = LCR_BLOCK / per;                       // reads per block (>= 1: dist_to_end <= 128)
-  const int lr = (int)threadIdx.x / per, s = (int)threadIdx.x - lr * per;
-  const int r = (int)blockIdx.x * rpb + lr;
-  if (lr >= rpb || r >= b.n_reads || s >= per - 1) return;
+  const long long idx = (long long)blockIdx.x * LCR_BLOCK + threadIdx.x;
+  const long long rl = idx / per;
+  const int s = (int)(idx - rl * per);
+  if (rl >= b.n_reads || s >= per - 1) return;
+  const int r = (int)rl;
   const int seq_len = b.seq_len[r], lead = b.lead[r], reb = seq_len - b.trail[r];
   const uint8_t* __restrict__ seq = b.bases + b.seq_off[r];
   const int c = s < D ? lead + s : reb - D + 1 + (s - D);
@@ -855,6 +856,6 @@ void launch_k1_zonefix(const BatchView& b, const ReadBin* rbin, int D, int L, in
 }
 void launch_k1_zonefix_slots(const BatchView& b, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s) {
   if (b.n_reads == 0 || D <= 0) return;
-  const int rpb = LCR_BLOCK / (2 * D);
-  hipLaunchKernelGGL(k1_zonefix, dim3((unsigned)((b.n_reads + rpb - 1) / rpb)), dim3(LCR_BLOCK), 0, s, b, D, L, n_cols, planes);
+  const long long n = (long long)b.n_reads * 2 * D;
+  hipLaunchKernelGGL(k1_zonefix, dim3((unsigned)((n + LCR_BLOCK - 1) / LCR_BLOCK)), dim3(LCR_BLOCK), 0, s, b, D, L, n_cols, planes);
 }

@@ -425,8 +425,10 @@ int lcr_host_unregister(void* p) { return p && hipHostUnregister(p) == hipSucces
 int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   if (!c || !p) return LCR_E_ARG;
   if (!c->loaded) { c->err = "lcr_pileup before lcr_load_batch"; return LCR_E_STATE; }
-  if (p->polya_len == 0 || p->polya_len > 16) { c->err = "polya_len must be in 1..16"; return LCR_E_ARG; }
-  if (p->dist_to_end > 128) { c->err = "dist_to_end must be <= 128"; return LCR_E_ARG; }
+  if (p->polya_len == 0) { c->err = "polya_len must be >= 1"; return LCR_E_ARG; }
+  // (the ends kernel of the poly-A mask takes dist_to_end <= 63 and polya_len in 2..16 -- every preset --, the per-offset kernel the rest;
+  // the thread index of the latter runs over n_reads x 2 x dist_to_end)
+  if ((uint64_t)c->bv.n_reads * 2ull * p->dist_to_end > 0x7FFFFF00ull * (uint64_t)LCR_BLOCK) { c->err = "dist_to_end x reads too large for one launch; split the batch"; return LCR_E_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   if (c->sor_thr < 0.f) c->sor_thr = lcr_device_sor_threshold(c->stream);  // candidate.rs:49-51, evaluated by the device's logf
   c->dp = to_dev(p, c->sor_thr);

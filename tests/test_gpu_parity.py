@@ -1356,11 +1356,11 @@ def test_one_context_over_batches_of_different_sizes(engine_cls):
     E.close()
 
 
-@pytest.mark.parametrize("dist_to_end,polya_len", [(40, 5), (63, 16), (100, 7), (10, 3), (1, 1)])
+@pytest.mark.parametrize("dist_to_end,polya_len", [(40, 5), (63, 16), (100, 7), (10, 3), (1, 1), (300, 5), (40, 24), (2000, 31)])
 def test_poly_a_mask_zone_sizes(engine_cls, orc, dist_to_end, polya_len):
     """The HiFi presets' poly-A / homopolymer mask (util.rs:754-789) for zones of several widths and window lengths: up to
-    63 offsets a thread per read end corrects K1's counts (k1_zonefix_ends), wider zones take a thread per offset
-    (k1_zonefix); MAS-Seq reads with aligned and soft-clipped poly-A tails, planes bit-exact against the oracle."""
+    63 offsets a thread per read end corrects K1's counts (k1_zonefix_ends), wider zones and windows beyond 16 bases take a
+    thread per offset (k1_zonefix: any width, the reference has no limit); MAS-Seq reads with aligned and soft-clipped poly-A tails, planes bit-exact against the oracle."""
     b = synth.make_batch("masseq", n_genes=2, gene_len=8000, depth=40, seed=53)
     p = _abi.make_params("hifi-masseq", seed=3, dist_to_end=dist_to_end, polya_len=polya_len)
     regs = oracle_all(orc, b, p)
@@ -1368,6 +1368,12 @@ def test_poly_a_mask_zone_sizes(engine_cls, orc, dist_to_end, polya_len):
     E.load_batch(b).fill_data_into_freq_vec()
     check_pileup(E, regs, b)
     E.close()
+    if dist_to_end >= 300:      # (the same width as an ONT end trim, util.rs:745-751: K0 clips the M blocks)
+        p2 = _abi.make_params("ont-cdna", seed=3, dist_to_end=dist_to_end, polya_len=polya_len)
+        E2 = engine_cls(0, p2)
+        E2.load_batch(b).fill_data_into_freq_vec()
+        check_pileup(E2, oracle_all(orc, b, p2, upto="pileup"), b)
+        E2.close()
 
 
 def test_bench_line_contract():
