@@ -299,11 +299,16 @@ typedef struct {            /* util.rs:652-668 / fragment.rs:32-49              
 } lcr_read_filter;          /* unmapped / secondary / supplementary records are always dropped            */
 /* *out is set even when the call fails (unless out of memory): lcr_bam_last_error explains, lcr_bam_close frees */
 int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out);
+/* The same with the residency policy spelled out: a file whose INFLATED size is at most keep_bytes is inflated once, at open, and
+ * stays inflated (lcr_bam_spans / lcr_bam_batch / lcr_bam_write_phased then never inflate a block again); a larger one keeps
+ * one contig at a time resident and inflates a contig's blocks when it is first used.  lcr_bam_open = keep_bytes of 4 GiB;
+ * 0 = never keep (the memory bound of one contig). */
+int lcr_bam_open_keep(const char* path, int32_t n_threads, int64_t keep_bytes, lcr_bam** out);
 void lcr_bam_close(lcr_bam*);
 const char* lcr_bam_last_error(const lcr_bam*);
 int lcr_bam_refs(lcr_bam*, int32_t* n_ref, const char* const** names, const int64_t** lengths);
 int lcr_bam_n_records(lcr_bam*, int64_t* n);
-/* bytes of inflated stream + record index held right now (one contig at a time) and their peak since lcr_bam_open */
+/* bytes of inflated stream + record index held right now (the whole stream of a file within keep_bytes, else one contig at a time) and their peak since lcr_bam_open */
 int lcr_bam_resident(lcr_bam*, int64_t* now, int64_t* peak);
 /* record.reference_start() / reference_end() of the reads of contig ref_id that pass the filter, in file order:
  * the input of lcr_discover_regions (util.rs:264-285) */

@@ -14,7 +14,7 @@ SYMBOLS = [
     "lcr_host_alloc", "lcr_host_free", "lcr_host_register", "lcr_host_unregister", "lcr_pileup", "lcr_get_columns", "lcr_candidates",
     "lcr_get_candidates", "lcr_get_candidates_device", "lcr_fragments", "lcr_get_fragmat", "lcr_phase", "lcr_get_phase_result", "lcr_get_read_records_device", "lcr_get_ld_blocks", "lcr_get_tie_census",
     "lcr_enable_timing", "lcr_kernel_ms", "lcr_pileup_bytes", "lcr_pileup_stage_bytes", "lcr_discover_regions", "lcr_version",
-    "lcr_bam_open", "lcr_bam_close", "lcr_bam_last_error", "lcr_bam_refs", "lcr_bam_n_records", "lcr_bam_resident", "lcr_bam_spans", "lcr_bam_batch", "lcr_bam_write_phased", "lcr_bam_write_reads",
+    "lcr_bam_open", "lcr_bam_open_keep", "lcr_bam_close", "lcr_bam_last_error", "lcr_bam_refs", "lcr_bam_n_records", "lcr_bam_resident", "lcr_bam_spans", "lcr_bam_batch", "lcr_bam_write_phased", "lcr_bam_write_reads",
 ]
 
 _lib = None
@@ -77,6 +77,7 @@ def load():
     l.lcr_pileup_stage_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
     flt = C.POINTER(_abi.LcrReadFilter)
     l.lcr_bam_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(vp)]
+    l.lcr_bam_open_keep.argtypes = [C.c_char_p, C.c_int32, C.c_int64, C.POINTER(vp)]
     l.lcr_bam_close.argtypes = [vp]
     l.lcr_bam_close.restype = None
     l.lcr_bam_last_error.argtypes = [vp]

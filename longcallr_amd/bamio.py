@@ -295,12 +295,15 @@ class NativeBam:
     parallel) and indexed, batches for `Engine.load_batch` are cut out of that index.  Mirrors read_bam /
     passes_filter / build_batch above."""
 
-    def __init__(self, path, threads=0):
+    def __init__(self, path, threads=0, keep_bytes=None):
+        """keep_bytes: files whose inflated size is within it stay inflated from the open pass on (None: lcr_bam_open's 4 GiB;
+        0: one contig at a time, inflated when it is first used)"""
         import ctypes as C
         from . import _lib
         self._C, self._l = C, _lib.load()
         self._h = C.c_void_p()
-        rc = self._l.lcr_bam_open(os.fsencode(path), threads, C.byref(self._h))
+        rc = (self._l.lcr_bam_open(os.fsencode(path), threads, C.byref(self._h)) if keep_bytes is None else
+              self._l.lcr_bam_open_keep(os.fsencode(path), threads, int(keep_bytes), C.byref(self._h)))
         if rc:
             msg = self._l.lcr_bam_last_error(self._h).decode() if self._h else "out of memory"
             self.close()

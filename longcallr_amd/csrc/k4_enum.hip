@@ -5,6 +5,9 @@
 #include "k4_dev.h"
 #include "k4_kernels.h"
 
+#ifndef ENUM_OCC
+#define ENUM_OCC 3
+#endif
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -326,7 +329,7 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
 #endif
     const uint32_t n_ev = min(s_nev, EVCAP);
 #ifdef ENUM_PROF
-    if (tid == 0) atomicAdd(&P.tie_ctr[6], (unsigned long long)((long long)wall_clock64() - prof_t0));
+    if (tid == 0) { atomicAdd(&P.tie_ctr[6], (unsigned long long)((long long)wall_clock64() - prof_t0)); atomicMax(&P.tie_ctr[2], (unsigned long long)((long long)wall_clock64() - prof_t0)); }
 #endif
     // ---- chunks of the restarts of maximal objective, in ascending order
     for (uint32_t cur = 0; cur < n_tied; cur += ENUM_TCAP) {
@@ -440,7 +443,8 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
     }
   }
 #ifdef ENUM_PROF
-  if (tid == 0 && dif) atomicAdd(&P.tie_ctr[5], (unsigned long long)((long long)wall_clock64() - prof_t0));
+  if (tid == 0 && dif) { atomicAdd(&P.tie_ctr[5], (unsigned long long)((long long)wall_clock64() - prof_t0)); atomicMax(&P.tie_ctr[1], (unsigned long long)((long long)wall_clock64() - prof_t0)); }
+  if (tid == 0 && !dif) atomicMax(&P.tie_ctr[0], (unsigned long long)((long long)wall_clock64() - prof_t0));
 #endif
   // ---- the winner's state -> the region's result slots
   const uint32_t we = s_win;
@@ -493,7 +497,7 @@ __device__ __forceinline__ unsigned long long enum_tie_rows_f64(unsigned long lo
 // tiles of restarts of regions whose per-lane share is <= CK entries (host decides).  Every restart stores its objective and --
 // unless a better one is known already -- its final state and signature; k4_enum_resolve decides the winner afterwards.
 template <int CK>
-__global__ void __launch_bounds__(64 * ENUM_WAVES, 3)   // (three waves per SIMD: <= 168 VGPRs)
+__global__ void __launch_bounds__(64 * ENUM_WAVES, ENUM_OCC)   // (three waves per SIMD: <= 168 VGPRs)
 k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uint32_t per, const int64_t* __restrict__ job_base,
             long long* __restrict__ job_obj, const int64_t* __restrict__ st_base, unsigned long long* __restrict__ st_words,
             long long* __restrict__ region_best) {

@@ -214,6 +214,11 @@ struct lcr_bam {
   int32_t cur_ref = INT32_MIN;
   RawBuf<uint8_t> data;
   size_t data_size = 0;
+  // a file whose inflated stream fits keep_bytes stays inflated from the open pass on (`full`): a contig is then a view into it and
+  // is never inflated a second time
+  uint64_t keep_bytes = 0;
+  RawBuf<uint8_t> full;
+  const uint8_t* view = nullptr;   // the resident contig's bytes: data.get(), or a window of `full`
   std::vector<Rec> recs;
   int64_t resident_now = 0, resident_peak = 0;
   // results of the last lcr_bam_spans / lcr_bam_batch call
@@ -348,7 +353,7 @@ int64_t inflate_blocks(const lcr_bam* b, size_t b0, size_t b1, uint8_t* dst, int
 }
 
 void note_resident(lcr_bam* b, int64_t extra) {
-  b->resident_now = (int64_t)b->data_size + (int64_t)(b->recs.capacity() * sizeof(Rec)) + (int64_t)(b->rec_bs.capacity() * 4) + extra;
+  b->resident_now = (int64_t)b->data_size + (int64_t)b->full.size() + (int64_t)(b->recs.capacity() * sizeof(Rec)) + (int64_t)(b->rec_bs.capacity() * 4) + extra;
   b->resident_peak = std::max(b->resident_peak, b->resident_now);
 }
 
@@ -391,7 +396,7 @@ bool index_record(Rec& r, const uint8_t* d, bool* long_bad) {
 int load_contig(lcr_bam* b, int32_t ref_id) {
   if (b->cur_ref == ref_id) return LCR_OK;
   b->cur_ref = INT32_MIN;
-  b->recs.clear(); b->data.reset(); b->data_size = 0;
+  b->recs.clear(); b->data.reset(); b->data_size = 0; b->view = nullptr;
   const size_t ci = (size_t)((int64_t)ref_id + 1);
   if (ref_id < -1 || ci >= b->ctg_n.size() || b->ctg_n[ci] == 0) { b->cur_ref = ref_id; note_resident(b, 0); return LCR_OK; }   // no records
   const uint64_t u0 = b->ctg_u0[ci], u1 = b->ctg_u1[ci];
@@ -401,12 +406,16 @@ int load_contig(lcr_bam* b, int32_t ref_id) {
   if (b0 >= b1) return fail(b, LCR_E_ARG, "inconsistent contig range");
   const uint64_t base = b->blks[b0].uoff, bytes = b->blks[b1 - 1].uoff + b->blks[b1 - 1].isize - base;
   PROF("load_contig");
-  if (!b->data.resize((size_t)bytes + 1)) return fail(b, LCR_E_NOMEM, "out of memory for the inflated contig");
-  LAP(0, "alloc");
-  b->data_size = (size_t)bytes;
-  if (inflate_blocks(b, b0, b1, b->data.get(), b->n_threads) >= 0) return fail(b, LCR_E_ARG, "BGZF block does not inflate / CRC mismatch");
+  if (b->full) b->view = b->full.get() + base;   // (inflated and CRC-checked by the open pass)
+  else {
+    if (!b->data.resize((size_t)bytes + 1)) return fail(b, LCR_E_NOMEM, "out of memory for the inflated contig");
+    LAP(0, "alloc");
+    b->data_size = (size_t)bytes;
+    if (inflate_blocks(b, b0, b1, b->data.get(), b->n_threads) >= 0) return fail(b, LCR_E_ARG, "BGZF block does not inflate / CRC mismatch");
+    b->view = b->data.get();
+  }
   LAP(1, "inflate");
-  const uint8_t* d = b->data.get();
+  const uint8_t* d = b->view;
   try { b->recs.reserve((size_t)b->ctg_n[ci]); } catch (...) { return fail(b, LCR_E_NOMEM, "out of memory for the record index"); }
   if (!b->ctg_scattered[ci]) {   // sorted file: the contig's records lie back to back, their sizes are known from the open pass
     size_t p = (size_t)(u0 - base);
@@ -441,7 +450,9 @@ int load_contig(lcr_bam* b, int32_t ref_id) {
 
 extern "C" {
 
-int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
+int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) { return lcr_bam_open_keep(path, n_threads, (int64_t)4 << 30, out); }
+
+int lcr_bam_open_keep(const char* path, int32_t n_threads, int64_t keep_bytes, lcr_bam** out) {
   if (!path || !out) return LCR_E_ARG;
   *out = nullptr;
   lcr_bam* b = new (std::nothrow) lcr_bam();
@@ -449,6 +460,7 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
   *out = b;   // returned even on failure so that lcr_bam_last_error can explain; the caller closes it
   if (n_threads < 1) n_threads = (int32_t)std::max(1u, std::thread::hardware_concurrency());
   b->n_threads = n_threads;
+  b->keep_bytes = keep_bytes > 0 ? (uint64_t)keep_bytes : 0;
   // ---- the compressed file: mapped, not read
   {
     const int fd = open(path, O_RDONLY);
@@ -494,7 +506,8 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
   // ---- one pass over the inflated stream in windows of <= 1024 blocks (64 MiB): CRC check of every block, BAM header,
   //      the block_size chain of the records -> per contig the range of the stream it occupies and its record count
   PROF("open");
-  const size_t WIN = 1024;
+  const bool keep_all = total > 0 && total <= b->keep_bytes;   // one window = the whole stream, kept
+  const size_t WIN = keep_all ? std::max<size_t>(blks.size(), 1) : 1024;
   RawBuf<uint8_t> buf;            // [carry of the previous window | this window]
   size_t carry = 0;               // bytes at the front of buf that belong to an unfinished item
   std::vector<std::pair<uint64_t, uint32_t>> win_recs;   // (offset past block_size, block_size) of the complete records of the window
@@ -505,7 +518,7 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
     const size_t w1 = std::min(blks.size(), w0 + WIN);
     const size_t wbytes = w0 < blks.size() ? (size_t)(blks[w1 - 1].uoff + blks[w1 - 1].isize - blks[w0].uoff) : 0;
     LAP(0, "other");
-    if (!buf.resize_keep(carry + wbytes + 1)) return fail(b, LCR_E_NOMEM, "out of memory for the scan window");
+    if (!(keep_all ? buf.resize(wbytes + 1) : buf.resize_keep(carry + wbytes + 1))) return fail(b, LCR_E_NOMEM, "out of memory for the scan window");
     LAP(1, "resize");
     b->resident_peak = std::max(b->resident_peak, (int64_t)buf.size());
     if (wbytes) {
@@ -592,7 +605,14 @@ int lcr_bam_open(const char* path, int32_t n_threads, lcr_bam** out) {
     buf_u0 += p; hp = 0;
     if (last) break;
   }
-  // (contigs are inflated and indexed on demand, load_contig; nothing is resident after open)
+  // (contigs are indexed on demand, load_contig; a small file stays inflated, of a large one nothing is resident after open)
+  if (keep_all) {
+    // the single window held the whole stream from offset 0 (the last iteration moved nothing: carry is the unparsed tail, 0)
+    if (buf_u0 + carry != total) return fail(b, LCR_E_ARG, "inconsistent stream length");
+    // buf_u0 == parse position of the end: the buffer still holds the stream from its first byte
+    b->full.p = buf.p; b->full.n = (size_t)total; b->full.cap = buf.cap; buf.p = nullptr; buf.n = buf.cap = 0;
+    note_resident(b, 0);
+  }
   return LCR_OK;
 }
 
@@ -673,7 +693,7 @@ int lcr_bam_batch(lcr_bam* b, int32_t ref_id, const lcr_read_filter* f, int32_t 
   b->b_name_off[nr] = no;
   if (!b->b_bases.resize(so) || !b->b_quals.resize(so) || !b->b_cigar.resize(co) || !b->b_names.resize(no)) return fail(b, LCR_E_NOMEM, "out of memory for the batch");
   static const char NT16[] = "=ACMGRSVTWYHKDBN";
-  const uint8_t* d = b->data.get();
+  const uint8_t* d = b->view;
   parallel_for((int64_t)nr, b->n_threads, 256, [&](int64_t k) {
     const Rec& r = b->recs[take[(size_t)k]];
     const uint8_t* q = d + r.off;
@@ -788,7 +808,7 @@ int lcr_bam_write_phased(lcr_bam* b, const char* out_path, int32_t n_regions, co
       }
       if (rc_all != LCR_OK) break;
     }
-    const uint8_t* d = b->data.get();
+    const uint8_t* d = b->view;
     const int64_t beg = start0[g] + 1, end = start0[g] + len[g] + 1;   // fetch((chr, start, end)), thread.rs:332-334
     const size_t hi = (size_t)(std::lower_bound(ipos.begin(), ipos.end(), end, [](int32_t v, int64_t e) { return (int64_t)v < e; }) - ipos.begin());
     size_t lo = (size_t)(std::upper_bound(iend_max.begin(), iend_max.end(), beg, [](int64_t bg, int32_t v) { return bg < (int64_t)v; }) - iend_max.begin());

@@ -211,7 +211,7 @@ def test_decoder_holds_one_contig_at_a_time(tmp_path):
     open(path, "wb").write(b"".join(blocks))
     total = len(payload)
     assert total > 120e6
-    nb = bamio.NativeBam(path, 8)
+    nb = bamio.NativeBam(path, 8, keep_bytes=0)     # (the bounded-memory form; lcr_bam_open keeps a file of this size inflated: below)
     assert nb.n_records == len(offs) * 35
     now, peak = nb.resident()
     assert now <= 2 ** 20, now                                     # open validates in the scan window: no contig is resident afterwards
@@ -238,6 +238,19 @@ def test_decoder_holds_one_contig_at_a_time(tmp_path):
     assert len(orecs) == 20 * len(want) and [r["name"] for r in orecs[::20]] == [r["name"] for r in want]
     tagged = [r for r in orecs if r["name"] == name]
     assert tagged and all(b"HPi" + struct.pack("<i", 1) in r["raw"][r["aux_off"]:] and b"PSI" + struct.pack("<I", 777) in r["raw"][r["aux_off"]:] for r in tagged)
+    # a file within keep_bytes (lcr_bam_open: 4 GiB) is inflated ONCE, at open, and stays inflated: same spans, batches, output
+    nk = bamio.NativeBam(path, 8)
+    assert total <= nk.resident()[0] <= total + 2 ** 21
+    s2, e2 = nk.spans(1, **flt)
+    assert np.array_equal(s2, s) and np.array_equal(e2, e)
+    bk = nk.batch(2, regions, win, **flt)
+    for f in _abi.ReadBatch.FIELDS + ["read_begin"]:
+        assert np.array_equal(getattr(bk, f), getattr(b2, f)), f
+    outk = str(tmp_path / "phased_keep.bam")
+    nk.write_phased(outk, [(0, 16729960, 13256)], [name], [1], [777], level=1)
+    assert bamio.bgzf_decompress(outk) == bamio.bgzf_decompress(out)
+    assert nk.resident()[1] <= total + len(parts[0]) * 0.2 + 18 * 2 ** 20
+    nk.close()
     nb.close()
 
 
