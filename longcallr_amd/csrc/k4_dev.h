@@ -34,6 +34,11 @@ __device__ __forceinline__ bool tie_row_flips(const int32_t* rp, const int32_t* 
                                               int sigma, const double* le, const double* l1e, bool* het) {
   double lp = 0.0, lm = 0.0;   // log_q2 (sigma = +1), log_q3 (sigma = -1)
   bool h = false;
+  if (rp[row + 1] - rp[row] <= 2) {   // two entries: a tie means a + b against b + a -- the same double; nothing to decide
+    for (int e = rp[row]; e < rp[row + 1]; e++) h |= et[pc[e]] == 0;
+    *het = h;
+    return false;
+  }
   for (int e = rp[row]; e < rp[row + 1]; e++) {
     const int i = pc[e];
     const uint8_t v = pv[e];

@@ -458,40 +458,32 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
   if (tid == 0) P.st_obj[slot] = best;
 }
 
-// the f64 scores of the rows in `tm` (fixed-point ties at rows with a het entry; bit = row - r_a): q < qn of phase.rs:77-96, 845-858
-// -> flip
-__device__ __forceinline__ unsigned long long enum_tie_rows_f64(unsigned long long tm, const unsigned long long win, const uint32_t dneg, const uint32_t eta0,
-                                                             const uint32_t etap, const int r_a, const uint16_t* rp, const uint16_t* ent16, const double* lut) {
-  unsigned long long ft = 0;
-  while (tm) {
-    const int roff = __ffsll((long long)tm) - 1;
-    tm &= tm - 1;
-    const int row = r_a + roff;
-    const uint32_t sneg = (uint32_t)(win >> roff) & 1u;
-    double lp = 0.0, lm = 0.0;   // the running sums log_q2 (sigma = +1) and log_q3 (sigma = -1), entry order
-    const int x1 = rp[row + 1];
-    for (int x = rp[row]; x < x1; x += 4) {   // four entries per round trip: their words, then their table values, then the adds in order
-      uint32_t v[4]; double tp[4], tm4[4];
+// the f64 scores of ONE row whose fixed-point sums tie (a row with a het entry and more than two entries): q < qn of
+// phase.rs:77-96, 845-858 -> flip.  sneg: the row's sigma is -1.
+__device__ __forceinline__ bool enum_tie_row_flips(const int row, const uint32_t sneg, const uint32_t dneg, const uint32_t eta0, const uint32_t etap,
+                                                   const uint16_t* rp, const uint16_t* ent16, const double* lut) {
+  double lp = 0.0, lm = 0.0;   // the running sums log_q2 (sigma = +1) and log_q3 (sigma = -1), entry order
+  const int x1 = rp[row + 1];
+  for (int x = rp[row]; x < x1; x += 4) {   // four entries per round trip: their words, then their table values, then the adds in order
+    uint32_t v[4]; double tp[4], tm4[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = ent16[min(x + u, x1 - 1)];
+    for (int u = 0; u < 4; u++) v[u] = ent16[min(x + u, x1 - 1)];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint32_t i = v[u] & 31u, pbit = (v[u] >> 5) & 1u, q = (v[u] >> 6) & 31u;
-        const uint32_t isHet = (eta0 >> i) & 1u;
-        const uint32_t mp = isHet ? (pbit ^ ((dneg >> i) & 1u)) : (((etap >> i) & 1u) ? pbit : pbit ^ 1u);
-        const uint32_t mm = isHet ? mp ^ 1u : mp;
-        tp[u] = lut[(mp ? 32u : 0u) + q]; tm4[u] = lut[(mm ? 32u : 0u) + q];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) if (x + u < x1) { lp += tp[u]; lm += tm4[u]; }
+    for (int u = 0; u < 4; u++) {
+      const uint32_t i = v[u] & 31u, pbit = (v[u] >> 5) & 1u, q = (v[u] >> 6) & 31u;
+      const uint32_t isHet = (eta0 >> i) & 1u;
+      const uint32_t mp = isHet ? (pbit ^ ((dneg >> i) & 1u)) : (((etap >> i) & 1u) ? pbit : pbit ^ 1u);
+      const uint32_t mm = isHet ? mp ^ 1u : mp;
+      tp[u] = lut[(mp ? 32u : 0u) + q]; tm4[u] = lut[(mm ? 32u : 0u) + q];
     }
-    if (lp == lm) continue;   // q == qn: nothing to decide (the usual case: the het entries' terms pair up in place)
-    const double l1 = sneg ? lm : lp, l1n = sneg ? lp : lm;
-    const double den = lp + lm;
-    const double q = 1.0 - l1 / den, qn = 1.0 - l1n / den;
-    if (q < qn) ft |= 1ull << roff;
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (x + u < x1) { lp += tp[u]; lm += tm4[u]; }
   }
-  return ft;
+  if (lp == lm) return false;   // q == qn: nothing to decide (the usual case: the het entries' terms pair up in place)
+  const double l1 = sneg ? lm : lp, l1n = sneg ? lp : lm;
+  const double den = lp + lm;
+  const double q = 1.0 - l1 / den, qn = 1.0 - l1n / den;
+  return q < qn;
 }
 
 // tiles of restarts of regions whose per-lane share is <= CK entries (host decides).  Every restart stores its objective and --
@@ -557,6 +549,8 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
   const int lane = tid & 63, wave = tid >> 6;
   unsigned long long* sgb = (unsigned long long*)(lds + L.state + wave * L.stride);   // bit = 1: sigma == -1
   unsigned long long* Macc = sgb + (R + 63) / 64 + 1;
+  uint32_t* tq = (uint32_t*)(Macc + 32);                 // queue of the wave's tied rows (sigma step)
+  uint32_t* tq_n = tq + ENUM_TQ;
   const int r_a = first_row[lane];
   // CK > 0: the lane's entries live in VGPRs; CK == 0: any share size, entries are re-read from LDS
   constexpr int NREG = CK > 0 ? CK : 1;
@@ -670,10 +664,32 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
         if (P.tie_arith < 2) { if (tm) n_tie_unres += (uint32_t)__popcll((unsigned long long)tm); }
         else if (__ballot(tm != 0)) {
           n_tie_f64 += (uint32_t)__popcll((unsigned long long)tm);
-          const mask_t ft = (mask_t)enum_tie_rows_f64((unsigned long long)tm, (unsigned long long)win, dneg, eta0, etap, r_a, rp, ent16, lut);
-          n_tie_flip += (uint32_t)__popcll((unsigned long long)ft);
-          fm |= ft;
-          if (!any && __ballot(ft != 0)) n_step++;   // only tie flips: "no improvement" (check_new_haplotag's sums are not formed)
+          // The tied rows of the whole wave go through a queue and are scored a lane each, whoever owns them (a lane that
+          // scored its own rows one after the other kept the wave waiting for the lane with the most: HiFi data ties in ~60
+          // rows per step).  A row of two entries ties only with both at het sites, one matching and one not, at one quality:
+          // log_q2 = a + b, log_q3 = b + a -- the same double (the first addition, to 0.0, is exact): not queued.
+          if (lane == 0) *tq_n = 0;
+          wave_lds_sync();
+          mask_t own = 0;   // (rows the queue had no room for)
+          for (mask_t t2 = tm; t2; t2 &= t2 - 1) {
+            const int roff = __ffsll((long long)(unsigned long long)t2) - 1, row = r_a + roff;
+            if (rp[row + 1] - rp[row] <= 2) continue;
+            const uint32_t slot = atomicAdd(tq_n, 1u);
+            if (slot < ENUM_TQ) tq[slot] = (uint32_t)row | ((uint32_t)(win >> roff) & 1u) << 16; else own |= (mask_t)1 << roff;
+          }
+          wave_lds_sync();
+          const uint32_t nq = min(*tq_n, ENUM_TQ);
+          uint32_t nfl = 0;
+          for (uint32_t j = lane; j < nq; j += 64) {
+            const uint32_t ent = tq[j], row = ent & 0xffffu;
+            if (enum_tie_row_flips((int)row, ent >> 16, dneg, eta0, etap, rp, ent16, lut)) { atomicXor(&sgb[row >> 6], 1ull << (row & 63u)); nfl++; }
+          }
+          for (; own; own &= own - 1) {
+            const int roff = __ffsll((long long)(unsigned long long)own) - 1;
+            if (enum_tie_row_flips(r_a + roff, (uint32_t)(win >> roff) & 1u, dneg, eta0, etap, rp, ent16, lut)) { fm |= (mask_t)1 << roff; nfl++; }
+          }
+          n_tie_flip += nfl;
+          if (!any && __ballot(nfl != 0)) n_step++;   // only tie flips: "no improvement" (check_new_haplotag's sums are not formed)
         }
         if (fm) {
           const unsigned long long fm64 = (unsigned long long)fm;

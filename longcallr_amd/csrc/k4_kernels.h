@@ -14,10 +14,11 @@ constexpr uint32_t ENUM_LDS_BYTES = 48 * 1024;
 
 // LDS image: wl2[32] {lo23, hi24 (signed)} | lut64[64] (log10 eps_q, log10 (1 - eps_q): the f64 tie path) | csr[E] {lo | meta << 24,
 //            hi | row_in_lane << 24} | csc[E] | rp[R+1] u16 | first_row[65] u16 | ent16[E] (row-order entries of the f64 tie paths) |
-//            per wave: sigma bits (u64 words, +1 pad) and M[32]
+//            per wave: sigma bits (u64 words, +1 pad), M[32] and the queue of tied rows
 //   csr meta : bits 0-4 SNP, 5 allele (1: p == +1), 6 last entry of its row, 7 valid
 //   csc      : bits 0-15 row, 16-20 SNP, 21 allele, 22-26 q, 31 valid
 //   ent16    : bits 0-4 SNP, 5 allele, 6-10 q, 11 last entry of its row
+constexpr uint32_t ENUM_TQ = 126;     // tied rows a wave queues per sigma step (+ 2 words: the count)
 constexpr uint32_t ENUM_TCAP = 256;   // configurations of maximal objective compared at a time (enum_resolve): a lane each
 struct EnumLayout { uint32_t lut, csr, csc, rp, first_row, ent16, state, stride, total; };
 __host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E) {
@@ -32,7 +33,7 @@ __host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E) {
   L.ent16 = o; o += 2 * ((E + 3) & ~3u);
   o = (o + 15) & ~15u;
   L.state = o;
-  L.stride = 8 * ((R + 63) / 64 + 1) + 8 * 32;
+  L.stride = 8 * ((R + 63) / 64 + 1) + 8 * 32 + 4 * (ENUM_TQ + 2);
   o += ENUM_WAVES * L.stride;
   L.total = o;
   return L;
