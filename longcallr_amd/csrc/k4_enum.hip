@@ -594,7 +594,11 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
   uint32_t n_tie_f64 = 0, n_tie_flip = 0, n_dtie = 0, n_step = 0, n_tie_unres = 0;   // census of this wave's restarts (lane 0 adds them up at the end)
   // rows of a lane as bits of a mask: 32 bits in the register-resident form (the host sends a region there only if no lane owns
   // more than 32 rows), 64 in the streaming form
+#ifdef ENUM_MASK64
+  using mask_t = unsigned long long;
+#else
   using mask_t = typename std::conditional<(CK > 0), uint32_t, unsigned long long>::type;
+#endif
   // one restart by this wave: its objective goes to job_obj[], its final state to st_words
   auto run_restart = [&](const uint32_t e_in) {
     const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_in);   // (wave-uniform: keep it in SGPRs)

@@ -671,7 +671,10 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     constexpr int NCLS = 5;
     std::vector<EnumSpan> spans[NCLS];
     size_t n_t[NCLS] = {0, 0, 0, 0, 0};   // tiles per class = grid of the class's kernel
-    const uint32_t per_of[NCLS] = {1u, 1u, ENUM_TILE_JOBS, 2u * ENUM_WAVES, 1u};
+#ifndef ENUM_PER3
+#define ENUM_PER3 2u
+#endif
+    const uint32_t per_of[NCLS] = {1u, 1u, ENUM_TILE_JOBS, ENUM_PER3 * ENUM_WAVES, 1u};
     std::vector<int64_t> job_base(ng, 0), st_base(ng, 0);   // st_base: first word of the region's saved restart states (classes 2 / 3)
     int64_t nj = 0, st_words = 0;
     uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0}, res_lds[NCLS] = {0, 0, 0, 0, 0};   // (res_lds: k4_enum_resolve's image of the class's largest region)
@@ -682,7 +685,11 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       const EnumLayout EL = enum_layout(st.R, st.E);
       int cls = 4;
       if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_BYTES && st.max_rows <= 64)
-        cls = force_stream ? 3 : (st.max_n <= 32 && st.max_rows <= 32 ? 2 : 3);   // (register-resident form: <= 32 entries and <= 32 rows per lane)   // (the 8 / 16 instantiations: one launch has one tail; a 40-entry one: below)
+#ifdef ENUM_MASK64
+        cls = force_stream ? 3 : (st.max_n <= 32 ? 2 : 3);
+#else
+        cls = force_stream ? 3 : (st.max_n <= 32 && st.max_rows <= 32 ? 2 : 3);
+#endif   // (register-resident form: <= 32 entries and <= 32 rows per lane)   // (the 8 / 16 instantiations: one launch has one tail; a 40-entry one: below)
       if (cls < 4) { lds_need[cls] = std::max(lds_need[cls], EL.total); res_lds[cls] = std::max(res_lds[cls], resolve_layout((uint32_t)st.R, (uint32_t)st.E, (uint32_t)S).total); }
       job_base[g] = nj;
       const uint64_t n = 1ull << S;
@@ -764,7 +771,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   // second only finds room as the first drains.  A few chain regions go first (C3: sixteen of them, 0.2 ms of work that
   // used to end with the enumeration 0.47 ms after its launch: phase stage 0.83 -> 0.72 ms); when they would fill the
   // device themselves (ONT-dRNA: 368) the few enumeration regions go first.
-  const bool chain_first = !chain_slots.empty() && (int)chain_slots.size() * 4 <= std::max(1, k4_grid_blocks());
+  // (round 4: the enumeration's host preparation now ends ~50 us earlier when it goes first, and its kernel + k4_enum_resolve + k4_post
+  // are the critical path: C3 2.48 -> 2.44 ms, C4 5.59 -> 5.57 with the chain regions behind it in every case)
+  const bool chain_first = false;
   if (chain_first) { const int rc = launch_chain_regions(); if (rc) return rc; }
   { const int rc = launch_enum_regions(); if (rc) return rc; }
   if (!chain_first) { const int rc = launch_chain_regions(); if (rc) return rc; }
