@@ -61,11 +61,11 @@ __device__ __forceinline__ bool tie_row_decide(const PhaseDev& P, const int32_t*
   if (P.tie_arith < 2) {
     het = false;
     for (int e = rp[row]; e < rp[row + 1]; e++) het |= et[pc[e]] == 0;
-    if (het) atomicAdd(&P.tie_ctr[TIE_SIGMA_UNRES], 1ull);
+    if (het) TIE_COUNT(P.tie_ctr, TIE_SIGMA_UNRES, 1ull);
     return false;
   }
   const bool f = tie_row_flips(rp, pc, pv, row, dl, et, sigma, le, l1e, &het);
-  if (het) { atomicAdd(&P.tie_ctr[TIE_SIGMA_F64], 1ull); if (f) atomicAdd(&P.tie_ctr[TIE_SIGMA_FLIPS], 1ull); }
+  if (het) { TIE_COUNT(P.tie_ctr, TIE_SIGMA_F64, 1ull); if (f) TIE_COUNT(P.tie_ctr, TIE_SIGMA_FLIPS, 1ull); }
   return f;
 }
 

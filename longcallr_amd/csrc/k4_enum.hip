@@ -69,10 +69,17 @@ __device__ __forceinline__ EnumTile enum_tile_of(const PhaseDev& P, const EnumSp
 //   3. strictly-greater-replaces over the list in order (phase.rs:1117); the winner's state goes to the region's result
 //      slots (no re-run of the winning restart).
 // ---------------------------------------------------------------------------------------------
+// measurement build (-DENUM_PROF): the slowest workgroup's time (10 ns units) up to a point of k4_enum_resolve -> tie census slot i
+#ifdef ENUM_PROF
+#define ENUM_PT(i) do { if (threadIdx.x == 0) atomicMax(&P.tie_ctr[i], (unsigned long long)((long long)wall_clock64() - prof_t0)); } while (0)
+#else
+#define ENUM_PT(i) do { } while (0)
+#endif
 __global__ void __launch_bounds__(64 * ENUM_WAVES)
 k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* __restrict__ job_base, const long long* __restrict__ job_obj,
                 const int64_t* __restrict__ st_base, const unsigned long long* __restrict__ st_words) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const long long prof_t0 = (long long)wall_clock64(); (void)prof_t0;
   const int slot = spans[blockIdx.x].slot;
   const RegionDev rd = P.reg[slot];
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
@@ -102,23 +109,22 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
   __shared__ uint32_t s_wcnt[ENUM_WAVES], s_dif[ENUM_WAVES], s_ntied;
   constexpr uint32_t TLCAP = 2048;
   uint16_t* tl = (uint16_t*)(lds + L.res + 16 * ENUM_TCAP + 96 * 10 + 16);   // [TLCAP] the restarts of maximal objective
-  __shared__ uint32_t s_win;
-  __shared__ double s_winsum;
+  __shared__ uint32_t s_win, s_wj[ENUM_WAVES];
+  __shared__ double s_winsum, s_wsum[ENUM_WAVES];
   __shared__ int s_flat;
-  auto ld_obj = [&](uint32_t e) { return __hip_atomic_load(&o[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  auto ld_st = [&](uint32_t e, uint32_t w) { return __hip_atomic_load(&st[(size_t)e * sw + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // (plain cached loads: the restarts' kernel has completed -- k4_enum_resolve is a launch of its own behind it)
+  auto ld_obj = [&](uint32_t e) { return o[e]; };
+  auto ld_st = [&](uint32_t e, uint32_t w) { return st[(size_t)e * sw + w]; };
   // ---- stage the region: row pointers, the row-order entries (SNP | allele | q | last-of-row), the table of libm values
   if (tid < 64) lut[tid] = (tid & 31) < 31 ? (tid < 32 ? P.lut64->le[tid] : P.lut64->l1e[tid - 32]) : 0.0;
   { const int32_t* g_rp = P.prow_ptr + rd.rp_off; for (int r = tid; r <= R; r += nt) rp[r] = (uint16_t)g_rp[r]; }
-  __syncthreads();
-  for (int r = tid; r < R; r += nt) {
-    const int e0 = rp[r], e1 = rp[r + 1];
-    for (int e = e0; e < e1; e++) {
-      const uint32_t v = P.pval[rd.e_off + e];
-      ent16[e] = (uint16_t)(((uint32_t)P.pcol[rd.e_off + e] & 31u) | (v & 32u) | ((v & 31u) << 6) | (e + 1 == e1 ? 0x800u : 0u));
-    }
+  for (int e = tid; e < (int)E; e += nt) {   // (a thread per entry; the last-of-row marks follow from the row pointers)
+    const uint32_t v = P.pval[rd.e_off + e];
+    ent16[e] = (uint16_t)(((uint32_t)P.pcol[rd.e_off + e] & 31u) | (v & 32u) | ((v & 31u) << 6));
   }
-  const long long prof_t0 = (long long)wall_clock64(); (void)prof_t0;
+  __syncthreads();
+  for (int r = tid; r < R; r += nt) if (rp[r + 1] > rp[r]) ent16[rp[r + 1] - 1] |= 0x800u;
+  ENUM_PT(0);
   // ---- the maximal objective and the restarts that have it, in ascending order (tl[0 .. n_tied)); do all of them carry the
   // first one's signature?  (the objectives of the first 1 024 restarts stay in registers between the two sweeps)
   constexpr int OV = 4;
@@ -157,24 +163,30 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
   dif = __ballot(dif != 0) ? 1u : 0u;
   if (lane == 0) s_dif[wave] = dif;
   if (n_tied_all > TLCAP || n_jobs > 65536u) {   // (more configurations of maximal objective than the list holds: first maximum wins, counted)
-    if (tid == 0) atomicAdd(&P.tie_ctr[TIE_BEST_UNRES], 1ull);
+    if (tid == 0) TIE_COUNT(P.tie_ctr, TIE_BEST_UNRES, 1ull);
     dif = 0;
     if (lane == 0) s_dif[wave] = 0;
   }
   if (tid == 0) { s_win = first; s_winsum = 0.0; s_flat = 1; }
   __syncthreads();
   for (int w = 0; w < ENUM_WAVES; w++) dif |= s_dif[w];
+  ENUM_PT(1);
 #ifdef ENUM_ABL_NOSUM
   dif = 0;
 #endif
-  if (dif && P.tie_arith < 1) { if (tid == 0) atomicAdd(&P.tie_ctr[TIE_BEST_UNRES], 1ull); dif = 0; }
+  if (dif && P.tie_arith < 1) { if (tid == 0) TIE_COUNT(P.tie_ctr, TIE_BEST_UNRES, 1ull); dif = 0; }
+#ifdef ENUM_PROF
+  long long prof_t5 = 0;
+  __shared__ uint32_t s_tloc[ENUM_WAVES], s_tfull[ENUM_WAVES];
+  if (tid < ENUM_WAVES) { s_tloc[tid] = 0; s_tfull[tid] = 0; }
+#endif
   if (dif) {
-    if (tid == 0) atomicAdd(&P.tie_ctr[TIE_BEST_F64], 1ull);
+    if (tid == 0) TIE_COUNT(P.tie_ctr, TIE_BEST_F64, 1ull);
     // ---- the reference configuration
     const unsigned long long rm0 = ld_st(first, nk);
     const uint32_t r_dneg = (uint32_t)rm0, r_eta0 = (uint32_t)(rm0 >> 32), r_etap = (uint32_t)ld_st(first, nk + 1);
     { int empty = 0; for (int k = tid; k < R; k += nt) empty |= rp[k] == rp[k + 1] ? 1 : 0; if (empty) s_flat = 0; }   // (rows without an entry: min_linkers = 0)
-    for (uint32_t x = E + tid; x < ((E + 3u) & ~3u); x += nt) ent16[x] = 0;   // padding of the last 8-byte read
+    for (uint32_t x = E + tid; x < ((E + 7u) & ~7u); x += nt) ent16[x] = 0;   // padding of the last 16-byte read
     for (uint32_t k = tid; k < nk; k += nt) sg_ref[k] = ld_st(first, k);
     // rows by their first het site, and the groups of het sites that rows tie together: a configuration whose delta is mirrored
     // on whole groups (independent groups of SNPs settle independently) differs from the reference exactly in the rows whose
@@ -202,44 +214,45 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
       if (lane < 32) s_grp[lane] = g;
     }
     __syncthreads();
+    ENUM_PT(2);
     const bool prefix_ok = true;
     // a configuration's terms added in the reference's order; ps_out != nullptr: the running sum before every row is kept
-    auto full_sum = [&](const uint32_t e, const uint32_t dneg, const uint32_t eta0, const uint32_t etap, double* ps_out) -> double {
+    auto full_sum = [&](const uint32_t e, const uint32_t dneg, const uint32_t eta0, const uint32_t etap) -> double {
       // match = [p == x] as three bit operations per entry (x depends on sigma only at het sites):
       //   het site: p == sigma * delta <=> pbit ^ sneg ^ dneg_i = 1;  hom site: p == eta <=> pbit ^ [eta_i == -1] = 1
       //   => match = pbit ^ c_i ^ (sneg & het_i),  c = (dneg & eta0) | (~etap & ~eta0)
       const uint32_t cm = (dneg & eta0) | (~etap & ~eta0);
       double acc = 0.0;
       if (s_flat) {
-        // the entries as one flat run (every row has an entry: the last-entry flags count the rows), four per 8-byte read;
-        // the entry words are the same for every lane: decoded on the scalar unit
+        // the entries as one flat run (every row has an entry: the last-entry flags count the rows), eight per 16-byte read;
+        // the entry words are the same for every lane: decoded on the scalar unit.  The next read and this batch's eight
+        // table values are in flight while the previous adds run.
         unsigned long long wsg = ld_st(e, 0), wnext = 0;
         int k = 0;
         uint32_t sneg = 0u - ((uint32_t)wsg & 1u);   // all ones: sigma == -1
-        const uint32_t E4 = (E + 3u) & ~3u;
-        if (ps_out) ps_out[0] = 0.0;
-        for (uint32_t x = 0; x < E4; x += 4) {
-          const uint2 raw = *(const uint2*)(ent16 + x);
-          const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.x), r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.y);
-          const uint32_t v[4] = {r0 & 0xffffu, r0 >> 16, r1 & 0xffffu, r1 >> 16};
-          double tv[4];
-          uint32_t rowend = 0;
+        const uint32_t E8 = (E + 7u) & ~7u;
+        uint4 nxt = E8 ? *(const uint4*)ent16 : make_uint4(0, 0, 0, 0);
+        for (uint32_t x = 0; x < E8; x += 8) {
+          const uint4 raw = nxt;
+          if (x + 8 < E8) nxt = *(const uint4*)(ent16 + x + 8);
+          const uint32_t r[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)raw.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.y),
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.w)};
+          double tv[8];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const uint32_t i = v[u] & 31u, pbit = (v[u] >> 5) & 1u, q = (v[u] >> 6) & 31u;   // (scalar)
+          for (int u = 0; u < 8; u++) {
+            const uint32_t v = (r[u >> 1] >> ((u & 1) * 16)) & 0xffffu;
+            const uint32_t i = v & 31u, pbit = (v >> 5) & 1u, q = (v >> 6) & 31u;   // (scalar)
             const uint32_t match = (pbit ^ (cm >> i) ^ ((sneg & eta0) >> i)) & 1u;
             tv[u] = lut[(match << 5) + q];
-            if (v[u] & 0x800u) {   // row end (uniform): the next row's sigma
-              rowend |= 1u << u;
+            if (v & 0x800u) {   // row end (uniform): the next row's sigma
               k++;
               if ((k & 63) == 32 && (uint32_t)(k >> 6) + 1 < nk) wnext = ld_st(e, (uint32_t)(k >> 6) + 1);
               if ((k & 63) == 0) wsg = wnext;
               sneg = 0u - ((uint32_t)(wsg >> (k & 63)) & 1u);
             }
           }
-          int kk = k - __popc(rowend);
 #pragma unroll
-          for (int u = 0; u < 4; u++) if (x + u < E) { acc += tv[u]; if (ps_out && (rowend >> u & 1u)) ps_out[++kk] = acc; }
+          for (int u = 0; u < 8; u++) if (x + u < E) acc += tv[u];
         }
       } else {
         unsigned long long wsg = 0;
@@ -269,23 +282,29 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
       for (uint32_t x = E + tid; x < ((E + 7u) & ~7u); x += nt) pse[x] = 0.0;   // (padding of the last batch)
     }
     __syncthreads();
+    ENUM_PT(3);
     // ... and their running sum by ONE lane: the adds are the reference's chain (phase.rs:257-276), eight terms per round trip
+    // (the next batch's terms are on their way while this one's adds run)
     if (tid == 0) {
       double acc = 0.0;
       const uint32_t E8 = (E + 7u) & ~7u;
-      uint32_t x = 0;
-      for (; x < E8; x += 8) {
-        double t[8];
+      double t[8], n8[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) t[u] = pse[x + u];
+      for (int u = 0; u < 8; u++) t[u] = E8 ? pse[u] : 0.0;
+      for (uint32_t x = 0; x < E8; x += 8) {
+        const uint32_t xn = x + 8 < E8 ? x + 8 : x;
+#pragma unroll
+        for (int u = 0; u < 8; u++) n8[u] = pse[xn + u];
 #pragma unroll
         for (int u = 0; u < 8; u++) { acc += t[u]; t[u] = acc; }
 #pragma unroll
         for (int u = 0; u < 8; u++) pse[x + u] = t[u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = n8[u];
       }
-      for (; x < E; x++) { acc += pse[x]; pse[x] = acc; }
     }
     __syncthreads();
+    ENUM_PT(4);
     // EVENTS of the reference's chain: an addition s + t that stays inside s's binade rounds t on its own (s is a multiple of the
     // binade's ulp), so two running sums a few ulps apart that take the same terms KEEP their distance -- except where the sum
     // crosses a power of two (the ulp doubles) or s + t lies exactly half way between two doubles (ties-to-even looks at s).
@@ -313,14 +332,12 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
       }
     }
     __syncthreads();
-    if (tid == 0) {   // ascending order (a few dozen)
+    {   // ascending order: every event finds its rank (an entry has at most one event)
       const uint32_t ne = min(s_nev, EVCAP);
-      for (uint32_t a2 = 1; a2 < ne; a2++) {
-        const uint16_t xx = ev_x[a2]; const double tt = ev_t[a2];
-        int b2 = (int)a2 - 1;
-        while (b2 >= 0 && ev_x[b2] > xx) { ev_x[b2 + 1] = ev_x[b2]; ev_t[b2 + 1] = ev_t[b2]; b2--; }
-        ev_x[b2 + 1] = xx; ev_t[b2 + 1] = tt;
-      }
+      uint16_t xx = 0; double tt = 0.0; uint32_t rank = 0;
+      if ((uint32_t)tid < ne) { xx = ev_x[tid]; tt = ev_t[tid]; for (uint32_t j = 0; j < ne; j++) rank += ev_x[j] < xx ? 1u : 0u; }
+      __syncthreads();
+      if ((uint32_t)tid < ne) { ev_x[rank] = xx; ev_t[rank] = tt; }
     }
     __syncthreads();
     const bool events_ok = s_nev <= EVCAP;
@@ -328,8 +345,9 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
     if (tid == 0) { atomicMax(&P.tie_ctr[3], (unsigned long long)s_nev); if (!events_ok) atomicAdd(&P.tie_ctr[5], 1ull); atomicAdd(&P.tie_ctr[1], (unsigned long long)s_nev); }
 #endif
     const uint32_t n_ev = min(s_nev, EVCAP);
+    ENUM_PT(5);
 #ifdef ENUM_PROF
-    if (tid == 0) { atomicAdd(&P.tie_ctr[6], (unsigned long long)((long long)wall_clock64() - prof_t0)); atomicMax(&P.tie_ctr[2], (unsigned long long)((long long)wall_clock64() - prof_t0)); }
+    prof_t5 = (long long)wall_clock64();
 #endif
     // ---- chunks of the restarts of maximal objective, in ascending order
     for (uint32_t cur = 0; cur < n_tied; cur += ENUM_TCAP) {
@@ -337,6 +355,9 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
       const uint32_t n = min(ENUM_TCAP, n_tied - cur);
       if ((uint32_t)tid < n) t_e[tid] = tl[cur + tid];
       __syncthreads();
+#ifdef ENUM_PROF
+      const long long pf0 = (long long)wall_clock64();
+#endif
       // ---- a lane per configuration: rows that differ from the reference's, each re-added from the reference's running sum
       bool fallback = false;
       uint32_t my_e = 0, dneg = 0, eta0 = 0, etap = 0;
@@ -421,30 +442,43 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
         }
       }
 #ifdef ENUM_PROF
-      const long long pf0 = (long long)wall_clock64();
+      const long long pf1 = (long long)wall_clock64();
+      if (lane == 0) atomicAdd(&s_tloc[wave], (uint32_t)(pf1 - pf0));
 #endif
-      if (__ballot(fallback)) { if (fallback) t_sum[tid] = full_sum(my_e, dneg, eta0, etap, nullptr);
+      if (__ballot(fallback)) { if (fallback) t_sum[tid] = full_sum(my_e, dneg, eta0, etap); }
 #ifdef ENUM_PROF
-        if (lane == 0) { atomicAdd(&P.tie_ctr[7], (unsigned long long)((long long)wall_clock64() - pf0)); atomicAdd(&P.tie_ctr[4], 1ull); atomicAdd(&P.tie_ctr[3], (unsigned long long)E); }
+      if (lane == 0) atomicAdd(&s_tfull[wave], (uint32_t)((long long)wall_clock64() - pf1));
 #endif
-      }
 #ifdef ENUM_VERIFY   // (measurement build: every sum that left the reference's chain, once more by adding all terms)
       { const bool dv = (uint32_t)tid < n && !fallback && t_sum[tid] != (E ? pse[E - 1] : 0.0);
-        if (__ballot(dv)) { if (dv) { atomicAdd(&P.tie_ctr[7], 1ull); if (full_sum(my_e, dneg, eta0, etap, nullptr) != t_sum[tid]) atomicAdd(&P.tie_ctr[2], 1ull); } }
+        if (__ballot(dv)) { if (dv) { atomicAdd(&P.tie_ctr[7], 1ull); if (full_sum(my_e, dneg, eta0, etap) != t_sum[tid]) atomicAdd(&P.tie_ctr[2], 1ull); } }
         if (fallback) atomicAdd(&P.tie_ctr[6], 1ull); }
 #endif
       __syncthreads();
-      if (tid == 0) {   // phase.rs:1117: strictly greater replaces; the first restart of the list is the first "best"
-        uint32_t j0 = 0;
-        if (cur == 0) { s_win = t_e[0]; s_winsum = t_sum[0]; j0 = 1; }
-        for (uint32_t j = j0; j < n; j++) if (t_sum[j] > s_winsum) { s_win = t_e[j]; s_winsum = t_sum[j]; }
+      {   // phase.rs:1117: strictly greater replaces -- the largest sum, the earliest of equals (a reduction per wave, then over the waves)
+        double bs = (uint32_t)tid < n ? t_sum[tid] : -__builtin_huge_val();
+        uint32_t bj = (uint32_t)tid;
+        for (int d = 32; d >= 1; d >>= 1) {
+          const double os = __shfl_xor(bs, d, 64); const uint32_t oj = (uint32_t)__shfl_xor((int)bj, d, 64);
+          if (os > bs || (os == bs && oj < bj)) { bs = os; bj = oj; }
+        }
+        if (lane == 0) { s_wsum[wave] = bs; s_wj[wave] = bj; }
+        __syncthreads();
+        if (tid == 0) {
+          double cb = s_wsum[0]; uint32_t cj = s_wj[0];
+          for (int w = 1; w < ENUM_WAVES; w++) if (s_wsum[w] > cb) { cb = s_wsum[w]; cj = s_wj[w]; }
+          if (cur == 0 || cb > s_winsum) { s_win = t_e[cj]; s_winsum = cb; }
+        }
       }
       __syncthreads();
     }
   }
+  if (dif) ENUM_PT(6);
 #ifdef ENUM_PROF
-  if (tid == 0 && dif) { atomicAdd(&P.tie_ctr[5], (unsigned long long)((long long)wall_clock64() - prof_t0)); atomicMax(&P.tie_ctr[1], (unsigned long long)((long long)wall_clock64() - prof_t0)); }
-  if (tid == 0 && !dif) atomicMax(&P.tie_ctr[0], (unsigned long long)((long long)wall_clock64() - prof_t0));
+  __shared__ unsigned long long s_prof;
+  if (tid == 0) s_prof = 0;
+  __syncthreads();
+  if (tid == 0 && dif) s_prof = ((unsigned long long)(((long long)wall_clock64() - prof_t5) & 0xfffff) << 24) | ((unsigned long long)min(max(max(s_tloc[0], s_tloc[1]), max(s_tloc[2], s_tloc[3])) >> 4, 4095u) << 12) | min(max(max(s_tfull[0], s_tfull[1]), max(s_tfull[2], s_tfull[3])) >> 4, 4095u);
 #endif
   // ---- the winner's state -> the region's result slots
   const uint32_t we = s_win;
@@ -456,6 +490,21 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
   }
   for (int row = tid; row < R; row += nt) P.st_sigma[rd.sig_off + row] = (int8_t)(((ld_st(we, (uint32_t)row >> 6) >> (row & 63)) & 1ull) ? -1 : 1);
   if (tid == 0) P.st_obj[slot] = best;
+#ifdef ENUM_PROF
+  __syncthreads();
+  if (tid == 0) atomicMax(&P.tie_ctr[7], ((unsigned long long)(((long long)wall_clock64() - prof_t0) & 0xfffff) << 44) | s_prof);
+#endif
+}
+
+// wave64 inclusive add-scan, DPP row shifts / broadcasts (lanes without a source add 0)
+__device__ __forceinline__ int enum_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
 }
 
 // the f64 scores of ONE row whose fixed-point sums tie (a row with a het entry and more than two entries): q < qn of
@@ -599,6 +648,9 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
 #else
   using mask_t = typename std::conditional<(CK > 0), uint32_t, unsigned long long>::type;
 #endif
+  // my rows of more than two entries (the rows whose tie needs the f64 scores, see the sigma step)
+  mask_t bigm = 0;
+  for (int row = r_a; row < (int)first_row[lane + 1]; row++) if (rp[row + 1] - rp[row] > 2) bigm |= (mask_t)1 << (row - r_a);
   // one restart by this wave: its objective goes to job_obj[], its final state to st_words
   auto run_restart = [&](const uint32_t e_in) {
     const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_in);   // (wave-uniform: keep it in SGPRs)
@@ -672,17 +724,18 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
           // scored its own rows one after the other kept the wave waiting for the lane with the most: HiFi data ties in ~60
           // rows per step).  A row of two entries ties only with both at het sites, one matching and one not, at one quality:
           // log_q2 = a + b, log_q3 = b + a -- the same double (the first addition, to 0.0, is exact): not queued.
-          if (lane == 0) *tq_n = 0;
-          wave_lds_sync();
+          // Queue slots come from a scan of the lanes' counts (no atomic round trips).
           mask_t own = 0;   // (rows the queue had no room for)
-          for (mask_t t2 = tm; t2; t2 &= t2 - 1) {
-            const int roff = __ffsll((long long)(unsigned long long)t2) - 1, row = r_a + roff;
-            if (rp[row + 1] - rp[row] <= 2) continue;
-            const uint32_t slot = atomicAdd(tq_n, 1u);
-            if (slot < ENUM_TQ) tq[slot] = (uint32_t)row | ((uint32_t)(win >> roff) & 1u) << 16; else own |= (mask_t)1 << roff;
+          const mask_t tb = tm & bigm;
+          const int cnt = __popcll((unsigned long long)tb), incl = enum_incl_scan(cnt);
+          const uint32_t n_all = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+          uint32_t slot = (uint32_t)(incl - cnt);
+          for (mask_t t2 = tb; t2; t2 &= t2 - 1, slot++) {
+            const int roff = __ffsll((long long)(unsigned long long)t2) - 1;
+            if (slot < ENUM_TQ) tq[slot] = (uint32_t)(r_a + roff) | ((uint32_t)(win >> roff) & 1u) << 16; else own |= (mask_t)1 << roff;
           }
-          wave_lds_sync();
-          const uint32_t nq = min(*tq_n, ENUM_TQ);
+          if (n_all) wave_lds_sync();
+          const uint32_t nq = min(n_all, ENUM_TQ);
           uint32_t nfl = 0;
           for (uint32_t j = lane; j < nq; j += 64) {
             const uint32_t ent = tq[j], row = ent & 0xffffu;
@@ -827,25 +880,22 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
     }
     // (device-coherent stores: read by the region's last tile, possibly on another XCD)
     unsigned long long* stp = st_reg + (size_t)e * stw;
-    if (keep) for (int k = lane; k < nk; k += 64) __hip_atomic_store(&stp[k], sgb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (plain stores: their reader is the next launch, k4_enum_resolve)
+    if (keep) for (int k = lane; k < nk; k += 64) stp[k] = sgb[k];
     if (lane == 0) {
-      if (keep) {
-        __hip_atomic_store(&stp[nk], (unsigned long long)dneg | ((unsigned long long)eta0 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&stp[nk + 1], (unsigned long long)etap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&stp[nk + 2], sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __hip_atomic_store(&job_obj[job_base[t.slot] + e], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (keep) { stp[nk] = (unsigned long long)dneg | ((unsigned long long)eta0 << 32); stp[nk + 1] = (unsigned long long)etap; stp[nk + 2] = sig; }
+      job_obj[job_base[t.slot] + e] = total;
     }
     wave_lds_sync();
   };
   for (uint32_t kk = wave; kk < ne; kk += ENUM_WAVES) run_restart(t.e0 + kk);
   n_tie_f64 = (uint32_t)wave_sum_ll((long long)n_tie_f64); n_tie_flip = (uint32_t)wave_sum_ll((long long)n_tie_flip); n_tie_unres = (uint32_t)wave_sum_ll((long long)n_tie_unres);   // (per-lane counts of the lanes' own rows)
   if (lane == 0) {
-    if (n_tie_f64) atomicAdd(&P.tie_ctr[TIE_SIGMA_F64], (unsigned long long)n_tie_f64);
-    if (n_tie_flip) atomicAdd(&P.tie_ctr[TIE_SIGMA_FLIPS], (unsigned long long)n_tie_flip);
-    if (n_tie_unres) atomicAdd(&P.tie_ctr[TIE_SIGMA_UNRES], (unsigned long long)n_tie_unres);
-    if (n_dtie) atomicAdd(&P.tie_ctr[TIE_DELTA_UNRES], (unsigned long long)n_dtie);
-    if (n_step) atomicAdd(&P.tie_ctr[TIE_STEP_UNRES], (unsigned long long)n_step);
+    if (n_tie_f64) TIE_COUNT(P.tie_ctr, TIE_SIGMA_F64, (unsigned long long)n_tie_f64);
+    if (n_tie_flip) TIE_COUNT(P.tie_ctr, TIE_SIGMA_FLIPS, (unsigned long long)n_tie_flip);
+    if (n_tie_unres) TIE_COUNT(P.tie_ctr, TIE_SIGMA_UNRES, (unsigned long long)n_tie_unres);
+    if (n_dtie) TIE_COUNT(P.tie_ctr, TIE_DELTA_UNRES, (unsigned long long)n_dtie);
+    if (n_step) TIE_COUNT(P.tie_ctr, TIE_STEP_UNRES, (unsigned long long)n_step);
   }
 }
 
@@ -897,7 +947,7 @@ __global__ void __launch_bounds__(64) k4_enum_pick(const EnumSpan* __restrict__ 
   int at_max = 0;
   for (uint32_t e = threadIdx.x; e < nj; e += 64) at_max += o[e] == best ? 1 : 0;
   for (int d = 32; d >= 1; d >>= 1) at_max += __shfl_xor(at_max, d, 64);
-  if (threadIdx.x == 0) { win_e[slot] = be; if (at_max > 1) atomicAdd(&tie_ctr[TIE_BEST_UNRES], 1ull); }
+  if (threadIdx.x == 0) { win_e[slot] = be; if (at_max > 1) TIE_COUNT(tie_ctr, TIE_BEST_UNRES, 1ull); }
 }
 }  // namespace
 

@@ -50,7 +50,7 @@ __host__ __device__ inline ResolveLayout resolve_layout(uint32_t R, uint32_t E, 
   uint32_t o = 0;
   L.lut = o; o += 512;
   L.rp = o; o += 2 * (R + 2);
-  o = (o + 7) & ~7u;
+  o = (o + 15) & ~15u;
   L.ent16 = o; o += 2 * ((E + 7) & ~7u);
   o = (o + 15) & ~15u;
   L.pse = o; o += 8 * ((E + 8) & ~7u);

@@ -43,6 +43,12 @@ enum { TIE_SIGMA_F64 = 0,      // sigma decisions with A == B at a row with an e
        TIE_BEST_UNRES = 5,     // ... left to "first maximum wins" (fallback kernels)
        TIE_SIGMA_UNRES = 6,    // sigma ties in kernels without the f64 path
        TIE_NCTR = 8 };
+// (-DENUM_PROF, a measurement build: the census slots carry k4_enum_resolve's times instead)
+#ifdef ENUM_PROF
+#define TIE_COUNT(ctr, which, n) do { } while (0)
+#else
+#define TIE_COUNT(ctr, which, n) atomicAdd(&(ctr)[which], (n))
+#endif
 
 // per-region sizes k4_stage reports to the host
 struct StageStat { int32_t R, E, max_n, max_rows, E_all, W; };   // max_*: per-lane share of k4_enum_reg's row partition; E_all: all entries;
