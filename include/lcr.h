@@ -342,7 +342,7 @@ int lcr_bam_write_reads(const char* out_path, const char* contig, int64_t contig
 
 /* Regions whose phase matrix is far beyond one CU are phased by persistent all-CU kernels; two such launches on one GPU --
  * of two contexts or two processes -- must not overlap, so they are serialised per device by a process-local mutex and an
- * flock on <dir>/grid_<pci bus id>.lock.  dir defaults to /tmp/liblcr-<uid> (created 0700); processes that share a GPU must
+ * flock on <dir>/grid_<pci bus id>.lock.  dir defaults to /tmp/liblcr-locks (shared by the users of the machine: sticky, world-writable; a directory named here is created 0700); processes that share a GPU must
  * see the same directory (containers without a common /tmp: name one on a shared mount).  A lock that cannot be taken makes
  * lcr_phase fail with LCR_E_DEVICE -- it is never skipped. */
 int lcr_ctx_set_lock_dir(lcr_ctx*, const char* dir);

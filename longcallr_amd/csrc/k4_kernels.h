@@ -10,7 +10,8 @@
 struct EnumSpan { int32_t slot; uint32_t tile0; };
 constexpr int ENUM_WAVES = 4;
 constexpr uint32_t ENUM_TILE_JOBS = 16;
-constexpr uint32_t ENUM_LDS_BYTES = 48 * 1024;
+constexpr uint32_t ENUM_LDS_BYTES = 48 * 1024;   // image of a region of the register / streaming classes (three workgroups per CU)
+constexpr uint32_t ENUM_LDS_MAX = 63 * 1024;     // ... of the large-image streaming class (a launch of its own; 64 KB less the kernels' static arrays)
 
 // LDS image: wl2[32] {lo23, hi24 (signed)} | lut64[64] (log10 eps_q, log10 (1 - eps_q): the f64 tie path) | csr[E] {lo | meta << 24,
 //            hi | row_in_lane << 24} | csc[E] | rp[R+1] u16 | first_row[65] u16 | ent16[E] (row-order entries of the f64 tie paths) |

@@ -299,6 +299,7 @@ struct GridLock {
   bool held = false;
   std::mutex* dev_mu = nullptr;
   hipStream_t q[3] = {nullptr, nullptr, nullptr};
+  int n_q = 0;
   static std::mutex& device_mutex(const std::string& bus) {
     static std::mutex table_mu;
     static std::map<std::string, std::mutex*> table;
@@ -310,22 +311,28 @@ struct GridLock {
   // returns an error text, or "" when the lock is held
   std::string acquire(const std::string& lock_dir, hipStream_t a, hipStream_t b, hipStream_t c) {
     if (held) return "";
-    q[0] = a; q[1] = b; q[2] = c;
+    q[0] = a; q[1] = b; q[2] = c; n_q = 3;
     int dev = 0;
     char bus[64] = "gpu";
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetPCIBusId(bus, sizeof(bus), dev);
     for (char* ch = bus; *ch; ch++) if (*ch == ':' || *ch == '/') *ch = '_';
+    // The default directory is shared by the users of the machine (two users' persistent launches on one GPU would wait for each
+    // other's workgroups forever just as two processes of one user would): /tmp/liblcr-locks, sticky and world-writable like /tmp
+    // itself, lock files world-writable.  A directory named by lcr_ctx_set_lock_dir is created 0700 and must be the caller's, or sticky.
     std::string dir = lock_dir;
-    if (dir.empty()) dir = "/tmp/liblcr-" + std::to_string((long long)getuid());
-    if (mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) return "cannot create lock directory " + dir + ": " + strerror(errno);
+    const bool shared = dir.empty();
+    if (shared) dir = "/tmp/liblcr-locks";
+    if (mkdir(dir.c_str(), shared ? 01777 : 0700) == 0) { if (shared) (void)chmod(dir.c_str(), 01777); /* (the umask) */ }
+    else if (errno != EEXIST) return "cannot create lock directory " + dir + ": " + strerror(errno);
     struct stat st;
-    if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid())
-      return "lock directory " + dir + " is not a directory owned by this user (lcr_ctx_set_lock_dir names another one)";
+    if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || (st.st_uid != getuid() && !(st.st_mode & S_ISVTX)))
+      return "lock directory " + dir + " is neither a directory owned by this user nor a sticky one (lcr_ctx_set_lock_dir names another one)";
     const std::string path = dir + "/grid_" + bus + ".lock";
     dev_mu = &device_mutex(bus);
     dev_mu->lock();
-    fd = open(path.c_str(), O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, 0600);
+    fd = open(path.c_str(), O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, shared ? 0666 : 0600);
     if (fd < 0) { const std::string e = "cannot open " + path + ": " + strerror(errno); dev_mu->unlock(); dev_mu = nullptr; return e; }
+    if (shared) { struct stat fs; if (fstat(fd, &fs) == 0 && fs.st_uid == getuid()) (void)fchmod(fd, 0666); }   // (created under a umask)
     int rc;
     while ((rc = flock(fd, LOCK_EX)) != 0 && errno == EINTR) {}
     if (rc != 0) { const std::string e = "flock(" + path + "): " + strerror(errno); close(fd); fd = -1; dev_mu->unlock(); dev_mu = nullptr; return e; }
@@ -334,7 +341,7 @@ struct GridLock {
   }
   ~GridLock() {
     if (!held) return;
-    for (hipStream_t s : q) if (s) (void)hipStreamSynchronize(s);   // (a persistent kernel may still be running on an error path)
+    for (int i = 0; i < n_q; i++) (void)hipStreamSynchronize(q[i]);   // (a persistent kernel may still be running on an error path; nullptr = the null stream, drained too)
     if (fd >= 0) { (void)flock(fd, LOCK_UN); close(fd); }
     if (dev_mu) dev_mu->unlock();
   }
@@ -674,7 +681,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
 #ifndef ENUM_PER3
 #define ENUM_PER3 2u
 #endif
-    const uint32_t per_of[NCLS] = {1u, 1u, ENUM_TILE_JOBS, ENUM_PER3 * ENUM_WAVES, 1u};
+    const uint32_t per_of[NCLS] = {1u, ENUM_PER3 * ENUM_WAVES, ENUM_TILE_JOBS, ENUM_PER3 * ENUM_WAVES, 1u};
     std::vector<int64_t> job_base(ng, 0), st_base(ng, 0);   // st_base: first word of the region's saved restart states (classes 2 / 3)
     int64_t nj = 0, st_words = 0;
     uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0}, res_lds[NCLS] = {0, 0, 0, 0, 0};   // (res_lds: k4_enum_resolve's image of the class's largest region)
@@ -684,12 +691,19 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       const StageStat& st = stat[g];
       const EnumLayout EL = enum_layout(st.R, st.E);
       int cls = 4;
-      if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_BYTES && st.max_rows <= 64)
+      if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_MAX && resolve_layout((uint32_t)st.R, (uint32_t)st.E, (uint32_t)S).total <= ENUM_LDS_MAX && st.max_rows <= 64)
 #ifdef ENUM_MASK64
         cls = force_stream ? 3 : (st.max_n <= 32 ? 2 : 3);
 #else
         cls = force_stream ? 3 : (st.max_n <= 32 && st.max_rows <= 32 ? 2 : 3);
 #endif   // (register-resident form: <= 32 entries and <= 32 rows per lane)   // (the 8 / 16 instantiations: one launch has one tail; a 40-entry one: below)
+      // class 1: the streaming kernel for the few regions whose image needs more than ENUM_LDS_BYTES (up to the 64 KB a launch gets
+      // without opting in): a launch of their own, so that their LDS does not set the occupancy of class 3's tiles
+      // (C4 share: three such regions used to take the global-memory kernel BEHIND class 3 on its queue, 0.68 ms of the critical
+      // path: step 5.49 -> 4.97 ms; a queue of their own was measured too: HIP maps a fourth stream onto one of the first three's
+      // hardware queues, no difference)
+      const uint32_t RL = resolve_layout((uint32_t)st.R, (uint32_t)st.E, (uint32_t)S).total;
+      if ((cls == 2 || cls == 3) && (std::max(EL.total, RL) > ENUM_LDS_BYTES || dbg.enum_force_stream == 2 /* test hook */)) cls = 1;
       if (cls < 4) { lds_need[cls] = std::max(lds_need[cls], EL.total); res_lds[cls] = std::max(res_lds[cls], resolve_layout((uint32_t)st.R, (uint32_t)st.E, (uint32_t)S).total); }
       job_base[g] = nj;
       const uint64_t n = 1ull << S;
@@ -699,7 +713,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       n_t[cls] += (size_t)((n + per_of[cls] - 1) / per_of[cls]);
       nj += (int64_t)n;
       if (!host_post[g] && !grid_post[g]) post_slots.push_back(g);
+      if (prof && cls == 4) fprintf(stderr, "[phase]   global-memory enumeration region %d: R %d E %d S %d max_rows %d max_n %d, LDS image %u B\n", g, st.R, st.E, S, st.max_rows, st.max_n, EL.total);
     }
+    if (prof) fprintf(stderr, "[phase]   enumeration classes: register %zu regions / %zu tiles, streaming %zu / %zu, streaming with a large image %zu / %zu, global %zu / %zu\n", spans[2].size(), n_t[2], spans[3].size(), n_t[3], spans[1].size(), n_t[1], spans[4].size(), n_t[4]);
     // one upload: spans of every class | job_base | slots | post slots ; then job objectives and winners
     size_t n_w[NCLS], s_off[NCLS], n_spans = 0;
     for (int k = 0; k < NCLS; k++) { n_w[k] = spans[k].size(); s_off[k] = n_spans; n_spans += n_w[k]; }
@@ -733,9 +749,13 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(hipMemsetAsync(d_rbest, 0x80, (size_t)ng * 8, stream));        // 0x8080...: far below any objective
     auto launch = [&](const size_t* cnt, const uint32_t* win) -> hipError_t {
       const bool fork = cnt[2] && (cnt[3] || cnt[4]);
-      hipStream_t s34 = fork ? aux : stream;
+            hipStream_t s34 = fork ? aux : stream, s1 = stream;
       hipError_t e = hipSuccess;
       if (fork) { if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e; }
+      if (cnt[1]) {   // (first, ahead of class 2 on its queue: the largest matrices have the longest restarts)
+        launch_k4_enum_reg(0, (unsigned)cnt[1], lds_need[1], s1, P, d_sp + s_off[1], (int32_t)n_w[1], per_of[1], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), d_rbest);
+        if (!win) launch_k4_enum_resolve((unsigned)n_w[1], res_lds[1], s1, P, d_sp + s_off[1], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());
+      }
       // classes 2 / 3: all restarts, then `prob > largest_prob` over each region's restarts from the objectives, signatures and
       // states they left (phase.rs:1113-1119; ties between configurations of maximal objective by their f64 sums) -- a workgroup
       // per region, each class's behind its own restarts (the streaming class's regions are resolved under the other's restarts)

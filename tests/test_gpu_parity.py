@@ -379,12 +379,14 @@ def test_k0_thousands_of_records_beyond_the_tile_window(engine_cls, orc):
     assert c.size >= 2
 
 
-@pytest.mark.parametrize("hook", ["LCR_ENUM_FORCE_STREAM", "LCR_ENUM_FORCE_BIG", "LCR_POST_HOST", "LCR_POST_HALF"])
+@pytest.mark.parametrize("hook", ["LCR_ENUM_FORCE_STREAM", "LCR_ENUM_FORCE_STREAM=2", "LCR_ENUM_FORCE_BIG", "LCR_POST_HOST", "LCR_POST_HALF"])
 def test_fallback_device_paths(engine_cls, orc, monkeypatch, hook):
     """The size-dependent fallbacks of the phase stage give the same results as the default kernels:
-    enumeration restarts with LDS-streamed entries / from global memory, post-phase epilogue on the host, the
-    eight-wave epilogue of the chain regions (taken when a batch has more chain regions than the device has CUs)."""
-    monkeypatch.setenv(hook, "1")
+    enumeration restarts with LDS-streamed entries (=2: in the launch of the regions with a large LDS image) / from global
+    memory, post-phase epilogue on the host, the eight-wave epilogue of the chain regions (taken when a batch has more chain
+    regions than the device has CUs)."""
+    hook, _, value = hook.partition("=")
+    monkeypatch.setenv(hook, value or "1")
     if hook == "LCR_ENUM_FORCE_BIG":     # (the global-memory enumeration kernel keeps the first maximum among restarts of equal objective)
         monkeypatch.setitem(ORACLE_TIE_MASK, 0, orc.tie_mask(1, 1))
     b = synth.make_batch("ont-drna", n_genes=3, gene_len=20000, depth=45, seed=14)

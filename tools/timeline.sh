@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/tl; mkdir -p gpurun_out/tl
-rocprofv3 --kernel-trace --memory-copy-trace -d gpurun_out/tl -o p --output-format csv -- python bench.py --steps 30 --warmup 5 --prewarm 30 --quick > gpurun_out/tl/log.txt 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace -d gpurun_out/tl -o p --output-format csv -- python bench.py ${WL:+--workload $WL --quick} --steps 30 --warmup 5 --prewarm 30 --no-cpu-baseline > gpurun_out/tl/log.txt 2>&1
 python - <<'PY'
 import csv, glob
 rows = list(csv.DictReader(open(glob.glob('gpurun_out/tl/*kernel_trace.csv')[0])))
