@@ -686,19 +686,20 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
           alo += __mul24((int)hit, (int)v0) - __mul24((int)mis, (int)v0);   // A - B of phase.rs:824-862
           ahi += __mul24((int)hit, (int)v1) - __mul24((int)mis, (int)v1);
           uacc |= use;
-          const bool end = (m >> 6) & 1u;
+          const uint32_t em = (uint32_t)((int)(v0 << 1) >> 31);   // all ones at the last entry of a row
           // sign of ahi * 2^23 + alo: fold alo's carry into ahi, the remainder is in [0, 2^23)
           const int top = ahi + (alo >> 23);
-          const mask_t bit = end ? (mask_t)1 << roff : (mask_t)0;
-          if (top < 0) fm |= bit;
+          const mask_t bit = (mask_t)(long long)(int)em & ((mask_t)1 << roff);   // (sign-extended: the streaming form's masks have 64 bits)
+          fm |= bit & (mask_t)(long long)(top >> 31);
           // A == B at a row with a het entry: the f64 scores decide (a row without one scores the same for both signs, term by term)
-          if (uacc && (top | (alo << 9)) == 0) tm |= bit;
-          alo = end ? 0 : alo; ahi = end ? 0 : ahi; uacc = end ? 0u : uacc;
+          const uint32_t zz = (uint32_t)top | ((uint32_t)alo << 9) | (uacc ^ 1u);
+          tm |= zz == 0u ? bit : (mask_t)0;
+          alo &= (int)~em; ahi &= (int)~em; uacc &= ~em;   // (bit operations: the compiler's selects cost a compare more)
         };
         if (CK > 0) {
 #pragma unroll
           for (int x = 0; x < NREG; x++) {
-            if (x >= n_sig) break;
+            if ((x & 3) == 0 && x >= n_sig) break;   // (a lane's slots beyond its share are zero words: no het entry, no row end)
             // opaque to the optimiser: otherwise every field extraction is hoisted out of the restart loop
             // into its own VGPR (x CK entries) and the kernel drops to one wave per SIMD
             asm volatile("" : "+v"(re0[x]), "+v"(re1[x]));
