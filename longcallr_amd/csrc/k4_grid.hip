@@ -694,8 +694,6 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
   __shared__ unsigned long long t_sum[4][8];   // delta step: partial sums / arrivals of the four-wave teams
   __shared__ long long rsum_all[CH_THREADS / 64][32];   // sigma step: row sums of the unit a wave is working on
   long long* const rsum = rsum_all[threadIdx.x >> 6];
-  __shared__ uint32_t rhet_all[CH_THREADS / 64];        // ... and which of its rows have an entry at a het site
-  uint32_t* const rhet = &rhet_all[threadIdx.x >> 6];
   __shared__ unsigned t_cnt[4][8];
   if (threadIdx.x < 32) { t_sum[threadIdx.x >> 3][threadIdx.x & 7] = 0; t_cnt[threadIdx.x >> 3][threadIdx.x & 7] = 0; }
   // ---- delta step order: SNPs by column length, dealt to the teams in serpentine order (longest to team 0, 1, .. T-1,
@@ -751,7 +749,6 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
             const int ub = __shfl(ub_l, k, 64), ue = __shfl(ue_l, k, 64);
             const uint32_t sbits = (uint32_t)__shfl((int)sb_l, k, 64);   // sigma of the unit's rows
             if (lane < 32) rsum[lane] = 0;
-            if (lane == 0) *rhet = 0;
             wave_lds_sync();
             uint32_t hm = 0;
             auto run4 = [&](const uint4& t, int e) {
@@ -780,14 +777,23 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
               for (int q = 0; q < 4; q++) { const int e = ub + 4 * lane + 256 * q; if (e < ue) run4(t4[q], e); }
               for (int e = ub + 4 * lane + 1024; e < ue; e += 256) run4(*reinterpret_cast<const uint4*>(pkr + e), e);
             }
-            if (hm) atomicOr(rhet, hm);
+            {   // which rows of the unit have an entry at a het site: OR over the lanes (DPP row shifts / broadcasts, the total in lane 63)
+              int h = (int)hm;
+              h |= __builtin_amdgcn_update_dpp(0, h, 0x111, 0xf, 0xf, false);
+              h |= __builtin_amdgcn_update_dpp(0, h, 0x112, 0xf, 0xf, false);
+              h |= __builtin_amdgcn_update_dpp(0, h, 0x114, 0xf, 0xf, false);
+              h |= __builtin_amdgcn_update_dpp(0, h, 0x118, 0xf, 0xf, false);
+              h |= __builtin_amdgcn_update_dpp(0, h, 0x142, 0xa, 0xf, false);
+              h |= __builtin_amdgcn_update_dpp(0, h, 0x143, 0xc, 0xf, false);
+              hm = (uint32_t)__builtin_amdgcn_readlane(h, 63);
+            }
             wave_lds_sync();
             const long long diff = lane < 32 ? rsum[lane] : 0;
             unsigned long long fb = __ballot(lane < 32 && diff < 0);
             if (fb) any = 1;
             // rows whose sums tie exactly, with an entry at a het site: the reference-order f64 scores decide (a lane per row;
             // a few dozen rows per step on C5)
-            const uint32_t tmask = (uint32_t)__ballot(lane < 32 && diff == 0 && 32 * u + lane < R) & *rhet;
+            const uint32_t tmask = (uint32_t)__ballot(lane < 32 && diff == 0 && 32 * u + lane < R) & hm;
             if (tmask) {
               bool tf = false;
               if (lane < 32 && ((tmask >> lane) & 1u))
