@@ -62,6 +62,8 @@ def check_f64_mode(orc, batch, params, regs, chrom):
     """ORC_MODE_F64 -- the reference's f64 ratio scores / sums in the reference's order at EVERY decision -- reaches the
     phasing of ORC_MODE_TIE (what liblcr computes) in every region whose census shows no tie of a class liblcr does not
     resolve; how many regions that is gets recorded (all of them on the BASELINE configs)."""
+    if ORACLE_TIE_MASK[0] not in (None, orc.TIE_MASK_LIBLCR):
+        return   # (a test of a fallback kernel / of the tie_arith switch: the claim is about the classes liblcr resolves by default)
     for g, R in enumerate(regs):
         A = orc.Region(batch, g, params).set_fast(1).run_all(orc.MODE_F64)
         F64_CHECKED["regions"] += 1
