@@ -514,11 +514,111 @@ int lcr_bam_open_keep(const char* path, int32_t n_threads, int64_t keep_bytes, l
   uint64_t buf_u0 = 0;            // inflated offset of buf[0]
   bool have_header = false;
   size_t hp = 0;                  // parse position inside buf
+  // parse_header: the BAM header (SAM spec 4.2) from d[0 .. n) -- may span windows, is parsed when it is complete (*done); p = first record
+  auto parse_header = [&](const uint8_t* d, size_t n, size_t& p, bool* done) -> int {
+    *done = false;
+    if (n < 12) return LCR_OK;
+    if (memcmp(d, "BAM\1", 4) != 0) return fail(b, LCR_E_ARG, "not a BAM file");
+    size_t q = 8 + (size_t)rd32(&d[4]);
+    if (q + 4 > n) return LCR_OK;
+    const int32_t n_ref = rdi32(&d[q]);
+    q += 4;
+    if (n_ref < 0) return fail(b, LCR_E_ARG, "bad reference count");
+    std::vector<std::string> names; std::vector<int64_t> lens;
+    for (int32_t i = 0; i < n_ref; i++) {
+      if (q + 4 > n) return LCR_OK;
+      const uint32_t l_name = rd32(&d[q]);
+      if (l_name == 0) return fail(b, LCR_E_ARG, "truncated reference table");
+      if (q + 4 + (size_t)l_name + 4 > n) return LCR_OK;
+      names.emplace_back(reinterpret_cast<const char*>(&d[q + 4]), l_name - 1);
+      lens.push_back(rdi32(&d[q + 4 + l_name]));
+      q += 8 + l_name;
+    }
+    b->ref_names = names; b->ref_len = lens;
+    b->header_size = q; b->header.assign(d, d + q);
+    p = q;
+    for (auto& s : b->ref_names) b->ref_name_ptrs.push_back(s.c_str());
+    b->ctg_u0.assign(b->ref_names.size() + 1, UINT64_MAX); b->ctg_u1.assign(b->ref_names.size() + 1, 0); b->ctg_n.assign(b->ref_names.size() + 1, 0);
+    b->ctg_first.assign(b->ref_names.size() + 1, -1); b->ctg_scattered.assign(b->ref_names.size() + 1, 0);
+    *done = true;
+    return LCR_OK;
+  };
+  // walk: the block_size chain of the complete records in d[p .. n) (d[0] = inflated offset u0): contig ranges, record sizes
+  auto walk = [&](const uint8_t* d, size_t n, bool last, uint64_t u0, size_t& p, std::vector<std::pair<uint64_t, uint32_t>>& out) -> int {
+    while (p < n) {
+      if (p + 4 > n) { if (last) return fail(b, LCR_E_ARG, "truncated record header"); break; }
+      const uint32_t bs = rd32(&d[p]);
+      if (bs < 32) return fail(b, LCR_E_ARG, "truncated record at inflated offset " + std::to_string(u0 + p));
+      if (p + 4 + (size_t)bs > n) { if (last) return fail(b, LCR_E_ARG, "truncated record at inflated offset " + std::to_string(u0 + p)); break; }
+      const int32_t rid = rdi32(&d[p + 4]);
+      const int64_t ci = (int64_t)rid + 1;
+      if (ci < 0 || (size_t)ci >= b->ctg_n.size()) return fail(b, LCR_E_ARG, "malformed record " + std::to_string(b->n_records) + ": reference id out of range");
+      b->ctg_u0[(size_t)ci] = std::min(b->ctg_u0[(size_t)ci], u0 + p);
+      b->ctg_u1[(size_t)ci] = std::max(b->ctg_u1[(size_t)ci], u0 + p + 4 + bs);
+      if (b->ctg_n[(size_t)ci] == 0) b->ctg_first[(size_t)ci] = b->n_records;
+      else if (b->ctg_first[(size_t)ci] + b->ctg_n[(size_t)ci] != b->n_records) b->ctg_scattered[(size_t)ci] = 1;
+      try { b->rec_bs.push_back(bs); out.push_back(std::make_pair((uint64_t)(p + 4), bs)); } catch (...) { return fail(b, LCR_E_NOMEM, "out of memory for the record table"); }
+      b->ctg_n[(size_t)ci]++; b->n_records++;
+      p += 4 + (size_t)bs;
+    }
+    return LCR_OK;
+  };
+  // the fixed fields / aux block of the records in `recs` (offsets into d) validated in parallel, so that a malformed file is
+  // refused at open without a second inflate; first_index = file index of recs[0]
+  auto validate = [&](const uint8_t* d, const std::vector<std::pair<uint64_t, uint32_t>>& recs, int64_t first_index) -> int {
+    std::atomic<int64_t> bad_rec{-1};
+    parallel_for((int64_t)recs.size(), n_threads, 1024, [&](int64_t i) {
+      Rec r{}; r.off = recs[(size_t)i].first; r.size = recs[(size_t)i].second;
+      bool lb = false;
+      if (!index_record(r, d, &lb)) bad_rec.store(i);
+    });
+    if (bad_rec.load() >= 0) return fail(b, LCR_E_ARG, "malformed record " + std::to_string(first_index + bad_rec.load()) + " (fixed fields / aux block)");
+    return LCR_OK;
+  };
+  if (keep_all) {
+    // The whole stream stays: windows of 1 024 blocks are inflated to their final place, and while the workers inflate window
+    // i + 1 ONE thread walks the record chain of window i (serial pointer chasing through freshly written memory: ~190 ns per
+    // record, as long as the inflate itself); the records are validated in one parallel pass at the end.
+    if (!buf.resize((size_t)total + 1)) return fail(b, LCR_E_NOMEM, "out of memory for the inflated stream");
+    LAP(1, "resize");
+    b->resident_peak = std::max(b->resident_peak, (int64_t)buf.size());
+    const uint8_t* d = buf.data();
+    size_t p = 0;
+    int chain_rc = LCR_OK;
+    std::thread chain;
+    const size_t KWIN = 1024;
+    for (size_t w0 = 0; w0 < blks.size(); w0 += KWIN) {
+      const size_t w1 = std::min(blks.size(), w0 + KWIN);
+      const int64_t badb = inflate_blocks(b, w0, w1, buf.data() + blks[w0].uoff, n_threads);
+      if (chain.joinable()) chain.join();
+      if (badb >= 0) return fail(b, LCR_E_ARG, "BGZF block " + std::to_string(badb) + " does not inflate / CRC mismatch");
+      if (chain_rc != LCR_OK) return chain_rc;
+      const size_t n = (size_t)(blks[w1 - 1].uoff + blks[w1 - 1].isize);
+      const bool last = w1 >= blks.size();
+      chain = std::thread([&, n, last]() {
+        if (!have_header) {
+          bool done = false;
+          chain_rc = parse_header(d, n, p, &done);
+          if (chain_rc != LCR_OK) return;
+          if (!done) { if (last) chain_rc = fail(b, LCR_E_ARG, n < 12 || memcmp(d, "BAM\1", 4) != 0 ? "not a BAM file" : "truncated BAM header"); return; }
+          have_header = true;
+        }
+        chain_rc = walk(d, n, last, 0, p, win_recs);
+      });
+    }
+    if (chain.joinable()) chain.join();
+    if (chain_rc != LCR_OK) return chain_rc;
+    LAP(2, "inflate + chain");
+    if (!have_header) return fail(b, LCR_E_ARG, "not a BAM file");
+    { const int rc = validate(d, win_recs, 0); if (rc != LCR_OK) return rc; }
+    LAP(4, "validate");
+    carry = total - p; buf_u0 = p;
+  } else
   for (size_t w0 = 0; w0 < blks.size() || !have_header; w0 += WIN) {
     const size_t w1 = std::min(blks.size(), w0 + WIN);
     const size_t wbytes = w0 < blks.size() ? (size_t)(blks[w1 - 1].uoff + blks[w1 - 1].isize - blks[w0].uoff) : 0;
     LAP(0, "other");
-    if (!(keep_all ? buf.resize(wbytes + 1) : buf.resize_keep(carry + wbytes + 1))) return fail(b, LCR_E_NOMEM, "out of memory for the scan window");
+    if (!buf.resize_keep(carry + wbytes + 1)) return fail(b, LCR_E_NOMEM, "out of memory for the scan window");
     LAP(1, "resize");
     b->resident_peak = std::max(b->resident_peak, (int64_t)buf.size());
     if (wbytes) {
@@ -530,74 +630,22 @@ int lcr_bam_open_keep(const char* path, int32_t n_threads, int64_t keep_bytes, l
     const uint8_t* d = buf.data();
     const bool last = w1 >= blks.size();
     size_t p = hp;
-    if (!have_header) {   // BAM header (SAM spec 4.2): may span windows, is parsed when it is complete
-      bool complete = false;
-      do {
-        if (n < 12) break;
-        if (memcmp(d, "BAM\1", 4) != 0) return fail(b, LCR_E_ARG, "not a BAM file");
-        size_t q = 8 + (size_t)rd32(&d[4]);
-        if (q + 4 > n) break;
-        const int32_t n_ref = rdi32(&d[q]);
-        q += 4;
-        if (n_ref < 0) return fail(b, LCR_E_ARG, "bad reference count");
-        std::vector<std::string> names; std::vector<int64_t> lens;
-        bool ok = true;
-        for (int32_t i = 0; i < n_ref; i++) {
-          if (q + 4 > n) { ok = false; break; }
-          const uint32_t l_name = rd32(&d[q]);
-          if (l_name == 0) return fail(b, LCR_E_ARG, "truncated reference table");
-          if (q + 4 + (size_t)l_name + 4 > n) { ok = false; break; }
-          names.emplace_back(reinterpret_cast<const char*>(&d[q + 4]), l_name - 1);
-          lens.push_back(rdi32(&d[q + 4 + l_name]));
-          q += 8 + l_name;
-        }
-        if (!ok) break;
-        b->ref_names = names; b->ref_len = lens;
-        b->header_size = q; b->header.assign(d, d + q);
-        complete = true;
-        p = q;
-      } while (false);
-      if (!complete) {
+    if (!have_header) {
+      bool done = false;
+      { const int rc = parse_header(d, n, p, &done); if (rc != LCR_OK) return rc; }
+      if (!done) {
         if (last) return fail(b, LCR_E_ARG, n < 12 || memcmp(d, "BAM\1", 4) != 0 ? "not a BAM file" : "truncated BAM header");
         carry = n; hp = 0;   // keep everything, read on
         continue;
       }
       have_header = true;
-      for (auto& s : b->ref_names) b->ref_name_ptrs.push_back(s.c_str());
-      b->ctg_u0.assign(b->ref_names.size() + 1, UINT64_MAX); b->ctg_u1.assign(b->ref_names.size() + 1, 0); b->ctg_n.assign(b->ref_names.size() + 1, 0);
-      b->ctg_first.assign(b->ref_names.size() + 1, -1); b->ctg_scattered.assign(b->ref_names.size() + 1, 0);
     }
-    // ---- records of this window: contig ranges, and the fixed fields / aux block of every record validated here (in parallel,
-    //      on the window that is inflated anyway) so that a malformed file is refused at open without a second inflate
+    // ---- records of this window
     win_recs.clear();
-    while (p < n) {
-      if (p + 4 > n) { if (last) return fail(b, LCR_E_ARG, "truncated record header"); break; }
-      const uint32_t bs = rd32(&d[p]);
-      if (bs < 32) return fail(b, LCR_E_ARG, "truncated record at inflated offset " + std::to_string(buf_u0 + p));
-      if (p + 4 + (size_t)bs > n) { if (last) return fail(b, LCR_E_ARG, "truncated record at inflated offset " + std::to_string(buf_u0 + p)); break; }
-      const int32_t rid = rdi32(&d[p + 4]);
-      const int64_t ci = (int64_t)rid + 1;
-      if (ci < 0 || (size_t)ci >= b->ctg_n.size()) return fail(b, LCR_E_ARG, "malformed record " + std::to_string(b->n_records) + ": reference id out of range");
-      b->ctg_u0[(size_t)ci] = std::min(b->ctg_u0[(size_t)ci], buf_u0 + p);
-      b->ctg_u1[(size_t)ci] = std::max(b->ctg_u1[(size_t)ci], buf_u0 + p + 4 + bs);
-      if (b->ctg_n[(size_t)ci] == 0) b->ctg_first[(size_t)ci] = b->n_records;
-      else if (b->ctg_first[(size_t)ci] + b->ctg_n[(size_t)ci] != b->n_records) b->ctg_scattered[(size_t)ci] = 1;
-      try { b->rec_bs.push_back(bs); } catch (...) { return fail(b, LCR_E_NOMEM, "out of memory for the record table"); }
-      b->ctg_n[(size_t)ci]++; b->n_records++;
-      win_recs.push_back(std::make_pair((uint64_t)(p + 4), bs));
-      p += 4 + (size_t)bs;
-    }
+    const int64_t first_index = b->n_records;
+    { const int rc = walk(d, n, last, buf_u0, p, win_recs); if (rc != LCR_OK) return rc; }
     LAP(3, "chain");
-    {
-      std::atomic<int64_t> bad_rec{-1};
-      parallel_for((int64_t)win_recs.size(), n_threads, 1024, [&](int64_t i) {
-        Rec r{}; r.off = win_recs[(size_t)i].first; r.size = win_recs[(size_t)i].second;
-        bool lb = false;
-        if (!index_record(r, d, &lb)) bad_rec.store(i);
-      });
-      if (bad_rec.load() >= 0)
-        return fail(b, LCR_E_ARG, "malformed record " + std::to_string(b->n_records - (int64_t)win_recs.size() + bad_rec.load()) + " (fixed fields / aux block)");
-    }
+    { const int rc = validate(d, win_recs, first_index); if (rc != LCR_OK) return rc; }
     LAP(4, "validate");
     // the unfinished tail moves to the front of the next window
     carry = n - p;
