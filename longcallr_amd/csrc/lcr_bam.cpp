@@ -595,7 +595,7 @@ int lcr_bam_open_keep(const char* path, int32_t n_threads, int64_t keep_bytes, l
       if (chain_rc != LCR_OK) return chain_rc;
       const size_t n = (size_t)(blks[w1 - 1].uoff + blks[w1 - 1].isize);
       const bool last = w1 >= blks.size();
-      chain = std::thread([&, n, last]() {
+      auto chain_step = [&, n, last]() {
         if (!have_header) {
           bool done = false;
           chain_rc = parse_header(d, n, p, &done);
@@ -604,7 +604,8 @@ int lcr_bam_open_keep(const char* path, int32_t n_threads, int64_t keep_bytes, l
           have_header = true;
         }
         chain_rc = walk(d, n, last, 0, p, win_recs);
-      });
+      };
+      try { chain = std::thread(chain_step); } catch (...) { chain_step(); }   // (no thread to be had: walk here)
     }
     if (chain.joinable()) chain.join();
     if (chain_rc != LCR_OK) return chain_rc;
