@@ -51,23 +51,27 @@ __device__ __forceinline__ EnumTile enum_tile_of(const PhaseDev& P, const EnumSp
 }
 
 // ---------------------------------------------------------------------------------------------
-// `prob > largest_prob` over the restarts of one region (phase.rs:1113-1119), run by the tile that completes the region.
+// k4_enum_resolve: `prob > largest_prob` over the restarts of one region (phase.rs:1113-1119) -- a workgroup per region, launched
+// per kernel class behind the class's restarts on its queue.
 // The fixed-point objectives decide; among the restarts of MAXIMAL objective the reference keeps the first one unless a
 // later one's f64 sum (cal_overall_probability, phase.rs:257-276: every phase entry's log10 term, fragment by fragment,
 // in ONE running sum) is greater by rounding noise.  Every restart left its final state and a SIGNATURE in st_words -- a
 // hash of the match bits of all entries (k4_enum_reg): equal signatures = the same sequence of terms = the same f64 sum.
 //   0. all restarts of maximal objective carry one signature (restarts that reached one optimum with the same sigma
-//      everywhere): the first of them wins, nothing is summed;
-//   1. else the first one is the REFERENCE configuration: one lane adds its terms in the reference's order (f64, LUT of
-//      the host's libm values) and keeps the running sum at every row boundary, ps[0 .. R];
-//   2. the others, a lane each, ENUM_TCAP at a time in ascending order.  A configuration of the reference's class -- same
-//      eta, the same or the mirrored delta at the het sites -- differs from it in the sigma of a few rows only (rows whose
-//      two orientations score alike: their sigma is whatever init_assignment drew).  Such a row is re-added alone from the
-//      reference's running sum ps[k]: if it arrives at ps[k + 1] bit for bit, everything behind it is the reference's sum
-//      again (f64 addition inside one binade rounds every term on its own, so this is the rule); when all its rows do, its
-//      sum IS ps[R].  Otherwise -- another class, or a row that rounds differently -- the lane adds all of its terms;
-//   3. strictly-greater-replaces over the list in order (phase.rs:1117); the winner's state goes to the region's result
-//      slots (no re-run of the winning restart).
+//      everywhere, or its mirror image): the first of them wins, nothing is summed;
+//   1. else the first one is the REFERENCE configuration: its terms (f64, table of the host's libm values) are formed in
+//      parallel and ONE lane adds them in the reference's order, keeping the running sum behind every entry, pse[0 .. E);
+//   2. the EVENTS of that chain: entries where the sum crosses a power of two, or where s + t lies exactly half way between two
+//      doubles (TwoSum's error term) -- the only places where two running sums a few ulps apart that take the same terms do
+//      not keep their distance (inside one binade fl(s + t) rounds t on its own);
+//   3. the others, a lane each, ENUM_TCAP at a time in ascending order.  A configuration of the reference's class -- same
+//      eta, delta mirrored on whole GROUPS of het sites (components of "share a row") -- differs from it in the sigma of a few
+//      rows only (rows whose two orientations score alike: their sigma is whatever init_assignment drew).  Such a row is
+//      re-added alone from the reference's running sum; once a row arrives elsewhere the distance dl is carried from event
+//      to event.  Another class, a delta that differs inside a group (macroscopic row differences), or a distance beyond
+//      ~1000 ulps: the lane adds all of its terms (full_sum);
+//   4. strictly-greater-replaces over the list in order (phase.rs:1117) as a reduction (largest sum, earliest of equals);
+//      the winner's state goes to the region's result slots (no re-run of the winning restart).
 // ---------------------------------------------------------------------------------------------
 // measurement build (-DENUM_PROF): the slowest workgroup's time (10 ns units) up to a point of k4_enum_resolve -> tie census slot i
 #ifdef ENUM_PROF
