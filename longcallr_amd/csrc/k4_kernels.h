@@ -6,7 +6,8 @@
 // ---- enumeration restarts (k4_enum.hip) ----
 // The grid of an enumeration kernel is the concatenation of its regions' tiles; the host uploads one span per region
 // (a few hundred) instead of one record per tile (tens of thousands), the workgroup finds its span with two rounds
-// of a 64-way search (spans are sorted by tile0).  Winner re-runs have one workgroup per span.
+// of a 64-way search (spans are sorted by tile0).  k4_enum_resolve and the winner re-runs of the global-memory class have one
+// workgroup per span.
 struct EnumSpan { int32_t slot; uint32_t tile0; };
 constexpr int ENUM_WAVES = 4;
 constexpr uint32_t ENUM_TILE_JOBS = 16;

@@ -8,8 +8,12 @@
 // few chain regions, see PhaseHost::run); k4_kernels.h / k4_grid.h hold their launchers and LDS layouts:
 //   k4_stage.hip  k4_stage      phase matrices (CSR + CSC, per-SNP constants) of every region from K3's fragment CSR
 //   k4_enum.hip   k4_enum_reg   S <= max_enum_snps: all 2^S enumeration restarts (phase.rs:1097-1122), one wave64 per
-//                               restart with the matrix in registers; k4_enum_big = fallback on global memory
-//                 k4_enum_pick  winner = first maximum (`prob > largest_prob`); it is re-run to materialise its state
+//                               restart with the matrix in registers (<0>: streamed from LDS); every restart leaves its
+//                               objective, final state and signature
+//                 k4_enum_resolve  `prob > largest_prob` (phase.rs:1113-1119) per region: the maximal objective, and among
+//                               the configurations that have it the reference's f64 sums (phase.rs:257-276) decide
+//                 k4_enum_big + k4_enum_pick  fallback on global memory (matrix beyond the LDS budget): first maximum,
+//                               winner re-run; its ties are counted as unresolved
 //   k4_grid.hip   k4_chain_wg / k4_chain_grid   S > max_enum_snps: the sequential chain (phase.rs:1123-1233) with one
 //                               workgroup per region, or all CUs on one large region (LD-block flip pass, perturbation rounds)
 //   k4_post.hip   k4_post       post-phase assignment, rescue and phase sets (f64, reference observation order)
@@ -17,8 +21,10 @@
 // Its decision arithmetic is exact: every emission term log10(eps_q) / log10(1-eps_q) comes from a
 // 31-entry table in fixed point (scale 2^40, int64), so sums are order-free and every comparison
 // the reference makes on f64 ratio scores (q < qn, argmax q1..q4, prob > largest_prob) becomes an
-// integer comparison of the log sums (the ratios 1 - A/D share a negative denominator D).  See
-// DESIGN.md "Decision arithmetic" for why this equals the reference except on rounding-noise ties.
+// integer comparison of the log sums (the ratios 1 - A/D share a negative denominator D).  Where such a comparison is an
+// exact TIE the reference's outcome is the rounding noise of its reference-order f64 sums: those sums are formed there
+// (sigma ties per row, `prob > largest_prob` per configuration; PhaseDebug::tie_arith, lcr_get_tie_census).  See
+// DESIGN.md "Decision arithmetic".
 // rand::thread_rng() is replaced by a counter-based generator evaluated at the draw index the
 // reference's call order implies, so restarts can run in parallel.
 #include <algorithm>
@@ -658,7 +664,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   return LCR_OK;
   };
   auto launch_enum_regions = [&]() -> int {
-  // ---- enumeration regions: all restarts in one launch per class, winner picked on the device and re-run
+  // ---- enumeration regions: all restarts in one launch per class, then k4_enum_resolve per class (the winner's state is taken
+  // from what its restart left; only the global-memory class re-runs its winner)
   if (!enum_slots.empty()) {
     // heaviest regions first (tiles are started in grid order: the kernel's tail should be the light ones; the post-phase
     // kernel's workgroups follow the same order)
