@@ -669,7 +669,15 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   if (!enum_slots.empty()) {
     // heaviest regions first (tiles are started in grid order: the kernel's tail should be the light ones; the post-phase
     // kernel's workgroups follow the same order)
-    std::stable_sort(enum_slots.begin(), enum_slots.end(), [&](int a, int b) { return stat[a].E > stat[b].E; });
+    // (this block is on the critical path -- the device idles between k4_stage and the first restart: one sort of packed keys,
+    // one layout computation per region, no allocation beyond the lists themselves: 48 -> ~10 us for C3's 366 regions)
+    {
+      std::vector<uint64_t>& key = enum_keys;   // descending E, ties in ascending region order (= the stable sort it replaces)
+      key.resize(enum_slots.size());
+      for (size_t k = 0; k < enum_slots.size(); k++) key[k] = ((uint64_t)(0xffffffffu - (uint32_t)stat[enum_slots[k]].E) << 32) | (uint32_t)enum_slots[k];
+      std::sort(key.begin(), key.end());
+      for (size_t k = 0; k < enum_slots.size(); k++) enum_slots[k] = (int32_t)(uint32_t)key[k];
+    }
     int32_t max_state = 0;
     for (int g : enum_slots) max_state = std::max(max_state, stat[g].R + 2 * (in.cand_region_off[g + 1] - in.cand_region_off[g]));
     const int32_t stride = (max_state + 63) & ~63;
@@ -684,21 +692,25 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     // from LDS at six: 0.61 vs 0.51 ms per launch pair on C4, 0.23 vs 0.13 on C3.)
     constexpr int NCLS = 5;
     std::vector<EnumSpan> spans[NCLS];
+    for (int k = 1; k < 4; k++) spans[k].reserve(enum_slots.size());
     size_t n_t[NCLS] = {0, 0, 0, 0, 0};   // tiles per class = grid of the class's kernel
 #ifndef ENUM_PER3
 #define ENUM_PER3 2u
 #endif
     const uint32_t per_of[NCLS] = {1u, ENUM_PER3 * ENUM_WAVES, ENUM_TILE_JOBS, ENUM_PER3 * ENUM_WAVES, 1u};
-    std::vector<int64_t> job_base(ng, 0), st_base(ng, 0);   // st_base: first word of the region's saved restart states (classes 2 / 3)
+    std::vector<int64_t>& job_base = enum_job_base; std::vector<int64_t>& st_base = enum_st_base;   // st_base: first word of the region's saved restart states (classes 1 - 3)
+    job_base.assign(ng, 0); st_base.assign(ng, 0);
     int64_t nj = 0, st_words = 0;
     uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0}, res_lds[NCLS] = {0, 0, 0, 0, 0};   // (res_lds: k4_enum_resolve's image of the class's largest region)
     std::vector<int32_t> post_slots;   // enumeration regions with the device epilogue
+    post_slots.reserve(enum_slots.size());
     for (int g : enum_slots) {
       const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
       const StageStat& st = stat[g];
       const EnumLayout EL = enum_layout(st.R, st.E);
+      const uint32_t RL = resolve_layout((uint32_t)st.R, (uint32_t)st.E, (uint32_t)S).total;
       int cls = 4;
-      if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_MAX && resolve_layout((uint32_t)st.R, (uint32_t)st.E, (uint32_t)S).total <= ENUM_LDS_MAX && st.max_rows <= 64)
+      if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_MAX && RL <= ENUM_LDS_MAX && st.max_rows <= 64)
 #ifdef ENUM_MASK64
         cls = force_stream ? 3 : (st.max_n <= 32 ? 2 : 3);
 #else
@@ -709,9 +721,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       // (C4 share: three such regions used to take the global-memory kernel BEHIND class 3 on its queue, 0.68 ms of the critical
       // path: step 5.49 -> 4.97 ms; a queue of their own was measured too: HIP maps a fourth stream onto one of the first three's
       // hardware queues, no difference)
-      const uint32_t RL = resolve_layout((uint32_t)st.R, (uint32_t)st.E, (uint32_t)S).total;
       if ((cls == 2 || cls == 3) && (std::max(EL.total, RL) > ENUM_LDS_BYTES || dbg.enum_force_stream == 2 /* test hook */)) cls = 1;
-      if (cls < 4) { lds_need[cls] = std::max(lds_need[cls], EL.total); res_lds[cls] = std::max(res_lds[cls], resolve_layout((uint32_t)st.R, (uint32_t)st.E, (uint32_t)S).total); }
+      if (cls < 4) { lds_need[cls] = std::max(lds_need[cls], EL.total); res_lds[cls] = std::max(res_lds[cls], RL); }
       job_base[g] = nj;
       const uint64_t n = 1ull << S;
       if (cls < 4) { st_base[g] = st_words; st_words += (int64_t)n * enum_state_words((uint32_t)st.R); }

@@ -151,6 +151,8 @@ struct PhaseHost {
   void* work = nullptr;   // PhaseWork (k4_phase.hip): per-region host state reused across calls
   ChainDev chain_dev{};                // chain-region buffers of the last run (LD blocks are read back from them)
   std::vector<ChainDesc> chain_desc;
+  std::vector<uint64_t> enum_keys;                   // scratch of the enumeration launch preparation, kept across calls
+  std::vector<int64_t> enum_job_base, enum_st_base;
   // LD blocks of one region of the last run in the reference's order (candidate.rs:733-745): off[n_blocks + 1], SNP indices
   int ld_blocks(const PhaseInputs& in, int region, std::vector<int32_t>* off, std::vector<int32_t>* snps, hipStream_t s, std::string* err);
   void free_work();
