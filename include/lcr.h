@@ -348,7 +348,8 @@ int lcr_bam_write_reads(const char* out_path, const char* contig, int64_t contig
 int lcr_ctx_set_lock_dir(lcr_ctx*, const char* dir);
 
 /* Debug / test switches (the library reads no environment variable): key = "phase_prof", "post_host", "grid_min_entries",
- * "grid_generic", "grid_spec_lanes", "post_half", "enum_force_big", "enum_force_stream", "host_threads", "tie_arith" (see PhaseDebug in
+ * "grid_generic", "grid_spec_lanes", "post_half", "enum_force_big", "enum_force_stream", "host_threads", "tie_arith", "timing_mask"
+ * (bit k: only the kernel groups LCR_K_* k are timed when timing is enabled; 0 = all) (see PhaseDebug in
  * csrc/lcr_phase_host.h), "hist_tiles" (quality histograms from K0's records: 0 = when the survivors are dense, 1 = whenever the
  * preset allows, -1 = never).  Unknown key: LCR_E_ARG.  The defaults are the product behaviour. */
 int lcr_debug_set(lcr_ctx*, const char* key, int64_t value);

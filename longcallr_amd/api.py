@@ -41,6 +41,8 @@ class Engine:
         self._keep = None
         if timing:
             self.lib.lcr_enable_timing(self.h, 1)
+            if timing is not True:   # an iterable of _abi.K_* : only these kernel groups get their two event records per call
+                self.debug_set("timing_mask", sum(1 << int(k) for k in timing))
         # developer / test hooks: the library reads no environment variable; this mirror hands LCR_* switches on (tests, tools)
         import os
         for env, key in _DEBUG_ENV.items():

@@ -81,6 +81,7 @@ struct lcr_ctx {
 
   // timing
   bool timing = false;
+  uint32_t timing_mask = 0;   // lcr_debug_set("timing_mask"): bit k = LCR_K_* k is timed; 0 = all of them (every timer is two event records on the stream)
   hipEvent_t ev[LCR_NKERNELS][2] = {};
   bool ev_valid[LCR_NKERNELS] = {};
   int64_t pileup_bytes = 0, stage_bytes = 0;
@@ -90,8 +91,9 @@ namespace {
 
 struct Timer {  // records HIP events on the ctx stream around one kernel
   lcr_ctx* c; int k;
-  Timer(lcr_ctx* c_, int k_) : c(c_), k(k_) { if (c->timing) { (void)hipEventRecord(c->ev[k][0], c->stream); } }
-  ~Timer() { if (c->timing) { (void)hipEventRecord(c->ev[k][1], c->stream); c->ev_valid[k] = true; } }
+  bool on() const { return c->timing && (c->timing_mask == 0 || ((c->timing_mask >> k) & 1u)); }
+  Timer(lcr_ctx* c_, int k_) : c(c_), k(k_) { if (on()) { (void)hipEventRecord(c->ev[k][0], c->stream); } }
+  ~Timer() { if (on()) { (void)hipEventRecord(c->ev[k][1], c->stream); c->ev_valid[k] = true; } }
 };
 
 DevParams to_dev(const lcr_params* p, float sor_thr) {
@@ -885,6 +887,7 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
   else if (k == "enum_force_stream") d.enum_force_stream = (int)value;
   else if (k == "host_threads") d.host_threads = (int)value;
   else if (k == "tie_arith") d.tie_arith = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2));
+  else if (k == "timing_mask") c->timing_mask = (uint32_t)value;
   else if (k == "plane_prefill") c->dbg_prefill = value != 0;
   else if (k == "bg_tiles") c->dbg_bg_tiles = (int)std::max<int64_t>(0, std::min<int64_t>(value, 4096));
   else if (k == "hist_tiles") c->dbg_hist_tiles = value > 0 ? 1 : value < 0 ? -1 : 0;
