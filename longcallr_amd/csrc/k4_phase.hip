@@ -702,7 +702,10 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     job_base.assign(ng, 0); st_base.assign(ng, 0);
     int64_t nj = 0, st_words = 0;
     uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0}, res_lds[NCLS] = {0, 0, 0, 0, 0};   // (res_lds: k4_enum_resolve's image of the class's largest region)
-    std::vector<int32_t> post_slots;   // enumeration regions with the device epilogue
+    // enumeration regions with the device epilogue: those of the streaming class (the largest matrices, so the longest epilogues)
+    // are post-processed on their own queue right behind their resolve kernel, beside the register class's resolve; the others
+    // behind everything on `stream`
+    std::vector<int32_t> post_slots, post_slots_b, post_slots_c;   // (c: the global-memory class, behind its winners' second launch)
     post_slots.reserve(enum_slots.size());
     for (int g : enum_slots) {
       const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
@@ -730,14 +733,14 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       spans[cls].push_back({g, (uint32_t)n_t[cls]});
       n_t[cls] += (size_t)((n + per_of[cls] - 1) / per_of[cls]);
       nj += (int64_t)n;
-      if (!host_post[g] && !grid_post[g]) post_slots.push_back(g);
+      if (!host_post[g] && !grid_post[g]) (cls == 3 ? post_slots_b : (cls == 4 ? post_slots_c : post_slots)).push_back(g);
       if (prof && cls == 4) fprintf(stderr, "[phase]   global-memory enumeration region %d: R %d E %d S %d max_rows %d max_n %d, LDS image %u B\n", g, st.R, st.E, S, st.max_rows, st.max_n, EL.total);
     }
     if (prof) fprintf(stderr, "[phase]   enumeration classes: register %zu regions / %zu tiles, streaming %zu / %zu, streaming with a large image %zu / %zu, global %zu / %zu\n", spans[2].size(), n_t[2], spans[3].size(), n_t[3], spans[1].size(), n_t[1], spans[4].size(), n_t[4]);
     // one upload: spans of every class | job_base | slots | post slots ; then job objectives and winners
     size_t n_w[NCLS], s_off[NCLS], n_spans = 0;
     for (int k = 0; k < NCLS; k++) { n_w[k] = spans[k].size(); s_off[k] = n_spans; n_spans += n_w[k]; }
-    const size_t ns = enum_slots.size(), nps = post_slots.size();
+    const size_t ns = enum_slots.size(), nps_a = post_slots.size(), nps_b = post_slots_b.size(), nps_c = post_slots_c.size(), nps = nps_a + nps_b + nps_c;
     const size_t off_jb_al = (n_spans * sizeof(EnumSpan) + 7) & ~(size_t)7;
     const size_t off_sb = off_jb_al + (size_t)ng * 8;   // st_base
     const size_t up_bytes = off_sb + (size_t)ng * 8 + (ns + nps) * 4;
@@ -750,7 +753,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     memcpy(up + off_jb_al, job_base.data(), (size_t)ng * 8);
     memcpy(up + off_sb, st_base.data(), (size_t)ng * 8);
     memcpy(up + off_sb + (size_t)ng * 8, enum_slots.data(), ns * 4);
-    memcpy(up + off_sb + (size_t)ng * 8 + ns * 4, post_slots.data(), nps * 4);
+    memcpy(up + off_sb + (size_t)ng * 8 + ns * 4, post_slots.data(), nps_a * 4);
+    memcpy(up + off_sb + (size_t)ng * 8 + (ns + nps_a) * 4, post_slots_b.data(), nps_b * 4);
+    memcpy(up + off_sb + (size_t)ng * 8 + (ns + nps_a + nps_b) * 4, post_slots_c.data(), nps_c * 4);
     PCHK(hipMemcpyAsync(b_job.p, up, up_bytes, hipMemcpyHostToDevice, stream));
     const EnumSpan* d_sp = b_job.as<EnumSpan>();
     const int64_t* d_jb = (const int64_t*)(b_job.as<uint8_t>() + off_jb_al);
@@ -767,23 +772,28 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     PCHK(hipMemsetAsync(d_rbest, 0x80, (size_t)ng * 8, stream));        // 0x8080...: far below any objective
     auto launch = [&](const size_t* cnt, const uint32_t* win) -> hipError_t {
       const bool fork = cnt[2] && (cnt[3] || cnt[4]);
-            hipStream_t s34 = fork ? aux : stream, s1 = stream;
+      hipStream_t s34 = fork ? aux : stream, s1 = stream;
       hipError_t e = hipSuccess;
       if (fork) { if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e; }
       if (cnt[1]) {   // (first, ahead of class 2 on its queue: the largest matrices have the longest restarts)
         launch_k4_enum_reg(0, (unsigned)cnt[1], lds_need[1], s1, P, d_sp + s_off[1], (int32_t)n_w[1], per_of[1], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), d_rbest);
         if (!win) launch_k4_enum_resolve((unsigned)n_w[1], res_lds[1], s1, P, d_sp + s_off[1], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());
       }
-      // classes 2 / 3: all restarts, then `prob > largest_prob` over each region's restarts from the objectives, signatures and
-      // states they left (phase.rs:1113-1119; ties between configurations of maximal objective by their f64 sums) -- a workgroup
-      // per region, each class's behind its own restarts (the streaming class's regions are resolved under the other's restarts)
-      if (cnt[2]) {
-        launch_k4_enum_reg(32, (unsigned)cnt[2], lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), d_rbest);
-        if (!win) launch_k4_enum_resolve((unsigned)n_w[2], res_lds[2], stream, P, d_sp + s_off[2], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());
-      }
-      if (cnt[3]) {
-        launch_k4_enum_reg(0, (unsigned)cnt[3], lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), d_rbest);
-        if (!win) launch_k4_enum_resolve((unsigned)n_w[3], res_lds[3], s34, P, d_sp + s_off[3], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());
+      // classes 2 / 3: all restarts (both kernels queued first), then per class `prob > largest_prob` over each region's restarts from
+      // the objectives, signatures and states they left (phase.rs:1113-1119; ties between configurations of maximal objective by
+      // their f64 sums) -- a workgroup per region -- and the post-phase kernel of the class's regions, each behind its own
+      // restarts on its own queue (the streaming class has the largest matrices, so the longest epilogues: they run beside the
+      // register class's resolve instead of behind it)
+      unsigned long long* const d_st = d_enum_st.as<unsigned long long>();
+      if (cnt[2]) launch_k4_enum_reg(32, (unsigned)cnt[2], lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, d_sb, d_st, d_rbest);
+      if (cnt[3]) launch_k4_enum_reg(0, (unsigned)cnt[3], lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, d_sb, d_st, d_rbest);
+      if (!win) {
+        if (cnt[2]) launch_k4_enum_resolve((unsigned)n_w[2], res_lds[2], stream, P, d_sp + s_off[2], d_jb, d_obj, d_sb, d_st);
+        // eight waves per region: the slowest region (most rows) sets the kernel's length, and every row sweep of the
+        // epilogue is a pass of <threads> rows (148 -> 103 us on C3)
+        if (nps_a && (e = launch_k4_post(2 * LCR_BLOCK, (unsigned)nps_a, post_lds, stream, pin, d_psl, (int32_t)nps_a, plut)) != hipSuccess) return e;
+        if (cnt[3]) launch_k4_enum_resolve((unsigned)n_w[3], res_lds[3], s34, P, d_sp + s_off[3], d_jb, d_obj, d_sb, d_st);
+        if (nps_b && (e = launch_k4_post(2 * LCR_BLOCK, (unsigned)nps_b, post_lds, s34, pin, d_psl + nps_a, (int32_t)nps_b, plut)) != hipSuccess) return e;
       }
       if (cnt[4]) launch_k4_enum_big((unsigned)cnt[4], s34, P, d_sp + s_off[4], (int32_t)n_w[4], per_of[4], d_jb, d_obj, win);
       if (fork) { if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e; }
@@ -795,11 +805,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       launch_k4_enum_pick((int32_t)n_w[4], stream, d_sp + s_off[4], P.reg, d_jb, d_obj, d_win, P.tie_ctr);
       PCHK(launch(only4, d_win));
     }
-    if (nps) {
-      // eight waves per region: the slowest region (most rows) sets the kernel's length, and every row sweep of the
-      // epilogue is a pass of <threads> rows (148 -> 103 us on C3)
-      PCHK(launch_k4_post(2 * LCR_BLOCK, (unsigned)nps, post_lds, stream, pin, d_psl, (int32_t)nps, plut));
-    }
+    if (nps_c) PCHK(launch_k4_post(2 * LCR_BLOCK, (unsigned)nps_c, post_lds, stream, pin, d_psl + nps_a + nps_b, (int32_t)nps_c, plut));
     PCHK(hipGetLastError());
   }
   return LCR_OK;
