@@ -26,6 +26,8 @@ struct lcr_ctx {
   // asynchronous input path (lcr_load_batch_async / lcr_bind_batch): two staging slots, filled on an upload stream
   struct UploadSlot { DevBuf buf[16]; hipEvent_t ev = nullptr; bool filled = false; lcr_reads rd{}; lcr_regions rg{}; } up[2];
   hipStream_t up_stream = nullptr;
+  hipEvent_t ev_dl = nullptr, ev_cand_dl = nullptr;   // lcr_candidates: the candidate records' download on the phase stage's second queue
+  bool cand_dl_other = false;
   hipStream_t fill_stream = nullptr;           // zero fill of the count planes beside K0 (lcr_pileup)
   hipEvent_t ev_fill0 = nullptr, ev_fill1 = nullptr;
   int bound_slot = -1;
@@ -163,6 +165,8 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
   for (auto& u : c->up) { for (auto& b : u.buf) b.release(); if (u.ev) (void)hipEventDestroy(u.ev); }
   if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+  if (c->ev_dl) (void)hipEventDestroy(c->ev_dl);
+  if (c->ev_cand_dl) (void)hipEventDestroy(c->ev_cand_dl);
   if (c->fill_stream) { (void)hipStreamSynchronize(c->fill_stream); (void)hipStreamDestroy(c->fill_stream); }
   if (c->ev_fill0) (void)hipEventDestroy(c->ev_fill0);
   if (c->ev_fill1) (void)hipEventDestroy(c->ev_fill1);
@@ -558,6 +562,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, hipSetDevice(c->device));
   c->dp = to_dev(p, c->dp.sor_threshold);
   const int ng = c->bv.n_regions, nt = c->n_tiles;
+  if (c->cand_pending && c->cand_dl_other) HIPCHK(c, hipEventSynchronize(c->ev_cand_dl));   // (a previous call's download nobody picked up: its source is rewritten below)
   HIPCHK(c, c->flags.reserve(std::max<size_t>(c->n_cols, 1)));
   HIPCHK(c, c->tile_count.reserve(std::max(nt, 1) * 4));
   HIPCHK(c, c->tile_off.reserve((std::max(nt, 1) + 1) * 4));
@@ -613,8 +618,20 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
                    c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), p->dense_win, p->min_dense_cnt, c->stream);
   HIPCHK(c, c->h_stage[1].reserve(std::max<size_t>(n_sv, 1) * sizeof(lcr_candidate)));
   HIPCHK(c, c->h_stage[2].reserve((size_t)(ng + 1) * 4));
-  if (n_sv) HIPCHK(c, hipMemcpyAsync(c->h_stage[1].p, c->d_cand.p, (size_t)n_sv * sizeof(lcr_candidate), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_stage[2].p, c->d_cand_off.p, (size_t)(ng + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+  // The records' capacity -- every survivor kept -- is what can be copied without knowing the count: 3 MB on C3, 30 us of the
+  // queue.  It goes to the phase stage's second queue when that exists (idle until lcr_phase), so that the fragment stage's
+  // kernels do not wait behind it.  (A queue of the context's own for it was measured: the process has four hardware queues,
+  // and a fourth stream pushes the phase stage's queues onto shared ones -- lcr_phase +0.15 ms.)
+  hipStream_t dl = c->phase.side ? c->phase.side : c->stream;
+  if (dl != c->stream) {
+    if (!c->ev_dl) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_dl, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_cand_dl, hipEventDisableTiming)); }
+    HIPCHK(c, hipEventRecord(c->ev_dl, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(dl, c->ev_dl, 0));
+  }
+  if (n_sv) HIPCHK(c, hipMemcpyAsync(c->h_stage[1].p, c->d_cand.p, (size_t)n_sv * sizeof(lcr_candidate), hipMemcpyDeviceToHost, dl));
+  HIPCHK(c, hipMemcpyAsync(c->h_stage[2].p, c->d_cand_off.p, (size_t)(ng + 1) * 4, hipMemcpyDeviceToHost, dl));
+  c->cand_dl_other = dl != c->stream;
+  if (c->cand_dl_other) HIPCHK(c, hipEventRecord(c->ev_cand_dl, dl));
   // rows of the fragment matrix per region (fragment.rs:51-54) depend on the candidates only: computed here so
   // that lcr_fragments starts without a round trip
   HIPCHK(c, c->region_rows.reserve(std::max(ng, 1) * 4));
@@ -649,6 +666,7 @@ int lcr_get_candidates(lcr_ctx* c, lcr_candidate_list* out) {
 static int cand_settle(lcr_ctx* c) {
   if (!c->cand_pending) return LCR_OK;
   HIPCHK(c, hipEventSynchronize(c->ev_cand));
+  if (c->cand_dl_other) HIPCHK(c, hipEventSynchronize(c->ev_cand_dl));
   const int ng = c->bv.n_regions;
   memcpy(c->h_cand_off.data(), c->h_stage[2].p, (size_t)(ng + 1) * 4);
   c->h_cand.assign(c->h_stage[1].as<lcr_candidate>(), c->h_stage[1].as<lcr_candidate>() + c->h_cand_off[ng]);
