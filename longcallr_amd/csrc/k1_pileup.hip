@@ -479,7 +479,7 @@ __device__ __forceinline__ int tile_class(int fill) { return fill > 0 ? __clz(fi
 __global__ void __launch_bounds__(256) k1_tiles_a(const int32_t* __restrict__ tile_fill, const int32_t* __restrict__ tile_ndiff,
                                                    const int32_t* __restrict__ tile_nent, int32_t n_tiles, TileScanTmp* __restrict__ tmp,
                                                    int2* __restrict__ blk_sum, const unsigned int* __restrict__ acct, int32_t n_acct,
-                                                   unsigned int* __restrict__ ctl) {
+                                                   unsigned int* __restrict__ ctl, unsigned int* __restrict__ host_ctl) {
   __shared__ int hist[33], ws[4][2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (blockIdx.x == 0 && w == 0) {   // K0's accounting slots -> control block, fetched by the host behind this kernel
@@ -487,7 +487,11 @@ __global__ void __launch_bounds__(256) k1_tiles_a(const int32_t* __restrict__ ti
     for (int i = lane; i < n_acct; i += 64) { it += (int)acct[32 * i]; rc += (int)acct[32 * i + 1]; pt = max(pt, (int)acct[32 * i + 2]); dt = max(dt, (int)acct[32 * i + 3]); }
     it = wave_incl_scan(it); rc = wave_incl_scan(rc);
     for (int o = 32; o > 0; o >>= 1) { pt = max(pt, __shfl_xor(pt, o, 64)); dt = max(dt, __shfl_xor(dt, o, 64)); }
-    if (lane == 63) { ctl[0] = (unsigned int)pt; ctl[1] = (unsigned int)it; ctl[2] = (unsigned int)rc; ctl[4] = (unsigned int)dt; }
+    if (lane == 63) {
+      ctl[0] = (unsigned int)pt; ctl[1] = (unsigned int)it; ctl[2] = (unsigned int)rc; ctl[4] = (unsigned int)dt;
+      // the same five words straight into the host's pinned block (ctl[3] = K0's verdict): no copy in the queue in front of k1_tiles_b
+      if (host_ctl) { host_ctl[0] = (unsigned int)pt; host_ctl[1] = (unsigned int)it; host_ctl[2] = (unsigned int)rc; host_ctl[3] = ctl[3]; host_ctl[4] = (unsigned int)dt; }
+    }
   }
   if (tid < 33) hist[tid] = 0;
   __syncthreads();
@@ -591,9 +595,9 @@ void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* til
 // the tile passes alone (the host fetches K0's control block behind pass A, before the rest is queued)
 size_t launch_k1_tiles_tmp_words(int32_t n_tiles) { return 88 + 2 * (size_t)((n_tiles + TS_TILES - 1) / TS_TILES) + 8; }
 void launch_k1_tiles_a(int32_t n_tiles, const int32_t* tile_fill, const int32_t* tile_ndiff, const int32_t* tile_nent, int32_t* tmp /* zeroed */,
-                       const unsigned int* acct, int32_t n_acct, unsigned int* ctl, hipStream_t s) {
+                       const unsigned int* acct, int32_t n_acct, unsigned int* ctl, unsigned int* host_ctl, hipStream_t s) {
   const int nb = (n_tiles + TS_TILES - 1) / TS_TILES;
-  hipLaunchKernelGGL(k1_tiles_a, dim3(nb), dim3(256), 0, s, tile_fill, tile_ndiff, tile_nent, n_tiles, (TileScanTmp*)tmp, (int2*)(tmp + 88), acct, n_acct, ctl);
+  hipLaunchKernelGGL(k1_tiles_a, dim3(nb), dim3(256), 0, s, tile_fill, tile_ndiff, tile_nent, n_tiles, (TileScanTmp*)tmp, (int2*)(tmp + 88), acct, n_acct, ctl, host_ctl);
 }
 void launch_k1_tiles_b(int32_t n_tiles, const int32_t* tile_fill, const int32_t* tile_ndiff, const int32_t* tile_nent, int32_t* tmp,
                        int32_t* tile_nbase, int32_t* ent_off, int32_t* order, hipStream_t s) {

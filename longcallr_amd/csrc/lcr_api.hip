@@ -502,9 +502,12 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
     int32_t* const ctl = c->h_stage[0].as<int32_t>();
     if (!c->ev_ctl) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ctl, hipEventDisableTiming));
     { Timer t(c, LCR_K_PILEUP);   // (the tally kernel with its ordering and chunk-binning passes)
-      if (nt > 0) launch_k1_tiles_a(nt, fill, fill + o_ndiff, fill + o_nch, fill + o_tmp, (unsigned int*)(fill + o_acct), launch_k0_acct_slots(),
-                                    (unsigned int*)(fill + nt + 1), c->stream);
-      HIPCHK(c, hipMemcpyAsync(ctl, fill + nt + 1, 32, hipMemcpyDeviceToHost, c->stream));
+      if (nt > 0) {   // (k1_tiles_a writes K0's verdict and counts straight into the pinned block: no copy in the queue in front of k1_tiles_b)
+        unsigned int* d_ctl = nullptr;
+        HIPCHK(c, hipHostGetDevicePointer((void**)&d_ctl, ctl, 0));
+        launch_k1_tiles_a(nt, fill, fill + o_ndiff, fill + o_nch, fill + o_tmp, (unsigned int*)(fill + o_acct), launch_k0_acct_slots(),
+                          (unsigned int*)(fill + nt + 1), d_ctl, c->stream);
+      } else HIPCHK(c, hipMemcpyAsync(ctl, fill + nt + 1, 32, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipEventRecord(c->ev_ctl, c->stream));
       if (nt > 0) launch_k1_tiles_b(nt, fill, fill + o_ndiff, fill + o_nch, fill + o_tmp, c->tile_nbase.as<int32_t>(), c->chunk_off.as<int32_t>(),
                                     c->tile_order.as<int32_t>(), c->stream);

@@ -158,7 +158,7 @@ void launch_k0_desc_bin(const void* ctl, const unsigned int* acct, unsigned int 
                         hipStream_t s);
 size_t launch_k1_tiles_tmp_words(int32_t n_tiles);
 void launch_k1_tiles_a(int32_t n_tiles, const int32_t* tile_fill, const int32_t* tile_ndiff, const int32_t* tile_nent, int32_t* tmp /* zeroed */,
-                       const unsigned int* acct, int32_t n_acct, unsigned int* ctl, hipStream_t s);
+                       const unsigned int* acct, int32_t n_acct, unsigned int* ctl, unsigned int* host_ctl /* pinned host block as the device sees it, or nullptr */, hipStream_t s);
 void launch_k1_tiles_b(int32_t n_tiles, const int32_t* tile_fill, const int32_t* tile_ndiff, const int32_t* tile_nent, int32_t* tmp,
                        int32_t* tile_nbase, int32_t* ent_off, int32_t* order, hipStream_t s);
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
