@@ -89,12 +89,13 @@ __global__ void __launch_bounds__(LCR_BLOCK) scan_phase3(OutT* __restrict__ out,
 __global__ void write_total_i32(const long long* total, int32_t* dst) { *dst = (int32_t)*total; }
 // out[i] = idx[i] < n_src ? src[idx[i]] : *total   (exclusive-scan values at selected positions, e.g. per region)
 __global__ void gather_i32(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, int32_t n, int32_t n_src,
-                           const int32_t* __restrict__ total, int32_t* __restrict__ out) {
+                           const int32_t* __restrict__ total, int32_t* __restrict__ out, int32_t* __restrict__ host_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = idx[i] < n_src ? src[idx[i]] : *total;
+  if (i < n) { const int32_t v = idx[i] < n_src ? src[idx[i]] : *total; out[i] = v; if (host_out) host_out[i] = v; }
 }
-void launch_gather_i32(const int32_t* src, const int32_t* idx, int32_t n, int32_t n_src, const int32_t* total, int32_t* out, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(gather_i32, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, n, n_src, total, out);
+// host_out: the same values into pinned host memory (as the device sees it), or nullptr -- the host then needs no copy behind the kernel
+void launch_gather_i32(const int32_t* src, const int32_t* idx, int32_t n, int32_t n_src, const int32_t* total, int32_t* out, hipStream_t s, int32_t* host_out) {
+  if (n > 0) hipLaunchKernelGGL(gather_i32, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, n, n_src, total, out, host_out);
 }
 __global__ void write_total_i64(const long long* total, int64_t* dst) { *dst = (int64_t)*total; }
 

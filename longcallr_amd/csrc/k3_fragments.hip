@@ -9,21 +9,22 @@
 
 // rows per region: reads with pos <= last candidate pos (reads are sorted by pos)
 __global__ void k3_rows(BatchView b, const lcr_candidate* __restrict__ cand, const int32_t* __restrict__ cand_region_off,
-                        int32_t* __restrict__ region_rows) {
+                        int32_t* __restrict__ region_rows, int32_t* __restrict__ host_out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= b.n_regions) return;
   const int c0 = cand_region_off[g], c1 = cand_region_off[g + 1];
-  if (c1 <= c0) { region_rows[g] = 0; return; }  // fragment.rs:24-26
+  if (c1 <= c0) { region_rows[g] = 0; if (host_out) host_out[g] = 0; return; }  // fragment.rs:24-26
   const int64_t last = cand[c1 - 1].pos;
   int lo = b.read_begin[g], hi = b.read_begin[g + 1];
   const int rb = lo;
   while (lo < hi) { int mid = (lo + hi) >> 1; if ((int64_t)b.pos[mid] > last) hi = mid; else lo = mid + 1; }
   region_rows[g] = lo - rb;
+  if (host_out) host_out[g] = lo - rb;
 }
 void launch_k3_rows(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off, int32_t* region_rows,
-                    hipStream_t s) {
+                    hipStream_t s, int32_t* host_out) {
   if (b.n_regions == 0) return;
-  hipLaunchKernelGGL(k3_rows, dim3((b.n_regions + 255) / 256), dim3(256), 0, s, b, cand, cand_region_off, region_rows);
+  hipLaunchKernelGGL(k3_rows, dim3((b.n_regions + 255) / 256), dim3(256), 0, s, b, cand, cand_region_off, region_rows, host_out);
 }
 
 // first row of every region: exclusive prefix sum of region_rows (one workgroup; a batch has at most a few
@@ -53,12 +54,12 @@ void launch_k3_row_offsets(const int32_t* region_rows, int32_t ng, int32_t* row_
 
 // first entry of every region: row_ptr at the regions' first rows ([ng] = all entries)
 __global__ void k3_region_entries(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ row_region_off, int32_t ng,
-                                  int64_t* __restrict__ region_e_off) {
+                                  int64_t* __restrict__ region_e_off, int64_t* __restrict__ host_out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g <= ng) region_e_off[g] = row_ptr[row_region_off[g]];
+  if (g <= ng) { const int64_t v = row_ptr[row_region_off[g]]; region_e_off[g] = v; if (host_out) host_out[g] = v; }
 }
-void launch_k3_region_entries(const int64_t* row_ptr, const int32_t* row_region_off, int32_t ng, int64_t* region_e_off, hipStream_t s) {
-  hipLaunchKernelGGL(k3_region_entries, dim3((ng + 256) / 256), dim3(256), 0, s, row_ptr, row_region_off, ng, region_e_off);
+void launch_k3_region_entries(const int64_t* row_ptr, const int32_t* row_region_off, int32_t ng, int64_t* region_e_off, hipStream_t s, int64_t* host_out) {
+  hipLaunchKernelGGL(k3_region_entries, dim3((ng + 256) / 256), dim3(256), 0, s, row_ptr, row_region_off, ng, region_e_off, host_out);
 }
 
 // Sixteen lanes per row (row16_walk_sites, lcr_dev.h): the region's candidates inside the read's reference

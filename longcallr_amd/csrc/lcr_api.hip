@@ -577,9 +577,10 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   // survivors per region = tile offsets at the regions' first tiles (gathered on the device, pinned D2H)
   HIPCHK(c, c->sv_region_off.reserve((ng + 1) * 4));
   HIPCHK(c, c->h_stage[0].reserve((ng + 2) * 4));
-  launch_gather_i32(c->tile_off.as<int32_t>(), c->first_tile.as<int32_t>(), ng + 1, nt, c->total.as<int32_t>(), c->sv_region_off.as<int32_t>(), c->stream);
   int32_t* const sv_off = c->h_stage[0].as<int32_t>();
-  HIPCHK(c, hipMemcpyAsync(sv_off, c->sv_region_off.p, (ng + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+  { int32_t* d_sv = nullptr;   // (the gather writes the offsets into the pinned block as well: the wait needs no copy behind it)
+    HIPCHK(c, hipHostGetDevicePointer((void**)&d_sv, sv_off, 0));
+    launch_gather_i32(c->tile_off.as<int32_t>(), c->first_tile.as<int32_t>(), ng + 1, nt, c->total.as<int32_t>(), c->sv_region_off.as<int32_t>(), c->stream, d_sv); }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   const int32_t n_sv = sv_off[ng];
@@ -639,10 +640,11 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   // that lcr_fragments starts without a round trip
   HIPCHK(c, c->region_rows.reserve(std::max(ng, 1) * 4));
   HIPCHK(c, c->h_stage[3].reserve(std::max(ng, 1) * 4));
-  launch_k3_rows(c->bv, c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->region_rows.as<int32_t>(), c->stream);
+  { int32_t* d_rr = nullptr;   // (the rows per region also go straight into the pinned block: no copy in the queue)
+    HIPCHK(c, hipHostGetDevicePointer((void**)&d_rr, c->h_stage[3].p, 0));
+    launch_k3_rows(c->bv, c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->region_rows.as<int32_t>(), c->stream, d_rr); }
   HIPCHK(c, c->row_region_off.reserve((ng + 1) * 4));
   launch_k3_row_offsets(c->region_rows.as<int32_t>(), ng, c->row_region_off.as<int32_t>(), c->stream);
-  if (ng) HIPCHK(c, hipMemcpyAsync(c->h_stage[3].p, c->region_rows.p, ng * 4, hipMemcpyDeviceToHost, c->stream));
   // no wait here: the host copies are picked up by whoever needs them first (cand_settle) -- lcr_fragments queues its
   // count pass before it does, so the GPU does not idle across the call boundary
   if (!c->ev_cand) HIPCHK(c, hipEventCreateWithFlags(&c->ev_cand, hipEventDisableTiming));
@@ -712,8 +714,9 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->h_nnz.reserve((size_t)(ng + 1) * 8));
   HIPCHK(c, c->region_e_off.reserve((size_t)(ng + 1) * 8));
   if (!c->ev_nnz) HIPCHK(c, hipEventCreateWithFlags(&c->ev_nnz, hipEventDisableTiming));
-  launch_k3_region_entries(c->row_ptr.as<int64_t>(), c->row_region_off.as<int32_t>(), ng, c->region_e_off.as<int64_t>(), c->stream);
-  HIPCHK(c, hipMemcpyAsync(c->h_nnz.p, c->region_e_off.p, (size_t)(ng + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+  { int64_t* d_nnz = nullptr;   // (straight into the pinned block: no copy in the queue in front of the fill pass)
+    HIPCHK(c, hipHostGetDevicePointer((void**)&d_nnz, c->h_nnz.p, 0));
+    launch_k3_region_entries(c->row_ptr.as<int64_t>(), c->row_region_off.as<int32_t>(), ng, c->region_e_off.as<int64_t>(), c->stream, d_nnz); }
   HIPCHK(c, hipEventRecord(c->ev_nnz, c->stream));
   c->nnz_pending = true;
   // now the candidates' host copies (long since there): rows per region, candidates per region

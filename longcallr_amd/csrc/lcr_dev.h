@@ -170,7 +170,8 @@ void launch_k1_zonefix(const BatchView& b, const ReadBin* rbin, int D, int L, in
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const int32_t* tile_fill, uint8_t* flags,
                       int32_t* tile_count, hipStream_t s);   // tile_fill: K0's record counters of the last lcr_pileup
-void launch_gather_i32(const int32_t* src, const int32_t* idx, int32_t n, int32_t n_src, const int32_t* total, int32_t* out, hipStream_t s);
+void launch_gather_i32(const int32_t* src, const int32_t* idx, int32_t n, int32_t n_src, const int32_t* total, int32_t* out, hipStream_t s,
+                       int32_t* host_out = nullptr /* pinned host memory as the device sees it: the same values, no copy needed */);
 void launch_scan_i32(DevBuf& tmp, const int32_t* in, int32_t* out_excl, int32_t n, int32_t* total, hipStream_t s);
 void launch_k2_compact(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                        int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const uint8_t* flags,
@@ -188,7 +189,7 @@ void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t*
                       int32_t n_regions, int32_t* pos, int32_t* idx, lcr_candidate* out, int32_t* cand_off, uint32_t dense_win,
                       uint32_t min_dense_cnt, hipStream_t s);
 void launch_k3_row_offsets(const int32_t* region_rows, int32_t ng, int32_t* row_region_off, hipStream_t s);
-void launch_k3_region_entries(const int64_t* row_ptr, const int32_t* row_region_off, int32_t ng, int64_t* region_e_off, hipStream_t s);
+void launch_k3_region_entries(const int64_t* row_ptr, const int32_t* row_region_off, int32_t ng, int64_t* region_e_off, hipStream_t s, int64_t* host_out = nullptr);
 void launch_k3_count(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
                      const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, uint32_t* row_links, int32_t* tmp_col,
                      uint8_t* tmp_val, hipStream_t s);   // tmp_*: launch_k3_inline() provisional entries per row
@@ -197,7 +198,7 @@ void launch_k3_fill(const BatchView& b, const ReadBin* rbin, const lcr_candidate
                     const uint8_t* tmp_val, int32_t* col, uint8_t* val, hipStream_t s);
 int launch_k3_inline();
 void launch_k3_rows(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off, int32_t* region_rows,
-                    hipStream_t s);
+                    hipStream_t s, int32_t* host_out = nullptr /* pinned host memory as the device sees it */);
 void launch_scan_i32_to_i64(DevBuf& tmp, const int32_t* in, int64_t* out_excl, int32_t n, hipStream_t s);
 
 void launch_k5_span_diff(const int32_t* ref_start, const int32_t* ref_end, int32_t n, int64_t contig_len, uint32_t* diff, hipStream_t s);
