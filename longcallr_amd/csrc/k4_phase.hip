@@ -510,7 +510,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   if (ng) {
     StageIn si{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, in.d_cand, in.d_cand_off, in.d_row_region_off, in.d_start0,
                prm.min_linkers, prm.max_enum_snps, prm.seed, std::max<int64_t>(grid_min, 1)};
-    StageOut so{b_reg.as<RegionDev>(), b_stat.as<StageStat>(), b_prp.as<int32_t>(), b_pc.as<int32_t>(), b_pv.as<uint8_t>(),
+    StageStat* d_stat = nullptr;   // the per-region sizes go straight into pinned host memory (no copy behind the staging kernels)
+    PCHK(hipHostGetDevicePointer((void**)&d_stat, stat, 0));
+    StageOut so{b_reg.as<RegionDev>(), d_stat, b_prp.as<int32_t>(), b_pc.as<int32_t>(), b_pv.as<uint8_t>(),
                 b_cp.as<int32_t>(), b_cr.as<int32_t>(), b_cv.as<uint8_t>(), b_snp.as<uint8_t>(), b_snp.as<int8_t>() + nc1,
                 b_snp.as<uint8_t>() + 2 * nc1, b_sc.as<long long>(), b_cur.as<int32_t>(), b_psrc.as<int32_t>()};
     launch_k4_stage((int32_t)ng, stream, si, so, L.dev);
@@ -522,7 +524,6 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       PCHK(hipEventRecord(ev_join, side));
       PCHK(hipStreamWaitEvent(stream, ev_join, 0));
     }
-    PCHK(hipMemcpyAsync(stat, b_stat.p, (size_t)ng * sizeof(StageStat), hipMemcpyDeviceToHost, stream));
     PCHK(hipMemsetAsync(b_st.p, 0, st_bytes, stream));
     PCHK(hipEventRecord(ev_csr, stream));   // the chain kernels on `side` read the staged matrices
   }
