@@ -455,6 +455,23 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   PCHK(hipMemsetAsync(d_tie.p, 0, TIE_NCTR * 8, stream));   // (before ev_in: every queue of this call starts behind it)
   P.lut64 = d_lut64.as<PostLut>(); P.tie_ctr = d_tie.as<unsigned long long>(); P.tie_arith = dbg.tie_arith;
 
+  // ---- queue `stream`: stage the phase matrices -- launched before the host sorts the regions into their kernel classes (the
+  // device would idle for that long); the per-region sizes arrive in pinned host memory
+  const int64_t grid_min = dbg.grid_min >= 0 ? dbg.grid_min : (1 << 17);   // chain regions with at least this many phase entries get all CUs (tests: 0 = every region)
+  StageStat* const stat = h_pin[5].as<StageStat>();
+  StageIn si{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, in.d_cand, in.d_cand_off, in.d_row_region_off, in.d_start0,
+             prm.min_linkers, prm.max_enum_snps, prm.seed, std::max<int64_t>(grid_min, 1)};
+  StageOut so{};
+  if (ng) {
+    StageStat* d_stat = nullptr;   // the per-region sizes go straight into pinned host memory (no copy behind the staging kernels)
+    PCHK(hipHostGetDevicePointer((void**)&d_stat, stat, 0));
+    so = StageOut{b_reg.as<RegionDev>(), d_stat, b_prp.as<int32_t>(), b_pc.as<int32_t>(), b_pv.as<uint8_t>(),
+                  b_cp.as<int32_t>(), b_cr.as<int32_t>(), b_cv.as<uint8_t>(), b_snp.as<uint8_t>(), b_snp.as<int8_t>() + nc1,
+                  b_snp.as<uint8_t>() + 2 * nc1, b_sc.as<long long>(), b_cur.as<int32_t>(), b_psrc.as<int32_t>()};
+    launch_k4_stage((int32_t)ng, stream, si, so, L.dev);
+    PCHK(hipGetLastError());
+  }
+
   // enumeration (S <= max_enum_snps) and chain regions
   std::vector<int32_t> enum_slots, chain_slots;
   for (int g = 0; g < ng; g++) {
@@ -466,7 +483,6 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   // the host epilogue (RegionHost) for the others and, as a cross-check, for all regions under LCR_POST_HOST=1.  The
   // regions' sizes are on the host already (lcr_fragments), so this is known before anything is queued.
   const bool force_host_post = dbg.post_host != 0;
-  const int64_t grid_min = dbg.grid_min >= 0 ? dbg.grid_min : (1 << 17);   // chain regions with at least this many phase entries get all CUs (tests: 0 = every region)
   std::vector<uint8_t> host_post(ng, 0), grid_post(ng, 0), grid_stage(ng, 0);
   bool any_host_post = false;
   uint32_t post_lds = 0;
@@ -506,17 +522,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   }
 
   // ---- queue `stream`: stage the phase matrices, fetch the per-region sizes
-  StageStat* const stat = h_pin[5].as<StageStat>();
   if (ng) {
-    StageIn si{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, in.d_cand, in.d_cand_off, in.d_row_region_off, in.d_start0,
-               prm.min_linkers, prm.max_enum_snps, prm.seed, std::max<int64_t>(grid_min, 1)};
-    StageStat* d_stat = nullptr;   // the per-region sizes go straight into pinned host memory (no copy behind the staging kernels)
-    PCHK(hipHostGetDevicePointer((void**)&d_stat, stat, 0));
-    StageOut so{b_reg.as<RegionDev>(), d_stat, b_prp.as<int32_t>(), b_pc.as<int32_t>(), b_pv.as<uint8_t>(),
-                b_cp.as<int32_t>(), b_cr.as<int32_t>(), b_cv.as<uint8_t>(), b_snp.as<uint8_t>(), b_snp.as<int8_t>() + nc1,
-                b_snp.as<uint8_t>() + 2 * nc1, b_sc.as<long long>(), b_cur.as<int32_t>(), b_psrc.as<int32_t>()};
-    launch_k4_stage((int32_t)ng, stream, si, so, L.dev);
-    PCHK(hipGetLastError());
     if (!gstage_slots.empty()) {   // large regions: all CUs on one region at a time (every persistent launch goes to `side`)
       GRID_LOCK();
       PCHK(b_ctl.reserve((4 + 16) * sizeof(GridCtl))); PCHK(b_btot.reserve((size_t)(2 * std::max(1, k4_grid_blocks()) + 1) * 4 + 64));
