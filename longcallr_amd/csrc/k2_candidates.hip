@@ -86,6 +86,32 @@ __global__ void __launch_bounds__(LCR_BLOCK) scan_phase3(OutT* __restrict__ out,
   for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) out[base + k] += (OutT)add;
   (void)write_last;
 }
+// Phases 2 + 3 + the total in one kernel for scans of up to SCAN_FUSED_BLOCKS blocks (every scan of the stage calls): a block adds up
+// the sums of the blocks before it itself (a few hundred coalesced words) instead of waiting for a one-block kernel to scan them --
+// five tiny kernels per scan-and-gather become three (each is ~5 us of queue whatever it does).
+#define SCAN_FUSED_BLOCKS 2048
+template <typename OutT>
+__global__ void __launch_bounds__(LCR_BLOCK) scan_phase3x(OutT* __restrict__ out, int32_t n, const long long* __restrict__ block_sum, int32_t n_blocks,
+                                                          int32_t* __restrict__ total32, int64_t* __restrict__ total64) {
+  __shared__ long long wsum[LCR_BLOCK / 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  long long s = 0;
+  for (int j = tid; j < (int)blockIdx.x; j += LCR_BLOCK) s += block_sum[j];
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+  if (lane == 0) wsum[w] = s;
+  __syncthreads();
+  long long add = 0;
+#pragma unroll
+  for (int i = 0; i < LCR_BLOCK / 64; i++) add += wsum[i];
+  const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)tid * SCAN_ITEMS;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) out[base + k] += (OutT)add;
+  if ((int)blockIdx.x == n_blocks - 1 && tid == 0) {
+    const long long tot = add + block_sum[n_blocks - 1];
+    if (total32) *total32 = (int32_t)tot;
+    if (total64) *total64 = (int64_t)tot;
+  }
+}
 __global__ void write_total_i32(const long long* total, int32_t* dst) { *dst = (int32_t)*total; }
 // out[i] = idx[i] < n_src ? src[idx[i]] : *total   (exclusive-scan values at selected positions, e.g. per region)
 __global__ void gather_i32(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, int32_t n, int32_t n_src,
@@ -104,7 +130,10 @@ void launch_scan_i32(DevBuf& tmp, const int32_t* in, int32_t* out_excl, int32_t 
   const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   (void)tmp.reserve(((size_t)nb + 2) * sizeof(long long));
   long long* bs = tmp.as<long long>();
-  if (n > 0) {
+  if (n > 0 && nb <= SCAN_FUSED_BLOCKS) {
+    hipLaunchKernelGGL(scan_phase1<int32_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, in, out_excl, n, bs);
+    hipLaunchKernelGGL(scan_phase3x<int32_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, out_excl, n, bs, nb, total, (int64_t*)nullptr);
+  } else if (n > 0) {
     hipLaunchKernelGGL(scan_phase1<int32_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, in, out_excl, n, bs);
     hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(1024), 0, s, bs, nb, bs + nb);
     hipLaunchKernelGGL(scan_phase3<int32_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, out_excl, n, bs, 0);
@@ -118,7 +147,10 @@ void launch_scan_i32_to_i64(DevBuf& tmp, const int32_t* in, int64_t* out_excl, i
   const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   (void)tmp.reserve(((size_t)nb + 2) * sizeof(long long));
   long long* bs = tmp.as<long long>();
-  if (n > 0) {
+  if (n > 0 && nb <= SCAN_FUSED_BLOCKS) {
+    hipLaunchKernelGGL(scan_phase1<int64_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, in, out_excl, n, bs);
+    hipLaunchKernelGGL(scan_phase3x<int64_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, out_excl, n, bs, nb, (int32_t*)nullptr, out_excl + n);
+  } else if (n > 0) {
     hipLaunchKernelGGL(scan_phase1<int64_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, in, out_excl, n, bs);
     hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(1024), 0, s, bs, nb, bs + nb);
     hipLaunchKernelGGL(scan_phase3<int64_t>, dim3(nb), dim3(LCR_BLOCK), 0, s, out_excl, n, bs, 0);
