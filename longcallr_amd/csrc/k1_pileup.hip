@@ -104,6 +104,18 @@ void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t
   if (b.n_regions == 0) return;
   hipLaunchKernelGGL(k0_read_region, dim3(b.n_regions), dim3(LCR_BLOCK), 0, s, b.read_begin, read_region);
 }
+// both tables in one launch (a block per region fills its tiles, then its reads)
+__global__ void __launch_bounds__(LCR_BLOCK) k0_tiles_read_region(const int32_t* __restrict__ first_tile, int32_t* __restrict__ tile_region,
+                                                                   int32_t* __restrict__ tile_col0, const int32_t* __restrict__ read_begin,
+                                                                   int32_t* __restrict__ read_region) {
+  const int g = blockIdx.x, t0 = first_tile[g], t1 = first_tile[g + 1];
+  for (int t = t0 + threadIdx.x; t < t1; t += blockDim.x) { tile_region[t] = g; tile_col0[t] = (t - t0) * LCR_TILE; }
+  for (int r = read_begin[g] + threadIdx.x; r < read_begin[g + 1]; r += blockDim.x) read_region[r] = g;
+}
+void launch_k0_tiles_read_region(const BatchView& b, const int32_t* first_tile, int32_t* tile_region, int32_t* tile_col0, int32_t* read_region, hipStream_t s) {
+  if (b.n_regions == 0) return;
+  hipLaunchKernelGGL(k0_tiles_read_region, dim3(b.n_regions), dim3(LCR_BLOCK), 0, s, first_tile, tile_region, tile_col0, b.read_begin, read_region);
+}
 
 // ---------------------------------------------------------------------------------------------
 // per-read header pack (once per batch): everything K0 needs about a read in one 64-byte line

@@ -51,6 +51,44 @@ __global__ void __launch_bounds__(1024) k3_row_offsets(const int32_t* __restrict
 void launch_k3_row_offsets(const int32_t* region_rows, int32_t ng, int32_t* row_region_off, hipStream_t s) {
   hipLaunchKernelGGL(k3_row_offsets, dim3(1), dim3(1024), 0, s, region_rows, ng, row_region_off);
 }
+// k3_rows + k3_row_offsets in one launch (one workgroup: a thread per region finds its rows, then the prefix sums)
+__global__ void __launch_bounds__(1024) k3_rows_offsets(BatchView b, const lcr_candidate* __restrict__ cand, const int32_t* __restrict__ cand_region_off,
+                                                        int32_t* __restrict__ region_rows, int32_t* __restrict__ row_region_off, int32_t* __restrict__ host_rows) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ng = b.n_regions;
+  if (tid == 0) { base_s = 0; row_region_off[0] = 0; }
+  __syncthreads();
+  for (int g0 = 0; g0 < ng; g0 += 1024) {
+    const int g = g0 + tid;
+    int rows = 0;
+    if (g < ng) {
+      const int c0 = cand_region_off[g], c1 = cand_region_off[g + 1];
+      if (c1 > c0) {   // fragment.rs:24-26, 51-54: reads with pos <= the last candidate's (reads are sorted by pos)
+        const int64_t last = cand[c1 - 1].pos;
+        int lo = b.read_begin[g], hi = b.read_begin[g + 1];
+        const int rb = lo;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)b.pos[mid] > last) hi = mid; else lo = mid + 1; }
+        rows = lo - rb;
+      }
+      region_rows[g] = rows;
+      if (host_rows) host_rows[g] = rows;
+    }
+    const int incl = wave_incl_scan(rows);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = base_s;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    if (g < ng) row_region_off[g + 1] = before + incl;
+    __syncthreads();
+    if (tid == 1023) base_s = before + incl;
+    __syncthreads();
+  }
+}
+void launch_k3_rows_offsets(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off, int32_t* region_rows, int32_t* row_region_off,
+                            hipStream_t s, int32_t* host_rows) {
+  hipLaunchKernelGGL(k3_rows_offsets, dim3(1), dim3(1024), 0, s, b, cand, cand_region_off, region_rows, row_region_off, host_rows);
+}
 
 // first entry of every region: row_ptr at the regions' first rows ([ng] = all entries)
 __global__ void k3_region_entries(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ row_region_off, int32_t ng,

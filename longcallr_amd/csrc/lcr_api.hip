@@ -295,12 +295,11 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   HIPCHK(c, c->first_tile.reserve((ng + 1) * 4));
   if (mem == LCR_MEM_HOST)   // (a device-resident batch had its prefix sums computed with the region fetch above)
     launch_k0_region_setup(b.start0, b.len, b.col_off, b.read_begin, ng, c->first_tile.as<int32_t>(), nullptr, nullptr, nullptr, nullptr, c->stream);
-  launch_k0_tiles(c->first_tile.as<int32_t>(), ng, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), c->stream);
   HIPCHK(c, c->read_rend.reserve(std::max<size_t>(nr, 1) * 4));
   b.read_rend = c->read_rend.as<int32_t>();
   HIPCHK(c, c->read_region.reserve(std::max(nr, 1) * 4));
   b.read_region = c->read_region.as<int32_t>();
-  launch_k0_read_region(b, c->read_region.as<int32_t>(), c->stream);
+  launch_k0_tiles_read_region(b, c->first_tile.as<int32_t>(), c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), c->read_region.as<int32_t>(), c->stream);
   b.region_first_tile = c->first_tile.as<int32_t>(); b.error_flag = nullptr;   // set by lcr_pileup
   HIPCHK(c, c->read_bin.reserve(std::max<size_t>(nr, 1) * sizeof(ReadBin)));
   // ---- the flat op space of K0 (k0_ops.hip): ops [cig0, cig0 + n_ops) of bv.cigar, read after read
@@ -640,11 +639,10 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   // that lcr_fragments starts without a round trip
   HIPCHK(c, c->region_rows.reserve(std::max(ng, 1) * 4));
   HIPCHK(c, c->h_stage[3].reserve(std::max(ng, 1) * 4));
+  HIPCHK(c, c->row_region_off.reserve((ng + 1) * 4));
   { int32_t* d_rr = nullptr;   // (the rows per region also go straight into the pinned block: no copy in the queue)
     HIPCHK(c, hipHostGetDevicePointer((void**)&d_rr, c->h_stage[3].p, 0));
-    launch_k3_rows(c->bv, c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->region_rows.as<int32_t>(), c->stream, d_rr); }
-  HIPCHK(c, c->row_region_off.reserve((ng + 1) * 4));
-  launch_k3_row_offsets(c->region_rows.as<int32_t>(), ng, c->row_region_off.as<int32_t>(), c->stream);
+    launch_k3_rows_offsets(c->bv, c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->region_rows.as<int32_t>(), c->row_region_off.as<int32_t>(), c->stream, d_rr); }
   // no wait here: the host copies are picked up by whoever needs them first (cand_settle) -- lcr_fragments queues its
   // count pass before it does, so the GPU does not idle across the call boundary
   if (!c->ev_cand) HIPCHK(c, hipEventCreateWithFlags(&c->ev_cand, hipEventDisableTiming));

@@ -140,6 +140,7 @@ void launch_k0_region_setup(const int64_t* start0, const int32_t* len, const int
                             hipStream_t s);
 void launch_k0_tiles(const int32_t* first_tile, int32_t n_regions, int32_t* tile_region, int32_t* tile_col0, hipStream_t s);
 void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s);
+void launch_k0_tiles_read_region(const BatchView& b, const int32_t* first_tile, int32_t* tile_region, int32_t* tile_col0, int32_t* read_region, hipStream_t s);   // launch_k0_tiles + launch_k0_read_region in one kernel
 void launch_k0_pack(const BatchView& b, ReadBin* out, int32_t* order_flag /* pinned host memory, device address */, hipStream_t s);
 // K0 (k0_ops.hip): op-parallel CIGAR decode + per-tile record binning; load-time helpers
 void launch_k0_cig_check(const uint64_t* cig_off, const uint32_t* n_cig, int32_t nr, int64_t n_cigar, int32_t* out, hipStream_t s);
@@ -199,6 +200,8 @@ void launch_k3_fill(const BatchView& b, const ReadBin* rbin, const lcr_candidate
 int launch_k3_inline();
 void launch_k3_rows(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off, int32_t* region_rows,
                     hipStream_t s, int32_t* host_out = nullptr /* pinned host memory as the device sees it */);
+void launch_k3_rows_offsets(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off, int32_t* region_rows, int32_t* row_region_off,
+                            hipStream_t s, int32_t* host_rows = nullptr);   // launch_k3_rows + launch_k3_row_offsets in one kernel
 void launch_scan_i32_to_i64(DevBuf& tmp, const int32_t* in, int64_t* out_excl, int32_t n, hipStream_t s);
 
 void launch_k5_span_diff(const int32_t* ref_start, const int32_t* ref_end, int32_t n, int64_t contig_len, uint32_t* diff, hipStream_t s);
