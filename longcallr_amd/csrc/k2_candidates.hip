@@ -609,9 +609,11 @@ float lcr_device_sor_threshold(hipStream_t s) {
 // kept survivor s -> candidate slot pos[s] (exclusive scan of keep); a region's candidates stay contiguous
 __global__ void __launch_bounds__(LCR_BLOCK)
 k2_scatter(const lcr_candidate* __restrict__ tmp, const int32_t* __restrict__ keep, const int32_t* __restrict__ pos, int32_t n_sv,
-           lcr_candidate* __restrict__ out) {
+           lcr_candidate* __restrict__ out, const int32_t* __restrict__ sv_region_off, int32_t n_regions, int32_t* __restrict__ cand_off) {
   // 128-byte records: eight 16-byte words per record, one word per thread (coalesced both ways)
   const int64_t id = (int64_t)blockIdx.x * LCR_BLOCK + threadIdx.x;
+  // (the candidates' region offsets on the side: cand_off[g] = pos[sv_region_off[g]] -- what a gather kernel of its own did)
+  if (id <= n_regions) cand_off[id] = sv_region_off[id] < n_sv ? pos[sv_region_off[id]] : pos[n_sv];
   const int s = (int)(id >> 3), w = (int)(id & 7);
   if (s >= n_sv || !keep[s]) return;
   reinterpret_cast<uint4*>(out + pos[s])[w] = reinterpret_cast<const uint4*>(tmp + s)[w];
@@ -669,10 +671,10 @@ void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t*
                       int32_t* cand_off /* n_regions + 1 */, uint32_t dense_win, uint32_t min_dense_cnt, hipStream_t s) {
   // pos = exclusive scan of keep, pos[n_sv] = number of candidates; cand_off[g] = pos[sv_region_off[g]]
   launch_scan_i32(scan_tmp, keep, pos, n_sv, pos + n_sv, s);
-  launch_gather_i32(pos, sv_region_off, n_regions + 1, n_sv, pos + n_sv, cand_off, s);
-  if (n_sv > 0) {
-    const int64_t nthreads = (int64_t)n_sv * 8;
-    hipLaunchKernelGGL(k2_scatter, dim3((unsigned)((nthreads + LCR_BLOCK - 1) / LCR_BLOCK)), dim3(LCR_BLOCK), 0, s, tmp, keep, pos, n_sv, out);
-  }
+  if (n_sv > 0) {   // (cand_off[g] = pos[sv_region_off[g]] rides on the scatter kernel; without survivors a gather of zeros)
+    const int64_t nthreads = std::max<int64_t>((int64_t)n_sv * 8, (int64_t)n_regions + 1);
+    hipLaunchKernelGGL(k2_scatter, dim3((unsigned)((nthreads + LCR_BLOCK - 1) / LCR_BLOCK)), dim3(LCR_BLOCK), 0, s, tmp, keep, pos, n_sv, out,
+                       sv_region_off, n_regions, cand_off);
+  } else launch_gather_i32(pos, sv_region_off, n_regions + 1, n_sv, pos + n_sv, cand_off, s);
   if (n_regions > 0) hipLaunchKernelGGL(k2_dense, dim3(n_regions), dim3(256), 0, s, out, cand_off, n_regions, idx, dense_win, min_dense_cnt);
 }

@@ -454,7 +454,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   // top) | tile-level intron difference array | chunks per tile | bin cursors | K0's accounting slots
   const size_t o_ndiff = (size_t)nt + 16, o_nch = o_ndiff + nt + 8, o_cur = o_nch + nt + 8, o_acct = o_cur + nt + 8;
   const size_t o_tmp = o_acct + launch_k0_acct_words();   // scratch of the tile passes (class counts, cursors, block sums)
-  const size_t fill_words = o_tmp + launch_k1_tiles_tmp_words(nt);
+  const size_t fill_words = (o_tmp + launch_k1_tiles_tmp_words(nt) + 63) & ~(size_t)63;   // (a multiple of 256 bytes: one fill kernel, not a body and a tail)
   HIPCHK(c, c->k0_tile_fill.reserve(fill_words * 4));
   int32_t* const fill = c->k0_tile_fill.as<int32_t>();
   b.error_flag = fill + nt + 4;
