@@ -182,23 +182,35 @@ def cpu_baseline(batch, params, budget_s=20.0):
     from oracle import orc
     orc.build()
     ncpu = os.cpu_count() or 1
-    t_all, th_all = cpu_pool(batch, params, 0)                       # every region once, all hardware threads
     cols = int(batch.col_off[-1])
+    # every region of the batch once per pool size: all hardware threads, the physical cores, 64 -- the stated baseline is the
+    # BEST of them (round 4 quoted the all-threads run although 64 threads were 27 % faster: SMT + two sockets do not pay here)
+    full = {}
+    spent = 0.0
+    for th in sorted({ncpu, max(1, ncpu // 2), min(64, ncpu)}, reverse=True):
+        if full and spent > 0.7 * budget_s:
+            continue
+        dt, th_used = cpu_pool(batch, params, th if th < ncpu else 0)
+        full[th_used] = dt
+        spent += dt
+    th_best = min(full, key=lambda k: full[k])
+    t_all, th_all = full[th_best], th_best
     out = dict(value=cols / t_all, unit="candidate_sites/s", cores=th_all, kind="port",
                sample="all %d regions of the rank-0 batch (%d columns, %d reads) once through orc_run_batch (native std::thread pool, "
-                      "heaviest regions first), ORC_MODE_F64_ONLY = the reference's arithmetic, full hot path P1-P17: %.2f s on %d threads"
-                      % (batch.n_regions, cols, batch.n_reads, t_all, th_all))
-    # thread scaling on the first regions of the batch (a fixed number per point: ~2-6 s of wall time each)
+                      "heaviest regions first), ORC_MODE_F64_ONLY = the reference's arithmetic, full hot path P1-P17, at %s threads: %s s; "
+                      "value = the best point (%d threads)"
+                      % (batch.n_regions, cols, batch.n_reads, sorted(full), ["%.2f" % full[k] for k in sorted(full)], th_all))
+    # thread scaling below that on the first regions of the batch (a fixed number per point: ~2-6 s of wall time each)
     scaling = {}
-    spent = t_all
-    for th, n_reg in ((1, 12), (16, 96), (64, 256)):
+    for th, n_reg in ((1, 12), (16, 96)):
         if th >= ncpu or spent > budget_s:
             continue
         hb = head_batch(batch, n_reg)
         dt, _ = cpu_pool(hb, params, th)
         spent += dt
         scaling[str(th)] = dict(sites_per_sec=int(hb.col_off[-1]) / dt, regions=hb.n_regions, seconds=dt)
-    scaling[str(th_all)] = dict(sites_per_sec=cols / t_all, regions=batch.n_regions, seconds=t_all)
+    for k in sorted(full):
+        scaling[str(k)] = dict(sites_per_sec=cols / full[k], regions=batch.n_regions, seconds=full[k])
     out["thread_scaling"] = scaling
     if "1" in scaling:
         out["single_thread_value"] = scaling["1"]["sites_per_sec"]
@@ -417,22 +429,30 @@ def demo_stage(api, _abi, device, cpu=True):
     p = _abi.make_params("hifi-masseq")
     E = api.Engine(device, p)
 
-    def one_pass():
-        nb = bamio.NativeBam(path, 8)
+    n_thr = max(1, min(8, os.cpu_count() or 1))   # (a 1.2 MB file: more inflate threads than BGZF blocks buy nothing)
+    parts = {}
+
+    def one_pass(acc=None):
+        tk = [time.perf_counter()]
+        def lap(name):
+            tk.append(time.perf_counter())
+            if acc is not None:
+                acc[name] = acc.get(name, 0.0) + tk[-1] - tk[-2]
+        nb = bamio.NativeBam(path, n_thr); lap("open_inflate_index")
         rid = [n for n, _ in nb.refs].index("chr20")
-        rs, re_ = nb.spans(rid, **_abi.READ_FILTER)
-        regions = E.discover_regions(rs, re_, nb.refs[rid][1])
-        b = nb.batch(rid, [(s, l) for s, l, _ in regions], [ref], name_format="blob", **_abi.READ_FILTER)
+        rs, re_ = nb.spans(rid, **_abi.READ_FILTER); lap("spans")
+        regions = E.discover_regions(rs, re_, nb.refs[rid][1]); lap("discover_regions")
+        b = nb.batch(rid, [(s, l) for s, l, _ in regions], [ref], name_format="blob", **_abi.READ_FILTER); lap("batch")
         E.load_batch(b).run_all()
-        c = E.candidates()[0]
-        nb.close()
+        c = E.candidates()[0]; lap("load_and_four_stage_calls")
+        nb.close(); lap("close")
         return b, c
     for _ in range(3):
         b, c = one_pass()
     n = 10
     t0 = time.perf_counter()
     for _ in range(n):
-        b, c = one_pass()
+        b, c = one_pass(parts)
     gpu = (time.perf_counter() - t0) / n
     # the four stage calls alone, inputs already decoded (host buffers, upload included)
     for _ in range(20):
@@ -447,8 +467,9 @@ def demo_stage(api, _abi, device, cpu=True):
     L = int(b.len[0])
     out = dict(workload="demo.bam (chr20:16 729 961-16 743 217, %d reads pass the filter, %d columns, %d candidates), hifi-masseq preset, pseudo-reference"
                         % (b.n_reads, L, int(c.size)),
-               file_to_candidates_ms=gpu * 1e3, stage_calls_ms=stages_only * 1e3, sites_per_sec_from_file=L / gpu, sites_per_sec_stage_calls=L / stages_only,
-               note="from the file = lcr_bam_open (inflate on 8 threads) + spans + lcr_discover_regions + lcr_bam_batch + load_batch + four stage "
+               file_to_candidates_ms=gpu * 1e3, file_to_candidates_parts_ms={k: v / n * 1e3 for k, v in parts.items()}, decode_threads=n_thr,
+               stage_calls_ms=stages_only * 1e3, sites_per_sec_from_file=L / gpu, sites_per_sec_stage_calls=L / stages_only,
+               note="from the file = lcr_bam_open (inflate on `decode_threads` threads) + spans + lcr_discover_regions (dense passes over the covered window of the contig only) + lcr_bam_batch + load_batch + four stage "
                     "calls + lcr_get_candidates, per pass; ~5 MB of traffic: launch- and latency-bound, not a roofline workload")
     if cpu:
         m = 3

@@ -113,7 +113,7 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
   __shared__ uint32_t s_wcnt[ENUM_WAVES], s_dif[ENUM_WAVES], s_ntied;
   constexpr uint32_t TLCAP = 2048;
   uint16_t* tl = (uint16_t*)(lds + L.res + 16 * ENUM_TCAP + 96 * 10 + 16);   // [TLCAP] the restarts of maximal objective
-  __shared__ uint32_t s_win, s_wj[ENUM_WAVES];
+  __shared__ uint32_t s_win, s_wj[ENUM_WAVES], s_first;   // s_first: the first restart of maximal objective (32 bits: tl[] holds 16)
   __shared__ double s_winsum, s_wsum[ENUM_WAVES];
   __shared__ int s_flat;
   // (plain cached loads: the restarts' kernel has completed -- k4_enum_resolve is a launch of its own behind it)
@@ -141,7 +141,7 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
   for (uint32_t e = tid + OV * 256u; e < n_jobs; e += nt) { const long long v = ld_obj(e); if (v > best) best = v; }
   for (int d = 32; d >= 1; d >>= 1) { const long long ob = __shfl_xor(best, d, 64); if (ob > best) best = ob; }
   if (lane == 0) s_best[wave] = best;
-  if (tid == 0) s_ntied = 0;
+  if (tid == 0) { s_ntied = 0; s_first = 0xffffffffu; }
   __syncthreads();
   for (int w = 0; w < ENUM_WAVES; w++) if (s_best[w] > best) best = s_best[w];
   for (uint32_t p0 = 0; p0 < n_jobs; p0 += 256u) {   // a pass of 256 restarts, thread = restart: ranks by ballot, wave offsets through LDS
@@ -155,12 +155,13 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
     for (int w = 0; w < ENUM_WAVES; w++) { if (w < wave) off += s_wcnt[w]; tot += s_wcnt[w]; }
     const uint32_t at = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     if (hit && at < TLCAP) tl[at] = (uint16_t)e;
+    if (hit && at == 0) s_first = e;   // (the list is in ascending order: slot 0 is the first maximum; regions of more than 2^16 restarts keep all 32 bits here)
     __syncthreads();
     if (tid == 0) s_ntied += tot;
     __syncthreads();
   }
   const uint32_t n_tied_all = s_ntied, n_tied = min(n_tied_all, TLCAP);
-  const uint32_t first = tl[0];
+  const uint32_t first = s_first;
   const unsigned long long sig0 = ld_st(first, nk + 2);
   uint32_t dif = 0;
   for (uint32_t j = tid; j < n_tied; j += nt) if (ld_st(tl[j], nk + 2) != sig0) dif = 1;

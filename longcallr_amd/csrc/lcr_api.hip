@@ -823,10 +823,29 @@ int lcr_discover_regions(lcr_ctx* c, int32_t mem, int32_t n_reads, const int32_t
     HIPCHK(c, hipMemcpyAsync(c->rd_end.p, ref_end, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
     d_s = c->rd_start.as<int32_t>(); d_e = c->rd_end.as<int32_t>();
   }
+  // the window of the contig that reads cover at all (host spans: one loop here; device spans: one small reduction)
+  int64_t w_lo = contig_len, w_hi = 0;
+  if (mem == LCR_MEM_HOST) {
+    for (int32_t r = 0; r < n_reads; r++) {
+      const int64_t s = ref_start[r], e = std::min<int64_t>(ref_end[r], contig_len);
+      if (s >= 0 && s < e) { w_lo = std::min(w_lo, s); w_hi = std::max(w_hi, e); }
+    }
+  } else {
+    HIPCHK(c, c->rd_cnt.reserve(16));
+    int32_t init[2] = {INT_MAX, 0}, got[2] = {INT_MAX, 0};
+    HIPCHK(c, hipMemcpyAsync(c->rd_cnt.p, init, 8, hipMemcpyHostToDevice, c->stream));
+    launch_k5_span_window(d_s, d_e, n_reads, contig_len, c->rd_cnt.as<int32_t>(), c->stream);
+    HIPCHK(c, hipMemcpyAsync(got, c->rd_cnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (got[1] > 0) { w_lo = got[0]; w_hi = got[1]; }
+  }
+  if (w_hi <= w_lo) return LCR_OK;   // no valid span
+  const int64_t full_len = contig_len;
+  contig_len = w_hi - w_lo;          // from here on positions are relative to w_lo
   const size_t nd = (size_t)contig_len + 2;
   HIPCHK(c, c->rd_diff.reserve(nd * 4)); HIPCHK(c, c->rd_ex.reserve((nd + 1) * 4));
   HIPCHK(c, hipMemsetAsync(c->rd_diff.p, 0, nd * 4, c->stream));
-  launch_k5_span_diff(d_s, d_e, n_reads, contig_len, c->rd_diff.as<uint32_t>(), c->stream);
+  launch_k5_span_diff(d_s, d_e, n_reads, full_len, w_lo, c->rd_diff.as<uint32_t>(), c->stream);
   launch_scan_i32(c->scan_tmp, (const int32_t*)c->rd_diff.p, c->rd_ex.as<int32_t>(), (int32_t)nd, nullptr, c->stream);
   const int32_t nb = (int32_t)((contig_len + 1023) / 1024);
   HIPCHK(c, c->rd_cnt.reserve(((size_t)nb + 1) * 4)); HIPCHK(c, c->rd_off.reserve(((size_t)nb + 2) * 4));
@@ -853,6 +872,7 @@ int lcr_discover_regions(lcr_ctx* c, int32_t mem, int32_t n_reads, const int32_t
   uint32_t running = 0;
   int64_t pend = -1;
   for (int i = 0; i < n_isl; i++) {
+    hs[i] += (int32_t)w_lo; he[i] += (int32_t)w_lo;   // back to contig positions
     running = std::max(running, hm[i]);
     if (pend < 0) pend = hs[i];
     if ((int64_t)he[i] > pend) {

@@ -204,7 +204,8 @@ void launch_k3_rows_offsets(const BatchView& b, const lcr_candidate* cand, const
                             hipStream_t s, int32_t* host_rows = nullptr);   // launch_k3_rows + launch_k3_row_offsets in one kernel
 void launch_scan_i32_to_i64(DevBuf& tmp, const int32_t* in, int64_t* out_excl, int32_t n, hipStream_t s);
 
-void launch_k5_span_diff(const int32_t* ref_start, const int32_t* ref_end, int32_t n, int64_t contig_len, uint32_t* diff, hipStream_t s);
+void launch_k5_span_window(const int32_t* ref_start, const int32_t* ref_end, int32_t n, int64_t contig_len, int32_t* out /* {INT_MAX, 0} */, hipStream_t s);
+void launch_k5_span_diff(const int32_t* ref_start, const int32_t* ref_end, int32_t n, int64_t contig_len, int64_t lo /* first position of diff */, uint32_t* diff, hipStream_t s);
 void launch_k5_bounds(bool write, const int32_t* ex, int64_t contig_len, int32_t n_blocks, int32_t* blk_cnt, const int32_t* blk_off,
                       int32_t* starts, int32_t* ends, hipStream_t s);
 void launch_k5_island_max(const int32_t* ex, const int32_t* starts, const int32_t* ends, int32_t n_islands, uint32_t* maxcov, hipStream_t s);

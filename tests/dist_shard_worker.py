@@ -44,8 +44,14 @@ def main():
         E.close()
         return c, reads
     c, reads = run(owner[rank])
-    gc = shard.gather_records(c, dist)
-    gr = shard.gather_records(reads, dist)
+    # the gather bench.py uses (asynchronous, fixed-capacity buffers; host records over gloo here, device pointers over RCCL:
+    # tests/dist_nccl_worker.py), and once more through the synchronous variable-length form
+    G = (shard.RecordGather(dist, torch.device("cpu"), c.dtype), shard.RecordGather(dist, torch.device("cpu"), reads.dtype))
+    h = (G[0].start(c), G[1].start(reads))
+    gc, gr = G[0].finish(h[0]), G[1].finish(h[1])
+    gc2 = shard.gather_records(c, dist)
+    if rank == 0:
+        assert gc2.tobytes() == gc.tobytes()
     if rank == 0:
         wc, wr = run(list(range(n_global)))
         gc = gc[np.argsort(gc["region"], kind="stable")]

@@ -868,6 +868,23 @@ def test_enumeration_threshold_variants(engine_cls, orc, max_enum_snps):
     full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=9, max_enum_snps=max_enum_snps))
 
 
+def test_enumeration_of_more_than_65536_restarts(engine_cls, orc):
+    """max_enum_snps = 17 on a 17-SNP region: 131 072 restarts -- the winner's index needs more than the 16 bits of
+    k4_enum_resolve's list of maximal restarts.  Allele errors at the het sites make the restarts end in
+    different optima, so the first maximum is not restart 0 by construction."""
+    b, sites = helpers.two_haplotype_batch(n_snps=17, n_reads=16, seed=3)
+    rng = np.random.default_rng(5)
+    alt_of = {ord("A"): ord("C"), ord("C"): ord("A"), ord("G"): ord("T"), ord("T"): ord("G")}
+    for k in range(b.n_reads):
+        for x in sites[0]:
+            if rng.random() < 0.2:   # toggle ref <-> alt: the sites stay biallelic
+                i = int(b.seq_off[k]) + (x - int(b.pos[k]))
+                r = int(b.ref[x - 5000])
+                b.bases[i] = alt_of[r] if b.bases[i] == r else r
+    c = full_check(engine_cls, orc, b, _abi.make_params("hifi-masseq", seed=9, max_enum_snps=17))
+    assert len(c) == 17
+
+
 def test_empty_batch_and_errors(engine_cls):
     from longcallr_amd.api import LcrError
     p = _abi.make_params()
@@ -1317,6 +1334,39 @@ def test_two_ranks_share_one_gpu(grid_min):
            "--master-port", str(29000 + os.getpid() % 2000), worker]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SHARD-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def _torchrun(args, env=None, timeout=600, nproc=1):
+    import os
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(29000 + (os.getpid() * 7 + len(args[0])) % 2000)] + list(args)
+    return subprocess.run(cmd, env=env or dict(os.environ), capture_output=True, text=True, timeout=timeout)
+
+
+def test_nccl_group_gathers_device_records():
+    """The first RCCL run made boring: a world-size-1 `nccl` process group on the test GPU drives
+    shard.RecordGather with device-pointer records for three overlapped batches == the host getters, byte for byte
+    (tests/dist_nccl_worker.py; thread.rs:204-221)."""
+    import os
+    r = _torchrun([os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_nccl_worker.py")])
+    assert r.returncode == 0 and "NCCL-GATHER-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_under_the_launcher_with_one_rank():
+    """`bench.py --gpus 1` under torch.distributed.run, as the driver launches N > 1: the nccl group, the device-pointer
+    gathers of every step, the world-size / backend asserts and the per-rank block of the JSON line all execute."""
+    import json
+    import os
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    r = _torchrun([bench, "--gpus", "1", "--steps", "3", "--warmup", "1", "--prewarm", "2", "--quick", "--genes", "24", "--gene-len", "12000"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    pr = line["config"]["per_rank"]
+    assert pr["backend"] == "nccl" and pr["world_size"] == 1 and len(pr["ms_per_step"]) == 1
+    assert pr["gather_bytes_per_step"][0] > 0 and line["config"]["gathered_records_last_batch"]["candidates"] > 0
+    assert line["n_gpus"] == 1 and line["value"] > 0
 
 
 def test_region_discovery_gpu(engine_cls):
