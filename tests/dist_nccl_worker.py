@@ -26,16 +26,26 @@ def main():
     E = api.Engine(local, params)
     E.set_stream(torch.cuda.current_stream().cuda_stream)
     G = (shard.RecordGather(dist, dev, _abi.CAND_DTYPE), shard.RecordGather(dist, dev, _abi.READ_REC_DTYPE))
-    # three batches of different sizes (the second is the largest: the capacity negotiated on the first, 2 x its count, holds it)
-    batches = [synth.make_batch("ont-cdna", n_genes=n, gene_len=9000, depth=30, seed=40 + k + 10 * rank) for k, n in enumerate((3, 5, 2))]
+    # three overlapped batches inside the capacity negotiated on the first (2 x its count), then a batch beyond it: RecordGather.start
+    # refuses it (every rank would have to agree on new buffers), reset() on every rank renegotiates
+    batches = [synth.make_batch("ont-cdna", n_genes=n, gene_len=9000, depth=30, seed=40 + k + 10 * rank) for k, n in enumerate((4, 5, 2, 12))]
     want, pending, got = [], None, []
-    for b in batches:
+    for k, b in enumerate(batches):
         E.load_batch(b).run_all()
         c = E.candidates()[0].copy()
         pr = E.phase_result()
         r = np.zeros(pr["haplotag"].size, dtype=_abi.READ_REC_DTYPE)
         r["row"], r["haplotag"], r["assignment"], r["phase_set"] = np.arange(r.size), pr["haplotag"], pr["assignment"], pr["phase_set"]
         want.append((c, r))
+        if k == 3:
+            got.append((G[0].finish(pending[0]), G[1].finish(pending[1])))
+            pending = None
+            try:
+                G[1].start(E.read_records_device())
+                raise AssertionError("a batch beyond the negotiated capacity must be refused")
+            except ValueError:
+                pass
+            G[0].reset(); G[1].reset()
         h = (G[0].start(E.candidates_device()), G[1].start(E.read_records_device()))   # gathers of batch i run under the kernels of batch i + 1
         if pending is not None:
             got.append((G[0].finish(pending[0]), G[1].finish(pending[1])))
