@@ -905,12 +905,16 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
   }
 }
 
-// the same tiles for regions whose matrix does not fit the LDS budget: one restart at a time per workgroup
+// the same tiles for regions whose matrix does not fit the LDS budget: one restart at a time per workgroup.  Every restart leaves
+// its objective and -- st_words != nullptr and the region has a span there (st_base >= 0) -- its final state in the layout of the
+// other classes (sigma bits | delta < 0, eta == 0 masks | eta == +1 mask | a signature of all of it) for k4_enum_resolve_big.
 __global__ void __launch_bounds__(LCR_BLOCK)
 k4_enum_big(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uint32_t per, const int64_t* __restrict__ job_base,
-            long long* __restrict__ job_obj, const uint32_t* __restrict__ win_e) {
+            long long* __restrict__ job_obj, const uint32_t* __restrict__ win_e, const int64_t* __restrict__ st_base,
+            unsigned long long* __restrict__ st_words) {
   __shared__ long long red[LCR_BLOCK / 64];
   __shared__ long long wl[32];
+  __shared__ unsigned long long s_sig[LCR_BLOCK / 64];
   const EnumTile t = enum_tile_of(P, spans, n_spans, per, win_e != nullptr);
   const RegionDev rd = P.reg[t.slot];
   load_w(P, wl);
@@ -918,6 +922,9 @@ k4_enum_big(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
   int8_t* sg = base; int8_t* dl = base + rd.R; int8_t* et = dl + rd.S;
   const int8_t* vt = P.snp_vt + rd.snp_off;
   const uint32_t ne = win_e ? 1u : t.ne;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t nk = (uint32_t)(rd.R + 63) / 64, sw = enum_state_words((uint32_t)rd.R);
+  const bool keep = !win_e && st_words && st_base[t.slot] >= 0;
   for (uint32_t k = 0; k < ne; k++) {
     const uint32_t e = win_e ? win_e[t.slot] : t.e0 + k;
     for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { dl[i] = ((e >> i) & 1u) ? -1 : 1; et[i] = init_genotype(vt[i]); }
@@ -929,31 +936,147 @@ k4_enum_big(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
       for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { P.st_delta[rd.snp_off + i] = dl[i]; P.st_eta[rd.snp_off + i] = et[i]; }
       for (int row = threadIdx.x; row < rd.R; row += blockDim.x) P.st_sigma[rd.sig_off + row] = sg[row];
       if (threadIdx.x == 0) P.st_obj[t.slot] = obj;
-    } else if (threadIdx.x == 0) job_obj[job_base[t.slot] + e] = obj;
+    } else {
+      if (threadIdx.x == 0) job_obj[job_base[t.slot] + e] = obj;
+      if (keep) {
+        unsigned long long* dst = st_words + st_base[t.slot] + (size_t)e * sw;
+        unsigned long long h = 0;
+        for (uint32_t w0 = (uint32_t)wave; w0 < nk; w0 += LCR_BLOCK / 64) {   // a wave per 64 rows
+          const uint32_t row = 64u * w0 + (uint32_t)lane;
+          const unsigned long long word = __ballot(row < (uint32_t)rd.R && sg[row] < 0);
+          if (lane == 0) dst[w0] = word;
+          h ^= mix64(word + 0x9E3779B97F4A7C15ull * (w0 + 1));
+        }
+        if (lane == 0) s_sig[wave] = h;
+        __syncthreads();
+        if (wave == 0) {   // (S <= 31: a restart index has 32 bits)
+          const bool in = lane < rd.S;
+          const unsigned long long dneg = __ballot(in && dl[in ? lane : 0] < 0), eta0 = __ballot(in && et[in ? lane : 0] == 0), etap = __ballot(in && et[in ? lane : 0] == 1);
+          if (lane == 0) {
+            const unsigned long long w0 = (dneg & 0xffffffffull) | (eta0 << 32), w1 = etap & 0xffffffffull;
+            unsigned long long sig = mix64(w0 + 1) ^ mix64(w1 + 0x5851F42D4C957F2Dull);
+            for (int w = 0; w < LCR_BLOCK / 64; w++) sig ^= s_sig[w];
+            dst[nk] = w0; dst[nk + 1] = w1; dst[nk + 2] = sig;
+          }
+        }
+      }
+    }
     __syncthreads();
   }
 }
 
-// winner of each enumeration region of the global-memory fallback class: first maximum over e (`prob > largest_prob`,
-// phase.rs:1113-1119); two restarts of maximal objective are not compared by their f64 sums here (counted: TIE_BEST_UNRES)
-__global__ void __launch_bounds__(64) k4_enum_pick(const EnumSpan* __restrict__ spans, int32_t n, const RegionDev* __restrict__ reg,
-                                                    const int64_t* __restrict__ job_base, const long long* __restrict__ job_obj,
-                                                    uint32_t* __restrict__ win_e, unsigned long long* __restrict__ tie_ctr) {
-  const int k = blockIdx.x;
-  if (k >= n) return;
-  const int slot = spans[k].slot;
-  const uint32_t nj = 1u << reg[slot].S;
+// Winner of each enumeration region of the global-memory class: `prob > largest_prob` (phase.rs:1113-1119) over the restarts in
+// order.  Decided on the exact objectives; among the restarts of MAXIMAL objective whose final configurations differ (signatures),
+// on the reference-order f64 sum of cal_overall_probability (phase.rs:257-276) of every distinct configuration: the first restart
+// with the largest sum wins (strictly-greater-replaces).  A workgroup per region; the f64 sum of a configuration: a thread per row
+// writes the rows' terms in entry order, wave 0 adds them up one by one (64 terms per load, v_readlane per add).  The winner's
+// index goes to win_e: k4_enum_big runs that restart once more and leaves its state in the region's result slots.
+// Not resolved (counted, first maximum kept): states not kept (st_base < 0: beyond the memory budget), more than TLB_CAP maxima.
+constexpr uint32_t TLB_CAP = 1024;
+__global__ void __launch_bounds__(LCR_BLOCK)
+k4_enum_resolve_big(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* __restrict__ job_base, const long long* __restrict__ job_obj,
+                    const int64_t* __restrict__ st_base, const unsigned long long* __restrict__ st_words, uint32_t* __restrict__ win_e,
+                    double* __restrict__ terms, int64_t terms_stride) {
+  __shared__ uint32_t tl[TLB_CAP];
+  __shared__ unsigned long long sig[TLB_CAP];
+  __shared__ double sum[TLB_CAP];
+  __shared__ uint16_t rep[TLB_CAP];
+  __shared__ double lut[64];
+  __shared__ long long s_best[LCR_BLOCK / 64];
+  __shared__ uint32_t s_wcnt[LCR_BLOCK / 64], s_ntied, s_first, s_dif;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slot = spans[blockIdx.x].slot;
+  const RegionDev rd = P.reg[slot];
+  const int R = rd.R, S = rd.S;
+  const uint32_t n_jobs = 1u << S, nk = (uint32_t)(R + 63) / 64, sw = enum_state_words((uint32_t)R);
   const long long* o = job_obj + job_base[slot];
-  long long best = LLONG_MIN; uint32_t be = 0xffffffffu;
-  for (uint32_t e = threadIdx.x; e < nj; e += 64) { const long long v = o[e]; if (v > best) { best = v; be = e; } }
-  for (int d = 32; d >= 1; d >>= 1) {
-    const long long ob = __shfl_xor(best, d, 64); const uint32_t oe = __shfl_xor(be, d, 64);
-    if (ob > best || (ob == best && oe < be)) { best = ob; be = oe; }
+  const bool have_st = st_words && st_base[slot] >= 0;
+  const unsigned long long* st = st_words + (have_st ? st_base[slot] : 0);
+  if (tid < 64) lut[tid] = (tid & 31) < 31 ? (tid < 32 ? P.lut64->le[tid] : P.lut64->l1e[tid - 32]) : 0.0;
+  long long best = LLONG_MIN;
+  for (uint32_t e = tid; e < n_jobs; e += LCR_BLOCK) { const long long v = o[e]; if (v > best) best = v; }
+  for (int d = 32; d >= 1; d >>= 1) { const long long ob = __shfl_xor(best, d, 64); if (ob > best) best = ob; }
+  if (lane == 0) s_best[wave] = best;
+  if (tid == 0) { s_ntied = 0; s_first = 0xffffffffu; s_dif = 0; }
+  __syncthreads();
+  for (int w = 0; w < LCR_BLOCK / 64; w++) if (s_best[w] > best) best = s_best[w];
+  for (uint32_t p0 = 0; p0 < n_jobs; p0 += LCR_BLOCK) {   // the maxima in ascending order (ranks by ballot, wave offsets through LDS)
+    const uint32_t e = p0 + (uint32_t)tid;
+    const bool hit = e < n_jobs && o[e] == best;
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = s_ntied, tot = 0;
+    for (int w = 0; w < LCR_BLOCK / 64; w++) { if (w < wave) off += s_wcnt[w]; tot += s_wcnt[w]; }
+    const uint32_t at = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (hit && at < TLB_CAP) tl[at] = e;
+    if (hit && at == 0) s_first = e;
+    __syncthreads();
+    if (tid == 0) s_ntied += tot;
+    __syncthreads();
   }
-  int at_max = 0;
-  for (uint32_t e = threadIdx.x; e < nj; e += 64) at_max += o[e] == best ? 1 : 0;
-  for (int d = 32; d >= 1; d >>= 1) at_max += __shfl_xor(at_max, d, 64);
-  if (threadIdx.x == 0) { win_e[slot] = be; if (at_max > 1) TIE_COUNT(tie_ctr, TIE_BEST_UNRES, 1ull); }
+  const uint32_t n_all = s_ntied, n_tied = min(n_all, TLB_CAP), first = s_first;
+  uint32_t win = first;
+  if (n_all > 1) {
+    if (!have_st || n_all > TLB_CAP || P.tie_arith < 1) { if (tid == 0) TIE_COUNT(P.tie_ctr, TIE_BEST_UNRES, 1ull); }
+    else {
+      for (uint32_t j = tid; j < n_tied; j += LCR_BLOCK) sig[j] = st[(size_t)tl[j] * sw + nk + 2];
+      __syncthreads();
+      for (uint32_t j = tid; j < n_tied; j += LCR_BLOCK) {   // the earliest restart with the same configuration
+        uint32_t r = j;
+        for (uint32_t i = 0; i < j; i++) if (sig[i] == sig[j]) { r = i; break; }
+        rep[j] = (uint16_t)r;
+        if (r != 0) s_dif = 1;
+      }
+      __syncthreads();
+      if (s_dif) {
+        if (tid == 0) TIE_COUNT(P.tie_ctr, TIE_BEST_F64, 1ull);
+        const MatView mv = global_view(P, rd);
+        const uint32_t E = (uint32_t)mv.rp[R];
+        double* tb = terms + (size_t)blockIdx.x * terms_stride;
+        for (uint32_t j = 0; j < n_tied; j++) {
+          if (rep[j] != j) continue;   // (uniform: LDS)
+          const unsigned long long* cf = st + (size_t)tl[j] * sw;
+          const unsigned long long rm0 = cf[nk];
+          const uint32_t dneg = (uint32_t)rm0, eta0 = (uint32_t)(rm0 >> 32), etap = (uint32_t)cf[nk + 1];
+          // match = [p == x]: het site: p == sigma * delta; hom site: p == eta (k4_enum_resolve's full_sum)
+          const uint32_t cm = (dneg & eta0) | (~etap & ~eta0);
+          for (int row = tid; row < R; row += LCR_BLOCK) {
+            const uint32_t sneg = 0u - (uint32_t)((cf[row >> 6] >> (row & 63)) & 1ull);
+            for (int x = mv.rp[row]; x < mv.rp[row + 1]; x++) {
+              const uint32_t i = (uint32_t)mv.pc[x], v = mv.pv[x];
+              const uint32_t pbit = (v >> 5) & 1u, q = v & 31u;
+              const uint32_t match = (pbit ^ (cm >> i) ^ ((sneg & eta0) >> i)) & 1u;
+              tb[x] = lut[(match << 5) + q];
+            }
+          }
+          __threadfence_block();
+          __syncthreads();
+          if (wave == 0) {
+            double acc = 0.0;
+            for (uint32_t b0 = 0; b0 < E; b0 += 64) {
+              const double tv = b0 + (uint32_t)lane < E ? tb[b0 + lane] : 0.0;
+              const int lo = (int)__double2loint(tv), hi = (int)__double2hiint(tv);
+              const uint32_t n = min(64u, E - b0);
+#pragma unroll 8
+              for (uint32_t kk = 0; kk < 64; kk++)
+                if (kk < n) acc += __hiloint2double(__builtin_amdgcn_readlane(hi, (int)kk), __builtin_amdgcn_readlane(lo, (int)kk));
+            }
+            if (lane == 0) sum[j] = acc;
+          }
+          __syncthreads();
+        }
+        if (tid == 0) {   // strictly-greater-replaces over the maxima in order (phase.rs:1117)
+          double bs = sum[0];
+          for (uint32_t j = 1; j < n_tied; j++) { const double sj = sum[rep[j]]; if (sj > bs) { bs = sj; win = tl[j]; } }
+          s_first = win;
+        }
+        __syncthreads();
+        win = s_first;
+      }
+    }
+  }
+  if (tid == 0) win_e[slot] = win;
 }
 }  // namespace
 
@@ -969,10 +1092,10 @@ void launch_k4_enum_resolve(unsigned n_regions, size_t dyn_lds, hipStream_t s, c
   hipLaunchKernelGGL(k4_enum_resolve, dim3(n_regions), dim3(64 * ENUM_WAVES), dyn_lds, s, P, spans, job_base, job_obj, st_base, st_words);
 }
 void launch_k4_enum_big(unsigned n_blocks, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, int32_t n_spans, uint32_t per,
-                        const int64_t* job_base, long long* job_obj, const uint32_t* win_e) {
-  hipLaunchKernelGGL(k4_enum_big, dim3(n_blocks), dim3(LCR_BLOCK), 0, s, P, spans, n_spans, per, job_base, job_obj, win_e);
+                        const int64_t* job_base, long long* job_obj, const uint32_t* win_e, const int64_t* st_base, unsigned long long* st_words) {
+  hipLaunchKernelGGL(k4_enum_big, dim3(n_blocks), dim3(LCR_BLOCK), 0, s, P, spans, n_spans, per, job_base, job_obj, win_e, st_base, st_words);
 }
-void launch_k4_enum_pick(int32_t n, hipStream_t s, const EnumSpan* spans, const RegionDev* reg, const int64_t* job_base, const long long* job_obj,
-                         uint32_t* win_e, unsigned long long* tie_ctr) {
-  hipLaunchKernelGGL(k4_enum_pick, dim3((unsigned)n), dim3(64), 0, s, spans, n, reg, job_base, job_obj, win_e, tie_ctr);
+void launch_k4_enum_resolve_big(int32_t n, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, const int64_t* job_base, const long long* job_obj,
+                                const int64_t* st_base, const unsigned long long* st_words, uint32_t* win_e, double* terms, int64_t terms_stride) {
+  hipLaunchKernelGGL(k4_enum_resolve_big, dim3((unsigned)n), dim3(LCR_BLOCK), 0, s, P, spans, job_base, job_obj, st_base, st_words, win_e, terms, terms_stride);
 }

@@ -76,9 +76,11 @@ void launch_k4_enum_reg(int ck, unsigned n_blocks, size_t dyn_lds, hipStream_t s
 void launch_k4_enum_resolve(unsigned n_regions, size_t dyn_lds, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, const int64_t* job_base,
                             const long long* job_obj, const int64_t* st_base, const unsigned long long* st_words);
 void launch_k4_enum_big(unsigned n_blocks, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, int32_t n_spans, uint32_t per,
-                        const int64_t* job_base, long long* job_obj, const uint32_t* win_e);
-void launch_k4_enum_pick(int32_t n, hipStream_t s, const EnumSpan* spans, const RegionDev* reg, const int64_t* job_base, const long long* job_obj,
-                         uint32_t* win_e, unsigned long long* tie_ctr);
+                        const int64_t* job_base, long long* job_obj, const uint32_t* win_e /* nullptr: all restarts; else the winners once more */,
+                        const int64_t* st_base /* per region: first word of its saved states, < 0: not kept */, unsigned long long* st_words);
+void launch_k4_enum_resolve_big(int32_t n, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, const int64_t* job_base, const long long* job_obj,
+                                const int64_t* st_base, const unsigned long long* st_words, uint32_t* win_e, double* terms /* n x terms_stride */,
+                                int64_t terms_stride);
 
 // ---- phase matrices (k4_stage.hip) ----
 constexpr int STAGE_THREADS = 256;    // (1024 threads per region were measured: more barrier cost than latency saved)

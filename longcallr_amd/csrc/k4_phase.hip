@@ -413,7 +413,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
          &b_stc = d_state[15], &b_slots = d_state[16], &b_psrc = d_state[21], &b_desc = d_state[22], &b_tbl = d_state[23],
          &b_adj = d_state[24], &b_part = d_state[25], &b_snpi = d_state[26], &b_snpb = d_state[27], &b_q = d_state[28],
          &b_info = d_state[29], &b_rowi = d_state[30], &b_enti = d_state[31], &b_work = d_state[32], &b_macc = d_state[33],
-         &b_ctl = d_state[34], &b_btot = d_state[35], &b_ps = d_state[36], &b_pse = d_state[37], &b_psp = d_state[38];
+         &b_ctl = d_state[34], &b_terms = d_state[17], &b_btot = d_state[35], &b_ps = d_state[36], &b_pse = d_state[37], &b_psp = d_state[38];
   const size_t nnz1 = (size_t)std::max<int64_t>(nnz, 1), nc1 = (size_t)std::max(ncand, 1), nr1 = (size_t)std::max(nrow, 1);
   PCHK(b_reg.reserve((size_t)std::max(ng, 1) * sizeof(RegionDev)));
   PCHK(b_stat.reserve((size_t)std::max(ng, 1) * sizeof(StageStat)));
@@ -707,7 +707,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     const uint32_t per_of[NCLS] = {1u, ENUM_PER3 * ENUM_WAVES, ENUM_TILE_JOBS, ENUM_PER3 * ENUM_WAVES, 1u};
     std::vector<int64_t>& job_base = enum_job_base; std::vector<int64_t>& st_base = enum_st_base;   // st_base: first word of the region's saved restart states (classes 1 - 3)
     job_base.assign(ng, 0); st_base.assign(ng, 0);
-    int64_t nj = 0, st_words = 0;
+    int64_t nj = 0, st_words = 0, big_words = 0, big_emax = 0;
     uint32_t lds_need[NCLS] = {0, 0, 0, 0, 0}, res_lds[NCLS] = {0, 0, 0, 0, 0};   // (res_lds: k4_enum_resolve's image of the class's largest region)
     // enumeration regions with the device epilogue: those of the streaming class (the largest matrices, so the longest epilogues)
     // are post-processed on their own queue right behind their resolve kernel, beside the register class's resolve; the others
@@ -735,7 +735,14 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
       if (cls < 4) { lds_need[cls] = std::max(lds_need[cls], EL.total); res_lds[cls] = std::max(res_lds[cls], RL); }
       job_base[g] = nj;
       const uint64_t n = 1ull << S;
+      // saved restart states: every region of classes 1 - 3; of the global-memory class while they fit a budget of 2^26 words
+      // (512 MB -- beyond it that region's equal-objective restarts fall to "first maximum", counted as unresolved)
+      st_base[g] = -1;
       if (cls < 4) { st_base[g] = st_words; st_words += (int64_t)n * enum_state_words((uint32_t)st.R); }
+      else if ((int64_t)n * enum_state_words((uint32_t)st.R) <= ((int64_t)1 << 26) - big_words) {
+        st_base[g] = st_words; st_words += (int64_t)n * enum_state_words((uint32_t)st.R); big_words += (int64_t)n * enum_state_words((uint32_t)st.R);
+        big_emax = std::max<int64_t>(big_emax, st.E);
+      }
       if (n_t[cls] + (n + per_of[cls] - 1) / per_of[cls] > 0x7fffffffull) { if (err) *err = "too many enumeration restarts for one launch"; return LCR_E_ARG; }
       spans[cls].push_back({g, (uint32_t)n_t[cls]});
       n_t[cls] += (size_t)((n + per_of[cls] - 1) / per_of[cls]);
@@ -802,14 +809,16 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
         if (cnt[3]) launch_k4_enum_resolve((unsigned)n_w[3], res_lds[3], s34, P, d_sp + s_off[3], d_jb, d_obj, d_sb, d_st);
         if (nps_b && (e = launch_k4_post(2 * LCR_BLOCK, (unsigned)nps_b, post_lds, s34, pin, d_psl + nps_a, (int32_t)nps_b, plut)) != hipSuccess) return e;
       }
-      if (cnt[4]) launch_k4_enum_big((unsigned)cnt[4], s34, P, d_sp + s_off[4], (int32_t)n_w[4], per_of[4], d_jb, d_obj, win);
+      if (cnt[4]) launch_k4_enum_big((unsigned)cnt[4], s34, P, d_sp + s_off[4], (int32_t)n_w[4], per_of[4], d_jb, d_obj, win, d_sb, d_enum_st.as<unsigned long long>());
       if (fork) { if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e; }
       return e;
     };
     PCHK(launch(n_t, nullptr));
-    if (n_w[4]) {   // the global-memory fallback kernel keeps the separate pick and the winners' second launch
+    if (n_w[4]) {   // the global-memory class: its own resolve kernel (equal objectives by the f64 sums) and the winners' second launch
       const size_t only4[NCLS] = {0, 0, 0, 0, n_w[4]};
-      launch_k4_enum_pick((int32_t)n_w[4], stream, d_sp + s_off[4], P.reg, d_jb, d_obj, d_win, P.tie_ctr);
+      const int64_t tstride = (big_emax + 63) & ~(int64_t)63;
+      PCHK(b_terms.reserve((size_t)std::max<int64_t>(tstride, 64) * n_w[4] * 8 + 64));
+      launch_k4_enum_resolve_big((int32_t)n_w[4], stream, P, d_sp + s_off[4], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), d_win, b_terms.as<double>(), tstride);
       PCHK(launch(only4, d_win));
     }
     if (nps_c) PCHK(launch_k4_post(2 * LCR_BLOCK, (unsigned)nps_c, post_lds, stream, pin, d_psl + nps_a + nps_b, (int32_t)nps_c, plut));

@@ -389,8 +389,6 @@ def test_fallback_device_paths(engine_cls, orc, monkeypatch, hook):
     regions than the device has CUs)."""
     hook, _, value = hook.partition("=")
     monkeypatch.setenv(hook, value or "1")
-    if hook == "LCR_ENUM_FORCE_BIG":     # (the global-memory enumeration kernel keeps the first maximum among restarts of equal objective)
-        monkeypatch.setitem(ORACLE_TIE_MASK, 0, orc.tie_mask(1, 1))
     b = synth.make_batch("ont-drna", n_genes=3, gene_len=20000, depth=45, seed=14)
     full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=14))
     full_check(engine_cls, orc, helpers.demo_batch(), _abi.make_params("hifi-masseq"), "chr20")
@@ -617,6 +615,39 @@ def test_deep_region_beyond_the_lds_images(engine_cls, orc):
     hold: the phase stage then works from global memory and finishes with the host epilogue."""
     b = synth.make_batch("ont-cdna", n_genes=1, gene_len=9000, depth=600, seed=91)
     full_check(engine_cls, orc, b, _abi.make_params("ont-cdna", seed=9))
+
+
+def _deep_low_s_batch(n_snps, n_reads, seed, err=0.08):
+    """one gene, depth n_reads, n_snps het sites: two haplotypes + allele errors at the het sites (ref <-> alt, so the sites stay
+    biallelic) and mixed base qualities -- the restarts end in several optima and many of them tie in objective"""
+    b, sites = helpers.two_haplotype_batch(n_snps=n_snps, n_reads=n_reads, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    alt_of = {ord("A"): ord("C"), ord("C"): ord("A"), ord("G"): ord("T"), ord("T"): ord("G")}
+    b.quals[:] = rng.choice(np.array([7, 12, 18, 25, 35], dtype=np.uint8), size=b.quals.size)
+    for k in range(b.n_reads):
+        for x in sites[0]:
+            if rng.random() < err:
+                i = int(b.seq_off[k]) + (x - int(b.pos[k]))
+                r = int(b.ref[x - 5000])
+                b.bases[i] = alt_of[r] if b.bases[i] == r else r
+    return b
+
+
+@pytest.mark.parametrize("preset,n_snps,n_reads", [("hifi-masseq", 5, 3200), ("ont-cdna", 8, 3000), ("hifi-masseq", 3, 4000)])
+def test_deep_region_with_few_sites(engine_cls, orc, preset, n_snps, n_reads):
+    """What real RNA-seq meets first: ONE highly expressed gene, depth >= 3 000, 3-8 het sites.  Its phase
+    matrix is beyond the enumeration kernels' LDS images, so the restarts run from global memory (k4_enum_big) -- compared under
+    the FULL oracle mask (sigma ties and `prob > largest_prob` at equal objective by the reference-order f64 sums) and with
+    ORC_MODE_F64, and the census reports no unresolved tie."""
+    b = _deep_low_s_batch(n_snps, n_reads, seed=n_snps)
+    p = _abi.make_params(preset, seed=3, max_depth=100000)
+    c = full_check(engine_cls, orc, b, p)
+    assert len(c) == n_snps
+    E = engine_cls(0, p)
+    E.load_batch(b).run_all()
+    hc = E.tie_census()
+    E.close()
+    assert hc["sigma_unresolved"] == 0 and hc["best_unresolved"] == 0, hc
 
 
 def test_bam_file_to_vcf_through_the_native_decoder(engine_cls, orc):
