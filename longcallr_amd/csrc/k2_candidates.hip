@@ -344,9 +344,14 @@ k2_compact(BatchView b, DevParams prm, BinomTable bt, const int32_t* __restrict_
 // fall inside the read's reference span are located against the CIGAR spread over the lanes, and
 // (allele, clamped q) of every *kept* base (same trim / poly-A mask as K1) is added to
 // hist[s][allele][q].  Reads that cover no survivor never load their CIGAR.
+// The walk also leaves what K3 needs (fragment.rs:93-194 walks the same reads against the candidates, a subset of these
+// survivors): per read the first LCR_HITS (survivor, base, raw quality) hits in survivor order -- every aligned base that faces a
+// survivor, masked or not (the fragment walk takes every aligned base) -- and the hit count; reads with more hits than the list
+// holds go to a list of their own (k3 walks those again).
 __global__ void __launch_bounds__(LCR_BLOCK)
 k2_hist(BatchView b, DevParams prm, const ReadBin* __restrict__ rbin, const Survivor* __restrict__ sv,
-        const int32_t* __restrict__ sv_region_off, uint32_t* __restrict__ hist) {
+        const int32_t* __restrict__ sv_region_off, uint32_t* __restrict__ hist, int32_t* __restrict__ hit_cnt, uint2* __restrict__ hit_list,
+        int32_t* __restrict__ ovf_cnt, int32_t* __restrict__ ovf_list) {
   const int r = (blockIdx.x * LCR_BLOCK + threadIdx.x) >> 4;
   const bool live = r < b.n_reads;
   const int rr = live ? r : 0;
@@ -355,25 +360,40 @@ k2_hist(BatchView b, DevParams prm, const ReadBin* __restrict__ rbin, const Surv
   const ReadBin h = rbin[rr];
   const uint8_t* __restrict__ seq = b.bases + h.seq_off;
   const uint8_t* __restrict__ qual = b.quals + h.seq_off;
+  const int l16 = threadIdx.x & 15, rbase = threadIdx.x & 48;
+  int nh = 0;   // hits of this read so far (row-uniform)
+  uint2* const hl = hit_list ? hit_list + (size_t)rr * LCR_HITS : nullptr;
   row16_walk_sites(b, live && s_lo < s_hi, h, b.read_rend[rr], s_lo, s_hi,
     [&](int i) { return sv[i].col; },
     [&](int cur, int c, bool hit) {   // lane <-> survivor
+      uint8_t base = 0, rq = 0;
+      if (hit) { base = seq[c]; rq = qual[c]; }
+      if (hl) {
+        const unsigned int hm = (unsigned int)(__ballot(hit) >> rbase) & 0xffffu;
+        const int at = nh + __popc(hm & ((1u << l16) - 1u));
+        if (hit && at < LCR_HITS) hl[at] = make_uint2((uint32_t)cur, (uint32_t)base | ((uint32_t)rq << 8));
+        nh += __popc(hm);
+      }
       if (!hit) return;
-      const uint8_t base = seq[c];
-      const uint8_t bq = qual[c] < 30 ? qual[c] : 30;  // MAX_BASE_QUALITY (util.rs:711-715)
+      const uint8_t bq = rq < 30 ? rq : 30;  // MAX_BASE_QUALITY (util.rs:711-715)
       bool masked = false;
       if (in_end_zone(c, h.lead, h.reb, prm.dist_to_end))
         masked = prm.ont ? true : polya_masked(seq, b.seq_len[rr], c, prm.polya_len, sv[cur].ref_base);
       const int bi = base_code(base);
       if (!masked && bi >= 0) atomicAdd(&hist[((int64_t)cur * 4 + bi) * 31 + bq], 1u);
     });
+  if (hl && live && l16 == 0) {
+    hit_cnt[r] = nh;
+    if (nh > LCR_HITS) ovf_list[atomicAdd(ovf_cnt, 1)] = r;
+  }
 }
 
 void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin, const Survivor* sv,
-                    const int32_t* sv_region_off, uint32_t* hist, hipStream_t s) {
+                    const int32_t* sv_region_off, uint32_t* hist, int32_t* hit_cnt, void* hit_list, int32_t* ovf_cnt, int32_t* ovf_list, hipStream_t s) {
   if (b.n_reads == 0) return;
   const int per = LCR_BLOCK / 16;
-  hipLaunchKernelGGL(k2_hist, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, p, rbin, sv, sv_region_off, hist);
+  hipLaunchKernelGGL(k2_hist, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, p, rbin, sv, sv_region_off, hist, hit_cnt, (uint2*)hit_list,
+                     ovf_cnt, ovf_list);
 }
 
 // ---- pass 2a, tile form.  When the survivors are DENSE (C5: every covered column of a 500x ONT-dRNA island passes the count

@@ -107,19 +107,19 @@ void launch_k3_region_entries(const int64_t* row_ptr, const int32_t* row_region_
 // fewer: a read crosses a handful of candidates), so the second pass is a copy for those rows (k3_place) and
 // only longer rows are walked again (FILL: rows with more than K3_INLINE entries).
 #define K3_INLINE 16
+static_assert(K3_INLINE == LCR_HITS, "a row's provisional slot holds what k2_hist's hit list holds");
+// one read (sixteen lanes) of the walk; `live` rows only do work
 template <bool FILL>
-__global__ void __launch_bounds__(LCR_BLOCK)
-k3_walk(BatchView b, const ReadBin* __restrict__ rbin, const lcr_candidate* __restrict__ cand,
-        const int32_t* __restrict__ cand_region_off, const int32_t* __restrict__ row_region_off, int32_t n_rows,
+__device__ __forceinline__ void k3_walk_read(const BatchView& b, const ReadBin* __restrict__ rbin, const lcr_candidate* __restrict__ cand,
+        const int32_t* __restrict__ cand_region_off, const int32_t* __restrict__ row_region_off, int r_, bool live_in,
         int32_t* __restrict__ row_cnt, uint32_t* __restrict__ row_links, const int64_t* __restrict__ row_ptr,
         int32_t* __restrict__ col, uint8_t* __restrict__ val) {
   // rows are the first region_rows[g] reads of each region: index by read (one load for the region)
-  const int r_ = (blockIdx.x * LCR_BLOCK + threadIdx.x) >> 4;
-  const int r = r_ < b.n_reads ? r_ : 0;
+  const int r = (live_in && r_ < b.n_reads) ? r_ : 0;
   const int g = region_of_read(b, r);
   const int k = r - b.read_begin[g];
   const int row0 = row_region_off[g];
-  bool live = r_ < b.n_reads && k < row_region_off[g + 1] - row0;
+  bool live = live_in && r_ < b.n_reads && k < row_region_off[g + 1] - row0;
   const int row = live ? row0 + k : 0;
   if (FILL) {   // shorter rows were placed from their provisional slots: most waves have nothing left to do
     live = live && row_cnt[row] > K3_INLINE;
@@ -162,6 +162,69 @@ k3_walk(BatchView b, const ReadBin* __restrict__ rbin, const lcr_candidate* __re
     });
   if (!FILL && live && l16 == 0) { row_cnt[row] = cnt; row_links[row] = links; }
 }
+// every read of the batch (batches without hit lists: the dense-survivor path of lcr_candidates)
+template <bool FILL>
+__global__ void __launch_bounds__(LCR_BLOCK)
+k3_walk(BatchView b, const ReadBin* __restrict__ rbin, const lcr_candidate* __restrict__ cand,
+        const int32_t* __restrict__ cand_region_off, const int32_t* __restrict__ row_region_off, int32_t n_rows,
+        int32_t* __restrict__ row_cnt, uint32_t* __restrict__ row_links, const int64_t* __restrict__ row_ptr,
+        int32_t* __restrict__ col, uint8_t* __restrict__ val) {
+  k3_walk_read<FILL>(b, rbin, cand, cand_region_off, row_region_off, (int)((blockIdx.x * LCR_BLOCK + threadIdx.x) >> 4), true, row_cnt, row_links, row_ptr, col, val);
+}
+// the reads of a list (those with more hits than k2_hist's list holds): a fixed grid walks it
+template <bool FILL>
+__global__ void __launch_bounds__(LCR_BLOCK)
+k3_walk_list(BatchView b, const ReadBin* __restrict__ rbin, const lcr_candidate* __restrict__ cand,
+             const int32_t* __restrict__ cand_region_off, const int32_t* __restrict__ row_region_off, const int32_t* __restrict__ n_list,
+             const int32_t* __restrict__ list, int32_t* __restrict__ row_cnt, uint32_t* __restrict__ row_links, const int64_t* __restrict__ row_ptr,
+             int32_t* __restrict__ col, uint8_t* __restrict__ val) {
+  const int n = *n_list, per = LCR_BLOCK / 16;
+  for (int i0 = (int)blockIdx.x * per; i0 < n; i0 += (int)gridDim.x * per) {   // (uniform over the workgroup; the waves' rows differ)
+    const int i = i0 + (int)(threadIdx.x >> 4);
+    const int w0 = i0 + (int)((threadIdx.x >> 6) << 2);   // first list index of this wave
+    if (w0 >= n) continue;                                 // (wave-uniform)
+    k3_walk_read<FILL>(b, rbin, cand, cand_region_off, row_region_off, i < n ? list[i] : 0, i < n, row_cnt, row_links, row_ptr, col, val);
+  }
+}
+
+// Count pass from k2_hist's hit lists: a row's entries are its hits at survivors that became candidates, in the same order --
+// no CIGAR is read.  Sixteen lanes per read, lane <-> hit; reads with more hits than the list holds are left to k3_walk_list.
+__global__ void __launch_bounds__(LCR_BLOCK)
+k3_hits(BatchView b, const lcr_candidate* __restrict__ cand, const int32_t* __restrict__ row_region_off, const int32_t* __restrict__ hit_cnt,
+        const uint2* __restrict__ hit_list, const int32_t* __restrict__ keep, const int32_t* __restrict__ pos,
+        int32_t* __restrict__ row_cnt, uint32_t* __restrict__ row_links, int32_t* __restrict__ col, uint8_t* __restrict__ val) {
+  const int r_ = (blockIdx.x * LCR_BLOCK + threadIdx.x) >> 4;
+  const int r = r_ < b.n_reads ? r_ : 0;
+  const int g = region_of_read(b, r);
+  const int k = r - b.read_begin[g];
+  const int row0 = row_region_off[g];
+  const int nh = hit_cnt[r];
+  const bool live = r_ < b.n_reads && k < row_region_off[g + 1] - row0 && nh <= LCR_HITS;
+  const int row = live ? row0 + k : 0;
+  const int l16 = threadIdx.x & 15, rbase = threadIdx.x & 48;
+  int p = 0; uint8_t base = 0, rq = 0; bool fphase = false; int idx = 0;
+  if (live && l16 < nh) {
+    const uint2 hv = hit_list[(size_t)r * LCR_HITS + l16];
+    if (keep[hv.x]) {
+      idx = pos[hv.x];
+      const lcr_candidate& c = cand[idx];
+      base = (uint8_t)(hv.y & 0xffu); rq = (uint8_t)((hv.y >> 8) & 0xffu);
+      if (base == c.ref_base) p = 1;                                                // fragment.rs:134-135
+      else if (base == c.allele1 || base == c.allele2) p = -1;                      // fragment.rs:136-140
+      if (c.flags & LCR_F_DENSE) p = 0;                                             // fragment.rs:148-152
+      fphase = (c.flags & LCR_F_FOR_PHASING) != 0;                                  // fragment.rs:144-146,242-250
+    }
+  }
+  const unsigned int em = (unsigned int)(__ballot(p != 0) >> rbase) & 0xffffu;
+  const unsigned int ph = (unsigned int)(__ballot(p != 0 && fphase) >> rbase) & 0xffffu;
+  if (p != 0) {
+    const int64_t at = (int64_t)row * K3_INLINE + __popc(em & ((1u << l16) - 1u));
+    const uint8_t bq = rq < 30 ? rq : 30;                                            // fragment.rs:127-131
+    col[at] = idx;
+    val[at] = (uint8_t)(bq | (p == 1 ? 32 : 0) | (base_code(base) << 6));
+  }
+  if (live && l16 == 0) { row_cnt[row] = __popc(em); row_links[row] = __popc(ph); }
+}
 
 // rows with at most K3_INLINE entries: provisional slot -> final CSR position (one thread per row)
 __global__ void __launch_bounds__(LCR_BLOCK)
@@ -177,19 +240,30 @@ k3_place(int32_t n_rows, const int32_t* __restrict__ row_cnt, const int64_t* __r
 
 void launch_k3_count(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
                      const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, uint32_t* row_links, int32_t* tmp_col,
-                     uint8_t* tmp_val, hipStream_t s) {
+                     uint8_t* tmp_val, const K3Hits& hits, hipStream_t s) {
   if (n_rows == 0) return;
   const int per = LCR_BLOCK / 16;
+  if (hits.hit_cnt) {
+    hipLaunchKernelGGL(k3_hits, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, cand, row_region_off, hits.hit_cnt, (const uint2*)hits.hit_list,
+                       hits.keep, hits.pos, row_cnt, row_links, tmp_col, tmp_val);
+    hipLaunchKernelGGL(k3_walk_list<false>, dim3(256), dim3(LCR_BLOCK), 0, s, b, rbin, cand, cand_region_off, row_region_off, hits.ovf_cnt, hits.ovf_list,
+                       row_cnt, row_links, (const int64_t*)nullptr, tmp_col, tmp_val);
+    return;
+  }
   hipLaunchKernelGGL(k3_walk<false>, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, rbin, cand,
                      cand_region_off, row_region_off, n_rows, row_cnt, row_links, (const int64_t*)nullptr, tmp_col, tmp_val);
 }
 void launch_k3_fill(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
                     const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, const int64_t* row_ptr, const int32_t* tmp_col,
-                    const uint8_t* tmp_val, int32_t* col, uint8_t* val, hipStream_t s) {
+                    const uint8_t* tmp_val, int32_t* col, uint8_t* val, const K3Hits& hits, hipStream_t s) {
   if (n_rows == 0) return;
   const int per = LCR_BLOCK / 16;
   hipLaunchKernelGGL(k3_place, dim3((n_rows + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, n_rows, row_cnt, row_ptr, tmp_col, tmp_val, col, val);
-  hipLaunchKernelGGL(k3_walk<true>, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, rbin, cand,
-                     cand_region_off, row_region_off, n_rows, row_cnt, (uint32_t*)nullptr, row_ptr, col, val);
+  if (hits.hit_cnt)   // (a row of more than K3_INLINE entries has more than LCR_HITS hits: it is on the list)
+    hipLaunchKernelGGL(k3_walk_list<true>, dim3(256), dim3(LCR_BLOCK), 0, s, b, rbin, cand, cand_region_off, row_region_off, hits.ovf_cnt, hits.ovf_list,
+                       row_cnt, (uint32_t*)nullptr, row_ptr, col, val);
+  else
+    hipLaunchKernelGGL(k3_walk<true>, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, rbin, cand,
+                       cand_region_off, row_region_off, n_rows, row_cnt, (uint32_t*)nullptr, row_ptr, col, val);
 }
 int launch_k3_inline() { return K3_INLINE; }

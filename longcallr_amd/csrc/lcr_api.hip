@@ -54,9 +54,12 @@ struct lcr_ctx {
   // K2
   bool have_cand = false;
   DevBuf flags, tile_count, tile_off, total, survivors, sv_region_off, hist, cand_tmp, keep;
+  DevBuf hit_cnt, hit_list, ovf_list;   // k2_hist's (read, survivor) hits for K3; the overflow counter sits behind the histograms
+  bool hits_valid = false; int32_t hits_n_sv = 0;
   int dbg_bg_tiles = 0;     // lcr_debug_set("bg_tiles"): > 0 = the record-free tiles' stores by this many workgroups on a second queue beside the tally
   int dbg_prefill = 0;      // lcr_debug_set("plane_prefill"): 1 = the count planes are zeroed on a second queue while K0 runs -- measured: 0.69 instead of 0.63 ms for the stage; 0: k1_empty_tiles writes the record-free tiles
   int dbg_hist_tiles = 0;   // lcr_debug_set("hist_tiles"): 0 = by survivor density, 1 = the tile form whenever it applies, -1 = never
+  int dbg_k3_hits = 1;      // lcr_debug_set("k3_hits"): 0 = K3's count pass walks every read's CIGAR itself (the path of batches without hit lists)
   std::vector<lcr_candidate> h_cand;
   std::vector<int32_t> h_cand_off;
   DevBuf d_cand, d_cand_off;
@@ -175,7 +178,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
                     &c->k0_tile_fill, &c->k0_items, &c->region_e_off, &c->frag_tmp_col, &c->frag_tmp_val, &c->tile_nbase, &c->blk_first_read, &c->read_scan, &c->cig_compact, &c->cig_off_new, &c->cig_new_off32, &c->planes, &c->flags,
                     &c->tile_count, &c->tile_off, &c->total, &c->survivors, &c->sv_region_off, &c->hist, &c->cand_tmp,
                     &c->keep, &c->d_cand, &c->d_cand_off, &c->region_rows, &c->row_region_off, &c->row_cnt,
-                    &c->row_links, &c->row_ptr, &c->col, &c->val, &c->tile_order};
+                    &c->row_links, &c->row_ptr, &c->col, &c->val, &c->tile_order, &c->hit_cnt, &c->hit_list, &c->ovf_list};
   for (auto* b : bufs) b->release();
   if (c->ev_nnz) (void)hipEventDestroy(c->ev_nnz);
   if (c->ev_cand) (void)hipEventDestroy(c->ev_cand);
@@ -584,7 +587,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, hipGetLastError());
   const int32_t n_sv = sv_off[ng];
   HIPCHK(c, c->survivors.reserve(std::max(n_sv, 1) * sizeof(Survivor)));
-  HIPCHK(c, c->hist.reserve(std::max<size_t>(n_sv, 1) * 124 * 4));
+  HIPCHK(c, c->hist.reserve(std::max<size_t>(n_sv, 1) * 124 * 4 + 64));   // (+ the hit lists' overflow counter: cleared with the histograms)
   HIPCHK(c, c->cand_tmp.reserve(std::max<size_t>(n_sv, 1) * sizeof(lcr_candidate)));
   HIPCHK(c, c->keep.reserve(((size_t)std::max(n_sv, 1) * 3 + 2) * 4));   // keep | pos (+1) | het/hom index scratch
   HIPCHK(c, c->d_cand.reserve(std::max<size_t>(n_sv, 1) * sizeof(lcr_candidate)));   // (capacity: every survivor kept)
@@ -594,13 +597,21 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   int32_t* const d_idx = d_pos + std::max(n_sv, 1) + 1;
   c->h_cand.clear();
   c->h_cand_off.assign(ng + 1, 0);
+  c->hits_valid = false;
   if (n_sv) {
     // quality histograms of the survivors: from K0's per-tile records when the survivors are dense (>= 1 per 8 columns: a second
     // pileup -- C5), else by walking the reads that cover them.  The tile form needs the ONT presets (end trim already cut out of
     // the records) and u16 counters (a survivor's depth is <= max_depth).
     const bool tiles_ok = c->dp.ont && p->max_depth <= 65535u;
     const bool hist_tiles = tiles_ok && c->dbg_hist_tiles >= 0 && (c->dbg_hist_tiles > 0 || (int64_t)n_sv * 8 >= c->n_cols);
-    HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (size_t)n_sv * 124 * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (size_t)n_sv * 124 * 4 + 64, c->stream));
+    c->hits_valid = !hist_tiles && c->dbg_k3_hits != 0;   // (the walk below leaves K3 its hits; the tile form does not walk reads)
+    c->hits_n_sv = n_sv;
+    if (c->hits_valid) {
+      HIPCHK(c, c->hit_cnt.reserve(std::max<size_t>(c->bv.n_reads, 1) * 4));
+      HIPCHK(c, c->hit_list.reserve(std::max<size_t>(c->bv.n_reads, 1) * LCR_HITS * 8));
+      HIPCHK(c, c->ovf_list.reserve(std::max<size_t>(c->bv.n_reads, 1) * 4));
+    }
     { Timer t(c, LCR_K_CAND_HIST);
       launch_k2_compact(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
                         c->planes.as<uint32_t>(), c->flags.as<uint8_t>(), c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(),
@@ -610,6 +621,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
                              c->chunk_off.as<int32_t>(), c->chunks.p, c->k0_items.as<unsigned long long>(), c->hist.as<uint32_t>(), c->stream);
       else
         launch_k2_hist(c->bv, c->dp, c->read_bin.as<ReadBin>(), c->survivors.as<Survivor>(), c->sv_region_off.as<int32_t>(), c->hist.as<uint32_t>(),
+                       c->hits_valid ? c->hit_cnt.as<int32_t>() : nullptr, c->hit_list.p, (int32_t*)(c->hist.as<uint32_t>() + (size_t)n_sv * 124), c->ovf_list.as<int32_t>(),
                        c->stream); }
     { Timer t(c, LCR_K_CAND_GT);
       launch_k2_gt(c->dp, c->survivors.as<Survivor>(), n_sv, c->hist.as<uint32_t>(), c->bv.start0,
@@ -703,9 +715,17 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->row_links.reserve(std::max(nr_cap, 1) * 4));
   HIPCHK(c, c->row_ptr.reserve((std::max(nr_cap, 1) + 1) * 8));
   if (nr_cap) HIPCHK(c, hipMemsetAsync(c->row_cnt.p, 0, (size_t)nr_cap * 4, c->stream));
+  // the count pass takes the (read, survivor) hits lcr_candidates' walk left (candidates are a subset of the survivors): no second
+  // CIGAR walk; without them (dense survivors: the tile histograms) it walks the reads itself
+  K3Hits hits{};
+  if (c->hits_valid) {
+    const int32_t* d_keep = c->keep.as<int32_t>();
+    hits = K3Hits{c->hit_cnt.as<int32_t>(), c->hit_list.p, (const int32_t*)(c->hist.as<uint32_t>() + (size_t)c->hits_n_sv * 124), c->ovf_list.as<int32_t>(),
+                  d_keep, d_keep + std::max(c->hits_n_sv, 1)};
+  }
   { Timer t(c, LCR_K_FRAG_COUNT);
     launch_k3_count(c->bv, c->read_bin.as<ReadBin>(), c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nr_cap,
-                    c->row_cnt.as<int32_t>(), c->row_links.as<uint32_t>(), c->frag_tmp_col.as<int32_t>(), c->frag_tmp_val.as<uint8_t>(), c->stream);
+                    c->row_cnt.as<int32_t>(), c->row_links.as<uint32_t>(), c->frag_tmp_col.as<int32_t>(), c->frag_tmp_val.as<uint8_t>(), hits, c->stream);
     launch_scan_i32_to_i64(c->scan_tmp, c->row_cnt.as<int32_t>(), c->row_ptr.as<int64_t>(), nr_cap, c->stream); }
   // the regions' first entries ([ng] = all entries) follow the count pass to the host: the phase stage sizes its
   // work from them without a round trip of its own
@@ -739,7 +759,7 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   { Timer t(c, LCR_K_FRAG_FILL);
     launch_k3_fill(c->bv, c->read_bin.as<ReadBin>(), c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), c->row_region_off.as<int32_t>(), nrow,
                    c->row_cnt.as<int32_t>(), c->row_ptr.as<int64_t>(), c->frag_tmp_col.as<int32_t>(), c->frag_tmp_val.as<uint8_t>(),
-                   c->col.as<int32_t>(), c->val.as<uint8_t>(), c->stream); }
+                   c->col.as<int32_t>(), c->val.as<uint8_t>(), hits, c->stream); }
   HIPCHK(c, hipGetLastError());
   c->have_frag = true;
   c->have_phase = false;
@@ -933,6 +953,7 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
   else if (k == "plane_prefill") c->dbg_prefill = value != 0;
   else if (k == "bg_tiles") c->dbg_bg_tiles = (int)std::max<int64_t>(0, std::min<int64_t>(value, 4096));
   else if (k == "hist_tiles") c->dbg_hist_tiles = value > 0 ? 1 : value < 0 ? -1 : 0;
+  else if (k == "k3_hits") c->dbg_k3_hits = value != 0;
   else if (k == "grid_spec_lanes") d.spec_lanes = (int)std::max<int64_t>(1, std::min<int64_t>(value, 16));
   else { c->err = "lcr_debug_set: unknown key " + k; return LCR_E_ARG; }
   return LCR_OK;

@@ -178,8 +178,10 @@ void launch_k2_compact(const BatchView& b, const DevParams& p, const int32_t* ti
                        int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const uint8_t* flags,
                        const int32_t* tile_count, const int32_t* tile_off, Survivor* out, hipStream_t s);
 float lcr_device_sor_threshold(hipStream_t s);
+#define LCR_HITS 16   // (read, survivor) hits k2_hist keeps per read for K3 (= K3's inline entries per row)
 void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin, const Survivor* sv, const int32_t* sv_region_off,
-                    uint32_t* hist /* n_sv * 4 * 31 */, hipStream_t s);
+                    uint32_t* hist /* n_sv * 4 * 31 */, int32_t* hit_cnt /* n_reads, or nullptr: no hit lists */, void* hit_list /* n_reads x LCR_HITS x uint2 */,
+                    int32_t* ovf_cnt /* zeroed */, int32_t* ovf_list /* n_reads */, hipStream_t s);
 // the same histograms from K0's per-tile records instead of a walk over the reads (ONT presets, batches whose survivors are dense)
 void launch_k2_hist_tiles(const BatchView& b, const int32_t* tile_col0, int32_t n_tiles, const int32_t* tile_count,
                           const int32_t* tile_off, const Survivor* sv, const int32_t* ent_off, const void* ents, const unsigned long long* recs,
@@ -191,12 +193,16 @@ void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t*
                       uint32_t min_dense_cnt, hipStream_t s);
 void launch_k3_row_offsets(const int32_t* region_rows, int32_t ng, int32_t* row_region_off, hipStream_t s);
 void launch_k3_region_entries(const int64_t* row_ptr, const int32_t* row_region_off, int32_t ng, int64_t* region_e_off, hipStream_t s, int64_t* host_out = nullptr);
+struct K3Hits {   // what k2_hist left for K3 (hit_cnt == nullptr: nothing -- K3 walks every read's CIGAR itself)
+  const int32_t* hit_cnt; const void* hit_list; const int32_t* ovf_cnt; const int32_t* ovf_list;
+  const int32_t* keep; const int32_t* pos;   // survivor s is candidate pos[s] if keep[s]
+};
 void launch_k3_count(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
                      const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, uint32_t* row_links, int32_t* tmp_col,
-                     uint8_t* tmp_val, hipStream_t s);   // tmp_*: launch_k3_inline() provisional entries per row
+                     uint8_t* tmp_val, const K3Hits& hits, hipStream_t s);   // tmp_*: launch_k3_inline() provisional entries per row
 void launch_k3_fill(const BatchView& b, const ReadBin* rbin, const lcr_candidate* cand, const int32_t* cand_region_off,
                     const int32_t* row_region_off, int32_t n_rows, int32_t* row_cnt, const int64_t* row_ptr, const int32_t* tmp_col,
-                    const uint8_t* tmp_val, int32_t* col, uint8_t* val, hipStream_t s);
+                    const uint8_t* tmp_val, int32_t* col, uint8_t* val, const K3Hits& hits, hipStream_t s);
 int launch_k3_inline();
 void launch_k3_rows(const BatchView& b, const lcr_candidate* cand, const int32_t* cand_region_off, int32_t* region_rows,
                     hipStream_t s, int32_t* host_out = nullptr /* pinned host memory as the device sees it */);

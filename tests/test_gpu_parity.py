@@ -381,17 +381,26 @@ def test_k0_thousands_of_records_beyond_the_tile_window(engine_cls, orc):
     assert c.size >= 2
 
 
-@pytest.mark.parametrize("hook", ["LCR_ENUM_FORCE_STREAM", "LCR_ENUM_FORCE_STREAM=2", "LCR_ENUM_FORCE_BIG", "LCR_POST_HOST", "LCR_POST_HALF"])
+@pytest.mark.parametrize("hook", ["LCR_ENUM_FORCE_STREAM", "LCR_ENUM_FORCE_STREAM=2", "LCR_ENUM_FORCE_BIG", "LCR_POST_HOST", "LCR_POST_HALF", "LCR_K3_HITS=0"])
 def test_fallback_device_paths(engine_cls, orc, monkeypatch, hook):
     """The size-dependent fallbacks of the phase stage give the same results as the default kernels:
     enumeration restarts with LDS-streamed entries (=2: in the launch of the regions with a large LDS image) / from global
     memory, post-phase epilogue on the host, the eight-wave epilogue of the chain regions (taken when a batch has more chain
-    regions than the device has CUs)."""
+    regions than the device has CUs), the fragment matrix's count pass walking the CIGARs itself instead of taking the hits
+    the candidate stage's walk left (LCR_K3_HITS=0: the path of batches whose histograms came from the tiles)."""
     hook, _, value = hook.partition("=")
     monkeypatch.setenv(hook, value or "1")
     b = synth.make_batch("ont-drna", n_genes=3, gene_len=20000, depth=45, seed=14)
     full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=14))
     full_check(engine_cls, orc, helpers.demo_batch(), _abi.make_params("hifi-masseq"), "chr20")
+    if hook == "LCR_ENUM_FORCE_BIG":
+        # a batch in which `prob > largest_prob` between two restarts of equal objective IS decided by the f64 sums (oracle
+        # census: region 6, one compare): k4_enum_resolve_big has to find the same winner
+        b = synth.make_batch("masseq", n_genes=12, gene_len=16000, depth=40, seed=2)
+        p = _abi.make_params("hifi-masseq", seed=2025)
+        regs = oracle_all(orc, b, p)
+        assert sum(int(R.tie_census()[7]) for R in regs) >= 1
+        full_check(engine_cls, orc, b, p)
 
 
 @pytest.mark.parametrize("tie_arith,enum_mask,chain_mask", [("0", 0, 0), ("1", 8, 0), ("2", 9, 1)])
@@ -417,6 +426,29 @@ def test_tie_arithmetic_switch(engine_cls, orc, monkeypatch, tie_arith, enum_mas
             X = [orc.Region(b, g, p).set_fast(1).run_all(orc.MODE_EXACT) for g in range(b.n_regions)]
             T = [orc.Region(b, g, p).set_fast(1).set_tie_mask(orc.tie_mask(0, 0)).run_all(orc.MODE_TIE) for g in range(b.n_regions)]
             assert all(x.vcf_text("c") == t.vcf_text("c") and np.array_equal(x.phase_result()["haplotag"], t.phase_result()["haplotag"]) for x, t in zip(X, T))
+
+
+def test_fragment_rows_beyond_the_hit_lists(engine_cls, orc):
+    """Reads that face more survivors than k2_hist's per-read hit list holds (LCR_HITS = 16): 40 het sites under every read plus
+    error columns -- those rows take the list walk (k3_walk_list, count and fill) beside rows that fit; both K3 paths and the
+    oracle agree."""
+    b, sites = helpers.two_haplotype_batch(n_snps=40, n_reads=36, seed=6)
+    rng = np.random.default_rng(8)
+    short = helpers.two_haplotype_batch(n_snps=40, n_reads=36, seed=6)[0]   # (same reference and sites)
+    del short
+    p = _abi.make_params("hifi-masseq", seed=5)
+    c = full_check(engine_cls, orc, b, p)
+    assert len(c) == 40
+    E = engine_cls(0, p)
+    E.load_batch(b).run_all()
+    fm1 = {k: v.copy() for k, v in E.fragmat().items()}
+    E.debug_set("k3_hits", 0)
+    E.load_batch(b).run_all()
+    fm0 = E.fragmat()
+    for k in fm1:
+        assert np.array_equal(fm1[k], fm0[k]), k
+    assert np.diff(fm1["row_ptr"]).max() == 40
+    E.close()
 
 
 def test_strand_bias_and_isoseq_preset(engine_cls, orc):
