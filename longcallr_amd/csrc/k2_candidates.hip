@@ -362,7 +362,7 @@ k2_hist(BatchView b, DevParams prm, const ReadBin* __restrict__ rbin, const Surv
   const uint8_t* __restrict__ qual = b.quals + h.seq_off;
   const int l16 = threadIdx.x & 15, rbase = threadIdx.x & 48;
   int nh = 0;   // hits of this read so far (row-uniform)
-  uint2* const hl = hit_list ? hit_list + (size_t)rr * LCR_HITS : nullptr;
+  uint2* const hl = hit_cnt ? hit_list + (size_t)rr * LCR_HITS : nullptr;   // (hit_cnt == nullptr: no hit lists asked for)
   row16_walk_sites(b, live && s_lo < s_hi, h, b.read_rend[rr], s_lo, s_hi,
     [&](int i) { return sv[i].col; },
     [&](int cur, int c, bool hit) {   // lane <-> survivor

@@ -195,26 +195,29 @@ k3_hits(BatchView b, const lcr_candidate* __restrict__ cand, const int32_t* __re
         int32_t* __restrict__ row_cnt, uint32_t* __restrict__ row_links, int32_t* __restrict__ col, uint8_t* __restrict__ val) {
   const int r_ = (blockIdx.x * LCR_BLOCK + threadIdx.x) >> 4;
   const int r = r_ < b.n_reads ? r_ : 0;
+  const int l16 = threadIdx.x & 15, rbase = threadIdx.x & 48;
+  // two short dependent chains side by side (the kernel is a handful of loads per row: their latency is all it costs):
+  // read -> region -> row, and read -> hit -> survivor's candidate -> its alleles
+  const int nh = hit_cnt[r];
+  const uint2 hv = hit_list[(size_t)r * LCR_HITS + l16];   // (slots beyond nh hold stale values: used only below nh)
   const int g = region_of_read(b, r);
+  const bool has = r_ < b.n_reads && nh <= LCR_HITS && l16 < nh;
+  const int kp = has ? keep[hv.x] : 0;
+  int idx = has ? pos[hv.x] : 0;
   const int k = r - b.read_begin[g];
   const int row0 = row_region_off[g];
-  const int nh = hit_cnt[r];
   const bool live = r_ < b.n_reads && k < row_region_off[g + 1] - row0 && nh <= LCR_HITS;
   const int row = live ? row0 + k : 0;
-  const int l16 = threadIdx.x & 15, rbase = threadIdx.x & 48;
-  int p = 0; uint8_t base = 0, rq = 0; bool fphase = false; int idx = 0;
-  if (live && l16 < nh) {
-    const uint2 hv = hit_list[(size_t)r * LCR_HITS + l16];
-    if (keep[hv.x]) {
-      idx = pos[hv.x];
-      const lcr_candidate& c = cand[idx];
-      base = (uint8_t)(hv.y & 0xffu); rq = (uint8_t)((hv.y >> 8) & 0xffu);
-      if (base == c.ref_base) p = 1;                                                // fragment.rs:134-135
-      else if (base == c.allele1 || base == c.allele2) p = -1;                      // fragment.rs:136-140
-      if (c.flags & LCR_F_DENSE) p = 0;                                             // fragment.rs:148-152
-      fphase = (c.flags & LCR_F_FOR_PHASING) != 0;                                  // fragment.rs:144-146,242-250
-    }
+  int p = 0; uint8_t base = 0, rq = 0; bool fphase = false;
+  if (has && kp) {
+    const lcr_candidate& c = cand[idx];
+    base = (uint8_t)(hv.y & 0xffu); rq = (uint8_t)((hv.y >> 8) & 0xffu);
+    if (base == c.ref_base) p = 1;                                                // fragment.rs:134-135
+    else if (base == c.allele1 || base == c.allele2) p = -1;                      // fragment.rs:136-140
+    if (c.flags & LCR_F_DENSE) p = 0;                                             // fragment.rs:148-152
+    fphase = (c.flags & LCR_F_FOR_PHASING) != 0;                                  // fragment.rs:144-146,242-250
   }
+  if (!live) p = 0;   // (a read behind the region's last candidate has no row: fragment.rs:51-54)
   const unsigned int em = (unsigned int)(__ballot(p != 0) >> rbase) & 0xffffu;
   const unsigned int ph = (unsigned int)(__ballot(p != 0 && fphase) >> rbase) & 0xffffu;
   if (p != 0) {
@@ -246,7 +249,7 @@ void launch_k3_count(const BatchView& b, const ReadBin* rbin, const lcr_candidat
   if (hits.hit_cnt) {
     hipLaunchKernelGGL(k3_hits, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, cand, row_region_off, hits.hit_cnt, (const uint2*)hits.hit_list,
                        hits.keep, hits.pos, row_cnt, row_links, tmp_col, tmp_val);
-    hipLaunchKernelGGL(k3_walk_list<false>, dim3(256), dim3(LCR_BLOCK), 0, s, b, rbin, cand, cand_region_off, row_region_off, hits.ovf_cnt, hits.ovf_list,
+    hipLaunchKernelGGL(k3_walk_list<false>, dim3(2048), dim3(LCR_BLOCK), 0, s, b, rbin, cand, cand_region_off, row_region_off, hits.ovf_cnt, hits.ovf_list,
                        row_cnt, row_links, (const int64_t*)nullptr, tmp_col, tmp_val);
     return;
   }
@@ -260,7 +263,7 @@ void launch_k3_fill(const BatchView& b, const ReadBin* rbin, const lcr_candidate
   const int per = LCR_BLOCK / 16;
   hipLaunchKernelGGL(k3_place, dim3((n_rows + LCR_BLOCK - 1) / LCR_BLOCK), dim3(LCR_BLOCK), 0, s, n_rows, row_cnt, row_ptr, tmp_col, tmp_val, col, val);
   if (hits.hit_cnt)   // (a row of more than K3_INLINE entries has more than LCR_HITS hits: it is on the list)
-    hipLaunchKernelGGL(k3_walk_list<true>, dim3(256), dim3(LCR_BLOCK), 0, s, b, rbin, cand, cand_region_off, row_region_off, hits.ovf_cnt, hits.ovf_list,
+    hipLaunchKernelGGL(k3_walk_list<true>, dim3(1024), dim3(LCR_BLOCK), 0, s, b, rbin, cand, cand_region_off, row_region_off, hits.ovf_cnt, hits.ovf_list,
                        row_cnt, (uint32_t*)nullptr, row_ptr, col, val);
   else
     hipLaunchKernelGGL(k3_walk<true>, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, rbin, cand,

@@ -586,6 +586,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   const int32_t n_sv = sv_off[ng];
+  if (c->phase.dbg.prof) fprintf(stderr, "[cand] %d survivors of the count filters in %lld columns, %d reads\n", n_sv, (long long)c->n_cols, c->bv.n_reads);
   HIPCHK(c, c->survivors.reserve(std::max(n_sv, 1) * sizeof(Survivor)));
   HIPCHK(c, c->hist.reserve(std::max<size_t>(n_sv, 1) * 124 * 4 + 64));   // (+ the hit lists' overflow counter: cleared with the histograms)
   HIPCHK(c, c->cand_tmp.reserve(std::max<size_t>(n_sv, 1) * sizeof(lcr_candidate)));
@@ -739,6 +740,11 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   c->nnz_pending = true;
   // now the candidates' host copies (long since there): rows per region, candidates per region
   { int rc = cand_settle(c); if (rc) return rc; }
+  if (c->phase.dbg.prof && c->hits_valid) {
+    int32_t n_ovf = 0;
+    HIPCHK(c, hipMemcpy(&n_ovf, c->hist.as<uint32_t>() + (size_t)c->hits_n_sv * 124, 4, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[frag] %d reads with more than %d survivor hits (walked again)\n", n_ovf, LCR_HITS);
+  }
   const int32_t* rr = c->h_stage[3].as<int32_t>();   // rows per region, from lcr_candidates
   c->h_row_region_off.assign(ng + 1, 0);
   for (int g = 0; g < ng; g++) c->h_row_region_off[g + 1] = c->h_row_region_off[g] + rr[g];
