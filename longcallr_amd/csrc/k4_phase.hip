@@ -378,8 +378,33 @@ int PhaseHost::ld_blocks(const PhaseInputs& in, int region, std::vector<int32_t>
   return LCR_OK;   // not a chain region: no blocks are built (phase.rs:1097-1122 never looks at them)
 }
 
-int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t stream, std::string* err) {
 #define PCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e_); return LCR_E_DEVICE; } } while (0)
+// collects what the last run() left in flight: waits for its queues, fetches the tie census, copies the candidates' updated
+// records and the objectives out of the pinned blocks k4_post wrote (the per-row results are read in place)
+int PhaseHost::settle(std::string* err) {
+  if (!pending) return LCR_OK;
+  pending = false;
+  PCHK(hipStreamSynchronize(side));
+  PCHK(hipMemcpyAsync(h_pin[11].p, d_tie.p, TIE_NCTR * 8, hipMemcpyDeviceToHost, main_q));   // (`side` is drained: every kernel that counts is done or ahead in the first queue)
+  PCHK(hipStreamSynchronize(main_q));
+  PCHK(hipGetLastError());
+  memcpy(tie_census, h_pin[11].p, TIE_NCTR * 8);
+  uint8_t* const h_res = h_pin[7].as<uint8_t>();
+  const long long* const h_obj = (const long long*)(h_pin[9].as<uint8_t>() + pend.hc_obj);
+  std::vector<lcr_candidate>& cand = *pend.cand;
+  for (int g = 0; g < pend.ng; g++) {
+    const int c0 = pend.cand_off[g], S = pend.cand_off[g + 1] - c0;
+    if (S == 0 || pend.host_post[g]) continue;
+    memcpy(cand.data() + c0, h_pin[9].as<lcr_candidate>() + c0, (size_t)S * sizeof(lcr_candidate));
+    objective[g] = (double)h_obj[g] / FX_SCALE;
+  }
+  r_haplotag = (int8_t*)(h_res + pend.res_tag); r_assignment = h_res + pend.res_asg; r_phase_set = (uint32_t*)(h_res + pend.res_ps);
+  read_rec_stale = pend.any_host_post;   // (rows of regions that took the host epilogue: records rebuilt on demand)
+  return LCR_OK;
+}
+
+int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t user_stream, std::string* err) {
+  { const int rc = settle(err); if (rc) return rc; }   // (a previous call nobody asked about: its pinned blocks are rewritten below)
   // Two queues: `stream` stages the phase matrices and runs the enumeration regions (S <= max_enum_snps) with their
   // post-phase kernel; `side` runs the chain regions (S > max_enum_snps): LD blocks, LD-seeded start, block-flip pass
   // and perturbation rounds in ONE kernel per region class (k4_grid.hip: a workgroup per region, or all CUs on one
@@ -396,6 +421,14 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
   auto lap = [&](const char* what) { if (!prof) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[phase] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
   std::vector<lcr_candidate>& cand = *in.cand;
   objective.assign(ng, 0.0);
+  if (!main_q) {
+    PCHK(hipStreamCreateWithFlags(&main_q, hipStreamNonBlocking));
+    PCHK(hipEventCreateWithFlags(&ev_user, hipEventDisableTiming));
+  }
+  // everything below is queued on the stage's own queues, behind what the caller's stream holds now (the fragment stage's kernels)
+  hipStream_t const stream = main_q;
+  PCHK(hipEventRecord(ev_user, user_stream));
+  PCHK(hipStreamWaitEvent(stream, ev_user, 0));
   if (!side) {
     PCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     PCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
@@ -884,6 +917,12 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     }
   }
   lap("chain launch");
+  pend.ng = ng; pend.any_host_post = any_host_post;
+  pend.cand_off.assign(in.cand_region_off, in.cand_region_off + ng + 1); pend.host_post = host_post;
+  pend.res_ps = res_ps; pend.res_tag = res_tag; pend.res_asg = res_asg; pend.hc_obj = hc_obj; pend.cand = in.cand;
+  pending = true;
+  // Everything is queued.  Without a reason to wait the call returns here: settle() collects the results when somebody asks.
+  if (!prof && !any_host_post && !grid_lock.held && !dbg.sync_phase) return LCR_OK;
   PCHK(hipStreamSynchronize(side));
   lap("chain kernels");
   if (prof && chain_dev.dbg && !chain_desc.empty()) {   // steps of the last grid-scope chain launch
@@ -915,25 +954,10 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t str
     static const char* nm2[] = {"stage delta/eta", "sigma step (workgroup 0)", "barrier 1", "stage sigma", "delta step (workgroup 0)", "barrier 2"};
     for (int k = 0; k < 6; k++) fprintf(stderr, "[phase]     grid chain rounds: %-26s %9.1f us per iteration\n", nm2[k], (double)clk[8 + k] / 100.0 / (double)std::max<long long>(clk[15], 1));
   }
-  PCHK(hipMemcpyAsync(h_pin[11].p, d_tie.p, TIE_NCTR * 8, hipMemcpyDeviceToHost, stream));   // (`side` is drained: every kernel that counts is done or ahead in `stream`)
-  PCHK(hipStreamSynchronize(stream));
-  PCHK(hipGetLastError());
-  memcpy(tie_census, h_pin[11].p, TIE_NCTR * 8);
+  { const int rc = settle(err); if (rc) return rc; }
   lap("enumeration kernels");
-
-  // ---- results: per-row haplotag / assignment / phase set, candidates and objectives were written to pinned host
-  // memory by k4_post on either queue
-  uint8_t* const h_res = h_pin[7].as<uint8_t>();
+  uint8_t* const h_res = h_pin[7].as<uint8_t>();   // (the host epilogue below writes its regions' rows into the same pinned block)
   int8_t* const h_tag = (int8_t*)(h_res + res_tag); uint8_t* const h_asg = h_res + res_asg; uint32_t* const h_ps = (uint32_t*)(h_res + res_ps);
-  const long long* const h_obj = (const long long*)(h_pin[9].as<uint8_t>() + hc_obj);
-  for (int g = 0; g < ng; g++) {
-    const int c0 = in.cand_region_off[g], S = in.cand_region_off[g + 1] - c0;
-    if (S == 0 || host_post[g]) continue;
-    memcpy(cand.data() + c0, h_pin[9].as<lcr_candidate>() + c0, (size_t)S * sizeof(lcr_candidate));
-    objective[g] = (double)h_obj[g] / FX_SCALE;
-  }
-  r_haplotag = h_tag; r_assignment = h_asg; r_phase_set = h_ps;
-  read_rec_stale = any_host_post;   // (rows of regions that took the host epilogue: records rebuilt on demand)
   if (prof && pin.dbg_clk) {   // steps of k4_post: the slowest workgroup of each kind of region, and the median total
     std::vector<long long> clk((size_t)ng * 16);
     PCHK(hipMemcpy(clk.data(), pin.dbg_clk, clk.size() * 8, hipMemcpyDeviceToHost));

@@ -163,6 +163,10 @@ int lcr_ctx_create(int device, lcr_ctx** out) {
 void lcr_ctx_destroy(lcr_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  (void)c->phase.settle(nullptr);   // (an lcr_phase whose results nobody collected: its queues are drained before anything is freed)
+  if (c->phase.main_q) (void)hipStreamSynchronize(c->phase.main_q);
+  if (c->phase.side) (void)hipStreamSynchronize(c->phase.side);
+  if (c->phase.aux) (void)hipStreamSynchronize(c->phase.aux);
   (void)hipStreamSynchronize(c->stream);
   for (auto& b : c->in_) b.release();
   if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
@@ -193,9 +197,14 @@ void lcr_ctx_destroy(lcr_ctx* c) {
 
 const char* lcr_last_error(const lcr_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
+// lcr_phase leaves its kernels in flight on the phase stage's own queues (lcr_phase_host.h): whoever needs its results, or is about
+// to overwrite what it reads / writes, collects them first
+static int phase_settle(lcr_ctx* c) { return c->phase.settle(&c->err); }
+
 int lcr_ctx_set_stream(lcr_ctx* c, void* s) {
   if (!c) return LCR_E_ARG;
   (void)hipSetDevice(c->device);
+  { int rc = phase_settle(c); if (rc) return rc; }
   if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
   if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
   else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
@@ -204,6 +213,8 @@ int lcr_ctx_set_stream(lcr_ctx* c, void* s) {
 
 int lcr_ctx_sync(lcr_ctx* c) {
   if (!c) return LCR_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  { int rc = phase_settle(c); if (rc) return rc; }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LCR_OK;
 }
@@ -234,6 +245,10 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   if (!c || !rd || !rg) return LCR_E_ARG;
   if (rd->n_reads < 0 || rg->n_regions < 0 || rd->mem != rg->mem) { c->err = "bad batch header"; return LCR_E_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
+  // a device-resident batch may be bound (and its pileup queued) while the previous batch's phase stage is still running: nothing
+  // here or in lcr_pileup touches what that stage reads.  A host batch is copied into the context's staging buffers, which hold
+  // the previous batch's region table: the stage has to be done first.
+  if (rd->mem == LCR_MEM_HOST) { int rc = phase_settle(c); if (rc) return rc; }
   c->loaded = c->have_planes = c->have_cand = c->have_frag = c->have_phase = false;
   c->bound_slot = -1;
   const int nr = rd->n_reads, ng = rg->n_regions, mem = rd->mem;
@@ -368,6 +383,7 @@ int lcr_load_batch_async(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg,
   if (rd->mem != LCR_MEM_HOST || rg->mem != LCR_MEM_HOST) { c->err = "lcr_load_batch_async takes LCR_MEM_HOST batches (a device-resident batch needs no upload)"; return LCR_E_ARG; }
   if (rd->n_reads < 0 || rg->n_regions < 0 || rd->n_bases < 0 || rd->n_cigar < 0) { c->err = "bad batch header"; return LCR_E_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
+  { int rc = phase_settle(c); if (rc) return rc; }   // (the slot may hold the region table a phase stage in flight reads)
   if (!c->up_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
   lcr_ctx::UploadSlot& u = c->up[slot];
   if (!u.ev) HIPCHK(c, hipEventCreateWithFlags(&u.ev, hipEventDisableTiming));
@@ -565,6 +581,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   if (!c || !p) return LCR_E_ARG;
   if (!c->have_planes) { c->err = "lcr_candidates before lcr_pileup"; return LCR_E_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
+  { int rc = phase_settle(c); if (rc) return rc; }   // (the previous batch's phase stage reads the candidate / fragment buffers rewritten from here on)
   c->dp = to_dev(p, c->dp.sor_threshold);
   const int ng = c->bv.n_regions, nt = c->n_tiles;
   if (c->cand_pending && c->cand_dl_other) HIPCHK(c, hipEventSynchronize(c->ev_cand_dl));   // (a previous call's download nobody picked up: its source is rewritten below)
@@ -671,6 +688,7 @@ int lcr_get_candidates(lcr_ctx* c, lcr_candidate_list* out) {
   if (!c || !out) return LCR_E_ARG;
   if (!c->have_cand) { c->err = "lcr_get_candidates before lcr_candidates"; return LCR_E_STATE; }
   { int rc = cand_settle(c); if (rc) return rc; }
+  { int rc = phase_settle(c); if (rc) return rc; }   // (after lcr_phase the records carry its results)
   out->n_cand = (int32_t)c->h_cand.size();
   out->n_regions = c->bv.n_regions;
   out->cand = c->h_cand.data();
@@ -776,6 +794,7 @@ int lcr_get_candidates_device(lcr_ctx* c, const lcr_candidate** dev_cand, int32_
   if (!c || !dev_cand || !n_cand) return LCR_E_ARG;
   if (!c->have_cand) { c->err = "lcr_get_candidates_device before lcr_candidates"; return LCR_E_STATE; }
   { int rc = cand_settle(c); if (rc) return rc; }
+  { int rc = phase_settle(c); if (rc) return rc; }
   *dev_cand = c->d_cand.as<lcr_candidate>();
   *n_cand = (int32_t)c->h_cand.size();
   return LCR_OK;
@@ -914,6 +933,7 @@ int lcr_discover_regions(lcr_ctx* c, int32_t mem, int32_t n_reads, const int32_t
 int lcr_get_phase_result(lcr_ctx* c, lcr_phase_result* out) {
   if (!c || !out) return LCR_E_ARG;
   if (!c->have_phase) { c->err = "lcr_get_phase_result before lcr_phase"; return LCR_E_STATE; }
+  { int rc = phase_settle(c); if (rc) return rc; }
   out->n_rows = c->n_rows; out->n_regions = c->bv.n_regions;
   out->haplotag = c->phase.r_haplotag; out->assignment = c->phase.r_assignment;
   out->phase_set = c->phase.r_phase_set; out->objective = c->phase.objective.data();
@@ -924,6 +944,7 @@ int lcr_get_read_records_device(lcr_ctx* c, const lcr_read_record** dev_rec, int
   if (!c || !dev_rec || !n_rows) return LCR_E_ARG;
   if (!c->have_phase) { c->err = "lcr_get_read_records_device before lcr_phase"; return LCR_E_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
+  { int rc = phase_settle(c); if (rc) return rc; }
   static_assert(sizeof(lcr_read_record) == 12, "lcr_read_record is 12 bytes");
   if (c->phase.read_rec_stale) {   // regions that took the host epilogue (debug hook / fallback): rebuild from the host arrays
     std::vector<lcr_read_record> h((size_t)std::max(c->n_rows, 0));
@@ -954,6 +975,7 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
   else if (k == "enum_force_big") d.enum_force_big = (int)value;
   else if (k == "enum_force_stream") d.enum_force_stream = (int)value;
   else if (k == "host_threads") d.host_threads = (int)value;
+  else if (k == "sync_phase") d.sync_phase = value != 0;
   else if (k == "tie_arith") d.tie_arith = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2));
   else if (k == "timing_mask") c->timing_mask = (uint32_t)value;
   else if (k == "plane_prefill") c->dbg_prefill = value != 0;
@@ -969,6 +991,7 @@ int lcr_get_ld_blocks(lcr_ctx* c, int32_t region, int32_t* n_blocks, const int32
   if (!c || !n_blocks || !block_off || !snp_idx) return LCR_E_ARG;
   if (!c->have_phase) { c->err = "lcr_get_ld_blocks before lcr_phase"; return LCR_E_STATE; }
   if (region < 0 || region >= c->bv.n_regions) { c->err = "lcr_get_ld_blocks: no such region"; return LCR_E_ARG; }
+  { int rc = phase_settle(c); if (rc) return rc; }
   PhaseInputs in;
   in.n_regions = c->bv.n_regions;
   in.cand_region_off = c->h_cand_off.data();
@@ -981,6 +1004,7 @@ int lcr_get_ld_blocks(lcr_ctx* c, int32_t region, int32_t* n_blocks, const int32
 int lcr_get_tie_census(lcr_ctx* c, uint64_t out[8]) {
   if (!c || !out) return LCR_E_ARG;
   if (!c->have_phase) { c->err = "lcr_get_tie_census before lcr_phase"; return LCR_E_STATE; }
+  { int rc = phase_settle(c); if (rc) return rc; }
   for (int i = 0; i < 8; i++) out[i] = i < TIE_NCTR ? (uint64_t)c->phase.tie_census[i] : 0;
   return LCR_OK;
 }

@@ -123,6 +123,7 @@ struct PhaseDebug {
   int spec_lanes = 8;           // "grid_spec_lanes": half-rounds of the perturbation loop run at once at grid scope (1: one after the other; C5 with packed entries: 454 / 370 / 348 / 366 ms with 2 / 4 / 8 / 16 -- eight lanes = one XCD each)
   int tie_arith = 2;            // "tie_arith": which exact fixed-point ties the reference-order f64 arithmetic decides (PhaseDev::tie_arith; 2 = all that liblcr resolves)
   int host_threads = 0;         // "host_threads": size of the host pool of the host epilogue (0: hardware threads / devices, <= 48)
+  int sync_phase = 0;           // "sync_phase": lcr_phase waits for its kernels and collects the results before it returns (rounds 1-4)
 };
 
 struct PhaseHost {
@@ -146,6 +147,21 @@ struct PhaseHost {
   hipStream_t side = nullptr;   // second queue: fragment matrix download + chain regions
   hipEvent_t ev_in = nullptr, ev_csr = nullptr, ev_fork = nullptr, ev_join = nullptr;
   hipStream_t aux = nullptr;   // enumeration classes 3 / 4 beside class 2
+  // The stage's FIRST queue is its own too (round 5): lcr_phase returns when everything is queued, the caller's stream is free for
+  // the next batch's lcr_load_batch / lcr_pileup -- whose kernels fill the CUs the phase stage leaves idle (the wait for the staged
+  // sizes, the resolve / post-phase tails of a few hundred workgroups) --, and the results are collected by settle(): every getter,
+  // lcr_ctx_sync, the next lcr_candidates / lcr_phase call it.  Persistent all-CU launches (device lock), the host epilogue and
+  // phase_prof settle before run() returns.
+  hipStream_t main_q = nullptr;
+  hipEvent_t ev_user = nullptr;
+  bool pending = false;
+  struct Pending {
+    int ng = 0; bool any_host_post = false;
+    std::vector<int32_t> cand_off; std::vector<uint8_t> host_post;
+    size_t res_ps = 0, res_tag = 0, res_asg = 0, hc_obj = 0;
+    std::vector<lcr_candidate>* cand = nullptr;
+  } pend;
+  int settle(std::string* err);
   HostPool* pool = nullptr;
   HelperThread* helper_thread = nullptr;
   void* work = nullptr;   // PhaseWork (k4_phase.hip): per-region host state reused across calls
@@ -168,6 +184,9 @@ struct PhaseHost {
     if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
     if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
     if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
+    if (main_q) { (void)hipStreamDestroy(main_q); main_q = nullptr; }
+    if (ev_user) { (void)hipEventDestroy(ev_user); ev_user = nullptr; }
+    pending = false;
     delete helper_thread; helper_thread = nullptr;
     delete pool; pool = nullptr;
     free_work();
