@@ -385,8 +385,8 @@ int PhaseHost::settle(std::string* err) {
   if (!pending) return LCR_OK;
   pending = false;
   PCHK(hipStreamSynchronize(side));
-  PCHK(hipMemcpyAsync(h_pin[11].p, d_tie.p, TIE_NCTR * 8, hipMemcpyDeviceToHost, main_q));   // (`side` is drained: every kernel that counts is done or ahead in the first queue)
-  PCHK(hipStreamSynchronize(main_q));
+  PCHK(hipMemcpyAsync(h_pin[11].p, d_tie.p, TIE_NCTR * 8, hipMemcpyDeviceToHost, q_first));   // (`side` is drained: every kernel that counts is done or ahead in the first queue)
+  PCHK(hipStreamSynchronize(q_first));
   PCHK(hipGetLastError());
   memcpy(tie_census, h_pin[11].p, TIE_NCTR * 8);
   uint8_t* const h_res = h_pin[7].as<uint8_t>();
@@ -421,14 +421,21 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
   auto lap = [&](const char* what) { if (!prof) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[phase] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
   std::vector<lcr_candidate>& cand = *in.cand;
   objective.assign(ng, 0.0);
-  if (!main_q) {
-    PCHK(hipStreamCreateWithFlags(&main_q, hipStreamNonBlocking));
-    PCHK(hipEventCreateWithFlags(&ev_user, hipEventDisableTiming));
+  // async_phase (opt-in): everything below is queued on the stage's OWN first queue, behind what the caller's stream holds now (the
+  // fragment stage's kernels), and the call returns without waiting.  Default: the caller's stream, results collected before the
+  // call returns -- measured on C3 (profiles/r05_async_phase.txt): the next batch's pileup then time-shares the CUs with the
+  // restarts (K0 214 -> 385 us, k4_enum_reg<32> 647 -> 1142 us), the resolve / post-phase tails stay exposed because the next
+  // lcr_candidates has to wait for this stage anyway, and a fourth stream of the process pushes `side` and `aux` onto one hardware
+  // queue: 2.19 -> 2.12 ms per step, and the pileup kernels' own durations (the roofline's measurement) grow by half.
+  const bool async_mode = dbg.async_phase != 0;
+  if (async_mode && !main_q) PCHK(hipStreamCreateWithFlags(&main_q, hipStreamNonBlocking));
+  if (!ev_user) PCHK(hipEventCreateWithFlags(&ev_user, hipEventDisableTiming));
+  hipStream_t const stream = async_mode ? main_q : user_stream;
+  if (async_mode) {
+    PCHK(hipEventRecord(ev_user, user_stream));
+    PCHK(hipStreamWaitEvent(stream, ev_user, 0));
   }
-  // everything below is queued on the stage's own queues, behind what the caller's stream holds now (the fragment stage's kernels)
-  hipStream_t const stream = main_q;
-  PCHK(hipEventRecord(ev_user, user_stream));
-  PCHK(hipStreamWaitEvent(stream, ev_user, 0));
+  q_first = stream;
   if (!side) {
     PCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     PCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
@@ -922,7 +929,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
   pend.res_ps = res_ps; pend.res_tag = res_tag; pend.res_asg = res_asg; pend.hc_obj = hc_obj; pend.cand = in.cand;
   pending = true;
   // Everything is queued.  Without a reason to wait the call returns here: settle() collects the results when somebody asks.
-  if (!prof && !any_host_post && !grid_lock.held && !dbg.sync_phase) return LCR_OK;
+  if (async_mode && !prof && !any_host_post && !grid_lock.held) return LCR_OK;
   PCHK(hipStreamSynchronize(side));
   lap("chain kernels");
   if (prof && chain_dev.dbg && !chain_desc.empty()) {   // steps of the last grid-scope chain launch

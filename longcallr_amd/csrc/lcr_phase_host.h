@@ -123,7 +123,7 @@ struct PhaseDebug {
   int spec_lanes = 8;           // "grid_spec_lanes": half-rounds of the perturbation loop run at once at grid scope (1: one after the other; C5 with packed entries: 454 / 370 / 348 / 366 ms with 2 / 4 / 8 / 16 -- eight lanes = one XCD each)
   int tie_arith = 2;            // "tie_arith": which exact fixed-point ties the reference-order f64 arithmetic decides (PhaseDev::tie_arith; 2 = all that liblcr resolves)
   int host_threads = 0;         // "host_threads": size of the host pool of the host epilogue (0: hardware threads / devices, <= 48)
-  int sync_phase = 0;           // "sync_phase": lcr_phase waits for its kernels and collects the results before it returns (rounds 1-4)
+  int async_phase = 0;          // "async_phase": lcr_phase returns when its kernels are queued (on a queue of its own); settle() collects the results
 };
 
 struct PhaseHost {
@@ -147,12 +147,11 @@ struct PhaseHost {
   hipStream_t side = nullptr;   // second queue: fragment matrix download + chain regions
   hipEvent_t ev_in = nullptr, ev_csr = nullptr, ev_fork = nullptr, ev_join = nullptr;
   hipStream_t aux = nullptr;   // enumeration classes 3 / 4 beside class 2
-  // The stage's FIRST queue is its own too (round 5): lcr_phase returns when everything is queued, the caller's stream is free for
-  // the next batch's lcr_load_batch / lcr_pileup -- whose kernels fill the CUs the phase stage leaves idle (the wait for the staged
-  // sizes, the resolve / post-phase tails of a few hundred workgroups) --, and the results are collected by settle(): every getter,
-  // lcr_ctx_sync, the next lcr_candidates / lcr_phase call it.  Persistent all-CU launches (device lock), the host epilogue and
-  // phase_prof settle before run() returns.
-  hipStream_t main_q = nullptr;
+  // lcr_debug_set("async_phase", 1) (round 5, opt-in): the stage's FIRST queue is its own too, lcr_phase returns when everything is
+  // queued, the caller's stream is free for the next batch's lcr_load_batch / lcr_pileup, and the results are collected by
+  // settle(): every getter, lcr_ctx_sync, the next lcr_candidates / lcr_phase call it.  Persistent all-CU launches (device
+  // lock), the host epilogue and phase_prof settle before run() returns.  Default: the caller's stream, settle() inside run().
+  hipStream_t main_q = nullptr, q_first = nullptr;   // q_first: the queue the last run() used as its first
   hipEvent_t ev_user = nullptr;
   bool pending = false;
   struct Pending {

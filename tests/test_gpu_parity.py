@@ -1432,6 +1432,40 @@ def test_bench_under_the_launcher_with_one_rank():
     assert line["n_gpus"] == 1 and line["value"] > 0
 
 
+def test_asynchronous_phase_stage(engine_cls):
+    """lcr_debug_set("async_phase", 1): lcr_phase returns with its kernels in flight on the stage's own queues; the next batch is
+    bound and its pileup queued beside them, every getter / the next lcr_candidates collects the results first.  Three batches
+    back to back (no getter in between), then getters in every order == the synchronous engine, byte for byte."""
+    p = _abi.make_params("ont-cdna", seed=77)
+    bs = [synth.make_batch("ont-cdna", n_genes=n, gene_len=10000, depth=35, seed=60 + k) for k, n in enumerate((5, 3, 6))]
+    import torch
+    dev = torch.device("cuda", 0)
+    import bench as _bench
+    dv = [_bench.to_device(b, torch, dev) for b in bs]   # device-resident inputs: the next bind does not wait for the phase stage
+    Es, Ea = engine_cls(0, p), engine_cls(0, p)
+    Ea.debug_set("async_phase", 1)
+    want = []
+    for d in dv:
+        Es.load_batch(d).run_all()
+        want.append((_result_bytes(Es), Es.columns().copy()))
+    for rep in range(2):
+        for k, d in enumerate(dv):      # back to back: batch k + 1's load + pileup are queued while batch k's phase stage runs
+            Ea.load_batch(d).run_all()
+            if rep == 1:
+                if k == 0:
+                    pr = Ea.phase_result(); c = Ea.candidates()[0]
+                elif k == 1:
+                    c = Ea.candidates()[0]; pr = Ea.phase_result()
+                assert _result_bytes(Ea) == want[k][0], "async batch %d" % k
+                assert np.array_equal(Ea.columns(), want[k][1])
+        assert _result_bytes(Ea) == want[-1][0]
+    # host batches: lcr_load_batch waits for the stage in flight (it rewrites the staging buffers)
+    for k, b in enumerate(bs):
+        Ea.load_batch(b).run_all()
+    assert _result_bytes(Ea) == want[-1][0]
+    Es.close(); Ea.close()
+
+
 def test_region_discovery_gpu(engine_cls):
     """lcr_discover_regions vs the loop-for-loop restatement of util.rs:236-332."""
     import os
