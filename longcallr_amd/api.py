@@ -175,7 +175,7 @@ class Engine:
         self._chk(self.lib.lcr_get_ld_blocks(self.h, int(region), C.byref(n), C.byref(off), C.byref(idx)), "lcr_get_ld_blocks")
         return [[idx[k] for k in range(off[b], off[b + 1])] for b in range(n.value)]
 
-    TIE_FIELDS = ("sigma_f64", "sigma_flips", "delta_unresolved", "step_unresolved", "best_f64", "best_unresolved", "sigma_unresolved", "reserved")
+    TIE_FIELDS = ("sigma_f64", "sigma_flips", "delta_unresolved", "step_unresolved", "best_f64", "best_unresolved", "sigma_unresolved", "delta_step_f64")
 
     def tie_census(self):
         """exact fixed-point ties of the last phase() and how they were decided (include/lcr.h: lcr_get_tie_census)"""

@@ -124,7 +124,8 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
                                     unsigned long long* racc = nullptr /* racc_cap words of LDS (any content), or nullptr */, int racc_cap = 0,
                                     const long long* snp_const_lds = nullptr /* the region's 4 S per-SNP constants in LDS, or nullptr */,
                                     int* iters_out = nullptr, long long* prof = nullptr /* thread 0: six step timers (LCR_PHASE_PROF) */,
-                                    int* flags = nullptr /* three ints of LDS: one barrier per iteration for both "anything changed" bits */) {
+                                    int* flags = nullptr /* three ints of LDS: one barrier per iteration for both "anything changed" bits */,
+                                    double* qrow = nullptr /* 2 R doubles of scratch: the COMPLETE tie contract (classes 2 / 4 too) in the plain form below; S <= 32 */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int32_t* rp = mv.rp;
   const int32_t* pc = mv.pc;
@@ -272,7 +273,15 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
   while (hg_inc | h_inc) {
     // ---- sigma step (phase.rs:824-862): A - B = sum over het sites of (+w if p == sigma*delta else -w);
     //      flip every row with A < B (sites with eta != 0 contribute equally to both)
-    int any = 0;
+    // Complete tie contract (qrow != nullptr, P.tie_arith >= 3): beside the sigma ties, (class 2) a delta / eta choice with two equal
+    // maxima takes the first maximum of the reference's f64 scores, and (class 4) a step whose only changes were tie changes is an
+    // improvement iff the reference's sums of scores say so (check_new_haplotag / check_new_haplotype_genotype, phase.rs:278-355).
+    // Without qrow those events are counted as unresolved ("first maximum", "no improvement").
+    const bool full = qrow != nullptr && P.tie_arith >= 3 && rd.S <= 32;
+    __shared__ double s_qn[32], s_qo[32];
+    __shared__ int8_t s_ch[32], s_cur[32];
+    __shared__ int s_verdict;
+    int any = 0, anyt = 0;
     for (int row = tid; row < rd.R; row += blockDim.x) {
       const int s = sg[row];
       long long diff = 0;
@@ -282,24 +291,101 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
         if (et[i] == 0) { const long long w = wl[v & 31]; diff += (((v & 32) ? 1 : -1) == s * dl[i]) ? w : -w; }
       }
       if (diff < 0) { sg[row] = (int8_t)(-s); any = 1; }
-      else if (diff == 0 && rp[row + 1] > rp[row] && tie_row_decide(P, rp, pc, pv, row, dl, et, s, le64, l1e64)) sg[row] = (int8_t)(-s);   // (Jacobi: a row reads its own sigma only)
+      else if (diff == 0 && rp[row + 1] > rp[row] && tie_row_decide(P, rp, pc, pv, row, dl, et, s, le64, l1e64)) { sg[row] = (int8_t)(full ? -2 * s : -s); anyt = 1; }   // (Jacobi: a row reads its own sigma only; +-2: flipped by a tie, until the step's verdict below)
     }
     any = __syncthreads_or(any);
+    anyt = __syncthreads_or(anyt);
+    if (anyt && !any) {   // a step of tie flips only
+      if (!full) { if (tid == 0) TIE_COUNT(P.tie_ctr, TIE_STEP_UNRES, 1ull); }
+      else {
+        if (tid == 0) TIE_COUNT(P.tie_ctr, TIE_STEP_F64, 1ull);
+        for (int row = tid; row < rd.R; row += blockDim.x) {   // every row's score under the new and the old sigma
+          double qn = 0.0, qo = 0.0;
+          if (rp[row + 1] > rp[row]) {
+            double lp = 0.0, lm = 0.0;   // log_q2 (sigma = +1), log_q3 (sigma = -1), entry order (phase.rs:82-90)
+            for (int e = rp[row]; e < rp[row + 1]; e++) {
+              const int i = pc[e];
+              const uint8_t v = pv[e];
+              const int p = (v & 32) ? 1 : -1, q = v & 31, eta = et[i], d = dl[i];
+              lp += p == (eta == 0 ? d : eta) ? l1e64[q] : le64[q];
+              lm += p == (eta == 0 ? -d : eta) ? l1e64[q] : le64[q];
+            }
+            const int sv = sg[row], sn = sv < 0 ? -1 : 1, so = (sv == 2 || sv == -2) ? -sn : sn;
+            const double den = lp + lm;
+            qn = 1.0 - (sn == 1 ? lp : lm) / den; qo = 1.0 - (so == 1 ? lp : lm) / den;
+          }
+          qrow[2 * row] = qn; qrow[2 * row + 1] = qo;   // (a row without an entry is not in the reference's sums: + 0.0 changes nothing)
+        }
+        __syncthreads();
+        if (wave == 0) {   // the two sums, rows in order
+          double logp = 0.0, pre = 0.0;
+          for (int base = 0; base < rd.R; base += 64) {
+            const int row = base + lane;
+            const double a = row < rd.R ? qrow[2 * row] : 0.0, b2 = row < rd.R ? qrow[2 * row + 1] : 0.0;
+            const int alo = (int)__double2loint(a), ahi = (int)__double2hiint(a), blo = (int)__double2loint(b2), bhi = (int)__double2hiint(b2);
+            const int n = min(64, rd.R - base);
+            for (int k = 0; k < n; k++) {
+              logp += __hiloint2double(__shfl(ahi, k, 64), __shfl(alo, k, 64));
+              pre += __hiloint2double(__shfl(bhi, k, 64), __shfl(blo, k, 64));
+            }
+          }
+          if (lane == 0) s_verdict = logp > pre ? 1 : 0;
+        }
+        __syncthreads();
+        any = s_verdict;
+      }
+    }
+    if (anyt && full) {   // back to +-1
+      for (int row = tid; row < rd.R; row += blockDim.x) { const int sv = sg[row]; if (sv == 2) sg[row] = 1; else if (sv == -2) sg[row] = -1; }
+      __syncthreads();
+    }
     tick(2);
     if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
     // ---- delta/eta step (phase.rs:872-959): per SNP the best of (d,0) (-d,0) (d,+1) (d,-1)
-    any = 0;
+    any = 0; anyt = 0;
+    if (full) { if (tid < 32) s_ch[tid] = -1; __syncthreads(); }
+    // the four f64 scores of SNP i for its delta d (phase.rs:128-176): four running sums over its column in row order + priors
+    auto col_scores = [&](int i, int d, double* q4) {
+      double Sd = 0.0, Sn = 0.0, Shr = 0.0, Shv = 0.0;
+      uint32_t cov = 0;
+      for (int e = cp[i]; e < cp[i + 1]; e++) {
+        const uint8_t v = cv[e];
+        const int p = (v & 32) ? 1 : -1, q = v & 31, x = sg[cr[e]] * d;
+        Sd += p == x ? l1e64[q] : le64[q]; Sn += p == -x ? l1e64[q] : le64[q];
+        Shr += p == 1 ? l1e64[q] : le64[q]; Shv += p == -1 ? l1e64[q] : le64[q];
+        cov++;
+      }
+      const double p_het = P.lut64->log_theta - (double)cov * P.lut64->log2;
+      const double hv = Shv + P.lut64->p_homvar, hr = Shr + P.lut64->p_homref, hd = Sd + p_het, hn = Sn + p_het;
+      const double den_d = hv + hd + hr + hn, den_n = hv + hn + hr + hd;
+      q4[0] = 1.0 - hd / den_d; q4[1] = 1.0 - hn / den_n; q4[2] = 1.0 - hr / den_d; q4[3] = 1.0 - hv / den_d;
+    };
     auto decide = [&](int i, long long M, int ncol) {
       const int d = dl[i], h = et[i];
       const long long het = P.lut.f_het0 - (long long)ncol * P.lut.f_log2;  // phase.rs:136-144
       const long long F = sc[4 * i], W = sc[4 * i + 1];
       long long N[4] = {F + M + het, F + W - M + het, sc[4 * i + 2] + P.lut.f_homref, sc[4 * i + 3] + P.lut.f_homvar};
       int ch;
-      if (with_genotype) { ch = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch]) ch = t; }   // phase.rs:908-921
-      else if (h == 0) ch = N[1] > N[0] ? 1 : 0;                                                // phase.rs:923-930
-      else ch = N[3] > N[2] ? 3 : 2;                                                            // phase.rs:931-938
+      bool tie = false;
+      if (with_genotype) { ch = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch]) ch = t; for (int t = 0; t < 4; t++) tie |= t != ch && N[t] == N[ch]; }   // phase.rs:908-921
+      else if (h == 0) { ch = N[1] > N[0] ? 1 : 0; tie = N[1] == N[0]; }                            // phase.rs:923-930
+      else { ch = N[3] > N[2] ? 3 : 2; tie = N[3] == N[2]; }                                        // phase.rs:931-938
+      if (tie) {
+        if (!full) TIE_COUNT(P.tie_ctr, TIE_DELTA_UNRES, 1ull);
+        else {   // the first maximum of the f64 scores (among the candidates the mode looks at)
+          TIE_COUNT(P.tie_ctr, TIE_STEP_F64, 1ull);
+          double q4[4];
+          col_scores(i, d, q4);
+          int cf;
+          if (with_genotype) { const double mx = fmax(q4[0], fmax(q4[1], fmax(q4[2], q4[3]))); cf = q4[0] == mx ? 0 : q4[1] == mx ? 1 : q4[2] == mx ? 2 : 3; }
+          else if (h == 0) { const double mx = fmax(q4[0], q4[1]); cf = q4[0] == mx ? 0 : 1; }
+          else { const double mx = fmax(q4[2], q4[3]); cf = q4[2] == mx ? 2 : 3; }
+          if (N[cf] == N[ch]) ch = cf;
+        }
+      }
       const int cur = h == 0 ? 0 : (h == 1 ? 2 : 3);
-      if (N[ch] > N[cur]) any = 1;
+      if (N[ch] > N[cur]) any = 1; else if (ch != cur) anyt = 1;
+      if (full) { s_ch[i] = (int8_t)ch; s_cur[i] = (int8_t)cur; }
       dl[i] = (int8_t)(ch == 1 ? -d : d);
       et[i] = (int8_t)(ch <= 1 ? 0 : (ch == 2 ? 1 : -1));
     };
@@ -337,6 +423,31 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
       }
     }
     any = __syncthreads_or(any);
+    anyt = __syncthreads_or(anyt);
+    if (anyt && !any) {   // a step of tie changes only: the sums of the SNPs' scores (check_new_haplotype_genotype, phase.rs:316-355), SNPs in order
+      if (!full) { if (tid == 0) TIE_COUNT(P.tie_ctr, TIE_STEP_UNRES, 1ull); }
+      else {
+        if (tid == 0) TIE_COUNT(P.tie_ctr, TIE_STEP_F64, 1ull);
+        if (tid < rd.S) {
+          double qn = 0.0, qo = 0.0;
+          const int ch = s_ch[tid];
+          if (ch >= 0) {
+            double q4[4];
+            col_scores(tid, ch == 1 ? -dl[tid] : dl[tid], q4);   // (the scores are those of the delta the step started from)
+            qn = q4[ch]; qo = q4[s_cur[tid]];
+          }
+          s_qn[tid] = qn; s_qo[tid] = qo;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          double logp = 0.0, pre = 0.0;
+          for (int i = 0; i < rd.S; i++) { logp += s_qn[i]; pre += s_qo[i]; }
+          s_verdict = logp > pre ? 1 : 0;
+        }
+        __syncthreads();
+        any = s_verdict;
+      }
+    }
     tick(4);
     if (!any) hg_inc = false; else { hg_inc = true; h_inc = true; }
     if (++iters > 20) break;  // phase.rs:967-972

@@ -546,7 +546,8 @@ template <int CK>
 __global__ void __launch_bounds__(64 * ENUM_WAVES, ENUM_OCC)   // (three waves per SIMD: <= 168 VGPRs)
 k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uint32_t per, const int64_t* __restrict__ job_base,
             long long* __restrict__ job_obj, const int64_t* __restrict__ st_base, unsigned long long* __restrict__ st_words,
-            long long* __restrict__ region_best) {
+            long long* __restrict__ region_best, uint32_t* __restrict__ redo /* [0]: count, [4 ..]: (slot, restart) pairs; nullptr: none */,
+            uint32_t redo_cap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const EnumTile t = enum_tile_of(P, spans, n_spans, per, false);
   const RegionDev rd = P.reg[t.slot];
@@ -674,6 +675,7 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
     bool hg_inc = true, h_inc = true;
     int iters = 0;
     long long obj_i = 0;
+    const uint32_t ev0 = n_dtie + n_step, n_step0 = n_step, n_dtie0 = n_dtie;   // (wave-uniform) this restart's ties at a delta / eta maximum + tie-only steps
     while (hg_inc | h_inc) {
       // ---- sigma step (phase.rs:824-862)
       {
@@ -835,13 +837,30 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
       if (!any2) hg_inc = false; else { hg_inc = true; h_inc = true; }
       if (++iters > 20) break;  // phase.rs:967-972
     }
+    // A restart that met such a tie took "first maximum" / "no improvement" there.  With the complete tie contract (tie_arith >= 3) it
+    // goes to the repair list: k4_enum_redo runs it once more through the one-workgroup cross_optimize, which decides those ties by
+    // the reference's f64 scores, and overwrites what this wave leaves (rare: C4 meets 147 such steps in 45 000 x 1 000 restarts).
+    bool redone = false;
+    if (redo && n_dtie + n_step != ev0 && P.tie_arith >= 3) {
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(&redo[0], 1u);
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+      if (at < redo_cap) {
+        if (lane == 0) { redo[4 + 2 * at] = (uint32_t)t.slot; redo[5 + 2 * at] = e; }
+        const uint32_t dd = n_dtie - n_dtie0, ds = n_step - n_step0;   // (not unresolved: the repair pass decides them)
+        n_dtie -= dd; n_step -= ds;
+        redone = true;
+      }
+    }
     // objective (phase.rs:257-276) = sum over phase entries of fe + hit * w = sum_i (F_i + hits_i) over live SNPs
     const long long total = wave_sum_ll_dpp(obj_i);
     // a restart below the best objective seen so far in this region can never win: neither signature nor state is kept
     // (region_best: monotone, device-coherent; a stale smaller value only costs a store that is not needed)
     const long long seen = __hip_atomic_load(&region_best[t.slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool keep = __builtin_amdgcn_readfirstlane((int)(total >= seen)) != 0;
-    if (total > seen && lane == 0) (void)__hip_atomic_fetch_max(&region_best[t.slot], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a restart on the repair list does not raise the bar: its objective may still change, and the others keep their state
+    // against the best of the restarts that stand)
+    if (total > seen && lane == 0 && !redone) (void)__hip_atomic_fetch_max(&region_best[t.slot], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // signature of the final configuration: a hash of the match bits [p == x] of all entries -- what the f64 form of the
     // objective (a running sum of LUT[match][q] over the entries in row order) depends on beside the matrix (enum_resolve)
     unsigned long long sig = 0;
@@ -907,11 +926,56 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
 
 // the same tiles for regions whose matrix does not fit the LDS budget: one restart at a time per workgroup.  Every restart leaves
 // its objective and -- st_words != nullptr and the region has a span there (st_base >= 0) -- its final state in the layout of the
-// other classes (sigma bits | delta < 0, eta == 0 masks | eta == +1 mask | a signature of all of it) for k4_enum_resolve_big.
+// other classes (sigma bits | delta < 0, eta == 0 masks | eta == +1 mask | a signature of all of it) for the resolve kernels.
+// qrow (2 R doubles per workgroup): cross_optimize's scratch for the complete tie contract (k4_dev.h).
+__device__ __forceinline__ void enum_big_restart(const PhaseDev& P, const RegionDev& rd, int slot, uint32_t e, bool winner, int8_t* base, double* qrow,
+                                                 long long* red, const long long* wl, unsigned long long* s_sig, const int64_t* __restrict__ job_base,
+                                                 long long* __restrict__ job_obj, const int64_t* __restrict__ st_base, unsigned long long* __restrict__ st_words) {
+  int8_t* sg = base; int8_t* dl = base + rd.R; int8_t* et = dl + rd.S;
+  const int8_t* vt = P.snp_vt + rd.snp_off;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t nk = (uint32_t)(rd.R + 63) / 64, sw = enum_state_words((uint32_t)rd.R);
+  const bool keep = !winner && st_words && st_base[slot] >= 0;
+  for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { dl[i] = ((e >> i) & 1u) ? -1 : 1; et[i] = init_genotype(vt[i]); }
+  const uint64_t ctr0 = (uint64_t)rd.S + (uint64_t)rd.R + (uint64_t)e * (uint64_t)rd.R;
+  for (int row = threadIdx.x; row < rd.R; row += blockDim.x) sg[row] = u01(rd.seed, ctr0 + row) < 0.5 ? -1 : 1;
+  __syncthreads();
+  const long long obj = cross_optimize(P, rd, global_view(P, rd), sg, dl, et, false, true, red, wl, nullptr, CROSS_MACC, nullptr, 0, nullptr, nullptr, nullptr, nullptr, qrow);
+  if (winner) {
+    for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { P.st_delta[rd.snp_off + i] = dl[i]; P.st_eta[rd.snp_off + i] = et[i]; }
+    for (int row = threadIdx.x; row < rd.R; row += blockDim.x) P.st_sigma[rd.sig_off + row] = sg[row];
+    if (threadIdx.x == 0) P.st_obj[slot] = obj;
+  } else {
+    if (threadIdx.x == 0) job_obj[job_base[slot] + e] = obj;
+    if (keep) {
+      unsigned long long* dst = st_words + st_base[slot] + (size_t)e * sw;
+      unsigned long long h = 0;
+      for (uint32_t w0 = (uint32_t)wave; w0 < nk; w0 += LCR_BLOCK / 64) {   // a wave per 64 rows
+        const uint32_t row = 64u * w0 + (uint32_t)lane;
+        const unsigned long long word = __ballot(row < (uint32_t)rd.R && sg[row] < 0);
+        if (lane == 0) dst[w0] = word;
+        h ^= mix64(word + 0x9E3779B97F4A7C15ull * (w0 + 1));
+      }
+      if (lane == 0) s_sig[wave] = h;
+      __syncthreads();
+      if (wave == 0) {   // (S <= 31: a restart index has 32 bits)
+        const bool in = lane < rd.S;
+        const unsigned long long dneg = __ballot(in && dl[in ? lane : 0] < 0), eta0 = __ballot(in && et[in ? lane : 0] == 0), etap = __ballot(in && et[in ? lane : 0] == 1);
+        if (lane == 0) {
+          const unsigned long long w0 = (dneg & 0xffffffffull) | (eta0 << 32), w1 = etap & 0xffffffffull;
+          unsigned long long sig = mix64(w0 + 1) ^ mix64(w1 + 0x5851F42D4C957F2Dull);
+          for (int w = 0; w < LCR_BLOCK / 64; w++) sig ^= s_sig[w];
+          dst[nk] = w0; dst[nk + 1] = w1; dst[nk + 2] = sig;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
 __global__ void __launch_bounds__(LCR_BLOCK)
 k4_enum_big(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uint32_t per, const int64_t* __restrict__ job_base,
             long long* __restrict__ job_obj, const uint32_t* __restrict__ win_e, const int64_t* __restrict__ st_base,
-            unsigned long long* __restrict__ st_words) {
+            unsigned long long* __restrict__ st_words, double* __restrict__ qrow, int64_t qrow_stride) {
   __shared__ long long red[LCR_BLOCK / 64];
   __shared__ long long wl[32];
   __shared__ unsigned long long s_sig[LCR_BLOCK / 64];
@@ -919,49 +983,28 @@ k4_enum_big(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
   const RegionDev rd = P.reg[t.slot];
   load_w(P, wl);
   int8_t* base = P.scratch + (size_t)blockIdx.x * P.scratch_stride;
-  int8_t* sg = base; int8_t* dl = base + rd.R; int8_t* et = dl + rd.S;
-  const int8_t* vt = P.snp_vt + rd.snp_off;
+  double* qr = qrow ? qrow + (size_t)blockIdx.x * qrow_stride : nullptr;
   const uint32_t ne = win_e ? 1u : t.ne;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t nk = (uint32_t)(rd.R + 63) / 64, sw = enum_state_words((uint32_t)rd.R);
-  const bool keep = !win_e && st_words && st_base[t.slot] >= 0;
-  for (uint32_t k = 0; k < ne; k++) {
-    const uint32_t e = win_e ? win_e[t.slot] : t.e0 + k;
-    for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { dl[i] = ((e >> i) & 1u) ? -1 : 1; et[i] = init_genotype(vt[i]); }
-    const uint64_t ctr0 = (uint64_t)rd.S + (uint64_t)rd.R + (uint64_t)e * (uint64_t)rd.R;
-    for (int row = threadIdx.x; row < rd.R; row += blockDim.x) sg[row] = u01(rd.seed, ctr0 + row) < 0.5 ? -1 : 1;
-    __syncthreads();
-    const long long obj = cross_optimize(P, rd, global_view(P, rd), sg, dl, et, false, true, red, wl);
-    if (win_e) {
-      for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { P.st_delta[rd.snp_off + i] = dl[i]; P.st_eta[rd.snp_off + i] = et[i]; }
-      for (int row = threadIdx.x; row < rd.R; row += blockDim.x) P.st_sigma[rd.sig_off + row] = sg[row];
-      if (threadIdx.x == 0) P.st_obj[t.slot] = obj;
-    } else {
-      if (threadIdx.x == 0) job_obj[job_base[t.slot] + e] = obj;
-      if (keep) {
-        unsigned long long* dst = st_words + st_base[t.slot] + (size_t)e * sw;
-        unsigned long long h = 0;
-        for (uint32_t w0 = (uint32_t)wave; w0 < nk; w0 += LCR_BLOCK / 64) {   // a wave per 64 rows
-          const uint32_t row = 64u * w0 + (uint32_t)lane;
-          const unsigned long long word = __ballot(row < (uint32_t)rd.R && sg[row] < 0);
-          if (lane == 0) dst[w0] = word;
-          h ^= mix64(word + 0x9E3779B97F4A7C15ull * (w0 + 1));
-        }
-        if (lane == 0) s_sig[wave] = h;
-        __syncthreads();
-        if (wave == 0) {   // (S <= 31: a restart index has 32 bits)
-          const bool in = lane < rd.S;
-          const unsigned long long dneg = __ballot(in && dl[in ? lane : 0] < 0), eta0 = __ballot(in && et[in ? lane : 0] == 0), etap = __ballot(in && et[in ? lane : 0] == 1);
-          if (lane == 0) {
-            const unsigned long long w0 = (dneg & 0xffffffffull) | (eta0 << 32), w1 = etap & 0xffffffffull;
-            unsigned long long sig = mix64(w0 + 1) ^ mix64(w1 + 0x5851F42D4C957F2Dull);
-            for (int w = 0; w < LCR_BLOCK / 64; w++) sig ^= s_sig[w];
-            dst[nk] = w0; dst[nk + 1] = w1; dst[nk + 2] = sig;
-          }
-        }
-      }
-    }
-    __syncthreads();
+  for (uint32_t k = 0; k < ne; k++)
+    enum_big_restart(P, rd, t.slot, win_e ? win_e[t.slot] : t.e0 + k, win_e != nullptr, base, qr, red, wl, s_sig, job_base, job_obj, st_base, st_words);
+}
+// the repair pass of the LDS classes: the restarts on a list (k4_enum_reg: those that met a tie of class 2 / 4) once more, through the
+// one-workgroup cross_optimize with the complete tie contract; objective and final state overwrite what the fast kernel left (the
+// state's signature is the global-memory class's: never equal to a fast kernel's, so the resolve kernel forms its f64 sum itself)
+__global__ void __launch_bounds__(LCR_BLOCK)
+k4_enum_redo(PhaseDev P, const uint32_t* __restrict__ redo, uint32_t redo_cap, int8_t* __restrict__ scratch, int32_t scratch_stride, double* __restrict__ qrow,
+             int64_t qrow_stride, const int64_t* __restrict__ job_base, long long* __restrict__ job_obj, const int64_t* __restrict__ st_base,
+             unsigned long long* __restrict__ st_words) {
+  __shared__ long long red[LCR_BLOCK / 64];
+  __shared__ long long wl[32];
+  __shared__ unsigned long long s_sig[LCR_BLOCK / 64];
+  const uint32_t n = min(redo[0], redo_cap);
+  if (blockIdx.x >= n) return;
+  load_w(P, wl);
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const int slot = (int)redo[4 + 2 * i];
+    enum_big_restart(P, P.reg[slot], slot, redo[5 + 2 * i], false, scratch + (size_t)blockIdx.x * scratch_stride, qrow + (size_t)blockIdx.x * qrow_stride,
+                     red, wl, s_sig, job_base, job_obj, st_base, st_words);
   }
 }
 
@@ -1082,18 +1125,23 @@ k4_enum_resolve_big(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_
 
 void launch_k4_enum_reg(int ck, unsigned n_blocks, size_t dyn_lds, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, int32_t n_spans,
                         uint32_t per, const int64_t* job_base, long long* job_obj, const int64_t* st_base, unsigned long long* st_words,
-                        long long* region_best) {
+                        long long* region_best, uint32_t* redo, uint32_t redo_cap) {
   const dim3 blk(64 * ENUM_WAVES);
-  if (ck == 32) hipLaunchKernelGGL(k4_enum_reg<32>, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, region_best);
-  else hipLaunchKernelGGL(k4_enum_reg<0>, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, region_best);
+  if (ck == 32) hipLaunchKernelGGL(k4_enum_reg<32>, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, region_best, redo, redo_cap);
+  else hipLaunchKernelGGL(k4_enum_reg<0>, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, region_best, redo, redo_cap);
+}
+void launch_k4_enum_redo(unsigned n_blocks, hipStream_t s, const PhaseDev& P, const uint32_t* redo, uint32_t redo_cap, int8_t* scratch, int32_t scratch_stride,
+                         double* qrow, int64_t qrow_stride, const int64_t* job_base, long long* job_obj, const int64_t* st_base, unsigned long long* st_words) {
+  hipLaunchKernelGGL(k4_enum_redo, dim3(n_blocks), dim3(LCR_BLOCK), 0, s, P, redo, redo_cap, scratch, scratch_stride, qrow, qrow_stride, job_base, job_obj, st_base, st_words);
 }
 void launch_k4_enum_resolve(unsigned n_regions, size_t dyn_lds, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, const int64_t* job_base,
                             const long long* job_obj, const int64_t* st_base, const unsigned long long* st_words) {
   hipLaunchKernelGGL(k4_enum_resolve, dim3(n_regions), dim3(64 * ENUM_WAVES), dyn_lds, s, P, spans, job_base, job_obj, st_base, st_words);
 }
 void launch_k4_enum_big(unsigned n_blocks, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, int32_t n_spans, uint32_t per,
-                        const int64_t* job_base, long long* job_obj, const uint32_t* win_e, const int64_t* st_base, unsigned long long* st_words) {
-  hipLaunchKernelGGL(k4_enum_big, dim3(n_blocks), dim3(LCR_BLOCK), 0, s, P, spans, n_spans, per, job_base, job_obj, win_e, st_base, st_words);
+                        const int64_t* job_base, long long* job_obj, const uint32_t* win_e, const int64_t* st_base, unsigned long long* st_words,
+                        double* qrow, int64_t qrow_stride) {
+  hipLaunchKernelGGL(k4_enum_big, dim3(n_blocks), dim3(LCR_BLOCK), 0, s, P, spans, n_spans, per, job_base, job_obj, win_e, st_base, st_words, qrow, qrow_stride);
 }
 void launch_k4_enum_resolve_big(int32_t n, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, const int64_t* job_base, const long long* job_obj,
                                 const int64_t* st_base, const unsigned long long* st_words, uint32_t* win_e, double* terms, int64_t terms_stride) {

@@ -72,12 +72,16 @@ __host__ __device__ inline uint32_t enum_chunk(uint32_t E) { return E ? (E + 63)
 // st_base[slot]: first word of the region's 2^S saved states in st_words
 void launch_k4_enum_reg(int ck, unsigned n_blocks, size_t dyn_lds, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, int32_t n_spans,
                         uint32_t per, const int64_t* job_base, long long* job_obj, const int64_t* st_base, unsigned long long* st_words,
-                        long long* region_best /* per region, far below any objective before the launch */);
+                        long long* region_best, uint32_t* redo /* repair list: [0] count (zeroed), [4 ..] (slot, restart) pairs; nullptr: none */, uint32_t redo_cap);
+void launch_k4_enum_redo(unsigned n_blocks, hipStream_t s, const PhaseDev& P, const uint32_t* redo, uint32_t redo_cap, int8_t* scratch /* n_blocks x stride */,
+                         int32_t scratch_stride, double* qrow /* n_blocks x qrow_stride */, int64_t qrow_stride, const int64_t* job_base, long long* job_obj,
+                         const int64_t* st_base, unsigned long long* st_words);
 void launch_k4_enum_resolve(unsigned n_regions, size_t dyn_lds, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, const int64_t* job_base,
                             const long long* job_obj, const int64_t* st_base, const unsigned long long* st_words);
 void launch_k4_enum_big(unsigned n_blocks, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, int32_t n_spans, uint32_t per,
                         const int64_t* job_base, long long* job_obj, const uint32_t* win_e /* nullptr: all restarts; else the winners once more */,
-                        const int64_t* st_base /* per region: first word of its saved states, < 0: not kept */, unsigned long long* st_words);
+                        const int64_t* st_base /* per region: first word of its saved states, < 0: not kept */, unsigned long long* st_words,
+                        double* qrow /* n_blocks x qrow_stride doubles (2 per row of the largest region): the complete tie contract, or nullptr */, int64_t qrow_stride);
 void launch_k4_enum_resolve_big(int32_t n, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, const int64_t* job_base, const long long* job_obj,
                                 const int64_t* st_base, const unsigned long long* st_words, uint32_t* win_e, double* terms /* n x terms_stride */,
                                 int64_t terms_stride);

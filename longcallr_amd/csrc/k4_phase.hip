@@ -453,7 +453,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
          &b_stc = d_state[15], &b_slots = d_state[16], &b_psrc = d_state[21], &b_desc = d_state[22], &b_tbl = d_state[23],
          &b_adj = d_state[24], &b_part = d_state[25], &b_snpi = d_state[26], &b_snpb = d_state[27], &b_q = d_state[28],
          &b_info = d_state[29], &b_rowi = d_state[30], &b_enti = d_state[31], &b_work = d_state[32], &b_macc = d_state[33],
-         &b_ctl = d_state[34], &b_terms = d_state[17], &b_btot = d_state[35], &b_ps = d_state[36], &b_pse = d_state[37], &b_psp = d_state[38];
+         &b_ctl = d_state[34], &b_terms = d_state[17], &b_qrow = d_state[18], &b_redo = d_state[19], &b_btot = d_state[35], &b_ps = d_state[36], &b_pse = d_state[37], &b_psp = d_state[38];
   const size_t nnz1 = (size_t)std::max<int64_t>(nnz, 1), nc1 = (size_t)std::max(ncand, 1), nr1 = (size_t)std::max(nrow, 1);
   PCHK(b_reg.reserve((size_t)std::max(ng, 1) * sizeof(RegionDev)));
   PCHK(b_stat.reserve((size_t)std::max(ng, 1) * sizeof(StageStat)));
@@ -819,8 +819,30 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     long long* d_obj = b_obj.as<long long>();
     uint32_t* d_win = (uint32_t*)(d_obj + nj);
     const size_t n_big_blocks = std::max(n_t[4], n_w[4]);
-    PCHK(b_scr.reserve((size_t)stride * n_big_blocks + 64));
+    // the repair pass (tie classes 2 / 4 met by a fast kernel's restart): per launch queue a list of REDO_CAP restarts and REDO_GRID
+    // workgroups' worth of state scratch + score scratch (2 doubles per row), behind the global-memory class's own
+    constexpr uint32_t REDO_CAP = 8192, REDO_GRID = 512;
+    const bool full_ties = dbg.tie_arith >= 3;
+    int32_t max_rows_any = 1;
+    for (int g : enum_slots) max_rows_any = std::max(max_rows_any, stat[g].R);
+    const int64_t qstride = ((int64_t)2 * max_rows_any + 15) & ~(int64_t)15;
+    const size_t n_scr_blocks = n_big_blocks + 2 * (size_t)REDO_GRID;
+    PCHK(b_scr.reserve((size_t)stride * n_scr_blocks + 64));
     P.scratch = b_scr.as<int8_t>();
+    if (full_ties) {
+      PCHK(b_qrow.reserve((size_t)qstride * n_scr_blocks * 8 + 64));
+      PCHK(b_redo.reserve(2 * (16 + 8 * (size_t)REDO_CAP) + 64));
+      PCHK(hipMemsetAsync(b_redo.p, 0, 2 * (16 + 8 * (size_t)REDO_CAP), stream));   // (the counts; the pairs behind them are written before they are read)
+    }
+    uint32_t* const redo_a = full_ties ? b_redo.as<uint32_t>() : nullptr;                          // classes 1 / 2 (first queue)
+    uint32_t* const redo_b = full_ties ? b_redo.as<uint32_t>() + 4 + 2 * REDO_CAP : nullptr;       // class 3 (`aux`)
+    double* const qrow_all = full_ties ? b_qrow.as<double>() : nullptr;
+    auto launch_redo = [&](uint32_t* redo, int which, hipStream_t q) {
+      if (!redo) return;
+      const size_t b0 = n_big_blocks + (size_t)which * REDO_GRID;
+      launch_k4_enum_redo(REDO_GRID, q, P, redo, REDO_CAP, b_scr.as<int8_t>() + (size_t)stride * b0, stride, qrow_all + (size_t)qstride * b0, qstride,
+                          d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());
+    };
     // the classes touch disjoint regions: class 2 on `stream`, classes 3 / 4 beside it on `aux` (their tails overlap)
     long long* const d_rbest = (long long*)(d_win + 2 * (size_t)ng);   // (8-byte aligned: behind the 2 x 4 x ng bytes of winners | tiles done)
     PCHK(hipMemsetAsync(d_rbest, 0x80, (size_t)ng * 8, stream));        // 0x8080...: far below any objective
@@ -830,8 +852,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       hipError_t e = hipSuccess;
       if (fork) { if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e; }
       if (cnt[1]) {   // (first, ahead of class 2 on its queue: the largest matrices have the longest restarts)
-        launch_k4_enum_reg(0, (unsigned)cnt[1], lds_need[1], s1, P, d_sp + s_off[1], (int32_t)n_w[1], per_of[1], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), d_rbest);
-        if (!win) launch_k4_enum_resolve((unsigned)n_w[1], res_lds[1], s1, P, d_sp + s_off[1], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());
+        launch_k4_enum_reg(0, (unsigned)cnt[1], lds_need[1], s1, P, d_sp + s_off[1], (int32_t)n_w[1], per_of[1], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), d_rbest, redo_a, REDO_CAP);
+        if (!win && !cnt[2]) launch_redo(redo_a, 0, s1);   // (with a class 2 launch behind it on this queue: one repair pass for both, below)
+        if (!win && !cnt[2]) launch_k4_enum_resolve((unsigned)n_w[1], res_lds[1], s1, P, d_sp + s_off[1], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());
       }
       // classes 2 / 3: all restarts (both kernels queued first), then per class `prob > largest_prob` over each region's restarts from
       // the objectives, signatures and states they left (phase.rs:1113-1119; ties between configurations of maximal objective by
@@ -839,17 +862,19 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       // restarts on its own queue (the streaming class has the largest matrices, so the longest epilogues: they run beside the
       // register class's resolve instead of behind it)
       unsigned long long* const d_st = d_enum_st.as<unsigned long long>();
-      if (cnt[2]) launch_k4_enum_reg(32, (unsigned)cnt[2], lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, d_sb, d_st, d_rbest);
-      if (cnt[3]) launch_k4_enum_reg(0, (unsigned)cnt[3], lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, d_sb, d_st, d_rbest);
+      if (cnt[2]) launch_k4_enum_reg(32, (unsigned)cnt[2], lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, d_sb, d_st, d_rbest, redo_a, REDO_CAP);
+      if (cnt[3]) launch_k4_enum_reg(0, (unsigned)cnt[3], lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, d_sb, d_st, d_rbest, redo_b, REDO_CAP);
       if (!win) {
+        if (cnt[2]) launch_redo(redo_a, 0, stream);
+        if (cnt[1] && cnt[2]) launch_k4_enum_resolve((unsigned)n_w[1], res_lds[1], s1, P, d_sp + s_off[1], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());
         if (cnt[2]) launch_k4_enum_resolve((unsigned)n_w[2], res_lds[2], stream, P, d_sp + s_off[2], d_jb, d_obj, d_sb, d_st);
         // eight waves per region: the slowest region (most rows) sets the kernel's length, and every row sweep of the
         // epilogue is a pass of <threads> rows (148 -> 103 us on C3)
         if (nps_a && (e = launch_k4_post(2 * LCR_BLOCK, (unsigned)nps_a, post_lds, stream, pin, d_psl, (int32_t)nps_a, plut)) != hipSuccess) return e;
-        if (cnt[3]) launch_k4_enum_resolve((unsigned)n_w[3], res_lds[3], s34, P, d_sp + s_off[3], d_jb, d_obj, d_sb, d_st);
+        if (cnt[3]) { launch_redo(redo_b, 1, s34); launch_k4_enum_resolve((unsigned)n_w[3], res_lds[3], s34, P, d_sp + s_off[3], d_jb, d_obj, d_sb, d_st); }
         if (nps_b && (e = launch_k4_post(2 * LCR_BLOCK, (unsigned)nps_b, post_lds, s34, pin, d_psl + nps_a, (int32_t)nps_b, plut)) != hipSuccess) return e;
       }
-      if (cnt[4]) launch_k4_enum_big((unsigned)cnt[4], s34, P, d_sp + s_off[4], (int32_t)n_w[4], per_of[4], d_jb, d_obj, win, d_sb, d_enum_st.as<unsigned long long>());
+      if (cnt[4]) launch_k4_enum_big((unsigned)cnt[4], s34, P, d_sp + s_off[4], (int32_t)n_w[4], per_of[4], d_jb, d_obj, win, d_sb, d_enum_st.as<unsigned long long>(), qrow_all, qstride);
       if (fork) { if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e; }
       return e;
     };

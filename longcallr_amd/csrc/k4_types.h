@@ -29,7 +29,8 @@ struct PhaseDev {
   // lut64 = the host's libm values of log10(eps_q), log10(1 - eps_q); tie_ctr = the census of the ties met (TIE_* below)
   const struct PostLut* lut64;
   unsigned long long* tie_ctr;
-  int32_t tie_arith;   // 0: fixed point only (ties change nothing), 1: + configurations of equal objective by their f64 sums, 2: + sigma ties by the f64 scores
+  int32_t tie_arith;   // 0: fixed point only (ties change nothing), 1: + configurations of equal objective by their f64 sums, 2: + sigma ties by the f64 scores,
+                       // 3: + (enumeration kernels) delta / eta ties at the maximum and the verdict of tie-only steps
   int32_t pad_;
 };
 // census of exact fixed-point ties of one lcr_phase call (lcr_get_tie_census): the RESOLVED classes follow the reference's f64
@@ -42,6 +43,7 @@ enum { TIE_SIGMA_F64 = 0,      // sigma decisions with A == B at a row with an e
        TIE_BEST_F64 = 4,       // regions whose configurations of maximal objective differ: `prob > largest_prob` by the f64 sums
        TIE_BEST_UNRES = 5,     // ... left to "first maximum wins" (fallback kernels)
        TIE_SIGMA_UNRES = 6,    // sigma ties in kernels without the f64 path
+       TIE_STEP_F64 = 7,       // delta / eta ties at the maximum + tie-only steps decided by the f64 scores (enumeration kernels, round 5)
        TIE_NCTR = 8 };
 // (-DENUM_PROF, a measurement build: the census slots carry k4_enum_resolve's times instead)
 #ifdef ENUM_PROF

@@ -121,7 +121,7 @@ struct PhaseDebug {
   int enum_force_big = 0;       // "enum_force_big" / "enum_force_stream": the fallback enumeration kernels
   int enum_force_stream = 0;    // (2: the large-image launch of the streaming kernel)
   int spec_lanes = 8;           // "grid_spec_lanes": half-rounds of the perturbation loop run at once at grid scope (1: one after the other; C5 with packed entries: 454 / 370 / 348 / 366 ms with 2 / 4 / 8 / 16 -- eight lanes = one XCD each)
-  int tie_arith = 2;            // "tie_arith": which exact fixed-point ties the reference-order f64 arithmetic decides (PhaseDev::tie_arith; 2 = all that liblcr resolves)
+  int tie_arith = 3;            // "tie_arith": which exact fixed-point ties the reference-order f64 arithmetic decides (PhaseDev::tie_arith; 3 = all that liblcr resolves)
   int host_threads = 0;         // "host_threads": size of the host pool of the host epilogue (0: hardware threads / devices, <= 48)
   int async_phase = 0;          // "async_phase": lcr_phase returns when its kernels are queued (on a queue of its own); settle() collects the results
 };

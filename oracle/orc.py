@@ -16,9 +16,10 @@ from longcallr_amd import _abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "liblcr_oracle.so")
 MODE_F64, MODE_EXACT, MODE_F64_ONLY, MODE_EXACT_ONLY, MODE_TIE = 0, 1, 2, 3, 4
-# the tie classes liblcr resolves with the reference's f64 arithmetic (include/lcr.h, lcr_get_tie_census): sigma ties (1) and
-# `prob > largest_prob` at equal objective (8) in the enumeration branch, sigma ties in the chain branch
-TIE_MASK_LIBLCR = 9 | (1 << 8) | (1 << 16)
+# the tie classes liblcr resolves with the reference's f64 arithmetic (include/lcr.h, lcr_get_tie_census): ALL FOUR in the
+# enumeration branch -- sigma ties (1), delta / eta ties at the maximum (2), the verdict of tie-only steps (4), `prob > largest_prob`
+# at equal objective (8) --, sigma ties in the chain branch
+TIE_MASK_LIBLCR = 15 | (1 << 8) | (1 << 16)
 
 
 def tie_mask(enum_mask, chain_mask):

@@ -52,10 +52,10 @@ ORACLE_TIE_MASK = {0: None}     # None: orc.TIE_MASK_LIBLCR (a test of a fallbac
 
 
 def unresolved_ties(census_tie, census_f64, is_chain):
-    """an oracle region's census (orc_get_tie_census) of the classes liblcr leaves to `a tie changes nothing`: delta / eta ties
-    at the maximum [1], steps whose only changes were tie changes [2] (counted by ORC_MODE_TIE), and -- chain branch -- a later
-    configuration of equal objective whose f64 sum is greater [7]"""
-    return int(census_f64[1]) + int(census_tie[2]) + (int(census_f64[7]) if is_chain else 0)
+    """an oracle region's census (orc_get_tie_census) of the classes liblcr leaves to `a tie changes nothing` -- in the CHAIN branch
+    only (the enumeration branch resolves all four classes since round 5): delta / eta ties at the maximum [1], steps whose only
+    changes were tie changes [2] (counted by ORC_MODE_TIE), a later configuration of equal objective whose f64 sum is greater [7]"""
+    return int(census_f64[1]) + int(census_tie[2]) + int(census_f64[7]) if is_chain else 0
 
 
 def check_f64_mode(orc, batch, params, regs, chrom):
@@ -403,11 +403,12 @@ def test_fallback_device_paths(engine_cls, orc, monkeypatch, hook):
         full_check(engine_cls, orc, b, p)
 
 
-@pytest.mark.parametrize("tie_arith,enum_mask,chain_mask", [("0", 0, 0), ("1", 8, 0), ("2", 9, 1)])
+@pytest.mark.parametrize("tie_arith,enum_mask,chain_mask", [("0", 0, 0), ("1", 8, 0), ("2", 9, 1), ("3", 15, 1)])
 def test_tie_arithmetic_switch(engine_cls, orc, monkeypatch, tie_arith, enum_mask, chain_mask):
     """lcr_debug_set("tie_arith"): 0 = every decision on the fixed-point sums alone (ORC_MODE_TIE with no class resolved = the
     contract of rounds 1-3, ORC_MODE_EXACT), 1 = configurations of equal objective by their f64 sums, 2 (default) = also the
-    sigma ties by the f64 scores; each equals the oracle with the same classes, and the census says what was met."""
+    sigma ties by the f64 scores, 3 (default) = also the delta / eta ties at the maximum and the verdict of tie-only steps in the
+    enumeration branch (repair pass); each equals the oracle with the same classes, and the census says what was met."""
     monkeypatch.setenv("LCR_TIE_ARITH", tie_arith)
     monkeypatch.setitem(ORACLE_TIE_MASK, 0, orc.tie_mask(enum_mask, chain_mask))
     for b, p in ((synth.make_batch("ont-drna", n_genes=4, gene_len=20000, depth=45, seed=31), _abi.make_params("ont-drna", seed=31)),
@@ -417,7 +418,7 @@ def test_tie_arithmetic_switch(engine_cls, orc, monkeypatch, tie_arith, enum_mas
         E.load_batch(b).run_all()
         hc = E.tie_census()
         E.close()
-        if tie_arith == "2":
+        if tie_arith in ("2", "3"):
             assert hc["sigma_f64"] > 0 and hc["sigma_unresolved"] == 0
         else:
             assert hc["sigma_f64"] == 0 and hc["sigma_unresolved"] > 0
@@ -449,6 +450,25 @@ def test_fragment_rows_beyond_the_hit_lists(engine_cls, orc):
         assert np.array_equal(fm1[k], fm0[k]), k
     assert np.diff(fm1["row_ptr"]).max() == 40
     E.close()
+
+
+def test_tie_only_steps_take_the_repair_pass(engine_cls, orc):
+    """A batch whose enumeration restarts meet steps with tie changes only (oracle census: 16 of them in one region): the fast
+    kernels put those restarts on the repair list, k4_enum_redo decides the steps by the reference's sums of f64 scores, and
+    the census reports them as decided -- none unresolved.  The same through the global-memory class."""
+    b = synth.make_batch("masseq", n_genes=12, gene_len=16000, depth=40, seed=1)
+    p = _abi.make_params("hifi-masseq", seed=2025)
+    regs = oracle_all(orc, b, p)
+    n_steps = sum(int(R.tie_census()[2]) for R in regs)
+    assert n_steps >= 10
+    full_check(engine_cls, orc, b, p)
+    for big in (0, 1):
+        E = engine_cls(0, p)
+        E.debug_set("enum_force_big", big)
+        E.load_batch(b).run_all()
+        hc = E.tie_census()
+        E.close()
+        assert hc["delta_step_f64"] >= n_steps and hc["step_unresolved"] == 0 and hc["delta_unresolved"] == 0 and hc["best_unresolved"] == 0, hc
 
 
 def test_strand_bias_and_isoseq_preset(engine_cls, orc):
