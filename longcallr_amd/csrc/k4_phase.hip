@@ -322,26 +322,47 @@ struct GridLock {
     char bus[64] = "gpu";
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetPCIBusId(bus, sizeof(bus), dev);
     for (char* ch = bus; *ch; ch++) if (*ch == ':' || *ch == '/') *ch = '_';
-    // The default directory is shared by the users of the machine (two users' persistent launches on one GPU would wait for each
-    // other's workgroups forever just as two processes of one user would): /tmp/liblcr-locks, sticky and world-writable like /tmp
-    // itself, lock files world-writable.  A directory named by lcr_ctx_set_lock_dir is created 0700 and must be the caller's, or sticky.
     std::string dir = lock_dir;
-    const bool shared = dir.empty();
-    if (shared) dir = "/tmp/liblcr-locks";
-    if (mkdir(dir.c_str(), shared ? 01777 : 0700) == 0) { if (shared) (void)chmod(dir.c_str(), 01777); /* (the umask) */ }
-    else if (errno != EEXIST) return "cannot create lock directory " + dir + ": " + strerror(errno);
-    struct stat st;
-    if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || (st.st_uid != getuid() && !(st.st_mode & S_ISVTX)))
-      return "lock directory " + dir + " is neither a directory owned by this user nor a sticky one (lcr_ctx_set_lock_dir names another one)";
+    bool shared = dir.empty();
+    //  a directory is trusted if it is the caller's or root's, and -- when others can write into it -- sticky: the owner
+    // of a directory can unlink and replace the lock file, which would let two processes' persistent launches meet on the GPU, and a
+    // foreign owner could hold the lock for ever.  The machine-wide default /tmp/liblcr-locks is used when it passes that test (this
+    // user created it, or an administrator did); otherwise the lock is per user: /tmp/liblcr-<uid>.
+    auto trusted = [&](const std::string& d) {
+      struct stat st;
+      if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+      if (st.st_uid != getuid() && st.st_uid != 0) return false;
+      return !(st.st_mode & 0022) || (st.st_mode & S_ISVTX) || st.st_uid == getuid();
+    };
+    if (shared) {
+      dir = "/tmp/liblcr-locks";
+      if (mkdir(dir.c_str(), 01777) == 0) (void)chmod(dir.c_str(), 01777);   // (the umask)
+      if (!trusted(dir)) { dir = "/tmp/liblcr-" + std::to_string((unsigned long)getuid()); shared = false; }
+    }
+    if (!shared && mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) return "cannot create lock directory " + dir + ": " + strerror(errno);
+    if (!trusted(dir)) return "lock directory " + dir + " is not a directory of this user or of root (sticky if others may write): lcr_ctx_set_lock_dir names another one";
     const std::string path = dir + "/grid_" + bus + ".lock";
     dev_mu = &device_mutex(bus);
     dev_mu->lock();
-    fd = open(path.c_str(), O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, shared ? 0666 : 0600);
-    if (fd < 0) { const std::string e = "cannot open " + path + ": " + strerror(errno); dev_mu->unlock(); dev_mu = nullptr; return e; }
-    if (shared) { struct stat fs; if (fstat(fd, &fs) == 0 && fs.st_uid == getuid()) (void)fchmod(fd, 0666); }   // (created under a umask)
-    int rc;
-    while ((rc = flock(fd, LOCK_EX)) != 0 && errno == EINTR) {}
-    if (rc != 0) { const std::string e = "flock(" + path + "): " + strerror(errno); close(fd); fd = -1; dev_mu->unlock(); dev_mu = nullptr; return e; }
+    auto fail = [&](const std::string& e) { if (fd >= 0) { close(fd); fd = -1; } dev_mu->unlock(); dev_mu = nullptr; return e; };
+    const auto t_start = std::chrono::steady_clock::now();
+    for (;;) {
+      fd = open(path.c_str(), O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, shared ? 0666 : 0600);
+      if (fd < 0) return fail("cannot open " + path + ": " + strerror(errno));
+      if (shared) { struct stat fs; if (fstat(fd, &fs) == 0 && fs.st_uid == getuid()) (void)fchmod(fd, 0666); }   // (created under a umask)
+      // bounded wait (a process that died holding the lock has released it; one that hangs must not hang everybody else for ever)
+      int rc;
+      while ((rc = flock(fd, LOCK_EX | LOCK_NB)) != 0 && (errno == EWOULDBLOCK || errno == EINTR)) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 600.0)
+          return fail("the device lock " + path + " has been held by another process for 10 minutes");
+        usleep(200);
+      }
+      if (rc != 0) return fail("flock(" + path + "): " + strerror(errno));
+      // the file we hold must still be the one the path names (it may have been unlinked and recreated between open and flock)
+      struct stat fa, fb;
+      if (fstat(fd, &fa) == 0 && stat(path.c_str(), &fb) == 0 && fa.st_ino == fb.st_ino && fa.st_dev == fb.st_dev) break;
+      (void)flock(fd, LOCK_UN); close(fd); fd = -1;
+    }
     held = true;
     return "";
   }
@@ -772,6 +793,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       // path: step 5.49 -> 4.97 ms; a queue of their own was measured too: HIP maps a fourth stream onto one of the first three's
       // hardware queues, no difference)
       if ((cls == 2 || cls == 3) && (std::max(EL.total, RL) > ENUM_LDS_BYTES || dbg.enum_force_stream == 2 /* test hook */)) cls = 1;
+      //  the saved restart states of the LDS classes are allocated up front: a raised max_enum_snps (2^20 restarts x
+      // R / 64 + 3 words) goes to the global-memory class instead, whose states are kept only inside a budget
+      if (cls < 4 && (int64_t)((uint64_t)1 << std::min(S, 62)) * enum_state_words((uint32_t)st.R) > ((int64_t)1 << 27)) cls = 4;
       if (cls < 4) { lds_need[cls] = std::max(lds_need[cls], EL.total); res_lds[cls] = std::max(res_lds[cls], RL); }
       job_base[g] = nj;
       const uint64_t n = 1ull << S;

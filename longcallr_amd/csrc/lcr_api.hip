@@ -163,6 +163,7 @@ int lcr_ctx_create(int device, lcr_ctx** out) {
 void lcr_ctx_destroy(lcr_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->cand_pending && c->cand_dl_other && c->ev_cand_dl) (void)hipEventSynchronize(c->ev_cand_dl);   // (the candidate download on the phase stage's queue writes h_stage[1..2], freed below)
   (void)c->phase.settle(nullptr);   // (an lcr_phase whose results nobody collected: its queues are drained before anything is freed)
   if (c->phase.main_q) (void)hipStreamSynchronize(c->phase.main_q);
   if (c->phase.side) (void)hipStreamSynchronize(c->phase.side);
@@ -215,6 +216,7 @@ int lcr_ctx_sync(lcr_ctx* c) {
   if (!c) return LCR_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   { int rc = phase_settle(c); if (rc) return rc; }
+  if (c->cand_pending && c->cand_dl_other) HIPCHK(c, hipEventSynchronize(c->ev_cand_dl));   // (the candidate records' download rides on the phase stage's second queue)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LCR_OK;
 }

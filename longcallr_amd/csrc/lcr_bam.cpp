@@ -596,14 +596,19 @@ int lcr_bam_open_keep(const char* path, int32_t n_threads, int64_t keep_bytes, l
       const size_t n = (size_t)(blks[w1 - 1].uoff + blks[w1 - 1].isize);
       const bool last = w1 >= blks.size();
       auto chain_step = [&, n, last]() {
-        if (!have_header) {
-          bool done = false;
-          chain_rc = parse_header(d, n, p, &done);
-          if (chain_rc != LCR_OK) return;
-          if (!done) { if (last) chain_rc = fail(b, LCR_E_ARG, n < 12 || memcmp(d, "BAM\1", 4) != 0 ? "not a BAM file" : "truncated BAM header"); return; }
-          have_header = true;
-        }
-        chain_rc = walk(d, n, last, 0, p, win_recs);
+        //  this runs on a thread of its own: an exception here (bad_alloc / length_error from a hostile n_ref or l_name
+        // in the header, or from the record index) must become an error code, not std::terminate
+        try {
+          if (!have_header) {
+            bool done = false;
+            chain_rc = parse_header(d, n, p, &done);
+            if (chain_rc != LCR_OK) return;
+            if (!done) { if (last) chain_rc = fail(b, LCR_E_ARG, n < 12 || memcmp(d, "BAM\1", 4) != 0 ? "not a BAM file" : "truncated BAM header"); return; }
+            have_header = true;
+          }
+          chain_rc = walk(d, n, last, 0, p, win_recs);
+        } catch (const std::bad_alloc&) { chain_rc = fail(b, LCR_E_NOMEM, "out of memory while indexing the BAM records");
+        } catch (const std::exception& e) { chain_rc = fail(b, LCR_E_ARG, std::string("malformed BAM: ") + e.what()); }
       };
       try { chain = std::thread(chain_step); } catch (...) { chain_step(); }   // (no thread to be had: walk here)
     }
