@@ -259,11 +259,15 @@ int lcr_get_ld_blocks(lcr_ctx*, int32_t region, int32_t* n_blocks, const int32_t
  * on the reference-order f64 scores of that row / configuration.  lcr_get_tie_census reports the ties of the last lcr_phase:
  *   out[0] sigma decisions with A == B at rows with an entry at a het site, decided by the f64 scores of phase.rs:77-96
  *   out[1] ... of which flipped (q < qn)
- *   out[2] delta / eta choices with a tie at the maximum -- the first maximum was kept (UNRESOLVED class)
- *   out[3] steps whose only changes were tie changes, taken as "no improvement" (check_new_*, phase.rs:278-355; UNRESOLVED)
+ *   out[2] delta / eta choices with a tie at the maximum where the first maximum was kept (UNRESOLVED: chain branch only since round 5)
+ *   out[3] steps whose only changes were tie changes, taken as "no improvement" (check_new_*, phase.rs:278-355; UNRESOLVED: chain
+ *          branch only since round 5)
  *   out[4] regions whose configurations of maximal objective differ and were compared by their f64 sums (phase.rs:257-276)
- *   out[5] regions where that compare fell to "first maximum wins" (fallback kernels; UNRESOLVED)
- *   out[6] sigma ties met by kernels without the f64 path (UNRESOLVED)      out[7] reserved
+ *   out[5] regions where that compare fell to "first maximum wins" (UNRESOLVED: more maxima than the list holds, states beyond the
+ *          memory budget)
+ *   out[6] sigma ties met by kernels without the f64 path (UNRESOLVED)
+ *   out[7] (round 5, enumeration branch) delta / eta ties at the maximum decided by the f64 scores of phase.rs:128-176 + tie-only steps
+ *          decided by the reference's sums of scores (check_new_haplotag / check_new_haplotype_genotype)
  * All UNRESOLVED counts zero = every decision of the call was the reference arithmetic's decision. */
 int lcr_get_tie_census(lcr_ctx*, uint64_t out[8]);
 
@@ -342,13 +346,16 @@ int lcr_bam_write_reads(const char* out_path, const char* contig, int64_t contig
 
 /* Regions whose phase matrix is far beyond one CU are phased by persistent all-CU kernels; two such launches on one GPU --
  * of two contexts or two processes -- must not overlap, so they are serialised per device by a process-local mutex and an
- * flock on <dir>/grid_<pci bus id>.lock.  dir defaults to /tmp/liblcr-locks (shared by the users of the machine: sticky, world-writable; a directory named here is created 0700); processes that share a GPU must
- * see the same directory (containers without a common /tmp: name one on a shared mount).  A lock that cannot be taken makes
- * lcr_phase fail with LCR_E_DEVICE -- it is never skipped. */
+ * flock on <dir>/grid_<pci bus id>.lock.  dir defaults to /tmp/liblcr-locks when that directory is this user's or root's (and sticky
+ * if others may write into it: an administrator creates it 1777 for a machine whose users share GPUs), else to /tmp/liblcr-<uid>; a
+ * directory named here is created 0700 and has to pass the same test.  Processes that share a GPU must see the same directory
+ * (containers without a common /tmp: name one on a shared mount).  The lock is waited for at most ten minutes; a lock that cannot
+ * be taken makes lcr_phase fail with LCR_E_DEVICE -- it is never skipped. */
 int lcr_ctx_set_lock_dir(lcr_ctx*, const char* dir);
 
 /* Debug / test switches (the library reads no environment variable): key = "phase_prof", "post_host", "grid_min_entries",
- * "grid_generic", "grid_spec_lanes", "post_half", "enum_force_big", "enum_force_stream", "host_threads", "tie_arith", "timing_mask"
+ * "grid_generic", "grid_spec_lanes", "post_half", "enum_force_big", "enum_force_stream", "host_threads", "tie_arith", "timing_mask",
+ * "k3_hits" (0: the fragment stage walks the CIGARs itself), "async_phase" (1: lcr_phase returns with its kernels in flight)
  * (bit k: only the kernel groups LCR_K_* k are timed when timing is enabled; 0 = all) (see PhaseDebug in
  * csrc/lcr_phase_host.h), "hist_tiles" (quality histograms from K0's records: 0 = when the survivors are dense, 1 = whenever the
  * preset allows, -1 = never).  Unknown key: LCR_E_ARG.  The defaults are the product behaviour. */

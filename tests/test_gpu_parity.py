@@ -1212,7 +1212,7 @@ def tie_statistics(orc, E, b, params, O, name, chrom="chrS"):
     cf, ct = A.tie_census(), O.tie_census()
     S = np.diff(O.cand_off)
     chain = S > params.max_enum_snps
-    unres = cf[:, 1] + ct[:, 2] + np.where(chain, cf[:, 7], 0)
+    unres = np.where(chain, cf[:, 1] + ct[:, 2] + cf[:, 7], 0)   # (the enumeration branch resolves all four classes since round 5)
     c, off = E.candidates()
     pr = E.phase_result()
     ta, tx = A.vcf_texts(chrom), X.vcf_texts(chrom)
@@ -1230,6 +1230,10 @@ def tie_statistics(orc, E, b, params, O, name, chrom="chrS"):
     en = ~chain
     # the enumeration kernels' census is the oracle's (the chain kernels at grid scope also count speculative half-rounds)
     assert hc["sigma_f64"] >= int(cf[en, 8].sum()) and hc["sigma_flips"] >= int(cf[en, 4].sum())
+    # nothing fell to "a tie changes nothing" in the enumeration branch, and its tie-only steps / delta ties went through the repair pass
+    assert hc["sigma_unresolved"] == 0 and hc["best_unresolved"] == 0 and hc["delta_step_f64"] >= int((cf[en, 1] + ct[en, 2]).sum())
+    if not chain.any() or int((cf[chain, 1] + ct[chain, 2]).sum()) == 0:
+        assert hc["delta_unresolved"] == 0 and hc["step_unresolved"] == 0
     FULL_SIZE_STATS[name] = dict(regions=int(b.n_regions), chain_regions=int(chain.sum()),
                                  regions_where_hip_differs_from_f64=int(differ_f64), regions_where_hip_differs_from_round3_fixed_point=int(differ_exact),
                                  regions_with_a_tie_of_an_unresolved_class=int((unres > 0).sum()),
