@@ -37,6 +37,10 @@ import time
 
 import numpy as np
 
+# The asynchronous phase stage (lcr_ctx_set_async_phase, include/lcr.h) uses four queues; ROCm's default of 4 hardware queues per process
+# maps two of them onto one (measured: no gain then).  Read by the HIP runtime when it starts, so it is set before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -555,6 +559,9 @@ def main():
                     help="batches in flight per GPU: N contexts driven by N host threads (a context per worker thread, as "
                          "the reference's rayon workers would hold); 1 = one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-phase", action="store_true",
+                    help="lcr_phase waits for its kernels before it returns (rounds 1-4).  Default at N = 1: lcr_ctx_set_async_phase -- the next "
+                         "step's bind + pileup are queued under the stage's resolve / post-phase tails (DESIGN.md §5)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
     if a.quick:
@@ -618,6 +625,10 @@ def main():
     # are timed in one more pass behind them (every timer costs two event records on the stream: all eight, ~0.06 ms per step)
     engines = [api.Engine(local, params, timing=(_abi.K_SPANS, _abi.K_PILEUP)) for _ in range(F)]
     E = engines[0]
+    # asynchronous phase stage: one context, one rank (at N > 1 every step hands its records to the gather, which collects them first)
+    async_phase = not a.sync_phase and dist is None and F == 1
+    if async_phase:
+        E.set_async_phase(True)
     if F == 1:
         E.set_stream(torch.cuda.current_stream().cuda_stream)  # torch.cuda.synchronize() then covers liblcr
 
@@ -753,6 +764,12 @@ def main():
                     "note": "ms_per_step = a rank's own K steps incl. its share of the gathers, before the closing barrier; `value` uses the slowest rank"}
 
     # stage breakdown (untimed extra pass: wall clock per ABI call with a sync after each, + HIP events)
+    iso_ms = None
+    if async_phase:   # the pileup stage's kernels once more WITHOUT the previous step's tails beside them: five synchronous steps
+        E.set_async_phase(False)
+        iso = [step(E) for _ in range(5)]
+        E.sync()
+        iso_ms = float(np.mean([t[0] + t[1] for t in iso[1:]]))
     api_ms = {}
     def timed(name, fn):
         ts = time.perf_counter(); fn(); E.sync(); api_ms[name] = (time.perf_counter() - ts) * 1e3
@@ -814,6 +831,9 @@ def main():
                        "gathered_records_last_batch": {"candidates": gathered[0], "reads": gathered[1]} if dist is not None else None,
                        "per_rank": per_rank,
                        "batches_in_flight_per_gpu": F,
+                       "phase_stage": ("asynchronous (lcr_ctx_set_async_phase: lcr_phase returns with its kernels in flight, the next step's pileup is queued "
+                                       "behind its restarts and runs beside its resolve / post-phase tails; results collected by the next lcr_candidates); "
+                                       "GPU_MAX_HW_QUEUES=%s" % os.environ.get("GPU_MAX_HW_QUEUES")) if async_phase else "synchronous",
                        "scaling_reference": ("the N = 1 point of THIS workload (one GPU's 1 000-gene share of C4) is `stages.c4_share.sites_per_sec` of the "
                                              "N = 1 line; the N = 1 headline `value` is C3, a different workload") if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": "pileup stage = k0_ops + k1_tiles_a/b + k0_desc_bin + k1_pileup + k1_empty_tiles (+ k1_zonefix on HiFi presets): what replaces fill_data_into_freq_vec",
@@ -821,6 +841,10 @@ def main():
                          "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / 8000.0,
                          "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic if traffic else traffic_note,
                          "algorithmic_bytes": stage_bytes, "avg_ms": stage_ms,
+                         "isolated": ({"avg_ms": iso_ms, "frac": stage_bytes / (iso_ms * 1e-3) / 8e12,
+                                       "note": "the same kernels in synchronous steps (nothing of the previous step beside them): in the timed steps the stage "
+                                               "runs beside the previous step's resolve / post-phase kernels (asynchronous phase stage), which costs it ~10 % and buys the step ~12 %"}
+                                      if iso_ms else None),
                          "note": "algorithmic bytes B + 4C + 37R + 53L (bases once, CIGAR, read headers, ref byte + 13 u32 planes per column); "
                                  "HIP events on the ctx stream, rank 0, mean over the timed steps",
                          "k0_ops": {"avg_ms": avg_k0_ms, "algorithmic_bytes": 4 * int(batch.cigar.size) + 64 * batch.n_reads + 8 * n_items,

@@ -344,6 +344,19 @@ int lcr_bam_write_phased(lcr_bam*, const char* out_path, int32_t n_regions, cons
  * "r<index>", mapq 60, flag 0 / 16, `ts:A:+` / `-` from lcr_reads.flags; BGZF at `level`, deflated on n_threads threads. */
 int lcr_bam_write_reads(const char* out_path, const char* contig, int64_t contig_len, const lcr_reads* rd, int32_t level, int32_t n_threads);
 
+/* Asynchronous phase stage (round 5; off by default).  on = 1: lcr_phase returns as soon as its kernels are queued -- on queues of the
+ * stage's own, behind the fragment stage's kernels -- and its results are collected by whoever asks for them first: every getter
+ * (lcr_get_candidates*, lcr_get_phase_result, lcr_get_read_records_device, lcr_get_tie_census, lcr_get_ld_blocks), lcr_ctx_sync, the
+ * next lcr_candidates / lcr_phase.  The caller's loop (thread.rs:93-201 per region; here per batch) can then bind the next
+ * device-resident batch and queue its pileup at once: lcr_pileup's kernels are held back until the dense part of the stage in flight
+ * -- the enumeration restarts -- is done, and run beside its resolve / post-phase tails, which leave most CUs idle.
+ * CONTRACT CHANGE while it is on: the input arrays of a device-resident batch must stay unchanged until that batch's results have
+ * been collected (a getter or lcr_ctx_sync) -- with the synchronous stage they are free when lcr_phase returns.  A host batch
+ * (lcr_load_batch with LCR_MEM_HOST, lcr_load_batch_async) waits for the stage in flight by itself.  Persistent all-CU launches,
+ * the host epilogue and phase_prof make lcr_phase wait as before.  The stage then uses four queues: the process should run with
+ * GPU_MAX_HW_QUEUES >= 8 in its environment (ROCm's default of 4 maps two of them onto one hardware queue). */
+int lcr_ctx_set_async_phase(lcr_ctx*, int on);
+
 /* Regions whose phase matrix is far beyond one CU are phased by persistent all-CU kernels; two such launches on one GPU --
  * of two contexts or two processes -- must not overlap, so they are serialised per device by a process-local mutex and an
  * flock on <dir>/grid_<pci bus id>.lock.  dir defaults to /tmp/liblcr-locks when that directory is this user's or root's (and sticky

@@ -10,7 +10,7 @@ SO_PATH = os.environ.get("LCR_LIB") or os.path.join(_HERE, "liblcr.so")   # LCR_
 # every symbol include/lcr.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "lcr_params_preset", "lcr_ctx_create", "lcr_ctx_destroy", "lcr_last_error", "lcr_ctx_set_stream",
-    "lcr_ctx_sync", "lcr_ctx_set_lock_dir", "lcr_debug_set", "lcr_load_batch", "lcr_load_batch_async", "lcr_bind_batch",
+    "lcr_ctx_sync", "lcr_ctx_set_lock_dir", "lcr_ctx_set_async_phase", "lcr_debug_set", "lcr_load_batch", "lcr_load_batch_async", "lcr_bind_batch",
     "lcr_host_alloc", "lcr_host_free", "lcr_host_register", "lcr_host_unregister", "lcr_pileup", "lcr_get_columns", "lcr_candidates",
     "lcr_get_candidates", "lcr_get_candidates_device", "lcr_fragments", "lcr_get_fragmat", "lcr_phase", "lcr_get_phase_result", "lcr_get_read_records_device", "lcr_get_ld_blocks", "lcr_get_tie_census",
     "lcr_enable_timing", "lcr_kernel_ms", "lcr_pileup_bytes", "lcr_pileup_stage_bytes", "lcr_discover_regions", "lcr_version",
@@ -51,6 +51,7 @@ def load():
     l.lcr_ctx_set_stream.argtypes = [vp, vp]
     l.lcr_ctx_sync.argtypes = [vp]
     l.lcr_ctx_set_lock_dir.argtypes = [vp, C.c_char_p]
+    l.lcr_ctx_set_async_phase.argtypes = [vp, C.c_int32]
     l.lcr_debug_set.argtypes = [vp, C.c_char_p, C.c_int64]
     l.lcr_load_batch.argtypes = [vp, C.POINTER(_abi.LcrReads), C.POINTER(_abi.LcrRegions)]
     l.lcr_load_batch_async.argtypes = [vp, C.POINTER(_abi.LcrReads), C.POINTER(_abi.LcrRegions), C.c_int32]

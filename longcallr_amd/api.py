@@ -73,6 +73,11 @@ class Engine:
     def sync(self):
         self._chk(self.lib.lcr_ctx_sync(self.h), "lcr_ctx_sync")
 
+    def set_async_phase(self, on=True):
+        """lcr_ctx_set_async_phase: phase() returns with its kernels in flight; getters / sync() collect the results (include/lcr.h)"""
+        self._chk(self.lib.lcr_ctx_set_async_phase(self.h, 1 if on else 0), "lcr_ctx_set_async_phase")
+        return self
+
     # ---- batch binding -------------------------------------------------------------------------
     def load_batch(self, batch):
         """batch: _abi.ReadBatch (host numpy) or a (LcrReads, LcrRegions, keepalive) device triple."""

@@ -450,7 +450,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
   // queue: 2.19 -> 2.12 ms per step, and the pileup kernels' own durations (the roofline's measurement) grow by half.
   const bool async_mode = dbg.async_phase != 0;
   if (async_mode && !main_q) PCHK(hipStreamCreateWithFlags(&main_q, hipStreamNonBlocking));
-  if (!ev_user) PCHK(hipEventCreateWithFlags(&ev_user, hipEventDisableTiming));
+  if (!ev_user) { PCHK(hipEventCreateWithFlags(&ev_user, hipEventDisableTiming)); PCHK(hipEventCreateWithFlags(&ev_gate[0], hipEventDisableTiming)); PCHK(hipEventCreateWithFlags(&ev_gate[1], hipEventDisableTiming)); }
+  gate_set[0] = gate_set[1] = false;
   hipStream_t const stream = async_mode ? main_q : user_stream;
   if (async_mode) {
     PCHK(hipEventRecord(ev_user, user_stream));
@@ -888,6 +889,11 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       unsigned long long* const d_st = d_enum_st.as<unsigned long long>();
       if (cnt[2]) launch_k4_enum_reg(32, (unsigned)cnt[2], lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, d_sb, d_st, d_rbest, redo_a, REDO_CAP);
       if (cnt[3]) launch_k4_enum_reg(0, (unsigned)cnt[3], lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, d_sb, d_st, d_rbest, redo_b, REDO_CAP);
+      if (!win && async_mode) {   // (the dense part of the stage ends here on both queues: the next batch's pileup waits for these)
+        if (cnt[1] || cnt[2]) { if ((e = hipEventRecord(ev_gate[0], stream)) != hipSuccess) return e; gate_set[0] = true; }
+        if (fork && cnt[3]) { if ((e = hipEventRecord(ev_gate[1], s34)) != hipSuccess) return e; gate_set[1] = true; }
+        else if (!fork && cnt[3]) { if ((e = hipEventRecord(ev_gate[0], stream)) != hipSuccess) return e; gate_set[0] = true; }
+      }
       if (!win) {
         if (cnt[2]) launch_redo(redo_a, 0, stream);
         if (cnt[1] && cnt[2]) launch_k4_enum_resolve((unsigned)n_w[1], res_lds[1], s1, P, d_sp + s_off[1], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());

@@ -460,6 +460,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   c->dp = to_dev(p, c->sor_thr);
   c->dp.dbg = 0;
   HIPCHK(c, c->planes.reserve(std::max<size_t>((size_t)c->n_cols * LCR_NPLANES, 1) * 4));
+  HIPCHK(c, c->phase.gate_stream(c->stream));   // (async_phase: behind the restarts of a phase stage still in flight, beside its tails)
   BatchView& b = c->bv;
   const int nt = c->n_tiles;
   // ---- K0: decode every CIGAR once into per-tile records (one op-parallel pass; a block's records lie back to back in the
@@ -956,6 +957,14 @@ int lcr_get_read_records_device(lcr_ctx* c, const lcr_read_record** dev_rec, int
   }
   *dev_rec = c->phase.d_read_rec.as<lcr_read_record>();
   *n_rows = c->n_rows;
+  return LCR_OK;
+}
+
+int lcr_ctx_set_async_phase(lcr_ctx* c, int on) {
+  if (!c) return LCR_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  { int rc = phase_settle(c); if (rc) return rc; }
+  c->phase.dbg.async_phase = on != 0;
   return LCR_OK;
 }
 

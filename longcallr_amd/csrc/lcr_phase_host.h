@@ -152,6 +152,17 @@ struct PhaseHost {
   // settle(): every getter, lcr_ctx_sync, the next lcr_candidates / lcr_phase call it.  Persistent all-CU launches (device
   // lock), the host epilogue and phase_prof settle before run() returns.  Default: the caller's stream, settle() inside run().
   hipStream_t main_q = nullptr, q_first = nullptr;   // q_first: the queue the last run() used as its first
+  // async_phase: the next batch's pileup is gated on these -- recorded behind the enumeration restarts on the stage's first queue and
+  // on `aux`: the dense part of the stage.  What follows them (repair pass, resolve, post-phase: a few hundred workgroups) leaves
+  // most CUs idle, and that is where the next pileup's kernels run -- beside the restarts they would only time-share the VALUs.
+  hipEvent_t ev_gate[2] = {nullptr, nullptr};
+  bool gate_set[2] = {false, false};
+  // makes `s` wait for the dense part of a stage in flight (no-op otherwise)
+  hipError_t gate_stream(hipStream_t s) {
+    if (!pending) return hipSuccess;
+    for (int k = 0; k < 2; k++) if (gate_set[k]) { hipError_t e = hipStreamWaitEvent(s, ev_gate[k], 0); if (e != hipSuccess) return e; }
+    return hipSuccess;
+  }
   hipEvent_t ev_user = nullptr;
   bool pending = false;
   struct Pending {
@@ -185,6 +196,7 @@ struct PhaseHost {
     if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
     if (main_q) { (void)hipStreamDestroy(main_q); main_q = nullptr; }
     if (ev_user) { (void)hipEventDestroy(ev_user); ev_user = nullptr; }
+    for (int k = 0; k < 2; k++) { if (ev_gate[k]) (void)hipEventDestroy(ev_gate[k]); ev_gate[k] = nullptr; gate_set[k] = false; }
     pending = false;
     delete helper_thread; helper_thread = nullptr;
     delete pool; pool = nullptr;

@@ -1457,8 +1457,9 @@ def test_bench_under_the_launcher_with_one_rank():
 
 
 def test_asynchronous_phase_stage(engine_cls):
-    """lcr_debug_set("async_phase", 1): lcr_phase returns with its kernels in flight on the stage's own queues; the next batch is
-    bound and its pileup queued beside them, every getter / the next lcr_candidates collects the results first.  Three batches
+    """lcr_ctx_set_async_phase(ctx, 1): lcr_phase returns with its kernels in flight on the stage's own queues; the next batch is
+    bound and its pileup queued behind the stage's restarts (beside its tails), every getter / the next lcr_candidates collects the
+    results first.  Three batches
     back to back (no getter in between), then getters in every order == the synchronous engine, byte for byte."""
     p = _abi.make_params("ont-cdna", seed=77)
     bs = [synth.make_batch("ont-cdna", n_genes=n, gene_len=10000, depth=35, seed=60 + k) for k, n in enumerate((5, 3, 6))]
@@ -1467,7 +1468,7 @@ def test_asynchronous_phase_stage(engine_cls):
     import bench as _bench
     dv = [_bench.to_device(b, torch, dev) for b in bs]   # device-resident inputs: the next bind does not wait for the phase stage
     Es, Ea = engine_cls(0, p), engine_cls(0, p)
-    Ea.debug_set("async_phase", 1)
+    Ea.set_async_phase(True)
     want = []
     for d in dv:
         Es.load_batch(d).run_all()
