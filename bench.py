@@ -137,10 +137,14 @@ def run_steps_simple(E, dev_batch, n):
     E.sync()
 
 
+ASYNC_PHASE = [True]   # (--sync-phase clears it: the workloads beside the headline one run the way the headline steps do)
+
+
 def time_workload(api, _abi, torch, device, params, batch, steps=20, warm=5):
     """ms per step, pileup-stage time and roofline fraction, per-call wall times of one more pass: a workload beside the headline one"""
     dv = to_device(batch, torch, torch.device("cuda", device))
     E = api.Engine(device, params, timing=(_abi.K_SPANS, _abi.K_PILEUP))   # (events around the pileup stage only: every timer is two records on the stream)
+    E.set_async_phase(ASYNC_PHASE[0])
     run_steps_simple(E, dv, warm)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -151,6 +155,7 @@ def time_workload(api, _abi, torch, device, params, batch, steps=20, warm=5):
         pile.append(E.kernel_ms(_abi.K_SPANS) + E.kernel_ms(_abi.K_PILEUP))
     E.sync()
     dt = (time.perf_counter() - t0) / steps
+    E.set_async_phase(False)
     ms = {}
     for name, fn in (("lcr_load_batch", lambda: E.load_batch(dv)), ("lcr_pileup", E.fill_data_into_freq_vec),
                      ("lcr_candidates", E.get_candidate_snps), ("lcr_fragments", E.get_fragments), ("lcr_phase", E.phase)):
@@ -626,6 +631,7 @@ def main():
     engines = [api.Engine(local, params, timing=(_abi.K_SPANS, _abi.K_PILEUP)) for _ in range(F)]
     E = engines[0]
     # asynchronous phase stage: one context, one rank (at N > 1 every step hands its records to the gather, which collects them first)
+    ASYNC_PHASE[0] = not a.sync_phase
     async_phase = not a.sync_phase and dist is None and F == 1
     if async_phase:
         E.set_async_phase(True)
