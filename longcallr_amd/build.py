@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "liblcr.so")
 SOURCES = ["k0_ops.hip", "k1_pileup.hip", "k2_candidates.hip", "k3_fragments.hip", "k4_phase.hip", "k4_enum.hip", "k4_stage.hip", "k4_post.hip", "k4_grid.hip", "k5_regions.hip", "lcr_api.hip",
            "lcr_bam.cpp"]   # lcr_bam.cpp: host-only BGZF / BAM decode (zlib)
-HEADERS = ["lcr_dev.h", "lcr_phase_host.h", "k4_dev.h", "k4_types.h", "k4_grid.h", "k4_kernels.h", "k4_post.h", os.path.join("..", "..", "include", "lcr.h")]
+HEADERS = ["lcr_dev.h", "lcr_phase_host.h", "k4_dev.h", "k4_types.h", "k4_grid.h", "k4_grid_batch.h", "k4_kernels.h", "k4_post.h", os.path.join("..", "..", "include", "lcr.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function"]
 

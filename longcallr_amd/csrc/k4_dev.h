@@ -30,19 +30,23 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 // (cal_sigma_delta_eta_log, phase.rs:77-96: the three running sums over the row's entries in list order, q = 1 - log_q1 /
 // (log_q2 + log_q3); flip iff q < qn, phase.rs:845-858).  le / l1e = the host's libm values of log10(eps_q), log10(1 - eps_q).
 // *het: the row has an entry at a het site (a row without one scores the same for both signs, term by term: no census entry).
-__device__ __forceinline__ bool tie_row_flips(const int32_t* rp, const int32_t* pc, const uint8_t* pv, int row, const int8_t* dl, const int8_t* et,
-                                              int sigma, const double* le, const double* l1e, bool* het) {
+// (get(i, &d, &eta): delta / eta of SNP i in the state the row is scored against -- byte arrays, or the bit masks of the batched rounds)
+template <class Get>
+__device__ __forceinline__ bool tie_row_flips_g(const int32_t* rp, const int32_t* pc, const uint8_t* pv, int row, Get get,
+                                                int sigma, const double* le, const double* l1e, bool* het) {
   double lp = 0.0, lm = 0.0;   // log_q2 (sigma = +1), log_q3 (sigma = -1)
   bool h = false;
   if (rp[row + 1] - rp[row] <= 2) {   // two entries: a tie means a + b against b + a -- the same double; nothing to decide
-    for (int e = rp[row]; e < rp[row + 1]; e++) h |= et[pc[e]] == 0;
+    for (int e = rp[row]; e < rp[row + 1]; e++) { int d, eta; get(pc[e], d, eta); h |= eta == 0; }
     *het = h;
     return false;
   }
   for (int e = rp[row]; e < rp[row + 1]; e++) {
     const int i = pc[e];
     const uint8_t v = pv[e];
-    const int p = (v & 32) ? 1 : -1, q = v & 31, eta = et[i], d = dl[i];
+    int d, eta;
+    get(i, d, eta);
+    const int p = (v & 32) ? 1 : -1, q = v & 31;
     const int xp = eta == 0 ? d : eta, xm = eta == 0 ? -d : eta;   // x of aki for sigma = +1 / -1 (phase.rs:32-49)
     h |= eta == 0;
     lp += p == xp ? l1e[q] : le[q];
@@ -54,19 +58,28 @@ __device__ __forceinline__ bool tie_row_flips(const int32_t* rp, const int32_t* 
   const double q = 1.0 - l1 / den, qn = 1.0 - l1n / den;
   return q < qn;
 }
+__device__ __forceinline__ bool tie_row_flips(const int32_t* rp, const int32_t* pc, const uint8_t* pv, int row, const int8_t* dl, const int8_t* et,
+                                              int sigma, const double* le, const double* l1e, bool* het) {
+  return tie_row_flips_g(rp, pc, pv, row, [&](int i, int& d, int& eta) { d = dl[i]; eta = et[i]; }, sigma, le, l1e, het);
+}
 // census + decision of one tied row (all sigma-step forms): true = flip
-__device__ __forceinline__ bool tie_row_decide(const PhaseDev& P, const int32_t* rp, const int32_t* pc, const uint8_t* pv, int row, const int8_t* dl,
-                                               const int8_t* et, int sigma, const double* le, const double* l1e) {
+template <class Get>
+__device__ __forceinline__ bool tie_row_decide_g(const PhaseDev& P, const int32_t* rp, const int32_t* pc, const uint8_t* pv, int row, Get get,
+                                                 int sigma, const double* le, const double* l1e) {
   bool het;
   if (P.tie_arith < 2) {
     het = false;
-    for (int e = rp[row]; e < rp[row + 1]; e++) het |= et[pc[e]] == 0;
+    for (int e = rp[row]; e < rp[row + 1]; e++) { int d, eta; get(pc[e], d, eta); het |= eta == 0; }
     if (het) TIE_COUNT(P.tie_ctr, TIE_SIGMA_UNRES, 1ull);
     return false;
   }
-  const bool f = tie_row_flips(rp, pc, pv, row, dl, et, sigma, le, l1e, &het);
+  const bool f = tie_row_flips_g(rp, pc, pv, row, get, sigma, le, l1e, &het);
   if (het) { TIE_COUNT(P.tie_ctr, TIE_SIGMA_F64, 1ull); if (f) TIE_COUNT(P.tie_ctr, TIE_SIGMA_FLIPS, 1ull); }
   return f;
+}
+__device__ __forceinline__ bool tie_row_decide(const PhaseDev& P, const int32_t* rp, const int32_t* pc, const uint8_t* pv, int row, const int8_t* dl,
+                                               const int8_t* et, int sigma, const double* le, const double* l1e) {
+  return tie_row_decide_g(P, rp, pc, pv, row, [&](int i, int& d, int& eta) { d = dl[i]; eta = et[i]; }, sigma, le, l1e);
 }
 
 // one cross_optimize (phase.rs:810-976); returns the exact objective (phase.rs:257-276) to all threads.

@@ -9,6 +9,10 @@ hipError_t k4_chain_launch_grid(const ChainDev& C, int which, size_t dyn_lds, hi
 // dynamic LDS the device-coherent perturbation rounds may use (sigma bit vector + delta / eta / het-delta bytes of the region)
 constexpr int K4_GRID_FAST_LDS_MAX = 96 * 1024;
 inline size_t k4_grid_fast_lds(int64_t R, int64_t S) { return (size_t)(8 * ((R + 63) / 64) + 3 * S + 64); }
+// the batched rounds (k4_grid_batch.h): spread masks of every SNP + team slots + set-up histogram
+constexpr int K4_GRID_BATCH_MAX_WG = 512;
+constexpr int K4_GRID_BATCH_CTL_BYTES = 128 + 2048 + 128 + K4_GRID_BATCH_MAX_WG * 128;
+inline size_t k4_grid_batch_lds(int64_t S) { return (size_t)(8 * (S + 2) + 8 * 1024); }
 // workgroups of a grid launch (co-resident by construction); 0 = no device
 int k4_grid_blocks();
 // k4_stage for one large region with all CUs; blk_tot: 2 * k4_grid_blocks() + 1 int32 of scratch

@@ -986,6 +986,8 @@ __device__ __forceinline__ bool chain_rounds_fast(GridScope& sc, const ChainDev&
   return true;
 }
 
+#include "k4_grid_batch.h"
+
 __device__ __forceinline__ void load_flip_lut(const ChainDev& C, FlipLut* L) {
   if (threadIdx.x < 32) { L->le[threadIdx.x] = threadIdx.x < 31 ? C.le[threadIdx.x] : 0.0; L->l1e[threadIdx.x] = threadIdx.x < 31 ? C.l1e[threadIdx.x] : 0.0; }
   if (threadIdx.x == 0) { L->p_homref = C.p_homref; L->p_homvar = C.p_homvar; L->log_theta = C.log_theta; L->log2 = C.log2; }
@@ -1073,7 +1075,10 @@ __global__ void __launch_bounds__(CH_THREADS) k4_chain_grid(ChainDev C, int32_t 
   };
   extern __shared__ __attribute__((aligned(16))) uint8_t dyn_fast[];
   auto fast_rounds = [&](long long best) -> bool {
-    if (!d.fast_lds || !C.pk_csr || (int64_t)v.mv.cp[rd.S] > C.pk_cap || rd.S >= (1 << 18)) return false;
+    if (!C.pk_csr || (int64_t)v.mv.cp[rd.S] > C.pk_cap || rd.S >= (1 << 18) - 1 || rd.R >= (1 << 24)) return false;
+    if (d.batch_lds && C.spec_batch && C.bt_pk4 && (int)gridDim.x <= K4_GRID_BATCH_MAX_WG)
+      return chain_rounds_batch(sc, C, rd, v, wl, dyn_fast, best, d.slot, L);
+    if (!d.fast_lds) return false;
     return chain_rounds_fast(sc, C, rd, v, wl, dyn_fast, best, d.slot, L);
   };
   chain_run(sc, C, rd, v, wl, L, stage, sm, cross, fast_rounds, d.slot);
@@ -1298,6 +1303,7 @@ hipError_t k4_chain_launch_grid(const ChainDev& C, int which, size_t dyn_lds, hi
   hipError_t e = hipMemsetAsync(C.ctl, 0, sizeof(GridCtl), s);
   if (e != hipSuccess) return e;
   if (C.spec_lanes > 1) { e = hipMemsetAsync(C.spec_ctl, 0, sizeof(GridCtl) * (size_t)C.spec_lanes, s); if (e != hipSuccess) return e; }
+  if (C.bt_ctl) { e = hipMemsetAsync(C.bt_ctl, 0, K4_GRID_BATCH_CTL_BYTES, s); if (e != hipSuccess) return e; }
   e = k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_chain_grid), K4_GRID_FAST_LDS_MAX, 2);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k4_chain_grid, dim3((unsigned)nb), dim3(CH_THREADS), dyn_lds, s, C, (int32_t)which);

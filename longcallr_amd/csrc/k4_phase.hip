@@ -622,6 +622,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     // others run side by side, one workgroup each.  LCR_GRID_MIN_ENTRIES moves the boundary (tests: 0 = every region).
     std::vector<int32_t> wide, big;
     const bool grid_generic = dbg.grid_generic != 0;   // test hook
+    bool w_fits_limbs = true;   // (the batched rounds split w into a 23-bit and a signed limb; w < 0 for q < 4)
+    for (int q = 0; q < 31; q++) w_fits_limbs = w_fits_limbs && std::llabs(P.lut.f1e[q] - P.lut.fe[q]) < (1ll << 45);
     for (int g : chain_slots) ((int64_t)stat[g].E >= grid_min ? big : wide).push_back(g);
     // longest first: a batch with more chain regions than CUs runs them in two generations (one sixteen-wave workgroup
     // per CU), and the workgroups are started in launch order -- the second generation should be the short regions
@@ -641,7 +643,11 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
       ChainDesc& d = desc[k];
       d.slot = g; d.W = std::max(1, std::min(stat[g].W, S)); d.fast_lds = 0;
-      if (k >= n_small && !grid_generic) { const size_t need = k4_grid_fast_lds(stat[g].R, S); if (need <= (size_t)K4_GRID_FAST_LDS_MAX) d.fast_lds = (int32_t)need; }
+      d.batch_lds = 0; d.pad_ = 0;
+      if (k >= n_small && !grid_generic) {
+        const size_t need = k4_grid_fast_lds(stat[g].R, S); if (need <= (size_t)K4_GRID_FAST_LDS_MAX) d.fast_lds = (int32_t)need;
+        const size_t need_b = k4_grid_batch_lds(S); if (dbg.spec_batch && w_fits_limbs && need_b <= (size_t)K4_GRID_FAST_LDS_MAX) d.batch_lds = (int32_t)need_b;
+      }
       d.tbl_off = tbl_cells; tbl_cells += (int64_t)S * d.W;
       d.adj_off = adj_n; adj_n += 2 * (int64_t)S * d.W;
       d.n_parts = k < n_small ? 16 : (int32_t)std::max<int64_t>(16, std::min<int64_t>(grid_waves, (int64_t)(1 << 23) / S));
@@ -670,8 +676,25 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       PCHK(d_spec_sig.reserve(lanes * ng_max * 8 + 64)); PCHK(d_spec_de.reserve(lanes * 2 * s8 + 64)); PCHK(d_spec_res.reserve(lanes * 8 + 64));
       C.spec_sig = d_spec_sig.as<unsigned long long>(); C.spec_de = d_spec_de.as<int8_t>(); C.spec_res = d_spec_res.as<long long>();
       C.spec_lanes = (int32_t)lanes; C.spec_ng = (int32_t)ng_max; C.spec_s8 = (int32_t)s8;
-      size_t e_max = 0;   // packed entries of the largest all-CU region with device-coherent rounds
-      for (int k = n_small; k < nc; k++) if (desc[k].fast_lds) e_max = std::max(e_max, (size_t)stat[desc[k].slot].E);
+      size_t e_max = 0, g4_max = 0, r_max = 0, sb_max = 0;   // packed entries of the largest all-CU region with device-coherent rounds
+      for (int k = n_small; k < nc; k++) if (desc[k].fast_lds || desc[k].batch_lds) e_max = std::max(e_max, (size_t)stat[desc[k].slot].E);
+      for (int k = n_small; k < nc; k++) if (desc[k].batch_lds) {
+        const int g = desc[k].slot;
+        g4_max = std::max(g4_max, ((size_t)stat[g].E + 3 * (size_t)stat[g].R + 3) / 4); r_max = std::max(r_max, (size_t)stat[g].R);
+        sb_max = std::max(sb_max, (size_t)(in.cand_region_off[g + 1] - in.cand_region_off[g]));
+      }
+      if (g4_max) {   // batched rounds: groups | unit pointers | sigma bytes | SNP masks | barrier payload
+        auto al = [](size_t x) { return (x + 63) / 64 * 64; };
+        const size_t nb = r_max / 64 + 2;   // blocks of 64 sorted rows; the groups: every row padded to its block's longest (<= 64 (S / 4 + 1) more)
+        g4_max += 64 * (sb_max / 4 + 2) + 64;
+        const size_t o_up = (g4_max + 4) * 16, o_bs = o_up + al(nb * 8), o_pm = o_bs + al(nb * 8), o_iv = o_pm + al(r_max * 4 + 256), o_sig = o_iv + al(r_max * 4 + 256),
+                     o_m = o_sig + al(r_max + 64), o_ctl = o_m + al((sb_max + 2) * 4);
+        PCHK(d_bt.reserve(o_ctl + K4_GRID_BATCH_CTL_BYTES + 64));
+        uint8_t* bp = d_bt.as<uint8_t>();
+        C.bt_pk4 = (uint32_t*)bp; C.bt_up4 = (int32_t*)(bp + o_up); C.bt_bs32 = (uint32_t*)(bp + o_bs); C.bt_perm = (int32_t*)(bp + o_pm); C.bt_inv = (int32_t*)(bp + o_iv);
+        C.bt_sig8 = bp + o_sig; C.bt_m32 = (uint32_t*)(bp + o_m); C.bt_ctl = bp + o_ctl;
+        C.bt_cap4 = (int64_t)g4_max; C.spec_batch = 1;
+      }
       C.pk_cap = (int64_t)e_max;
       if (e_max) { PCHK(d_pk.reserve(2 * (e_max + 8) * 4 + 64)); C.pk_csr = d_pk.as<uint32_t>(); C.pk_csc = C.pk_csr + (e_max + 8); }
     }
@@ -715,7 +738,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     };
     PCHK(launch_class(wide, 0, max_state, 64 * 1024));
     if (n_big) GRID_LOCK();
-    for (int k = 0; k < n_big; k++) PCHK(k4_chain_launch_grid(C, n_small + k, (size_t)desc[n_small + k].fast_lds, side));
+    for (int k = 0; k < n_big; k++) PCHK(k4_chain_launch_grid(C, n_small + k, (size_t)std::max(desc[n_small + k].fast_lds, desc[n_small + k].batch_lds), side));
     PostIn pinc = pin;
     pinc.st_sigma = Pc.st_sigma; pinc.st_delta = Pc.st_delta; pinc.st_eta = Pc.st_eta; pinc.st_obj = Pc.st_obj;
     if (nps) {
@@ -1013,7 +1036,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       }
     }
     fprintf(stderr, "[phase]     grid chain: %lld iterations in the rounds\n", clk[15]);
-    static const char* nm2[] = {"stage delta/eta", "sigma step (workgroup 0)", "barrier 1", "stage sigma", "delta step (workgroup 0)", "barrier 2"};
+    if (chain_desc.back().batch_lds && clk[14]) fprintf(stderr, "[phase]     grid chain rounds (batched): %lld groups of four het-site entries incl. padding (%d rows, %d entries)\n", clk[14], stat[chain_desc.back().slot].R, stat[chain_desc.back().slot].E);
+    static const char* nm2[] = {"stage delta/eta", "sigma step (workgroup 0)", "barrier 1", "stage sigma / invalidate", "delta step (workgroup 0)", "barrier 2"};
     for (int k = 0; k < 6; k++) fprintf(stderr, "[phase]     grid chain rounds: %-26s %9.1f us per iteration\n", nm2[k], (double)clk[8 + k] / 100.0 / (double)std::max<long long>(clk[15], 1));
   }
   { const int rc = settle(err); if (rc) return rc; }

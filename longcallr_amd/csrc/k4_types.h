@@ -67,6 +67,8 @@ struct ChainDesc {
   int64_t part_off;    // per (row part, SNP) counters of the ordered column index, offset in int32
   int32_t n_parts;
   int32_t fast_lds;    // grid scope: bytes of dynamic LDS for the device-coherent perturbation rounds (0: generic path)
+  int32_t batch_lds;   // grid scope: bytes of dynamic LDS for the batched rounds (k4_grid_batch.h; 0: not for this region)
+  int32_t pad_;
 };
 struct GridCtl { unsigned arrive, gen, flag[2]; unsigned long long acc[2]; int slot; unsigned pad_[7]; };   // grid barrier + reductions
 struct ChainDev {
@@ -95,6 +97,10 @@ struct ChainDev {
   // the region's phase entries as one dword each -- value byte << 24 | SNP (row order) / value byte << 24 | row (column order) --
   // so that the rounds read four entries per 16-byte load; pk_cap entries each (+ 8 of padding), filled when the rounds begin
   uint32_t* pk_csr; uint32_t* pk_csc; int64_t pk_cap;
+  // batched rounds (k4_grid_batch.h): groups of four entries of one row (bt_cap4 groups), {first group, rounds} and best sigma bits of every block
+  // of 64 sorted rows, the sort's permutation and its inverse, sigma bits of the eight states per row, delta / eta bit masks per SNP,
+  // barrier payload and counters (K4_GRID_BATCH_CTL_BYTES, zeroed by the launcher)
+  uint32_t* bt_pk4; int32_t* bt_up4; uint32_t* bt_bs32; int32_t* bt_perm; int32_t* bt_inv; uint8_t* bt_sig8; uint32_t* bt_m32; void* bt_ctl; int64_t bt_cap4; int32_t spec_batch;
   long long* dbg;                 // LCR_PHASE_PROF: 100 MHz timestamps of the chain steps of a grid launch, 16 per launch (else nullptr)
   double le[31], l1e[31], p_homref, p_homvar, log_theta, log2;   // libm values of the block-flip sums (host table)
 };

@@ -120,6 +120,7 @@ struct PhaseDebug {
   int post_half = 0;            // "post_half": the eight-wave epilogue of the chain regions
   int enum_force_big = 0;       // "enum_force_big" / "enum_force_stream": the fallback enumeration kernels
   int enum_force_stream = 0;    // (2: the large-image launch of the streaming kernel)
+  int spec_batch = 1;           // "grid_spec_batch": eight speculative half-rounds per pass over the matrix (k4_grid_batch.h); 0: the side-by-side lanes below
   int spec_lanes = 8;           // "grid_spec_lanes": half-rounds of the perturbation loop run at once at grid scope (1: one after the other; C5 with packed entries: 454 / 370 / 348 / 366 ms with 2 / 4 / 8 / 16 -- eight lanes = one XCD each)
   int tie_arith = 3;            // "tie_arith": which exact fixed-point ties the reference-order f64 arithmetic decides (PhaseDev::tie_arith; 3 = all that liblcr resolves)
   int host_threads = 0;         // "host_threads": size of the host pool of the host epilogue (0: hardware threads / devices, <= 48)
@@ -137,7 +138,7 @@ struct PhaseHost {
   const uint8_t* r_assignment = nullptr;
   const uint32_t* r_phase_set = nullptr;
   DevBuf d_state[40];
-  DevBuf d_spec_sig, d_spec_de, d_spec_res, d_pk;   // working states / results of the speculative half-rounds (k4_grid.hip)
+  DevBuf d_spec_sig, d_spec_de, d_spec_res, d_pk, d_bt;   // working states / results of the speculative half-rounds (k4_grid.hip)
   DevBuf d_read_rec;             // per-row results as 12-byte records in HBM, written by k4_post
   DevBuf d_lut64, d_tie, d_enum_st;   // f64 table of the tie paths (PostLut), census counters, final states of the enumeration restarts
   bool lut64_ready = false;
@@ -186,7 +187,7 @@ struct PhaseHost {
   void release() {
     for (auto& b : d_state) b.release();
     d_lut64.release(); d_tie.release(); d_enum_st.release(); lut64_ready = false;
-    d_read_rec.release(); d_spec_sig.release(); d_spec_de.release(); d_spec_res.release(); d_pk.release();
+    d_read_rec.release(); d_spec_sig.release(); d_spec_de.release(); d_spec_res.release(); d_pk.release(); d_bt.release();
     for (auto& b : h_pin) b.release();
     if (side) { (void)hipStreamDestroy(side); side = nullptr; }
     if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }

@@ -1306,8 +1306,8 @@ def test_c5_island_against_the_oracle(engine_cls, orc):
 
 
 def test_c5_scopes_and_paths_agree(engine_cls, monkeypatch):
-    """One island (200 kb x 150x) through the forms of the chain kernel -- all CUs with device-coherent rounds run four
-    half-rounds at a time speculatively (default at this size), the same with 1 / 8 / 16 lanes, all CUs with fenced
+    """One island (200 kb x 150x) through the forms of the chain kernel -- all CUs with eight speculative half-rounds per pass
+    over the matrix (default), with the half-rounds side by side on sub-grids (8, 1, 4, 16 lanes), all CUs with fenced
     barriers only (LCR_GRID_GENERIC), one workgroup -- and through the host epilogue: identical bytes."""
     b = synth.make_island("ont-drna-c5", n_loci=8, locus_len=25000, depth=150, seed=4)
     p = _abi.make_params("ont-drna", seed=12)
@@ -1319,11 +1319,14 @@ def test_c5_scopes_and_paths_agree(engine_cls, monkeypatch):
         r = _result_bytes(E) + (repr(E.ld_blocks(0)),)
         E.close()
         return r
-    ref = run()      # (default: eight speculative half-rounds at a time, each on an eighth of the workgroups -- one XCD)
+    ref = run()      # (default: eight speculative half-rounds per pass over the matrix, k4_grid_batch.h)
+    monkeypatch.setenv("LCR_GRID_SPEC_BATCH", "0")   # the half-rounds side by side, each on an eighth of the workgroups -- one XCD
+    assert run() == ref, "speculative rounds side by side"
     for lanes in ("1", "4", "16"):   # one half-round after the other; other batch widths: same commits, same bytes
         monkeypatch.setenv("LCR_GRID_SPEC_LANES", lanes)
         assert run() == ref, "speculative rounds with %s lanes" % lanes
     monkeypatch.delenv("LCR_GRID_SPEC_LANES")
+    monkeypatch.delenv("LCR_GRID_SPEC_BATCH")
     monkeypatch.setenv("LCR_GRID_GENERIC", "1")
     assert run() == ref
     monkeypatch.delenv("LCR_GRID_GENERIC")
