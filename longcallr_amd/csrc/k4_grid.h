@@ -12,7 +12,7 @@ inline size_t k4_grid_fast_lds(int64_t R, int64_t S) { return (size_t)(8 * ((R +
 // the batched rounds (k4_grid_batch.h): spread masks of every SNP + team slots + set-up histogram
 constexpr int K4_GRID_BATCH_MAX_WG = 512;
 constexpr int K4_GRID_BATCH_CTL_BYTES = 128 + 2048 + 128 + K4_GRID_BATCH_MAX_WG * 128;
-inline size_t k4_grid_batch_lds(int64_t S) { return (size_t)(8 * (S + 2) + 8 * 1024); }
+inline size_t k4_grid_batch_lds(int64_t S) { return (size_t)(12 * (S + 2) + 24 * 1024); }
 // workgroups of a grid launch (co-resident by construction); 0 = no device
 int k4_grid_blocks();
 // k4_stage for one large region with all CUs; blk_tot: 2 * k4_grid_blocks() + 1 int32 of scratch

@@ -20,7 +20,7 @@
 //              (Measured before: a wave per 32-row unit with lanes over the unit's groups and LDS atomics per group -- 28 us per
 //              step on C5 against 12 here: 290 instructions per group, a third of them the flush, and units of 2.1 passes.)
 //              Everything per row -- sigma bits, the column-order entries' row numbers -- is kept by sorted POSITION.
-// delta step   teams of four waves per SNP as in chain_rounds_fast; sigma comes from sig8 by a byte gather (333 KB on C5:
+// delta step   teams of BATCH_TW waves per SNP (chain_rounds_fast: four); sigma comes from sig8 by a byte gather (333 KB on C5:
 //              L2 resident), which is why the barrier in front of the step is followed by an L2 / L1 INVALIDATE (acquire
 //              fence at agent scope, one wave per workgroup) -- the only non-coherent read of mutable data in the rounds.
 //              Lanes 0-7 of the last wave of a team to arrive take the decisions of the eight states.
@@ -47,6 +47,11 @@ struct BatchCtl {                      // device words of the batched rounds (ze
   unsigned long long arr[K4_GRID_BATCH_MAX_WG][16];
 };
 static_assert(sizeof(BatchCtl) <= K4_GRID_BATCH_CTL_BYTES, "BatchCtl");
+
+struct BatchCol { int i, c0, c1, fp; long long F, Wt, D2, D3; };   // a team's column of one round of the delta step (LDS, set once)
+constexpr int BATCH_ROUNDS = 16;
+constexpr int BATCH_TW = 2;                          // waves of a team (one column at a time); teams of a workgroup:
+constexpr int BATCH_TEAMS = 16 / BATCH_TW;
 
 __device__ __forceinline__ uint32_t spread8(uint32_t x) {   // bit s -> bit 2 s
   x = (x | (x << 4)) & 0x0F0Fu; x = (x | (x << 2)) & 0x3333u; x = (x | (x << 1)) & 0x5555u;
@@ -153,21 +158,25 @@ __device__ __forceinline__ bool chain_rounds_batch(GridScope& sc, const ChainDev
   uint2* const s_m = reinterpret_cast<uint2*>(dyn);                                  // S + 1: spread masks of every SNP (+ the null SNP)
   uint2* const s_w = s_m + ((S + 2) & ~1);                                           // w = .x (low 23 bits) + 2^23 .y (signed)
   unsigned long long* const t_sum = reinterpret_cast<unsigned long long*>(s_w + 32); // [team][slot][state]
-  unsigned* const t_cnt = reinterpret_cast<unsigned*>(t_sum + 4 * 8 * 8);            // [team][slot]
-  unsigned long long* const s_acc = reinterpret_cast<unsigned long long*>(t_cnt + 32);
+  unsigned* const t_cnt = reinterpret_cast<unsigned*>(t_sum + BATCH_TEAMS * 8 * 8);  // [team][slot]
+  unsigned long long* const s_acc = reinterpret_cast<unsigned long long*>(t_cnt + BATCH_TEAMS * 8);
   unsigned long long* const s_out = s_acc + 8;
   unsigned* const s_misc = reinterpret_cast<unsigned*>(s_out + 8);                   // [0] changed bits of this workgroup, [1] of the grid, [2] next block, [3] tied (row, state) pairs
   unsigned* const s_hist = s_misc + 4;                                               // 256: set-up histogram; then the sigma step's list of tied (position | state << 24)
   constexpr unsigned TIE_CAP = 256;
+  BatchCol* const s_col = reinterpret_cast<BatchCol*>(s_hist + 256);                 // [team][round]
+  uint32_t* const s_raw = reinterpret_cast<uint32_t*>(s_col + BATCH_TEAMS * BATCH_ROUNDS);     // S: m32 as staged for the iteration
   if (threadIdx.x < 32) { const long long w = wl[threadIdx.x]; s_w[threadIdx.x] = make_uint2((uint32_t)(w & 0x7FFFFF), (uint32_t)(w >> 23)); }
-  for (int k = threadIdx.x; k < 4 * 8 * 8; k += blockDim.x) t_sum[k] = 0;
-  if (threadIdx.x < 32) t_cnt[threadIdx.x] = 0;
+  for (int k = threadIdx.x; k < BATCH_TEAMS * 8 * 8; k += blockDim.x) t_sum[k] = 0;
+  if (threadIdx.x < BATCH_TEAMS * 8) t_cnt[threadIdx.x] = 0;
   if (threadIdx.x < 8) s_acc[threadIdx.x] = 0;
   if (threadIdx.x < 4) s_misc[threadIdx.x] = 0;
   if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
   __syncthreads();
   // ---- the rows sorted by their number of groups (four het-site entries each), longest first
   const int n_blocks = (R + 63) >> 6;
+  const int n_rounds = (S + BATCH_TEAMS * (int)sc.nblk() - 1) / (BATCH_TEAMS * (int)sc.nblk());   // columns per team of the delta step
+  if (n_rounds > BATCH_ROUNDS) return false;
   {
     const int32_t* pc = v.mv.pc; const uint8_t* pv = v.mv.pv; const int32_t* cr = v.mv.cr; const uint8_t* cv = v.mv.cv;
     const int E = cp[S];
@@ -264,6 +273,19 @@ __device__ __forceinline__ bool chain_rounds_batch(GridScope& sc, const ChainDev
     if (lane == 0) cstore(&bs64[b], bb);
   }
   sc.sync();   // (fenced: everything above was written with plain stores)
+  // the columns of this workgroup's four teams, round by round (fixed for the whole launch), with their constants
+  for (int t = threadIdx.x; t < BATCH_TEAMS * BATCH_ROUNDS; t += blockDim.x) {
+    const int team = t / BATCH_ROUNDS, r = t % BATCH_ROUNDS, nteams = nblk * BATCH_TEAMS, gteam = team * nblk + blk;
+    const int pl = r * nteams + ((r & 1) ? nteams - 1 - gteam : gteam);
+    BatchCol c{-1, 0, 0, 0, 0, 0, 0, 0};
+    if (r < n_rounds && pl < S) {
+      const int i = ord[pl];
+      c.i = i; c.c0 = cp[i]; c.c1 = cp[i + 1]; c.fp = fp[i];
+      c.F = scn[4 * i]; c.Wt = scn[4 * i + 1]; c.D2 = scn[4 * i + 2]; c.D3 = scn[4 * i + 3];
+    }
+    s_col[t] = c;
+  }
+  __syncthreads();
   const uint64_t SF = (uint64_t)S + (uint64_t)R;
   const int H = 2 * (S / 4 + 1);
   unsigned bstamp = 0;   // barriers passed (the words are zero at the launch)
@@ -362,6 +384,7 @@ __device__ __forceinline__ bool chain_rounds_batch(GridScope& sc, const ChainDev
       if (threadIdx.x == 0) { s_misc[2] = 0; s_misc[3] = 0; }
       for (int i = threadIdx.x; i <= S; i += blockDim.x) {
         const uint32_t m = i < S ? cload(&m32[i]) : 0u;
+        if (i < S) s_raw[i] = m;
         s_m[i] = make_uint2(spread8(m & 0xFFu) | (spread8((m >> 8) & 0xFFu) << 16), spread8((m >> 16) & 0xFFu) | (spread8(m >> 24) << 16));
       }
       __syncthreads();
@@ -466,27 +489,29 @@ __device__ __forceinline__ bool chain_rounds_batch(GridScope& sc, const ChainDev
       const long long wg_t1 = C.dbg ? (long long)wall_clock64() : 0;
       long long acc = 0;   // lane s < 8: the objective terms of state s this wave decided
       {
-        const int team = threadIdx.x >> 8, wt = (threadIdx.x >> 6) & 3, nteams = nblk * 4, gteam = team * nblk + blk;
-        int it = 0, i_l = -1, c0_l = 0, c1_l = 0, fp_l = 0;
-        uint32_t m_l = 0;
-        long long F_l = 0, Wt_l = 0, D2_l = 0, D3_l = 0;
-        auto shfl_ll = [&](long long x, int k) -> long long {
-          return ((long long)__shfl((int)(x >> 32), k, 64) << 32) | (unsigned int)__shfl((int)x, k, 64);
+        const int team = wv / BATCH_TW, wt = wv % BATCH_TW;
+        constexpr int PASS = 256 * BATCH_TW;   // entries of a column a team takes per load
+        const BatchCol* const cols = s_col + team * BATCH_ROUNDS;
+        // a column's first 2 048 entries are requested while the column before it is worked on (the matrix comes from beyond
+        // L2 after the invalidate: one exposed trip per step instead of one per column)
+        uint4 ta_n = make_uint4(0, 0, 0, 0), tb_n = ta_n;
+        auto request = [&](int r) {
+          const BatchCol& c = cols[r];
+          const bool sw = c.i >= 0 && (s_raw[max(c.i, 0)] & 0xFFu) != 0;
+          const int ea = c.c0 + 4 * (64 * wt + lane), eb2 = ea + PASS;
+          ta_n = (sw && ea < c.c1) ? *reinterpret_cast<const uint4*>(pkc + ea) : make_uint4(0, 0, 0, 0);
+          tb_n = (sw && eb2 < c.c1) ? *reinterpret_cast<const uint4*>(pkc + eb2) : make_uint4(0, 0, 0, 0);
         };
-        for (int base = 0; base < S; base += nteams, it++) {
-          if ((it & 63) == 0) {
-            const int itl = it + lane, pl = itl * nteams + ((itl & 1) ? nteams - 1 - gteam : gteam);
-            i_l = ((int64_t)itl * nteams < S && pl < S) ? ord[pl] : -1;
-            c0_l = i_l >= 0 ? cp[i_l] : 0; c1_l = i_l >= 0 ? cp[i_l + 1] : 0;
-            if (i_l >= 0) { F_l = scn[4 * i_l]; Wt_l = scn[4 * i_l + 1]; D2_l = scn[4 * i_l + 2]; D3_l = scn[4 * i_l + 3]; fp_l = fp[i_l]; m_l = cload(&m32[i_l]); }
-          }
+        request(0);
+        for (int it = 0; it < n_rounds; it++) {
           if ((it & 7) == 0 && it) __syncthreads();   // the ring of 8 slots per team wraps (uniform trip count)
-          const int k = it & 63;
-          const int i = __shfl(i_l, k, 64);
-          const int c0 = __shfl(c0_l, k, 64), c1 = __shfl(c1_l, k, 64);
+          const BatchCol col = cols[it];
+          const uint4 ta = ta_n, tb = tb_n;
+          if (it + 1 < n_rounds) request(it + 1);
+          const int i = col.i, c0 = col.c0, c1 = col.c1;
           if (i < 0) continue;
           if (c0 == c1) continue;
-          const uint32_t m = (uint32_t)__shfl((int)m_l, k, 64);
+          const uint32_t m = s_raw[i];
           const uint32_t dneg8 = (m >> 8) & 0xFFu, ndz8 = ~(m >> 16) & 0xFFu;
           const bool sweep = (m & 0xFFu) != 0;   // a het site (in every state); a hom site's decision needs no column sum
           if (!sweep && wt) continue;            // (its team's first wave decides it)
@@ -521,24 +546,26 @@ __device__ __forceinline__ bool chain_rounds_batch(GridScope& sc, const ChainDev
             }
           };
           if (sweep) {
-            const int ea = c0 + 4 * (64 * wt + lane), eb2 = ea + 1024;
-            const uint4 ta = ea < c1 ? *reinterpret_cast<const uint4*>(pkc + ea) : make_uint4(0, 0, 0, 0);
-            const uint4 tb = eb2 < c1 ? *reinterpret_cast<const uint4*>(pkc + eb2) : make_uint4(0, 0, 0, 0);
+            const int ea = c0 + 4 * (64 * wt + lane), eb2 = ea + PASS;
             if (ea < c1) run4(ta, ea);
             if (eb2 < c1) run4(tb, eb2);
             int n = 0;   // (wave_reduce8 takes limb sums of up to 32 entries per lane: columns beyond 8 192 entries flush on the way)
-            for (int e = ea + 2048; e < c1; e += 1024) { run4(*reinterpret_cast<const uint4*>(pkc + e), e); if (++n == 6) { flush(); n = 0; } }
+            for (int eb = c0 + 2 * PASS; eb < c1; eb += PASS) {   // (wave-uniform trip count: flush() is a cross-lane step)
+              const int e = eb + 4 * (64 * wt + lane);
+              if (e < c1) run4(*reinterpret_cast<const uint4*>(pkc + e), e);
+              if (++n == 6) { flush(); n = 0; }
+            }
             flush();
           }
           long long M = 0;
-          const long long F = shfl_ll(F_l, k), Wt = shfl_ll(Wt_l, k), D2 = shfl_ll(D2_l, k), D3 = shfl_ll(D3_l, k);
-          const int fpi = __shfl(fp_l, k, 64);
-          unsigned arrived = 3;
+          const long long F = col.F, Wt = col.Wt, D2 = col.D2, D3 = col.D3;
+          const int fpi = col.fp;
+          unsigned arrived = BATCH_TW - 1;
           if (sweep) {
             if (lane == 0) arrived = __hip_atomic_fetch_add(tc, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
             arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
           }
-          if (arrived == 3) {
+          if (arrived == BATCH_TW - 1) {
             bool flipd = false, chg = false, to3 = false;
             if (lane < 8) {
               if (sweep) {

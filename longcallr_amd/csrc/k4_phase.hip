@@ -1036,6 +1036,13 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       }
     }
     fprintf(stderr, "[phase]     grid chain: %lld iterations in the rounds\n", clk[15]);
+    if (chain_desc.back().batch_lds && clk[14] && chain_dev.bt_ctl) {   // rows by their number of groups (BatchCtl::hist at byte 128)
+      unsigned hist[256];
+      PCHK(hipMemcpy(hist, (const uint8_t*)chain_dev.bt_ctl + 128, sizeof(hist), hipMemcpyDeviceToHost));
+      std::string line;
+      for (int l = 0; l < 256; l++) if (hist[l]) line += " " + std::to_string(l) + ":" + std::to_string(hist[l]);
+      fprintf(stderr, "[phase]     grid chain rounds (batched): rows by groups%s\n", line.c_str());
+    }
     if (chain_desc.back().batch_lds && clk[14]) fprintf(stderr, "[phase]     grid chain rounds (batched): %lld groups of four het-site entries incl. padding (%d rows, %d entries)\n", clk[14], stat[chain_desc.back().slot].R, stat[chain_desc.back().slot].E);
     static const char* nm2[] = {"stage delta/eta", "sigma step (workgroup 0)", "barrier 1", "stage sigma / invalidate", "delta step (workgroup 0)", "barrier 2"};
     for (int k = 0; k < 6; k++) fprintf(stderr, "[phase]     grid chain rounds: %-26s %9.1f us per iteration\n", nm2[k], (double)clk[8 + k] / 100.0 / (double)std::max<long long>(clk[15], 1));

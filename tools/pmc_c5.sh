@@ -1,0 +1,18 @@
+#!/bin/bash
+# PMC counters of the C5 chain kernel: tools/pmc_c5.sh   (two counter passes; per-launch values of k4_chain_grid)
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+for CTR in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  rm -rf /tmp/kpmc
+  rocprofv3 --kernel-trace --pmc $CTR -d /tmp/kpmc -o p --output-format csv -- python tools/c5_run.py --repeat 1 > /tmp/kpmc.log 2>&1
+  python - <<'PY'
+import csv, re, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
+for f in glob.glob("/tmp/kpmc/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if re.search("k4_chain_grid|k4_gpost|k2_hist_tiles", r["Kernel_Name"]):
+            agg[r["Kernel_Name"][:40]][r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Kernel_Name"][:40]].add(r["Dispatch_Id"])
+for k, d in sorted(agg.items()):
+    print("%-40s" % k, "launches", len(n[k]), " ".join("%s=%.4g" % (c, v / len(n[k])) for c, v in sorted(d.items())))
+PY
+done
