@@ -1238,6 +1238,7 @@ __global__ void __launch_bounds__(CH_THREADS) k4_gpost(PostIn in, PostScratch ps
   v.rptr = ps.rptr; v.ecol = ps.ecol; v.erow = ps.erow; v.cent = ps.cent; v.ccptr = ps.ccptr; v.ev = ps.ev;
   v.tag = ps.tag; v.asg = ps.asg; v.fp = ps.fp; v.lok = ps.lok; v.dirty = ps.dirty;
   v.shap = ps.shap; v.sgt = ps.sgt; v.svt = ps.svt; v.rcode = ps.rcode;
+  v.fdirt = ps.fdirt; v.minf = ps.minf; v.ndraw = ps.ndraw; v.gwords = ps.gwords;
   v.cand = in.cand + c0;
   v.stage = stage;
   int n_mark = 0;

@@ -974,7 +974,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     PostScratch ps{};
     ps.n_parts = (int32_t)std::max<int64_t>(16, std::min<int64_t>(grid_waves, (int64_t)(1 << 23) / (int64_t)gp_S));
     const size_t S8 = (gp_S + 8) & ~(size_t)7, R8 = (gp_rows + 8) & ~(size_t)7, E8 = (gp_E + 8) & ~(size_t)7;
-    PCHK(b_ps.reserve(S8 * (3 * 8 + 4 * 4 + 4) + R8 * (4 + 5) + 64));   // per SNP: 3 doubles, 4 int32, 4 bytes; per row: rptr + 5 bytes
+    PCHK(b_ps.reserve(S8 * (3 * 8 + 4 * 4 + 4 + 2 * 4) + R8 * (4 + 5 + 4) + 64 + 64));   // per SNP: 3 doubles, 4 + 2 int32, 4 bytes; per row: rptr, fdirt + 5 bytes
     PCHK(b_pse.reserve(E8 * (3 * 4 + 1) + 64));
     PCHK(b_psp.reserve((size_t)ps.n_parts * gp_S * 4 + 64));
     PCHK(b_ctl.reserve((4 + 16) * sizeof(GridCtl)));
@@ -984,6 +984,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     ps.rptr = (int32_t*)p; p += 4 * R8;
     ps.shap = (int8_t*)p; p += S8; ps.sgt = (int8_t*)p; p += S8; ps.svt = (int8_t*)p; p += S8; ps.rcode = p; p += S8;
     ps.tag = (int8_t*)p; p += R8; ps.asg = p; p += R8; ps.fp = p; p += R8; ps.lok = p; p += R8; ps.dirty = p; p += R8;
+    ps.fdirt = (int32_t*)p; p += 4 * R8; ps.minf = (int32_t*)p; p += 4 * S8; ps.ndraw = (int32_t*)p; p += 4 * S8; ps.gwords = (int32_t*)p; p += 64;
     uint8_t* q = b_pse.as<uint8_t>();
     ps.ecol = (int32_t*)q; q += 4 * E8; ps.erow = (int32_t*)q; q += 4 * E8; ps.cent = (int32_t*)q; q += 4 * E8; ps.ev = q;
     ps.pcnt = b_psp.as<int32_t>();

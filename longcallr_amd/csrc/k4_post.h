@@ -9,6 +9,7 @@
 // a*b+c unfused, so the decisions are the host path's bit for bit; only phase_score's final log10 is the device libm.
 #pragma once
 #include <climits>
+#include <type_traits>
 #include "k4_dev.h"
 
 namespace {
@@ -27,6 +28,7 @@ struct PostView {
   int8_t *shap, *sgt, *svt; uint8_t* rcode;
   lcr_candidate* cand;
   double* stage;                 // LDS: per wave 4 * 65 doubles
+  int32_t *fdirt = nullptr, *minf = nullptr, *ndraw = nullptr, *gwords = nullptr;   // grid scope: the rescue lists' parallel commit
 };
 
 constexpr int POST_SSTR = 65;   // stage row stride in doubles (lanes a = 0..3 read different banks)
@@ -188,6 +190,140 @@ __device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<
   }
   auto rescue = [&](uint32_t list_flag, float min_ps, bool low_frac, uint64_t rseed) -> bool {   // true: some SNP state changed
     int start = 0, chg = 0;
+    if constexpr (std::is_same<SC, GridScope>::value) {
+      // GRID SCOPE: the same rounds with the commit in parallel as well (one wave walking the members one after the other, three
+      // dependent trips to memory per 512 entries of a column, was 12.5 of k4_gpost's 20 ms on C5).  Whether a row is changed by a
+      // success depends on the row alone (touch = draw || !fp), so: (C) every success marks the rows it would change with its index
+      // (atomicMin: the FIRST member to change the row) and counts its draws; (D) a member is stale iff one of its rows carries a
+      // smaller index than its own -- the first stale member ends the round, exactly the serial rule; (F) the members before it commit
+      // side by side: two committed successes share only rows neither changes (a shared row that one of them changes makes the later one
+      // stale), and a success's first draw is the draws of the successes before it.  A pending member is evaluated again only if one
+      // of its rows was changed since (its row minimum below the round's end): the others' scores are those the serial walk would see.
+      int32_t* const fdirt = v.fdirt; int32_t* const minf = v.minf; int32_t* const ndraw = v.ndraw; int32_t* const gw = v.gwords;
+      for (int ti = sc.tid(); ti < S; ti += sc.nt()) minf[ti] = -1;   // (not evaluated yet)
+      sc.sync();
+      for (;;) {
+        for (int r = sc.tid(); r < nrow; r += sc.nt()) fdirt[r] = INT_MAX;
+        if (sc.tid() == 0) gw[0] = S;
+        for (int ti = start + sc.wave(); ti < S; ti += sc.nwaves()) {
+          if (!(soflags[ti] & list_flag)) { if (lane == 0) rcode[ti] = 0; continue; }
+          if (minf[ti] >= start) continue;   // no row of its column changed since it was evaluated
+          uint8_t code = 0;
+          if (ccptr[ti] == ccptr[ti + 1]) code = 1;
+          else if (svt[ti] != 1) code = 2;
+          else {
+            double q[2]; int hap1, hap2, nobs;
+            col_sums(ti, true, [&](int sg, uint8_t x, double* t) { t[0] = lg(sg, 1, 0, x); t[1] = lg(sg, -1, 0, x); },
+                     q, 2, hap1, hap2, nobs);
+            if (nobs == 0 || hap1 < 2 || hap2 < 2) code = 3;
+            else {
+              const double pa = -10.0 * log10(1.0 - (1.0 - q[0] / (q[0] + q[1])));
+              const double pb = -10.0 * log10(1.0 - (1.0 - q[1] / (q[0] + q[1])));
+              if (lane == 0) { rpa[ti] = pa; rpb[ti] = pb; }
+              code = fmax(pa, pb) >= (double)min_ps ? 4 : 5;
+            }
+          }
+          if (lane == 0) rcode[ti] = code;
+        }
+        sc.sync();
+        for (int ti = start + sc.wave(); ti < S; ti += sc.nwaves()) {   // (C)
+          if (rcode[ti] != 4) continue;
+          int nd = 0;
+          const int kb = (int)ccptr[ti], ke = (int)ccptr[ti + 1];
+          for (int k0 = kb; k0 < ke; k0 += 64 * 8) {
+            int rr[8]; int tg[8], ag[8], fv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int k = k0 + 64 * u + lane; rr[u] = k < ke ? (int)erow[cent[k]] : -1; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int r = max(rr[u], 0); tg[u] = tag[r]; ag[u] = asg[r]; fv[u] = fp[r]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const bool in_col = rr[u] >= 0;
+              const bool draw = in_col && (tg[u] == 0 || ag[u] == 0);
+              if (in_col && (draw || !fv[u])) atomicMin(&fdirt[rr[u]], ti);
+              nd += __popcll(__ballot(draw));
+            }
+          }
+          if (lane == 0) ndraw[ti] = nd;
+        }
+        sc.sync();
+        for (int ti = start + sc.wave(); ti < S; ti += sc.nwaves()) {   // (D)
+          if (rcode[ti] < 3) continue;   // (codes 1 / 2 do not look at the rows)
+          int m = INT_MAX;
+          const int kb = (int)ccptr[ti], ke = (int)ccptr[ti + 1];
+          for (int k0 = kb; k0 < ke; k0 += 64 * 8) {
+            int rr[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int k = k0 + 64 * u + lane; rr[u] = k < ke ? (int)erow[cent[k]] : -1; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (rr[u] >= 0) m = min(m, fdirt[rr[u]]);
+          }
+#pragma unroll
+          for (int d = 32; d >= 1; d >>= 1) m = min(m, __shfl_xor(m, d, 64));
+          if (lane == 0) { minf[ti] = m; if (m < ti) atomicMin(&gw[0], ti); }
+        }
+        sc.sync();
+        const int end = gw[0];
+        {   // draws of the successes of [start, t): every wave sums what it needs (a few hundred members at most)
+          auto draws_before = [&](int t) -> unsigned long long {
+            unsigned long long n = 0;
+            for (int x = start + lane; x < t; x += 64) if (rcode[x] == 4) n += (unsigned long long)ndraw[x];
+            return (unsigned long long)wave_sum_ll_dpp((long long)n);
+          };
+          for (int ti = start + sc.wave(); ti < end; ti += sc.nwaves()) {   // (F)
+            const uint8_t code = rcode[ti];
+            if (code == 0) continue;
+            if (code == 4) {
+              unsigned long long c = ctr + draws_before(ti);
+              const int kb4 = (int)ccptr[ti], ke4 = (int)ccptr[ti + 1];
+              for (int k0 = kb4; k0 < ke4; k0 += 64 * 8) {
+                int rr[8]; int tg[8], ag[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int k = k0 + 64 * u + lane; rr[u] = k < ke4 ? (int)erow[cent[k]] : -1; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int r = max(rr[u], 0); tg[u] = tag[r]; ag[u] = asg[r]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                  if (k0 + 64 * u >= ke4) break;
+                  const bool in_col = rr[u] >= 0;
+                  const int r = max(rr[u], 0);
+                  const bool draw = in_col && (tg[u] == 0 || ag[u] == 0);
+                  const unsigned long long dm = __ballot(draw);
+                  if (in_col) fp[r] = 1;
+                  if (draw) tag[r] = u01(rseed, c + (unsigned long long)__popcll(dm & ((1ull << lane) - 1ull))) < 0.5 ? -1 : 1;
+                  c += (unsigned long long)__popcll(dm);
+                }
+              }
+            }
+            if (lane == 0) {
+              const uint32_t fl_old = sflags[ti];
+              if (code == 1 || code == 3) sflags[ti] |= LCR_F_SINGLE;
+              else if (code == 2) sflags[ti] |= LCR_F_NON_SELECTED;
+              else if (code == 5) {
+                sflags[ti] &= ~(uint32_t)LCR_F_SINGLE;
+                sflags[ti] |= LCR_F_NON_SELECTED;
+                if (low_frac) { sflags[ti] |= LCR_F_CAND_SOMATIC; sflags[ti] &= ~(uint32_t)LCR_F_FOR_PHASING; }
+                else sflags[ti] |= LCR_F_RNA_EDIT;
+              } else {   // rescued
+                sflags[ti] &= ~(uint32_t)(LCR_F_SINGLE | LCR_F_NON_SELECTED | LCR_F_RNA_EDIT);
+                if (low_frac) sflags[ti] &= ~(uint32_t)LCR_F_CAND_SOMATIC;
+                sflags[ti] |= LCR_F_FOR_PHASING;
+                shap[ti] = rpa[ti] >= rpb[ti] ? 1 : -1;
+                sgt[ti] = 0; svt[ti] = 1; sps[ti] = fmax(rpa[ti], rpb[ti]);
+                chg = 1;
+              }
+              if ((sflags[ti] ^ fl_old) & LCR_F_FOR_PHASING) chg = 1;
+            }
+          }
+          ctr += draws_before(end);
+        }
+        if (in.dbg_clk && sc.tid() == 0) in.dbg_clk[(size_t)v.g * 16 + (low_frac ? 12 : 11)] += 1;   // LCR_PHASE_PROF: rounds of the list
+        sc.sync();
+        start = end;
+        if (start >= S) break;
+      }
+      return sc.sync_or(chg) != 0;
+    }
     for (;;) {
       for (int r = sc.tid(); r < nrow; r += sc.nt()) dirty[r] = 0;
       for (int ti = start + sc.wave(); ti < S; ti += sc.nwaves()) {

@@ -125,6 +125,7 @@ struct PostScratch {
   int32_t *rptr, *ecol, *erow, *cent; uint8_t* ev;
   int8_t* tag; uint8_t *asg, *fp, *lok, *dirty; int8_t *shap, *sgt, *svt; uint8_t* rcode;
   int32_t* pcnt; int32_t n_parts, pad_;
+  int32_t *fdirt, *minf, *ndraw, *gwords;   // rescue lists: first member to change a row, a member's row minimum, its draws; {round end}
   GridCtl* ctl;
 };
 // arguments of the post-phase kernels (k4_post: one workgroup per region; k4_gpost: all CUs on one region)
