@@ -399,26 +399,30 @@ void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin,
 // ---- pass 2a, tile form.  When the survivors are DENSE (C5: every covered column of a 500x ONT-dRNA island passes the count
 // filters: 2.2e5 survivors, 1.1e8 (read, survivor) observations, 47 ms of the walk above) the histograms are a second pileup, and
 // K0's per-tile records are still there.  HT_SPLIT workgroups per tile, each with its share of the tile's records, keep
-// hist[survivor][allele][q] as u16 pairs in LDS (HT_SLOTS survivors x 124 counters per pass over their records; a survivor's depth
+// hist[survivor][allele][q] as u16 pairs in LDS (HT_SLOTS survivors x 124 counters per pass over their records -- every survivor of a tile in one pass; a survivor's depth
 // is <= max_depth <= 65 535) and add their non-zero counters to the zeroed histograms at the end.  Sixteen lanes per record, a lane
 // per base, the first 64 bases of a record requested before any is used.  What this replaced, measured on C5: a workgroup per tile
 // with a thread per record 26 ms, with sixteen lanes per record and 64 slots 30 ms -- the island's bases sit in 845 of its 3 843
 // tiles (6.4e5 bases each, up to four passes), so a workgroup per tile left most CUs idle behind a few long dependent chains.
 // ONT presets only: their end trim is already cut out of the records, the HiFi poly-A mask is not (those presets keep the walk).
 #ifndef HT_SLOTS
-#define HT_SLOTS 128
+#define HT_SLOTS 256
 #endif
 #ifndef HT_SPLIT
-#define HT_SPLIT 32   // (C5: 8 / 32 / 64 workgroups per tile 10.6 / 8.9 / 9.3 ms; 64 slots per pass instead of 128: 10.0)
+#define HT_SPLIT 32   // (C5, round 4, 256 threads and 128 slots: 8 / 32 / 64 workgroups per tile 10.6 / 8.9 / 9.3 ms; 64 slots per pass: 10.0.  Round 5: 256 slots with
+                      // 256 threads 12.7 ms (two workgroups per CU), with 512 threads 8.3 (split 16: 8.4; 1 024 threads, split 8: 10.8); the tally without branches 5.9)
 #endif
-__global__ void __launch_bounds__(LCR_BLOCK)
+#ifndef HT_BLOCK
+#define HT_BLOCK 512
+#endif
+__global__ void __launch_bounds__(HT_BLOCK)
 k2_hist_tiles(BatchView b, const int32_t* __restrict__ tile_col0, const int32_t* __restrict__ tile_count, const int32_t* __restrict__ tile_off,
               const Survivor* __restrict__ sv, const int32_t* __restrict__ ent_off, const uint2* __restrict__ ents,
               const unsigned long long* __restrict__ recs, uint32_t* __restrict__ hist) {
   const int tile = blockIdx.x / HT_SPLIT, part = blockIdx.x % HT_SPLIT, cnt = tile_count[tile];
   if (cnt == 0) return;
   __shared__ uint32_t hp[HT_SLOTS * 62];           // counter (slot, allele, q) = half (slot * 124 + allele * 31 + q) & 1 of word >> 1
-  __shared__ uint8_t slot_of[LCR_TILE];            // tile column -> survivor slot of this pass, 0xFF: none
+  __shared__ uint16_t slot_of[LCR_TILE];           // tile column -> survivor slot of this pass, 0xFFFF: none
   const int tid = threadIdx.x, grp = tid >> 4, ln = tid & 15;
   const int s0 = tile_off[tile], tc0 = tile_col0[tile];
   const int e0 = ent_off[tile];
@@ -427,10 +431,10 @@ k2_hist_tiles(BatchView b, const int32_t* __restrict__ tile_col0, const int32_t*
   if (j_lo >= j_hi) return;
   for (int p0 = 0; p0 < cnt; p0 += HT_SLOTS) {
     const int pc = min(HT_SLOTS, cnt - p0);
-    for (int i = tid; i < LCR_TILE; i += LCR_BLOCK) slot_of[i] = 0xFFu;
-    for (int i = tid; i < pc * 62; i += LCR_BLOCK) hp[i] = 0u;
+    for (int i = tid; i < LCR_TILE; i += HT_BLOCK) slot_of[i] = 0xFFFFu;
+    for (int i = tid; i < pc * 62; i += HT_BLOCK) hp[i] = 0u;
     __syncthreads();
-    for (int i = tid; i < pc; i += LCR_BLOCK) slot_of[sv[s0 + p0 + i].col - tc0] = (uint8_t)i;
+    for (int i = tid; i < pc; i += HT_BLOCK) slot_of[sv[s0 + p0 + i].col - tc0] = (uint16_t)i;
     __syncthreads();
     const int c_lo = sv[s0 + p0].col - tc0, c_hi = sv[s0 + p0 + pc - 1].col - tc0;   // the pass's column range (survivors are in column order)
     // a 16-lane group per record; the records two iterations ahead are requested while this one is tallied
@@ -439,37 +443,39 @@ k2_hist_tiles(BatchView b, const int32_t* __restrict__ tile_col0, const int32_t*
       const uint2 en = ents[e0 + (j >> 4)];
       return ((unsigned int)j & 15u) < en.y ? recs[en.x + ((unsigned int)j & 15u)] : ~0ull;
     };
-    unsigned long long nx = fetch(j_lo + grp), nx2 = fetch(j_lo + grp + LCR_BLOCK / 16);
-    for (int j = j_lo + grp; j < j_hi; j += LCR_BLOCK / 16) {
+    unsigned long long nx = fetch(j_lo + grp), nx2 = fetch(j_lo + grp + HT_BLOCK / 16);
+    for (int j = j_lo + grp; j < j_hi; j += HT_BLOCK / 16) {
       const unsigned long long rec = nx;
       nx = nx2;
-      nx2 = fetch(j + 2 * (LCR_BLOCK / 16));
+      nx2 = fetch(j + 2 * (HT_BLOCK / 16));
       const unsigned long long off = rec & REC_OFF_MASK;
-      if (off >= REC_KIND_N) continue;             // idle slot, D / I / N record: no base
+      const bool live = off < REC_KIND_N;          // (else: idle slot, D / I / N record: no base -- an empty range, no branch)
       const int col0 = (int)((rec >> 40) & 1023u), len = (int)((rec >> 50) & 1023u) + 1;
-      const int d_lo = max(0, c_lo - col0), d_hi = min(len - 1, c_hi - col0);
-      auto tally = [&](int dd, uint8_t base, uint8_t qual) {
-        const uint32_t slot = slot_of[col0 + dd];
-        const int bi = base_code(base);
-        if (slot == 0xFFu || bi < 0) return;
-        const uint32_t q = min((uint32_t)qual, 30u);   // MAX_BASE_QUALITY (util.rs:711-715)
-        const uint32_t idx = slot * 124u + (uint32_t)bi * 31u + q;
-        atomicAdd(&hp[idx >> 1], 1u << (16 * (idx & 1u)));
+      const int d_lo = max(0, c_lo - col0), d_hi = live ? min(len - 1, c_hi - col0) : -1;
+      // (no branch before the atomic: a switch on the base and early returns cost twice as many scalar as vector instructions here)
+      auto tally = [&](int dd, bool in, uint32_t base, uint32_t qual) {
+        const uint32_t slot = slot_of[min(col0 + max(dd, 0), LCR_TILE - 1)];
+        const uint32_t u = (base & 0xDFu) - 65u;                      // 'A' 'C' 'G' 'T' (either case, util.rs:822-889) -> 0, 2, 6, 19
+        const bool acgt = u < 20u && ((0x80045u >> u) & 1u);
+        const uint32_t k = ((base & 0xDFu) >> 1) & 3u, bi = k ^ (k >> 1);   // -> 0, 1, 2, 3
+        const uint32_t q = min(qual, 30u);   // MAX_BASE_QUALITY (util.rs:711-715)
+        const uint32_t idx = slot * 124u + bi * 31u + q;
+        if (in && acgt && slot != 0xFFFFu) atomicAdd(&hp[idx >> 1], 1u << (16 * (idx & 1u)));
       };
-      uint8_t bb[4], qq[4];
+      uint32_t bb[4], qq[4];
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         const int dd = d_lo + ln + 16 * t;
-        bb[t] = dd <= d_hi ? b.bases[off + dd] : (uint8_t)0;
-        qq[t] = dd <= d_hi ? b.quals[off + dd] : (uint8_t)0;
+        bb[t] = dd <= d_hi ? b.bases[off + dd] : 0u;
+        qq[t] = dd <= d_hi ? b.quals[off + dd] : 0u;
       }
 #pragma unroll
-      for (int t = 0; t < 4; t++) { const int dd = d_lo + ln + 16 * t; if (dd <= d_hi) tally(dd, bb[t], qq[t]); }
-      for (int dd = d_lo + ln + 64; dd <= d_hi; dd += 16) tally(dd, b.bases[off + dd], b.quals[off + dd]);
+      for (int t = 0; t < 4; t++) { const int dd = d_lo + ln + 16 * t; tally(dd, dd <= d_hi, bb[t], qq[t]); }
+      for (int dd = d_lo + ln + 64; dd <= d_hi; dd += 16) tally(dd, true, b.bases[off + dd], b.quals[off + dd]);
     }
     __syncthreads();
     uint32_t* out = hist + (int64_t)(s0 + p0) * 124;
-    for (int i = tid; i < pc * 124; i += LCR_BLOCK) {
+    for (int i = tid; i < pc * 124; i += HT_BLOCK) {
       const uint32_t v = (hp[i >> 1] >> (16 * (i & 1))) & 0xffffu;
       if (v) atomicAdd(&out[i], v);
     }
@@ -481,7 +487,7 @@ void launch_k2_hist_tiles(const BatchView& b, const int32_t* tile_col0, int32_t 
                           const int32_t* tile_off, const Survivor* sv, const int32_t* ent_off, const void* ents, const unsigned long long* recs,
                           uint32_t* hist /* zeroed */, hipStream_t s) {
   if (n_tiles == 0) return;
-  hipLaunchKernelGGL(k2_hist_tiles, dim3((unsigned)n_tiles * HT_SPLIT), dim3(LCR_BLOCK), 0, s, b, tile_col0, tile_count, tile_off, sv, ent_off,
+  hipLaunchKernelGGL(k2_hist_tiles, dim3((unsigned)n_tiles * HT_SPLIT), dim3(HT_BLOCK), 0, s, b, tile_col0, tile_count, tile_off, sv, ent_off,
                      (const uint2*)ents, recs, hist);
 }
 

@@ -201,14 +201,15 @@ __device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<
       // of its rows was changed since (its row minimum below the round's end): the others' scores are those the serial walk would see.
       int32_t* const fdirt = v.fdirt; int32_t* const minf = v.minf; int32_t* const ndraw = v.ndraw; int32_t* const gw = v.gwords;
       for (int ti = sc.tid(); ti < S; ti += sc.nt()) minf[ti] = -1;   // (not evaluated yet)
+      for (int r = sc.tid(); r < nrow; r += sc.nt()) fdirt[r] = INT_MAX;
+      if (sc.tid() == 0) gw[0] = S;
       sc.sync();
       for (;;) {
-        for (int r = sc.tid(); r < nrow; r += sc.nt()) fdirt[r] = INT_MAX;
-        if (sc.tid() == 0) gw[0] = S;
-        for (int ti = start + sc.wave(); ti < S; ti += sc.nwaves()) {
+        for (int ti = start + sc.wave(); ti < S; ti += sc.nwaves()) {   // (B) + (C): the same wave has member ti in every loop
           if (!(soflags[ti] & list_flag)) { if (lane == 0) rcode[ti] = 0; continue; }
-          if (minf[ti] >= start) continue;   // no row of its column changed since it was evaluated
-          uint8_t code = 0;
+          uint8_t code = rcode[ti];
+          if (minf[ti] < start) {   // (else: no row of its column changed since it was evaluated)
+          code = 0;
           if (ccptr[ti] == ccptr[ti + 1]) code = 1;
           else if (svt[ti] != 1) code = 2;
           else {
@@ -224,10 +225,8 @@ __device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<
             }
           }
           if (lane == 0) rcode[ti] = code;
-        }
-        sc.sync();
-        for (int ti = start + sc.wave(); ti < S; ti += sc.nwaves()) {   // (C)
-          if (rcode[ti] != 4) continue;
+          }
+          if (code != 4) continue;
           int nd = 0;
           const int kb = (int)ccptr[ti], ke = (int)ccptr[ti + 1];
           for (int k0 = kb; k0 < ke; k0 += 64 * 8) {
@@ -318,6 +317,10 @@ __device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<
           ctr += draws_before(end);
         }
         if (in.dbg_clk && sc.tid() == 0) in.dbg_clk[(size_t)v.g * 16 + (low_frac ? 12 : 11)] += 1;   // LCR_PHASE_PROF: rounds of the list
+        if (end < S) {   // the next round's marks start from a clean slate (everybody has read gw[0])
+          for (int r = sc.tid(); r < nrow; r += sc.nt()) fdirt[r] = INT_MAX;
+          if (sc.tid() == 0) gw[0] = S;
+        }
         sc.sync();
         start = end;
         if (start >= S) break;
