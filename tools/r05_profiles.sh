@@ -14,6 +14,8 @@ rocprofv3 --kernel-trace --stats -d $O/prof_c4 -o p --output-format csv -- pytho
 cp $O/prof_c4/p_kernel_stats.csv $O/bench_c4_one_gpu_kernel_stats.csv
 rocprofv3 --kernel-trace --stats -d $O/prof_c5 -o p --output-format csv -- python tools/c5_run.py --repeat 2 > $O/c5_run.json 2> $O/prof_c5.log
 cp $O/prof_c5/p_kernel_stats.csv $O/c5_kernel_stats.csv
+LCR_PHASE_PROF=1 python tools/c5_run.py --repeat 1 2>&1 >/dev/null | grep '^\[phase\]' > $O/c5_phase_prof.txt
+tools/pmc_c5.sh > $O/c5_pmc.txt 2>&1
 P="--steps 2 --warmup 1 --prewarm 2 $Q"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_sq -o p --output-format csv -- python bench.py $P > $O/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $O/pmc_lds -o p --output-format csv -- python bench.py $P > $O/pmc_lds.log 2>&1
