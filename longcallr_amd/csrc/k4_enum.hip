@@ -924,6 +924,427 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k4_enum_bits: the same restarts, EIGHT per wave as bit states (round 5; what k4_grid_batch.h does for the chain's speculative
+// half-rounds).  The 2^S restarts of a region differ in their start delta and sigma only, so a wave carries restarts e .. e + 7 as eight
+// bits per row (sg8: bit s = sigma of restart s is -1) and per SNP (het / delta < 0 / eta == +1): an entry of the matrix is read and
+// decoded once, and its contribution to a row or column sum costs three instructions per restart -- the masks are "spread" (state s at
+// bit 2 s), het | mis << 1 is the 2-bit signed factor of every state, one v_bfe_i32 and two v_mad_i32_i24 on the limbs of w.
+//   sigma step : lane <-> a run of whole rows in CSR order as in k4_enum_reg, the entries streamed from LDS; at a row's last entry the
+//                lane takes the eight decisions (sign of the sum; an exact tie with a het entry goes to the wave's queue, where a lane
+//                per (row, state) forms the f64 scores -- enum_tie_row_flips, unchanged)
+//   delta step : lane <-> a chunk of the CSC entries, M[state][SNP] by LDS atomics; then a lane per (state, SNP), eight SNPs per pass,
+//                takes the four-way decision; the ballots ARE the restarts' new masks
+//   The eight restarts run in lock step; one that has settled (or made 21 iterations) is frozen.  Everything a restart leaves --
+//   objective, final state, signature, repair-list entry, census -- is what k4_enum_reg leaves (tests compare the two kernels).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t enum_spread8(uint32_t x) { x = (x | (x << 4)) & 0x0F0Fu; x = (x | (x << 2)) & 0x3333u; x = (x | (x << 1)) & 0x5555u; return x; }
+__device__ __forceinline__ int enum_mad24(int a, int b, int c) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+
+__global__ void __launch_bounds__(64 * ENUM_WAVES)
+k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uint32_t per, const int64_t* __restrict__ job_base,
+             long long* __restrict__ job_obj, const int64_t* __restrict__ st_base, unsigned long long* __restrict__ st_words,
+             long long* __restrict__ region_best, uint32_t* __restrict__ redo, uint32_t redo_cap) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const EnumTile t = enum_tile_of(P, spans, n_spans, per, false);
+  const RegionDev rd = P.reg[t.slot];
+  const int R = rd.R, S = rd.S;
+  const uint32_t E = (uint32_t)P.prow_ptr[rd.rp_off + R];
+  const EnumLayout L = enum_layout(R, E, true);
+  uint2* wl2 = (uint2*)lds;
+  double* lut = (double*)(lds + L.lut);
+  uint2* csr = (uint2*)(lds + L.csr);
+  uint32_t* csc = (uint32_t*)(lds + L.csc);
+  uint16_t* rp = (uint16_t*)(lds + L.rp); uint16_t* first_row = (uint16_t*)(lds + L.first_row);
+  uint16_t* ent16 = (uint16_t*)(lds + L.ent16);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t c = enum_chunk(E);
+  __shared__ long long s_cF[32], s_cW[32], s_cRef[32], s_cVar[32], s_het[32];
+  __shared__ uint8_t s_live[32];
+  // ---- stage the region (once per workgroup; as k4_enum_reg)
+  if (tid < 32) {
+    const long long w = tid < 31 ? P.lut.f1e[tid] - P.lut.fe[tid] : 0;
+    wl2[tid] = make_uint2((uint32_t)w & 0x7fffffu, (uint32_t)(w >> 23) & 0xffffffu);
+  }
+  if (tid < 64) lut[tid] = (tid & 31) < 31 ? (tid < 32 ? P.lut64->le[tid] : P.lut64->l1e[tid - 32]) : 0.0;
+  const int32_t* g_rp = P.prow_ptr + rd.rp_off;
+  for (int r = tid; r <= R; r += nt) rp[r] = (uint16_t)g_rp[r];
+  __shared__ int32_t cps[33];
+  if (tid <= S && tid < 33) cps[tid] = P.ccol_ptr[rd.cp_off + tid];
+  int eta_init = 0;
+  if (tid < 32) {
+    long long cF = 0, cW = 0, cRef = 0, cVar = 0, het = 0; bool live = false;
+    if (tid < S) {
+      const long long* sc = P.snp_const + 4ll * (rd.snp_off + tid);
+      cF = sc[0]; cW = sc[1]; cRef = sc[2] + P.lut.f_homref; cVar = sc[3] + P.lut.f_homvar;
+      const int n = P.ccol_ptr[rd.cp_off + tid + 1] - P.ccol_ptr[rd.cp_off + tid];
+      het = P.lut.f_het0 - (long long)n * P.lut.f_log2;                     // phase.rs:136-144
+      live = P.snp_fp[rd.snp_off + tid] != 0 && n > 0;
+      eta_init = init_genotype(P.snp_vt[rd.snp_off + tid]);
+    }
+    s_cF[tid] = cF; s_cW[tid] = cW; s_cRef[tid] = cRef; s_cVar[tid] = cVar; s_het[tid] = het; s_live[tid] = live ? 1 : 0;
+  }
+  __shared__ uint32_t s_e0i, s_epi;
+  if (tid < 64) {   // (the first wave: lanes < 32 hold the SNPs' start genotypes)
+    const uint32_t a = (uint32_t)__ballot(tid < S && tid < 32 && eta_init == 0), b = (uint32_t)__ballot(tid < S && tid < 32 && eta_init == 1);
+    if (tid == 0) { s_e0i = a; s_epi = b; }
+  }
+  __syncthreads();
+  for (int l = tid; l <= 64; l += nt) {   // first row whose start offset is >= l * c
+    const uint32_t target = (uint32_t)l * c;
+    int lo = 0, hi = R;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (rp[mid] < target) lo = mid + 1; else hi = mid; }
+    first_row[l] = (uint16_t)lo;
+  }
+  for (int e = tid; e < (int)E; e += nt) {
+    const uint32_t cv = P.cval[rd.e_off + e];
+    int col = 0;
+    for (int i = 0; i < S; i++) col += (int)((uint32_t)e >= (uint32_t)cps[i + 1]);
+    csc[e] = (uint32_t)P.crow[rd.e_off + e] | ((uint32_t)col << 16) | ((cv & 32u) << 16) | ((cv & 31u) << 22) | 0x80000000u;
+  }
+  __syncthreads();
+  for (int r = tid; r < R; r += nt) {
+    const int e0 = rp[r], e1 = rp[r + 1];
+    if (e0 == e1) continue;
+    const uint32_t owner = (uint32_t)e0 / c;
+    const uint32_t roff = (uint32_t)r - first_row[owner];
+    for (int e = e0; e < e1; e++) {
+      const uint32_t v = P.pval[rd.e_off + e];
+      const uint32_t meta = (uint32_t)P.pcol[rd.e_off + e] | (v & 32u) | (e + 1 == e1 ? 64u : 0u) | 128u;
+      const uint2 w = wl2[v & 31u];
+      csr[e] = make_uint2(w.x | (meta << 24), w.y | (roff << 24));
+      ent16[e] = (uint16_t)((meta & 63u) | ((v & 31u) << 6) | (e + 1 == e1 ? 0x800u : 0u));
+    }
+  }
+  __syncthreads();
+  // ---- per wave
+  const int lane = tid & 63, wave = tid >> 6;
+  uint8_t* const wst = lds + L.state + wave * L.stride;
+  uint8_t* const sg8 = wst;                                                     // [R]: bit s = sigma of restart s is -1
+  unsigned long long* const Macc = (unsigned long long*)(wst + ((R + 15) & ~7u)); // [8][32]
+  uint2* const mt = (uint2*)(Macc + 8 * 32);                                    // [32]: .x = het16 | dneg16 << 16 (spread), .y = dneg8 | het8 << 8 | etap8 << 16
+  uint32_t* const ms = (uint32_t*)(mt + 32);                                    // [3][8]: dneg, eta0, etap of every restart
+  uint32_t* const tq = ms + 24 + 32;                                            // queue of tied rows: row | tie8 << 16 | sneg8 << 24
+  uint32_t* const tq_n = tq + ENUM_TQ;
+  const int r_a = first_row[lane], r_b = first_row[lane + 1];
+  const int s0 = rp[r_a], s1 = rp[r_b];
+  const int c0 = min((int)E, lane * (int)c), c1 = min((int)E, (lane + 1) * (int)c);
+  int n_sig;
+  { int n = s1 - s0; for (int d = 32; d >= 1; d >>= 1) n = max(n, __shfl_xor(n, d, 64)); n_sig = __builtin_amdgcn_readfirstlane(n); }
+  const int n_del = (int)min(c, E);
+  const uint32_t smask = S >= 32 ? 0xffffffffu : ((1u << S) - 1u);
+  const uint32_t e0_init = s_e0i, ep_init = s_epi;
+  const int nk = (R + 63) / 64;
+  unsigned long long* const st_reg = st_words + st_base[t.slot];
+  const uint32_t stw = enum_state_words((uint32_t)R);
+  uint32_t n_tie_f64 = 0, n_tie_flip = 0, n_tie_unres = 0;   // per lane
+  uint32_t n_dtie = 0, n_step = 0;                          // wave-uniform
+  const int n_pass = (S + 7) >> 3;
+  for (uint32_t g0 = 8u * wave; g0 < t.ne; g0 += 8u * ENUM_WAVES) {
+    const uint32_t e_base = t.e0 + g0;                      // (a multiple of 8: restart s of the group is e_base + s)
+    const int nst = (int)min(8u, t.ne - g0);
+    const uint32_t valid8 = (1u << nst) - 1u;
+    // ---- start states
+    if (lane < 8) { ms[lane] = (e_base + (uint32_t)lane) & smask; ms[8 + lane] = e0_init; ms[16 + lane] = ep_init; }
+    for (int k = 0; k < nk; k++) {
+      const int row = lane + 64 * k;
+      uint32_t b = 0;
+#pragma unroll
+      for (int s = 0; s < 8; s++) {   // init_assignment (phase.rs:673-680): top bit of the draw clear -> sigma = -1
+        const uint64_t ctr0 = (uint64_t)S + (uint64_t)R + (uint64_t)(e_base + s) * (uint64_t)R;
+        b |= (uint32_t)((mix64(rd.seed + (ctr0 + row + 1) * 0x9E3779B97F4A7C15ULL) >> 63) == 0) << s;
+      }
+      if (row < R) sg8[row] = (uint8_t)b;
+    }
+    for (int k = lane; k < 8 * 32; k += 64) Macc[k] = 0;
+    if (lane == 0) tq_n[0] = 0;
+    wave_lds_sync();
+    uint32_t act = valid8, hinc = valid8, hginc = valid8;
+    int iters = 0;
+    uint32_t ev_d[8], ev_s[8];   // this group's delta / eta ties and tie-only steps per restart (wave-uniform)
+#pragma unroll
+    for (int s = 0; s < 8; s++) { ev_d[s] = 0; ev_s[s] = 0; }
+    long long objl[4] = {0, 0, 0, 0};   // lane (state, SNP of pass p): the chosen branch's data term of the restart's last iteration
+    while (act) {
+      // ---- the SNPs' masks of this iteration from the restarts' masks
+      if (lane < 32) {
+        uint32_t dn = 0, h8 = 0, ep = 0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) { dn |= ((ms[s] >> lane) & 1u) << s; h8 |= ((ms[8 + s] >> lane) & 1u) << s; ep |= ((ms[16 + s] >> lane) & 1u) << s; }
+        mt[lane] = make_uint2(enum_spread8(h8) | (enum_spread8(dn) << 16), dn | (h8 << 8) | (ep << 16));
+      }
+      wave_lds_sync();
+      // ---- sigma step (phase.rs:824-862)
+      uint32_t any8 = 0, tflip8 = 0;
+      {
+        int alo[8], ahi[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) { alo[s] = 0; ahi[s] = 0; }
+        uint32_t uacc = 0, sg16 = 0, sgb = 0;
+        int cur = -1;
+        for (int x0 = 0; x0 < n_sig; x0 += 4) {
+          uint2 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) v[u] = s0 + x0 + u < s1 ? csr[s0 + x0 + u] : make_uint2(0, 0);
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t v0 = v[u].x, v1 = v[u].y;
+            const uint32_t m = v0 >> 24, i = m & 31u;
+            const int roff = (int)(v1 >> 24);
+            if ((m & 128u) && roff != cur) { cur = roff; sgb = sg8[r_a + roff]; sg16 = enum_spread8(sgb); }
+            const uint32_t mm = mt[i].x;
+            const uint32_t use16 = (m & 128u) ? (mm & 0xFFFFu) : 0u;                          // het sites only
+            const uint32_t hit16 = (((m & 32u) ? 0x5555u : 0u) ^ sg16 ^ (mm >> 16)) & use16;   // p == sigma * delta
+            const uint32_t code = use16 | ((hit16 ^ use16) << 1);                              // 01: +w (A), 11: -w (B)
+            uacc |= use16;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+              const int sgn = __builtin_amdgcn_sbfe((int)code, 2 * s, 2);
+              alo[s] = enum_mad24(sgn, (int)v0, alo[s]); ahi[s] = enum_mad24(sgn, (int)v1, ahi[s]);
+            }
+            if (m & 64u) {   // the row's last entry: its eight decisions
+              uint32_t fl = 0, tie = 0;
+#pragma unroll
+              for (int s = 0; s < 8; s++) {
+                const int top = ahi[s] + (alo[s] >> 23);   // sign of ahi * 2^23 + alo
+                fl |= (uint32_t)(top < 0) << s;
+                tie |= (uint32_t)(top == 0 && (alo[s] & 0x7fffff) == 0 && ((uacc >> (2 * s)) & 1u)) << s;
+                alo[s] = 0; ahi[s] = 0;
+              }
+              uacc = 0;
+              fl &= act; tie &= act;
+              any8 |= fl;
+              const int row = r_a + roff;
+              if (fl) sg8[row] = (uint8_t)(sgb ^ fl);
+              if (tie) {
+                // A == B at a row with a het entry: the f64 scores decide (a row without one scores the same for both signs, term by term)
+                if (P.tie_arith < 2) n_tie_unres += (uint32_t)__popc(tie);
+                else {
+                  n_tie_f64 += (uint32_t)__popc(tie);
+                  if (rp[row + 1] - rp[row] > 2) {   // (two entries: log_q2 = a + b, log_q3 = b + a -- the same double)
+                    const uint32_t at = atomicAdd(tq_n, 1u);
+                    if (at < ENUM_TQ) tq[at] = (uint32_t)row | (tie << 16) | (sgb << 24);
+                    else {
+                      for (uint32_t tt = tie; tt; tt &= tt - 1u) {
+                        const int s = __ffs((int)tt) - 1;
+                        if (enum_tie_row_flips(row, (sgb >> s) & 1u, ms[s], ms[8 + s], ms[16 + s], rp, ent16, lut)) {
+                          atomicXor((uint32_t*)(sg8 + (row & ~3)), 1u << (8 * (row & 3) + s));
+                          n_tie_flip++; tflip8 |= 1u << s;
+                        }
+                      }
+                    }
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      wave_lds_sync();
+      {   // the queue: a lane per (row, state)
+        const uint32_t nq = min(tq_n[0], ENUM_TQ);
+        for (uint32_t b0 = 0; b0 < nq; b0 += 8) {
+          const uint32_t j = b0 + (uint32_t)(lane >> 3);
+          const int s = lane & 7;
+          if (j < nq) {
+            const uint32_t ent = tq[j], row = ent & 0xffffu;
+            if ((ent >> (16 + s)) & 1u) {
+              if (enum_tie_row_flips((int)row, (ent >> (24 + s)) & 1u, ms[s], ms[8 + s], ms[16 + s], rp, ent16, lut)) {
+                atomicXor((uint32_t*)(sg8 + (row & ~3u)), 1u << (8 * (row & 3u) + s));
+                n_tie_flip++; tflip8 |= 1u << s;
+              }
+            }
+          }
+        }
+        if (lane == 0) tq_n[0] = 0;
+      }
+      {   // OR over the wave
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { any8 |= (uint32_t)__shfl_xor((int)any8, d, 64); tflip8 |= (uint32_t)__shfl_xor((int)tflip8, d, 64); }
+      }
+#pragma unroll
+      for (int s = 0; s < 8; s++) if (((tflip8 & ~any8) >> s) & 1u) { n_step++; ev_s[s]++; }   // only tie flips: "no improvement"
+      // (!any: h_inc = false; else both true)
+      hinc = (hinc & ~act) | (any8 & act); hginc |= any8 & act;
+      wave_lds_sync();
+      // ---- delta / eta step (phase.rs:872-959): a lane's chunk is CSC-ordered (SNP index non-decreasing)
+      {
+        int cur = -1;
+        uint32_t alo[8]; int ahi[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) { alo[s] = 0; ahi[s] = 0; }
+        auto flush = [&]() {
+#pragma unroll
+          for (int s = 0; s < 8; s++) {
+            if (alo[s] | (uint32_t)ahi[s]) atomicAdd(&Macc[s * 32 + cur], (unsigned long long)((long long)alo[s] + (long long)ahi[s] * (1ll << 23)));
+            alo[s] = 0; ahi[s] = 0;
+          }
+        };
+        for (int h = 0; h < n_del; h += 4) {
+          uint32_t v4[4], sw[4], dn[4]; uint2 wq[4];
+#pragma unroll
+          for (int x = 0; x < 4; x++) v4[x] = c0 + h + x < c1 ? csc[c0 + h + x] : 0u;
+#pragma unroll
+          for (int x = 0; x < 4; x++) { sw[x] = sg8[v4[x] & 0xffffu]; wq[x] = wl2[(v4[x] >> 22) & 31u]; dn[x] = mt[(v4[x] >> 16) & 31u].y & 0xFFu; }
+#pragma unroll
+          for (int x = 0; x < 4; x++) {
+            const uint32_t v = v4[x];
+            const int i = (v >> 16) & 31;
+            if ((v >> 31) && i != cur) { if (cur >= 0) flush(); cur = i; }
+            const uint32_t hit = (v >> 31) ? ((((v >> 21) & 1u) ? 0xFFu : 0u) ^ sw[x] ^ dn[x]) & 0xFFu : 0u;
+            const int whi = ((int)(wq[x].y << 8)) >> 8;   // the signed 24-bit limb
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+              const uint32_t b = (hit >> s) & 1u;
+              alo[s] += __umul24(b, wq[x].x); ahi[s] += __mul24((int)b, whi);
+            }
+          }
+        }
+        if (cur >= 0) flush();
+      }
+      wave_lds_sync();
+      // a lane per (state, SNP), eight SNPs per pass: the four-way decision (first maximum, phase.rs:908-921)
+      uint32_t any2 = 0, chg8 = 0;   // per state: an improvement / a mask changed
+      {
+        const int s = lane >> 3;
+        const uint32_t od = ms[s], oe0 = ms[8 + s], oep = ms[16 + s];
+        uint32_t nd = od, ne0 = oe0, nep = oep;
+        for (int p = 0; p < n_pass; p++) {
+          const int i = 8 * p + (lane & 7);
+          const bool in = i < S;
+          const bool live = in && s_live[i & 31] != 0;
+          int d_new = (int)((od >> i) & 1u), h_new = ((oe0 >> i) & 1u) ? 0 : (((oep >> i) & 1u) ? 1 : -1);
+          bool changed = false, dtie = false;
+          if (live && ((act >> s) & 1u)) {
+            const long long M = (long long)Macc[s * 32 + i];
+            const long long cF = s_cF[i], cW = s_cW[i], cRef = s_cRef[i], cVar = s_cVar[i], het = s_het[i];
+            const long long N0 = cF + M + het, N1 = cF + cW - M + het;
+            int ch = 0; long long nb = N0;
+            if (N1 > nb) { ch = 1; nb = N1; }
+            if (cRef > nb) { ch = 2; nb = cRef; }
+            if (cVar > nb) { ch = 3; nb = cVar; }
+            dtie = (int)(N0 == nb) + (int)(N1 == nb) + (int)(cRef == nb) + (int)(cVar == nb) > 1;   // a tie at the maximum: the first one is kept
+            const long long ncur = h_new == 0 ? N0 : (h_new == 1 ? cRef : cVar);
+            changed = nb > ncur;
+            if (ch == 1) d_new ^= 1;
+            h_new = ch <= 1 ? 0 : (ch == 2 ? 1 : -1);
+            objl[p] = ch <= 1 ? nb - het : (ch == 2 ? cRef - P.lut.f_homref : cVar - P.lut.f_homvar);
+          }
+          if (in) Macc[s * 32 + i] = 0;
+          const unsigned long long bd = __ballot(in && d_new), b0 = __ballot(in && h_new == 0), bp = __ballot(in && h_new == 1);
+          const unsigned long long bc = __ballot(changed), bt = __ballot(dtie);
+          const uint32_t sh = 8u * (uint32_t)s, keep = ~(0xFFu << (8 * p));
+          nd = (nd & keep) | ((uint32_t)((bd >> sh) & 0xFFull) << (8 * p));
+          ne0 = (ne0 & keep) | ((uint32_t)((b0 >> sh) & 0xFFull) << (8 * p));
+          nep = (nep & keep) | ((uint32_t)((bp >> sh) & 0xFFull) << (8 * p));
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            if ((bc >> (8 * q)) & 0xFFull) any2 |= 1u << q;
+            const uint32_t nt8 = (uint32_t)__popcll((bt >> (8 * q)) & 0xFFull);
+            n_dtie += nt8; ev_d[q] += nt8;
+          }
+        }
+        nd &= smask; ne0 &= smask; nep &= smask;
+        const bool frozen = !((act >> s) & 1u);
+        if (frozen) { nd = od; ne0 = oe0; nep = oep; }
+        const unsigned long long bm = __ballot(nd != od || ne0 != oe0 || nep != oep);
+#pragma unroll
+        for (int q = 0; q < 8; q++) if ((bm >> (8 * q)) & 0xFFull) chg8 |= 1u << q;
+        wave_lds_sync();
+        if ((lane & 7) == 0) { ms[s] = nd; ms[8 + s] = ne0; ms[16 + s] = nep; }
+      }
+      any2 &= act;
+#pragma unroll
+      for (int q = 0; q < 8; q++) if (((chg8 & ~any2 & act) >> q) & 1u) { n_step++; ev_s[q]++; }   // only tie changes in this step
+      // (!any2: hg_inc = false; else both true)
+      hginc = (hginc & ~act) | (any2 & act); hinc |= any2 & act;
+      wave_lds_sync();
+      iters++;
+      act &= hinc | hginc;
+      if (iters > 20) act = 0;  // phase.rs:967-972
+    }
+    // ---- what the restarts leave
+    long long tot = objl[0] + objl[1] + objl[2] + objl[3];
+    tot += __shfl_xor(tot, 1, 64); tot += __shfl_xor(tot, 2, 64); tot += __shfl_xor(tot, 4, 64);   // lanes 8 s .. 8 s + 7: the objective of restart s
+    // the SNPs' masks of the FINAL states
+    if (lane < 32) {
+      uint32_t dn = 0, h8 = 0, ep = 0;
+#pragma unroll
+      for (int s = 0; s < 8; s++) { dn |= ((ms[s] >> lane) & 1u) << s; h8 |= ((ms[8 + s] >> lane) & 1u) << s; ep |= ((ms[16 + s] >> lane) & 1u) << s; }
+      mt[lane] = make_uint2(0u, dn | (h8 << 8) | (ep << 16));
+    }
+    wave_lds_sync();
+    // signatures of the final configurations (as k4_enum_reg: a hash of the match bits [p == x] of the lane's entries, 32 at a time;
+    // compared only among the restarts of one region)
+    unsigned long long hs[8];
+    {
+      uint32_t word[8];
+#pragma unroll
+      for (int s = 0; s < 8; s++) { hs[s] = 0; word[s] = 0; }
+      int nb = 0, widx = 0;
+      for (int x = 0; x < n_sig; x++) {
+        const uint2 v = s0 + x < s1 ? csr[s0 + x] : make_uint2(0, 0);
+        const uint32_t m = v.x >> 24, i = m & 31u, roff = v.y >> 24;
+        const uint32_t y = mt[i].y, dn8 = y & 0xFFu, h8 = (y >> 8) & 0xFFu, ep8 = (y >> 16) & 0xFFu;
+        const uint32_t p8 = (m & 32u) ? 0xFFu : 0u, sn8 = sg8[min(r_a + (int)roff, max(R - 1, 0))];
+        const uint32_t match = (m & 128u) ? ((h8 & (p8 ^ sn8 ^ dn8)) | (~h8 & ~(p8 ^ ep8))) & 0xFFu : 0u;
+#pragma unroll
+        for (int s = 0; s < 8; s++) word[s] |= ((match >> s) & 1u) << nb;
+        if (++nb == 32) {
+#pragma unroll
+          for (int s = 0; s < 8; s++) { hs[s] = mix64(hs[s] ^ (word[s] + (unsigned long long)(lane * 64 + widx + 1) * 0x9E3779B97F4A7C15ULL)); word[s] = 0; }
+          nb = 0; widx++;
+        }
+      }
+      if (nb) {
+#pragma unroll
+        for (int s = 0; s < 8; s++) hs[s] = mix64(hs[s] ^ (word[s] + (unsigned long long)(lane * 64 + widx + 1) * 0x9E3779B97F4A7C15ULL));
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+      if (s >= nst) break;
+      const uint32_t e = e_base + (uint32_t)s;
+      const long long total = ((long long)__builtin_amdgcn_readlane((int)(tot >> 32), 8 * s) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)tot, 8 * s);
+      // a restart that met a tie at a delta / eta maximum or a tie-only step goes to the repair list (as k4_enum_reg)
+      bool redone = false;
+      if (redo && ev_d[s] + ev_s[s] != 0 && P.tie_arith >= 3) {
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(&redo[0], 1u);
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        if (at < redo_cap) {
+          if (lane == 0) { redo[4 + 2 * at] = (uint32_t)t.slot; redo[5 + 2 * at] = e; }
+          n_dtie -= ev_d[s]; n_step -= ev_s[s];   // (not unresolved: the repair pass decides them)
+          redone = true;
+        }
+      }
+      const long long seen = __hip_atomic_load(&region_best[t.slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool keep = __builtin_amdgcn_readfirstlane((int)(total >= seen)) != 0;
+      if (total > seen && lane == 0 && !redone) (void)__hip_atomic_fetch_max(&region_best[t.slot], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long* stp = st_reg + (size_t)e * stw;
+      if (keep) {
+        const unsigned long long sig = (unsigned long long)wave_sum_ll((long long)hs[s]);
+        for (int k = 0; k < nk; k++) {
+          const int row = 64 * k + lane;
+          const unsigned long long w = __ballot(row < R && ((sg8[min(row, max(R - 1, 0))] >> s) & 1u));
+          if (lane == 0) stp[k] = w;
+        }
+        if (lane == 0) { stp[nk] = (unsigned long long)ms[s] | ((unsigned long long)ms[8 + s] << 32); stp[nk + 1] = (unsigned long long)ms[16 + s]; stp[nk + 2] = sig; }
+      }
+      if (lane == 0) job_obj[job_base[t.slot] + e] = total;
+    }
+    wave_lds_sync();
+  }
+  n_tie_f64 = (uint32_t)wave_sum_ll((long long)n_tie_f64); n_tie_flip = (uint32_t)wave_sum_ll((long long)n_tie_flip); n_tie_unres = (uint32_t)wave_sum_ll((long long)n_tie_unres);
+  if (lane == 0) {
+    if (n_tie_f64) TIE_COUNT(P.tie_ctr, TIE_SIGMA_F64, (unsigned long long)n_tie_f64);
+    if (n_tie_flip) TIE_COUNT(P.tie_ctr, TIE_SIGMA_FLIPS, (unsigned long long)n_tie_flip);
+    if (n_tie_unres) TIE_COUNT(P.tie_ctr, TIE_SIGMA_UNRES, (unsigned long long)n_tie_unres);
+    if (n_dtie) TIE_COUNT(P.tie_ctr, TIE_DELTA_UNRES, (unsigned long long)n_dtie);
+    if (n_step) TIE_COUNT(P.tie_ctr, TIE_STEP_UNRES, (unsigned long long)n_step);
+  }
+}
+
 // the same tiles for regions whose matrix does not fit the LDS budget: one restart at a time per workgroup.  Every restart leaves
 // its objective and -- st_words != nullptr and the region has a span there (st_base >= 0) -- its final state in the layout of the
 // other classes (sigma bits | delta < 0, eta == 0 masks | eta == +1 mask | a signature of all of it) for the resolve kernels.
@@ -1127,7 +1548,8 @@ void launch_k4_enum_reg(int ck, unsigned n_blocks, size_t dyn_lds, hipStream_t s
                         uint32_t per, const int64_t* job_base, long long* job_obj, const int64_t* st_base, unsigned long long* st_words,
                         long long* region_best, uint32_t* redo, uint32_t redo_cap) {
   const dim3 blk(64 * ENUM_WAVES);
-  if (ck == 32) hipLaunchKernelGGL(k4_enum_reg<32>, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, region_best, redo, redo_cap);
+  if (ck < 0) hipLaunchKernelGGL(k4_enum_bits, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, region_best, redo, redo_cap);
+  else if (ck == 32) hipLaunchKernelGGL(k4_enum_reg<32>, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, region_best, redo, redo_cap);
   else hipLaunchKernelGGL(k4_enum_reg<0>, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, region_best, redo, redo_cap);
 }
 void launch_k4_enum_redo(unsigned n_blocks, hipStream_t s, const PhaseDev& P, const uint32_t* redo, uint32_t redo_cap, int8_t* scratch, int32_t scratch_stride,

@@ -22,8 +22,12 @@ constexpr uint32_t ENUM_LDS_MAX = 63 * 1024;     // ... of the large-image strea
 //   ent16    : bits 0-4 SNP, 5 allele, 6-10 q, 11 last entry of its row
 constexpr uint32_t ENUM_TQ = 126;     // tied rows a wave queues per sigma step (+ 2 words: the count)
 constexpr uint32_t ENUM_TCAP = 256;   // configurations of maximal objective compared at a time (enum_resolve): a lane each
+// k4_enum_bits (eight restarts per wave as bit states): per wave sigma of the eight restarts as a byte per row, M[state][32], the SNPs' spread
+// masks [32] and byte masks [32], the per-restart masks [3][8] and the queue of tied rows
+constexpr uint32_t ENUM_BITS_PER = 64;   // restarts per tile of k4_enum_bits (ENUM_WAVES waves x 8 x 2)
+__host__ __device__ inline uint32_t enum_bits_stride(uint32_t R) { return ((R + 15) & ~7u) + 8 * 8 * 32 + 8 * 32 + 4 * 32 + 4 * 24 + 4 * (ENUM_TQ + 2); }
 struct EnumLayout { uint32_t lut, csr, csc, rp, first_row, ent16, state, stride, total; };
-__host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E) {
+__host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E, bool bits = false) {
   EnumLayout L;
   uint32_t o = 256;
   L.lut = o; o += 512;
@@ -35,7 +39,7 @@ __host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E) {
   L.ent16 = o; o += 2 * ((E + 3) & ~3u);
   o = (o + 15) & ~15u;
   L.state = o;
-  L.stride = 8 * ((R + 63) / 64 + 1) + 8 * 32 + 4 * (ENUM_TQ + 2);
+  L.stride = bits ? enum_bits_stride(R) : 8 * ((R + 63) / 64 + 1) + 8 * 32 + 4 * (ENUM_TQ + 2);
   o += ENUM_WAVES * L.stride;
   L.total = o;
   return L;
@@ -68,7 +72,7 @@ __host__ __device__ inline ResolveLayout resolve_layout(uint32_t R, uint32_t E, 
 // lane l owns the rows whose first entry index lies in [l*c, (l+1)*c), c = ceil(E / 64)
 __host__ __device__ inline uint32_t enum_chunk(uint32_t E) { return E ? (E + 63) / 64 : 1; }
 
-// CK = 32 | 0: k4_enum_reg<CK> (the per-lane share of the region's entries held in registers; 0 = streamed from LDS)
+// CK = 32 | 0: k4_enum_reg<CK> (the per-lane share of the region's entries held in registers; 0 = streamed from LDS); -1: k4_enum_bits
 // st_base[slot]: first word of the region's 2^S saved states in st_words
 void launch_k4_enum_reg(int ck, unsigned n_blocks, size_t dyn_lds, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, int32_t n_spans,
                         uint32_t per, const int64_t* job_base, long long* job_obj, const int64_t* st_base, unsigned long long* st_words,

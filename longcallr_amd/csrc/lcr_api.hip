@@ -994,6 +994,7 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
   else if (k == "hist_tiles") c->dbg_hist_tiles = value > 0 ? 1 : value < 0 ? -1 : 0;
   else if (k == "k3_hits") c->dbg_k3_hits = value != 0;
   else if (k == "grid_spec_batch") d.spec_batch = (int)value;
+  else if (k == "enum_bits") d.enum_bits = (int)value;
   else if (k == "grid_spec_lanes") d.spec_lanes = (int)std::max<int64_t>(1, std::min<int64_t>(value, 16));
   else { c->err = "lcr_debug_set: unknown key " + k; return LCR_E_ARG; }
   return LCR_OK;

@@ -120,6 +120,7 @@ struct PhaseDebug {
   int post_half = 0;            // "post_half": the eight-wave epilogue of the chain regions
   int enum_force_big = 0;       // "enum_force_big" / "enum_force_stream": the fallback enumeration kernels
   int enum_force_stream = 0;    // (2: the large-image launch of the streaming kernel)
+  int enum_bits = 1;            // "enum_bits": the enumeration restarts of the LDS classes eight per wave as bit states (k4_enum_bits)
   int spec_batch = 1;           // "grid_spec_batch": eight speculative half-rounds per pass over the matrix (k4_grid_batch.h); 0: the side-by-side lanes below
   int spec_lanes = 8;           // "grid_spec_lanes": half-rounds of the perturbation loop run at once at grid scope (1: one after the other; C5 with packed entries: 454 / 370 / 348 / 366 ms with 2 / 4 / 8 / 16 -- eight lanes = one XCD each)
   int tie_arith = 3;            // "tie_arith": which exact fixed-point ties the reference-order f64 arithmetic decides (PhaseDev::tie_arith; 3 = all that liblcr resolves)
