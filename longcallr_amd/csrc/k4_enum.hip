@@ -950,7 +950,8 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
   const RegionDev rd = P.reg[t.slot];
   const int R = rd.R, S = rd.S;
   const uint32_t E = (uint32_t)P.prow_ptr[rd.rp_off + R];
-  const EnumLayout L = enum_layout(R, E, true);
+  const EnumLayout L = enum_layout(R, E, true, (uint32_t)S);
+  const int Sp = (int)enum_bits_sp((uint32_t)S);
   uint2* wl2 = (uint2*)lds;
   double* lut = (double*)(lds + L.lut);
   uint2* csr = (uint2*)(lds + L.csr);
@@ -1021,10 +1022,10 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
   const int lane = tid & 63, wave = tid >> 6;
   uint8_t* const wst = lds + L.state + wave * L.stride;
   uint8_t* const sg8 = wst;                                                     // [R]: bit s = sigma of restart s is -1
-  unsigned long long* const Macc = (unsigned long long*)(wst + ((R + 15) & ~7u)); // [8][32]
-  uint2* const mt = (uint2*)(Macc + 8 * 32);                                    // [32]: .x = het16 | dneg16 << 16 (spread), .y = dneg8 | het8 << 8 | etap8 << 16
+  unsigned long long* const Macc = (unsigned long long*)(wst + ((R + 15) & ~7u)); // [8][Sp]
+  uint2* const mt = (uint2*)(Macc + 8 * Sp);                                    // [32]: .x = het16 | dneg16 << 16 (spread), .y = dneg8 | het8 << 8 | etap8 << 16
   uint32_t* const ms = (uint32_t*)(mt + 32);                                    // [3][8]: dneg, eta0, etap of every restart
-  uint32_t* const tq = ms + 24 + 32;                                            // queue of tied rows: row | tie8 << 16 | sneg8 << 24
+  uint32_t* const tq = ms + 24;                                            // queue of tied rows: row | tie8 << 16 | sneg8 << 24
   uint32_t* const tq_n = tq + ENUM_TQ;
   const int r_a = first_row[lane], r_b = first_row[lane + 1];
   const int s0 = rp[r_a], s1 = rp[r_b];
@@ -1056,7 +1057,7 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
       }
       if (row < R) sg8[row] = (uint8_t)b;
     }
-    for (int k = lane; k < 8 * 32; k += 64) Macc[k] = 0;
+    for (int k = lane; k < 8 * Sp; k += 64) Macc[k] = 0;
     if (lane == 0) tq_n[0] = 0;
     wave_lds_sync();
     uint32_t act = valid8, hinc = valid8, hginc = valid8;
@@ -1176,7 +1177,7 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
         auto flush = [&]() {
 #pragma unroll
           for (int s = 0; s < 8; s++) {
-            if (alo[s] | (uint32_t)ahi[s]) atomicAdd(&Macc[s * 32 + cur], (unsigned long long)((long long)alo[s] + (long long)ahi[s] * (1ll << 23)));
+            if (alo[s] | (uint32_t)ahi[s]) atomicAdd(&Macc[s * Sp + cur], (unsigned long long)((long long)alo[s] + (long long)ahi[s] * (1ll << 23)));
             alo[s] = 0; ahi[s] = 0;
           }
         };
@@ -1216,7 +1217,7 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
           int d_new = (int)((od >> i) & 1u), h_new = ((oe0 >> i) & 1u) ? 0 : (((oep >> i) & 1u) ? 1 : -1);
           bool changed = false, dtie = false;
           if (live && ((act >> s) & 1u)) {
-            const long long M = (long long)Macc[s * 32 + i];
+            const long long M = (long long)Macc[s * Sp + i];
             const long long cF = s_cF[i], cW = s_cW[i], cRef = s_cRef[i], cVar = s_cVar[i], het = s_het[i];
             const long long N0 = cF + M + het, N1 = cF + cW - M + het;
             int ch = 0; long long nb = N0;
@@ -1230,7 +1231,7 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
             h_new = ch <= 1 ? 0 : (ch == 2 ? 1 : -1);
             objl[p] = ch <= 1 ? nb - het : (ch == 2 ? cRef - P.lut.f_homref : cVar - P.lut.f_homvar);
           }
-          if (in) Macc[s * 32 + i] = 0;
+          if (in) Macc[s * Sp + i] = 0;
           const unsigned long long bd = __ballot(in && d_new), b0 = __ballot(in && h_new == 0), bp = __ballot(in && h_new == 1);
           const unsigned long long bc = __ballot(changed), bt = __ballot(dtie);
           const uint32_t sh = 8u * (uint32_t)s, keep = ~(0xFFu << (8 * p));

@@ -22,12 +22,13 @@ constexpr uint32_t ENUM_LDS_MAX = 63 * 1024;     // ... of the large-image strea
 //   ent16    : bits 0-4 SNP, 5 allele, 6-10 q, 11 last entry of its row
 constexpr uint32_t ENUM_TQ = 126;     // tied rows a wave queues per sigma step (+ 2 words: the count)
 constexpr uint32_t ENUM_TCAP = 256;   // configurations of maximal objective compared at a time (enum_resolve): a lane each
-// k4_enum_bits (eight restarts per wave as bit states): per wave sigma of the eight restarts as a byte per row, M[state][32], the SNPs' spread
-// masks [32] and byte masks [32], the per-restart masks [3][8] and the queue of tied rows
+// k4_enum_bits (eight restarts per wave as bit states): per wave sigma of the eight restarts as a byte per row, M[state][32], the SNPs' masks
+// [32], the per-restart masks [3][8] and the queue of tied rows
 constexpr uint32_t ENUM_BITS_PER = 64;   // restarts per tile of k4_enum_bits (ENUM_WAVES waves x 8 x 2)
-__host__ __device__ inline uint32_t enum_bits_stride(uint32_t R) { return ((R + 15) & ~7u) + 8 * 8 * 32 + 8 * 32 + 4 * 32 + 4 * 24 + 4 * (ENUM_TQ + 2); }
+__host__ __device__ inline uint32_t enum_bits_sp(uint32_t S) { return (S + 7) & ~7u; }   // SNP slots of M[state][]
+__host__ __device__ inline uint32_t enum_bits_stride(uint32_t R, uint32_t S) { return ((R + 15) & ~7u) + 8 * 8 * enum_bits_sp(S) + 8 * 32 + 4 * 24 + 4 * (ENUM_TQ + 2); }
 struct EnumLayout { uint32_t lut, csr, csc, rp, first_row, ent16, state, stride, total; };
-__host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E, bool bits = false) {
+__host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E, bool bits = false, uint32_t S = 32) {
   EnumLayout L;
   uint32_t o = 256;
   L.lut = o; o += 512;
@@ -39,7 +40,7 @@ __host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E, bool b
   L.ent16 = o; o += 2 * ((E + 3) & ~3u);
   o = (o + 15) & ~15u;
   L.state = o;
-  L.stride = bits ? enum_bits_stride(R) : 8 * ((R + 63) / 64 + 1) + 8 * 32 + 4 * (ENUM_TQ + 2);
+  L.stride = bits ? enum_bits_stride(R, S) : 8 * ((R + 63) / 64 + 1) + 8 * 32 + 4 * (ENUM_TQ + 2);
   o += ENUM_WAVES * L.stride;
   L.total = o;
   return L;

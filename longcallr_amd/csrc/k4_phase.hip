@@ -790,7 +790,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
 #define ENUM_PER3 2u
 #endif
     const bool ebits = dbg.enum_bits != 0;   // classes 1 - 3 by k4_enum_bits: eight restarts per wave
-    const uint32_t per_of[NCLS] = {1u, ebits ? ENUM_BITS_PER : ENUM_PER3 * ENUM_WAVES, ebits ? ENUM_BITS_PER : ENUM_TILE_JOBS, ebits ? ENUM_BITS_PER : ENUM_PER3 * ENUM_WAVES, 1u};
+    const uint32_t per_of[NCLS] = {1u, ENUM_PER3 * ENUM_WAVES, ENUM_TILE_JOBS, ebits ? ENUM_BITS_PER : ENUM_PER3 * ENUM_WAVES, 1u};
     std::vector<int64_t>& job_base = enum_job_base; std::vector<int64_t>& st_base = enum_st_base;   // st_base: first word of the region's saved restart states (classes 1 - 3)
     job_base.assign(ng, 0); st_base.assign(ng, 0);
     int64_t nj = 0, st_words = 0, big_words = 0, big_emax = 0;
@@ -803,7 +803,10 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     for (int g : enum_slots) {
       const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
       const StageStat& st = stat[g];
-      const EnumLayout EL = enum_layout(st.R, st.E, ebits);
+      const EnumLayout EL_old = enum_layout(st.R, st.E), EL_bits = enum_layout(st.R, st.E, true, (uint32_t)std::min(S, 32));
+      // k4_enum_bits where its image (a sigma byte per row and wave) fits; regions beyond it keep the streaming kernel (class 1, a launch of its own)
+      const bool use_bits = ebits && S <= 31 && EL_bits.total <= ENUM_LDS_MAX;
+      const EnumLayout EL = use_bits ? EL_bits : EL_old;
       const uint32_t RL = resolve_layout((uint32_t)st.R, (uint32_t)st.E, (uint32_t)S).total;
       int cls = 4;
       if (!force_big && st.R < 65536 && st.E < 65536 && S <= 31 && EL.total <= ENUM_LDS_MAX && RL <= ENUM_LDS_MAX && st.max_rows <= 64)
@@ -817,7 +820,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       // (C4 share: three such regions used to take the global-memory kernel BEHIND class 3 on its queue, 0.68 ms of the critical
       // path: step 5.49 -> 4.97 ms; a queue of their own was measured too: HIP maps a fourth stream onto one of the first three's
       // hardware queues, no difference)
-      if (ebits && cls < 4) cls = 3;   // (k4_enum_bits serves every LDS-resident region: one launch, one queue)
+      // with k4_enum_bits: class 3 = its regions (one launch), class 1 = the LDS-resident regions beyond its image (streaming kernel)
+      if (ebits && cls < 4) cls = use_bits ? 3 : 1;
       if (!ebits && (cls == 2 || cls == 3) && (std::max(EL.total, RL) > ENUM_LDS_BYTES || dbg.enum_force_stream == 2 /* test hook */)) cls = 1;
       //  the saved restart states of the LDS classes are allocated up front: a raised max_enum_snps (2^20 restarts x
       // R / 64 + 3 words) goes to the global-memory class instead, whose states are kept only inside a budget
@@ -897,12 +901,12 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     long long* const d_rbest = (long long*)(d_win + 2 * (size_t)ng);   // (8-byte aligned: behind the 2 x 4 x ng bytes of winners | tiles done)
     PCHK(hipMemsetAsync(d_rbest, 0x80, (size_t)ng * 8, stream));        // 0x8080...: far below any objective
     auto launch = [&](const size_t* cnt, const uint32_t* win) -> hipError_t {
-      const bool fork = cnt[2] && (cnt[3] || cnt[4]);
+      const bool fork = (cnt[2] || (ebits && cnt[1])) && (cnt[3] || cnt[4]);   // (with k4_enum_bits: the streaming kernel's few large regions beside its launch)
       hipStream_t s34 = fork ? aux : stream, s1 = stream;
       hipError_t e = hipSuccess;
       if (fork) { if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e; }
       if (cnt[1]) {   // (first, ahead of class 2 on its queue: the largest matrices have the longest restarts)
-        launch_k4_enum_reg(ebits ? -1 : 0, (unsigned)cnt[1], lds_need[1], s1, P, d_sp + s_off[1], (int32_t)n_w[1], per_of[1], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), d_rbest, redo_a, REDO_CAP);
+        launch_k4_enum_reg(0, (unsigned)cnt[1], lds_need[1], s1, P, d_sp + s_off[1], (int32_t)n_w[1], per_of[1], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(), d_rbest, redo_a, REDO_CAP);
         if (!win && !cnt[2]) launch_redo(redo_a, 0, s1);   // (with a class 2 launch behind it on this queue: one repair pass for both, below)
         if (!win && !cnt[2]) launch_k4_enum_resolve((unsigned)n_w[1], res_lds[1], s1, P, d_sp + s_off[1], d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());
       }
@@ -912,7 +916,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       // restarts on its own queue (the streaming class has the largest matrices, so the longest epilogues: they run beside the
       // register class's resolve instead of behind it)
       unsigned long long* const d_st = d_enum_st.as<unsigned long long>();
-      if (cnt[2]) launch_k4_enum_reg(ebits ? -1 : 32, (unsigned)cnt[2], lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, d_sb, d_st, d_rbest, redo_a, REDO_CAP);
+      if (cnt[2]) launch_k4_enum_reg(32, (unsigned)cnt[2], lds_need[2], stream, P, d_sp + s_off[2], (int32_t)n_w[2], per_of[2], d_jb, d_obj, d_sb, d_st, d_rbest, redo_a, REDO_CAP);
       if (cnt[3]) launch_k4_enum_reg(ebits ? -1 : 0, (unsigned)cnt[3], lds_need[3], s34, P, d_sp + s_off[3], (int32_t)n_w[3], per_of[3], d_jb, d_obj, d_sb, d_st, d_rbest, redo_b, REDO_CAP);
       if (!win && async_mode) {   // (the dense part of the stage ends here on both queues: the next batch's pileup waits for these)
         if (cnt[1] || cnt[2]) { if ((e = hipEventRecord(ev_gate[0], stream)) != hipSuccess) return e; gate_set[0] = true; }
