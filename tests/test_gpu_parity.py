@@ -381,15 +381,19 @@ def test_k0_thousands_of_records_beyond_the_tile_window(engine_cls, orc):
     assert c.size >= 2
 
 
-@pytest.mark.parametrize("hook", ["LCR_ENUM_FORCE_STREAM", "LCR_ENUM_FORCE_STREAM=2", "LCR_ENUM_FORCE_BIG", "LCR_POST_HOST", "LCR_POST_HALF", "LCR_K3_HITS=0"])
+@pytest.mark.parametrize("hook", ["LCR_ENUM_BITS=0", "LCR_ENUM_BITS=0+LCR_ENUM_FORCE_STREAM", "LCR_ENUM_BITS=0+LCR_ENUM_FORCE_STREAM=2", "LCR_ENUM_FORCE_STREAM",
+                                  "LCR_ENUM_FORCE_BIG", "LCR_POST_HOST", "LCR_POST_HALF", "LCR_K3_HITS=0"])
 def test_fallback_device_paths(engine_cls, orc, monkeypatch, hook):
-    """The size-dependent fallbacks of the phase stage give the same results as the default kernels:
-    enumeration restarts with LDS-streamed entries (=2: in the launch of the regions with a large LDS image) / from global
+    """The size-dependent fallbacks of the phase stage give the same results as the default kernels: the enumeration restarts one
+    per wave (LCR_ENUM_BITS=0: the kernels of rounds 2-4, register-resident /
+    with LDS-streamed entries (=2: in the launch of the regions with a large LDS image) / from global
     memory, post-phase epilogue on the host, the eight-wave epilogue of the chain regions (taken when a batch has more chain
     regions than the device has CUs), the fragment matrix's count pass walking the CIGARs itself instead of taking the hits
     the candidate stage's walk left (LCR_K3_HITS=0: the path of batches whose histograms came from the tiles)."""
-    hook, _, value = hook.partition("=")
-    monkeypatch.setenv(hook, value or "1")
+    for h in hook.split("+"):
+        name, _, value = h.partition("=")
+        monkeypatch.setenv(name, value or "1")
+    hook = hook.split("+")[-1].partition("=")[0]
     b = synth.make_batch("ont-drna", n_genes=3, gene_len=20000, depth=45, seed=14)
     full_check(engine_cls, orc, b, _abi.make_params("ont-drna", seed=14))
     full_check(engine_cls, orc, helpers.demo_batch(), _abi.make_params("hifi-masseq"), "chr20")
@@ -401,6 +405,25 @@ def test_fallback_device_paths(engine_cls, orc, monkeypatch, hook):
         regs = oracle_all(orc, b, p)
         assert sum(int(R.tie_census()[7]) for R in regs) >= 1
         full_check(engine_cls, orc, b, p)
+
+
+def test_enumeration_kernels_agree(engine_cls, monkeypatch):
+    """k4_enum_bits (eight restarts per wave as bit states, the default) and k4_enum_reg (one restart per wave) leave the same
+    objectives and states: identical results AND an identical tie census (every f64-scored row, every flip, every repair-list
+    entry is met by both), on batches with sigma ties and with tie-only steps."""
+    for b, p in ((synth.make_batch("ont-cdna", n_genes=10, gene_len=16000, depth=40, seed=7), _abi.make_params("ont-cdna", seed=2025)),
+                 (synth.make_batch("masseq", n_genes=12, gene_len=16000, depth=40, seed=2), _abi.make_params("hifi-masseq", seed=2025))):
+        got = {}
+        for v in ("1", "0"):
+            monkeypatch.setenv("LCR_ENUM_BITS", v)
+            E = engine_cls(0, p)
+            E.load_batch(b).run_all()
+            got[v] = (_result_bytes(E), dict(E.tie_census()))
+            E.close()
+        assert got["1"][0] == got["0"][0]
+        assert got["1"][1] == got["0"][1], (got["1"][1], got["0"][1])
+        assert got["1"][1]["sigma_f64"] > 0
+    monkeypatch.delenv("LCR_ENUM_BITS")
 
 
 @pytest.mark.parametrize("tie_arith,enum_mask,chain_mask", [("0", 0, 0), ("1", 8, 0), ("2", 9, 1), ("3", 15, 1)])

@@ -38,7 +38,7 @@ for tag in ("pmc_sq", "pmc_lds"):
             seen.add(key); n[k] += 1
     print("==", tag)
     for k in sorted(agg):
-        if any(s in k for s in ["k0_ops", "k0_desc", "k1_", "k2_hist", "k2_filter", "k3_walk", "k3_hits", "k4_enum_reg", "k4_enum_redo", "k4_enum_resolve", "k4_stage", "k4_chain", "k4_post"]):
+        if any(s in k for s in ["k0_ops", "k0_desc", "k1_", "k2_hist", "k2_filter", "k3_walk", "k3_hits", "k4_enum_reg", "k4_enum_bits", "k4_enum_redo", "k4_enum_resolve", "k4_stage", "k4_chain", "k4_post"]):
             print("  %-42s launches %3d  " % (k, n[k]) + "  ".join("%s=%.4g" % (a, b / n[k]) for a, b in sorted(agg[k].items())))
 PY
 cut -c1-200 $O/pmc_summary.txt
