@@ -368,7 +368,9 @@ int lcr_ctx_set_lock_dir(lcr_ctx*, const char* dir);
 
 /* Debug / test switches (the library reads no environment variable): key = "phase_prof", "post_host", "grid_min_entries",
  * "grid_generic", "grid_spec_lanes", "post_half", "enum_force_big", "enum_force_stream", "host_threads", "tie_arith", "timing_mask",
- * "k3_hits" (0: the fragment stage walks the CIGARs itself), "async_phase" (1: lcr_phase returns with its kernels in flight)
+ * "k3_hits" (0: the fragment stage walks the CIGARs itself), "async_phase" (1: lcr_phase returns with its kernels in flight),
+ * "enum_bits" (0: the enumeration restarts one per wave, the kernels of rounds 2-4; default 1: eight per wave as bit states),
+ * "grid_spec_batch" (0: the all-CU chain kernel's speculative half-rounds side by side on sub-grids; default 1: as eight bits of one state)
  * (bit k: only the kernel groups LCR_K_* k are timed when timing is enabled; 0 = all) (see PhaseDebug in
  * csrc/lcr_phase_host.h), "hist_tiles" (quality histograms from K0's records: 0 = when the survivors are dense, 1 = whenever the
  * preset allows, -1 = never).  Unknown key: LCR_E_ARG.  The defaults are the product behaviour. */
