@@ -120,7 +120,9 @@ def to_device(batch, torch, dev):
             a = a.view(np.int64)
         elif a.dtype == np.uint32:
             a = a.view(np.int32)
-        t[f] = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        # (through a page-locked copy: the runtime's path for pageable sources -- it pins the caller's pages chunk by chunk -- raised a
+        # device memory fault in one test-suite run out of five on this stack; liblcr stages its own host uploads for the same reason)
+        t[f] = torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(dev)
     reads, regions = batch.c_reads(), batch.c_regions()
     reads.mem = regions.mem = _abi.LCR_MEM_DEVICE
     for f in batch.FIELDS:

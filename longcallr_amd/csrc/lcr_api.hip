@@ -49,6 +49,7 @@ struct lcr_ctx {
   hipEvent_t ev_nnz = nullptr, ev_cand = nullptr, ev_ctl = nullptr;
   bool nnz_pending = false, cand_pending = false;
   HostBuf h_order;      // pinned: k0_pack raises it when a region's reads are not sorted by position
+  HostBuf h_up[2]; hipEvent_t ev_up[2] = {nullptr, nullptr}; bool up_busy[2] = {false, false};   // staging of pageable host batches (upload_bytes)
   HostBuf h_stage[4];   // pinned staging of lcr_candidates / lcr_fragments: survivor offsets, candidate records, keep flags, region rows
 
   // K2
@@ -113,11 +114,43 @@ DevParams to_dev(const lcr_params* p, float sor_thr) {
   return d;
 }
 
+// Host -> device copy of a caller's (pageable) array on the context's stream.  Page-locked sources (hipHostMalloc / hipHostRegister: what
+// lcr_load_batch_async asks for) go straight to the DMA engines.  Pageable ones are staged through two page-locked buffers of the context,
+// 8 MB at a time: the runtime's own path for them pins the caller's pages chunk by chunk, and on this stack (ROCm 7, MI355X) a device memory
+// fault inside that path (rocr VMFaultHandler under hsaCopyStagedOrPinned / addPinnedMem, the caller still inside hipMemcpyAsync) aborted one
+// test-suite run in five -- in torch's own .to() as well as here.  Small copies (<= 64 KB) are staged by the runtime itself either way.
+int upload_bytes(lcr_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t q = nullptr) {
+  if (!q) q = c->stream;
+  if (bytes <= 64 * 1024) { HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, q)); return LCR_OK; }
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost) {
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, q));
+    return LCR_OK;
+  }
+  (void)hipGetLastError();   // (an unregistered pointer is reported as an error by some runtimes)
+  constexpr size_t CH = 8u << 20;
+  for (int k = 0; k < 2; k++) {
+    HIPCHK(c, c->h_up[k].reserve(CH));
+    if (!c->ev_up[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming));
+  }
+  size_t off = 0;
+  for (int i = 0; off < bytes; i++, off += CH) {
+    const int k = i & 1;
+    const size_t n = std::min(CH, bytes - off);
+    if (c->up_busy[k]) HIPCHK(c, hipEventSynchronize(c->ev_up[k]));
+    memcpy(c->h_up[k].p, (const uint8_t*)src + off, n);
+    HIPCHK(c, hipMemcpyAsync((uint8_t*)dst + off, c->h_up[k].p, n, hipMemcpyHostToDevice, q));
+    HIPCHK(c, hipEventRecord(c->ev_up[k], q));
+    c->up_busy[k] = true;
+  }
+  return LCR_OK;
+}
+
 template <class T>
 int upload(lcr_ctx* c, DevBuf& buf, const T* src, size_t n, const T** dst, int mem) {
   if (mem == LCR_MEM_DEVICE) { *dst = src; return LCR_OK; }
   HIPCHK(c, buf.reserve(std::max<size_t>(n, 1) * sizeof(T)));
-  if (n) HIPCHK(c, hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  if (n) { const int rc = upload_bytes(c, buf.p, src, n * sizeof(T)); if (rc) return rc; }
   *dst = buf.as<T>();
   return LCR_OK;
 }
@@ -188,6 +221,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   if (c->ev_nnz) (void)hipEventDestroy(c->ev_nnz);
   if (c->ev_cand) (void)hipEventDestroy(c->ev_cand);
   if (c->ev_ctl) (void)hipEventDestroy(c->ev_ctl);
+  for (int k = 0; k < 2; k++) { if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]); c->h_up[k].release(); }
   HostBuf* hb[] = {&c->h_order, &c->h_nnz, &c->h_stage[0], &c->h_stage[1], &c->h_stage[2], &c->h_stage[3], &c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
   for (auto* b : hb) b->release();
   c->phase.release();
@@ -406,7 +440,7 @@ int lcr_load_batch_async(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg,
     HIPCHK(c, u.buf[i].reserve(std::max<size_t>(bytes, 1)));
     if (bytes) {
       if (!src) { c->err = "lcr_load_batch_async: null array"; return LCR_E_ARG; }
-      HIPCHK(c, hipMemcpyAsync(u.buf[i].p, src, bytes, hipMemcpyHostToDevice, c->up_stream));
+      { const int rc2 = upload_bytes(c, u.buf[i].p, src, bytes, c->up_stream); if (rc2) return rc2; }   // (page-locked arrays: asynchronous; pageable ones are staged)
     }
     *dst = u.buf[i].p;
     return LCR_OK;
@@ -867,8 +901,7 @@ int lcr_discover_regions(lcr_ctx* c, int32_t mem, int32_t n_reads, const int32_t
   const int32_t *d_s = ref_start, *d_e = ref_end;
   if (mem == LCR_MEM_HOST) {
     HIPCHK(c, c->rd_start.reserve((size_t)n_reads * 4)); HIPCHK(c, c->rd_end.reserve((size_t)n_reads * 4));
-    HIPCHK(c, hipMemcpyAsync(c->rd_start.p, ref_start, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->rd_end.p, ref_end, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
+    { int rc2 = upload_bytes(c, c->rd_start.p, ref_start, (size_t)n_reads * 4); if (rc2) return rc2; rc2 = upload_bytes(c, c->rd_end.p, ref_end, (size_t)n_reads * 4); if (rc2) return rc2; }
     d_s = c->rd_start.as<int32_t>(); d_e = c->rd_end.as<int32_t>();
   }
   // the window of the contig that reads cover at all (host spans: one loop here; device spans: one small reduction)
@@ -952,7 +985,7 @@ int lcr_get_read_records_device(lcr_ctx* c, const lcr_read_record** dev_rec, int
   if (c->phase.read_rec_stale) {   // regions that took the host epilogue (debug hook / fallback): rebuild from the host arrays
     std::vector<lcr_read_record> h((size_t)std::max(c->n_rows, 0));
     for (int r = 0; r < c->n_rows; r++) h[r] = lcr_read_record{r, c->phase.r_haplotag[r], c->phase.r_assignment[r], 0, c->phase.r_phase_set[r]};
-    if (c->n_rows) HIPCHK(c, hipMemcpy(c->phase.d_read_rec.p, h.data(), h.size() * sizeof(lcr_read_record), hipMemcpyHostToDevice));
+    if (c->n_rows) { const int rc2 = upload_bytes(c, c->phase.d_read_rec.p, h.data(), h.size() * sizeof(lcr_read_record)); if (rc2) return rc2; HIPCHK(c, hipStreamSynchronize(c->stream)); }
     c->phase.read_rec_stale = false;
   }
   *dev_rec = c->phase.d_read_rec.as<lcr_read_record>();

@@ -1035,7 +1035,7 @@ def test_device_resident_inputs_and_idempotence(engine_cls):
     ref_planes, ref_c = E.columns(), E.candidates()[0]
     dev = {f: torch.from_numpy(getattr(b, f).view(np.int64) if getattr(b, f).dtype == np.uint64 else
                                (getattr(b, f).view(np.int32) if getattr(b, f).dtype == np.uint32 else getattr(b, f))
-                               ).cuda() for f in b.FIELDS + ["start0", "len", "col_off", "read_begin", "ref"]}
+                               ).pin_memory().cuda() for f in b.FIELDS + ["start0", "len", "col_off", "read_begin", "ref"]}
     torch.cuda.synchronize()
     reads, regions = b.c_reads(), b.c_regions()
     reads.mem = regions.mem = _abi.LCR_MEM_DEVICE
