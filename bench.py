@@ -327,8 +327,12 @@ def seeds_stage(api, _abi, torch, device, wl, params, seeds, steps=15):
     out = {}
     for s in seeds:
         b = build_workload(wl, seed=s)
-        r = time_workload(api, _abi, torch, device, params, b, steps=steps, warm=4)
+        # (the faster of two passes of `steps`: a side stage of 15 steps once caught a 60 ms stall of the box -- 5.8 ms per step for a seed
+        # that runs at 1.7 --; the headline's 100 steps are reported as they come)
+        rs = [time_workload(api, _abi, torch, device, params, b, steps=steps, warm=4) for _ in range(2)]
+        r = min(rs, key=lambda x: x["ms_per_step"])
         out[str(s)] = {k: r[k] for k in ("columns", "aligned_bases", "ms_per_step", "sites_per_sec", "pileup_stage_ms", "pileup_stage_frac_of_hbm_peak", "candidates")}
+        out[str(s)]["ms_per_step_passes"] = [x["ms_per_step"] for x in rs]
     return out
 
 
