@@ -191,9 +191,9 @@ int lcr_ctx_set_stream(lcr_ctx*, void* hip_stream);
 int lcr_ctx_sync(lcr_ctx*);
 
 /* Bind a batch (reads + regions).  LCR_MEM_HOST inputs are copied to HBM here (the call returns when the copies are done) --
- * page-locked arrays (lcr_host_alloc / lcr_host_register) straight by DMA, pageable ones through two page-locked staging buffers of
- * the context, 8 MB at a time: ~10 GB/s instead of the link's rate, but not through the runtime's pin-the-caller's-pages path, which
- * raised device memory faults on ROCm 7 / MI355X.  LCR_MEM_DEVICE inputs are used in place and must outlive
+ * page-locked arrays (lcr_host_alloc / lcr_host_register) straight by DMA, pageable ones through page-locked staging buffers of
+ * the context, 8 MB at a time (four lanes on threads of their own for uploads of 64 MB and more: ~47 GB/s), not through the runtime's
+ * pin-the-caller's-pages path, which raised device memory faults on ROCm 7 / MI355X.  LCR_MEM_DEVICE inputs are used in place and must outlive
  * the calls below. */
 int lcr_load_batch(lcr_ctx*, const lcr_reads*, const lcr_regions*);
 /* Asynchronous input path for a caller whose reads are decoded on the host (the reference's loop, thread.rs:77-143, decodes the

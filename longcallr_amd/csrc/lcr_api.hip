@@ -1,6 +1,8 @@
 // lcr_api.hip — C ABI (include/lcr.h) over the HIP kernels: context, batch binding, stage drivers
 // and the small sequential host epilogues (dense-cluster sweep, candidate.rs:465-526).
 // There is NO CPU fallback: every stage launches HIP kernels and fails with LCR_E_DEVICE otherwise.
+#include <atomic>
+#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -49,7 +51,8 @@ struct lcr_ctx {
   hipEvent_t ev_nnz = nullptr, ev_cand = nullptr, ev_ctl = nullptr;
   bool nnz_pending = false, cand_pending = false;
   HostBuf h_order;      // pinned: k0_pack raises it when a region's reads are not sorted by position
-  HostBuf h_up[2]; hipEvent_t ev_up[2] = {nullptr, nullptr}; bool up_busy[2] = {false, false};   // staging of pageable host batches (upload_bytes)
+  static constexpr int UP_LANES = 4;   // staging lanes of pageable host uploads (upload_bytes): two page-locked 8 MB buffers + events each
+  HostBuf h_up[2 * UP_LANES]; hipEvent_t ev_up[2 * UP_LANES] = {}; bool up_busy[2 * UP_LANES] = {};
   HostBuf h_stage[4];   // pinned staging of lcr_candidates / lcr_fragments: survivor offsets, candidate records, keep flags, region rows
 
   // K2
@@ -115,7 +118,7 @@ DevParams to_dev(const lcr_params* p, float sor_thr) {
 }
 
 // Host -> device copy of a caller's (pageable) array on the context's stream.  Page-locked sources (hipHostMalloc / hipHostRegister: what
-// lcr_load_batch_async asks for) go straight to the DMA engines.  Pageable ones are staged through two page-locked buffers of the context,
+// lcr_load_batch_async asks for) go straight to the DMA engines.  Pageable ones are staged through page-locked buffers of the context,
 // 8 MB at a time: the runtime's own path for them pins the caller's pages chunk by chunk, and on this stack (ROCm 7, MI355X) a device memory
 // fault inside that path (rocr VMFaultHandler under hsaCopyStagedOrPinned / addPinnedMem, the caller still inside hipMemcpyAsync) aborted one
 // test-suite run in five -- in torch's own .to() as well as here.  Small copies (<= 64 KB) are staged by the runtime itself either way.
@@ -129,20 +132,41 @@ int upload_bytes(lcr_ctx* c, void* dst, const void* src, size_t bytes, hipStream
   }
   (void)hipGetLastError();   // (an unregistered pointer is reported as an error by some runtimes)
   constexpr size_t CH = 8u << 20;
-  for (int k = 0; k < 2; k++) {
+  // one staging lane = two buffers + their events; large uploads run UP_LANES lanes on threads of their own (one thread's memcpy is
+  // ~10 GB/s against the link's 50: 33 ms instead of 21 per C3 batch with a single lane)
+  const int lanes = bytes >= (64u << 20) ? lcr_ctx::UP_LANES : 1;
+  for (int k = 0; k < 2 * lanes; k++) {
     HIPCHK(c, c->h_up[k].reserve(CH));
     if (!c->ev_up[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming));
   }
-  size_t off = 0;
-  for (int i = 0; off < bytes; i++, off += CH) {
-    const int k = i & 1;
-    const size_t n = std::min(CH, bytes - off);
-    if (c->up_busy[k]) HIPCHK(c, hipEventSynchronize(c->ev_up[k]));
-    memcpy(c->h_up[k].p, (const uint8_t*)src + off, n);
-    HIPCHK(c, hipMemcpyAsync((uint8_t*)dst + off, c->h_up[k].p, n, hipMemcpyHostToDevice, q));
-    HIPCHK(c, hipEventRecord(c->ev_up[k], q));
-    c->up_busy[k] = true;
+  const size_t n_ch = (bytes + CH - 1) / CH;
+  std::atomic<int> bad{0};
+  auto lane_fn = [&](int w) {
+    (void)hipSetDevice(c->device);
+    int use = 0;
+    for (size_t i = (size_t)w; i < n_ch && !bad.load(std::memory_order_relaxed); i += (size_t)lanes, use ^= 1) {
+      const int k = 2 * w + use;
+      const size_t off = i * CH, n = std::min(CH, bytes - off);
+      hipError_t e = c->up_busy[k] ? hipEventSynchronize(c->ev_up[k]) : hipSuccess;
+      if (e == hipSuccess) {
+        memcpy(c->h_up[k].p, (const uint8_t*)src + off, n);
+        e = hipMemcpyAsync((uint8_t*)dst + off, c->h_up[k].p, n, hipMemcpyHostToDevice, q);
+      }
+      if (e == hipSuccess) e = hipEventRecord(c->ev_up[k], q);
+      if (e != hipSuccess) { bad.store((int)e); return; }
+      c->up_busy[k] = true;
+    }
+  };
+  if (lanes == 1) lane_fn(0);
+  else {
+    std::vector<std::thread> th;
+    try { for (int w = 1; w < lanes; w++) th.emplace_back(lane_fn, w); } catch (...) { }   // (no thread to be had: their chunks are taken below)
+    const int started = (int)th.size() + 1;
+    lane_fn(0);
+    for (auto& t : th) t.join();
+    for (int w = started; w < lanes; w++) lane_fn(w);
   }
+  if (bad.load()) { c->err = std::string("host upload: ") + hipGetErrorString((hipError_t)bad.load()); return LCR_E_DEVICE; }
   return LCR_OK;
 }
 
@@ -221,7 +245,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   if (c->ev_nnz) (void)hipEventDestroy(c->ev_nnz);
   if (c->ev_cand) (void)hipEventDestroy(c->ev_cand);
   if (c->ev_ctl) (void)hipEventDestroy(c->ev_ctl);
-  for (int k = 0; k < 2; k++) { if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]); c->h_up[k].release(); }
+  for (int k = 0; k < 2 * lcr_ctx::UP_LANES; k++) { if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]); c->h_up[k].release(); }
   HostBuf* hb[] = {&c->h_order, &c->h_nnz, &c->h_stage[0], &c->h_stage[1], &c->h_stage[2], &c->h_stage[3], &c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
   for (auto* b : hb) b->release();
   c->phase.release();
