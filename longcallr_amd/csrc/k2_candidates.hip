@@ -400,8 +400,8 @@ void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin,
 // filters: 2.2e5 survivors, 1.1e8 (read, survivor) observations, 47 ms of the walk above) the histograms are a second pileup, and
 // K0's per-tile records are still there.  HT_SPLIT workgroups per tile, each with its share of the tile's records, keep
 // hist[survivor][allele][q] as u16 pairs in LDS (HT_SLOTS survivors x 124 counters per pass over their records -- every survivor of a tile in one pass; a survivor's depth
-// is <= max_depth <= 65 535) and add their non-zero counters to the zeroed histograms at the end.  Sixteen lanes per record, a lane
-// per base, the first 64 bases of a record requested before any is used.  What this replaced, measured on C5: a workgroup per tile
+// is <= max_depth <= 65 535) and add their non-zero counters to the zeroed histograms at the end.  Eight lanes per record, four
+// consecutive bases per lane and load (round 5; before: sixteen lanes, a byte each).  What this replaced, measured on C5: a workgroup per tile
 // with a thread per record 26 ms, with sixteen lanes per record and 64 slots 30 ms -- the island's bases sit in 845 of its 3 843
 // tiles (6.4e5 bases each, up to four passes), so a workgroup per tile left most CUs idle behind a few long dependent chains.
 // ONT presets only: their end trim is already cut out of the records, the HiFi poly-A mask is not (those presets keep the walk).
@@ -410,7 +410,7 @@ void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin,
 #endif
 #ifndef HT_SPLIT
 #define HT_SPLIT 32   // (C5, round 4, 256 threads and 128 slots: 8 / 32 / 64 workgroups per tile 10.6 / 8.9 / 9.3 ms; 64 slots per pass: 10.0.  Round 5: 256 slots with
-                      // 256 threads 12.7 ms (two workgroups per CU), with 512 threads 8.3 (split 16: 8.4; 1 024 threads, split 8: 10.8); the tally without branches 5.9)
+                      // 256 threads 12.7 ms (two workgroups per CU), with 512 threads 8.3 (split 16: 8.4; 1 024 threads, split 8: 10.8); the tally without branches 5.9; a dword load of four bases per lane 4.6; eight lanes per record instead of sixteen 3.8 (four: 3.7))
 #endif
 #ifndef HT_BLOCK
 #define HT_BLOCK 512
@@ -423,7 +423,8 @@ k2_hist_tiles(BatchView b, const int32_t* __restrict__ tile_col0, const int32_t*
   if (cnt == 0) return;
   __shared__ uint32_t hp[HT_SLOTS * 62];           // counter (slot, allele, q) = half (slot * 124 + allele * 31 + q) & 1 of word >> 1
   __shared__ uint16_t slot_of[LCR_TILE];           // tile column -> survivor slot of this pass, 0xFFFF: none
-  const int tid = threadIdx.x, grp = tid >> 4, ln = tid & 15;
+  constexpr int HT_LANES = 8;   // lanes per record, four bases each (median M run of an ONT read: 26 bases)
+  const int tid = threadIdx.x, grp = tid / HT_LANES, ln = tid % HT_LANES;
   const int s0 = tile_off[tile], tc0 = tile_col0[tile];
   const int e0 = ent_off[tile];
   const int n_ent = ent_off[tile + 1] - e0;
@@ -443,11 +444,11 @@ k2_hist_tiles(BatchView b, const int32_t* __restrict__ tile_col0, const int32_t*
       const uint2 en = ents[e0 + (j >> 4)];
       return ((unsigned int)j & 15u) < en.y ? recs[en.x + ((unsigned int)j & 15u)] : ~0ull;
     };
-    unsigned long long nx = fetch(j_lo + grp), nx2 = fetch(j_lo + grp + HT_BLOCK / 16);
-    for (int j = j_lo + grp; j < j_hi; j += HT_BLOCK / 16) {
+    unsigned long long nx = fetch(j_lo + grp), nx2 = fetch(j_lo + grp + HT_BLOCK / HT_LANES);
+    for (int j = j_lo + grp; j < j_hi; j += HT_BLOCK / HT_LANES) {
       const unsigned long long rec = nx;
       nx = nx2;
-      nx2 = fetch(j + 2 * (HT_BLOCK / 16));
+      nx2 = fetch(j + 2 * (HT_BLOCK / HT_LANES));
       const unsigned long long off = rec & REC_OFF_MASK;
       const bool live = off < REC_KIND_N;          // (else: idle slot, D / I / N record: no base -- an empty range, no branch)
       const int col0 = (int)((rec >> 40) & 1023u), len = (int)((rec >> 50) & 1023u) + 1;
@@ -462,16 +463,20 @@ k2_hist_tiles(BatchView b, const int32_t* __restrict__ tile_col0, const int32_t*
         const uint32_t idx = slot * 124u + bi * 31u + q;
         if (in && acgt && slot != 0xFFFFu) atomicAdd(&hp[idx >> 1], 1u << (16 * (idx & 1u)));
       };
-      uint32_t bb[4], qq[4];
+      // a lane takes FOUR consecutive bases with one (unaligned) dword load each of the bases and the qualities -- two memory instructions
+      // per four bases instead of eight; the last three bytes of the batch's arrays are read by byte
+      for (int d0 = d_lo + 4 * ln; d0 <= d_hi; d0 += 4 * HT_LANES) {
+        const unsigned long long at = off + (unsigned long long)d0;
+        uint32_t bw, qw;
+        if (at + 4 <= (unsigned long long)b.n_bases) {
+          bw = *reinterpret_cast<const uint32_t*>(b.bases + at); qw = *reinterpret_cast<const uint32_t*>(b.quals + at);
+        } else {
+          bw = 0; qw = 0;
+          for (int t = 0; t < 4; t++) if (at + t < (unsigned long long)b.n_bases) { bw |= (uint32_t)b.bases[at + t] << (8 * t); qw |= (uint32_t)b.quals[at + t] << (8 * t); }
+        }
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int dd = d_lo + ln + 16 * t;
-        bb[t] = dd <= d_hi ? b.bases[off + dd] : 0u;
-        qq[t] = dd <= d_hi ? b.quals[off + dd] : 0u;
+        for (int t = 0; t < 4; t++) tally(d0 + t, d0 + t <= d_hi, (bw >> (8 * t)) & 0xFFu, (qw >> (8 * t)) & 0xFFu);
       }
-#pragma unroll
-      for (int t = 0; t < 4; t++) { const int dd = d_lo + ln + 16 * t; tally(dd, dd <= d_hi, bb[t], qq[t]); }
-      for (int dd = d_lo + ln + 64; dd <= d_hi; dd += 16) tally(dd, true, b.bases[off + dd], b.quals[off + dd]);
     }
     __syncthreads();
     uint32_t* out = hist + (int64_t)(s0 + p0) * 124;
