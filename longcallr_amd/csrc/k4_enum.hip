@@ -605,7 +605,6 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
   unsigned long long* sgb = (unsigned long long*)(lds + L.state + wave * L.stride);   // bit = 1: sigma == -1
   unsigned long long* Macc = sgb + (R + 63) / 64 + 1;
   uint32_t* tq = (uint32_t*)(Macc + 32);                 // queue of the wave's tied rows (sigma step)
-  uint32_t* tq_n = tq + ENUM_TQ;
   const int r_a = first_row[lane];
   // CK > 0: the lane's entries live in VGPRs; CK == 0: any share size, entries are re-read from LDS
   constexpr int NREG = CK > 0 ? CK : 1;
