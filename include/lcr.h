@@ -381,7 +381,9 @@ int lcr_debug_set(lcr_ctx*, const char* key, int64_t value);
 
 /* Timing: HIP-event time (ms) of the last launch of each kernel on the ctx's stream. */
 enum { LCR_K_SPANS = 0 /* K0: CIGAR decode + binning */, LCR_K_PILEUP, LCR_K_CAND_FILTER, LCR_K_CAND_HIST, LCR_K_CAND_GT,
-       LCR_K_FRAG_COUNT, LCR_K_FRAG_FILL, LCR_K_PHASE, LCR_NKERNELS };
+       LCR_K_FRAG_COUNT, LCR_K_FRAG_FILL, LCR_K_PHASE,
+       LCR_K_BIND /* lcr_load_batch: read headers, read / tile -> region tables, op blocks' first reads (part of the pileup stage) */,
+       LCR_K_BIND_TABLE /* lcr_load_batch of a device batch: region table + CIGAR layout check, before its one host wait */, LCR_NKERNELS };
 int lcr_enable_timing(lcr_ctx*, int on);
 int lcr_kernel_ms(lcr_ctx*, int kernel, float* ms);
 /* Bytes the pileup tally kernel (K1) of the last lcr_pileup has to move: read bases once (B) + 8-byte

@@ -17,8 +17,8 @@ PLANE_NAMES = ["a", "c", "g", "t", "n", "d", "ni", "fwd_a", "fwd_c", "fwd_g", "f
 F_RNA_EDIT, F_DENSE, F_HET, F_FOR_PHASING, F_HOM, F_SINGLE, F_NON_SELECTED, F_CAND_SOMATIC = (
     1, 2, 4, 8, 16, 32, 64, 128)
 
-(K_SPANS, K_PILEUP, K_CAND_FILTER, K_CAND_HIST, K_CAND_GT, K_FRAG_COUNT, K_FRAG_FILL, K_PHASE,
- NKERNELS) = range(9)
+(K_SPANS, K_PILEUP, K_CAND_FILTER, K_CAND_HIST, K_CAND_GT, K_FRAG_COUNT, K_FRAG_FILL, K_PHASE, K_BIND, K_BIND_TABLE,
+ NKERNELS) = range(11)
 
 
 class LcrReads(C.Structure):

@@ -140,6 +140,99 @@ void launch_k0_pack(const BatchView& b, ReadBin* out, int32_t* order_flag, hipSt
 }
 
 // ---------------------------------------------------------------------------------------------
+// The bind kernels of a batch, fused (round 6; VERDICT r05: five launches -- k0_region_setup, k0_cig_check, k0_tiles_read_region,
+// k0_pack, k0_block_reads -- were 44 us per step of a device-resident batch, outside the stage's timers).  Two launches remain:
+//   k0_bind_a  (before the host's one wait) block 0: the region table -- first tile of every region, the four small region arrays
+//              into pinned host memory --, blocks >= 1: the layout check of the flat op space (k0_cig_check's three verdicts);
+//   k0_bind_b  (behind it) a thread per read: region of the read (binary search in read_begin: a region's reads are a range),
+//              read -> region table, the 64-byte header K0 reads (ReadBin), the order check of k3_rows' precondition, the op blocks'
+//              first reads; the threads behind the reads fill the tile tables the same way (binary search in first_tile).
+__global__ void __launch_bounds__(1024) k0_bind_a(const int64_t* __restrict__ start0, const int32_t* __restrict__ len,
+                                                   const int64_t* __restrict__ col_off, const int32_t* __restrict__ read_begin, int32_t ng,
+                                                   int32_t* __restrict__ first_tile, int64_t* h_start0, int32_t* h_len, int64_t* h_col_off,
+                                                   int32_t* h_read_begin, const uint64_t* __restrict__ cig_off, const uint32_t* __restrict__ n_cig,
+                                                   int32_t nr, int64_t n_cigar, int32_t* out) {
+  const int tid = threadIdx.x;
+  if (blockIdx.x > 0) {   // (k0_cig_check) out (pinned, zeroed): [1] ops not back to back, [2] ops beyond n_cigar, uint64 at byte 16 / 24: first op, end
+    const int r = (int)(blockIdx.x - 1) * 1024 + tid;
+    if (r + 1 < nr && cig_off[r + 1] != cig_off[r] + n_cig[r]) out[1] = 1;
+    if (r < nr && (cig_off[r] > (uint64_t)n_cigar || (uint64_t)n_cig[r] > (uint64_t)n_cigar - cig_off[r])) out[2] = 1;
+    if (r == 0) { uint64_t* g = reinterpret_cast<uint64_t*>(out + 4); g[0] = cig_off[0]; g[1] = cig_off[nr - 1] + n_cig[nr - 1]; }
+    return;
+  }
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int lane = tid & 63, wave = tid >> 6;
+  if (h_start0) {
+    for (int g = tid; g < ng; g += 1024) { h_start0[g] = start0[g]; h_len[g] = len[g]; }
+    for (int g = tid; g <= ng; g += 1024) { h_col_off[g] = col_off[g]; h_read_begin[g] = read_begin[g]; }
+  }
+  if (tid == 0) { base_s = 0; first_tile[0] = 0; }
+  __syncthreads();
+  for (int g0 = 0; g0 < ng; g0 += 1024) {
+    const int g = g0 + tid;
+    const int n = g < ng ? (max(len[g], 0) + LCR_TILE - 1) / LCR_TILE : 0;
+    const int incl = wave_incl_scan(n);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = base_s;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    if (g < ng) first_tile[g + 1] = before + incl;
+    __syncthreads();
+    if (tid == 1023) base_s = before + incl;
+    __syncthreads();
+  }
+}
+void launch_k0_bind_a(const int64_t* start0, const int32_t* len, const int64_t* col_off, const int32_t* read_begin, int32_t ng,
+                      int32_t* first_tile, int64_t* h_start0, int32_t* h_len, int64_t* h_col_off, int32_t* h_read_begin,
+                      const uint64_t* cig_off, const uint32_t* n_cig, int32_t nr, int64_t n_cigar, int32_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(k0_bind_a, dim3(1 + (nr + 1023) / 1024), dim3(1024), 0, s, start0, len, col_off, read_begin, ng, first_tile, h_start0, h_len,
+                     h_col_off, h_read_begin, cig_off, n_cig, nr, n_cigar, out);
+}
+
+// last index g in [0, n) with a[g] <= x (a ascending, a[0] <= x): the region of a read / of a tile; empty regions are stepped over
+__device__ __forceinline__ int last_le(const int32_t* __restrict__ a, int n, int x) {
+  int lo = 0, hi = n;   // a[lo] <= x < a[hi] (a[n] = total > x)
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a[mid] <= x) lo = mid; else hi = mid; }
+  return lo;
+}
+__global__ void __launch_bounds__(LCR_BLOCK) k0_bind_b(BatchView b, ReadBin* __restrict__ rbin, int32_t* order_flag, int32_t* __restrict__ read_region,
+                                                        int32_t n_tiles, int32_t* __restrict__ tile_region, int32_t* __restrict__ tile_col0,
+                                                        uint64_t cig0, int32_t opb, int32_t n_blocks, int32_t* __restrict__ blk_first_read) {
+  const int i = blockIdx.x * LCR_BLOCK + threadIdx.x;
+  if (i >= b.n_reads) {
+    const int t = i - b.n_reads;
+    if (t < n_tiles) { const int g = last_le(b.region_first_tile, b.n_regions, t); tile_region[t] = g; tile_col0[t] = (t - b.region_first_tile[g]) * LCR_TILE; }
+    return;
+  }
+  const int r = i;
+  const int g = last_le(b.read_begin, b.n_regions, r);
+  read_region[r] = g;
+  const int32_t pos = b.pos[r];
+  // precondition of k3_rows / lcr_fragments (binary searches on pos): a region's reads are sorted by position
+  if (r > b.read_begin[g] && pos < b.pos[r - 1]) *order_flag = 1;
+  ReadBin h;
+  h.rel_pos = (int32_t)((int64_t)pos - b.start0[g]);
+  h.vec = b.len[g]; h.ftile = b.region_first_tile[g]; h.n_cig = (int32_t)b.n_cig[r];
+  h.gbase = b.col_off[g] + g;
+  h.seq_off = b.seq_off[r]; h.cig_off = b.cig_off[r];
+  h.lead = b.lead[r]; h.reb = b.seq_len[r] - b.trail[r];
+  h.flags = b.flags[r]; h.pad_ = 0; h.pad2_ = 0;
+  rbin[r] = h;
+  // first read of every op block (k0_ops.hip): a read writes the entries of the block borders its ops span
+  if (r == 0) blk_first_read[n_blocks] = b.n_reads - 1;
+  const uint64_t cb = h.cig_off - cig0, ce = cb + (uint32_t)h.n_cig;
+  for (uint64_t k = (cb + opb - 1) / opb; k * opb < ce; k++) blk_first_read[k] = r;
+}
+void launch_k0_bind_b(const BatchView& b, ReadBin* rbin, int32_t* order_flag, int32_t* read_region, int32_t n_tiles, int32_t* tile_region,
+                      int32_t* tile_col0, uint64_t cig0, int32_t opb, int32_t n_blocks, int32_t* blk_first_read, hipStream_t s) {
+  const int64_t n = (int64_t)b.n_reads + n_tiles;
+  if (n == 0) return;
+  hipLaunchKernelGGL(k0_bind_b, dim3((unsigned)((n + LCR_BLOCK - 1) / LCR_BLOCK)), dim3(LCR_BLOCK), 0, s, b, rbin, order_flag, read_region, n_tiles,
+                     tile_region, tile_col0, cig0, opb, n_blocks, blk_first_read);
+}
+
+// ---------------------------------------------------------------------------------------------
 // LDS planes of one tile (u32 each, LCR_TILE + 1 entries so that "end" markers at tile_len fit)
 enum {
   P_DIFF_DEPTH_F = 0,  // difference array: kept aligned bases of forward reads

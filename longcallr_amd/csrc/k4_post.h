@@ -202,9 +202,12 @@ __device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<
       int32_t* const fdirt = v.fdirt; int32_t* const minf = v.minf; int32_t* const ndraw = v.ndraw; int32_t* const gw = v.gwords;
       for (int ti = sc.tid(); ti < S; ti += sc.nt()) minf[ti] = -1;   // (not evaluated yet)
       for (int r = sc.tid(); r < nrow; r += sc.nt()) fdirt[r] = INT_MAX;
-      if (sc.tid() == 0) gw[0] = S;
+      // the round's end lives in gw[round & 1]: the word of the NEXT round is reset while stragglers may still be reading this round's
+      // (a workgroup leaves the barrier below microseconds after another; one word reset in place could be read as S by a late one)
+      if (sc.tid() == 0) { gw[0] = S; gw[1] = S; }
+      int rnd = 0;
       sc.sync();
-      for (;;) {
+      for (;; rnd ^= 1) {
         for (int ti = start + sc.wave(); ti < S; ti += sc.nwaves()) {   // (B) + (C): the same wave has member ti in every loop
           if (!(soflags[ti] & list_flag)) { if (lane == 0) rcode[ti] = 0; continue; }
           uint8_t code = rcode[ti];
@@ -259,10 +262,10 @@ __device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<
           }
 #pragma unroll
           for (int d = 32; d >= 1; d >>= 1) m = min(m, __shfl_xor(m, d, 64));
-          if (lane == 0) { minf[ti] = m; if (m < ti) atomicMin(&gw[0], ti); }
+          if (lane == 0) { minf[ti] = m; if (m < ti) atomicMin(&gw[rnd], ti); }
         }
         sc.sync();
-        const int end = gw[0];
+        const int end = gw[rnd];
         {   // draws of the successes of [start, t): every wave sums what it needs (a few hundred members at most)
           auto draws_before = [&](int t) -> unsigned long long {
             unsigned long long n = 0;
@@ -317,9 +320,9 @@ __device__ void post_run(SC& sc, const PostIn& in, const PostLut& lut, PostView<
           ctr += draws_before(end);
         }
         if (in.dbg_clk && sc.tid() == 0) in.dbg_clk[(size_t)v.g * 16 + (low_frac ? 12 : 11)] += 1;   // LCR_PHASE_PROF: rounds of the list
-        if (end < S) {   // the next round's marks start from a clean slate (everybody has read gw[0])
+        if (end < S) {   // the next round's marks start from a clean slate; its end word is the OTHER one (last read a whole round ago)
           for (int r = sc.tid(); r < nrow; r += sc.nt()) fdirt[r] = INT_MAX;
-          if (sc.tid() == 0) gw[0] = S;
+          if (sc.tid() == 0) gw[rnd ^ 1] = S;
         }
         sc.sync();
         start = end;

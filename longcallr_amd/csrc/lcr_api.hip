@@ -325,13 +325,13 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
     uint8_t* st = c->h_stage[0].as<uint8_t>();
     uint8_t* dst = nullptr;   // the pinned buffer as the device sees it
     HIPCHK(c, hipHostGetDevicePointer((void**)&dst, st, 0));
-    launch_k0_region_setup(rg->start0, rg->len, rg->col_off, rg->read_begin, ng, c->first_tile.as<int32_t>(), (int64_t*)dst,
-                           (int32_t*)(dst + o2), (int64_t*)(dst + o1), (int32_t*)(dst + o3), c->stream);
-    // the same wait brings the geometry of the flat op space: first op, end of the last read's ops, "CIGARs lie back to back"
+    // the same launch and the same wait bring the geometry of the flat op space: first op, end of the last read's ops, "CIGARs lie back to back"
     HIPCHK(c, c->h_order.reserve(64));
     memset(c->h_order.p, 0, 64);
     { int32_t* d_flag = nullptr; HIPCHK(c, hipHostGetDevicePointer((void**)&d_flag, c->h_order.p, 0));
-      launch_k0_cig_check(rd->cig_off, rd->n_cig, nr, rd->n_cigar, d_flag, c->stream); }
+      Timer t(c, LCR_K_BIND_TABLE);
+      launch_k0_bind_a(rg->start0, rg->len, rg->col_off, rg->read_begin, ng, c->first_tile.as<int32_t>(), (int64_t*)dst,
+                       (int32_t*)(dst + o2), (int64_t*)(dst + o1), (int32_t*)(dst + o3), rd->cig_off, rd->n_cig, nr, rd->n_cigar, d_flag, c->stream); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     if (ng) { memcpy(c->h_start0.data(), st, ng * sizeof(int64_t)); memcpy(c->h_len.data(), st + o2, ng * sizeof(int32_t)); }
@@ -377,7 +377,6 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   b.read_rend = c->read_rend.as<int32_t>();
   HIPCHK(c, c->read_region.reserve(std::max(nr, 1) * 4));
   b.read_region = c->read_region.as<int32_t>();
-  launch_k0_tiles_read_region(b, c->first_tile.as<int32_t>(), c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), c->read_region.as<int32_t>(), c->stream);
   b.region_first_tile = c->first_tile.as<int32_t>(); b.error_flag = nullptr;   // set by lcr_pileup
   HIPCHK(c, c->read_bin.reserve(std::max<size_t>(nr, 1) * sizeof(ReadBin)));
   // ---- the flat op space of K0 (k0_ops.hip): ops [cig0, cig0 + n_ops) of bv.cigar, read after read
@@ -423,12 +422,14 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   }
   c->cig0 = cig0; c->n_ops = (uint32_t)(cig_end - cig0);
   *c->h_order.as<int32_t>() = 0;   // (the previous batch's k0_pack finished long ago: every lcr_pileup waits behind it)
+  // ONE launch: read -> region and tile tables, the packed read headers, the order check, the op blocks' first reads (k0_bind_b)
   { int32_t* d_flag = nullptr; HIPCHK(c, hipHostGetDevicePointer((void**)&d_flag, c->h_order.p, 0));
-    launch_k0_pack(b, c->read_bin.as<ReadBin>(), d_flag, c->stream); }
-  { const int opb = launch_k0_opb();
+    const int opb = launch_k0_opb();
     const int32_t n_blocks = (int32_t)(((uint64_t)c->n_ops + opb - 1) / opb);
     HIPCHK(c, c->blk_first_read.reserve(((size_t)n_blocks + 2) * 4));
-    launch_k0_block_reads(c->read_bin.as<ReadBin>(), nr, c->cig0, opb, n_blocks, c->blk_first_read.as<int32_t>(), c->stream); }
+    Timer t(c, LCR_K_BIND);
+    launch_k0_bind_b(b, c->read_bin.as<ReadBin>(), d_flag, c->read_region.as<int32_t>(), c->n_tiles, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(),
+                     c->cig0, opb, n_blocks, c->blk_first_read.as<int32_t>(), c->stream); }
   // host batch: the caller's arrays are free again when this returns; device batch: no wait, the next stage queues
   // behind these kernels on the same stream (the arrays stay the caller's to keep alive, include/lcr.h)
   if (mem == LCR_MEM_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1044,7 +1045,7 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
   else if (k == "enum_force_stream") d.enum_force_stream = (int)value;
   else if (k == "host_threads") d.host_threads = (int)value;
   else if (k == "async_phase") d.async_phase = value != 0;
-  else if (k == "tie_arith") d.tie_arith = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2));
+  else if (k == "tie_arith") d.tie_arith = (int)std::max<int64_t>(0, std::min<int64_t>(value, 3));   // (3 = the default: all four classes in the enumeration branch)
   else if (k == "timing_mask") c->timing_mask = (uint32_t)value;
   else if (k == "plane_prefill") c->dbg_prefill = value != 0;
   else if (k == "bg_tiles") c->dbg_bg_tiles = (int)std::max<int64_t>(0, std::min<int64_t>(value, 4096));

@@ -142,6 +142,11 @@ void launch_k0_tiles(const int32_t* first_tile, int32_t n_regions, int32_t* tile
 void launch_k0_read_region(const BatchView& b, int32_t* read_region, hipStream_t s);
 void launch_k0_tiles_read_region(const BatchView& b, const int32_t* first_tile, int32_t* tile_region, int32_t* tile_col0, int32_t* read_region, hipStream_t s);   // launch_k0_tiles + launch_k0_read_region in one kernel
 void launch_k0_pack(const BatchView& b, ReadBin* out, int32_t* order_flag /* pinned host memory, device address */, hipStream_t s);
+void launch_k0_bind_a(const int64_t* start0, const int32_t* len, const int64_t* col_off, const int32_t* read_begin, int32_t ng,
+                      int32_t* first_tile, int64_t* h_start0, int32_t* h_len, int64_t* h_col_off, int32_t* h_read_begin,
+                      const uint64_t* cig_off, const uint32_t* n_cig, int32_t nr, int64_t n_cigar, int32_t* out, hipStream_t s);
+void launch_k0_bind_b(const BatchView& b, ReadBin* rbin, int32_t* order_flag, int32_t* read_region, int32_t n_tiles, int32_t* tile_region,
+                      int32_t* tile_col0, uint64_t cig0, int32_t opb, int32_t n_blocks, int32_t* blk_first_read, hipStream_t s);
 // K0 (k0_ops.hip): op-parallel CIGAR decode + per-tile record binning; load-time helpers
 void launch_k0_cig_check(const uint64_t* cig_off, const uint32_t* n_cig, int32_t nr, int64_t n_cigar, int32_t* out, hipStream_t s);
 void launch_k0_cig_compact(const uint32_t* cigar, const uint64_t* cig_off, const uint32_t* n_cig, const int32_t* new_off, int32_t nr,

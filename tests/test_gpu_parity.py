@@ -450,6 +450,21 @@ def test_tie_arithmetic_switch(engine_cls, orc, monkeypatch, tie_arith, enum_mas
             X = [orc.Region(b, g, p).set_fast(1).run_all(orc.MODE_EXACT) for g in range(b.n_regions)]
             T = [orc.Region(b, g, p).set_fast(1).set_tie_mask(orc.tie_mask(0, 0)).run_all(orc.MODE_TIE) for g in range(b.n_regions)]
             assert all(x.vcf_text("c") == t.vcf_text("c") and np.array_equal(x.phase_result()["haplotag"], t.phase_result()["haplotag"]) for x, t in zip(X, T))
+    # levels 2 and 3 differ only where a step's changes are all tie changes: the batch of test_tie_only_steps_take_the_repair_pass meets
+    # 16 of them -- level 3 must send them through the repair pass, level 2 must count them as unresolved (the switch used to
+    # clamp 3 to 2 and the cases above could not tell)
+    if tie_arith in ("2", "3"):
+        b = synth.make_batch("masseq", n_genes=12, gene_len=16000, depth=40, seed=1)
+        p = _abi.make_params("hifi-masseq", seed=2025)
+        full_check(engine_cls, orc, b, p)
+        E = engine_cls(0, p)
+        E.load_batch(b).run_all()
+        hc = E.tie_census()
+        E.close()
+        if tie_arith == "3":
+            assert hc["delta_step_f64"] >= 10 and hc["step_unresolved"] == 0 and hc["delta_unresolved"] == 0, hc
+        else:
+            assert hc["delta_step_f64"] == 0 and hc["step_unresolved"] >= 10, hc
 
 
 def test_fragment_rows_beyond_the_hit_lists(engine_cls, orc):
