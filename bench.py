@@ -132,31 +132,83 @@ def to_device(batch, torch, dev):
     return reads, regions, t
 
 
-def run_steps_simple(E, dev_batch, n):
+PILE_TIMERS = ("K_BIND_TABLE", "K_BIND", "K_SPANS", "K_PILEUP")   # the kernel groups of the pileup stage (bind kernels included: VERDICT r05)
+
+
+def consume(res, sink):
+    """What a caller does with a batch's results (thread.rs:204-221 pushes them onto the output queues): here the records are read --
+    candidates, phased reads -- and counted, so that every timed step delivers its batch's results to the host."""
+    sink[0] += int(res["cand"].size)
+    sink[1] += int(np.count_nonzero(res["assignment"]))
+    sink[2] += 1
+
+
+def pipelined_step(E, dev_batch, sink, have):
+    """One step of a long-lived worker: bind batch k, queue its pileup, THEN collect batch k - 1's results (lcr_collect_phase: with the
+    asynchronous phase stage this is where the stage in flight is waited for -- batch k's pileup is already queued beside its tails),
+    then candidates / fragments / phase of batch k.  With the synchronous stage the same calls in the same order cost nothing extra."""
+    E.load_batch(dev_batch)
+    E.fill_data_into_freq_vec()
+    if have[0]:
+        consume(E.collect_phase(), sink)
+    E.get_candidate_snps().get_fragments().phase()
+    have[0] = True
+
+
+def run_steps_simple(E, dev_batch, n, sink=None, have=None, stamps=None):
+    sink = sink if sink is not None else [0, 0, 0]
+    have = have if have is not None else [False]
     for _ in range(n):
-        E.load_batch(dev_batch)
-        E.fill_data_into_freq_vec().get_candidate_snps().get_fragments().phase()
+        pipelined_step(E, dev_batch, sink, have)
+        if stamps is not None:
+            stamps.append(time.perf_counter())
+    if have[0]:
+        consume(E.collect_phase(), sink); have[0] = False
     E.sync()
+    return sink
+
+
+def step_stats(stamps, t0):
+    """p50 / p99 / max of the host-side duration of the timed steps (stamps: perf_counter after every step's last call)"""
+    d = np.diff(np.array([t0] + list(stamps))) * 1e3
+    return {"p50": float(np.percentile(d, 50)), "p99": float(np.percentile(d, 99)), "max": float(d.max()), "max_over_median": float(d.max() / np.median(d)), "steps": int(d.size)}
+
+
+def pile_ms_of(E, _abi):
+    return sum(E.kernel_ms(getattr(_abi, k)) for k in PILE_TIMERS)
 
 
 ASYNC_PHASE = [True]   # (--sync-phase clears it: the workloads beside the headline one run the way the headline steps do)
 
 
-def time_workload(api, _abi, torch, device, params, batch, steps=20, warm=5):
-    """ms per step, pileup-stage time and roofline fraction, per-call wall times of one more pass: a workload beside the headline one"""
+def side_engine(api, _abi, device, params):
+    """The context of a side stage: a long-lived worker's (thread.rs:77-143 keeps one per rayon thread)"""
+    E = api.Engine(device, params, timing=tuple(getattr(_abi, k) for k in PILE_TIMERS))   # (events around the pileup stage only: every timer is two records on the stream)
+    return E
+
+
+def time_workload(api, _abi, torch, device, params, batch, steps=20, warm=5, E=None):
+    """ms per step (every step's results collected and read: pipelined_step), per-step p50 / p99 / max, pileup-stage time and roofline
+    fraction, per-call wall times of one more pass: a workload beside the headline one.  E: a context to reuse (one long-lived worker
+    across workloads, as a caller would hold it; profiles/r06_stall.txt: a context created right behind a fresh upload can lose 65-85 ms
+    once in its first steps)."""
     dv = to_device(batch, torch, torch.device("cuda", device))
-    E = api.Engine(device, params, timing=(_abi.K_SPANS, _abi.K_PILEUP))   # (events around the pileup stage only: every timer is two records on the stream)
+    own = E is None
+    if own:
+        E = side_engine(api, _abi, device, params)
     E.set_async_phase(ASYNC_PHASE[0])
     run_steps_simple(E, dv, warm)
     torch.cuda.synchronize()
+    sink, have, stamps, pile = [0, 0, 0], [False], [], []
     t0 = time.perf_counter()
-    pile = []
     for _ in range(steps):
-        E.load_batch(dv)
-        E.fill_data_into_freq_vec().get_candidate_snps().get_fragments().phase()
-        pile.append(E.kernel_ms(_abi.K_SPANS) + E.kernel_ms(_abi.K_PILEUP))
+        pipelined_step(E, dv, sink, have)
+        pile.append(pile_ms_of(E, _abi))
+        stamps.append(time.perf_counter())
+    consume(E.collect_phase(), sink)
     E.sync()
     dt = (time.perf_counter() - t0) / steps
+    assert sink[2] == steps
     E.set_async_phase(False)
     ms = {}
     for name, fn in (("lcr_load_batch", lambda: E.load_batch(dv)), ("lcr_pileup", E.fill_data_into_freq_vec),
@@ -168,7 +220,10 @@ def time_workload(api, _abi, torch, device, params, batch, steps=20, warm=5):
                pileup_stage_frac_of_hbm_peak=E.pileup_stage_bytes() / (float(np.mean(pile)) * 1e-3) / 8e12, api_ms=ms,
                candidates=int(E.candidates()[0].size), phasing_reads=int(fm["row_for_phasing"].sum()), fragment_nnz=int(fm["col"].size))
     out["phased_reads_per_sec"] = out["phasing_reads"] / ((ms["lcr_fragments"] + ms["lcr_phase"]) * 1e-3)
-    E.close()
+    out["step_ms"] = step_stats(stamps, t0)
+    out["results_collected_per_step"] = {"candidates": sink[0] // steps, "assigned_reads": sink[1] // steps}
+    if own:
+        E.close()
     del dv
     torch.cuda.empty_cache()
     return out
@@ -322,28 +377,34 @@ def batches_in_flight_stage(api, torch, device, params, dev_batch, cols, context
             "note": "%d contexts on %d host threads share the GPU (bench.py --inflight %d times the whole run this way)" % (contexts, contexts, contexts)}
 
 
-def seeds_stage(api, _abi, torch, device, wl, params, seeds, steps=15):
-    """generator seeds 1..5 per config.  Seed 1 is the headline run; the others: ms per step and pileup fraction."""
+def seeds_stage(api, _abi, torch, device, wl, params, seeds, steps=15, E=None):
+    """generator seeds 1..5 per config.  Seed 1 is the headline run; the others: ms per step and pileup fraction.
+    E: the headline run's context (ONE long-lived worker for all seeds, thread.rs:77-143)."""
     out = {}
+    own = E is None
+    if own:
+        E = side_engine(api, _abi, device, params)
     for s in seeds:
         b = build_workload(wl, seed=s)
-        # (the faster of two passes of `steps`: a side stage of 15 steps once caught a 60 ms stall of the box -- 5.8 ms per step for a seed
-        # that runs at 1.7 --; the headline's 100 steps are reported as they come)
-        rs = [time_workload(api, _abi, torch, device, params, b, steps=steps, warm=4) for _ in range(2)]
-        r = min(rs, key=lambda x: x["ms_per_step"])
-        out[str(s)] = {k: r[k] for k in ("columns", "aligned_bases", "ms_per_step", "sites_per_sec", "pileup_stage_ms", "pileup_stage_frac_of_hbm_peak", "candidates")}
-        out[str(s)]["ms_per_step_passes"] = [x["ms_per_step"] for x in rs]
+        r = time_workload(api, _abi, torch, device, params, b, steps=steps, warm=4, E=E)   # (one pass, reported as it comes)
+        out[str(s)] = {k: r[k] for k in ("columns", "aligned_bases", "ms_per_step", "sites_per_sec", "pileup_stage_ms", "pileup_stage_frac_of_hbm_peak", "candidates", "step_ms")}
+    if own:
+        E.close()
     return out
 
 
-def c4_share_stage(api, _abi, synth, torch, device, cpu=True):
+def c4_share_stage(api, _abi, synth, torch, device, cpu=True, E=None):
     """One GPU's share of BASELINE configs[3] (the workload N > 1 runs: 1 000 distinct MAS-Seq genes x 25 kb, 60x) at N = 1, and the
     CPU oracle pool on its first regions."""
     t0 = time.perf_counter()
     b = build_workload("c4")
     gen = time.perf_counter() - t0
     p = _abi.make_params("hifi-masseq", seed=2025)
-    out = time_workload(api, _abi, torch, device, p, b, steps=20, warm=5)
+    if E is not None:   # (the long-lived context of the run, with this workload's preset)
+        keep_params, E.params = E.params, p
+    out = time_workload(api, _abi, torch, device, p, b, steps=20, warm=5, E=E)
+    if E is not None:
+        E.params = keep_params
     out["workload"], out["generate_s"] = WORKLOADS["c4"][4] + ": 1 000 distinct genes, hifi-masseq preset", gen
     if cpu:
         hb = head_batch(b, 256)
@@ -634,7 +695,7 @@ def main():
     F = max(1, a.inflight)
     # HIP events around the pileup stage only during the timed steps (the roofline's measurement); the other kernel groups
     # are timed in one more pass behind them (every timer costs two event records on the stream: all eight, ~0.06 ms per step)
-    engines = [api.Engine(local, params, timing=(_abi.K_SPANS, _abi.K_PILEUP)) for _ in range(F)]
+    engines = [api.Engine(local, params, timing=tuple(getattr(_abi, k) for k in PILE_TIMERS)) for _ in range(F)]
     E = engines[0]
     # asynchronous phase stage: one context, one rank (at N > 1 every step hands its records to the gather, which collects them first)
     ASYNC_PHASE[0] = not a.sync_phase
@@ -650,12 +711,26 @@ def main():
     gathered = [0, 0]
     gstat = {"wait_s": 0.0, "bytes": 0, "batches": 0}   # this rank's share of the final gathers: time spent waiting for them, bytes sent
 
+    sink, have, stamps = [0, 0, 0], {}, []   # results read per step (consume), "this context has a batch's results to collect"
+
     def step(Ej):
+        # bind batch k, queue its pileup, collect and read batch k - 1's results (lcr_collect_phase: the pipelined getter, valid across the
+        # binding), then the other three stages of batch k.  At N > 1 the gathers take the records instead (publish, right behind phase).
         Ej.load_batch((reads, regions, keep))
         Ej.fill_data_into_freq_vec()
+        if G is None and have.get(id(Ej)):
+            consume(Ej.collect_phase(), sink)
         Ej.get_candidate_snps().get_fragments().phase()
-        # HIP events on the ctx stream, read after the step (lcr_pileup returns while K1 is still running)
-        return (Ej.kernel_ms(_abi.K_PILEUP), Ej.kernel_ms(_abi.K_SPANS))
+        have[id(Ej)] = True
+        # HIP events on the ctx stream, read after the step (lcr_pileup returns while K1 is still running); the bind kernels count
+        # (they read the 37R of the numerator)
+        return (Ej.kernel_ms(_abi.K_PILEUP), Ej.kernel_ms(_abi.K_SPANS) + Ej.kernel_ms(_abi.K_BIND) + Ej.kernel_ms(_abi.K_BIND_TABLE))
+
+    def collect_last():   # the last batch's results: collected and read before the clock stops
+        for Ej in engines:
+            if G is None and have.get(id(Ej)):
+                consume(Ej.collect_phase(), sink)
+                have[id(Ej)] = False
 
     def read_records_host(Ej):
         pr = Ej.phase_result()
@@ -696,6 +771,7 @@ def main():
             for k in range(n):
                 piles[k] = step(E)
                 publish(E)
+                stamps.append(time.perf_counter())
             return piles
         import threading
         turn = threading.Condition()
@@ -740,13 +816,16 @@ def main():
 
     run_steps(a.prewarm + a.warmup)
     drain()
+    collect_last()
     if dist is not None:
         dist.barrier()
     sync_all()
     gstat.update(wait_s=0.0, bytes=0, batches=0)
+    sink[:] = [0, 0, 0]; del stamps[:]
     t0 = time.perf_counter()
     pile_ms = run_steps(a.steps)
     drain()   # the last batch's records are on rank 0 before the clock stops
+    collect_last()   # (N = 1: every one of the K batches' results has been collected and read inside the timed region)
     sync_all()
     dt_own = time.perf_counter() - t0      # this rank's K steps + its share of the gathers, before the closing barrier
     if dist is not None:
@@ -776,6 +855,10 @@ def main():
                     "note": "ms_per_step = a rank's own K steps incl. its share of the gathers, before the closing barrier; `value` uses the slowest rank"}
 
     # stage breakdown (untimed extra pass: wall clock per ABI call with a sync after each, + HIP events)
+    step_ms = step_stats(stamps, t0) if (F == 1 and stamps) else None
+    collected = (sink[0] // max(sink[2], 1), sink[1] // max(sink[2], 1), sink[2])
+    if G is None and F == 1:
+        assert sink[2] == a.steps, (sink, a.steps)
     iso_ms = None
     if async_phase:   # the pileup stage's kernels once more WITHOUT the previous step's tails beside them: five synchronous steps
         E.set_async_phase(False)
@@ -829,6 +912,10 @@ def main():
         out = {
             "metric": "candidate_sites_per_sec", "value": int(tot[0]) * a.steps / dt, "unit": "sites/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "step_ms": step_ms,   # host-side duration of every timed step: p50 / p99 / max (profiles/r06_stall.txt)
+            "results_collected_per_step": ({"candidates": collected[0], "assigned_reads": collected[1], "batches": collected[2],
+                                            "how": "lcr_collect_phase of batch k - 1 behind lcr_pileup of batch k: host records read and counted inside the timed region"}
+                                           if G is None and F == 1 else "the RCCL gathers take every batch's records (config.gathered_records_last_batch)"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 in, u32 counts, f64 likelihoods, i64 fixed-point phase scores", "data": "synthetic",
             "config": {"workload": "%s; synthetic %s reads, %d distinct genes (regions) x %d bp per GPU at %.0fx mean aligned depth, "
@@ -844,11 +931,11 @@ def main():
                        "per_rank": per_rank,
                        "batches_in_flight_per_gpu": F,
                        "phase_stage": ("asynchronous (lcr_ctx_set_async_phase: lcr_phase returns with its kernels in flight, the next step's pileup is queued "
-                                       "behind its restarts and runs beside its resolve / post-phase tails; results collected by the next lcr_candidates); "
+                                       "behind its restarts and runs beside its resolve / post-phase tails; every batch's results collected by lcr_collect_phase before the next lcr_candidates); "
                                        "GPU_MAX_HW_QUEUES=%s" % os.environ.get("GPU_MAX_HW_QUEUES")) if async_phase else "synchronous",
                        "scaling_reference": ("the N = 1 point of THIS workload (one GPU's 1 000-gene share of C4) is `stages.c4_share.sites_per_sec` of the "
                                              "N = 1 line; the N = 1 headline `value` is C3, a different workload") if world > 1 else None},
-            "roofline": {"bound": "hbm", "kernel": "pileup stage = k0_ops + k1_tiles_a/b + k0_desc_bin + k1_pileup + k1_empty_tiles (+ k1_zonefix on HiFi presets): what replaces fill_data_into_freq_vec",
+            "roofline": {"bound": "hbm", "kernel": "pileup stage = k0_bind_a/b (read headers, tables) + k0_ops + k1_tiles_a/b + k0_desc_bin + k1_pileup + k1_empty_tiles (+ k1_zonefix on HiFi presets): what replaces fill_data_into_freq_vec",
                          "achieved": stage_bytes / (stage_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / 8000.0,
                          "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic if traffic else traffic_note,
@@ -861,7 +948,7 @@ def main():
                                  "HIP events on the ctx stream, rank 0, mean over the timed steps",
                          "k0_ops": {"avg_ms": avg_k0_ms, "algorithmic_bytes": 4 * int(batch.cigar.size) + 64 * batch.n_reads + 8 * n_items,
                                     "frac": (4 * int(batch.cigar.size) + 64 * batch.n_reads + 8 * n_items) / (avg_k0_ms * 1e-3) / 8e12,
-                                    "note": "4C + 64R read, 8 B per record item written"},
+                                    "note": "4C + 64R read, 8 B per record item written; avg_ms includes the two bind kernels of lcr_load_batch"},
                          "k1": {"algorithmic_bytes": pbytes, "avg_ms": avg_ms, "achieved": achieved, "frac": achieved / 8000.0,
                                 "note": "the tally with its tile passes and the chunk binning (k1_tiles_a/b + k0_desc_bin + k1_pileup + k1_empty_tiles): bases once + 8 B per record item + 53 B/column"}},
             "stages": {"pileup_plus_candidates_s": t_call, "fragments_plus_phase_s": t_phase,
@@ -886,16 +973,20 @@ def main():
             st["end_to_end_from_bam"] = end_to_end_stage(api, _abi, torch, local, batch, params,
                                                          (cols / cpu["value"]) if cpu else None, cpu["cores"] if cpu else None)
             st["host_fed"] = host_fed_stage(api, local, batch, params, cols)
-        E.close()
         del keep, reads, regions
         torch.cuda.empty_cache()
         if extras:
-            st["demo"] = demo_stage(api, _abi, local, cpu=not a.no_cpu_baseline)
+            # the other seeds and the C4 share run through the headline run's context: ONE long-lived worker, as the caller holds it
+            # (thread.rs:77-143); every pass is reported as it comes, with its per-step p50 / p99 / max
+            E.set_async_phase(ASYNC_PHASE[0] and F == 1)
             if wl == "c3" and a.seed == 1:
-                st["seeds"] = seeds_stage(api, _abi, torch, local, "c3", params, [2, 3, 4, 5])
+                st["seeds"] = seeds_stage(api, _abi, torch, local, "c3", params, [2, 3, 4, 5], E=E if F == 1 else None)
                 st["seeds"]["1"] = {"columns": cols, "aligned_bases": int(batch.bases.size), "ms_per_step": out["ms_per_step"], "sites_per_sec": out["value"],
-                                    "pileup_stage_ms": stage_ms, "pileup_stage_frac_of_hbm_peak": out["roofline"]["frac"], "candidates": int(cands.size)}
-            st["c4_share"] = c4_share_stage(api, _abi, synth, torch, local, cpu=not a.no_cpu_baseline)
+                                    "pileup_stage_ms": stage_ms, "pileup_stage_frac_of_hbm_peak": out["roofline"]["frac"], "candidates": int(cands.size), "step_ms": step_ms}
+            st["c4_share"] = c4_share_stage(api, _abi, synth, torch, local, cpu=not a.no_cpu_baseline, E=E if F == 1 else None)
+        E.close()
+        if extras:
+            st["demo"] = demo_stage(api, _abi, local, cpu=not a.no_cpu_baseline)
             st["c5"] = c5_stage(api, _abi, synth, torch, local, cpu=not a.no_cpu_baseline)
         print(json.dumps(out))
     if dist is not None:

@@ -249,6 +249,28 @@ typedef struct {
 } lcr_read_record;
 int lcr_get_read_records_device(lcr_ctx*, const lcr_read_record** dev_rec, int32_t* n_rows);
 
+/* Everything the last lcr_phase produced, in one call -- the getter of a PIPELINED caller (thread.rs:204-221 collects per region what
+ * the closure of thread.rs:93-201 returns).  The getters above answer for the batch that is bound: once the next batch has been bound
+ * (lcr_load_batch of a device batch, lcr_bind_batch) they return LCR_E_STATE.  This one stays valid across lcr_load_batch / lcr_bind_batch
+ * and lcr_pileup of the next batch -- none of them touches the buffers named here -- until the next lcr_candidates; with the
+ * asynchronous phase stage it is the call that waits for the stage in flight, so the order
+ *   lcr_phase(N); lcr_load_batch(N + 1); lcr_pileup(N + 1); lcr_collect_phase(results of N); lcr_candidates(N + 1); ...
+ * delivers every batch's results while batch N + 1's pileup runs beside batch N's resolve / post-phase tails.  Host arrays as in
+ * lcr_candidate_list / lcr_phase_result (candidates updated by the stage); dev_cand / dev_read_rec: the same records in HBM. */
+typedef struct {
+  int32_t n_regions, n_rows, n_cand, pad_;
+  const lcr_candidate* cand;            /* n_cand records, region by region                         */
+  const int32_t* cand_region_off;       /* n_regions + 1                                            */
+  const int32_t* row_region_off;        /* n_regions + 1: fragment rows of every region              */
+  const int8_t* haplotag;               /* n_rows, as lcr_phase_result                               */
+  const uint8_t* assignment;
+  const uint32_t* phase_set;
+  const double* objective;              /* n_regions                                                */
+  const lcr_candidate* dev_cand;        /* HBM: n_cand records                                      */
+  const lcr_read_record* dev_read_rec;  /* HBM: n_rows records                                      */
+} lcr_phase_collected;
+int lcr_collect_phase(lcr_ctx*, lcr_phase_collected* out);
+
 /* LD blocks of one region of the last lcr_phase (SNPFrag.ld_blocks, snpfrags.rs:29; built by divide_snps_into_blocks,
  * candidate.rs:615-747): block b = snp_idx[block_off[b] .. block_off[b + 1]) (candidate indices inside the region), in
  * the reference's block and node order.  Only regions with more than max_enum_snps candidates build blocks (the
@@ -348,7 +370,8 @@ int lcr_bam_write_phased(lcr_bam*, const char* out_path, int32_t n_regions, cons
 int lcr_bam_write_reads(const char* out_path, const char* contig, int64_t contig_len, const lcr_reads* rd, int32_t level, int32_t n_threads);
 
 /* Asynchronous phase stage (round 5; off by default).  on = 1: lcr_phase returns as soon as its kernels are queued -- on queues of the
- * stage's own, behind the fragment stage's kernels -- and its results are collected by whoever asks for them first: every getter
+ * stage's own, behind the fragment stage's kernels -- and its results are collected by whoever asks for them first: lcr_collect_phase
+ * (valid after the next batch has been bound: the pipelined order is spelled out there), every getter of the bound batch
  * (lcr_get_candidates*, lcr_get_phase_result, lcr_get_read_records_device, lcr_get_tie_census, lcr_get_ld_blocks), lcr_ctx_sync, the
  * next lcr_candidates / lcr_phase.  The caller's loop (thread.rs:93-201 per region; here per batch) can then bind the next
  * device-resident batch and queue its pileup at once: lcr_pileup's kernels are held back until the dense part of the stage in flight
@@ -379,7 +402,8 @@ int lcr_ctx_set_lock_dir(lcr_ctx*, const char* dir);
  * preset allows, -1 = never).  Unknown key: LCR_E_ARG.  The defaults are the product behaviour. */
 int lcr_debug_set(lcr_ctx*, const char* key, int64_t value);
 
-/* Timing: HIP-event time (ms) of the last launch of each kernel on the ctx's stream. */
+/* Timing: HIP-event time (ms) of the last launch of each kernel on the ctx's stream.  (LCR_K_PHASE brackets what lcr_phase puts on the
+ * ctx's stream: with the asynchronous phase stage that is the hand-over to the stage's queues only, not the stage.) */
 enum { LCR_K_SPANS = 0 /* K0: CIGAR decode + binning */, LCR_K_PILEUP, LCR_K_CAND_FILTER, LCR_K_CAND_HIST, LCR_K_CAND_GT,
        LCR_K_FRAG_COUNT, LCR_K_FRAG_FILL, LCR_K_PHASE,
        LCR_K_BIND /* lcr_load_batch: read headers, read / tile -> region tables, op blocks' first reads (part of the pileup stage) */,
@@ -391,6 +415,13 @@ int lcr_kernel_ms(lcr_ctx*, int kernel, float* ms);
  * stage (K0 + K1): B + 4C + 37R + (4*LCR_NPLANES + 1)*L.  See DESIGN.md. */
 int lcr_pileup_bytes(lcr_ctx*, int64_t* bytes);
 int lcr_pileup_stage_bytes(lcr_ctx*, int64_t* bytes);
+
+/* Memory given back by contexts (lcr_ctx_destroy, buffers that grow) is kept in a process-wide cache per device -- at most 24 GiB of HBM
+ * and 2 GiB of page-locked host memory each -- and handed to the next context: a worker that recreates its context per task does not
+ * churn hipMalloc / hipFree.  lcr_release_cached_memory returns all of it to the runtime (a process that shares the GPU with another
+ * allocator calls it between phases); lcr_set_cache_limits changes the two bounds (bytes per device; 0 = keep nothing). */
+int lcr_release_cached_memory(void);
+int lcr_set_cache_limits(int64_t device_bytes, int64_t host_bytes);
 
 const char* lcr_version(void);
 

@@ -91,6 +91,13 @@ class LcrPhaseResult(C.Structure):
                 ("assignment", C.c_void_p), ("phase_set", C.c_void_p), ("objective", C.c_void_p)]
 
 
+class LcrPhaseCollected(C.Structure):   # include/lcr.h: lcr_phase_collected
+    _fields_ = [("n_regions", C.c_int32), ("n_rows", C.c_int32), ("n_cand", C.c_int32), ("pad_", C.c_int32),
+                ("cand", C.c_void_p), ("cand_region_off", C.c_void_p), ("row_region_off", C.c_void_p),
+                ("haplotag", C.c_void_p), ("assignment", C.c_void_p), ("phase_set", C.c_void_p), ("objective", C.c_void_p),
+                ("dev_cand", C.c_void_p), ("dev_read_rec", C.c_void_p)]
+
+
 # presets: the code values of main.rs:272-396 (not the help text)
 PRESETS = {
     "hifi-isoseq": dict(platform=LCR_PLATFORM_HIFI, min_depth=6, min_phase_score=11.0, min_af=0.15,

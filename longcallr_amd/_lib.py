@@ -12,8 +12,8 @@ SYMBOLS = [
     "lcr_params_preset", "lcr_ctx_create", "lcr_ctx_destroy", "lcr_last_error", "lcr_ctx_set_stream",
     "lcr_ctx_sync", "lcr_ctx_set_lock_dir", "lcr_ctx_set_async_phase", "lcr_debug_set", "lcr_load_batch", "lcr_load_batch_async", "lcr_bind_batch",
     "lcr_host_alloc", "lcr_host_free", "lcr_host_register", "lcr_host_unregister", "lcr_pileup", "lcr_get_columns", "lcr_candidates",
-    "lcr_get_candidates", "lcr_get_candidates_device", "lcr_fragments", "lcr_get_fragmat", "lcr_phase", "lcr_get_phase_result", "lcr_get_read_records_device", "lcr_get_ld_blocks", "lcr_get_tie_census",
-    "lcr_enable_timing", "lcr_kernel_ms", "lcr_pileup_bytes", "lcr_pileup_stage_bytes", "lcr_discover_regions", "lcr_version",
+    "lcr_get_candidates", "lcr_get_candidates_device", "lcr_fragments", "lcr_get_fragmat", "lcr_phase", "lcr_get_phase_result", "lcr_get_read_records_device", "lcr_collect_phase", "lcr_get_ld_blocks", "lcr_get_tie_census",
+    "lcr_enable_timing", "lcr_kernel_ms", "lcr_pileup_bytes", "lcr_pileup_stage_bytes", "lcr_discover_regions", "lcr_version", "lcr_release_cached_memory", "lcr_set_cache_limits",
     "lcr_bam_open", "lcr_bam_open_keep", "lcr_bam_close", "lcr_bam_last_error", "lcr_bam_refs", "lcr_bam_n_records", "lcr_bam_resident", "lcr_bam_spans", "lcr_bam_batch", "lcr_bam_write_phased", "lcr_bam_write_reads",
 ]
 
@@ -69,6 +69,9 @@ def load():
     l.lcr_get_read_records_device.argtypes = [vp, C.POINTER(vp), C.POINTER(i32)]
     l.lcr_get_fragmat.argtypes = [vp, C.POINTER(_abi.LcrFragmat)]
     l.lcr_get_phase_result.argtypes = [vp, C.POINTER(_abi.LcrPhaseResult)]
+    l.lcr_collect_phase.argtypes = [vp, C.POINTER(_abi.LcrPhaseCollected)]
+    l.lcr_release_cached_memory.argtypes = []
+    l.lcr_set_cache_limits.argtypes = [C.c_int64, C.c_int64]
     l.lcr_get_tie_census.argtypes = [vp, C.POINTER(C.c_uint64)]
     l.lcr_get_ld_blocks.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]
     l.lcr_discover_regions.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.c_int64, C.POINTER(_abi.LcrRegionList)]

@@ -23,6 +23,14 @@ def _view(ptr, dtype, n):
     return np.frombuffer(buf, dtype=dtype, count=n).copy()
 
 
+def _view_nocopy(ptr, dtype, n):
+    """the context's own buffer as an array (no copy): valid until the call that rewrites it"""
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (np.dtype(dtype).itemsize * n)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
 _DEBUG_ENV = {"LCR_PHASE_PROF": "phase_prof", "LCR_POST_HOST": "post_host", "LCR_GRID_MIN_ENTRIES": "grid_min_entries",
               "LCR_GRID_GENERIC": "grid_generic", "LCR_GRID_SPEC_LANES": "grid_spec_lanes", "LCR_GRID_SPEC_BATCH": "grid_spec_batch", "LCR_ENUM_BITS": "enum_bits", "LCR_POST_HALF": "post_half", "LCR_ENUM_FORCE_BIG": "enum_force_big",
               "LCR_ENUM_FORCE_STREAM": "enum_force_stream", "LCR_HOST_THREADS": "host_threads", "LCR_HIST_TILES": "hist_tiles", "LCR_TIE_ARITH": "tie_arith", "LCR_PLANE_PREFILL": "plane_prefill", "LCR_BG_TILES": "bg_tiles", "LCR_K3_HITS": "k3_hits", "LCR_ASYNC_PHASE": "async_phase"}
@@ -173,6 +181,19 @@ class Engine:
         return dict(haplotag=_view(o.haplotag, np.int8, o.n_rows), assignment=_view(o.assignment, np.uint8, o.n_rows),
                     phase_set=_view(o.phase_set, np.uint32, o.n_rows),
                     objective=_view(o.objective, np.float64, o.n_regions))
+
+    def collect_phase(self, copy=False):
+        """lcr_collect_phase: everything the last phase() produced -- valid after the NEXT batch has been bound and its pileup queued (until
+        the next get_candidate_snps()): the getter of a pipelined caller under set_async_phase.  copy=False: the arrays ARE the context's
+        buffers (read them before the next get_candidate_snps())."""
+        o = _abi.LcrPhaseCollected()
+        self._chk(self.lib.lcr_collect_phase(self.h, C.byref(o)), "lcr_collect_phase")
+        v = _view if copy else _view_nocopy
+        return dict(cand=v(o.cand, _abi.CAND_DTYPE, o.n_cand), cand_region_off=v(o.cand_region_off, np.int32, o.n_regions + 1),
+                    row_region_off=v(o.row_region_off, np.int32, o.n_regions + 1),
+                    haplotag=v(o.haplotag, np.int8, o.n_rows), assignment=v(o.assignment, np.uint8, o.n_rows),
+                    phase_set=v(o.phase_set, np.uint32, o.n_rows), objective=v(o.objective, np.float64, o.n_regions),
+                    dev_cand=(int(o.dev_cand or 0), int(o.n_cand)), dev_read_rec=(int(o.dev_read_rec or 0), int(o.n_rows)))
 
     def ld_blocks(self, region):
         """SNPFrag.ld_blocks of one region after phase(): list of lists of candidate indices (reference order)."""

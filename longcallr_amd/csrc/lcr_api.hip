@@ -33,6 +33,7 @@ struct lcr_ctx {
   hipStream_t fill_stream = nullptr;           // zero fill of the count planes beside K0 (lcr_pileup)
   hipEvent_t ev_fill0 = nullptr, ev_fill1 = nullptr;
   int bound_slot = -1;
+  bool bound_host = false;   // the bound batch was copied into in_[] (LCR_MEM_HOST)
   DevBuf scan_tmp, read_region, read_bin, read_rend, tile_region, tile_col0, first_tile, k0_tile_fill, k0_items, tile_nbase, tile_order;
   DevBuf desc_tile, desc_val, chunks, chunk_off;   // K0's chunk descriptors, the same sorted by tile, their per-tile offsets
   DevBuf blk_first_read, read_scan, cig_compact, cig_off_new, cig_new_off32;   // K0 op blocks (k0_ops.hip)
@@ -79,6 +80,9 @@ struct lcr_ctx {
 
   // K4 + post-phase
   bool have_phase = false;
+  bool res_valid = false;   // lcr_collect_phase: the last lcr_phase's results (host + HBM) are intact -- they outlive lcr_load_batch / lcr_pileup of the next batch
+  int32_t res_ng = 0;
+  int phase_slot = -1;      // staging slot of the batch whose (asynchronous) phase stage may be in flight: -1 = the caller's own device arrays, -2 = in_[] (a host batch)
   PhaseHost phase;
   std::vector<int32_t> ld_off, ld_snps;   // lcr_get_ld_blocks
 
@@ -95,6 +99,44 @@ struct lcr_ctx {
   bool ev_valid[LCR_NKERNELS] = {};
   int64_t pileup_bytes = 0, stage_bytes = 0;
 };
+
+// ---- block cache (lcr_dev.h): freed device / page-locked blocks per device, first fit in size order
+#include <map>
+#include <mutex>
+namespace {
+struct BlockCache {
+  std::mutex mu;
+  std::multimap<size_t, void*> blocks[2][16];   // [host][device]: capacity -> block
+  size_t held[2][16] = {};
+  size_t limit[2] = {(size_t)24 << 30, (size_t)2 << 30};   // bytes kept per device: HBM blocks, page-locked host blocks
+};
+BlockCache& block_cache() { static BlockCache* c = new BlockCache(); return *c; }   // (never destroyed: contexts may outlive static destructors)
+}  // namespace
+void* lcr_cache_take(int host, size_t want, size_t* cap) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  BlockCache& bc = block_cache();
+  std::lock_guard<std::mutex> g(bc.mu);
+  auto& m = bc.blocks[host ? 1 : 0][dev];
+  auto it = m.lower_bound(want);
+  if (it == m.end() || it->first > 2 * want + (1u << 20)) return nullptr;
+  void* p = it->second;
+  *cap = it->first;
+  bc.held[host ? 1 : 0][dev] -= it->first;
+  m.erase(it);
+  return p;
+}
+bool lcr_cache_put(int host, void* p, size_t cap) {
+  int dev = 0;
+  if (!p || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+  BlockCache& bc = block_cache();
+  std::lock_guard<std::mutex> g(bc.mu);
+  const int h = host ? 1 : 0;
+  if (bc.held[h][dev] + cap > bc.limit[h]) return false;
+  bc.blocks[h][dev].emplace(cap, p);
+  bc.held[h][dev] += cap;
+  return true;
+}
 
 namespace {
 
@@ -184,6 +226,30 @@ int upload(lcr_ctx* c, DevBuf& buf, const T* src, size_t n, const T** dst, int m
 extern "C" {
 
 const char* lcr_version(void) { return "liblcr 0.1 (gfx950)"; }
+
+int lcr_release_cached_memory(void) {   // every block the cache holds goes back to the runtime (all devices)
+  BlockCache& bc = block_cache();
+  std::lock_guard<std::mutex> g(bc.mu);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (int dev = 0; dev < 16; dev++) {
+    if (bc.blocks[0][dev].empty() && bc.blocks[1][dev].empty()) continue;
+    (void)hipSetDevice(dev);
+    for (auto& kv : bc.blocks[0][dev]) (void)hipFree(kv.second);
+    for (auto& kv : bc.blocks[1][dev]) (void)hipHostFree(kv.second);
+    bc.blocks[0][dev].clear(); bc.blocks[1][dev].clear();
+    bc.held[0][dev] = bc.held[1][dev] = 0;
+  }
+  (void)hipSetDevice(cur);
+  return LCR_OK;
+}
+int lcr_set_cache_limits(int64_t device_bytes, int64_t host_bytes) {   // per device; 0 = keep nothing (every block is freed when it is given back)
+  if (device_bytes < 0 || host_bytes < 0) return LCR_E_ARG;
+  BlockCache& bc = block_cache();
+  std::lock_guard<std::mutex> g(bc.mu);
+  bc.limit[0] = (size_t)device_bytes; bc.limit[1] = (size_t)host_bytes;
+  return LCR_OK;
+}
 
 int lcr_params_preset(int preset, lcr_params* o) {
   if (!o || preset < 0 || preset > 3) return LCR_E_ARG;
@@ -311,6 +377,7 @@ int lcr_load_batch(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg) {
   if (rd->mem == LCR_MEM_HOST) { int rc = phase_settle(c); if (rc) return rc; }
   c->loaded = c->have_planes = c->have_cand = c->have_frag = c->have_phase = false;
   c->bound_slot = -1;
+  c->bound_host = rd->mem == LCR_MEM_HOST;
   const int nr = rd->n_reads, ng = rg->n_regions, mem = rd->mem;
   // host copies of the small per-region arrays
   c->h_start0.assign(ng, 0); c->h_len.assign(ng, 0); c->h_col_off.assign(ng + 1, 0); c->h_read_begin.assign(ng + 1, 0);
@@ -444,7 +511,9 @@ int lcr_load_batch_async(lcr_ctx* c, const lcr_reads* rd, const lcr_regions* rg,
   if (rd->mem != LCR_MEM_HOST || rg->mem != LCR_MEM_HOST) { c->err = "lcr_load_batch_async takes LCR_MEM_HOST batches (a device-resident batch needs no upload)"; return LCR_E_ARG; }
   if (rd->n_reads < 0 || rg->n_regions < 0 || rd->n_bases < 0 || rd->n_cigar < 0) { c->err = "bad batch header"; return LCR_E_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
-  { int rc = phase_settle(c); if (rc) return rc; }   // (the slot may hold the region table a phase stage in flight reads)
+  // a phase stage in flight reads the region table of ITS batch: it has to be done only if that batch lives in the slot rewritten here
+  // (two slots alternate: batch k + 1 is uploaded while batch k's stage runs -- lcr_collect_phase fetches batch k's results afterwards)
+  if (c->phase.pending && c->phase_slot == slot) { int rc = phase_settle(c); if (rc) return rc; }
   if (!c->up_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
   lcr_ctx::UploadSlot& u = c->up[slot];
   if (!u.ev) HIPCHK(c, hipEventCreateWithFlags(&u.ev, hipEventDisableTiming));
@@ -638,12 +707,14 @@ int lcr_get_columns(lcr_ctx* c, lcr_columns* out) {
 }
 
 static int cand_settle(lcr_ctx* c);
+static int read_records_fresh(lcr_ctx* c);
 
 int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   if (!c || !p) return LCR_E_ARG;
   if (!c->have_planes) { c->err = "lcr_candidates before lcr_pileup"; return LCR_E_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   { int rc = phase_settle(c); if (rc) return rc; }   // (the previous batch's phase stage reads the candidate / fragment buffers rewritten from here on)
+  c->res_valid = false;   // (its results are rewritten from here on: lcr_collect_phase had to come before this call)
   c->dp = to_dev(p, c->dp.sor_threshold);
   const int ng = c->bv.n_regions, nt = c->n_tiles;
   if (c->cand_pending && c->cand_dl_other) HIPCHK(c, hipEventSynchronize(c->ev_cand_dl));   // (a previous call's download nobody picked up: its source is rewritten below)
@@ -911,8 +982,15 @@ int lcr_phase(lcr_ctx* c, const lcr_params* p) {
   in.d_row_region_off = c->row_region_off.as<int32_t>(); in.d_start0 = c->bv.start0;
   Timer t(c, LCR_K_PHASE);
   int rc = c->phase.run(in, *p, c->stream, &c->err);
-  if (rc) return rc;
+  if (rc) {   // (an error part of the way through an asynchronous stage leaves kernels queued that read the candidate / fragment buffers)
+    if (c->phase.q_first) (void)hipStreamSynchronize(c->phase.q_first);
+    if (c->phase.side) (void)hipStreamSynchronize(c->phase.side);
+    if (c->phase.aux) (void)hipStreamSynchronize(c->phase.aux);
+    return rc;
+  }
   c->have_phase = true;
+  c->res_valid = true; c->res_ng = c->bv.n_regions;
+  c->phase_slot = c->bound_slot >= 0 ? c->bound_slot : (c->bound_host ? -2 : -1);
   return LCR_OK;
 }
 
@@ -1007,14 +1085,34 @@ int lcr_get_read_records_device(lcr_ctx* c, const lcr_read_record** dev_rec, int
   HIPCHK(c, hipSetDevice(c->device));
   { int rc = phase_settle(c); if (rc) return rc; }
   static_assert(sizeof(lcr_read_record) == 12, "lcr_read_record is 12 bytes");
-  if (c->phase.read_rec_stale) {   // regions that took the host epilogue (debug hook / fallback): rebuild from the host arrays
-    std::vector<lcr_read_record> h((size_t)std::max(c->n_rows, 0));
-    for (int r = 0; r < c->n_rows; r++) h[r] = lcr_read_record{r, c->phase.r_haplotag[r], c->phase.r_assignment[r], 0, c->phase.r_phase_set[r]};
-    if (c->n_rows) { const int rc2 = upload_bytes(c, c->phase.d_read_rec.p, h.data(), h.size() * sizeof(lcr_read_record)); if (rc2) return rc2; HIPCHK(c, hipStreamSynchronize(c->stream)); }
-    c->phase.read_rec_stale = false;
-  }
+  { int rc = read_records_fresh(c); if (rc) return rc; }
   *dev_rec = c->phase.d_read_rec.as<lcr_read_record>();
   *n_rows = c->n_rows;
+  return LCR_OK;
+}
+
+static int read_records_fresh(lcr_ctx* c) {   // regions that took the host epilogue (debug hook / fallback): the HBM records are rebuilt from the host arrays
+  if (!c->phase.read_rec_stale) return LCR_OK;
+  std::vector<lcr_read_record> h((size_t)std::max(c->n_rows, 0));
+  for (int r = 0; r < c->n_rows; r++) h[r] = lcr_read_record{r, c->phase.r_haplotag[r], c->phase.r_assignment[r], 0, c->phase.r_phase_set[r]};
+  if (c->n_rows) { const int rc2 = upload_bytes(c, c->phase.d_read_rec.p, h.data(), h.size() * sizeof(lcr_read_record)); if (rc2) return rc2; HIPCHK(c, hipStreamSynchronize(c->stream)); }
+  c->phase.read_rec_stale = false;
+  return LCR_OK;
+}
+
+// The pipelined consumer's getter: everything the last lcr_phase produced, valid although the NEXT batch has been bound
+// (lcr_load_batch / lcr_bind_batch) and its pileup queued -- none of those touch the buffers named here -- until the next lcr_candidates.
+int lcr_collect_phase(lcr_ctx* c, lcr_phase_collected* out) {
+  if (!c || !out) return LCR_E_ARG;
+  if (!c->res_valid) { c->err = "lcr_collect_phase: no phase results (call it after lcr_phase and before the next lcr_candidates)"; return LCR_E_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  { int rc = phase_settle(c); if (rc) return rc; }
+  { int rc = read_records_fresh(c); if (rc) return rc; }
+  out->n_regions = c->res_ng; out->n_rows = c->n_rows; out->n_cand = (int32_t)c->h_cand.size(); out->pad_ = 0;
+  out->cand = c->h_cand.data(); out->cand_region_off = c->h_cand_off.data(); out->row_region_off = c->h_row_region_off.data();
+  out->haplotag = c->phase.r_haplotag; out->assignment = c->phase.r_assignment; out->phase_set = c->phase.r_phase_set;
+  out->objective = c->phase.objective.data();
+  out->dev_cand = c->d_cand.as<lcr_candidate>(); out->dev_read_rec = c->phase.d_read_rec.as<lcr_read_record>();
   return LCR_OK;
 }
 

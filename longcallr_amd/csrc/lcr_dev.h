@@ -94,21 +94,32 @@ struct Survivor {
     }                                                                                  \
   } while (0)
 
+// Process-wide cache of the blocks contexts give back (lcr_api.hip).  A context that is destroyed hands its device and page-locked
+// buffers to the cache, the next context on that device takes them from there: a worker that recreates its context per task does not
+// churn hipMalloc / hipFree (GBs per context), and -- profiles/r06_stall.txt -- a context created right behind a large upload no longer
+// loses 65-85 ms in its first steps.  Bounded (LCR_CACHE_DEV_BYTES / LCR_CACHE_HOST_BYTES per device, beyond that blocks are freed);
+// lcr_release_cached_memory() returns everything to the runtime.
+void* lcr_cache_take(int host, size_t want, size_t* cap);   // a cached block with want <= cap <= 2 * want + 1 MiB of the current device, or nullptr
+bool lcr_cache_put(int host, void* p, size_t cap);          // false: the cache is full, the caller frees the block
+
 // growable device buffer
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
+    // (hipFree waits for the device before it releases a block: so does handing one to the cache -- a kernel in flight may still read it)
+    if (p) { (void)hipDeviceSynchronize(); if (!lcr_cache_put(0, p, cap)) (void)hipFree(p); }
     p = nullptr;
     cap = 0;
     size_t want = bytes + bytes / 8 + 256;
+    if ((p = lcr_cache_take(0, want, &cap)) != nullptr) return hipSuccess;
     hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want;
+    if (e == hipSuccess) cap = want; else p = nullptr;
     return e;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  // (the owner has drained its queues: lcr_ctx_destroy)
+  void release() { if (p && !lcr_cache_put(0, p, cap)) (void)hipFree(p); p = nullptr; cap = 0; }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 struct HostBuf {  // pinned
@@ -116,15 +127,16 @@ struct HostBuf {  // pinned
   size_t cap = 0;
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipHostFree(p);
+    if (p) { (void)hipDeviceSynchronize(); if (!lcr_cache_put(1, p, cap)) (void)hipHostFree(p); }
     p = nullptr;
     cap = 0;
     size_t want = bytes + bytes / 8 + 256;
+    if ((p = lcr_cache_take(1, want, &cap)) != nullptr) return hipSuccess;
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-    if (e == hipSuccess) cap = want;
+    if (e == hipSuccess) cap = want; else p = nullptr;
     return e;
   }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  void release() { if (p && !lcr_cache_put(1, p, cap)) (void)hipHostFree(p); p = nullptr; cap = 0; }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 

@@ -105,13 +105,15 @@ def _gather_names(name_off, blob, rows):
 
 
 def run(bam_path, ref_path, out_vcf, out_bam=None, preset="hifi-masseq", contigs=None, device=0, threads=0, seed=2025,
-        read_filter=None, devices=None, chunk_cost=2.0e9, **param_overrides):
+        read_filter=None, devices=None, chunk_cost=2.0e9, async_phase=True, **param_overrides):
     """BAM + FASTA (+ .fai) -> phased VCF and, with out_bam, the phased BAM.  Returns a dict of counts.
     devices: GPUs to use (default [device]); a contig's regions are cut into chunks (chunk_regions) that the engines --
     one context and one host thread per device -- take in turn (regions are independent units, thread.rs:77; the BAM
     decoder cuts the batches on the calling thread).  A GPU may be named more than once (devices=[0, 0, 0]): that many
     chunks are then in flight on it, each filling the queue gaps of the others' host round trips (bench.py
-    stages.batches_in_flight: +25 % at three).  The output does not depend on devices or chunk_cost."""
+    stages.batches_in_flight: +25 % at three).  async_phase: the engines run the asynchronous phase stage (a chunk's upload + pileup
+    beside the previous chunk's resolve / post-phase tails, results through lcr_collect_phase).  The output does not depend on devices,
+    chunk_cost or async_phase."""
     from concurrent.futures import ThreadPoolExecutor
     import threading
     fai = ref_path + ".fai"
@@ -133,31 +135,59 @@ def run(bam_path, ref_path, out_vcf, out_bam=None, preset="hifi-masseq", contigs
     free_lock = threading.Condition()
     stats = dict(contigs=0, regions=0, reads=0, candidates=0, vcf_records=0, chunks=0)
 
-    def work(batch, name, want_reads):   # one chunk on whichever engine is free
+    # Every engine is a long-lived worker with the ASYNCHRONOUS phase stage (lcr_ctx_set_async_phase, include/lcr.h): a chunk is uploaded
+    # into one of the context's two staging slots (lcr_load_batch_async + lcr_bind_batch: the device-resident form, which does not wait
+    # for the stage in flight), its pileup is queued, THEN the previous chunk's results are collected (lcr_collect_phase: the getter that
+    # outlives the binding) and turned into VCF text / read tags while this chunk's kernels run, then candidates / fragments / phase.
+    results = {}            # chunk index -> dict(text, n_cand[, hp, ps, names])
+    in_flight = [None] * len(engines)   # per engine: (chunk index, name, batch, want_reads, fragmat info) of the chunk whose phase stage runs
+    n_slot = [0] * len(engines)
+    for E in engines:
+        E.set_async_phase(async_phase)
+
+    def finish(k):          # collect engine k's chunk in flight
+        E = engines[k]
+        idx, name, batch, want_reads, fm = in_flight[k]
+        in_flight[k] = None
+        res = E.collect_phase()
+        cands = res["cand"]
+        lines = vcf.format_records(cands, name, params.min_phase_score)
+        out = dict(text=lines if isinstance(lines, str) else "".join(lines), n_cand=int(cands.size))
+        if want_reads:
+            asg = res["assignment"].astype(np.int32)
+            # thread.rs:204-214: every for_phasing fragment has an assignment entry (0 / 1 / 2), a phase set only if set
+            out["hp"] = np.where((fm["row_for_phasing"] != 0) | (asg != 0), asg, -1)
+            out["ps"] = res["phase_set"].copy()
+            out["names"] = _gather_names(batch.name_off, batch.name_blob, fm["row_read"].astype(np.int64))
+        results[idx] = out
+
+    def work(idx, batch, name, want_reads):   # one chunk on whichever engine is free
         with free_lock:
             while not free:
                 free_lock.wait()
             k = free.pop()
         try:
             E = engines[k]
-            E.load_batch(batch).run_all()
-            cands, _ = E.candidates()
-            lines = vcf.format_records(cands, name, params.min_phase_score)
-            out = dict(text=lines if isinstance(lines, str) else "".join(lines), n_cand=int(cands.size))
-            if want_reads:
-                fm, pr = E.fragmat(), E.phase_result()
-                asg = pr["assignment"].astype(np.int32)
-                # thread.rs:204-214: every for_phasing fragment has an assignment entry (0 / 1 / 2), a phase set only if set
-                out["hp"] = np.where((fm["row_for_phasing"] != 0) | (asg != 0), asg, -1)
-                out["ps"] = pr["phase_set"]
-                out["names"] = _gather_names(batch.name_off, batch.name_blob, fm["row_read"].astype(np.int64))
-            return out
+            slot = n_slot[k] & 1
+            n_slot[k] += 1
+            E.load_batch_async(batch, slot).bind_batch(slot)
+            E.fill_data_into_freq_vec()
+            if in_flight[k] is not None:
+                finish(k)
+            E.get_candidate_snps().get_fragments()
+            fm = None
+            if want_reads:      # rows of the fragment matrix (read of every row, num_hete_links >= min_linkers): known before the phase stage
+                f = E.fragmat()
+                fm = dict(row_for_phasing=f["row_for_phasing"], row_read=f["row_read"])
+            E.phase()
+            in_flight[k] = (idx, name, batch, want_reads, fm)
         finally:
             with free_lock:
                 free.append(k)
                 free_lock.notify()
 
-    results, regions_out = [], []
+    regions_out = []
+    n_chunks = 0
     with ThreadPoolExecutor(max_workers=len(engines)) as pool:
         pending = []
         for name, length in contig_lengths:
@@ -180,10 +210,16 @@ def run(bam_path, ref_path, out_vcf, out_bam=None, preset="hifi-masseq", contigs
                 batch = nb.batch(rid, [(s, l) for s, l, _ in chunk], wins, name_format="blob", **flt)
                 stats["reads"] += batch.n_reads; stats["chunks"] += 1
                 while len(pending) > len(engines):     # bounded: at most one batch waiting per engine
-                    results.append(pending.pop(0).result())
-                pending.append(pool.submit(work, batch, name, out_bam is not None))
+                    pending.pop(0).result()
+                pending.append(pool.submit(work, n_chunks, batch, name, out_bam is not None))
+                n_chunks += 1
                 regions_out.extend((rid, s, l) for s, l, _ in chunk)
-        results.extend(f.result() for f in pending)
+        for f in pending:
+            f.result()
+    for k in range(len(engines)):       # the last chunk of every engine
+        if in_flight[k] is not None:
+            finish(k)
+    results = [results[i] for i in range(n_chunks)]
     for E in engines + [scout]:
         E.close()
     text = "".join(r["text"] for r in results)

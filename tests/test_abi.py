@@ -93,7 +93,7 @@ def test_integration_md_rust_block_matches_the_header(tmp_path):
         fields = [("ref" if a.strip() == "ref_" else a.strip(), b) for a, b in re.findall(r"pub (\w+):\s*([^,}]+)", body)]
         structs[m.group(1)] = layout(fields)
     want = ["lcr_reads", "lcr_regions", "lcr_params", "lcr_columns", "lcr_candidate", "lcr_candidate_list", "lcr_fragmat",
-            "lcr_phase_result", "lcr_region_list", "lcr_read_filter", "lcr_read_record"]
+            "lcr_phase_result", "lcr_phase_collected", "lcr_region_list", "lcr_read_filter", "lcr_read_record"]
     assert sorted(structs) == sorted(want)
     lines = ['#include "lcr.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(){"]
     for name in want:

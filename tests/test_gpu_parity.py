@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import helpers
-from longcallr_amd import _abi, synth, vcf
+from longcallr_amd import _abi, api, synth, vcf
 
 pytestmark = pytest.mark.gpu
 
@@ -979,6 +979,15 @@ def test_driver_on_a_synthetic_two_contig_bam(engine_cls, tmp_path):
     assert st2["chunks"] == 6 and st2["reads"] == st["reads"] and st2["candidates"] == st["candidates"]
     assert open(out_vcf2).read() == open(out_vcf).read()
     assert bamio.bgzf_decompress(out_bam1) == bamio.bgzf_decompress(out_bam2)
+    # the engines' asynchronous phase stage (pipeline.run's default: a chunk's upload + pileup beside the previous chunk's tails, results
+    # through lcr_collect_phase) against the synchronous stage, one context over six single-region chunks: the same files
+    out_bam3, out_vcf3 = str(tmp_path / "p3.bam"), str(tmp_path / "syn3.vcf")
+    st3 = pipeline.run(bam, fa, out_vcf3, out_bam3, preset="ont-cdna", threads=4, seed=2025, chunk_cost=1.0, async_phase=False)
+    out_bam4, out_vcf4 = str(tmp_path / "p4.bam"), str(tmp_path / "syn4.vcf")
+    st4 = pipeline.run(bam, fa, out_vcf4, out_bam4, preset="ont-cdna", threads=4, seed=2025, chunk_cost=1.0, async_phase=True)
+    assert st3["chunks"] == st4["chunks"] == 6 and st3 == st4
+    assert open(out_vcf3).read() == open(out_vcf4).read() == open(out_vcf).read()
+    assert bamio.bgzf_decompress(out_bam3) == bamio.bgzf_decompress(out_bam4) == bamio.bgzf_decompress(out_bam1)
 
 
 @pytest.mark.parametrize("max_enum_snps", [0, 3, 12])
@@ -1497,6 +1506,35 @@ def test_bench_under_the_launcher_with_one_rank():
     assert line["n_gpus"] == 1 and line["value"] > 0
 
 
+def test_bench_dry_run_at_eight_ranks():
+    """The first real 8-GPU line must not fail on shard construction or capacity negotiation (thread.rs:77,204-221):
+    `bench.py --gpus 8 --dist-backend gloo --quick` -- EIGHT ranks sharing the one GPU, one list of 8 x 16 distinct MAS-Seq genes through
+    shard.assign_regions (LPT on len x max_coverage), both RecordGathers every step, the per-rank block with eight entries -- and the records
+    gathered on rank 0 == what ONE rank gathers over the whole list (same genes: the list depends on world x genes only)."""
+    import json
+    import os
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    common = ["--dist-backend", "gloo", "--quick", "--workload", "c4", "--steps", "2", "--warmup", "1", "--prewarm", "1", "--gene-len", "12000"]
+    r8 = _torchrun([bench, "--gpus", "8", "--genes", "16"] + common, nproc=8, timeout=900)
+    assert r8.returncode == 0, r8.stdout[-2000:] + r8.stderr[-4000:]
+    l8 = json.loads([x for x in r8.stdout.splitlines() if x.startswith("{")][-1])
+    pr = l8["config"]["per_rank"]
+    assert l8["n_gpus"] == 8 and pr["world_size"] == 8 and pr["backend"] == "gloo"
+    for k in ("ms_per_step", "columns", "aligned_bases", "reads", "regions", "lpt_cost", "gather_wait_ms_per_step", "gather_bytes_per_step"):
+        assert len(pr[k]) == 8, k
+    assert sum(pr["regions"]) == 128 and min(pr["regions"]) >= 1 and min(pr["gather_bytes_per_step"]) > 0
+    assert pr["lpt_cost_imbalance_max_over_mean"] < 1.5      # LPT over 128 genes on 8 ranks
+    g8 = l8["config"]["gathered_records_last_batch"]
+    assert g8["candidates"] == l8["config"]["candidates"] > 0 and g8["reads"] > 0
+    r1 = _torchrun([bench, "--gpus", "1", "--genes", "128"] + common, nproc=1, timeout=900)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    l1 = json.loads([x for x in r1.stdout.splitlines() if x.startswith("{")][-1])
+    g1 = l1["config"]["gathered_records_last_batch"]
+    assert g1 == g8, (g1, g8)
+    for k in ("columns", "aligned_bases", "reads", "candidates", "fragment_nnz", "phasing_reads"):
+        assert l1["config"][k] == l8["config"][k], k
+
+
 def test_asynchronous_phase_stage(engine_cls):
     """lcr_ctx_set_async_phase(ctx, 1): lcr_phase returns with its kernels in flight on the stage's own queues; the next batch is
     bound and its pileup queued behind the stage's restarts (beside its tails), every getter / the next lcr_candidates collects the
@@ -1530,6 +1568,61 @@ def test_asynchronous_phase_stage(engine_cls):
         Ea.load_batch(b).run_all()
     assert _result_bytes(Ea) == want[-1][0]
     Es.close(); Ea.close()
+
+
+def test_pipelined_collect_of_the_asynchronous_stage(engine_cls):
+    """with the asynchronous stage the per-batch getters answer LCR_E_STATE once the next batch is bound -- lcr_collect_phase is
+    the getter that outlives the binding.  Order of a pipelined caller: phase(k); load(k + 1); pileup(k + 1); collect (-> k); candidates(k + 1) ...
+    Every batch's collected candidates, per-row results, objectives and both HBM record arrays == the synchronous engine's, byte for byte;
+    the per-batch getters refuse after the binding; collect refuses after the next lcr_candidates."""
+    import torch
+    import bench as _bench
+    p = _abi.make_params("ont-cdna", seed=77)
+    bs = [synth.make_batch("ont-cdna", n_genes=n, gene_len=10000, depth=35, seed=160 + k) for k, n in enumerate((4, 6, 3, 5))]
+    dev = torch.device("cuda", 0)
+    dv = [_bench.to_device(b, torch, dev) for b in bs]
+    Es = engine_cls(0, p)
+    want = []
+    for d in dv:
+        Es.load_batch(d).run_all()
+        c, off = Es.candidates(); pr = Es.phase_result(); fm = Es.fragmat()
+        pc, nc = Es.candidates_device(); prr, nr = Es.read_records_device()
+        want.append(dict(cand=c.tobytes(), off=off.tobytes(), rro=fm["row_region_off"].tobytes(), tag=pr["haplotag"].tobytes(), asg=pr["assignment"].tobytes(),
+                         ps=pr["phase_set"].tobytes(), obj=pr["objective"].tobytes(), n=(nc, nr)))
+    Es.close()
+
+    def dev_bytes(ptr_n, itemsize):
+        ptr, n = ptr_n
+        out = torch.empty(n * itemsize, dtype=torch.uint8, device=dev)
+        if n:
+            import ctypes as C
+            hip = C.CDLL("libamdhip64.so")
+            assert hip.hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), C.c_size_t(n * itemsize), 3) == 0
+        return out.cpu().numpy().tobytes()
+
+    for async_on in (True, False):
+        Ea = engine_cls(0, p)
+        Ea.set_async_phase(async_on)
+        Ea.load_batch(dv[0]).run_all()
+        for k in range(1, len(dv) + 1):
+            if k < len(dv):
+                Ea.load_batch(dv[k]).fill_data_into_freq_vec()
+                with pytest.raises(api.LcrError):      # the bound batch has no phase results: the per-batch getters refuse
+                    Ea.phase_result()
+            r = Ea.collect_phase(copy=True)            # batch k - 1
+            w = want[k - 1]
+            assert r["cand"].tobytes() == w["cand"] and r["cand_region_off"].tobytes() == w["off"] and r["row_region_off"].tobytes() == w["rro"], k
+            assert r["haplotag"].tobytes() == w["tag"] and r["assignment"].tobytes() == w["asg"] and r["phase_set"].tobytes() == w["ps"] and r["objective"].tobytes() == w["obj"], k
+            assert (r["dev_cand"][1], r["dev_read_rec"][1]) == w["n"]
+            assert dev_bytes(r["dev_cand"], _abi.CAND_DTYPE.itemsize) == w["cand"]
+            rec = np.frombuffer(dev_bytes(r["dev_read_rec"], 12), dtype=_abi.READ_REC_DTYPE)
+            assert rec["haplotag"].tobytes() == w["tag"] and rec["assignment"].tobytes() == w["asg"] and rec["phase_set"].tobytes() == w["ps"]
+            if k < len(dv):
+                Ea.get_candidate_snps()
+                with pytest.raises(api.LcrError):      # its buffers are being rewritten
+                    Ea.collect_phase()
+                Ea.get_fragments().phase()
+        Ea.close()
 
 
 def test_region_discovery_gpu(engine_cls):
