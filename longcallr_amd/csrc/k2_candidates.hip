@@ -348,39 +348,55 @@ k2_compact(BatchView b, DevParams prm, BinomTable bt, const int32_t* __restrict_
 // survivors): per read the first LCR_HITS (survivor, base, raw quality) hits in survivor order -- every aligned base that faces a
 // survivor, masked or not (the fragment walk takes every aligned base) -- and the hit count; reads with more hits than the list
 // holds go to a list of their own (k3 walks those again).
+// Round 6: the chain of dependent loads per read is four deep instead of seven -- read header + reference end | survivor offsets of the
+// first / last TILE of the read's span (tile_off: k2_compact's offsets; no region look-up, no scan from the region's first survivor) beside
+// the read's first 64 CIGAR ops, requested before anyone knows whether the read covers a survivor | the survivors' columns | base + quality.
 __global__ void __launch_bounds__(LCR_BLOCK)
 k2_hist(BatchView b, DevParams prm, const ReadBin* __restrict__ rbin, const Survivor* __restrict__ sv,
-        const int32_t* __restrict__ sv_region_off, uint32_t* __restrict__ hist, int32_t* __restrict__ hit_cnt, uint2* __restrict__ hit_list,
+        const int32_t* __restrict__ tile_off, int32_t n_tiles, int32_t n_sv, uint32_t* __restrict__ hist, int32_t* __restrict__ hit_cnt, uint2* __restrict__ hit_list,
         int32_t* __restrict__ ovf_cnt, int32_t* __restrict__ ovf_list) {
   const int r = (blockIdx.x * LCR_BLOCK + threadIdx.x) >> 4;
   const bool live = r < b.n_reads;
   const int rr = live ? r : 0;
-  const int g = region_of_read(b, rr);
-  const int s_lo = sv_region_off[g], s_hi = sv_region_off[g + 1];
   const ReadBin h = rbin[rr];
+  const int rend = b.read_rend[rr];
   const uint8_t* __restrict__ seq = b.bases + h.seq_off;
   const uint8_t* __restrict__ qual = b.quals + h.seq_off;
   const int l16 = threadIdx.x & 15, rbase = threadIdx.x & 48;
+  // survivors of the tiles the read's span [max(rel_pos, 0), min(rend, vec)) touches: a contiguous index range (survivors are ordered
+  // by tile, then by column)
+  const int key = h.rel_pos > 0 ? h.rel_pos : 0, rend_c = min(rend, h.vec);
+  const bool span = live && rend_c > key;
+  const int t0 = h.ftile + (int)((unsigned int)key / (unsigned int)LCR_TILE), t1 = h.ftile + (int)((unsigned int)(max(rend_c, 1) - 1) / (unsigned int)LCR_TILE) + 1;
+  uint32_t pre[4];
+  {
+    const uint32_t* __restrict__ cg = b.cigar + h.cig_off;
+#pragma unroll
+    for (int k = 0; k < 4; k++) pre[k] = (span && (uint32_t)(16 * k + l16) < (uint32_t)h.n_cig) ? cg[16 * k + l16] : 0u;
+  }
+  const int s_lo = span ? tile_off[t0] : 0, s_hi = span ? (t1 < n_tiles ? tile_off[t1] : n_sv) : 0;
   int nh = 0;   // hits of this read so far (row-uniform)
   uint2* const hl = hit_cnt ? hit_list + (size_t)rr * LCR_HITS : nullptr;   // (hit_cnt == nullptr: no hit lists asked for)
-  row16_walk_sites(b, live && s_lo < s_hi, h, b.read_rend[rr], s_lo, s_hi,
-    [&](int i) { return sv[i].col; },
-    [&](int cur, int c, bool hit) {   // lane <-> survivor
+  int cur, s_end;
+  auto site_col = [&](int i) { return sv[i].col; };
+  row16_find_sites(span && s_lo < s_hi, h, rend, s_lo, s_hi, site_col, &cur, &s_end);
+  row16_walk_range(b, h, cur, s_end, pre, site_col,
+    [&](int cur_s, int c, bool hit) {   // lane <-> survivor
       uint8_t base = 0, rq = 0;
       if (hit) { base = seq[c]; rq = qual[c]; }
       if (hl) {
         const unsigned int hm = (unsigned int)(__ballot(hit) >> rbase) & 0xffffu;
         const int at = nh + __popc(hm & ((1u << l16) - 1u));
-        if (hit && at < LCR_HITS) hl[at] = make_uint2((uint32_t)cur, (uint32_t)base | ((uint32_t)rq << 8));
+        if (hit && at < LCR_HITS) hl[at] = make_uint2((uint32_t)cur_s, (uint32_t)base | ((uint32_t)rq << 8));
         nh += __popc(hm);
       }
       if (!hit) return;
       const uint8_t bq = rq < 30 ? rq : 30;  // MAX_BASE_QUALITY (util.rs:711-715)
       bool masked = false;
       if (in_end_zone(c, h.lead, h.reb, prm.dist_to_end))
-        masked = prm.ont ? true : polya_masked(seq, b.seq_len[rr], c, prm.polya_len, sv[cur].ref_base);
+        masked = prm.ont ? true : polya_masked(seq, b.seq_len[rr], c, prm.polya_len, sv[cur_s].ref_base);
       const int bi = base_code(base);
-      if (!masked && bi >= 0) atomicAdd(&hist[((int64_t)cur * 4 + bi) * 31 + bq], 1u);
+      if (!masked && bi >= 0) atomicAdd(&hist[((int64_t)cur_s * 4 + bi) * 31 + bq], 1u);
     });
   if (hl && live && l16 == 0) {
     hit_cnt[r] = nh;
@@ -389,10 +405,10 @@ k2_hist(BatchView b, DevParams prm, const ReadBin* __restrict__ rbin, const Surv
 }
 
 void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin, const Survivor* sv,
-                    const int32_t* sv_region_off, uint32_t* hist, int32_t* hit_cnt, void* hit_list, int32_t* ovf_cnt, int32_t* ovf_list, hipStream_t s) {
+                    const int32_t* tile_off, int32_t n_tiles, int32_t n_sv, uint32_t* hist, int32_t* hit_cnt, void* hit_list, int32_t* ovf_cnt, int32_t* ovf_list, hipStream_t s) {
   if (b.n_reads == 0) return;
   const int per = LCR_BLOCK / 16;
-  hipLaunchKernelGGL(k2_hist, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, p, rbin, sv, sv_region_off, hist, hit_cnt, (uint2*)hit_list,
+  hipLaunchKernelGGL(k2_hist, dim3((b.n_reads + per - 1) / per), dim3(LCR_BLOCK), 0, s, b, p, rbin, sv, tile_off, n_tiles, n_sv, hist, hit_cnt, (uint2*)hit_list,
                      ovf_cnt, ovf_list);
 }
 

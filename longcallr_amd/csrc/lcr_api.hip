@@ -771,7 +771,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
         launch_k2_hist_tiles(c->bv, c->tile_col0.as<int32_t>(), nt, c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(), c->survivors.as<Survivor>(),
                              c->chunk_off.as<int32_t>(), c->chunks.p, c->k0_items.as<unsigned long long>(), c->hist.as<uint32_t>(), c->stream);
       else
-        launch_k2_hist(c->bv, c->dp, c->read_bin.as<ReadBin>(), c->survivors.as<Survivor>(), c->sv_region_off.as<int32_t>(), c->hist.as<uint32_t>(),
+        launch_k2_hist(c->bv, c->dp, c->read_bin.as<ReadBin>(), c->survivors.as<Survivor>(), c->tile_off.as<int32_t>(), nt, n_sv, c->hist.as<uint32_t>(),
                        c->hits_valid ? c->hit_cnt.as<int32_t>() : nullptr, c->hit_list.p, (int32_t*)(c->hist.as<uint32_t>() + (size_t)n_sv * 124), c->ovf_list.as<int32_t>(),
                        c->stream); }
     { Timer t(c, LCR_K_CAND_GT);

@@ -196,7 +196,7 @@ void launch_k2_compact(const BatchView& b, const DevParams& p, const int32_t* ti
                        const int32_t* tile_count, const int32_t* tile_off, Survivor* out, hipStream_t s);
 float lcr_device_sor_threshold(hipStream_t s);
 #define LCR_HITS 16   // (read, survivor) hits k2_hist keeps per read for K3 (= K3's inline entries per row)
-void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin, const Survivor* sv, const int32_t* sv_region_off,
+void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin, const Survivor* sv, const int32_t* tile_off /* survivors in front of every tile (k2_compact's offsets) */, int32_t n_tiles, int32_t n_sv,
                     uint32_t* hist /* n_sv * 4 * 31 */, int32_t* hit_cnt /* n_reads, or nullptr: no hit lists */, void* hit_list /* n_reads x LCR_HITS x uint2 */,
                     int32_t* ovf_cnt /* zeroed */, int32_t* ovf_list /* n_reads */, hipStream_t s);
 // the same histograms from K0's per-tile records instead of a walk over the reads (ONT presets, batches whose survivors are dense)
@@ -313,11 +313,11 @@ __device__ __forceinline__ int row16_incl_scan(int v) {
 //      and may use row ballots to keep the sites' order.
 // A read that covers no site returns before touching its CIGAR.  Four reads share a wave64.
 // `live` = this row has a read; rows without one pass live = false (their lanes still call).
-template <class ColFn, class Sink>
-__device__ __forceinline__ void row16_walk_sites(const BatchView& b, bool live, const ReadBin& h, int rend, int s_lo, int s_hi,
-                                                 ColFn site_col, Sink sink) {
+// step 1 of the walk: first site with column >= key = max(rel_pos, 0) (cur) and first site with column >= rend (s_end) among the
+// ascending sites [s_lo, s_hi); live = false or no site inside the span: cur >= s_end
+template <class ColFn>
+__device__ __forceinline__ void row16_find_sites(bool live, const ReadBin& h, int rend, int s_lo, int s_hi, ColFn site_col, int* cur_out, int* s_end_out) {
   const int lane = threadIdx.x & 63, l16 = lane & 15, rbase = lane & 48;
-  // ---- 1. first site with column >= key, first site with column >= rend
   int cur = s_hi, s_end = s_hi;
   if (live) {
     const int key = h.rel_pos > 0 ? h.rel_pos : 0;
@@ -332,6 +332,14 @@ __device__ __forceinline__ void row16_walk_sites(const BatchView& b, bool live, 
     }
     if (!found_cur) cur = s_end;
   }
+  *cur_out = cur; *s_end_out = s_end;
+}
+
+// steps 2 + 3: the sites [cur, s_end) of the read against its CIGAR.  pre != nullptr: the read's first 64 ops (four words per lane, op
+// 16 k + l16 in pre[k], 0 beyond the CIGAR) were requested by the caller beside its own loads (k2_hist: one round trip less in the chain)
+template <class ColFn, class Sink>
+__device__ __forceinline__ void row16_walk_range(const BatchView& b, const ReadBin& h, int cur, int s_end, const uint32_t* pre, ColFn site_col, Sink sink) {
+  const int lane = threadIdx.x & 63, l16 = lane & 15, rbase = lane & 48;
   if (cur >= s_end) return;   // (row-uniform)
   const uint32_t ncig = (uint32_t)h.n_cig;
   const uint32_t* __restrict__ cg = b.cigar + h.cig_off;
@@ -346,8 +354,13 @@ __device__ __forceinline__ void row16_walk_sites(const BatchView& b, bool live, 
     int cc = __shfl(my_cc, rbase, 64);
     for (uint32_t c0 = 0; c0 < ncig && j < n; c0 += 64) {
       uint32_t w4[4];
+      if (pre && c0 == 0) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) w4[k] = c0 + 16 * k + l16 < ncig ? cg[c0 + 16 * k + l16] : 0u;
+        for (int k = 0; k < 4; k++) w4[k] = pre[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) w4[k] = c0 + 16 * k + l16 < ncig ? cg[c0 + 16 * k + l16] : 0u;
+      }
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const uint32_t w = w4[k];
@@ -375,6 +388,14 @@ __device__ __forceinline__ void row16_walk_sites(const BatchView& b, bool live, 
     }
     sink(first + l16, myc, myc >= 0);
   }
+}
+
+template <class ColFn, class Sink>
+__device__ __forceinline__ void row16_walk_sites(const BatchView& b, bool live, const ReadBin& h, int rend, int s_lo, int s_hi,
+                                                 ColFn site_col, Sink sink) {
+  int cur, s_end;
+  row16_find_sites(live, h, rend, s_lo, s_hi, site_col, &cur, &s_end);
+  row16_walk_range(b, h, cur, s_end, nullptr, site_col, sink);
 }
 
 // region index of read r: precomputed by k0_read_region (a binary search over read_begin would cost

@@ -33,7 +33,43 @@ def run_oracle(b, p, threads):
     return R, time.time() - t
 
 
-if __name__ == "__main__":
+def digests(pr, c, text, blocks):
+    """what test_c5_full_size compares, as SHA-256 digests (the f64 fixture keeps these instead of a second copy of the arrays)"""
+    ints = ("pos", "ref_base", "allele1", "allele2", "n_alt", "cnt1", "cnt2", "depth", "variant_type", "genotype", "haplotype", "flags", "phase_set")
+    d = {f: hashlib.sha256(np.ascontiguousarray(pr[f]).tobytes()).hexdigest() for f in ("haplotag", "assignment", "phase_set")}
+    d["cand_int_fields"] = hashlib.sha256(b"".join(np.ascontiguousarray(c[f]).tobytes() for f in ints)).hexdigest()
+    d["vcf"] = hashlib.sha256(text.encode()).hexdigest()
+    d["ld_blocks"] = hashlib.sha256(repr([list(map(int, x)) for x in blocks]).encode()).hexdigest()
+    return d
+
+
+def run_oracle_f64(b, p, threads):
+    """ORC_MODE_F64: the reference's f64 ratio scores / sums in the reference's order at EVERY decision"""
+    R = orc.Region(b, 0, p).set_fast(threads)
+    t = time.time()
+    R.run_all(orc.MODE_F64)
+    return R, time.time() - t
+
+
+if __name__ == "__main__" and "--mode" in sys.argv and sys.argv[sys.argv.index("--mode") + 1] == "f64":
+    # python tests/golden/make_c5_golden.py 200 --mode f64  -> gpurun_out/c5_full_size_oracle_f64.json (kept as tests/golden/c5_full_size_oracle_f64.json)
+    import json
+    threads = int(sys.argv[1]) if sys.argv[1].isdigit() else 64
+    b, p = build()
+    R, secs = run_oracle_f64(b, p, threads)
+    pr, c, text, blocks = R.phase_result(), R.cands(), R.vcf_text("chrS"), R.ld_blocks()
+    d = digests(pr, c, text, blocks)
+    G = np.load(os.path.join(ROOT, "tests", "golden", "c5_full_size_oracle.npz"))
+    gd = digests({f: G[f] for f in ("haplotag", "assignment", "phase_set")}, G["cands"].view(_abi.CAND_DTYPE), G["vcf"].tobytes().decode(),
+                 [G["ld_snps"][G["ld_off"][k]:G["ld_off"][k + 1]].tolist() for k in range(G["ld_off"].size - 1)])
+    out = os.path.join(ROOT, "gpurun_out", "c5_full_size_oracle_f64.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    rec = dict(input_sha256=input_digest(b), mode="ORC_MODE_F64", digests=d, objective_f64=float(pr["objective"]), phase_score_sum=float(np.sum(c["phase_score"])),
+               tie_census=[int(x) for x in R.tie_census()], stats={k: int(v) for k, v in R.stats().items()}, oracle_seconds=secs, oracle_threads=threads,
+               equals_the_tie_mode_fixture={k: d[k] == gd[k] for k in d}, tie_mode_objective=float(G["objective"]))
+    json.dump(rec, open(out, "w"), indent=1)
+    print(json.dumps(rec))
+elif __name__ == "__main__":
     threads = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     b, p = build()
     R, secs = run_oracle(b, p, threads)
