@@ -32,6 +32,7 @@ extern "C" {
 #define LCR_E_DEVICE (-3)  /* HIP runtime error (message via lcr_last_error)                       */
 #define LCR_E_STATE (-4)   /* call order violated (e.g. lcr_candidates before lcr_pileup)          */
 #define LCR_E_NOMEM (-5)
+#define LCR_W_HW_QUEUES 1  /* lcr_ctx_set_async_phase(on): accepted, but the process has fewer than 8 hardware queues (below) */
 
 #define LCR_PLATFORM_HIFI 0 /* main.rs:35-38 Platform::Hifi */
 #define LCR_PLATFORM_ONT 1  /* Platform::Ont  */
@@ -380,14 +381,17 @@ int lcr_bam_write_reads(const char* out_path, const char* contig, int64_t contig
  * been collected (a getter or lcr_ctx_sync) -- with the synchronous stage they are free when lcr_phase returns.  A host batch
  * (lcr_load_batch with LCR_MEM_HOST, lcr_load_batch_async) waits for the stage in flight by itself.  Persistent all-CU launches,
  * the host epilogue and phase_prof make lcr_phase wait as before.  The stage then uses four queues: the process should run with
- * GPU_MAX_HW_QUEUES >= 8 in its environment (ROCm's default of 4 maps two of them onto one hardware queue). */
+ * GPU_MAX_HW_QUEUES >= 8 in its environment (ROCm's default of 4 maps two of them onto one hardware queue: correct, but measured
+ * without gain).  The HIP runtime reads that variable when it starts, so the library cannot set it: lcr_ctx_set_async_phase(ctx, 1)
+ * returns LCR_W_HW_QUEUES (> 0: the mode IS on) when the variable is unset or below 8, and lcr_last_error says what to export. */
 int lcr_ctx_set_async_phase(lcr_ctx*, int on);
 
 /* Regions whose phase matrix is far beyond one CU are phased by persistent all-CU kernels; two such launches on one GPU --
  * of two contexts or two processes -- must not overlap, so they are serialised per device by a process-local mutex and an
- * flock on <dir>/grid_<pci bus id>.lock.  dir defaults to /tmp/liblcr-locks when that directory is this user's or root's (and sticky
- * if others may write into it: an administrator creates it 1777 for a machine whose users share GPUs), else to /tmp/liblcr-<uid>; a
- * directory named here is created 0700 and has to pass the same test.  Processes that share a GPU must see the same directory
+ * flock on <dir>/grid_<pci bus id>.lock.  dir defaults to /tmp/liblcr-locks (created 1777 by whoever comes first); it has to be this user's
+ * or root's, and sticky if others may write into it -- otherwise lcr_phase fails with LCR_E_DEVICE and says so (round 6: it used to fall back
+ * to a per-user directory silently, which would have left two users' launches unserialised).  A directory named here is created 0700 and
+ * has to pass the same test; "/tmp/liblcr-<uid>" is the per-user lock for a machine whose GPUs are not shared.  Processes that share a GPU must see the same directory
  * (containers without a common /tmp: name one on a shared mount).  The lock is waited for at most ten minutes; a lock that cannot
  * be taken makes lcr_phase fail with LCR_E_DEVICE -- it is never skipped. */
 int lcr_ctx_set_lock_dir(lcr_ctx*, const char* dir);

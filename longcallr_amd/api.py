@@ -83,7 +83,10 @@ class Engine:
 
     def set_async_phase(self, on=True):
         """lcr_ctx_set_async_phase: phase() returns with its kernels in flight; getters / sync() collect the results (include/lcr.h)"""
-        self._chk(self.lib.lcr_ctx_set_async_phase(self.h, 1 if on else 0), "lcr_ctx_set_async_phase")
+        rc = self.lib.lcr_ctx_set_async_phase(self.h, 1 if on else 0)
+        self.async_warning = self.lib.lcr_last_error(self.h).decode() if rc > 0 else None   # (LCR_W_HW_QUEUES: on, but GPU_MAX_HW_QUEUES < 8)
+        if rc < 0:
+            self._chk(rc, "lcr_ctx_set_async_phase")
         return self
 
     # ---- batch binding -------------------------------------------------------------------------

@@ -1103,24 +1103,14 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
               alo[s] = enum_mad24(sgn, (int)v0, alo[s]); ahi[s] = enum_mad24(sgn, (int)v1, ahi[s]);
             }
             if (m & 64u) {   // the row's last entry: its eight decisions
-              // (round 6) ONE test for "any exact zero among the eight sums" -- the minimum of top | low limb as unsigned words -- instead of
-              // eight tie tests: the tie bits are only formed behind it (a row without a het entry for any state has uacc == 0: no tie)
-              uint32_t fl = 0, tie = 0, zmin = 0xffffffffu;
+              uint32_t fl = 0, tie = 0;
 #pragma unroll
               for (int s = 0; s < 8; s++) {
                 const int top = ahi[s] + (alo[s] >> 23);   // sign of ahi * 2^23 + alo
                 fl |= (uint32_t)(top < 0) << s;
-                zmin = min(zmin, (uint32_t)top | ((uint32_t)alo[s] & 0x7fffffu));
+                tie |= (uint32_t)(top == 0 && (alo[s] & 0x7fffff) == 0 && ((uacc >> (2 * s)) & 1u)) << s;
+                alo[s] = 0; ahi[s] = 0;
               }
-              if (zmin == 0u && uacc != 0u) {
-#pragma unroll
-                for (int s = 0; s < 8; s++) {
-                  const int top = ahi[s] + (alo[s] >> 23);
-                  tie |= (uint32_t)(top == 0 && (alo[s] & 0x7fffff) == 0 && ((uacc >> (2 * s)) & 1u)) << s;
-                }
-              }
-#pragma unroll
-              for (int s = 0; s < 8; s++) { alo[s] = 0; ahi[s] = 0; }
               uacc = 0;
               fl &= act; tie &= act;
               any8 |= fl;

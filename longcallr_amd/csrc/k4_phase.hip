@@ -297,7 +297,7 @@ struct PhaseWork {   // host epilogue structures, reused across calls
 // that each hold a part of the CUs would wait for each other's workgroups forever.
 // Persistent all-CU launches of different processes (or contexts) on one GPU would wait for each other's workgroups forever:
 // they are serialised per DEVICE -- a process-local mutex keyed by the PCI bus id, and across processes an flock on
-// <lock_dir>/grid_<bus id>.lock (lock_dir: lcr_ctx_set_lock_dir; default /tmp/liblcr-<uid>, created 0700 and refused unless it
+// <lock_dir>/grid_<bus id>.lock (lock_dir: lcr_ctx_set_lock_dir, created 0700; default the machine-wide /tmp/liblcr-locks, refused unless it
 // is a directory of this user; the file is opened O_NOFOLLOW | O_CLOEXEC).  A lock that cannot be taken is an error, never
 // silently skipped.  The destructor drains the queues it was given before it lets go (error paths return early).
 struct GridLock {
@@ -337,7 +337,11 @@ struct GridLock {
     if (shared) {
       dir = "/tmp/liblcr-locks";
       if (mkdir(dir.c_str(), 01777) == 0) (void)chmod(dir.c_str(), 01777);   // (the umask)
-      if (!trusted(dir)) { dir = "/tmp/liblcr-" + std::to_string((unsigned long)getuid()); shared = false; }
+      //  an untrusted machine-wide directory is an error, not a silent per-user lock: whoever created it would go on
+      // trusting it while everybody else locked /tmp/liblcr-<uid>, and two users' persistent launches on one GPU would no longer be
+      // serialised.  The per-user lock is there for whoever asks for it: lcr_ctx_set_lock_dir(ctx, "/tmp/liblcr-<uid>").
+      if (!trusted(dir)) return "the machine-wide lock directory " + dir + " exists but is not root's or this user's (or is writable by others without the sticky bit): "
+                                "remove it, have an administrator create it 1777, or name a directory all processes that share this GPU see with lcr_ctx_set_lock_dir";
     }
     if (!shared && mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) return "cannot create lock directory " + dir + ": " + strerror(errno);
     if (!trusted(dir)) return "lock directory " + dir + " is not a directory of this user or of root (sticky if others may write): lcr_ctx_set_lock_dir names another one";

@@ -1121,6 +1121,14 @@ int lcr_ctx_set_async_phase(lcr_ctx* c, int on) {
   HIPCHK(c, hipSetDevice(c->device));
   { int rc = phase_settle(c); if (rc) return rc; }
   c->phase.dbg.async_phase = on != 0;
+  if (on) {   // the stage's four queues need hardware queues of their own: the runtime's default of 4 per process maps two of them onto one
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    if (!q || atoi(q) < 8) {
+      c->err = "asynchronous phase stage: GPU_MAX_HW_QUEUES is unset or below 8 in this process's environment -- the HIP runtime then shares hardware queues "
+               "between the stage's streams (results are the same, the overlap is lost); export GPU_MAX_HW_QUEUES=8 before the process starts";
+      return LCR_W_HW_QUEUES;
+    }
+  }
   return LCR_OK;
 }
 

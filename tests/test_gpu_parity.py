@@ -1438,6 +1438,16 @@ def test_c5_full_size(engine_cls, orc):
     assert np.all(np.abs(c["phase_score"] - oc["phase_score"]) <= 1e-4)
     assert vcf.format_records(c, "chrS", p.min_phase_score) == otext
     assert E.ld_blocks(0) == oblocks
+    # ---- and against ORC_MODE_F64 at full size: the reference's f64 scores / sums in the reference's order at EVERY decision
+    # of the island's 2 345 cross_optimize calls -- 416 s of the oracle on 200 threads, kept as digests (tests/golden/c5_full_size_oracle_f64.json,
+    # make_c5_golden.py --mode f64).  The HIP path's outputs hash to the same values; the f64 objective is the fixed-point one within 1e-4.
+    import json
+    F = json.load(open(os.path.join(helpers.GOLDEN, "c5_full_size_oracle_f64.json")))
+    assert F["input_sha256"] == G["input_sha256"].tobytes().decode() and F["mode"] == "ORC_MODE_F64"
+    hd = mk.digests(pr, c, vcf.format_records(c, "chrS", p.min_phase_score), E.ld_blocks(0))
+    assert hd == F["digests"], {k: hd[k] == F["digests"][k] for k in hd}
+    assert abs(pr["objective"][0] - F["objective_f64"]) < 1e-4 and abs(float(np.sum(c["phase_score"])) - F["phase_score_sum"]) < 1e-4 * c.size
+    assert F["tie_census"][1] == 0 and F["tie_census"][2] == 0 and F["tie_census"][7] == 0   # the oracle met no delta / eta tie, no tie-only step, no later equal-objective configuration with the greater f64 sum
     hc = E.tie_census()
     assert hc["sigma_unresolved"] == 0 and hc["delta_unresolved"] == 0 and hc["sigma_f64"] >= int(G["tie_census"][8])
     FULL_SIZE_STATS["c5_phase"] = dict(oracle_seconds=float(G["oracle_seconds"]), oracle_threads=int(G["oracle_threads"]), cross_optimize_calls=int(G["stats"][0]),
@@ -1600,9 +1610,21 @@ def test_pipelined_collect_of_the_asynchronous_stage(engine_cls):
             assert hip.hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), C.c_size_t(n * itemsize), 3) == 0
         return out.cpu().numpy().tobytes()
 
+    import os
     for async_on in (True, False):
         Ea = engine_cls(0, p)
         Ea.set_async_phase(async_on)
+        if async_on:   # LCR_W_HW_QUEUES: the mode is on either way, the library says when the process has too few hardware queues for it to pay
+            assert Ea.async_warning is None or "GPU_MAX_HW_QUEUES" in Ea.async_warning
+            keep_env = os.environ.get("GPU_MAX_HW_QUEUES")
+            os.environ["GPU_MAX_HW_QUEUES"] = "4"
+            assert "GPU_MAX_HW_QUEUES" in (Ea.set_async_phase(True).async_warning or "")
+            os.environ["GPU_MAX_HW_QUEUES"] = "8"
+            assert Ea.set_async_phase(True).async_warning is None
+            if keep_env is None:
+                del os.environ["GPU_MAX_HW_QUEUES"]
+            else:
+                os.environ["GPU_MAX_HW_QUEUES"] = keep_env
         Ea.load_batch(dv[0]).run_all()
         for k in range(1, len(dv) + 1):
             if k < len(dv):
