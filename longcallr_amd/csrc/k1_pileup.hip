@@ -28,6 +28,7 @@
 #include <climits>
 
 #include "lcr_dev.h"
+#include "k2_eval.h"
 
 // Ablation switches of the profiling experiments (tools/k1time.py): compile-time only (-DLCR_K1_ABLATE=n builds a
 // measurement library that computes WRONG planes); the product build has no switch that skips work.
@@ -265,7 +266,7 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
           int64_t n_cols, const int32_t* __restrict__ tile_fill, const int32_t* __restrict__ ent_off, const uint2* __restrict__ ents,
           const unsigned long long* __restrict__ recs,
           const int32_t* __restrict__ tile_nbase, uint32_t* __restrict__ planes, const int32_t* __restrict__ order,
-          const int32_t* __restrict__ n_full) {
+          const int32_t* __restrict__ n_full, BinomTable bt, uint8_t* __restrict__ flt_flags, int32_t* __restrict__ flt_count) {
   // (tiles with records first, fullest first, the record-free ones behind them: k1_tiles_b.  Dealing the record-free
   // tiles -- pure streams of plane stores, 75 % of the stage's HBM writes -- between the full ones so that the stores run
   // under the tally was measured: 0.74 instead of 0.43 ms, XCD-aware or not; the full tiles' dependent loads then queue
@@ -496,6 +497,8 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
 
   // assemble the ABI planes and write them out (coalesced: consecutive threads, consecutive columns)
   const uint32_t nbase = (uint32_t)tile_nbase[tile];
+  static_assert(K1_CPT == 1, "the fused filter counts one column per thread");
+  int n_pass = 0;
   for (int col = tid; col < tlen; col += K1_THREADS) {
     const uint8_t R = refl[REF_PAD + col];
     const int ri = R == 'A' ? 0 : R == 'C' ? 1 : R == 'G' ? 2 : R == 'T' ? 3 : -1;
@@ -524,6 +527,21 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
     planes[(int64_t)LCR_PL_NI * n_cols + o] = pl[P_NI * TSTRIDE + col];
     planes[(int64_t)LCR_PL_TS_FWD * n_cols + o] = pl[P_DIFF_TS0 * TSTRIDE + col];
     planes[(int64_t)LCR_PL_TS_REV * n_cols + o] = pl[P_DIFF_TS1 * TSTRIDE + col];
+    // pass 1 of the candidate filters (candidate.rs:90-234, k2_eval.h) on the counts this thread holds: the presets without a poly-A pass
+    // behind this kernel (ONT) get k2_filter's flags and per-tile counts here -- one pass over the planes less (round 6)
+    if (flt_flags) {
+      uint32_t cnt[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) cnt[k] = f[k] + rv[k];
+      const ColEval ev = eval_counts(cnt, R, prm, bt, [&]() { return pl[P_DIFF_D * TSTRIDE + col]; }, [&]() { return nbase + pl[P_DIFF_N * TSTRIDE + col]; },
+                                     [&](int k) { return f[k]; });
+      flt_flags[o] = ev.pass ? 1 : 0;
+      n_pass += ev.pass ? 1 : 0;
+    }
+  }
+  if (flt_flags) {
+    const int total = __syncthreads_count(n_pass);   // (one column per thread: n_pass is 0 or 1)
+    if (tid == 0) flt_count[tile] = total;
   }
 }
 
@@ -534,12 +552,14 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
 // One workgroup of 128 threads per tile: 16-byte stores, 4 consecutive columns per thread and plane.
 __global__ void __launch_bounds__(128) k1_empty_tiles(BatchView b, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0,
                                                        int64_t n_cols, const int32_t* __restrict__ tile_nbase, uint32_t* __restrict__ planes,
-                                                       const int32_t* __restrict__ order, const int32_t* __restrict__ n_full, int zeroed, int n_tiles, int bg_tiles) {
+                                                       const int32_t* __restrict__ order, const int32_t* __restrict__ n_full, int zeroed, int n_tiles, int bg_tiles,
+                                                       int32_t* __restrict__ flt_count) {
   const int nf = *n_full;
   if (*b.error_flag != 0) return;
   // bg_tiles > 0: a few workgroups walk all record-free tiles (a throttled store stream beside the tally, launch_k1_pileup)
   for (int bt = blockIdx.x; bt + nf < n_tiles; bt += bg_tiles > 0 ? (int)gridDim.x : n_tiles) {
   const int tile = order[nf + bt];
+  if (flt_count && threadIdx.x == 0) flt_count[tile] = 0;   // (a record-free tile has no survivor of the count filters: k2_filter's verdict for it)
   const int g = tile_region[tile], tc0 = tile_col0[tile];
   const int tlen = min(LCR_TILE, b.len[g] - tc0);
   const int64_t gcol0 = b.col_off[g] + tc0;
@@ -684,17 +704,44 @@ __global__ void __launch_bounds__(256) k1_tiles_b(const int32_t* __restrict__ ti
 void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const int32_t* tile_fill, const int32_t* ent_off, const void* ents,
                       const unsigned long long* recs, const int32_t* tile_nbase, uint32_t* planes, const int32_t* order /* launch_k1_tiles_b */,
-                      const int32_t* tiles_tmp, int zeroed, hipStream_t s, hipStream_t bg, hipEvent_t ev0, hipEvent_t ev1, int bg_wgs) {
+                      const int32_t* tiles_tmp, int zeroed, hipStream_t s, hipStream_t bg, hipEvent_t ev0, hipEvent_t ev1, int bg_wgs,
+                      uint8_t* flt_flags, int32_t* flt_count) {
+  static const BinomTable bt = make_binom_table();
   if (n_tiles == 0) return;
+  if (bg_wgs == -2) {
+    // lcr_debug_set("bg_tiles", -2): the record-free tiles' stores FIRST, the tally behind them on the same queue -- the tally then is the last
+    // kernel of the stage to touch memory, and what it read (the read bases) is what the Infinity Cache holds when k2_hist asks for the
+    // survivors' bases (measured with the stores early on a second queue: k2_hist 0.24 -> 0.20 ms)
+    hipLaunchKernelGGL(k1_empty_tiles, dim3(n_tiles), dim3(128), 0, s, b, tile_region, tile_col0, n_cols, tile_nbase, planes, order, tiles_tmp + 80, zeroed, n_tiles, 0, flt_count);
+    hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_fill, ent_off,
+                       (const uint2*)ents, recs, tile_nbase, planes, order, tiles_tmp + 80 /* TileScanTmp::n_full */, bt, flt_flags, flt_count);
+    return;
+  }
+  if (bg && bg_wgs < 0) {
+    // (measurement switch, lcr_debug_set("bg_tiles", -1)) the record-free tiles' stores at full width on a second queue, started BEFORE the
+    // caller queues k0_desc_bin + the tally on `s`: ev0 was recorded behind k1_tiles_b by the caller (launch_k1_empty_early)
+    hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_fill, ent_off,
+                       (const uint2*)ents, recs, tile_nbase, planes, order, tiles_tmp + 80 /* TileScanTmp::n_full */, bt, flt_flags, flt_count);
+    hipStreamWaitEvent(s, ev1, 0);
+    return;
+  }
   if (bg && bg_wgs > 0) {   // the record-free tiles' stores as a throttled stream on a second queue, beside the tally
     hipEventRecord(ev0, s); hipStreamWaitEvent(bg, ev0, 0);
-    hipLaunchKernelGGL(k1_empty_tiles, dim3(bg_wgs), dim3(128), 0, bg, b, tile_region, tile_col0, n_cols, tile_nbase, planes, order, tiles_tmp + 80, zeroed, n_tiles, 1);
+    hipLaunchKernelGGL(k1_empty_tiles, dim3(bg_wgs), dim3(128), 0, bg, b, tile_region, tile_col0, n_cols, tile_nbase, planes, order, tiles_tmp + 80, zeroed, n_tiles, 1, flt_count);
     hipEventRecord(ev1, bg);
   }
   hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_fill, ent_off,
-                     (const uint2*)ents, recs, tile_nbase, planes, order, tiles_tmp + 80 /* TileScanTmp::n_full */);
+                     (const uint2*)ents, recs, tile_nbase, planes, order, tiles_tmp + 80 /* TileScanTmp::n_full */, bt, flt_flags, flt_count);
   if (bg && bg_wgs > 0) hipStreamWaitEvent(s, ev1, 0);
-  else hipLaunchKernelGGL(k1_empty_tiles, dim3(n_tiles), dim3(128), 0, s, b, tile_region, tile_col0, n_cols, tile_nbase, planes, order, tiles_tmp + 80, zeroed, n_tiles, 0);
+  else hipLaunchKernelGGL(k1_empty_tiles, dim3(n_tiles), dim3(128), 0, s, b, tile_region, tile_col0, n_cols, tile_nbase, planes, order, tiles_tmp + 80, zeroed, n_tiles, 0, flt_count);
+}
+// the record-free tiles on queue `bg`, behind the tile passes of `s` (ev0) -- beside k0_desc_bin and the start of the tally; ev1 = done
+void launch_k1_empty_early(const BatchView& b, const int32_t* tile_region, const int32_t* tile_col0, int32_t n_tiles, int64_t n_cols, const int32_t* tile_nbase,
+                           uint32_t* planes, const int32_t* order, const int32_t* tiles_tmp, hipStream_t s, hipStream_t bg, hipEvent_t ev0, hipEvent_t ev1, int32_t* flt_count) {
+  if (n_tiles == 0) return;
+  hipEventRecord(ev0, s); hipStreamWaitEvent(bg, ev0, 0);
+  hipLaunchKernelGGL(k1_empty_tiles, dim3(n_tiles), dim3(128), 0, bg, b, tile_region, tile_col0, n_cols, tile_nbase, planes, order, tiles_tmp + 80, 0, n_tiles, 0, flt_count);
+  hipEventRecord(ev1, bg);
 }
 // the tile-order / intron-base / accounting pass alone (the host fetches K0's control block behind it, before K1 is queued)
 // the tile passes alone (the host fetches K0's control block behind pass A, before the rest is queued)

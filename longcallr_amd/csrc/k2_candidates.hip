@@ -14,8 +14,7 @@
 // The dense-cluster sweeps (candidate.rs:465-526) run on the device too: k2_dense, a workgroup per region, a thread per start index
 // over the region's compacted candidates (below).
 #include "lcr_dev.h"
-
-struct BinomTable { uint32_t reject[31]; };  // bit k of reject[n]: binomial_two_tailed(k, n, .5) < 0.05
+#include "k2_eval.h"
 
 // ---- generic 3-phase exclusive scan over int32 ------------------------------------------------
 #define SCAN_ITEMS 4
@@ -161,89 +160,17 @@ void launch_scan_i32_to_i64(DevBuf& tmp, const int32_t* in, int64_t* out_excl, i
 }
 
 // ---- pass 1 ------------------------------------------------------------------------------------
-// candidate.rs:24-35 in f32 (no contraction: built with -ffp-contract=off)
-__device__ __forceinline__ float strand_odds_ratio(int ref_fw, int ref_rv, int alt_fw, int alt_rv) {
-  float x00 = (float)(ref_fw + 1), x01 = (float)(ref_rv + 1), x10 = (float)(alt_fw + 1), x11 = (float)(alt_rv + 1);
-  float sym = (x00 * x11) / (x01 * x10) + (x01 * x10) / (x00 * x11);
-  float ref_ratio = fminf(x00, x01) / fmaxf(x00, x01);
-  float alt_ratio = fminf(x10, x11) / fmaxf(x10, x11);
-  return logf(sym) + logf(ref_ratio) - logf(alt_ratio);
-}
+// (the filters on one column's counts: k2_eval.h, shared with k1_pileup's epilogue)
 __global__ void k2_sor_threshold(float* out) { *out = strand_odds_ratio(5, 5, 9, 1); }  // candidate.rs:49-51
-
-struct ColEval {
-  bool pass;
-  uint8_t ref_base, allele1, allele2, n_alt;
-  uint32_t cnt1, cnt2, depth;
-  float af1, af2;
-};
-
-// BaseFreq::get_two_major_alleles (util.rs:162-176): stable sort by count, descending
-__device__ __forceinline__ void two_major(const uint32_t cnt[4], uint8_t ref_base, uint8_t* a1, uint32_t* c1, uint8_t* a2,
-                                          uint32_t* c2) {
-  const uint8_t ch[4] = {'A', 'C', 'G', 'T'};
-  int order[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int rank = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) rank += (cnt[j] > cnt[i]) || (cnt[j] == cnt[i] && j < i);
-    order[rank] = i;
-  }
-  int second = 1;
-  if (ch[order[0]] != ref_base && ch[order[1]] != ref_base) {
-    if (cnt[order[2]] == cnt[order[1]] && ch[order[2]] == ref_base) second = 2;
-    else if (cnt[order[3]] == cnt[order[1]] && ch[order[3]] == ref_base) second = 3;
-  }
-  *a1 = ch[order[0]]; *c1 = cnt[order[0]]; *a2 = ch[order[second]]; *c2 = cnt[order[second]];
-}
 
 __device__ __forceinline__ ColEval eval_column(const uint32_t* __restrict__ planes, int64_t n_cols, int64_t o, uint8_t ref_base,
                                                const DevParams& prm, const BinomTable& bt) {
-  ColEval ev;
-  ev.pass = false;
-  uint32_t cnt[4], fwd[4];
+  uint32_t cnt[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) { cnt[k] = planes[(int64_t)(LCR_PL_A + k) * n_cols + o]; }
-  const uint32_t total = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-  ev.depth = total;
-  if (total < prm.min_depth || total > prm.max_depth) return ev;  // candidate.rs:90-94
-  // a reference byte other than upper-case ACGT never reaches a candidate (candidate.rs:132,243-265)
-  if (!(ref_base == 'A' || ref_base == 'C' || ref_base == 'G' || ref_base == 'T')) return ev;
-  two_major(cnt, ref_base, &ev.allele1, &ev.cnt1, &ev.allele2, &ev.cnt2);
-  ev.af1 = (float)ev.cnt1 / (float)total;
-  ev.af2 = (float)ev.cnt2 / (float)total;
-  ev.ref_base = ref_base;
-  uint8_t alt0; uint32_t altc0; float altf0;
-  if (ev.allele1 == ref_base) { ev.n_alt = 1; alt0 = ev.allele2; altc0 = ev.cnt2; altf0 = ev.af2; }
-  else if (ev.allele2 == ref_base) { ev.n_alt = 1; alt0 = ev.allele1; altc0 = ev.cnt1; altf0 = ev.af1; }
-  else { ev.n_alt = 2; alt0 = ev.allele1; altc0 = ev.cnt1; altf0 = ev.af1; }
-  if (ev.n_alt == 1) {  // candidate.rs:142-155
-    if (total < 200 && altf0 < prm.low_frac_cut) return ev;
-    if (total >= 200 && altc0 < prm.low_cnt_cut) return ev;
-  }
-  const uint32_t d = planes[(int64_t)LCR_PL_D * n_cols + o], n = planes[(int64_t)LCR_PL_N * n_cols + o];
-  if (d >= altc0) return ev;  // candidate.rs:165
-  if ((float)(ev.cnt1 + ev.cnt2) / (float)(total + d + n) < prm.min_af_intron) return ev;  // candidate.rs:170
-  if (prm.use_strand_bias) {  // candidate.rs:199-234
-#pragma unroll
-    for (int k = 0; k < 4; k++) fwd[k] = planes[(int64_t)(LCR_PL_FWD_A + k) * n_cols + o];
-    const int ri = base_code(ref_base), a0 = base_code(alt0);
-    const int ref_fw = (int)fwd[ri], ref_rv = (int)(cnt[ri] - fwd[ri]);
-    const int alt_fw = (int)fwd[a0], alt_rv = (int)(cnt[a0] - fwd[a0]);
-    float sor = strand_odds_ratio(ref_fw, ref_rv, alt_fw, alt_rv);
-    if (ev.n_alt == 2) {
-      const int a1i = base_code(ev.allele2);
-      sor = fmaxf(sor, strand_odds_ratio(ref_fw, ref_rv, (int)fwd[a1i], (int)(cnt[a1i] - fwd[a1i])));
-    }
-    if (sor > prm.sor_threshold) return ev;
-    if (ev.n_alt == 1) {
-      if (alt_fw + alt_rv <= 30 && ((bt.reject[alt_fw + alt_rv] >> alt_fw) & 1u)) return ev;
-      if (alt_fw * alt_rv == 0) return ev;
-    }
-  }
-  ev.pass = true;
-  return ev;
+  return eval_counts(cnt, ref_base, prm, bt,
+                     [&]() { return planes[(int64_t)LCR_PL_D * n_cols + o]; }, [&]() { return planes[(int64_t)LCR_PL_N * n_cols + o]; },
+                     [&](int k) { return planes[(int64_t)(LCR_PL_FWD_A + k) * n_cols + o]; });
 }
 
 __global__ void __launch_bounds__(LCR_BLOCK)
@@ -268,27 +195,6 @@ k2_filter(BatchView b, DevParams prm, BinomTable bt, const int32_t* __restrict__
   if (mine) atomicAdd(&cnt_s, mine);
   __syncthreads();
   if (threadIdx.x == 0) tile_count[blockIdx.x] = cnt_s;
-}
-
-static BinomTable make_binom_table() {
-  // exact sums of C(n,k)/2^n restate statrs 0.16 Binomial(0.5, n).cdf for the n <= 30 the reference
-  // allows (candidate.rs:37-47, 223-229)
-  BinomTable t;
-  for (int n = 0; n <= 30; n++) {
-    t.reject[n] = 0;
-    double cdf[32];
-    double c = 1.0, s = 0.0, p2 = 1.0;
-    for (int i = 0; i < n; i++) p2 *= 2.0;
-    for (int k = 0; k <= n; k++) { s += c; cdf[k] = (k >= n) ? 1.0 : s / p2; c = c * (double)(n - k) / (double)(k + 1); }
-    for (int k = 0; k <= n; k++) {
-      double p;
-      if (k == 0) p = 2.0 * cdf[0];
-      else if (k == n) p = 2.0 * (1.0 - (n - 1 >= n ? 1.0 : cdf[n - 1]));
-      else { double lo = cdf[k], hi = 1.0 - cdf[k - 1]; p = 2.0 * (lo < hi ? lo : hi); }
-      if (p < 0.05) t.reject[n] |= (1u << k);
-    }
-  }
-  return t;
 }
 
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,

@@ -64,6 +64,9 @@ struct lcr_ctx {
   int dbg_bg_tiles = 0;     // lcr_debug_set("bg_tiles"): > 0 = the record-free tiles' stores by this many workgroups on a second queue beside the tally
   int dbg_prefill = 0;      // lcr_debug_set("plane_prefill"): 1 = the count planes are zeroed on a second queue while K0 runs -- measured: 0.69 instead of 0.63 ms for the stage; 0: k1_empty_tiles writes the record-free tiles
   int dbg_hist_tiles = 0;   // lcr_debug_set("hist_tiles"): 0 = by survivor density, 1 = the tile form whenever it applies, -1 = never
+  int dbg_fuse_filter = 1;  // lcr_debug_set("fuse_filter"): 0 = pass 1 of the candidate filters always by k2_filter (its own pass over the planes)
+  bool flt_fused = false;   // the last lcr_pileup left k2_filter's flags and per-tile counts (ONT presets: no poly-A pass behind the tally)
+  DevParams flt_dp{};       // ... computed with these parameters
   int dbg_k3_hits = 1;      // lcr_debug_set("k3_hits"): 0 = K3's count pass walks every read's CIGAR itself (the path of batches without hit lists)
   std::vector<lcr_candidate> h_cand;
   std::vector<int32_t> h_cand_off;
@@ -619,7 +622,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   // ALL planes are zeroed on a second queue while K0 runs, K1 then writes the tiles with records and the intron constants.
   // (Under the tally the same stream hurts: the tiles' dependent loads queue behind it.  DESIGN.md K1.)
   const bool prefill = c->dbg_prefill != 0 && nt > 0;
-  if ((prefill || c->dbg_bg_tiles > 0) && !c->fill_stream) { HIPCHK(c, hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fill0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fill1, hipEventDisableTiming)); }
+  if ((prefill || c->dbg_bg_tiles > 0 || c->dbg_bg_tiles == -1) && !c->fill_stream) { HIPCHK(c, hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fill0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fill1, hipEventDisableTiming)); }
   if (prefill) {
     if (!c->fill_stream) { HIPCHK(c, hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fill0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fill1, hipEventDisableTiming)); }
     HIPCHK(c, hipEventRecord(c->ev_fill0, c->stream));            // (the planes' last readers of the previous batch are ahead in the ctx stream)
@@ -627,6 +630,11 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
     HIPCHK(c, hipMemsetAsync(c->planes.p, 0, (size_t)c->n_cols * LCR_NPLANES * 4, c->fill_stream));
     HIPCHK(c, hipEventRecord(c->ev_fill1, c->fill_stream));
   }
+  // pass 1 of the candidate filters inside the tally's epilogue (k2_eval.h): presets whose planes are final when K1 stores them (ONT: the
+  // HiFi presets subtract the poly-A mask afterwards, k1_zonefix); lcr_candidates uses the flags if it is called with the same filters
+  const bool fuse = c->dbg_fuse_filter != 0 && c->dp.ont && nt > 0;
+  c->flt_fused = false;
+  if (fuse) { HIPCHK(c, c->flags.reserve(std::max<size_t>(c->n_cols, 1))); HIPCHK(c, c->tile_count.reserve(std::max(nt, 1) * 4)); }
   for (;;) {
     // the pool and the descriptor array are cut into launch_k0_acct_slots() shards (a block allocates from shard blockIdx % shards)
     const size_t nsh = (size_t)launch_k0_acct_slots();
@@ -660,6 +668,10 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
       HIPCHK(c, hipEventRecord(c->ev_ctl, c->stream));
       if (nt > 0) launch_k1_tiles_b(nt, fill, fill + o_ndiff, fill + o_nch, fill + o_tmp, c->tile_nbase.as<int32_t>(), c->chunk_off.as<int32_t>(),
                                     c->tile_order.as<int32_t>(), c->stream);
+      const bool early_empty = c->dbg_bg_tiles == -1 && nt > 0 && !prefill;
+      if (early_empty)   // (measurement switch) the record-free tiles' store stream beside k0_desc_bin and the start of the tally
+        launch_k1_empty_early(b, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols, c->tile_nbase.as<int32_t>(), c->planes.as<uint32_t>(),
+                              c->tile_order.as<int32_t>(), fill + o_tmp, c->stream, c->fill_stream, c->ev_fill0, c->ev_fill1, fuse ? c->tile_count.as<int32_t>() : nullptr);
       if (nt > 0 && c->n_ops > 0)
         launch_k0_desc_bin(fill + nt + 1, (const unsigned int*)(fill + o_acct), desc_sub, c->desc_tile.as<uint32_t>(), c->desc_val.p, c->chunk_off.as<int32_t>(), fill + o_cur,
                            c->chunks.p, n_blocks / 8 + 1, c->stream);
@@ -668,7 +680,8 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
       if (prefill) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fill1, 0));
       launch_k1_pileup(b, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols, fill, c->chunk_off.as<int32_t>(),
                        c->chunks.p, c->k0_items.as<unsigned long long>(), c->tile_nbase.as<int32_t>(), c->planes.as<uint32_t>(),
-                       c->tile_order.as<int32_t>(), fill + o_tmp, prefill ? 1 : 0, c->stream, c->dbg_bg_tiles > 0 ? c->fill_stream : nullptr, c->ev_fill0, c->ev_fill1, c->dbg_bg_tiles);
+                       c->tile_order.as<int32_t>(), fill + o_tmp, prefill ? 1 : 0, c->stream, (c->dbg_bg_tiles > 0 || c->dbg_bg_tiles == -1) ? c->fill_stream : nullptr, c->ev_fill0, c->ev_fill1, c->dbg_bg_tiles,
+                       fuse ? c->flags.as<uint8_t>() : nullptr, fuse ? c->tile_count.as<int32_t>() : nullptr);
       if (!c->dp.ont && c->dp.dist_to_end > 0)
         launch_k1_zonefix(b, c->read_bin.as<ReadBin>(), c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->stream); }
     HIPCHK(c, hipGetLastError());
@@ -691,6 +704,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   c->stage_bytes = c->n_bases + 4 * c->n_cigar + 37 * (int64_t)b.n_reads + (4 * LCR_NPLANES + 1) * c->n_cols;
   c->have_planes = true;
   c->have_cand = c->have_frag = c->have_phase = false;
+  c->flt_fused = fuse; c->flt_dp = c->dp;
   return LCR_OK;
 }
 
@@ -722,7 +736,12 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->tile_count.reserve(std::max(nt, 1) * 4));
   HIPCHK(c, c->tile_off.reserve((std::max(nt, 1) + 1) * 4));
   HIPCHK(c, c->total.reserve(16));
+  // (the tally's epilogue has taken pass 1 already when lcr_pileup ran with the same filter parameters: ONT presets, k2_eval.h)
+  const DevParams &fa = c->flt_dp, &fb = c->dp;
+  const bool have_flt = c->flt_fused && c->dbg_fuse_filter != 0 && fa.ont == fb.ont && fa.min_depth == fb.min_depth && fa.max_depth == fb.max_depth && fa.low_cnt_cut == fb.low_cnt_cut &&
+                        fa.use_strand_bias == fb.use_strand_bias && fa.min_af_intron == fb.min_af_intron && fa.low_frac_cut == fb.low_frac_cut && fa.sor_threshold == fb.sor_threshold;
   { Timer t(c, LCR_K_CAND_FILTER);
+    if (!have_flt)
     launch_k2_filter(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
                      c->planes.as<uint32_t>(), c->k0_tile_fill.as<int32_t>(), c->flags.as<uint8_t>(), c->tile_count.as<int32_t>(), c->stream);
     launch_scan_i32(c->scan_tmp, c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(), nt, c->total.as<int32_t>(), c->stream); }
@@ -1154,9 +1173,10 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
   else if (k == "tie_arith") d.tie_arith = (int)std::max<int64_t>(0, std::min<int64_t>(value, 3));   // (3 = the default: all four classes in the enumeration branch)
   else if (k == "timing_mask") c->timing_mask = (uint32_t)value;
   else if (k == "plane_prefill") c->dbg_prefill = value != 0;
-  else if (k == "bg_tiles") c->dbg_bg_tiles = (int)std::max<int64_t>(0, std::min<int64_t>(value, 4096));
+  else if (k == "bg_tiles") c->dbg_bg_tiles = (int)std::max<int64_t>(-2, std::min<int64_t>(value, 4096));
   else if (k == "hist_tiles") c->dbg_hist_tiles = value > 0 ? 1 : value < 0 ? -1 : 0;
   else if (k == "k3_hits") c->dbg_k3_hits = value != 0;
+  else if (k == "fuse_filter") c->dbg_fuse_filter = value != 0;
   else if (k == "grid_spec_batch") d.spec_batch = (int)value;
   else if (k == "enum_bits") d.enum_bits = (int)value;
   else if (k == "grid_spec_lanes") d.spec_lanes = (int)std::max<int64_t>(1, std::min<int64_t>(value, 16));

@@ -490,6 +490,34 @@ def test_fragment_rows_beyond_the_hit_lists(engine_cls, orc):
     E.close()
 
 
+def test_filter_pass_in_the_tally_epilogue(engine_cls, orc):
+    """Round 6: on the ONT presets (no poly-A pass behind the tally) k1_pileup's epilogue takes pass 1 of the candidate filters
+    (candidate.rs:90-234, k2_eval.h) on the counts it holds, and lcr_candidates uses those flags when it is called with the same filter
+    parameters.  Both ways -- and a call with other parameters than the pileup's, which must take k2_filter's pass -- give the oracle's
+    candidates; strand-bias preset (ont-cdna) and the one without (ont-drna)."""
+    for prof, preset, seed in (("ont-cdna", "ont-cdna", 21), ("ont-drna", "ont-drna", 22)):
+        b = synth.make_batch(prof, n_genes=4, gene_len=11000, depth=40, seed=seed)
+        p = _abi.make_params(preset, seed=seed)
+        full_check(engine_cls, orc, b, p)                       # (default: fused)
+        E1, E0 = engine_cls(0, p), engine_cls(0, p)
+        E0.debug_set("fuse_filter", 0)
+        E1.load_batch(b).run_all(); E0.load_batch(b).run_all()
+        assert _result_bytes(E1) == _result_bytes(E0)
+        # other filter parameters at lcr_candidates than at lcr_pileup: the flags of the epilogue do not apply
+        p2 = _abi.make_params(preset, seed=seed, min_depth=int(p.min_depth) + 6)
+        E1.load_batch(b).fill_data_into_freq_vec()
+        E1.params = p2
+        E1.get_candidate_snps().get_fragments().phase()
+        E0.params = p2
+        E0.load_batch(b).run_all()
+        assert _result_bytes(E1) == _result_bytes(E0)
+        c2 = E1.candidates()[0]
+        E1.params = p
+        E1.load_batch(b).run_all()
+        assert E1.candidates()[0].size >= c2.size
+        E1.close(); E0.close()
+
+
 def test_tie_only_steps_take_the_repair_pass(engine_cls, orc):
     """A batch whose enumeration restarts meet steps with tie changes only (oracle census: 16 of them in one region): the fast
     kernels put those restarts on the repair list, k4_enum_redo decides the steps by the reference's sums of f64 scores, and
