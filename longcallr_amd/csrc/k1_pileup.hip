@@ -44,6 +44,9 @@
 #define K1_CPT (LCR_TILE / K1_THREADS)  // columns per thread in the tile epilogue
 #define K1_RPB 2                        // records per thread and batch
 #define K1_PMAP (8 * K1_THREADS)         // pieces per batch with a direct piece -> record map in LDS
+#ifndef K1_NT_STORES
+#define K1_NT_STORES 0                  // k1_empty_tiles: non-temporal plane stores (measurement builds: -DK1_NT_STORES=1; measured slower, HISTORY.md Appendix C)
+#endif
 #ifndef K1_PIF
 #define K1_PIF 4                        // 16-byte pieces in flight per thread (a batch of 1024 records has ~2500 pieces)
 #endif
@@ -572,8 +575,14 @@ __global__ void __launch_bounds__(128) k1_empty_tiles(BatchView b, const int32_t
     const int64_t o = gcol0 + col;
     if (col + 4 <= tlen) {
 #pragma unroll
-      for (int k = 0; k < LCR_NPLANES; k++)
-        *reinterpret_cast<uint4*>(planes + (int64_t)k * n_cols + o) = k == LCR_PL_N ? make_uint4(nb, nb, nb, nb) : make_uint4(0u, 0u, 0u, 0u);
+      for (int k = 0; k < LCR_NPLANES; k++) {
+        // (K1_NT_STORES: non-temporal stores -- 350 MB of zeros that nobody reads before the next batch would then not push the read bases k2_hist
+        // asks for next out of the Infinity Cache; measured: k2_hist 0.24 -> 0.20-0.23 ms, but this kernel 53 -> ~110 us: slower in sum)
+        typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+        const u4_t v = k == LCR_PL_N ? (u4_t){nb, nb, nb, nb} : (u4_t){0u, 0u, 0u, 0u};
+        if (K1_NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<u4_t*>(planes + (int64_t)k * n_cols + o));
+        else *reinterpret_cast<u4_t*>(planes + (int64_t)k * n_cols + o) = v;
+      }
     } else {
       for (int c2 = col; c2 < tlen; c2++) {
 #pragma unroll
