@@ -990,29 +990,63 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
     if (tid == 0) { s_e0i = a; s_epi = b; }
   }
   __syncthreads();
-  for (int l = tid; l <= 64; l += nt) {   // first row whose start offset is >= l * c
-    const uint32_t target = (uint32_t)l * c;
-    int lo = 0, hi = R;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (rp[mid] < target) lo = mid + 1; else hi = mid; }
-    first_row[l] = (uint16_t)lo;
-  }
   for (int e = tid; e < (int)E; e += nt) {
     const uint32_t cv = P.cval[rd.e_off + e];
     int col = 0;
     for (int i = 0; i < S; i++) col += (int)((uint32_t)e >= (uint32_t)cps[i + 1]);
     csc[e] = (uint32_t)P.crow[rd.e_off + e] | ((uint32_t)col << 16) | ((cv & 32u) << 16) | ((cv & 31u) << 22) | 0x80000000u;
   }
+  // Round 6: the rows of ONE entry (57 % of the phasing rows of the ONT-cDNA / MAS-Seq batches: a read over one het site) are taken out of
+  // the sigma step's main loop.  Their decision is the sign of one term -- bit operations, no sums, no tie -- in a pass of their own, a
+  // lane per row; the main loop's lanes share the entries of the OTHER rows evenly (its eight-sums row end then runs for those only).
+  //   perm[0 .. nM)        the rows of more than one entry, in row order      rpm[k] = first csr slot of perm[k] (rpm[nM] = eM)
+  //   perm[nM .. nM + nS)  the rows of one entry, in row order: csr[eM + x]
+  uint16_t* const perm = (uint16_t*)(lds + L.pos);
+  uint16_t* const rpm = perm + ((R + 3) & ~3);
+  uint16_t* const kidx = (uint16_t*)(lds + L.state);   // (staging only: the waves' state area is set up behind the barrier below)
+  __shared__ int s_cnt[3];
+  __syncthreads();
+  if (tid < 64) {
+    const int ln = tid;
+    const unsigned long long lt = (1ull << ln) - 1ull;
+    int nM = 0, eM = 0, nS = 0;
+    for (int base = 0; base < R; base += 64) {
+      const int r = base + ln;
+      const int n = r < R ? (int)rp[r + 1] - (int)rp[r] : 0;
+      const bool isM = n >= 2, isS = n == 1;
+      const unsigned long long bm = __ballot(isM), bs = __ballot(isS);
+      const int inc = wave_incl_scan(isM ? n : 0);
+      if (isM) { const int k = nM + __popcll(bm & lt); kidx[r] = (uint16_t)k; perm[k] = (uint16_t)r; rpm[k] = (uint16_t)(eM + inc - n); }
+      if (isS) kidx[r] = (uint16_t)(nS + __popcll(bs & lt));
+      nM += __popcll(bm); nS += __popcll(bs); eM += __builtin_amdgcn_readlane(inc, 63);
+    }
+    if (ln == 0) { rpm[nM] = (uint16_t)eM; s_cnt[0] = nM; s_cnt[1] = eM; s_cnt[2] = nS; }
+  }
+  __syncthreads();
+  const int nM = s_cnt[0], eM = s_cnt[1], nS = s_cnt[2];
+  const uint32_t cm = enum_chunk((uint32_t)eM);
+  for (int l = tid; l <= 64; l += nt) {   // first row (in perm) whose first slot is >= l * cm: the main loop's lane <-> rows map
+    const uint32_t target = (uint32_t)l * cm;
+    int lo = 0, hi = nM;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (rpm[mid] < target) lo = mid + 1; else hi = mid; }
+    first_row[l] = (uint16_t)lo;
+  }
   __syncthreads();
   for (int r = tid; r < R; r += nt) {
     const int e0 = rp[r], e1 = rp[r + 1];
     if (e0 == e1) continue;
-    const uint32_t owner = (uint32_t)e0 / c;
-    const uint32_t roff = (uint32_t)r - first_row[owner];
+    int at; uint32_t roff = 0;
+    if (e1 - e0 >= 2) {
+      const int k = kidx[r];
+      at = rpm[k];
+      const uint32_t owner = (uint32_t)at / cm;   // (a lane's rows start at or behind owner * cm and in front of (owner + 1) * cm)
+      roff = (uint32_t)k - first_row[owner];
+    } else { perm[nM + kidx[r]] = (uint16_t)r; at = eM + kidx[r]; }
     for (int e = e0; e < e1; e++) {
       const uint32_t v = P.pval[rd.e_off + e];
       const uint32_t meta = (uint32_t)P.pcol[rd.e_off + e] | (v & 32u) | (e + 1 == e1 ? 64u : 0u) | 128u;
       const uint2 w = wl2[v & 31u];
-      csr[e] = make_uint2(w.x | (meta << 24), w.y | (roff << 24));
+      csr[at + (e - e0)] = make_uint2(w.x | (meta << 24), w.y | (roff << 24));
       ent16[e] = (uint16_t)((meta & 63u) | ((v & 31u) << 6) | (e + 1 == e1 ? 0x800u : 0u));
     }
   }
@@ -1026,11 +1060,12 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
   uint32_t* const ms = (uint32_t*)(mt + 32);                                    // [3][8]: dneg, eta0, etap of every restart
   uint32_t* const tq = ms + 24;                                            // queue of tied rows: row | tie8 << 16 | sneg8 << 24
   uint32_t* const tq_n = tq + ENUM_TQ;
-  const int r_a = first_row[lane], r_b = first_row[lane + 1];
-  const int s0 = rp[r_a], s1 = rp[r_b];
+  const int r_a = first_row[lane], r_b = first_row[lane + 1];   // (positions in perm: the lane's rows of more than one entry)
+  const int s0 = rpm[r_a], s1 = rpm[r_b];
   const int c0 = min((int)E, lane * (int)c), c1 = min((int)E, (lane + 1) * (int)c);
-  int n_sig;
-  { int n = s1 - s0; for (int d = 32; d >= 1; d >>= 1) n = max(n, __shfl_xor(n, d, 64)); n_sig = __builtin_amdgcn_readfirstlane(n); }
+  int n_sig_m;   // entries of the main loop's longest lane
+  const int em = s1 - s0;
+  { int a = em; for (int d = 32; d >= 1; d >>= 1) a = max(a, __shfl_xor(a, d, 64)); n_sig_m = __builtin_amdgcn_readfirstlane(a); }
   const int n_del = (int)min(c, E);
   const uint32_t smask = S >= 32 ? 0xffffffffu : ((1u << S) - 1u);
   const uint32_t e0_init = s_e0i, ep_init = s_epi;
@@ -1081,17 +1116,17 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
 #pragma unroll
         for (int s = 0; s < 8; s++) { alo[s] = 0; ahi[s] = 0; }
         uint32_t uacc = 0, sg16 = 0, sgb = 0;
-        int cur = -1;
-        for (int x0 = 0; x0 < n_sig; x0 += 4) {
+        int cur = -1, crow = 0;
+        for (int x0 = 0; x0 < n_sig_m; x0 += 4) {
           uint2 v[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) v[u] = s0 + x0 + u < s1 ? csr[s0 + x0 + u] : make_uint2(0, 0);
+          for (int u = 0; u < 4; u++) v[u] = x0 + u < em ? csr[s0 + x0 + u] : make_uint2(0, 0);
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t v0 = v[u].x, v1 = v[u].y;
             const uint32_t m = v0 >> 24, i = m & 31u;
             const int roff = (int)(v1 >> 24);
-            if ((m & 128u) && roff != cur) { cur = roff; sgb = sg8[r_a + roff]; sg16 = enum_spread8(sgb); }
+            if ((m & 128u) && roff != cur) { cur = roff; crow = perm[r_a + roff]; sgb = sg8[crow]; sg16 = enum_spread8(sgb); }
             const uint32_t mm = mt[i].x;
             const uint32_t use16 = (m & 128u) ? (mm & 0xFFFFu) : 0u;                          // het sites only
             const uint32_t hit16 = (((m & 32u) ? 0x5555u : 0u) ^ sg16 ^ (mm >> 16)) & use16;   // p == sigma * delta
@@ -1114,7 +1149,7 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
               uacc = 0;
               fl &= act; tie &= act;
               any8 |= fl;
-              const int row = r_a + roff;
+              const int row = crow;
               if (fl) sg8[row] = (uint8_t)(sgb ^ fl);
               if (tie) {
                 // A == B at a row with a het entry: the f64 scores decide (a row without one scores the same for both signs, term by term)
@@ -1137,6 +1172,29 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
                 }
               }
             }
+          }
+        }
+        // ---- the rows of one entry, a lane per row: the sum is +-w, the row flips where it is negative (w < 0 for q <= 3) -- no tie (w != 0)
+        for (int x0 = lane; x0 < nS; x0 += 4 * 64) {
+          uint2 v[4]; int rw[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int x = x0 + 64 * u; v[u] = x < nS ? csr[eM + x] : make_uint2(0, 0); rw[u] = x < nS ? (int)perm[nM + x] : 0; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t v0 = v[u].x, v1 = v[u].y;
+            const uint32_t m = v0 >> 24, i = m & 31u;
+            if (!(m & 128u)) continue;
+            const int row = rw[u];
+            const uint32_t sb = sg8[row], s16 = enum_spread8(sb);
+            const uint32_t mm = mt[i].x;
+            const uint32_t use16 = mm & 0xFFFFu;                                              // het sites only
+            const uint32_t hit16 = (((m & 32u) ? 0x5555u : 0u) ^ s16 ^ (mm >> 16)) & use16;   // p == sigma * delta: the term is + w
+            const bool wneg = ((v1 >> 23) & 1u) != 0;                                         // (sign of the signed 24-bit limb = sign of w)
+            uint32_t f = wneg ? hit16 : (use16 & ~hit16);                                     // states whose sum is negative, at bit 2 s
+            f &= 0x5555u; f = (f | (f >> 1)) & 0x3333u; f = (f | (f >> 2)) & 0x0F0Fu; f = (f | (f >> 4)) & 0xFFu;
+            f &= act;
+            any8 |= f;
+            if (f) sg8[row] = (uint8_t)(sb ^ f);
           }
         }
       }
@@ -1282,11 +1340,15 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
 #pragma unroll
       for (int s = 0; s < 8; s++) { hs[s] = 0; word[s] = 0; }
       int nb = 0, widx = 0;
-      for (int x = 0; x < n_sig; x++) {
-        const uint2 v = s0 + x < s1 ? csr[s0 + x] : make_uint2(0, 0);
+      const int n_one = (nS + 63) / 64;   // (the rows of one entry: lane <-> row x = lane + 64 j, behind the lane's share of the others)
+      for (int x = 0; x < n_sig_m + n_one; x++) {
+        const bool one = x >= n_sig_m;
+        const int xs = lane + 64 * (x - n_sig_m);
+        const uint2 v = one ? (xs < nS ? csr[eM + xs] : make_uint2(0, 0)) : (x < em ? csr[s0 + x] : make_uint2(0, 0));
         const uint32_t m = v.x >> 24, i = m & 31u, roff = v.y >> 24;
         const uint32_t y = mt[i].y, dn8 = y & 0xFFu, h8 = (y >> 8) & 0xFFu, ep8 = (y >> 16) & 0xFFu;
-        const uint32_t p8 = (m & 32u) ? 0xFFu : 0u, sn8 = sg8[min(r_a + (int)roff, max(R - 1, 0))];
+        const int srow = (m & 128u) ? (int)perm[one ? nM + xs : r_a + (int)roff] : 0;
+        const uint32_t p8 = (m & 32u) ? 0xFFu : 0u, sn8 = sg8[srow];
         const uint32_t match = (m & 128u) ? ((h8 & (p8 ^ sn8 ^ dn8)) | (~h8 & ~(p8 ^ ep8))) & 0xFFu : 0u;
 #pragma unroll
         for (int s = 0; s < 8; s++) word[s] |= ((match >> s) & 1u) << nb;

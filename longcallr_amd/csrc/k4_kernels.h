@@ -27,7 +27,7 @@ constexpr uint32_t ENUM_TCAP = 256;   // configurations of maximal objective com
 constexpr uint32_t ENUM_BITS_PER = 64;   // restarts per tile of k4_enum_bits (ENUM_WAVES waves x 8 x 2)
 __host__ __device__ inline uint32_t enum_bits_sp(uint32_t S) { return (S + 7) & ~7u; }   // SNP slots of M[state][]
 __host__ __device__ inline uint32_t enum_bits_stride(uint32_t R, uint32_t S) { return ((R + 15) & ~7u) + 8 * 8 * enum_bits_sp(S) + 8 * 32 + 4 * 24 + 4 * (ENUM_TQ + 2); }
-struct EnumLayout { uint32_t lut, csr, csc, rp, first_row, ent16, state, stride, total; };
+struct EnumLayout { uint32_t lut, csr, csc, rp, first_row, ent16, pos, state, stride, total; };
 __host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E, bool bits = false, uint32_t S = 32) {
   EnumLayout L;
   uint32_t o = 256;
@@ -35,9 +35,10 @@ __host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E, bool b
   L.csr = o; o += 8 * E;
   L.csc = o; o += 4 * E;
   L.rp = o; o += 2 * (R + 1);
-  L.first_row = o; o += 2 * 65;
+  L.first_row = o; o += 2 * 65 + (bits ? 2 * 64 : 0);   // (k4_enum_bits: + the entries of every lane's run that belong to rows of more than one entry)
   o = (o + 7) & ~7u;
   L.ent16 = o; o += 2 * ((E + 3) & ~3u);
+  L.pos = o; if (bits) o += 2 * ((R + 3) & ~3u) + 2 * ((R + 4) & ~3u);   // (k4_enum_bits: the rows in the order [more than one entry | one entry] + the entry prefix of the former)
   o = (o + 15) & ~15u;
   L.state = o;
   L.stride = bits ? enum_bits_stride(R, S) : 8 * ((R + 63) / 64 + 1) + 8 * 32 + 4 * (ENUM_TQ + 2);
