@@ -111,7 +111,7 @@ k4_enum_resolve(PhaseDev P, const EnumSpan* __restrict__ spans, const int64_t* _
   __shared__ uint32_t s_nev;
   __shared__ long long s_best[ENUM_WAVES];
   __shared__ uint32_t s_wcnt[ENUM_WAVES], s_dif[ENUM_WAVES], s_ntied;
-  constexpr uint32_t TLCAP = 2048;
+  const uint32_t TLCAP = resolve_tlcap((uint32_t)S);
   uint16_t* tl = (uint16_t*)(lds + L.res + 16 * ENUM_TCAP + 96 * 10 + 16);   // [TLCAP] the restarts of maximal objective
   __shared__ uint32_t s_win, s_wj[ENUM_WAVES], s_first;   // s_first: the first restart of maximal objective (32 bits: tl[] holds 16)
   __shared__ double s_winsum, s_wsum[ENUM_WAVES];

@@ -51,6 +51,9 @@ __host__ __device__ inline uint32_t enum_state_words(uint32_t R) { return (R + 6
 // LDS image of k4_enum_resolve (one workgroup per region): table | rp u16 | ent16 | pse f64[E + 8] | sigma words of the reference
 // configuration | rows with a het entry | rows by first het site [S][nk] | per compared configuration: restart, f64 objective |
 // events of the reference's chain
+// entries of k4_enum_resolve's list of the restarts of maximal objective: every restart of a region of up to 12 SNPs (round 6: the list held 2 048, and a
+// sweep with max_enum_snps = 12 met a region with more maxima than that -- first maximum kept, counted); 4 096 beyond (counted when exceeded)
+__host__ __device__ inline uint32_t resolve_tlcap(uint32_t S) { return S >= 12 ? 4096u : (S < 6 ? 64u : (1u << S)); }
 struct ResolveLayout { uint32_t lut, rp, ent16, pse, sg_ref, hetw, repmask, rowsnps, res, total; };
 __host__ __device__ inline ResolveLayout resolve_layout(uint32_t R, uint32_t E, uint32_t S) {
   ResolveLayout L;
@@ -67,7 +70,7 @@ __host__ __device__ inline ResolveLayout resolve_layout(uint32_t R, uint32_t E, 
   L.repmask = o; o += 8 * nk * (S ? S : 1);
   L.rowsnps = o; o += 4 * (R + 1);        // the SNPs of a row's entries as a mask
   o = (o + 7) & ~7u;
-  L.res = o; o += ENUM_TCAP * 16 + 96 * 10 + 16 + 2 * 2048;   // + the list of the restarts of maximal objective
+  L.res = o; o += ENUM_TCAP * 16 + 96 * 10 + 16 + 2 * resolve_tlcap(S);   // + the list of the restarts of maximal objective
   L.total = (o + 15) & ~15u;
   return L;
 }
