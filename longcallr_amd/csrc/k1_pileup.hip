@@ -717,6 +717,17 @@ void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* til
                       uint8_t* flt_flags, int32_t* flt_count) {
   static const BinomTable bt = make_binom_table();
   if (n_tiles == 0) return;
+  if (bg && bg_wgs == -3) {
+    // HiFi presets (round 6): the record-free tiles' stores on a second queue BESIDE the poly-A pass that the caller queues on `s` behind the
+    // tally (k1_zonefix_ends: instruction-bound, a few global atomics, on tiles with records only -- the store stream touches the other
+    // tiles); the caller makes `s` wait for ev1 behind the poly-A pass
+    hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_fill, ent_off,
+                       (const uint2*)ents, recs, tile_nbase, planes, order, tiles_tmp + 80 /* TileScanTmp::n_full */, bt, flt_flags, flt_count);
+    hipEventRecord(ev0, s); hipStreamWaitEvent(bg, ev0, 0);
+    hipLaunchKernelGGL(k1_empty_tiles, dim3(n_tiles), dim3(128), 0, bg, b, tile_region, tile_col0, n_cols, tile_nbase, planes, order, tiles_tmp + 80, zeroed, n_tiles, 0, flt_count);
+    hipEventRecord(ev1, bg);
+    return;
+  }
   if (bg_wgs == -2) {
     // lcr_debug_set("bg_tiles", -2): the record-free tiles' stores FIRST, the tally behind them on the same queue -- the tally then is the last
     // kernel of the stage to touch memory, and what it read (the read bases) is what the Infinity Cache holds when k2_hist asks for the
