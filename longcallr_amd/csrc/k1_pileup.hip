@@ -553,25 +553,21 @@ k1_pileup(BatchView b, DevParams prm, const int32_t* __restrict__ tile_region, c
 // are like this: a pure store stream, written by small workgroups without LDS (inside k1_pileup's 512-thread, 52 KB
 // workgroups -- three per CU -- the same stores ran at 3.7 TB/s; hipMemset reaches 6.8 on this part).
 // One workgroup of 128 threads per tile: 16-byte stores, 4 consecutive columns per thread and plane.
-__global__ void __launch_bounds__(128) k1_empty_tiles(BatchView b, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0,
-                                                       int64_t n_cols, const int32_t* __restrict__ tile_nbase, uint32_t* __restrict__ planes,
-                                                       const int32_t* __restrict__ order, const int32_t* __restrict__ n_full, int zeroed, int n_tiles, int bg_tiles,
-                                                       int32_t* __restrict__ flt_count) {
-  const int nf = *n_full;
-  if (*b.error_flag != 0) return;
-  // bg_tiles > 0: a few workgroups walk all record-free tiles (a throttled store stream beside the tally, launch_k1_pileup)
-  for (int bt = blockIdx.x; bt + nf < n_tiles; bt += bg_tiles > 0 ? (int)gridDim.x : n_tiles) {
+// one record-free tile (the bt-th behind the tiles with records in `order`) by the `nthr` threads lt = 0 .. nthr - 1 (nthr = 128)
+__device__ __forceinline__ void empty_tile_body(const BatchView& b, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0, int64_t n_cols,
+                                                const int32_t* __restrict__ tile_nbase, uint32_t* __restrict__ planes, const int32_t* __restrict__ order, int nf, int bt,
+                                                int lt, int zeroed, int32_t* __restrict__ flt_count) {
   const int tile = order[nf + bt];
-  if (flt_count && threadIdx.x == 0) flt_count[tile] = 0;   // (a record-free tile has no survivor of the count filters: k2_filter's verdict for it)
+  if (flt_count && lt == 0) flt_count[tile] = 0;   // (a record-free tile has no survivor of the count filters: k2_filter's verdict for it)
   const int g = tile_region[tile], tc0 = tile_col0[tile];
   const int tlen = min(LCR_TILE, b.len[g] - tc0);
   const int64_t gcol0 = b.col_off[g] + tc0;
   const uint32_t nb = (uint32_t)tile_nbase[tile];
   if (zeroed) {   // the planes were zeroed while K0 ran (lcr_pileup): only the intron plane of a tile inside introns is left to write
-    if (nb != 0) for (int col = (int)threadIdx.x; col < tlen; col += 128) planes[(int64_t)LCR_PL_N * n_cols + gcol0 + col] = nb;
-    continue;
+    if (nb != 0) for (int col = lt; col < tlen; col += 128) planes[(int64_t)LCR_PL_N * n_cols + gcol0 + col] = nb;
+    return;
   }
-  for (int col = (int)threadIdx.x * 4; col < tlen; col += 128 * 4) {
+  for (int col = lt * 4; col < tlen; col += 128 * 4) {
     const int64_t o = gcol0 + col;
     if (col + 4 <= tlen) {
 #pragma unroll
@@ -590,7 +586,16 @@ __global__ void __launch_bounds__(128) k1_empty_tiles(BatchView b, const int32_t
       }
     }
   }
-  }
+}
+__global__ void __launch_bounds__(128) k1_empty_tiles(BatchView b, const int32_t* __restrict__ tile_region, const int32_t* __restrict__ tile_col0,
+                                                       int64_t n_cols, const int32_t* __restrict__ tile_nbase, uint32_t* __restrict__ planes,
+                                                       const int32_t* __restrict__ order, const int32_t* __restrict__ n_full, int zeroed, int n_tiles, int bg_tiles,
+                                                       int32_t* __restrict__ flt_count) {
+  const int nf = *n_full;
+  if (*b.error_flag != 0) return;
+  // bg_tiles > 0: a few workgroups walk all record-free tiles (a throttled store stream beside the tally, launch_k1_pileup)
+  for (int bt = blockIdx.x; bt + nf < n_tiles; bt += bg_tiles > 0 ? (int)gridDim.x : n_tiles)
+    empty_tile_body(b, tile_region, tile_col0, n_cols, tile_nbase, planes, order, nf, bt, (int)threadIdx.x, zeroed, flt_count);
 }
 
 // Workgroups are started in grid order and a tile's time goes with its records (none: a few us; 15 000: ~150 us), so K1
@@ -717,6 +722,11 @@ void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* til
                       uint8_t* flt_flags, int32_t* flt_count) {
   static const BinomTable bt = make_binom_table();
   if (n_tiles == 0) return;
+  if (bg_wgs == -4) {   // the tally alone: the record-free tiles go with the poly-A pass (launch_k1_zonefix_tiles, HiFi presets)
+    hipLaunchKernelGGL(k1_pileup, dim3(n_tiles), dim3(K1_THREADS), 0, s, b, p, tile_region, tile_col0, n_cols, tile_fill, ent_off,
+                       (const uint2*)ents, recs, tile_nbase, planes, order, tiles_tmp + 80 /* TileScanTmp::n_full */, bt, flt_flags, flt_count);
+    return;
+  }
   if (bg && bg_wgs == -3) {
     // HiFi presets (round 6): the record-free tiles' stores on a second queue BESIDE the poly-A pass that the caller queues on `s` behind the
     // tally (k1_zonefix_ends: instruction-bound, a few global atomics, on tiles with records only -- the store stream touches the other
@@ -887,9 +897,7 @@ void launch_k1_zonefix_slots(const BatchView& b, int D, int L, int64_t n_cols, u
 // start in [c-L, c+1]) in a 64-bit mask per base; most read ends have none and stop there.  The marked offsets are
 // then walked with a CIGAR cursor (forwards in the leading zone, backwards from the read's reference end in the
 // trailing zone).
-__global__ void __launch_bounds__(LCR_BLOCK)
-k1_zonefix_ends(BatchView b, const ReadBin* __restrict__ rbin, int D, int L, int64_t n_cols, uint32_t* __restrict__ planes) {
-  const int id = blockIdx.x * LCR_BLOCK + threadIdx.x;
+__device__ __forceinline__ void zonefix_ends_body(const BatchView& b, int id, int D, int L, int64_t n_cols, uint32_t* __restrict__ planes) {
   const int r = id >> 1, end = id & 1;
   if (r >= b.n_reads) return;
   const int seq_len = b.seq_len[r], lead = b.lead[r], reb = seq_len - b.trail[r];
@@ -1022,6 +1030,42 @@ k1_zonefix_ends(BatchView b, const ReadBin* __restrict__ rbin, int D, int L, int
   }
 }
 
+__global__ void __launch_bounds__(LCR_BLOCK)
+k1_zonefix_ends(BatchView b, const ReadBin* __restrict__ rbin, int D, int L, int64_t n_cols, uint32_t* __restrict__ planes) {
+  zonefix_ends_body(b, (int)(blockIdx.x * LCR_BLOCK + threadIdx.x), D, L, n_cols, planes);
+}
+// (measurement switch zonefix_fused; measured SLOWER: the tally group 1.21 -> 1.36 ms on the C4 share -- the pass's atomics and dependent loads queue behind the store stream)
+// Round 6 (HiFi presets): the poly-A pass and the record-free tiles' stores in ONE launch.  The pass is instruction-bound (0.33 ms on the C4
+// share), the stores are a pure HBM write stream (0.19-0.22 ms) on OTHER tiles (a masked base lies in a tile with records), and as two
+// kernels on one queue they ran one after the other (on two queues the second stream lands on a hardware queue of the phase stage's: slower).
+// Of every (rt + 1) consecutive workgroups the first takes 256 read ends, the others two record-free tiles each, until the read ends run out.
+__global__ void __launch_bounds__(LCR_BLOCK)
+k1_zonefix_ends_tiles(BatchView b, int D, int L, int64_t n_cols, uint32_t* __restrict__ planes, const int32_t* __restrict__ tile_region,
+                      const int32_t* __restrict__ tile_col0, const int32_t* __restrict__ tile_nbase, const int32_t* __restrict__ order,
+                      const int32_t* __restrict__ n_full, int n_tiles, int32_t* __restrict__ flt_count, unsigned int n_zf, unsigned int rt) {
+  const unsigned int q = blockIdx.x;
+  unsigned int unit;   // pair of record-free tiles, or ~0u: a workgroup of the poly-A pass
+  unsigned int zf = 0;
+  if (q < n_zf * (rt + 1u)) {
+    const unsigned int a = q / (rt + 1u), r = q - a * (rt + 1u);
+    if (r == 0) { unit = ~0u; zf = a; } else unit = a * rt + (r - 1u);
+  } else unit = n_zf * rt + (q - n_zf * (rt + 1u));
+  if (unit == ~0u) { zonefix_ends_body(b, (int)(zf * LCR_BLOCK + threadIdx.x), D, L, n_cols, planes); return; }
+  const int nf = *n_full;
+  if (*b.error_flag != 0) return;
+  const int bt = 2 * (int)unit + (int)(threadIdx.x >> 7);
+  if (bt + nf < n_tiles) empty_tile_body(b, tile_region, tile_col0, n_cols, tile_nbase, planes, order, nf, bt, (int)(threadIdx.x & 127), 0, flt_count);
+}
+// the tally alone + (behind it, one launch) the poly-A pass with the record-free tiles
+bool launch_k1_zonefix_tiles(const BatchView& b, int D, int L, int64_t n_cols, uint32_t* planes, const int32_t* tile_region, const int32_t* tile_col0,
+                             int32_t n_tiles, const int32_t* tile_nbase, const int32_t* order, const int32_t* tiles_tmp, int32_t* flt_count, hipStream_t s) {
+  if (!(b.n_reads > 0 && D > 0 && D <= 63 && L >= 2 && L <= 16 && n_tiles > 0)) return false;
+  const unsigned int n_zf = (unsigned int)((2ll * b.n_reads + LCR_BLOCK - 1) / LCR_BLOCK), n_units = (unsigned int)((n_tiles + 1) / 2);
+  const unsigned int rt = n_units / n_zf;
+  hipLaunchKernelGGL(k1_zonefix_ends_tiles, dim3(n_zf + n_units), dim3(LCR_BLOCK), 0, s, b, D, L, n_cols, planes, tile_region, tile_col0, tile_nbase, order,
+                     tiles_tmp + 80, n_tiles, flt_count, n_zf, rt);
+  return true;
+}
 void launch_k1_zonefix(const BatchView& b, const ReadBin* rbin, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s) {
   if (b.n_reads > 0 && D > 0 && D <= 63 && L >= 2 && L <= 16) {   // (L = 1: every base is a window, the per-offset kernel)
     const int n = 2 * b.n_reads;

@@ -64,6 +64,7 @@ struct lcr_ctx {
   int dbg_bg_tiles = 0;     // lcr_debug_set("bg_tiles"): > 0 = the record-free tiles' stores by this many workgroups on a second queue beside the tally
   int dbg_prefill = 0;      // lcr_debug_set("plane_prefill"): 1 = the count planes are zeroed on a second queue while K0 runs -- measured: 0.69 instead of 0.63 ms for the stage; 0: k1_empty_tiles writes the record-free tiles
   int dbg_hist_tiles = 0;   // lcr_debug_set("hist_tiles"): 0 = by survivor density, 1 = the tile form whenever it applies, -1 = never
+  int dbg_zf_fused = 0;     // lcr_debug_set("zonefix_fused", 1) (measurement switch): HiFi presets -- the poly-A pass and the record-free tiles' stores in one launch; measured slower (HISTORY.md Appendix C)
   int dbg_zf_overlap = 0;   // lcr_debug_set("zonefix_overlap", 1) (measurement switch): HiFi presets -- the record-free tiles' stores on a second queue beside the poly-A pass; measured slower with the asynchronous phase stage (HISTORY.md Appendix C)
   int dbg_fuse_filter = 1;  // lcr_debug_set("fuse_filter"): 0 = pass 1 of the candidate filters always by k2_filter (its own pass over the planes)
   bool flt_fused = false;   // the last lcr_pileup left k2_filter's flags and per-tile counts (ONT presets: no poly-A pass behind the tally)
@@ -623,6 +624,9 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   // ALL planes are zeroed on a second queue while K0 runs, K1 then writes the tiles with records and the intron constants.
   // (Under the tally the same stream hurts: the tiles' dependent loads queue behind it.  DESIGN.md K1.)
   const bool prefill = c->dbg_prefill != 0 && nt > 0;
+  // (measurement switch) HiFi presets: the record-free tiles' stores in ONE launch with the poly-A pass
+  const bool zf_fused = c->dbg_zf_fused != 0 && !c->dp.ont && c->dp.dist_to_end > 0 && c->dp.dist_to_end <= 63 && c->dp.polya_len >= 2 && c->dp.polya_len <= 16 &&
+                        nt > 0 && !prefill && c->dbg_bg_tiles == 0 && c->dbg_zf_overlap == 0 && b.n_reads > 0;
   // (measurement switch) HiFi presets: the record-free tiles' stores beside the poly-A pass
   const bool zf_overlap = c->dbg_zf_overlap != 0 && !c->dp.ont && c->dp.dist_to_end > 0 && nt > 0 && !prefill && c->dbg_bg_tiles == 0;
   if ((prefill || c->dbg_bg_tiles > 0 || c->dbg_bg_tiles == -1 || zf_overlap) && !c->fill_stream) { HIPCHK(c, hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fill0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_fill1, hipEventDisableTiming)); }
@@ -683,9 +687,12 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
       if (prefill) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fill1, 0));
       launch_k1_pileup(b, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols, fill, c->chunk_off.as<int32_t>(),
                        c->chunks.p, c->k0_items.as<unsigned long long>(), c->tile_nbase.as<int32_t>(), c->planes.as<uint32_t>(),
-                       c->tile_order.as<int32_t>(), fill + o_tmp, prefill ? 1 : 0, c->stream, (c->dbg_bg_tiles > 0 || c->dbg_bg_tiles == -1 || zf_overlap) ? c->fill_stream : nullptr, c->ev_fill0, c->ev_fill1, zf_overlap ? -3 : c->dbg_bg_tiles,
+                       c->tile_order.as<int32_t>(), fill + o_tmp, prefill ? 1 : 0, c->stream, (c->dbg_bg_tiles > 0 || c->dbg_bg_tiles == -1 || zf_overlap) ? c->fill_stream : nullptr, c->ev_fill0, c->ev_fill1, zf_fused ? -4 : zf_overlap ? -3 : c->dbg_bg_tiles,
                        fuse ? c->flags.as<uint8_t>() : nullptr, fuse ? c->tile_count.as<int32_t>() : nullptr);
-      if (!c->dp.ont && c->dp.dist_to_end > 0)
+      if (zf_fused)
+        (void)launch_k1_zonefix_tiles(b, c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt,
+                                      c->tile_nbase.as<int32_t>(), c->tile_order.as<int32_t>(), fill + o_tmp, fuse ? c->tile_count.as<int32_t>() : nullptr, c->stream);
+      else if (!c->dp.ont && c->dp.dist_to_end > 0)
         launch_k1_zonefix(b, c->read_bin.as<ReadBin>(), c->dp.dist_to_end, c->dp.polya_len, c->n_cols, c->planes.as<uint32_t>(), c->stream);
       if (zf_overlap) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fill1, 0)); }
     HIPCHK(c, hipGetLastError());
@@ -1182,6 +1189,7 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
   else if (k == "k3_hits") c->dbg_k3_hits = value != 0;
   else if (k == "fuse_filter") c->dbg_fuse_filter = value != 0;
   else if (k == "zonefix_overlap") c->dbg_zf_overlap = value != 0;
+  else if (k == "zonefix_fused") c->dbg_zf_fused = value != 0;
   else if (k == "grid_spec_batch") d.spec_batch = (int)value;
   else if (k == "enum_bits") d.enum_bits = (int)value;
   else if (k == "grid_spec_lanes") d.spec_lanes = (int)std::max<int64_t>(1, std::min<int64_t>(value, 16));

@@ -187,6 +187,8 @@ void launch_k1_pileup(const BatchView& b, const DevParams& p, const int32_t* til
                       uint8_t* flt_flags = nullptr /* n_cols: != nullptr = pass 1 of the candidate filters in the tally's epilogue (k2_filter's flags) */, int32_t* flt_count = nullptr /* n_tiles: survivors per tile */);
 void launch_k1_empty_early(const BatchView& b, const int32_t* tile_region, const int32_t* tile_col0, int32_t n_tiles, int64_t n_cols, const int32_t* tile_nbase,
                            uint32_t* planes, const int32_t* order, const int32_t* tiles_tmp, hipStream_t s, hipStream_t bg, hipEvent_t ev0, hipEvent_t ev1, int32_t* flt_count);
+bool launch_k1_zonefix_tiles(const BatchView& b, int D, int L, int64_t n_cols, uint32_t* planes, const int32_t* tile_region, const int32_t* tile_col0,
+                             int32_t n_tiles, const int32_t* tile_nbase, const int32_t* order, const int32_t* tiles_tmp, int32_t* flt_count, hipStream_t s);   // poly-A pass + record-free tiles in one launch; false: not applicable (launch them separately)
 void launch_k1_zonefix(const BatchView& b, const ReadBin* rbin, int D, int L, int64_t n_cols, uint32_t* planes, hipStream_t s);
 void launch_k2_filter(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                       int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const int32_t* tile_fill, uint8_t* flags,
