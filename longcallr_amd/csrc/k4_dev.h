@@ -192,20 +192,24 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
         }
     }
   };
-  // per-SNP decision of the delta / eta step (phase.rs:872-959): the best of (d,0) (-d,0) (d,+1) (d,-1); true if it improves
-  auto decide_snp = [&](int i, long long M, int ncol) -> bool {
+  // per-SNP decision of the delta / eta step (phase.rs:872-959): the best of (d,0) (-d,0) (d,+1) (d,-1); bit 0: it improves, bit 1: it changes
+  // the state without improving (a tie change).  Round 6: a tie at the maximum (class 2: the first maximum is kept where the reference's f64
+  // scores might pick the other) is COUNTED here too -- the chain kernels do not resolve classes 2 / 4, but lcr_get_tie_census now says so.
+  auto decide_snp = [&](int i, long long M, int ncol) -> int {
     const int d = dl[i], h = et[i];
     const long long het = P.lut.f_het0 - (long long)ncol * P.lut.f_log2;  // phase.rs:136-144
     const long long F = sc[4 * i], W = sc[4 * i + 1];
     long long N[4] = {F + M + het, F + W - M + het, sc[4 * i + 2] + P.lut.f_homref, sc[4 * i + 3] + P.lut.f_homvar};
     int ch;
-    if (with_genotype) { ch = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch]) ch = t; }   // phase.rs:908-921
-    else if (h == 0) ch = N[1] > N[0] ? 1 : 0;                                                // phase.rs:923-930
-    else ch = N[3] > N[2] ? 3 : 2;                                                            // phase.rs:931-938
+    bool tie = false;
+    if (with_genotype) { ch = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch]) ch = t; for (int t = 0; t < 4; t++) tie |= t != ch && N[t] == N[ch]; }   // phase.rs:908-921
+    else if (h == 0) { ch = N[1] > N[0] ? 1 : 0; tie = N[1] == N[0]; }                        // phase.rs:923-930
+    else { ch = N[3] > N[2] ? 3 : 2; tie = N[3] == N[2]; }                                    // phase.rs:931-938
+    if (tie) TIE_COUNT(P.tie_ctr, TIE_DELTA_UNRES, 1ull);
     const int cur = h == 0 ? 0 : (h == 1 ? 2 : 3);
     dl[i] = (int8_t)(ch == 1 ? -d : d);
     et[i] = (int8_t)(ch <= 1 ? 0 : (ch == 2 ? 1 : -1));
-    return N[ch] > N[cur];
+    return N[ch] > N[cur] ? 1 : (ch != cur ? 2 : 0);
   };
   if (rows_balanced) {
     // Three barriers per iteration: sigma sweep | delta sweep (sigma taken from the pending sums) | row and SNP
@@ -247,7 +251,7 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
       for (int row = tid; row < rd.R; row += blockDim.x) {
         const long long diff = (long long)racc[row];
         racc[row] = 0;
-        if (diff < 0) { sg[row] = (int8_t)(-sg[row]); if (diff != LLONG_MIN) chg |= 1; }   // (LLONG_MIN: the marker of a tie flip -- not an improvement)
+        if (diff < 0) { sg[row] = (int8_t)(-sg[row]); chg |= diff != LLONG_MIN ? 1 : 4; }   // (LLONG_MIN: the marker of a tie flip -- not an improvement; bit 2: a tie change)
       }
       long long tsum = 0;
       for (int i = tid; i < rd.S; i += blockDim.x) {
@@ -257,17 +261,19 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
         const long long term = h == 0 ? M2 : (h == 1 ? sc[4 * i + 2] - sc[4 * i] : sc[4 * i + 3] - sc[4 * i]);
         tsum += term;
         if (!fp[i] || (keep_conserved && cons[i]) || cp[i + 1] == cp[i]) continue;
-        if (decide_snp(i, M2, cp[i + 1] - cp[i])) chg |= 2;
+        { const int dv = decide_snp(i, M2, cp[i + 1] - cp[i]); chg |= (dv & 1) ? 2 : ((dv & 2) ? 8 : 0); }
       }
       if (wave * 64 < rd.S) {   // (wave-uniform: the waves that own SNPs)
         tsum = wave_sum_ll_dpp(tsum);
         if (lane == 0 && tsum) atomicAdd(reinterpret_cast<unsigned long long*>(&red[fp_at]), (unsigned long long)tsum);
       }
-      const int wchg = (__ballot(chg & 1) ? 1 : 0) | (__ballot(chg & 2) ? 2 : 0);
+      const int wchg = (__ballot(chg & 1) ? 1 : 0) | (__ballot(chg & 2) ? 2 : 0) | (__ballot(chg & 4) ? 4 : 0) | (__ballot(chg & 8) ? 8 : 0);
       if (lane == 0 && wchg) atomicOr(&flags[fp_at], wchg);
       __syncthreads();
       const int r = flags[fp_at];
-      settled = r == 0; settled_sum = red[fp_at];
+      // class 4 (a step whose only changes were tie changes: "no improvement" here, the reference's sums of f64 scores might say otherwise): counted
+      if (tid == 0) { if ((r & 4) && !(r & 1)) TIE_COUNT(P.tie_ctr, TIE_STEP_UNRES, 1ull); if ((r & 8) && !(r & 2)) TIE_COUNT(P.tie_ctr, TIE_STEP_UNRES, 1ull); }
+      settled = (r & 3) == 0; settled_sum = red[fp_at];
       fp_at = fp_at == 2 ? 0 : fp_at + 1;
       if (tid == 0) { flags[fp_at == 2 ? 0 : fp_at + 1] = 0; red[fp_at == 2 ? 0 : fp_at + 1] = 0; }
       tick(4);

@@ -518,6 +518,40 @@ def test_filter_pass_in_the_tally_epilogue(engine_cls, orc):
         E1.close(); E0.close()
 
 
+def test_chain_ties_are_counted(engine_cls, orc):
+    """Round 6: the chain kernels do not resolve tie classes 2 / 4 (a delta / eta choice with two equal maxima keeps the first; a step whose
+    only changes were tie changes is "no improvement"), but they now COUNT them: on chain regions built to meet such ties -- twelve het
+    sites, three of them with the allele flipped in half the reads of each haplotype, equal qualities: 30-54 delta ties and up to two
+    tie-only steps per region -- the HIP results are the oracle's under the same contract (ORC_MODE_TIE, chain mask 1) AND the device's
+    delta_unresolved / step_unresolved are the oracle's census, count for count.  (With the full chain mask the oracle decides those ties by
+    the reference's f64 scores: the gap lcr_get_tie_census reports.)"""
+    alt_of = {ord("A"): ord("C"), ord("C"): ord("A"), ord("G"): ord("T"), ord("T"): ord("G")}
+    met = [0, 0]
+    for seed in (16, 21, 22, 29, 38):
+        b, sites = helpers.two_haplotype_batch(n_snps=12, n_reads=12, seed=seed)
+        rng = np.random.default_rng(seed)
+        bases = b.bases.copy()
+        for j in rng.choice(12, size=3, replace=False):
+            x = sites[0][j] - 5000
+            for k in range(b.n_reads):
+                if (k // 2) % 2 == 0:
+                    o = int(b.seq_off[k]) + x
+                    bases[o] = alt_of[int(bases[o])]
+        b2 = _abi.ReadBatch(**{f: getattr(b, f) for f in b.FIELDS if f != "bases"}, bases=bases, start0=b.start0, len=b.len, read_begin=b.read_begin, ref=b.ref)
+        p = _abi.make_params("hifi-masseq", seed=seed)
+        c = full_check(engine_cls, orc, b2, p)
+        assert len(c) == 12                         # one chain region (S > max_enum_snps = 10)
+        regs = oracle_all(orc, b2, p)
+        oc = regs[0].tie_census()
+        E = engine_cls(0, p)
+        E.load_batch(b2).run_all()
+        hc = E.tie_census()
+        E.close()
+        assert hc["delta_unresolved"] == int(oc[1]) and hc["step_unresolved"] == int(oc[2]), (seed, hc, oc.tolist())
+        met[0] += int(oc[1]); met[1] += int(oc[2])
+    assert met[0] > 100 and met[1] >= 1, met
+
+
 def test_tie_only_steps_take_the_repair_pass(engine_cls, orc):
     """A batch whose enumeration restarts meet steps with tie changes only (oracle census: 16 of them in one region): the fast
     kernels put those restarts on the repair list, k4_enum_redo decides the steps by the reference's sums of f64 scores, and
