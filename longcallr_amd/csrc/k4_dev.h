@@ -138,7 +138,10 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
                                     const long long* snp_const_lds = nullptr /* the region's 4 S per-SNP constants in LDS, or nullptr */,
                                     int* iters_out = nullptr, long long* prof = nullptr /* thread 0: six step timers (LCR_PHASE_PROF) */,
                                     int* flags = nullptr /* three ints of LDS: one barrier per iteration for both "anything changed" bits */,
-                                    double* qrow = nullptr /* 2 R doubles of scratch: the COMPLETE tie contract (classes 2 / 4 too) in the plain form below; S <= 32 */) {
+                                    double* qrow = nullptr /* 2 R doubles of scratch: the COMPLETE tie contract (classes 2 / 4 too) in the plain form below; S <= 32 */,
+                                    unsigned long long* tie_local = nullptr /* two words of LDS: the class-2 ties and class-4 steps this call does NOT resolve are
+                                                                              counted there instead of the census (the chain kernel decides what they mean) */,
+                                    double* qsnp = nullptr /* 2 S doubles */, int8_t* chs = nullptr /* 2 S bytes: with qrow, the complete contract for any S */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int32_t* rp = mv.rp;
   const int32_t* pc = mv.pc;
@@ -152,6 +155,7 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
   const double* const le64 = P.lut64->le; const double* const l1e64 = P.lut64->l1e;   // (the f64 tie path: rare, from global memory)
   bool hg_inc = true, h_inc = true;
   int iters = 0;
+  auto count_unres = [&](int local, int which) { if (tie_local) atomicAdd(&tie_local[local], 1ull); else TIE_COUNT(P.tie_ctr, which, 1ull); };
   long long tk0 = prof ? (long long)wall_clock64() : 0;
   auto tick = [&](int k) { if (prof) { const long long t = (long long)wall_clock64(); prof[k] += t - tk0; tk0 = t; } };
   const bool cols_balanced = macc && rd.S <= macc_cap;
@@ -205,7 +209,7 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
     if (with_genotype) { ch = 0; for (int t = 1; t < 4; t++) if (N[t] > N[ch]) ch = t; for (int t = 0; t < 4; t++) tie |= t != ch && N[t] == N[ch]; }   // phase.rs:908-921
     else if (h == 0) { ch = N[1] > N[0] ? 1 : 0; tie = N[1] == N[0]; }                        // phase.rs:923-930
     else { ch = N[3] > N[2] ? 3 : 2; tie = N[3] == N[2]; }                                    // phase.rs:931-938
-    if (tie) TIE_COUNT(P.tie_ctr, TIE_DELTA_UNRES, 1ull);
+    if (tie) count_unres(0, TIE_DELTA_UNRES);
     const int cur = h == 0 ? 0 : (h == 1 ? 2 : 3);
     dl[i] = (int8_t)(ch == 1 ? -d : d);
     et[i] = (int8_t)(ch <= 1 ? 0 : (ch == 2 ? 1 : -1));
@@ -272,7 +276,7 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
       __syncthreads();
       const int r = flags[fp_at];
       // class 4 (a step whose only changes were tie changes: "no improvement" here, the reference's sums of f64 scores might say otherwise): counted
-      if (tid == 0) { if ((r & 4) && !(r & 1)) TIE_COUNT(P.tie_ctr, TIE_STEP_UNRES, 1ull); if ((r & 8) && !(r & 2)) TIE_COUNT(P.tie_ctr, TIE_STEP_UNRES, 1ull); }
+      if (tid == 0) { if ((r & 4) && !(r & 1)) count_unres(1, TIE_STEP_UNRES); if ((r & 8) && !(r & 2)) count_unres(1, TIE_STEP_UNRES); }
       settled = (r & 3) == 0; settled_sum = red[fp_at];
       fp_at = fp_at == 2 ? 0 : fp_at + 1;
       if (tid == 0) { flags[fp_at == 2 ? 0 : fp_at + 1] = 0; red[fp_at == 2 ? 0 : fp_at + 1] = 0; }
@@ -296,9 +300,12 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
     // maxima takes the first maximum of the reference's f64 scores, and (class 4) a step whose only changes were tie changes is an
     // improvement iff the reference's sums of scores say so (check_new_haplotag / check_new_haplotype_genotype, phase.rs:278-355).
     // Without qrow those events are counted as unresolved ("first maximum", "no improvement").
-    const bool full = qrow != nullptr && P.tie_arith >= 3 && rd.S <= 32;
-    __shared__ double s_qn[32], s_qo[32];
-    __shared__ int8_t s_ch[32], s_cur[32];
+    const bool full = qrow != nullptr && P.tie_arith >= 3 && (rd.S <= 32 || (qsnp && chs));
+    __shared__ double s_qn32[32], s_qo32[32];
+    __shared__ int8_t s_ch32[32], s_cur32[32];
+    double* const s_qn = qsnp ? qsnp : s_qn32; double* const s_qo = qsnp ? qsnp + rd.S : s_qo32;   // (the chain kernel's regions: global scratch)
+    int8_t* const s_ch = chs ? chs : s_ch32; int8_t* const s_cur = chs ? chs + rd.S : s_cur32;
+    const int n_ch = chs ? rd.S : 32;
     __shared__ int s_verdict;
     int any = 0, anyt = 0;
     for (int row = tid; row < rd.R; row += blockDim.x) {
@@ -315,7 +322,7 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
     any = __syncthreads_or(any);
     anyt = __syncthreads_or(anyt);
     if (anyt && !any) {   // a step of tie flips only
-      if (!full) { if (tid == 0) TIE_COUNT(P.tie_ctr, TIE_STEP_UNRES, 1ull); }
+      if (!full) { if (tid == 0) count_unres(1, TIE_STEP_UNRES); }
       else {
         if (tid == 0) TIE_COUNT(P.tie_ctr, TIE_STEP_F64, 1ull);
         for (int row = tid; row < rd.R; row += blockDim.x) {   // every row's score under the new and the old sigma
@@ -362,7 +369,7 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
     if (!any) h_inc = false; else { h_inc = true; hg_inc = true; }
     // ---- delta/eta step (phase.rs:872-959): per SNP the best of (d,0) (-d,0) (d,+1) (d,-1)
     any = 0; anyt = 0;
-    if (full) { if (tid < 32) s_ch[tid] = -1; __syncthreads(); }
+    if (full) { for (int i = tid; i < n_ch; i += blockDim.x) s_ch[i] = -1; __syncthreads(); }
     // the four f64 scores of SNP i for its delta d (phase.rs:128-176): four running sums over its column in row order + priors
     auto col_scores = [&](int i, int d, double* q4) {
       double Sd = 0.0, Sn = 0.0, Shr = 0.0, Shv = 0.0;
@@ -390,7 +397,7 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
       else if (h == 0) { ch = N[1] > N[0] ? 1 : 0; tie = N[1] == N[0]; }                            // phase.rs:923-930
       else { ch = N[3] > N[2] ? 3 : 2; tie = N[3] == N[2]; }                                        // phase.rs:931-938
       if (tie) {
-        if (!full) TIE_COUNT(P.tie_ctr, TIE_DELTA_UNRES, 1ull);
+        if (!full) count_unres(0, TIE_DELTA_UNRES);
         else {   // the first maximum of the f64 scores (among the candidates the mode looks at)
           TIE_COUNT(P.tie_ctr, TIE_STEP_F64, 1ull);
           double q4[4];
@@ -444,18 +451,18 @@ __device__ __forceinline__ long long cross_optimize(const PhaseDev& P, const Reg
     any = __syncthreads_or(any);
     anyt = __syncthreads_or(anyt);
     if (anyt && !any) {   // a step of tie changes only: the sums of the SNPs' scores (check_new_haplotype_genotype, phase.rs:316-355), SNPs in order
-      if (!full) { if (tid == 0) TIE_COUNT(P.tie_ctr, TIE_STEP_UNRES, 1ull); }
+      if (!full) { if (tid == 0) count_unres(1, TIE_STEP_UNRES); }
       else {
         if (tid == 0) TIE_COUNT(P.tie_ctr, TIE_STEP_F64, 1ull);
-        if (tid < rd.S) {
+        for (int i = tid; i < rd.S; i += blockDim.x) {
           double qn = 0.0, qo = 0.0;
-          const int ch = s_ch[tid];
+          const int ch = s_ch[i];
           if (ch >= 0) {
             double q4[4];
-            col_scores(tid, ch == 1 ? -dl[tid] : dl[tid], q4);   // (the scores are those of the delta the step started from)
-            qn = q4[ch]; qo = q4[s_cur[tid]];
+            col_scores(i, ch == 1 ? -dl[i] : dl[i], q4);   // (the scores are those of the delta the step started from)
+            qn = q4[ch]; qo = q4[s_cur[i]];
           }
-          s_qn[tid] = qn; s_qo[tid] = qo;
+          s_qn[i] = qn; s_qo[i] = qo;
         }
         __syncthreads();
         if (tid == 0) {

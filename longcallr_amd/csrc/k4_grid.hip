@@ -996,7 +996,13 @@ __device__ __forceinline__ void load_flip_lut(const ChainDev& C, FlipLut* L) {
 // one workgroup of sixteen waves per chain region; the working state (and the matrix, when it fits) lives in dynamic
 // LDS.  (Eight-wave workgroups, two regions per CU, were measured for batches with more chain regions than CUs -- 368 on
 // the ONT-dRNA C3-shaped batch: every serial step of a region gets longer, phase stage 1.89 ms instead of 1.62 ms.)
-template <int NT>
+// Ties (round 6).  The fast instantiation decides sigma ties by the reference-order f64 scores (class 1) and COUNTS, per region, the
+// class-2 ties (a delta / eta choice with two equal maxima) and class-4 steps (only tie changes) it meets, which it leaves at "first
+// maximum" / "no improvement".  A region that met one is flagged (C.tie_flag) and run again by the COMPLETE instantiation, launched right
+// behind on the same queue: the same chain with the plain form of cross_optimize and its complete tie contract (k4_dev.h; f64 scores
+// through global scratch, C.tie_qrow / tie_qsnp / tie_ch).  A region that met none took no decision the complete contract takes
+// differently, so its result stands.  Without C.tie_flag (debug key "chain_ties" = 0) the counts go to the census as unresolved.
+template <int NT, bool COMPLETE>
 __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int32_t n) {
   constexpr int NW = NT / 64;
   constexpr int MACC = CROSS_MACC;
@@ -1008,10 +1014,13 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
   __shared__ double stage[NW * 4 * SSTR];
   extern __shared__ __attribute__((aligned(16))) int8_t dyn_state[];
   if ((int)blockIdx.x >= n) return;
+  const ChainDesc d = C.desc[first + blockIdx.x];
+  if constexpr (COMPLETE) { if (!C.tie_flag[d.slot]) return; }
+  __shared__ unsigned long long s_tie[2];
+  if (threadIdx.x < 2) s_tie[threadIdx.x] = 0;
   for (int i = threadIdx.x; i < MACC; i += blockDim.x) macc[i] = 0;
   load_flip_lut(C, &L);
   load_w(C.P, wl);
-  const ChainDesc d = C.desc[first + blockIdx.x];
   const RegionDev rd = C.P.reg[d.slot];
   const uint32_t E = (uint32_t)C.P.prow_ptr[rd.rp_off + rd.R];
   __shared__ int wg_bc;
@@ -1035,9 +1044,15 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
     auto cross = [&](bool keep_conserved, bool with_genotype) -> long long {
       const bool timed = C.dbg && blockIdx.x == 0 && threadIdx.x == 0;   // (LCR_PHASE_PROF)
       int iters = 0;
-      const long long obj = cross_optimize(C.P, rd, mvl, v.sg, v.dl, v.et, keep_conserved, with_genotype, red, wl, macc, MACC,
-                                           reinterpret_cast<unsigned long long*>(stage), NW * 4 * SSTR,   // (free outside block_flip)
-                                           rd.S <= SCN ? scn : nullptr, &iters, timed ? C.dbg + 8 : nullptr, &sm[0][0]);
+      long long obj;
+      if constexpr (COMPLETE)
+        obj = cross_optimize(C.P, rd, mvl, v.sg, v.dl, v.et, keep_conserved, with_genotype, red, wl, macc, MACC, nullptr, 0,
+                             rd.S <= SCN ? scn : nullptr, &iters, nullptr, nullptr, C.tie_qrow + 2ll * rd.sig_off, nullptr,
+                             C.tie_qsnp + 2ll * rd.snp_off, C.tie_ch + 2ll * rd.snp_off);
+      else
+        obj = cross_optimize(C.P, rd, mvl, v.sg, v.dl, v.et, keep_conserved, with_genotype, red, wl, macc, MACC,
+                             reinterpret_cast<unsigned long long*>(stage), NW * 4 * SSTR,   // (free outside block_flip)
+                             rd.S <= SCN ? scn : nullptr, &iters, timed ? C.dbg + 8 : nullptr, &sm[0][0], nullptr, s_tie);
       if (timed) { C.dbg[14] += 1; C.dbg[15] += iters; }
       return obj;
     };
@@ -1045,6 +1060,13 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
   };
   if (C.P.lds_state && matview_bytes(rd.R, rd.S, E) <= (uint32_t)C.P.lds_mat) body(std::true_type{});
   else body(std::false_type{});
+  if constexpr (!COMPLETE) {
+    __syncthreads();
+    if (threadIdx.x == 0 && (s_tie[0] | s_tie[1])) {
+      if (C.tie_flag) C.tie_flag[d.slot] = 1;
+      else { if (s_tie[0]) TIE_COUNT(C.P.tie_ctr, TIE_DELTA_UNRES, s_tie[0]); if (s_tie[1]) TIE_COUNT(C.P.tie_ctr, TIE_STEP_UNRES, s_tie[1]); }
+    }
+  }
 }
 
 // all workgroups of the launch on one region (desc[which])
@@ -1280,9 +1302,15 @@ hipError_t k4_set_dyn_lds_once(const void* fn, int bytes, int slot) {
 
 hipError_t k4_chain_launch_wg(const ChainDev& C, int first, int n, size_t dyn_lds, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  hipError_t e = k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_chain_wg<CH_THREADS>), 64 * 1024, 1);
+  hipError_t e = k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_chain_wg<CH_THREADS, false>), 64 * 1024, 1);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k4_chain_wg<CH_THREADS>, dim3((unsigned)n), dim3(CH_THREADS), dyn_lds, s, C, (int32_t)first, (int32_t)n);
+  hipLaunchKernelGGL((k4_chain_wg<CH_THREADS, false>), dim3((unsigned)n), dim3(CH_THREADS), dyn_lds, s, C, (int32_t)first, (int32_t)n);
+  e = hipGetLastError();
+  if (e != hipSuccess || !C.tie_flag) return e;
+  // the regions that met a class-2 / class-4 tie, again under the complete contract (every other workgroup leaves at once)
+  e = k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_chain_wg<CH_THREADS, true>), 64 * 1024, 3);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k4_chain_wg<CH_THREADS, true>), dim3((unsigned)n), dim3(CH_THREADS), dyn_lds, s, C, (int32_t)first, (int32_t)n);
   return hipGetLastError();
 }
 

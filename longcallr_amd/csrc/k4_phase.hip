@@ -720,6 +720,11 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     C.macc = b_macc.as<unsigned long long>(); C.ctl = b_ctl.as<GridCtl>(); C.spec_ctl = b_ctl.as<GridCtl>() + 4; C.sig_words = d_state[39].as<unsigned long long>();
     for (int q = 0; q < 31; q++) { C.le[q] = L.le[q]; C.l1e[q] = L.l1e[q]; }
     C.p_homref = L.p_homref; C.p_homvar = L.p_homvar; C.log_theta = L.log_theta; C.log2 = L.log2;
+    if (dbg.chain_ties && dbg.tie_arith >= 3 && n_small) {
+      PCHK(d_tie_flag.reserve((size_t)std::max(ng, 1) * 4 + 64)); PCHK(d_tie_q.reserve((2 * nr1 + 2 * nc1) * 8 + 64)); PCHK(d_tie_ch.reserve(2 * nc1 + 64));
+      C.tie_flag = d_tie_flag.as<int32_t>(); C.tie_qrow = d_tie_q.as<double>(); C.tie_qsnp = C.tie_qrow + 2 * nr1; C.tie_ch = d_tie_ch.as<int8_t>();
+      PCHK(hipMemsetAsync(C.tie_flag, 0, (size_t)std::max(ng, 1) * 4, side));
+    }
     if (prof) { C.dbg = d_state[20].as<long long>() + (size_t)ng * 16; PCHK(hipMemsetAsync(C.dbg, 0, (16 + 2 * 1024) * 8, side)); }   // 16 step timers + per-workgroup sigma / delta step times
     chain_dev = C; chain_desc = desc;   // (lcr_get_ld_blocks reads the blocks back)
     PCHK(hipStreamWaitEvent(side, ev_csr, 0));

@@ -123,6 +123,7 @@ struct PhaseDebug {
   int enum_bits = 1;            // "enum_bits": the enumeration restarts of the LDS classes eight per wave as bit states (k4_enum_bits)
   int spec_batch = 1;           // "grid_spec_batch": eight speculative half-rounds per pass over the matrix (k4_grid_batch.h); 0: the side-by-side lanes below
   int spec_lanes = 8;           // "grid_spec_lanes": half-rounds of the perturbation loop run at once at grid scope (1: one after the other; C5 with packed entries: 454 / 370 / 348 / 366 ms with 2 / 4 / 8 / 16 -- eight lanes = one XCD each)
+  int chain_ties = 1;           // "chain_ties": chain regions of workgroup scope that meet a class-2 / class-4 tie run again under the complete tie contract (0: counted as unresolved)
   int tie_arith = 3;            // "tie_arith": which exact fixed-point ties the reference-order f64 arithmetic decides (PhaseDev::tie_arith; 3 = all that liblcr resolves)
   int host_threads = 0;         // "host_threads": size of the host pool of the host epilogue (0: hardware threads / devices, <= 48)
   int async_phase = 0;          // "async_phase": lcr_phase returns when its kernels are queued (on a queue of its own); settle() collects the results
@@ -139,6 +140,7 @@ struct PhaseHost {
   const uint8_t* r_assignment = nullptr;
   const uint32_t* r_phase_set = nullptr;
   DevBuf d_state[40];
+  DevBuf d_tie_flag, d_tie_q, d_tie_ch;   // k4_chain_wg: regions that met a class-2 / class-4 tie, scratch of their second run
   DevBuf d_spec_sig, d_spec_de, d_spec_res, d_pk, d_bt;   // working states / results of the speculative half-rounds (k4_grid.hip)
   DevBuf d_read_rec;             // per-row results as 12-byte records in HBM, written by k4_post
   DevBuf d_lut64, d_tie, d_enum_st;   // f64 table of the tie paths (PostLut), census counters, final states of the enumeration restarts

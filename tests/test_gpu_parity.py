@@ -518,13 +518,14 @@ def test_filter_pass_in_the_tally_epilogue(engine_cls, orc):
         E1.close(); E0.close()
 
 
-def test_chain_ties_are_counted(engine_cls, orc):
-    """Round 6: the chain kernels do not resolve tie classes 2 / 4 (a delta / eta choice with two equal maxima keeps the first; a step whose
-    only changes were tie changes is "no improvement"), but they now COUNT them: on chain regions built to meet such ties -- twelve het
-    sites, three of them with the allele flipped in half the reads of each haplotype, equal qualities: 30-54 delta ties and up to two
-    tie-only steps per region -- the HIP results are the oracle's under the same contract (ORC_MODE_TIE, chain mask 1) AND the device's
-    delta_unresolved / step_unresolved are the oracle's census, count for count.  (With the full chain mask the oracle decides those ties by
-    the reference's f64 scores: the gap lcr_get_tie_census reports.)"""
+def test_chain_ties_of_classes_2_and_4(engine_cls, orc, monkeypatch):
+    """Round 6: chain regions of workgroup scope that meet a tie of class 2 (a delta / eta choice with two equal maxima) or class 4 (a step
+    whose only changes were tie changes) are run again by k4_chain_wg's COMPLETE instantiation, which decides them by the reference-order
+    f64 scores.  On chain regions built to meet such ties -- twelve het sites, three of them with the allele flipped in half the reads of
+    each haplotype, equal qualities: 30-54 delta ties and up to two tie-only steps per region -- the HIP results are the oracle's with
+    those classes resolved (ORC_MODE_TIE, chain mask 7), none is reported unresolved and the decided ones are the oracle's census, count for
+    count.  With lcr_debug_set("chain_ties", 0) the first run's result stands: the oracle's under chain mask 1, and delta_unresolved /
+    step_unresolved are ITS census, count for count."""
     alt_of = {ord("A"): ord("C"), ord("C"): ord("A"), ord("G"): ord("T"), ord("T"): ord("G")}
     met = [0, 0]
     for seed in (16, 21, 22, 29, 38):
@@ -539,16 +540,22 @@ def test_chain_ties_are_counted(engine_cls, orc):
                     bases[o] = alt_of[int(bases[o])]
         b2 = _abi.ReadBatch(**{f: getattr(b, f) for f in b.FIELDS if f != "bases"}, bases=bases, start0=b.start0, len=b.len, read_begin=b.read_begin, ref=b.ref)
         p = _abi.make_params("hifi-masseq", seed=seed)
-        c = full_check(engine_cls, orc, b2, p)
-        assert len(c) == 12                         # one chain region (S > max_enum_snps = 10)
-        regs = oracle_all(orc, b2, p)
-        oc = regs[0].tie_census()
-        E = engine_cls(0, p)
-        E.load_batch(b2).run_all()
-        hc = E.tie_census()
-        E.close()
-        assert hc["delta_unresolved"] == int(oc[1]) and hc["step_unresolved"] == int(oc[2]), (seed, hc, oc.tolist())
-        met[0] += int(oc[1]); met[1] += int(oc[2])
+        for resolve in (1, 0):
+            monkeypatch.setenv("LCR_CHAIN_TIES", str(resolve))
+            monkeypatch.setitem(ORACLE_TIE_MASK, 0, orc.TIE_MASK_LIBLCR if resolve else orc.TIE_MASK_LIBLCR_GRID)
+            c = full_check(engine_cls, orc, b2, p)
+            assert len(c) == 12                         # one chain region (S > max_enum_snps = 10)
+            regs = oracle_all(orc, b2, p)
+            oc = regs[0].tie_census()
+            E = engine_cls(0, p)
+            E.load_batch(b2).run_all()
+            hc = E.tie_census()
+            E.close()
+            if resolve:
+                assert hc["delta_unresolved"] == 0 and hc["step_unresolved"] == 0 and hc["delta_step_f64"] == int(oc[1]) + int(oc[2]), (seed, hc, oc.tolist())
+            else:
+                assert hc["delta_unresolved"] == int(oc[1]) and hc["step_unresolved"] == int(oc[2]), (seed, hc, oc.tolist())
+                met[0] += int(oc[1]); met[1] += int(oc[2])
     assert met[0] > 100 and met[1] >= 1, met
 
 
