@@ -565,9 +565,11 @@ __device__ void block_flip(SC& sc, const ChainDev& C, const ChainView& v, const 
 // ------------------------------------------------------------------------------------------------------------
 // the chain, written once for both scopes
 // ------------------------------------------------------------------------------------------------------------
-template <class SC, class Cross, class FastRounds>
+// tie8(): called (by every thread) when a configuration's fixed-point objective EQUALS the best one's -- class 8, `prob > largest_prob`
+// (phase.rs:1140-1144 ...) between configurations of equal objective; true: the working state becomes the best one.
+template <class SC, class Cross, class FastRounds, class Tie8>
 __device__ __forceinline__ void chain_run(SC& sc, const ChainDev& C, const RegionDev& rd, const ChainView& v, const long long* wl, const FlipLut& L,
-                          double* stage, int (*sm)[16], Cross cross, FastRounds fast_rounds, int slot) {
+                          double* stage, int (*sm)[16], Cross cross, FastRounds fast_rounds, Tie8 tie8, int slot) {
   const int S = rd.S, R = rd.R;
   int n_mark = 0;
   auto mark = [&]() { if (C.dbg && sc.tid() == 0 && (sc.nblk() > 1 || blockIdx.x == 0)) C.dbg[n_mark] = (long long)wall_clock64(); n_mark++; };
@@ -601,6 +603,7 @@ __device__ __forceinline__ void chain_run(SC& sc, const ChainDev& C, const Regio
   {
     const long long obj = objective_scope(sc, rd, v, wl);
     if (obj > best) { best = obj; save(); }   // `prob > largest_prob` (phase.rs:1140-1144)
+    else if (obj == best && tie8()) save();
     load();
   }
   mark();
@@ -616,12 +619,14 @@ __device__ __forceinline__ void chain_run(SC& sc, const ChainDev& C, const Regio
     sc.sync();
     long long obj = cross(false, false);
     if (obj > best) { best = obj; save(); }
+    else if (obj == best && tie8()) save();
     load();
     for (int row = sc.tid(); row < R; row += sc.nt())
       if (u01(rd.seed, ctr_t + S + row) < 0.1) v.sg[row] = (int8_t)(-v.sg[row]);
     sc.sync();
     obj = cross(false, false);
     if (obj > best) { best = obj; save(); }
+    else if (obj == best && tie8()) save();
     load();
   }
   mark();
@@ -993,12 +998,55 @@ __device__ __forceinline__ void load_flip_lut(const ChainDev& C, FlipLut* L) {
   if (threadIdx.x == 0) { L->p_homref = C.p_homref; L->p_homvar = C.p_homvar; L->log_theta = C.log_theta; L->log2 = C.log2; }
 }
 
+// The f64 objectives of two configurations (phase.rs:257-276): ONE running sum each over the entries' terms in row order.  The terms of both --
+// the table value picked by "does the entry's allele match" -- are written to global scratch by a thread per row, then wave 0 adds them up in
+// order, 64 entries per coalesced 16-byte load, the two sums as two independent chains of v_add_f64 fed by v_readlane (padding terms are
+// + 0.0).  (Only at class-8 ties whose match bits differ; a first form walked the rows on wave 0 alone -- four dependent loads per row -- and
+// made the phase stage of C3 0.92 -> 2.3 ms.)
+__device__ __forceinline__ bool objective_f64_greater_wg(const PhaseDev& P, const MatView& mv, int R, const int8_t* sg, const int8_t* dl, const int8_t* et,
+                                                         const int8_t* bsg, const int8_t* bdl, const int8_t* bet, double* T, int* s_out) {
+  const int lane = threadIdx.x & 63;
+  const double* const le64 = P.lut64->le; const double* const l1e64 = P.lut64->l1e;
+  for (int row = threadIdx.x; row < R; row += blockDim.x) {
+    const int sc_ = sg[row], sb_ = bsg[row];
+    for (int e = mv.rp[row]; e < mv.rp[row + 1]; e++) {
+      const int i = mv.pc[e];
+      const uint8_t v = mv.pv[e];
+      const int p = (v & 32) ? 1 : -1, q = v & 31, hc = et[i], hb = bet[i];
+      const double2 t = make_double2(p == (hc == 0 ? sc_ * dl[i] : hc) ? l1e64[q] : le64[q], p == (hb == 0 ? sb_ * bdl[i] : hb) ? l1e64[q] : le64[q]);
+      reinterpret_cast<double2*>(T)[e] = t;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int E = mv.rp[R];
+    const double2* T2 = reinterpret_cast<const double2*>(T);
+    double a = 0.0, b = 0.0;
+    double2 nxt = lane < E ? T2[lane] : make_double2(0.0, 0.0);
+    for (int base = 0; base < E; base += 64) {
+      const double2 cur = nxt;
+      nxt = base + 64 + lane < E ? T2[base + 64 + lane] : make_double2(0.0, 0.0);
+      const int xl = (int)__double2loint(cur.x), xh = (int)__double2hiint(cur.x), yl = (int)__double2loint(cur.y), yh = (int)__double2hiint(cur.y);
+#pragma unroll
+      for (int k = 0; k < 64; k++) {
+        a += __hiloint2double(__builtin_amdgcn_readlane(xh, k), __builtin_amdgcn_readlane(xl, k));
+        b += __hiloint2double(__builtin_amdgcn_readlane(yh, k), __builtin_amdgcn_readlane(yl, k));
+      }
+    }
+    if (lane == 0) *s_out = a > b ? 1 : 0;
+  }
+  __syncthreads();
+  const int r = *s_out;
+  __syncthreads();
+  return r != 0;
+}
+
 // one workgroup of sixteen waves per chain region; the working state (and the matrix, when it fits) lives in dynamic
 // LDS.  (Eight-wave workgroups, two regions per CU, were measured for batches with more chain regions than CUs -- 368 on
 // the ONT-dRNA C3-shaped batch: every serial step of a region gets longer, phase stage 1.89 ms instead of 1.62 ms.)
-// Ties (round 6).  The fast instantiation decides sigma ties by the reference-order f64 scores (class 1) and COUNTS, per region, the
-// class-2 ties (a delta / eta choice with two equal maxima) and class-4 steps (only tie changes) it meets, which it leaves at "first
-// maximum" / "no improvement".  A region that met one is flagged (C.tie_flag) and run again by the COMPLETE instantiation, launched right
+// Ties (round 6).  The fast instantiation decides sigma ties by the reference-order f64 scores (class 1) and configurations of equal
+// objective by their f64 sums (class 8, tie8 below), and COUNTS, per region, the class-2 ties (a delta / eta choice with two equal maxima)
+// and class-4 steps (only tie changes) it meets, which it leaves at "first maximum" / "no improvement".  A region that met one is flagged (C.tie_flag) and run again by the COMPLETE instantiation, launched right
 // behind on the same queue: the same chain with the plain form of cross_optimize and its complete tie contract (k4_dev.h; f64 scores
 // through global scratch, C.tie_qrow / tie_qsnp / tie_ch).  A region that met none took no decision the complete contract takes
 // differently, so its result stands.  Without C.tie_flag (debug key "chain_ties" = 0) the counts go to the census as unresolved.
@@ -1016,8 +1064,9 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
   if ((int)blockIdx.x >= n) return;
   const ChainDesc d = C.desc[first + blockIdx.x];
   if constexpr (COMPLETE) { if (!C.tie_flag[d.slot]) return; }
-  __shared__ unsigned long long s_tie[2];
-  if (threadIdx.x < 2) s_tie[threadIdx.x] = 0;
+  __shared__ unsigned long long s_tie[3];   // class-2 ties, class-4 steps, class-8 compares the fast instantiation met
+  __shared__ int s_f64;
+  if (threadIdx.x < 3) s_tie[threadIdx.x] = 0;
   for (int i = threadIdx.x; i < MACC; i += blockDim.x) macc[i] = 0;
   load_flip_lut(C, &L);
   load_w(C.P, wl);
@@ -1056,15 +1105,44 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
       if (timed) { C.dbg[14] += 1; C.dbg[15] += iters; }
       return obj;
     };
-    chain_run(sc, C, rd, v, wl, L, stage, sm, cross, [](long long) { return false; }, d.slot);
+    // Class 8: a configuration whose fixed-point objective equals the best one's.  The reference compares the f64 sums of the two, and those
+    // are one running sum each over the entries' terms, a term = a table value picked by "does the entry's allele match": two states with
+    // the same match bits (the same state; the mirrored one; states that differ in the sigma of rows without a het entry -- nearly every
+    // equal compare on gene batches) have the same sum.  So: (1) the states, element by element (every thread compares what it saved
+    // itself); (2) the match bits, a thread per row; (3) only if those differ the two sums, wave 0 in the reference's order -- decided in
+    // place by both instantiations (without C.tie_flag: counted as unresolved).
+    auto tie8 = [&]() -> bool {
+      int diff = 0;
+      for (int i = threadIdx.x; i < rd.S; i += blockDim.x) diff |= (v.dl[i] != v.bdl[i]) | (v.et[i] != v.bet[i]);
+      for (int row = threadIdx.x; row < rd.R; row += blockDim.x) diff |= v.sg[row] != v.bsg[row];
+      if (!__syncthreads_or(diff)) return false;
+      diff = 0;
+      for (int row = threadIdx.x; row < rd.R; row += blockDim.x) {
+        const int sc_ = v.sg[row], sb_ = v.bsg[row];
+        for (int e = mvl.rp[row]; e < mvl.rp[row + 1]; e++) {
+          const int i = mvl.pc[e], p = (mvl.pv[e] & 32) ? 1 : -1;
+          const int hc = v.et[i], hb = v.bet[i];
+          diff |= (p == (hc == 0 ? sc_ * v.dl[i] : hc)) != (p == (hb == 0 ? sb_ * v.bdl[i] : hb));
+        }
+      }
+      if (!__syncthreads_or(diff)) return false;
+      if (!C.tie_flag) { if (threadIdx.x == 0) s_tie[2]++; return false; }
+      if (threadIdx.x == 0) TIE_COUNT(C.P.tie_ctr, TIE_BEST_F64, 1ull);
+      return objective_f64_greater_wg(C.P, mvl, rd.R, v.sg, v.dl, v.et, v.bsg, v.bdl, v.bet, C.tie_terms + 2ll * d.term_off, &s_f64);
+    };
+    chain_run(sc, C, rd, v, wl, L, stage, sm, cross, [](long long) { return false; }, tie8, d.slot);
   };
   if (C.P.lds_state && matview_bytes(rd.R, rd.S, E) <= (uint32_t)C.P.lds_mat) body(std::true_type{});
   else body(std::false_type{});
   if constexpr (!COMPLETE) {
     __syncthreads();
-    if (threadIdx.x == 0 && (s_tie[0] | s_tie[1])) {
-      if (C.tie_flag) C.tie_flag[d.slot] = 1;
-      else { if (s_tie[0]) TIE_COUNT(C.P.tie_ctr, TIE_DELTA_UNRES, s_tie[0]); if (s_tie[1]) TIE_COUNT(C.P.tie_ctr, TIE_STEP_UNRES, s_tie[1]); }
+    if (threadIdx.x == 0 && (s_tie[0] | s_tie[1] | s_tie[2])) {
+      if (C.tie_flag) { if (s_tie[0] | s_tie[1]) C.tie_flag[d.slot] = 1; }
+      else {
+        if (s_tie[0]) TIE_COUNT(C.P.tie_ctr, TIE_DELTA_UNRES, s_tie[0]);
+        if (s_tie[1]) TIE_COUNT(C.P.tie_ctr, TIE_STEP_UNRES, s_tie[1]);
+        if (s_tie[2]) TIE_COUNT(C.P.tie_ctr, TIE_BEST_UNRES, s_tie[2]);
+      }
     }
   }
 }
@@ -1103,7 +1181,7 @@ __global__ void __launch_bounds__(CH_THREADS) k4_chain_grid(ChainDev C, int32_t 
     if (!d.fast_lds) return false;
     return chain_rounds_fast(sc, C, rd, v, wl, dyn_fast, best, d.slot, L);
   };
-  chain_run(sc, C, rd, v, wl, L, stage, sm, cross, fast_rounds, d.slot);
+  chain_run(sc, C, rd, v, wl, L, stage, sm, cross, fast_rounds, []() { return false; }, d.slot);
 }
 
 

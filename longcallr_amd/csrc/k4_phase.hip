@@ -640,14 +640,15 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     const int n_small = (int)wide.size(), n_big = (int)big.size(), nc = n_small + n_big;
     const int grid_waves = std::max(1, k4_grid_blocks()) * 16;
     std::vector<ChainDesc> desc(nc);
-    int64_t tbl_cells = 0, adj_n = 0, part_n = 0;
+    int64_t tbl_cells = 0, adj_n = 0, part_n = 0, term_n = 0;
     int32_t max_state = 0;
     for (int k = 0; k < nc; k++) {
       const int g = k < n_small ? wide[k] : big[k - n_small];
       const int S = in.cand_region_off[g + 1] - in.cand_region_off[g];
       ChainDesc& d = desc[k];
       d.slot = g; d.W = std::max(1, std::min(stat[g].W, S)); d.fast_lds = 0;
-      d.batch_lds = 0; d.pad_ = 0;
+      d.batch_lds = 0; d.term_off = 0;
+      if (k < n_small) { d.term_off = (int32_t)std::min<int64_t>(term_n, INT32_MAX); term_n += stat[g].E; }
       if (k >= n_small && !grid_generic) {
         const size_t need = k4_grid_fast_lds(stat[g].R, S); if (need <= (size_t)K4_GRID_FAST_LDS_MAX) d.fast_lds = (int32_t)need;
         const size_t need_b = k4_grid_batch_lds(S); if (dbg.spec_batch && w_fits_limbs && need_b <= (size_t)K4_GRID_FAST_LDS_MAX) d.batch_lds = (int32_t)need_b;
@@ -720,7 +721,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     C.macc = b_macc.as<unsigned long long>(); C.ctl = b_ctl.as<GridCtl>(); C.spec_ctl = b_ctl.as<GridCtl>() + 4; C.sig_words = d_state[39].as<unsigned long long>();
     for (int q = 0; q < 31; q++) { C.le[q] = L.le[q]; C.l1e[q] = L.l1e[q]; }
     C.p_homref = L.p_homref; C.p_homvar = L.p_homvar; C.log_theta = L.log_theta; C.log2 = L.log2;
-    if (dbg.chain_ties && dbg.tie_arith >= 3 && n_small) {
+    if (dbg.chain_ties && dbg.tie_arith >= 3 && n_small && term_n < INT32_MAX) {
+      PCHK(d_tie_terms.reserve((size_t)term_n * 16 + 64)); C.tie_terms = d_tie_terms.as<double>();
       PCHK(d_tie_flag.reserve((size_t)std::max(ng, 1) * 4 + 64)); PCHK(d_tie_q.reserve((2 * nr1 + 2 * nc1) * 8 + 64)); PCHK(d_tie_ch.reserve(2 * nc1 + 64));
       C.tie_flag = d_tie_flag.as<int32_t>(); C.tie_qrow = d_tie_q.as<double>(); C.tie_qsnp = C.tie_qrow + 2 * nr1; C.tie_ch = d_tie_ch.as<int8_t>();
       PCHK(hipMemsetAsync(C.tie_flag, 0, (size_t)std::max(ng, 1) * 4, side));

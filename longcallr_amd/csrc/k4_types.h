@@ -68,7 +68,7 @@ struct ChainDesc {
   int32_t n_parts;
   int32_t fast_lds;    // grid scope: bytes of dynamic LDS for the device-coherent perturbation rounds (0: generic path)
   int32_t batch_lds;   // grid scope: bytes of dynamic LDS for the batched rounds (k4_grid_batch.h; 0: not for this region)
-  int32_t pad_;
+  int32_t term_off;    // workgroup scope: the region's slice of ChainDev::tie_terms, in entries
 };
 struct GridCtl { unsigned arrive, gen, flag[2]; unsigned long long acc[2]; int slot; unsigned pad_[7]; };   // grid barrier + reductions
 struct ChainDev {
@@ -104,6 +104,7 @@ struct ChainDev {
   // ties of classes 2 / 4 at workgroup scope (k4_chain_wg): per region "met one" (nullptr: count them as unresolved), and the scratch of the
   // complete contract -- two f64 scores per phasing row (at 2 (sig_off + k)) and per SNP (at 2 (snp_off + i)), two choice bytes per SNP
   int32_t* tie_flag; double* tie_qrow; double* tie_qsnp; int8_t* tie_ch;
+  double* tie_terms;              // class 8: the f64 terms of two configurations, entry by entry (2 per phase entry, at 2 (term_off + e))
   long long* dbg;                 // LCR_PHASE_PROF: 100 MHz timestamps of the chain steps of a grid launch, 16 per launch (else nullptr)
   double le[31], l1e[31], p_homref, p_homvar, log_theta, log2;   // libm values of the block-flip sums (host table)
 };

@@ -19,9 +19,10 @@ MODE_F64, MODE_EXACT, MODE_F64_ONLY, MODE_EXACT_ONLY, MODE_TIE = 0, 1, 2, 3, 4
 # the tie classes liblcr resolves with the reference's f64 arithmetic (include/lcr.h, lcr_get_tie_census): ALL FOUR in the
 # enumeration branch -- sigma ties (1), delta / eta ties at the maximum (2), the verdict of tie-only steps (4), `prob > largest_prob`
 # at equal objective (8) --, sigma ties in the chain branch
-# (round 6: classes 2 and 4 too in chain regions of workgroup scope -- k4_chain_wg runs a region that met one again under the complete
-# contract; a chain region that gets all CUs (k4_chain_grid: >= 2^17 phase entries, or the tests' grid_min_entries = 0) resolves sigma ties only)
-TIE_MASK_LIBLCR = 15 | (7 << 8) | (1 << 16)
+# (round 6: all four classes in chain regions of workgroup scope too -- k4_chain_wg runs a region that met a tie of classes 2 / 4 / 8 again
+# under the complete contract; a chain region that gets all CUs (k4_chain_grid: >= 2^17 phase entries, or the tests' grid_min_entries = 0)
+# resolves sigma ties only)
+TIE_MASK_LIBLCR = 15 | (15 << 8) | (1 << 16)
 TIE_MASK_LIBLCR_GRID = 15 | (1 << 8) | (1 << 16)
 
 

@@ -426,7 +426,7 @@ def test_enumeration_kernels_agree(engine_cls, monkeypatch):
     monkeypatch.delenv("LCR_ENUM_BITS")
 
 
-@pytest.mark.parametrize("tie_arith,enum_mask,chain_mask", [("0", 0, 0), ("1", 8, 0), ("2", 9, 1), ("3", 15, 1)])
+@pytest.mark.parametrize("tie_arith,enum_mask,chain_mask", [("0", 0, 0), ("1", 8, 0), ("2", 9, 1), ("3", 15, 15)])
 def test_tie_arithmetic_switch(engine_cls, orc, monkeypatch, tie_arith, enum_mask, chain_mask):
     """lcr_debug_set("tie_arith"): 0 = every decision on the fixed-point sums alone (ORC_MODE_TIE with no class resolved = the
     contract of rounds 1-3, ORC_MODE_EXACT), 1 = configurations of equal objective by their f64 sums, 2 (default) = also the
@@ -519,11 +519,11 @@ def test_filter_pass_in_the_tally_epilogue(engine_cls, orc):
 
 
 def test_chain_ties_of_classes_2_and_4(engine_cls, orc, monkeypatch):
-    """Round 6: chain regions of workgroup scope that meet a tie of class 2 (a delta / eta choice with two equal maxima) or class 4 (a step
-    whose only changes were tie changes) are run again by k4_chain_wg's COMPLETE instantiation, which decides them by the reference-order
-    f64 scores.  On chain regions built to meet such ties -- twelve het sites, three of them with the allele flipped in half the reads of
+    """Round 6: chain regions of workgroup scope that meet a tie of class 2 (a delta / eta choice with two equal maxima), class 4 (a step
+    whose only changes were tie changes) or class 8 (a later configuration of equal objective that differs from the best one) are run again
+    by k4_chain_wg's COMPLETE instantiation, which decides them by the reference-order f64 scores / sums.  On chain regions built to meet such ties -- twelve het sites, three of them with the allele flipped in half the reads of
     each haplotype, equal qualities: 30-54 delta ties and up to two tie-only steps per region -- the HIP results are the oracle's with
-    those classes resolved (ORC_MODE_TIE, chain mask 7), none is reported unresolved and the decided ones are the oracle's census, count for
+    every class resolved (ORC_MODE_TIE, chain mask 15), none is reported unresolved and the decided ones are the oracle's census, count for
     count.  With lcr_debug_set("chain_ties", 0) the first run's result stands: the oracle's under chain mask 1, and delta_unresolved /
     step_unresolved are ITS census, count for count."""
     alt_of = {ord("A"): ord("C"), ord("C"): ord("A"), ord("G"): ord("T"), ord("T"): ord("G")}

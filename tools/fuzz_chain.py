@@ -18,6 +18,7 @@ for seed in range(a, b):
     for grid in ((False, True) if seed % 4 == 0 else (False,)):
         if grid:
             os.environ["LCR_GRID_MIN_ENTRIES"] = "0"
+        t.ORACLE_TIE_MASK[0] = orc.TIE_MASK_LIBLCR_GRID if grid else None   # (all CUs on a region: sigma ties only)
         try:
             c = t.full_check(api.Engine, orc, batch, p)
             if not grid:
@@ -40,4 +41,5 @@ for seed in range(a, b):
                 print("MISMATCH seed", seed, prof, "grid" if grid else "wg", str(e)[:200], flush=True)
         finally:
             os.environ.pop("LCR_GRID_MIN_ENTRIES", None)
+            t.ORACLE_TIE_MASK[0] = None
 print("seeds %d..%d: %d regions, %d on the chain branch, %d mismatches (%d forced-grid batches agreed under the fixed-point contract only: ties of their global-memory enumeration regions)" % (a, b, n_reg, n_chain, bad, n_unres))
