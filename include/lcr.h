@@ -285,15 +285,19 @@ int lcr_get_ld_blocks(lcr_ctx*, int32_t region, int32_t* n_blocks, const int32_t
  * on the reference-order f64 scores of that row / configuration.  lcr_get_tie_census reports the ties of the last lcr_phase:
  *   out[0] sigma decisions with A == B at rows with an entry at a het site, decided by the f64 scores of phase.rs:77-96
  *   out[1] ... of which flipped (q < qn)
- *   out[2] delta / eta choices with a tie at the maximum where the first maximum was kept (UNRESOLVED: chain branch only since round 5)
- *   out[3] steps whose only changes were tie changes, taken as "no improvement" (check_new_*, phase.rs:278-355; UNRESOLVED: chain
- *          branch only since round 5)
- *   out[4] regions whose configurations of maximal objective differ and were compared by their f64 sums (phase.rs:257-276)
- *   out[5] regions where that compare fell to "first maximum wins" (UNRESOLVED: more maxima than the list holds, states beyond the
- *          memory budget)
+ *   out[2] delta / eta choices with a tie at the maximum where the first maximum was kept (UNRESOLVED; round 6: reported by chain regions of
+ *          workgroup scope only when lcr_debug_set("chain_ties", 0) keeps them from running again under the complete contract -- the
+ *          all-CU chain kernels, regions of >= 2^17 phase entries, neither resolve nor count them)
+ *   out[3] steps whose only changes were tie changes, taken as "no improvement" (check_new_*, phase.rs:278-355; UNRESOLVED: as out[2])
+ *   out[4] enumeration branch: regions whose configurations of maximal objective differ and were compared by their f64 sums
+ *          (phase.rs:257-276); chain regions of workgroup scope (round 6): compares of two configurations of equal objective whose
+ *          match bits differ, decided by their f64 sums
+ *   out[5] compares that fell to "first maximum wins" (UNRESOLVED: more maxima than the list holds, states beyond the memory budget;
+ *          chain regions with "chain_ties" = 0)
  *   out[6] sigma ties met by kernels without the f64 path (UNRESOLVED)
- *   out[7] (round 5, enumeration branch) delta / eta ties at the maximum decided by the f64 scores of phase.rs:128-176 + tie-only steps
- *          decided by the reference's sums of scores (check_new_haplotag / check_new_haplotype_genotype)
+ *   out[7] (round 5: enumeration branch; round 6: chain regions of workgroup scope too) delta / eta ties at the maximum decided by the f64
+ *          scores of phase.rs:128-176 + tie-only steps decided by the reference's sums of scores (check_new_haplotag /
+ *          check_new_haplotype_genotype)
  * All UNRESOLVED counts zero = every decision of the call was the reference arithmetic's decision. */
 int lcr_get_tie_census(lcr_ctx*, uint64_t out[8]);
 

@@ -38,12 +38,12 @@ struct PhaseDev {
 // rounding noise might have decided otherwise
 enum { TIE_SIGMA_F64 = 0,      // sigma decisions with A == B at a row with an entry at a het site: decided by the f64 scores
        TIE_SIGMA_FLIPS = 1,    // ... of which flipped (q < qn)
-       TIE_DELTA_UNRES = 2,    // delta / eta choices with a tie at the maximum (phase.rs:905-940): first maximum kept
+       TIE_DELTA_UNRES = 2,    // delta / eta choices with a tie at the maximum (phase.rs:905-940): first maximum kept (chain regions: only with chain_ties = 0)
        TIE_STEP_UNRES = 3,     // steps whose only changes were tie changes (check_new_*, phase.rs:278-355): taken as "no improvement"
-       TIE_BEST_F64 = 4,       // regions whose configurations of maximal objective differ: `prob > largest_prob` by the f64 sums
+       TIE_BEST_F64 = 4,       // regions whose configurations of maximal objective differ: `prob > largest_prob` by the f64 sums (k4_chain_wg: per compare)
        TIE_BEST_UNRES = 5,     // ... left to "first maximum wins" (fallback kernels)
        TIE_SIGMA_UNRES = 6,    // sigma ties in kernels without the f64 path
-       TIE_STEP_F64 = 7,       // delta / eta ties at the maximum + tie-only steps decided by the f64 scores (enumeration kernels, round 5)
+       TIE_STEP_F64 = 7,       // delta / eta ties at the maximum + tie-only steps decided by the f64 scores (enumeration kernels, round 5; k4_chain_wg<COMPLETE>, round 6)
        TIE_NCTR = 8 };
 // (-DENUM_PROF, a measurement build: the census slots carry k4_enum_resolve's times instead)
 #ifdef ENUM_PROF
