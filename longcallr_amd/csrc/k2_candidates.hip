@@ -631,3 +631,20 @@ void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t*
   } else launch_gather_i32(pos, sv_region_off, n_regions + 1, n_sv, pos + n_sv, cand_off, s);
   if (n_regions > 0) hipLaunchKernelGGL(k2_dense, dim3(n_regions), dim3(256), 0, s, out, cand_off, n_regions, idx, dense_win, min_dense_cnt);
 }
+
+// The kept candidates and their per-region offsets into pinned host memory, by a kernel: the host cannot size a copy before it has the
+// count, and a copy of the records' CAPACITY (every survivor kept: 3 MB on C3) on a second queue held up the fragment stage's first
+// kernel for as long as it ran -- a kernel's end-of-kernel release waits for the device's writes to host memory in flight (30 us per step).
+__global__ void __launch_bounds__(256) k2_export(const lcr_candidate* __restrict__ cand, const int32_t* __restrict__ cand_off, int32_t ng,
+                                                 lcr_candidate* __restrict__ h_cand, int32_t* __restrict__ h_off) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+  const size_t n16 = (size_t)cand_off[ng] * (sizeof(lcr_candidate) / 16);
+  const uint4* src = reinterpret_cast<const uint4*>(cand);
+  uint4* dst = reinterpret_cast<uint4*>(h_cand);
+  for (size_t i = t; i < n16; i += nt) dst[i] = src[i];
+  for (size_t g = t; g <= (size_t)ng; g += nt) h_off[g] = cand_off[g];
+}
+void launch_k2_export(const lcr_candidate* cand, const int32_t* cand_off, int32_t ng, lcr_candidate* h_cand, int32_t* h_off, hipStream_t s) {
+  static_assert(sizeof(lcr_candidate) % 16 == 0, "k2_export copies 16-byte words");
+  hipLaunchKernelGGL(k2_export, dim3(64), dim3(256), 0, s, cand, cand_off, ng, h_cand, h_off);
+}

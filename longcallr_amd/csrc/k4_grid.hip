@@ -1044,13 +1044,15 @@ __device__ __forceinline__ bool objective_f64_greater_wg(const PhaseDev& P, cons
 // one workgroup of sixteen waves per chain region; the working state (and the matrix, when it fits) lives in dynamic
 // LDS.  (Eight-wave workgroups, two regions per CU, were measured for batches with more chain regions than CUs -- 368 on
 // the ONT-dRNA C3-shaped batch: every serial step of a region gets longer, phase stage 1.89 ms instead of 1.62 ms.)
-// Ties (round 6).  The fast instantiation decides sigma ties by the reference-order f64 scores (class 1) and configurations of equal
-// objective by their f64 sums (class 8, tie8 below), and COUNTS, per region, the class-2 ties (a delta / eta choice with two equal maxima)
-// and class-4 steps (only tie changes) it meets, which it leaves at "first maximum" / "no improvement".  A region that met one is flagged (C.tie_flag) and run again by the COMPLETE instantiation, launched right
-// behind on the same queue: the same chain with the plain form of cross_optimize and its complete tie contract (k4_dev.h; f64 scores
-// through global scratch, C.tie_qrow / tie_qsnp / tie_ch).  A region that met none took no decision the complete contract takes
-// differently, so its result stands.  Without C.tie_flag (debug key "chain_ties" = 0) the counts go to the census as unresolved.
-template <int NT, bool COMPLETE>
+// Ties (round 6).  The first pass over a region -- the fast form of cross_optimize -- decides sigma ties by the reference-order f64 scores
+// (class 1) and configurations of equal objective by their f64 sums (class 8, tie8 below), and COUNTS the class-2 ties (a delta / eta choice
+// with two equal maxima) and class-4 steps (only tie changes) it meets, which it leaves at "first maximum" / "no improvement".  A region that
+// met one is run again by the same workgroup with the plain form of cross_optimize and its complete tie contract (k4_dev.h; f64 scores
+// through global scratch, C.tie_qrow / tie_qsnp / tie_ch): the whole chain, the draws are counters.  A region that met none took no decision
+// the complete contract takes differently, so its result stands.  Without C.tie_flag (debug key "chain_ties" = 0) the counts go to the census
+// as unresolved.  (The second pass as a launch of its own behind the first, workgroups of unflagged regions leaving at once: 100 us on C3
+// although nothing ran -- sixteen-wave workgroups with 64 KB of LDS wait for a whole free CU beside the next batch's K0.)
+template <int NT>
 __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int32_t n) {
   constexpr int NW = NT / 64;
   constexpr int MACC = CROSS_MACC;
@@ -1063,7 +1065,6 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
   extern __shared__ __attribute__((aligned(16))) int8_t dyn_state[];
   if ((int)blockIdx.x >= n) return;
   const ChainDesc d = C.desc[first + blockIdx.x];
-  if constexpr (COMPLETE) { if (!C.tie_flag[d.slot]) return; }
   __shared__ unsigned long long s_tie[3];   // class-2 ties, class-4 steps, class-8 compares the fast instantiation met
   __shared__ int s_f64;
   if (threadIdx.x < 3) s_tie[threadIdx.x] = 0;
@@ -1079,7 +1080,8 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
   // Two instantiations of the same body: with state and matrix in LDS every pointer of the sweeps has ONE provenance,
   // so the compiler emits ds_read / ds_write for them; a pointer that is "LDS or HBM" at run time makes them flat_load /
   // flat_store, which take the long way round even when they hit LDS (the sweeps of cross_optimize were 3x slower).
-  auto body = [&](auto in_lds) {
+  auto body = [&](auto in_lds, auto complete_pass) {
+    constexpr bool COMPLETE = decltype(complete_pass)::value;
     ChainView v = make_view(C, d, rd);
     MatView mvl = v.mv;
     if constexpr (decltype(in_lds)::value) {
@@ -1112,19 +1114,31 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
     // itself); (2) the match bits, a thread per row; (3) only if those differ the two sums, wave 0 in the reference's order -- decided in
     // place by both instantiations (without C.tie_flag: counted as unresolved).
     auto tie8 = [&]() -> bool {
+      // (the best state lives in global memory: step 1 leaves a copy of its delta / eta in the stage rows -- free between cross_optimize
+      // calls -- so that step 2's two reads per entry stay in LDS; read per entry from L2 they made the kernel 575 -> 660 us on C3)
+      int8_t* const lb = reinterpret_cast<int8_t*>(stage);
+      const bool copy = 2 * (size_t)rd.S <= sizeof(stage);
       int diff = 0;
-      for (int i = threadIdx.x; i < rd.S; i += blockDim.x) diff |= (v.dl[i] != v.bdl[i]) | (v.et[i] != v.bet[i]);
+      for (int i = threadIdx.x; i < rd.S; i += blockDim.x) {
+        const int8_t bd = v.bdl[i], be = v.bet[i];
+        if (copy) { lb[i] = bd; lb[rd.S + i] = be; }
+        diff |= (v.dl[i] != bd) | (v.et[i] != be);
+      }
       for (int row = threadIdx.x; row < rd.R; row += blockDim.x) diff |= v.sg[row] != v.bsg[row];
       if (!__syncthreads_or(diff)) return false;
-      diff = 0;
-      for (int row = threadIdx.x; row < rd.R; row += blockDim.x) {
-        const int sc_ = v.sg[row], sb_ = v.bsg[row];
-        for (int e = mvl.rp[row]; e < mvl.rp[row + 1]; e++) {
-          const int i = mvl.pc[e], p = (mvl.pv[e] & 32) ? 1 : -1;
-          const int hc = v.et[i], hb = v.bet[i];
-          diff |= (p == (hc == 0 ? sc_ * v.dl[i] : hc)) != (p == (hb == 0 ? sb_ * v.bdl[i] : hb));
+      auto match_differs = [&](const int8_t* bdl, const int8_t* bet) {
+        int df = 0;
+        for (int row = threadIdx.x; row < rd.R; row += blockDim.x) {
+          const int sc_ = v.sg[row], sb_ = v.bsg[row];
+          for (int e = mvl.rp[row]; e < mvl.rp[row + 1]; e++) {
+            const int i = mvl.pc[e], p = (mvl.pv[e] & 32) ? 1 : -1;
+            const int hc = v.et[i], hb = bet[i];
+            df |= (p == (hc == 0 ? sc_ * v.dl[i] : hc)) != (p == (hb == 0 ? sb_ * bdl[i] : hb));
+          }
         }
-      }
+        return df;
+      };
+      diff = copy ? match_differs(lb, lb + rd.S) : match_differs(v.bdl, v.bet);
       if (!__syncthreads_or(diff)) return false;
       if (!C.tie_flag) { if (threadIdx.x == 0) s_tie[2]++; return false; }
       if (threadIdx.x == 0) TIE_COUNT(C.P.tie_ctr, TIE_BEST_F64, 1ull);
@@ -1132,19 +1146,22 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
     };
     chain_run(sc, C, rd, v, wl, L, stage, sm, cross, [](long long) { return false; }, tie8, d.slot);
   };
-  if (C.P.lds_state && matview_bytes(rd.R, rd.S, E) <= (uint32_t)C.P.lds_mat) body(std::true_type{});
-  else body(std::false_type{});
-  if constexpr (!COMPLETE) {
-    __syncthreads();
-    if (threadIdx.x == 0 && (s_tie[0] | s_tie[1] | s_tie[2])) {
-      if (C.tie_flag) { if (s_tie[0] | s_tie[1]) C.tie_flag[d.slot] = 1; }
-      else {
-        if (s_tie[0]) TIE_COUNT(C.P.tie_ctr, TIE_DELTA_UNRES, s_tie[0]);
-        if (s_tie[1]) TIE_COUNT(C.P.tie_ctr, TIE_STEP_UNRES, s_tie[1]);
-        if (s_tie[2]) TIE_COUNT(C.P.tie_ctr, TIE_BEST_UNRES, s_tie[2]);
-      }
+  const bool mat_in_lds = C.P.lds_state && matview_bytes(rd.R, rd.S, E) <= (uint32_t)C.P.lds_mat;
+  if (mat_in_lds) body(std::true_type{}, std::false_type{});
+  else body(std::false_type{}, std::false_type{});
+  __syncthreads();
+  const bool met = (s_tie[0] | s_tie[1]) != 0;
+  if (!C.tie_flag) {
+    if (threadIdx.x == 0) {
+      if (s_tie[0]) TIE_COUNT(C.P.tie_ctr, TIE_DELTA_UNRES, s_tie[0]);
+      if (s_tie[1]) TIE_COUNT(C.P.tie_ctr, TIE_STEP_UNRES, s_tie[1]);
+      if (s_tie[2]) TIE_COUNT(C.P.tie_ctr, TIE_BEST_UNRES, s_tie[2]);
     }
+    return;
   }
+  if (!met) return;
+  if (mat_in_lds) body(std::true_type{}, std::true_type{});
+  else body(std::false_type{}, std::true_type{});
 }
 
 // all workgroups of the launch on one region (desc[which])
@@ -1380,15 +1397,9 @@ hipError_t k4_set_dyn_lds_once(const void* fn, int bytes, int slot) {
 
 hipError_t k4_chain_launch_wg(const ChainDev& C, int first, int n, size_t dyn_lds, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  hipError_t e = k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_chain_wg<CH_THREADS, false>), 64 * 1024, 1);
+  hipError_t e = k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_chain_wg<CH_THREADS>), 64 * 1024, 1);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k4_chain_wg<CH_THREADS, false>), dim3((unsigned)n), dim3(CH_THREADS), dyn_lds, s, C, (int32_t)first, (int32_t)n);
-  e = hipGetLastError();
-  if (e != hipSuccess || !C.tie_flag) return e;
-  // the regions that met a class-2 / class-4 tie, again under the complete contract (every other workgroup leaves at once)
-  e = k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_chain_wg<CH_THREADS, true>), 64 * 1024, 3);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k4_chain_wg<CH_THREADS, true>), dim3((unsigned)n), dim3(CH_THREADS), dyn_lds, s, C, (int32_t)first, (int32_t)n);
+  hipLaunchKernelGGL(k4_chain_wg<CH_THREADS>, dim3((unsigned)n), dim3(CH_THREADS), dyn_lds, s, C, (int32_t)first, (int32_t)n);
   return hipGetLastError();
 }
 

@@ -430,6 +430,7 @@ int PhaseHost::settle(std::string* err) {
 
 int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t user_stream, std::string* err) {
   { const int rc = settle(err); if (rc) return rc; }   // (a previous call nobody asked about: its pinned blocks are rewritten below)
+  HT("phase");
   // Two queues: `stream` stages the phase matrices and runs the enumeration regions (S <= max_enum_snps) with their
   // post-phase kernel; `side` runs the chain regions (S > max_enum_snps): LD blocks, LD-seeded start, block-flip pass
   // and perturbation rounds in ONE kernel per region class (k4_grid.hip: a workgroup per region, or all CUs on one
@@ -457,10 +458,10 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
   if (!ev_user) { PCHK(hipEventCreateWithFlags(&ev_user, hipEventDisableTiming)); PCHK(hipEventCreateWithFlags(&ev_gate[0], hipEventDisableTiming)); PCHK(hipEventCreateWithFlags(&ev_gate[1], hipEventDisableTiming)); }
   gate_set[0] = gate_set[1] = false;
   hipStream_t const stream = async_mode ? main_q : user_stream;
-  if (async_mode) {
-    PCHK(hipEventRecord(ev_user, user_stream));
-    PCHK(hipStreamWaitEvent(stream, ev_user, 0));
-  }
+  // (round 6) the staging kernel and the fills in front of it stay on the CALLER's queue -- right behind the fragment stage's kernels, no
+  // queue-to-queue hand-over in front of them (16 us on this platform) --, the host waits for the sizes there, and the stage's own queue
+  // picks up behind an event that is long complete when the first restarts are queued
+  hipStream_t const sq = user_stream;
   q_first = stream;
   if (!side) {
     PCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
@@ -517,8 +518,17 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
   for (int q = 0; q < 31; q++) { plut.le[q] = L.le[q]; plut.l1e[q] = L.l1e[q]; }
   plut.p_homref = L.p_homref; plut.p_homvar = L.p_homvar; plut.log_theta = L.log_theta; plut.log2 = L.log2;
   PCHK(d_lut64.reserve(sizeof(PostLut))); PCHK(d_tie.reserve(TIE_NCTR * 8)); PCHK(h_pin[11].reserve(TIE_NCTR * 8));
-  if (!lut64_ready) { PCHK(hipMemcpyAsync(d_lut64.p, &plut, sizeof(PostLut), hipMemcpyHostToDevice, stream)); PCHK(hipStreamSynchronize(stream)); lut64_ready = true; }
-  PCHK(hipMemsetAsync(d_tie.p, 0, TIE_NCTR * 8, stream));   // (before ev_in: every queue of this call starts behind it)
+  if (!lut64_ready) { PCHK(hipMemcpyAsync(d_lut64.p, &plut, sizeof(PostLut), hipMemcpyHostToDevice, sq)); PCHK(hipStreamSynchronize(sq)); lut64_ready = true; }
+  // the stage's fills in ONE launch in front of the staging kernel (the host's wait for the sizes ends with that kernel, and every command
+  // between it and the first restart is idle GPU time): the tie census, the result state, the enumeration branch's best objective seen per
+  // region (0x8080...: far below any objective) and the repair lists' counts (the pairs behind them are written before they are read)
+  constexpr uint32_t REDO_CAP = 8192, REDO_GRID = 512;   // the repair pass of the enumeration branch (below)
+  PCHK(d_rbest_buf.reserve((size_t)std::max(ng, 1) * 8 + 64));
+  if (dbg.tie_arith >= 3) PCHK(b_redo.reserve(2 * (16 + 8 * (size_t)REDO_CAP) + 64));
+  { void* const fp[4] = {d_tie.p, b_st.p, d_rbest_buf.p, b_redo.p};
+    const int fv[4] = {0, 0, 0x80, 0};
+    const size_t fs[4] = {TIE_NCTR * 8, ng ? st_bytes : 0, (size_t)ng * 8, dbg.tie_arith >= 3 ? 2 * (16 + 8 * (size_t)REDO_CAP) : 0};
+    PCHK(lcr_fill_multi_async(4, fp, fv, fs, sq)); }
   P.lut64 = d_lut64.as<PostLut>(); P.tie_ctr = d_tie.as<unsigned long long>(); P.tie_arith = dbg.tie_arith;
 
   // ---- queue `stream`: stage the phase matrices -- launched before the host sorts the regions into their kernel classes (the
@@ -534,8 +544,9 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     so = StageOut{b_reg.as<RegionDev>(), d_stat, b_prp.as<int32_t>(), b_pc.as<int32_t>(), b_pv.as<uint8_t>(),
                   b_cp.as<int32_t>(), b_cr.as<int32_t>(), b_cv.as<uint8_t>(), b_snp.as<uint8_t>(), b_snp.as<int8_t>() + nc1,
                   b_snp.as<uint8_t>() + 2 * nc1, b_sc.as<long long>(), b_cur.as<int32_t>(), b_psrc.as<int32_t>()};
-    launch_k4_stage((int32_t)ng, stream, si, so, L.dev);
+    launch_k4_stage((int32_t)ng, sq, si, so, L.dev);
     PCHK(hipGetLastError());
+  HT("  ph:stage_q");
   }
 
   // enumeration (S <= max_enum_snps) and chain regions
@@ -574,7 +585,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
 #define GRID_LOCK() do { const std::string e_ = grid_lock.acquire(lock_dir, stream, side, aux); if (!e_.empty()) { if (err) *err = "device lock of the persistent launches: " + e_; return LCR_E_DEVICE; } } while (0)
 
   // ---- queue `side`: the fragment matrix goes to the host (pinned) only when a region takes the host epilogue
-  PCHK(hipEventRecord(ev_in, stream));
+  PCHK(hipEventRecord(ev_in, sq));
   PCHK(hipStreamWaitEvent(side, ev_in, 0));
   if (any_host_post) {
     PCHK(h_pin[0].reserve((nr1 + 1) * 8)); PCHK(h_pin[1].reserve(nnz1 * 4));
@@ -594,11 +605,12 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       PCHK(b_ctl.reserve((4 + 16) * sizeof(GridCtl))); PCHK(b_btot.reserve((size_t)(2 * std::max(1, k4_grid_blocks()) + 1) * 4 + 64));
       for (int g : gstage_slots) PCHK(k4_stage_launch_grid(si, so, L.dev, g, b_ctl.as<GridCtl>(), b_btot.as<int32_t>(), side));
       PCHK(hipEventRecord(ev_join, side));
-      PCHK(hipStreamWaitEvent(stream, ev_join, 0));
+      PCHK(hipStreamWaitEvent(sq, ev_join, 0));
     }
-    PCHK(hipMemsetAsync(b_st.p, 0, st_bytes, stream));
-    PCHK(hipEventRecord(ev_csr, stream));   // the chain kernels on `side` read the staged matrices
+    PCHK(hipEventRecord(ev_csr, sq));   // the chain kernels on `side` read the staged matrices
   }
+  if (async_mode) { PCHK(hipEventRecord(ev_user, sq)); PCHK(hipStreamWaitEvent(stream, ev_user, 0)); }
+  HT("ph:presync");
   if (!pool) {
     // one ctx per GPU: share the host's hardware threads between the GPUs of the node
     int ndev = 1;
@@ -608,7 +620,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     nthreads = std::max(1, std::min(nthreads, dbg.host_threads > 0 ? 256 : 48));
     pool = new HostPool(nthreads > 1 ? nthreads : 0);
   }
-  if (ng) PCHK(hipStreamSynchronize(stream));
+  if (ng) PCHK(hipStreamSynchronize(sq));
+  HT("ph:synced");
   lap("stage + sizes");
 
   PostIn pin{in.d_row_ptr, in.d_col, in.d_val, in.d_row_links, const_cast<lcr_candidate*>(in.d_cand), in.d_cand_off,
@@ -725,7 +738,6 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       PCHK(d_tie_terms.reserve((size_t)term_n * 16 + 64)); C.tie_terms = d_tie_terms.as<double>();
       PCHK(d_tie_flag.reserve((size_t)std::max(ng, 1) * 4 + 64)); PCHK(d_tie_q.reserve((2 * nr1 + 2 * nc1) * 8 + 64)); PCHK(d_tie_ch.reserve(2 * nc1 + 64));
       C.tie_flag = d_tie_flag.as<int32_t>(); C.tie_qrow = d_tie_q.as<double>(); C.tie_qsnp = C.tie_qrow + 2 * nr1; C.tie_ch = d_tie_ch.as<int8_t>();
-      PCHK(hipMemsetAsync(C.tie_flag, 0, (size_t)std::max(ng, 1) * 4, side));
     }
     if (prof) { C.dbg = d_state[20].as<long long>() + (size_t)ng * 16; PCHK(hipMemsetAsync(C.dbg, 0, (16 + 2 * 1024) * 8, side)); }   // 16 step timers + per-workgroup sigma / delta step times
     chain_dev = C; chain_desc = desc;   // (lcr_get_ld_blocks reads the blocks back)
@@ -781,6 +793,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       std::sort(key.begin(), key.end());
       for (size_t k = 0; k < enum_slots.size(); k++) enum_slots[k] = (int32_t)(uint32_t)key[k];
     }
+    HT("en:sorted");
     int32_t max_state = 0;
     for (int g : enum_slots) max_state = std::max(max_state, stat[g].R + 2 * (in.cand_region_off[g + 1] - in.cand_region_off[g]));
     const int32_t stride = (max_state + 63) & ~63;
@@ -863,6 +876,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     const size_t off_jb_al = (n_spans * sizeof(EnumSpan) + 7) & ~(size_t)7;
     const size_t off_sb = off_jb_al + (size_t)ng * 8;   // st_base
     const size_t up_bytes = off_sb + (size_t)ng * 8 + (ns + nps) * 4;
+    HT("en:classes");
     PCHK(d_enum_st.reserve((size_t)std::max<int64_t>(st_words, 1) * 8));
     PCHK(b_job.reserve(up_bytes + 64));
     PCHK(b_obj.reserve((size_t)nj * 8 + (size_t)ng * 8 + (size_t)ng * 8 + 64));   // objectives | winners | tiles done | best objective seen per region
@@ -876,6 +890,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     memcpy(up + off_sb + (size_t)ng * 8 + (ns + nps_a) * 4, post_slots_b.data(), nps_b * 4);
     memcpy(up + off_sb + (size_t)ng * 8 + (ns + nps_a + nps_b) * 4, post_slots_c.data(), nps_c * 4);
     PCHK(hipMemcpyAsync(b_job.p, up, up_bytes, hipMemcpyHostToDevice, stream));
+    HT("en:up_q");
     const EnumSpan* d_sp = b_job.as<EnumSpan>();
     const int64_t* d_jb = (const int64_t*)(b_job.as<uint8_t>() + off_jb_al);
     const int64_t* d_sb = (const int64_t*)(b_job.as<uint8_t>() + off_sb);
@@ -886,7 +901,6 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     const size_t n_big_blocks = std::max(n_t[4], n_w[4]);
     // the repair pass (tie classes 2 / 4 met by a fast kernel's restart): per launch queue a list of REDO_CAP restarts and REDO_GRID
     // workgroups' worth of state scratch + score scratch (2 doubles per row), behind the global-memory class's own
-    constexpr uint32_t REDO_CAP = 8192, REDO_GRID = 512;
     const bool full_ties = dbg.tie_arith >= 3;
     int32_t max_rows_any = 1;
     for (int g : enum_slots) max_rows_any = std::max(max_rows_any, stat[g].R);
@@ -896,8 +910,6 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
     P.scratch = b_scr.as<int8_t>();
     if (full_ties) {
       PCHK(b_qrow.reserve((size_t)qstride * n_scr_blocks * 8 + 64));
-      PCHK(b_redo.reserve(2 * (16 + 8 * (size_t)REDO_CAP) + 64));
-      PCHK(hipMemsetAsync(b_redo.p, 0, 2 * (16 + 8 * (size_t)REDO_CAP), stream));   // (the counts; the pairs behind them are written before they are read)
     }
     uint32_t* const redo_a = full_ties ? b_redo.as<uint32_t>() : nullptr;                          // classes 1 / 2 (first queue)
     uint32_t* const redo_b = full_ties ? b_redo.as<uint32_t>() + 4 + 2 * REDO_CAP : nullptr;       // class 3 (`aux`)
@@ -909,8 +921,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
                           d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());
     };
     // the classes touch disjoint regions: class 2 on `stream`, classes 3 / 4 beside it on `aux` (their tails overlap)
-    long long* const d_rbest = (long long*)(d_win + 2 * (size_t)ng);   // (8-byte aligned: behind the 2 x 4 x ng bytes of winners | tiles done)
-    PCHK(hipMemsetAsync(d_rbest, 0x80, (size_t)ng * 8, stream));        // 0x8080...: far below any objective
+    long long* const d_rbest = d_rbest_buf.as<long long>();   // (filled in front of the staging kernel)
     auto launch = [&](const size_t* cnt, const uint32_t* win) -> hipError_t {
       const bool fork = (cnt[2] || (ebits && cnt[1])) && (cnt[3] || cnt[4]);   // (with k4_enum_bits: the streaming kernel's few large regions beside its launch)
       hipStream_t s34 = fork ? aux : stream, s1 = stream;
@@ -949,6 +960,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       return e;
     };
     PCHK(launch(n_t, nullptr));
+    HT("en:launched");
     if (n_w[4]) {   // the global-memory class: its own resolve kernel (equal objectives by the f64 sums) and the winners' second launch
       const size_t only4[NCLS] = {0, 0, 0, 0, n_w[4]};
       const int64_t tstride = (big_emax + 63) & ~(int64_t)63;
@@ -971,6 +983,7 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
   const bool chain_first = false;
   if (chain_first) { const int rc = launch_chain_regions(); if (rc) return rc; }
   { const int rc = launch_enum_regions(); if (rc) return rc; }
+  HT("ph:enum_q");
   if (!chain_first) { const int rc = launch_chain_regions(); if (rc) return rc; }
   if (prof && !enum_slots.empty()) {   // share sizes of the enumeration regions (entries per lane decide the kernel class)
     std::vector<int> mn; uint64_t jobs[3] = {0, 0, 0};
@@ -1025,6 +1038,8 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
   pend.res_ps = res_ps; pend.res_tag = res_tag; pend.res_asg = res_asg; pend.hc_obj = hc_obj; pend.cand = in.cand;
   pending = true;
   // Everything is queued.  Without a reason to wait the call returns here: settle() collects the results when somebody asks.
+  HT("ph:ret");
+  if (g_lcr_host_trace) lcr_host_trace_flush();
   if (async_mode && !prof && !any_host_post && !grid_lock.held) return LCR_OK;
   PCHK(hipStreamSynchronize(side));
   lap("chain kernels");

@@ -101,8 +101,8 @@ struct ChainDev {
   // of 64 sorted rows, the sort's permutation and its inverse, sigma bits of the eight states per row, delta / eta bit masks per SNP,
   // barrier payload and counters (K4_GRID_BATCH_CTL_BYTES, zeroed by the launcher)
   uint32_t* bt_pk4; int32_t* bt_up4; uint32_t* bt_bs32; int32_t* bt_perm; int32_t* bt_inv; uint8_t* bt_sig8; uint32_t* bt_m32; void* bt_ctl; int64_t bt_cap4; int32_t spec_batch;
-  // ties of classes 2 / 4 at workgroup scope (k4_chain_wg): per region "met one" (nullptr: count them as unresolved), and the scratch of the
-  // complete contract -- two f64 scores per phasing row (at 2 (sig_off + k)) and per SNP (at 2 (snp_off + i)), two choice bytes per SNP
+  // ties of classes 2 / 4 / 8 at workgroup scope (k4_chain_wg): tie_flag != nullptr = resolve them (nullptr: count them as unresolved; the
+  // array itself is spare), and the scratch of the complete contract -- two f64 scores per phasing row (at 2 (sig_off + k)) and per SNP (at 2 (snp_off + i)), two choice bytes per SNP
   int32_t* tie_flag; double* tie_qrow; double* tie_qsnp; int8_t* tie_ch;
   double* tie_terms;              // class 8: the f64 terms of two configurations, entry by entry (2 per phase entry, at 2 (term_off + e))
   long long* dbg;                 // LCR_PHASE_PROF: 100 MHz timestamps of the chain steps of a grid launch, 16 per launch (else nullptr)

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <cstdlib>
 
+#include <chrono>
 #include "lcr_dev.h"
 #include "lcr_phase_host.h"
 
@@ -227,6 +228,76 @@ int upload(lcr_ctx* c, DevBuf& buf, const T* src, size_t n, const T** dst, int m
 }
 
 }  // namespace
+
+int g_lcr_own_fill = 1;
+namespace {
+__global__ void __launch_bounds__(256) lcr_fill_kernel(uint8_t* p, uint32_t word, size_t head, size_t n16, size_t tail) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+  if (t < head) p[t] = (uint8_t)word;
+  uint4* const body = reinterpret_cast<uint4*>(p + head);
+  const uint4 w = make_uint4(word, word, word, word);
+  for (size_t i = t; i < n16; i += nt) body[i] = w;
+  if (t < tail) p[head + 16 * n16 + t] = (uint8_t)word;
+}
+}
+namespace {
+struct FillRanges { uint8_t* p[4]; size_t head[4], n16[4], tail[4]; uint32_t word[4]; };
+__global__ void __launch_bounds__(256) lcr_fill_multi_kernel(FillRanges r) {
+  const int k = blockIdx.y;
+  uint8_t* const p = r.p[k];
+  if (!p) return;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+  const uint32_t word = r.word[k];
+  if (t < r.head[k]) p[t] = (uint8_t)word;
+  uint4* const body = reinterpret_cast<uint4*>(p + r.head[k]);
+  const uint4 w = make_uint4(word, word, word, word);
+  for (size_t i = t; i < r.n16[k]; i += nt) body[i] = w;
+  if (t < r.tail[k]) p[r.head[k] + 16 * r.n16[k] + t] = (uint8_t)word;
+}
+}
+// up to four fills in one launch (every launch of its own costs ~5 us of queue time on this platform)
+hipError_t lcr_fill_multi_async(int n, void* const* ptrs, const int* bytes_val, const size_t* sizes, hipStream_t s) {
+  if (!g_lcr_own_fill) { for (int k = 0; k < n; k++) if (sizes[k]) { const hipError_t e = hipMemsetAsync(ptrs[k], bytes_val[k], sizes[k], s); if (e != hipSuccess) return e; } return hipSuccess; }
+  FillRanges r{};
+  size_t most = 0;
+  int m = 0;
+  for (int k = 0; k < n && m < 4; k++) {
+    if (!sizes[k]) continue;
+    const size_t mis = (size_t)((uintptr_t)ptrs[k] & 15), head = std::min(sizes[k], mis ? 16 - mis : 0), n16 = (sizes[k] - head) / 16;
+    const uint32_t b = (uint32_t)(bytes_val[k] & 255);
+    r.p[m] = (uint8_t*)ptrs[k]; r.head[m] = head; r.n16[m] = n16; r.tail[m] = sizes[k] - head - 16 * n16; r.word[m] = b | (b << 8) | (b << 16) | (b << 24);
+    most = std::max(most, n16); m++;
+  }
+  if (!m) return hipSuccess;
+  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((most + 255) / 256, 1024));
+  hipLaunchKernelGGL(lcr_fill_multi_kernel, dim3(blocks, (unsigned)m), dim3(256), 0, s, r);
+  return hipGetLastError();
+}
+
+hipError_t lcr_fill_async(void* p, int byte, size_t bytes, hipStream_t s) {
+  if (!bytes) return hipSuccess;
+  if (!g_lcr_own_fill) return hipMemsetAsync(p, byte, bytes, s);
+  const size_t mis = (size_t)((uintptr_t)p & 15), head = std::min(bytes, mis ? 16 - mis : 0), n16 = (bytes - head) / 16, tail = bytes - head - 16 * n16;
+  const uint32_t b = (uint32_t)(byte & 255), word = b | (b << 8) | (b << 16) | (b << 24);
+  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((n16 + 255) / 256, 2048));
+  hipLaunchKernelGGL(lcr_fill_kernel, dim3(blocks), dim3(256), 0, s, (uint8_t*)p, word, head, n16, tail);
+  return hipGetLastError();
+}
+
+int g_lcr_host_trace = 0;
+namespace {
+struct HtMark { const char* tag; std::chrono::steady_clock::time_point t; };
+thread_local std::vector<HtMark> g_ht;
+}
+void lcr_host_trace_mark(const char* tag) { g_ht.push_back({tag, std::chrono::steady_clock::now()}); }
+void lcr_host_trace_flush() {
+  if (g_ht.empty()) return;
+  std::string line = "[host]";
+  char buf[96];
+  for (const HtMark& m : g_ht) { snprintf(buf, sizeof buf, " %s %.1f", m.tag, std::chrono::duration<double, std::micro>(m.t - g_ht[0].t).count()); line += buf; }
+  fprintf(stderr, "%s\n", line.c_str());
+  g_ht.clear();
+}
 
 extern "C" {
 
@@ -582,6 +653,7 @@ int lcr_host_register(void* p, size_t bytes) {
 int lcr_host_unregister(void* p) { return p && hipHostUnregister(p) == hipSuccess ? LCR_OK : LCR_E_ARG; }
 
 int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
+  HT("pileup");
   if (!c || !p) return LCR_E_ARG;
   if (!c->loaded) { c->err = "lcr_pileup before lcr_load_batch"; return LCR_E_STATE; }
   if (p->polya_len == 0) { c->err = "polya_len must be >= 1"; return LCR_E_ARG; }
@@ -593,7 +665,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
   c->dp = to_dev(p, c->sor_thr);
   c->dp.dbg = 0;
   HIPCHK(c, c->planes.reserve(std::max<size_t>((size_t)c->n_cols * LCR_NPLANES, 1) * 4));
-  HIPCHK(c, c->phase.gate_stream(c->stream));   // (async_phase: behind the restarts of a phase stage still in flight, beside its tails)
+  bool gated = false;   // (async_phase: K0 waits for the restarts of a phase stage still in flight -- below, behind the fill in front of it)
   BatchView& b = c->bv;
   const int nt = c->n_tiles;
   // ---- K0: decode every CIGAR once into per-tile records (one op-parallel pass; a block's records lie back to back in the
@@ -655,7 +727,9 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
     // pool slots, a record outside the window one pool slot, one descriptor and one entry of its own -- so the entry list is
     // bounded by pool / 16 + descriptors, not by pool / 16 (thousands of reads across an intron of > 65 536 columns)
     HIPCHK(c, c->chunks.reserve((pool_sub64 * nsh / 16 + desc_sub64 * nsh + 16) * 8));
-    HIPCHK(c, hipMemsetAsync(fill, 0, fill_words * 4, c->stream));
+    HIPCHK(c, lcr_fill_async(fill, 0, fill_words * 4, c->stream));
+    // (async_phase: behind the restarts of a phase stage still in flight, beside its tails -- a matter of speed, not of order: the fill runs early)
+    if (!gated) { HIPCHK(c, c->phase.gate_stream(c->stream)); gated = true; }
     { Timer t(c, LCR_K_SPANS);
       launch_k0_ops(b, c->read_bin.as<ReadBin>(), c->blk_first_read.as<int32_t>(), c->cig0, c->n_ops, c->dp.ont, c->dp.dist_to_end, nt,
                     fill, fill + o_nch, fill + o_ndiff, fill + nt + 1, (unsigned int*)(fill + o_acct), pool_sub, c->k0_items.as<unsigned long long>(),
@@ -697,6 +771,7 @@ int lcr_pileup(lcr_ctx* c, const lcr_params* p) {
       if (zf_overlap) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fill1, 0)); }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventSynchronize(c->ev_ctl));
+  HT("pile:ctl");
     n_ops = ctl[1]; n_recs = ctl[2]; bad = ctl[3];
     if (*c->h_order.as<int32_t>() != 0) { c->err = "the reads of a region must be sorted by position (lcr_reads.pos)"; return LCR_E_ARG; }
     if (bad == 1) { c->err = "unknown CIGAR operation (reference panics: util.rs:944)"; return LCR_E_CIGAR; }
@@ -735,10 +810,12 @@ static int cand_settle(lcr_ctx* c);
 static int read_records_fresh(lcr_ctx* c);
 
 int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
+  HT("cand");
   if (!c || !p) return LCR_E_ARG;
   if (!c->have_planes) { c->err = "lcr_candidates before lcr_pileup"; return LCR_E_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   { int rc = phase_settle(c); if (rc) return rc; }   // (the previous batch's phase stage reads the candidate / fragment buffers rewritten from here on)
+  HT("cand:settled");
   c->res_valid = false;   // (its results are rewritten from here on: lcr_collect_phase had to come before this call)
   c->dp = to_dev(p, c->dp.sor_threshold);
   const int ng = c->bv.n_regions, nt = c->n_tiles;
@@ -766,6 +843,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   const int32_t n_sv = sv_off[ng];
+  HT("cand:n_sv");
   if (c->phase.dbg.prof) fprintf(stderr, "[cand] %d survivors of the count filters in %lld columns, %d reads\n", n_sv, (long long)c->n_cols, c->bv.n_reads);
   HIPCHK(c, c->survivors.reserve(std::max(n_sv, 1) * sizeof(Survivor)));
   HIPCHK(c, c->hist.reserve(std::max<size_t>(n_sv, 1) * 124 * 4 + 64));   // (+ the hit lists' overflow counter: cleared with the histograms)
@@ -785,7 +863,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
     // the records) and u16 counters (a survivor's depth is <= max_depth).
     const bool tiles_ok = c->dp.ont && p->max_depth <= 65535u;
     const bool hist_tiles = tiles_ok && c->dbg_hist_tiles >= 0 && (c->dbg_hist_tiles > 0 || (int64_t)n_sv * 8 >= c->n_cols);
-    HIPCHK(c, hipMemsetAsync(c->hist.p, 0, (size_t)n_sv * 124 * 4 + 64, c->stream));
+    HIPCHK(c, lcr_fill_async(c->hist.p, 0, (size_t)n_sv * 124 * 4 + 64, c->stream));
     c->hits_valid = !hist_tiles && c->dbg_k3_hits != 0;   // (the walk below leaves K3 its hits; the tile form does not walk reads)
     c->hits_n_sv = n_sv;
     if (c->hits_valid) {
@@ -812,22 +890,16 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   // host copy (getters, chain-region host steps) arrives with the same round trip as the offsets
   launch_k2_finish(c->scan_tmp, c->cand_tmp.as<lcr_candidate>(), d_keep, n_sv, c->sv_region_off.as<int32_t>(), ng, d_pos, d_idx,
                    c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), p->dense_win, p->min_dense_cnt, c->stream);
+  HT("cand:finish_q");
   HIPCHK(c, c->h_stage[1].reserve(std::max<size_t>(n_sv, 1) * sizeof(lcr_candidate)));
   HIPCHK(c, c->h_stage[2].reserve((size_t)(ng + 1) * 4));
-  // The records' capacity -- every survivor kept -- is what can be copied without knowing the count: 3 MB on C3, 30 us of the
-  // queue.  It goes to the phase stage's second queue when that exists (idle until lcr_phase), so that the fragment stage's
-  // kernels do not wait behind it.  (A queue of the context's own for it was measured: the process has four hardware queues,
-  // and a fourth stream pushes the phase stage's queues onto shared ones -- lcr_phase +0.15 ms.)
-  hipStream_t dl = c->phase.side ? c->phase.side : c->stream;
-  if (dl != c->stream) {
-    if (!c->ev_dl) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_dl, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_cand_dl, hipEventDisableTiming)); }
-    HIPCHK(c, hipEventRecord(c->ev_dl, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(dl, c->ev_dl, 0));
-  }
-  if (n_sv) HIPCHK(c, hipMemcpyAsync(c->h_stage[1].p, c->d_cand.p, (size_t)n_sv * sizeof(lcr_candidate), hipMemcpyDeviceToHost, dl));
-  HIPCHK(c, hipMemcpyAsync(c->h_stage[2].p, c->d_cand_off.p, (size_t)(ng + 1) * 4, hipMemcpyDeviceToHost, dl));
-  c->cand_dl_other = dl != c->stream;
-  if (c->cand_dl_other) HIPCHK(c, hipEventRecord(c->ev_cand_dl, dl));
+  // the kept records and the offsets leave for the host by a kernel that reads the count on the device (k2_export: a copy of the
+  // records' capacity on a second queue -- 3 MB on C3 -- held up the fragment stage's first kernel for 30 us)
+  { lcr_candidate* hp = nullptr; int32_t* ho = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer((void**)&hp, c->h_stage[1].p, 0));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&ho, c->h_stage[2].p, 0));
+    launch_k2_export(c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), ng, hp, ho, c->stream); }
+  c->cand_dl_other = false;
   // rows of the fragment matrix per region (fragment.rs:51-54) depend on the candidates only: computed here so
   // that lcr_fragments starts without a round trip
   HIPCHK(c, c->region_rows.reserve(std::max(ng, 1) * 4));
@@ -843,6 +915,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, hipGetLastError());
   c->cand_pending = true;
   c->have_cand = true;
+  HT("cand:ret");
   c->have_frag = c->have_phase = false;
   return LCR_OK;
 }
@@ -881,6 +954,7 @@ static int frag_settle(lcr_ctx* c) {
 }
 
 int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
+  HT("frag");
   if (!c || !p) return LCR_E_ARG;
   if (!c->have_cand) { c->err = "lcr_fragments before lcr_candidates"; return LCR_E_STATE; }
   if (p->min_linkers == 0) { c->err = "min_linkers must be > 0 (fragment.rs:252)"; return LCR_E_ARG; }
@@ -896,7 +970,8 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
   HIPCHK(c, c->frag_tmp_val.reserve((size_t)std::max(nr_cap, 1) * launch_k3_inline()));
   HIPCHK(c, c->row_links.reserve(std::max(nr_cap, 1) * 4));
   HIPCHK(c, c->row_ptr.reserve((std::max(nr_cap, 1) + 1) * 8));
-  if (nr_cap) HIPCHK(c, hipMemsetAsync(c->row_cnt.p, 0, (size_t)nr_cap * 4, c->stream));
+  if (nr_cap) HIPCHK(c, lcr_fill_async(c->row_cnt.p, 0, (size_t)nr_cap * 4, c->stream));
+  HT("frag:memset_q");
   // the count pass takes the (read, survivor) hits lcr_candidates' walk left (candidates are a subset of the survivors): no second
   // CIGAR walk; without them (dense survivors: the tile histograms) it walks the reads itself
   K3Hits hits{};
@@ -919,9 +994,11 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
     launch_k3_region_entries(c->row_ptr.as<int64_t>(), c->row_region_off.as<int32_t>(), ng, c->region_e_off.as<int64_t>(), c->stream, d_nnz); }
   HIPCHK(c, hipEventRecord(c->ev_nnz, c->stream));
   c->nnz_pending = true;
+  HT("frag:count_q");
   // now the candidates' host copies (long since there): rows per region, candidates per region
   { int rc = cand_settle(c); if (rc) return rc; }
   if (c->phase.dbg.prof && c->hits_valid) {
+  HT("frag:cand_settled");
     int32_t n_ovf = 0;
     HIPCHK(c, hipMemcpy(&n_ovf, c->hist.as<uint32_t>() + (size_t)c->hits_n_sv * 124, 4, hipMemcpyDeviceToHost));
     fprintf(stderr, "[frag] %d reads with more than %d survivor hits (walked again)\n", n_ovf, LCR_HITS);
@@ -949,6 +1026,7 @@ int lcr_fragments(lcr_ctx* c, const lcr_params* p) {
                    c->col.as<int32_t>(), c->val.as<uint8_t>(), hits, c->stream); }
   HIPCHK(c, hipGetLastError());
   c->have_frag = true;
+  HT("frag:ret");
   c->have_phase = false;
   return LCR_OK;
 }
@@ -1181,6 +1259,8 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
   else if (k == "enum_force_stream") d.enum_force_stream = (int)value;
   else if (k == "host_threads") d.host_threads = (int)value;
   else if (k == "async_phase") d.async_phase = value != 0;
+  else if (k == "host_trace") g_lcr_host_trace = value != 0;
+  else if (k == "own_fill") g_lcr_own_fill = value != 0;
   else if (k == "chain_ties") d.chain_ties = value != 0;
   else if (k == "tie_arith") d.tie_arith = (int)std::max<int64_t>(0, std::min<int64_t>(value, 3));   // (3 = the default: all four classes in the enumeration branch)
   else if (k == "timing_mask") c->timing_mask = (uint32_t)value;

@@ -103,6 +103,20 @@ void* lcr_cache_take(int host, size_t want, size_t* cap);   // a cached block wi
 bool lcr_cache_put(int host, void* p, size_t cap);          // false: the cache is full, the caller frees the block
 
 // growable device buffer
+// Measurement aid (lcr_debug_set("host_trace", 1)): wall-clock marks of the calling thread inside the stage calls, printed to stderr by
+// lcr_host_trace_flush (end of lcr_phase) as microseconds since the first mark -- where does the host wait, when does it queue what.
+extern int g_lcr_host_trace;
+void lcr_host_trace_mark(const char* tag);
+void lcr_host_trace_flush();
+#define HT(tag) do { if (g_lcr_host_trace) lcr_host_trace_mark(tag); } while (0)
+
+// Byte fill on a stream by a kernel of the library's own (the same contract as hipMemsetAsync for device memory).  The runtime's fill is a blit
+// kernel too, but behind an event record it starts 35 - 57 us late on this platform (profiles/r06_timeline.txt); lcr_debug_set("own_fill", 0)
+// goes back to hipMemsetAsync.
+extern int g_lcr_own_fill;
+hipError_t lcr_fill_async(void* p, int byte, size_t bytes, hipStream_t s);
+hipError_t lcr_fill_multi_async(int n /* <= 4 */, void* const* ptrs, const int* bytes_val, const size_t* sizes, hipStream_t s);
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -210,6 +224,7 @@ void launch_k2_hist_tiles(const BatchView& b, const int32_t* tile_col0, int32_t 
                           uint32_t* hist, hipStream_t s);
 void launch_k2_gt(const DevParams& p, const Survivor* sv, int32_t n_sv, const uint32_t* hist, const int64_t* start0,
                   lcr_candidate* out, int32_t* keep, hipStream_t s);
+void launch_k2_export(const lcr_candidate* cand, const int32_t* cand_off, int32_t ng, lcr_candidate* h_cand, int32_t* h_off, hipStream_t s);
 void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t* keep, int32_t n_sv, const int32_t* sv_region_off,
                       int32_t n_regions, int32_t* pos, int32_t* idx, lcr_candidate* out, int32_t* cand_off, uint32_t dense_win,
                       uint32_t min_dense_cnt, hipStream_t s);

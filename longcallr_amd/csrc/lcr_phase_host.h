@@ -140,7 +140,8 @@ struct PhaseHost {
   const uint8_t* r_assignment = nullptr;
   const uint32_t* r_phase_set = nullptr;
   DevBuf d_state[40];
-  DevBuf d_tie_flag, d_tie_q, d_tie_ch, d_tie_terms;   // k4_chain_wg: regions that met a class-2 / class-4 tie, scratch of their second run
+  DevBuf d_tie_flag, d_tie_q, d_tie_ch, d_tie_terms;
+  DevBuf d_rbest_buf;   // enumeration branch: best objective seen per region (filled before the staging kernel)   // k4_chain_wg: regions that met a class-2 / class-4 tie, scratch of their second run
   DevBuf d_spec_sig, d_spec_de, d_spec_res, d_pk, d_bt;   // working states / results of the speculative half-rounds (k4_grid.hip)
   DevBuf d_read_rec;             // per-row results as 12-byte records in HBM, written by k4_post
   DevBuf d_lut64, d_tie, d_enum_st;   // f64 table of the tie paths (PostLut), census counters, final states of the enumeration restarts
