@@ -576,7 +576,7 @@ k2_scatter(const lcr_candidate* __restrict__ tmp, const int32_t* __restrict__ ke
 // are marked dense and taken out of phasing.  idx = scratch list of the region's het/hom candidates.
 __global__ void __launch_bounds__(256)
 k2_dense(lcr_candidate* __restrict__ cand, const int32_t* __restrict__ cand_off, int32_t n_regions, int32_t* __restrict__ idx,
-         uint32_t dense_win, uint32_t min_dense_cnt) {
+         uint32_t dense_win, uint32_t min_dense_cnt, lcr_candidate* __restrict__ h_cand, int32_t* __restrict__ h_off) {
   // The two dense-cluster sweeps of candidate.rs:465-526, one workgroup per region.  The reference's loops are sequential, but
   // what they do is order-free: every start index i marks ONE interval [i, e_i) of the het / hom list (flags |= DENSE, &= ~FOR_PHASING:
   // idempotent), so a thread per start index finds its interval with a forward scan and marks it with atomics.  (One thread per
@@ -618,10 +618,23 @@ k2_dense(lcr_candidate* __restrict__ cand, const int32_t* __restrict__ cand_off,
     sweep(i, (int64_t)dense_win, min_dense_cnt);   // `diff > dense_win_size`
     sweep(i, 4, 3u);                               // `diff >= 5`, three or more
   }
+  // The region's records are final: they and the region's offset leave for pinned host memory here (h_cand != nullptr).  The host cannot
+  // size a copy before it has the count, and a copy of the records' CAPACITY (every survivor kept: 3 MB on C3) on a second queue held up
+  // the fragment stage's first kernel for as long as it ran -- a kernel's end-of-kernel release waits for the device's writes to host
+  // memory in flight (30 us per step).
+  if (!h_cand) return;
+  __syncthreads();
+  const uint4* src = reinterpret_cast<const uint4*>(cand + lo);
+  uint4* dst = reinterpret_cast<uint4*>(h_cand + lo);
+  const int n16 = (hi - lo) * (int)(sizeof(lcr_candidate) / 16);
+  for (int i = tid; i < n16; i += 256) dst[i] = src[i];
+  if (tid == 0) { h_off[g] = lo; if (g == n_regions - 1) h_off[n_regions] = hi; }
 }
 void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t* keep, int32_t n_sv, const int32_t* sv_region_off,
                       int32_t n_regions, int32_t* pos /* n_sv + 1 */, int32_t* idx /* n_sv */, lcr_candidate* out,
-                      int32_t* cand_off /* n_regions + 1 */, uint32_t dense_win, uint32_t min_dense_cnt, hipStream_t s) {
+                      int32_t* cand_off /* n_regions + 1 */, uint32_t dense_win, uint32_t min_dense_cnt, hipStream_t s,
+                      lcr_candidate* h_cand /* pinned (device pointer): the records and ... */, int32_t* h_off /* ... their offsets, or nullptr */) {
+  static_assert(sizeof(lcr_candidate) % 16 == 0, "k2_dense exports 16-byte words");
   // pos = exclusive scan of keep, pos[n_sv] = number of candidates; cand_off[g] = pos[sv_region_off[g]]
   launch_scan_i32(scan_tmp, keep, pos, n_sv, pos + n_sv, s);
   if (n_sv > 0) {   // (cand_off[g] = pos[sv_region_off[g]] rides on the scatter kernel; without survivors a gather of zeros)
@@ -629,22 +642,5 @@ void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t*
     hipLaunchKernelGGL(k2_scatter, dim3((unsigned)((nthreads + LCR_BLOCK - 1) / LCR_BLOCK)), dim3(LCR_BLOCK), 0, s, tmp, keep, pos, n_sv, out,
                        sv_region_off, n_regions, cand_off);
   } else launch_gather_i32(pos, sv_region_off, n_regions + 1, n_sv, pos + n_sv, cand_off, s);
-  if (n_regions > 0) hipLaunchKernelGGL(k2_dense, dim3(n_regions), dim3(256), 0, s, out, cand_off, n_regions, idx, dense_win, min_dense_cnt);
-}
-
-// The kept candidates and their per-region offsets into pinned host memory, by a kernel: the host cannot size a copy before it has the
-// count, and a copy of the records' CAPACITY (every survivor kept: 3 MB on C3) on a second queue held up the fragment stage's first
-// kernel for as long as it ran -- a kernel's end-of-kernel release waits for the device's writes to host memory in flight (30 us per step).
-__global__ void __launch_bounds__(256) k2_export(const lcr_candidate* __restrict__ cand, const int32_t* __restrict__ cand_off, int32_t ng,
-                                                 lcr_candidate* __restrict__ h_cand, int32_t* __restrict__ h_off) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
-  const size_t n16 = (size_t)cand_off[ng] * (sizeof(lcr_candidate) / 16);
-  const uint4* src = reinterpret_cast<const uint4*>(cand);
-  uint4* dst = reinterpret_cast<uint4*>(h_cand);
-  for (size_t i = t; i < n16; i += nt) dst[i] = src[i];
-  for (size_t g = t; g <= (size_t)ng; g += nt) h_off[g] = cand_off[g];
-}
-void launch_k2_export(const lcr_candidate* cand, const int32_t* cand_off, int32_t ng, lcr_candidate* h_cand, int32_t* h_off, hipStream_t s) {
-  static_assert(sizeof(lcr_candidate) % 16 == 0, "k2_export copies 16-byte words");
-  hipLaunchKernelGGL(k2_export, dim3(64), dim3(256), 0, s, cand, cand_off, ng, h_cand, h_off);
+  if (n_regions > 0) hipLaunchKernelGGL(k2_dense, dim3(n_regions), dim3(256), 0, s, out, cand_off, n_regions, idx, dense_win, min_dense_cnt, h_cand, h_off);
 }

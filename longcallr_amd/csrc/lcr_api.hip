@@ -832,13 +832,14 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
     if (!have_flt)
     launch_k2_filter(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
                      c->planes.as<uint32_t>(), c->k0_tile_fill.as<int32_t>(), c->flags.as<uint8_t>(), c->tile_count.as<int32_t>(), c->stream);
-    launch_scan_i32(c->scan_tmp, c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(), nt, c->total.as<int32_t>(), c->stream); }
+  }
   // survivors per region = tile offsets at the regions' first tiles (gathered on the device, pinned D2H)
   HIPCHK(c, c->sv_region_off.reserve((ng + 1) * 4));
   HIPCHK(c, c->h_stage[0].reserve((ng + 2) * 4));
   int32_t* const sv_off = c->h_stage[0].as<int32_t>();
   { int32_t* d_sv = nullptr;   // (the gather writes the offsets into the pinned block as well: the wait needs no copy behind it)
     HIPCHK(c, hipHostGetDevicePointer((void**)&d_sv, sv_off, 0));
+    launch_scan_i32(c->scan_tmp, c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(), nt, c->total.as<int32_t>(), c->stream);
     launch_gather_i32(c->tile_off.as<int32_t>(), c->first_tile.as<int32_t>(), ng + 1, nt, c->total.as<int32_t>(), c->sv_region_off.as<int32_t>(), c->stream, d_sv); }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
@@ -888,17 +889,17 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
   }
   // ordered compaction of the kept candidates + dense-cluster sweep (candidate.rs:465-526) on the device; the
   // host copy (getters, chain-region host steps) arrives with the same round trip as the offsets
-  launch_k2_finish(c->scan_tmp, c->cand_tmp.as<lcr_candidate>(), d_keep, n_sv, c->sv_region_off.as<int32_t>(), ng, d_pos, d_idx,
-                   c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), p->dense_win, p->min_dense_cnt, c->stream);
-  HT("cand:finish_q");
+  // (the kept records and their offsets leave for pinned host memory inside the last kernel, which knows the count: a copy of the records'
+  // capacity on a second queue -- 3 MB on C3 -- held up the fragment stage's first kernel for 30 us)
   HIPCHK(c, c->h_stage[1].reserve(std::max<size_t>(n_sv, 1) * sizeof(lcr_candidate)));
   HIPCHK(c, c->h_stage[2].reserve((size_t)(ng + 1) * 4));
-  // the kept records and the offsets leave for the host by a kernel that reads the count on the device (k2_export: a copy of the
-  // records' capacity on a second queue -- 3 MB on C3 -- held up the fragment stage's first kernel for 30 us)
   { lcr_candidate* hp = nullptr; int32_t* ho = nullptr;
     HIPCHK(c, hipHostGetDevicePointer((void**)&hp, c->h_stage[1].p, 0));
     HIPCHK(c, hipHostGetDevicePointer((void**)&ho, c->h_stage[2].p, 0));
-    launch_k2_export(c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), ng, hp, ho, c->stream); }
+    if (ng == 0) c->h_stage[2].as<int32_t>()[0] = 0;
+    launch_k2_finish(c->scan_tmp, c->cand_tmp.as<lcr_candidate>(), d_keep, n_sv, c->sv_region_off.as<int32_t>(), ng, d_pos, d_idx,
+                     c->d_cand.as<lcr_candidate>(), c->d_cand_off.as<int32_t>(), p->dense_win, p->min_dense_cnt, c->stream, hp, ho); }
+  HT("cand:finish_q");
   c->cand_dl_other = false;
   // rows of the fragment matrix per region (fragment.rs:51-54) depend on the candidates only: computed here so
   // that lcr_fragments starts without a round trip

@@ -224,10 +224,9 @@ void launch_k2_hist_tiles(const BatchView& b, const int32_t* tile_col0, int32_t 
                           uint32_t* hist, hipStream_t s);
 void launch_k2_gt(const DevParams& p, const Survivor* sv, int32_t n_sv, const uint32_t* hist, const int64_t* start0,
                   lcr_candidate* out, int32_t* keep, hipStream_t s);
-void launch_k2_export(const lcr_candidate* cand, const int32_t* cand_off, int32_t ng, lcr_candidate* h_cand, int32_t* h_off, hipStream_t s);
 void launch_k2_finish(DevBuf& scan_tmp, const lcr_candidate* tmp, const int32_t* keep, int32_t n_sv, const int32_t* sv_region_off,
                       int32_t n_regions, int32_t* pos, int32_t* idx, lcr_candidate* out, int32_t* cand_off, uint32_t dense_win,
-                      uint32_t min_dense_cnt, hipStream_t s);
+                      uint32_t min_dense_cnt, hipStream_t s, lcr_candidate* h_cand = nullptr, int32_t* h_off = nullptr);
 void launch_k3_row_offsets(const int32_t* region_rows, int32_t ng, int32_t* row_region_off, hipStream_t s);
 void launch_k3_region_entries(const int64_t* row_ptr, const int32_t* row_region_off, int32_t ng, int64_t* region_e_off, hipStream_t s, int64_t* host_out = nullptr);
 struct K3Hits {   // what k2_hist left for K3 (hit_cnt == nullptr: nothing -- K3 walks every read's CIGAR itself)
