@@ -566,7 +566,8 @@ __device__ void block_flip(SC& sc, const ChainDev& C, const ChainView& v, const 
 // the chain, written once for both scopes
 // ------------------------------------------------------------------------------------------------------------
 // tie8(): called (by every thread) when a configuration's fixed-point objective EQUALS the best one's -- class 8, `prob > largest_prob`
-// (phase.rs:1140-1144 ...) between configurations of equal objective; true: the working state becomes the best one.
+// (phase.rs:1140-1144 ...) between configurations of equal objective; 1: the working state becomes the best one, 0: the best one stays, 2: it
+// stays and the working state is known to equal it (no load_best_configuration needed -- the common case: a round falls back into the optimum).
 template <class SC, class Cross, class FastRounds, class Tie8>
 __device__ __forceinline__ void chain_run(SC& sc, const ChainDev& C, const RegionDev& rd, const ChainView& v, const long long* wl, const FlipLut& L,
                           double* stage, int (*sm)[16], Cross cross, FastRounds fast_rounds, Tie8 tie8, int slot) {
@@ -598,13 +599,17 @@ __device__ __forceinline__ void chain_run(SC& sc, const ChainDev& C, const Regio
     for (int i = sc.tid(); i < S; i += sc.nt()) { v.dl[i] = v.bdl[i]; v.et[i] = v.bet[i]; }
     for (int row = sc.tid(); row < R; row += sc.nt()) v.sg[row] = v.bsg[row];
   };
+  // `prob > largest_prob` + load_best_configuration behind a cross_optimize (phase.rs:1140-1144, 1210-1231): afterwards the working state is the best one
+  auto settle = [&](long long obj) {
+    if (obj > best) { best = obj; save(); return; }   // (working == best now)
+    if (obj == best) { const int t8 = tie8(); if (t8 == 1) { save(); return; } if (t8 == 2) return; }
+    load();
+  };
   save();   // (every thread saves / loads / perturbs the same elements: no barrier between those steps)
   block_flip(sc, C, v, L, stage);
   {
     const long long obj = objective_scope(sc, rd, v, wl);
-    if (obj > best) { best = obj; save(); }   // `prob > largest_prob` (phase.rs:1140-1144)
-    else if (obj == best && tie8()) save();
-    load();
+    settle(obj);   // `prob > largest_prob` (phase.rs:1140-1144), load_best_configuration
   }
   mark();
   if (fast_rounds(best)) { mark(); return; }   // (grid scope: the rounds with device-coherent state, see below)
@@ -617,17 +622,11 @@ __device__ __forceinline__ void chain_run(SC& sc, const ChainDev& C, const Regio
       else if (rg >= 0.9) v.dl[i] = flip ? -1 : 1;
     }
     sc.sync();
-    long long obj = cross(false, false);
-    if (obj > best) { best = obj; save(); }
-    else if (obj == best && tie8()) save();
-    load();
+    settle(cross(false, false));
     for (int row = sc.tid(); row < R; row += sc.nt())
       if (u01(rd.seed, ctr_t + S + row) < 0.1) v.sg[row] = (int8_t)(-v.sg[row]);
     sc.sync();
-    obj = cross(false, false);
-    if (obj > best) { best = obj; save(); }
-    else if (obj == best && tie8()) save();
-    load();
+    settle(cross(false, false));
   }
   mark();
   if (sc.tid() == 0) C.P.st_obj[slot] = best;
@@ -1103,7 +1102,11 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
       else
         obj = cross_optimize(C.P, rd, mvl, v.sg, v.dl, v.et, keep_conserved, with_genotype, red, wl, macc, MACC,
                              reinterpret_cast<unsigned long long*>(stage), NW * 4 * SSTR,   // (free outside block_flip)
+#if defined(CHAIN_ABL) && (CHAIN_ABL & 4)
+                             rd.S <= SCN ? scn : nullptr, &iters, timed ? C.dbg + 8 : nullptr, &sm[0][0], nullptr, nullptr);   // (measurement build: ties to the census)
+#else
                              rd.S <= SCN ? scn : nullptr, &iters, timed ? C.dbg + 8 : nullptr, &sm[0][0], nullptr, s_tie);
+#endif
       if (timed) { C.dbg[14] += 1; C.dbg[15] += iters; }
       return obj;
     };
@@ -1113,7 +1116,10 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
     // equal compare on gene batches) have the same sum.  So: (1) the states, element by element (every thread compares what it saved
     // itself); (2) the match bits, a thread per row; (3) only if those differ the two sums, wave 0 in the reference's order -- decided in
     // place by both instantiations (without C.tie_flag: counted as unresolved).
-    auto tie8 = [&]() -> bool {
+    auto tie8 = [&]() -> int {
+#if defined(CHAIN_ABL) && (CHAIN_ABL & 1)
+      return 0;   // (measurement build: no class-8 handling)
+#endif
       // (the best state lives in global memory: step 1 leaves a copy of its delta / eta in the stage rows -- free between cross_optimize
       // calls -- so that step 2's two reads per entry stay in LDS; read per entry from L2 they made the kernel 575 -> 660 us on C3)
       int8_t* const lb = reinterpret_cast<int8_t*>(stage);
@@ -1125,7 +1131,7 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
         diff |= (v.dl[i] != bd) | (v.et[i] != be);
       }
       for (int row = threadIdx.x; row < rd.R; row += blockDim.x) diff |= v.sg[row] != v.bsg[row];
-      if (!__syncthreads_or(diff)) return false;
+      if (!__syncthreads_or(diff)) return 2;
       auto match_differs = [&](const int8_t* bdl, const int8_t* bet) {
         int df = 0;
         for (int row = threadIdx.x; row < rd.R; row += blockDim.x) {
@@ -1139,10 +1145,10 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
         return df;
       };
       diff = copy ? match_differs(lb, lb + rd.S) : match_differs(v.bdl, v.bet);
-      if (!__syncthreads_or(diff)) return false;
-      if (!C.tie_flag) { if (threadIdx.x == 0) s_tie[2]++; return false; }
+      if (!__syncthreads_or(diff)) return 0;
+      if (!C.tie_flag) { if (threadIdx.x == 0) s_tie[2]++; return 0; }
       if (threadIdx.x == 0) TIE_COUNT(C.P.tie_ctr, TIE_BEST_F64, 1ull);
-      return objective_f64_greater_wg(C.P, mvl, rd.R, v.sg, v.dl, v.et, v.bsg, v.bdl, v.bet, C.tie_terms + 2ll * d.term_off, &s_f64);
+      return objective_f64_greater_wg(C.P, mvl, rd.R, v.sg, v.dl, v.et, v.bsg, v.bdl, v.bet, C.tie_terms + 2ll * d.term_off, &s_f64) ? 1 : 0;
     };
     chain_run(sc, C, rd, v, wl, L, stage, sm, cross, [](long long) { return false; }, tie8, d.slot);
   };
@@ -1160,8 +1166,12 @@ __global__ void __launch_bounds__(NT) k4_chain_wg(ChainDev C, int32_t first, int
     return;
   }
   if (!met) return;
+#if defined(CHAIN_ABL) && (CHAIN_ABL & 2)
+  return;   // (measurement build: no second pass in the kernel)
+#else
   if (mat_in_lds) body(std::true_type{}, std::true_type{});
   else body(std::false_type{}, std::true_type{});
+#endif
 }
 
 // all workgroups of the launch on one region (desc[which])
@@ -1198,7 +1208,7 @@ __global__ void __launch_bounds__(CH_THREADS) k4_chain_grid(ChainDev C, int32_t 
     if (!d.fast_lds) return false;
     return chain_rounds_fast(sc, C, rd, v, wl, dyn_fast, best, d.slot, L);
   };
-  chain_run(sc, C, rd, v, wl, L, stage, sm, cross, fast_rounds, []() { return false; }, d.slot);
+  chain_run(sc, C, rd, v, wl, L, stage, sm, cross, fast_rounds, []() { return 0; }, d.slot);
 }
 
 

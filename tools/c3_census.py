@@ -6,7 +6,7 @@ import torch
 import bench
 from longcallr_amd import _abi, api, synth
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
-params = _abi.make_params(synth.preset_for("ont-cdna" if wl == "c3" else "masseq"))
+params = _abi.make_params(synth.preset_for("ont-cdna" if wl == "c3" else "masseq")) if hasattr(synth, "preset_for") else None
 b = bench.build_workload(wl, seed=1)
 dv = bench.to_device(b, torch, torch.device("cuda", 0))
 for ct in (0, 1):
