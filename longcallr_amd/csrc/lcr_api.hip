@@ -1262,6 +1262,30 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
   else if (k == "async_phase") d.async_phase = value != 0;
   else if (k == "host_trace") g_lcr_host_trace = value != 0;
   else if (k == "own_fill") g_lcr_own_fill = value != 0;
+  else if (k == "fill_selftest") {   // lcr_fill_async / lcr_fill_multi_async against the host on every alignment of both ends (a test hook: returns LCR_E_DEVICE on a difference)
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = 4096;
+    DevBuf buf; HIPCHK(c, buf.reserve(4 * N));
+    std::vector<uint8_t> host(4 * N), want(4 * N);
+    for (size_t off = 0; off < 18; off++)
+      for (size_t len : {(size_t)0, (size_t)1, (size_t)15, (size_t)16, (size_t)17, (size_t)255, (size_t)1000 + off, (size_t)2049}) {
+        HIPCHK(c, hipMemsetAsync(buf.p, 0xAB, 4 * N, c->stream));
+        std::fill(want.begin(), want.end(), (uint8_t)0xAB);
+        uint8_t* base = buf.as<uint8_t>();
+        HIPCHK(c, lcr_fill_async(base + off, 0x5C, len, c->stream));
+        std::fill(want.begin() + off, want.begin() + off + len, (uint8_t)0x5C);
+        void* const ptrs[4] = {base + N + off, base + 2 * N + 3, nullptr, base + 3 * N + off};
+        const int vals[4] = {0x80, 0, 7, 0xFF};
+        const size_t sizes[4] = {len, 33, 0, len / 2};
+        HIPCHK(c, lcr_fill_multi_async(4, ptrs, vals, sizes, c->stream));
+        std::fill(want.begin() + N + off, want.begin() + N + off + len, (uint8_t)0x80);
+        std::fill(want.begin() + 2 * N + 3, want.begin() + 2 * N + 3 + 33, (uint8_t)0);
+        std::fill(want.begin() + 3 * N + off, want.begin() + 3 * N + off + len / 2, (uint8_t)0xFF);
+        HIPCHK(c, hipMemcpyAsync(host.data(), buf.p, 4 * N, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (host != want) { c->err = "fill_selftest: a fill kernel wrote other bytes than asked (offset " + std::to_string(off) + ", length " + std::to_string(len) + ")"; return LCR_E_DEVICE; }
+      }
+  }
   else if (k == "chain_ties") d.chain_ties = value != 0;
   else if (k == "tie_arith") d.tie_arith = (int)std::max<int64_t>(0, std::min<int64_t>(value, 3));   // (3 = the default: all four classes in the enumeration branch)
   else if (k == "timing_mask") c->timing_mask = (uint32_t)value;

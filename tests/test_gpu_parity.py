@@ -518,6 +518,18 @@ def test_filter_pass_in_the_tally_epilogue(engine_cls, orc):
         E1.close(); E0.close()
 
 
+def test_fill_kernels_and_the_runtime_fallback(engine_cls, orc, monkeypatch):
+    """Round 6: the stage calls fill their buffers with kernels of the library's own (lcr_fill_async, several ranges per launch: every launch
+    costs ~5 us of queue, and the runtime's fill started late behind an event record).  Every alignment of both ends against the host
+    (lcr_debug_set("fill_selftest")), and the whole path once with lcr_debug_set("own_fill", 0) = hipMemsetAsync."""
+    E = engine_cls(0, _abi.make_params("ont-cdna"))
+    E.debug_set("fill_selftest", 1)
+    E.close()
+    monkeypatch.setenv("LCR_OWN_FILL", "0")
+    b = synth.make_batch("ont-cdna", n_genes=3, gene_len=8000, depth=30, seed=7)
+    full_check(engine_cls, orc, b, _abi.make_params("ont-cdna"))
+
+
 def test_chain_ties_of_classes_2_and_4(engine_cls, orc, monkeypatch):
     """Round 6: chain regions of workgroup scope that meet a tie of class 2 (a delta / eta choice with two equal maxima), class 4 (a step
     whose only changes were tie changes) or class 8 (a later configuration of equal objective that differs from the best one) are run again
