@@ -1411,9 +1411,12 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
 // its objective and -- st_words != nullptr and the region has a span there (st_base >= 0) -- its final state in the layout of the
 // other classes (sigma bits | delta < 0, eta == 0 masks | eta == +1 mask | a signature of all of it) for the resolve kernels.
 // qrow (2 R doubles per workgroup): cross_optimize's scratch for the complete tie contract (k4_dev.h).
+// (mv / macc: the matrix the sweeps read -- global memory, or the repair pass's copy in LDS -- and, with it, <= 32 zeroed LDS words for the
+// entry-balanced delta sweep of the plain form; same integers, same decisions)
 __device__ __forceinline__ void enum_big_restart(const PhaseDev& P, const RegionDev& rd, int slot, uint32_t e, bool winner, int8_t* base, double* qrow,
                                                  long long* red, const long long* wl, unsigned long long* s_sig, const int64_t* __restrict__ job_base,
-                                                 long long* __restrict__ job_obj, const int64_t* __restrict__ st_base, unsigned long long* __restrict__ st_words) {
+                                                 long long* __restrict__ job_obj, const int64_t* __restrict__ st_base, unsigned long long* __restrict__ st_words,
+                                                 const MatView& mv, unsigned long long* macc = nullptr) {
   int8_t* sg = base; int8_t* dl = base + rd.R; int8_t* et = dl + rd.S;
   const int8_t* vt = P.snp_vt + rd.snp_off;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1423,7 +1426,7 @@ __device__ __forceinline__ void enum_big_restart(const PhaseDev& P, const Region
   const uint64_t ctr0 = (uint64_t)rd.S + (uint64_t)rd.R + (uint64_t)e * (uint64_t)rd.R;
   for (int row = threadIdx.x; row < rd.R; row += blockDim.x) sg[row] = u01(rd.seed, ctr0 + row) < 0.5 ? -1 : 1;
   __syncthreads();
-  const long long obj = cross_optimize(P, rd, global_view(P, rd), sg, dl, et, false, true, red, wl, nullptr, CROSS_MACC, nullptr, 0, nullptr, nullptr, nullptr, nullptr, qrow);
+  const long long obj = cross_optimize(P, rd, mv, sg, dl, et, false, true, red, wl, macc, 32, nullptr, 0, nullptr, nullptr, nullptr, nullptr, qrow);
   if (winner) {
     for (int i = threadIdx.x; i < rd.S; i += blockDim.x) { P.st_delta[rd.snp_off + i] = dl[i]; P.st_eta[rd.snp_off + i] = et[i]; }
     for (int row = threadIdx.x; row < rd.R; row += blockDim.x) P.st_sigma[rd.sig_off + row] = sg[row];
@@ -1469,7 +1472,7 @@ k4_enum_big(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
   double* qr = qrow ? qrow + (size_t)blockIdx.x * qrow_stride : nullptr;
   const uint32_t ne = win_e ? 1u : t.ne;
   for (uint32_t k = 0; k < ne; k++)
-    enum_big_restart(P, rd, t.slot, win_e ? win_e[t.slot] : t.e0 + k, win_e != nullptr, base, qr, red, wl, s_sig, job_base, job_obj, st_base, st_words);
+    enum_big_restart(P, rd, t.slot, win_e ? win_e[t.slot] : t.e0 + k, win_e != nullptr, base, qr, red, wl, s_sig, job_base, job_obj, st_base, st_words, global_view(P, rd));
 }
 // the repair pass of the LDS classes: the restarts on a list (k4_enum_reg: those that met a tie of class 2 / 4) once more, through the
 // one-workgroup cross_optimize with the complete tie contract; objective and final state overwrite what the fast kernel left (the
@@ -1477,17 +1480,31 @@ k4_enum_big(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
 __global__ void __launch_bounds__(LCR_BLOCK)
 k4_enum_redo(PhaseDev P, const uint32_t* __restrict__ redo, uint32_t redo_cap, int8_t* __restrict__ scratch, int32_t scratch_stride, double* __restrict__ qrow,
              int64_t qrow_stride, const int64_t* __restrict__ job_base, long long* __restrict__ job_obj, const int64_t* __restrict__ st_base,
-             unsigned long long* __restrict__ st_words) {
+             unsigned long long* __restrict__ st_words, uint32_t lds_bytes) {
   __shared__ long long red[LCR_BLOCK / 64];
   __shared__ long long wl[32];
   __shared__ unsigned long long s_sig[LCR_BLOCK / 64];
+  __shared__ unsigned long long macc[32];
+  extern __shared__ __attribute__((aligned(16))) uint8_t redo_dyn[];   // lds_bytes: working state + the region's matrix, when they fit
   const uint32_t n = min(redo[0], redo_cap);
   if (blockIdx.x >= n) return;
   load_w(P, wl);
+  if (threadIdx.x < 32) macc[threadIdx.x] = 0;
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
     const int slot = (int)redo[4 + 2 * i];
-    enum_big_restart(P, P.reg[slot], slot, redo[5 + 2 * i], false, scratch + (size_t)blockIdx.x * scratch_stride, qrow + (size_t)blockIdx.x * qrow_stride,
-                     red, wl, s_sig, job_base, job_obj, st_base, st_words);
+    const RegionDev rd = P.reg[slot];
+    const uint32_t E = (uint32_t)P.prow_ptr[rd.rp_off + rd.R];
+    const uint32_t st_b = ((uint32_t)(rd.R + 2 * rd.S) + 63u) & ~63u;
+    __syncthreads();   // (the previous restart's readers of the LDS image are done)
+    // Round 6: on the C4 share this pass was the longest kernel of the stage's tail (0.81 ms: the one-workgroup cross_optimize sweeping the
+    // matrix in global memory, a wave per SNP), and the tail ended after the next batch's pileup: with the matrix and the state in LDS and
+    // the entry-balanced delta sweep a restart is several times shorter.  Two call sites: the sweeps' pointers keep ONE provenance each.
+    if (st_b + matview_bytes((uint32_t)rd.R, (uint32_t)rd.S, E) <= lds_bytes)
+      enum_big_restart(P, rd, slot, redo[5 + 2 * i], false, reinterpret_cast<int8_t*>(redo_dyn), qrow + (size_t)blockIdx.x * qrow_stride,
+                       red, wl, s_sig, job_base, job_obj, st_base, st_words, stage_view(P, rd, redo_dyn + st_b, E), macc);
+    else
+      enum_big_restart(P, rd, slot, redo[5 + 2 * i], false, scratch + (size_t)blockIdx.x * scratch_stride, qrow + (size_t)blockIdx.x * qrow_stride,
+                       red, wl, s_sig, job_base, job_obj, st_base, st_words, global_view(P, rd));
   }
 }
 
@@ -1614,9 +1631,13 @@ void launch_k4_enum_reg(int ck, unsigned n_blocks, size_t dyn_lds, hipStream_t s
   else if (ck == 32) hipLaunchKernelGGL(k4_enum_reg<32>, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, region_best, redo, redo_cap);
   else hipLaunchKernelGGL(k4_enum_reg<0>, dim3(n_blocks), blk, dyn_lds, s, P, spans, n_spans, per, job_base, job_obj, st_base, st_words, region_best, redo, redo_cap);
 }
+hipError_t k4_set_dyn_lds_once(const void* fn, int bytes, int slot);   // (k4_grid.hip: once per device)
 void launch_k4_enum_redo(unsigned n_blocks, hipStream_t s, const PhaseDev& P, const uint32_t* redo, uint32_t redo_cap, int8_t* scratch, int32_t scratch_stride,
-                         double* qrow, int64_t qrow_stride, const int64_t* job_base, long long* job_obj, const int64_t* st_base, unsigned long long* st_words) {
-  hipLaunchKernelGGL(k4_enum_redo, dim3(n_blocks), dim3(LCR_BLOCK), 0, s, P, redo, redo_cap, scratch, scratch_stride, qrow, qrow_stride, job_base, job_obj, st_base, st_words);
+                         double* qrow, int64_t qrow_stride, const int64_t* job_base, long long* job_obj, const int64_t* st_base, unsigned long long* st_words,
+                         uint32_t lds_bytes) {
+  lds_bytes = std::min<uint32_t>(lds_bytes, 128 * 1024);
+  if (lds_bytes > 32 * 1024 && k4_set_dyn_lds_once(reinterpret_cast<const void*>(&k4_enum_redo), 128 * 1024, 6) != hipSuccess) { (void)hipGetLastError(); lds_bytes = 32 * 1024; }
+  hipLaunchKernelGGL(k4_enum_redo, dim3(n_blocks), dim3(LCR_BLOCK), lds_bytes, s, P, redo, redo_cap, scratch, scratch_stride, qrow, qrow_stride, job_base, job_obj, st_base, st_words, lds_bytes);
 }
 void launch_k4_enum_resolve(unsigned n_regions, size_t dyn_lds, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, const int64_t* job_base,
                             const long long* job_obj, const int64_t* st_base, const unsigned long long* st_words) {

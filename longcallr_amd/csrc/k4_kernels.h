@@ -84,7 +84,7 @@ void launch_k4_enum_reg(int ck, unsigned n_blocks, size_t dyn_lds, hipStream_t s
                         long long* region_best, uint32_t* redo /* repair list: [0] count (zeroed), [4 ..] (slot, restart) pairs; nullptr: none */, uint32_t redo_cap);
 void launch_k4_enum_redo(unsigned n_blocks, hipStream_t s, const PhaseDev& P, const uint32_t* redo, uint32_t redo_cap, int8_t* scratch /* n_blocks x stride */,
                          int32_t scratch_stride, double* qrow /* n_blocks x qrow_stride */, int64_t qrow_stride, const int64_t* job_base, long long* job_obj,
-                         const int64_t* st_base, unsigned long long* st_words);
+                         const int64_t* st_base, unsigned long long* st_words, uint32_t lds_bytes /* dynamic LDS: state + matrix of a restart's region, where they fit */);
 void launch_k4_enum_resolve(unsigned n_regions, size_t dyn_lds, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, const int64_t* job_base,
                             const long long* job_obj, const int64_t* st_base, const unsigned long long* st_words);
 void launch_k4_enum_big(unsigned n_blocks, hipStream_t s, const PhaseDev& P, const EnumSpan* spans, int32_t n_spans, uint32_t per,

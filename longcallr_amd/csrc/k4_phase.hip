@@ -918,7 +918,11 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
       if (!redo) return;
       const size_t b0 = n_big_blocks + (size_t)which * REDO_GRID;
       launch_k4_enum_redo(REDO_GRID, q, P, redo, REDO_CAP, b_scr.as<int8_t>() + (size_t)stride * b0, stride, qrow_all + (size_t)qstride * b0, qstride,
-                          d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>());
+                          d_jb, d_obj, d_sb, d_enum_st.as<unsigned long long>(),
+                          // (the matrix in LDS where it fits -- not for the queue that, with k4_enum_bits, only carries the regions beyond ITS image: their
+                          // matrices are the largest, and that launch runs beside the bit-state kernel, where 512 workgroups asking for 64 KB each wait for
+                          // it to drain even when the list is empty: 5 us -> 0.98 ms on the C4 share)
+                          (which == 0 && ebits) ? 0u : (uint32_t)std::max(0, dbg.redo_lds));
     };
     // the classes touch disjoint regions: class 2 on `stream`, classes 3 / 4 beside it on `aux` (their tails overlap)
     long long* const d_rbest = d_rbest_buf.as<long long>();   // (filled in front of the staging kernel)

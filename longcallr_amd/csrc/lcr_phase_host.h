@@ -123,6 +123,7 @@ struct PhaseDebug {
   int enum_bits = 1;            // "enum_bits": the enumeration restarts of the LDS classes eight per wave as bit states (k4_enum_bits)
   int spec_batch = 1;           // "grid_spec_batch": eight speculative half-rounds per pass over the matrix (k4_grid_batch.h); 0: the side-by-side lanes below
   int spec_lanes = 8;           // "grid_spec_lanes": half-rounds of the perturbation loop run at once at grid scope (1: one after the other; C5 with packed entries: 454 / 370 / 348 / 366 ms with 2 / 4 / 8 / 16 -- eight lanes = one XCD each)
+  int redo_lds = 64 * 1024;     // "redo_lds": bytes of dynamic LDS of the enumeration branch's repair pass (k4_enum_redo: state + matrix of a restart's region where they fit; 0: global memory)
   int chain_ties = 1;           // "chain_ties": chain regions of workgroup scope that meet a class-2 / class-4 tie run again under the complete tie contract (0: counted as unresolved)
   int tie_arith = 3;            // "tie_arith": which exact fixed-point ties the reference-order f64 arithmetic decides (PhaseDev::tie_arith; 3 = all that liblcr resolves)
   int host_threads = 0;         // "host_threads": size of the host pool of the host epilogue (0: hardware threads / devices, <= 48)

@@ -6,9 +6,10 @@ import numpy as np
 import torch
 import bench
 from longcallr_amd import _abi, api, synth
-params = _abi.make_params(synth.preset_for("ont-cdna"))
+WL = os.environ.get("HT_WORKLOAD", "c3")
+params = _abi.make_params(synth.preset_for("ont-cdna" if WL == "c3" else "masseq"))
 dev = torch.device("cuda", 0)
-b = bench.build_workload("c3", seed=1)
+b = bench.build_workload(WL, seed=1)
 dv = bench.to_device(b, torch, dev)
 timing = tuple(getattr(_abi, k) for k in bench.PILE_TIMERS) if os.environ.get("HT_TIMERS", "1") == "1" else ()
 E = api.Engine(0, params, timing=timing); E.set_async_phase(True)
