@@ -997,56 +997,86 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
     csc[e] = (uint32_t)P.crow[rd.e_off + e] | ((uint32_t)col << 16) | ((cv & 32u) << 16) | ((cv & 31u) << 22) | 0x80000000u;
   }
   // Round 6: the rows of ONE entry (57 % of the phasing rows of the ONT-cDNA / MAS-Seq batches: a read over one het site) are taken out of
-  // the sigma step's main loop.  Their decision is the sign of one term -- bit operations, no sums, no tie -- in a pass of their own, a
-  // lane per row; the main loop's lanes share the entries of the OTHER rows evenly (its eight-sums row end then runs for those only).
-  //   perm[0 .. nM)        the rows of more than one entry, in row order      rpm[k] = first csr slot of perm[k] (rpm[nM] = eM)
-  //   perm[nM .. nM + nS)  the rows of one entry, in row order: csr[eM + x]
+  // the sigma step's main loop: their decision is the sign of one term -- bit operations, no sums, no tie -- in a pass of their own, a
+  // lane per row.  The rows of MORE than one entry are sorted by their length (descending, row order within a length: the same order in every
+  // workgroup of a region -- the signatures are compared across them) and dealt to the lanes 64 at a time, a LANE PER ROW in lock step: the
+  // eight-sums row end, as long as three entries' work, runs once per 64 rows (with a lane per run of rows some lane met a row end at nearly
+  // every step, so the whole wave ran it at nearly every step).
+  //   perm[0 .. nM)        the rows of more than one entry, (length descending, row ascending); group g = perm[64 g .. 64 g + 64)
+  //   gof[g]               first csr slot of group g, in units of 64 slots; its entries: csr[64 gof[g] + 64 k + j] = entry k of row perm[64 g + j]
+  //                        (zero words behind a row's last entry: the group is as long as its first row); gof[nG] = end of the groups
+  //   perm[nM .. nM + nS)  the rows of one entry, in row order: csr[eM + x], eM = 64 gof[nG]
   uint16_t* const perm = (uint16_t*)(lds + L.pos);
-  uint16_t* const rpm = perm + ((R + 3) & ~3);
+  uint16_t* const gof = perm + ((R + 3) & ~3);
   uint16_t* const kidx = (uint16_t*)(lds + L.state);   // (staging only: the waves' state area is set up behind the barrier below)
   __shared__ int s_cnt[3];
+  __shared__ int s_lstart[32];   // first position in perm of the rows of length L
   __syncthreads();
   if (tid < 64) {
     const int ln = tid;
     const unsigned long long lt = (1ull << ln) - 1ull;
-    int nM = 0, eM = 0, nS = 0;
+    int nS = 0;
+    int tot[32];   // rows of length L so far (wave-uniform)
+#pragma unroll
+    for (int Lk = 0; Lk < 32; Lk++) tot[Lk] = 0;
     for (int base = 0; base < R; base += 64) {
       const int r = base + ln;
-      const int n = r < R ? (int)rp[r + 1] - (int)rp[r] : 0;
-      const bool isM = n >= 2, isS = n == 1;
-      const unsigned long long bm = __ballot(isM), bs = __ballot(isS);
-      const int inc = wave_incl_scan(isM ? n : 0);
-      if (isM) { const int k = nM + __popcll(bm & lt); kidx[r] = (uint16_t)k; perm[k] = (uint16_t)r; rpm[k] = (uint16_t)(eM + inc - n); }
-      if (isS) kidx[r] = (uint16_t)(nS + __popcll(bs & lt));
-      nM += __popcll(bm); nS += __popcll(bs); eM += __builtin_amdgcn_readlane(inc, 63);
+      const int n = r < R ? min(31, (int)rp[r + 1] - (int)rp[r]) : 0;   // (a row has at most S <= 31 entries)
+      const unsigned long long bs = __ballot(n == 1);
+      if (n == 1) kidx[r] = (uint16_t)(nS + __popcll(bs & lt));
+      nS += __popcll(bs);
+      if (__ballot(n >= 2)) {
+#pragma unroll
+        for (int Lk = 2; Lk < 32; Lk++) {
+          if (Lk > S) break;   // (a row has at most S entries)
+          const unsigned long long bm = __ballot(n == Lk);
+          if (n == Lk) kidx[r] = (uint16_t)(tot[Lk] + __popcll(bm & lt));   // rank among the rows of its length, in row order
+          tot[Lk] += __popcll(bm);
+        }
+      }
     }
-    if (ln == 0) { rpm[nM] = (uint16_t)eM; s_cnt[0] = nM; s_cnt[1] = eM; s_cnt[2] = nS; }
+    int mine = 0;
+#pragma unroll
+    for (int Lk = 2; Lk < 32; Lk++) if (ln == Lk) mine = tot[Lk];
+    // descending lengths: start[L] = rows longer than L
+    int longer = 0;
+    for (int Lk = 31; Lk >= 2; Lk--) { const int tl = __shfl(mine, Lk, 64); if (ln == Lk) s_lstart[ln] = longer; longer += tl; }
+    if (ln == 0) { s_cnt[0] = longer; s_cnt[2] = nS; }
   }
   __syncthreads();
-  const int nM = s_cnt[0], eM = s_cnt[1], nS = s_cnt[2];
-  const uint32_t cm = enum_chunk((uint32_t)eM);
-  for (int l = tid; l <= 64; l += nt) {   // first row (in perm) whose first slot is >= l * cm: the main loop's lane <-> rows map
-    const uint32_t target = (uint32_t)l * cm;
-    int lo = 0, hi = nM;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (rpm[mid] < target) lo = mid + 1; else hi = mid; }
-    first_row[l] = (uint16_t)lo;
+  const int nM = s_cnt[0], nS = s_cnt[2], nG = (nM + 63) >> 6;
+  for (int r = tid; r < R; r += nt) {
+    const int n = min(31, (int)rp[r + 1] - (int)rp[r]);
+    if (n >= 2) perm[s_lstart[n] + kidx[r]] = (uint16_t)r;
   }
+  __syncthreads();
+  if (tid < 64) {   // group offsets: a group is as long as its first (longest) row
+    int carry = 0;
+    for (int g0 = 0; g0 <= nG; g0 += 64) {
+      const int g = g0 + tid;
+      const int len = g < nG ? min(31, (int)rp[perm[64 * g] + 1] - (int)rp[perm[64 * g]]) : 0;
+      const int inc = wave_incl_scan(len);
+      if (g <= nG) gof[g] = (uint16_t)(carry + inc - len);
+      carry += __builtin_amdgcn_readlane(inc, 63);
+    }
+  }
+  __syncthreads();
+  const int eM = 64 * (int)gof[nG];
+  for (int x = tid; x < eM; x += nt) csr[x] = make_uint2(0u, 0u);
   __syncthreads();
   for (int r = tid; r < R; r += nt) {
     const int e0 = rp[r], e1 = rp[r + 1];
     if (e0 == e1) continue;
-    int at; uint32_t roff = 0;
+    int at, step;
     if (e1 - e0 >= 2) {
-      const int k = kidx[r];
-      at = rpm[k];
-      const uint32_t owner = (uint32_t)at / cm;   // (a lane's rows start at or behind owner * cm and in front of (owner + 1) * cm)
-      roff = (uint32_t)k - first_row[owner];
-    } else { perm[nM + kidx[r]] = (uint16_t)r; at = eM + kidx[r]; }
+      const int k = s_lstart[min(31, e1 - e0)] + kidx[r];
+      at = 64 * (int)gof[k >> 6] + (k & 63); step = 64;
+    } else { perm[nM + kidx[r]] = (uint16_t)r; at = eM + kidx[r]; step = 1; }
     for (int e = e0; e < e1; e++) {
       const uint32_t v = P.pval[rd.e_off + e];
       const uint32_t meta = (uint32_t)P.pcol[rd.e_off + e] | (v & 32u) | (e + 1 == e1 ? 64u : 0u) | 128u;
       const uint2 w = wl2[v & 31u];
-      csr[at + (e - e0)] = make_uint2(w.x | (meta << 24), w.y | (roff << 24));
+      csr[at + (e - e0) * step] = make_uint2(w.x | (meta << 24), w.y);
       ent16[e] = (uint16_t)((meta & 63u) | ((v & 31u) << 6) | (e + 1 == e1 ? 0x800u : 0u));
     }
   }
@@ -1060,12 +1090,7 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
   uint32_t* const ms = (uint32_t*)(mt + 32);                                    // [3][8]: dneg, eta0, etap of every restart
   uint32_t* const tq = ms + 24;                                            // queue of tied rows: row | tie8 << 16 | sneg8 << 24
   uint32_t* const tq_n = tq + ENUM_TQ;
-  const int r_a = first_row[lane], r_b = first_row[lane + 1];   // (positions in perm: the lane's rows of more than one entry)
-  const int s0 = rpm[r_a], s1 = rpm[r_b];
   const int c0 = min((int)E, lane * (int)c), c1 = min((int)E, (lane + 1) * (int)c);
-  int n_sig_m;   // entries of the main loop's longest lane
-  const int em = s1 - s0;
-  { int a = em; for (int d = 32; d >= 1; d >>= 1) a = max(a, __shfl_xor(a, d, 64)); n_sig_m = __builtin_amdgcn_readfirstlane(a); }
   const int n_del = (int)min(c, E);
   const uint32_t smask = S >= 32 ? 0xffffffffu : ((1u << S) - 1u);
   const uint32_t e0_init = s_e0i, ep_init = s_epi;
@@ -1115,57 +1140,62 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
         int alo[8], ahi[8];
 #pragma unroll
         for (int s = 0; s < 8; s++) { alo[s] = 0; ahi[s] = 0; }
-        uint32_t uacc = 0, sg16 = 0, sgb = 0;
-        int cur = -1, crow = 0;
-        for (int x0 = 0; x0 < n_sig_m; x0 += 4) {
-          uint2 v[4];
+        for (int g = 0; g < nG; g++) {   // 64 rows of (nearly) one length, a lane per row
+          const int gb = __builtin_amdgcn_readfirstlane((int)gof[g]), Lg = __builtin_amdgcn_readfirstlane((int)gof[g + 1]) - gb;
+          const int kq = 64 * g + lane;
+          const int row = kq < nM ? (int)perm[kq] : 0;
+          const uint32_t sgb = kq < nM ? (uint32_t)sg8[row] : 0u;
+          const uint32_t sg16 = enum_spread8(sgb);
+          const uint2* const pe = csr + 64 * gb + lane;
+          uint32_t uacc = 0;
+          for (int x0 = 0; x0 < Lg; x0 += 2) {   // (two entries per step: most groups are two to four long, and Lg is the wave's)
+            const bool two = x0 + 1 < Lg;
+            uint2 v[2]; uint32_t mmv[2];
+            v[0] = pe[64 * x0]; v[1] = two ? pe[64 * (x0 + 1)] : make_uint2(0, 0);
+            mmv[0] = mt[(v[0].x >> 24) & 31u].x; mmv[1] = mt[(v[1].x >> 24) & 31u].x;
 #pragma unroll
-          for (int u = 0; u < 4; u++) v[u] = x0 + u < em ? csr[s0 + x0 + u] : make_uint2(0, 0);
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const uint32_t v0 = v[u].x, v1 = v[u].y;
-            const uint32_t m = v0 >> 24, i = m & 31u;
-            const int roff = (int)(v1 >> 24);
-            if ((m & 128u) && roff != cur) { cur = roff; crow = perm[r_a + roff]; sgb = sg8[crow]; sg16 = enum_spread8(sgb); }
-            const uint32_t mm = mt[i].x;
-            const uint32_t use16 = (m & 128u) ? (mm & 0xFFFFu) : 0u;                          // het sites only
-            const uint32_t hit16 = (((m & 32u) ? 0x5555u : 0u) ^ sg16 ^ (mm >> 16)) & use16;   // p == sigma * delta
-            const uint32_t code = use16 | ((hit16 ^ use16) << 1);                              // 01: +w (A), 11: -w (B)
-            uacc |= use16;
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-              const int sgn = __builtin_amdgcn_sbfe((int)code, 2 * s, 2);
-              alo[s] = enum_mad24(sgn, (int)v0, alo[s]); ahi[s] = enum_mad24(sgn, (int)v1, ahi[s]);
-            }
-            if (m & 64u) {   // the row's last entry: its eight decisions
-              uint32_t fl = 0, tie = 0;
+            for (int u = 0; u < 2; u++) {
+              if (u == 1 && !two) break;
+              const uint32_t v0 = v[u].x, v1 = v[u].y;
+              const uint32_t m = v0 >> 24;
+              const uint32_t mm = mmv[u];
+              const uint32_t use16 = (m & 128u) ? (mm & 0xFFFFu) : 0u;                          // het sites only (a zero word: behind the row's last entry)
+              const uint32_t hit16 = (((m & 32u) ? 0x5555u : 0u) ^ sg16 ^ (mm >> 16)) & use16;   // p == sigma * delta
+              const uint32_t code = use16 | ((hit16 ^ use16) << 1);                              // 01: +w (A), 11: -w (B)
+              uacc |= use16;
 #pragma unroll
               for (int s = 0; s < 8; s++) {
-                const int top = ahi[s] + (alo[s] >> 23);   // sign of ahi * 2^23 + alo
-                fl |= (uint32_t)(top < 0) << s;
-                tie |= (uint32_t)(top == 0 && (alo[s] & 0x7fffff) == 0 && ((uacc >> (2 * s)) & 1u)) << s;
-                alo[s] = 0; ahi[s] = 0;
+                const int sgn = __builtin_amdgcn_sbfe((int)code, 2 * s, 2);
+                alo[s] = enum_mad24(sgn, (int)v0, alo[s]); ahi[s] = enum_mad24(sgn, (int)v1, ahi[s]);
               }
-              uacc = 0;
-              fl &= act; tie &= act;
-              any8 |= fl;
-              const int row = crow;
-              if (fl) sg8[row] = (uint8_t)(sgb ^ fl);
-              if (tie) {
-                // A == B at a row with a het entry: the f64 scores decide (a row without one scores the same for both signs, term by term)
-                if (P.tie_arith < 2) n_tie_unres += (uint32_t)__popc(tie);
-                else {
-                  n_tie_f64 += (uint32_t)__popc(tie);
-                  if (rp[row + 1] - rp[row] > 2) {   // (two entries: log_q2 = a + b, log_q3 = b + a -- the same double)
-                    const uint32_t at = atomicAdd(tq_n, 1u);
-                    if (at < ENUM_TQ) tq[at] = (uint32_t)row | (tie << 16) | (sgb << 24);
-                    else {
-                      for (uint32_t tt = tie; tt; tt &= tt - 1u) {
-                        const int s = __ffs((int)tt) - 1;
-                        if (enum_tie_row_flips(row, (sgb >> s) & 1u, ms[s], ms[8 + s], ms[16 + s], rp, ent16, lut)) {
-                          atomicXor((uint32_t*)(sg8 + (row & ~3)), 1u << (8 * (row & 3) + s));
-                          n_tie_flip++; tflip8 |= 1u << s;
-                        }
+            }
+          }
+          {   // the rows' eight decisions
+            uint32_t fl = 0, tie = 0;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+              const int top = ahi[s] + (alo[s] >> 23);   // sign of ahi * 2^23 + alo
+              fl |= (uint32_t)(top < 0) << s;
+              tie |= (uint32_t)(top == 0 && (alo[s] & 0x7fffff) == 0 && ((uacc >> (2 * s)) & 1u)) << s;
+              alo[s] = 0; ahi[s] = 0;
+            }
+            fl &= act; tie &= act;
+            any8 |= fl;
+            if (fl) sg8[row] = (uint8_t)(sgb ^ fl);
+            if (tie) {
+              // A == B at a row with a het entry: the f64 scores decide (a row without one scores the same for both signs, term by term)
+              if (P.tie_arith < 2) n_tie_unres += (uint32_t)__popc(tie);
+              else {
+                n_tie_f64 += (uint32_t)__popc(tie);
+                if (rp[row + 1] - rp[row] > 2) {   // (two entries: log_q2 = a + b, log_q3 = b + a -- the same double)
+                  const uint32_t at = atomicAdd(tq_n, 1u);
+                  if (at < ENUM_TQ) tq[at] = (uint32_t)row | (tie << 16) | (sgb << 24);
+                  else {
+                    for (uint32_t tt = tie; tt; tt &= tt - 1u) {
+                      const int s = __ffs((int)tt) - 1;
+                      if (enum_tie_row_flips(row, (sgb >> s) & 1u, ms[s], ms[8 + s], ms[16 + s], rp, ent16, lut)) {
+                        atomicXor((uint32_t*)(sg8 + (row & ~3)), 1u << (8 * (row & 3) + s));
+                        n_tie_flip++; tflip8 |= 1u << s;
                       }
                     }
                   }
@@ -1340,14 +1370,18 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
 #pragma unroll
       for (int s = 0; s < 8; s++) { hs[s] = 0; word[s] = 0; }
       int nb = 0, widx = 0;
-      const int n_one = (nS + 63) / 64;   // (the rows of one entry: lane <-> row x = lane + 64 j, behind the lane's share of the others)
-      for (int x = 0; x < n_sig_m + n_one; x++) {
-        const bool one = x >= n_sig_m;
-        const int xs = lane + 64 * (x - n_sig_m);
-        const uint2 v = one ? (xs < nS ? csr[eM + xs] : make_uint2(0, 0)) : (x < em ? csr[s0 + x] : make_uint2(0, 0));
-        const uint32_t m = v.x >> 24, i = m & 31u, roff = v.y >> 24;
+      // (the lane's entries: entry k of its row of every group -- slot 64 x + lane of the groups' part of csr, row perm[64 g + lane], g the group
+      // of slot row x --, then the rows of one entry: lane <-> row x = lane + 64 j)
+      const int n_grp = (int)gof[nG], n_one = (nS + 63) / 64;
+      int gq = 0;
+      for (int x = 0; x < n_grp + n_one; x++) {
+        const bool one = x >= n_grp;
+        const int xs = lane + 64 * (x - n_grp);
+        if (!one) while ((int)gof[gq + 1] <= x) gq++;   // (wave-uniform)
+        const uint2 v = one ? (xs < nS ? csr[eM + xs] : make_uint2(0, 0)) : csr[64 * x + lane];
+        const uint32_t m = v.x >> 24, i = m & 31u;
         const uint32_t y = mt[i].y, dn8 = y & 0xFFu, h8 = (y >> 8) & 0xFFu, ep8 = (y >> 16) & 0xFFu;
-        const int srow = (m & 128u) ? (int)perm[one ? nM + xs : r_a + (int)roff] : 0;
+        const int srow = (m & 128u) ? (int)perm[one ? nM + xs : 64 * gq + lane] : 0;
         const uint32_t p8 = (m & 32u) ? 0xFFu : 0u, sn8 = sg8[srow];
         const uint32_t match = (m & 128u) ? ((h8 & (p8 ^ sn8 ^ dn8)) | (~h8 & ~(p8 ^ ep8))) & 0xFFu : 0u;
 #pragma unroll

@@ -32,7 +32,7 @@ __host__ __device__ inline EnumLayout enum_layout(uint32_t R, uint32_t E, bool b
   EnumLayout L;
   uint32_t o = 256;
   L.lut = o; o += 512;
-  L.csr = o; o += 8 * E;
+  L.csr = o; o += 8 * (E + (bits ? 64 * (S < 31 ? S : 31) : 0));   // (k4_enum_bits: the rows of more than one entry in groups of 64 as long as their longest: <= 64 x the longest row of padding)
   L.csc = o; o += 4 * E;
   L.rp = o; o += 2 * (R + 1);
   L.first_row = o; o += 2 * 65 + (bits ? 2 * 64 : 0);   // (k4_enum_bits: + the entries of every lane's run that belong to rows of more than one entry)
