@@ -940,7 +940,10 @@ k4_enum_reg(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uin
 __device__ __forceinline__ uint32_t enum_spread8(uint32_t x) { x = (x | (x << 4)) & 0x0F0Fu; x = (x | (x << 2)) & 0x3333u; x = (x | (x << 1)) & 0x5555u; return x; }
 __device__ __forceinline__ int enum_mad24(int a, int b, int c) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 
-__global__ void __launch_bounds__(64 * ENUM_WAVES)
+#ifndef ENUM_BITS_OCC
+#define ENUM_BITS_OCC 2
+#endif
+__global__ void __launch_bounds__(64 * ENUM_WAVES, ENUM_BITS_OCC)   // (waves per SIMD the register allocation aims at; -DENUM_BITS_OCC: measurement builds)
 k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, uint32_t per, const int64_t* __restrict__ job_base,
              long long* __restrict__ job_obj, const int64_t* __restrict__ st_base, unsigned long long* __restrict__ st_words,
              long long* __restrict__ region_best, uint32_t* __restrict__ redo, uint32_t redo_cap) {
@@ -1028,10 +1031,11 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
       if (__ballot(n >= 2)) {
 #pragma unroll
         for (int Lk = 2; Lk < 32; Lk++) {
-          if (Lk > S) break;   // (a row has at most S entries)
-          const unsigned long long bm = __ballot(n == Lk);
-          if (n == Lk) kidx[r] = (uint16_t)(tot[Lk] + __popcll(bm & lt));   // rank among the rows of its length, in row order
-          tot[Lk] += __popcll(bm);
+          if (Lk <= S) {   // (a row has at most S entries; no break: the loop has to unroll for tot[] to stay in registers)
+            const unsigned long long bm = __ballot(n == Lk);
+            if (n == Lk) kidx[r] = (uint16_t)(tot[Lk] + __popcll(bm & lt));   // rank among the rows of its length, in row order
+            tot[Lk] += __popcll(bm);
+          }
         }
       }
     }

@@ -24,7 +24,10 @@ constexpr uint32_t ENUM_TQ = 126;     // tied rows a wave queues per sigma step 
 constexpr uint32_t ENUM_TCAP = 256;   // configurations of maximal objective compared at a time (enum_resolve): a lane each
 // k4_enum_bits (eight restarts per wave as bit states): per wave sigma of the eight restarts as a byte per row, M[state][32], the SNPs' masks
 // [32], the per-restart masks [3][8] and the queue of tied rows
-constexpr uint32_t ENUM_BITS_PER = 64;   // restarts per tile of k4_enum_bits (ENUM_WAVES waves x 8 x 2)
+#ifndef ENUM_BITS_PER_V
+#define ENUM_BITS_PER_V 64
+#endif
+constexpr uint32_t ENUM_BITS_PER = ENUM_BITS_PER_V;   // restarts per tile of k4_enum_bits (ENUM_WAVES waves x 8 x 2; -DENUM_BITS_PER_V: measurement builds)
 __host__ __device__ inline uint32_t enum_bits_sp(uint32_t S) { return (S + 7) & ~7u; }   // SNP slots of M[state][]
 __host__ __device__ inline uint32_t enum_bits_stride(uint32_t R, uint32_t S) { return ((R + 15) & ~7u) + 8 * 8 * enum_bits_sp(S) + 8 * 32 + 4 * 24 + 4 * (ENUM_TQ + 2); }
 struct EnumLayout { uint32_t lut, csr, csc, rp, first_row, ent16, pos, state, stride, total; };
