@@ -407,7 +407,12 @@ int lcr_ctx_set_lock_dir(lcr_ctx*, const char* dir);
  * "grid_spec_batch" (0: the all-CU chain kernel's speculative half-rounds side by side on sub-grids; default 1: as eight bits of one state)
  * (bit k: only the kernel groups LCR_K_* k are timed when timing is enabled; 0 = all) (see PhaseDebug in
  * csrc/lcr_phase_host.h), "hist_tiles" (quality histograms from K0's records: 0 = when the survivors are dense, 1 = whenever the
- * preset allows, -1 = never).  Unknown key: LCR_E_ARG.  The defaults are the product behaviour. */
+ * preset allows, -1 = never); round 6: "chain_ties" (0: chain regions of workgroup scope keep the tie contract of round 5: sigma ties
+ * only), "redo_lds" (bytes of dynamic LDS of the enumeration branch's repair pass; 0: its matrices in global memory), "fuse_filter",
+ * "bg_tiles", "zonefix_overlap", "zonefix_fused" (measurement switches of the pileup stage), "own_fill" (0: hipMemsetAsync instead of the
+ * library's fill kernels), "fill_selftest" (checks those kernels against the host; LCR_E_DEVICE on a difference), "host_trace" (1: a
+ * "[host]" line of wall-clock marks per lcr_phase on stderr; process-wide like own_fill).  Unknown key: LCR_E_ARG.  The defaults are the
+ * product behaviour. */
 int lcr_debug_set(lcr_ctx*, const char* key, int64_t value);
 
 /* Timing: HIP-event time (ms) of the last launch of each kernel on the ctx's stream.  (LCR_K_PHASE brackets what lcr_phase puts on the
