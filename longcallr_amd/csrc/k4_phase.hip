@@ -454,7 +454,14 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
   // lcr_candidates has to wait for this stage anyway, and a fourth stream of the process pushes `side` and `aux` onto one hardware
   // queue: 2.19 -> 2.12 ms per step, and the pileup kernels' own durations (the roofline's measurement) grow by half.
   const bool async_mode = dbg.async_phase != 0;
-  if (async_mode && !main_q) PCHK(hipStreamCreateWithFlags(&main_q, hipStreamNonBlocking));
+  auto new_queue = [&](hipStream_t* q) -> hipError_t {
+    if (!dbg.phase_prio) return hipStreamCreateWithFlags(q, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    const hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    return hipStreamCreateWithPriority(q, hipStreamNonBlocking, greatest);
+  };
+  if (async_mode && !main_q) PCHK(new_queue(&main_q));
   if (!ev_user) { PCHK(hipEventCreateWithFlags(&ev_user, hipEventDisableTiming)); PCHK(hipEventCreateWithFlags(&ev_gate[0], hipEventDisableTiming)); PCHK(hipEventCreateWithFlags(&ev_gate[1], hipEventDisableTiming)); }
   gate_set[0] = gate_set[1] = false;
   hipStream_t const stream = async_mode ? main_q : user_stream;
@@ -464,10 +471,10 @@ int PhaseHost::run(const PhaseInputs& in, const lcr_params& prm, hipStream_t use
   hipStream_t const sq = user_stream;
   q_first = stream;
   if (!side) {
-    PCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    PCHK(new_queue(&side));
     PCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
     PCHK(hipEventCreateWithFlags(&ev_csr, hipEventDisableTiming));
-    PCHK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+    PCHK(new_queue(&aux));
     PCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     PCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
   }

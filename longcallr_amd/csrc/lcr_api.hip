@@ -1287,6 +1287,8 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
       }
   }
   else if (k == "chain_ties") d.chain_ties = value != 0;
+  else if (k == "phase_prio") d.phase_prio = value != 0;
+  else if (k == "no_gate") d.no_gate = value != 0;
   else if (k == "redo_lds") d.redo_lds = (int)std::max<int64_t>(0, std::min<int64_t>(value, 128 * 1024));
   else if (k == "tie_arith") d.tie_arith = (int)std::max<int64_t>(0, std::min<int64_t>(value, 3));   // (3 = the default: all four classes in the enumeration branch)
   else if (k == "timing_mask") c->timing_mask = (uint32_t)value;

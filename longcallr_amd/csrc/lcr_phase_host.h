@@ -123,6 +123,8 @@ struct PhaseDebug {
   int enum_bits = 1;            // "enum_bits": the enumeration restarts of the LDS classes eight per wave as bit states (k4_enum_bits)
   int spec_batch = 1;           // "grid_spec_batch": eight speculative half-rounds per pass over the matrix (k4_grid_batch.h); 0: the side-by-side lanes below
   int spec_lanes = 8;           // "grid_spec_lanes": half-rounds of the perturbation loop run at once at grid scope (1: one after the other; C5 with packed entries: 454 / 370 / 348 / 366 ms with 2 / 4 / 8 / 16 -- eight lanes = one XCD each)
+  int phase_prio = 0;           // "phase_prio" (measurement switch): 1 = the stage's own queues are created at the device's greatest priority
+  int no_gate = 0;              // "no_gate" (measurement switch): 1 = the next batch's K0 does not wait for the restarts of the stage in flight
   int redo_lds = 64 * 1024;     // "redo_lds": bytes of dynamic LDS of the enumeration branch's repair pass (k4_enum_redo: state + matrix of a restart's region where they fit; 0: global memory)
   int chain_ties = 1;           // "chain_ties": chain regions of workgroup scope that meet a class-2 / class-4 tie run again under the complete tie contract (0: counted as unresolved)
   int tie_arith = 3;            // "tie_arith": which exact fixed-point ties the reference-order f64 arithmetic decides (PhaseDev::tie_arith; 3 = all that liblcr resolves)
@@ -165,7 +167,7 @@ struct PhaseHost {
   bool gate_set[2] = {false, false};
   // makes `s` wait for the dense part of a stage in flight (no-op otherwise)
   hipError_t gate_stream(hipStream_t s) {
-    if (!pending) return hipSuccess;
+    if (!pending || dbg.no_gate) return hipSuccess;
     for (int k = 0; k < 2; k++) if (gate_set[k]) { hipError_t e = hipStreamWaitEvent(s, ev_gate[k], 0); if (e != hipSuccess) return e; }
     return hipSuccess;
   }
