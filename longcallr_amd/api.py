@@ -33,7 +33,7 @@ def _view_nocopy(ptr, dtype, n):
 
 _DEBUG_ENV = {"LCR_PHASE_PROF": "phase_prof", "LCR_POST_HOST": "post_host", "LCR_GRID_MIN_ENTRIES": "grid_min_entries",
               "LCR_GRID_GENERIC": "grid_generic", "LCR_GRID_SPEC_LANES": "grid_spec_lanes", "LCR_GRID_SPEC_BATCH": "grid_spec_batch", "LCR_ENUM_BITS": "enum_bits", "LCR_POST_HALF": "post_half", "LCR_ENUM_FORCE_BIG": "enum_force_big",
-              "LCR_ENUM_FORCE_STREAM": "enum_force_stream", "LCR_HOST_THREADS": "host_threads", "LCR_HIST_TILES": "hist_tiles", "LCR_TIE_ARITH": "tie_arith", "LCR_CHAIN_TIES": "chain_ties", "LCR_PLANE_PREFILL": "plane_prefill", "LCR_BG_TILES": "bg_tiles", "LCR_K3_HITS": "k3_hits", "LCR_FUSE_FILTER": "fuse_filter", "LCR_ZF_OVERLAP": "zonefix_overlap", "LCR_ZF_FUSED": "zonefix_fused", "LCR_ASYNC_PHASE": "async_phase", "LCR_HOST_TRACE": "host_trace", "LCR_OWN_FILL": "own_fill", "LCR_REDO_LDS": "redo_lds", "LCR_PHASE_PRIO": "phase_prio", "LCR_NO_GATE": "no_gate"}
+              "LCR_ENUM_FORCE_STREAM": "enum_force_stream", "LCR_HOST_THREADS": "host_threads", "LCR_HIST_TILES": "hist_tiles", "LCR_TIE_ARITH": "tie_arith", "LCR_CHAIN_TIES": "chain_ties", "LCR_PLANE_PREFILL": "plane_prefill", "LCR_BG_TILES": "bg_tiles", "LCR_K3_HITS": "k3_hits", "LCR_FUSE_FILTER": "fuse_filter", "LCR_ZF_OVERLAP": "zonefix_overlap", "LCR_ZF_FUSED": "zonefix_fused", "LCR_ASYNC_PHASE": "async_phase", "LCR_HOST_TRACE": "host_trace", "LCR_OWN_FILL": "own_fill", "LCR_REDO_LDS": "redo_lds", "LCR_PHASE_PRIO": "phase_prio", "LCR_SPEC_COMPACT": "spec_compact", "LCR_NO_GATE": "no_gate"}
 
 
 class Engine:

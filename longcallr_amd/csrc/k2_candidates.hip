@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(LCR_BLOCK)
 k2_compact(BatchView b, DevParams prm, BinomTable bt, const int32_t* __restrict__ tile_region,
            const int32_t* __restrict__ tile_col0, int64_t n_cols, const uint32_t* __restrict__ planes,
            const uint8_t* __restrict__ flags, const int32_t* __restrict__ tile_count, const int32_t* __restrict__ tile_off,
-           Survivor* __restrict__ out) {
+           Survivor* __restrict__ out, int32_t out_cap /* survivors `out` holds: a launch queued before the host knows their number drops the rest */) {
   __shared__ int wsum[4];
   if (tile_count[blockIdx.x] == 0) return;   // (its flags were not even written if the tile holds no records)
   const int g = tile_region[blockIdx.x], tc0 = tile_col0[blockIdx.x];
@@ -240,7 +240,8 @@ k2_compact(BatchView b, DevParams prm, BinomTable bt, const int32_t* __restrict_
     sv.cnt1 = ev.cnt1; sv.cnt2 = ev.cnt2; sv.depth = ev.depth; sv.af1 = ev.af1; sv.af2 = ev.af2;
     sv.ts_fwd = planes[(int64_t)LCR_PL_TS_FWD * n_cols + gcol0 + col];
     sv.ts_rev = planes[(int64_t)LCR_PL_TS_REV * n_cols + gcol0 + col];
-    out[rank++] = sv;
+    if (rank < out_cap) out[rank] = sv;
+    rank++;
   }
 }
 
@@ -540,11 +541,11 @@ void launch_k2_gt(const DevParams& p, const Survivor* sv, int32_t n_sv, const ui
 
 void launch_k2_compact(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                        int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const uint8_t* flags,
-                       const int32_t* tile_count, const int32_t* tile_off, Survivor* out, hipStream_t s) {
+                       const int32_t* tile_count, const int32_t* tile_off, Survivor* out, int32_t out_cap, hipStream_t s) {
   static const BinomTable bt = make_binom_table();
   if (n_tiles == 0) return;
   hipLaunchKernelGGL(k2_compact, dim3(n_tiles), dim3(LCR_BLOCK), 0, s, b, p, bt, tile_region, tile_col0, n_cols,
-                     planes, flags, tile_count, tile_off, out);
+                     planes, flags, tile_count, tile_off, out, out_cap);
 }
 
 float lcr_device_sor_threshold(hipStream_t s) {

@@ -50,7 +50,8 @@ struct lcr_ctx {
   HostBuf h_planes;
   HostBuf h_nnz;              // pinned: first entry of every region of the fragment matrix, [ng] = entry count (lcr_fragments -> frag_settle)
   DevBuf region_e_off, frag_tmp_col, frag_tmp_val;
-  hipEvent_t ev_nnz = nullptr, ev_cand = nullptr, ev_ctl = nullptr;
+  hipEvent_t ev_nnz = nullptr, ev_cand = nullptr, ev_ctl = nullptr, ev_sv = nullptr;
+  int32_t sv_cap_guess = 0;   // lcr_candidates: survivors the buffers are sized for before their number is known (the last call's + a quarter; 0: wait first)
   bool nnz_pending = false, cand_pending = false;
   HostBuf h_order;      // pinned: k0_pack raises it when a region's reads are not sorted by position
   static constexpr int UP_LANES = 4;   // staging lanes of pageable host uploads (upload_bytes): two page-locked 8 MB buffers + events each
@@ -67,6 +68,7 @@ struct lcr_ctx {
   int dbg_hist_tiles = 0;   // lcr_debug_set("hist_tiles"): 0 = by survivor density, 1 = the tile form whenever it applies, -1 = never
   int dbg_zf_fused = 0;     // lcr_debug_set("zonefix_fused", 1) (measurement switch): HiFi presets -- the poly-A pass and the record-free tiles' stores in one launch; measured slower (HISTORY.md Appendix C)
   int dbg_zf_overlap = 0;   // lcr_debug_set("zonefix_overlap", 1) (measurement switch): HiFi presets -- the record-free tiles' stores on a second queue beside the poly-A pass; measured slower with the asynchronous phase stage (HISTORY.md Appendix C)
+  int dbg_spec_compact = 1; // lcr_debug_set("spec_compact"): 0 = lcr_candidates waits for the survivors' number before it queues their compaction
   int dbg_fuse_filter = 1;  // lcr_debug_set("fuse_filter"): 0 = pass 1 of the candidate filters always by k2_filter (its own pass over the planes)
   bool flt_fused = false;   // the last lcr_pileup left k2_filter's flags and per-tile counts (ONT presets: no poly-A pass behind the tally)
   DevParams flt_dp{};       // ... computed with these parameters
@@ -386,6 +388,7 @@ void lcr_ctx_destroy(lcr_ctx* c) {
   for (auto* b : bufs) b->release();
   if (c->ev_nnz) (void)hipEventDestroy(c->ev_nnz);
   if (c->ev_cand) (void)hipEventDestroy(c->ev_cand);
+  if (c->ev_sv) (void)hipEventDestroy(c->ev_sv);
   if (c->ev_ctl) (void)hipEventDestroy(c->ev_ctl);
   for (int k = 0; k < 2 * lcr_ctx::UP_LANES; k++) { if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]); c->h_up[k].release(); }
   HostBuf* hb[] = {&c->h_order, &c->h_nnz, &c->h_stage[0], &c->h_stage[1], &c->h_stage[2], &c->h_stage[3], &c->h_planes, &c->h_row_ptr, &c->h_row_read, &c->h_col, &c->h_val, &c->h_row_fp, &c->h_row_links};
@@ -841,9 +844,25 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
     HIPCHK(c, hipHostGetDevicePointer((void**)&d_sv, sv_off, 0));
     launch_scan_i32(c->scan_tmp, c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(), nt, c->total.as<int32_t>(), c->stream);
     launch_gather_i32(c->tile_off.as<int32_t>(), c->first_tile.as<int32_t>(), ng + 1, nt, c->total.as<int32_t>(), c->sv_region_off.as<int32_t>(), c->stream, d_sv); }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // Round 6: the survivors' compaction (and the fill of their histograms) is queued BEFORE the host knows how many there are, into buffers sized
+  // by the last call's count + a quarter, and the host waits for an event in front of it: the round trip (28 us on C3) runs under that kernel
+  // instead of in front of it.  More survivors than the guess (or no guess yet): the kernel dropped the rest, and runs again below.
+  const int32_t cap_guess = (c->dbg_spec_compact && nt > 0) ? c->sv_cap_guess : 0;
+  if (cap_guess > 0) {
+    if (!c->ev_sv) HIPCHK(c, hipEventCreateWithFlags(&c->ev_sv, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_sv, c->stream));
+    HIPCHK(c, c->survivors.reserve((size_t)cap_guess * sizeof(Survivor)));
+    HIPCHK(c, c->hist.reserve((size_t)cap_guess * 124 * 4 + 64));
+    HIPCHK(c, lcr_fill_async(c->hist.p, 0, (size_t)cap_guess * 124 * 4 + 64, c->stream));
+    launch_k2_compact(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
+                      c->planes.as<uint32_t>(), c->flags.as<uint8_t>(), c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(),
+                      c->survivors.as<Survivor>(), cap_guess, c->stream);
+    HIPCHK(c, hipEventSynchronize(c->ev_sv));
+  } else HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   const int32_t n_sv = sv_off[ng];
+  const bool compacted = cap_guess > 0 && n_sv <= cap_guess;   // (survivors and a cleared hist are in place, or on their way)
+  c->sv_cap_guess = n_sv > 0 ? n_sv + n_sv / 4 + 64 : 0;
   HT("cand:n_sv");
   if (c->phase.dbg.prof) fprintf(stderr, "[cand] %d survivors of the count filters in %lld columns, %d reads\n", n_sv, (long long)c->n_cols, c->bv.n_reads);
   HIPCHK(c, c->survivors.reserve(std::max(n_sv, 1) * sizeof(Survivor)));
@@ -864,7 +883,7 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
     // the records) and u16 counters (a survivor's depth is <= max_depth).
     const bool tiles_ok = c->dp.ont && p->max_depth <= 65535u;
     const bool hist_tiles = tiles_ok && c->dbg_hist_tiles >= 0 && (c->dbg_hist_tiles > 0 || (int64_t)n_sv * 8 >= c->n_cols);
-    HIPCHK(c, lcr_fill_async(c->hist.p, 0, (size_t)n_sv * 124 * 4 + 64, c->stream));
+    if (!compacted) HIPCHK(c, lcr_fill_async(c->hist.p, 0, (size_t)n_sv * 124 * 4 + 64, c->stream));
     c->hits_valid = !hist_tiles && c->dbg_k3_hits != 0;   // (the walk below leaves K3 its hits; the tile form does not walk reads)
     c->hits_n_sv = n_sv;
     if (c->hits_valid) {
@@ -873,9 +892,10 @@ int lcr_candidates(lcr_ctx* c, const lcr_params* p) {
       HIPCHK(c, c->ovf_list.reserve(std::max<size_t>(c->bv.n_reads, 1) * 4));
     }
     { Timer t(c, LCR_K_CAND_HIST);
+      if (!compacted)
       launch_k2_compact(c->bv, c->dp, c->tile_region.as<int32_t>(), c->tile_col0.as<int32_t>(), nt, c->n_cols,
                         c->planes.as<uint32_t>(), c->flags.as<uint8_t>(), c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(),
-                        c->survivors.as<Survivor>(), c->stream);
+                        c->survivors.as<Survivor>(), n_sv, c->stream);
       if (hist_tiles)
         launch_k2_hist_tiles(c->bv, c->tile_col0.as<int32_t>(), nt, c->tile_count.as<int32_t>(), c->tile_off.as<int32_t>(), c->survivors.as<Survivor>(),
                              c->chunk_off.as<int32_t>(), c->chunks.p, c->k0_items.as<unsigned long long>(), c->hist.as<uint32_t>(), c->stream);
@@ -1297,6 +1317,7 @@ int lcr_debug_set(lcr_ctx* c, const char* key, int64_t value) {
   else if (k == "hist_tiles") c->dbg_hist_tiles = value > 0 ? 1 : value < 0 ? -1 : 0;
   else if (k == "k3_hits") c->dbg_k3_hits = value != 0;
   else if (k == "fuse_filter") c->dbg_fuse_filter = value != 0;
+  else if (k == "spec_compact") c->dbg_spec_compact = value != 0;
   else if (k == "zonefix_overlap") c->dbg_zf_overlap = value != 0;
   else if (k == "zonefix_fused") c->dbg_zf_fused = value != 0;
   else if (k == "grid_spec_batch") d.spec_batch = (int)value;

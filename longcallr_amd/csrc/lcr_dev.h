@@ -212,7 +212,7 @@ void launch_gather_i32(const int32_t* src, const int32_t* idx, int32_t n, int32_
 void launch_scan_i32(DevBuf& tmp, const int32_t* in, int32_t* out_excl, int32_t n, int32_t* total, hipStream_t s);
 void launch_k2_compact(const BatchView& b, const DevParams& p, const int32_t* tile_region, const int32_t* tile_col0,
                        int32_t n_tiles, int64_t n_cols, const uint32_t* planes, const uint8_t* flags,
-                       const int32_t* tile_count, const int32_t* tile_off, Survivor* out, hipStream_t s);
+                       const int32_t* tile_count, const int32_t* tile_off, Survivor* out, int32_t out_cap, hipStream_t s);
 float lcr_device_sor_threshold(hipStream_t s);
 #define LCR_HITS 16   // (read, survivor) hits k2_hist keeps per read for K3 (= K3's inline entries per row)
 void launch_k2_hist(const BatchView& b, const DevParams& p, const ReadBin* rbin, const Survivor* sv, const int32_t* tile_off /* survivors in front of every tile (k2_compact's offsets) */, int32_t n_tiles, int32_t n_sv,

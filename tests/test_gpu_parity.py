@@ -518,6 +518,31 @@ def test_filter_pass_in_the_tally_epilogue(engine_cls, orc):
         E1.close(); E0.close()
 
 
+def test_survivor_compaction_queued_before_its_count_is_known(engine_cls, orc):
+    """Round 6: lcr_candidates queues the survivors' compaction before the host knows their number, into buffers sized by the context's
+    previous batch (+ a quarter).  A context that has seen a small batch and then gets one with many times the survivors (the kernel drops
+    what does not fit and is run again), and the other way round, must produce what a fresh context does -- and the oracle."""
+    small = synth.make_batch("ont-cdna", n_genes=2, gene_len=6000, depth=25, seed=3)
+    big = synth.make_batch("ont-cdna", n_genes=6, gene_len=14000, depth=60, seed=4)
+    p = _abi.make_params("ont-cdna")
+    E = engine_cls(0, p)
+    got = {}
+    for name, b in (("small", small), ("big", big), ("small2", small), ("big2", big)):
+        E.load_batch(b).run_all()
+        c, off = E.candidates()
+        got[name] = (c.tobytes(), off.tobytes(), E.phase_result()["haplotag"].tobytes())
+    E.close()
+    assert got["small"] == got["small2"] and got["big"] == got["big2"]
+    for name, b in (("small", small), ("big", big)):
+        F = engine_cls(0, p)
+        F.debug_set("spec_compact", 0)
+        F.load_batch(b).run_all()
+        c, off = F.candidates()
+        assert got[name] == (c.tobytes(), off.tobytes(), F.phase_result()["haplotag"].tobytes()), name
+        F.close()
+    full_check(engine_cls, orc, big, p)
+
+
 def test_fill_kernels_and_the_runtime_fallback(engine_cls, orc, monkeypatch):
     """Round 6: the stage calls fill their buffers with kernels of the library's own (lcr_fill_async, several ranges per launch: every launch
     costs ~5 us of queue, and the runtime's fill started late behind an event record).  Every alignment of both ends against the host
