@@ -1110,15 +1110,29 @@ k4_enum_bits(PhaseDev P, const EnumSpan* __restrict__ spans, int32_t n_spans, ui
     const uint32_t valid8 = (1u << nst) - 1u;
     // ---- start states
     if (lane < 8) { ms[lane] = (e_base + (uint32_t)lane) & smask; ms[8 + lane] = e0_init; ms[16 + lane] = ep_init; }
-    for (int k = 0; k < nk; k++) {
-      const int row = lane + 64 * k;
-      uint32_t b = 0;
+    {
+      // init_assignment (phase.rs:673-680): top bit of the draw clear -> sigma = -1.  The draw of (restart e_base + s, row) is mix64(seed + (S + R +
+      // (e_base + s) R + row + 1) G): the argument advances by R G per restart and by 64 G per 64 rows (adds instead of 64-bit multiplies), and only the top
+      // bit of the second multiply of mix64 is formed (three 32-bit multiplies instead of the full product: the last xor-shift cannot reach bit 63).
+      constexpr uint64_t G = 0x9E3779B97F4A7C15ULL;
+      const uint64_t RG = (uint64_t)R * G;
+      uint64_t a_row = rd.seed + ((uint64_t)S + (uint64_t)R + (uint64_t)e_base * (uint64_t)R + (uint64_t)lane + 1ull) * G;
+      for (int k = 0; k < nk; k++) {
+        const int row = lane + 64 * k;
+        uint32_t b = 0;
+        uint64_t a = a_row;
 #pragma unroll
-      for (int s = 0; s < 8; s++) {   // init_assignment (phase.rs:673-680): top bit of the draw clear -> sigma = -1
-        const uint64_t ctr0 = (uint64_t)S + (uint64_t)R + (uint64_t)(e_base + s) * (uint64_t)R;
-        b |= (uint32_t)((mix64(rd.seed + (ctr0 + row + 1) * 0x9E3779B97F4A7C15ULL) >> 63) == 0) << s;
+        for (int s = 0; s < 8; s++) {
+          uint64_t z = (a ^ (a >> 30)) * 0xBF58476D1CE4E5B9ULL;
+          z ^= z >> 27;
+          const uint32_t zl = (uint32_t)z, zh = (uint32_t)(z >> 32);
+          const uint32_t top = __umulhi(zl, 0x133111EBu) + zl * 0x94D049BBu + zh * 0x133111EBu;   // bits 32..63 of z * 0x94D049BB133111EB
+          b |= (uint32_t)((top >> 31) == 0) << s;
+          a += RG;
+        }
+        if (row < R) sg8[row] = (uint8_t)b;
+        a_row += 64ull * G;
       }
-      if (row < R) sg8[row] = (uint8_t)b;
     }
     for (int k = lane; k < 8 * Sp; k += 64) Macc[k] = 0;
     if (lane == 0) tq_n[0] = 0;
