@@ -409,7 +409,9 @@ int lcr_ctx_set_lock_dir(lcr_ctx*, const char* dir);
  * csrc/lcr_phase_host.h), "hist_tiles" (quality histograms from K0's records: 0 = when the survivors are dense, 1 = whenever the
  * preset allows, -1 = never); round 6: "chain_ties" (0: chain regions of workgroup scope keep the tie contract of round 5: sigma ties
  * only), "redo_lds" (bytes of dynamic LDS of the enumeration branch's repair pass; 0: its matrices in global memory), "fuse_filter",
- * "bg_tiles", "zonefix_overlap", "zonefix_fused" (measurement switches of the pileup stage), "own_fill" (0: hipMemsetAsync instead of the
+ * "bg_tiles", "zonefix_overlap", "zonefix_fused" (measurement switches of the pileup stage), "spec_compact" (0: lcr_candidates waits for the
+ * survivors' number before it queues their compaction), "phase_prio", "no_gate" (measurement switches of the asynchronous stage),
+ * "own_fill" (0: hipMemsetAsync instead of the
  * library's fill kernels), "fill_selftest" (checks those kernels against the host; LCR_E_DEVICE on a difference), "host_trace" (1: a
  * "[host]" line of wall-clock marks per lcr_phase on stderr; process-wide like own_fill).  Unknown key: LCR_E_ARG.  The defaults are the
  * product behaviour. */
